@@ -1,0 +1,336 @@
+// Mini-batch aggregation over the sampler's per-hop CSR: segmented sum/mean SpMM (GraphSAGE) and
+// edge-softmax SDDMM + weighted SpMM (GAT), hand-written for gfx950.
+//
+// The reference has no such kernel (it calls torch_geometric.nn.SAGEConv/GATConv; call sites
+// /root/reference/python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59,178-199).
+// Semantics are PyG's public formulas, fp32; see include/wgamd_ext.h.
+//
+// Roofline: HBM-bound gather-reduce.  Algorithmic bytes per layer:
+//   SpMM  E*(4F+4) + N_dst*(4F+8);   flops E*F  (0.25 flop/byte -> no MFMA here; the dense
+//   lin_l/lin_r tail is a hipBLASLt GEMM in the host layer).
+// Layout: one power-of-two lane group per destination row, 16 B (float4) per lane along the
+// feature axis (F=100: 25 of 32 lanes, two rows per wave64; F=128: 32; F=256: the whole wave).
+// The row's neighbour ids are fetched with ONE coalesced load per group and broadcast with
+// bpermute, so the feature-row loads of different neighbours are independent (no
+// col -> x dependent-load chain); 4 neighbour rows are kept in flight per lane.
+// Sums run in CSR order => bit-identical to a sequential fp32 loop.
+#include "wg_common.hpp"
+
+namespace wgamd {
+namespace {
+
+template <typename IdT>
+__device__ __forceinline__ int64_t src_row(const IdT* src_ids, int c)
+{
+  return (int64_t)src_ids[c];
+}
+template <>
+__device__ __forceinline__ int64_t src_row<void>(const void*, int c)
+{
+  return (int64_t)c;
+}
+
+// VEC = 4 (float4 path: F % 4 == 0, 16 B aligned rows) or 1.
+template <int VEC, typename IdT>
+__global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ row_ptr,
+                                                       const int* __restrict__ col,
+                                                       int64_t n_rows,
+                                                       const float* __restrict__ x,
+                                                       int64_t ldx,
+                                                       int F,
+                                                       const IdT* __restrict__ src_ids,
+                                                       int mean,
+                                                       float* __restrict__ out,
+                                                       int64_t ldo,
+                                                       int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int lane        = threadIdx.x & 63;
+  const int sub         = lane & (lanes - 1);
+  const int gbase       = lane & ~(lanes - 1);  // first lane of my group inside the wave
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+
+  // grid-stride over rows; all lanes of a wave iterate together (rows past the end idle) so the
+  // bpermute broadcasts below are executed by the full wave.
+  const int64_t rows_per_iter = ngroups;
+  const int64_t iters         = (n_rows + rows_per_iter - 1) / rows_per_iter;
+  for (int64_t it = 0; it < iters; it++) {
+    const int64_t row = group + it * rows_per_iter;
+    int s = 0, e = 0;
+    if (row < n_rows) {
+      s = row_ptr[row];
+      e = row_ptr[row + 1];
+    }
+    const int deg = e - s;
+    for (int f0 = sub * VEC; f0 < ((F + lanes * VEC - 1) / (lanes * VEC)) * (lanes * VEC); f0 += lanes * VEC) {
+      const bool live = f0 < F;
+      float acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) acc[v] = 0.f;
+      // longest row in this wave decides the trip count of the broadcast loop
+      int maxdeg = deg;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, d, 64));
+      for (int c0 = 0; c0 < maxdeg; c0 += lanes) {
+        // one coalesced fetch of up to `lanes` neighbour ids of my row
+        int my_c = (c0 + sub < deg) ? col[s + c0 + sub] : 0;
+        int64_t my_src = (c0 + sub < deg) ? src_row<IdT>(src_ids, my_c) : 0;
+        const int chunk = min(lanes, maxdeg - c0);
+        for (int j0 = 0; j0 < chunk; j0 += 4) {
+          float vals[4][VEC];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            // broadcast neighbour (j0+k) of my group's row
+            int src_lane  = gbase | ((j0 + k) & (lanes - 1));
+            int lo        = __shfl((int)(my_src & 0xffffffff), src_lane, 64);
+            int hi        = __shfl((int)(my_src >> 32), src_lane, 64);
+            int64_t r     = ((int64_t)hi << 32) | (uint32_t)lo;
+            ok[k]         = live && (j0 + k < chunk) && (c0 + j0 + k < deg);
+            if (ok[k]) {
+              const float* p = x + r * ldx + f0;
+              if constexpr (VEC == 4) {
+                float4 t   = *reinterpret_cast<const float4*>(p);
+                vals[k][0] = t.x; vals[k][1] = t.y; vals[k][2] = t.z; vals[k][3] = t.w;
+              } else {
+                vals[k][0] = *p;
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (ok[k]) {
+#pragma unroll
+              for (int v = 0; v < VEC; v++) acc[v] += vals[k][v];
+            }
+          }
+        }
+      }
+      if (live && row < n_rows) {
+        const float denom = (mean && deg > 0) ? (float)deg : 1.0f;
+        float* q          = out + row * ldo + f0;
+        if constexpr (VEC == 4) {
+          *reinterpret_cast<float4*>(q) = make_float4(acc[0] / denom, acc[1] / denom, acc[2] / denom, acc[3] / denom);
+        } else {
+          q[0] = acc[0] / denom;
+        }
+      }
+    }
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) spmm_csr_bwd_kernel(const int* __restrict__ row_ptr,
+                                                           const int* __restrict__ col,
+                                                           int64_t n_rows,
+                                                           const float* __restrict__ g,
+                                                           int64_t ldg,
+                                                           int F,
+                                                           int mean,
+                                                           float* __restrict__ gx,
+                                                           int64_t ldx,
+                                                           int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  for (int64_t row = group; row < n_rows; row += ngroups) {
+    const int s = row_ptr[row], e = row_ptr[row + 1];
+    if (e <= s) continue;
+    const float scale = mean ? 1.0f / (float)(e - s) : 1.0f;
+    for (int f0 = sub * VEC; f0 < F; f0 += lanes * VEC) {
+      float gv[VEC];
+      if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(g + row * ldg + f0);
+        gv[0] = t.x * scale; gv[1] = t.y * scale; gv[2] = t.z * scale; gv[3] = t.w * scale;
+      } else {
+        gv[0] = g[row * ldg + f0] * scale;
+      }
+      for (int j = s; j < e; j++) {
+        float* q = gx + (int64_t)col[j] * ldx + f0;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) atomicAdd(q + v, gv[v]);
+      }
+    }
+  }
+}
+
+// GAT: one lane group per destination row, lane -> VEC consecutive channels of one head;
+// single pass over the neighbour rows with an online (running max / running sum) softmax.
+template <int VEC>
+__global__ void __launch_bounds__(256) gat_csr_kernel(const int* __restrict__ row_ptr,
+                                                      const int* __restrict__ col,
+                                                      int64_t n_rows,
+                                                      const float* __restrict__ x,
+                                                      int64_t ldx,
+                                                      const float* __restrict__ a_src,
+                                                      const float* __restrict__ a_dst,
+                                                      int H,
+                                                      int C,
+                                                      float slope,
+                                                      float* __restrict__ alpha_out,
+                                                      float* __restrict__ out,
+                                                      int64_t ldo,
+                                                      int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const int HC          = H * C;
+  for (int64_t row = group; row < n_rows; row += ngroups) {
+    const int s = row_ptr[row], e = row_ptr[row + 1];
+    for (int f0 = sub * VEC; f0 < HC; f0 += lanes * VEC) {
+      const int h    = f0 / C;  // VEC divides C on the VEC=4 path, so all VEC channels share a head
+      const float ad = a_dst[row * H + h];
+      float m = -INFINITY, d = 0.f;
+      float acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) acc[v] = 0.f;
+      for (int j = s; j < e; j++) {
+        const int c   = col[j];
+        float sc      = a_src[(int64_t)c * H + h] + ad;
+        sc            = sc > 0.f ? sc : sc * slope;
+        const float mn = fmaxf(m, sc);
+        const float rescale = expf(m - mn);  // exp(-inf) = 0 on the first edge
+        const float p  = expf(sc - mn);
+        d              = d * rescale + p;
+        const float* xp = x + (int64_t)c * ldx + f0;
+        if constexpr (VEC == 4) {
+          float4 t = *reinterpret_cast<const float4*>(xp);
+          acc[0] = acc[0] * rescale + p * t.x;
+          acc[1] = acc[1] * rescale + p * t.y;
+          acc[2] = acc[2] * rescale + p * t.z;
+          acc[3] = acc[3] * rescale + p * t.w;
+        } else {
+          acc[0] = acc[0] * rescale + p * xp[0];
+        }
+        m = mn;
+      }
+      const float inv = e > s ? 1.0f / d : 0.f;
+      float* q        = out + row * ldo + f0;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(q) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+      } else {
+        q[0] = acc[0] * inv;
+      }
+      // the first lane of every head also writes the attention coefficients
+      if (alpha_out != nullptr && (f0 % C) == 0) {
+        for (int j = s; j < e; j++) {
+          float sc = a_src[(int64_t)col[j] * H + h] + ad;
+          sc       = sc > 0.f ? sc : sc * slope;
+          alpha_out[(int64_t)j * H + h] = expf(sc - m) * inv;
+        }
+      }
+    }
+  }
+}
+
+inline int lanes_log2_for(int units)
+{
+  int l = 0;
+  while ((1 << l) < units && l < 6) l++;
+  return l;
+}
+
+inline int grid_rows(int64_t n_rows, int log2_lanes)
+{
+  int64_t groups_per_block = 256 >> log2_lanes;
+  int64_t blocks           = (n_rows + groups_per_block - 1) / groups_per_block;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+inline bool vec4_ok(const void* a, int64_t lda, const void* b, int64_t ldb, int F)
+{
+  return F % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(b) & 15) == 0;
+}
+
+}  // namespace
+}  // namespace wgamd
+
+extern "C" {
+
+wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                            int64_t ldx, int F, const void* src_ids,
+                                            wholememory_dtype_t src_ids_dtype, int mean, float* out, int64_t ldo,
+                                            void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_spmm_csr_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && F > 0, "bad sizes");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(row_ptr && col && x && out, "null pointer");
+    WG_REQUIRE_INPUT(src_ids == nullptr || src_ids_dtype == WHOLEMEMORY_DT_INT || src_ids_dtype == WHOLEMEMORY_DT_INT64,
+                     "src_ids dtype must be INT|INT64");
+    auto st        = static_cast<hipStream_t>(stream);
+    const bool v4  = vec4_ok(x, ldx, out, ldo, F);
+    const int l2   = lanes_log2_for(v4 ? F / 4 : F);
+    const int grid = grid_rows(n_rows, l2);
+#define WG_SPMM(VEC, IDT, IDP) \
+  spmm_csr_kernel<VEC, IDT><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, IDP, mean, out, ldo, l2)
+    if (src_ids == nullptr) {
+      if (v4) WG_SPMM(4, void, (const void*)nullptr); else WG_SPMM(1, void, (const void*)nullptr);
+    } else if (src_ids_dtype == WHOLEMEMORY_DT_INT) {
+      if (v4) WG_SPMM(4, int32_t, static_cast<const int32_t*>(src_ids)); else WG_SPMM(1, int32_t, static_cast<const int32_t*>(src_ids));
+    } else {
+      if (v4) WG_SPMM(4, int64_t, static_cast<const int64_t*>(src_ids)); else WG_SPMM(1, int64_t, static_cast<const int64_t*>(src_ids));
+    }
+#undef WG_SPMM
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows,
+                                                const float* grad_out, int64_t ldg, int F, int mean, float* grad_x,
+                                                int64_t ldx, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_spmm_csr_bwd_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && F > 0, "bad sizes");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(row_ptr && col && grad_out && grad_x, "null pointer");
+    auto st        = static_cast<hipStream_t>(stream);
+    const bool v4  = vec4_ok(grad_out, ldg, grad_x, ldx, F);
+    const int l2   = lanes_log2_for(v4 ? F / 4 : F);
+    const int grid = grid_rows(n_rows, l2);
+    if (v4)
+      spmm_csr_bwd_kernel<4><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, grad_out, ldg, F, mean, grad_x, ldx, l2);
+    else
+      spmm_csr_bwd_kernel<1><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, grad_out, ldg, F, mean, grad_x, ldx, l2);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                           int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
+                                           float negative_slope, float* alpha_out, float* out, int64_t ldo,
+                                           void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gat_csr_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && H > 0 && C > 0, "bad sizes");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && out, "null pointer");
+    auto st        = static_cast<hipStream_t>(stream);
+    const int HC   = H * C;
+    const bool v4  = (C % 4 == 0) && vec4_ok(x, ldx, out, ldo, HC);
+    const int l2   = lanes_log2_for(v4 ? HC / 4 : HC);
+    const int grid = grid_rows(n_rows, l2);
+    if (v4)
+      gat_csr_kernel<4><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope,
+                                              alpha_out, out, ldo, l2);
+    else
+      gat_csr_kernel<1><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope,
+                                              alpha_out, out, ldo, l2);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// Edge renumbering of a sampled hop (graph_append_unique) and csr_add_self_loop, for gfx950.
+//
+// Replaces /root/reference/cpp/include/wholememory/graph_op.h:27-48 (reference kernels
+// cpp/src/graph_ops/append_unique_func.cuh:44-341, csr_add_self_loop_func.cuh:13-47).
+//
+// Design (not the reference's bucketed CAS table with slot-order ids):
+//   one open-addressing table keyed by node id whose value is the MINIMUM position of that id in
+//   the concatenation  targets ++ neighbours  (atomicMin => order-independent, deterministic).
+//     position <  T  -> the id is a target, its local id is that position
+//     position == T+e-> neighbour e is the FIRST occurrence of a new id
+//   flag first occurrences, exclusive-scan the flags over the neighbour list, and
+//   local id = T + rank.  The tail of `unique` therefore comes out in first-appearance order —
+//   exactly what the reference's host oracle produces
+//   (cpp/tests/graph_ops/append_unique_test_utils.cu:52-84) and a strict refinement of the
+//   reference device op, which leaves that order to CAS races.
+#include "wg_common.hpp"
+
+namespace wgamd {
+namespace {
+
+constexpr int kEmptyPos = 0x7fffffff;
+
+template <typename KeyT>
+struct key_traits;
+template <>
+struct key_traits<int32_t> {
+  using cas_t                         = unsigned int;
+  static constexpr int32_t kEmpty     = -1;
+  static constexpr wholememory_dtype_t dt = WHOLEMEMORY_DT_INT;
+};
+template <>
+struct key_traits<int64_t> {
+  using cas_t                         = unsigned long long;
+  static constexpr int64_t kEmpty     = -1;
+  static constexpr wholememory_dtype_t dt = WHOLEMEMORY_DT_INT64;
+};
+
+__device__ __forceinline__ uint32_t hash_key(uint64_t k)
+{
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 29;
+  return (uint32_t)(k ^ (k >> 32));
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256) table_clear_kernel(KeyT* keys, int* minpos, int64_t slots)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < slots) {
+    keys[i]   = key_traits<KeyT>::kEmpty;
+    minpos[i] = kEmptyPos;
+  }
+}
+
+// thread p < T inserts target p, thread T+e inserts neighbour e; remembers its slot.
+template <typename KeyT>
+__global__ void __launch_bounds__(256) table_insert_kernel(const KeyT* __restrict__ targets,
+                                                           dev_count T_,
+                                                           const KeyT* __restrict__ neighbors,
+                                                           dev_count E_,
+                                                           KeyT* keys,
+                                                           int* minpos,
+                                                           uint32_t slot_mask,
+                                                           int* __restrict__ slot_of)
+{
+  using cas_t = typename key_traits<KeyT>::cas_t;
+  const int T = T_.get(), E = E_.get();
+  int p       = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= T + E) return;
+  KeyT key   = p < T ? targets[p] : neighbors[p - T];
+  uint32_t h = hash_key((uint64_t)(int64_t)key) & slot_mask;
+  while (true) {
+    KeyT cur = keys[h];
+    if (cur == key_traits<KeyT>::kEmpty) {
+      cas_t old = atomicCAS(reinterpret_cast<cas_t*>(keys + h), (cas_t)key_traits<KeyT>::kEmpty, (cas_t)key);
+      cur       = (KeyT)old;
+      if (cur == key_traits<KeyT>::kEmpty) cur = key;  // we own the slot now
+    }
+    if (cur == key) break;
+    h = (h + 1) & slot_mask;
+  }
+  atomicMin(minpos + h, p);
+  slot_of[p] = (int)h;
+}
+
+// flag[e] = 1 iff neighbour e is the first occurrence of an id that is not a target
+__global__ void __launch_bounds__(256)
+first_flag_kernel(const int* __restrict__ minpos, const int* __restrict__ slot_of, dev_count T_, dev_count E_,
+                  int* __restrict__ flag)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E_.host) return;
+  const int T = T_.get();
+  flag[e] = (e < E_.get() && minpos[slot_of[T + e]] == T + e) ? 1 : 0;  // capacity slack -> 0
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restrict__ targets,
+                                                            const KeyT* __restrict__ neighbors,
+                                                            const int* __restrict__ minpos,
+                                                            const int* __restrict__ slot_of,
+                                                            const int* __restrict__ rank,  // exclusive scan of flag, [E.host+1]
+                                                            dev_count T_,
+                                                            dev_count E_,
+                                                            KeyT* __restrict__ unique_out,
+                                                            int* __restrict__ map_out,
+                                                            int* __restrict__ counts_out)
+{
+  const int T = T_.get(), E = E_.get();
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0 && counts_out) {
+    counts_out[0] = E;
+    counts_out[1] = T + rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
+  }
+  if (p < T) {
+    unique_out[p] = targets[p];
+    return;
+  }
+  int e = p - T;
+  if (e >= E) return;
+  int first = minpos[slot_of[p]];  // position (in targets ++ neighbours) of the id's first occurrence
+  int local = first < T ? first : T + rank[first - T];
+  if (first == p) unique_out[local] = neighbors[e];
+  if (map_out) map_out[e] = local;
+}
+
+template <typename KeyT>
+void append_unique_impl(const KeyT* targets, int T, const KeyT* neighbors, int E, void* unique_ctx, int* map_out,
+                        wholememory_env_func_t* env, hipStream_t stream)
+{
+  const int P         = T + E;
+  const int64_t slots = append_unique_slots(P);
+  temp_buffer keys_b(env), pos_b(env), slot_b(env), flag_b(env), tmp_b(env);
+  KeyT* keys   = static_cast<KeyT*>(keys_b.alloc(slots, key_traits<KeyT>::dt));
+  int* minpos  = pos_b.device<int>(slots, WHOLEMEMORY_DT_INT);
+  int* slot_of = slot_b.device<int>(P, WHOLEMEMORY_DT_INT);
+  int* rank    = flag_b.device<int>(E + 1, WHOLEMEMORY_DT_INT);
+  int* stmp    = tmp_b.device<int>(scan_tmp_ints(E + 1), WHOLEMEMORY_DT_INT);
+  const bool k64 = sizeof(KeyT) == 8;
+  dev_count Tc{T, nullptr}, Ec{E, nullptr};
+
+  append_unique_prepare_enqueue(targets, Tc, neighbors, Ec, k64, keys, minpos, slots, slot_of, rank, stmp, stream);
+  int U = 0;
+  WG_HIP_CHECK(hipMemcpyAsync(&U, rank + E, sizeof(int), hipMemcpyDeviceToHost, stream));
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // output size
+
+  KeyT* unique_out = static_cast<KeyT*>(output_alloc(env, unique_ctx, (int64_t)T + U, key_traits<KeyT>::dt));
+  append_unique_emit_enqueue(targets, Tc, neighbors, Ec, k64, minpos, slot_of, rank, unique_out, map_out, nullptr, stream);
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
+}
+
+__global__ void __launch_bounds__(256)
+add_self_loop_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int rows, int* __restrict__ out_row_ptr,
+                     int* __restrict__ out_col)
+{
+  // one wave per row
+  int row  = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  int s = row_ptr[row], e = row_ptr[row + 1];
+  if (lane == 0) {
+    out_row_ptr[row] = s + row;
+    if (row == rows - 1) out_row_ptr[rows] = e + rows;
+  }
+  for (int j = lane; j <= e - s; j += 64) out_col[s + row + j] = j == 0 ? row : col[s + j - 1];
+}
+
+}  // namespace
+
+int64_t append_unique_slots(int64_t capacity)
+{
+  int64_t slots = 1024;
+  while (slots < 2 * capacity) slots <<= 1;
+  return slots;
+}
+
+template <typename KeyT>
+static void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, KeyT* keys, int* minpos,
+                      int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
+{
+  const int P = T.host + E.host;
+  table_clear_kernel<KeyT><<<ceil_div(slots, 256), 256, 0, stream>>>(keys, minpos, slots);
+  if (P > 0)
+    table_insert_kernel<KeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, keys, minpos,
+                                                                   (uint32_t)(slots - 1), slot_of);
+  if (E.host > 0) first_flag_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(minpos, slot_of, T, E, rank);
+  WG_HIP_CHECK(hipGetLastError());
+  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream);  // flags -> ranks, rank[E.host] = #new nodes
+}
+
+void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+                                   void* keys, int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp,
+                                   hipStream_t stream)
+{
+  if (ids64)
+    prepare_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E,
+                       static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+  else
+    prepare_t<int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E,
+                       static_cast<int32_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+}
+
+void append_unique_emit_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+                                const int* minpos, const int* slot_of, const int* rank, void* unique_out, int* map_out,
+                                int* counts_out, hipStream_t stream)
+{
+  const int P = T.host + E.host;
+  const int grid = P > 0 ? ceil_div(P, 256) : 1;  // thread 0 also publishes the counts
+  if (ids64)
+    renumber_emit_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(targets),
+                                                           static_cast<const int64_t*>(neighbors), minpos, slot_of, rank,
+                                                           T, E, static_cast<int64_t*>(unique_out), map_out, counts_out);
+  else
+    renumber_emit_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(targets),
+                                                           static_cast<const int32_t*>(neighbors), minpos, slot_of, rank,
+                                                           T, E, static_cast<int32_t*>(unique_out), map_out, counts_out);
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace wgamd
+
+extern "C" {
+
+wholememory_error_code_t graph_append_unique(wholememory_tensor_t target_nodes_tensor,
+                                             wholememory_tensor_t neighbor_nodes_tensor,
+                                             void* output_unique_node_memory_context,
+                                             wholememory_tensor_t output_neighbor_raw_to_unique_mapping_tensor,
+                                             wholememory_env_func_t* p_env_fns, void* stream)
+{
+  using namespace wgamd;
+  return guarded("graph_append_unique", [&] {
+    WG_REQUIRE_INPUT(target_nodes_tensor && neighbor_nodes_tensor && p_env_fns, "null tensor / env");
+    WG_REQUIRE_INPUT(output_unique_node_memory_context != nullptr, "output_unique_node_memory_context is NULL");
+    auto td = target_nodes_tensor->desc, nd = neighbor_nodes_tensor->desc;
+    WG_REQUIRE_INPUT(td.dim == 1 && nd.dim == 1, "target / neighbor tensors must be 1-D");
+    WG_REQUIRE_INPUT(td.dtype == nd.dtype, "target and neighbor dtypes differ");
+    WG_REQUIRE_INPUT(td.dtype == WHOLEMEMORY_DT_INT || td.dtype == WHOLEMEMORY_DT_INT64, "node ids must be INT|INT64");
+    WG_REQUIRE_INPUT(td.sizes[0] + nd.sizes[0] < ((int64_t)1 << 30), "too many nodes for one call");
+    int* map_out = nullptr;
+    auto mt      = output_neighbor_raw_to_unique_mapping_tensor;
+    if (mt != nullptr && mt->desc.dim != 0 && tensor_data(mt) != nullptr) {
+      WG_REQUIRE_INPUT(mt->desc.dim == 1 && mt->desc.dtype == WHOLEMEMORY_DT_INT, "mapping tensor must be 1-D INT");
+      WG_REQUIRE_INPUT(mt->desc.sizes[0] == nd.sizes[0], "mapping tensor size != neighbor count");
+      map_out = static_cast<int*>(tensor_data(mt));
+    }
+    auto s = static_cast<hipStream_t>(stream);
+    if (td.dtype == WHOLEMEMORY_DT_INT) {
+      append_unique_impl<int32_t>(static_cast<const int32_t*>(tensor_data(target_nodes_tensor)), (int)td.sizes[0],
+                                  static_cast<const int32_t*>(tensor_data(neighbor_nodes_tensor)), (int)nd.sizes[0],
+                                  output_unique_node_memory_context, map_out, p_env_fns, s);
+    } else {
+      append_unique_impl<int64_t>(static_cast<const int64_t*>(tensor_data(target_nodes_tensor)), (int)td.sizes[0],
+                                  static_cast<const int64_t*>(tensor_data(neighbor_nodes_tensor)), (int)nd.sizes[0],
+                                  output_unique_node_memory_context, map_out, p_env_fns, s);
+    }
+  });
+}
+
+wholememory_error_code_t csr_add_self_loop(wholememory_tensor_t csr_row_ptr_tensor,
+                                           wholememory_tensor_t csr_col_ptr_tensor,
+                                           wholememory_tensor_t output_csr_row_ptr_tensor,
+                                           wholememory_tensor_t output_csr_col_ptr_tensor, void* stream)
+{
+  using namespace wgamd;
+  return guarded("csr_add_self_loop", [&] {
+    WG_REQUIRE_INPUT(csr_row_ptr_tensor && csr_col_ptr_tensor && output_csr_row_ptr_tensor && output_csr_col_ptr_tensor,
+                     "null tensor");
+    auto rd = csr_row_ptr_tensor->desc, cd = csr_col_ptr_tensor->desc;
+    auto ord = output_csr_row_ptr_tensor->desc, ocd = output_csr_col_ptr_tensor->desc;
+    WG_REQUIRE_INPUT(rd.dim == 1 && cd.dim == 1 && ord.dim == 1 && ocd.dim == 1, "all tensors must be 1-D");
+    WG_REQUIRE_INPUT(rd.dtype == WHOLEMEMORY_DT_INT && cd.dtype == WHOLEMEMORY_DT_INT && ord.dtype == WHOLEMEMORY_DT_INT &&
+                       ocd.dtype == WHOLEMEMORY_DT_INT,
+                     "csr_add_self_loop supports INT only");
+    WG_REQUIRE_INPUT(rd.sizes[0] >= 1 && ord.sizes[0] == rd.sizes[0], "output row_ptr size must equal input row_ptr size");
+    WG_REQUIRE_INPUT(ocd.sizes[0] == cd.sizes[0] + rd.sizes[0] - 1, "output col size must be nnz + rows");
+    int rows = (int)rd.sizes[0] - 1;
+    if (rows == 0) {
+      WG_HIP_CHECK(hipMemsetAsync(tensor_data(output_csr_row_ptr_tensor), 0, sizeof(int), static_cast<hipStream_t>(stream)));
+      return;
+    }
+    add_self_loop_kernel<<<ceil_div((int64_t)rows * 64, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const int*>(tensor_data(csr_row_ptr_tensor)), static_cast<const int*>(tensor_data(csr_col_ptr_tensor)), rows,
+      static_cast<int*>(tensor_data(output_csr_row_ptr_tensor)), static_cast<int*>(tensor_data(output_csr_col_ptr_tensor)));
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

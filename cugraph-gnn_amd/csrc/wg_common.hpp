@@ -1,0 +1,195 @@
+// Internal helpers shared by the C-ABI translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "wgamd_ops.h"
+#include "wgamd_tensor.h"
+#include "wgamd_types.h"
+
+struct wholememory_tensor_ {
+  void* storage_ptr;  // element 0 before storage_offset
+  wholememory_tensor_description_t desc;
+  wholememory_tensor_* root;      // nullptr for a root tensor
+  wholememory_handle_t handle;    // nullptr unless backed by a DISTRIBUTED handle
+};
+
+namespace wgamd {
+
+struct hip_error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct logic_error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct invalid_input : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+inline std::string fmt(const char* f, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof(buf), f, ap);
+  va_end(ap);
+  return buf;
+}
+
+#define WG_HIP_CHECK(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      throw ::wgamd::hip_error(::wgamd::fmt("%s:%d HIP error %d (%s) in %s", __FILE__,       \
+                                            __LINE__, (int)e__, hipGetErrorString(e__), #expr)); \
+    }                                                                                        \
+  } while (0)
+
+#define WG_EXPECTS(cond, ...)                                                              \
+  do {                                                                                     \
+    if (!(cond)) throw ::wgamd::logic_error(::wgamd::fmt(__VA_ARGS__));                    \
+  } while (0)
+
+#define WG_REQUIRE_INPUT(cond, ...)                                                        \
+  do {                                                                                     \
+    if (!(cond)) throw ::wgamd::invalid_input(::wgamd::fmt(__VA_ARGS__));                  \
+  } while (0)
+
+// Runs `body`, mapping exceptions to the ABI's return codes (one stderr line each), the same
+// convention as /root/reference/cpp/src/wholegraph_ops/unweighted_sample_without_replacement_impl_mapped.cu:57-66.
+template <typename F>
+inline wholememory_error_code_t guarded(const char* op, F&& body)
+{
+  try {
+    body();
+  } catch (const invalid_input& e) {
+    fprintf(stderr, "[wholegraph_amd] %s: invalid input: %s\n", op, e.what());
+    return WHOLEMEMORY_INVALID_INPUT;
+  } catch (const logic_error& e) {
+    fprintf(stderr, "[wholegraph_amd] %s: logic error: %s\n", op, e.what());
+    return WHOLEMEMORY_LOGIC_ERROR;
+  } catch (const hip_error& e) {
+    fprintf(stderr, "[wholegraph_amd] %s: device error: %s\n", op, e.what());
+    return WHOLEMEMORY_CUDA_ERROR;
+  } catch (const std::bad_alloc&) {
+    fprintf(stderr, "[wholegraph_amd] %s: out of memory\n", op);
+    return WHOLEMEMORY_OUT_OF_MEMORY;
+  } catch (...) {
+    fprintf(stderr, "[wholegraph_amd] %s: unknown error\n", op);
+    return WHOLEMEMORY_UNKNOW_ERROR;
+  }
+  return WHOLEMEMORY_SUCCESS;
+}
+
+inline size_t dtype_size(wholememory_dtype_t d) { return wholememory_dtype_get_element_size(d); }
+
+// pointer to element `storage_offset` of a raw-pointer tensor
+inline void* tensor_data(wholememory_tensor_t t)
+{
+  if (t == nullptr || t->storage_ptr == nullptr) return nullptr;
+  return static_cast<char*>(t->storage_ptr) + t->desc.storage_offset * (int64_t)dtype_size(t->desc.dtype);
+}
+
+// ---- scratch / output memory through the caller's callbacks --------------------------------
+// (the roles of /root/reference/cpp/src/wholememory_ops/temp_memory_handle.hpp:12-62 and
+//  output_memory_handle.hpp:22-35, re-expressed as small RAII objects)
+class temp_buffer {
+ public:
+  explicit temp_buffer(wholememory_env_func_t* env) : env_(env)
+  {
+    env_->temporary_fns.create_memory_context_fn(&ctx_, env_->temporary_fns.global_context);
+  }
+  temp_buffer(const temp_buffer&)            = delete;
+  temp_buffer& operator=(const temp_buffer&) = delete;
+  ~temp_buffer()
+  {
+    if (ptr_) env_->temporary_fns.free_fn(ctx_, env_->temporary_fns.global_context);
+    env_->temporary_fns.destroy_memory_context_fn(ctx_, env_->temporary_fns.global_context);
+  }
+  void* alloc(int64_t elt_count, wholememory_dtype_t dtype,
+              wholememory_memory_allocation_type_t where = WHOLEMEMORY_MA_DEVICE)
+  {
+    if (ptr_) {
+      env_->temporary_fns.free_fn(ctx_, env_->temporary_fns.global_context);
+      ptr_ = nullptr;
+    }
+    wholememory_tensor_description_t d;
+    wholememory_initialize_tensor_desc(&d);
+    d.dim        = 1;
+    d.sizes[0]   = elt_count > 0 ? elt_count : 1;  // never hand a 0-byte request to the allocator
+    d.strides[0] = 1;
+    d.dtype      = dtype;
+    ptr_ = env_->temporary_fns.malloc_fn(&d, where, ctx_, env_->temporary_fns.global_context);
+    if (!ptr_) throw std::bad_alloc();
+    return ptr_;
+  }
+  template <typename T>
+  T* device(int64_t n, wholememory_dtype_t dt)
+  {
+    return static_cast<T*>(alloc(n, dt, WHOLEMEMORY_MA_DEVICE));
+  }
+  void* bytes(int64_t n) { return alloc(n, WHOLEMEMORY_DT_INT8, WHOLEMEMORY_MA_DEVICE); }
+  void* pinned_bytes(int64_t n) { return alloc(n, WHOLEMEMORY_DT_INT8, WHOLEMEMORY_MA_PINNED); }
+
+ private:
+  wholememory_env_func_t* env_;
+  void* ctx_ = nullptr;
+  void* ptr_ = nullptr;
+};
+
+// Allocates an op OUTPUT of `elt_count` elements in the caller's memory_context (never freed here).
+inline void* output_alloc(wholememory_env_func_t* env, void* memory_context, int64_t elt_count,
+                          wholememory_dtype_t dtype)
+{
+  wholememory_tensor_description_t d;
+  wholememory_initialize_tensor_desc(&d);
+  d.dim        = 1;
+  d.sizes[0]   = elt_count;
+  d.strides[0] = 1;
+  d.dtype      = dtype;
+  void* p = env->output_fns.malloc_fn(&d, WHOLEMEMORY_MA_DEVICE, memory_context,
+                                      env->output_fns.global_context);
+  if (elt_count > 0 && p == nullptr) throw std::bad_alloc();
+  return p;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// A size that lives either on the host (ABI ops: the value is known) or on the device (no-sync
+// walk: `dev` points at it and `host` is only the capacity used to size the grid).
+struct dev_count {
+  int host;
+  const int* dev;
+  __device__ __forceinline__ int get() const { return dev ? *dev : host; }
+};
+
+// ---- device-side utilities implemented in wg_scan.hip ---------------------------------------
+// out[0..n] (n+1 entries) = exclusive scan of in[0..n-1]; out[n] = total. in/out may alias.
+// `tmp` needs scan_tmp_ints(n) ints.
+int64_t scan_tmp_ints(int64_t n);
+void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream);
+
+
+// ---- building blocks shared by the ABI ops and the no-sync walk (wg_fused.hip) -----------------
+// uniform sampling of `n` targets (n.host = capacity): cnt/offsets have n.host+1 entries
+void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
+                            dev_count n, int M, uint64_t random_seed, const int* offsets, void* dst, int* src_lid,
+                            int64_t* edge_gid, hipStream_t stream);
+void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
+                          int* big_deg, hipStream_t stream);
+// renumbering: table of `slots` (power of two >= 2*(T.host+E.host)) entries, slot_of[T.host+E.host],
+// rank[E.host+1], scan_tmp[scan_tmp_ints(E.host+1)].  unique_out may be NULL for `prepare`.
+int64_t append_unique_slots(int64_t capacity);
+void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+                                   void* keys, int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp,
+                                   hipStream_t stream);
+void append_unique_emit_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+                                const int* minpos, const int* slot_of, const int* rank, void* unique_out, int* map_out,
+                                int* counts_out /*nullable: {E, T+U}*/, hipStream_t stream);
+
+}  // namespace wgamd

@@ -1,0 +1,341 @@
+// Row gather / scatter of a feature (embedding) table by index — the feature fetch of a mini-batch.
+//
+// Replaces wholememory_gather / wholememory_scatter
+// (/root/reference/cpp/include/wholememory/wholememory_op.h:25-47; reference kernels
+// cpp/src/wholememory_ops/functions/gather_scatter_func.cuh:242-365,508-650) for tables that wrap
+// a device pointer.  DISTRIBUTED tables go through the RCCL all-to-all pipeline built on top of
+// these local kernels (cugraph-gnn_amd/wholegraph_amd/dist.py).
+//
+// gfx950 design: the op is pure HBM traffic (random 100 B – 1 KiB row reads, streaming writes).
+//   * same dtype in/out  -> dtype-agnostic byte-row copy with the widest aligned vector
+//     (16 B/lane), a power-of-two lane group per row (F=100 fp32: 25 of 32 lanes, two rows per
+//     wave64; F=128: 32 lanes; F=256: the whole wave), and 4 rows in flight per group so each
+//     wave keeps >= 4 independent 16 B loads outstanding per lane before the first store.
+//   * converting gathers -> one templated element kernel (load InT, convert through fp32 for the
+//     16-bit types, store OutT), lanes along the row for coalescing.
+// A negative index leaves its row untouched (gather_scatter_func.cuh:285).
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "wg_common.hpp"
+
+namespace wgamd {
+namespace {
+
+template <int V>
+struct vec_of;
+template <>
+struct vec_of<16> {
+  using type = uint4;
+};
+template <>
+struct vec_of<8> {
+  using type = uint2;
+};
+template <>
+struct vec_of<4> {
+  using type = uint32_t;
+};
+template <>
+struct vec_of<2> {
+  using type = uint16_t;
+};
+template <>
+struct vec_of<1> {
+  using type = uint8_t;
+};
+
+constexpr int kRowsInFlight = 4;
+
+// GATHER : dst row i   <- src row idx[i]
+// SCATTER: dst row idx[i] <- src row i
+template <int V, typename IdxT, bool SCATTER>
+__global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ src,
+                                                       int64_t src_stride,  // bytes
+                                                       const IdxT* __restrict__ idx,
+                                                       int64_t n,
+                                                       int row_bytes,
+                                                       char* __restrict__ dst,
+                                                       int64_t dst_stride,  // bytes
+                                                       int log2_lanes)
+{
+  using vec_t         = typename vec_of<V>::type;
+  const int lanes     = 1 << log2_lanes;
+  const int64_t tid   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t group = tid >> log2_lanes;
+  const int sub       = (int)(tid & (lanes - 1));
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const int step      = lanes * V;
+
+  for (int64_t row0 = group * kRowsInFlight; row0 < n; row0 += ngroups * kRowsInFlight) {
+    int64_t r[kRowsInFlight];
+#pragma unroll
+    for (int k = 0; k < kRowsInFlight; k++) r[k] = (row0 + k < n) ? (int64_t)idx[row0 + k] : -1;
+    for (int off = sub * V; off < row_bytes; off += step) {
+      vec_t v[kRowsInFlight];
+#pragma unroll
+      for (int k = 0; k < kRowsInFlight; k++) {
+        if (r[k] >= 0) {
+          const char* p = SCATTER ? src + (row0 + k) * src_stride + off : src + r[k] * src_stride + off;
+          v[k]          = *reinterpret_cast<const vec_t*>(p);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kRowsInFlight; k++) {
+        if (r[k] >= 0) {
+          char* q = SCATTER ? dst + r[k] * dst_stride + off : dst + (row0 + k) * dst_stride + off;
+          *reinterpret_cast<vec_t*>(q) = v[k];
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v)
+{
+  return (float)v;
+}
+template <>
+__device__ __forceinline__ float to_f32<__half>(__half v)
+{
+  return __half2float(v);
+}
+template <>
+__device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 v)
+{
+  return __bfloat162float(v);
+}
+template <typename T>
+__device__ __forceinline__ T from_f32(float v)
+{
+  return (T)v;
+}
+template <>
+__device__ __forceinline__ __half from_f32<__half>(float v)
+{
+  return __float2half(v);
+}
+template <>
+__device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(float v)
+{
+  return __float2bfloat16(v);
+}
+
+template <typename InT, typename OutT>
+__device__ __forceinline__ OutT convert(InT v)
+{
+  if constexpr (std::is_same<InT, OutT>::value) {
+    return v;
+  } else if constexpr (std::is_integral<InT>::value && std::is_integral<OutT>::value) {
+    return (OutT)v;
+  } else if constexpr (std::is_same<InT, double>::value && std::is_same<OutT, float>::value) {
+    return (float)v;
+  } else if constexpr (std::is_same<InT, float>::value && std::is_same<OutT, double>::value) {
+    return (double)v;
+  } else if constexpr (std::is_same<OutT, double>::value) {
+    return (double)to_f32<InT>(v);
+  } else if constexpr (std::is_same<InT, double>::value) {
+    return from_f32<OutT>((float)v);
+  } else {
+    return from_f32<OutT>(to_f32<InT>(v));
+  }
+}
+
+template <typename InT, typename OutT, typename IdxT, bool SCATTER>
+__global__ void __launch_bounds__(256) row_convert_kernel(const InT* __restrict__ src,
+                                                          int64_t src_stride,  // elements
+                                                          const IdxT* __restrict__ idx,
+                                                          int64_t n,
+                                                          int row_elems,
+                                                          OutT* __restrict__ dst,
+                                                          int64_t dst_stride,
+                                                          int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t group   = tid >> log2_lanes;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  for (int64_t row = group; row < n; row += ngroups) {
+    int64_t r = (int64_t)idx[row];
+    if (r < 0) continue;
+    const InT* p = SCATTER ? src + row * src_stride : src + r * src_stride;
+    OutT* q      = SCATTER ? dst + r * dst_stride : dst + row * dst_stride;
+    for (int e = sub; e < row_elems; e += lanes) q[e] = convert<InT, OutT>(p[e]);
+  }
+}
+
+inline int log2_ceil_lanes(int64_t units)
+{
+  int l = 0;
+  while ((1 << l) < units && l < 6) l++;
+  return l;
+}
+
+inline int grid_for(int64_t n_rows, int log2_lanes, int rows_per_group)
+{
+  int64_t groups_per_block = 256 >> log2_lanes;
+  int64_t blocks           = (n_rows + groups_per_block * rows_per_group - 1) / (groups_per_block * rows_per_group);
+  // memory-bound: cap at 8 workgroups per CU and grid-stride the rest
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <typename IdxT, bool SCATTER>
+void launch_copy(const char* src, int64_t src_stride, const IdxT* idx, int64_t n, int row_bytes, char* dst,
+                 int64_t dst_stride, hipStream_t stream)
+{
+  int V = 16;
+  while (V > 1 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)src_stride |
+                    (uintptr_t)dst_stride | (uintptr_t)row_bytes) %
+                   V) != 0)
+    V >>= 1;
+  int l2   = log2_ceil_lanes((row_bytes + V - 1) / V);
+  int grid = grid_for(n, l2, kRowsInFlight);
+#define WG_LAUNCH(VV)                                                                                                  \
+  row_copy_kernel<VV, IdxT, SCATTER><<<grid, 256, 0, stream>>>(src, src_stride, idx, n, row_bytes, dst, dst_stride, l2)
+  switch (V) {
+    case 16: WG_LAUNCH(16); break;
+    case 8: WG_LAUNCH(8); break;
+    case 4: WG_LAUNCH(4); break;
+    case 2: WG_LAUNCH(2); break;
+    default: WG_LAUNCH(1); break;
+  }
+#undef WG_LAUNCH
+}
+
+template <typename InT, typename OutT, typename IdxT, bool SCATTER>
+void launch_convert(const void* src, int64_t src_stride, const IdxT* idx, int64_t n, int row_elems, void* dst,
+                    int64_t dst_stride, hipStream_t stream)
+{
+  int l2   = log2_ceil_lanes(row_elems);
+  int grid = grid_for(n, l2, 1);
+  row_convert_kernel<InT, OutT, IdxT, SCATTER><<<grid, 256, 0, stream>>>(
+    static_cast<const InT*>(src), src_stride, idx, n, row_elems, static_cast<OutT*>(dst), dst_stride, l2);
+}
+
+template <typename InT, typename IdxT, bool SCATTER>
+void convert_out(wholememory_dtype_t out_dt, const void* src, int64_t ss, const IdxT* idx, int64_t n, int f, void* dst,
+                 int64_t ds, hipStream_t st)
+{
+  if constexpr (std::is_integral<InT>::value) {
+    switch (out_dt) {
+      case WHOLEMEMORY_DT_INT8: return launch_convert<InT, int8_t, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      case WHOLEMEMORY_DT_INT16: return launch_convert<InT, int16_t, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      case WHOLEMEMORY_DT_INT: return launch_convert<InT, int32_t, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      case WHOLEMEMORY_DT_INT64: return launch_convert<InT, int64_t, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      default: break;
+    }
+  } else {
+    switch (out_dt) {
+      case WHOLEMEMORY_DT_HALF: return launch_convert<InT, __half, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      case WHOLEMEMORY_DT_BF16: return launch_convert<InT, __hip_bfloat16, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      case WHOLEMEMORY_DT_FLOAT: return launch_convert<InT, float, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      case WHOLEMEMORY_DT_DOUBLE: return launch_convert<InT, double, IdxT, SCATTER>(src, ss, idx, n, f, dst, ds, st);
+      default: break;
+    }
+  }
+  throw logic_error("unsupported output dtype");
+}
+
+template <typename IdxT, bool SCATTER>
+void convert_in(wholememory_dtype_t in_dt, wholememory_dtype_t out_dt, const void* src, int64_t ss, const IdxT* idx,
+                int64_t n, int f, void* dst, int64_t ds, hipStream_t st)
+{
+  switch (in_dt) {
+    case WHOLEMEMORY_DT_INT8: return convert_out<int8_t, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_INT16: return convert_out<int16_t, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_INT: return convert_out<int32_t, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_INT64: return convert_out<int64_t, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_HALF: return convert_out<__half, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_BF16: return convert_out<__hip_bfloat16, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_FLOAT: return convert_out<float, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    case WHOLEMEMORY_DT_DOUBLE: return convert_out<double, IdxT, SCATTER>(out_dt, src, ss, idx, n, f, dst, ds, st);
+    default: throw logic_error("unsupported input dtype");
+  }
+}
+
+// src_t rows are read, dst_t rows are written; `indexed_is_src` <=> gather
+template <bool SCATTER>
+void rows_op(const char* op, wholememory_tensor_t src_t, wholememory_tensor_t idx_t, wholememory_tensor_t dst_t,
+             hipStream_t stream)
+{
+  WG_REQUIRE_INPUT(src_t && idx_t && dst_t, "null tensor");
+  wholememory_tensor_t table = SCATTER ? dst_t : src_t;
+  if (table->handle != nullptr) {
+    throw logic_error(fmt("%s: DISTRIBUTED tables are served by the RCCL all-to-all pipeline "
+                          "(wholegraph_amd.dist), not by the single-GPU C entry point", op));
+  }
+  wholememory_tensor_description_t sd = src_t->desc, dd = dst_t->desc;
+  WG_REQUIRE_INPUT(sd.dim == 1 || sd.dim == 2, "table / input should be 1D or 2D tensor");
+  WG_REQUIRE_INPUT(dd.dim == sd.dim, "output tensor should be same dim as input tensor");
+  WG_REQUIRE_INPUT(idx_t->desc.dim == 1, "indices tensor should be 1D tensor");
+  if (sd.dim == 1) {
+    WG_EXPECTS(wholememory_unsqueeze_tensor(&sd, 1) && wholememory_unsqueeze_tensor(&dd, 1), "unsqueeze failed");
+  }
+  wholememory_matrix_description_t sm, dm;
+  wholememory_array_description_t id;
+  WG_REQUIRE_INPUT(wholememory_convert_tensor_desc_to_matrix(&sm, &sd), "cannot view input as a matrix");
+  WG_REQUIRE_INPUT(wholememory_convert_tensor_desc_to_matrix(&dm, &dd), "cannot view output as a matrix");
+  WG_REQUIRE_INPUT(wholememory_convert_tensor_desc_to_array(&id, &idx_t->desc), "indices must be contiguous 1-D");
+  WG_REQUIRE_INPUT(id.dtype == WHOLEMEMORY_DT_INT || id.dtype == WHOLEMEMORY_DT_INT64, "indices must be INT|INT64");
+  WG_REQUIRE_INPUT(sm.sizes[1] == dm.sizes[1], "embedding dims differ: %ld vs %ld", (long)sm.sizes[1], (long)dm.sizes[1]);
+  const int64_t n = id.size;
+  WG_REQUIRE_INPUT((SCATTER ? sm.sizes[0] : dm.sizes[0]) >= n, "fewer dense rows than indices");
+  bool sf = wholememory_dtype_is_floating_number(sm.dtype), df = wholememory_dtype_is_floating_number(dm.dtype);
+  WG_EXPECTS(sf == df, "embedding and output should be same number type, e.g. floating number or integer number.");
+  if (n == 0) return;
+
+  const size_t ses = dtype_size(sm.dtype), des = dtype_size(dm.dtype);
+  const char* src  = static_cast<const char*>(src_t->storage_ptr) + sm.storage_offset * (int64_t)ses;
+  char* dst        = static_cast<char*>(dst_t->storage_ptr) + dm.storage_offset * (int64_t)des;
+  const void* idx  = tensor_data(idx_t);
+  WG_REQUIRE_INPUT(src_t->storage_ptr && dst_t->storage_ptr && idx, "null data pointer");
+  const int F = (int)sm.sizes[1];
+
+  if (sm.dtype == dm.dtype) {
+    if (id.dtype == WHOLEMEMORY_DT_INT)
+      launch_copy<int32_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int32_t*>(idx), n, F * (int)ses, dst,
+                                    dm.stride * (int64_t)des, stream);
+    else
+      launch_copy<int64_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int64_t*>(idx), n, F * (int)ses, dst,
+                                    dm.stride * (int64_t)des, stream);
+  } else {
+    if (id.dtype == WHOLEMEMORY_DT_INT)
+      convert_in<int32_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int32_t*>(idx), n, F, dst,
+                                   dm.stride, stream);
+    else
+      convert_in<int64_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int64_t*>(idx), n, F, dst,
+                                   dm.stride, stream);
+  }
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+}  // namespace wgamd
+
+extern "C" {
+
+wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor, wholememory_tensor_t indices_tensor,
+                                            wholememory_tensor_t output_tensor, wholememory_env_func_t* /*p_env_fns*/,
+                                            void* stream, int /*gather_sms*/)
+{
+  return wgamd::guarded("wholememory_gather", [&] {
+    wgamd::rows_op<false>("wholememory_gather", wholememory_tensor, indices_tensor, output_tensor,
+                          static_cast<hipStream_t>(stream));
+  });
+}
+
+wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor, wholememory_tensor_t indices_tensor,
+                                             wholememory_tensor_t wholememory_tensor, wholememory_env_func_t* /*p_env_fns*/,
+                                             void* stream, int /*scatter_sms*/)
+{
+  return wgamd::guarded("wholememory_scatter", [&] {
+    wgamd::rows_op<true>("wholememory_scatter", input_tensor, indices_tensor, wholememory_tensor,
+                         static_cast<hipStream_t>(stream));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,646 @@
+// One-hop neighbour sampling without replacement over a CSR graph (uniform + weighted A-Res),
+// hand-written for gfx950 (wave64).
+//
+// Replaces wholegraph_csr_{un,}weighted_sample_without_replacement
+// (/root/reference/cpp/include/wholememory/wholegraph_op.h:31-73; reference kernels
+// cpp/src/wholegraph_ops/unweighted_sample_without_replacement_func.cuh:28-271,
+// weighted_sample_without_replacement_func.cuh:33-281).  The RESULT is bit-identical to the
+// reference's host oracle (cpp/tests/wholegraph_ops/graph_sampling_test_utils.cu:312-401); the
+// way it is computed is not the reference's:
+//
+//  * M <= 32 (every fan-out of the BASELINE configs): the reference runs one 32-thread block per
+//    seed = half an idle wave64.  Here a wave carries TWO seeds, one per 32-lane half; lane t
+//    draws r_t from PCG stream (i*32+t) — the stream numbering the reference fixes — and the
+//    sequential Fisher-Yates table is resolved in registers with wave ballots: step t needs
+//    Q[r_t] and Q[N-t-1], each "the value written by the latest earlier step that touched that
+//    position, else the position itself", found with one ballot + one bpermute.  No LDS, no
+//    radix sort, no pointer jumping.
+//  * 32 < M <= 1024: one workgroup per seed; draws in parallel with the reference's
+//    (block-size, items-per-lane) stream layout, then one lane walks the swap table through a
+//    small LDS hash (only <= M of the N table positions are ever touched).
+//  * M > 1024: reservoir with a max-reduction per slot, as the reference's large kernel.
+//  * weighted: keys key_e = log2(u_e)/w_e with the reference's per-lane stream layout, then an
+//    exact top-M by 4-pass radix select on the key bits, emitted in CSR order.
+#include <cmath>
+
+#include "wg_common.hpp"
+#include "wg_rng.hpp"
+
+namespace wgamd {
+namespace {
+
+template <typename T>
+struct dtype_of;
+template <>
+struct dtype_of<int32_t> {
+  static constexpr wholememory_dtype_t value = WHOLEMEMORY_DT_INT;
+};
+template <>
+struct dtype_of<int64_t> {
+  static constexpr wholememory_dtype_t value = WHOLEMEMORY_DT_INT64;
+};
+
+// launch table of the reference (…_func.cuh:412-446): PCG stream of lane j of seed i is i*B+j,
+// its k-th draw belongs to sample position k*B+j.
+__host__ __device__ constexpr int ref_block_threads(int M)
+{
+  int f = (M - 1) / 32;
+  return f < 3 ? 32 : f < 6 ? 64 : f < 12 ? 128 : 256;
+}
+__host__ __device__ constexpr int ref_items_per_thread(int M)
+{
+  constexpr int t[32] = {1, 2, 3, 2, 3, 3, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2,
+                         3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
+  return t[(M - 1) / 32];
+}
+
+// the reference computes `int gidx = threadIdx.x + blockIdx.x*blockDim.x` and widens it
+__device__ __forceinline__ uint64_t stream_id(int64_t seed_index, int B, int lane)
+{
+  return (uint64_t)(int64_t)(int32_t)(seed_index * B + lane);
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename SeedT>
+__global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __restrict__ row_ptr,
+                                                           const SeedT* __restrict__ seeds,
+                                                           dev_count n_,
+                                                           int M,
+                                                           int* __restrict__ cnt,
+                                                           int* __restrict__ big_deg /*nullable*/)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_.host) return;
+  if (i >= n_.get()) {  // capacity slack of the no-sync walk: contributes nothing to the scan
+    cnt[i] = 0;
+    if (big_deg) big_deg[i] = 0;
+    return;
+  }
+  int64_t nid = (int64_t)seeds[i];
+  int deg     = (int)(row_ptr[nid + 1] - row_ptr[nid]);
+  cnt[i]      = (M > 0 && deg > M) ? M : deg;
+  if (big_deg) big_deg[i] = (M > 0 && deg > M) ? deg : 0;  // rows that need key scratch (weighted)
+}
+
+template <typename ColT>
+__device__ __forceinline__ void emit(ColT* dst, int* src_lid, int64_t* edge_gid, int64_t out, ColT v,
+                                     int seed_index, int64_t gid)
+{
+  dst[out] = v;
+  if (src_lid) src_lid[out] = seed_index;
+  if (edge_gid) edge_gid[out] = gid;
+}
+
+// ---- M <= 32: two seeds per wave64, everything in registers --------------------------------
+template <typename SeedT, typename ColT>
+__global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int64_t* __restrict__ row_ptr,
+                                                                      const ColT* __restrict__ col,
+                                                                      const SeedT* __restrict__ seeds,
+                                                                      dev_count n_,
+                                                                      int M,
+                                                                      uint64_t random_seed,
+                                                                      const int* __restrict__ offsets,
+                                                                      ColT* __restrict__ dst,
+                                                                      int* __restrict__ src_lid,
+                                                                      int64_t* __restrict__ edge_gid)
+{
+  const int n    = n_.get();
+  const int lane = threadIdx.x & 63;
+  const int hl   = lane & 31;         // lane inside the half
+  const int hb   = lane & 32;         // first lane of my half
+  const int i    = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5);  // seed index
+  int64_t start = 0;
+  int N = 0, base = 0;
+  if (i < n) {
+    int64_t nid = (int64_t)seeds[i];
+    start       = row_ptr[nid];
+    N           = (int)(row_ptr[nid + 1] - start);
+    base        = offsets[i];
+  }
+  const bool pick = N > M;  // uniform inside a half
+  // Is any half of this wave sampling?  (wave-uniform branch around the resolve loop)
+  if (__ballot(pick) == 0ull) {
+    if (hl < N) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + hl], i, start + hl);
+    return;
+  }
+  int r = 0;
+  if (pick && hl < M) {
+    Pcg32 g(random_seed, stream_id(i, 32, hl));
+    r = g.next_i31() % (N - hl);
+  }
+  // Fisher-Yates:  a[t] = Q[r_t];  Q[r_t] = Q[N-t-1].  Lane s remembers (pos=r_s, val=the value
+  // step s stored there).
+  int val = 0, a = 0;
+  for (int t = 0; t < M; t++) {
+    const int rt    = __shfl(r, hb | t, 64);
+    const int tail  = N - t - 1;
+    const bool done = hl < t;  // steps already executed
+    uint64_t m1     = __ballot(done && r == rt);
+    uint64_t m2     = __ballot(done && r == tail);
+    uint32_t h1     = (uint32_t)(m1 >> hb);
+    uint32_t h2     = (uint32_t)(m2 >> hb);
+    int s1          = hb | (31 - __clz((int)h1));
+    int s2          = hb | (31 - __clz((int)h2));
+    int v1          = __shfl(val, s1 & 63, 64);
+    int v2          = __shfl(val, s2 & 63, 64);
+    int q_rt        = h1 ? v1 : rt;
+    int q_tail      = h2 ? v2 : tail;
+    if (hl == t) {
+      a   = q_rt;
+      val = q_tail;
+    }
+  }
+  if (pick) {
+    if (hl < M) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + a], i, start + a);
+  } else if (hl < N) {
+    emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + hl], i, start + hl);
+  }
+}
+
+// ---- 32 < M <= 1024: one workgroup per seed ------------------------------------------------
+constexpr int kHashSlots = 4096;  // >= 2 * (M + M) touched positions, power of two
+
+__device__ __forceinline__ int lds_hash_find(const int* keys, int pos)
+{
+  uint32_t h = ((uint32_t)pos * 2654435761u) & (kHashSlots - 1);
+  while (true) {
+    int k = keys[h];
+    if (k == pos || k == -1) return (int)h;
+    h = (h + 1) & (kHashSlots - 1);
+  }
+}
+
+template <typename SeedT, typename ColT>
+__global__ void __launch_bounds__(256) sample_uniform_block_kernel(const int64_t* __restrict__ row_ptr,
+                                                                   const ColT* __restrict__ col,
+                                                                   const SeedT* __restrict__ seeds,
+                                                                   dev_count n_,
+                                                                   int M,
+                                                                   int B,
+                                                                   int items,
+                                                                   uint64_t random_seed,
+                                                                   const int* __restrict__ offsets,
+                                                                   ColT* __restrict__ dst,
+                                                                   int* __restrict__ src_lid,
+                                                                   int64_t* __restrict__ edge_gid)
+{
+  __shared__ int r[1024];
+  __shared__ int a[1024];
+  __shared__ int hkeys[kHashSlots];
+  __shared__ int hvals[kHashSlots];
+  const int i = blockIdx.x;
+  if (i >= n_.get()) return;
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  const int N         = (int)(row_ptr[nid + 1] - start);
+  if (N <= 0) return;
+  const int base = offsets[i];
+  if (N <= M) {
+    for (int j = threadIdx.x; j < N; j += blockDim.x)
+      emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + j, col[start + j], i, start + j);
+    return;
+  }
+  for (int h = threadIdx.x; h < kHashSlots; h += blockDim.x) hkeys[h] = -1;
+  if ((int)threadIdx.x < B) {
+    Pcg32 g(random_seed, stream_id(i, B, threadIdx.x));
+    for (int k = 0; k < items; k++) {
+      int id = k * B + threadIdx.x;
+      int v  = g.next_i31();
+      if (id < M) r[id] = v % (N - id);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 0; t < M; t++) {
+      const int rt = r[t], tail = N - t - 1;
+      int s1     = lds_hash_find(hkeys, rt);
+      int q_rt   = hkeys[s1] == rt ? hvals[s1] : rt;
+      int s2     = lds_hash_find(hkeys, tail);
+      int q_tail = hkeys[s2] == tail ? hvals[s2] : tail;
+      a[t]       = q_rt;
+      hkeys[s1]  = rt;  // s1 is either rt's slot or the empty slot its probe ended on
+      hvals[s1]  = q_tail;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < M; t += blockDim.x)
+    emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + t, col[start + a[t]], i, start + a[t]);
+}
+
+// ---- M > 1024: reservoir, slot s keeps max{idx : draw % (idx+1) == s} ----------------------
+template <typename SeedT, typename ColT>
+__global__ void __launch_bounds__(64) sample_uniform_reservoir_kernel(const int64_t* __restrict__ row_ptr,
+                                                                      const ColT* __restrict__ col,
+                                                                      const SeedT* __restrict__ seeds,
+                                                                      dev_count n_,
+                                                                      int M,
+                                                                      uint64_t random_seed,
+                                                                      const int* __restrict__ offsets,
+                                                                      ColT* __restrict__ dst,
+                                                                      int* __restrict__ src_lid,
+                                                                      int64_t* __restrict__ edge_gid)
+{
+  const int i = blockIdx.x;
+  if (i >= n_.get()) return;
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  const int N         = (int)(row_ptr[nid + 1] - start);
+  if (N <= 0) return;
+  const int64_t base = offsets[i];
+  if (N <= M) {
+    for (int j = threadIdx.x; j < N; j += blockDim.x)
+      emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
+    return;
+  }
+  for (int s = threadIdx.x; s < M; s += blockDim.x) dst[base + s] = (ColT)s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    Pcg32 g(random_seed, stream_id(i, 32, threadIdx.x));
+    for (int idx = M + threadIdx.x; idx < N; idx += 32) {
+      int rn = g.next_i31() % (idx + 1);
+      if (rn < M) {
+        if constexpr (sizeof(ColT) == 8)
+          atomicMax(reinterpret_cast<long long*>(dst + base + rn), (long long)idx);
+        else
+          atomicMax(reinterpret_cast<int*>(dst + base + rn), idx);
+      }
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < M; s += blockDim.x) {
+    // device-scope load: the slot was updated by L2 atomics, never trust this CU's L1 copy
+    int sel = (int)__hip_atomic_load(dst + base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    emit<ColT>(dst, src_lid, edge_gid, base + s, col[start + sel], i, start + sel);
+  }
+}
+
+// ---- weighted --------------------------------------------------------------------------------
+__device__ __forceinline__ float ares_key(float w, Pcg32& g)
+{
+  float u = g.next_f32();
+  u       = (float)(-(0.5 + 0.5 * (double)u));
+  uint64_t x;
+  int zero_draws = -1;
+  do {
+    x = g.next_u64();
+    zero_draws++;
+  } while (!x);
+  int one_bit = __clzll((long long)x) + zero_draws * 64;
+  u *= exp2f((float)(-one_bit));
+  return (log1pf(u) / logf(2.0f)) * (1.0f / w);
+}
+
+// order-preserving float -> uint (larger key <=> larger uint)
+__device__ __forceinline__ uint32_t key_bits(float k)
+{
+  uint32_t b = __float_as_uint(k);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// One workgroup per seed with deg > M: keys into scratch, exact top-M via radix select, emitted
+// in CSR order (ties on the threshold key: lowest neighbour index first).
+template <typename SeedT, typename ColT, typename WeightT, int B>
+__global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __restrict__ row_ptr,
+                                                            const ColT* __restrict__ col,
+                                                            const WeightT* __restrict__ weight,
+                                                            const SeedT* __restrict__ seeds,
+                                                            int n,
+                                                            int M,
+                                                            uint64_t random_seed,
+                                                            const int* __restrict__ offsets,
+                                                            const int* __restrict__ key_offsets,
+                                                            uint32_t* __restrict__ key_scratch,
+                                                            ColT* __restrict__ dst,
+                                                            int* __restrict__ src_lid,
+                                                            int64_t* __restrict__ edge_gid)
+{
+  __shared__ int hist[256];
+  __shared__ int sh_digit, sh_need;
+  __shared__ int wave_cnt[2][B / 64];
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  const int N         = (int)(row_ptr[nid + 1] - start);
+  if (N <= 0) return;
+  const int64_t base = offsets[i];
+  if (M <= 0 || N <= M) {
+    for (int j = threadIdx.x; j < N; j += B)
+      emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
+    return;
+  }
+  uint32_t* keys = key_scratch + key_offsets[i];
+  {
+    Pcg32 g(random_seed, stream_id(i, B, threadIdx.x));
+    for (int id = threadIdx.x; id < N; id += B) keys[id] = key_bits(ares_key((float)weight[start + id], g));
+  }
+  __syncthreads();
+  // keys[] are written and re-read by different lanes of the same workgroup through global memory,
+  // and neighbouring workgroups' key segments share cache lines: the re-reads below are
+  // device-scope loads so they never hit a stale line in this CU's L1.
+  uint32_t prefix = 0, prefix_mask = 0;
+  int need = M;  // how many keys we still have to take among those matching `prefix`
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int h = threadIdx.x; h < 256; h += B) hist[h] = 0;
+    __syncthreads();
+    for (int id = threadIdx.x; id < N; id += B) {
+      uint32_t k = __hip_atomic_load(keys + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, d = 255;
+      for (; d > 0; d--) {
+        if (acc + hist[d] >= need) break;
+        acc += hist[d];
+      }
+      sh_digit = d;
+      sh_need  = need - acc;
+    }
+    __syncthreads();
+    prefix |= (uint32_t)sh_digit << shift;
+    prefix_mask |= 255u << shift;
+    need = sh_need;
+    __syncthreads();
+  }
+  // prefix == the M-th largest key; take every key > prefix and the first `need` keys == prefix.
+  const uint32_t thr = prefix;
+  int out_run = 0, tie_run = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int chunk = 0; chunk < N; chunk += B) {
+    int id     = chunk + threadIdx.x;
+    uint32_t k = id < N ? __hip_atomic_load(keys + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    bool gt    = id < N && k > thr;
+    bool eq    = id < N && k == thr;
+    uint64_t meq = __ballot(eq);
+    int eq_before_in_wave = __popcll(meq & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[1][wave] = __popcll(meq);
+    __syncthreads();
+    int eq_before = tie_run + eq_before_in_wave, eq_total = 0;
+    for (int w = 0; w < B / 64; w++) {
+      if (w < wave) eq_before += wave_cnt[1][w];
+      eq_total += wave_cnt[1][w];
+    }
+    bool take      = gt || (eq && eq_before < need);
+    uint64_t mtake = __ballot(take);
+    int before_in_wave = __popcll(mtake & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[0][wave] = __popcll(mtake);
+    __syncthreads();
+    int before = out_run + before_in_wave, total = 0;
+    for (int w = 0; w < B / 64; w++) {
+      if (w < wave) before += wave_cnt[0][w];
+      total += wave_cnt[0][w];
+    }
+    if (take) emit<ColT>(dst, src_lid, edge_gid, base + before, col[start + id], i, start + id);
+    out_run += total;
+    tie_run += eq_total;
+    __syncthreads();
+  }
+}
+
+template <typename SeedT, typename ColT>
+void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds, dev_count n, int M,
+                    uint64_t random_seed, const int* offsets, ColT* dst, int* lid, int64_t* gid, hipStream_t stream)
+{
+  const int cap = n.host;
+  if (cap <= 0) return;
+  if (M <= 0) {
+    // sample-all: every row is copied whole (rows can be long -> workgroup copy path)
+    sample_uniform_block_kernel<SeedT, ColT><<<cap, 64, 0, stream>>>(row_ptr, col, seeds, n, 0x7fffffff, 32, 1,
+                                                                     random_seed, offsets, dst, lid, gid);
+  } else if (M <= 32) {
+    sample_uniform_halfwave_kernel<SeedT, ColT><<<ceil_div((int64_t)cap * 32, 256), 256, 0, stream>>>(
+      row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid);
+  } else if (M <= 1024) {
+    const int B = ref_block_threads(M);
+    sample_uniform_block_kernel<SeedT, ColT><<<cap, B < 64 ? 64 : B, 0, stream>>>(
+      row_ptr, col, seeds, n, M, B, ref_items_per_thread(M), random_seed, offsets, dst, lid, gid);
+  } else {
+    sample_uniform_reservoir_kernel<SeedT, ColT><<<cap, 64, 0, stream>>>(row_ptr, col, seeds, n, M, random_seed,
+                                                                         offsets, dst, lid, gid);
+  }
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+struct sample_args {
+  wholememory_tensor_t row_ptr, col, weight, seeds, out_offsets;
+  int M;
+  void *dst_ctx, *lid_ctx, *gid_ctx;
+  uint64_t random_seed;
+  wholememory_env_func_t* env;
+  hipStream_t stream;
+};
+
+void validate(const sample_args& a, bool weighted)
+{
+  WG_REQUIRE_INPUT(a.row_ptr && a.col && a.seeds && a.out_offsets && a.env, "null tensor / env");
+  WG_REQUIRE_INPUT(a.dst_ctx != nullptr, "output_dest_memory_context must not be NULL");
+  auto rd = a.row_ptr->desc, cd = a.col->desc, sd = a.seeds->desc, od = a.out_offsets->desc;
+  WG_REQUIRE_INPUT(rd.dim == 1 && cd.dim == 1 && sd.dim == 1 && od.dim == 1, "all tensors must be 1-D");
+  WG_REQUIRE_INPUT(!a.row_ptr->handle && !a.col->handle,
+                   "CSR tensors must wrap device pointers (the CSR is replicated per GPU; DESIGN.md §multi-GPU)");
+  WG_EXPECTS(rd.dtype == WHOLEMEMORY_DT_INT64, "csr_row_ptr dtype must be INT64, got %d", (int)rd.dtype);
+  WG_EXPECTS(od.dtype == WHOLEMEMORY_DT_INT, "output_sample_offset dtype must be INT, got %d", (int)od.dtype);
+  WG_REQUIRE_INPUT(cd.dtype == WHOLEMEMORY_DT_INT || cd.dtype == WHOLEMEMORY_DT_INT64, "csr_col dtype must be INT|INT64");
+  WG_REQUIRE_INPUT(sd.dtype == WHOLEMEMORY_DT_INT || sd.dtype == WHOLEMEMORY_DT_INT64, "center_nodes dtype must be INT|INT64");
+  WG_REQUIRE_INPUT(od.sizes[0] == sd.sizes[0] + 1, "output_sample_offset must have center_node_count+1 entries");
+  WG_REQUIRE_INPUT(sd.sizes[0] < (int64_t)1 << 31, "too many center nodes");
+  if (weighted) {
+    WG_REQUIRE_INPUT(a.weight && !a.weight->handle && a.weight->desc.dim == 1, "csr_weight must be a 1-D device tensor");
+    WG_REQUIRE_INPUT(a.weight->desc.dtype == WHOLEMEMORY_DT_FLOAT || a.weight->desc.dtype == WHOLEMEMORY_DT_DOUBLE,
+                     "csr_weight dtype must be FLOAT|DOUBLE");
+    WG_REQUIRE_INPUT(a.weight->desc.sizes[0] == cd.sizes[0], "csr_weight and csr_col sizes differ");
+  }
+}
+
+template <typename SeedT, typename ColT, typename WeightT>
+void run(const sample_args& a, bool weighted)
+{
+  const int n            = (int)a.seeds->desc.sizes[0];
+  const int M            = a.M;
+  hipStream_t stream     = a.stream;
+  const auto* row_ptr    = static_cast<const int64_t*>(tensor_data(a.row_ptr));
+  const auto* col        = static_cast<const ColT*>(tensor_data(a.col));
+  const auto* seeds      = static_cast<const SeedT*>(tensor_data(a.seeds));
+  int* offsets           = static_cast<int*>(tensor_data(a.out_offsets));
+  const WeightT* weights = weighted ? static_cast<const WeightT*>(tensor_data(a.weight)) : nullptr;
+
+  temp_buffer cnt_buf(a.env), scan_tmp(a.env), big_buf(a.env);
+  int* cnt     = cnt_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT);
+  int* stmp    = scan_tmp.device<int>(scan_tmp_ints(n + 1), WHOLEMEMORY_DT_INT);
+  int* big_deg = (weighted && M > 0) ? big_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT) : nullptr;
+  int h_tot[2] = {0, 0};
+
+  sample_count_enqueue(row_ptr, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M, cnt, big_deg, stream);
+  exclusive_scan_i32(cnt, offsets, n, stmp, stream);
+  WG_HIP_CHECK(hipMemcpyAsync(&h_tot[0], offsets + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+  if (big_deg) {
+    exclusive_scan_i32(big_deg, big_deg, n, stmp, stream);
+    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[1], big_deg + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+  }
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // the one unavoidable sync: output sizes
+  const int total = h_tot[0];
+
+  auto* dst = static_cast<ColT*>(output_alloc(a.env, a.dst_ctx, total, dtype_of<ColT>::value));
+  int* lid  = a.lid_ctx ? static_cast<int*>(output_alloc(a.env, a.lid_ctx, total, WHOLEMEMORY_DT_INT)) : nullptr;
+  auto* gid = a.gid_ctx ? static_cast<int64_t*>(output_alloc(a.env, a.gid_ctx, total, WHOLEMEMORY_DT_INT64)) : nullptr;
+  if (n == 0 || total == 0) return;
+
+  if (weighted) {
+    temp_buffer key_buf(a.env);
+    uint32_t* keys = key_buf.device<uint32_t>(h_tot[1], WHOLEMEMORY_DT_INT);
+    if (M > 256) {
+      sample_weighted_kernel<SeedT, ColT, WeightT, 256><<<n, 256, 0, stream>>>(
+        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid);
+    } else {
+      sample_weighted_kernel<SeedT, ColT, WeightT, 128><<<n, 128, 0, stream>>>(
+        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid);
+    }
+    WG_HIP_CHECK(hipGetLastError());
+    WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
+    return;
+  }
+  uniform_sample_enqueue(row_ptr, col, sizeof(ColT) == 8, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M,
+                         a.random_seed, offsets, dst, lid, gid, stream);
+  WG_HIP_CHECK(hipGetLastError());
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // outputs complete on return (reference contract)
+}
+
+template <typename WeightT>
+void dispatch(const sample_args& a, bool weighted)
+{
+  const bool s64 = a.seeds->desc.dtype == WHOLEMEMORY_DT_INT64;
+  const bool c64 = a.col->desc.dtype == WHOLEMEMORY_DT_INT64;
+  if (s64 && c64) return run<int64_t, int64_t, WeightT>(a, weighted);
+  if (s64 && !c64) return run<int64_t, int32_t, WeightT>(a, weighted);
+  if (!s64 && c64) return run<int32_t, int64_t, WeightT>(a, weighted);
+  return run<int32_t, int32_t, WeightT>(a, weighted);
+}
+
+}  // namespace
+
+void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
+                          int* big_deg, hipStream_t stream)
+{
+  if (n.host <= 0) return;
+  if (seeds64)
+    sample_count_kernel<int64_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
+      row_ptr, static_cast<const int64_t*>(seeds), n, M, cnt, big_deg);
+  else
+    sample_count_kernel<int32_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
+      row_ptr, static_cast<const int32_t*>(seeds), n, M, cnt, big_deg);
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
+                            dev_count n, int M, uint64_t random_seed, const int* offsets, void* dst, int* src_lid,
+                            int64_t* edge_gid, hipStream_t stream)
+{
+#define WG_U(ST, CT)                                                                                               \
+  uniform_launch<ST, CT>(row_ptr, static_cast<const CT*>(col), static_cast<const ST*>(seeds), n, M, random_seed, \
+                         offsets, static_cast<CT*>(dst), src_lid, edge_gid, stream)
+  if (seeds64 && col64) WG_U(int64_t, int64_t);
+  else if (seeds64) WG_U(int64_t, int32_t);
+  else if (col64) WG_U(int32_t, int64_t);
+  else WG_U(int32_t, int32_t);
+#undef WG_U
+}
+
+}  // namespace wgamd
+
+extern "C" {
+
+wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t center_nodes_tensor, int max_sample_count,
+  wholememory_tensor_t output_sample_offset_tensor, void* output_dest_memory_context,
+  void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
+  unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream)
+{
+  return wgamd::guarded("wholegraph_csr_unweighted_sample_without_replacement", [&] {
+    wgamd::sample_args a{wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, nullptr, center_nodes_tensor,
+                         output_sample_offset_tensor, max_sample_count, output_dest_memory_context,
+                         output_center_localid_memory_context, output_edge_gid_memory_context,
+                         (uint64_t)random_seed, p_env_fns, static_cast<hipStream_t>(stream)};
+    wgamd::validate(a, false);
+    wgamd::dispatch<float>(a, false);
+  });
+}
+
+wholememory_error_code_t wholegraph_csr_weighted_sample_without_replacement(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t wm_csr_weight_ptr_tensor, wholememory_tensor_t center_nodes_tensor,
+  int max_sample_count, wholememory_tensor_t output_sample_offset_tensor,
+  void* output_dest_memory_context, void* output_center_localid_memory_context,
+  void* output_edge_gid_memory_context, unsigned long long random_seed,
+  wholememory_env_func_t* p_env_fns, void* stream)
+{
+  return wgamd::guarded("wholegraph_csr_weighted_sample_without_replacement", [&] {
+    wgamd::sample_args a{wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, wm_csr_weight_ptr_tensor,
+                         center_nodes_tensor, output_sample_offset_tensor, max_sample_count,
+                         output_dest_memory_context, output_center_localid_memory_context,
+                         output_edge_gid_memory_context, (uint64_t)random_seed, p_env_fns,
+                         static_cast<hipStream_t>(stream)};
+    wgamd::validate(a, true);
+    if (a.weight->desc.dtype == WHOLEMEMORY_DT_DOUBLE)
+      wgamd::dispatch<double>(a, true);
+    else
+      wgamd::dispatch<float>(a, true);
+  });
+}
+
+wholememory_error_code_t generate_random_positive_int_cpu(int64_t random_seed, int64_t subsequence,
+                                                          wholememory_tensor_t output)
+{
+  if (output == nullptr || output->desc.dim != 1) {
+    fprintf(stderr, "[wholegraph_amd] generate_random_positive_int_cpu: output should be 1D tensor.\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (output->desc.dtype != WHOLEMEMORY_DT_INT && output->desc.dtype != WHOLEMEMORY_DT_INT64) {
+    fprintf(stderr, "[wholegraph_amd] generate_random_positive_int_cpu: output should be int64 or int32 tensor.\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  wgamd::Pcg32 g((uint64_t)random_seed, (uint64_t)subsequence);
+  void* p = wgamd::tensor_data(output);
+  for (int64_t k = 0; k < output->desc.sizes[0]; k++) {
+    if (output->desc.dtype == WHOLEMEMORY_DT_INT)
+      static_cast<int32_t*>(p)[k] = g.next_i31();
+    else
+      static_cast<int64_t*>(p)[k] = g.next_i63();
+  }
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t generate_exponential_distribution_negative_float_cpu(int64_t random_seed,
+                                                                              int64_t subsequence,
+                                                                              wholememory_tensor_t output)
+{
+  if (output == nullptr || output->desc.dim != 1) {
+    fprintf(stderr, "[wholegraph_amd] generate_exponential_distribution_negative_float_cpu: output should be 1D tensor.\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (output->desc.dtype != WHOLEMEMORY_DT_FLOAT) {
+    fprintf(stderr, "[wholegraph_amd] generate_exponential_distribution_negative_float_cpu: output should be float.\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  wgamd::Pcg32 g((uint64_t)random_seed, (uint64_t)subsequence);
+  float* p = static_cast<float*>(wgamd::tensor_data(output));
+  for (int64_t k = 0; k < output->desc.sizes[0]; k++) {
+    float u = g.next_f32();
+    u       = (float)(-(0.5 + 0.5 * (double)u));
+    uint64_t x;
+    int zero_draws = -1;
+    do {
+      x = g.next_u64();
+      zero_draws++;
+    } while (!x);
+    int lz = 0;
+    for (uint64_t probe = x; !(probe >> 63); probe <<= 1) lz++;
+    u    = (float)((double)u * std::pow(2.0, -(lz + zero_draws * 64)));
+    p[k] = (float)(std::log1p((double)u) / std::log(2.0));
+  }
+  return WHOLEMEMORY_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// int32 exclusive scan over up to 2^31 elements, wave64-native.
+//   n <= TILE        : one launch (single workgroup).
+//   otherwise        : tile sums -> single-workgroup scan of the sums -> tile rescans (3 launches).
+// Used for sample offsets (role of thrust::exclusive_scan in
+// /root/reference/cpp/src/wholegraph_ops/unweighted_sample_without_replacement_func.cuh:323-326)
+// and for the first-appearance ranks of append_unique.
+#include "wg_common.hpp"
+
+namespace wgamd {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems   = 8;
+constexpr int kTile    = kThreads * kItems;  // 2048 ints = 8 KiB per workgroup
+
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int up = __shfl_up(v, d, 64);
+    if (lane >= d) v += up;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over the workgroup; returns exclusive prefix, total in *total
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total)
+{
+  __shared__ int wave_sums[kThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = wave_inclusive_scan(v);
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  int wave_off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    int s = wave_sums[w];
+    if (w < wave) wave_off += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return wave_off + inc - v;
+}
+
+// Thread t owns items [t*kItems, (t+1)*kItems) of the tile (blocked arrangement: each lane reads
+// 32 contiguous bytes -> two dwordx4 loads).
+__device__ __forceinline__ void load_tile(const int* in, int64_t base, int64_t n, int (&x)[kItems])
+{
+  int64_t p = base + (int64_t)threadIdx.x * kItems;
+  if (p + kItems <= n && ((reinterpret_cast<uintptr_t>(in + p) & 15) == 0)) {
+    const int4* v = reinterpret_cast<const int4*>(in + p);
+    int4 a = v[0], b = v[1];
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+    x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kItems; k++) x[k] = (p + k < n) ? in[p + k] : 0;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) scan_single_kernel(const int* in, int* out, int64_t n)
+{
+  int x[kItems];
+  load_tile(in, 0, n, x);
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) s += x[k];
+  int total;
+  int run = block_exclusive_scan(s, &total);
+  int64_t p = (int64_t)threadIdx.x * kItems;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    if (p + k < n) out[p + k] = run;
+    run += x[k];
+  }
+  if (threadIdx.x == 0) out[n] = total;
+}
+
+__global__ void __launch_bounds__(kThreads) scan_tile_sums_kernel(const int* in, int64_t n, int* sums)
+{
+  int x[kItems];
+  load_tile(in, (int64_t)blockIdx.x * kTile, n, x);
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) s += x[k];
+  int total;
+  (void)block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// exclusive scan of sums[0..m) in place, sums[m] = grand total
+__global__ void __launch_bounds__(kThreads) scan_sums_kernel(int* sums, int64_t m)
+{
+  int carry = 0;
+  for (int64_t base = 0; base < m; base += kThreads) {
+    int64_t i = base + threadIdx.x;
+    int v     = i < m ? sums[i] : 0;
+    int total;
+    int ex = block_exclusive_scan(v, &total);
+    if (i < m) sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) sums[m] = carry;
+}
+
+__global__ void __launch_bounds__(kThreads)
+scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int64_t m)
+{
+  int x[kItems];
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  load_tile(in, base, n, x);
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) s += x[k];
+  int total;
+  int run   = block_exclusive_scan(s, &total) + sums[blockIdx.x];
+  int64_t p = base + (int64_t)threadIdx.x * kItems;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    if (p + k < n) out[p + k] = run;
+    run += x[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[m];
+}
+
+}  // namespace
+
+int64_t scan_tmp_ints(int64_t n) { return (n + kTile - 1) / kTile + 2; }
+
+void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream)
+{
+  if (n <= kTile) {
+    scan_single_kernel<<<1, kThreads, 0, stream>>>(in, out, n);
+  } else {
+    int64_t m = (n + kTile - 1) / kTile;
+    scan_tile_sums_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, n, tmp);
+    scan_sums_kernel<<<1, kThreads, 0, stream>>>(tmp, m);
+    // in-place is safe: every tile reads its inputs into registers before writing them back,
+    // and out[n] is written from tmp, not from `in`.
+    scan_tile_final_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, out, n, tmp, m);
+  }
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace wgamd

@@ -1,0 +1,15 @@
+"""wholegraph_amd — MI355X-native mirror of ``pylibwholegraph.torch`` for the mini-batch hot path.
+
+Public surface (same names as /root/reference/python/pylibwholegraph/pylibwholegraph/torch/__init__.py
+for the files SURVEY.md §8 puts on the path): ``GraphStructure``, ``WholeMemoryTensor``,
+``create_wholememory_tensor``, ``wholegraph_ops``, ``graph_ops``; plus ``nn`` (SAGEConv / GATConv over the
+sampler CSR) and ``fused`` (no-host-sync walk), which have no reference counterpart.
+
+Everything computes through ``lib/libwholegraph_amd.so`` (HIP, gfx950); a missing library raises
+``WholeGraphLibraryError`` — there is no CPU fallback.
+"""
+from . import _lib, dist, env, fused, graph_ops, nn, wholegraph_ops  # noqa: F401
+from ._lib import WholeGraphLibraryError, WholeMemoryError  # noqa: F401
+from .graph_structure import GraphStructure  # noqa: F401
+from .tensor import (WholeMemoryTensor, create_wholememory_tensor,  # noqa: F401
+                     equal_entry_partition)

@@ -1,0 +1,164 @@
+"""ctypes view of ``libwholegraph_amd.so`` — the C-ABI boundary declared in ``include/*.h``.
+
+This is the role of the reference's Cython module
+(/root/reference/python/pylibwholegraph/pylibwholegraph/binding/wholememory_binding.pyx:1-262):
+declare the C structs/enums, load the shared library, turn return codes into exceptions.
+There is NO fallback: if the HIP library is missing every op raises ``WholeGraphLibraryError``.
+"""
+import ctypes
+import os
+from ctypes import (CFUNCTYPE, POINTER, Structure, c_bool, c_float, c_int, c_int64, c_size_t,
+                    c_ulonglong, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libwholegraph_amd.so"))
+
+WHOLEMEMORY_MAX_TENSOR_DIM = 8
+
+# wholememory_error_code_t (include/wgamd_types.h)
+(WHOLEMEMORY_SUCCESS, WHOLEMEMORY_UNKNOW_ERROR, WHOLEMEMORY_NOT_IMPLEMENTED, WHOLEMEMORY_LOGIC_ERROR,
+ WHOLEMEMORY_CUDA_ERROR, WHOLEMEMORY_COMMUNICATION_ERROR, WHOLEMEMORY_INVALID_INPUT,
+ WHOLEMEMORY_INVALID_VALUE, WHOLEMEMORY_OUT_OF_MEMORY, WHOLEMEMORY_NOT_SUPPORTED,
+ WHOLEMEMORY_SYSTEM_ERROR) = range(11)
+
+_ERROR_NAMES = ["SUCCESS", "UNKNOW_ERROR", "NOT_IMPLEMENTED", "LOGIC_ERROR", "CUDA_ERROR",
+                "COMMUNICATION_ERROR", "INVALID_INPUT", "INVALID_VALUE", "OUT_OF_MEMORY",
+                "NOT_SUPPORTED", "SYSTEM_ERROR"]
+
+# wholememory_dtype_t
+(DT_UNKNOWN, DT_FLOAT, DT_HALF, DT_DOUBLE, DT_BF16, DT_INT, DT_INT64, DT_INT16, DT_INT8,
+ DT_COUNT) = range(10)
+
+# wholememory_memory_allocation_type_t
+MA_NONE, MA_DEVICE, MA_HOST, MA_PINNED = range(4)
+
+
+class WholeGraphLibraryError(RuntimeError):
+    pass
+
+
+class WholeMemoryError(RuntimeError):
+    """Raised for a non-SUCCESS return code; mirrors check_wholememory_error_code
+    (binding .pyx:241-262), which maps codes to Python exceptions."""
+
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what} failed: WHOLEMEMORY_{_ERROR_NAMES[code] if 0 <= code < 11 else code}")
+
+
+class TensorDescription(Structure):
+    _fields_ = [("sizes", c_int64 * WHOLEMEMORY_MAX_TENSOR_DIM),
+                ("strides", c_int64 * WHOLEMEMORY_MAX_TENSOR_DIM),
+                ("storage_offset", c_int64),
+                ("dim", c_int),
+                ("dtype", c_int)]
+
+
+CREATE_CTX_FN = CFUNCTYPE(None, POINTER(c_void_p), c_void_p)
+DESTROY_CTX_FN = CFUNCTYPE(None, c_void_p, c_void_p)
+MALLOC_FN = CFUNCTYPE(c_void_p, POINTER(TensorDescription), c_int, c_void_p, c_void_p)
+FREE_FN = CFUNCTYPE(None, c_void_p, c_void_p)
+
+
+class TempMemoryFns(Structure):
+    _fields_ = [("create_memory_context_fn", CREATE_CTX_FN),
+                ("destroy_memory_context_fn", DESTROY_CTX_FN),
+                ("malloc_fn", MALLOC_FN),
+                ("free_fn", FREE_FN),
+                ("global_context", c_void_p)]
+
+
+class OutputMemoryFns(Structure):
+    _fields_ = [("malloc_fn", MALLOC_FN),
+                ("free_fn", FREE_FN),
+                ("global_context", c_void_p)]
+
+
+class EnvFns(Structure):
+    _fields_ = [("temporary_fns", TempMemoryFns), ("output_fns", OutputMemoryFns)]
+
+
+# every symbol include/*.h declares: name -> (restype, argtypes)
+_T = c_void_p  # wholememory_tensor_t
+SYMBOLS = {
+    # wgamd_types.h
+    "wholememory_dtype_get_element_size": (c_size_t, [c_int]),
+    "wholememory_dtype_is_floating_number": (c_bool, [c_int]),
+    "wholememory_dtype_is_integer_number": (c_bool, [c_int]),
+    "wholememory_create_array_desc": None,
+    "wholememory_create_matrix_desc": None,
+    "wholememory_initialize_tensor_desc": (None, [POINTER(TensorDescription)]),
+    "wholememory_copy_array_desc_to_matrix": None,
+    "wholememory_copy_array_desc_to_tensor": None,
+    "wholememory_copy_matrix_desc_to_tensor": None,
+    "wholememory_convert_tensor_desc_to_array": None,
+    "wholememory_convert_tensor_desc_to_matrix": None,
+    "wholememory_get_memory_element_count_from_array": None,
+    "wholememory_get_memory_size_from_array": None,
+    "wholememory_get_memory_element_count_from_matrix": None,
+    "wholememory_get_memory_size_from_matrix": None,
+    "wholememory_get_memory_element_count_from_tensor": (c_int64, [POINTER(TensorDescription)]),
+    "wholememory_get_memory_size_from_tensor": (c_int64, [POINTER(TensorDescription)]),
+    "wholememory_squeeze_tensor": (c_bool, [POINTER(TensorDescription), c_int]),
+    "wholememory_unsqueeze_tensor": (c_bool, [POINTER(TensorDescription), c_int]),
+    "wholememory_get_default_env_func": (POINTER(EnvFns), []),
+    "wgamd_create_default_memory_context": (c_void_p, []),
+    "wgamd_destroy_default_memory_context": (None, [c_void_p]),
+    # wgamd_tensor.h
+    "wholememory_make_tensor_from_pointer": (c_int, [POINTER(_T), c_void_p, POINTER(TensorDescription)]),
+    "wholememory_destroy_tensor": (c_int, [_T]),
+    "wholememory_tensor_has_handle": (c_bool, [_T]),
+    "wholememory_tensor_get_memory_handle": (c_void_p, [_T]),
+    "wholememory_tensor_get_tensor_description": (POINTER(TensorDescription), [_T]),
+    "wholememory_tensor_get_data_pointer": (c_void_p, [_T]),
+    "wholememory_tensor_get_subtensor": (c_int, [_T, POINTER(c_int64), POINTER(c_int64), POINTER(_T)]),
+    "wholememory_tensor_get_root": (_T, [_T]),
+    "get_wholememory_tensor_count": (c_int64, []),
+    # wgamd_ops.h
+    "wholegraph_csr_unweighted_sample_without_replacement":
+        (c_int, [_T, _T, _T, c_int, _T, c_void_p, c_void_p, c_void_p, c_ulonglong, POINTER(EnvFns), c_void_p]),
+    "wholegraph_csr_weighted_sample_without_replacement":
+        (c_int, [_T, _T, _T, _T, c_int, _T, c_void_p, c_void_p, c_void_p, c_ulonglong, POINTER(EnvFns), c_void_p]),
+    "generate_random_positive_int_cpu": (c_int, [c_int64, c_int64, _T]),
+    "generate_exponential_distribution_negative_float_cpu": (c_int, [c_int64, c_int64, _T]),
+    "graph_append_unique": (c_int, [_T, _T, c_void_p, _T, POINTER(EnvFns), c_void_p]),
+    "csr_add_self_loop": (c_int, [_T, _T, _T, _T, c_void_p]),
+    "wholememory_gather": (c_int, [_T, _T, _T, POINTER(EnvFns), c_void_p, c_int]),
+    "wholememory_scatter": (c_int, [_T, _T, _T, POINTER(EnvFns), c_void_p, c_int]),
+    # wgamd_ext.h
+    "wgamd_spmm_csr_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
+                                   c_int, c_void_p, c_int64, c_void_p]),
+    "wgamd_spmm_csr_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                       c_int64, c_void_p]),
+    "wgamd_gat_csr_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                  c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wgamd_sample_hop_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "wgamd_sample_hop_nosync": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
+                                        c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library (loaded once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WholeGraphLibraryError(
+                f"{LIB_PATH} not found: build the HIP library first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C cugraph-gnn_amd/csrc). "
+                "There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, sig in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError == a declared symbol is not exported
+            if sig is not None:
+                fn.restype, fn.argtypes = sig
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != WHOLEMEMORY_SUCCESS:
+        raise WholeMemoryError(code, what)

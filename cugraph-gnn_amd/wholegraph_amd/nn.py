@@ -1,0 +1,191 @@
+"""GraphSAGE / GAT mini-batch aggregation on the sampler's per-hop CSR (HIP kernels of
+``include/wgamd_ext.h``), packaged as the conv layers the reference's models instantiate.
+
+The reference has no aggregation kernel: ``HomoGNNModel`` builds ``torch_geometric.nn.SAGEConv`` /
+``GATConv`` and feeds them ``(x, x_target)`` plus the hop's ``[csr_row_ptr, csr_col_ind]`` or COO
+(/root/reference/python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59,119-125,178-199).
+``SAGEConv`` / ``GATConv`` below keep PyG's parameter names (``lin_l``, ``lin_r``, ``lin``,
+``att_src``, ``att_dst``, ``bias``) and maths so they are a drop-in for that call shape; the
+segmented reduce / edge softmax run in hand-written gfx950 kernels, the dense ``lin_*`` tail is a
+plain ``torch.nn.functional.linear`` (hipBLASLt, MFMA).
+"""
+import math
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .env import get_stream, torch_dtype_to_wm
+
+
+def _check_csr(row_ptr, col):
+    assert row_ptr.dtype == torch.int32 and col.dtype == torch.int32, "per-hop CSR is int32 (sampler output)"
+    assert row_ptr.is_cuda and col.is_cuda and row_ptr.is_contiguous() and col.is_contiguous()
+
+
+def spmm_csr_forward(row_ptr, col, x, mean=True, src_ids=None, out=None):
+    """out[i] = mean/sum_{e in row i} x[src(e)], src(e) = col[e] or src_ids[col[e]] (fused fetch)."""
+    _check_csr(row_ptr, col)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    n_rows = row_ptr.shape[0] - 1
+    if out is None:
+        out = torch.empty((n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
+    ids_ptr, ids_dt = None, 0
+    if src_ids is not None:
+        assert src_ids.is_contiguous()
+        ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
+    L.check(L.lib().wgamd_spmm_csr_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0),
+                                       x.shape[1], ids_ptr, ids_dt, int(bool(mean)), out.data_ptr(),
+                                       out.stride(0), get_stream()), "wgamd_spmm_csr_f32")
+    return out
+
+
+class _SpmmCsr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, row_ptr, col, mean):
+        ctx.save_for_backward(row_ptr, col)
+        ctx.mean, ctx.n_src = mean, x.shape[0]
+        return spmm_csr_forward(row_ptr, col, x.contiguous(), mean)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        row_ptr, col = ctx.saved_tensors
+        g = grad_out.contiguous()
+        gx = torch.zeros((ctx.n_src, g.shape[1]), dtype=torch.float32, device=g.device)
+        L.check(L.lib().wgamd_spmm_csr_bwd_f32(row_ptr.data_ptr(), col.data_ptr(), row_ptr.shape[0] - 1,
+                                               g.data_ptr(), g.stride(0), g.shape[1], int(bool(ctx.mean)),
+                                               gx.data_ptr(), gx.stride(0), get_stream()),
+                "wgamd_spmm_csr_bwd_f32")
+        return gx, None, None, None
+
+
+def spmm_csr(x, row_ptr, col, reduce: str = "mean"):
+    """Differentiable segmented mean/sum aggregation over a destination-major CSR."""
+    assert reduce in ("mean", "sum", "add")
+    return _SpmmCsr.apply(x, row_ptr, col, reduce == "mean")
+
+
+def gat_forward(row_ptr, col, x, a_src, a_dst, heads, negative_slope=0.2, need_alpha=True):
+    """Edge softmax + weighted aggregation.  x [N_src, H*C], a_src [N_src, H], a_dst [n_rows, H]."""
+    _check_csr(row_ptr, col)
+    n_rows = row_ptr.shape[0] - 1
+    HC = x.shape[1]
+    C = HC // heads
+    out = torch.empty((n_rows, HC), dtype=torch.float32, device=x.device)
+    alpha = torch.empty((col.shape[0], heads), dtype=torch.float32, device=x.device) if need_alpha else None
+    L.check(L.lib().wgamd_gat_csr_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0),
+                                      a_src.data_ptr(), a_dst.data_ptr(), heads, C, float(negative_slope),
+                                      alpha.data_ptr() if need_alpha else None, out.data_ptr(), out.stride(0),
+                                      get_stream()), "wgamd_gat_csr_f32")
+    return out, alpha
+
+
+class _GatCsr(torch.autograd.Function):
+    """Forward: fused HIP kernel.  Backward: edge-wise torch ops on the saved attention (the
+    training-time gradient path is not on the north-star hot path)."""
+
+    @staticmethod
+    def forward(ctx, x, a_src, a_dst, row_ptr, col, heads, slope):
+        x, a_src, a_dst = x.contiguous(), a_src.contiguous(), a_dst.contiguous()
+        out, alpha = gat_forward(row_ptr, col, x, a_src, a_dst, heads, slope, need_alpha=True)
+        ctx.save_for_backward(x, a_src, a_dst, row_ptr, col, alpha)
+        ctx.heads, ctx.slope = heads, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a_src, a_dst, row_ptr, col, alpha = ctx.saved_tensors
+        H = ctx.heads
+        C = x.shape[1] // H
+        n_rows = row_ptr.shape[0] - 1
+        deg = (row_ptr[1:] - row_ptr[:-1]).long()
+        dst = torch.repeat_interleave(torch.arange(n_rows, device=x.device), deg)
+        src = col.long()
+        g3 = g.reshape(n_rows, H, C)[dst]                      # [E,H,C]
+        x3 = x.reshape(-1, H, C)[src]                          # [E,H,C]
+        gx = torch.zeros_like(x).reshape(-1, H, C).index_add_(0, src, alpha.unsqueeze(-1) * g3)
+        dalpha = (g3 * x3).sum(-1)                             # [E,H]
+        dot = torch.zeros((n_rows, H), device=x.device).index_add_(0, dst, alpha * dalpha)
+        ds = alpha * (dalpha - dot[dst])
+        s = a_src[src] + a_dst[dst]
+        ds = torch.where(s > 0, ds, ds * ctx.slope)
+        ga_src = torch.zeros_like(a_src).index_add_(0, src, ds)
+        ga_dst = torch.zeros_like(a_dst).index_add_(0, dst, ds)
+        return gx.reshape(x.shape), ga_src, ga_dst, None, None, None, None
+
+
+def _to_csr(edge_index, n_dst):
+    """edge_index [2,E] (row 0 = source j, row 1 = destination i; PyG) -> destination-major CSR."""
+    dst = edge_index[1]
+    order = torch.sort(dst, stable=True).indices
+    col = edge_index[0][order].to(torch.int32).contiguous()
+    counts = torch.bincount(dst, minlength=n_dst)
+    row_ptr = torch.zeros(n_dst + 1, dtype=torch.int32, device=dst.device)
+    row_ptr[1:] = torch.cumsum(counts, 0)
+    return row_ptr, col
+
+
+def _split_graph(graph, n_dst):
+    if isinstance(graph, (tuple, list)) and len(graph) == 2 and graph[0].dim() == 1:
+        return graph[0], graph[1]          # [csr_row_ptr, csr_col_ind] as the sampler emits them
+    return _to_csr(graph, n_dst)           # COO edge_index
+
+
+class SAGEConv(torch.nn.Module):
+    """``out = lin_l(mean_{j in N(i)} x_j) + lin_r(x_i)`` (PyG ``SAGEConv``, aggr mean|sum)."""
+
+    def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int, aggr: str = "mean",
+                 root_weight: bool = True, bias: bool = True):
+        super().__init__()
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        self.in_channels, self.out_channels, self.aggr, self.root_weight = in_channels, out_channels, aggr, root_weight
+        self.lin_l = torch.nn.Linear(in_channels[0], out_channels, bias=bias)
+        self.lin_r = torch.nn.Linear(in_channels[1], out_channels, bias=False) if root_weight else None
+
+    def forward(self, x, graph):
+        x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
+        row_ptr, col = _split_graph(graph, x_dst.shape[0])
+        out = self.lin_l(spmm_csr(x_src, row_ptr, col, self.aggr))
+        if self.lin_r is not None:
+            out = out + self.lin_r(x_dst[: out.shape[0]])
+        return out
+
+
+class GATConv(torch.nn.Module):
+    """PyG ``GATConv`` (shared ``lin``, ``att_src``/``att_dst``, LeakyReLU 0.2, per-destination
+    softmax, concat or mean over heads, optional self loops)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 negative_slope: float = 0.2, add_self_loops: bool = True, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.add_self_loops = concat, negative_slope, add_self_loops
+        self.lin = torch.nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = torch.nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = torch.nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels)) if bias else None
+        bound = math.sqrt(6.0 / (heads + out_channels))
+        torch.nn.init.uniform_(self.att_src, -bound, bound)
+        torch.nn.init.uniform_(self.att_dst, -bound, bound)
+
+    def forward(self, x, graph):
+        from . import graph_ops
+        x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
+        H, C = self.heads, self.out_channels
+        n_dst = x_dst.shape[0]
+        row_ptr, col = _split_graph(graph, n_dst)
+        if self.add_self_loops:
+            # destinations are the first n_dst sources (sampler layout), so "self" = own row index
+            row_ptr, col = graph_ops.add_csr_self_loop(row_ptr, col)
+        h_src = self.lin(x_src)
+        h_dst = h_src[:n_dst] if x_dst is x_src or x_dst.data_ptr() == x_src.data_ptr() else self.lin(x_dst)
+        a_src = (h_src.view(-1, H, C) * self.att_src).sum(-1)
+        a_dst = (h_dst.view(-1, H, C) * self.att_dst).sum(-1)
+        out = _GatCsr.apply(h_src, a_src, a_dst, row_ptr, col, H, self.negative_slope)
+        if not self.concat:
+            out = out.view(-1, H, C).mean(1)
+        if self.bias is not None:
+            out = out + self.bias
+        return out

@@ -1,0 +1,123 @@
+/*
+ * wgamd_ext.h — entry points that have NO counterpart in libwholegraph's C ABI.
+ *
+ * (1) Mini-batch aggregation.  The reference ships no SpMM/SDDMM kernel: its models call
+ *     torch_geometric.nn.SAGEConv / GATConv (third party; call sites
+ *     /root/reference/python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59,119-125,178-199).
+ *     These entry points are what a PyTorch-ROCm autograd.Function binds to get the same maths
+ *     (PyG formulas, fp32) from hand-written gfx950 kernels over the sampler's per-hop CSR
+ *     (row_ptr = sample offsets, col = raw_to_unique mapping; graph_structure.py:186-195).
+ * (2) A no-host-sync variant of the sampling + renumbering walk for the loader's steady state:
+ *     same results as chaining the wgamd_ops.h ops, but every size stays on the device and
+ *     outputs go to caller-provided capacity buffers, so a whole multi-hop mini-batch is a
+ *     fixed sequence of launches (hipGraph-capturable) with no D2H round trip per op
+ *     (the reference pays >= 5 stream syncs per hop).
+ *
+ * Plain pointers and sizes only; all pointers are device pointers unless stated; `stream` is a
+ * hipStream_t passed as void*.  All calls are asynchronous on `stream`.
+ */
+#ifndef WGAMD_EXT_H_
+#define WGAMD_EXT_H_
+
+#include "wgamd_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) aggregation -------------------------------------------------------------------- */
+
+/* out[i, 0:F] = REDUCE_{e in [row_ptr[i], row_ptr[i+1])} x[src(e), 0:F]
+ *   src(e) = col[e]                      when src_ids == NULL
+ *          = src_ids[col[e]]             otherwise (fused feature fetch: x is then the global
+ *                                        feature table and src_ids the batch's local->global map;
+ *                                        src_ids_dtype = WHOLEMEMORY_DT_INT | WHOLEMEMORY_DT_INT64)
+ *   REDUCE = sum (mean == 0) or sum / max(deg_i, 1) (mean != 0).  fp32, summed in CSR order.
+ * row_ptr int32[n_rows+1], col int32[nnz]; ldx / ldo = row strides in elements. */
+wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr,
+                                            const int* col,
+                                            int64_t n_rows,
+                                            const float* x,
+                                            int64_t ldx,
+                                            int F,
+                                            const void* src_ids,
+                                            wholememory_dtype_t src_ids_dtype,
+                                            int mean,
+                                            float* out,
+                                            int64_t ldo,
+                                            void* stream);
+
+/* Backward of the above w.r.t. x (src_ids == NULL form):
+ *   grad_x[col[e], :] += grad_out[i, :] * (mean ? 1/max(deg_i,1) : 1)   for every edge e of row i.
+ * grad_x must be zero-initialised (or hold the gradient to accumulate into) by the caller. */
+wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr,
+                                                const int* col,
+                                                int64_t n_rows,
+                                                const float* grad_out,
+                                                int64_t ldg,
+                                                int F,
+                                                int mean,
+                                                float* grad_x,
+                                                int64_t ldx,
+                                                void* stream);
+
+/* GATConv message passing (edge-softmax SDDMM + weighted SpMM), H heads x C channels:
+ *   s_e      = leaky_relu(a_src[col[e], h] + a_dst[i, h], negative_slope)
+ *   alpha_e  = softmax over the edges e of row i (per head)
+ *   out[i,h,:] = sum_e alpha_e * x[col[e], h, :]
+ * x [N_src, H*C] (row stride ldx), a_src [N_src, H], a_dst [n_rows, H], out [n_rows, H*C]
+ * (row stride ldo), alpha_out nullable [nnz, H].  Rows without edges produce zeros. */
+wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr,
+                                           const int* col,
+                                           int64_t n_rows,
+                                           const float* x,
+                                           int64_t ldx,
+                                           const float* a_src,
+                                           const float* a_dst,
+                                           int H,
+                                           int C,
+                                           float negative_slope,
+                                           float* alpha_out,
+                                           float* out,
+                                           int64_t ldo,
+                                           void* stream);
+
+/* ---- (2) no-sync sampling walk ---------------------------------------------------------- */
+
+/* One hop of uniform sampling + renumbering with device-resident sizes.
+ *   in : targets (INT|INT64 = id_dtype)[<= target_cap], *n_targets_dev = how many are valid
+ *   out: offsets int32[target_cap+1]   exclusive scan of min(deg, M); entries past n_targets
+ *                                      repeat the total
+ *        neighbor_lid int32[edge_cap]  raw_to_unique mapping of every sampled edge (CSR col)
+ *        center_lid  int32[edge_cap]   row index of every sampled edge (nullable)
+ *        edge_gid    int64[edge_cap]   CSR position of every sampled edge (nullable)
+ *        unique      (id_dtype)[target_cap + edge_cap]  targets ++ new nodes (first appearance)
+ *        counts_dev  int32[2]          {n_edges, n_unique}
+ * edge_cap must be >= target_cap * M (M > 0 required).  Results are identical to
+ * wholegraph_csr_unweighted_sample_without_replacement followed by graph_append_unique.
+ * workspace: wgamd_sample_hop_workspace_bytes(target_cap, edge_cap, id_dtype) bytes. */
+size_t wgamd_sample_hop_workspace_bytes(int64_t target_cap, int64_t edge_cap, wholememory_dtype_t id_dtype);
+
+wholememory_error_code_t wgamd_sample_hop_nosync(const int64_t* csr_row_ptr,
+                                                 const void* csr_col,
+                                                 wholememory_dtype_t id_dtype,
+                                                 const void* targets,
+                                                 const int* n_targets_dev,
+                                                 int64_t target_cap,
+                                                 int max_sample_count,
+                                                 unsigned long long random_seed,
+                                                 int* offsets,
+                                                 int* neighbor_lid,
+                                                 int* center_lid,
+                                                 int64_t* edge_gid,
+                                                 int64_t edge_cap,
+                                                 void* unique,
+                                                 int* counts_dev,
+                                                 void* workspace,
+                                                 size_t workspace_bytes,
+                                                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGAMD_EXT_H_ */
