@@ -1,0 +1,300 @@
+#!/usr/bin/env python
+"""bench.py — sampled-edges/s of the mini-batch hot path on the ogbn-products-like workload.
+
+One "step" = one mini-batch of 1024 seeds through the whole hot path with everything resident in
+HBM:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->  feature gather
+x = feat[n_id] (fp32, F=100)  ->  2-layer GraphSAGE forward (mean SpMM in HIP + hipBLASLt lin_l/lin_r).
+`value` = sampled edges of all ranks / max-over-ranks wall time of exactly K steps.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0 with `roofline` (dominant HIP kernel, measured live with HIP
+events on the launch stream) and `cpu_baseline` (the C oracle, OpenMP over host cores, bounded sample).
+Synthetic data: RMAT (a=.57,b=.19,c=.19) symmetrised + dedup, V=2,449,029, ~123.7 M directed
+edges; features U(-1,1) fp32 [V,100]; random-init weights.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "cugraph-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+V_PRODUCTS = 2_449_029
+E_UNDIRECTED = 61_859_140
+FEAT_DIM = 100
+HIDDEN = 256
+CLASSES = 47
+BATCH = 1024
+FANOUT = [25, 10]
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
+
+
+def rmat_csr(n_nodes, n_undirected, seed, device, a=0.57, b=0.19, c=0.19):
+    """RMAT edges at scale ceil(log2 V), folded into [0,V), randomly relabelled, symmetrised,
+    deduplicated, returned as CSR (row_ptr int64, col int64) on `device`."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    scale = int(np.ceil(np.log2(n_nodes)))
+    src = torch.zeros(n_undirected, dtype=torch.int64, device=device)
+    dst = torch.zeros(n_undirected, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        u = torch.rand(n_undirected, generator=g, device=device)
+        sbit = (u >= a + b).to(torch.int64)
+        dbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)
+        src = (src << 1) | sbit
+        dst = (dst << 1) | dbit
+    perm = torch.randperm(1 << scale, generator=g, device=device)
+    src, dst = perm[src] % n_nodes, perm[dst] % n_nodes
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    keys = torch.cat([src * n_nodes + dst, dst * n_nodes + src])
+    del src, dst, perm
+    keys = torch.unique(keys)  # sorted => CSR order, duplicates dropped
+    rows = torch.div(keys, n_nodes, rounding_mode="floor")
+    col = (keys - rows * n_nodes).contiguous()
+    deg = torch.bincount(rows, minlength=n_nodes)
+    row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(deg, 0)
+    return row_ptr, col
+
+
+class SagePipeline:
+    """The measured hot path (one instance per rank)."""
+
+    def __init__(self, row_ptr, col, feat_table, device):
+        from wholegraph_amd import fused, nn
+        self.nn = nn
+        self.device = device
+        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, torch.int64)
+        self.feat = feat_table  # WholeMemoryTensor
+        g = torch.Generator(device=device).manual_seed(1)
+        self.conv1 = nn.SAGEConv(FEAT_DIM, HIDDEN).to(device)
+        self.conv2 = nn.SAGEConv(HIDDEN, CLASSES).to(device)
+        for p in list(self.conv1.parameters()) + list(self.conv2.parameters()):
+            p.data = (torch.rand(p.shape, generator=g, device=device) - 0.5) * 0.1
+            p.requires_grad_(False)
+        self.caps = self.walk.target_caps + [self.walk.target_caps[-1] + self.walk.edge_caps[-1]]
+        self.x = torch.zeros((self.caps[2], FEAT_DIM), dtype=torch.float32, device=device)
+        self.edges = torch.zeros((), dtype=torch.int64, device=device)
+        self.distributed = self.feat.is_distributed
+
+    def step(self, seeds, step_id, ev=None):
+        """ev: optional list collecting (name, start_event, end_event) per stage."""
+        nn = self.nn
+
+        def stage(name, fn):
+            if ev is None:
+                return fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn()
+            e.record()
+            ev.append((name, s, e))
+            return out
+
+        res = stage("walk(sample+renumber x2)", lambda: self.walk.run(seeds, [62 + 2 * step_id, 63 + 2 * step_id]))
+        n_id = res.unique[1]  # capacity-sized, -1 padded
+        if self.distributed:
+            # remote rows come through the RCCL all-to-all pipeline, which needs exact counts
+            n_unique = int(res.counts[1, 1])
+            x = stage("gather(all-to-all)", lambda: self.feat.gather(n_id[:n_unique]))
+        else:
+            from wholegraph_amd.tensor import local_gather
+            x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id, self.x))
+        t1 = self.caps[1]
+        agg1 = stage("spmm1(mean,F=100)", lambda: nn.spmm_csr_forward(res.offsets[1], res.neighbor_lid[1], x, True))
+        h1 = stage("dense1", lambda: torch.relu(self.conv1.lin_l(agg1) + self.conv1.lin_r(x[:t1])))
+        agg2 = stage("spmm2(mean,F=256)", lambda: nn.spmm_csr_forward(res.offsets[0], res.neighbor_lid[0], h1, True))
+        out = stage("dense2", lambda: self.conv2.lin_l(agg2) + self.conv2.lin_r(h1[:BATCH]))
+        self.edges += res.counts[:, 0].sum()
+        return out, res
+
+
+def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
+    """The C oracle (OpenMP over seeds) + torch-CPU dense layers on the same workload, bounded."""
+    import oracle
+    oracle.build()
+    threads = oracle.num_threads()
+    torch.set_num_threads(max(1, threads))
+    (w1l, b1l, w1r), (w2l, b2l, w2r) = weights
+    t0 = time.perf_counter()
+    edges, batches = 0, 0
+    for b in range(len(seeds_h)):
+        tg, ei, rp, ci = oracle.multilayer_sample(row_ptr_h, col_h, seeds_h[b], FANOUT, [62 + 2 * b, 63 + 2 * b])
+        x = feat_h[tg[0]]
+        a1 = oracle.spmm_csr(rp[0], ci[0], x, mean=True)
+        h1 = torch.relu(torch.from_numpy(a1) @ w1l.T + b1l + torch.from_numpy(x[: len(tg[1])]) @ w1r.T)
+        a2 = oracle.spmm_csr(rp[1], ci[1], h1.numpy(), mean=True)
+        _ = torch.from_numpy(a2) @ w2l.T + b2l + h1[:BATCH] @ w2r.T
+        edges += int(ci[0].size + ci[1].size)
+        batches += 1
+        if time.perf_counter() - t0 > budget_s and batches >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": edges / dt, "unit": "sampled-edges/s", "cores": threads, "kind": "port",
+            "sample": f"{batches} mini-batches of {BATCH} seeds, fan-out {FANOUT}, same graph/features "
+                      f"(C oracle with OpenMP + torch CPU linear), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
+    ap.add_argument("--edges", type=int, default=E_UNDIRECTED, help="undirected RMAT edges before symmetrising")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from wholegraph_amd import WholeMemoryTensor, equal_entry_partition
+
+    # ---- synthetic workload (replicated CSR, range-partitioned features) --------------------
+    row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
+    V, E = args.nodes, int(col.shape[0])
+    gfeat = torch.Generator(device=device).manual_seed(100 + rank)
+    if world == 1:
+        feat = WholeMemoryTensor((torch.rand((V, FEAT_DIM), generator=gfeat, device=device) * 2 - 1))
+    else:
+        offs = equal_entry_partition(V, world)
+        local = torch.rand((offs[rank + 1] - offs[rank], FEAT_DIM), generator=gfeat, device=device) * 2 - 1
+        feat = WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)
+    pipe = SagePipeline(row_ptr, col, feat, device)
+
+    total = args.steps + args.warmup
+    gseed = torch.Generator(device=device).manual_seed(7 + rank)  # every rank its own seed shard
+    reps = (total * BATCH + V - 1) // V
+    order = torch.cat([torch.randperm(V, generator=gseed, device=device) for _ in range(reps)])
+    batches = order[: total * BATCH].view(total, BATCH).contiguous()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        pipe.step(batches[s], s)
+    pipe.edges.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        pipe.step(batches[s], s)
+    barrier()
+    dt = time.perf_counter() - t0
+    edges_local = int(pipe.edges)
+
+    stats = torch.tensor([dt, float(edges_local)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        esum = stats[1:].clone()
+        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        dt, edges_total = float(tmax), float(esum)
+    else:
+        edges_total = float(edges_local)
+
+    # ---- per-stage HIP-event timing pass (same pipeline, same stream; after the timed region) --
+    stage_ms, stage_n = {}, 0
+    e_hop = torch.zeros(2, dtype=torch.float64)
+    n_unique = 0.0
+    probe_steps = min(args.steps, 50)
+    for s in range(args.warmup, args.warmup + probe_steps):
+        ev = []
+        _, res = pipe.step(batches[s], s, ev)
+        torch.cuda.synchronize()
+        for name, a, b in ev:
+            stage_ms[name] = stage_ms.get(name, 0.0) + a.elapsed_time(b)
+        c = res.counts.cpu().double()
+        e_hop += c[:, 0]
+        n_unique += float(c[1, 1])
+        stage_n += 1
+    stage_ms = {k: v / stage_n for k, v in stage_ms.items()}
+    e1, e2 = (e_hop / stage_n).tolist()       # hop-1 (seeds) and hop-2 edges per batch
+    n_src = n_unique / stage_n
+    n_dst1 = float(res.counts[0, 1])           # frontier after hop 1 (rows of the layer-1 SpMM)
+
+    if rank == 0:
+        # algorithmic bytes per launch; b = 8-byte ids, fp32 features
+        F = FEAT_DIM
+        kernels = {
+            "gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F)),
+            "spmm1(mean,F=100)": ("spmm_csr_kernel", e2 * (4 * F + 4) + n_dst1 * (4 * F + 8)),
+            "spmm2(mean,F=256)": ("spmm_csr_kernel", e1 * (4 * HIDDEN + 4) + BATCH * (4 * HIDDEN + 8)),
+        }
+        dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
+        roofline = None
+        if dom is not None:
+            ach = kernels[dom][1] / (stage_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": kernels[dom][0], "stage": dom, "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "algorithmic_bytes_per_launch": int(kernels[dom][1]),
+                        "avg_launch_ms": round(stage_ms[dom], 5),
+                        "timing": "HIP events around the launch on the launch stream, per-step, averaged over "
+                                  f"{stage_n} steps"}
+        spmm_gbps = None
+        if "spmm1(mean,F=100)" in stage_ms:
+            spmm_gbps = kernels["spmm1(mean,F=100)"][1] / (stage_ms["spmm1(mean,F=100)"] * 1e-3) / 1e9
+        cpu = None
+        if not args.no_cpu_baseline:
+            nb = 64
+            cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()
+            if world > 1:
+                feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
+            else:
+                feat_h = feat.local_tensor.cpu().numpy()
+            weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in (pipe.conv1, pipe.conv2)]
+            cpu = cpu_baseline(row_ptr.cpu().numpy(), col.cpu().numpy(), feat_h, cb, weights, args.cpu_budget)
+        out = {
+            "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), ogbn-products-like fan-out [25,10]",
+            "value": edges_total / dt,
+            "unit": "sampled-edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64 ids + f32 features",
+            "data": "synthetic",
+            "config": {"workload": "ogbn-products-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
+                                   "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, 2-layer SAGEConv(mean) %d-%d-%d fwd"
+                                   % (V, E, FEAT_DIM, "" if world == 1 else " range-partitioned + RCCL all-to-all",
+                                      BATCH, FANOUT, FEAT_DIM, HIDDEN, CLASSES),
+                       "parallelism": "dp%d (seeds sharded, no data-path collective)" % world if world == 1
+                       else "dp%d seeds + feature all-to-all" % world},
+            "edges_per_batch": {"hop1": e1, "hop2": e2, "unique_nodes": n_src},
+            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
+            "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu is not None:
+            out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,9 @@ __global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restri
     counts_out[0] = E;
     counts_out[1] = T + rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
   }
+  // no-sync walk: pad the capacity slack of `unique` with -1 so that a capacity-sized feature
+  // gather skips those rows (negative index => row untouched)
+  if (counts_out && p >= T + rank[E_.host] && p < T_.host + E_.host) unique_out[p] = (KeyT)-1;
   if (p < T) {
     unique_out[p] = targets[p];
     return;

@@ -164,7 +164,7 @@ wholememory_error_code_t wholememory_make_tensor_from_pointer(wholememory_tensor
 {
   if (out == nullptr || desc == nullptr) return WHOLEMEMORY_INVALID_INPUT;
   if (desc->dim < 0 || desc->dim > WHOLEMEMORY_MAX_TENSOR_DIM) return WHOLEMEMORY_INVALID_INPUT;
-  if (desc->dim > 0 && desc->strides[desc->dim - 1] != 1) {
+  if (desc->dim > 0 && desc->sizes[desc->dim - 1] > 1 && desc->strides[desc->dim - 1] != 1) {
     fprintf(stderr, "[wholegraph_amd] make_tensor_from_pointer: innermost stride must be 1\n");
     return WHOLEMEMORY_INVALID_VALUE;
   }

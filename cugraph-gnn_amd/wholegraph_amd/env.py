@@ -153,9 +153,11 @@ class WrappedTensor:
             if t.dim() > L.WHOLEMEMORY_MAX_TENSOR_DIM:
                 raise ValueError("too many dims")
             desc.dim = t.dim()
-            for i in range(t.dim()):
+            dense = 1  # torch reports arbitrary strides for extent-0/1 dims: normalise them
+            for i in reversed(range(t.dim())):
                 desc.sizes[i] = t.shape[i]
-                desc.strides[i] = t.stride(i)
+                desc.strides[i] = t.stride(i) if t.shape[i] > 1 else dense
+                dense = desc.strides[i] * max(int(t.shape[i]), 1)
             desc.dtype = torch_dtype_to_wm(t.dtype)
             desc.storage_offset = 0  # data_ptr() already points at the first element of the view
             ptr = t.data_ptr()

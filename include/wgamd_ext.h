@@ -91,7 +91,8 @@ wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr,
  *        neighbor_lid int32[edge_cap]  raw_to_unique mapping of every sampled edge (CSR col)
  *        center_lid  int32[edge_cap]   row index of every sampled edge (nullable)
  *        edge_gid    int64[edge_cap]   CSR position of every sampled edge (nullable)
- *        unique      (id_dtype)[target_cap + edge_cap]  targets ++ new nodes (first appearance)
+ *        unique      (id_dtype)[target_cap + edge_cap]  targets ++ new nodes (first appearance),
+ *                                        capacity slack padded with -1 (a gather skips it)
  *        counts_dev  int32[2]          {n_edges, n_unique}
  * edge_cap must be >= target_cap * M (M > 0 required).  Results are identical to
  * wholegraph_csr_unweighted_sample_without_replacement followed by graph_append_unique.

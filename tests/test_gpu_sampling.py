@@ -38,7 +38,7 @@ def _run(oracle_mod, row_ptr, col, seeds, M, rs):
                                                   (np.int64, np.int32), (np.int32, np.int64)])
 def test_uniform_vs_oracle(oracle_mod, hiplib, nodes, edges, n_seeds, M, seed_dtype, col_dtype):
     row_ptr, col = random_csr(nodes, edges, seed=nodes + M, col_dtype=col_dtype)
-    rng = np.random.default_rng(M)
+    rng = np.random.default_rng(abs(M))
     seeds = rng.integers(0, nodes, n_seeds).astype(seed_dtype)
     _run(oracle_mod, row_ptr, col, seeds, M, 0x1234567 + M)
 
