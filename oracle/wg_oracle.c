@@ -339,7 +339,8 @@ void wgo_unweighted_sample(const int64_t* row_ptr,
 /* ------------------------------------------------------------------------------------------
  * A.3  weighted (A-Res) sampling  (graph_sampling_test_utils.cu:559-656)
  * Output order inside a seed: the reference leaves it unspecified (its tests sort per segment);
- * this restatement fixes it to key DEscending, ties by neighbour index ascending.
+ * this restatement selects the M largest keys (ties: lower neighbour index wins) and emits the
+ * selected edges in CSR order (neighbour index ascending).
  * `keys_out` (optional, same length as dst) receives the key of every sampled edge (NaN-free;
  * 0 for rows copied whole) so that tests can reason about 1-ulp libm differences.
  * ---------------------------------------------------------------------------------------- */
@@ -347,6 +348,13 @@ typedef struct {
   float key;
   int idx;
 } wgo_kv_t;
+
+static int wgo_kv_cmp_idx(const void* pa, const void* pb)
+{
+  const wgo_kv_t* a = (const wgo_kv_t*)pa;
+  const wgo_kv_t* b = (const wgo_kv_t*)pb;
+  return (a->idx > b->idx) - (a->idx < b->idx);
+}
 
 static int wgo_kv_cmp_desc(const void* pa, const void* pb)
 {
@@ -405,6 +413,7 @@ void wgo_weighted_sample(const int64_t* row_ptr,
       }
     }
     qsort(kv, (size_t)N, sizeof(wgo_kv_t), wgo_kv_cmp_desc);
+    qsort(kv, (size_t)M, sizeof(wgo_kv_t), wgo_kv_cmp_idx);
     for (int t = 0; t < M; t++) {
       wgo_set(dst, col_is64, base + t, wgo_idx(col, col_is64, start + kv[t].idx));
       if (src_lid) src_lid[base + t] = (int32_t)i;

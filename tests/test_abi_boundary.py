@@ -1,0 +1,131 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/*.h declares;
+host-side descriptor arithmetic behaves like the reference's
+(/root/reference/cpp/src/wholememory/tensor_description.cpp).  No GPU compute is invoked."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+def declared_functions():
+    names = set()
+    for fn in sorted(os.listdir(INC)):
+        if not fn.endswith(".h"):
+            continue
+        text = open(os.path.join(INC, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//.*", "", text)
+        text = re.sub(r"typedef[^;{]*\([^;]*;", "", text)          # function-pointer typedefs
+        text = re.sub(r"#define.*", "", text)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text):
+            names.add(m.group(1))
+    return names
+
+
+def test_headers_compile_as_c_and_cpp(tmp_path):
+    src = '#include "wholegraph_amd.h"\nint main(void){return (int)WHOLEMEMORY_DT_COUNT - 9;}\n'
+    for comp, name in (("gcc", "t.c"), ("g++", "t.cpp")):
+        p = tmp_path / name
+        p.write_text(src)
+        subprocess.check_call([comp, "-I", INC, "-fsyntax-only", "-Wall", "-Werror", str(p)])
+
+
+def test_every_declared_symbol_is_exported(hiplib):
+    from wholegraph_amd import _lib
+    declared = declared_functions()
+    assert len(declared) >= 40
+    missing = [n for n in sorted(declared) if not hasattr(hiplib, n)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    # and the ctypes table covers the whole boundary
+    assert declared <= set(_lib.SYMBOLS), sorted(declared - set(_lib.SYMBOLS))
+
+
+def test_enum_values_match_reference_order():
+    from wholegraph_amd import _lib as L
+    # tensor_description.h:18-29 ; wholememory.h:21-33
+    assert (L.DT_FLOAT, L.DT_HALF, L.DT_DOUBLE, L.DT_BF16, L.DT_INT, L.DT_INT64, L.DT_INT16, L.DT_INT8) == tuple(range(1, 9))
+    assert L.WHOLEMEMORY_LOGIC_ERROR == 3 and L.WHOLEMEMORY_INVALID_INPUT == 6 and L.WHOLEMEMORY_SYSTEM_ERROR == 10
+
+
+def test_dtype_helpers(hiplib):
+    from wholegraph_amd import _lib as L
+    sizes = {L.DT_FLOAT: 4, L.DT_HALF: 2, L.DT_DOUBLE: 8, L.DT_BF16: 2, L.DT_INT: 4, L.DT_INT64: 8, L.DT_INT16: 2, L.DT_INT8: 1}
+    for dt, sz in sizes.items():
+        assert hiplib.wholememory_dtype_get_element_size(dt) == sz
+        assert hiplib.wholememory_dtype_is_floating_number(dt) == (dt in (L.DT_FLOAT, L.DT_HALF, L.DT_DOUBLE, L.DT_BF16))
+        assert hiplib.wholememory_dtype_is_integer_number(dt) != hiplib.wholememory_dtype_is_floating_number(dt)
+    assert hiplib.wholememory_dtype_get_element_size(L.DT_UNKNOWN) == 0
+
+
+def test_tensor_descriptor_arithmetic(hiplib):
+    from wholegraph_amd import _lib as L
+    d = L.TensorDescription()
+    hiplib.wholememory_initialize_tensor_desc(ctypes.byref(d))
+    assert d.dim == 0 and d.storage_offset == 0 and list(d.sizes) == [1] * 8 and list(d.strides) == [1] * 8
+    d.dim, d.dtype = 1, L.DT_FLOAT
+    d.sizes[0] = 100
+    assert hiplib.wholememory_unsqueeze_tensor(ctypes.byref(d), 1)       # [100] -> [100,1]
+    assert d.dim == 2 and (d.sizes[0], d.sizes[1], d.strides[0], d.strides[1]) == (100, 1, 1, 1)
+    assert hiplib.wholememory_get_memory_element_count_from_tensor(ctypes.byref(d)) == 100
+    assert hiplib.wholememory_get_memory_size_from_tensor(ctypes.byref(d)) == 400
+    assert hiplib.wholememory_squeeze_tensor(ctypes.byref(d), 1) and d.dim == 1
+    assert not hiplib.wholememory_squeeze_tensor(ctypes.byref(d), 0)     # size 100 != 1
+    d2 = L.TensorDescription()
+    hiplib.wholememory_initialize_tensor_desc(ctypes.byref(d2))
+    d2.dim, d2.dtype = 2, L.DT_HALF
+    d2.sizes[0], d2.sizes[1], d2.strides[0] = 7, 11, 12                  # stride-12 rows (gtest dim 11)
+    assert hiplib.wholememory_get_memory_element_count_from_tensor(ctypes.byref(d2)) == 84
+    assert hiplib.wholememory_unsqueeze_tensor(ctypes.byref(d2), 0) and d2.dim == 3 and d2.strides[0] == 12
+
+
+def test_wrap_tensor_lifecycle_and_subtensor(hiplib):
+    import torch
+    from wholegraph_amd import _lib as L
+    from wholegraph_amd.env import wrap_torch_tensor
+    base = hiplib.get_wholememory_tensor_count()
+    t = torch.arange(24, dtype=torch.int64).view(6, 4)
+    w = wrap_torch_tensor(t)
+    assert hiplib.get_wholememory_tensor_count() == base + 1
+    desc = hiplib.wholememory_tensor_get_tensor_description(w.c).contents
+    assert desc.dim == 2 and desc.sizes[0] == 6 and desc.strides[0] == 4 and desc.dtype == L.DT_INT64
+    assert hiplib.wholememory_tensor_get_data_pointer(w.c) == t.data_ptr()
+    assert not hiplib.wholememory_tensor_has_handle(w.c)
+    sub = ctypes.c_void_p()
+    starts, ends = (ctypes.c_int64 * 2)(2, -1), (ctypes.c_int64 * 2)(5, -1)
+    assert hiplib.wholememory_tensor_get_subtensor(w.c, starts, ends, ctypes.byref(sub)) == 0
+    sd = hiplib.wholememory_tensor_get_tensor_description(sub).contents
+    assert (sd.sizes[0], sd.sizes[1], sd.storage_offset) == (3, 4, 8)
+    assert hiplib.wholememory_tensor_get_root(sub) == w.c.value
+    hiplib.wholememory_destroy_tensor(sub)
+    bad = (ctypes.c_int64 * 2)(5, 0)
+    assert hiplib.wholememory_tensor_get_subtensor(w.c, bad, (ctypes.c_int64 * 2)(2, -1), ctypes.byref(sub)) == L.WHOLEMEMORY_INVALID_VALUE
+    del w
+    assert hiplib.get_wholememory_tensor_count() == base
+    none = wrap_torch_tensor(None)          # "output not requested"
+    assert hiplib.wholememory_tensor_get_tensor_description(none.c).contents.dim == 0
+    assert not hiplib.wholememory_tensor_get_data_pointer(none.c)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from wholegraph_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libwholegraph_amd.so")
+    with pytest.raises(_lib.WholeGraphLibraryError):
+        _lib.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cugraph-gnn_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M) or "wg_oracle" in text:
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders

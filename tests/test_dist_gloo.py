@@ -1,0 +1,110 @@
+"""N>1 path on CPU: world_size-2 gloo run of the range-partitioned feature store
+(bucket ids -> all-to-all ids -> local gather -> all-to-all rows -> un-permute;
+reference algorithm /root/reference/cpp/src/wholememory_ops/gather_op_impl_nccl.cu:23-171).
+
+The product's local row kernels are HIP; here the TEST injects the oracle's CPU row kernels as
+``local_ops`` so the host logic (partitioning, bucketing, exchange, permutation) runs without a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class OracleLocalOps:
+    """test-only stand-in for wholegraph_amd.tensor.HipLocalOps, backed by the oracle"""
+
+    @staticmethod
+    def gather(table, idx, out):
+        import oracle
+        oracle.gather(table.numpy(), idx.numpy(), out=out.numpy())
+        return out
+
+    @staticmethod
+    def scatter(inp, idx, table):
+        import oracle
+        oracle.scatter(inp.numpy(), idx.numpy(), table.numpy())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, offsets, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "cugraph-gnn_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wholegraph_amd import WholeMemoryTensor, create_wholememory_tensor, equal_entry_partition
+        V, F = 1003, 7
+        full = (torch.arange(V).view(-1, 1) * 10 + torch.arange(F).view(1, -1)).float()  # KAT: row i = 10*i + j
+        offs = offsets if offsets is not None else equal_entry_partition(V, world)
+        wm = create_wholememory_tensor((V, F), torch.float32, device="cpu", partition_offsets=offs, local_ops=OracleLocalOps)
+        assert wm.shape == (V, F) and wm.local_tensor.shape[0] == offs[rank + 1] - offs[rank]
+        # load through the distributed scatter: each rank contributes an interleaved half of the rows
+        mine = torch.arange(rank, V, world)
+        wm.scatter(full[mine], mine)
+        dist.barrier()
+        assert torch.equal(wm.local_tensor, full[offs[rank]:offs[rank + 1]])
+        assert wm.get_local_tensor()[1] == offs[rank]
+        # gather arbitrary (rank-dependent, repeated, negative) indices
+        g = torch.Generator().manual_seed(100 + rank)
+        idx = torch.randint(0, V, (517 + 31 * rank,), generator=g)
+        idx[5] = -1
+        idx[6] = idx[7]
+        out = wm.gather(idx)
+        ref = full[idx.clamp(min=0)]
+        ref[5] = 0  # skipped row: reference leaves it untouched; our output buffer starts undefined -> compare others
+        mask = torch.ones(len(idx), dtype=torch.bool)
+        mask[5] = False
+        assert torch.equal(out[mask], ref[mask])
+        # int32 indices, empty request on one rank (every rank must still take part in the collectives)
+        idx32 = torch.randint(0, V, (0 if rank == 0 else 64,), generator=g).int()
+        out32 = wm.gather(idx32)
+        assert torch.equal(out32, full[idx32.long()])
+        # 1-D table
+        wm1 = WholeMemoryTensor(torch.arange(offs[rank], offs[rank + 1]) * 3, global_rows=V, partition_offsets=offs,
+                                local_ops=OracleLocalOps)
+        assert torch.equal(wm1.gather(idx[mask]), idx[mask] * 3)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("offsets", [None, [0, 17, 1003], [0, 1003, 1003]])
+def test_partitioned_feature_store_world2(oracle_mod, offsets):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, offsets, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_equal_entry_partition_matches_reference_formula():
+    # per = ceil(V/W); rank r owns [min(r*per,V), min((r+1)*per,V))  (memory_handle.cpp:1613-1629)
+    import sys
+    from wholegraph_amd import equal_entry_partition
+    assert equal_entry_partition(10, 3) == [0, 4, 8, 10]
+    assert equal_entry_partition(2449029, 8)[-1] == 2449029
+    assert equal_entry_partition(3, 8) == [0, 1, 2, 3, 3, 3, 3, 3, 3]
+    for V, W in ((111059956, 8), (67108864, 8), (7, 2)):
+        o = equal_entry_partition(V, W)
+        assert len(o) == W + 1 and o[0] == 0 and o[-1] == V and all(b >= a for a, b in zip(o, o[1:]))

@@ -1,0 +1,65 @@
+"""Pins the oracle's RNG.  raft's PCGenerator is a third-party, un-vendored dependency of the
+reference (rapidsai/raft 26.10): the raw stream is "parity unpinned" against raft
+itself, so it is pinned here to (i) the published PCG32 reference output, (ii) an independent
+pure-Python PCG32, (iii) the jump-ahead == stepping identity, and the C-ABI host helpers
+(generate_random_positive_int_cpu / generate_exponential_distribution_negative_float_cpu,
+/root/reference/cpp/include/wholememory/wholegraph_op.h:82-94) are checked against the oracle."""
+import numpy as np
+import pytest
+
+
+def test_pcg32_published_demo_vector(oracle_mod):
+    # pcg32_srandom(42, 54) — output of the reference PCG "pcg32-demo" (also vendored in
+    # pyarrow/include/arrow/vendored/pcg); SURVEY.md §7 step 1
+    got = oracle_mod.pcg_raw_u32(42, 54, 0, 6)
+    assert [int(v) for v in got] == [0xA15C02B7, 0x7B47F409, 0xBA1D3330, 0x83D2F293, 0xBFA4784B, 0xCBED606E]
+
+
+@pytest.mark.parametrize("seed,sub,off", [(0, 0, 0), (42, 54, 0), (2**64 - 1, 2**63 + 5, 17), (99, 5, 37), (1, 10**9, 100)])
+def test_pcg32_vs_independent_python(oracle_mod, seed, sub, off):
+    assert [int(v) for v in oracle_mod.pcg_raw_u32(seed, sub, off, 16)] == oracle_mod.py_pcg_u32_stream(seed, sub, off, 16)
+
+
+def test_skipahead_equals_stepping(oracle_mod):
+    for delta in (1, 2, 63, 1000, 12345):
+        a = oracle_mod.pcg_raw_u32(1234, 77, delta, 8)
+        b = oracle_mod.pcg_raw_u32(1234, 77, 0, delta + 8)[delta:]
+        assert np.array_equal(a, b)
+
+
+def test_positive_int_is_masked_draw(oracle_mod):
+    # next(int32) = u32 & 0x7fffffff ; next(int64) = (lo | hi<<32) & 0x7fff...; ctor skips `sub` draws (A1)
+    sub = 11
+    raw = oracle_mod.pcg_raw_u32(5, sub, sub, 8).astype(np.uint64)
+    assert np.array_equal(oracle_mod.generate_random_positive_int(5, sub, 8), (raw & 0x7FFFFFFF).astype(np.int32))
+    i64 = oracle_mod.generate_random_positive_int(5, sub, 4, np.int64)
+    want = [(int(raw[2 * k]) | (int(raw[2 * k + 1]) << 32)) & 0x7FFFFFFFFFFFFFFF for k in range(4)]
+    assert [int(v) for v in i64] == want
+
+
+def test_golden_rng(oracle_mod):
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "hotpath_golden.npz"))
+    assert np.array_equal(oracle_mod.generate_random_positive_int(42, 0, 8), g["rng_i31_seed42_sub0"])
+    assert np.array_equal(oracle_mod.generate_random_positive_int(42, 5, 8), g["rng_i31_seed42_sub5"])
+    assert np.array_equal(oracle_mod.generate_random_positive_int(7, 3, 4, np.int64), g["rng_i63_seed7_sub3"])
+    np.testing.assert_allclose(oracle_mod.generate_exponential_distribution_negative_float(9, 2, 8),
+                               g["rng_expneg_seed9_sub2"], rtol=1e-6)
+
+
+def test_expneg_distribution_shape(oracle_mod):
+    # log2(u), u ~ U(0,1): all negative, mean = -1/ln2
+    v = oracle_mod.generate_exponential_distribution_negative_float(3, 1, 20000)
+    assert np.all(v < 0) and abs(v.mean() + 1.0 / np.log(2)) < 0.03
+
+
+def test_abi_host_rng_helpers_match_oracle(oracle_mod, hiplib):
+    # host-only entry points of the C ABI: no GPU involved
+    import torch
+    from wholegraph_amd import wholegraph_ops as ops
+    for seed, sub in ((42, 0), (42, 5), (123456789, 4097)):
+        assert np.array_equal(ops.generate_random_positive_int_cpu(seed, sub, 33).numpy(),
+                              oracle_mod.generate_random_positive_int(seed, sub, 33))
+        np.testing.assert_allclose(ops.generate_exponential_distribution_negative_float_cpu(seed, sub, 33).numpy(),
+                                   oracle_mod.generate_exponential_distribution_negative_float(seed, sub, 33), rtol=1e-6)
+    assert ops.generate_random_positive_int_cpu(1, 2, 0).shape == (0,)
+    assert isinstance(ops.generate_random_positive_int_cpu(1, 2, 3), torch.Tensor)
