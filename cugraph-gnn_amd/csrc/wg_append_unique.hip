@@ -13,6 +13,13 @@
 //   exactly what the reference's host oracle produces
 //   (cpp/tests/graph_ops/append_unique_test_utils.cu:52-84) and a strict refinement of the
 //   reference device op, which leaves that order to CAS races.
+//
+// Call groups (no-sync walk, G mini-batches per launch): the table key becomes the pair
+// (batch, id) packed in an int64, so each mini-batch is renumbered on its own in the same pass;
+// targets/edges of one batch are contiguous, hence "minimum position" is still "first
+// appearance inside the batch".  Output rows are global rows of the concatenated per-batch
+// unique lists:  row(target i of batch b) = i + rank[edge_seg[b]],
+//                row(new node first seen at edge e of batch b) = target_seg[b+1] + rank[e].
 #include "wg_common.hpp"
 
 namespace wgamd {
@@ -24,14 +31,12 @@ template <typename KeyT>
 struct key_traits;
 template <>
 struct key_traits<int32_t> {
-  using cas_t                         = unsigned int;
-  static constexpr int32_t kEmpty     = -1;
+  using cas_t                             = unsigned int;
   static constexpr wholememory_dtype_t dt = WHOLEMEMORY_DT_INT;
 };
 template <>
 struct key_traits<int64_t> {
-  using cas_t                         = unsigned long long;
-  static constexpr int64_t kEmpty     = -1;
+  using cas_t                             = unsigned long long;
   static constexpr wholememory_dtype_t dt = WHOLEMEMORY_DT_INT64;
 };
 
@@ -43,39 +48,51 @@ __device__ __forceinline__ uint32_t hash_key(uint64_t k)
   return (uint32_t)(k ^ (k >> 32));
 }
 
-template <typename KeyT>
-__global__ void __launch_bounds__(256) table_clear_kernel(KeyT* keys, int* minpos, int64_t slots)
+template <typename TableKeyT>
+__global__ void __launch_bounds__(256) table_clear_kernel(TableKeyT* keys, int* minpos, int64_t slots)
 {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < slots) {
-    keys[i]   = key_traits<KeyT>::kEmpty;
+    keys[i]   = (TableKeyT)-1;
     minpos[i] = kEmptyPos;
   }
 }
 
+// batch of position p (p < T: target p, else edge p - T)
+__device__ __forceinline__ int batch_of(const batch_view& bv, int p, int T)
+{
+  if (bv.target_batch == nullptr) return 0;
+  return p < T ? bv.target_batch[p] : bv.target_batch[bv.edge_row[p - T]];
+}
+
 // thread p < T inserts target p, thread T+e inserts neighbour e; remembers its slot.
-template <typename KeyT>
+template <typename KeyT, typename TableKeyT>
 __global__ void __launch_bounds__(256) table_insert_kernel(const KeyT* __restrict__ targets,
                                                            dev_count T_,
                                                            const KeyT* __restrict__ neighbors,
                                                            dev_count E_,
-                                                           KeyT* keys,
+                                                           batch_view bv,
+                                                           TableKeyT* keys,
                                                            int* minpos,
                                                            uint32_t slot_mask,
                                                            int* __restrict__ slot_of)
 {
-  using cas_t = typename key_traits<KeyT>::cas_t;
+  using cas_t = typename key_traits<TableKeyT>::cas_t;
   const int T = T_.get(), E = E_.get();
   int p       = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= T + E) return;
-  KeyT key   = p < T ? targets[p] : neighbors[p - T];
+  KeyT id       = p < T ? targets[p] : neighbors[p - T];
+  TableKeyT key = (TableKeyT)id;
+  if constexpr (sizeof(TableKeyT) == 8) {
+    if (bv.target_batch != nullptr) key = (TableKeyT)(((int64_t)batch_of(bv, p, T) << 40) | (int64_t)id);
+  }
   uint32_t h = hash_key((uint64_t)(int64_t)key) & slot_mask;
   while (true) {
-    KeyT cur = keys[h];
-    if (cur == key_traits<KeyT>::kEmpty) {
-      cas_t old = atomicCAS(reinterpret_cast<cas_t*>(keys + h), (cas_t)key_traits<KeyT>::kEmpty, (cas_t)key);
-      cur       = (KeyT)old;
-      if (cur == key_traits<KeyT>::kEmpty) cur = key;  // we own the slot now
+    TableKeyT cur = keys[h];
+    if (cur == (TableKeyT)-1) {
+      cas_t old = atomicCAS(reinterpret_cast<cas_t*>(keys + h), (cas_t)(TableKeyT)-1, (cas_t)key);
+      cur       = (TableKeyT)old;
+      if (cur == (TableKeyT)-1) cur = key;  // we own the slot now
     }
     if (cur == key) break;
     h = (h + 1) & slot_mask;
@@ -103,29 +120,44 @@ __global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restri
                                                             const int* __restrict__ rank,  // exclusive scan of flag, [E.host+1]
                                                             dev_count T_,
                                                             dev_count E_,
+                                                            batch_view bv,
                                                             KeyT* __restrict__ unique_out,
                                                             int* __restrict__ map_out,
                                                             int* __restrict__ counts_out)
 {
   const int T = T_.get(), E = E_.get();
+  const int U = rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p == 0 && counts_out) {
     counts_out[0] = E;
-    counts_out[1] = T + rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
+    counts_out[1] = T + U;
+  }
+  const bool batched = bv.target_batch != nullptr;
+  if (batched && bv.unique_seg && p <= bv.G) {
+    // first unique row of batch p (p == G: one past the end)
+    bv.unique_seg[p] = bv.target_seg[p] + rank[bv.edge_offsets[bv.target_seg[p]]];
   }
   // no-sync walk: pad the capacity slack of `unique` with -1 so that a capacity-sized feature
   // gather skips those rows (negative index => row untouched)
-  if (counts_out && p >= T + rank[E_.host] && p < T_.host + E_.host) unique_out[p] = (KeyT)-1;
+  if (counts_out && p >= T + U && p < T_.host + E_.host) unique_out[p] = (KeyT)-1;
+  if (p >= T + E) return;
+  const int b = batch_of(bv, p, T);
+  // rows contributed by the new nodes of earlier batches / first row after my batch's targets
+  const int shift    = batched ? rank[bv.edge_offsets[bv.target_seg[b]]] : 0;
+  const int tail_row = batched ? bv.target_seg[b + 1] : T;
   if (p < T) {
-    unique_out[p] = targets[p];
+    unique_out[p + shift] = targets[p];
+    if (bv.unique_batch) bv.unique_batch[p + shift] = b;
     return;
   }
-  int e = p - T;
-  if (e >= E) return;
-  int first = minpos[slot_of[p]];  // position (in targets ++ neighbours) of the id's first occurrence
-  int local = first < T ? first : T + rank[first - T];
-  if (first == p) unique_out[local] = neighbors[e];
-  if (map_out) map_out[e] = local;
+  const int e     = p - T;
+  const int first = minpos[slot_of[p]];  // position (in targets ++ neighbours) of the id's first occurrence
+  const int row   = first < T ? first + shift : tail_row + rank[first - T];
+  if (first == p) {
+    unique_out[row] = neighbors[e];
+    if (bv.unique_batch) bv.unique_batch[row] = b;
+  }
+  if (map_out) map_out[e] = row;
 }
 
 template <typename KeyT>
@@ -142,14 +174,17 @@ void append_unique_impl(const KeyT* targets, int T, const KeyT* neighbors, int E
   int* stmp    = tmp_b.device<int>(scan_tmp_ints(E + 1), WHOLEMEMORY_DT_INT);
   const bool k64 = sizeof(KeyT) == 8;
   dev_count Tc{T, nullptr}, Ec{E, nullptr};
+  batch_view one{};
+  one.G = 1;
 
-  append_unique_prepare_enqueue(targets, Tc, neighbors, Ec, k64, keys, minpos, slots, slot_of, rank, stmp, stream);
+  append_unique_prepare_enqueue(targets, Tc, neighbors, Ec, k64, one, keys, minpos, slots, slot_of, rank, stmp, stream);
   int U = 0;
   WG_HIP_CHECK(hipMemcpyAsync(&U, rank + E, sizeof(int), hipMemcpyDeviceToHost, stream));
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // output size
 
   KeyT* unique_out = static_cast<KeyT*>(output_alloc(env, unique_ctx, (int64_t)T + U, key_traits<KeyT>::dt));
-  append_unique_emit_enqueue(targets, Tc, neighbors, Ec, k64, minpos, slot_of, rank, unique_out, map_out, nullptr, stream);
+  append_unique_emit_enqueue(targets, Tc, neighbors, Ec, k64, one, minpos, slot_of, rank, unique_out, map_out, nullptr,
+                             stream);
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
 }
 
@@ -169,6 +204,20 @@ add_self_loop_kernel(const int* __restrict__ row_ptr, const int* __restrict__ co
   for (int j = lane; j <= e - s; j += 64) out_col[s + row + j] = j == 0 ? row : col[s + j - 1];
 }
 
+template <typename KeyT, typename TableKeyT>
+void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, TableKeyT* keys,
+               int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
+{
+  const int P = T.host + E.host;
+  table_clear_kernel<TableKeyT><<<ceil_div(slots, 256), 256, 0, stream>>>(keys, minpos, slots);
+  if (P > 0)
+    table_insert_kernel<KeyT, TableKeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, keys,
+                                                                              minpos, (uint32_t)(slots - 1), slot_of);
+  if (E.host > 0) first_flag_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(minpos, slot_of, T, E, rank);
+  WG_HIP_CHECK(hipGetLastError());
+  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream);  // flags -> ranks, rank[E.host] = #new nodes
+}
+
 }  // namespace
 
 int64_t append_unique_slots(int64_t capacity)
@@ -178,46 +227,36 @@ int64_t append_unique_slots(int64_t capacity)
   return slots;
 }
 
-template <typename KeyT>
-static void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, KeyT* keys, int* minpos,
-                      int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
-{
-  const int P = T.host + E.host;
-  table_clear_kernel<KeyT><<<ceil_div(slots, 256), 256, 0, stream>>>(keys, minpos, slots);
-  if (P > 0)
-    table_insert_kernel<KeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, keys, minpos,
-                                                                   (uint32_t)(slots - 1), slot_of);
-  if (E.host > 0) first_flag_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(minpos, slot_of, T, E, rank);
-  WG_HIP_CHECK(hipGetLastError());
-  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream);  // flags -> ranks, rank[E.host] = #new nodes
-}
-
 void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
-                                   void* keys, int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp,
-                                   hipStream_t stream)
+                                   batch_view bv, void* keys, int* minpos, int64_t slots, int* slot_of, int* rank,
+                                   int* scan_tmp, hipStream_t stream)
 {
+  const bool batched = bv.target_batch != nullptr;
   if (ids64)
-    prepare_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E,
-                       static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+    prepare_t<int64_t, int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv,
+                                static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+  else if (batched)
+    prepare_t<int32_t, int64_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv,
+                                static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
   else
-    prepare_t<int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E,
-                       static_cast<int32_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+    prepare_t<int32_t, int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv,
+                                static_cast<int32_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
 }
 
 void append_unique_emit_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
-                                const int* minpos, const int* slot_of, const int* rank, void* unique_out, int* map_out,
-                                int* counts_out, hipStream_t stream)
+                                batch_view bv, const int* minpos, const int* slot_of, const int* rank,
+                                void* unique_out, int* map_out, int* counts_out, hipStream_t stream)
 {
-  const int P = T.host + E.host;
-  const int grid = P > 0 ? ceil_div(P, 256) : 1;  // thread 0 also publishes the counts
+  const int P    = T.host + E.host;
+  const int grid = ceil_div(P > bv.G + 1 ? P : bv.G + 1, 256);  // thread 0 publishes the counts, threads <= G the segments
   if (ids64)
     renumber_emit_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(targets),
                                                            static_cast<const int64_t*>(neighbors), minpos, slot_of, rank,
-                                                           T, E, static_cast<int64_t*>(unique_out), map_out, counts_out);
+                                                           T, E, bv, static_cast<int64_t*>(unique_out), map_out, counts_out);
   else
     renumber_emit_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(targets),
                                                            static_cast<const int32_t*>(neighbors), minpos, slot_of, rank,
-                                                           T, E, static_cast<int32_t*>(unique_out), map_out, counts_out);
+                                                           T, E, bv, static_cast<int32_t*>(unique_out), map_out, counts_out);
   WG_HIP_CHECK(hipGetLastError());
 }
 

@@ -168,6 +168,29 @@ struct dev_count {
   __device__ __forceinline__ int get() const { return dev ? *dev : host; }
 };
 
+// Where a seed's PCG streams come from.  ABI ops: one scalar `seed`, stream index = the seed's
+// index in the call.  Batched no-sync walk: mini-batch b of the call group has its own 64-bit seed
+// (`seeds_dev[b]`) and its streams are numbered from the START of its own segment, so every
+// mini-batch reproduces exactly what a single-batch call with that seed would have drawn.
+struct rng_plan {
+  uint64_t seed;
+  const unsigned long long* seeds_dev;  // [G] or nullptr
+  const int* target_batch;              // [T] batch of every target, or nullptr (single batch)
+  const int* target_seg;                // [G+1] first target of every batch
+  __device__ __forceinline__ void resolve(int i, uint64_t& s, int& i_local) const
+  {
+    s       = seed;
+    i_local = i;
+    if (target_batch) {
+      const int b = target_batch[i];
+      i_local     = i - target_seg[b];
+      s           = seeds_dev[b];
+    } else if (seeds_dev) {
+      s = seeds_dev[0];
+    }
+  }
+};
+
 // ---- device-side utilities implemented in wg_scan.hip ---------------------------------------
 // out[0..n] (n+1 entries) = exclusive scan of in[0..n-1]; out[n] = total. in/out may alias.
 // `tmp` needs scan_tmp_ints(n) ints.
@@ -178,18 +201,30 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
 // ---- building blocks shared by the ABI ops and the no-sync walk (wg_fused.hip) -----------------
 // uniform sampling of `n` targets (n.host = capacity): cnt/offsets have n.host+1 entries
 void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
-                            dev_count n, int M, uint64_t random_seed, const int* offsets, void* dst, int* src_lid,
+                            dev_count n, int M, rng_plan random_seed, const int* offsets, void* dst, int* src_lid,
                             int64_t* edge_gid, hipStream_t stream);
 void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
                           int* big_deg, hipStream_t stream);
 // renumbering: table of `slots` (power of two >= 2*(T.host+E.host)) entries, slot_of[T.host+E.host],
 // rank[E.host+1], scan_tmp[scan_tmp_ints(E.host+1)].  unique_out may be NULL for `prepare`.
 int64_t append_unique_slots(int64_t capacity);
+// `bv` describes the call group (single batch: all-null / G = 1).  With G > 1 the table keys are
+// (batch, id) pairs packed in int64, so `keys` must then hold int64 slots whatever the id type.
+struct batch_view {
+  const int* target_batch;  // [T]   batch of every target            (nullptr: one batch)
+  const int* target_seg;    // [G+1] first target of every batch      (nullptr: one batch)
+  const int* edge_row;      // [E]   target row of every sampled edge (needed when G > 1)
+  const int* edge_offsets;  // [T+1] sample offsets (edge_seg[b] = edge_offsets[target_seg[b]])
+  int G;
+  int* unique_batch;        // out [T+E] batch of every unique entry  (nullable)
+  int* unique_seg;          // out [G+1] first unique entry of every batch (nullable)
+};
 void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
-                                   void* keys, int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp,
-                                   hipStream_t stream);
+                                   batch_view bv, void* keys, int* minpos, int64_t slots, int* slot_of, int* rank,
+                                   int* scan_tmp, hipStream_t stream);
 void append_unique_emit_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
-                                const int* minpos, const int* slot_of, const int* rank, void* unique_out, int* map_out,
-                                int* counts_out /*nullable: {E, T+U}*/, hipStream_t stream);
+                                batch_view bv, const int* minpos, const int* slot_of, const int* rank,
+                                void* unique_out, int* map_out, int* counts_out /*nullable: {E, T+U}*/,
+                                hipStream_t stream);
 
 }  // namespace wgamd

@@ -1,10 +1,14 @@
-// No-host-sync hop: uniform sampling + renumbering with device-resident sizes (include/wgamd_ext.h).
+// No-host-sync hop: uniform sampling + renumbering with device-resident sizes (include/wgamd_ext.h),
+// for ONE mini-batch or for a CALL GROUP of G mini-batches processed by the same launches.
 //
 // The reference's walk (GraphStructure.multilayer_sample_without_replacement,
 // /root/reference/python/pylibwholegraph/pylibwholegraph/torch/graph_structure.py:136-196) pays at
 // least five stream synchronisations per hop because every op returns an
-// exact-size tensor.  Here the SAME kernels run with capacity-sized grids and read the live
-// sizes from device memory, so a mini-batch is a fixed launch sequence with no D2H round trip.
+// exact-size tensor, and its kernels see 1024 seeds at a time — a few hundred workgroups on a
+// 256-CU chip.  Here the SAME kernels run with capacity-sized grids and read the live sizes from
+// device memory, and a call group (the idea of cugraph_pyg's `local_seeds_per_call`,
+// python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:279-343) gives every launch G x the
+// work while each mini-batch keeps exactly the result a single-batch call would produce.
 #include "wg_common.hpp"
 
 namespace wgamd {
@@ -17,7 +21,7 @@ struct hop_workspace {
   int64_t slots;
 };
 
-hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes)
+hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool batched)
 {
   hop_workspace w{};
   size_t off = 0;
@@ -26,17 +30,77 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes)
     off += align_up(bytes);
     return at;
   };
-  w.slots         = append_unique_slots(target_cap + edge_cap);
-  int64_t scan_n  = std::max(target_cap, edge_cap) + 1;
-  w.cnt           = take(sizeof(int) * (size_t)(target_cap + 1));
-  w.scan_tmp      = take(sizeof(int) * (size_t)scan_tmp_ints(scan_n));
-  w.nbr           = take(id_bytes * (size_t)edge_cap);
-  w.keys          = take(id_bytes * (size_t)w.slots);
-  w.minpos        = take(sizeof(int) * (size_t)w.slots);
-  w.slot_of       = take(sizeof(int) * (size_t)(target_cap + edge_cap));
-  w.rank          = take(sizeof(int) * (size_t)(edge_cap + 1));
-  w.total         = off;
+  w.slots        = append_unique_slots(target_cap + edge_cap);
+  int64_t scan_n = std::max(target_cap, edge_cap) + 1;
+  w.cnt          = take(sizeof(int) * (size_t)(target_cap + 1));
+  w.scan_tmp     = take(sizeof(int) * (size_t)scan_tmp_ints(scan_n));
+  w.nbr          = take(id_bytes * (size_t)edge_cap);
+  w.keys         = take((batched ? 8 : id_bytes) * (size_t)w.slots);
+  w.minpos       = take(sizeof(int) * (size_t)w.slots);
+  w.slot_of      = take(sizeof(int) * (size_t)(target_cap + edge_cap));
+  w.rank         = take(sizeof(int) * (size_t)(edge_cap + 1));
+  w.total        = off;
   return w;
+}
+
+struct hop_args {
+  const int64_t* csr_row_ptr;
+  const void* csr_col;
+  wholememory_dtype_t id_dtype;
+  const void* targets;
+  const int* n_targets_dev;
+  int64_t target_cap;
+  int M;
+  rng_plan rng;
+  batch_view bv;
+  int* offsets;
+  int* neighbor_row;
+  int* center_row;
+  int64_t* edge_gid;
+  int64_t edge_cap;
+  void* unique;
+  int* counts_dev;
+  void* workspace;
+  size_t workspace_bytes;
+  hipStream_t stream;
+};
+
+void run_hop(hop_args a)
+{
+  WG_REQUIRE_INPUT(a.id_dtype == WHOLEMEMORY_DT_INT || a.id_dtype == WHOLEMEMORY_DT_INT64, "id dtype must be INT|INT64");
+  WG_REQUIRE_INPUT(a.csr_row_ptr && a.csr_col && a.targets && a.n_targets_dev && a.offsets && a.neighbor_row &&
+                     a.unique && a.workspace,
+                   "null pointer");
+  WG_REQUIRE_INPUT(a.M > 0, "the no-sync walk needs a positive fan-out (capacity = targets * M)");
+  WG_REQUIRE_INPUT(a.target_cap > 0 && a.edge_cap >= a.target_cap * (int64_t)a.M, "edge_cap < target_cap * M");
+  WG_REQUIRE_INPUT(a.target_cap + a.edge_cap < ((int64_t)1 << 30), "capacities too large for one call");
+  const bool i64     = a.id_dtype == WHOLEMEMORY_DT_INT64;
+  const bool batched = a.bv.target_batch != nullptr;
+  hop_workspace w    = plan(a.target_cap, a.edge_cap, i64 ? 8 : 4, batched);
+  WG_REQUIRE_INPUT(a.workspace_bytes >= w.total, "workspace too small: need %zu bytes", w.total);
+  WG_REQUIRE_INPUT((reinterpret_cast<uintptr_t>(a.workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  char* base    = static_cast<char*>(a.workspace);
+  int* cnt      = reinterpret_cast<int*>(base + w.cnt);
+  int* scan_tmp = reinterpret_cast<int*>(base + w.scan_tmp);
+  void* nbr     = base + w.nbr;
+  void* keys    = base + w.keys;
+  int* minpos   = reinterpret_cast<int*>(base + w.minpos);
+  int* slot_of  = reinterpret_cast<int*>(base + w.slot_of);
+  int* rank     = reinterpret_cast<int*>(base + w.rank);
+  hipStream_t st = a.stream;
+
+  dev_count T{(int)a.target_cap, a.n_targets_dev};
+  sample_count_enqueue(a.csr_row_ptr, a.targets, i64, T, a.M, cnt, nullptr, st);
+  exclusive_scan_i32(cnt, a.offsets, a.target_cap, scan_tmp, st);  // slack rows add 0: offsets[cap] = #edges
+  uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, a.targets, i64, T, a.M, a.rng, a.offsets, nbr, a.center_row,
+                         a.edge_gid, st);
+  dev_count E{(int)a.edge_cap, a.offsets + a.target_cap};
+  batch_view bv   = a.bv;
+  bv.edge_row     = a.center_row;
+  bv.edge_offsets = a.offsets;
+  append_unique_prepare_enqueue(a.targets, T, nbr, E, i64, bv, keys, minpos, w.slots, slot_of, rank, scan_tmp, st);
+  append_unique_emit_enqueue(a.targets, T, nbr, E, i64, bv, minpos, slot_of, rank, a.unique, a.neighbor_row,
+                             a.counts_dev, st);
 }
 
 }  // namespace
@@ -48,7 +112,7 @@ size_t wgamd_sample_hop_workspace_bytes(int64_t target_cap, int64_t edge_cap, wh
 {
   if (target_cap < 0 || edge_cap < 0) return 0;
   size_t idb = id_dtype == WHOLEMEMORY_DT_INT64 ? 8 : 4;
-  return wgamd::plan(target_cap, edge_cap, idb).total;
+  return wgamd::plan(target_cap, edge_cap, idb, true).total;  // sized for the batched table (int64 keys)
 }
 
 wholememory_error_code_t wgamd_sample_hop_nosync(const int64_t* csr_row_ptr, const void* csr_col,
@@ -60,35 +124,43 @@ wholememory_error_code_t wgamd_sample_hop_nosync(const int64_t* csr_row_ptr, con
 {
   using namespace wgamd;
   return guarded("wgamd_sample_hop_nosync", [&] {
-    WG_REQUIRE_INPUT(id_dtype == WHOLEMEMORY_DT_INT || id_dtype == WHOLEMEMORY_DT_INT64, "id dtype must be INT|INT64");
-    WG_REQUIRE_INPUT(csr_row_ptr && csr_col && targets && n_targets_dev && offsets && neighbor_lid && unique &&
-                       counts_dev && workspace,
-                     "null pointer");
-    WG_REQUIRE_INPUT(max_sample_count > 0, "the no-sync walk needs a positive fan-out (capacity = targets * M)");
-    WG_REQUIRE_INPUT(target_cap > 0 && edge_cap >= target_cap * (int64_t)max_sample_count, "edge_cap < target_cap * M");
-    WG_REQUIRE_INPUT(target_cap + edge_cap < ((int64_t)1 << 30), "capacities too large for one call");
-    const bool i64  = id_dtype == WHOLEMEMORY_DT_INT64;
-    hop_workspace w = plan(target_cap, edge_cap, i64 ? 8 : 4);
-    WG_REQUIRE_INPUT(workspace_bytes >= w.total, "workspace too small: need %zu bytes", w.total);
-    WG_REQUIRE_INPUT((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
-    auto st    = static_cast<hipStream_t>(stream);
-    char* base = static_cast<char*>(workspace);
-    int* cnt      = reinterpret_cast<int*>(base + w.cnt);
-    int* scan_tmp = reinterpret_cast<int*>(base + w.scan_tmp);
-    void* nbr     = base + w.nbr;
-    void* keys    = base + w.keys;
-    int* minpos   = reinterpret_cast<int*>(base + w.minpos);
-    int* slot_of  = reinterpret_cast<int*>(base + w.slot_of);
-    int* rank     = reinterpret_cast<int*>(base + w.rank);
+    WG_REQUIRE_INPUT(counts_dev != nullptr, "counts_dev is NULL");
+    hop_args a{};
+    a.csr_row_ptr = csr_row_ptr; a.csr_col = csr_col; a.id_dtype = id_dtype; a.targets = targets;
+    a.n_targets_dev = n_targets_dev; a.target_cap = target_cap; a.M = max_sample_count;
+    a.rng = rng_plan{(uint64_t)random_seed, nullptr, nullptr, nullptr};
+    a.bv.G = 1;
+    a.offsets = offsets; a.neighbor_row = neighbor_lid; a.center_row = center_lid; a.edge_gid = edge_gid;
+    a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
+    run_hop(a);
+  });
+}
 
-    dev_count T{(int)target_cap, n_targets_dev};
-    sample_count_enqueue(csr_row_ptr, targets, i64, T, max_sample_count, cnt, nullptr, st);
-    exclusive_scan_i32(cnt, offsets, target_cap, scan_tmp, st);  // slack rows add 0: offsets[cap] = #edges
-    uniform_sample_enqueue(csr_row_ptr, csr_col, i64, targets, i64, T, max_sample_count, (uint64_t)random_seed,
-                           offsets, nbr, center_lid, edge_gid, st);
-    dev_count E{(int)edge_cap, offsets + target_cap};
-    append_unique_prepare_enqueue(targets, T, nbr, E, i64, keys, minpos, w.slots, slot_of, rank, scan_tmp, st);
-    append_unique_emit_enqueue(targets, T, nbr, E, i64, minpos, slot_of, rank, unique, neighbor_lid, counts_dev, st);
+wholememory_error_code_t wgamd_sample_hop_batched_nosync(
+  const int64_t* csr_row_ptr, const void* csr_col, wholememory_dtype_t id_dtype, const void* targets,
+  const int* target_batch, const int* target_seg, int n_batches, int64_t target_cap, int max_sample_count,
+  const unsigned long long* random_seeds_dev, int* offsets, int* neighbor_row, int* center_row, int64_t* edge_gid,
+  int64_t edge_cap, void* unique, int* unique_batch, int* unique_seg, int* counts_dev, void* workspace,
+  size_t workspace_bytes, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_sample_hop_batched_nosync", [&] {
+    WG_REQUIRE_INPUT(target_batch && target_seg && random_seeds_dev && center_row && unique_batch && unique_seg &&
+                       counts_dev,
+                     "null pointer");
+    WG_REQUIRE_INPUT(n_batches >= 1 && n_batches < (1 << 20), "bad batch count");
+    hop_args a{};
+    a.csr_row_ptr = csr_row_ptr; a.csr_col = csr_col; a.id_dtype = id_dtype; a.targets = targets;
+    a.n_targets_dev = target_seg + n_batches;  // the last segment boundary IS the live target count
+    a.target_cap = target_cap; a.M = max_sample_count;
+    a.rng = rng_plan{0, random_seeds_dev, target_batch, target_seg};
+    a.bv.target_batch = target_batch; a.bv.target_seg = target_seg; a.bv.G = n_batches;
+    a.bv.unique_batch = unique_batch; a.bv.unique_seg = unique_seg;
+    a.offsets = offsets; a.neighbor_row = neighbor_row; a.center_row = center_row; a.edge_gid = edge_gid;
+    a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
+    run_hop(a);
   });
 }
 

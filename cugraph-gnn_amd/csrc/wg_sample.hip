@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
                                                                       const SeedT* __restrict__ seeds,
                                                                       dev_count n_,
                                                                       int M,
-                                                                      uint64_t random_seed,
+                                                                      rng_plan rng,
                                                                       const int* __restrict__ offsets,
                                                                       ColT* __restrict__ dst,
                                                                       int* __restrict__ src_lid,
@@ -125,7 +125,10 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   }
   int r = 0;
   if (pick && hl < M) {
-    Pcg32 g(random_seed, stream_id(i, 32, hl));
+    uint64_t random_seed;
+    int i_local;
+    rng.resolve(i, random_seed, i_local);
+    Pcg32 g(random_seed, stream_id(i_local, 32, hl));
     r = g.next_i31() % (N - hl);
   }
   // Fisher-Yates:  a[t] = Q[r_t];  Q[r_t] = Q[N-t-1].  Lane s remembers (pos=r_s, val=the value
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(256) sample_uniform_block_kernel(const int64_t
                                                                    int M,
                                                                    int B,
                                                                    int items,
-                                                                   uint64_t random_seed,
+                                                                   rng_plan rng,
                                                                    const int* __restrict__ offsets,
                                                                    ColT* __restrict__ dst,
                                                                    int* __restrict__ src_lid,
@@ -202,7 +205,10 @@ __global__ void __launch_bounds__(256) sample_uniform_block_kernel(const int64_t
   }
   for (int h = threadIdx.x; h < kHashSlots; h += blockDim.x) hkeys[h] = -1;
   if ((int)threadIdx.x < B) {
-    Pcg32 g(random_seed, stream_id(i, B, threadIdx.x));
+    uint64_t random_seed;
+    int i_local;
+    rng.resolve(i, random_seed, i_local);
+    Pcg32 g(random_seed, stream_id(i_local, B, threadIdx.x));
     for (int k = 0; k < items; k++) {
       int id = k * B + threadIdx.x;
       int v  = g.next_i31();
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(64) sample_uniform_reservoir_kernel(const int6
                                                                       const SeedT* __restrict__ seeds,
                                                                       dev_count n_,
                                                                       int M,
-                                                                      uint64_t random_seed,
+                                                                      rng_plan rng,
                                                                       const int* __restrict__ offsets,
                                                                       ColT* __restrict__ dst,
                                                                       int* __restrict__ src_lid,
@@ -255,7 +261,10 @@ __global__ void __launch_bounds__(64) sample_uniform_reservoir_kernel(const int6
   for (int s = threadIdx.x; s < M; s += blockDim.x) dst[base + s] = (ColT)s;
   __syncthreads();
   if (threadIdx.x < 32) {
-    Pcg32 g(random_seed, stream_id(i, 32, threadIdx.x));
+    uint64_t random_seed;
+    int i_local;
+    rng.resolve(i, random_seed, i_local);
+    Pcg32 g(random_seed, stream_id(i_local, 32, threadIdx.x));
     for (int idx = M + threadIdx.x; idx < N; idx += 32) {
       int rn = g.next_i31() % (idx + 1);
       if (rn < M) {
@@ -400,7 +409,7 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
 
 template <typename SeedT, typename ColT>
 void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds, dev_count n, int M,
-                    uint64_t random_seed, const int* offsets, ColT* dst, int* lid, int64_t* gid, hipStream_t stream)
+                    rng_plan random_seed, const int* offsets, ColT* dst, int* lid, int64_t* gid, hipStream_t stream)
 {
   const int cap = n.host;
   if (cap <= 0) return;
@@ -502,7 +511,7 @@ void run(const sample_args& a, bool weighted)
     return;
   }
   uniform_sample_enqueue(row_ptr, col, sizeof(ColT) == 8, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M,
-                         a.random_seed, offsets, dst, lid, gid, stream);
+                         rng_plan{a.random_seed, nullptr, nullptr, nullptr}, offsets, dst, lid, gid, stream);
   WG_HIP_CHECK(hipGetLastError());
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // outputs complete on return (reference contract)
 }
@@ -534,7 +543,7 @@ void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds6
 }
 
 void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
-                            dev_count n, int M, uint64_t random_seed, const int* offsets, void* dst, int* src_lid,
+                            dev_count n, int M, rng_plan random_seed, const int* offsets, void* dst, int* src_lid,
                             int64_t* edge_gid, hipStream_t stream)
 {
 #define WG_U(ST, CT)                                                                                               \

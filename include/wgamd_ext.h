@@ -118,6 +118,50 @@ wholememory_error_code_t wgamd_sample_hop_nosync(const int64_t* csr_row_ptr,
                                                  size_t workspace_bytes,
                                                  void* stream);
 
+/* The same hop for a CALL GROUP of n_batches mini-batches handled by one launch sequence (the
+ * idea of cugraph_pyg's local_seeds_per_call,
+ * /root/reference/python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:279-343): every
+ * launch carries G x the work, every mini-batch gets exactly the result a single-batch call with
+ * its own seed would produce (its PCG streams are numbered from the start of its own segment and
+ * it is renumbered on its own).
+ *   in : targets        concatenation of the batches' targets, batch b = [target_seg[b], target_seg[b+1])
+ *        target_batch   int32[target_cap]  batch of every target
+ *        target_seg     int32[n_batches+1] (device); target_seg[n_batches] = live target count
+ *        random_seeds_dev u64[n_batches]   (device) one sampling seed per mini-batch
+ *   out: offsets        int32[target_cap+1] global CSR row_ptr over all targets
+ *        neighbor_row   int32[edge_cap]  GLOBAL row (into `unique`) of every sampled edge's neighbour;
+ *                                        the per-batch local id is neighbor_row - unique_seg[b]
+ *        center_row     int32[edge_cap]  global target row of every sampled edge (required)
+ *        unique         ids[target_cap+edge_cap]  per-batch unique lists, concatenated: batch b =
+ *                                        [unique_seg[b], unique_seg[b+1]) = its targets ++ its new nodes;
+ *                                        slack padded with -1
+ *        unique_batch   int32[target_cap+edge_cap], unique_seg int32[n_batches+1]:
+ *                                        feed them back as target_batch / target_seg of the next hop
+ *        counts_dev     int32[2] {n_edges, n_unique}
+ * Workspace as for the single-batch hop. */
+wholememory_error_code_t wgamd_sample_hop_batched_nosync(const int64_t* csr_row_ptr,
+                                                         const void* csr_col,
+                                                         wholememory_dtype_t id_dtype,
+                                                         const void* targets,
+                                                         const int* target_batch,
+                                                         const int* target_seg,
+                                                         int n_batches,
+                                                         int64_t target_cap,
+                                                         int max_sample_count,
+                                                         const unsigned long long* random_seeds_dev,
+                                                         int* offsets,
+                                                         int* neighbor_row,
+                                                         int* center_row,
+                                                         int64_t* edge_gid,
+                                                         int64_t edge_cap,
+                                                         void* unique,
+                                                         int* unique_batch,
+                                                         int* unique_seg,
+                                                         int* counts_dev,
+                                                         void* workspace,
+                                                         size_t workspace_bytes,
+                                                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif
