@@ -66,13 +66,18 @@ def rmat_csr(n_nodes, n_undirected, seed, device, a=0.57, b=0.19, c=0.19):
 
 
 class SagePipeline:
-    """The measured hot path (one instance per rank)."""
+    """The measured hot path (one instance per rank).  Mini-batches are processed in CALL GROUPS of G
+    (cugraph_pyg's local_seeds_per_call idea): one launch sequence samples + renumbers G mini-batches
+    (each with its own seed, each renumbered on its own), then ONE gather / SpMM / GEMM runs over the
+    block-diagonal concatenation.  Groups are software-pipelined: the walk of group g+1 is enqueued
+    before the host reads the (tiny, pinned) size vector of group g, so the GPU queue never drains."""
 
-    def __init__(self, row_ptr, col, feat_table, device):
+    def __init__(self, row_ptr, col, feat_table, device, G):
         from wholegraph_amd import fused, nn
         self.nn = nn
         self.device = device
-        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, torch.int64)
+        self.G = G
+        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, torch.int64, G)
         self.feat = feat_table  # WholeMemoryTensor
         g = torch.Generator(device=device).manual_seed(1)
         self.conv1 = nn.SAGEConv(FEAT_DIM, HIDDEN).to(device)
@@ -80,41 +85,68 @@ class SagePipeline:
         for p in list(self.conv1.parameters()) + list(self.conv2.parameters()):
             p.data = (torch.rand(p.shape, generator=g, device=device) - 0.5) * 0.1
             p.requires_grad_(False)
-        self.caps = self.walk.target_caps + [self.walk.target_caps[-1] + self.walk.edge_caps[-1]]
-        self.x = torch.zeros((self.caps[2], FEAT_DIM), dtype=torch.float32, device=device)
-        self.edges = torch.zeros((), dtype=torch.int64, device=device)
+        self.w1r_t = self.conv1.lin_r.weight.t().contiguous()
+        self.w2r_t = self.conv2.lin_r.weight.t().contiguous()
         self.distributed = self.feat.is_distributed
 
-    def step(self, seeds, step_id, ev=None):
-        """ev: optional list collecting (name, start_event, end_event) per stage."""
+    def sample(self, seeds, group_id):
+        """Enqueue the walk of one call group + the async D2H of its sizes."""
+        hops = len(FANOUT)
+        rs = (torch.arange(self.G, device=self.device, dtype=torch.int64).view(1, -1) * hops
+              + torch.arange(hops, device=self.device, dtype=torch.int64).view(-1, 1)
+              + 62 + group_id * self.G * hops)          # seed of (hop k, batch b) = 62 + hops*global_batch + k
+        res = self.walk.run(seeds, rs)
+        sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
+        sizes_h.copy_(res.counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return res, sizes_h, ev
+
+    def forward(self, res, sizes_h, ev, timers=None):
+        """Feature fetch + 2-layer SAGE forward of one call group with exact (host-known) sizes."""
         nn = self.nn
+        ev.synchronize()
+        (e1, u1), (e2, u2) = sizes_h.tolist()   # hop-1 (seeds) edges/unique, hop-2 edges/unique
+        t0 = self.G * BATCH
 
         def stage(name, fn):
-            if ev is None:
+            if timers is None:
                 return fn()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             out = fn()
             e.record()
-            ev.append((name, s, e))
+            timers.append((name, s, e))
             return out
 
-        res = stage("walk(sample+renumber x2)", lambda: self.walk.run(seeds, [62 + 2 * step_id, 63 + 2 * step_id]))
-        n_id = res.unique[1]  # capacity-sized, -1 padded
+        n_id = res.unique[1][:u2]
         if self.distributed:
-            # remote rows come through the RCCL all-to-all pipeline, which needs exact counts
-            n_unique = int(res.counts[1, 1])
-            x = stage("gather(all-to-all)", lambda: self.feat.gather(n_id[:n_unique]))
+            x = stage("gather(all-to-all)", lambda: self.feat.gather(n_id))
         else:
             from wholegraph_amd.tensor import local_gather
-            x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id, self.x))
-        t1 = self.caps[1]
-        agg1 = stage("spmm1(mean,F=100)", lambda: nn.spmm_csr_forward(res.offsets[1], res.neighbor_lid[1], x, True))
-        h1 = stage("dense1", lambda: torch.relu(self.conv1.lin_l(agg1) + self.conv1.lin_r(x[:t1])))
-        agg2 = stage("spmm2(mean,F=256)", lambda: nn.spmm_csr_forward(res.offsets[0], res.neighbor_lid[0], h1, True))
-        out = stage("dense2", lambda: self.conv2.lin_l(agg2) + self.conv2.lin_r(h1[:BATCH]))
-        self.edges += res.counts[:, 0].sum()
-        return out, res
+            x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id,
+                                                     torch.empty((u2, FEAT_DIM), dtype=torch.float32, device=self.device)))
+        agg1 = stage("spmm1(mean,F=100)",
+                     lambda: nn.spmm_csr_forward(res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], x, True))
+
+        def dense1():
+            h = self.conv1.lin_l(agg1)
+            x_dst = x[res.target_rows_in_unique(1, u1)]   # "x[:num_dst]" of the block-diagonal layout
+            h.addmm_(x_dst, self.w1r_t)
+            return h.relu_()
+
+        h1 = stage("dense1", dense1)
+        agg2 = stage("spmm2(mean,F=256)",
+                     lambda: nn.spmm_csr_forward(res.offsets[0][:t0 + 1], res.neighbor_row[0][:e1], h1, True))
+
+        def dense2():
+            o = self.conv2.lin_l(agg2)
+            # the seeds of batch b are the first BATCH rows of its hop-1 unique list
+            seed_rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
+            return o.addmm_(h1[seed_rows], self.w2r_t)
+
+        out = stage("dense2", dense2)
+        return out, (e1, u1, e2, u2)
 
 
 def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
@@ -146,10 +178,11 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=640)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
     ap.add_argument("--edges", type=int, default=E_UNDIRECTED, help="undirected RMAT edges before symmetrising")
+    ap.add_argument("--call-group", type=int, default=16, help="max mini-batches per launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -177,29 +210,41 @@ def main():
         offs = equal_entry_partition(V, world)
         local = torch.rand((offs[rank + 1] - offs[rank], FEAT_DIM), generator=gfeat, device=device) * 2 - 1
         feat = WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)
-    pipe = SagePipeline(row_ptr, col, feat, device)
-
-    total = args.steps + args.warmup
+    # call group: the largest divisor of --steps not above --call-group
+    G = max(d for d in range(1, min(args.call_group, args.steps) + 1) if args.steps % d == 0)
+    pipe = SagePipeline(row_ptr, col, feat, device, G)
+    groups = args.steps // G
+    warm_groups = (args.warmup + G - 1) // G
+    total_groups = groups + warm_groups
     gseed = torch.Generator(device=device).manual_seed(7 + rank)  # every rank its own seed shard
-    reps = (total * BATCH + V - 1) // V
+    need = total_groups * G * BATCH
+    reps = (need + V - 1) // V
     order = torch.cat([torch.randperm(V, generator=gseed, device=device) for _ in range(reps)])
-    batches = order[: total * BATCH].view(total, BATCH).contiguous()
+    batches = order[:need].view(total_groups, G * BATCH).contiguous()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        pipe.step(batches[s], s)
-    pipe.edges.zero_()
+    def run_groups(first, last, timers=None, sizes=None):
+        """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
+        pending = pipe.sample(batches[first], first)
+        for g in range(first, last):
+            nxt = pipe.sample(batches[g + 1], g + 1) if g + 1 < last else None
+            _, sz = pipe.forward(*pending, timers=timers)
+            if sizes is not None:
+                sizes.append(sz)
+            pending = nxt
+
+    run_groups(0, warm_groups)
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.warmup, total):
-        pipe.step(batches[s], s)
+    sizes = []
+    run_groups(warm_groups, total_groups, sizes=sizes)
     barrier()
     dt = time.perf_counter() - t0
-    edges_local = int(pipe.edges)
+    edges_local = sum(s[0] + s[2] for s in sizes)
 
     stats = torch.tensor([dt, float(edges_local)], dtype=torch.float64, device=device)
     if world > 1:
@@ -213,23 +258,26 @@ def main():
 
     # ---- per-stage HIP-event timing pass (same pipeline, same stream; after the timed region) --
     stage_ms, stage_n = {}, 0
-    e_hop = torch.zeros(2, dtype=torch.float64)
-    n_unique = 0.0
-    probe_steps = min(args.steps, 50)
-    for s in range(args.warmup, args.warmup + probe_steps):
-        ev = []
-        _, res = pipe.step(batches[s], s, ev)
+    probe = min(groups, 20)
+    psizes = []
+    for g in range(warm_groups, warm_groups + probe):
+        timers = []
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
+        pend = pipe.sample(batches[g], g)
+        w1.record()
+        _, sz = pipe.forward(*pend, timers=timers)
         torch.cuda.synchronize()
-        for name, a, b in ev:
+        timers.append(("walk(sample+renumber x2)", w0, w1))
+        for name, a, b in timers:
             stage_ms[name] = stage_ms.get(name, 0.0) + a.elapsed_time(b)
-        c = res.counts.cpu().double()
-        e_hop += c[:, 0]
-        n_unique += float(c[1, 1])
+        psizes.append(sz)
         stage_n += 1
-    stage_ms = {k: v / stage_n for k, v in stage_ms.items()}
-    e1, e2 = (e_hop / stage_n).tolist()       # hop-1 (seeds) and hop-2 edges per batch
-    n_src = n_unique / stage_n
-    n_dst1 = float(res.counts[0, 1])           # frontier after hop 1 (rows of the layer-1 SpMM)
+    stage_ms = {k: v / stage_n for k, v in stage_ms.items()}         # per call group
+    e1 = sum(s[0] for s in psizes) / stage_n                         # per call group
+    n_dst1 = sum(s[1] for s in psizes) / stage_n
+    e2 = sum(s[2] for s in psizes) / stage_n
+    n_src = sum(s[3] for s in psizes) / stage_n
 
     if rank == 0:
         # algorithmic bytes per launch; b = 8-byte ids, fp32 features
@@ -237,7 +285,7 @@ def main():
         kernels = {
             "gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F)),
             "spmm1(mean,F=100)": ("spmm_csr_kernel", e2 * (4 * F + 4) + n_dst1 * (4 * F + 8)),
-            "spmm2(mean,F=256)": ("spmm_csr_kernel", e1 * (4 * HIDDEN + 4) + BATCH * (4 * HIDDEN + 8)),
+            "spmm2(mean,F=256)": ("spmm_csr_kernel", e1 * (4 * HIDDEN + 4) + G * BATCH * (4 * HIDDEN + 8)),
         }
         dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
         roofline = None
@@ -247,15 +295,15 @@ def main():
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                         "traffic": None, "algorithmic_bytes_per_launch": int(kernels[dom][1]),
                         "avg_launch_ms": round(stage_ms[dom], 5),
-                        "timing": "HIP events around the launch on the launch stream, per-step, averaged over "
-                                  f"{stage_n} steps"}
+                        "timing": "HIP events around the launch on the launch stream, one launch per call group of "
+                                  f"{G} mini-batches, averaged over {stage_n} call groups"}
         spmm_gbps = None
         if "spmm1(mean,F=100)" in stage_ms:
             spmm_gbps = kernels["spmm1(mean,F=100)"][1] / (stage_ms["spmm1(mean,F=100)"] * 1e-3) / 1e9
         cpu = None
         if not args.no_cpu_baseline:
             nb = 64
-            cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()
+            cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()  # same seed stream, one mini-batch at a time
             if world > 1:
                 feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
             else:
@@ -276,13 +324,15 @@ def main():
             "dtype": "int64 ids + f32 features",
             "data": "synthetic",
             "config": {"workload": "ogbn-products-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
-                                   "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, 2-layer SAGEConv(mean) %d-%d-%d fwd"
+                                   "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, 2-layer SAGEConv(mean) %d-%d-%d fwd, "
+                                   "%d mini-batches per launch sequence (call group)"
                                    % (V, E, FEAT_DIM, "" if world == 1 else " range-partitioned + RCCL all-to-all",
-                                      BATCH, FANOUT, FEAT_DIM, HIDDEN, CLASSES),
+                                      BATCH, FANOUT, FEAT_DIM, HIDDEN, CLASSES, G),
                        "parallelism": "dp%d (seeds sharded, no data-path collective)" % world if world == 1
                        else "dp%d seeds + feature all-to-all" % world},
-            "edges_per_batch": {"hop1": e1, "hop2": e2, "unique_nodes": n_src},
-            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "call_group": G,
+            "edges_per_batch": {"hop1": e1 / G, "hop2": e2 / G, "unique_nodes": n_src / G},
+            "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
             "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
             "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
             "roofline": roofline,

@@ -33,6 +33,7 @@ class WalkResult:
     unique: List[torch.Tensor] = field(default_factory=list)
     unique_seg: List[torch.Tensor] = field(default_factory=list)   # int32 [G+1] per hop
     target_seg: List[torch.Tensor] = field(default_factory=list)   # int32 [G+1] per hop (input segments)
+    target_batch: List[torch.Tensor] = field(default_factory=list)  # int32 [target_cap] batch of every target
     offsets: List[torch.Tensor] = field(default_factory=list)      # int32 [target_cap+1]
     neighbor_row: List[torch.Tensor] = field(default_factory=list)  # int32 [edge_cap]
     center_row: List[torch.Tensor] = field(default_factory=list)    # int32 [edge_cap]
@@ -47,6 +48,13 @@ class WalkResult:
     @property
     def center_lid(self):
         return self.center_row
+
+    def target_rows_in_unique(self, k: int, n_targets: int) -> torch.Tensor:
+        """Row (in ``unique[k]``) of every hop-k target: target i of batch b sits at
+        ``i + (unique_seg[k][b] - target_seg[k][b])`` — the ``x[:num_dst]`` slice of the single-batch
+        layout becomes this index list in the block-diagonal one."""
+        shift = (self.unique_seg[k][:-1] - self.target_seg[k][:-1]).long()
+        return torch.arange(n_targets, device=shift.device) + shift[self.target_batch[k][:n_targets].long()]
 
     def finalize_batches(self):
         """One round of small D2H copies, then per mini-batch the reference tuple
@@ -151,6 +159,7 @@ class NoSyncWalk:
             res.unique.append(unique)
             res.unique_seg.append(u_seg)
             res.target_seg.append(t_seg)
+            res.target_batch.append(t_batch)
             res.offsets.append(offsets)
             res.neighbor_row.append(nbr_row)
             res.center_row.append(ctr_row)
