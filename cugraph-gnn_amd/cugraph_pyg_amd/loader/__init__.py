@@ -1,0 +1,2 @@
+from .neighbor_loader import NeighborLoader  # noqa: F401
+from .node_loader import NodeLoader  # noqa: F401

@@ -1,0 +1,49 @@
+"""Duck-typed ``torch_geometric.loader.NeighborLoader`` — the GraphSAGE neighbour-sampling loader
+(/root/reference/python/cugraph-pyg/cugraph_pyg/loader/neighbor_loader.py:20-236)."""
+import warnings
+from typing import Callable, Dict, List, Optional, Union
+
+from ..data.graph_store import GraphStore
+from ..sampler import BaseSampler, NeighborSampler
+from .node_loader import NodeLoader
+
+
+class NeighborLoader(NodeLoader):
+    def __init__(self, data, num_neighbors: Union[List[int], Dict], input_nodes=None, input_time=None,
+                 replace: bool = False, subgraph_type: str = "directional", disjoint: bool = False,
+                 temporal_strategy: str = "uniform", time_attr: Optional[str] = None,
+                 weight_attr: Optional[str] = None, transform: Optional[Callable] = None,
+                 transform_sampler_output: Optional[Callable] = None, is_sorted: bool = False,
+                 filter_per_worker: Optional[bool] = None, neighbor_sampler=None, directed: bool = True,
+                 batch_size: int = 16, compression: Optional[str] = None,
+                 local_seeds_per_call: Optional[int] = None, temporal_comparison: Optional[str] = None, **kwargs):
+        subgraph_type = getattr(subgraph_type, "value", subgraph_type)
+        if not directed:
+            subgraph_type = "induced"
+            warnings.warn("The 'directed' argument is deprecated. Use subgraph_type='induced' instead.")
+        if subgraph_type != "directional":
+            raise ValueError("Only directional subgraphs are currently supported")
+        if temporal_strategy != "uniform":
+            warnings.warn("Only the uniform temporal strategy is currently supported")
+        if neighbor_sampler is not None:
+            raise ValueError("Passing a neighbor sampler is currently unsupported")
+        if is_sorted:
+            warnings.warn("The 'is_sorted' argument is ignored by cuGraph.")
+        if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
+            raise NotImplementedError("Currently can't accept non-cugraph graphs")
+        feature_store, graph_store = data
+        if compression is not None and compression not in ["CSR", "COO"]:
+            raise ValueError("Invalid value for compression (expected 'CSR' or 'COO')")
+        if not graph_store.is_homogeneous or isinstance(num_neighbors, dict):
+            raise NotImplementedError("heterogeneous sampling is not implemented yet (SURVEY.md §8(f) rank 2)")
+        if time_attr is not None:
+            raise NotImplementedError("temporal sampling is not implemented yet (SURVEY.md §8(f) rank 2)")
+        if weight_attr is not None:
+            graph_store._set_weight_attr((feature_store, weight_attr))
+        sampler = BaseSampler(
+            NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
+                            with_replacement=replace, disjoint=disjoint, heterogeneous=False, temporal=False),
+            (feature_store, graph_store), batch_size=batch_size)
+        super().__init__((feature_store, graph_store), sampler, input_nodes=input_nodes, input_time=input_time,
+                         transform=transform, transform_sampler_output=transform_sampler_output,
+                         filter_per_worker=filter_per_worker, batch_size=batch_size, **kwargs)
