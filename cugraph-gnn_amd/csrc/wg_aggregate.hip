@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
                                                        int mean,
                                                        float* __restrict__ out,
                                                        int64_t ldo,
-                                                       int log2_lanes)
+                                                       int log2_lanes,
+                                                       const int64_t* __restrict__ self_rows)
 {
   const int lanes       = 1 << log2_lanes;
   const int lane        = threadIdx.x & 63;
@@ -115,6 +116,15 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
           *reinterpret_cast<float4*>(q) = make_float4(acc[0] / denom, acc[1] / denom, acc[2] / denom, acc[3] / denom);
         } else {
           q[0] = acc[0] / denom;
+        }
+        if (self_rows != nullptr) {
+          // SAGEConv root term: out[row, F:2F] = x[self_rows[row], :]  ->  one GEMM over [mean | self]
+          const float* p = x + self_rows[row] * ldx + f0;
+          if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(q + F) = *reinterpret_cast<const float4*>(p);
+          } else {
+            q[F] = p[0];
+          }
         }
       }
     }
@@ -257,13 +267,13 @@ inline bool vec4_ok(const void* a, int64_t lda, const void* b, int64_t ldb, int 
 
 extern "C" {
 
-wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                            int64_t ldx, int F, const void* src_ids,
-                                            wholememory_dtype_t src_ids_dtype, int mean, float* out, int64_t ldo,
-                                            void* stream)
+static wholememory_error_code_t spmm_entry(const char* name, const int* row_ptr, const int* col, int64_t n_rows,
+                                           const float* x, int64_t ldx, int F, const void* src_ids,
+                                           wholememory_dtype_t src_ids_dtype, int mean, float* out, int64_t ldo,
+                                           const int64_t* self_rows, void* stream)
 {
   using namespace wgamd;
-  return guarded("wgamd_spmm_csr_f32", [&] {
+  return guarded(name, [&] {
     WG_REQUIRE_INPUT(n_rows >= 0 && F > 0, "bad sizes");
     if (n_rows == 0) return;
     WG_REQUIRE_INPUT(row_ptr && col && x && out, "null pointer");
@@ -274,7 +284,7 @@ wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr, const int* col, 
     const int l2   = lanes_log2_for(v4 ? F / 4 : F);
     const int grid = grid_rows(n_rows, l2);
 #define WG_SPMM(VEC, IDT, IDP) \
-  spmm_csr_kernel<VEC, IDT><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, IDP, mean, out, ldo, l2)
+  spmm_csr_kernel<VEC, IDT><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, IDP, mean, out, ldo, l2, self_rows)
     if (src_ids == nullptr) {
       if (v4) WG_SPMM(4, void, (const void*)nullptr); else WG_SPMM(1, void, (const void*)nullptr);
     } else if (src_ids_dtype == WHOLEMEMORY_DT_INT) {
@@ -285,6 +295,27 @@ wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr, const int* col, 
 #undef WG_SPMM
     WG_HIP_CHECK(hipGetLastError());
   });
+}
+
+wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                            int64_t ldx, int F, const void* src_ids,
+                                            wholememory_dtype_t src_ids_dtype, int mean, float* out, int64_t ldo,
+                                            void* stream)
+{
+  return spmm_entry("wgamd_spmm_csr_f32", row_ptr, col, n_rows, x, ldx, F, src_ids, src_ids_dtype, mean, out, ldo,
+                    nullptr, stream);
+}
+
+wholememory_error_code_t wgamd_sage_aggregate_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                  int64_t ldx, int F, const int64_t* self_rows, int mean, float* out,
+                                                  int64_t ldo, void* stream)
+{
+  if (self_rows == nullptr || ldo < 2 * (int64_t)F) {
+    fprintf(stderr, "[wholegraph_amd] wgamd_sage_aggregate_f32: self_rows is NULL or ldo < 2F\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  return spmm_entry("wgamd_sage_aggregate_f32", row_ptr, col, n_rows, x, ldx, F, nullptr, WHOLEMEMORY_DT_UNKNOWN,
+                    mean, out, ldo, self_rows, stream);
 }
 
 wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows,

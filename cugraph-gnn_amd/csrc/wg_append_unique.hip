@@ -48,9 +48,23 @@ __device__ __forceinline__ uint32_t hash_key(uint64_t k)
   return (uint32_t)(k ^ (k >> 32));
 }
 
-template <typename TableKeyT>
-__global__ void __launch_bounds__(256) table_clear_kernel(TableKeyT* keys, int* minpos, int64_t slots)
+// The table buffer is sized for the CAPACITY of the call (no host sync => worst case), but only a
+// power-of-two prefix sized for the LIVE element count is used: a call group that fills a third of
+// its capacity then touches a third of the memory (less to clear, and the random probes of the
+// insert stay inside a footprint the 256 MB Infinity Cache holds).
+__device__ __forceinline__ uint32_t live_slot_mask(int live_elements, int64_t capacity_slots)
 {
+  uint32_t want = 2u * (uint32_t)(live_elements > 512 ? live_elements : 512);
+  uint32_t s    = 1u << (32 - __clz((int)(want - 1u)));  // next power of two >= want
+  if ((int64_t)s > capacity_slots) s = (uint32_t)capacity_slots;
+  return s - 1u;
+}
+
+template <typename TableKeyT>
+__global__ void __launch_bounds__(256)
+table_clear_kernel(TableKeyT* keys, int* minpos, int64_t capacity_slots, dev_count T_, dev_count E_)
+{
+  const int64_t slots = (int64_t)live_slot_mask(T_.get() + E_.get(), capacity_slots) + 1;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < slots) {
     keys[i]   = (TableKeyT)-1;
@@ -74,11 +88,12 @@ __global__ void __launch_bounds__(256) table_insert_kernel(const KeyT* __restric
                                                            batch_view bv,
                                                            TableKeyT* keys,
                                                            int* minpos,
-                                                           uint32_t slot_mask,
+                                                           int64_t capacity_slots,
                                                            int* __restrict__ slot_of)
 {
   using cas_t = typename key_traits<TableKeyT>::cas_t;
   const int T = T_.get(), E = E_.get();
+  const uint32_t slot_mask = live_slot_mask(T + E, capacity_slots);
   int p       = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= T + E) return;
   KeyT id       = p < T ? targets[p] : neighbors[p - T];
@@ -209,10 +224,10 @@ void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_coun
                int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
 {
   const int P = T.host + E.host;
-  table_clear_kernel<TableKeyT><<<ceil_div(slots, 256), 256, 0, stream>>>(keys, minpos, slots);
+  table_clear_kernel<TableKeyT><<<ceil_div(slots, 256), 256, 0, stream>>>(keys, minpos, slots, T, E);
   if (P > 0)
     table_insert_kernel<KeyT, TableKeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, keys,
-                                                                              minpos, (uint32_t)(slots - 1), slot_of);
+                                                                              minpos, slots, slot_of);
   if (E.host > 0) first_flag_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(minpos, slot_of, T, E, rank);
   WG_HIP_CHECK(hipGetLastError());
   exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream);  // flags -> ranks, rank[E.host] = #new nodes

@@ -15,6 +15,42 @@
 
 namespace wgamd {
 
+// ---- jump tables -----------------------------------------------------------------------------
+// Jumping an LCG  s -> A*s + inc  ahead by n draws is the affine map  s -> A^n * s + inc * S(n),
+// S(n) = 1 + A + ... + A^(n-1)  (mod 2^64), and  (A^m, S(m)) o (A^n, S(n)) = (A^m A^n, S(m) A^n + S(n)).
+// Neither A^n nor S(n) depends on the stream (inc), so they can be tabulated once: with n written
+// in base 256, n = c0 + c1*256 + c2*256^2 + c3*256^3, four lookups and three compositions replace
+// the ~4*log2(n) dependent 64-bit multiplies of the generic jump loop — that loop was >50 % of the
+// M <= 32 sampling kernel's issue cycles (64-bit multiplies are quarter-rate on CDNA).
+struct PcgJump {
+  uint64_t a;  // A^n
+  uint64_t s;  // S(n)
+};
+
+struct PcgJumpTables {
+  PcgJump t[4][256];
+  constexpr PcgJumpTables() : t{}
+  {
+    uint64_t base_a = 6364136223846793005ULL, base_s = 1;  // jump by 256^k, k = 0
+    for (int k = 0; k < 4; k++) {
+      t[k][0].a = 1;
+      t[k][0].s = 0;
+      for (int c = 1; c < 256; c++) {
+        t[k][c].a = t[k][c - 1].a * base_a;
+        t[k][c].s = t[k][c - 1].s * base_a + base_s;
+      }
+      // (base)^256 by eight doublings:  (a, s) o (a, s) = (a*a, s*a + s)
+      for (int d = 0; d < 8; d++) {
+        uint64_t na = base_a * base_a, ns = base_s * base_a + base_s;
+        base_a = na;
+        base_s = ns;
+      }
+    }
+  }
+};
+
+__device__ __constant__ const PcgJumpTables g_pcg_jump{};
+
 struct Pcg32 {
   uint64_t state;
   uint64_t inc;
@@ -55,6 +91,26 @@ struct Pcg32 {
     state += seed;
     (void)next_u32();
     skipahead(subsequence);
+  }
+
+  // Same generator as Pcg32(seed, subsequence) for 0 <= subsequence < 2^31, via the jump tables.
+  struct table_tag {};
+  __device__ __forceinline__ Pcg32(uint64_t seed, uint32_t subsequence, table_tag)
+  {
+    inc   = ((uint64_t)subsequence << 1u) | 1u;
+    // two plain steps from state 0 with `seed` added in between:  ((0*A + inc) + seed)*A + inc
+    state = (inc + seed) * kMult + inc;
+    PcgJump j = g_pcg_jump.t[0][subsequence & 255u];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const uint32_t c = (subsequence >> (8 * k)) & 255u;
+      if (c) {
+        const PcgJump n = g_pcg_jump.t[k][c];
+        j.s             = j.s * n.a + n.s;
+        j.a             = j.a * n.a;
+      }
+    }
+    state = j.a * state + inc * j.s;
   }
 
   __host__ __device__ __forceinline__ int32_t next_i31() { return (int32_t)(next_u32() & 0x7fffffffu); }

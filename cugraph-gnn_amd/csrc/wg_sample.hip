@@ -128,8 +128,17 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
     uint64_t random_seed;
     int i_local;
     rng.resolve(i, random_seed, i_local);
-    Pcg32 g(random_seed, stream_id(i_local, 32, hl));
-    r = g.next_i31() % (N - hl);
+    // stream index = i_local*32 + lane; the table jump covers every index below 2^31, the generic
+    // loop keeps the reference's sign-extension semantics beyond that
+    int32_t r_draw;
+    if (i_local < (1 << 26)) {
+      Pcg32 g(random_seed, (uint32_t)(i_local * 32 + hl), Pcg32::table_tag{});
+      r_draw = g.next_i31();
+    } else {
+      Pcg32 g(random_seed, stream_id(i_local, 32, hl));
+      r_draw = g.next_i31();
+    }
+    r = r_draw % (N - hl);
   }
   // Fisher-Yates:  a[t] = Q[r_t];  Q[r_t] = Q[N-t-1].  Lane s remembers (pos=r_s, val=the value
   // step s stored there).

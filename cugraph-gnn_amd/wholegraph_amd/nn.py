@@ -41,6 +41,21 @@ def spmm_csr_forward(row_ptr, col, x, mean=True, src_ids=None, out=None):
     return out
 
 
+def sage_aggregate_forward(row_ptr, col, x, self_rows, mean=True):
+    """-> [n_rows, 2F] = [ mean_{e in row i} x[col[e]] | x[self_rows[i]] ]  (one kernel; feeds ONE GEMM with
+    the concatenated weight [W_l | W_r])."""
+    _check_csr(row_ptr, col)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    assert self_rows.dtype == torch.int64 and self_rows.is_contiguous()
+    n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
+    assert self_rows.shape[0] == n_rows
+    out = torch.empty((n_rows, 2 * F_), dtype=torch.float32, device=x.device)
+    L.check(L.lib().wgamd_sage_aggregate_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_,
+                                             self_rows.data_ptr(), int(bool(mean)), out.data_ptr(), out.stride(0),
+                                             get_stream()), "wgamd_sage_aggregate_f32")
+    return out
+
+
 class _SpmmCsr(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, row_ptr, col, mean):

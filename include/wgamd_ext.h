@@ -47,6 +47,24 @@ wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr,
                                             int64_t ldo,
                                             void* stream);
 
+/* SAGEConv input builder: the mean (or sum) aggregate AND the root term side by side, so that
+ *   lin_l(mean_j x_j) + lin_r(x_i)  is ONE dense GEMM  [agg | x_self] @ [W_l | W_r]^T :
+ *   out[i, 0:F]  = REDUCE_{e in row i} x[col[e], :]
+ *   out[i, F:2F] = x[self_rows[i], :]
+ * self_rows int64[n_rows] = row of destination i inside x (i itself for a single mini-batch, the
+ * block-diagonal row for a call group); ldo >= 2F. */
+wholememory_error_code_t wgamd_sage_aggregate_f32(const int* row_ptr,
+                                                  const int* col,
+                                                  int64_t n_rows,
+                                                  const float* x,
+                                                  int64_t ldx,
+                                                  int F,
+                                                  const int64_t* self_rows,
+                                                  int mean,
+                                                  float* out,
+                                                  int64_t ldo,
+                                                  void* stream);
+
 /* Backward of the above w.r.t. x (src_ids == NULL form):
  *   grad_x[col[e], :] += grad_out[i, :] * (mean ? 1/max(deg_i,1) : 1)   for every edge e of row i.
  * grad_x must be zero-initialised (or hold the gradient to accumulate into) by the caller. */

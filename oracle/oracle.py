@@ -22,7 +22,7 @@ __all__ = [
     "build", "lib", "pcg_raw_u32", "generate_random_positive_int",
     "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets",
     "unweighted_sample", "weighted_sample", "append_unique", "csr_add_self_loop",
-    "multilayer_sample", "gather", "scatter", "spmm_csr", "gat_csr", "num_threads",
+    "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "num_threads",
     "set_num_threads", "py_pcg_u32_stream", "py_unweighted_sample_small",
 ]
 
@@ -267,6 +267,17 @@ def gather(table, idx, out=None, out_dtype=None):
     o2 = out if two_d else out[:, None]
     ok = idx >= 0
     o2[ok] = t2[idx[ok]].astype(o2.dtype)
+    return out
+
+
+def gather_rows(table, idx):
+    """Same-dtype row gather through the C kernel (OpenMP over rows) — used by the CPU baseline."""
+    table = np.ascontiguousarray(table)
+    idx = _c(idx)
+    out = np.empty((idx.size,) + table.shape[1:], dtype=table.dtype)
+    row_bytes = table.dtype.itemsize * int(np.prod(table.shape[1:], dtype=np.int64))
+    lib().wgo_gather_rows(_p(table), i64(row_bytes), _p(idx), cint(_is64(idx)), i64(idx.size), i64(row_bytes),
+                          _p(out), i64(row_bytes))
     return out
 
 

@@ -278,7 +278,7 @@ static void wgo_uniform_one(const int64_t* row_ptr,
   }
   int f = (M - 1) / 32;
   int B = k_warp_count[f] * 32, items = k_items[f];
-  int32_t* r = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > B * items ? N : B * items));
+  int32_t* r = (int32_t*)malloc(sizeof(int32_t) * (size_t)(B * items));
   for (int j = 0; j < B; j++) {
     wgo_pcg_t g;
     /* device: int gidx = threadIdx.x + blockIdx.x*blockDim.x; PCGenerator(rngstate,(uint64_t)gidx) */
@@ -286,12 +286,31 @@ static void wgo_uniform_one(const int64_t* row_ptr,
     for (int k = 0; k < items; k++) {
       int id     = k * B + j;
       int32_t rn = wgo_pcg_i31(&g);
-      if (id < N) r[id] = id < M ? rn % (N - id) : N;
+      if (id < M && id < N) r[id] = rn % (N - id); /* draws with id >= M are made and discarded */
     }
   }
   int* a = (int*)malloc(sizeof(int) * (size_t)M);
-  int* Q = (int*)malloc(sizeof(int) * (size_t)N);
-  wgo_swap_table_select(a, r, M, N, Q);
+  int* Q = NULL;
+  if (M <= 128 && N > 8 * M) {
+    /* Same selection without materialising Q[0..N): only the <= M positions written so far can
+     * differ from the identity, so keep them in a small list (latest write wins).  Identical
+     * result; keeps the CPU baseline from paying O(deg) per hub. */
+    int wpos[128], wval[128], nw = 0;
+    for (int t = 0; t < M; t++) {
+      int rt = r[t], tail = N - t - 1, q_rt = rt, q_tail = tail;
+      for (int s = nw - 1; s >= 0; s--)
+        if (wpos[s] == rt) { q_rt = wval[s]; break; }
+      for (int s = nw - 1; s >= 0; s--)
+        if (wpos[s] == tail) { q_tail = wval[s]; break; }
+      a[t]     = q_rt;
+      wpos[nw] = rt;
+      wval[nw] = q_tail;
+      nw++;
+    }
+  } else {
+    Q = (int*)malloc(sizeof(int) * (size_t)N);
+    wgo_swap_table_select(a, r, M, N, Q);
+  }
   for (int t = 0; t < M; t++) {
     wgo_set(dst, col_is64, out_base + t, wgo_idx(col, col_is64, start + a[t]));
     if (src_lid) src_lid[out_base + t] = (int32_t)i;

@@ -99,3 +99,17 @@ def test_sage_and_gat_layers_train_step(hiplib):
     assert z.shape == (300, 64)
     (y.sum() + z.sum()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in list(sage.parameters()) + list(gat.parameters()))
+
+
+@pytest.mark.parametrize("F", [100, 256, 7])
+def test_sage_aggregate_concat_self(oracle_mod, hiplib, F):
+    import torch
+    from wholegraph_amd import nn
+    rp, col = _csr(2000, 6000, 25, F + 1)
+    x = np.random.default_rng(F).standard_normal((6000, F)).astype(np.float32)
+    self_rows = np.random.default_rng(1).integers(0, 6000, 2000).astype(np.int64)
+    out = nn.sage_aggregate_forward(torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(x).cuda(),
+                                    torch.from_numpy(self_rows).cuda(), True).cpu().numpy()
+    assert out.shape == (2000, 2 * F)
+    assert np.array_equal(out[:, :F], oracle_mod.spmm_csr(rp, col, x, mean=True, acc_double=False))
+    assert np.array_equal(out[:, F:], x[self_rows])
