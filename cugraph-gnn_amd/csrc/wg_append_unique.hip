@@ -122,9 +122,11 @@ first_flag_kernel(const int* __restrict__ minpos, const int* __restrict__ slot_o
                   int* __restrict__ flag)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E_.host) return;
+  const int E = E_.get();
+  // the scan reads whole tiles: zero-fill the slack of the tile that holds the live end, skip the rest
+  if (e >= E_.host || e >= (E / kScanTile + 1) * kScanTile) return;
   const int T = T_.get();
-  flag[e] = (e < E_.get() && minpos[slot_of[T + e]] == T + e) ? 1 : 0;  // capacity slack -> 0
+  flag[e] = (e < E && minpos[slot_of[T + e]] == T + e) ? 1 : 0;
 }
 
 template <typename KeyT>
@@ -230,7 +232,7 @@ void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_coun
                                                                               minpos, slots, slot_of);
   if (E.host > 0) first_flag_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(minpos, slot_of, T, E, rank);
   WG_HIP_CHECK(hipGetLastError());
-  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream);  // flags -> ranks, rank[E.host] = #new nodes
+  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);  // flags -> ranks, rank[E.host] = #new nodes
 }
 
 }  // namespace

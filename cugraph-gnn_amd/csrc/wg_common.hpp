@@ -193,9 +193,13 @@ struct rng_plan {
 
 // ---- device-side utilities implemented in wg_scan.hip ---------------------------------------
 // out[0..n] (n+1 entries) = exclusive scan of in[0..n-1]; out[n] = total. in/out may alias.
-// `tmp` needs scan_tmp_ints(n) ints.
+// `tmp` needs scan_tmp_ints(n) ints.  With `n_live_dev` (device int, <= n) the inputs past the live
+// count must be zero up to the end of the tile holding it; outputs are then defined for
+// [0, *n_live_dev] and at [n] only, and tiles past the live count cost no memory traffic.
 int64_t scan_tmp_ints(int64_t n);
-void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream);
+constexpr int kScanTile = 2048;
+void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream,
+                        const int* n_live_dev = nullptr);
 
 
 // ---- building blocks shared by the ABI ops and the no-sync walk (wg_fused.hip) -----------------

@@ -91,7 +91,7 @@ void run_hop(hop_args a)
 
   dev_count T{(int)a.target_cap, a.n_targets_dev};
   sample_count_enqueue(a.csr_row_ptr, a.targets, i64, T, a.M, cnt, nullptr, st);
-  exclusive_scan_i32(cnt, a.offsets, a.target_cap, scan_tmp, st);  // slack rows add 0: offsets[cap] = #edges
+  exclusive_scan_i32(cnt, a.offsets, a.target_cap, scan_tmp, st, a.n_targets_dev);  // offsets[cap] = #edges
   uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, a.targets, i64, T, a.M, a.rng, a.offsets, nbr, a.center_row,
                          a.edge_gid, st);
   dev_count E{(int)a.edge_cap, a.offsets + a.target_cap};

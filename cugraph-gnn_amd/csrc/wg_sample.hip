@@ -71,7 +71,9 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_.host) return;
-  if (i >= n_.get()) {  // capacity slack of the no-sync walk: contributes nothing to the scan
+  const int n_live = n_.get();
+  if (i >= n_live) {  // capacity slack of the no-sync walk: zero the rest of the live scan tile only
+    if (i >= (n_live / kScanTile + 1) * kScanTile) return;
     cnt[i] = 0;
     if (big_deg) big_deg[i] = 0;
     return;
@@ -140,28 +142,28 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
     }
     r = r_draw % (N - hl);
   }
-  // Fisher-Yates:  a[t] = Q[r_t];  Q[r_t] = Q[N-t-1].  Lane s remembers (pos=r_s, val=the value
-  // step s stored there).
-  int val = 0, a = 0;
-  for (int t = 0; t < M; t++) {
-    const int rt    = __shfl(r, hb | t, 64);
-    const int tail  = N - t - 1;
-    const bool done = hl < t;  // steps already executed
-    uint64_t m1     = __ballot(done && r == rt);
-    uint64_t m2     = __ballot(done && r == tail);
-    uint32_t h1     = (uint32_t)(m1 >> hb);
-    uint32_t h2     = (uint32_t)(m2 >> hb);
-    int s1          = hb | (31 - __clz((int)h1));
-    int s2          = hb | (31 - __clz((int)h2));
-    int v1          = __shfl(val, s1 & 63, 64);
-    int v2          = __shfl(val, s2 & 63, 64);
-    int q_rt        = h1 ? v1 : rt;
-    int q_tail      = h2 ? v2 : tail;
-    if (hl == t) {
-      a   = q_rt;
-      val = q_tail;
-    }
+  // Fisher-Yates:  a[t] = Q[r_t];  Q[r_t] = Q[N-t-1], resolved WITHOUT walking the M steps in order.
+  // Step t writes position r_t with the value it found at position N-t-1.  For lane t let
+  //   p1 = latest step s < t that wrote position r_t      (r_s == r_t),
+  //   p2 = latest step s < t that wrote position N-t-1    (r_s == N-t-1).
+  // Then  val_t = (p2 exists) ? val_{p2} : N-t-1  is a chain that always ends at a step with no
+  // earlier write, so val_t = N - root(t) - 1 with root found by pointer jumping (ceil(log2 M)
+  // rounds), and  a_t = (p1 exists) ? val_{p1} : r_t.  All-pairs compare = M-1 independent
+  // bpermutes instead of 3M dependent ones.
+  const int tail = N - hl - 1;
+  int p1 = -1, p2 = -1;
+  for (int s = 0; s + 1 < M; s++) {
+    const int rs    = __shfl(r, hb | s, 64);
+    const bool prev = s < hl;
+    p1 = (prev && rs == r) ? s : p1;
+    p2 = (prev && rs == tail) ? s : p2;
   }
+  int root = p2 >= 0 ? p2 : hl;
+#pragma unroll
+  for (int round = 0; round < 5; round++) root = __shfl(root, hb | root, 64);
+  const int val = N - root - 1;
+  const int vp1 = __shfl(val, hb | (p1 & 31), 64);
+  const int a   = p1 >= 0 ? vp1 : r;
   if (pick) {
     if (hl < M) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + a], i, start + a);
   } else if (hl < N) {

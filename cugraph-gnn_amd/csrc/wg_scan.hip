@@ -13,6 +13,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kItems   = 8;
 constexpr int kTile    = kThreads * kItems;  // 2048 ints = 8 KiB per workgroup
+static_assert(kTile == kScanTile, "wg_common.hpp publishes the tile size to the kernels that zero-fill scan inputs");
 
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {
@@ -79,8 +80,19 @@ __global__ void __launch_bounds__(kThreads) scan_single_kernel(const int* in, in
   if (threadIdx.x == 0) out[n] = total;
 }
 
-__global__ void __launch_bounds__(kThreads) scan_tile_sums_kernel(const int* in, int64_t n, int* sums)
+// `live` (device count, may be null): only tiles that hold live elements do any memory traffic;
+// slack tiles contribute 0 without being read (the no-sync walk scans capacity-sized arrays).
+__device__ __forceinline__ bool tile_is_live(dev_count live, unsigned tile)
 {
+  return live.dev == nullptr || (int64_t)tile * kTile <= (int64_t)live.get();
+}
+
+__global__ void __launch_bounds__(kThreads) scan_tile_sums_kernel(const int* in, int64_t n, int* sums, dev_count live)
+{
+  if (!tile_is_live(live, blockIdx.x)) {
+    if (threadIdx.x == 0) sums[blockIdx.x] = 0;
+    return;
+  }
   int x[kItems];
   load_tile(in, (int64_t)blockIdx.x * kTile, n, x);
   int s = 0;
@@ -107,8 +119,10 @@ __global__ void __launch_bounds__(kThreads) scan_sums_kernel(int* sums, int64_t 
 }
 
 __global__ void __launch_bounds__(kThreads)
-scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int64_t m)
+scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int64_t m, dev_count live)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[m];
+  if (!tile_is_live(live, blockIdx.x)) return;
   int x[kItems];
   int64_t base = (int64_t)blockIdx.x * kTile;
   load_tile(in, base, n, x);
@@ -123,24 +137,24 @@ scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int6
     if (p + k < n) out[p + k] = run;
     run += x[k];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[m];
 }
 
 }  // namespace
 
 int64_t scan_tmp_ints(int64_t n) { return (n + kTile - 1) / kTile + 2; }
 
-void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream)
+void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream, const int* n_live_dev)
 {
+  dev_count live{(int)n, n_live_dev};
   if (n <= kTile) {
     scan_single_kernel<<<1, kThreads, 0, stream>>>(in, out, n);
   } else {
     int64_t m = (n + kTile - 1) / kTile;
-    scan_tile_sums_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, n, tmp);
+    scan_tile_sums_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, n, tmp, live);
     scan_sums_kernel<<<1, kThreads, 0, stream>>>(tmp, m);
     // in-place is safe: every tile reads its inputs into registers before writing them back,
     // and out[n] is written from tmp, not from `in`.
-    scan_tile_final_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, out, n, tmp, m);
+    scan_tile_final_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, out, n, tmp, m, live);
   }
   WG_HIP_CHECK(hipGetLastError());
 }
