@@ -23,6 +23,8 @@ for p in (ROOT, os.path.join(ROOT, "cugraph-gnn_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline: no spinning OpenMP workers (read at libgomp load)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -151,11 +153,26 @@ class SagePipeline:
         return out, (e1, u1, e2, u2)
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (a container that
+    reports 128 cores but is throttled to a few makes spinning OpenMP threads stall for tens of ms)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
     """The C oracle (OpenMP over seeds) + torch-CPU dense layers on the same workload, bounded."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # must be set before libgomp is loaded by the oracle
     import oracle
     oracle.build()
-    threads = oracle.num_threads()
+    threads = usable_cpus()
+    oracle.set_num_threads(threads)
     torch.set_num_threads(max(1, threads))
     (w1l, b1l, w1r), (w2l, b2l, w2r) = weights
     t0 = time.perf_counter()
@@ -184,7 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
     ap.add_argument("--edges", type=int, default=E_UNDIRECTED, help="undirected RMAT edges before symmetrising")
-    ap.add_argument("--call-group", type=int, default=16, help="max mini-batches per launch sequence")
+    ap.add_argument("--call-group", type=int, default=64, help="max mini-batches per launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -306,7 +323,7 @@ def main():
             spmm_gbps = kernels["spmm1(mean,F=100)+self"][1] / (stage_ms["spmm1(mean,F=100)+self"] * 1e-3) / 1e9
         cpu = None
         if not args.no_cpu_baseline:
-            nb = 64
+            nb = min(2048, order.numel() // BATCH)   # time-bounded inside cpu_baseline (--cpu-budget seconds)
             cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()  # same seed stream, one mini-batch at a time
             if world > 1:
                 feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
