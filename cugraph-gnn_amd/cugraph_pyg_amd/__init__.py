@@ -1,7 +1,7 @@
 """cugraph_pyg_amd — the PyG-facing plugin surface (GraphStore / FeatureStore / NeighborLoader /
 sampler) of ``cugraph_pyg`` (/root/reference/python/cugraph-pyg/cugraph_pyg/) on the MI355X-native
-hot path of ``wholegraph_amd``.  Homogeneous node loaders are implemented; link loaders,
-heterogeneous and temporal sampling are SURVEY.md §8(f) "next"."""
+hot path of ``wholegraph_amd``.  Node loaders (homogeneous and heterogeneous, uniform and biased) are
+implemented; link loaders / negative sampling, temporal and disjoint sampling are SURVEY.md §8(f) "next"."""
 from . import data, loader, sampler, tensor  # noqa: F401
 from .data import FeatureStore, GraphStore  # noqa: F401
 from .loader import NeighborLoader, NodeLoader  # noqa: F401

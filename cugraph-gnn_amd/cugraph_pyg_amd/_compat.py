@@ -12,10 +12,10 @@ from typing import Any, Optional, Tuple
 
 try:  # pragma: no cover - not available in the build image
     import torch_geometric  # noqa: F401
-    from torch_geometric.data import Data
+    from torch_geometric.data import Data, HeteroData
     from torch_geometric.data.feature_store import TensorAttr
     from torch_geometric.data.graph_store import EdgeAttr, EdgeLayout
-    from torch_geometric.sampler import NodeSamplerInput, SamplerOutput
+    from torch_geometric.sampler import HeteroSamplerOutput, NodeSamplerInput, SamplerOutput
     HAS_PYG = True
 except ImportError:
     HAS_PYG = False
@@ -90,6 +90,34 @@ except ImportError:
             parts = [f"{k}={list(v.shape) if isinstance(v, torch.Tensor) else v}" for k, v in self._store.items()]
             return "Data(" + ", ".join(parts) + ")"
 
+    class HeteroData:
+        """``data[node_type]`` / ``data[src, rel, dst]`` -> attribute bags (subset of
+        torch_geometric.data.HeteroData the loader fills)."""
+
+        def __init__(self):
+            self._stores = {}
+
+        def __getitem__(self, key):
+            key = tuple(key) if isinstance(key, (tuple, list)) else key
+            if key not in self._stores:
+                self._stores[key] = Data()
+            return self._stores[key]
+
+        @property
+        def node_types(self):
+            return [k for k in self._stores if not isinstance(k, tuple)]
+
+        @property
+        def edge_types(self):
+            return [k for k in self._stores if isinstance(k, tuple)]
+
+        def set_value_dict(self, name, value_dict):
+            for k, v in (value_dict or {}).items():
+                self[k][name] = v
+
+        def __repr__(self):
+            return "HeteroData(" + ", ".join(f"{k}={v}" for k, v in self._stores.items()) + ")"
+
     @dataclass
     class NodeSamplerInput:
         """torch_geometric.sampler.NodeSamplerInput"""
@@ -101,6 +129,20 @@ except ImportError:
     @dataclass
     class SamplerOutput:
         """torch_geometric.sampler.SamplerOutput"""
+        node: Any
+        row: Any
+        col: Any
+        edge: Any
+        batch: Any = None
+        num_sampled_nodes: Any = None
+        num_sampled_edges: Any = None
+        orig_row: Any = None
+        orig_col: Any = None
+        metadata: Any = field(default=None)
+
+    @dataclass
+    class HeteroSamplerOutput:
+        """torch_geometric.sampler.HeteroSamplerOutput"""
         node: Any
         row: Any
         col: Any

@@ -59,6 +59,7 @@ class GraphStore(_PygGraphStore):
         if self.__finalized:
             raise NotImplementedError("Modifying a finalized GraphStore is not supported.")
         self.__graph = None
+        self.__hetero = None
         self.__vertex_offsets = None
         self.__numeric_edge_types = None
 
@@ -140,6 +141,7 @@ class GraphStore(_PygGraphStore):
         if time_attr is not None:
             raise NotImplementedError("temporal sampling is not implemented (SURVEY.md §8(f))")
         self.__construct_graph()
+        self._hetero_graphs  # noqa: B018
         self._vertex_offsets  # noqa: B018  cache before the slices go away
         self._numeric_edge_types  # noqa: B018
         self.__edge_indices = {k: None for k in self.__edge_indices}
@@ -150,9 +152,12 @@ class GraphStore(_PygGraphStore):
         """``(feature_store, attr_name)``: edge weights for biased sampling (graph_store.py:430-446)."""
         if attr != self.__weight_attr:
             self.__graph = None
+            self.__hetero = None
         self.__weight_attr = attr
 
     def _num_vertices(self) -> Dict[str, int]:
+        if self.__finalized:
+            return dict(self.__num_vertices_cache)
         num = {}
         for attr in self.get_all_edge_attrs():
             src_t, _, dst_t = attr.edge_type
@@ -206,6 +211,49 @@ class GraphStore(_PygGraphStore):
     def _graph(self) -> CSRGraph:
         return self.__construct_graph()
 
+    def __gathered_edge_index(self, key, dev):
+        """All ranks' COO slices of one edge type, concatenated in rank order (= global edge-id order)."""
+        ei = self.__edge_indices[key]
+        ws, _ = _world()
+        if ws == 1:
+            return ei
+        n_local = torch.tensor([ei.shape[1]], dtype=torch.int64, device=dev)
+        sizes = torch.empty(ws, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, n_local)
+        sizes_h = sizes.tolist()
+        pad = max(max(sizes_h), 1)
+        buf = torch.zeros((2, pad), dtype=torch.int64, device=dev)
+        buf[:, : ei.shape[1]] = ei
+        allbuf = torch.empty((ws, 2, pad), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allbuf.view(-1), buf.view(-1))
+        return torch.cat([allbuf[r, :, : sizes_h[r]] for r in range(ws)], dim=1)
+
+    @property
+    def _hetero_graphs(self) -> Dict[Tuple[str, str, str], CSRGraph]:
+        """One CSR per edge type in TYPE-LOCAL vertex ids: rows = vertices of the PyG target type
+        (``edge_type[2]``), ``col`` = in-neighbours of the source type (``edge_type[0]``).  This is what
+        heterogeneous sampling expands (per-edge-type fan-out)."""
+        if getattr(self, "_GraphStore__hetero", None) is None:
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+            nv = self._num_vertices()
+            out = {}
+            for key in sorted(self.__edge_indices.keys()):
+                ei = self.__gathered_edge_index(key, dev)
+                n_rows = nv[key[2]]
+                order = torch.sort(ei[1], stable=True).indices
+                row_ptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+                row_ptr[1:] = torch.cumsum(torch.bincount(ei[1], minlength=n_rows), 0)
+                w = None
+                if self.__weight_attr is not None:
+                    fs, name = self.__weight_attr
+                    wt = fs[key, name, None]
+                    wt = wt[torch.arange(ei.shape[1], device=dev)] if not isinstance(wt, torch.Tensor) else wt
+                    w = wt.to(device=dev, dtype=torch.float32).view(-1)[order].contiguous()
+                out[key] = CSRGraph(row_ptr=row_ptr, col=ei[0][order].contiguous(), edge_id=order.contiguous(),
+                                    edge_type=None, weight=w, num_vertices=n_rows)
+            self.__hetero = out
+        return self.__hetero
+
     def __construct_graph(self) -> CSRGraph:
         if self.__graph is not None:
             return self.__graph
@@ -216,18 +264,7 @@ class GraphStore(_PygGraphStore):
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         rows, cols, eids, etps, wgts = [], [], [], [], []
         for t, key in enumerate(sorted_keys):
-            ei = self.__edge_indices[key]
-            n_local = torch.tensor([ei.shape[1]], dtype=torch.int64, device=dev)
-            if ws > 1:
-                sizes = torch.empty(ws, dtype=torch.int64, device=dev)
-                dist.all_gather_into_tensor(sizes, n_local)
-                sizes_h = sizes.tolist()
-                pad = max(sizes_h)
-                buf = torch.zeros((2, pad), dtype=torch.int64, device=dev)
-                buf[:, : ei.shape[1]] = ei
-                allbuf = torch.empty((ws, 2, pad), dtype=torch.int64, device=dev)
-                dist.all_gather_into_tensor(allbuf.view(-1), buf.view(-1))
-                ei = torch.cat([allbuf[r, :, : sizes_h[r]] for r in range(ws)], dim=1)  # rank-order == global edge id order
+            ei = self.__gathered_edge_index(key, dev)
             src_t, _, dst_t = key
             rows.append(ei[1] + offs[dst_t])     # expanded vertex = PyG message target
             cols.append(ei[0] + offs[src_t])

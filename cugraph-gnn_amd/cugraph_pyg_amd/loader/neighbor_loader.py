@@ -4,7 +4,7 @@ import warnings
 from typing import Callable, Dict, List, Optional, Union
 
 from ..data.graph_store import GraphStore
-from ..sampler import BaseSampler, NeighborSampler
+from ..sampler import BaseSampler, HeteroNeighborSampler, NeighborSampler
 from .node_loader import NodeLoader
 
 
@@ -34,16 +34,25 @@ class NeighborLoader(NodeLoader):
         feature_store, graph_store = data
         if compression is not None and compression not in ["CSR", "COO"]:
             raise ValueError("Invalid value for compression (expected 'CSR' or 'COO')")
-        if not graph_store.is_homogeneous or isinstance(num_neighbors, dict):
-            raise NotImplementedError("heterogeneous sampling is not implemented yet (SURVEY.md §8(f) rank 2)")
         if time_attr is not None:
             raise NotImplementedError("temporal sampling is not implemented yet (SURVEY.md §8(f) rank 2)")
         if weight_attr is not None:
             graph_store._set_weight_attr((feature_store, weight_attr))
-        sampler = BaseSampler(
-            NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
-                            with_replacement=replace, disjoint=disjoint, heterogeneous=False, temporal=False),
-            (feature_store, graph_store), batch_size=batch_size)
+        if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
+            core = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
+                                   with_replacement=replace, disjoint=disjoint, heterogeneous=False, temporal=False)
+        else:
+            if compression is not None and compression != "COO":
+                raise ValueError("Only COO format is supported for heterogeneous graphs!")
+            etypes = [a.edge_type for a in graph_store.get_all_edge_attrs()]
+            if not isinstance(num_neighbors, dict):      # a plain list applies to every edge type (PyG)
+                num_neighbors = {et: list(num_neighbors) for et in etypes}
+            unknown = [k for k in num_neighbors if k not in etypes]
+            if unknown:
+                raise ValueError(f"fan-out given for unknown edge types: {unknown}")
+            core = HeteroNeighborSampler(graph_store._hetero_graphs, num_neighbors, biased=(weight_attr is not None),
+                                         with_replacement=replace, disjoint=disjoint, temporal=False)
+        sampler = BaseSampler(core, (feature_store, graph_store), batch_size=batch_size)
         super().__init__((feature_store, graph_store), sampler, input_nodes=input_nodes, input_time=input_time,
                          transform=transform, transform_sampler_output=transform_sampler_output,
                          filter_per_worker=filter_per_worker, batch_size=batch_size, **kwargs)

@@ -1,1 +1,2 @@
-from .sampler import BaseSampler, NeighborSampler, SampleIterator, neighbor_sample  # noqa: F401
+from .sampler import (BaseSampler, HeteroNeighborSampler, NeighborSampler, SampleIterator,  # noqa: F401
+                      hetero_neighbor_sample, neighbor_sample)

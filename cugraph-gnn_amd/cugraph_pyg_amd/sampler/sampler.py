@@ -22,7 +22,7 @@ import torch
 
 from wholegraph_amd import graph_ops, wholegraph_ops
 
-from .._compat import Data, NodeSamplerInput, SamplerOutput
+from .._compat import Data, HeteroData, HeteroSamplerOutput, NodeSamplerInput, SamplerOutput
 from ..data.graph_store import CSRGraph
 
 _GOLDEN = 0x9E3779B97F4A7C15
@@ -73,6 +73,89 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
     return nodes, cat(rows), cat(cols), cat(edges), num_nodes, num_edges
 
 
+def _one_hop(graph: CSRGraph, frontier, fan, seed, biased):
+    """(neighbours, row index in `frontier`, CSR slot) of one hop on one CSR; zero-weight edges dropped
+    for biased sampling."""
+    if biased:
+        off, nbr, lid, gid = wholegraph_ops.weighted_sample_without_replacement(
+            graph.row_ptr, graph.col, graph.weight, frontier, int(fan), seed, True, True)
+        keep = graph.weight[gid] > 0
+        if not bool(keep.all()):
+            nbr, lid, gid = nbr[keep], lid[keep], gid[keep]
+    else:
+        off, nbr, lid, gid = wholegraph_ops.unweighted_sample_without_replacement(
+            graph.row_ptr, graph.col, frontier, int(fan), seed, True, True)
+    return nbr, lid, gid
+
+
+def hetero_neighbor_sample(graphs, seed_type: str, seeds: torch.Tensor, fanout, random_state: int,
+                           biased: bool = False):
+    """Heterogeneous PyG-style sampling: per hop, for every edge type (src_t, rel, dst_t) in sorted
+    order, the frontier vertices of type ``dst_t`` draw up to ``fanout[etype][hop]`` in-neighbours of
+    type ``src_t``; vertices first seen during a hop form the next hop's frontier of their type.
+    Seeds of hop-h / edge-type-index-t calls are ``hop_seed(random_state, h * n_etypes + t)`` — the
+    flat ``[hop * num_etypes + etype]`` indexing of the reference's fan-out array
+    (loader/neighbor_loader.py:192-201).  Ids are TYPE-LOCAL throughout.
+
+    Returns (node{type}, row{etype}, col{etype}, edge{etype}, num_sampled_nodes{type}[hops+1],
+    num_sampled_edges{etype}[hops])."""
+    etypes = sorted(graphs.keys())
+    dev = next(iter(graphs.values())).row_ptr.device
+    ntypes = sorted({t for et in etypes for t in (et[0], et[2])} | {seed_type})
+    empty = lambda: torch.zeros(0, dtype=torch.int64, device=dev)  # noqa: E731
+    node = {t: empty() for t in ntypes}
+    node[seed_type] = seeds.to(device=dev, dtype=torch.int64)
+    frontier_start = {t: 0 for t in ntypes}                  # first row of the current frontier in node[t]
+    n_hops = len(next(iter(fanout.values())))
+    rows = {et: [] for et in etypes}
+    cols = {et: [] for et in etypes}
+    edges = {et: [] for et in etypes}
+    num_nodes = {t: [int(node[t].shape[0])] for t in ntypes}
+    num_edges = {et: [] for et in etypes}
+    for h in range(n_hops):
+        hop_begin = {t: int(node[t].shape[0]) for t in ntypes}   # vertices added from here on are next frontier
+        for ti, et in enumerate(etypes):
+            src_t, _, dst_t = et
+            fan = fanout.get(et, [0] * n_hops)[h]
+            frontier = node[dst_t][frontier_start[dst_t]:hop_begin[dst_t]]
+            if fan == 0 or frontier.shape[0] == 0:
+                num_edges[et].append(0)
+                continue
+            nbr, lid, gid = _one_hop(graphs[et], frontier, fan, hop_seed(random_state, h * len(etypes) + ti), biased)
+            new_nodes, mapping = graph_ops.append_unique(node[src_t], nbr, need_neighbor_raw_to_unique=True)
+            node[src_t] = new_nodes
+            rows[et].append(mapping.long())
+            cols[et].append(lid.long() + frontier_start[dst_t])
+            edges[et].append(graphs[et].edge_id[gid])
+            num_edges[et].append(int(nbr.shape[0]))
+        for t in ntypes:
+            num_nodes[t].append(int(node[t].shape[0]) - hop_begin[t])
+            frontier_start[t] = hop_begin[t]
+    cat = lambda xs: torch.cat(xs) if xs else empty()  # noqa: E731
+    return (node, {et: cat(rows[et]) for et in etypes}, {et: cat(cols[et]) for et in etypes},
+            {et: cat(edges[et]) for et in etypes}, num_nodes, num_edges)
+
+
+class HeteroNeighborSampler:
+    """Heterogeneous counterpart of ``NeighborSampler`` (per-edge-type CSRs, dict fan-out)."""
+
+    def __init__(self, graphs, fanout, biased: bool = False, with_replacement: bool = False,
+                 disjoint: bool = False, temporal: bool = False, **_ignored):
+        if with_replacement or disjoint or temporal:
+            raise NotImplementedError("with_replacement / disjoint / temporal sampling are not implemented")
+        n_hops = {len(v) for v in fanout.values()}
+        if len(n_hops) != 1:
+            raise ValueError("every edge type needs the same number of hops")
+        if biased and any(g.weight is None for g in graphs.values()):
+            raise ValueError("biased sampling needs a weight attribute on every edge type")
+        self.graphs, self.fanout, self.biased = graphs, {k: [int(f) for f in v] for k, v in fanout.items()}, biased
+
+    def sample_batches(self, seed_type, seeds, batch_size, random_state):
+        for b, start in enumerate(range(0, seeds.shape[0], batch_size)):
+            yield b, hetero_neighbor_sample(self.graphs, seed_type, seeds[start:start + batch_size], self.fanout,
+                                            random_state + b, self.biased)
+
+
 class NeighborSampler:
     """The role of ``DistributedNeighborSampler`` for the homogeneous case: owns the CSR, the fan-out
     and the flags; ``sample_batches`` is the hot loop."""
@@ -107,6 +190,17 @@ class BaseSampler:
         nodes = index.node
         input_id = index.input_id
         bs = self.__batch_size
+        if isinstance(self.__sampler, HeteroNeighborSampler):
+            it = index.input_type
+            for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(it, nodes, bs, random_state):
+                n_seeds = nn[it][0]
+                ids = input_id[b * bs: b * bs + n_seeds]
+                yield HeteroSamplerOutput(
+                    node=node, row=row, col=col, edge=edge, batch={it: node[it][:n_seeds]},
+                    num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
+                    num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()},
+                    metadata=((it, ids), None))
+            return
         for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(nodes, bs, random_state):
             n_seeds = nn[0]
             ids = input_id[b * bs: b * bs + n_seeds]
@@ -140,8 +234,34 @@ class SampleIterator:
         self.__feature_store, self.__graph_store = data
         self.__output_iter = output_iter
 
+    def __next_hetero(self, s):
+        data = HeteroData()
+        for et in s.row:
+            data[et].edge_index = torch.stack([s.row[et], s.col[et]], dim=0)
+            data[et].e_id = s.edge[et].to(torch.long)
+        for nt, ids in s.node.items():
+            data[nt].n_id = ids
+            data[nt].num_nodes = ids.size(0)
+        for attr in self.__feature_store.get_all_tensor_attrs():
+            g = attr.group_name
+            if isinstance(g, tuple):
+                if g in s.edge:
+                    data[g][attr.attr_name] = self.__feature_store[g, attr.attr_name, None][s.edge[g]]
+            elif g in s.node:
+                data[g][attr.attr_name] = self.__feature_store[g, attr.attr_name, None][s.node[g]]
+        data.set_value_dict("batch", s.batch)
+        data.set_value_dict("num_sampled_nodes", s.num_sampled_nodes)
+        data.set_value_dict("num_sampled_edges", s.num_sampled_edges)
+        input_type, input_id = s.metadata[0]
+        data[input_type].input_id = input_id
+        data[input_type].batch_size = input_id.size(0)
+        data[input_type].seed_time = s.metadata[1]
+        return data
+
     def __next__(self):
         s = next(self.__output_iter)
+        if isinstance(s, HeteroSamplerOutput):
+            return self.__next_hetero(s)
         data = filter_store(self.__feature_store, self.__graph_store, s.node, s.row, s.col, s.edge)
         if "n_id" not in data:
             data.n_id = s.node

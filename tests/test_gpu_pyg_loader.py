@@ -167,3 +167,123 @@ def test_neighbor_loader_powerlaw_batches_vs_oracle(oracle_mod, hiplib):
         conv = wnn.SAGEConv(100, 32).cuda()
         out = conv(batch.x, batch.edge_index)
         assert out.shape == (batch.n_id.numel(), 32) and torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------- heterogeneous
+def oracle_hetero_sample(oracle_mod, graphs, seed_type, seeds, fanout, random_state):
+    """Same composition as cugraph_pyg_amd.sampler.hetero_neighbor_sample, on the oracle."""
+    from cugraph_pyg_amd.sampler.sampler import hop_seed
+    etypes = sorted(graphs.keys())
+    ntypes = sorted({t for et in etypes for t in (et[0], et[2])} | {seed_type})
+    node = {t: np.zeros(0, np.int64) for t in ntypes}
+    node[seed_type] = np.asarray(seeds, np.int64)
+    fstart = {t: 0 for t in ntypes}
+    n_hops = len(next(iter(fanout.values())))
+    rows, cols, edges = {et: [] for et in etypes}, {et: [] for et in etypes}, {et: [] for et in etypes}
+    for h in range(n_hops):
+        begin = {t: len(node[t]) for t in ntypes}
+        for ti, et in enumerate(etypes):
+            src_t, _, dst_t = et
+            fan = fanout.get(et, [0] * n_hops)[h]
+            frontier = node[dst_t][fstart[dst_t]:begin[dst_t]]
+            if fan == 0 or len(frontier) == 0:
+                continue
+            rp, col, eid = graphs[et]
+            off, nbr, lid, gid = oracle_mod.unweighted_sample(rp, col, frontier, fan, hop_seed(random_state, h * len(etypes) + ti))
+            node[src_t], mp = oracle_mod.append_unique(node[src_t], nbr.astype(np.int64))
+            rows[et].append(mp.astype(np.int64))
+            cols[et].append(lid.astype(np.int64) + fstart[dst_t])
+            edges[et].append(eid[gid])
+        for t in ntypes:
+            fstart[t] = begin[t]
+    z = np.zeros(0, np.int64)
+    c = lambda xs: np.concatenate(xs) if xs else z  # noqa: E731
+    return node, {et: c(rows[et]) for et in etypes}, {et: c(cols[et]) for et in etypes}, {et: c(edges[et]) for et in etypes}
+
+
+def test_neighbor_loader_hetero_basic_reference_example(hiplib):
+    # tests/loader/test_neighbor_loader.py:355-409, same assertions
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    src = torch.tensor([0, 1, 2, 4, 3, 4, 5, 5])
+    dst = torch.tensor([4, 5, 4, 3, 2, 1, 0, 1])
+    asrc = torch.tensor([0, 1, 2, 3, 3, 0])
+    adst = torch.tensor([0, 1, 2, 3, 4, 5])
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store[("paper", "cites", "paper"), "coo", False, (6, 6)] = [src, dst]
+    graph_store[("author", "writes", "paper"), "coo", False, (4, 6)] = [asrc, adst]
+    feature_store["paper", "x", None] = torch.arange(6, dtype=torch.float32).view(-1, 1).repeat(1, 8)
+    loader = NeighborLoader((feature_store, graph_store),
+                            num_neighbors={("paper", "cites", "paper"): [1, 1], ("author", "writes", "paper"): [1, 1]},
+                            input_nodes=("paper", torch.tensor([0, 1])), batch_size=2)
+    out = next(iter(loader))
+    ei_out = out["paper"].n_id.cpu()[out["paper", "cites", "paper"].edge_index.cpu()]
+    assert (src[out["paper", "cites", "paper"].e_id.cpu()] == ei_out[0]).all()
+    assert (dst[out["paper", "cites", "paper"].e_id.cpu()] == ei_out[1]).all()
+    ej_out = torch.stack([out["author"].n_id.cpu()[out["author", "writes", "paper"].edge_index[0].cpu()],
+                          out["paper"].n_id.cpu()[out["author", "writes", "paper"].edge_index[1].cpu()]])
+    assert (asrc[out["author", "writes", "paper"].e_id.cpu()] == ej_out[0]).all()
+    assert (adst[out["author", "writes", "paper"].e_id.cpu()] == ej_out[1]).all()
+    assert out["paper"].n_id[:2].tolist() == [0, 1] and out["paper"].batch_size == 2
+    assert torch.equal(out["paper"].x.cpu()[:, 0], out["paper"].n_id.cpu().float())
+
+
+def test_hetero_mag_like_sampling_vs_oracle_and_gat(oracle_mod, hiplib):
+    """BASELINE configs[4] shape at test scale: 4 node types, 2-hop per-edge-type fan-out, then the GAT
+    edge-softmax aggregation of one relation on the sampled bipartite subgraph vs the oracle."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd import nn as wnn
+    rng = np.random.default_rng(0)
+    n = {"paper": 3000, "author": 4000, "institution": 100, "field": 300}
+    rel = {("author", "writes", "paper"): 9000, ("paper", "cites", "paper"): 12000,
+           ("paper", "has_topic", "field"): 7000, ("author", "affiliated_with", "institution"): 4000,
+           ("paper", "rev_writes", "author"): 9000, ("field", "rev_has_topic", "paper"): 7000}
+    gs, fs = GraphStore(), FeatureStore()
+    coo = {}
+    for (s, r, d), m in rel.items():
+        ei = torch.from_numpy(np.stack([rng.integers(0, n[s], m), rng.integers(0, n[d], m)]))
+        coo[(s, r, d)] = ei
+        gs[(s, r, d), "coo", False, (n[s], n[d])] = ei
+    xp = torch.randn(n["paper"], 128)
+    fs["paper", "x", None] = xp
+    fs["author", "x", None] = torch.randn(n["author"], 128)
+    fanout = {et: [5, 3] for et in rel}
+    seeds = torch.from_numpy(rng.permutation(n["paper"])[:200])
+    loader = NeighborLoader((fs, gs), fanout, input_nodes=("paper", seeds), batch_size=128, random_state=5)
+    hg = gs._hetero_graphs
+    graphs_np = {et: (g.row_ptr.cpu().numpy(), g.col.cpu().numpy(), g.edge_id.cpu().numpy()) for et, g in hg.items()}
+    nb = 0
+    for b, batch in enumerate(loader):
+        nb += 1
+        s = seeds[b * 128:(b + 1) * 128].numpy()
+        node, row, col, edge = oracle_hetero_sample(oracle_mod, graphs_np, "paper", s, fanout, 5 + b)
+        for t in n:
+            assert np.array_equal(batch[t].n_id.cpu().numpy(), node[t]), t
+        for et in rel:
+            assert np.array_equal(batch[et].edge_index.cpu().numpy(), np.stack([row[et], col[et]])), et
+            assert np.array_equal(batch[et].e_id.cpu().numpy(), edge[et]), et
+            # e_id indexes the ORIGINAL per-type edge list (hetero edge-id rule of the reference test)
+            g_src = batch[et[0]].n_id.cpu()[batch[et].edge_index[0].cpu()]
+            g_dst = batch[et[2]].n_id.cpu()[batch[et].edge_index[1].cpu()]
+            assert torch.equal(coo[et][0][batch[et].e_id.cpu()], g_src) and torch.equal(coo[et][1][batch[et].e_id.cpu()], g_dst)
+        assert torch.equal(batch["paper"].x.cpu(), xp[batch["paper"].n_id.cpu()])
+        assert int(batch["paper"].num_sampled_nodes.sum()) == batch["paper"].n_id.numel()
+        # GAT over (author -writes-> paper) on the sampled bipartite subgraph, 4 heads
+        et = ("author", "writes", "paper")
+        ei = batch[et].edge_index
+        x_src, x_dst = batch["author"].x, batch["paper"].x
+        gat = wnn.GATConv(128, 32, heads=4, add_self_loops=False).cuda()
+        out = gat((x_src, x_dst), ei)
+        assert out.shape == (x_dst.shape[0], 128)
+        # oracle on the same CSR
+        rp, cc = wnn._to_csr(ei, x_dst.shape[0])
+        h_src, h_dst = gat.lin(x_src), gat.lin(x_dst)
+        a_s = (h_src.view(-1, 4, 32) * gat.att_src).sum(-1)
+        a_d = (h_dst.view(-1, 4, 32) * gat.att_dst).sum(-1)
+        oref, _ = oracle_mod.gat_csr(rp.cpu().numpy(), cc.cpu().numpy(), h_src.detach().cpu().numpy().reshape(-1, 4, 32),
+                                     a_s.detach().cpu().numpy(), a_d.detach().cpu().numpy(), 0.2)
+        np.testing.assert_allclose((out - gat.bias).detach().cpu().numpy().reshape(-1, 4, 32), oref, rtol=1e-4, atol=1e-5)
+    assert nb == 2

@@ -94,8 +94,28 @@ def test_loader_len_rules_and_validation():
         NeighborLoader((fs, gs), [1], compression="CSC")
     with pytest.raises(NotImplementedError):
         NeighborLoader((fs, None), [1])
-    with pytest.raises(NotImplementedError):
-        NeighborLoader((fs, gs), {("person", "knows", "person"): [1]})
+    with pytest.raises(ValueError):
+        NeighborLoader((fs, gs), {("person", "likes", "person"): [1]})       # unknown edge type
+    with pytest.raises(ValueError):
+        NeighborLoader((fs, gs), {("person", "knows", "person"): [1]}, compression="CSR")
+
+
+def test_hetero_type_local_csrs():
+    from cugraph_pyg_amd.data import GraphStore
+    gs = GraphStore()
+    # tests/loader/test_neighbor_loader.py:355-373
+    src, dst = torch.tensor([0, 1, 2, 4, 3, 4, 5, 5]), torch.tensor([4, 5, 4, 3, 2, 1, 0, 1])
+    asrc, adst = torch.tensor([0, 1, 2, 3, 3, 0]), torch.tensor([0, 1, 2, 3, 4, 5])
+    gs[("paper", "cites", "paper"), "coo", False, (6, 6)] = [src, dst]
+    gs[("author", "writes", "paper"), "coo", False, (4, 6)] = [asrc, adst]
+    hg = gs._hetero_graphs
+    w = hg[("author", "writes", "paper")]
+    assert w.num_vertices == 6 and w.row_ptr.tolist() == [0, 1, 2, 3, 4, 5, 6]
+    assert w.col.tolist() == [0, 1, 2, 3, 3, 0] and w.edge_id.tolist() == [0, 1, 2, 3, 4, 5]
+    c = hg[("paper", "cites", "paper")]
+    for v in range(6):      # row v = in-neighbours of paper v, edge ids point into the ORIGINAL arrays
+        ids = c.edge_id[c.row_ptr[v]:c.row_ptr[v + 1]]
+        assert (dst[ids] == v).all() and torch.equal(src[ids], c.col[c.row_ptr[v]:c.row_ptr[v + 1]])
 
 
 def test_hop_seed_derivation_is_stable():
