@@ -32,7 +32,11 @@ import torch.distributed as dist  # noqa: E402
 V_PRODUCTS = 2_449_029
 E_UNDIRECTED = 61_859_140
 FEAT_DIM = 100
+# name -> (V, undirected RMAT edges, feature dim, classes)   [SURVEY.md §8 dataset sizes]
+WORKLOADS = {"products": (V_PRODUCTS, E_UNDIRECTED, 100, 47),
+             "papers100m": (111_059_956, 807_842_936, 128, 172)}
 HIDDEN = 256
+SPMM1, SPMM2 = "spmm1(mean)+self", "spmm2(mean)+self"   # stage labels (layer-1 F = feature dim, layer-2 F = HIDDEN)
 CLASSES = 47
 BATCH = 1024
 FANOUT = [25, 10]
@@ -54,14 +58,18 @@ def rmat_csr(n_nodes, n_undirected, seed, device, a=0.57, b=0.19, c=0.19):
         dst = (dst << 1) | dbit
     perm = torch.randperm(1 << scale, generator=g, device=device)
     src, dst = perm[src] % n_nodes, perm[dst] % n_nodes
+    del perm
     keep = src != dst
     src, dst = src[keep], dst[keep]
+    del keep
     keys = torch.cat([src * n_nodes + dst, dst * n_nodes + src])
-    del src, dst, perm
+    del src, dst
     keys = torch.unique(keys)  # sorted => CSR order, duplicates dropped
     rows = torch.div(keys, n_nodes, rounding_mode="floor")
-    col = (keys - rows * n_nodes).contiguous()
+    col = keys - rows * n_nodes
+    del keys
     deg = torch.bincount(rows, minlength=n_nodes)
+    del rows
     row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(deg, 0)
     return row_ptr, col
@@ -142,12 +150,12 @@ class SagePipeline:
                                                      torch.empty((u2, FEAT_DIM), dtype=torch.float32, device=self.device)))
         # layer 1: one kernel builds [mean_j x_j | x_i], one GEMM applies [W_l | W_r] with bias, then ReLU
         rows1 = res.target_rows_in_unique(1, u1)   # "x[:num_dst]" of the block-diagonal layout
-        cat1 = stage("spmm1(mean,F=100)+self",
+        cat1 = stage(SPMM1,
                      lambda: nn.sage_aggregate_forward(res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], x, rows1, True))
         h1 = stage("dense1", lambda: self.dense(cat1, self.w1_t, self.b1, relu=True))
         # layer 2: destinations are the seeds = the first BATCH rows of every batch's hop-1 unique list
         seed_rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
-        cat2 = stage("spmm2(mean,F=256)+self",
+        cat2 = stage(SPMM2,
                      lambda: nn.sage_aggregate_forward(res.offsets[0][:t0 + 1], res.neighbor_row[0][:e1], h1, seed_rows, True))
         out = stage("dense2", lambda: self.dense(cat2, self.w2_t, self.b2, relu=False))
         return out, (e1, u1, e2, u2)
@@ -199,8 +207,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=640)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
-    ap.add_argument("--edges", type=int, default=E_UNDIRECTED, help="undirected RMAT edges before symmetrising")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="products",
+                    help="products = BASELINE configs[1] (the metric's config); papers100m = configs[2] scale on ONE GPU "
+                         "(the north-star 10x-vs-CPU statement)")
+    ap.add_argument("--nodes", type=int, default=None)
+    ap.add_argument("--edges", type=int, default=None, help="undirected RMAT edges before symmetrising")
     ap.add_argument("--call-group", type=int, default=64, help="max mini-batches per launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -220,6 +231,10 @@ def main():
     from wholegraph_amd import WholeMemoryTensor, equal_entry_partition
 
     # ---- synthetic workload (replicated CSR, range-partitioned features) --------------------
+    global FEAT_DIM, CLASSES
+    wv, we, FEAT_DIM, CLASSES = WORKLOADS[args.workload]
+    args.nodes = args.nodes or wv
+    args.edges = args.edges or we
     row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
     V, E = args.nodes, int(col.shape[0])
     gfeat = torch.Generator(device=device).manual_seed(100 + rank)
@@ -304,8 +319,8 @@ def main():
         kernels = {
             "gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F)),
             # + the root term copied next to the aggregate: one more row read and written per destination
-            "spmm1(mean,F=100)+self": ("spmm_csr_kernel", e2 * (4 * F + 4) + n_dst1 * (4 * F + 8) + n_dst1 * (8 * F + 8)),
-            "spmm2(mean,F=256)+self": ("spmm_csr_kernel", e1 * (4 * HIDDEN + 4) + G * BATCH * (4 * HIDDEN + 8)
+            SPMM1: ("spmm_csr_kernel", e2 * (4 * F + 4) + n_dst1 * (4 * F + 8) + n_dst1 * (8 * F + 8)),
+            SPMM2: ("spmm_csr_kernel", e1 * (4 * HIDDEN + 4) + G * BATCH * (4 * HIDDEN + 8)
                                        + G * BATCH * (8 * HIDDEN + 8)),
         }
         dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
@@ -319,20 +334,24 @@ def main():
                         "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                   f"{G} mini-batches, averaged over {stage_n} call groups"}
         spmm_gbps = None
-        if "spmm1(mean,F=100)+self" in stage_ms:
-            spmm_gbps = kernels["spmm1(mean,F=100)+self"][1] / (stage_ms["spmm1(mean,F=100)+self"] * 1e-3) / 1e9
+        if SPMM1 in stage_ms:
+            spmm_gbps = kernels[SPMM1][1] / (stage_ms[SPMM1] * 1e-3) / 1e9
         cpu = None
         if not args.no_cpu_baseline:
             nb = min(2048, order.numel() // BATCH)   # time-bounded inside cpu_baseline (--cpu-budget seconds)
             cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()  # same seed stream, one mini-batch at a time
-            if world > 1:
+            if V * FEAT_DIM * 4 > (8 << 30):
+                # papers100M-scale table: a lazily-zeroed host array of the same shape (only the gathered
+                # rows' pages are ever touched; values do not matter for the timing)
+                feat_h = np.zeros((V, FEAT_DIM), dtype=np.float32)
+            elif world > 1:
                 feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
             else:
                 feat_h = feat.local_tensor.cpu().numpy()
             weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in (pipe.conv1, pipe.conv2)]
             cpu = cpu_baseline(row_ptr.cpu().numpy(), col.cpu().numpy(), feat_h, cb, weights, args.cpu_budget)
         out = {
-            "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), ogbn-products-like fan-out [25,10]",
+            "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), ogbn-%s-like fan-out [25,10]" % args.workload,
             "value": edges_total / dt,
             "unit": "sampled-edges/s",
             "n_gpus": world,
@@ -344,7 +363,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int64 ids + f32 features",
             "data": "synthetic",
-            "config": {"workload": "ogbn-products-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
+            "config": {"workload": "ogbn-" + args.workload + "-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
                                    "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, 2-layer SAGEConv(mean) %d-%d-%d fwd, "
                                    "%d mini-batches per launch sequence (call group)"
                                    % (V, E, FEAT_DIM, "" if world == 1 else " range-partitioned + RCCL all-to-all",
