@@ -76,7 +76,7 @@ table_clear_kernel(TableKeyT* keys, int* minpos, int64_t capacity_slots, dev_cou
 __device__ __forceinline__ int batch_of(const batch_view& bv, int p, int T)
 {
   if (bv.target_batch == nullptr) return 0;
-  return p < T ? bv.target_batch[p] : bv.target_batch[bv.edge_row[p - T]];
+  return p < T ? bv.target_batch[p] : bv.sbatch()[bv.edge_row[p - T]];
 }
 
 // thread p < T inserts target p, thread T+e inserts neighbour e; remembers its slot.
@@ -152,7 +152,10 @@ __global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restri
   const bool batched = bv.target_batch != nullptr;
   if (batched && bv.unique_seg && p <= bv.G) {
     // first unique row of batch p (p == G: one past the end)
-    bv.unique_seg[p] = bv.target_seg[p] + rank[bv.edge_offsets[bv.target_seg[p]]];
+    const int new_before = rank[bv.edge_offsets[bv.sseg()[p]]];   // new vertices of batches < p
+    bv.unique_seg[p] = bv.target_seg[p] + new_before;
+    if (bv.frontier_seg_out) bv.frontier_seg_out[p] = new_before;
+    if (bv.frontier_local0_out && p < bv.G) bv.frontier_local0_out[p] = bv.target_seg[p + 1] - bv.target_seg[p];
   }
   // no-sync walk: pad the capacity slack of `unique` with -1 so that a capacity-sized feature
   // gather skips those rows (negative index => row untouched)
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restri
   if (p >= T + E) return;
   const int b = batch_of(bv, p, T);
   // rows contributed by the new nodes of earlier batches / first row after my batch's targets
-  const int shift    = batched ? rank[bv.edge_offsets[bv.target_seg[b]]] : 0;
+  const int shift    = batched ? rank[bv.edge_offsets[bv.sseg()[b]]] : 0;
   const int tail_row = batched ? bv.target_seg[b + 1] : T;
   if (p < T) {
     unique_out[p + shift] = targets[p];
@@ -173,8 +176,17 @@ __global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restri
   if (first == p) {
     unique_out[row] = neighbors[e];
     if (bv.unique_batch) bv.unique_batch[row] = b;
+    if (bv.frontier_out) {  // next frontier, ordered by (batch, first appearance) == by rank
+      static_cast<KeyT*>(bv.frontier_out)[rank[e]] = neighbors[e];
+      bv.frontier_batch_out[rank[e]]               = b;
+    }
   }
   if (map_out) map_out[e] = row;
+  if (bv.neighbor_local_out) bv.neighbor_local_out[e] = row - ((batched ? bv.target_seg[b] : 0) + shift);
+  if (bv.center_local_out) {
+    const int r = bv.edge_row[e];
+    bv.center_local_out[e] = batched ? r - bv.sseg()[b] + (bv.sample_local0 ? bv.sample_local0[b] : 0) : r;
+  }
 }
 
 template <typename KeyT>

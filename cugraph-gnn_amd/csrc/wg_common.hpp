@@ -222,6 +222,19 @@ struct batch_view {
   int G;
   int* unique_batch;        // out [T+E] batch of every unique entry  (nullable)
   int* unique_seg;          // out [G+1] first unique entry of every batch (nullable)
+  // PyG-style walk ("expand only the vertices discovered by the previous hop"): the SAMPLED list
+  // (frontier) is then not the renumber target list (all vertices so far).  Null = same lists.
+  const int* sample_batch;  // [S]   batch of every sampled (frontier) vertex; edge_row indexes this list
+  const int* sample_seg;    // [G+1] first frontier vertex of every batch; edge_offsets is over this list
+  const int* sample_local0; // [G]   local id (inside its batch) of every batch's first frontier vertex
+  void* frontier_out;       // out [E]   ids first seen in this hop, by (batch, first appearance) = next frontier
+  int* frontier_batch_out;  // out [E]
+  int* frontier_seg_out;    // out [G+1]
+  int* frontier_local0_out; // out [G]   local id of the next frontier's first vertex = batch size before this hop
+  int* neighbor_local_out;  // out [E]   per-batch LOCAL id of every edge's neighbour
+  int* center_local_out;    // out [E]   per-batch LOCAL id of every edge's expanded vertex
+  __host__ __device__ const int* sbatch() const { return sample_batch ? sample_batch : target_batch; }
+  __host__ __device__ const int* sseg() const { return sample_seg ? sample_seg : target_seg; }
 };
 void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
                                    batch_view bv, void* keys, int* minpos, int64_t slots, int* slot_of, int* rank,

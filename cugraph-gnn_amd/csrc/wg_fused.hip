@@ -10,6 +10,7 @@
 // python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:279-343) gives every launch G x the
 // work while each mini-batch keeps exactly the result a single-batch call would produce.
 #include "wg_common.hpp"
+#include "wgamd_ext.h"
 
 namespace wgamd {
 namespace {
@@ -44,6 +45,10 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
 }
 
 struct hop_args {
+  // PyG-style walk: the sampled list (frontier) differs from the renumber target list; null = same list
+  const void* sample_targets = nullptr;
+  const int* n_sample_dev    = nullptr;
+  int64_t sample_cap         = 0;
   const int64_t* csr_row_ptr;
   const void* csr_col;
   wholememory_dtype_t id_dtype;
@@ -72,11 +77,14 @@ void run_hop(hop_args a)
                      a.unique && a.workspace,
                    "null pointer");
   WG_REQUIRE_INPUT(a.M > 0, "the no-sync walk needs a positive fan-out (capacity = targets * M)");
-  WG_REQUIRE_INPUT(a.target_cap > 0 && a.edge_cap >= a.target_cap * (int64_t)a.M, "edge_cap < target_cap * M");
+  const void* s_targets = a.sample_targets ? a.sample_targets : a.targets;
+  const int* s_n_dev    = a.sample_targets ? a.n_sample_dev : a.n_targets_dev;
+  const int64_t s_cap   = a.sample_targets ? a.sample_cap : a.target_cap;
+  WG_REQUIRE_INPUT(a.target_cap > 0 && s_cap > 0 && a.edge_cap >= s_cap * (int64_t)a.M, "edge_cap < sampled_cap * M");
   WG_REQUIRE_INPUT(a.target_cap + a.edge_cap < ((int64_t)1 << 30), "capacities too large for one call");
   const bool i64     = a.id_dtype == WHOLEMEMORY_DT_INT64;
   const bool batched = a.bv.target_batch != nullptr;
-  hop_workspace w    = plan(a.target_cap, a.edge_cap, i64 ? 8 : 4, batched);
+  hop_workspace w    = plan(std::max(a.target_cap, s_cap), a.edge_cap, i64 ? 8 : 4, batched);
   WG_REQUIRE_INPUT(a.workspace_bytes >= w.total, "workspace too small: need %zu bytes", w.total);
   WG_REQUIRE_INPUT((reinterpret_cast<uintptr_t>(a.workspace) & 255) == 0, "workspace must be 256-byte aligned");
   char* base    = static_cast<char*>(a.workspace);
@@ -90,11 +98,12 @@ void run_hop(hop_args a)
   hipStream_t st = a.stream;
 
   dev_count T{(int)a.target_cap, a.n_targets_dev};
-  sample_count_enqueue(a.csr_row_ptr, a.targets, i64, T, a.M, cnt, nullptr, st);
-  exclusive_scan_i32(cnt, a.offsets, a.target_cap, scan_tmp, st, a.n_targets_dev);  // offsets[cap] = #edges
-  uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, a.targets, i64, T, a.M, a.rng, a.offsets, nbr, a.center_row,
+  dev_count S{(int)s_cap, s_n_dev};
+  sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st);
+  exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
+  uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
                          a.edge_gid, st);
-  dev_count E{(int)a.edge_cap, a.offsets + a.target_cap};
+  dev_count E{(int)a.edge_cap, a.offsets + s_cap};
   batch_view bv   = a.bv;
   bv.edge_row     = a.center_row;
   bv.edge_offsets = a.offsets;
@@ -160,6 +169,38 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(
     a.offsets = offsets; a.neighbor_row = neighbor_row; a.center_row = center_row; a.edge_gid = edge_gid;
     a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
     a.workspace_bytes = workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
+    run_hop(a);
+  });
+}
+
+wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_sample_hop_pyg_nosync", [&] {
+    WG_REQUIRE_INPUT(p != nullptr, "null parameter block");
+    WG_REQUIRE_INPUT(p->nodes && p->node_batch && p->node_seg && p->frontier && p->frontier_batch && p->frontier_seg &&
+                       p->frontier_local0 && p->random_seeds_dev && p->center_local && p->neighbor_local &&
+                       p->nodes_out && p->nodes_out_batch && p->nodes_out_seg && p->frontier_out &&
+                       p->frontier_out_batch && p->frontier_out_seg && p->frontier_out_local0 && p->counts_dev &&
+                       p->center_row_scratch,
+                     "null pointer");
+    WG_REQUIRE_INPUT(p->n_batches >= 1 && p->n_batches < (1 << 20), "bad batch count");
+    hop_args a{};
+    a.csr_row_ptr = p->csr_row_ptr; a.csr_col = p->csr_col; a.id_dtype = p->id_dtype;
+    a.targets = p->nodes; a.n_targets_dev = p->node_seg + p->n_batches; a.target_cap = p->node_cap;
+    a.sample_targets = p->frontier; a.n_sample_dev = p->frontier_seg + p->n_batches; a.sample_cap = p->frontier_cap;
+    a.M = p->max_sample_count;
+    a.rng = rng_plan{0, p->random_seeds_dev, p->frontier_batch, p->frontier_seg};
+    a.bv.target_batch = p->node_batch; a.bv.target_seg = p->node_seg; a.bv.G = p->n_batches;
+    a.bv.sample_batch = p->frontier_batch; a.bv.sample_seg = p->frontier_seg; a.bv.sample_local0 = p->frontier_local0;
+    a.bv.unique_batch = p->nodes_out_batch; a.bv.unique_seg = p->nodes_out_seg;
+    a.bv.frontier_out = p->frontier_out; a.bv.frontier_batch_out = p->frontier_out_batch;
+    a.bv.frontier_seg_out = p->frontier_out_seg; a.bv.frontier_local0_out = p->frontier_out_local0;
+    a.bv.neighbor_local_out = p->neighbor_local; a.bv.center_local_out = p->center_local;
+    a.offsets = p->offsets; a.neighbor_row = p->neighbor_row_scratch; a.center_row = p->center_row_scratch;
+    a.edge_gid = p->edge_gid; a.edge_cap = p->edge_cap; a.unique = p->nodes_out; a.counts_dev = p->counts_dev;
+    a.workspace = p->workspace; a.workspace_bytes = p->workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
+    WG_REQUIRE_INPUT(a.neighbor_row != nullptr, "neighbor_row_scratch is NULL");
     run_hop(a);
   });
 }

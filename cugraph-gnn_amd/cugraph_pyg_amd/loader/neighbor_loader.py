@@ -40,7 +40,8 @@ class NeighborLoader(NodeLoader):
             graph_store._set_weight_attr((feature_store, weight_attr))
         if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
             core = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
-                                   with_replacement=replace, disjoint=disjoint, heterogeneous=False, temporal=False)
+                                   with_replacement=replace, disjoint=disjoint, heterogeneous=False, temporal=False,
+                                   local_seeds_per_call=local_seeds_per_call)
         else:
             if compression is not None and compression != "COO":
                 raise ValueError("Only COO format is supported for heterogeneous graphs!")

@@ -162,7 +162,7 @@ class NeighborSampler:
 
     def __init__(self, graph: CSRGraph, fanout: Sequence[int], biased: bool = False,
                  with_replacement: bool = False, disjoint: bool = False, heterogeneous: bool = False,
-                 temporal: bool = False, **_ignored):
+                 temporal: bool = False, local_seeds_per_call: Optional[int] = None, **_ignored):
         if with_replacement:
             raise NotImplementedError("sampling with replacement is not implemented (kernels sample without)")
         if disjoint or heterogeneous or temporal:
@@ -170,12 +170,42 @@ class NeighborSampler:
         if biased and graph.weight is None:
             raise ValueError("biased sampling needs a weight attribute (weight_attr=...)")
         self.graph, self.fanout, self.biased = graph, [int(f) for f in fanout], biased
+        self.local_seeds_per_call = local_seeds_per_call
+        self._walks = {}
+
+    def _call_group_walk(self, batch_size: int, n_batches: int):
+        from wholegraph_amd.fused import PygNoSyncWalk
+        key = (batch_size, n_batches)
+        if key not in self._walks:
+            self._walks[key] = PygNoSyncWalk(self.graph.row_ptr, self.graph.col, batch_size, self.fanout, n_batches)
+        return self._walks[key]
 
     def sample_batches(self, seeds: torch.Tensor, batch_size: int, random_state: int) -> Iterator:
+        """Yields ``(batch index, (node, row, col, edge, num_sampled_nodes, num_sampled_edges))``.
+
+        Uniform sampling with positive fan-outs runs in CALL GROUPS (``local_seeds_per_call`` seeds per
+        launch sequence, default 16 mini-batches — the reference splits its seeds the same way,
+        sampler/distributed_sampler.py:391-410) on the no-host-sync kernels; everything else (biased,
+        fan-out -1, the ragged last batch) goes through the one-batch-at-a-time C-ABI ops.  Both routes
+        return identical results (tests/test_gpu_pyg_loader.py)."""
         n = seeds.shape[0]
-        for b, start in enumerate(range(0, n, batch_size)):
-            yield b, neighbor_sample(self.graph, seeds[start:start + batch_size], self.fanout, random_state + b,
-                                     self.biased)
+        fast = (not self.biased) and all(f > 0 for f in self.fanout) and seeds.is_cuda
+        n_full = n // batch_size if fast else 0
+        per_call = self.local_seeds_per_call or 16 * batch_size
+        G = max(1, per_call // batch_size)
+        seeds = seeds.to(self.graph.col.dtype)
+        b = 0
+        while b < n_full:
+            g = min(G, n_full - b)
+            walk = self._call_group_walk(batch_size, g)
+            rs = [[hop_seed(random_state + b + j, k) for j in range(g)] for k in range(len(self.fanout))]
+            res = walk.run(seeds[b * batch_size:(b + g) * batch_size].contiguous(), rs)
+            for j, out in enumerate(res.finalize_batches(self.graph.edge_id)):
+                yield b + j, out
+            b += g
+        for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
+            yield bb, neighbor_sample(self.graph, seeds[start:start + batch_size], self.fanout, random_state + bb,
+                                      self.biased)
 
 
 class BaseSampler:

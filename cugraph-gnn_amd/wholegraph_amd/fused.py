@@ -204,3 +204,143 @@ class SingleBatchNoSyncWalk:
             res.unique_seg.append(u_seg)
             targets, n_ptr, t_seg = unique, counts[k].data_ptr() + 4, u_seg
         return res
+
+
+# --------------------------------------------------------------------------------------------------
+# PyG-style call-group walk (expand only the vertices first seen by the previous hop)
+# --------------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+class _PygHop(_ct.Structure):
+    """ctypes mirror of ``wgamd_pyg_hop_t`` (include/wgamd_ext.h)."""
+    _fields_ = [("csr_row_ptr", _ct.c_void_p), ("csr_col", _ct.c_void_p), ("id_dtype", _ct.c_int),
+                ("n_batches", _ct.c_int), ("max_sample_count", _ct.c_int), ("random_seeds_dev", _ct.c_void_p),
+                ("nodes", _ct.c_void_p), ("node_batch", _ct.c_void_p), ("node_seg", _ct.c_void_p),
+                ("node_cap", _ct.c_int64),
+                ("frontier", _ct.c_void_p), ("frontier_batch", _ct.c_void_p), ("frontier_seg", _ct.c_void_p),
+                ("frontier_local0", _ct.c_void_p), ("frontier_cap", _ct.c_int64),
+                ("offsets", _ct.c_void_p), ("neighbor_local", _ct.c_void_p), ("center_local", _ct.c_void_p),
+                ("edge_gid", _ct.c_void_p), ("edge_cap", _ct.c_int64),
+                ("nodes_out", _ct.c_void_p), ("nodes_out_batch", _ct.c_void_p), ("nodes_out_seg", _ct.c_void_p),
+                ("frontier_out", _ct.c_void_p), ("frontier_out_batch", _ct.c_void_p),
+                ("frontier_out_seg", _ct.c_void_p), ("frontier_out_local0", _ct.c_void_p),
+                ("counts_dev", _ct.c_void_p), ("neighbor_row_scratch", _ct.c_void_p),
+                ("center_row_scratch", _ct.c_void_p), ("workspace", _ct.c_void_p), ("workspace_bytes", _ct.c_size_t)]
+
+
+@dataclass
+class PygWalkResult:
+    """Capacity-sized outputs of one PyG-style walk over a call group (everything on the device).
+    Hop k: ``offsets[k]`` (CSR over that hop's frontier), ``row_local[k]`` / ``col_local[k]`` (per-batch local
+    ids of the sampled neighbour / the expanded vertex), ``edge_gid[k]`` (CSR slot), ``frontier_seg[k]``
+    (input frontier segments; hop 0: b*B).  ``nodes`` / ``node_seg``: the final per-batch vertex lists."""
+    hops: int
+    n_batches: int
+    batch_size: int
+    nodes: torch.Tensor = None
+    node_seg: torch.Tensor = None
+    offsets: List[torch.Tensor] = field(default_factory=list)
+    row_local: List[torch.Tensor] = field(default_factory=list)
+    col_local: List[torch.Tensor] = field(default_factory=list)
+    edge_gid: List[torch.Tensor] = field(default_factory=list)
+    frontier_seg: List[torch.Tensor] = field(default_factory=list)
+    counts: torch.Tensor = None
+
+    def finalize_batches(self, edge_id: torch.Tensor = None):
+        """Per mini-batch ``(node, row, col, edge, num_sampled_nodes, num_sampled_edges)`` — the tuple of
+        ``cugraph_pyg_amd.sampler.neighbor_sample``.  ``edge_id`` maps CSR slots to original edge ids."""
+        G, hops = self.n_batches, self.hops
+        fseg = [t.cpu().tolist() for t in self.frontier_seg]          # hops+1 lists (the last one = final new counts)
+        nseg = self.node_seg.cpu().tolist()
+        eseg = [self.offsets[k][torch.as_tensor(fseg[k], device=self.offsets[k].device).long()].cpu().tolist()
+                for k in range(hops)]
+        out = []
+        for b in range(G):
+            rows, cols, edges, nn, ne = [], [], [], [fseg[0][b + 1] - fseg[0][b]], []
+            for k in range(hops):
+                e0, e1 = eseg[k][b], eseg[k][b + 1]
+                rows.append(self.row_local[k][e0:e1].long())
+                cols.append(self.col_local[k][e0:e1].long())
+                gid = self.edge_gid[k][e0:e1]
+                edges.append(edge_id[gid] if edge_id is not None else gid)
+                ne.append(e1 - e0)
+                nn.append(fseg[k + 1][b + 1] - fseg[k + 1][b])
+            out.append((self.nodes[nseg[b]:nseg[b + 1]], torch.cat(rows), torch.cat(cols), torch.cat(edges), nn, ne))
+        return out
+
+
+class PygNoSyncWalk:
+    """Call-group sampler with PyG hop semantics on ``wgamd_sample_hop_pyg_nosync`` — the MI355X-native
+    counterpart of one ``pylibcugraph.homogeneous_uniform_neighbor_sample`` call over many batches
+    (SURVEY.md §8 row a14)."""
+
+    def __init__(self, csr_row_ptr, csr_col_ind, batch_size: int, fanout: List[int], n_batches: int = 1):
+        assert csr_row_ptr.is_cuda and csr_col_ind.is_cuda and csr_col_ind.dtype in (torch.int32, torch.int64)
+        assert all(0 < f for f in fanout), "the no-sync walk needs positive fan-outs"
+        self.row_ptr, self.col = csr_row_ptr, csr_col_ind
+        self.id_dtype, self.wm_dtype = csr_col_ind.dtype, torch_dtype_to_wm(csr_col_ind.dtype)
+        self.G, self.B, self.fanout = int(n_batches), int(batch_size), [int(f) for f in fanout]
+        dev = csr_row_ptr.device
+        self.frontier_caps, self.edge_caps, self.node_caps = [], [], []
+        f, n = self.G * self.B, self.G * self.B
+        for m in self.fanout:
+            self.frontier_caps.append(f)
+            self.node_caps.append(n)
+            self.edge_caps.append(f * m)
+            n, f = n + f * m, f * m
+        assert n < (1 << 30), "call group too large: lower n_batches"
+        lib = L.lib()
+        ws = max(lib.wgamd_sample_hop_workspace_bytes(max(nc, fc), ec, self.wm_dtype)
+                 for nc, fc, ec in zip(self.node_caps, self.frontier_caps, self.edge_caps))
+        self.workspace = torch.empty(ws + 256, dtype=torch.uint8, device=dev)
+        self.ws_off, self.ws_bytes, self.dev = (-self.workspace.data_ptr()) % 256, ws, dev
+        self.seed_seg = (torch.arange(self.G + 1, dtype=torch.int32, device=dev) * self.B).contiguous()
+        self.seed_batch = torch.arange(self.G, dtype=torch.int32, device=dev).repeat_interleave(self.B).contiguous()
+        self.zeros_g = torch.zeros(self.G, dtype=torch.int32, device=dev)
+
+    def run(self, seeds: torch.Tensor, random_seeds) -> PygWalkResult:
+        """``seeds`` [G*B] (batch b = seeds[b*B:(b+1)*B]); ``random_seeds`` int64 tensor / nested list [hops, G]."""
+        assert seeds.dtype == self.id_dtype and seeds.shape[0] == self.G * self.B
+        lib, dev, G = L.lib(), self.dev, self.G
+        hops = len(self.fanout)
+        if isinstance(random_seeds, torch.Tensor):
+            rs = random_seeds.to(device=dev, dtype=torch.int64).contiguous()
+        else:
+            rs = torch.tensor([[v - (1 << 64) if v & (1 << 63) else v for v in (int(x) & 0xFFFFFFFFFFFFFFFF for x in row)]
+                               for row in random_seeds], dtype=torch.int64, device=dev)
+        assert rs.shape == (hops, G)
+        res = PygWalkResult(hops, G, self.B, counts=torch.empty((hops, 2), dtype=torch.int32, device=dev))
+        res._keepalive = [rs]
+        nodes, n_batch, n_seg = seeds, self.seed_batch, self.seed_seg
+        front, f_batch, f_seg, f_local0 = seeds, self.seed_batch, self.seed_seg, self.zeros_g
+        i32 = dict(dtype=torch.int32, device=dev)
+        for k, (m, fc, nc, ec) in enumerate(zip(self.fanout, self.frontier_caps, self.node_caps, self.edge_caps)):
+            offsets = torch.empty(fc + 1, **i32)
+            row_l, col_l = torch.empty(ec, **i32), torch.empty(ec, **i32)
+            scratch_r, scratch_c = torch.empty(ec, **i32), torch.empty(ec, **i32)
+            gid = torch.empty(ec, dtype=torch.int64, device=dev)
+            nodes_out = torch.empty(nc + ec, dtype=self.id_dtype, device=dev)
+            nodes_out_batch, nodes_out_seg = torch.empty(nc + ec, **i32), torch.empty(G + 1, **i32)
+            f_out = torch.empty(ec, dtype=self.id_dtype, device=dev)
+            f_out_batch, f_out_seg, f_out_l0 = torch.empty(ec, **i32), torch.empty(G + 1, **i32), torch.empty(G, **i32)
+            p = _PygHop(self.row_ptr.data_ptr(), self.col.data_ptr(), self.wm_dtype, G, m, rs[k].data_ptr(),
+                        nodes.data_ptr(), n_batch.data_ptr(), n_seg.data_ptr(), nc,
+                        front.data_ptr(), f_batch.data_ptr(), f_seg.data_ptr(), f_local0.data_ptr(), fc,
+                        offsets.data_ptr(), row_l.data_ptr(), col_l.data_ptr(), gid.data_ptr(), ec,
+                        nodes_out.data_ptr(), nodes_out_batch.data_ptr(), nodes_out_seg.data_ptr(),
+                        f_out.data_ptr(), f_out_batch.data_ptr(), f_out_seg.data_ptr(), f_out_l0.data_ptr(),
+                        res.counts[k].data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(),
+                        self.workspace.data_ptr() + self.ws_off, self.ws_bytes)
+            L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
+            res.offsets.append(offsets)
+            res.row_local.append(row_l)
+            res.col_local.append(col_l)
+            res.edge_gid.append(gid)
+            res.frontier_seg.append(f_seg)
+            res._keepalive += [scratch_r, scratch_c, f_batch, n_batch, front, f_local0]
+            nodes, n_batch, n_seg = nodes_out, nodes_out_batch, nodes_out_seg
+            front, f_batch, f_seg, f_local0 = f_out, f_out_batch, f_out_seg, f_out_l0
+        res.frontier_seg.append(f_seg)      # new vertices of the last hop (for num_sampled_nodes)
+        res.nodes, res.node_seg = nodes, n_seg
+        return res

@@ -180,6 +180,65 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(const int64_t* csr_row_
                                                          size_t workspace_bytes,
                                                          void* stream);
 
+/* One hop of the PyG-style walk for a call group — what cugraph_pyg's sampling call produces
+ * (pylibcugraph.*_neighbor_sample(renumber=True, prior_sources_behavior="exclude",
+ * deduplicate_sources=True, retain_seeds=True); call site
+ * /root/reference/python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:877-908): hop k expands only
+ * the vertices FIRST SEEN by hop k-1 (the frontier), and renumbers the sampled neighbours against ALL
+ * vertices of the mini-batch so far.  Same kernels as the WholeGraph-style hop; per mini-batch the
+ * result equals chaining wholegraph_csr_unweighted_sample_without_replacement(frontier) and
+ * graph_append_unique(nodes, neighbours) with that batch's seed.
+ *   nodes / node_batch / node_seg        per-batch vertex lists so far, concatenated (batch b =
+ *                                        [node_seg[b], node_seg[b+1]); node_seg[G] = live count)
+ *   frontier / _batch / _seg / _local0   the vertices to expand, by batch; local0[b] = local id (inside
+ *                                        batch b) of its first frontier vertex
+ *   offsets           int32[frontier_cap+1]  CSR row_ptr over the frontier
+ *   neighbor_local / center_local  int32[edge_cap]  per-batch LOCAL ids of both ends of every sampled edge
+ *                                        (PyG: row = neighbor_local, col = center_local)
+ *   edge_gid          int64[edge_cap] CSR slot of every sampled edge (nullable)
+ *   nodes_out / _batch / _seg            the grown per-batch lists (input lists ++ new vertices), slack = -1
+ *   frontier_out / _batch / _seg / _local0   the next hop's frontier (= vertices first seen now)
+ *   counts_dev        int32[2] {n_edges, n_nodes_out}
+ *   neighbor_row_scratch / center_row_scratch int32[edge_cap] scratch
+ * Capacities: edge_cap >= frontier_cap * M; nodes_out holds node_cap + edge_cap entries.
+ * Workspace: wgamd_sample_hop_workspace_bytes(max(node_cap, frontier_cap), edge_cap, id_dtype). */
+typedef struct wgamd_pyg_hop_t {
+  const int64_t* csr_row_ptr;
+  const void* csr_col;
+  wholememory_dtype_t id_dtype;
+  int n_batches;
+  int max_sample_count;
+  const unsigned long long* random_seeds_dev;
+  const void* nodes;
+  const int* node_batch;
+  const int* node_seg;
+  int64_t node_cap;
+  const void* frontier;
+  const int* frontier_batch;
+  const int* frontier_seg;
+  const int* frontier_local0;
+  int64_t frontier_cap;
+  int* offsets;
+  int* neighbor_local;
+  int* center_local;
+  int64_t* edge_gid;
+  int64_t edge_cap;
+  void* nodes_out;
+  int* nodes_out_batch;
+  int* nodes_out_seg;
+  void* frontier_out;
+  int* frontier_out_batch;
+  int* frontier_out_seg;
+  int* frontier_out_local0;
+  int* counts_dev;
+  int* neighbor_row_scratch;
+  int* center_row_scratch;
+  void* workspace;
+  size_t workspace_bytes;
+} wgamd_pyg_hop_t;
+
+wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

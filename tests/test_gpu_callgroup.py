@@ -82,3 +82,32 @@ def test_batched_block_diagonal_aggregation_matches_per_batch(oracle_mod, hiplib
         otg, oei, orp, oci = oracle_mod.multilayer_sample(row_ptr, col, seeds[b * B:(b + 1) * B], fan, [10 + b, 20 + b])
         ref = oracle_mod.spmm_csr(orp[0], oci[0], feat[otg[0]], mean=True, acc_double=False)
         assert np.array_equal(agg[tseg[b]:tseg[b + 1]].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("G,B", [(1, 200), (6, 100), (16, 33)])
+@pytest.mark.parametrize("fanouts", [[25, 10], [10, 5, 3], [4]])
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_pyg_style_call_group_walk_vs_oracle(oracle_mod, hiplib, G, B, fanouts, dtype):
+    """PyG hop semantics (expand only newly discovered vertices) for a call group: every mini-batch must equal
+    the oracle composition sample(frontier) -> append_unique(all nodes so far, neighbours)."""
+    import torch
+    from wholegraph_amd.fused import PygNoSyncWalk
+    from test_gpu_pyg_loader import oracle_neighbor_sample
+    from cugraph_pyg_amd.sampler.sampler import hop_seed
+    row_ptr, col = powerlaw_csr(15000, 14, seed=8, col_dtype=dtype, max_deg=2500)
+    eid = np.random.default_rng(3).permutation(col.size).astype(np.int64)     # arbitrary slot -> edge-id map
+    rng = np.random.default_rng(G + B)
+    seeds = np.concatenate([rng.permutation(15000)[:B] for _ in range(G)]).astype(dtype)
+    rstate = [500 + b for b in range(G)]
+    rs = [[hop_seed(rstate[b], k) for b in range(G)] for k in range(len(fanouts))]
+    walk = PygNoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), B, fanouts, G)
+    res = walk.run(torch.from_numpy(seeds).cuda(), rs)
+    per_batch = res.finalize_batches(torch.from_numpy(eid).cuda())
+    for b in range(G):
+        node, row, colv, edge, nn, ne = oracle_neighbor_sample(oracle_mod, row_ptr, col, eid, seeds[b * B:(b + 1) * B],
+                                                               fanouts, rstate[b])
+        g_node, g_row, g_col, g_edge, g_nn, g_ne = per_batch[b]
+        assert np.array_equal(g_node.cpu().numpy(), node)
+        assert np.array_equal(g_row.cpu().numpy(), row) and np.array_equal(g_col.cpu().numpy(), colv)
+        assert np.array_equal(g_edge.cpu().numpy(), edge)
+        assert g_nn == nn and g_ne == ne
