@@ -213,6 +213,11 @@ def main():
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--edges", type=int, default=None, help="undirected RMAT edges before symmetrising")
     ap.add_argument("--call-group", type=int, default=64, help="max mini-batches per launch sequence")
+    ap.add_argument("--feature-placement", choices=["auto", "replicated", "partitioned"], default="auto",
+                    help="N>1: replicate the feature table on every GPU when it is small next to 288 GB of HBM "
+                         "(auto: <= 36 GB), otherwise range-partition it and fetch remote rows by RCCL all-to-all")
+    ap.add_argument("--force-partitioned", action="store_true",
+                    help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -220,8 +225,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_partitioned:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
@@ -238,7 +244,13 @@ def main():
     row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
     V, E = args.nodes, int(col.shape[0])
     gfeat = torch.Generator(device=device).manual_seed(100 + rank)
-    if world == 1:
+    table_bytes = V * FEAT_DIM * 4
+    partitioned = args.force_partitioned or (world > 1 and (args.feature_placement == "partitioned" or (
+        args.feature_placement == "auto" and table_bytes > (36 << 30))))
+    if not partitioned:
+        # single GPU, or a table that is small next to 288 GB of HBM3E: every GPU keeps the whole table and the
+        # walk + fetch need no collective at all (seeds are the independent units)
+        gfeat.manual_seed(100)
         feat = WholeMemoryTensor((torch.rand((V, FEAT_DIM), generator=gfeat, device=device) * 2 - 1))
     else:
         offs = equal_entry_partition(V, world)
@@ -344,7 +356,7 @@ def main():
                 # papers100M-scale table: a lazily-zeroed host array of the same shape (only the gathered
                 # rows' pages are ever touched; values do not matter for the timing)
                 feat_h = np.zeros((V, FEAT_DIM), dtype=np.float32)
-            elif world > 1:
+            elif partitioned and world > 1:
                 feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
             else:
                 feat_h = feat.local_tensor.cpu().numpy()
@@ -366,10 +378,11 @@ def main():
             "config": {"workload": "ogbn-" + args.workload + "-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
                                    "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, 2-layer SAGEConv(mean) %d-%d-%d fwd, "
                                    "%d mini-batches per launch sequence (call group)"
-                                   % (V, E, FEAT_DIM, "" if world == 1 else " range-partitioned + RCCL all-to-all",
+                                   % (V, E, FEAT_DIM, " range-partitioned + RCCL all-to-all" if partitioned else
+                                      ("" if world == 1 else " replicated per GPU"),
                                       BATCH, FANOUT, FEAT_DIM, HIDDEN, CLASSES, G),
-                       "parallelism": "dp%d (seeds sharded, no data-path collective)" % world if world == 1
-                       else "dp%d seeds + feature all-to-all" % world},
+                       "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
+                       else "dp%d (seeds sharded, no data-path collective)" % world},
             "call_group": G,
             "edges_per_batch": {"hop1": e1 / G, "hop2": e2 / G, "unique_nodes": n_src / G},
             "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
@@ -380,8 +393,11 @@ def main():
         }
         if cpu is not None:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
-        print(json.dumps(out))
-    if world > 1:
+        # RCCL writes a version banner through C stdio; push it out first so the JSON is the LAST line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
