@@ -171,7 +171,7 @@ class GraphStore(_PygGraphStore):
                     num[dst_t] = max(num.get(dst_t, 0), int(ei[1].max()) + 1)
         if self.is_multi_gpu:
             for k in sorted(num):
-                t = torch.tensor(num[k], device="cuda")
+                t = torch.tensor(num[k], device="cuda" if torch.cuda.is_available() else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 num[k] = int(t)
         return num

@@ -15,12 +15,14 @@ class DistTensor:
     """1-D (or N-D with dim-0 partitioning) distributed tensor."""
 
     _ndim = 1
+    default_local_ops = HipLocalOps   # the product's row kernels; CPU tests inject the oracle's here
 
     def __init__(self, src: Optional[torch.Tensor] = None, shape: Optional[Sequence[int]] = None,
                  dtype: Optional[torch.dtype] = None, device: str = "cuda", backend: Optional[str] = None,
-                 partition_offsets: Optional[Sequence[int]] = None, group=None, local_ops=HipLocalOps):
+                 partition_offsets: Optional[Sequence[int]] = None, group=None, local_ops=None):
         if src is None and (shape is None or dtype is None):
             raise ValueError("Please specify shape and dtype for empty tensor.")
+        local_ops = local_ops if local_ops is not None else DistTensor.default_local_ops
         self._group = group
         ws, rk = _dist.world_size(group), _dist.rank(group)
         dev = "cuda" if torch.cuda.is_available() else "cpu"

@@ -108,3 +108,66 @@ def test_equal_entry_partition_matches_reference_formula():
     for V, W in ((111059956, 8), (67108864, 8), (7, 2)):
         o = equal_entry_partition(V, W)
         assert len(o) == W + 1 and o[0] == 0 and o[-1] == V and all(b >= a for a, b in zip(o, o[1:]))
+
+
+def _store_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "cugraph-gnn_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cugraph_pyg_amd.data import FeatureStore, GraphStore
+        from cugraph_pyg_amd.tensor import DistTensor
+        DistTensor.default_local_ops = OracleLocalOps          # test-only injection (no GPU here)
+        # every rank contributes its own slice of the edges (graph_store.py: "each worker should have a slice")
+        g = torch.Generator().manual_seed(0)
+        full = torch.stack([torch.randint(0, 50, (400,), generator=g), torch.randint(0, 50, (400,), generator=g)])
+        mine = full[:, :150] if rank == 0 else full[:, 150:]    # uneven slices, rank order = global edge-id order
+        gs = GraphStore()
+        gs.put_edge_index(mine, ("n", "e", "n"), "coo", False, (50, 50))
+        assert gs.is_multi_gpu and gs.is_homogeneous
+        csr = gs._graph
+        # reference CSR from the full edge list on one process
+        order = torch.sort(full[1], stable=True).indices
+        assert torch.equal(csr.col, full[0][order]) and torch.equal(csr.edge_id, order)
+        assert csr.row_ptr.tolist() == [0] + torch.cumsum(torch.bincount(full[1], minlength=50), 0).tolist()
+        hg = gs._hetero_graphs[("n", "e", "n")]
+        assert torch.equal(hg.col, csr.col) and torch.equal(hg.edge_id, csr.edge_id)
+        # size inference needs the MAX over ranks
+        gs2 = GraphStore()
+        gs2.put_edge_index(torch.tensor([[rank * 7], [rank * 9]]), ("n", "e", "n"), "coo")
+        assert gs2._num_vertices() == {"n": 10}
+        # FeatureStore: slices concatenated in rank order, global gathers from any rank
+        fs = FeatureStore()
+        x = torch.arange(30 * 4, dtype=torch.float32).view(30, 4)
+        fs["n", "x", None] = x[:12] if rank == 0 else x[12:]
+        assert tuple(fs.get_tensor_size("n", "x", None)) == (30, 4)
+        idx = torch.tensor([29, 0, 12, 11, 5, 5])
+        assert torch.equal(fs["n", "x", None][idx], x[idx])
+        assert torch.equal(fs["n", "x", idx], x[idx])
+        y = torch.arange(30)
+        fs["n", "y", None] = y[:12] if rank == 0 else y[12:]
+        assert torch.equal(fs["n", "y", None][idx], y[idx])
+        names = sorted(a.attr_name for a in fs.get_all_tensor_attrs())
+        assert names == ["x", "y"]
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pyg_stores_world2(oracle_mod):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_store_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
