@@ -1,2 +1,3 @@
+from .link_loader import LinkLoader, LinkNeighborLoader  # noqa: F401
 from .neighbor_loader import NeighborLoader  # noqa: F401
 from .node_loader import NodeLoader  # noqa: F401

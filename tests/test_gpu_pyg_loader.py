@@ -287,3 +287,74 @@ def test_hetero_mag_like_sampling_vs_oracle_and_gat(oracle_mod, hiplib):
                                      a_s.detach().cpu().numpy(), a_d.detach().cpu().numpy(), 0.2)
         np.testing.assert_allclose((out - gat.bias).detach().cpu().numpy().reshape(-1, 4, 32), oref, rtol=1e-4, atol=1e-5)
     assert nb == 2
+
+
+# ------------------------------------------------------------------------------- link loaders
+def _link_fixture():
+    import torch
+    from graphgen import powerlaw_csr
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    V = 3000
+    rp, col = powerlaw_csr(V, 10, seed=31, max_deg=300)
+    dst = np.repeat(np.arange(V), np.diff(rp))
+    ei = torch.stack([torch.from_numpy(col), torch.from_numpy(dst)])
+    gs = GraphStore()
+    gs.put_edge_index(ei, ("n", "e", "n"), "coo", False, (V, V))
+    fs = FeatureStore()
+    x = torch.randn(V, 16)
+    fs["n", "x", None] = x
+    return V, ei, gs, fs, x
+
+
+@pytest.mark.parametrize("neg", [None, "binary", ("binary", 2.0), "triplet"])
+def test_link_neighbor_loader(hiplib, neg):
+    """Structure of the reference's link tests (tests/loader/test_neighbor_loader.py:138-350): the label
+    index points at the seed edges' endpoints inside n_id; positives first; negatives labelled 0."""
+    import torch
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    V, ei, gs, fs, x = _link_fixture()
+    seeds = ei[:, torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(1))[:333]]
+    loader = LinkNeighborLoader((fs, gs), [5, 3], edge_label_index=seeds, batch_size=100, neg_sampling=neg,
+                                random_state=9)
+    assert len(loader) == 4
+    seen = 0
+    for b, batch in enumerate(loader):
+        n_pos = min(100, 333 - b * 100)
+        n_id = batch.n_id.cpu()
+        assert batch.batch_size == n_pos and torch.equal(batch.input_id.cpu(), torch.arange(b * 100, b * 100 + n_pos))
+        assert torch.equal(batch.x.cpu(), x[n_id]) and n_id.unique().numel() == n_id.numel()
+        pos = seeds[:, b * 100:b * 100 + n_pos]
+        if neg == "triplet":
+            assert torch.equal(n_id[batch.src_index.cpu()], pos[0]) and torch.equal(n_id[batch.dst_pos_index.cpu()], pos[1])
+            assert batch.dst_neg_index.numel() == n_pos and int(batch.dst_neg_index.max()) < n_id.numel()
+        else:
+            eli = batch.edge_label_index.cpu()
+            assert torch.equal(n_id[eli[0, :n_pos]], pos[0]) and torch.equal(n_id[eli[1, :n_pos]], pos[1])
+            if neg is None:
+                assert eli.shape[1] == n_pos
+            else:
+                amount = 2.0 if isinstance(neg, tuple) else 1.0
+                assert eli.shape[1] == n_pos + int(round(n_pos * amount))
+                assert batch.edge_label.cpu().tolist() == [1.0] * n_pos + [0.0] * int(round(n_pos * amount))
+        # the sampled subgraph is a valid neighbourhood: every edge exists, seeds' endpoints come first
+        gsrc, gdst = n_id[batch.edge_index[0].cpu()], n_id[batch.edge_index[1].cpu()]
+        assert torch.equal(ei[0][batch.e_id.cpu()], gsrc) and torch.equal(ei[1][batch.e_id.cpu()], gdst)
+        seen += n_pos
+    assert seen == 333
+
+
+def test_link_loader_labels_and_determinism(hiplib):
+    import torch
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    V, ei, gs, fs, x = _link_fixture()
+    seeds = ei[:, :64]
+    labels = torch.arange(64) % 3
+    a = [b for b in LinkNeighborLoader((fs, gs), [4], edge_label_index=seeds, edge_label=labels, batch_size=32,
+                                       neg_sampling="binary", random_state=3)]
+    b2 = [b for b in LinkNeighborLoader((fs, gs), [4], edge_label_index=seeds, edge_label=labels, batch_size=32,
+                                        neg_sampling="binary", random_state=3)]
+    for u, v in zip(a, b2):
+        assert torch.equal(u.n_id, v.n_id) and torch.equal(u.edge_label_index, v.edge_label_index)
+    assert a[0].edge_label.cpu()[:32].tolist() == (labels[:32] + 1).tolist()      # positives shifted by one, negatives 0
+    plain = next(iter(LinkNeighborLoader((fs, gs), [4], edge_label_index=seeds, edge_label=labels, batch_size=32)))
+    assert plain.edge_label.cpu().tolist() == labels[:32].tolist()
