@@ -124,7 +124,7 @@ class SagePipeline:
         ev.record()
         return res, sizes_h, ev
 
-    def forward(self, res, sizes_h, ev, timers=None):
+    def forward(self, res, sizes_h, ev, timers=None, fused_fetch=False):
         """Feature fetch + 2-layer SAGE forward of one call group with exact (host-known) sizes."""
         nn = self.nn
         ev.synchronize()
@@ -142,7 +142,9 @@ class SagePipeline:
             return out
 
         n_id = res.unique[1][:u2]
-        if self.distributed:
+        if fused_fetch:
+            x = None          # never materialised: layer 1 reads the feature table through n_id
+        elif self.distributed:
             x = stage("gather(all-to-all)", lambda: self.feat.gather(n_id))
         else:
             from wholegraph_amd.tensor import local_gather
@@ -150,8 +152,12 @@ class SagePipeline:
                                                      torch.empty((u2, FEAT_DIM), dtype=torch.float32, device=self.device)))
         # layer 1: one kernel builds [mean_j x_j | x_i], one GEMM applies [W_l | W_r] with bias, then ReLU
         rows1 = res.target_rows_in_unique(1, u1)   # "x[:num_dst]" of the block-diagonal layout
-        cat1 = stage(SPMM1,
-                     lambda: nn.sage_aggregate_forward(res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], x, rows1, True))
+        if fused_fetch:
+            cat1 = stage("fetch+" + SPMM1, lambda: nn.sage_aggregate_fetch_forward(
+                res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], self.feat.local_tensor, n_id, rows1, True))
+        else:
+            cat1 = stage(SPMM1, lambda: nn.sage_aggregate_forward(res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], x,
+                                                                  rows1, True))
         h1 = stage("dense1", lambda: self.dense(cat1, self.w1_t, self.b1, relu=True))
         # layer 2: destinations are the seeds = the first BATCH rows of every batch's hop-1 unique list
         seed_rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
@@ -273,12 +279,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_groups(first, last, timers=None, sizes=None):
+    def run_groups(first, last, timers=None, sizes=None, fused_fetch=False):
         """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
         pending = pipe.sample(batches[first], first)
         for g in range(first, last):
             nxt = pipe.sample(batches[g + 1], g + 1) if g + 1 < last else None
-            _, sz = pipe.forward(*pending, timers=timers)
+            _, sz = pipe.forward(*pending, timers=timers, fused_fetch=fused_fetch)
             if sizes is not None:
                 sizes.append(sz)
             pending = nxt
@@ -301,6 +307,27 @@ def main():
         dt, edges_total = float(tmax), float(esum)
     else:
         edges_total = float(edges_local)
+
+    # ---- variant: feature fetch fused into the layer-1 aggregation (x never materialised); same groups,
+    # reported next to the headline, which keeps the reference's explicit gather stage
+    fused = None
+    if not partitioned:
+        run_groups(0, warm_groups, fused_fetch=True)
+        barrier()
+        tf0 = time.perf_counter()
+        fsizes = []
+        run_groups(warm_groups, total_groups, sizes=fsizes, fused_fetch=True)
+        barrier()
+        tf = time.perf_counter() - tf0
+        fstats = torch.tensor([tf, float(sum(s[0] + s[2] for s in fsizes))], dtype=torch.float64, device=device)
+        if world > 1:
+            a, b2 = fstats[:1].clone(), fstats[1:].clone()
+            dist.all_reduce(a, op=dist.ReduceOp.MAX)
+            dist.all_reduce(b2, op=dist.ReduceOp.SUM)
+            fstats = torch.cat([a, b2])
+        fused = {"value": float(fstats[1] / fstats[0]), "ms_per_step": float(fstats[0]) / args.steps * 1e3,
+                 "note": "same workload with the feature fetch fused into the layer-1 aggregation kernel "
+                         "(wgamd_sage_aggregate_fetch_f32): x = feat[n_id] is never written to HBM"}
 
     # ---- per-stage HIP-event timing pass (same pipeline, same stream; after the timed region) --
     stage_ms, stage_n = {}, 0
@@ -388,6 +415,7 @@ def main():
             "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
             "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
             "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
+            "fused_fetch_variant": fused,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
         }
         if (self_rows != nullptr) {
           // SAGEConv root term: out[row, F:2F] = x[self_rows[row], :]  ->  one GEMM over [mean | self]
-          const float* p = x + self_rows[row] * ldx + f0;
+          const float* p = x + src_row<IdT>(src_ids, (int)self_rows[row]) * ldx + f0;
           if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(q + F) = *reinterpret_cast<const float4*>(p);
           } else {
@@ -304,6 +304,19 @@ wholememory_error_code_t wgamd_spmm_csr_f32(const int* row_ptr, const int* col, 
 {
   return spmm_entry("wgamd_spmm_csr_f32", row_ptr, col, n_rows, x, ldx, F, src_ids, src_ids_dtype, mean, out, ldo,
                     nullptr, stream);
+}
+
+wholememory_error_code_t wgamd_sage_aggregate_fetch_f32(const int* row_ptr, const int* col, int64_t n_rows,
+                                                        const float* table, int64_t ldt, int F, const void* src_ids,
+                                                        wholememory_dtype_t src_ids_dtype, const int64_t* self_rows,
+                                                        int mean, float* out, int64_t ldo, void* stream)
+{
+  if (self_rows == nullptr || src_ids == nullptr || ldo < 2 * (int64_t)F) {
+    fprintf(stderr, "[wholegraph_amd] wgamd_sage_aggregate_fetch_f32: self_rows / src_ids is NULL or ldo < 2F\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  return spmm_entry("wgamd_sage_aggregate_fetch_f32", row_ptr, col, n_rows, table, ldt, F, src_ids, src_ids_dtype, mean,
+                    out, ldo, self_rows, stream);
 }
 
 wholememory_error_code_t wgamd_sage_aggregate_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,

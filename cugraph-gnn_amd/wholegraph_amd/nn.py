@@ -56,6 +56,21 @@ def sage_aggregate_forward(row_ptr, col, x, self_rows, mean=True):
     return out
 
 
+def sage_aggregate_fetch_forward(row_ptr, col, table, src_ids, self_rows, mean=True):
+    """``sage_aggregate_forward`` with the feature fetch fused in: ``table`` is the global feature table and
+    ``src_ids`` the batch's local->global map, so ``x = table[src_ids]`` is never written to HBM."""
+    _check_csr(row_ptr, col)
+    assert table.dtype == torch.float32 and table.dim() == 2 and table.stride(1) == 1
+    assert self_rows.dtype == torch.int64 and self_rows.is_contiguous() and src_ids.is_contiguous()
+    n_rows, F_ = row_ptr.shape[0] - 1, table.shape[1]
+    out = torch.empty((n_rows, 2 * F_), dtype=torch.float32, device=table.device)
+    L.check(L.lib().wgamd_sage_aggregate_fetch_f32(
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, table.data_ptr(), table.stride(0), F_, src_ids.data_ptr(),
+        torch_dtype_to_wm(src_ids.dtype), self_rows.data_ptr(), int(bool(mean)), out.data_ptr(), out.stride(0),
+        get_stream()), "wgamd_sage_aggregate_fetch_f32")
+    return out
+
+
 class _SpmmCsr(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, row_ptr, col, mean):

@@ -65,6 +65,23 @@ wholememory_error_code_t wgamd_sage_aggregate_f32(const int* row_ptr,
                                                   int64_t ldo,
                                                   void* stream);
 
+/* The same with the FEATURE FETCH fused in: `table` is the global feature table and src_ids the mini-batch's
+ * local -> global map (INT|INT64), so the batch feature matrix x = table[src_ids] is never materialised:
+ *   out[i, 0:F]  = REDUCE_e table[src_ids[col[e]], :]      out[i, F:2F] = table[src_ids[self_rows[i]], :] */
+wholememory_error_code_t wgamd_sage_aggregate_fetch_f32(const int* row_ptr,
+                                                        const int* col,
+                                                        int64_t n_rows,
+                                                        const float* table,
+                                                        int64_t ldt,
+                                                        int F,
+                                                        const void* src_ids,
+                                                        wholememory_dtype_t src_ids_dtype,
+                                                        const int64_t* self_rows,
+                                                        int mean,
+                                                        float* out,
+                                                        int64_t ldo,
+                                                        void* stream);
+
 /* Backward of the above w.r.t. x (src_ids == NULL form):
  *   grad_x[col[e], :] += grad_out[i, :] * (mean ? 1/max(deg_i,1) : 1)   for every edge e of row i.
  * grad_x must be zero-initialised (or hold the gradient to accumulate into) by the caller. */

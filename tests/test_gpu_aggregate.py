@@ -113,3 +113,22 @@ def test_sage_aggregate_concat_self(oracle_mod, hiplib, F):
     assert out.shape == (2000, 2 * F)
     assert np.array_equal(out[:, :F], oracle_mod.spmm_csr(rp, col, x, mean=True, acc_double=False))
     assert np.array_equal(out[:, F:], x[self_rows])
+
+
+def test_sage_aggregate_fused_feature_fetch(oracle_mod, hiplib):
+    import torch
+    from wholegraph_amd import nn
+    rp, col = _csr(1500, 4000, 25, 3)
+    table = np.random.default_rng(0).standard_normal((50000, 100)).astype(np.float32)
+    n_id = np.random.default_rng(1).permutation(50000)[:4000].astype(np.int64)
+    self_rows = np.random.default_rng(2).integers(0, 4000, 1500).astype(np.int64)
+    out = nn.sage_aggregate_fetch_forward(torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda(),
+                                          torch.from_numpy(table).cuda(), torch.from_numpy(n_id).cuda(),
+                                          torch.from_numpy(self_rows).cuda(), True).cpu().numpy()
+    x = table[n_id]
+    assert np.array_equal(out[:, :100], oracle_mod.spmm_csr(rp, col, x, mean=True, acc_double=False))
+    assert np.array_equal(out[:, 100:], x[self_rows])
+    # identical to the unfused pair (gather, then aggregate)
+    ref = nn.sage_aggregate_forward(torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(x).cuda(),
+                                    torch.from_numpy(self_rows).cuda(), True).cpu().numpy()
+    assert np.array_equal(out, ref)
