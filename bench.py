@@ -82,7 +82,7 @@ class SagePipeline:
     block-diagonal concatenation.  Groups are software-pipelined: the walk of group g+1 is enqueued
     before the host reads the (tiny, pinned) size vector of group g, so the GPU queue never drains."""
 
-    def __init__(self, row_ptr, col, feat_table, device, G):
+    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True):
         from wholegraph_amd import fused, nn
         self.nn = nn
         self.device = device
@@ -100,6 +100,7 @@ class SagePipeline:
         self.w2_t = torch.cat([self.conv2.lin_l.weight, self.conv2.lin_r.weight], dim=1).t().contiguous()
         self.b1, self.b2 = self.conv1.lin_l.bias, self.conv2.lin_l.bias
         self.fused_relu = hasattr(torch, "_addmm_activation")
+        self.walk_stream = torch.cuda.Stream(device=device) if overlap_walk else None
         self.distributed = self.feat.is_distributed
 
     def dense(self, a, w_t, bias, relu):
@@ -117,11 +118,23 @@ class SagePipeline:
         rs = (torch.arange(self.G, device=self.device, dtype=torch.int64).view(1, -1) * hops
               + torch.arange(hops, device=self.device, dtype=torch.int64).view(-1, 1)
               + 62 + group_id * self.G * hops)          # seed of (hop k, batch b) = 62 + hops*global_batch + k
-        res = self.walk.run(seeds, rs)
-        sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
-        sizes_h.copy_(res.counts, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        if self.walk_stream is None:
+            res = self.walk.run(seeds, rs)
+            sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
+            sizes_h.copy_(res.counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return res, sizes_h, ev
+        # The walk (integer, random-access bound) of group g+1 runs on its own HIP stream next to the feature
+        # fetch / aggregation / GEMM of group g: different bottlenecks (random sectors + atomics vs streaming HBM +
+        # MFMA), so they overlap instead of queueing behind each other.
+        self.walk_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.walk_stream):
+            res = self.walk.run(seeds, rs)
+            sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
+            sizes_h.copy_(res.counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.walk_stream)
         return res, sizes_h, ev
 
     def forward(self, res, sizes_h, ev, timers=None, fused_fetch=False):
@@ -129,6 +142,13 @@ class SagePipeline:
         nn = self.nn
         ev.synchronize()
         (e1, u1), (e2, u2) = sizes_h.tolist()   # hop-1 (seeds) edges/unique, hop-2 edges/unique
+        if self.walk_stream is not None:
+            # the walk's outputs were allocated on the walk stream and are consumed here on the main one
+            main = torch.cuda.current_stream()
+            for lst in (res.unique, res.unique_seg, res.target_seg, res.target_batch, res.offsets, res.neighbor_row,
+                        res.center_row):
+                for t in lst:
+                    t.record_stream(main)
         t0 = self.G * BATCH
 
         def stage(name, fn):
@@ -224,6 +244,7 @@ def main():
                          "(auto: <= 36 GB), otherwise range-partition it and fetch remote rows by RCCL all-to-all")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
+    ap.add_argument("--no-overlap", action="store_true", help="run the walk on the main stream (no second HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -264,7 +285,7 @@ def main():
         feat = WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)
     # call group: the largest divisor of --steps not above --call-group
     G = max(d for d in range(1, min(args.call_group, args.steps) + 1) if args.steps % d == 0)
-    pipe = SagePipeline(row_ptr, col, feat, device, G)
+    pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap)
     groups = args.steps // G
     warm_groups = (args.warmup + G - 1) // G
     total_groups = groups + warm_groups
@@ -336,9 +357,11 @@ def main():
     for g in range(warm_groups, warm_groups + probe):
         timers = []
         w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        w0.record()
+        ws = pipe.walk_stream if pipe.walk_stream is not None else torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        w0.record(ws)
         pend = pipe.sample(batches[g], g)
-        w1.record()
+        w1.record(ws)
         _, sz = pipe.forward(*pend, timers=timers)
         torch.cuda.synchronize()
         timers.append(("walk(sample+renumber x2)", w0, w1))
