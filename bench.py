@@ -154,6 +154,10 @@ class SagePipeline:
         def stage(name, fn):
             if timers is None:
                 return fn()
+            # a short device-side spin first: the host prepares and enqueues the launch while it runs, so the
+            # start event is reached with the kernel already queued behind it and the event pair brackets the
+            # kernel itself, not the host's launch latency (rocprofv3's per-kernel average is the cross-check)
+            torch.cuda._sleep(300_000)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             out = fn()
