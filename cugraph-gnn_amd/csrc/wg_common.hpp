@@ -17,6 +17,7 @@ struct wholememory_tensor_ {
   wholememory_tensor_description_t desc;
   wholememory_tensor_* root;      // nullptr for a root tensor
   wholememory_handle_t handle;    // nullptr unless backed by a DISTRIBUTED handle
+  bool owns_handle = false;       // wholememory_create_tensor: destroy_tensor frees the handle too
 };
 
 namespace wgamd {
@@ -28,6 +29,9 @@ struct logic_error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 struct invalid_input : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct comm_error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
@@ -76,6 +80,9 @@ inline wholememory_error_code_t guarded(const char* op, F&& body)
   } catch (const hip_error& e) {
     fprintf(stderr, "[wholegraph_amd] %s: device error: %s\n", op, e.what());
     return WHOLEMEMORY_CUDA_ERROR;
+  } catch (const comm_error& e) {
+    fprintf(stderr, "[wholegraph_amd] %s: communication error: %s\n", op, e.what());
+    return WHOLEMEMORY_COMMUNICATION_ERROR;
   } catch (const std::bad_alloc&) {
     fprintf(stderr, "[wholegraph_amd] %s: out of memory\n", op);
     return WHOLEMEMORY_OUT_OF_MEMORY;
@@ -243,5 +250,18 @@ void append_unique_emit_enqueue(const void* targets, dev_count T, const void* ne
                                 batch_view bv, const int* minpos, const int* slot_of, const int* rank,
                                 void* unique_out, int* map_out, int* counts_out /*nullable: {E, T+U}*/,
                                 hipStream_t stream);
+
+
+// ---- local row kernels (wg_gather.hip) and the DISTRIBUTED pipeline built on them (wg_comm.hip) ----
+void local_rows_gather(const char* table, wholememory_matrix_description_t tm, const void* idx,
+                       wholememory_dtype_t idx_dtype, int64_t n, char* out, wholememory_matrix_description_t om,
+                       hipStream_t stream);
+void local_rows_scatter(const char* in, wholememory_matrix_description_t im, const void* idx,
+                        wholememory_dtype_t idx_dtype, int64_t n, char* table, wholememory_matrix_description_t tm,
+                        hipStream_t stream);
+// gather: dense = output rows; scatter: dense = input rows.  `tm` describes the GLOBAL table (sizes[0] = all rows).
+void distributed_rows_op(bool scatter, wholememory_handle_t handle, wholememory_matrix_description_t tm, const void* idx,
+                         wholememory_dtype_t idx_dtype, int64_t n, char* dense, wholememory_matrix_description_t dense_m,
+                         wholememory_env_func_t* env, hipStream_t stream);
 
 }  // namespace wgamd

@@ -3,8 +3,9 @@
 // Replaces wholememory_gather / wholememory_scatter
 // (/root/reference/cpp/include/wholememory/wholememory_op.h:25-47; reference kernels
 // cpp/src/wholememory_ops/functions/gather_scatter_func.cuh:242-365,508-650) for tables that wrap
-// a device pointer.  DISTRIBUTED tables go through the RCCL all-to-all pipeline built on top of
-// these local kernels (cugraph-gnn_amd/wholegraph_amd/dist.py).
+// a device pointer.  DISTRIBUTED tables (wholememory_malloc / wholememory_create_tensor with a communicator)
+// go through the RCCL all-to-all pipeline of wg_comm.hip built on top of these local kernels; the Python host
+// layer has the same pipeline over torch.distributed (cugraph-gnn_amd/wholegraph_amd/dist.py).
 //
 // gfx950 design: the op is pure HBM traffic (random 100 B – 1 KiB row reads, streaming writes).
 //   * same dtype in/out  -> dtype-agnostic byte-row copy with the widest aligned vector
@@ -257,17 +258,38 @@ void convert_in(wholememory_dtype_t in_dt, wholememory_dtype_t out_dt, const voi
   }
 }
 
-// src_t rows are read, dst_t rows are written; `indexed_is_src` <=> gather
+template <bool SCATTER>
+void rows_launch(const char* src, wholememory_matrix_description_t sm, const void* idx, wholememory_dtype_t idx_dtype,
+                 int64_t n, char* dst, wholememory_matrix_description_t dm, hipStream_t stream)
+{
+  if (n == 0) return;
+  const size_t ses = dtype_size(sm.dtype), des = dtype_size(dm.dtype);
+  const int F      = (int)sm.sizes[1];
+  if (sm.dtype == dm.dtype) {
+    if (idx_dtype == WHOLEMEMORY_DT_INT)
+      launch_copy<int32_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int32_t*>(idx), n, F * (int)ses, dst,
+                                    dm.stride * (int64_t)des, stream);
+    else
+      launch_copy<int64_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int64_t*>(idx), n, F * (int)ses, dst,
+                                    dm.stride * (int64_t)des, stream);
+  } else {
+    if (idx_dtype == WHOLEMEMORY_DT_INT)
+      convert_in<int32_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int32_t*>(idx), n, F, dst,
+                                   dm.stride, stream);
+    else
+      convert_in<int64_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int64_t*>(idx), n, F, dst,
+                                   dm.stride, stream);
+  }
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+// src_t rows are read, dst_t rows are written; gather: src is the (possibly DISTRIBUTED) table
 template <bool SCATTER>
 void rows_op(const char* op, wholememory_tensor_t src_t, wholememory_tensor_t idx_t, wholememory_tensor_t dst_t,
-             hipStream_t stream)
+             wholememory_env_func_t* env, hipStream_t stream)
 {
   WG_REQUIRE_INPUT(src_t && idx_t && dst_t, "null tensor");
   wholememory_tensor_t table = SCATTER ? dst_t : src_t;
-  if (table->handle != nullptr) {
-    throw logic_error(fmt("%s: DISTRIBUTED tables are served by the RCCL all-to-all pipeline "
-                          "(wholegraph_amd.dist), not by the single-GPU C entry point", op));
-  }
   wholememory_tensor_description_t sd = src_t->desc, dd = dst_t->desc;
   WG_REQUIRE_INPUT(sd.dim == 1 || sd.dim == 2, "table / input should be 1D or 2D tensor");
   WG_REQUIRE_INPUT(dd.dim == sd.dim, "output tensor should be same dim as input tensor");
@@ -286,54 +308,62 @@ void rows_op(const char* op, wholememory_tensor_t src_t, wholememory_tensor_t id
   WG_REQUIRE_INPUT((SCATTER ? sm.sizes[0] : dm.sizes[0]) >= n, "fewer dense rows than indices");
   bool sf = wholememory_dtype_is_floating_number(sm.dtype), df = wholememory_dtype_is_floating_number(dm.dtype);
   WG_EXPECTS(sf == df, "embedding and output should be same number type, e.g. floating number or integer number.");
+  const void* idx = tensor_data(idx_t);
+  if (table->handle != nullptr) {
+    // DISTRIBUTED table: RCCL all-to-all pipeline (wg_comm.hip); every rank must make this call
+    wholememory_tensor_t dense = SCATTER ? src_t : dst_t;
+    WG_REQUIRE_INPUT(env != nullptr, "p_env_fns is required for a DISTRIBUTED table");
+    WG_REQUIRE_INPUT(n == 0 || (dense->storage_ptr && idx), "null data pointer");
+    const size_t des = dtype_size((SCATTER ? sm : dm).dtype);
+    char* dense_ptr  = static_cast<char*>(dense->storage_ptr) + (SCATTER ? sm : dm).storage_offset * (int64_t)des;
+    distributed_rows_op(SCATTER, table->handle, SCATTER ? dm : sm, idx, id.dtype, n, dense_ptr, SCATTER ? sm : dm, env,
+                        stream);
+    return;
+  }
   if (n == 0) return;
-
   const size_t ses = dtype_size(sm.dtype), des = dtype_size(dm.dtype);
   const char* src  = static_cast<const char*>(src_t->storage_ptr) + sm.storage_offset * (int64_t)ses;
   char* dst        = static_cast<char*>(dst_t->storage_ptr) + dm.storage_offset * (int64_t)des;
-  const void* idx  = tensor_data(idx_t);
   WG_REQUIRE_INPUT(src_t->storage_ptr && dst_t->storage_ptr && idx, "null data pointer");
-  const int F = (int)sm.sizes[1];
-
-  if (sm.dtype == dm.dtype) {
-    if (id.dtype == WHOLEMEMORY_DT_INT)
-      launch_copy<int32_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int32_t*>(idx), n, F * (int)ses, dst,
-                                    dm.stride * (int64_t)des, stream);
-    else
-      launch_copy<int64_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int64_t*>(idx), n, F * (int)ses, dst,
-                                    dm.stride * (int64_t)des, stream);
-  } else {
-    if (id.dtype == WHOLEMEMORY_DT_INT)
-      convert_in<int32_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int32_t*>(idx), n, F, dst,
-                                   dm.stride, stream);
-    else
-      convert_in<int64_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int64_t*>(idx), n, F, dst,
-                                   dm.stride, stream);
-  }
-  WG_HIP_CHECK(hipGetLastError());
+  rows_launch<SCATTER>(src, sm, idx, id.dtype, n, dst, dm, stream);
 }
 
 }  // namespace
+
+void local_rows_gather(const char* table, wholememory_matrix_description_t tm, const void* idx,
+                       wholememory_dtype_t idx_dtype, int64_t n, char* out, wholememory_matrix_description_t om,
+                       hipStream_t stream)
+{
+  rows_launch<false>(table, tm, idx, idx_dtype, n, out, om, stream);
+}
+
+void local_rows_scatter(const char* in, wholememory_matrix_description_t im, const void* idx,
+                        wholememory_dtype_t idx_dtype, int64_t n, char* table, wholememory_matrix_description_t tm,
+                        hipStream_t stream)
+{
+  rows_launch<true>(in, im, idx, idx_dtype, n, table, tm, stream);
+}
+
 }  // namespace wgamd
 
 extern "C" {
 
 wholememory_error_code_t wholememory_gather(wholememory_tensor_t wholememory_tensor, wholememory_tensor_t indices_tensor,
-                                            wholememory_tensor_t output_tensor, wholememory_env_func_t* /*p_env_fns*/,
+                                            wholememory_tensor_t output_tensor, wholememory_env_func_t* p_env_fns,
                                             void* stream, int /*gather_sms*/)
 {
   return wgamd::guarded("wholememory_gather", [&] {
-    wgamd::rows_op<false>("wholememory_gather", wholememory_tensor, indices_tensor, output_tensor,
+    wgamd::rows_op<false>("wholememory_gather", wholememory_tensor, indices_tensor, output_tensor, p_env_fns,
                           static_cast<hipStream_t>(stream));
   });
 }
 
 wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor, wholememory_tensor_t indices_tensor,
-                                             wholememory_tensor_t wholememory_tensor, wholememory_env_func_t* /*p_env_fns*/,
+                                             wholememory_tensor_t wholememory_tensor, wholememory_env_func_t* p_env_fns,
                                              void* stream, int /*scatter_sms*/)
 {
   return wgamd::guarded("wholememory_scatter", [&] {
-    wgamd::rows_op<true>("wholememory_scatter", input_tensor, indices_tensor, wholememory_tensor,
+    wgamd::rows_op<true>("wholememory_scatter", input_tensor, indices_tensor, wholememory_tensor, p_env_fns,
                          static_cast<hipStream_t>(stream));
   });
 }

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "wg_common.hpp"
+#include "wgamd_comm.h"
 
 namespace {
 
@@ -182,6 +183,7 @@ wholememory_error_code_t wholememory_make_tensor_from_pointer(wholememory_tensor
 wholememory_error_code_t wholememory_destroy_tensor(wholememory_tensor_t t)
 {
   if (t == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  if (t->owns_handle && t->handle != nullptr) wholememory_free(t->handle);
   delete t;
   g_live_tensors--;
   return WHOLEMEMORY_SUCCESS;

@@ -78,6 +78,15 @@ class EnvFns(Structure):
     _fields_ = [("temporary_fns", TempMemoryFns), ("output_fns", OutputMemoryFns)]
 
 
+class UniqueId(Structure):
+    """wholememory_unique_id_t (include/wgamd_comm.h): the 128-byte RCCL bootstrap id, passed BY VALUE."""
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+# wholememory_memory_type_t / wholememory_memory_location_t
+MT_NONE, MT_CONTINUOUS, MT_CHUNKED, MT_DISTRIBUTED, MT_HIERARCHY = range(5)
+ML_NONE, ML_DEVICE, ML_HOST = range(3)
+
 # every symbol include/*.h declares: name -> (restype, argtypes)
 _T = c_void_p  # wholememory_tensor_t
 SYMBOLS = {
@@ -125,8 +134,35 @@ SYMBOLS = {
     "csr_add_self_loop": (c_int, [_T, _T, _T, _T, c_void_p]),
     "wholememory_gather": (c_int, [_T, _T, _T, POINTER(EnvFns), c_void_p, c_int]),
     "wholememory_scatter": (c_int, [_T, _T, _T, POINTER(EnvFns), c_void_p, c_int]),
+    # wgamd_comm.h
+    "wholememory_init": (c_int, [ctypes.c_uint, c_int]),
+    "wholememory_finalize": (c_int, []),
+    "wholememory_create_unique_id": (c_int, [POINTER(UniqueId)]),
+    "wholememory_create_communicator": (c_int, [POINTER(c_void_p), UniqueId, c_int, c_int]),
+    "wholememory_destroy_communicator": (c_int, [c_void_p]),
+    "wholememory_communicator_support_type_location": (c_int, [c_void_p, c_int, c_int]),
+    "wholememory_communicator_get_rank": (c_int, [POINTER(c_int), c_void_p]),
+    "wholememory_communicator_get_size": (c_int, [POINTER(c_int), c_void_p]),
+    "wholememory_communicator_barrier": (c_int, [c_void_p]),
+    "wholememory_malloc": (c_int, [POINTER(c_void_p), c_size_t, c_void_p, c_int, c_int, c_size_t, POINTER(c_size_t)]),
+    "wholememory_free": (c_int, [c_void_p]),
+    "wholememory_get_communicator": (c_int, [POINTER(c_void_p), c_void_p]),
+    "wholememory_get_memory_type": (c_int, [c_void_p]),
+    "wholememory_get_memory_location": (c_int, [c_void_p]),
+    "wholememory_get_total_size": (c_size_t, [c_void_p]),
+    "wholememory_get_data_granularity": (c_size_t, [c_void_p]),
+    "wholememory_get_local_memory": (c_int, [POINTER(c_void_p), POINTER(c_size_t), POINTER(c_size_t), c_void_p]),
+    "wholememory_equal_entry_partition_plan": (c_int, [POINTER(c_size_t), c_size_t, c_int]),
+    "wholememory_get_rank_partition_sizes": (c_int, [POINTER(c_size_t), c_void_p]),
+    "wholememory_get_rank_partition_offsets": (c_int, [POINTER(c_size_t), c_void_p]),
+    "wholememory_create_tensor": (c_int, [POINTER(_T), POINTER(TensorDescription), c_void_p, c_int, c_int,
+                                          POINTER(c_size_t)]),
+    "wholememory_make_tensor_from_handle": (c_int, [POINTER(_T), c_void_p, POINTER(TensorDescription)]),
+    "wholememory_tensor_get_local_entry_count": (c_int, [POINTER(c_size_t), _T]),
+    "wholememory_tensor_get_local_entry_start": (c_int, [POINTER(c_size_t), _T]),
+    "wholememory_tensor_map_local_tensor": (c_int, [_T, POINTER(_T)]),
     # wgamd_ext.h
-    "wgamd_spmm_csr_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
+    "wgamd_spmm_csr_f32":(c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
                                    c_int, c_void_p, c_int64, c_void_p]),
     "wgamd_sage_aggregate_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
                                          c_void_p, c_int64, c_void_p]),

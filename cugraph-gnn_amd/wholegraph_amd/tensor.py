@@ -120,6 +120,137 @@ class WholeMemoryTensor(object):
             self.local_ops.scatter(input_tensor, indice, table2d)
 
 
+class _DevicePointerView:
+    """``__cuda_array_interface__`` carrier so torch can view memory owned by a wholememory handle."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner  # keeps the handle alive as long as any view of it lives
+
+
+_TYPESTR = {torch.float32: "<f4", torch.float64: "<f8", torch.float16: "<f2", torch.bfloat16: "<i2",
+            torch.int32: "<i4", torch.int64: "<i8", torch.int16: "<i2", torch.int8: "|i1"}
+
+
+class DistributedWholeMemoryTensor(object):
+    r"""A table whose storage is a C-level ``WHOLEMEMORY_MT_DISTRIBUTED`` handle (include/wgamd_comm.h):
+    rank r holds a contiguous row range in its own HBM; ``gather``/``scatter`` run the RCCL all-to-all
+    pipeline INSIDE the library (csrc/wg_comm.hip) and are collective over the communicator.  Same methods as
+    ``pylibwholegraph.torch.tensor.WholeMemoryTensor`` (tensor.py:24-123)."""
+
+    def __init__(self, c_tensor, comm, dtype, shape):
+        import ctypes
+        self.c = ctypes.c_void_p(c_tensor)
+        self.comm = comm
+        self._dtype = dtype
+        self._shape = tuple(int(v) for v in shape)
+        self._local_view = None
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def dim(self):
+        return len(self._shape)
+
+    @property
+    def shape(self):
+        return self._shape
+
+    def stride(self):
+        return (self._shape[1], 1) if self.dim() == 2 else (1,)
+
+    def storage_offset(self):
+        return 0
+
+    @property
+    def is_distributed(self):
+        return True
+
+    def get_comm(self):
+        return self.comm
+
+    def get_local_tensor(self, host_view: bool = False):
+        """(torch view of this rank's rows, first global row held here) — tensor.py:106-123."""
+        import ctypes
+        lib = L.lib()
+        n, start = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        L.check(lib.wholememory_tensor_get_local_entry_count(ctypes.byref(n), self.c), "tensor_get_local_entry_count")
+        L.check(lib.wholememory_tensor_get_local_entry_start(ctypes.byref(start), self.c),
+                "tensor_get_local_entry_start")
+        if self._local_view is None:
+            ptr, size, off = ctypes.c_void_p(), ctypes.c_size_t(0), ctypes.c_size_t(0)
+            handle = ctypes.c_void_p(lib.wholememory_tensor_get_memory_handle(self.c))
+            L.check(lib.wholememory_get_local_memory(ctypes.byref(ptr), ctypes.byref(size), ctypes.byref(off), handle),
+                    "wholememory_get_local_memory")
+            shape = (n.value,) + self._shape[1:]
+            if n.value == 0:
+                self._local_view = torch.empty(shape, dtype=self._dtype, device="cuda")
+            else:
+                view = torch.as_tensor(_DevicePointerView(ptr.value, shape, _TYPESTR[self._dtype], self),
+                                       device="cuda")
+                self._local_view = view.view(self._dtype) if view.dtype != self._dtype else view
+        t = self._local_view
+        return (t.cpu() if host_view else t), start.value
+
+    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None):
+        assert indice.dim() == 1
+        embedding_dim = self._shape[1] if self.dim() == 2 else 1
+        out = torch.empty([indice.shape[0], embedding_dim] if self.dim() == 2 else [indice.shape[0]],
+                          device=indice.device, dtype=force_dtype if force_dtype is not None else self._dtype)
+        w_i, w_o = wrap_torch_tensor(indice), wrap_torch_tensor(out)
+        L.check(L.lib().wholememory_gather(self.c, w_i.c, w_o.c, get_wholegraph_env_fns(), get_stream(), -1),
+                "wholememory_gather")
+        return out
+
+    def scatter(self, input_tensor: torch.Tensor, indice: torch.Tensor):
+        assert indice.dim() == 1 and input_tensor.dim() == self.dim()
+        assert indice.shape[0] == input_tensor.shape[0]
+        w_in, w_i = wrap_torch_tensor(input_tensor), wrap_torch_tensor(indice)
+        L.check(L.lib().wholememory_scatter(w_in.c, w_i.c, self.c, get_wholegraph_env_fns(), get_stream(), -1),
+                "wholememory_scatter")
+
+    def destroy(self):
+        if self.c is not None and self.c.value:
+            self._local_view = None
+            L.check(L.lib().wholememory_destroy_tensor(self.c), "wholememory_destroy_tensor")
+            self.c = None
+
+
+def _create_handle_tensor(comm, memory_type, memory_location, sizes, dtype, strides, tensor_entry_partition):
+    """Reference signature create_wholememory_tensor(comm, memory_type, memory_location, sizes, dtype,
+    strides, tensor_entry_partition) — tensor.py:200-247."""
+    import ctypes
+    from .comm import memory_location_code, memory_type_code
+    from .env import torch_dtype_to_wm
+    sizes = [int(v) for v in sizes]
+    assert len(sizes) in (1, 2), "sizes should be 1D or 2D"
+    if strides is None:
+        strides = [sizes[1], 1] if len(sizes) == 2 else [1]
+    desc = L.TensorDescription()
+    L.lib().wholememory_initialize_tensor_desc(ctypes.byref(desc))
+    desc.dim = len(sizes)
+    for i, (n, st) in enumerate(zip(sizes, strides)):
+        desc.sizes[i], desc.strides[i] = n, int(st)
+    desc.dtype = torch_dtype_to_wm(dtype)
+    part = None
+    if tensor_entry_partition is not None:
+        part = (ctypes.c_size_t * len(tensor_entry_partition))(*[int(v) for v in tensor_entry_partition])
+    c = ctypes.c_void_p()
+    L.check(L.lib().wholememory_create_tensor(ctypes.byref(c), ctypes.byref(desc), comm.c_comm,
+                                              memory_type_code(memory_type), memory_location_code(memory_location),
+                                              part),
+            "wholememory_create_tensor")
+    return DistributedWholeMemoryTensor(c.value, comm, dtype, sizes)
+
+
+def destroy_wholememory_tensor(wm_tensor):
+    """tensor.py:322-328."""
+    if isinstance(wm_tensor, DistributedWholeMemoryTensor):
+        wm_tensor.destroy()
+
+
 def equal_entry_partition(total_rows: int, world_size: int):
     """Row offsets of the equal range partition: per = ceil(V/W), rank r owns
     [min(r*per, V), min((r+1)*per, V))
@@ -129,10 +260,27 @@ def equal_entry_partition(total_rows: int, world_size: int):
     return [min(r * per, total_rows) for r in range(world_size + 1)]
 
 
-def create_wholememory_tensor(shape, dtype, *, device=None, group=None, partition_offsets=None,
-                              local_ops=HipLocalOps):
-    """Allocate a (possibly range-partitioned) table.  With a process group of size > 1 every rank
-    allocates only its own slice (tensor.py:200-247 with memory type 'distributed')."""
+def create_wholememory_tensor(*args, device=None, group=None, partition_offsets=None, local_ops=HipLocalOps,
+                              **kwargs):
+    """Allocate a (possibly range-partitioned) table.
+
+    Two call forms:
+      * the reference's ``(comm, memory_type, memory_location, sizes, dtype, strides,
+        tensor_entry_partition=None)`` with a ``comm.WholeMemoryCommunicator`` first (tensor.py:200-247): the
+        storage is a C-level DISTRIBUTED handle and gather/scatter exchange rows inside the library;
+      * ``(shape, dtype, *, device, group, partition_offsets)``: torch tensors per rank, exchange over
+        ``torch.distributed`` (``dist.py``; works with the gloo backend on CPU for tests).
+    With more than one rank every rank allocates only its own slice."""
+    from .comm import WholeMemoryCommunicator
+    first = args[0] if args else kwargs.get("comm")
+    if isinstance(first, WholeMemoryCommunicator):
+        names = ["comm", "memory_type", "memory_location", "sizes", "dtype", "strides", "tensor_entry_partition"]
+        bound = dict(zip(names, args))
+        bound.update(kwargs)
+        return _create_handle_tensor(bound["comm"], bound["memory_type"], bound["memory_location"], bound["sizes"],
+                                     bound["dtype"], bound.get("strides"), bound.get("tensor_entry_partition"))
+    shape = args[0] if args else kwargs["shape"]
+    dtype = args[1] if len(args) > 1 else kwargs["dtype"]
     shape = tuple(shape)
     device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
     ws = _dist.world_size(group)

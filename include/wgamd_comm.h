@@ -1,0 +1,102 @@
+/*
+ * wgamd_comm.h — communicator + DISTRIBUTED memory handles: the part of libwholegraph's runtime that
+ * the multi-GPU feature fetch stands on (/root/reference/cpp/include/wholememory/wholememory.h:84-420,
+ * wholememory_tensor.h:27-76; implementation cpp/src/wholememory/communicator.cpp, nccl_comms.cpp,
+ * memory_handle.cpp:1393-1745).
+ *
+ * One process per GPU.  The communicator wraps an RCCL communicator (bootstrap: 128-byte unique id moved
+ * by the caller, e.g. torch.distributed.broadcast — comm.py:159-166 of the reference).  The only memory
+ * type implemented is WHOLEMEMORY_MT_DISTRIBUTED on WHOLEMEMORY_ML_DEVICE: every rank holds a contiguous
+ * range of the entries in its own HBM and remote rows are fetched by all-to-all over xGMI
+ * (wholememory_gather / wholememory_scatter accept tensors backed by such a handle).  The CUDA-VMM / IPC /
+ * NVSHMEM / host-pinned mappings of the reference (CONTINUOUS, CHUNKED, HIERARCHY) are not reproduced and
+ * return WHOLEMEMORY_NOT_SUPPORTED (a world_size-1 communicator accepts CONTINUOUS/CHUNKED as aliases of the
+ * single local partition).  RCCL is resolved at run time (dlopen "librccl.so"), so the library loads on a
+ * CPU-only box and inside a PyTorch process shares torch's RCCL.
+ */
+#ifndef WGAMD_COMM_H_
+#define WGAMD_COMM_H_
+
+#include "wgamd_tensor.h"
+#include "wgamd_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* wholememory.h:91-98 — process-wide init / teardown (log_level: 0 fatal … 5 trace; only stored) */
+wholememory_error_code_t wholememory_init(unsigned int flags, int log_level);
+wholememory_error_code_t wholememory_finalize(void);
+
+#define WHOLEMEMORY_UNIQUE_ID_BYTES (128)
+typedef struct wholememory_unique_id_t {
+  char internal[WHOLEMEMORY_UNIQUE_ID_BYTES];
+} wholememory_unique_id_t;
+
+/* wholememory.h:118-134 */
+wholememory_error_code_t wholememory_create_unique_id(wholememory_unique_id_t* unique_id);
+wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* comm,
+                                                         wholememory_unique_id_t unique_id,
+                                                         int rank,
+                                                         int size);
+wholememory_error_code_t wholememory_destroy_communicator(wholememory_comm_t comm);
+/* wholememory.h:160-205 */
+wholememory_error_code_t wholememory_communicator_support_type_location(
+  wholememory_comm_t comm, wholememory_memory_type_t memory_type, wholememory_memory_location_t memory_location);
+wholememory_error_code_t wholememory_communicator_get_rank(int* rank, wholememory_comm_t comm);
+wholememory_error_code_t wholememory_communicator_get_size(int* size, wholememory_comm_t comm);
+wholememory_error_code_t wholememory_communicator_barrier(wholememory_comm_t comm);
+
+/* wholememory.h:225-236 — total_size bytes split into entries of data_granularity bytes; rank_entry_partition
+ * (entries per rank, nullable) overrides the equal split of wholememory_equal_entry_partition_plan. */
+wholememory_error_code_t wholememory_malloc(wholememory_handle_t* wholememory_handle_ptr,
+                                            size_t total_size,
+                                            wholememory_comm_t comm,
+                                            wholememory_memory_type_t memory_type,
+                                            wholememory_memory_location_t memory_location,
+                                            size_t data_granularity,
+                                            size_t* rank_entry_partition WGAMD_DEFAULT(NULL));
+wholememory_error_code_t wholememory_free(wholememory_handle_t wholememory_handle);
+/* wholememory.h:245-330 */
+wholememory_error_code_t wholememory_get_communicator(wholememory_comm_t* comm,
+                                                      wholememory_handle_t wholememory_handle);
+wholememory_memory_type_t wholememory_get_memory_type(wholememory_handle_t wholememory_handle);
+wholememory_memory_location_t wholememory_get_memory_location(wholememory_handle_t wholememory_handle);
+size_t wholememory_get_total_size(wholememory_handle_t wholememory_handle);
+size_t wholememory_get_data_granularity(wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_local_memory(void** local_ptr,
+                                                      size_t* local_size,
+                                                      size_t* local_offset,
+                                                      wholememory_handle_t wholememory_handle);
+/* wholememory.h:380-420 — equal split: per = ceil(total / world); rank r owns [min(r*per,total), min((r+1)*per,total)) */
+wholememory_error_code_t wholememory_equal_entry_partition_plan(size_t* entry_per_rank,
+                                                                size_t total_entry_count,
+                                                                int world_size);
+wholememory_error_code_t wholememory_get_rank_partition_sizes(size_t* rank_mem_sizes,
+                                                              wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_rank_partition_offsets(size_t* rank_mem_offsets,
+                                                                wholememory_handle_t wholememory_handle);
+
+/* wholememory_tensor.h:27-76 — a tensor whose storage is a handle (dim 1 or 2, partitioned along dim 0) */
+wholememory_error_code_t wholememory_create_tensor(wholememory_tensor_t* wholememory_tensor,
+                                                   wholememory_tensor_description_t* tensor_description,
+                                                   wholememory_comm_t comm,
+                                                   wholememory_memory_type_t memory_type,
+                                                   wholememory_memory_location_t memory_location,
+                                                   size_t* tensor_entry_partition WGAMD_DEFAULT(NULL));
+wholememory_error_code_t wholememory_make_tensor_from_handle(
+  wholememory_tensor_t* wholememory_tensor,
+  wholememory_handle_t wholememory_handle,
+  wholememory_tensor_description_t* tensor_description);
+/* wholememory_tensor.h:132-160 */
+wholememory_error_code_t wholememory_tensor_get_local_entry_count(size_t* local_entry_count,
+                                                                  wholememory_tensor_t wholememory_tensor);
+wholememory_error_code_t wholememory_tensor_get_local_entry_start(size_t* local_entry_start,
+                                                                  wholememory_tensor_t wholememory_tensor);
+wholememory_error_code_t wholememory_tensor_map_local_tensor(wholememory_tensor_t wholememory_tensor,
+                                                             wholememory_tensor_t* local_tensor);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGAMD_COMM_H_ */

@@ -129,3 +129,18 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M) or "wg_oracle" in text:
                     offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_equal_entry_partition_plan_matches_python_mirror():
+    """wholememory_equal_entry_partition_plan (host-only entry point) == wholegraph_amd.equal_entry_partition."""
+    import ctypes
+    import wholegraph_amd as wg
+    lib = wg._lib.lib()
+    for total, world in [(0, 1), (1, 8), (7, 8), (8, 8), (9, 8), (2449029, 8), (111059956, 3)]:
+        per = ctypes.c_size_t(0)
+        assert lib.wholememory_equal_entry_partition_plan(ctypes.byref(per), total, world) == 0
+        offs = wg.equal_entry_partition(total, world)
+        assert offs[1] - offs[0] == min(per.value, total)
+        assert offs[-1] == total and all(b - a <= per.value for a, b in zip(offs, offs[1:]))
+    assert lib.wholememory_equal_entry_partition_plan(None, 10, 2) != 0
+    assert lib.wholememory_equal_entry_partition_plan(ctypes.byref(per), 10, 0) != 0

@@ -1,0 +1,116 @@
+"""C-level communicator + DISTRIBUTED handle (include/wgamd_comm.h, csrc/wg_comm.hip) on one GPU.
+
+A world_size-1 RCCL communicator exercises the full pipeline (owner histogram, bucket, the grouped
+send/recv self-exchange, local gather, un-permute); results are compared with the oracle's row gather /
+scatter (wholememory_ops/functions/gather_scatter_func.cuh semantics: a negative index leaves its row
+untouched).  World sizes > 1 of the same algorithm are covered on CPU by tests/test_dist_gloo.py and run by
+the driver's multi-GPU bench.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm():
+    import wholegraph_amd as wg
+    c = wg.create_group_communicator()
+    yield c
+    c.destroy()
+
+
+def test_communicator_queries(comm):
+    assert comm.get_rank() == 0 and comm.get_size() == 1
+    assert comm.support_type_location("distributed", "cuda")
+    assert not comm.support_type_location("distributed", "cpu")
+    assert not comm.support_type_location("hierarchy", "cuda")
+    comm.barrier()
+
+
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.float32, None), (torch.float16, torch.float32),
+                                             (torch.bfloat16, None), (torch.int64, None), (torch.int8, torch.int32)])
+@pytest.mark.parametrize("idx_dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("rows,dim,n", [(1000, 100, 4096), (37, 1, 100), (5000, 33, 0), (5000, 128, 1)])
+def test_handle_scatter_then_gather_matches_oracle(comm, dtype, out_dtype, idx_dtype, rows, dim, n):
+    import wholegraph_amd as wg
+    from oracle import oracle
+    rng = np.random.default_rng(rows * 7 + dim + n)
+    t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows, dim], dtype, [dim, 1])
+    try:
+        local, start = t.get_local_tensor()
+        assert start == 0 and tuple(local.shape) == (rows, dim) and local.dtype == dtype
+        if dtype.is_floating_point:
+            host = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)).to(dtype)
+        else:
+            host = torch.from_numpy(rng.integers(-100, 100, (rows, dim))).to(dtype)
+        # fill through the collective scatter (a permutation of all rows), read back through the local view
+        perm = torch.from_numpy(rng.permutation(rows)).to(idx_dtype).cuda()
+        t.scatter(host.cuda()[perm.long()], perm)
+        torch.cuda.synchronize()
+        assert torch.equal(local.cpu(), host)
+        idx = rng.integers(0, rows, n)
+        if n > 3:
+            idx[1] = -1  # negative index: output row stays as it was
+        got = torch.full((n, dim), 7, dtype=out_dtype or dtype, device="cuda")
+        w_i = wg.env.wrap_torch_tensor(torch.from_numpy(idx).to(idx_dtype).cuda())
+        w_o = wg.env.wrap_torch_tensor(got)
+        wg._lib.check(wg._lib.lib().wholememory_gather(t.c, w_i.c, w_o.c, wg.env.get_wholegraph_env_fns(),
+                                                        wg.env.get_stream(), -1), "wholememory_gather")
+        torch.cuda.synchronize()
+        want = host.to(out_dtype or dtype)[torch.from_numpy(np.where(idx < 0, 0, idx))]
+        if n > 3:
+            want[1] = 7
+        assert torch.equal(got.cpu(), want)
+        if dtype == torch.float32 and n:
+            ref = oracle.gather_rows(host.numpy(), np.where(idx < 0, 0, idx).astype(np.int64))
+            keep = idx >= 0
+            assert np.array_equal(got.cpu().numpy()[keep], ref[keep])
+        # the method form
+        if n:
+            out = t.gather(torch.from_numpy(np.abs(idx)).to(idx_dtype).cuda(), force_dtype=out_dtype)
+            assert torch.equal(out.cpu(), host.to(out_dtype or dtype)[torch.from_numpy(np.abs(idx))])
+    finally:
+        wg.destroy_wholememory_tensor(t)
+
+
+def test_handle_1d_and_partition_queries(comm):
+    import wholegraph_amd as wg
+    L = wg._lib
+    t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [4097], torch.int64, [1])
+    try:
+        h = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(t.c))
+        assert L.lib().wholememory_tensor_has_handle(t.c)
+        assert L.lib().wholememory_get_total_size(h) == 4097 * 8
+        assert L.lib().wholememory_get_data_granularity(h) == 8
+        assert L.lib().wholememory_get_memory_type(h) == L.MT_DISTRIBUTED
+        assert L.lib().wholememory_get_memory_location(h) == L.ML_DEVICE
+        sizes, offs = (ctypes.c_size_t * 1)(), (ctypes.c_size_t * 2)()
+        L.check(L.lib().wholememory_get_rank_partition_sizes(sizes, h), "sizes")
+        L.check(L.lib().wholememory_get_rank_partition_offsets(offs, h), "offsets")
+        assert sizes[0] == 4097 * 8 and list(offs) == [0, 4097 * 8]
+        vals = torch.arange(4097, dtype=torch.int64, device="cuda") * 3
+        t.scatter(vals, torch.arange(4097, device="cuda"))
+        idx = torch.tensor([0, 4096, 17, 17, 2048], device="cuda")
+        assert torch.equal(t.gather(idx), idx * 3)
+        # local tensor mapped as a plain-pointer wholememory tensor
+        lt = ctypes.c_void_p()
+        L.check(L.lib().wholememory_tensor_map_local_tensor(t.c, ctypes.byref(lt)), "map_local_tensor")
+        assert not L.lib().wholememory_tensor_has_handle(lt)
+        assert L.lib().wholememory_tensor_get_data_pointer(lt) == t.get_local_tensor()[0].data_ptr()
+        L.lib().wholememory_destroy_tensor(lt)
+    finally:
+        wg.destroy_wholememory_tensor(t)
+
+
+def test_unsupported_memory_types_are_refused(comm):
+    import wholegraph_amd as wg
+    with pytest.raises(wg.WholeMemoryError):
+        wg.create_wholememory_tensor(comm, "hierarchy", "cuda", [16, 4], torch.float32, [4, 1])
+    with pytest.raises(wg.WholeMemoryError):
+        wg.create_wholememory_tensor(comm, "distributed", "cpu", [16, 4], torch.float32, [4, 1])
+    with pytest.raises(wg.WholeMemoryError):  # partition that does not add up
+        wg.create_wholememory_tensor(comm, "distributed", "cuda", [16, 4], torch.float32, [4, 1], [15])

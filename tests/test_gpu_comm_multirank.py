@@ -1,0 +1,109 @@
+"""World sizes 2..5 of the C-level DISTRIBUTED gather / scatter (csrc/wg_comm.hip) on ONE GPU.
+
+RCCL cannot put two ranks on one device, so the test process loads tests/shim/libfake_rccl.so (an in-process
+stand-in for the nine RCCL calls, selected through WGAMD_RCCL_LIBRARY) and runs every rank as a thread.
+Everything else — owner histogram, bucketing, id localisation, local row kernels, un-permute, uneven and empty
+partitions, negative indices, dtype conversion — is the product code.  Runs in a subprocess because the RCCL
+choice is made once per process.
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "tests", "shim")
+SHIM = os.path.join(SHIM_DIR, "build", "libfake_rccl.so")
+
+WORKER = textwrap.dedent(r"""
+    import ctypes, sys, threading
+    import numpy as np, torch
+    sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/cugraph-gnn_amd")
+    import wholegraph_amd as wg
+    from wholegraph_amd import _lib as L
+    from wholegraph_amd.comm import WholeMemoryCommunicator
+    W, rows, dim, n = (int(v) for v in sys.argv[2:6])
+    part = [int(v) for v in sys.argv[6].split(",")] if len(sys.argv) > 6 and sys.argv[6] else None
+    tdt, odt = torch.float16, torch.float32
+    lib = L.lib()
+    uid = L.UniqueId()
+    L.check(lib.wholememory_create_unique_id(ctypes.byref(uid)), "uid")
+    rng = np.random.default_rng(W * 1000 + rows)
+    table = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)).to(tdt)
+    errors, results = [], [None] * W
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            c = ctypes.c_void_p()
+            L.check(lib.wholememory_create_communicator(ctypes.byref(c), uid, r, W), "create_communicator")
+            comm = WholeMemoryCommunicator(c.value)
+            assert comm.get_rank() == r and comm.get_size() == W
+            t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows, dim], tdt, [dim, 1], part)
+            local, start = t.get_local_tensor()
+            offs = np.concatenate([[0], np.cumsum(part)]) if part else np.minimum(
+                np.arange(W + 1) * -(-rows // W), rows)
+            assert start == offs[r] and local.shape[0] == offs[r + 1] - offs[r], (start, local.shape, offs)
+            local.zero_()
+            comm.barrier()
+            # rank r writes the rows with id % W == r (wherever they live), in a shuffled order, int32 ids
+            mine = np.arange(r, rows, W)
+            np.random.default_rng(r).shuffle(mine)
+            t.scatter(table[torch.from_numpy(mine)].cuda(), torch.from_numpy(mine).int().cuda())
+            comm.barrier()
+            assert torch.equal(local.cpu(), table[offs[r]:offs[r + 1]]), "scatter landed wrong"
+            # gather with duplicates, negatives, fp16 -> fp32 conversion, a different count on every rank
+            k = n + 37 * r if n else (0 if r % 2 == 0 else 5)
+            idx = np.random.default_rng(100 + r).integers(0, rows, k)
+            if k > 4:
+                idx[::5] = -1
+            out = torch.full((k, dim), 3.0, dtype=odt, device="cuda")
+            w_i, w_o = wg.env.wrap_torch_tensor(torch.from_numpy(idx).cuda()), wg.env.wrap_torch_tensor(out)
+            L.check(lib.wholememory_gather(t.c, w_i.c, w_o.c, wg.env.get_wholegraph_env_fns(), wg.env.get_stream(), -1),
+                    "wholememory_gather")
+            want = table.to(odt)[torch.from_numpy(np.where(idx < 0, 0, idx))]
+            want[torch.from_numpy(idx < 0)] = 3.0
+            assert torch.equal(out.cpu(), want), f"rank {r}: gather mismatch"
+            comm.barrier()
+            wg.destroy_wholememory_tensor(t)
+            comm.destroy()
+            results[r] = "ok"
+        except BaseException as e:  # noqa
+            import traceback; traceback.print_exc()
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(W)]
+    for th in threads: th.start()
+    for th in threads: th.join(120)
+    alive = [i for i, th in enumerate(threads) if th.is_alive()]
+    if alive or errors or any(v != "ok" for v in results):
+        print("FAILED", alive, errors, results); sys.stdout.flush()
+        import os; os._exit(1)
+    print("ALL_RANKS_OK")
+""")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if not os.path.exists(SHIM):
+        subprocess.run(["make", "-C", SHIM_DIR, "-s"], check=True)
+    return SHIM
+
+
+@pytest.mark.parametrize("W,rows,dim,n,part", [
+    (2, 1000, 64, 3000, ""),
+    (3, 1001, 7, 500, ""),
+    (4, 50000, 128, 20000, ""),
+    (4, 10, 4, 64, "0,7,0,3"),        # empty partitions
+    (5, 777, 33, 0, "100,200,77,300,100"),  # some ranks gather nothing
+    (8, 4096, 100, 4096, ""),
+])
+def test_world_gt1_threads_over_fake_rccl(shim, W, rows, dim, n, part):
+    env = dict(os.environ, WGAMD_RCCL_LIBRARY=shim)
+    p = subprocess.run([sys.executable, "-c", WORKER, ROOT, str(W), str(rows), str(dim), str(n), part],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ALL_RANKS_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
