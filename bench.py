@@ -32,11 +32,17 @@ import torch.distributed as dist  # noqa: E402
 V_PRODUCTS = 2_449_029
 E_UNDIRECTED = 61_859_140
 FEAT_DIM = 100
-# name -> (V, undirected RMAT edges, feature dim, classes)   [SURVEY.md §8 dataset sizes]
-WORKLOADS = {"products": (V_PRODUCTS, E_UNDIRECTED, 100, 47),
-             "papers100m": (111_059_956, 807_842_936, 128, 172)}
+# name -> (V, undirected RMAT edges, feature dim, classes, fan-out)   [SURVEY.md §8 dataset sizes / BASELINE configs]
+WORKLOADS = {"products": (V_PRODUCTS, E_UNDIRECTED, 100, 47, [25, 10]),
+             "papers100m": (111_059_956, 807_842_936, 128, 172, [25, 10]),
+             "rmat26": (1 << 26, 1 << 29, 256, 64, [15, 10, 5])}
 HIDDEN = 256
-SPMM1, SPMM2 = "spmm1(mean)+self", "spmm2(mean)+self"   # stage labels (layer-1 F = feature dim, layer-2 F = HIDDEN)
+SPMM1, SPMM2 = "spmm1(mean)+self", "spmm2(mean)+self"   # stage labels (layer-1 F = feature dim, layer-j F = HIDDEN)
+
+
+def spmm_label(j):
+    return "spmm%d(mean)+self" % (j + 1)
+
 CLASSES = 47
 BATCH = 1024
 FANOUT = [25, 10]
@@ -90,15 +96,17 @@ class SagePipeline:
         self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, torch.int64, G)
         self.feat = feat_table  # WholeMemoryTensor
         g = torch.Generator(device=device).manual_seed(1)
-        self.conv1 = nn.SAGEConv(FEAT_DIM, HIDDEN).to(device)
-        self.conv2 = nn.SAGEConv(HIDDEN, CLASSES).to(device)
-        for p in list(self.conv1.parameters()) + list(self.conv2.parameters()):
-            p.data = (torch.rand(p.shape, generator=g, device=device) - 0.5) * 0.1
-            p.requires_grad_(False)
+        L = len(FANOUT)
+        dims = [FEAT_DIM] + [HIDDEN] * (L - 1) + [CLASSES]
+        self.dims = dims
+        self.convs = [nn.SAGEConv(dims[j], dims[j + 1]).to(device) for j in range(L)]
+        for c in self.convs:
+            for p in c.parameters():
+                p.data = (torch.rand(p.shape, generator=g, device=device) - 0.5) * 0.1
+                p.requires_grad_(False)
         # [W_l | W_r]^T so that lin_l(agg) + lin_r(x_self) is one GEMM over the [agg | x_self] rows
-        self.w1_t = torch.cat([self.conv1.lin_l.weight, self.conv1.lin_r.weight], dim=1).t().contiguous()
-        self.w2_t = torch.cat([self.conv2.lin_l.weight, self.conv2.lin_r.weight], dim=1).t().contiguous()
-        self.b1, self.b2 = self.conv1.lin_l.bias, self.conv2.lin_l.bias
+        self.w_t = [torch.cat([c.lin_l.weight, c.lin_r.weight], dim=1).t().contiguous() for c in self.convs]
+        self.bias = [c.lin_l.bias for c in self.convs]
         self.fused_relu = hasattr(torch, "_addmm_activation")
         self.walk_stream = torch.cuda.Stream(device=device) if overlap_walk else None
         self.distributed = self.feat.is_distributed
@@ -138,10 +146,12 @@ class SagePipeline:
         return res, sizes_h, ev
 
     def forward(self, res, sizes_h, ev, timers=None, fused_fetch=False):
-        """Feature fetch + 2-layer SAGE forward of one call group with exact (host-known) sizes."""
+        """Feature fetch + L-layer SAGE forward of one call group with exact (host-known) sizes."""
         nn = self.nn
         ev.synchronize()
-        (e1, u1), (e2, u2) = sizes_h.tolist()   # hop-1 (seeds) edges/unique, hop-2 edges/unique
+        sz = sizes_h.tolist()                   # per hop (seed hop first): [edges, unique nodes after the hop]
+        L = len(sz)
+        n_edges, n_uniq = [v[0] for v in sz], [v[1] for v in sz]
         if self.walk_stream is not None:
             # the walk's outputs were allocated on the walk stream and are consumed here on the main one
             main = torch.cuda.current_stream()
@@ -165,7 +175,8 @@ class SagePipeline:
             timers.append((name, s, e))
             return out
 
-        n_id = res.unique[1][:u2]
+        u_last = n_uniq[L - 1]
+        n_id = res.unique[L - 1][:u_last]
         if fused_fetch:
             x = None          # never materialised: layer 1 reads the feature table through n_id
         elif self.distributed:
@@ -173,22 +184,26 @@ class SagePipeline:
         else:
             from wholegraph_amd.tensor import local_gather
             x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id,
-                                                     torch.empty((u2, FEAT_DIM), dtype=torch.float32, device=self.device)))
-        # layer 1: one kernel builds [mean_j x_j | x_i], one GEMM applies [W_l | W_r] with bias, then ReLU
-        rows1 = res.target_rows_in_unique(1, u1)   # "x[:num_dst]" of the block-diagonal layout
-        if fused_fetch:
-            cat1 = stage("fetch+" + SPMM1, lambda: nn.sage_aggregate_fetch_forward(
-                res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], self.feat.local_tensor, n_id, rows1, True))
-        else:
-            cat1 = stage(SPMM1, lambda: nn.sage_aggregate_forward(res.offsets[1][:u1 + 1], res.neighbor_row[1][:e2], x,
-                                                                  rows1, True))
-        h1 = stage("dense1", lambda: self.dense(cat1, self.w1_t, self.b1, relu=True))
-        # layer 2: destinations are the seeds = the first BATCH rows of every batch's hop-1 unique list
-        seed_rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
-        cat2 = stage(SPMM2,
-                     lambda: nn.sage_aggregate_forward(res.offsets[0][:t0 + 1], res.neighbor_row[0][:e1], h1, seed_rows, True))
-        out = stage("dense2", lambda: self.dense(cat2, self.w2_t, self.b2, relu=False))
-        return out, (e1, u1, e2, u2)
+                                                     torch.empty((u_last, FEAT_DIM), dtype=torch.float32, device=self.device)))
+        # layer j consumes hop k = L-1-j (deepest first): one kernel builds [mean_j x_j | x_i] for the hop's targets,
+        # one GEMM applies [W_l | W_r] with bias (+ ReLU between layers)
+        h = x
+        for j in range(L):
+            k = L - 1 - j
+            if k >= 1:
+                n_dst = n_uniq[k - 1]
+                rows = res.target_rows_in_unique(k, n_dst)   # "x[:num_dst]" of the block-diagonal layout
+            else:
+                n_dst = t0   # the seeds = the first BATCH rows of every batch's hop-0 unique list
+                rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
+            ptr, nbr = res.offsets[k][:n_dst + 1], res.neighbor_row[k][:n_edges[k]]
+            if j == 0 and fused_fetch:
+                cat = stage("fetch+" + spmm_label(0), lambda: nn.sage_aggregate_fetch_forward(
+                    ptr, nbr, self.feat.local_tensor, n_id, rows, True))
+            else:
+                cat = stage(spmm_label(j), lambda: nn.sage_aggregate_forward(ptr, nbr, h, rows, True))
+            h = stage("dense%d" % (j + 1), lambda: self.dense(cat, self.w_t[j], self.bias[j], relu=j < L - 1))
+        return h, tuple(v for pair in sz for v in pair)
 
 
 def usable_cpus():
@@ -205,6 +220,7 @@ def usable_cpus():
 
 
 def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
+    L = len(FANOUT)
     """The C oracle (OpenMP over seeds) + torch-CPU dense layers on the same workload, bounded."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # must be set before libgomp is loaded by the oracle
     import oracle
@@ -212,17 +228,16 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
     threads = usable_cpus()
     oracle.set_num_threads(threads)
     torch.set_num_threads(max(1, threads))
-    (w1l, b1l, w1r), (w2l, b2l, w2r) = weights
     t0 = time.perf_counter()
     edges, batches = 0, 0
     for b in range(len(seeds_h)):
-        tg, ei, rp, ci = oracle.multilayer_sample(row_ptr_h, col_h, seeds_h[b], FANOUT, [62 + 2 * b, 63 + 2 * b])
-        x = oracle.gather_rows(feat_h, tg[0])
-        a1 = oracle.spmm_csr(rp[0], ci[0], x, mean=True)
-        h1 = torch.relu(torch.from_numpy(a1) @ w1l.T + b1l + torch.from_numpy(x[: len(tg[1])]) @ w1r.T)
-        a2 = oracle.spmm_csr(rp[1], ci[1], h1.numpy(), mean=True)
-        _ = torch.from_numpy(a2) @ w2l.T + b2l + h1[:BATCH] @ w2r.T
-        edges += int(ci[0].size + ci[1].size)
+        tg, ei, rp, ci = oracle.multilayer_sample(row_ptr_h, col_h, seeds_h[b], FANOUT, [62 + L * b + k for k in range(L)])
+        h = oracle.gather_rows(feat_h, tg[0])
+        for j, (wl, bl, wr) in enumerate(weights):
+            agg = oracle.spmm_csr(rp[j], ci[j], h, mean=True)
+            out = torch.from_numpy(agg) @ wl.T + bl + torch.from_numpy(h[: len(tg[j + 1])]) @ wr.T
+            h = (torch.relu(out) if j < L - 1 else out).numpy()
+        edges += int(sum(c.size for c in ci))
         batches += 1
         if time.perf_counter() - t0 > budget_s and batches >= 3:
             break
@@ -268,8 +283,9 @@ def main():
     from wholegraph_amd import WholeMemoryTensor, equal_entry_partition
 
     # ---- synthetic workload (replicated CSR, range-partitioned features) --------------------
-    global FEAT_DIM, CLASSES
-    wv, we, FEAT_DIM, CLASSES = WORKLOADS[args.workload]
+    global FEAT_DIM, CLASSES, FANOUT
+    wv, we, FEAT_DIM, CLASSES, FANOUT = WORKLOADS[args.workload]
+    L = len(FANOUT)
     args.nodes = args.nodes or wv
     args.edges = args.edges or we
     row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
@@ -321,7 +337,7 @@ def main():
     run_groups(warm_groups, total_groups, sizes=sizes)
     barrier()
     dt = time.perf_counter() - t0
-    edges_local = sum(s[0] + s[2] for s in sizes)
+    edges_local = sum(sum(s[0::2]) for s in sizes)
 
     stats = torch.tensor([dt, float(edges_local)], dtype=torch.float64, device=device)
     if world > 1:
@@ -344,7 +360,7 @@ def main():
         run_groups(warm_groups, total_groups, sizes=fsizes, fused_fetch=True)
         barrier()
         tf = time.perf_counter() - tf0
-        fstats = torch.tensor([tf, float(sum(s[0] + s[2] for s in fsizes))], dtype=torch.float64, device=device)
+        fstats = torch.tensor([tf, float(sum(sum(s[0::2]) for s in fsizes))], dtype=torch.float64, device=device)
         if world > 1:
             a, b2 = fstats[:1].clone(), fstats[1:].clone()
             dist.all_reduce(a, op=dist.ReduceOp.MAX)
@@ -368,27 +384,27 @@ def main():
         w1.record(ws)
         _, sz = pipe.forward(*pend, timers=timers)
         torch.cuda.synchronize()
-        timers.append(("walk(sample+renumber x2)", w0, w1))
+        timers.append(("walk(sample+renumber x%d)" % L, w0, w1))
         for name, a, b in timers:
             stage_ms[name] = stage_ms.get(name, 0.0) + a.elapsed_time(b)
         psizes.append(sz)
         stage_n += 1
     stage_ms = {k: v / stage_n for k, v in stage_ms.items()}         # per call group
-    e1 = sum(s[0] for s in psizes) / stage_n                         # per call group
-    n_dst1 = sum(s[1] for s in psizes) / stage_n
-    e2 = sum(s[2] for s in psizes) / stage_n
-    n_src = sum(s[3] for s in psizes) / stage_n
+    hop_e = [sum(s[2 * k] for s in psizes) / stage_n for k in range(L)]       # edges per call group, seed hop first
+    hop_u = [sum(s[2 * k + 1] for s in psizes) / stage_n for k in range(L)]   # unique nodes after each hop
+    n_src = hop_u[L - 1]
 
     if rank == 0:
         # algorithmic bytes per launch; b = 8-byte ids, fp32 features
         F = FEAT_DIM
-        kernels = {
-            "gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F)),
+        kernels = {"gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F))}
+        for j in range(L):
+            k = L - 1 - j
+            fj = pipe.dims[j]
+            n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
             # + the root term copied next to the aggregate: one more row read and written per destination
-            SPMM1: ("spmm_csr_kernel", e2 * (4 * F + 4) + n_dst1 * (4 * F + 8) + n_dst1 * (8 * F + 8)),
-            SPMM2: ("spmm_csr_kernel", e1 * (4 * HIDDEN + 4) + G * BATCH * (4 * HIDDEN + 8)
-                                       + G * BATCH * (8 * HIDDEN + 8)),
-        }
+            kernels[spmm_label(j)] = ("spmm_csr_kernel",
+                                      hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 8) + n_dst * (8 * fj + 8))
         dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
         roofline = None
         if dom is not None:
@@ -414,10 +430,12 @@ def main():
                 feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
             else:
                 feat_h = feat.local_tensor.cpu().numpy()
-            weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in (pipe.conv1, pipe.conv2)]
+            weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in pipe.convs]
             cpu = cpu_baseline(row_ptr.cpu().numpy(), col.cpu().numpy(), feat_h, cb, weights, args.cpu_budget)
+        wl_name = "RMAT-26" if args.workload == "rmat26" else "ogbn-" + args.workload
         out = {
-            "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), ogbn-%s-like fan-out [25,10]" % args.workload,
+            "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), %s-like fan-out %s"
+                      % (wl_name, FANOUT),
             "value": edges_total / dt,
             "unit": "sampled-edges/s",
             "n_gpus": world,
@@ -429,16 +447,16 @@ def main():
             "vs_baseline": None,
             "dtype": "int64 ids + f32 features",
             "data": "synthetic",
-            "config": {"workload": "ogbn-" + args.workload + "-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
-                                   "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, 2-layer SAGEConv(mean) %d-%d-%d fwd, "
+            "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
+                                   "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, %d-layer SAGEConv(mean) %s fwd, "
                                    "%d mini-batches per launch sequence (call group)"
                                    % (V, E, FEAT_DIM, " range-partitioned + RCCL all-to-all" if partitioned else
                                       ("" if world == 1 else " replicated per GPU"),
-                                      BATCH, FANOUT, FEAT_DIM, HIDDEN, CLASSES, G),
+                                      BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), G),
                        "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
                        else "dp%d (seeds sharded, no data-path collective)" % world},
             "call_group": G,
-            "edges_per_batch": {"hop1": e1 / G, "hop2": e2 / G, "unique_nodes": n_src / G},
+            "edges_per_batch": dict([("hop%d" % (k + 1), hop_e[k] / G) for k in range(L)] + [("unique_nodes", n_src / G)]),
             "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
             "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
             "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),

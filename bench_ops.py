@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Per-operator throughput of the C-ABI entry points on one MI355X (companion of bench.py).
+
+Each line of the result is one §8(a) row timed on its own through the same Python wrappers the parity tests use:
+algorithmic bytes per SURVEY.md §8(d) ÷ wall time of the call (the ABI ops synchronise internally, so a call is
+complete on return; HIP events bracket the enqueue-only ops).  ``frac`` is against the 8 TB/s HBM3E spec.  The sizes
+are one call group of the products workload (64 mini-batches of 1024 seeds, fan-out [25, 10]) plus the reference's
+``gather_scatter_bench`` shape (cpp/bench/wholememory_ops/gather_scatter_bench.cu:331-360: 1 M gathered rows).
+
+    python bench_ops.py [--json profiles/rNN/ops_n1.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "cugraph-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from bench import HBM_PEAK_GBPS, V_PRODUCTS, E_UNDIRECTED, rmat_csr  # noqa: E402
+
+
+def timed(fn, iters=20, warm=3, events=False):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    if events:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e-3 / iters
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
+    ap.add_argument("--edges", type=int, default=E_UNDIRECTED)
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "bench_ops.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", 0)
+    import wholegraph_amd as wg
+    from wholegraph_amd import graph_ops, nn, wholegraph_ops
+    from wholegraph_amd.tensor import local_gather, local_scatter
+
+    row_ptr, col = rmat_csr(args.nodes, args.edges, 0, dev)
+    V, E = args.nodes, col.shape[0]
+    g = torch.Generator(device=dev).manual_seed(3)
+    weight = torch.rand(E, generator=g, device=dev) + 0.01
+    rows = []
+
+    def add(name, ref, seconds, nbytes, units, unit_name, note=""):
+        gbps = nbytes / seconds / 1e9
+        rows.append({"op": name, "reference": ref, "ms": round(seconds * 1e3, 4), "algorithmic_bytes": int(nbytes),
+                     "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+                     unit_name + "_per_s": round(units / seconds, 1), "note": note})
+        print(rows[-1], flush=True)
+
+    # ---- a1: uniform sampling, hop 1 (65,536 seeds, M=25) and hop 2 (~600 k frontier, M=10) ------------------
+    seeds = torch.randperm(V, generator=g, device=dev)[:64 * 1024]
+    b = 8
+    for name, centers, M in (("unweighted_sample hop1 M=25", seeds, 25), ("unweighted_sample hop2 M=10", None, 10)):
+        if centers is None:
+            centers = frontier
+        out = wholegraph_ops.unweighted_sample_without_replacement(row_ptr, col, centers, M, random_seed=62)
+        e_hop = out[1].shape[0]
+        t = timed(lambda: wholegraph_ops.unweighted_sample_without_replacement(row_ptr, col, centers, M, random_seed=62))
+        add(name, "wholegraph_op.h:31-42", t, centers.shape[0] * (b + 16 + 4) + e_hop * (2 * b + 4), e_hop, "edges",
+            "ABI op: 2 internal host syncs (count, total)")
+        if M == 25:
+            hop1 = out
+            uniq, mapping = graph_ops.append_unique(seeds, out[1], need_neighbor_raw_to_unique=True)
+            frontier = uniq
+    # ---- a4: weighted sampling ---------------------------------------------------------------------------------
+    outw = wholegraph_ops.weighted_sample_without_replacement(row_ptr, col, weight, frontier, 10, random_seed=62)
+    deg_sum = int((row_ptr[frontier + 1] - row_ptr[frontier]).sum())
+    t = timed(lambda: wholegraph_ops.weighted_sample_without_replacement(row_ptr, col, weight, frontier, 10, random_seed=62),
+              iters=10)
+    add("weighted_sample hop2 M=10", "wholegraph_op.h:61-73", t,
+        frontier.shape[0] * (b + 16 + 4) + deg_sum * 4 + outw[1].shape[0] * (2 * b + 4), outw[1].shape[0], "edges",
+        "reads every candidate weight (Σdeg = %d) to key it" % deg_sum)
+    # ---- a7: renumber --------------------------------------------------------------------------------------------
+    hop2 = wholegraph_ops.unweighted_sample_without_replacement(row_ptr, col, frontier, 10, random_seed=63)
+    T, Eh = frontier.shape[0], hop2[1].shape[0]
+    u2, _ = graph_ops.append_unique(frontier, hop2[1], need_neighbor_raw_to_unique=True)
+    t = timed(lambda: graph_ops.append_unique(frontier, hop2[1], need_neighbor_raw_to_unique=True))
+    add("graph_append_unique hop2", "graph_op.h:27-33", t, (T + Eh) * b + u2.shape[0] * b + 4 * Eh, T + Eh, "keys",
+        "hash-table traffic is overhead, not counted (§8d)")
+    # ---- a9: self loops --------------------------------------------------------------------------------------------
+    rp32, ci32 = hop2[0], torch.randint(0, T, (Eh,), device=dev, dtype=torch.int32)
+    t = timed(lambda: graph_ops.add_csr_self_loop(rp32, ci32))
+    add("csr_add_self_loop", "graph_op.h:44-48", t, (T + 1) * 8 + Eh * 4 + (Eh + T) * 4, Eh + T, "entries")
+    # ---- a10/a11: gather / scatter ----------------------------------------------------------------------------
+    for F, n_rows, label in ((100, u2.shape[0], "products rows"), (128, 1 << 20, "1M rows (gather_scatter_bench)"),
+                             (256, 1 << 20, "1M rows"), (1024, 1 << 18, "256k rows")):
+        table = torch.rand((V, F), generator=g, device=dev)
+        idx = torch.randint(0, V, (n_rows,), generator=g, device=dev)
+        out = torch.empty((n_rows, F), device=dev)
+        t = timed(lambda: local_gather(table, idx, out), events=True)
+        add("wholememory_gather F=%d, %s" % (F, label), "wholememory_op.h:25-30", t, n_rows * (b + 8 * F), n_rows, "rows",
+            "reference-style figure n*4F/t = %.1f GB/s" % (n_rows * 4 * F / t / 1e9))
+        perm = torch.randperm(V, generator=g, device=dev)[:n_rows]
+        t = timed(lambda: local_scatter(out, perm, table), events=True)
+        add("wholememory_scatter F=%d, %s" % (F, label), "wholememory_op.h:42-47", t, n_rows * (b + 8 * F), n_rows, "rows")
+        if F == 100:
+            half = table.half()
+            t = timed(lambda: local_gather(half, idx, out), events=True)
+            add("wholememory_gather fp16->fp32 F=100", "gather_scatter_func.cuh:242-505", t, n_rows * (b + 6 * F), n_rows,
+                "rows")
+        del table, out
+    # ---- a18: aggregation ----------------------------------------------------------------------------------------
+    n_src = u2.shape[0]
+    col2 = graph_ops.append_unique(frontier, hop2[1], need_neighbor_raw_to_unique=True)[1]
+    for F in (100, 256):
+        x = torch.rand((n_src, F), generator=g, device=dev)
+        t = timed(lambda: nn.spmm_csr_forward(hop2[0], col2, x, mean=True), events=True)
+        add("SAGE mean SpMM F=%d" % F, "torch_geometric SAGEConv (external)", t, Eh * (4 * F + 4) + T * (4 * F + 8), Eh, "edges")
+        gout = torch.rand((T, F), generator=g, device=dev)
+        fn = nn._SpmmCsr.apply
+        xr = x.clone().requires_grad_(True)
+        y = fn(xr, hop2[0], col2, True)
+
+        def bwd():
+            xr.grad = None
+            y.backward(gout, retain_graph=True)
+        t = timed(bwd, events=True, iters=10)
+        add("SAGE mean SpMM backward F=%d" % F, "—", t, Eh * (8 * F + 4) + T * (4 * F + 8) + n_src * 4 * F, Eh, "edges",
+            "CSR transpose (stable sort) + forward gather kernel, no atomics")
+        t = timed(lambda: nn.spmm_csr_backward(hop2[0], col2, gout, n_src, True, atomic=True), events=True, iters=10)
+        add("SAGE mean SpMM backward (atomic variant) F=%d" % F, "—", t, Eh * (8 * F + 4) + T * (4 * F + 8) + n_src * 4 * F,
+            Eh, "edges", "wgamd_spmm_csr_bwd_f32: one kernel, fp32 atomic scatter-add (incl. zeroing grad_x)")
+    for H, C in ((4, 64), (1, 256)):
+        x = torch.rand((n_src, H * C), generator=g, device=dev)
+        a_s = torch.rand((n_src, H), generator=g, device=dev)
+        a_d = torch.rand((T, H), generator=g, device=dev)
+        t = timed(lambda: nn.gat_forward(hop2[0], col2, x, a_s, a_d, H, 0.2, need_alpha=False), events=True)
+        add("GAT edge-softmax + SpMM H=%d C=%d" % (H, C), "torch_geometric GATConv (external)", t,
+            Eh * (4 * H + 4) + T * 4 * H + Eh * (4 * H * C + 4 * H + 4) + T * 4 * H * C, Eh, "edges",
+            "one fused kernel (online softmax): scores are never written")
+        t = timed(lambda: nn.gat_forward(hop2[0], col2, x, a_s, a_d, H, 0.2, need_alpha=True), events=True)
+        add("GAT (+alpha out for backward) H=%d C=%d" % (H, C), "—", t,
+            Eh * (4 * H + 4) + T * 4 * H + Eh * (4 * H * C + 4 * H + 4) + T * 4 * H * C + Eh * 4 * H, Eh, "edges")
+    result = {"device": torch.cuda.get_device_name(0), "graph": {"V": V, "E_directed": int(E)}, "hbm_peak_GBps": HBM_PEAK_GBPS,
+              "rows": rows}
+    if args.json:
+        os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
+        with open(args.json, "w") as f:
+            json.dump(result, f, indent=1)
+    print(json.dumps({"ops": len(rows)}))
+
+
+if __name__ == "__main__":
+    main()

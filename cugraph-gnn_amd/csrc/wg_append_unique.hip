@@ -20,6 +20,8 @@
 // appearance inside the batch".  Output rows are global rows of the concatenated per-batch
 // unique lists:  row(target i of batch b) = i + rank[edge_seg[b]],
 //                row(new node first seen at edge e of batch b) = target_seg[b+1] + rank[e].
+#include <algorithm>
+
 #include "wg_common.hpp"
 
 namespace wgamd {
@@ -65,16 +67,23 @@ __device__ __forceinline__ uint32_t slot_for(uint32_t hash, uint32_t slots)
   return (uint32_t)(((uint64_t)hash * slots) >> 32);
 }
 
+// Fixed grid, 16 B per lane per store, grid-stride over the LIVE slot prefix only (the buffers come from the
+// caller's allocator, 256-B aligned; both byte patterns are uniform, so whole int4 stores are valid).
 template <typename TableKeyT>
 __global__ void __launch_bounds__(256)
 table_clear_kernel(TableKeyT* keys, int* minpos, int64_t capacity_slots, dev_count T_, dev_count E_)
 {
-  const int64_t slots = (int64_t)live_slot_count(T_.get() + E_.get(), capacity_slots);
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < slots) {
-    keys[i]   = (TableKeyT)-1;
-    minpos[i] = kEmptyPos;
-  }
+  const int64_t slots  = (int64_t)live_slot_count(T_.get() + E_.get(), capacity_slots);
+  const int64_t tid    = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  constexpr int KPV    = 16 / (int)sizeof(TableKeyT);  // keys per 16-byte store
+  const int4 kfill = make_int4(-1, -1, -1, -1);
+  const int4 pfill = make_int4(kEmptyPos, kEmptyPos, kEmptyPos, kEmptyPos);
+  const int64_t kvec = (slots + KPV - 1) / KPV, pvec = (slots + 3) / 4;  // capacity is a multiple of 1024 slots
+  int4* k4 = reinterpret_cast<int4*>(keys);
+  int4* p4 = reinterpret_cast<int4*>(minpos);
+  for (int64_t i = tid; i < kvec; i += stride) k4[i] = kfill;
+  for (int64_t i = tid; i < pvec; i += stride) p4[i] = pfill;
 }
 
 // batch of position p (p < T: target p, else edge p - T)
@@ -250,7 +259,8 @@ void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_coun
                int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
 {
   const int P = T.host + E.host;
-  table_clear_kernel<TableKeyT><<<ceil_div(slots, 256), 256, 0, stream>>>(keys, minpos, slots, T, E);
+  table_clear_kernel<TableKeyT><<<(int)std::min<int64_t>(ceil_div(slots, 1024), 4096), 256, 0, stream>>>(keys, minpos, slots, T,
+                                                                                                   E);
   if (P > 0)
     table_insert_kernel<KeyT, TableKeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, keys,
                                                                               minpos, slots, slot_of);

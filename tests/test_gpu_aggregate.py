@@ -60,6 +60,17 @@ def test_spmm_backward_matches_torch(hiplib):
     ref.backward(gout)
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
+    # both backward flavours (transposed gather = default, atomic scatter-add) and the sum reduction; the transposed
+    # one is deterministic: two runs are bit-identical
+    for mean in (True, False):
+        a = nn.spmm_csr_backward(rpt, ct, gout, 800, mean)
+        b = nn.spmm_csr_backward(rpt, ct, gout, 800, mean, atomic=True)
+        assert torch.equal(a, nn.spmm_csr_backward(rpt, ct, gout, 800, mean))
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+        if mean:
+            torch.testing.assert_close(a, x2.grad, rtol=1e-4, atol=1e-5)
+    rpt_t, ct_t = nn.csr_transpose(rpt, ct, 800)
+    assert rpt_t[-1].item() == ct.shape[0] and torch.equal(torch.diff(rpt_t).long(), torch.bincount(ct, minlength=800))
 
 
 @pytest.mark.parametrize("H,C", [(1, 8), (4, 32), (4, 16), (2, 5), (8, 64)])
