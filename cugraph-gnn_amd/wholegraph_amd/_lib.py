@@ -161,6 +161,9 @@ SYMBOLS = {
     "wholememory_tensor_get_local_entry_count": (c_int, [POINTER(c_size_t), _T]),
     "wholememory_tensor_get_local_entry_start": (c_int, [POINTER(c_size_t), _T]),
     "wholememory_tensor_map_local_tensor": (c_int, [_T, POINTER(_T)]),
+    "wholememory_load_from_file": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, POINTER(ctypes.c_char_p), c_int,
+                                           c_int]),
+    "wholememory_store_to_file": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, ctypes.c_char_p]),
     # wgamd_ext.h
     "wgamd_spmm_csr_f32":(c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
                                    c_int, c_void_p, c_int64, c_void_p]),

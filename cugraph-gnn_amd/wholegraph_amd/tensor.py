@@ -11,6 +11,7 @@ replicated CSR array) OR a node-local range partition — rank r owns rows
 all-to-all pipeline in ``dist.py``.  The reference's mapped memory types (CUDA VMM / cudaIpc /
 NVSHMEM; memory_handle.cpp) are deliberately not reproduced.
 """
+import os
 from typing import Optional, Sequence, Union
 
 import torch
@@ -120,6 +121,15 @@ class WholeMemoryTensor(object):
             self.local_ops.scatter(input_tensor, indice, table2d)
 
 
+def get_part_file_name(prefix: str, part_id: int, part_count: int):
+    """Part-file naming of the reference (torch/utils.py:180-188)."""
+    return "%s_part_%d_of_%d" % (prefix, part_id, part_count)
+
+
+def get_part_file_list(prefix: str, part_count: int):
+    return [get_part_file_name(prefix, i, part_count) for i in range(part_count)]
+
+
 class _DevicePointerView:
     """``__cuda_array_interface__`` carrier so torch can view memory owned by a wholememory handle."""
 
@@ -211,6 +221,38 @@ class DistributedWholeMemoryTensor(object):
         L.check(L.lib().wholememory_scatter(w_in.c, w_i.c, self.c, get_wholegraph_env_fns(), get_stream(), -1),
                 "wholememory_scatter")
 
+    # ---- binary file I/O (tensor.py:153-198; format: headerless row-major entries) -------------------------
+    def _entry_bytes(self):
+        row = self._shape[1] if self.dim() == 2 else 1
+        return row * torch.empty((), dtype=self._dtype).element_size()
+
+    def from_filelist(self, filelist, round_robin_size: int = 0):
+        """Collective: the files, read as one concatenated array of rows, fill the tensor (rank-local rows only
+        are read by each rank); ``round_robin_size`` > 0 deals blocks of that many rows to the ranks in turn."""
+        import ctypes
+        if isinstance(filelist, str):
+            filelist = [filelist]
+        names = (ctypes.c_char_p * len(filelist))(*[os.fsencode(f) for f in filelist])
+        handle = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(self.c))
+        eb = self._entry_bytes()
+        L.check(L.lib().wholememory_load_from_file(handle, 0, eb, eb, names, len(filelist), int(round_robin_size)),
+                "wholememory_load_from_file")
+
+    def from_file_prefix(self, file_prefix: str, part_count: Union[int, None] = None):
+        if part_count is None:
+            part_count = self.comm.get_size()
+        self.from_filelist(get_part_file_list(file_prefix, part_count))
+
+    def local_to_file(self, filename: str):
+        """Collective: every rank writes its own rows to its own file."""
+        import ctypes
+        handle = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(self.c))
+        eb = self._entry_bytes()
+        L.check(L.lib().wholememory_store_to_file(handle, 0, eb, eb, os.fsencode(filename)), "wholememory_store_to_file")
+
+    def to_file_prefix(self, file_prefix: str):
+        self.local_to_file(get_part_file_name(file_prefix, self.comm.get_rank(), self.comm.get_size()))
+
     def destroy(self):
         if self.c is not None and self.c.value:
             self._local_view = None
@@ -249,6 +291,62 @@ def destroy_wholememory_tensor(wm_tensor):
     """tensor.py:322-328."""
     if isinstance(wm_tensor, DistributedWholeMemoryTensor):
         wm_tensor.destroy()
+
+
+def _torch_from_filelist(self, filelist, round_robin_size: int = 0):
+    """File loading for the torch-backed table (same format and sharding rules as the C entry point; each rank
+    reads only its own rows with numpy memory maps)."""
+    import numpy as np
+    if isinstance(filelist, str):
+        filelist = [filelist]
+    local = self.local_tensor
+    row_shape = tuple(local.shape[1:])
+    np_dtype = torch.empty((), dtype=torch.int16 if self.dtype == torch.bfloat16 else self.dtype).numpy().dtype
+    per_row = int(np.prod(row_shape)) if row_shape else 1
+    maps = [np.memmap(f, dtype=np_dtype, mode="r").reshape(-1, per_row) if os.path.getsize(f) else
+            np.empty((0, per_row), np_dtype) for f in filelist]  # an empty part (a rank without rows) cannot be mapped
+    first = np.concatenate([[0], np.cumsum([m.shape[0] for m in maps])])
+    total = int(first[-1])
+    assert total <= self._rows, f"the files hold {total} rows, the tensor only {self._rows}"
+    ws, rk = _dist.world_size(self.group), _dist.rank(self.group)
+    start = self.partition_offsets[rk] if self.is_distributed else 0
+
+    def read(lo, hi):  # rows [lo, hi) of the concatenated array
+        parts = []
+        while lo < hi:
+            f = int(np.searchsorted(first, lo, side="right")) - 1
+            take = min(hi, int(first[f + 1])) - lo
+            parts.append(np.asarray(maps[f][lo - int(first[f]): lo - int(first[f]) + take]))
+            lo += take
+        arr = np.concatenate(parts) if parts else np.empty((0, per_row), np_dtype)
+        t = torch.from_numpy(arr.reshape((-1,) + row_shape))
+        return t.view(self.dtype) if self.dtype == torch.bfloat16 else t
+
+    if round_robin_size == 0:
+        lo, hi = min(start, total), min(start + local.shape[0], total)
+        if hi > lo:
+            local[: hi - lo] = read(lo, hi).to(local.device)
+    else:
+        rr, k = int(round_robin_size), 0
+        while (k * ws + rk) * rr < total:
+            g = (k * ws + rk) * rr
+            cnt = min(rr, total - g)
+            assert k * rr + cnt <= local.shape[0], f"round-robin shard of rank {rk} does not fit its {local.shape[0]} rows"
+            local[k * rr: k * rr + cnt] = read(g, g + cnt).to(local.device)
+            k += 1
+
+
+def _torch_local_to_file(self, filename: str):
+    t = self.local_tensor.detach().cpu().contiguous()
+    (t.view(torch.int16) if t.dtype == torch.bfloat16 else t).numpy().tofile(filename)
+
+
+WholeMemoryTensor.from_filelist = _torch_from_filelist
+WholeMemoryTensor.from_file_prefix = lambda self, prefix, part_count=None: _torch_from_filelist(
+    self, get_part_file_list(prefix, part_count if part_count is not None else _dist.world_size(self.group)))
+WholeMemoryTensor.local_to_file = _torch_local_to_file
+WholeMemoryTensor.to_file_prefix = lambda self, prefix: _torch_local_to_file(
+    self, get_part_file_name(prefix, _dist.rank(self.group), _dist.world_size(self.group)))
 
 
 def equal_entry_partition(total_rows: int, world_size: int):

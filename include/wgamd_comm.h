@@ -96,6 +96,23 @@ wholememory_error_code_t wholememory_tensor_get_local_entry_start(size_t* local_
 wholememory_error_code_t wholememory_tensor_map_local_tensor(wholememory_tensor_t wholememory_tensor,
                                                              wholememory_tensor_t* local_tensor);
 
+/* wholememory.h:422-461 — headerless binary files of `file_entry_size`-byte entries <-> the handle's entries
+ * (`memory_entry_size` = row stride in bytes, payload `memory_offset` bytes into the entry).  The files of the list are
+ * one concatenated array; round_robin_size == 0 keeps file order = memory order, rr > 0 deals blocks of rr entries to
+ * the ranks in turn.  Collective (ends with a barrier).  store writes THIS rank's entries to its own file. */
+wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t wholememory_handle,
+                                                    size_t memory_offset,
+                                                    size_t memory_entry_size,
+                                                    size_t file_entry_size,
+                                                    const char** file_names,
+                                                    int file_count,
+                                                    int round_robin_size);
+wholememory_error_code_t wholememory_store_to_file(wholememory_handle_t wholememory_handle,
+                                                   size_t memory_offset,
+                                                   size_t memory_entry_stride,
+                                                   size_t file_entry_size,
+                                                   const char* local_file_name);
+
 #ifdef __cplusplus
 }
 #endif

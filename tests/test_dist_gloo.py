@@ -75,6 +75,26 @@ def _worker(rank, world, port, offsets, q):
         wm1 = WholeMemoryTensor(torch.arange(offs[rank], offs[rank + 1]) * 3, global_rows=V, partition_offsets=offs,
                                 local_ops=OracleLocalOps)
         assert torch.equal(wm1.gather(idx[mask]), idx[mask] * 3)
+        # binary file I/O: store per-rank part files, reload them (plain and round-robin sharded) into fresh tables
+        import tempfile
+        tmp = [tempfile.mkdtemp() if rank == 0 else None]
+        dist.broadcast_object_list(tmp, src=0)
+        prefix = os.path.join(tmp[0], "feat")
+        wm.to_file_prefix(prefix)
+        dist.barrier()
+        assert os.path.getsize("%s_part_%d_of_%d" % (prefix, rank, world)) == (offs[rank + 1] - offs[rank]) * F * 4
+        wm2 = create_wholememory_tensor((V, F), torch.float32, device="cpu", partition_offsets=offs, local_ops=OracleLocalOps)
+        wm2.local_tensor.fill_(-1)
+        wm2.from_file_prefix(prefix)                      # part files of a DIFFERENT split than the reader's are fine
+        assert torch.equal(wm2.local_tensor, full[offs[rank]:offs[rank + 1]])
+        rr_rows = [sum(min(50, V - g0) for g0 in range(r * 50, V, world * 50)) for r in range(world)]
+        eq = [sum(rr_rows[:r]) for r in range(world + 1)]   # a round-robin shard must fit the rank's rows
+        wm3 = create_wholememory_tensor((V, F), torch.float32, device="cpu", partition_offsets=eq, local_ops=OracleLocalOps)
+        wm3.local_tensor.fill_(-1)
+        wm3.from_filelist(["%s_part_%d_of_%d" % (prefix, r, world) for r in range(world)], round_robin_size=50)
+        n_local = eq[rank + 1] - eq[rank]
+        rows = [g0 + j for k in range(V) for g0 in [(k * world + rank) * 50] if g0 < V for j in range(min(50, V - g0))]
+        assert len(rows) <= n_local and torch.equal(wm3.local_tensor[:len(rows)], full[rows])
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback

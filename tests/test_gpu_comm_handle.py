@@ -114,3 +114,47 @@ def test_unsupported_memory_types_are_refused(comm):
         wg.create_wholememory_tensor(comm, "distributed", "cpu", [16, 4], torch.float32, [4, 1])
     with pytest.raises(wg.WholeMemoryError):  # partition that does not add up
         wg.create_wholememory_tensor(comm, "distributed", "cuda", [16, 4], torch.float32, [4, 1], [15])
+
+
+@pytest.mark.parametrize("dtype,dim", [(torch.float32, 100), (torch.float16, 33), (torch.int64, 1)])
+def test_handle_file_roundtrip(comm, tmp_path, dtype, dim):
+    """wholememory_store_to_file / wholememory_load_from_file: headerless row-major binary files; a list of files
+    is one concatenated array (reference file_io.cpp:1893-2160), also split across files at arbitrary rows."""
+    import wholegraph_amd as wg
+    rows = 70001  # > one 16 MB staging chunk for the wide dtypes? no: several chunks at dim 100 fp32 = 28 MB
+    rng = np.random.default_rng(5)
+    host = (rng.standard_normal((rows, dim)).astype(np.float32) if dtype.is_floating_point
+            else rng.integers(-1000, 1000, (rows, dim)))
+    host = torch.from_numpy(host).to(dtype)
+    t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows, dim], dtype, [dim, 1])
+    t2 = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows + 10, dim], dtype, [dim, 1])
+    try:
+        t.get_local_tensor()[0].copy_(host)
+        t.to_file_prefix(str(tmp_path / "tab"))
+        part = tmp_path / "tab_part_0_of_1"
+        assert part.stat().st_size == rows * dim * host.element_size()
+        raw = np.fromfile(part, dtype=np.int8)
+        assert np.array_equal(raw, host.view(torch.int8).numpy().reshape(-1))
+        # reload from three files cut at arbitrary rows (one of them empty) into a LARGER table: the tail stays
+        cuts = [0, 12345, 12345, rows]
+        names = []
+        for i in range(3):
+            f = tmp_path / f"piece{i}.bin"
+            host[cuts[i]:cuts[i + 1]].view(torch.int8).numpy().tofile(f)
+            names.append(str(f))
+        t2.get_local_tensor()[0].fill_(7)
+        t2.from_filelist(names)
+        got = t2.get_local_tensor()[0].cpu()
+        assert torch.equal(got[:rows], host) and bool((got[rows:] == 7).all())
+        # errors: file size not a multiple of the row size; more rows than the table holds
+        bad = tmp_path / "bad.bin"
+        bad.write_bytes(b"x" * (dim * host.element_size() + 1))
+        with pytest.raises(wg.WholeMemoryError):
+            t.from_filelist(str(bad))
+        with pytest.raises(wg.WholeMemoryError):
+            t.from_filelist(names + names)
+        with pytest.raises(wg.WholeMemoryError):
+            t.from_filelist(str(tmp_path / "missing.bin"))
+    finally:
+        wg.destroy_wholememory_tensor(t)
+        wg.destroy_wholememory_tensor(t2)

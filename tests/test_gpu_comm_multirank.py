@@ -35,6 +35,8 @@ WORKER = textwrap.dedent(r"""
     rng = np.random.default_rng(W * 1000 + rows)
     table = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)).to(tdt)
     errors, results = [], [None] * W
+    import tempfile
+    tmpdir = tempfile.mkdtemp()
 
     def rank_main(r):
         try:
@@ -69,6 +71,25 @@ WORKER = textwrap.dedent(r"""
             want[torch.from_numpy(idx < 0)] = 3.0
             assert torch.equal(out.cpu(), want), f"rank {r}: gather mismatch"
             comm.barrier()
+            # file I/O: every rank stores its rows; reload (a) the part files in order into a table with a DIFFERENT
+            # partition, (b) round-robin sharded (blocks of 16 rows dealt to the ranks in turn)
+            import os, tempfile
+            prefix = os.path.join(tmpdir, "tab")
+            t.to_file_prefix(prefix)
+            names = [f"{prefix}_part_{i}_of_{W}" for i in range(W)]
+            assert os.path.getsize(names[r]) == (offs[r + 1] - offs[r]) * dim * 2
+            t2 = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows, dim], tdt, [dim, 1])
+            t2.from_filelist(names)
+            l2, s2 = t2.get_local_tensor()
+            assert torch.equal(l2.cpu(), table[s2:s2 + l2.shape[0]]), "reload mismatch"
+            if rows >= 16 * W:
+                rr_rows = [sum(min(16, rows - g0) for g0 in range(q * 16, rows, W * 16)) for q in range(W)]
+                t3 = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows, dim], tdt, [dim, 1], rr_rows)
+                t3.from_filelist(names, round_robin_size=16)
+                want = [g0 + j for g0 in range(r * 16, rows, W * 16) for j in range(min(16, rows - g0))]
+                assert torch.equal(t3.get_local_tensor()[0].cpu(), table[want]), "round-robin reload mismatch"
+                wg.destroy_wholememory_tensor(t3)
+            wg.destroy_wholememory_tensor(t2)
             wg.destroy_wholememory_tensor(t)
             comm.destroy()
             results[r] = "ok"
