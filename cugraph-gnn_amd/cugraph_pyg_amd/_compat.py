@@ -115,6 +115,13 @@ except ImportError:
             for k, v in (value_dict or {}).items():
                 self[k][name] = v
 
+        def __getattr__(self, name):
+            # data.<attr>_dict -> {type: value} over the stores that hold <attr> (PyG's collect())
+            if name.endswith("_dict") and not name.startswith("_"):
+                attr = name[:-5]
+                return {k: st[attr] for k, st in self._stores.items() if attr in st}
+            raise AttributeError(name)
+
         def __repr__(self):
             return "HeteroData(" + ", ".join(f"{k}={v}" for k, v in self._stores.items()) + ")"
 

@@ -8,8 +8,9 @@ the endpoints of the seed edges (plus negatives) are deduplicated in first-appea
 renumbering kernel with an empty target list does exactly that and returns the inverse map, which IS
 ``edge_label_index`` — then the unique endpoints are expanded like node seeds.
 
-Implemented: homogeneous graphs, ``neg_sampling`` = None | "binary" | "triplet" (uniform negative
-destinations).  Not implemented: temporal constraints, heterogeneous edge seeds.
+Implemented: homogeneous and heterogeneous graphs (edge seeds of ONE edge type, endpoints of both node types
+seeded together), ``neg_sampling`` = None | "binary" | "triplet" (uniform negatives inside the endpoint types'
+id ranges).  Not implemented: temporal constraints.
 """
 import warnings
 from typing import Optional, Tuple, Union
@@ -19,8 +20,9 @@ import torch
 from wholegraph_amd import graph_ops
 
 from ..data.graph_store import GraphStore
-from ..sampler.sampler import NeighborSampler, SampleIterator, filter_store, neighbor_sample
-from .._compat import Data
+from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, SampleIterator, build_hetero_data, filter_store,
+                               hetero_neighbor_sample, neighbor_sample)
+from .._compat import Data, HeteroSamplerOutput
 from .node_loader import generate_seed
 
 
@@ -45,7 +47,7 @@ class LinkLoader:
                  random_state: Optional[int] = None, **kwargs):
         if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
-        if not isinstance(link_sampler, NeighborSampler):
+        if not isinstance(link_sampler, (NeighborSampler, HeteroNeighborSampler)):
             raise NotImplementedError("Must provide a cuGraph sampler")
         if edge_label_time is not None:
             raise NotImplementedError("temporal link sampling is not implemented")
@@ -56,14 +58,20 @@ class LinkLoader:
         if self.__mode not in (None, "binary", "triplet"):
             raise ValueError(f"unknown negative sampling mode {self.__mode!r}")
         graph_store = data[1]
-        if not graph_store.is_homogeneous:
-            raise NotImplementedError("heterogeneous edge seeds are not implemented")
         dev = "cuda" if torch.cuda.is_available() else "cpu"
+        self.__etype = None
         if isinstance(edge_label_index, (tuple, list)) and len(edge_label_index) == 2 and not torch.is_tensor(
-                edge_label_index[0]):
-            edge_label_index = edge_label_index[1]            # (edge_type, tensor)
-        if edge_label_index is None:                          # all edges of the graph
-            edge_label_index = graph_store.get_edge_index(graph_store.get_all_edge_attrs()[0].edge_type, "coo")
+                edge_label_index[0]) and isinstance(edge_label_index[0], (tuple, list)):
+            self.__etype = tuple(edge_label_index[0])         # (edge_type, tensor | None)
+            edge_label_index = edge_label_index[1]
+        self.__hetero = isinstance(link_sampler, HeteroNeighborSampler)
+        if self.__hetero and self.__etype is None:
+            raise ValueError("heterogeneous graphs need edge_label_index=(edge_type, 2 x N tensor)")
+        if edge_label_index is None:                          # all edges of the (given) type
+            et = self.__etype or graph_store.get_all_edge_attrs()[0].edge_type
+            edge_label_index = graph_store.get_edge_index(et, "coo")
+        if isinstance(edge_label_index, (tuple, list)):
+            edge_label_index = torch.stack([torch.as_tensor(t) for t in edge_label_index])
         self.__eli = torch.as_tensor(edge_label_index).to(dev).long()
         if self.__eli.dim() != 2 or self.__eli.shape[0] != 2:
             raise ValueError("edge_label_index must be a 2 x N tensor")
@@ -75,7 +83,11 @@ class LinkLoader:
         self.__data, self.__sampler = data, link_sampler
         self.__batch_size, self.__shuffle, self.__drop_last = batch_size, shuffle, drop_last
         self.__random_state = random_state
-        self.__num_nodes = graph_store._graph.num_vertices
+        if self.__hetero:
+            nv = graph_store._num_vertices()
+            self.__num_src, self.__num_dst = int(nv[self.__etype[0]]), int(nv[self.__etype[2]])
+        else:
+            self.__num_nodes = graph_store._graph.num_vertices
 
     def __len__(self):
         n = self.__eli.shape[1]
@@ -89,6 +101,9 @@ class LinkLoader:
             perm = perm[: n - n % self.__batch_size]
         seed = self.__random_state if self.__random_state is not None else generate_seed()
         fs, gs = self.__data
+        if self.__hetero:
+            yield from self.__hetero_batches(perm, seed)
+            return
         graph = self.__sampler.graph
         for b, start in enumerate(range(0, perm.numel(), self.__batch_size)):
             ix = perm[start:start + self.__batch_size]
@@ -130,6 +145,58 @@ class LinkLoader:
                     data.edge_label = self.__label[ix]
             yield data
 
+    def __hetero_batches(self, perm, seed):
+        """Edge seeds of one edge type (src_t, rel, dst_t): the src endpoints seed type src_t, the dst endpoints type
+        dst_t (one joint list when both are the same type); ids are type-local (sampler.py:280-490 decode contract:
+        ``edge_label_index`` under the seed edge type, local ids into ``n_id`` of the endpoint types)."""
+        fs, gs = self.__data
+        src_t, _, dst_t = self.__etype
+        dev = self.__eli.device
+        smp = self.__sampler
+        for b, start in enumerate(range(0, perm.numel(), self.__batch_size)):
+            ix = perm[start:start + self.__batch_size]
+            src, dst = self.__eli[0, ix], self.__eli[1, ix]
+            n_pos = ix.numel()
+            gen = torch.Generator(device=dev).manual_seed((seed + b) & 0x7FFFFFFFFFFFFFFF)
+            n_neg = int(round(n_pos * self.__amount)) if self.__mode else 0
+            if self.__mode == "binary":
+                src_all = torch.cat([src, torch.randint(0, self.__num_src, (n_neg,), generator=gen, device=dev)])
+                dst_all = torch.cat([dst, torch.randint(0, self.__num_dst, (n_neg,), generator=gen, device=dev)])
+            elif self.__mode == "triplet":
+                src_all = torch.cat([src, src.repeat_interleave(max(n_neg // max(n_pos, 1), 1))[:n_neg]])
+                dst_all = torch.cat([dst, torch.randint(0, self.__num_dst, (n_neg,), generator=gen, device=dev)])
+            else:
+                src_all, dst_all = src, dst
+            empty = src_all[:0].contiguous()
+            if src_t == dst_t:
+                uniq, inv = graph_ops.append_unique(empty, torch.cat([src_all, dst_all]).contiguous(),
+                                                    need_neighbor_raw_to_unique=True)
+                seeds = {src_t: uniq}
+                inv_src, inv_dst = inv[:src_all.numel()].long(), inv[src_all.numel():].long()
+            else:
+                us, inv_src = graph_ops.append_unique(empty, src_all.contiguous(), need_neighbor_raw_to_unique=True)
+                ud, inv_dst = graph_ops.append_unique(empty, dst_all.contiguous(), need_neighbor_raw_to_unique=True)
+                seeds = {src_t: us, dst_t: ud}
+                inv_src, inv_dst = inv_src.long(), inv_dst.long()
+            node, row, col, edge, nn, ne = hetero_neighbor_sample(smp.graphs, None, seeds, smp.fanout, seed + b, smp.biased)
+            out = HeteroSamplerOutput(node=node, row=row, col=col, edge=edge,
+                                      batch={t: node[t][:v.numel()] for t, v in seeds.items()},
+                                      num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
+                                      num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()}, metadata=None)
+            data = build_hetero_data(fs, out)
+            st = data[self.__etype]
+            st.edge_label_index = torch.stack([inv_src, inv_dst])
+            st.input_id = self.__input_id[ix]
+            st.batch_size = n_pos
+            if self.__mode is not None:
+                pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
+                st.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
+                if self.__mode == "triplet":
+                    st.src_index, st.dst_pos_index, st.dst_neg_index = inv_src[:n_pos], inv_dst[:n_pos], inv_dst[n_pos:]
+            elif self.__label is not None:
+                st.edge_label = self.__label[ix]
+            yield data
+
     def __iter__(self):
         return self.__batches()
 
@@ -155,8 +222,18 @@ class LinkNeighborLoader(LinkLoader):
         feature_store, graph_store = data
         if weight_attr is not None:
             graph_store._set_weight_attr((feature_store, weight_attr))
-        sampler = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
-                                  with_replacement=replace, disjoint=disjoint)
+        if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
+            sampler = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
+                                      with_replacement=replace, disjoint=disjoint)
+        else:
+            etypes = [a.edge_type for a in graph_store.get_all_edge_attrs()]
+            if not isinstance(num_neighbors, dict):
+                num_neighbors = {et: list(num_neighbors) for et in etypes}
+            unknown = [k for k in num_neighbors if k not in etypes]
+            if unknown:
+                raise ValueError(f"fan-out given for unknown edge types: {unknown}")
+            sampler = HeteroNeighborSampler(graph_store._hetero_graphs, num_neighbors, biased=(weight_attr is not None),
+                                            with_replacement=replace, disjoint=disjoint)
         super().__init__((feature_store, graph_store), sampler, edge_label_index=edge_label_index,
                          edge_label=edge_label, edge_label_time=edge_label_time, neg_sampling=neg_sampling,
                          neg_sampling_ratio=neg_sampling_ratio, transform=transform,

@@ -88,23 +88,25 @@ def _one_hop(graph: CSRGraph, frontier, fan, seed, biased):
     return nbr, lid, gid
 
 
-def hetero_neighbor_sample(graphs, seed_type: str, seeds: torch.Tensor, fanout, random_state: int,
-                           biased: bool = False):
+def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, biased: bool = False):
     """Heterogeneous PyG-style sampling: per hop, for every edge type (src_t, rel, dst_t) in sorted
     order, the frontier vertices of type ``dst_t`` draw up to ``fanout[etype][hop]`` in-neighbours of
     type ``src_t``; vertices first seen during a hop form the next hop's frontier of their type.
     Seeds of hop-h / edge-type-index-t calls are ``hop_seed(random_state, h * n_etypes + t)`` — the
     flat ``[hop * num_etypes + etype]`` indexing of the reference's fan-out array
-    (loader/neighbor_loader.py:192-201).  Ids are TYPE-LOCAL throughout.
+    (loader/neighbor_loader.py:192-201).  Ids are TYPE-LOCAL throughout.  ``seeds`` may also be a dict
+    ``{node type: ids}`` (``seed_type`` is then ignored): link prediction seeds both endpoint types at once.
 
     Returns (node{type}, row{etype}, col{etype}, edge{etype}, num_sampled_nodes{type}[hops+1],
     num_sampled_edges{etype}[hops])."""
     etypes = sorted(graphs.keys())
     dev = next(iter(graphs.values())).row_ptr.device
-    ntypes = sorted({t for et in etypes for t in (et[0], et[2])} | {seed_type})
+    seed_dict = seeds if isinstance(seeds, dict) else {seed_type: seeds}
+    ntypes = sorted({t for et in etypes for t in (et[0], et[2])} | set(seed_dict))
     empty = lambda: torch.zeros(0, dtype=torch.int64, device=dev)  # noqa: E731
     node = {t: empty() for t in ntypes}
-    node[seed_type] = seeds.to(device=dev, dtype=torch.int64)
+    for t, ids in seed_dict.items():
+        node[t] = ids.to(device=dev, dtype=torch.int64)
     frontier_start = {t: 0 for t in ntypes}                  # first row of the current frontier in node[t]
     n_hops = len(next(iter(fanout.values())))
     rows = {et: [] for et in etypes}
@@ -257,6 +259,33 @@ def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
     return data
 
 
+def build_hetero_data(feature_store, s: HeteroSamplerOutput) -> HeteroData:
+    """HeteroSamplerOutput -> HeteroData with every stored attribute joined (sampler.py:96-165)."""
+    data = HeteroData()
+    for et in s.row:
+        data[et].edge_index = torch.stack([s.row[et], s.col[et]], dim=0)
+        data[et].e_id = s.edge[et].to(torch.long)
+    for nt, ids in s.node.items():
+        data[nt].n_id = ids
+        data[nt].num_nodes = ids.size(0)
+    for attr in feature_store.get_all_tensor_attrs():
+        g = attr.group_name
+        if isinstance(g, tuple):
+            if g in s.edge:
+                data[g][attr.attr_name] = feature_store[g, attr.attr_name, None][s.edge[g]]
+        elif g in s.node:
+            data[g][attr.attr_name] = feature_store[g, attr.attr_name, None][s.node[g]]
+    data.set_value_dict("batch", s.batch)
+    data.set_value_dict("num_sampled_nodes", s.num_sampled_nodes)
+    data.set_value_dict("num_sampled_edges", s.num_sampled_edges)
+    if s.metadata is not None and s.metadata[0] is not None:
+        input_type, input_id = s.metadata[0]
+        data[input_type].input_id = input_id
+        data[input_type].batch_size = input_id.size(0)
+        data[input_type].seed_time = s.metadata[1]
+    return data
+
+
 class SampleIterator:
     """Joins features to sampler outputs and emits PyG ``Data`` (sampler.py:51-165)."""
 
@@ -265,28 +294,7 @@ class SampleIterator:
         self.__output_iter = output_iter
 
     def __next_hetero(self, s):
-        data = HeteroData()
-        for et in s.row:
-            data[et].edge_index = torch.stack([s.row[et], s.col[et]], dim=0)
-            data[et].e_id = s.edge[et].to(torch.long)
-        for nt, ids in s.node.items():
-            data[nt].n_id = ids
-            data[nt].num_nodes = ids.size(0)
-        for attr in self.__feature_store.get_all_tensor_attrs():
-            g = attr.group_name
-            if isinstance(g, tuple):
-                if g in s.edge:
-                    data[g][attr.attr_name] = self.__feature_store[g, attr.attr_name, None][s.edge[g]]
-            elif g in s.node:
-                data[g][attr.attr_name] = self.__feature_store[g, attr.attr_name, None][s.node[g]]
-        data.set_value_dict("batch", s.batch)
-        data.set_value_dict("num_sampled_nodes", s.num_sampled_nodes)
-        data.set_value_dict("num_sampled_edges", s.num_sampled_edges)
-        input_type, input_id = s.metadata[0]
-        data[input_type].input_id = input_id
-        data[input_type].batch_size = input_id.size(0)
-        data[input_type].seed_time = s.metadata[1]
-        return data
+        return build_hetero_data(self.__feature_store, s)
 
     def __next__(self):
         s = next(self.__output_iter)

@@ -358,3 +358,97 @@ def test_link_loader_labels_and_determinism(hiplib):
     assert a[0].edge_label.cpu()[:32].tolist() == (labels[:32] + 1).tolist()      # positives shifted by one, negatives 0
     plain = next(iter(LinkNeighborLoader((fs, gs), [4], edge_label_index=seeds, edge_label=labels, batch_size=32)))
     assert plain.edge_label.cpu().tolist() == labels[:32].tolist()
+
+
+def _paper_author_stores():
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    src = torch.tensor([0, 1, 2, 4, 3, 4, 5, 5])
+    dst = torch.tensor([4, 5, 4, 3, 2, 1, 0, 1])
+    asrc = torch.tensor([0, 1, 2, 3, 3, 0])
+    adst = torch.tensor([0, 1, 2, 3, 4, 5])
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store[("paper", "cites", "paper"), "coo", False, (6, 6)] = [src, dst]
+    graph_store[("author", "writes", "paper"), "coo", False, (4, 6)] = [asrc, adst]
+    return feature_store, graph_store, asrc, adst
+
+
+def test_link_neighbor_loader_hetero_linkpred_reference_example(hiplib):
+    # tests/loader/test_neighbor_loader.py:455-523: exact outputs (fan-out >= degree => deterministic)
+    import torch
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    feature_store, graph_store, asrc, adst = _paper_author_stores()
+    loader = LinkNeighborLoader((feature_store, graph_store),
+                                num_neighbors={("paper", "cites", "paper"): [2, 2], ("author", "writes", "paper"): [2, 2]},
+                                edge_label_index=(("author", "writes", "paper"), torch.stack([asrc, adst])), batch_size=5)
+    out = next(iter(loader))
+    assert out["paper"].n_id.tolist() == [0, 1, 2, 3, 4, 5]
+    assert out["author"].n_id.tolist() == [0, 1, 2, 3]
+    assert out["paper"].num_sampled_nodes.tolist() == [5, 1, 0]
+    assert out["author"].num_sampled_nodes.tolist() == [4, 0, 0]
+    assert out["paper", "cites", "paper"].edge_index.shape == torch.Size([2, 8])
+    assert out["paper", "cites", "paper"].num_sampled_edges.tolist() == [7, 1]
+    assert "edge_label_index" not in out["paper", "cites", "paper"]
+    assert out["author", "writes", "paper"].edge_index.shape == torch.Size([2, 6])
+    assert out["author", "writes", "paper"].num_sampled_edges.tolist() == [5, 1]
+    eli = out["author", "writes", "paper"].edge_label_index
+    assert list(eli.shape) == [2, 5]
+    assert eli.tolist()[0] == [0, 1, 2, 3, 3] and eli.tolist()[1] == [0, 1, 2, 3, 4]
+    assert len(loader) == 2
+
+
+def test_link_neighbor_loader_hetero_bidirectional(hiplib):
+    # tests/loader/test_neighbor_loader.py:529-583: nonexistent seed edges, two edge types that mirror each other
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    src = torch.tensor([1, 5, 5, 8, 1, 1])
+    dst = torch.tensor([4, 2, 3, 1, 0, 4])
+    feature_store, graph_store = FeatureStore(), GraphStore()
+    graph_store[("user", "to", "merchant"), "coo", False, (9, 5)] = torch.stack([src, dst])
+    graph_store[("merchant", "rev_to", "user"), "coo", False, (5, 9)] = torch.stack([dst, src])
+    eli = torch.tensor([[0, 5, 8, 1, 7, 2], [4, 4, 2, 3, 1, 0]])
+    loader = LinkNeighborLoader(data=(feature_store, graph_store),
+                                num_neighbors={("user", "to", "merchant"): [2, 2], ("merchant", "rev_to", "user"): [2, 2]},
+                                edge_label_index=(("user", "to", "merchant"), eli), edge_label=None, batch_size=2,
+                                shuffle=False)
+    n = 0
+    for i, batch in enumerate(loader):
+        li = batch["user", "to", "merchant"].edge_label_index.cpu()
+        r_i = torch.stack([batch["user"].n_id.cpu()[li[0]], batch["merchant"].n_id.cpu()[li[1]]])
+        assert (r_i == eli[:, i * 2:(i + 1) * 2]).all()
+        # sampled edges are real edges of their type
+        ei = batch["user", "to", "merchant"].edge_index.cpu()
+        e = batch["user", "to", "merchant"].e_id.cpu()
+        assert (src[e] == batch["user"].n_id.cpu()[ei[0]]).all() and (dst[e] == batch["merchant"].n_id.cpu()[ei[1]]).all()
+        n += 1
+    assert n == 3
+
+
+@pytest.mark.parametrize("batch_size", [1, 3])
+@pytest.mark.parametrize("mode,amount", [("binary", 1), ("binary", 2), ("triplet", 1), ("triplet", 3)])
+def test_link_neighbor_loader_hetero_negative_sampling(hiplib, batch_size, mode, amount):
+    # tests/loader/test_neighbor_loader.py:742-835, same assertions
+    import torch
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    feature_store, graph_store, asrc, adst = _paper_author_stores()
+    et = ("author", "writes", "paper")
+    loader = LinkNeighborLoader((feature_store, graph_store),
+                                num_neighbors={("paper", "cites", "paper"): [2, 2], et: [2, 2]},
+                                edge_label_index=(et, torch.stack([asrc, adst])), batch_size=batch_size,
+                                neg_sampling=(mode, float(amount)), shuffle=False)
+    seen = 0
+    for batch in loader:
+        assert [et] == list(batch.edge_label_index_dict.keys())
+        assert [et] == list(batch.edge_label_dict.keys())
+        labels = batch[et].edge_label
+        assert torch.any(labels == 1.0) and torch.any(labels == 0.0)
+        assert (labels == 0.0).sum() == amount * (labels == 1.0).sum()
+        eli = batch[et].edge_label_index
+        assert eli.shape[0] == 2 and eli.shape[1] == labels.shape[0] > 0
+        assert int(eli[0].max()) < batch["author"].n_id.numel() and int(eli[1].max()) < batch["paper"].n_id.numel()
+        n_pos = int((labels == 1.0).sum())
+        pos = torch.stack([batch["author"].n_id[eli[0, :n_pos]], batch["paper"].n_id[eli[1, :n_pos]]]).cpu()
+        assert torch.equal(pos, torch.stack([asrc, adst])[:, seen:seen + n_pos])
+        seen += n_pos
+    assert seen == asrc.numel()
