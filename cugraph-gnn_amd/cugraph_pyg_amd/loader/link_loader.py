@@ -123,7 +123,7 @@ class LinkLoader:
             uniq, inverse = graph_ops.append_unique(ends[:0].contiguous(), ends.contiguous(),
                                                     need_neighbor_raw_to_unique=True)
             node, row, col, edge, nn, ne = neighbor_sample(graph, uniq, self.__sampler.fanout, seed + b,
-                                                           self.__sampler.biased)
+                                                           self.__sampler.biased, self.__sampler.disjoint)
             data = filter_store(fs, gs, node, row, col, edge)
             data.n_id, data.e_id = node, edge
             data.num_sampled_nodes, data.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)

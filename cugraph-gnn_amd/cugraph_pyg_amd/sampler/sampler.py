@@ -36,10 +36,17 @@ def hop_seed(random_state: int, hop: int) -> int:
 
 
 def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int], random_state: int,
-                    biased: bool = False):
-    """One mini-batch.  Returns (node, row, col, edge, num_sampled_nodes, num_sampled_edges)."""
+                    biased: bool = False, disjoint: bool = False):
+    """One mini-batch.  Returns (node, row, col, edge, num_sampled_nodes, num_sampled_edges).
+
+    ``disjoint``: every seed grows its own tree and a vertex belongs to at most ONE tree of the batch — the tree of
+    the first sampled edge that reaches it (first appearance = the renumbering order); sampled edges that lead into
+    another tree's vertex are dropped.  This is the behaviour the reference's tests pin for libcugraph's disjoint
+    sampling (tests/loader/test_neighbor_loader.py:840-943: seeds {0, 1} that share their only neighbour 2 yield ONE
+    edge and n_id {0, 1, 2}; the per-seed vertex sets of a batch never intersect)."""
     seeds = seeds.to(device=graph.row_ptr.device, dtype=graph.col.dtype)
     nodes = seeds
+    tree = torch.arange(seeds.shape[0], device=seeds.device) if disjoint else None   # tree id of every node
     frontier, f_start = seeds, 0
     rows, cols, edges = [], [], []
     num_nodes, num_edges = [int(seeds.shape[0])], []
@@ -61,8 +68,22 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
             off, nbr, lid, gid = wholegraph_ops.unweighted_sample_without_replacement(
                 graph.row_ptr, graph.col, frontier, int(fan), hop_seed(random_state, k), True, True)
         new_nodes, mapping = graph_ops.append_unique(nodes, nbr, need_neighbor_raw_to_unique=True)
-        rows.append(mapping.long())
-        cols.append(lid.long() + f_start)
+        mapping = mapping.long()
+        src_row = lid.long() + f_start
+        if disjoint and nbr.shape[0] > 0:
+            n_old, n_new = int(nodes.shape[0]), int(new_nodes.shape[0])
+            edge_tree = tree[src_row]
+            if n_new > n_old:
+                # a new vertex joins the tree of the FIRST edge that reaches it
+                e_ids = torch.arange(mapping.shape[0], device=mapping.device)
+                first = torch.full((n_new - n_old,), mapping.shape[0], dtype=torch.int64, device=mapping.device)
+                is_new = mapping >= n_old
+                first.scatter_reduce_(0, mapping[is_new] - n_old, e_ids[is_new], reduce="amin")
+                tree = torch.cat([tree, edge_tree[first]])
+            keep = tree[mapping] == edge_tree
+            mapping, src_row, gid, nbr = mapping[keep], src_row[keep], gid[keep], nbr[keep]
+        rows.append(mapping)
+        cols.append(src_row)
         edges.append(graph.edge_id[gid])
         num_edges.append(int(nbr.shape[0]))
         num_nodes.append(int(new_nodes.shape[0] - nodes.shape[0]))
@@ -167,11 +188,11 @@ class NeighborSampler:
                  temporal: bool = False, local_seeds_per_call: Optional[int] = None, **_ignored):
         if with_replacement:
             raise NotImplementedError("sampling with replacement is not implemented (kernels sample without)")
-        if disjoint or heterogeneous or temporal:
-            raise NotImplementedError("disjoint / heterogeneous / temporal sampling: SURVEY.md §8(f) 'next'")
+        if heterogeneous or temporal:
+            raise NotImplementedError("temporal sampling: SURVEY.md §8(f) 'next' (heterogeneous: HeteroNeighborSampler)")
         if biased and graph.weight is None:
             raise ValueError("biased sampling needs a weight attribute (weight_attr=...)")
-        self.graph, self.fanout, self.biased = graph, [int(f) for f in fanout], biased
+        self.graph, self.fanout, self.biased, self.disjoint = graph, [int(f) for f in fanout], biased, bool(disjoint)
         self.local_seeds_per_call = local_seeds_per_call
         self._walks = {}
 
@@ -191,7 +212,7 @@ class NeighborSampler:
         fan-out -1, the ragged last batch) goes through the one-batch-at-a-time C-ABI ops.  Both routes
         return identical results (tests/test_gpu_pyg_loader.py)."""
         n = seeds.shape[0]
-        fast = (not self.biased) and all(f > 0 for f in self.fanout) and seeds.is_cuda
+        fast = (not self.biased) and (not self.disjoint) and all(f > 0 for f in self.fanout) and seeds.is_cuda
         n_full = n // batch_size if fast else 0
         per_call = self.local_seeds_per_call or 16 * batch_size
         G = max(1, per_call // batch_size)
@@ -207,7 +228,7 @@ class NeighborSampler:
             b += g
         for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
             yield bb, neighbor_sample(self.graph, seeds[start:start + batch_size], self.fanout, random_state + bb,
-                                      self.biased)
+                                      self.biased, self.disjoint)
 
 
 class BaseSampler:

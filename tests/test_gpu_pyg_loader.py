@@ -452,3 +452,78 @@ def test_link_neighbor_loader_hetero_negative_sampling(hiplib, batch_size, mode,
         assert torch.equal(pos, torch.stack([asrc, adst])[:, seen:seen + n_pos])
         seen += n_pos
     assert seen == asrc.numel()
+
+
+def test_neighbor_loader_disjoint_reference_example(hiplib):
+    # tests/loader/test_neighbor_loader.py:840-885: two seeds sharing their only neighbour
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store.put_edge_index(torch.stack([torch.tensor([2, 2]), torch.tensor([0, 1])]), ("node", "connects", "node"),
+                               "coo", False, (3, 3))
+    feature_store["node", "feat", None] = torch.randint(128, (3, 8))
+    kw = dict(input_nodes=torch.tensor([0, 1]), batch_size=2)
+    batch_nd = next(iter(NeighborLoader((feature_store, graph_store), [1], disjoint=False, **kw)))
+    assert batch_nd.e_id.numel() == 2
+    batch_d = next(iter(NeighborLoader((feature_store, graph_store), [1], disjoint=True, **kw)))
+    assert batch_d.e_id.numel() == 1
+    assert batch_d.input_id.min() >= 0 and batch_d.input_id.max() == batch_d.batch_size - 1
+    assert sorted(batch_d.input_id.tolist()) == [0, 1]
+    assert sorted(batch_d.n_id.tolist()) == [0, 1, 2]
+
+
+@pytest.mark.parametrize("batch_size", [1, 2, 4, 8, 16])
+def test_neighbor_loader_disjoint_batch_structure(hiplib, batch_size):
+    # tests/loader/test_neighbor_loader.py:888-943 on karate: the per-seed trees of a batch never share a vertex
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    src, dst = (torch.from_numpy(a) for a in _karate())
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store.put_edge_index(torch.stack([dst, src]), ("person", "knows", "person"), "coo", False, (34, 34))
+    feature_store["person", "feat", None] = torch.randint(128, (34, 16))
+    loader = NeighborLoader((feature_store, graph_store), [5, 5], input_nodes=torch.arange(34), batch_size=batch_size,
+                            disjoint=True)
+    n_batches = 0
+    for batch in loader:
+        ei = batch.edge_index.cpu()
+        trees = {}
+        for n_id in range(int(batch.num_sampled_nodes[0])):
+            trees[n_id] = {n_id}
+            off = 0
+            for hop in range(len(batch.num_sampled_edges)):
+                cnt = int(batch.num_sampled_edges[hop])
+                e_h = ei[:, off:off + cnt]
+                e_in = torch.isin(e_h[1], torch.tensor(sorted(trees[n_id])))
+                trees[n_id].update(e_h[0][e_in].tolist())
+                off += cnt
+        sets = list(trees.values())
+        for i in range(len(sets)):
+            for j in range(i + 1, len(sets)):
+                assert not (sets[i] & sets[j])
+        # every non-seed vertex belongs to some tree, and sampled edges are real edges
+        assert set().union(*sets) == set(range(batch.n_id.numel()))
+        g = batch.n_id.cpu()[ei]
+        e = batch.e_id.cpu()
+        assert (dst[e] == g[0]).all() and (src[e] == g[1]).all()
+        n_batches += 1
+    assert n_batches == (34 + batch_size - 1) // batch_size
+
+
+def test_link_neighbor_loader_disjoint_reference_example(hiplib):
+    # tests/loader/test_neighbor_loader.py:138-190
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store[("node", "connects", "node"), "coo", False, (5, 5)] = torch.stack(
+        [torch.tensor([4, 4, 4, 4]), torch.tensor([0, 1, 2, 3])])
+    eli = torch.tensor([[0, 2], [1, 3]])
+    kw = dict(num_neighbors=[1], edge_label_index=eli, batch_size=2, shuffle=False)
+    assert next(iter(LinkNeighborLoader((feature_store, graph_store), disjoint=False, **kw))).e_id.numel() == 4
+    batch_d = next(iter(LinkNeighborLoader((feature_store, graph_store), disjoint=True, **kw)))
+    assert batch_d.e_id.numel() == 1
+    li = batch_d.edge_label_index
+    assert tuple(li.shape) == (2, 2) and li.min() >= 0 and li.max() < batch_d.n_id.numel()
+    assert batch_d.n_id[li[0]].cpu().tolist() == [0, 2] and batch_d.n_id[li[1]].cpu().tolist() == [1, 3]
