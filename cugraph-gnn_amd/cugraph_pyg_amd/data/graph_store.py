@@ -41,6 +41,7 @@ class CSRGraph:
     edge_type: Optional[torch.Tensor]  # int32 [E] (None: one edge type)
     weight: Optional[torch.Tensor]     # float32 [E]
     num_vertices: int
+    time: Optional[torch.Tensor] = None  # int64 [E] edge timestamps (temporal sampling)
 
 
 class GraphStore(_PygGraphStore):
@@ -51,6 +52,7 @@ class GraphStore(_PygGraphStore):
         self.__sizes = {}
         self.__finalized = False
         self.__weight_attr = None
+        self.__time_attr = None
         self.__clear_graph()
         if HAS_PYG:  # pragma: no cover
             super().__init__()
@@ -139,7 +141,7 @@ class GraphStore(_PygGraphStore):
         if weight_attr is not None:
             self._set_weight_attr(weight_attr)
         if time_attr is not None:
-            raise NotImplementedError("temporal sampling is not implemented (SURVEY.md §8(f))")
+            self._set_time_attr(time_attr)
         self.__construct_graph()
         self._hetero_graphs  # noqa: B018
         self._vertex_offsets  # noqa: B018  cache before the slices go away
@@ -154,6 +156,20 @@ class GraphStore(_PygGraphStore):
             self.__graph = None
             self.__hetero = None
         self.__weight_attr = attr
+
+    def _set_time_attr(self, attr):
+        """``(feature_store, attr_name)``: edge timestamps for temporal sampling (graph_store.py:448-464)."""
+        if attr != self.__time_attr:
+            self.__graph = None
+            self.__hetero = None
+        self.__time_attr = attr
+
+    def __edge_values(self, attr, key, n_edges, dev, dtype):
+        """Per-edge values of one edge type in edge-id order, from a ``(feature_store, name)`` attribute."""
+        fs, name = attr
+        v = fs[key, name, None]
+        v = v[torch.arange(n_edges, device=dev)] if not isinstance(v, torch.Tensor) else v
+        return v.to(device=dev, dtype=dtype).view(-1)
 
     def _num_vertices(self) -> Dict[str, int]:
         if self.__finalized:
@@ -249,8 +265,11 @@ class GraphStore(_PygGraphStore):
                     wt = fs[key, name, None]
                     wt = wt[torch.arange(ei.shape[1], device=dev)] if not isinstance(wt, torch.Tensor) else wt
                     w = wt.to(device=dev, dtype=torch.float32).view(-1)[order].contiguous()
+                tm = None
+                if self.__time_attr is not None:
+                    tm = self.__edge_values(self.__time_attr, key, ei.shape[1], dev, torch.int64)[order].contiguous()
                 out[key] = CSRGraph(row_ptr=row_ptr, col=ei[0][order].contiguous(), edge_id=order.contiguous(),
-                                    edge_type=None, weight=w, num_vertices=n_rows)
+                                    edge_type=None, weight=w, num_vertices=n_rows, time=tm)
             self.__hetero = out
         return self.__hetero
 
@@ -262,7 +281,7 @@ class GraphStore(_PygGraphStore):
         offs = self._vertex_offsets
         V = sum(self.__num_vertices_cache.values())
         dev = "cuda" if torch.cuda.is_available() else "cpu"
-        rows, cols, eids, etps, wgts = [], [], [], [], []
+        rows, cols, eids, etps, wgts, tms = [], [], [], [], [], []
         for t, key in enumerate(sorted_keys):
             ei = self.__gathered_edge_index(key, dev)
             src_t, _, dst_t = key
@@ -275,6 +294,8 @@ class GraphStore(_PygGraphStore):
                 w = fs[key, name, None]
                 w = w[torch.arange(ei.shape[1], device=dev)] if not isinstance(w, torch.Tensor) else w
                 wgts.append(w.to(device=dev, dtype=torch.float32).view(-1))
+            if self.__time_attr is not None:
+                tms.append(self.__edge_values(self.__time_attr, key, ei.shape[1], dev, torch.int64))
         row = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.int64, device=dev)
         col = torch.cat(cols) if cols else torch.zeros(0, dtype=torch.int64, device=dev)
         order = torch.sort(row, stable=True).indices         # CSR order; ties keep edge-id order
@@ -284,5 +305,6 @@ class GraphStore(_PygGraphStore):
             row_ptr=row_ptr, col=col[order].contiguous(),
             edge_id=torch.cat(eids)[order].contiguous() if eids else col,
             edge_type=torch.cat(etps)[order].contiguous() if len(sorted_keys) > 1 else None,
-            weight=torch.cat(wgts)[order].contiguous() if wgts else None, num_vertices=V)
+            weight=torch.cat(wgts)[order].contiguous() if wgts else None, num_vertices=V,
+            time=torch.cat(tms)[order].contiguous() if tms else None)
         return self.__graph

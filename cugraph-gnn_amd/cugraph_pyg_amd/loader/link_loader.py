@@ -10,7 +10,7 @@ renumbering kernel with an empty target list does exactly that and returns the i
 
 Implemented: homogeneous and heterogeneous graphs (edge seeds of ONE edge type, endpoints of both node types
 seeded together), ``neg_sampling`` = None | "binary" | "triplet" (uniform negatives inside the endpoint types'
-id ranges).  Not implemented: temporal constraints.
+id ranges), ``disjoint``, temporal seeds (``edge_label_time`` + ``time_attr``; negatives are NOT time-filtered).
 """
 import warnings
 from typing import Optional, Tuple, Union
@@ -24,6 +24,13 @@ from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, SampleIte
                                hetero_neighbor_sample, neighbor_sample)
 from .._compat import Data, HeteroSamplerOutput
 from .node_loader import generate_seed
+
+
+def _first_occurrence(inverse, values, n_unique):
+    """values[first position i with inverse[i] == u] for every u in [0, n_unique)."""
+    first = torch.full((n_unique,), inverse.numel(), dtype=torch.int64, device=inverse.device)
+    first.scatter_reduce_(0, inverse, torch.arange(inverse.numel(), device=inverse.device), reduce="amin")
+    return values[first]
 
 
 def _parse_neg_sampling(neg_sampling) -> Tuple[Optional[str], float]:
@@ -49,8 +56,6 @@ class LinkLoader:
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
         if not isinstance(link_sampler, (NeighborSampler, HeteroNeighborSampler)):
             raise NotImplementedError("Must provide a cuGraph sampler")
-        if edge_label_time is not None:
-            raise NotImplementedError("temporal link sampling is not implemented")
         if neg_sampling_ratio is not None:
             warnings.warn("neg_sampling_ratio is deprecated; use neg_sampling=('binary', ratio)")
             neg_sampling = ("binary", float(neg_sampling_ratio))
@@ -77,6 +82,9 @@ class LinkLoader:
             raise ValueError("edge_label_index must be a 2 x N tensor")
         n = self.__eli.shape[1]
         self.__label = None if edge_label is None else torch.as_tensor(edge_label).to(dev)
+        self.__time = None if edge_label_time is None else torch.as_tensor(edge_label_time).to(dev).long()
+        if getattr(link_sampler, "temporal", False) and self.__time is None:
+            raise ValueError("temporal link sampling needs edge_label_time")
         self.__input_id = torch.arange(n, device=dev) if input_id is None else torch.as_tensor(input_id).to(dev)
         if n < batch_size and drop_last:
             raise ValueError("The number of input edges is less than the batch size and drop_last is True.")
@@ -122,8 +130,13 @@ class LinkLoader:
             # first-appearance dedup + inverse map = renumbering with no targets
             uniq, inverse = graph_ops.append_unique(ends[:0].contiguous(), ends.contiguous(),
                                                     need_neighbor_raw_to_unique=True)
+            seed_time = None
+            if self.__sampler.temporal:
+                reps = ends.numel() // max(n_pos, 1)   # every endpoint of seed edge i (and its negatives) starts at time i
+                seed_time = _first_occurrence(inverse.long(), self.__time[ix].repeat(reps)[:ends.numel()], uniq.numel())
             node, row, col, edge, nn, ne = neighbor_sample(graph, uniq, self.__sampler.fanout, seed + b,
-                                                           self.__sampler.biased, self.__sampler.disjoint)
+                                                           self.__sampler.biased, self.__sampler.disjoint, seed_time,
+                                                           self.__sampler.temporal_comparison)
             data = filter_store(fs, gs, node, row, col, edge)
             data.n_id, data.e_id = node, edge
             data.num_sampled_nodes, data.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)
@@ -178,7 +191,18 @@ class LinkLoader:
                 ud, inv_dst = graph_ops.append_unique(empty, dst_all.contiguous(), need_neighbor_raw_to_unique=True)
                 seeds = {src_t: us, dst_t: ud}
                 inv_src, inv_dst = inv_src.long(), inv_dst.long()
-            node, row, col, edge, nn, ne = hetero_neighbor_sample(smp.graphs, None, seeds, smp.fanout, seed + b, smp.biased)
+            seed_time = None
+            if smp.temporal:
+                t_src = self.__time[ix].repeat(max(src_all.numel() // max(n_pos, 1), 1))[:src_all.numel()]
+                t_dst = self.__time[ix].repeat(max(dst_all.numel() // max(n_pos, 1), 1))[:dst_all.numel()]
+                if src_t == dst_t:
+                    seed_time = {src_t: _first_occurrence(torch.cat([inv_src, inv_dst]), torch.cat([t_src, t_dst]),
+                                                          seeds[src_t].numel())}
+                else:
+                    seed_time = {src_t: _first_occurrence(inv_src, t_src, seeds[src_t].numel()),
+                                 dst_t: _first_occurrence(inv_dst, t_dst, seeds[dst_t].numel())}
+            node, row, col, edge, nn, ne = hetero_neighbor_sample(smp.graphs, None, seeds, smp.fanout, seed + b, smp.biased,
+                                                                  seed_time, smp.temporal_comparison)
             out = HeteroSamplerOutput(node=node, row=row, col=col, edge=edge,
                                       batch={t: node[t][:v.numel()] for t, v in seeds.items()},
                                       num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
@@ -210,21 +234,23 @@ class LinkNeighborLoader(LinkLoader):
                  time_attr: Optional[str] = None, weight_attr: Optional[str] = None, transform=None,
                  transform_sampler_output=None, is_sorted: bool = False, filter_per_worker=None,
                  neighbor_sampler=None, directed: bool = True, batch_size: int = 16, compression=None,
-                 local_seeds_per_call=None, **kwargs):
+                 local_seeds_per_call=None, temporal_comparison: Optional[str] = None, **kwargs):
         if getattr(subgraph_type, "value", subgraph_type) != "directional" or not directed:
             raise ValueError("Only directional subgraphs are currently supported")
         if neighbor_sampler is not None:
             raise ValueError("Passing a neighbor sampler is currently unsupported")
-        if time_attr is not None:
-            raise NotImplementedError("temporal sampling is not implemented")
         if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
         feature_store, graph_store = data
+        is_temporal = time_attr is not None
+        if is_temporal:
+            graph_store._set_time_attr((feature_store, time_attr))
         if weight_attr is not None:
             graph_store._set_weight_attr((feature_store, weight_attr))
         if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
             sampler = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
-                                      with_replacement=replace, disjoint=disjoint)
+                                      with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
+                                      temporal_comparison=temporal_comparison)
         else:
             etypes = [a.edge_type for a in graph_store.get_all_edge_attrs()]
             if not isinstance(num_neighbors, dict):
@@ -233,7 +259,8 @@ class LinkNeighborLoader(LinkLoader):
             if unknown:
                 raise ValueError(f"fan-out given for unknown edge types: {unknown}")
             sampler = HeteroNeighborSampler(graph_store._hetero_graphs, num_neighbors, biased=(weight_attr is not None),
-                                            with_replacement=replace, disjoint=disjoint)
+                                            with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
+                                            temporal_comparison=temporal_comparison)
         super().__init__((feature_store, graph_store), sampler, edge_label_index=edge_label_index,
                          edge_label=edge_label, edge_label_time=edge_label_time, neg_sampling=neg_sampling,
                          neg_sampling_ratio=neg_sampling_ratio, transform=transform,

@@ -34,13 +34,23 @@ class NeighborLoader(NodeLoader):
         feature_store, graph_store = data
         if compression is not None and compression not in ["CSR", "COO"]:
             raise ValueError("Invalid value for compression (expected 'CSR' or 'COO')")
-        if time_attr is not None:
-            raise NotImplementedError("temporal sampling is not implemented yet (SURVEY.md §8(f) rank 2)")
+        is_temporal = time_attr is not None
+        if is_temporal:
+            # edge timestamps come from the feature store; seeds without input_time take their node's timestamp
+            # (neighbor_loader.py:173-187)
+            graph_store._set_time_attr((feature_store, time_attr))
+            if input_time is None:
+                if isinstance(input_nodes, (tuple, list)) and len(input_nodes) == 2 and isinstance(input_nodes[0], str):
+                    in_type, in_nodes = input_nodes
+                else:
+                    in_type, in_nodes = sorted(graph_store._num_vertices().keys())[0], input_nodes
+                input_time = feature_store[in_type, time_attr, None][in_nodes]
         if weight_attr is not None:
             graph_store._set_weight_attr((feature_store, weight_attr))
         if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
             core = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
-                                   with_replacement=replace, disjoint=disjoint, heterogeneous=False, temporal=False,
+                                   with_replacement=replace, disjoint=disjoint, heterogeneous=False,
+                                   temporal=is_temporal, temporal_comparison=temporal_comparison,
                                    local_seeds_per_call=local_seeds_per_call)
         else:
             if compression is not None and compression != "COO":
@@ -52,7 +62,8 @@ class NeighborLoader(NodeLoader):
             if unknown:
                 raise ValueError(f"fan-out given for unknown edge types: {unknown}")
             core = HeteroNeighborSampler(graph_store._hetero_graphs, num_neighbors, biased=(weight_attr is not None),
-                                         with_replacement=replace, disjoint=disjoint, temporal=False)
+                                         with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
+                                         temporal_comparison=temporal_comparison)
         sampler = BaseSampler(core, (feature_store, graph_store), batch_size=batch_size)
         super().__init__((feature_store, graph_store), sampler, input_nodes=input_nodes, input_time=input_time,
                          transform=transform, transform_sampler_output=transform_sampler_output,

@@ -59,7 +59,8 @@ class NodeLoader:
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         self.__input_data = NodeSamplerInput(
             input_id=torch.arange(len(input_nodes), dtype=torch.int64, device=dev) if input_id is None else input_id,
-            node=input_nodes.to(dev), time=input_time, input_type=input_type)
+            node=input_nodes.to(dev), time=None if input_time is None else torch.as_tensor(input_time).to(dev),
+            input_type=input_type)
         self.__data, self.__node_sampler = data, node_sampler
         self.__batch_size, self.__shuffle, self.__drop_last = batch_size, shuffle, drop_last
         self.__random_state = random_state

@@ -35,8 +35,52 @@ def hop_seed(random_state: int, hop: int) -> int:
     return (int(random_state) + hop * _GOLDEN) & _MASK
 
 
+_TEMPORAL_OK = {
+    # candidate edge (time t_e) of a vertex reached at time t_v qualifies when ...
+    "strictly_increasing": lambda te, tv: te > tv,
+    "monotonically_increasing": lambda te, tv: te >= tv,
+    "strictly_decreasing": lambda te, tv: te < tv,
+    "monotonically_decreasing": lambda te, tv: te <= tv,
+}
+
+
+def _temporal_hop(graph: CSRGraph, frontier, frontier_time, fan, seed, biased, comparison):
+    """One hop restricted to the edges whose timestamp passes ``comparison`` against the time at which their
+    frontier vertex was reached (seeds: the input time; later vertices: the time of the edge that discovered them —
+    the walk semantics the reference's tests pin, tests/loader/test_neighbor_loader.py:946-1057).  Runs on the
+    weighted kernel: the qualifying candidates get weight w (or 1), the others 0, A-Res then draws ``fan`` of the
+    qualifying ones without replacement and zero-weight picks (rows with fewer than ``fan`` qualifying edges) are
+    dropped.  The effective-weight scratch is a persistent zero array touched only at the frontier's CSR ranges."""
+    if comparison not in _TEMPORAL_OK:
+        raise ValueError(f"unknown temporal_comparison {comparison!r}; expected one of {sorted(_TEMPORAL_OK)}")
+    dev = graph.col.device
+    scratch = getattr(graph, "_temporal_scratch", None)
+    if scratch is None or scratch.shape[0] != graph.col.shape[0]:
+        scratch = torch.zeros(graph.col.shape[0], dtype=torch.float32, device=dev)
+        graph._temporal_scratch = scratch
+    f = frontier.long()
+    start = graph.row_ptr[f]
+    deg = graph.row_ptr[f + 1] - start
+    total = int(deg.sum())
+    if total == 0:
+        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        return frontier[:0], z.int(), z
+    first = torch.cumsum(deg, 0) - deg
+    pos = torch.repeat_interleave(start - first, deg, output_size=total) + torch.arange(total, device=dev)
+    t_v = torch.repeat_interleave(frontier_time.to(dev).long(), deg, output_size=total)
+    ok = _TEMPORAL_OK[comparison](graph.time[pos], t_v)
+    scratch[pos] = ok.float() * (graph.weight[pos] if biased else 1.0)
+    try:
+        off, nbr, lid, gid = wholegraph_ops.weighted_sample_without_replacement(
+            graph.row_ptr, graph.col, scratch, frontier, int(fan), seed, True, True)
+        keep = scratch[gid] > 0
+    finally:
+        scratch[pos] = 0
+    return nbr[keep], lid[keep], gid[keep]
+
+
 def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int], random_state: int,
-                    biased: bool = False, disjoint: bool = False):
+                    biased: bool = False, disjoint: bool = False, seed_time=None, temporal_comparison=None):
     """One mini-batch.  Returns (node, row, col, edge, num_sampled_nodes, num_sampled_edges).
 
     ``disjoint``: every seed grows its own tree and a vertex belongs to at most ONE tree of the batch — the tree of
@@ -47,6 +91,8 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
     seeds = seeds.to(device=graph.row_ptr.device, dtype=graph.col.dtype)
     nodes = seeds
     tree = torch.arange(seeds.shape[0], device=seeds.device) if disjoint else None   # tree id of every node
+    temporal = seed_time is not None
+    node_time = seed_time.to(seeds.device).long() if temporal else None               # time every node was reached at
     frontier, f_start = seeds, 0
     rows, cols, edges = [], [], []
     num_nodes, num_edges = [int(seeds.shape[0])], []
@@ -55,7 +101,10 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
             num_edges.append(0)
             num_nodes.append(0)
             continue
-        if biased:
+        if temporal:
+            nbr, lid, gid = _temporal_hop(graph, frontier, node_time[f_start:f_start + frontier.shape[0]], fan,
+                                          hop_seed(random_state, k), biased, temporal_comparison)
+        elif biased:
             off, nbr, lid, gid = wholegraph_ops.weighted_sample_without_replacement(
                 graph.row_ptr, graph.col, graph.weight, frontier, int(fan), hop_seed(random_state, k), True, True)
             # libcugraph's biased sampling never returns a zero-weight edge, even when the row is
@@ -70,17 +119,19 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
         new_nodes, mapping = graph_ops.append_unique(nodes, nbr, need_neighbor_raw_to_unique=True)
         mapping = mapping.long()
         src_row = lid.long() + f_start
+        n_old, n_new = int(nodes.shape[0]), int(new_nodes.shape[0])
+        if (disjoint or temporal) and n_new > n_old:
+            # the FIRST edge that reaches a new vertex decides its tree (disjoint) and its time (temporal)
+            e_ids = torch.arange(mapping.shape[0], device=mapping.device)
+            first = torch.full((n_new - n_old,), mapping.shape[0], dtype=torch.int64, device=mapping.device)
+            is_new = mapping >= n_old
+            first.scatter_reduce_(0, mapping[is_new] - n_old, e_ids[is_new], reduce="amin")
+            if temporal:
+                node_time = torch.cat([node_time, graph.time[gid[first]]])
+            if disjoint:
+                tree = torch.cat([tree, tree[src_row][first]])
         if disjoint and nbr.shape[0] > 0:
-            n_old, n_new = int(nodes.shape[0]), int(new_nodes.shape[0])
-            edge_tree = tree[src_row]
-            if n_new > n_old:
-                # a new vertex joins the tree of the FIRST edge that reaches it
-                e_ids = torch.arange(mapping.shape[0], device=mapping.device)
-                first = torch.full((n_new - n_old,), mapping.shape[0], dtype=torch.int64, device=mapping.device)
-                is_new = mapping >= n_old
-                first.scatter_reduce_(0, mapping[is_new] - n_old, e_ids[is_new], reduce="amin")
-                tree = torch.cat([tree, edge_tree[first]])
-            keep = tree[mapping] == edge_tree
+            keep = tree[mapping] == tree[src_row]
             mapping, src_row, gid, nbr = mapping[keep], src_row[keep], gid[keep], nbr[keep]
         rows.append(mapping)
         cols.append(src_row)
@@ -109,7 +160,8 @@ def _one_hop(graph: CSRGraph, frontier, fan, seed, biased):
     return nbr, lid, gid
 
 
-def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, biased: bool = False):
+def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, biased: bool = False,
+                           seed_time=None, temporal_comparison=None):
     """Heterogeneous PyG-style sampling: per hop, for every edge type (src_t, rel, dst_t) in sorted
     order, the frontier vertices of type ``dst_t`` draw up to ``fanout[etype][hop]`` in-neighbours of
     type ``src_t``; vertices first seen during a hop form the next hop's frontier of their type.
@@ -128,6 +180,11 @@ def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, 
     node = {t: empty() for t in ntypes}
     for t, ids in seed_dict.items():
         node[t] = ids.to(device=dev, dtype=torch.int64)
+    temporal = seed_time is not None
+    if temporal:   # seed_time: tensor (single seed type) or {type: tensor}
+        st = seed_time if isinstance(seed_time, dict) else {next(iter(seed_dict)): seed_time}
+        node_time = {t: (st[t].to(dev).long() if t in st else torch.zeros(0, dtype=torch.int64, device=dev))
+                     for t in ntypes}
     frontier_start = {t: 0 for t in ntypes}                  # first row of the current frontier in node[t]
     n_hops = len(next(iter(fanout.values())))
     rows = {et: [] for et in etypes}
@@ -144,8 +201,20 @@ def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, 
             if fan == 0 or frontier.shape[0] == 0:
                 num_edges[et].append(0)
                 continue
-            nbr, lid, gid = _one_hop(graphs[et], frontier, fan, hop_seed(random_state, h * len(etypes) + ti), biased)
+            if temporal:
+                nbr, lid, gid = _temporal_hop(graphs[et], frontier, node_time[dst_t][frontier_start[dst_t]:hop_begin[dst_t]],
+                                              fan, hop_seed(random_state, h * len(etypes) + ti), biased,
+                                              temporal_comparison)
+            else:
+                nbr, lid, gid = _one_hop(graphs[et], frontier, fan, hop_seed(random_state, h * len(etypes) + ti), biased)
+            n_old = int(node[src_t].shape[0])
             new_nodes, mapping = graph_ops.append_unique(node[src_t], nbr, need_neighbor_raw_to_unique=True)
+            if temporal and new_nodes.shape[0] > n_old:
+                m = mapping.long()
+                first = torch.full((new_nodes.shape[0] - n_old,), m.shape[0], dtype=torch.int64, device=dev)
+                is_new = m >= n_old
+                first.scatter_reduce_(0, m[is_new] - n_old, torch.arange(m.shape[0], device=dev)[is_new], reduce="amin")
+                node_time[src_t] = torch.cat([node_time[src_t], graphs[et].time[gid[first]]])
             node[src_t] = new_nodes
             rows[et].append(mapping.long())
             cols[et].append(lid.long() + frontier_start[dst_t])
@@ -163,9 +232,14 @@ class HeteroNeighborSampler:
     """Heterogeneous counterpart of ``NeighborSampler`` (per-edge-type CSRs, dict fan-out)."""
 
     def __init__(self, graphs, fanout, biased: bool = False, with_replacement: bool = False,
-                 disjoint: bool = False, temporal: bool = False, **_ignored):
-        if with_replacement or disjoint or temporal:
-            raise NotImplementedError("with_replacement / disjoint / temporal sampling are not implemented")
+                 disjoint: bool = False, temporal: bool = False, temporal_comparison: Optional[str] = None,
+                 **_ignored):
+        if with_replacement or disjoint:
+            raise NotImplementedError("heterogeneous with_replacement / disjoint sampling are not implemented")
+        if temporal and any(g.time is None for g in graphs.values()):
+            raise ValueError("temporal sampling needs a time attribute on every edge type (time_attr=...)")
+        self.temporal = bool(temporal)
+        self.temporal_comparison = temporal_comparison or "monotonically_decreasing"
         n_hops = {len(v) for v in fanout.values()}
         if len(n_hops) != 1:
             raise ValueError("every edge type needs the same number of hops")
@@ -173,10 +247,13 @@ class HeteroNeighborSampler:
             raise ValueError("biased sampling needs a weight attribute on every edge type")
         self.graphs, self.fanout, self.biased = graphs, {k: [int(f) for f in v] for k, v in fanout.items()}, biased
 
-    def sample_batches(self, seed_type, seeds, batch_size, random_state):
+    def sample_batches(self, seed_type, seeds, batch_size, random_state, seed_time=None):
+        if self.temporal and seed_time is None:
+            raise ValueError("temporal sampling needs input_time")
         for b, start in enumerate(range(0, seeds.shape[0], batch_size)):
-            yield b, hetero_neighbor_sample(self.graphs, seed_type, seeds[start:start + batch_size], self.fanout,
-                                            random_state + b, self.biased)
+            yield b, hetero_neighbor_sample(
+                self.graphs, seed_type, seeds[start:start + batch_size], self.fanout, random_state + b, self.biased,
+                seed_time[start:start + batch_size] if self.temporal else None, self.temporal_comparison)
 
 
 class NeighborSampler:
@@ -185,11 +262,16 @@ class NeighborSampler:
 
     def __init__(self, graph: CSRGraph, fanout: Sequence[int], biased: bool = False,
                  with_replacement: bool = False, disjoint: bool = False, heterogeneous: bool = False,
-                 temporal: bool = False, local_seeds_per_call: Optional[int] = None, **_ignored):
+                 temporal: bool = False, local_seeds_per_call: Optional[int] = None,
+                 temporal_comparison: Optional[str] = None, **_ignored):
         if with_replacement:
             raise NotImplementedError("sampling with replacement is not implemented (kernels sample without)")
-        if heterogeneous or temporal:
-            raise NotImplementedError("temporal sampling: SURVEY.md §8(f) 'next' (heterogeneous: HeteroNeighborSampler)")
+        if heterogeneous:
+            raise NotImplementedError("heterogeneous graphs go through HeteroNeighborSampler")
+        if temporal and graph.time is None:
+            raise ValueError("temporal sampling needs a time attribute (time_attr=...)")
+        self.temporal = bool(temporal)
+        self.temporal_comparison = temporal_comparison or "monotonically_decreasing"
         if biased and graph.weight is None:
             raise ValueError("biased sampling needs a weight attribute (weight_attr=...)")
         self.graph, self.fanout, self.biased, self.disjoint = graph, [int(f) for f in fanout], biased, bool(disjoint)
@@ -203,7 +285,7 @@ class NeighborSampler:
             self._walks[key] = PygNoSyncWalk(self.graph.row_ptr, self.graph.col, batch_size, self.fanout, n_batches)
         return self._walks[key]
 
-    def sample_batches(self, seeds: torch.Tensor, batch_size: int, random_state: int) -> Iterator:
+    def sample_batches(self, seeds: torch.Tensor, batch_size: int, random_state: int, seed_time=None) -> Iterator:
         """Yields ``(batch index, (node, row, col, edge, num_sampled_nodes, num_sampled_edges))``.
 
         Uniform sampling with positive fan-outs runs in CALL GROUPS (``local_seeds_per_call`` seeds per
@@ -212,7 +294,10 @@ class NeighborSampler:
         fan-out -1, the ragged last batch) goes through the one-batch-at-a-time C-ABI ops.  Both routes
         return identical results (tests/test_gpu_pyg_loader.py)."""
         n = seeds.shape[0]
-        fast = (not self.biased) and (not self.disjoint) and all(f > 0 for f in self.fanout) and seeds.is_cuda
+        if self.temporal and seed_time is None:
+            raise ValueError("temporal sampling needs input_time")
+        fast = (not self.biased) and (not self.disjoint) and (not self.temporal) and all(
+            f > 0 for f in self.fanout) and seeds.is_cuda
         n_full = n // batch_size if fast else 0
         per_call = self.local_seeds_per_call or 16 * batch_size
         G = max(1, per_call // batch_size)
@@ -228,7 +313,9 @@ class NeighborSampler:
             b += g
         for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
             yield bb, neighbor_sample(self.graph, seeds[start:start + batch_size], self.fanout, random_state + bb,
-                                      self.biased, self.disjoint)
+                                      self.biased, self.disjoint,
+                                      seed_time[start:start + batch_size] if self.temporal else None,
+                                      self.temporal_comparison)
 
 
 class BaseSampler:
@@ -245,22 +332,24 @@ class BaseSampler:
         bs = self.__batch_size
         if isinstance(self.__sampler, HeteroNeighborSampler):
             it = index.input_type
-            for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(it, nodes, bs, random_state):
+            for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(it, nodes, bs, random_state,
+                                                                                   seed_time=index.time):
                 n_seeds = nn[it][0]
                 ids = input_id[b * bs: b * bs + n_seeds]
                 yield HeteroSamplerOutput(
                     node=node, row=row, col=col, edge=edge, batch={it: node[it][:n_seeds]},
                     num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
                     num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()},
-                    metadata=((it, ids), None))
+                    metadata=((it, ids), None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
             return
-        for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(nodes, bs, random_state):
+        for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(nodes, bs, random_state,
+                                                                               seed_time=index.time):
             n_seeds = nn[0]
             ids = input_id[b * bs: b * bs + n_seeds]
             yield SamplerOutput(
                 node=node, row=row, col=col, edge=edge, batch=node[:n_seeds],
                 num_sampled_nodes=torch.tensor(nn), num_sampled_edges=torch.tensor(ne),
-                metadata=(ids, None))
+                metadata=(ids, None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
 
     def sample_from_edges(self, index, neg_sampling=None, **kwargs):
         raise NotImplementedError("link loaders / negative sampling: SURVEY.md §8(f) rank 1")

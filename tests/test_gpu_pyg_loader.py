@@ -527,3 +527,118 @@ def test_link_neighbor_loader_disjoint_reference_example(hiplib):
     li = batch_d.edge_label_index
     assert tuple(li.shape) == (2, 2) and li.min() >= 0 and li.max() < batch_d.n_id.numel()
     assert batch_d.n_id[li[0]].cpu().tolist() == [0, 2] and batch_d.n_id[li[1]].cpu().tolist() == [1, 3]
+
+
+def _temporal_stores(hetero):
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    src_cite, dst_cite, tme_cite = torch.tensor([3, 2, 1, 2]), torch.tensor([2, 1, 0, 0]), torch.tensor([0, 1, 2, 0])
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store[("paper", "cites", "paper"), "coo", False, (4, 4)] = [dst_cite, src_cite]
+    feature_store[("paper", "cites", "paper"), "time", None] = tme_cite
+    feature_store[("paper", "cites", "paper"), "bias", None] = torch.ones(4, device="cuda")
+    if hetero:
+        src_author = torch.tensor([3, 2, 2, 1, 3, 2, 0])
+        dst_author = torch.tensor([0, 0, 1, 1, 2, 2, 2])
+        graph_store[("author", "writes", "paper"), "coo", False, (3, 4)] = [dst_author, src_author]
+        feature_store[("author", "writes", "paper"), "time", None] = torch.tensor([0, 0, 1, 0, 2, 1, 1])
+        feature_store[("author", "writes", "paper"), "bias", None] = torch.ones(7, device="cuda")
+    return feature_store, graph_store
+
+
+@pytest.mark.parametrize("biased", [True, False])
+def test_neighbor_loader_temporal_simple(hiplib, biased):
+    # tests/loader/test_neighbor_loader.py:946-990: exact outputs of a strictly-increasing temporal walk
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    feature_store, graph_store = _temporal_stores(False)
+    loader = NeighborLoader((feature_store, graph_store), num_neighbors=[2, 2, 2], batch_size=1, input_nodes=torch.tensor([3]),
+                            input_time=torch.tensor([-1]), time_attr="time", shuffle=False,
+                            weight_attr="bias" if biased else None, temporal_comparison="strictly_increasing")
+    out = next(iter(loader))
+    assert out.n_id.tolist() == [3, 2, 1, 0]
+    assert out.e_id.tolist() == [0, 1, 2]
+    assert out.num_sampled_nodes.tolist() == [1, 1, 1, 1]
+    assert out.num_sampled_edges.tolist() == [1, 1, 1]
+    # the default comparison (monotonically_decreasing) from time 0 only follows edges with t <= previous
+    loader = NeighborLoader((feature_store, graph_store), num_neighbors=[2, 2, 2], batch_size=1, input_nodes=torch.tensor([3]),
+                            input_time=torch.tensor([0]), time_attr="time", shuffle=False)
+    out = next(iter(loader))
+    assert out.n_id.tolist() == [3, 2, 0] and out.e_id.tolist() == [0, 3]
+
+
+@pytest.mark.parametrize("biased", [True, False])
+def test_neighbor_loader_temporal_hetero(hiplib, biased):
+    # tests/loader/test_neighbor_loader.py:993-1057
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    feature_store, graph_store = _temporal_stores(True)
+    loader = NeighborLoader((feature_store, graph_store),
+                            num_neighbors={("paper", "cites", "paper"): [2, 2, 2], ("author", "writes", "paper"): [2, 2, 0]},
+                            batch_size=1, input_nodes=("paper", torch.tensor([3])), input_time=torch.tensor([-1]),
+                            time_attr="time", weight_attr="bias" if biased else None, shuffle=False,
+                            temporal_comparison="strictly_increasing")
+    out = next(iter(loader))
+    assert sorted(out["author"].n_id.tolist()) == [0, 1, 2]
+    assert out["paper"].n_id.tolist() == [3, 2, 1, 0]
+    assert sorted(out["author", "writes", "paper"].e_id.tolist()) == [0, 2, 4, 5]
+    assert out["author", "writes", "paper"].num_sampled_edges.tolist() == [2, 2, 0]
+
+
+@pytest.mark.parametrize("biased", [True, False])
+def test_link_neighbor_loader_temporal(hiplib, biased):
+    # tests/loader/test_neighbor_loader.py:1061-1176 (homogeneous and heterogeneous edge seeds)
+    import torch
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    feature_store, graph_store = _temporal_stores(False)
+    loader = LinkNeighborLoader((feature_store, graph_store), num_neighbors=[2, 2, 2], batch_size=1,
+                                edge_label_index=torch.tensor([[3], [3]]), edge_label_time=torch.tensor([-1]),
+                                time_attr="time", weight_attr="bias" if biased else None, shuffle=False,
+                                temporal_comparison="strictly_increasing")
+    assert next(iter(loader)).n_id.tolist() == [3, 2, 1, 0]
+    feature_store, graph_store = _temporal_stores(True)
+    loader = LinkNeighborLoader((feature_store, graph_store),
+                                num_neighbors={("paper", "cites", "paper"): [2, 2, 2], ("author", "writes", "paper"): [2, 2, 0]},
+                                batch_size=1, edge_label_index=(("author", "writes", "paper"), torch.tensor([[0], [3]])),
+                                edge_label_time=torch.tensor([-1]), time_attr="time",
+                                weight_attr="bias" if biased else None, shuffle=False,
+                                temporal_comparison="strictly_increasing")
+    out = next(iter(loader))
+    assert sorted(out["author"].n_id.tolist()) == [0, 1, 2]
+    assert out["paper"].n_id.tolist() == [3, 2, 1, 0]
+    assert sorted(out["author", "writes", "paper"].e_id.tolist()) == [0, 2, 4, 5]
+    assert out["author", "writes", "paper"].num_sampled_edges.tolist() == [2, 2, 0]
+
+
+def test_temporal_sampling_respects_fanout_and_order_on_random_graph(hiplib):
+    """Property check at a larger size: every sampled edge passes the comparison against the time its expanded vertex
+    was reached at, and no vertex takes more than fan-out edges per hop."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    g = torch.Generator().manual_seed(0)
+    V, E = 500, 6000
+    ei = torch.randint(0, V, (2, E), generator=g)
+    tm = torch.randint(0, 100, (E,), generator=g)
+    graph_store, feature_store = GraphStore(), FeatureStore()
+    graph_store[("n", "e", "n"), "coo", False, (V, V)] = ei
+    feature_store[("n", "e", "n"), "time", None] = tm
+    seeds = torch.arange(0, 64)
+    loader = NeighborLoader((feature_store, graph_store), num_neighbors=[4, 3], batch_size=8, input_nodes=seeds,
+                            input_time=torch.full((64,), 60), time_attr="time", shuffle=False, disjoint=True)
+    for batch in loader:
+        e = batch.e_id.cpu()
+        loc = batch.edge_index.cpu()
+        n_id = batch.n_id.cpu()
+        assert (ei[0][e] == n_id[loc[0]]).all() and (ei[1][e] == n_id[loc[1]]).all()
+        reached = torch.full((n_id.numel(),), -1)
+        reached[: batch.batch_size] = 60
+        off = 0
+        for hop, cnt in enumerate(batch.num_sampled_edges.tolist()):
+            rows, cols, ts = loc[0, off:off + cnt], loc[1, off:off + cnt], tm[e[off:off + cnt]]
+            assert (reached[cols] >= 0).all() and (ts <= reached[cols]).all()          # monotonically decreasing
+            assert torch.bincount(cols).max() <= [4, 3][hop]
+            for r, t in zip(rows.tolist(), ts.tolist()):                              # first edge decides the time
+                if reached[r] < 0:
+                    reached[r] = t
+            off += cnt
