@@ -86,12 +86,14 @@ def main():
             frontier = uniq
     # ---- a4: weighted sampling ---------------------------------------------------------------------------------
     outw = wholegraph_ops.weighted_sample_without_replacement(row_ptr, col, weight, frontier, 10, random_seed=62)
-    deg_sum = int((row_ptr[frontier + 1] - row_ptr[frontier]).sum())
+    fdeg = row_ptr[frontier + 1] - row_ptr[frontier]
+    deg_sum = int(fdeg.sum())
     t = timed(lambda: wholegraph_ops.weighted_sample_without_replacement(row_ptr, col, weight, frontier, 10, random_seed=62),
               iters=10)
     add("weighted_sample hop2 M=10", "wholegraph_op.h:61-73", t,
         frontier.shape[0] * (b + 16 + 4) + deg_sum * 4 + outw[1].shape[0] * (2 * b + 4), outw[1].shape[0], "edges",
-        "reads every candidate weight (Σdeg = %d) to key it" % deg_sum)
+        "reads every candidate weight (Σdeg = %d) to key it; %d rows > 1024 candidates (Σ = %d, max %d)"
+        % (deg_sum, int((fdeg > 1024).sum()), int(fdeg[fdeg > 1024].sum()), int(fdeg.max())))
     # ---- a7: renumber --------------------------------------------------------------------------------------------
     hop2 = wholegraph_ops.unweighted_sample_without_replacement(row_ptr, col, frontier, 10, random_seed=63)
     T, Eh = frontier.shape[0], hop2[1].shape[0]

@@ -93,24 +93,31 @@ struct Pcg32 {
     skipahead(subsequence);
   }
 
-  // Same generator as Pcg32(seed, subsequence) for 0 <= subsequence < 2^31, via the jump tables.
+  // jump ahead by n < 2^32 draws with the tables (at most 4 lookups, 3 compositions)
+  __device__ __forceinline__ void jump_table(uint32_t n)
+  {
+    PcgJump j = g_pcg_jump.t[0][n & 255u];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const uint32_t c = (n >> (8 * k)) & 255u;
+      if (c) {
+        const PcgJump m = g_pcg_jump.t[k][c];
+        j.s             = j.s * m.a + m.s;
+        j.a             = j.a * m.a;
+      }
+    }
+    state = j.a * state + inc * j.s;
+  }
+
+  // Same generator as Pcg32(seed, subsequence) for 0 <= subsequence < 2^31, via the jump tables; `extra_draws`
+  // (< 2^31) positions it that many draws further along its stream in the same jump.
   struct table_tag {};
-  __device__ __forceinline__ Pcg32(uint64_t seed, uint32_t subsequence, table_tag)
+  __device__ __forceinline__ Pcg32(uint64_t seed, uint32_t subsequence, table_tag, uint32_t extra_draws = 0)
   {
     inc   = ((uint64_t)subsequence << 1u) | 1u;
     // two plain steps from state 0 with `seed` added in between:  ((0*A + inc) + seed)*A + inc
     state = (inc + seed) * kMult + inc;
-    PcgJump j = g_pcg_jump.t[0][subsequence & 255u];
-#pragma unroll
-    for (int k = 1; k < 4; k++) {
-      const uint32_t c = (subsequence >> (8 * k)) & 255u;
-      if (c) {
-        const PcgJump n = g_pcg_jump.t[k][c];
-        j.s             = j.s * n.a + n.s;
-        j.a             = j.a * n.a;
-      }
-    }
-    state = j.a * state + inc * j.s;
+    jump_table(subsequence + extra_draws);
   }
 
   __host__ __device__ __forceinline__ int32_t next_i31() { return (int32_t)(next_u32() & 0x7fffffffu); }

@@ -60,6 +60,15 @@ __device__ __forceinline__ uint64_t stream_id(int64_t seed_index, int B, int lan
   return (uint64_t)(int64_t)(int32_t)(seed_index * B + lane);
 }
 
+// generator of stream seed_index*B + lane: table jump for indices below 2^31, the generic loop (with the reference's
+// sign extension of the 32-bit index) beyond
+__device__ __forceinline__ Pcg32 stream_generator(uint64_t random_seed, int64_t seed_index, int B, int lane)
+{
+  const int64_t sid = seed_index * B + lane;
+  if (sid < (1ll << 31)) return Pcg32(random_seed, (uint32_t)sid, Pcg32::table_tag{});
+  return Pcg32(random_seed, stream_id(seed_index, B, lane));
+}
+
 // ------------------------------------------------------------------------------------------
 template <typename SeedT>
 __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __restrict__ row_ptr,
@@ -67,7 +76,10 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
                                                            dev_count n_,
                                                            int M,
                                                            int* __restrict__ cnt,
-                                                           int* __restrict__ big_deg /*nullable*/)
+                                                           int* __restrict__ big_deg /*nullable*/,
+                                                           int big_threshold = 0,
+                                                           int* __restrict__ big_list = nullptr,
+                                                           int* __restrict__ big_count = nullptr)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_.host) return;
@@ -81,7 +93,10 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
   int64_t nid = (int64_t)seeds[i];
   int deg     = (int)(row_ptr[nid + 1] - row_ptr[nid]);
   cnt[i]      = (M > 0 && deg > M) ? M : deg;
-  if (big_deg) big_deg[i] = (M > 0 && deg > M) ? deg : 0;  // rows that need key scratch (weighted)
+  // weighted: rows longer than the one-wave kernel holds in registers need key scratch + the workgroup kernel
+  const bool big = M > 0 && deg > M && deg > big_threshold;
+  if (big_deg) big_deg[i] = big ? deg : 0;
+  if (big && big_list) big_list[atomicAdd(big_count, 1)] = i;
 }
 
 template <typename ColT>
@@ -310,6 +325,8 @@ __device__ __forceinline__ float ares_key(float w, Pcg32& g)
   return (log1pf(u) / logf(2.0f)) * (1.0f / w);
 }
 
+constexpr int kWaveRowCap = 1024;  // rows the one-wave weighted kernel keeps in registers (16 keys per lane)
+
 // order-preserving float -> uint (larger key <=> larger uint)
 __device__ __forceinline__ uint32_t key_bits(float k)
 {
@@ -317,10 +334,17 @@ __device__ __forceinline__ uint32_t key_bits(float k)
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-// One workgroup per seed with deg > M: keys into scratch, exact top-M via radix select, emitted
-// in CSR order (ties on the threshold key: lowest neighbour index first).
-template <typename SeedT, typename ColT, typename WeightT, int B>
-__global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __restrict__ row_ptr,
+// One workgroup per seed with deg > M: keys, exact top-M via radix select, emitted in CSR order (ties on the threshold
+// key: lowest neighbour index first).  B = the reference's stream layout (lane j of its B-thread block owns neighbours
+// j, j+B, ... and draws their keys one after the other from stream seed*B+j); T >= B = threads really used.  With
+// T > B thread t starts at neighbour t — stream t % B positioned 3*(t/B) draws in (one key = 3 draws unless a 64-bit
+// draw comes back 0, probability 2^-64) — and hops T/B keys at a time with a table jump, so a 100k-candidate row is
+// keyed by 1024 threads instead of 128.  A thread that does see a zero draw raises a flag and the row is redone the
+// sequential way, which keeps the result exact.  Keys live in LDS when the row fits (kLdsKeys), else in scratch.
+constexpr int kLdsKeys = 12288;  // 48 KB of the 64 KB static LDS a workgroup may declare
+
+template <typename SeedT, typename ColT, typename WeightT, int B, int T>
+__global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __restrict__ row_ptr,
                                                             const ColT* __restrict__ col,
                                                             const WeightT* __restrict__ weight,
                                                             const SeedT* __restrict__ seeds,
@@ -332,12 +356,15 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
                                                             uint32_t* __restrict__ key_scratch,
                                                             ColT* __restrict__ dst,
                                                             int* __restrict__ src_lid,
-                                                            int64_t* __restrict__ edge_gid)
+                                                            int64_t* __restrict__ edge_gid,
+                                                            const int* __restrict__ seed_list /*nullable*/)
 {
+  static_assert(T % B == 0 && T % 64 == 0, "threads must be a multiple of the stream layout and of the wave");
+  __shared__ uint32_t lds_keys[kLdsKeys];
   __shared__ int hist[256];
-  __shared__ int sh_digit, sh_need;
-  __shared__ int wave_cnt[2][B / 64];
-  const int i = blockIdx.x;
+  __shared__ int sh_digit, sh_need, sh_redo;
+  __shared__ int wave_cnt[2][T / 64];
+  const int i = seed_list ? seed_list[blockIdx.x] : (int)blockIdx.x;
   if (i >= n) return;
   const int64_t nid   = (int64_t)seeds[i];
   const int64_t start = row_ptr[nid];
@@ -345,37 +372,89 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
   if (N <= 0) return;
   const int64_t base = offsets[i];
   if (M <= 0 || N <= M) {
-    for (int j = threadIdx.x; j < N; j += B)
+    for (int j = threadIdx.x; j < N; j += T)
       emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
     return;
   }
-  uint32_t* keys = key_scratch + key_offsets[i];
+  const bool in_lds = N <= kLdsKeys;
+  uint32_t* gkeys   = key_scratch + key_offsets[i];
+  // keys written to global scratch are re-read by other lanes of this workgroup, and neighbouring workgroups' key
+  // segments share cache lines: those re-reads are device-scope loads so they never hit a stale line in this CU's L1
+  auto put = [&](int id, uint32_t k) { if (in_lds) lds_keys[id] = k; else gkeys[id] = k; };
+  auto get = [&](int id) -> uint32_t {
+    return in_lds ? lds_keys[id] : __hip_atomic_load(gkeys + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (threadIdx.x == 0) sh_redo = 0;
+  __syncthreads();
   {
-    Pcg32 g(random_seed, stream_id(i, B, threadIdx.x));
-    for (int id = threadIdx.x; id < N; id += B) keys[id] = key_bits(ares_key((float)weight[start + id], g));
+    constexpr int hop = T / B;  // keys of one stream between two keys of the same thread
+    const int lane = threadIdx.x % B, first_key = threadIdx.x / B;
+    const int64_t sid = (int64_t)i * B + lane;
+    Pcg32 g = (sid < (1ll << 31)) ? Pcg32(random_seed, (uint32_t)sid, Pcg32::table_tag{}, 3u * (uint32_t)first_key)
+                                  : Pcg32(random_seed, stream_id(i, B, lane));
+    if (hop > 1 && sid >= (1ll << 31)) g.skipahead(3u * (uint64_t)first_key);
+    bool redrawn = false;
+    for (int id = threadIdx.x; id < N; id += T) {
+      const uint64_t before = g.state;
+      put(id, key_bits(ares_key((float)weight[start + id], g)));
+      if (hop > 1) {
+        // exactly three draws? (state after 3 steps is a fixed affine map of the state before)
+        Pcg32 chk = g;
+        chk.state = before;
+        chk.jump_table(3u);
+        redrawn |= chk.state != g.state;
+        g.jump_table(3u * (uint32_t)(hop - 1));
+      }
+    }
+    if (redrawn) sh_redo = 1;
   }
   __syncthreads();
-  // keys[] are written and re-read by different lanes of the same workgroup through global memory,
-  // and neighbouring workgroups' key segments share cache lines: the re-reads below are
-  // device-scope loads so they never hit a stale line in this CU's L1.
+  if (T > B && sh_redo) {  // a 64-bit draw was 0 somewhere: redo the row with the sequential stream walk
+    if (threadIdx.x < B) {
+      Pcg32 g = stream_generator(random_seed, i, B, threadIdx.x);
+      for (int id = threadIdx.x; id < N; id += B) put(id, key_bits(ares_key((float)weight[start + id], g)));
+    }
+    __syncthreads();
+  }
   uint32_t prefix = 0, prefix_mask = 0;
   int need = M;  // how many keys we still have to take among those matching `prefix`
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int h = threadIdx.x; h < 256; h += B) hist[h] = 0;
+    for (int h = threadIdx.x; h < 256; h += T) hist[h] = 0;
     __syncthreads();
-    for (int id = threadIdx.x; id < N; id += B) {
-      uint32_t k = __hip_atomic_load(keys + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int id = threadIdx.x; id < N; id += T) {
+      uint32_t k = get(id);
       if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, d = 255;
-      for (; d > 0; d--) {
-        if (acc + hist[d] >= need) break;
-        acc += hist[d];
+    if (threadIdx.x < 64) {
+      // highest digit d with  #(digits > d) < need <= #(digits >= d):  lane l owns bins 4l..4l+3, a suffix sum over
+      // the lanes finds the owning lane (exactly one: at least `need` keys match the prefix), which scans its 4 bins
+      const int l  = threadIdx.x;
+      const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+      const int own = h0 + h1 + h2 + h3;
+      int inc = own;
+      for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_down(inc, off);
+        if (l + off < 64) inc += v;
       }
-      sh_digit = d;
-      sh_need  = need - acc;
+      int acc = inc - own;  // keys in the bins of higher lanes
+      if (acc < need && need <= inc) {
+        int d = 4 * l + 3;
+        if (acc + h3 < need) {
+          acc += h3;
+          d = 4 * l + 2;
+          if (acc + h2 < need) {
+            acc += h2;
+            d = 4 * l + 1;
+            if (acc + h1 < need) {
+              acc += h1;
+              d = 4 * l;
+            }
+          }
+        }
+        sh_digit = d;
+        sh_need  = need - acc;
+      }
     }
     __syncthreads();
     prefix |= (uint32_t)sh_digit << shift;
@@ -387,9 +466,9 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
   const uint32_t thr = prefix;
   int out_run = 0, tie_run = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int chunk = 0; chunk < N; chunk += B) {
+  for (int chunk = 0; chunk < N; chunk += T) {
     int id     = chunk + threadIdx.x;
-    uint32_t k = id < N ? __hip_atomic_load(keys + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t k = id < N ? get(id) : 0u;
     bool gt    = id < N && k > thr;
     bool eq    = id < N && k == thr;
     uint64_t meq = __ballot(eq);
@@ -397,7 +476,7 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
     if (lane == 0) wave_cnt[1][wave] = __popcll(meq);
     __syncthreads();
     int eq_before = tie_run + eq_before_in_wave, eq_total = 0;
-    for (int w = 0; w < B / 64; w++) {
+    for (int w = 0; w < T / 64; w++) {
       if (w < wave) eq_before += wave_cnt[1][w];
       eq_total += wave_cnt[1][w];
     }
@@ -407,7 +486,7 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
     if (lane == 0) wave_cnt[0][wave] = __popcll(mtake);
     __syncthreads();
     int before = out_run + before_in_wave, total = 0;
-    for (int w = 0; w < B / 64; w++) {
+    for (int w = 0; w < T / 64; w++) {
       if (w < wave) before += wave_cnt[0][w];
       total += wave_cnt[0][w];
     }
@@ -415,6 +494,81 @@ __global__ void __launch_bounds__(B) sample_weighted_kernel(const int64_t* __res
     out_run += total;
     tie_run += eq_total;
     __syncthreads();
+  }
+}
+
+// One WAVE per seed for rows of up to 64*KMAX candidates (B = 128 stream layout, i.e. M <= 256): the keys stay in
+// registers (slot s of lane l = neighbour (s/2)*128 + (s%2)*64 + l, drawn from stream l or l+64 exactly as lane
+// l / l+64 of the reference's 128-thread block would), the M-th largest key is found by a bitwise binary search
+// whose counts are wave ballots, and the picks are emitted in CSR order with ballot prefix sums.  No LDS, no
+// scratch, no barrier: a seed costs one short dependency chain instead of ~10 workgroup barriers, which is what
+// bounded the workgroup kernel on mini-batch frontiers (hundreds of thousands of rows of ~100 candidates).
+template <typename SeedT, typename ColT, typename WeightT, int KMAX>
+__global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t* __restrict__ row_ptr,
+                                                                   const ColT* __restrict__ col,
+                                                                   const WeightT* __restrict__ weight,
+                                                                   const SeedT* __restrict__ seeds,
+                                                                   int n,
+                                                                   int M,
+                                                                   uint64_t random_seed,
+                                                                   const int* __restrict__ offsets,
+                                                                   ColT* __restrict__ dst,
+                                                                   int* __restrict__ src_lid,
+                                                                   int64_t* __restrict__ edge_gid)
+{
+  const int lane = threadIdx.x & 63;
+  const int i    = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  const int N         = (int)(row_ptr[nid + 1] - start);
+  if (N <= 0) return;
+  const int64_t base = offsets[i];
+  if (M <= 0 || N <= M) {
+    for (int j = lane; j < N; j += 64) emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
+    return;
+  }
+  if (N > 64 * KMAX) return;  // the workgroup kernel takes these (seed list built by the count kernel)
+  uint32_t k[KMAX];
+  {
+    Pcg32 ga = stream_generator(random_seed, i, 128, lane);
+    Pcg32 gb = ga;
+    if (N > 64) gb = stream_generator(random_seed, i, 128, lane + 64);
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) {
+      k[s] = 0u;  // below every real key (key_bits of any float, -inf and NaN included, is > 0)
+      if (s * 64 < N) {
+        const int id = (s >> 1) * 128 + (s & 1) * 64 + lane;
+        if (id < N) k[s] = key_bits(ares_key((float)weight[start + id], (s & 1) ? gb : ga));
+      }
+    }
+  }
+  uint32_t prefix = 0;
+  int need        = M;
+  for (int bit = 31; bit >= 0; bit--) {
+    const uint32_t cand = prefix | (1u << bit);
+    const uint32_t hi   = ~((1u << bit) - 1u);
+    int cnt             = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; s++)
+      if (s * 64 < N) cnt += __popcll(__ballot((k[s] & hi) == cand));
+    if (cnt >= need) prefix = cand; else need -= cnt;
+  }
+  // prefix == the M-th largest key: take every key above it and the first `need` equal to it (index order)
+  const uint64_t below = (1ull << lane) - 1ull;
+  int out_run = 0, tie_run = 0;
+#pragma unroll
+  for (int s = 0; s < KMAX; s++) {
+    if (s * 64 < N) {
+      const int id       = (s >> 1) * 128 + (s & 1) * 64 + lane;
+      const bool eq      = k[s] == prefix;  // prefix > 0, so an empty slot never matches
+      const uint64_t meq = __ballot(eq);
+      const bool take    = k[s] > prefix || (eq && tie_run + __popcll(meq & below) < need);
+      const uint64_t mt  = __ballot(take);
+      if (take) emit<ColT>(dst, src_lid, edge_gid, base + out_run + __popcll(mt & below), col[start + id], i, start + id);
+      out_run += __popcll(mt);
+      tie_run += __popcll(meq);
+    }
   }
 }
 
@@ -486,13 +640,26 @@ void run(const sample_args& a, bool weighted)
   int* offsets           = static_cast<int*>(tensor_data(a.out_offsets));
   const WeightT* weights = weighted ? static_cast<const WeightT*>(tensor_data(a.weight)) : nullptr;
 
-  temp_buffer cnt_buf(a.env), scan_tmp(a.env), big_buf(a.env);
+  temp_buffer cnt_buf(a.env), scan_tmp(a.env), big_buf(a.env), list_buf(a.env);
   int* cnt     = cnt_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT);
   int* stmp    = scan_tmp.device<int>(scan_tmp_ints(n + 1), WHOLEMEMORY_DT_INT);
   int* big_deg = (weighted && M > 0) ? big_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT) : nullptr;
-  int h_tot[2] = {0, 0};
+  // weighted, M <= 256: rows of up to kWaveRowCap candidates go to the one-wave kernel, the longer ones are listed
+  // (list[0] = count, list[1..] = seed indices) for the workgroup kernel
+  const bool wave_path = weighted && M > 0 && M <= 256;
+  int* big_list        = wave_path ? list_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT) : nullptr;
+  int h_tot[3]         = {0, 0, 0};
 
-  sample_count_enqueue(row_ptr, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M, cnt, big_deg, stream);
+  if (wave_path) {
+    WG_HIP_CHECK(hipMemsetAsync(big_list, 0, sizeof(int), stream));
+    if (n > 0)
+      sample_count_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(row_ptr, seeds, dev_count{n, nullptr}, M, cnt, big_deg,
+                                                                      kWaveRowCap, big_list + 1, big_list);
+    WG_HIP_CHECK(hipGetLastError());
+    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[2], big_list, sizeof(int), hipMemcpyDeviceToHost, stream));
+  } else {
+    sample_count_enqueue(row_ptr, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M, cnt, big_deg, stream);
+  }
   exclusive_scan_i32(cnt, offsets, n, stmp, stream);
   WG_HIP_CHECK(hipMemcpyAsync(&h_tot[0], offsets + n, sizeof(int), hipMemcpyDeviceToHost, stream));
   if (big_deg) {
@@ -510,12 +677,16 @@ void run(const sample_args& a, bool weighted)
   if (weighted) {
     temp_buffer key_buf(a.env);
     uint32_t* keys = key_buf.device<uint32_t>(h_tot[1], WHOLEMEMORY_DT_INT);
-    if (M > 256) {
-      sample_weighted_kernel<SeedT, ColT, WeightT, 256><<<n, 256, 0, stream>>>(
-        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid);
+    if (!wave_path) {  // M > 256 (256-thread stream layout) or sample-all
+      sample_weighted_kernel<SeedT, ColT, WeightT, 256, 256><<<n, 256, 0, stream>>>(
+        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid, nullptr);
     } else {
-      sample_weighted_kernel<SeedT, ColT, WeightT, 128><<<n, 128, 0, stream>>>(
-        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid);
+      // long rows first: their one-workgroup-per-row tail then drains while the one-wave kernel fills the GPU
+      if (h_tot[2] > 0)
+        sample_weighted_kernel<SeedT, ColT, WeightT, 128, 512><<<h_tot[2], 512, 0, stream>>>(
+          row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid, big_list + 1);
+      sample_weighted_wave_kernel<SeedT, ColT, WeightT, kWaveRowCap / 64><<<ceil_div(n, 4), 256, 0, stream>>>(
+        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, dst, lid, gid);
     }
     WG_HIP_CHECK(hipGetLastError());
     WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
