@@ -419,7 +419,7 @@ def main():
         if SPMM1 in stage_ms:
             spmm_gbps = kernels[SPMM1][1] / (stage_ms[SPMM1] * 1e-3) / 1e9
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only (rank 0 owns the host cores)
             nb = min(2048, order.numel() // BATCH)   # time-bounded inside cpu_baseline (--cpu-budget seconds)
             cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()  # same seed stream, one mini-batch at a time
             if V * FEAT_DIM * 4 > (8 << 30):
