@@ -44,11 +44,70 @@ def timed(fn, iters=20, warm=3, events=False):
     return (time.perf_counter() - t0) / iters
 
 
+def hetero_section(dev):
+    """BASELINE configs[4] shape: ogbn-mag-like heterogeneous graph (4 node types, 4 relations + 2 reverse), 2-hop
+    fan-out [25, 10] per edge type, batch 1024, sampled in call groups of 32 mini-batches; then GATConv (4 heads x 64)
+    over the sampled author-writes-paper relation of one call group."""
+    import numpy as np
+    from cugraph_pyg_amd.data import GraphStore
+    from cugraph_pyg_amd.sampler.sampler import HeteroNeighborSampler, hetero_neighbor_sample
+    from wholegraph_amd import nn
+    g = torch.Generator(device=dev).manual_seed(11)
+    n = {"paper": 736_389, "author": 1_134_649, "institution": 8_740, "field_of_study": 59_965}
+    rel = {("author", "writes", "paper"): 7_145_660, ("paper", "cites", "paper"): 5_416_271,
+           ("paper", "has_topic", "field_of_study"): 7_505_078, ("author", "affiliated_with", "institution"): 1_043_998,
+           ("paper", "rev_writes", "author"): 7_145_660, ("field_of_study", "rev_has_topic", "paper"): 7_505_078}
+    gs = GraphStore()
+    for (s_, r_, d_), m in rel.items():
+        # skewed endpoints (squared uniform) so that hubs exist, as in the real graph
+        src = (torch.rand(m, generator=g, device=dev) ** 2 * n[s_]).long().clamp_(max=n[s_] - 1)
+        dst = (torch.rand(m, generator=g, device=dev) ** 2 * n[d_]).long().clamp_(max=n[d_] - 1)
+        gs[(s_, r_, d_), "coo", False, (n[s_], n[d_])] = torch.stack([src, dst])
+    graphs = gs._hetero_graphs
+    fanout = {et: [25, 10] for et in rel}
+    B, G, groups = 1024, 32, 6
+    seeds = torch.randperm(n["paper"], generator=g, device=dev)[:B * G * groups]
+    smp = HeteroNeighborSampler(graphs, fanout, local_seeds_per_call=B * G)
+    list(smp.sample_batches("paper", seeds[:B * G], B, 1))          # warm-up (allocations, workspace)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = nodes = nb = 0
+    last = None
+    for b, out in smp.sample_batches("paper", seeds, B, 7):
+        edges += sum(sum(v) for v in out[5].values())
+        nodes += sum(int(v.numel()) for v in out[0].values())
+        nb += 1
+        last = out
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for b in range(4):                                                # the one-batch-at-a-time route, for scale
+        hetero_neighbor_sample(graphs, "paper", seeds[b * B:(b + 1) * B], smp.fanout, 7 + b)
+    torch.cuda.synchronize()
+    slow = (time.perf_counter() - t1) / 4
+    et = ("author", "writes", "paper")
+    node, row, col, _, _, _ = last
+    n_dst, n_src, H, C = node["paper"].numel(), node["author"].numel(), 4, 64
+    rp, cc = nn._to_csr(torch.stack([row[et], col[et]]), n_dst)
+    x = torch.rand((n_src, H * C), generator=g, device=dev)
+    a_s, a_d = torch.rand((n_src, H), generator=g, device=dev), torch.rand((n_dst, H), generator=g, device=dev)
+    tg = timed(lambda: nn.gat_forward(rp, cc, x, a_s, a_d, H, 0.2, need_alpha=False), events=True)
+    return {"op": "hetero (ogbn-mag-like) call-group sampling, 2-hop [25,10] x 6 edge types, batch 1024",
+            "reference": "pylibcugraph.heterogeneous_uniform_neighbor_sample via cugraph_pyg (a14)",
+            "ms_per_batch": round(dt / nb * 1e3, 4), "edges_per_s": round(edges / dt, 1),
+            "edges_per_batch": round(edges / nb, 1), "nodes_per_batch": round(nodes / nb, 1),
+            "ms_per_batch_one_at_a_time": round(slow * 1e3, 3), "call_group": G,
+            "gat_one_batch_ms": round(tg * 1e3, 4),
+            "note": "per-batch outputs materialised as python tuples (finalize_batches); GAT H=4 C=64 forward on the "
+                    "sampled author-writes-paper relation of one mini-batch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
     ap.add_argument("--edges", type=int, default=E_UNDIRECTED)
+    ap.add_argument("--hetero", action="store_true", help="add the ogbn-mag-like heterogeneous loader measurement")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench_ops.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", 0)
@@ -155,6 +214,9 @@ def main():
         t = timed(lambda: nn.gat_forward(hop2[0], col2, x, a_s, a_d, H, 0.2, need_alpha=True), events=True)
         add("GAT (+alpha out for backward) H=%d C=%d" % (H, C), "—", t,
             Eh * (4 * H + 4) + T * 4 * H + Eh * (4 * H * C + 4 * H + 4) + T * 4 * H * C + Eh * 4 * H, Eh, "edges")
+    if args.hetero:
+        rows.append(hetero_section(dev))
+        print(rows[-1], flush=True)
     result = {"device": torch.cuda.get_device_name(0), "graph": {"V": V, "E_directed": int(E)}, "hbm_peak_GBps": HBM_PEAK_GBPS,
               "rows": rows}
     if args.json:

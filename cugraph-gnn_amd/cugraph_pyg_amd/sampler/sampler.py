@@ -29,6 +29,12 @@ _GOLDEN = 0x9E3779B97F4A7C15
 _MASK = 0xFFFFFFFFFFFFFFFF
 
 
+def _as_i64(v: int) -> int:
+    """two's-complement view of a 64-bit seed (torch has no uint64 tensors)"""
+    v &= _MASK
+    return v - (1 << 64) if v & (1 << 63) else v
+
+
 def hop_seed(random_state: int, hop: int) -> int:
     """Seed of hop ``hop`` of a call whose ``random_state`` is given (batch b of a loader epoch uses
     ``random_state + b``, as ``random_state + rank`` in distributed_sampler.py:896)."""
@@ -233,7 +239,9 @@ class HeteroNeighborSampler:
 
     def __init__(self, graphs, fanout, biased: bool = False, with_replacement: bool = False,
                  disjoint: bool = False, temporal: bool = False, temporal_comparison: Optional[str] = None,
-                 **_ignored):
+                 local_seeds_per_call: Optional[int] = None, **_ignored):
+        self.local_seeds_per_call = local_seeds_per_call
+        self._walks = {}
         if with_replacement or disjoint:
             raise NotImplementedError("heterogeneous with_replacement / disjoint sampling are not implemented")
         if temporal and any(g.time is None for g in graphs.values()):
@@ -247,12 +255,38 @@ class HeteroNeighborSampler:
             raise ValueError("biased sampling needs a weight attribute on every edge type")
         self.graphs, self.fanout, self.biased = graphs, {k: [int(f) for f in v] for k, v in fanout.items()}, biased
 
+    def _call_group_walk(self, batch_size: int, n_batches: int):
+        from wholegraph_amd.fused import HeteroPygWalk
+        key = (batch_size, n_batches)
+        if key not in self._walks:
+            self._walks[key] = HeteroPygWalk(self.graphs, batch_size, self.fanout, n_batches)
+        return self._walks[key]
+
     def sample_batches(self, seed_type, seeds, batch_size, random_state, seed_time=None):
+        """Uniform, non-temporal sampling of full mini-batches runs in CALL GROUPS of ``local_seeds_per_call`` seeds
+        on the batched no-sync kernel (one launch sequence per hop and edge type for the whole group); everything else
+        goes one batch at a time through the C-ABI ops.  Both routes return identical results."""
         if self.temporal and seed_time is None:
             raise ValueError("temporal sampling needs input_time")
-        for b, start in enumerate(range(0, seeds.shape[0], batch_size)):
-            yield b, hetero_neighbor_sample(
-                self.graphs, seed_type, seeds[start:start + batch_size], self.fanout, random_state + b, self.biased,
+        n = seeds.shape[0]
+        fast = (not self.biased) and (not self.temporal) and seeds.is_cuda and all(
+            g.col.dtype == torch.int64 for g in self.graphs.values())
+        n_full = n // batch_size if fast else 0
+        G = max(1, (self.local_seeds_per_call or 16 * batch_size) // batch_size)
+        n_et, hops = len(self.graphs), len(next(iter(self.fanout.values())))
+        b = 0
+        while b < n_full:
+            g = min(G, n_full - b)
+            walk = self._call_group_walk(batch_size, g)
+            rs = torch.tensor([[_as_i64(hop_seed(random_state + b + j, k)) for j in range(g)] for k in range(hops * n_et)],
+                              dtype=torch.int64)
+            rec = walk.run(seed_type, seeds[b * batch_size:(b + g) * batch_size].to(torch.int64).contiguous(), rs)
+            for j, out in enumerate(walk.finalize_batches(rec)):
+                yield b + j, out
+            b += g
+        for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
+            yield bb, hetero_neighbor_sample(
+                self.graphs, seed_type, seeds[start:start + batch_size], self.fanout, random_state + bb, self.biased,
                 seed_time[start:start + batch_size] if self.temporal else None, self.temporal_comparison)
 
 

@@ -344,3 +344,159 @@ class PygNoSyncWalk:
         res.frontier_seg.append(f_seg)      # new vertices of the last hop (for num_sampled_nodes)
         res.nodes, res.node_seg = nodes, n_seg
         return res
+
+
+class HeteroPygWalk:
+    """Call-group sampler for HETEROGENEOUS graphs on ``wgamd_sample_hop_pyg_nosync`` (one call per hop and edge type
+    for all G mini-batches): the frontier of the edge type's destination node type is sampled on that type's CSR and
+    the neighbours are renumbered against the per-batch vertex lists of the source node type.  Produces, per
+    mini-batch, exactly what ``cugraph_pyg_amd.sampler.hetero_neighbor_sample`` returns for that batch alone (same
+    per-batch seeds; tests/test_gpu_pyg_loader.py) — the counterpart of one
+    ``pylibcugraph.heterogeneous_uniform_neighbor_sample`` call over many batches.
+    No host synchronisation inside ``run``; sizes are read once in ``finalize_batches``."""
+
+    def __init__(self, graphs, batch_size: int, fanout, n_batches: int):
+        self.etypes = sorted(graphs.keys())
+        self.graphs = graphs
+        self.G, self.B = int(n_batches), int(batch_size)
+        self.fanout = {et: [int(f) for f in fanout.get(et, [])] for et in self.etypes}
+        self.hops = len(next(iter(fanout.values())))
+        for et in self.etypes:
+            if not self.fanout[et]:
+                self.fanout[et] = [0] * self.hops
+            assert len(self.fanout[et]) == self.hops and all(f >= 0 for f in self.fanout[et])
+            assert graphs[et].col.dtype == torch.int64 and graphs[et].row_ptr.is_cuda
+        self.ntypes = sorted({t for et in self.etypes for t in (et[0], et[2])})
+        self.dev = graphs[self.etypes[0]].row_ptr.device
+        self.wm_dtype = torch_dtype_to_wm(torch.int64)
+        self._ws = None
+        dev = self.dev
+        self.seed_seg = (torch.arange(self.G + 1, dtype=torch.int32, device=dev) * self.B).contiguous()
+        self.seed_batch = torch.arange(self.G, dtype=torch.int32, device=dev).repeat_interleave(self.B).contiguous()
+        self.zeros_g = torch.zeros(self.G, dtype=torch.int32, device=dev)
+        self.zeros_g1 = torch.zeros(self.G + 1, dtype=torch.int32, device=dev)
+
+    def _workspace(self, node_cap, edge_cap):
+        need = L.lib().wgamd_sample_hop_workspace_bytes(node_cap, edge_cap, self.wm_dtype)
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.dev)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    def _frontier(self, st, cap):
+        """Batch-major list of the vertices a type gained since ``st['begin']`` (per-batch local index), capacity
+        ``cap``: (ids, batch, seg, local0).  Entries past the live total are padding the kernels never read."""
+        G, dev = self.G, self.dev
+        size_b = st["seg"][1:] - st["seg"][:-1]
+        cnt = (size_b - st["begin"]).to(torch.int32)
+        f_seg = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+        f_seg[1:] = torch.cumsum(cnt, 0)
+        p = torch.arange(cap, dtype=torch.int32, device=dev)
+        b = torch.searchsorted(f_seg[1:].contiguous(), p, right=True).clamp_(max=G - 1)
+        src = st["seg"][:-1][b].long() + st["begin"][b].long() + (p - f_seg[:-1][b]).long()
+        ids = st["nodes"][src.clamp_(0, st["nodes"].shape[0] - 1)]
+        return ids.contiguous(), b.to(torch.int32).contiguous(), f_seg, st["begin"].contiguous()
+
+    def run(self, seed_type: str, seeds: torch.Tensor, random_seeds: torch.Tensor):
+        """``seeds`` [G*B] type-local ids of ``seed_type``; ``random_seeds`` int64 [hops * n_etypes, G]: row
+        ``h * n_etypes + t`` holds the per-batch seeds of hop h / edge type t (sorted order)."""
+        lib, dev, G = L.lib(), self.dev, self.G
+        assert seeds.dtype == torch.int64 and seeds.shape[0] == G * self.B and seeds.is_cuda
+        rs = random_seeds.to(device=dev, dtype=torch.int64).contiguous()
+        assert rs.shape == (self.hops * len(self.etypes), G)
+        i32 = dict(dtype=torch.int32, device=dev)
+        state = {}
+        for t in self.ntypes:   # per node type: batch-major vertex lists, capacity, start of the current frontier
+            state[t] = dict(nodes=torch.zeros(1, dtype=torch.int64, device=dev), batch=torch.zeros(1, **i32),
+                            seg=self.zeros_g1, cap=0, begin=self.zeros_g, gained_cap=0)
+        state[seed_type] = dict(nodes=seeds, batch=self.seed_batch, seg=self.seed_seg, cap=G * self.B,
+                                begin=self.zeros_g, gained_cap=G * self.B)
+        rec = dict(calls=[], sizes=[{t: (state[t]["seg"][1:] - state[t]["seg"][:-1]) for t in self.ntypes}])
+        keep = [rs]
+        for h in range(self.hops):
+            fronts = {t: (self._frontier(state[t], state[t]["gained_cap"]) if state[t]["gained_cap"] > 0 else None)
+                      for t in self.ntypes}
+            f_caps = {t: state[t]["gained_cap"] for t in self.ntypes}
+            for t in self.ntypes:   # what this hop adds becomes the next frontier
+                st = state[t]
+                st["begin"] = (st["seg"][1:] - st["seg"][:-1]).to(torch.int32).contiguous()
+                st["gained_cap"] = 0
+            for ti, et in enumerate(self.etypes):
+                src_t, _, dst_t = et
+                m, fr = self.fanout[et][h], fronts[dst_t]
+                if m == 0 or fr is None:
+                    rec["calls"].append(None)
+                    continue
+                g = self.graphs[et]
+                f_ids, f_batch, f_seg, f_l0 = fr
+                fc = f_caps[dst_t]
+                ec = fc * m
+                st = state[src_t]
+                nc = max(st["cap"], 1)
+                offsets = torch.empty(fc + 1, **i32)
+                row_l, col_l = torch.empty(ec, **i32), torch.empty(ec, **i32)
+                scratch_r, scratch_c = torch.empty(ec, **i32), torch.empty(ec, **i32)
+                gid = torch.empty(ec, dtype=torch.int64, device=dev)
+                nodes_out = torch.empty(nc + ec, dtype=torch.int64, device=dev)
+                nodes_out_batch, nodes_out_seg = torch.empty(nc + ec, **i32), torch.empty(G + 1, **i32)
+                f_out = torch.empty(ec, dtype=torch.int64, device=dev)
+                f_out_batch, f_out_seg, f_out_l0 = torch.empty(ec, **i32), torch.empty(G + 1, **i32), torch.empty(G, **i32)
+                counts = torch.empty(2, **i32)
+                ws_ptr, ws_bytes = self._workspace(max(nc, fc), ec)
+                p = _PygHop(g.row_ptr.data_ptr(), g.col.data_ptr(), self.wm_dtype, G, m,
+                            rs[h * len(self.etypes) + ti].data_ptr(),
+                            st["nodes"].data_ptr(), st["batch"].data_ptr(), st["seg"].data_ptr(), nc,
+                            f_ids.data_ptr(), f_batch.data_ptr(), f_seg.data_ptr(), f_l0.data_ptr(), fc,
+                            offsets.data_ptr(), row_l.data_ptr(), col_l.data_ptr(), gid.data_ptr(), ec,
+                            nodes_out.data_ptr(), nodes_out_batch.data_ptr(), nodes_out_seg.data_ptr(),
+                            f_out.data_ptr(), f_out_batch.data_ptr(), f_out_seg.data_ptr(), f_out_l0.data_ptr(),
+                            counts.data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(), ws_ptr, ws_bytes)
+                L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
+                keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
+                         st["nodes"], st["batch"], st["seg"]]
+                rec["calls"].append(dict(et=et, offsets=offsets, row=row_l, col=col_l, gid=gid, f_seg=f_seg))
+                st["nodes"], st["batch"], st["seg"] = nodes_out, nodes_out_batch, nodes_out_seg
+                st["cap"] = nc + ec
+                st["gained_cap"] += ec
+            rec["sizes"].append({t: (state[t]["seg"][1:] - state[t]["seg"][:-1]) for t in self.ntypes})
+        rec["state"], rec["keep"] = state, keep
+        return rec
+
+    def finalize_batches(self, rec):
+        """Per mini-batch the tuple of ``hetero_neighbor_sample``: (node{type}, row{etype}, col{etype}, edge{etype},
+        num_sampled_nodes{type}, num_sampled_edges{etype})."""
+        G, dev = self.G, self.dev
+        state = rec["state"]
+        nseg = {t: state[t]["seg"].cpu().tolist() for t in self.ntypes}
+        sizes = [{t: v.cpu().tolist() for t, v in s.items()} for s in rec["sizes"]]
+        calls = []
+        for c in rec["calls"]:
+            if c is None:
+                calls.append(None)
+                continue
+            fs = c["f_seg"].long()
+            calls.append(dict(c, eseg=c["offsets"][fs].cpu().tolist()))
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        n_et = len(self.etypes)
+        out = []
+        for b in range(G):
+            node = {t: (state[t]["nodes"][nseg[t][b]:nseg[t][b + 1]] if state[t]["cap"] > 0 else empty) for t in self.ntypes}
+            rows, cols, edges = {et: [] for et in self.etypes}, {et: [] for et in self.etypes}, {et: [] for et in self.etypes}
+            num_edges = {et: [] for et in self.etypes}
+            for h in range(self.hops):
+                for ti, et in enumerate(self.etypes):
+                    c = calls[h * n_et + ti]
+                    if c is None:
+                        num_edges[et].append(0)
+                        continue
+                    e0, e1 = c["eseg"][b], c["eseg"][b + 1]
+                    rows[et].append(c["row"][e0:e1].long())
+                    cols[et].append(c["col"][e0:e1].long())
+                    edges[et].append(self.graphs[et].edge_id[c["gid"][e0:e1]])
+                    num_edges[et].append(e1 - e0)
+            num_nodes = {t: [sizes[0][t][b]] + [sizes[h + 1][t][b] - sizes[h][t][b] for h in range(self.hops)]
+                         for t in self.ntypes}
+            cat = lambda xs: torch.cat(xs) if xs else empty  # noqa: E731
+            out.append((node, {et: cat(rows[et]) for et in self.etypes}, {et: cat(cols[et]) for et in self.etypes},
+                        {et: cat(edges[et]) for et in self.etypes}, num_nodes, num_edges))
+        return out

@@ -642,3 +642,38 @@ def test_temporal_sampling_respects_fanout_and_order_on_random_graph(hiplib):
                 if reached[r] < 0:
                     reached[r] = t
             off += cnt
+
+
+@pytest.mark.parametrize("G", [1, 3, 8])
+def test_hetero_call_group_walk_equals_single_batch_path(hiplib, G):
+    """HeteroPygWalk (one batched no-sync launch sequence per hop and edge type for G mini-batches) returns, batch by
+    batch, exactly what hetero_neighbor_sample computes for that batch alone through the C-ABI ops."""
+    import torch
+    from cugraph_pyg_amd.data import GraphStore
+    from cugraph_pyg_amd.sampler.sampler import HeteroNeighborSampler, hetero_neighbor_sample
+    rng = np.random.default_rng(G)
+    n = {"paper": 2000, "author": 1500, "institution": 50, "field": 200}
+    rel = {("author", "writes", "paper"): 8000, ("paper", "cites", "paper"): 9000,
+           ("paper", "has_topic", "field"): 3000, ("author", "affiliated_with", "institution"): 2000,
+           ("paper", "rev_writes", "author"): 8000, ("field", "rev_has_topic", "paper"): 3000}
+    gs = GraphStore()
+    for (s, r, d), m in rel.items():
+        gs[(s, r, d), "coo", False, (n[s], n[d])] = torch.from_numpy(np.stack([rng.integers(0, n[s], m), rng.integers(0, n[d], m)]))
+    fanout = {et: [4, 3, 2] for et in rel}
+    fanout[("field", "rev_has_topic", "paper")] = [2, 0, 1]          # a zero fan-out in the middle
+    fanout[("author", "affiliated_with", "institution")] = [3, 3, 3]  # destination type never reached from papers
+    B = 32
+    seeds = torch.from_numpy(rng.permutation(n["paper"])[:B * 8 + 5]).cuda()
+    smp = HeteroNeighborSampler(gs._hetero_graphs, fanout, local_seeds_per_call=G * B)
+    got = dict(smp.sample_batches("paper", seeds, B, 1234))
+    assert len(got) == 9
+    for b in range(9):
+        ref = hetero_neighbor_sample(gs._hetero_graphs, "paper", seeds[b * B:(b + 1) * B], smp.fanout, 1234 + b)
+        node, row, col, edge, nn, ne = got[b]
+        for t in n:
+            assert torch.equal(node[t], ref[0][t]), (b, t)
+            assert list(nn[t]) == list(ref[4][t]), (b, t, nn[t], ref[4][t])
+        for et in rel:
+            assert torch.equal(row[et], ref[1][et]) and torch.equal(col[et], ref[2][et]), (b, et)
+            assert torch.equal(edge[et], ref[3][et]), (b, et)
+            assert list(ne[et]) == list(ref[5][et]), (b, et)
