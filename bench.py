@@ -145,7 +145,7 @@ class SagePipeline:
             ev.record(self.walk_stream)
         return res, sizes_h, ev
 
-    def forward(self, res, sizes_h, ev, timers=None, fused_fetch=False):
+    def forward(self, res, sizes_h, ev, timers=None, mode="split"):
         """Feature fetch + L-layer SAGE forward of one call group with exact (host-known) sizes."""
         nn = self.nn
         ev.synchronize()
@@ -175,6 +175,11 @@ class SagePipeline:
             timers.append((name, s, e))
             return out
 
+        # mode: "split" = gather | aggregate kernel | library GEMM;  "fused" = gather | ONE kernel per layer (aggregate in
+        # LDS + fp32-MFMA transform) where the shape allows;  "split_fetch" / "fused_fetch" = the same two with the feature
+        # fetch folded into layer 1 (x = feat[n_id] never materialised)
+        fused_fetch = mode.endswith("_fetch")
+        fused_layer = mode.startswith("fused")
         u_last = n_uniq[L - 1]
         n_id = res.unique[L - 1][:u_last]
         if fused_fetch:
@@ -197,6 +202,12 @@ class SagePipeline:
                 n_dst = t0   # the seeds = the first BATCH rows of every batch's hop-0 unique list
                 rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
             ptr, nbr = res.offsets[k][:n_dst + 1], res.neighbor_row[k][:n_edges[k]]
+            if fused_layer and nn.sage_layer_fused_preferred(self.dims[j], self.dims[j + 1]):
+                fetch = j == 0 and fused_fetch
+                h = stage(("fetch+" if fetch else "") + "sage_layer%d(fused)" % (j + 1), lambda: nn.sage_layer_fused_forward(
+                    ptr, nbr, self.feat.local_tensor if fetch else h, rows, self.w_t[j], self.bias[j], relu=j < L - 1,
+                    mean=True, src_ids=n_id if fetch else None))
+                continue
             if j == 0 and fused_fetch:
                 cat = stage("fetch+" + spmm_label(0), lambda: nn.sage_aggregate_fetch_forward(
                     ptr, nbr, self.feat.local_tensor, n_id, rows, True))
@@ -264,6 +275,9 @@ def main():
     ap.add_argument("--force-partitioned", action="store_true",
                     help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
     ap.add_argument("--no-overlap", action="store_true", help="run the walk on the main stream (no second HIP stream)")
+    ap.add_argument("--layer-kernel", choices=["auto", "fused", "split"], default="auto",
+                    help="auto/fused: one kernel per SAGE layer where the shape allows; split: aggregate kernel + library GEMM")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes of the other code paths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -281,6 +295,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from wholegraph_amd import WholeMemoryTensor, equal_entry_partition
+    from wholegraph_amd import nn as nn_mod
 
     # ---- synthetic workload (replicated CSR, range-partitioned features) --------------------
     global FEAT_DIM, CLASSES, FANOUT
@@ -320,55 +335,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_groups(first, last, timers=None, sizes=None, fused_fetch=False):
+    def run_groups(first, last, timers=None, sizes=None, mode="split"):
         """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
         pending = pipe.sample(batches[first], first)
         for g in range(first, last):
             nxt = pipe.sample(batches[g + 1], g + 1) if g + 1 < last else None
-            _, sz = pipe.forward(*pending, timers=timers, fused_fetch=fused_fetch)
+            _, sz = pipe.forward(*pending, timers=timers, mode=mode)
             if sizes is not None:
                 sizes.append(sz)
             pending = nxt
 
-    run_groups(0, warm_groups)
-    barrier()
-    t0 = time.perf_counter()
-    sizes = []
-    run_groups(warm_groups, total_groups, sizes=sizes)
-    barrier()
-    dt = time.perf_counter() - t0
-    edges_local = sum(sum(s[0::2]) for s in sizes)
-
-    stats = torch.tensor([dt, float(edges_local)], dtype=torch.float64, device=device)
-    if world > 1:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        esum = stats[1:].clone()
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-        dt, edges_total = float(tmax), float(esum)
-    else:
-        edges_total = float(edges_local)
-
-    # ---- variant: feature fetch fused into the layer-1 aggregation (x never materialised); same groups,
-    # reported next to the headline, which keeps the reference's explicit gather stage
-    fused = None
-    if not partitioned:
-        run_groups(0, warm_groups, fused_fetch=True)
+    def measure(mode):
+        """warm-up groups, then EXACTLY args.steps mini-batches between barriers; (max seconds over ranks, total edges)"""
+        run_groups(0, warm_groups, mode=mode)
         barrier()
-        tf0 = time.perf_counter()
-        fsizes = []
-        run_groups(warm_groups, total_groups, sizes=fsizes, fused_fetch=True)
+        t_start = time.perf_counter()
+        szs = []
+        run_groups(warm_groups, total_groups, sizes=szs, mode=mode)
         barrier()
-        tf = time.perf_counter() - tf0
-        fstats = torch.tensor([tf, float(sum(sum(s[0::2]) for s in fsizes))], dtype=torch.float64, device=device)
+        secs = time.perf_counter() - t_start
+        st = torch.tensor([secs, float(sum(sum(v[0::2]) for v in szs))], dtype=torch.float64, device=device)
         if world > 1:
-            a, b2 = fstats[:1].clone(), fstats[1:].clone()
-            dist.all_reduce(a, op=dist.ReduceOp.MAX)
-            dist.all_reduce(b2, op=dist.ReduceOp.SUM)
-            fstats = torch.cat([a, b2])
-        fused = {"value": float(fstats[1] / fstats[0]), "ms_per_step": float(fstats[0]) / args.steps * 1e3,
-                 "note": "same workload with the feature fetch fused into the layer-1 aggregation kernel "
-                         "(wgamd_sage_aggregate_fetch_f32): x = feat[n_id] is never written to HBM"}
+            tmax, esum = st[:1].clone(), st[1:].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+            return float(tmax), float(esum)
+        return float(st[0]), float(st[1])
+
+    # headline: explicit feature-gather stage (the reference's flow), every SAGE layer whose shape allows it in ONE
+    # kernel (aggregate in LDS + fp32-MFMA transform); --layer-kernel split keeps aggregate kernel + library GEMM
+    fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])
+    head_mode = "fused" if (args.layer_kernel != "split" and fusable) else "split"
+    dt, edges_total = measure(head_mode)
+
+    # variants on the same groups: the other layer kernel, and the feature fetch folded into layer 1
+    variants = {}
+    others = (["split"] if head_mode == "fused" else []) + ([] if partitioned else ["split_fetch"] + (["fused_fetch"] if fusable else []))
+    notes = {"split": "aggregate kernel -> [agg|x_self] in HBM -> hipBLASLt GEMM (two kernels per layer)",
+             "split_fetch": "feature fetch folded into the layer-1 aggregation kernel (wgamd_sage_aggregate_fetch_f32), then GEMM",
+             "fused_fetch": "feature fetch + aggregation + fp32-MFMA transform of layer 1 in ONE kernel "
+                            "(wgamd_sage_layer_fused_f32 reading the feature table through n_id): x = feat[n_id] never exists"}
+    for m in ([] if args.no_variants else others):
+        vs, ve = measure(m)
+        variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
+    fused = variants.get("fused_fetch") or variants.get("split_fetch")
 
     # ---- per-stage HIP-event timing pass (same pipeline, same stream; after the timed region) --
     stage_ms, stage_n = {}, 0
@@ -382,7 +392,7 @@ def main():
         w0.record(ws)
         pend = pipe.sample(batches[g], g)
         w1.record(ws)
-        _, sz = pipe.forward(*pend, timers=timers)
+        _, sz = pipe.forward(*pend, timers=timers, mode=head_mode)
         torch.cuda.synchronize()
         timers.append(("walk(sample+renumber x%d)" % L, w0, w1))
         for name, a, b in timers:
@@ -405,6 +415,12 @@ def main():
             # + the root term copied next to the aggregate: one more row read and written per destination
             kernels[spmm_label(j)] = ("spmm_csr_kernel",
                                       hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 8) + n_dst * (8 * fj + 8))
+        for j in range(L):   # one-kernel layers: same reads minus the [agg|x_self] round trip, plus the output write
+            k = L - 1 - j
+            fj, nj = pipe.dims[j], pipe.dims[j + 1]
+            n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
+            kernels["sage_layer%d(fused)" % (j + 1)] = ("sage_layer_fused_kernel",
+                                                        hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
         dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
         roofline = None
         if dom is not None:
@@ -460,7 +476,9 @@ def main():
             "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
             "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
             "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
+            "layer_kernel": head_mode,
             "fused_fetch_variant": fused,
+            "variants": variants,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

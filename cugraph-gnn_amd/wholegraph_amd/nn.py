@@ -71,6 +71,38 @@ def sage_aggregate_fetch_forward(row_ptr, col, table, src_ids, self_rows, mean=T
     return out
 
 
+def sage_layer_fused_supported(F_: int, N: int) -> bool:
+    """Shapes ``wgamd_sage_layer_fused_f32`` is built for (include/wgamd_ext.h)."""
+    return F_ % 4 == 0 and F_ <= 256 and N in (64, 128, 256)
+
+
+def sage_layer_fused_preferred(F_: int, N: int) -> bool:
+    """Shapes where the one-kernel layer beats aggregate kernel + library GEMM: two operand tiles must fit the 160 KB of
+    LDS so that a workgroup can gather one tile while it multiplies the other (2F <= 304)."""
+    return sage_layer_fused_supported(F_, N) and F_ <= 152
+
+
+def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None):
+    """A whole SAGEConv layer over a sampled hop in ONE kernel: ``act([mean_j X[col_j] | X[self_i]] @ w_t + bias)`` with
+    ``X[r] = x[src_ids[r]]`` when ``src_ids`` is given (``x`` is then the global feature table: the feature fetch is fused
+    in too).  ``w_t`` = ``cat([W_l, W_r], 1).t()`` ([2F, N], contiguous).  The ``[n_rows, 2F]`` operand never leaves LDS."""
+    _check_csr(row_ptr, col)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
+    assert self_rows.dtype == torch.int64 and self_rows.is_contiguous()
+    n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], w_t.shape[1]
+    out = torch.empty((n_rows, N), dtype=torch.float32, device=x.device)
+    ids_ptr, ids_dt = None, 0
+    if src_ids is not None:
+        assert src_ids.is_contiguous()
+        ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
+    L.check(L.lib().wgamd_sage_layer_fused_f32(
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_, ids_ptr, ids_dt, self_rows.data_ptr(),
+        int(bool(mean)), w_t.data_ptr(), w_t.stride(0), N, None if bias is None else bias.data_ptr(), int(bool(relu)),
+        out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_f32")
+    return out
+
+
 def csr_transpose(row_ptr, col, n_src):
     """Destination-major hop CSR -> source-major CSR (rows = sources, entries = destination rows, in edge order:
     a stable radix sort, so the gradient sums below are run-to-run deterministic)."""

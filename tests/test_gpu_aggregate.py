@@ -143,3 +143,49 @@ def test_sage_aggregate_fused_feature_fetch(oracle_mod, hiplib):
     ref = nn.sage_aggregate_forward(torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(x).cuda(),
                                     torch.from_numpy(self_rows).cuda(), True).cpu().numpy()
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("F,N", [(100, 256), (128, 256), (64, 64), (256, 128), (4, 128), (36, 256)])
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, with_ids):
+    """wgamd_sage_layer_fused_f32 (gather -> aggregate in LDS -> fp32-MFMA transform, one kernel) against the oracle's
+    sequential fp32 SpMM + an fp64 matmul; and against the two-kernel product path (aggregate kernel + library GEMM)."""
+    import torch
+    from wholegraph_amd import nn
+    n_dst, n_src, V = 1000 + F, 2500, 40000     # n_dst not a multiple of the 64-row tile
+    rp, col = _csr(n_dst, n_src, 14, F)
+    rng = np.random.default_rng(F + N)
+    table = rng.standard_normal((V if with_ids else n_src, F)).astype(np.float32)
+    ids = rng.permutation(V)[:n_src].astype(np.int64) if with_ids else None
+    x_local = table[ids] if with_ids else table
+    self_rows = rng.integers(0, n_src, n_dst).astype(np.int64)
+    w_t = (rng.standard_normal((2 * F, N)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    cu = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    for relu in (True, False):
+        got = nn.sage_layer_fused_forward(cu(rp), cu(col), cu(table), cu(self_rows), cu(w_t), cu(bias), relu=relu, mean=True,
+                                          src_ids=cu(ids) if with_ids else None).cpu().numpy()
+        agg = oracle_mod.spmm_csr(rp, col, x_local, mean=True, acc_double=False)
+        cat = np.concatenate([agg, x_local[self_rows]], axis=1)
+        ref = cat.astype(np.float64) @ w_t.astype(np.float64) + bias
+        if relu:
+            ref = np.maximum(ref, 0)
+        scale = np.abs(cat).astype(np.float64) @ np.abs(w_t).astype(np.float64) + np.abs(bias)
+        assert np.all(np.abs(got - ref) <= 1e-5 * scale + 1e-6), np.abs(got - ref).max()
+    # the two-kernel path computes the same layer
+    cat_g = nn.sage_aggregate_forward(cu(rp), cu(col), cu(x_local), cu(self_rows), True)
+    two = torch.addmm(cu(bias), cat_g, cu(w_t)).cpu().numpy()
+    np.testing.assert_allclose(got, two, rtol=2e-5, atol=2e-5)
+    assert nn.sage_layer_fused_supported(F, N)
+
+
+def test_sage_layer_fused_rejects_unsupported_shapes(hiplib):
+    import torch
+    import wholegraph_amd as wg
+    from wholegraph_amd import nn
+    rp = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    col = torch.zeros(1, dtype=torch.int32, device="cuda")
+    x = torch.zeros((1, 100), device="cuda")
+    with pytest.raises(wg.WholeMemoryError):       # N = 47 is not a multiple of 64
+        nn.sage_layer_fused_forward(rp, col, x, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros((200, 47), device="cuda"))
+    assert not nn.sage_layer_fused_supported(100, 47) and not nn.sage_layer_fused_supported(102, 256)
