@@ -39,6 +39,7 @@ struct layer_args {
   int64_t n_rows;
   const float* x;
   int64_t ldx;
+  int64_t x_rows;
   int F;
   const void* src_ids;
   const int64_t* self_rows;
@@ -58,9 +59,12 @@ struct layer_args {
 // past a row's degree / idle lanes read row 0 or the last 16 B of the row, which stay in L1, and are masked by a select):
 // a load under a branch costs the branch and makes the compiler fall back to s_waitcnt vmcnt(0), which would put the
 // whole phase in series.
-template <typename IdT, int LG, int WAVES>
+// OFF32: every byte offset into x fits 32 bits (x smaller than 4 GB) -> one shuffle per neighbour instead of two and
+// `uniform base + 32-bit lane offset` addressing, i.e. no 64-bit select/add per neighbour row
+template <typename IdT, int LG, int WAVES, bool OFF32>
 __device__ __forceinline__ void gather_tile(const layer_args& a, int64_t tile, float* a_tile, int S, int tw, int lane)
 {
+  using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
   constexpr int kGroupsPerWave = 64 / LG;
   constexpr int kGroups        = kGroupsPerWave * WAVES;
   constexpr int IT             = kTileRows / kGroups;  // rows of the tile per lane group
@@ -78,7 +82,10 @@ __device__ __forceinline__ void gather_tile(const layer_args& a, int64_t tile, f
   const int64_t row0 = tile * kTileRows;
 
   int s_[IT], d_[IT], lcol_[IT];
-  int64_t src_[IT], self_[IT], lself_[IT];
+  int64_t lself_[IT];
+  off_t src_[IT], self_[IT];   // BYTE offsets of the neighbour / self rows (incl. the lane's column offset for self)
+  bool has_self_[IT];
+  const char* xb = reinterpret_cast<const char*>(x);
 #pragma unroll
   for (int it = 0; it < IT; it++) {
     const int64_t row  = row0 + group + it * kGroups;
@@ -101,9 +108,9 @@ __device__ __forceinline__ void gather_tile(const layer_args& a, int64_t tile, f
 #pragma unroll
   for (int it = 0; it < IT; it++) {
     const int64_t row = row0 + group + it * kGroups;
-    src_[it]          = table_row<IdT>(src_ids, (int64_t)lcol_[it]) * ldx;   // element offset of the neighbour row
-    self_[it]         = table_row<IdT>(src_ids, lself_[it]) * ldx;
-    if (row >= n_rows) self_[it] = -1;
+    src_[it]          = (off_t)(table_row<IdT>(src_ids, (int64_t)lcol_[it]) * ldx * 4);
+    self_[it]         = (off_t)(table_row<IdT>(src_ids, lself_[it]) * ldx * 4);
+    has_self_[it]     = row < n_rows;
   }
   // ring of kDepth row buffers: the fetches of rows it+1 .. it+kDepth-1 are in flight while row it is summed (the
   // accumulator tiles of the transform phase are not live here, so the gather may spend ~180 VGPRs on this)
@@ -113,12 +120,18 @@ __device__ __forceinline__ void gather_tile(const layer_args& a, int64_t tile, f
 #pragma unroll
     for (int k = 0; k < kNb; k++) {
       const int src_lane = gbase | (k & (LG - 1));
-      const int lo       = __shfl((int)(src_[it] & 0xffffffff), src_lane, 64);
-      const int hi       = __shfl((int)(src_[it] >> 32), src_lane, 64);
-      const int64_t off  = k < d_[it] ? (((int64_t)hi << 32) | (uint32_t)lo) : 0;
-      v[k]               = *reinterpret_cast<const f32x4*>(x + off + f0c);
+      off_t off;
+      if constexpr (OFF32) {
+        off = (uint32_t)__shfl((int)src_[it], src_lane, 64);
+      } else {
+        const int lo = __shfl((int)(src_[it] & 0xffffffff), src_lane, 64);
+        const int hi = __shfl((int)(src_[it] >> 32), src_lane, 64);
+        off          = ((int64_t)hi << 32) | (uint32_t)lo;
+      }
+      off  = k < d_[it] ? off : (off_t)0;
+      v[k] = *reinterpret_cast<const f32x4*>(xb + off + (off_t)(f0c * 4));
     }
-    v[kNb] = *reinterpret_cast<const f32x4*>(x + (self_[it] >= 0 ? self_[it] : 0) + f0c);
+    v[kNb] = *reinterpret_cast<const f32x4*>(xb + (has_self_[it] ? self_[it] : (off_t)0) + (off_t)(f0c * 4));
   };
 #pragma unroll
   for (int it = 0; it < kDepth - 1; it++) issue(it, buf[it]);
@@ -135,7 +148,7 @@ __device__ __forceinline__ void gather_tile(const layer_args& a, int64_t tile, f
       if (a.mean && deg > 0 && deg <= kNb) acc /= (float)deg;
       const int r = group + it * kGroups;
       *reinterpret_cast<f32x4*>(a_tile + r * S + f0)     = acc;
-      *reinterpret_cast<f32x4*>(a_tile + r * S + F + f0) = self_[it] >= 0 ? v[kNb] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a_tile + r * S + F + f0) = has_self_[it] ? v[kNb] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   // second pass, kept OUT of the pipelined loop (a branch with loads in it would make every join a vmcnt(0) wait): rows
@@ -266,7 +279,7 @@ __host__ __device__ inline int tile_stride(int F) { return (2 * F + 15) / 16 * 1
 
 // LG = lanes per destination row in the gather phase (power of two >= F/4), WAVES = N / 64 waves per team,
 // TEAMS = 2: ping-pong (team t handles the workgroup's tiles t, t+2, ... one phase behind team t-1), TEAMS = 1: plain
-template <typename IdT, int LG, int WAVES, int TEAMS>
+template <typename IdT, int LG, int WAVES, int TEAMS, bool OFF32>
 __global__ void __launch_bounds__(WAVES * 64 * TEAMS, 2)
 sage_layer_fused_kernel(layer_args a)
 {
@@ -292,7 +305,7 @@ sage_layer_fused_kernel(layer_args a)
       const int64_t n    = (my >> 1) * TEAMS + team;
       const int64_t tile = blockIdx.x + n * gridDim.x;
       if (n < mine) {
-        if ((my & 1) == 0) gather_tile<IdT, LG, WAVES>(a, tile, a_tile, S, tw, lane);
+        if ((my & 1) == 0) gather_tile<IdT, LG, WAVES, OFF32>(a, tile, a_tile, S, tw, lane);
         else transform_tile(a, tile, a_tile, S, tw, lane);
       }
     }
@@ -319,8 +332,11 @@ void launch(const layer_args& a, hipStream_t st)
     kern<<<grid < 1 ? 1 : grid, threads, lds, st>>>(a);
     WG_HIP_CHECK(hipGetLastError());
   };
-  if (pingpong) go(sage_layer_fused_kernel<IdT, LG, WAVES, 2>, WAVES * 128);
-  else go(sage_layer_fused_kernel<IdT, LG, WAVES, 1>, WAVES * 64);
+  const bool off32 = a.x_rows > 0 && (uint64_t)a.x_rows * (uint64_t)a.ldx * 4u < (1ull << 32);
+  if (pingpong && off32) go(sage_layer_fused_kernel<IdT, LG, WAVES, 2, true>, WAVES * 128);
+  else if (pingpong) go(sage_layer_fused_kernel<IdT, LG, WAVES, 2, false>, WAVES * 128);
+  else if (off32) go(sage_layer_fused_kernel<IdT, LG, WAVES, 1, true>, WAVES * 64);
+  else go(sage_layer_fused_kernel<IdT, LG, WAVES, 1, false>, WAVES * 64);
 }
 
 template <typename IdT, int LG>
@@ -347,7 +363,8 @@ void launch_groups(int N, const layer_args& a, hipStream_t st)
 }  // namespace wgamd
 
 extern "C" wholememory_error_code_t wgamd_sage_layer_fused_f32(const int* row_ptr, const int* col, int64_t n_rows,
-                                                               const float* x, int64_t ldx, int F, const void* src_ids,
+                                                               const float* x, int64_t ldx, int64_t x_rows, int F,
+                                                               const void* src_ids,
                                                                wholememory_dtype_t src_ids_dtype, const int64_t* self_rows,
                                                                int mean, const float* w_t, int64_t ldw, int N,
                                                                const float* bias, int relu, float* out, int64_t ldo,
@@ -363,7 +380,7 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_f32(const int* row_pt
         (reinterpret_cast<uintptr_t>(x) & 15) != 0)
       throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), N=%d (64, 128 or 256), 16-B aligned rows", F, N));
     WG_REQUIRE_INPUT(ldw >= N && ldo >= N, "leading dimensions smaller than N");
-    layer_args a{row_ptr, col, n_rows, x, ldx, F, src_ids, self_rows, mean, w_t, ldw, bias, relu, out, ldo};
+    layer_args a{row_ptr, col, n_rows, x, ldx, x_rows, F, src_ids, self_rows, mean, w_t, ldw, bias, relu, out, ldo};
     auto st = static_cast<hipStream_t>(stream);
     if (src_ids == nullptr) launch_groups<void>(N, a, st);
     else if (src_ids_dtype == WHOLEMEMORY_DT_INT) launch_groups<int32_t>(N, a, st);

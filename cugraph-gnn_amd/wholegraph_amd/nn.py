@@ -97,7 +97,8 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
         assert src_ids.is_contiguous()
         ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
     L.check(L.lib().wgamd_sage_layer_fused_f32(
-        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_, ids_ptr, ids_dt, self_rows.data_ptr(),
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
+        self_rows.data_ptr(),
         int(bool(mean)), w_t.data_ptr(), w_t.stride(0), N, None if bias is None else bias.data_ptr(), int(bool(relu)),
         out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_f32")
     return out

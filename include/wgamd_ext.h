@@ -260,11 +260,12 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
  *   out[i,:] = act( [ mean|sum_{e in row i} X[col[e]] | X[self_rows[i]] ] @ w_t + bias ),  X[r] = x[src_ids ? src_ids[r] : r]
  * feature fetch -> aggregation (fp32, CSR order) -> fp32-MFMA transform; the [n_rows, 2F] operand lives only in LDS.
  * w_t: [2F, N] row-major (rows 0..F-1 = W_l^T, rows F..2F-1 = W_r^T), ldw >= N; bias nullable; relu != 0 applies max(.,0).
+ * x_rows = number of rows of x (0 = unknown): below 4 GB the kernel uses 32-bit row offsets.
  * Shapes: F % 4 == 0, F <= 256, N in {64, 128, 256}, x rows 16-B aligned — anything else returns WHOLEMEMORY_LOGIC_ERROR
  * (callers then use wgamd_sage_aggregate_f32 + a library GEMM).  Semantics: torch_geometric.nn.SAGEConv as the reference
  * uses it (python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59). */
 wholememory_error_code_t wgamd_sage_layer_fused_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                    int64_t ldx, int F, const void* src_ids,
+                                                    int64_t ldx, int64_t x_rows, int F, const void* src_ids,
                                                     wholememory_dtype_t src_ids_dtype, const int64_t* self_rows, int mean,
                                                     const float* w_t, int64_t ldw, int N, const float* bias, int relu,
                                                     float* out, int64_t ldo, void* stream);
