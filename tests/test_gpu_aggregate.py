@@ -189,3 +189,36 @@ def test_sage_layer_fused_rejects_unsupported_shapes(hiplib):
     with pytest.raises(wg.WholeMemoryError):       # N = 47 is not a multiple of 64
         nn.sage_layer_fused_forward(rp, col, x, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros((200, 47), device="cuda"))
     assert not nn.sage_layer_fused_supported(100, 47) and not nn.sage_layer_fused_supported(102, 256)
+
+
+def test_sage_layer_fused_64bit_offset_path_and_tiny_inputs(hiplib):
+    """x_rows = 0 (unknown extent) selects the 64-bit row-offset code path; it must agree bit-for-bit with the 32-bit one.
+    Also: fewer rows than one 64-row tile, a single row, int32 id indirection."""
+    import torch
+    from wholegraph_amd import _lib as L
+    from wholegraph_amd import nn
+    from wholegraph_amd.env import get_stream
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n_dst in (1, 37, 64, 65, 300):
+        F, N, n_src = 100, 256, 500
+        deg = torch.randint(0, 14, (n_dst,), generator=g, device="cuda")
+        rp = torch.zeros(n_dst + 1, dtype=torch.int32, device="cuda")
+        rp[1:] = torch.cumsum(deg, 0)
+        col = torch.randint(0, n_src, (int(rp[-1]),), generator=g, device="cuda", dtype=torch.int32)
+        table = torch.randn((3000, F), generator=g, device="cuda")
+        ids = torch.randperm(3000, generator=g, device="cuda")[:n_src].int()
+        rows = torch.randint(0, n_src, (n_dst,), generator=g, device="cuda")
+        w_t = torch.randn((2 * F, N), generator=g, device="cuda") * 0.1
+        bias = torch.randn(N, generator=g, device="cuda")
+        a = nn.sage_layer_fused_forward(rp, col, table, rows, w_t, bias, relu=True, src_ids=ids)
+        b = torch.empty_like(a)
+        L.check(L.lib().wgamd_sage_layer_fused_f32(rp.data_ptr(), col.data_ptr() if col.numel() else rp.data_ptr(), n_dst,
+                                                   table.data_ptr(), table.stride(0), 0, F, ids.data_ptr(), L.DT_INT,
+                                                   rows.data_ptr(), 1, w_t.data_ptr(), w_t.stride(0), N, bias.data_ptr(), 1,
+                                                   b.data_ptr(), b.stride(0), get_stream()), "fused")
+        assert torch.equal(a, b)
+        x = table[ids.long()]
+        cat = nn.sage_aggregate_forward(rp, col if col.numel() else torch.zeros(1, dtype=torch.int32, device="cuda")[:0].contiguous(),
+                                        x, rows, True) if col.numel() else torch.cat([torch.zeros((n_dst, F), device="cuda"), x[rows]], 1)
+        ref = torch.relu(torch.addmm(bias, cat, w_t))
+        torch.testing.assert_close(a, ref, rtol=2e-5, atol=2e-5)
