@@ -1,0 +1,158 @@
+// Backward of the fused GAT aggregation (wgamd_gat_csr_f32):  out_i = sum_j alpha_ij x_j,  alpha = softmax_j(e_ij),
+// e_ij = LeakyReLU(a_src[j] + a_dst[i]) per head.  Given g = dL/dout:
+//   dalpha_ij = <g_i, x_j>_head,  ds_ij = alpha_ij (dalpha_ij - sum_k alpha_ik dalpha_ik),  de_ij = ds_ij * LeakyReLU'(.)
+//   ga_dst[i] = sum_j de_ij,   ga_src[j] = sum_i de_ij,   gx_j = sum_i alpha_ij g_i
+// Two kernels, no atomics, no [E, H, C] temporaries (the torch-op version needs three of them):
+//   1. destination-major (the forward's CSR): one lane group per destination row; the per-head dot products are reduced
+//      with xor-shuffles inside the head's lanes; writes de[E, H] and ga_dst;
+//   2. source-major (the transposed CSR: edge ids sorted by source, stable): gathers g rows weighted by alpha, sums de.
+// Semantics of torch_geometric.nn.GATConv's message/aggregate as used by the reference's model zoo
+// (python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:45-59); the formulas are the standard softmax backward.
+#include <algorithm>
+
+#include "wg_common.hpp"
+#include "wgamd_ext.h"
+
+namespace wgamd {
+namespace {
+
+// lanes = lane group per row (power of two, >= H*C/4); LH = C/4 lanes per head (power of two)
+__global__ void __launch_bounds__(256)
+gat_bwd_dst_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows, const float* __restrict__ x,
+                   int64_t ldx, const float* __restrict__ a_src, const float* __restrict__ a_dst, int H, int C, float slope,
+                   const float* __restrict__ alpha, const float* __restrict__ g, int64_t ldg, float* __restrict__ de,
+                   float* __restrict__ ga_dst, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const int HC = H * C, LH = C / 4;
+  const int f0    = sub * 4;
+  const bool live = f0 < HC;
+  const int h     = live ? f0 / C : 0;
+  const int t     = sub & (LH - 1);  // my index among the lanes of my head
+  const int64_t iters = (n_rows + ngroups - 1) / ngroups;
+  for (int64_t it = 0; it < iters; it++) {  // all lanes of a wave iterate together: the shuffles below need them
+    const int64_t row = group + it * ngroups;
+    const bool valid  = row < n_rows && live;
+    int s = 0, e = 0;
+    if (row < n_rows) {
+      s = row_ptr[row];
+      e = row_ptr[row + 1];
+    }
+    int maxdeg = e - s;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, d, 64));
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) g4 = *reinterpret_cast<const float4*>(g + row * ldg + f0);
+    // pass 1: dalpha per edge and head (parked in de), dot = sum alpha * dalpha
+    float dot = 0.f;
+    for (int j = 0; j < maxdeg; j++) {
+      float p = 0.f;
+      const bool on = valid && s + j < e;
+      if (on) {
+        const float4 x4 = *reinterpret_cast<const float4*>(x + (int64_t)col[s + j] * ldx + f0);
+        p = g4.x * x4.x + g4.y * x4.y + g4.z * x4.z + g4.w * x4.w;
+      }
+      for (int d = LH >> 1; d >= 1; d >>= 1) p += __shfl_xor(p, d, 64);
+      if (on) {
+        dot += alpha[(int64_t)(s + j) * H + h] * p;
+        if (t == 0) de[(int64_t)(s + j) * H + h] = p;
+      }
+    }
+    // pass 2: the LH lanes of a head split the row's edges
+    float gad = 0.f;
+    if (valid) {
+      const float ad = a_dst[row * H + h];
+      for (int j = s + t; j < e; j += LH) {
+        const int64_t eh = (int64_t)j * H + h;
+        const float sc   = a_src[(int64_t)col[j] * H + h] + ad;
+        float ds         = alpha[eh] * (de[eh] - dot);
+        ds               = sc > 0.f ? ds : ds * slope;
+        de[eh]           = ds;
+        gad += ds;
+      }
+    }
+    for (int d = LH >> 1; d >= 1; d >>= 1) gad += __shfl_xor(gad, d, 64);
+    if (valid && t == 0) ga_dst[row * H + h] = gad;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gat_bwd_src_kernel(const int* __restrict__ row_ptr_t, const int* __restrict__ edge_perm, const int* __restrict__ edge_dst,
+                   int64_t n_src, int H, int C, const float* __restrict__ alpha, const float* __restrict__ de,
+                   const float* __restrict__ g, int64_t ldg, float* __restrict__ gx, int64_t ldgx,
+                   float* __restrict__ ga_src, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const int HC = H * C;
+  const int f0 = sub * 4;
+  if (f0 >= HC) return;
+  const int h = f0 / C;
+  for (int64_t row = group; row < n_src; row += ngroups) {
+    const int s = row_ptr_t[row], e = row_ptr_t[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gas  = 0.f;
+    for (int j = s; j < e; j++) {
+      const int eid   = edge_perm[j];
+      const float al  = alpha[(int64_t)eid * H + h];
+      const float4 t4 = *reinterpret_cast<const float4*>(g + (int64_t)edge_dst[eid] * ldg + f0);
+      acc.x += al * t4.x;
+      acc.y += al * t4.y;
+      acc.z += al * t4.z;
+      acc.w += al * t4.w;
+      gas += de[(int64_t)eid * H + h];
+    }
+    *reinterpret_cast<float4*>(gx + row * ldgx + f0) = acc;
+    if ((f0 % C) == 0) ga_src[row * H + h] = gas;
+  }
+}
+
+inline int log2_ceil(int v)
+{
+  int l = 0;
+  while ((1 << l) < v) l++;
+  return l;
+}
+
+}  // namespace
+}  // namespace wgamd
+
+extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                          int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
+                                                          float negative_slope, const float* alpha, const float* grad_out,
+                                                          int64_t ldg, const int* row_ptr_t, const int* edge_perm,
+                                                          const int* edge_dst, int64_t n_src, float* de, float* grad_x,
+                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gat_csr_bwd_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && n_src >= 0 && H > 0 && C > 0, "bad sizes");
+    const int HC = H * C, LH = C / 4;
+    if (C % 4 != 0 || (LH & (LH - 1)) != 0 || HC > 256 || ldx % 4 != 0 || ldg % 4 != 0 || ldgx % 4 != 0)
+      throw logic_error(fmt("unsupported shape: H=%d C=%d (C/4 a power of two, H*C <= 256, 16-B aligned rows)", H, C));
+    WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && alpha && grad_out && row_ptr_t && edge_perm && edge_dst && de &&
+                       grad_x && grad_a_src && grad_a_dst,
+                     "null pointer");
+    auto st      = static_cast<hipStream_t>(stream);
+    const int l2 = log2_ceil(HC / 4);
+    const int gpb = 256 >> l2;  // lane groups per workgroup
+    if (n_rows > 0) {
+      const int grid = (int)std::min<int64_t>((n_rows + gpb - 1) / gpb, 256 * 16);
+      gat_bwd_dst_kernel<<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, alpha,
+                                               grad_out, ldg, de, grad_a_dst, l2);
+    }
+    if (n_src > 0) {
+      const int grid = (int)std::min<int64_t>((n_src + gpb - 1) / gpb, 256 * 16);
+      gat_bwd_src_kernel<<<grid, 256, 0, st>>>(row_ptr_t, edge_perm, edge_dst, n_src, H, C, alpha, de, grad_out, ldg, grad_x,
+                                               ldgx, grad_a_src, l2);
+    }
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}

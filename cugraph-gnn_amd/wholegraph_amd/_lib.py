@@ -171,6 +171,9 @@ SYMBOLS = {
                                          c_void_p, c_int64, c_void_p]),
     "wgamd_sage_aggregate_fetch_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
                                                c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "wgamd_gat_csr_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_float,
+                                      c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_int64, c_void_p, c_void_p, c_void_p]),
     "wgamd_sage_layer_fused_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
                                            c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,
                                            c_void_p]),

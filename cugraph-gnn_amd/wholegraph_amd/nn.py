@@ -171,6 +171,34 @@ def gat_forward(row_ptr, col, x, a_src, a_dst, heads, negative_slope=0.2, need_a
     return out, alpha
 
 
+def gat_backward_supported(H: int, C: int) -> bool:
+    """Shapes ``wgamd_gat_csr_bwd_f32`` is built for (include/wgamd_ext.h)."""
+    return C % 4 == 0 and ((C // 4) & (C // 4 - 1)) == 0 and H * C <= 256
+
+
+def gat_backward(row_ptr, col, x, a_src, a_dst, alpha, grad_out, heads, negative_slope=0.2):
+    """(grad_x, grad_a_src, grad_a_dst) of ``gat_forward`` on the HIP kernels: a destination-major pass (per-head dot
+    products, softmax backward, grad_a_dst) and a source-major pass over the transposed hop CSR (grad_x, grad_a_src)."""
+    _check_csr(row_ptr, col)
+    n_rows, n_src, E = row_ptr.shape[0] - 1, x.shape[0], col.shape[0]
+    C = x.shape[1] // heads
+    g = grad_out.contiguous()
+    deg = (row_ptr[1:] - row_ptr[:-1]).long()
+    edge_dst = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int32, device=col.device), deg, output_size=E)
+    edge_perm = torch.sort(col, stable=True).indices.to(torch.int32).contiguous()
+    row_ptr_t = torch.zeros(n_src + 1, dtype=torch.int32, device=col.device)
+    row_ptr_t[1:] = torch.cumsum(torch.bincount(col, minlength=n_src), 0)
+    de = torch.empty((E, heads), dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x)
+    ga_src, ga_dst = torch.empty_like(a_src), torch.empty_like(a_dst)
+    L.check(L.lib().wgamd_gat_csr_bwd_f32(
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), a_src.data_ptr(), a_dst.data_ptr(), heads, C,
+        float(negative_slope), alpha.data_ptr(), g.data_ptr(), g.stride(0), row_ptr_t.data_ptr(), edge_perm.data_ptr(),
+        edge_dst.data_ptr(), n_src, de.data_ptr(), gx.data_ptr(), gx.stride(0), ga_src.data_ptr(), ga_dst.data_ptr(),
+        get_stream()), "wgamd_gat_csr_bwd_f32")
+    return gx, ga_src, ga_dst
+
+
 class _GatCsr(torch.autograd.Function):
     """Forward: fused HIP kernel.  Backward: edge-wise torch ops on the saved attention (the
     training-time gradient path is not on the north-star hot path)."""
@@ -189,6 +217,8 @@ class _GatCsr(torch.autograd.Function):
         H = ctx.heads
         C = x.shape[1] // H
         n_rows = row_ptr.shape[0] - 1
+        if gat_backward_supported(H, C) and col.shape[0] > 0:
+            return gat_backward(row_ptr, col, x, a_src, a_dst, alpha, g, H, ctx.slope) + (None, None, None, None)
         deg = (row_ptr[1:] - row_ptr[:-1]).long()
         dst = torch.repeat_interleave(torch.arange(n_rows, device=x.device), deg)
         src = col.long()
