@@ -111,6 +111,17 @@ class SagePipeline:
         self.fused_relu = hasattr(torch, "_addmm_activation")
         self.walk_stream = torch.cuda.Stream(device=device) if overlap_walk else None
         self.distributed = self.feat.is_distributed
+        self._bufs = {}
+
+    def rows_buffer(self, name, n_rows, n_cols):
+        """[n_rows, n_cols] view of a per-purpose buffer that only ever grows (by 12 % steps): the sizes of a call group
+        differ by a per cent or so from group to group, and a fresh multi-GB block from the caching allocator (hipMalloc)
+        in the middle of the timed region costs tens of milliseconds.  Safe to reuse: every use is on the main stream."""
+        buf = self._bufs.get(name)
+        if buf is None or buf.shape[0] < n_rows or buf.shape[1] != n_cols:
+            buf = torch.empty((int(n_rows * 1.12) + 1024, n_cols), dtype=torch.float32, device=self.device)
+            self._bufs[name] = buf
+        return buf[:n_rows]
 
     def dense(self, a, w_t, bias, relu):
         if relu and self.fused_relu:
@@ -190,7 +201,7 @@ class SagePipeline:
         else:
             from wholegraph_amd.tensor import local_gather
             x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id,
-                                                     torch.empty((u_last, FEAT_DIM), dtype=torch.float32, device=self.device)))
+                                                     self.rows_buffer("x", u_last, FEAT_DIM)))
         # layer j consumes hop k = L-1-j (deepest first): one kernel builds [mean_j x_j | x_i] for the hop's targets,
         # one GEMM applies [W_l | W_r] with bias (+ ReLU between layers)
         h = x
@@ -207,7 +218,7 @@ class SagePipeline:
                 fetch = j == 0 and fused_fetch
                 h = stage(("fetch+" if fetch else "") + "sage_layer%d(fused)" % (j + 1), lambda: nn.sage_layer_fused_forward(
                     ptr, nbr, self.feat.local_tensor if fetch else h, rows, self.w_t[j], self.bias[j], relu=j < L - 1,
-                    mean=True, src_ids=n_id if fetch else None))
+                    mean=True, src_ids=n_id if fetch else None, out=self.rows_buffer("h%d" % j, n_dst, self.dims[j + 1])))
                 continue
             if j == 0 and fused_fetch:
                 cat = stage("fetch+" + spmm_label(0), lambda: nn.sage_aggregate_fetch_forward(

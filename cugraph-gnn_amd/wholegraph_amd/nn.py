@@ -82,7 +82,7 @@ def sage_layer_fused_preferred(F_: int, N: int) -> bool:
     return sage_layer_fused_supported(F_, N) and F_ <= 152
 
 
-def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None):
+def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None, out=None):
     """A whole SAGEConv layer over a sampled hop in ONE kernel: ``act([mean_j X[col_j] | X[self_i]] @ w_t + bias)`` with
     ``X[r] = x[src_ids[r]]`` when ``src_ids`` is given (``x`` is then the global feature table: the feature fetch is fused
     in too).  ``w_t`` = ``cat([W_l, W_r], 1).t()`` ([2F, N], contiguous).  The ``[n_rows, 2F]`` operand never leaves LDS."""
@@ -91,7 +91,9 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
     assert self_rows.dtype == torch.int64 and self_rows.is_contiguous()
     n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], w_t.shape[1]
-    out = torch.empty((n_rows, N), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((n_rows, N), dtype=torch.float32, device=x.device)
+    assert out.shape == (n_rows, N) and out.dtype == torch.float32 and out.stride(1) == 1
     ids_ptr, ids_dt = None, 0
     if src_ids is not None:
         assert src_ids.is_contiguous()
