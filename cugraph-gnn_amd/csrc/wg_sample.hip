@@ -21,6 +21,7 @@
 //  * M > 1024: reservoir with a max-reduction per slot, as the reference's large kernel.
 //  * weighted: keys key_e = log2(u_e)/w_e with the reference's per-lane stream layout, then an
 //    exact top-M by 4-pass radix select on the key bits, emitted in CSR order.
+#include <algorithm>
 #include <cmath>
 
 #include "wg_common.hpp"
@@ -78,8 +79,9 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
                                                            int* __restrict__ cnt,
                                                            int* __restrict__ big_deg /*nullable*/,
                                                            int big_threshold = 0,
-                                                           int* __restrict__ big_list = nullptr,
-                                                           int* __restrict__ big_count = nullptr)
+                                                           int* __restrict__ big_list = nullptr /*[0] = count, [1..] = seeds*/,
+                                                           int* __restrict__ max_scratch_row = nullptr,
+                                                           int scratch_threshold = 0)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_.host) return;
@@ -96,7 +98,8 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
   // weighted: rows longer than the one-wave kernel holds in registers need key scratch + the workgroup kernel
   const bool big = M > 0 && deg > M && deg > big_threshold;
   if (big_deg) big_deg[i] = big ? deg : 0;
-  if (big && big_list) big_list[atomicAdd(big_count, 1)] = i;
+  if (big && big_list) big_list[1 + atomicAdd(big_list, 1)] = i;
+  if (big && max_scratch_row && deg > scratch_threshold) atomicMax(max_scratch_row, deg);  // longest row that needs a slab
 }
 
 template <typename ColT>
@@ -348,36 +351,45 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
                                                             const ColT* __restrict__ col,
                                                             const WeightT* __restrict__ weight,
                                                             const SeedT* __restrict__ seeds,
-                                                            int n,
+                                                            dev_count n_,
                                                             int M,
-                                                            uint64_t random_seed,
+                                                            rng_plan rng,
                                                             const int* __restrict__ offsets,
-                                                            const int* __restrict__ key_offsets,
-                                                            uint32_t* __restrict__ key_scratch,
+                                                            uint32_t* __restrict__ slab,
+                                                            int64_t slab_len,
                                                             ColT* __restrict__ dst,
                                                             int* __restrict__ src_lid,
                                                             int64_t* __restrict__ edge_gid,
-                                                            const int* __restrict__ seed_list /*nullable*/)
+                                                            const int* __restrict__ seed_list /*nullable: [0] = count*/)
 {
   static_assert(T % B == 0 && T % 64 == 0, "threads must be a multiple of the stream layout and of the wave");
   __shared__ uint32_t lds_keys[kLdsKeys];
   __shared__ int hist[256];
   __shared__ int sh_digit, sh_need, sh_redo;
   __shared__ int wave_cnt[2][T / 64];
-  const int i = seed_list ? seed_list[blockIdx.x] : (int)blockIdx.x;
-  if (i >= n) return;
+  // persistent workgroups: the rows to do (all seeds, or the listed long ones) are dealt out round-robin; a workgroup
+  // owns ONE scratch slab of slab_len keys (>= the longest row) for the rows that do not fit LDS
+  const int n_live = n_.get();
+  const int count  = seed_list ? seed_list[0] : n_live;
+  uint32_t* gkeys  = slab + (int64_t)blockIdx.x * slab_len;
+  for (int li = blockIdx.x; li < count; li += gridDim.x) {
+  __syncthreads();  // the previous row's readers of the shared counters are done
+  const int i = seed_list ? seed_list[1 + li] : li;
+  if (i >= n_live) continue;
+  uint64_t random_seed;
+  int i_rng;
+  rng.resolve(i, random_seed, i_rng);
   const int64_t nid   = (int64_t)seeds[i];
   const int64_t start = row_ptr[nid];
   const int N         = (int)(row_ptr[nid + 1] - start);
-  if (N <= 0) return;
+  if (N <= 0) continue;
   const int64_t base = offsets[i];
   if (M <= 0 || N <= M) {
     for (int j = threadIdx.x; j < N; j += T)
       emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
-    return;
+    continue;
   }
   const bool in_lds = N <= kLdsKeys;
-  uint32_t* gkeys   = key_scratch + key_offsets[i];
   // keys written to global scratch are re-read by other lanes of this workgroup, and neighbouring workgroups' key
   // segments share cache lines: those re-reads are device-scope loads so they never hit a stale line in this CU's L1
   auto put = [&](int id, uint32_t k) { if (in_lds) lds_keys[id] = k; else gkeys[id] = k; };
@@ -389,9 +401,9 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   {
     constexpr int hop = T / B;  // keys of one stream between two keys of the same thread
     const int lane = threadIdx.x % B, first_key = threadIdx.x / B;
-    const int64_t sid = (int64_t)i * B + lane;
+    const int64_t sid = (int64_t)i_rng * B + lane;
     Pcg32 g = (sid < (1ll << 31)) ? Pcg32(random_seed, (uint32_t)sid, Pcg32::table_tag{}, 3u * (uint32_t)first_key)
-                                  : Pcg32(random_seed, stream_id(i, B, lane));
+                                  : Pcg32(random_seed, stream_id(i_rng, B, lane));
     if (hop > 1 && sid >= (1ll << 31)) g.skipahead(3u * (uint64_t)first_key);
     bool redrawn = false;
     for (int id = threadIdx.x; id < N; id += T) {
@@ -411,7 +423,7 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   __syncthreads();
   if (T > B && sh_redo) {  // a 64-bit draw was 0 somewhere: redo the row with the sequential stream walk
     if (threadIdx.x < B) {
-      Pcg32 g = stream_generator(random_seed, i, B, threadIdx.x);
+      Pcg32 g = stream_generator(random_seed, i_rng, B, threadIdx.x);
       for (int id = threadIdx.x; id < N; id += B) put(id, key_bits(ares_key((float)weight[start + id], g)));
     }
     __syncthreads();
@@ -495,6 +507,7 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
     tie_run += eq_total;
     __syncthreads();
   }
+  }  // persistent loop over rows
 }
 
 // One WAVE per seed for rows of up to 64*KMAX candidates (B = 128 stream layout, i.e. M <= 256): the keys stay in
@@ -508,9 +521,9 @@ __global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t
                                                                    const ColT* __restrict__ col,
                                                                    const WeightT* __restrict__ weight,
                                                                    const SeedT* __restrict__ seeds,
-                                                                   int n,
+                                                                   dev_count n_,
                                                                    int M,
-                                                                   uint64_t random_seed,
+                                                                   rng_plan rng,
                                                                    const int* __restrict__ offsets,
                                                                    ColT* __restrict__ dst,
                                                                    int* __restrict__ src_lid,
@@ -518,7 +531,10 @@ __global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t
 {
   const int lane = threadIdx.x & 63;
   const int i    = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+  if (i >= n_.get()) return;
+  uint64_t random_seed;
+  int i_rng;
+  rng.resolve(i, random_seed, i_rng);
   const int64_t nid   = (int64_t)seeds[i];
   const int64_t start = row_ptr[nid];
   const int N         = (int)(row_ptr[nid + 1] - start);
@@ -531,9 +547,9 @@ __global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t
   if (N > 64 * KMAX) return;  // the workgroup kernel takes these (seed list built by the count kernel)
   uint32_t k[KMAX];
   {
-    Pcg32 ga = stream_generator(random_seed, i, 128, lane);
+    Pcg32 ga = stream_generator(random_seed, i_rng, 128, lane);
     Pcg32 gb = ga;
-    if (N > 64) gb = stream_generator(random_seed, i, 128, lane + 64);
+    if (N > 64) gb = stream_generator(random_seed, i_rng, 128, lane + 64);
 #pragma unroll
     for (int s = 0; s < KMAX; s++) {
       k[s] = 0u;  // below every real key (key_bits of any float, -inf and NaN included, is > 0)
@@ -596,6 +612,30 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
   WG_HIP_CHECK(hipGetLastError());
 }
 
+// Weighted hop over n seeds (live count n.get()).  M in 1..256: the one-wave kernel covers rows of up to kWaveRowCap
+// candidates, the persistent workgroup kernel the listed longer ones (long rows first: their tail then drains while the
+// wave kernel fills the GPU); otherwise (256-thread stream layout / sample-all) the workgroup kernel walks all seeds.
+// `slab` holds `blocks` slabs of slab_len keys (slab_len >= the longest row above kLdsKeys candidates).
+constexpr int kWeightedBlocks = 1024;
+
+template <typename SeedT, typename ColT, typename WeightT>
+void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const WeightT* weights, const SeedT* seeds, dev_count n,
+                            int M, rng_plan rng, const int* offsets, const int* big_list, int blocks, uint32_t* slab,
+                            int64_t slab_len, ColT* dst, int* lid, int64_t* gid, hipStream_t stream)
+{
+  if (n.host <= 0) return;
+  if (M <= 0 || M > 256) {
+    sample_weighted_kernel<SeedT, ColT, WeightT, 256, 256><<<std::max(blocks, 1), 256, 0, stream>>>(
+      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, nullptr);
+    return;
+  }
+  if (blocks > 0)
+    sample_weighted_kernel<SeedT, ColT, WeightT, 128, 512><<<blocks, 512, 0, stream>>>(
+      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, big_list);
+  sample_weighted_wave_kernel<SeedT, ColT, WeightT, kWaveRowCap / 64><<<ceil_div(n.host, 4), 256, 0, stream>>>(
+    row_ptr, col, weights, seeds, n, M, rng, offsets, dst, lid, gid);
+}
+
 // ------------------------------------------------------------------------------------------
 struct sample_args {
   wholememory_tensor_t row_ptr, col, weight, seeds, out_offsets;
@@ -640,32 +680,29 @@ void run(const sample_args& a, bool weighted)
   int* offsets           = static_cast<int*>(tensor_data(a.out_offsets));
   const WeightT* weights = weighted ? static_cast<const WeightT*>(tensor_data(a.weight)) : nullptr;
 
-  temp_buffer cnt_buf(a.env), scan_tmp(a.env), big_buf(a.env), list_buf(a.env);
-  int* cnt     = cnt_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT);
-  int* stmp    = scan_tmp.device<int>(scan_tmp_ints(n + 1), WHOLEMEMORY_DT_INT);
-  int* big_deg = (weighted && M > 0) ? big_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT) : nullptr;
-  // weighted, M <= 256: rows of up to kWaveRowCap candidates go to the one-wave kernel, the longer ones are listed
-  // (list[0] = count, list[1..] = seed indices) for the workgroup kernel
+  temp_buffer cnt_buf(a.env), scan_tmp(a.env), list_buf(a.env);
+  int* cnt  = cnt_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT);
+  int* stmp = scan_tmp.device<int>(scan_tmp_ints(n + 1), WHOLEMEMORY_DT_INT);
+  // weighted: list[0] = number of long rows, list[1..] = their seed indices, list[n+1] = longest row that needs a slab
   const bool wave_path = weighted && M > 0 && M <= 256;
-  int* big_list        = wave_path ? list_buf.device<int>(n + 1, WHOLEMEMORY_DT_INT) : nullptr;
-  int h_tot[3]         = {0, 0, 0};
+  int* big_list        = weighted ? list_buf.device<int>(n + 2, WHOLEMEMORY_DT_INT) : nullptr;
+  int h_tot[3]         = {0, 0, 0};  // total samples, long rows, longest slab row
 
-  if (wave_path) {
+  if (weighted) {
     WG_HIP_CHECK(hipMemsetAsync(big_list, 0, sizeof(int), stream));
+    WG_HIP_CHECK(hipMemsetAsync(big_list + n + 1, 0, sizeof(int), stream));
     if (n > 0)
-      sample_count_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(row_ptr, seeds, dev_count{n, nullptr}, M, cnt, big_deg,
-                                                                      kWaveRowCap, big_list + 1, big_list);
+      sample_count_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(
+        row_ptr, seeds, dev_count{n, nullptr}, M, cnt, nullptr, wave_path ? kWaveRowCap : 0, wave_path ? big_list : nullptr,
+        big_list + n + 1, kLdsKeys);
     WG_HIP_CHECK(hipGetLastError());
-    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[2], big_list, sizeof(int), hipMemcpyDeviceToHost, stream));
+    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[1], big_list, sizeof(int), hipMemcpyDeviceToHost, stream));
+    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[2], big_list + n + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
   } else {
-    sample_count_enqueue(row_ptr, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M, cnt, big_deg, stream);
+    sample_count_enqueue(row_ptr, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M, cnt, nullptr, stream);
   }
   exclusive_scan_i32(cnt, offsets, n, stmp, stream);
   WG_HIP_CHECK(hipMemcpyAsync(&h_tot[0], offsets + n, sizeof(int), hipMemcpyDeviceToHost, stream));
-  if (big_deg) {
-    exclusive_scan_i32(big_deg, big_deg, n, stmp, stream);
-    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[1], big_deg + n, sizeof(int), hipMemcpyDeviceToHost, stream));
-  }
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // the one unavoidable sync: output sizes
   const int total = h_tot[0];
 
@@ -675,19 +712,14 @@ void run(const sample_args& a, bool weighted)
   if (n == 0 || total == 0) return;
 
   if (weighted) {
+    const int rows_for_blocks = wave_path ? h_tot[1] : n;
+    const int blocks          = std::min(rows_for_blocks, kWeightedBlocks);
+    const int64_t slab_len    = std::max(h_tot[2], 1);
     temp_buffer key_buf(a.env);
-    uint32_t* keys = key_buf.device<uint32_t>(h_tot[1], WHOLEMEMORY_DT_INT);
-    if (!wave_path) {  // M > 256 (256-thread stream layout) or sample-all
-      sample_weighted_kernel<SeedT, ColT, WeightT, 256, 256><<<n, 256, 0, stream>>>(
-        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid, nullptr);
-    } else {
-      // long rows first: their one-workgroup-per-row tail then drains while the one-wave kernel fills the GPU
-      if (h_tot[2] > 0)
-        sample_weighted_kernel<SeedT, ColT, WeightT, 128, 512><<<h_tot[2], 512, 0, stream>>>(
-          row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, big_deg, keys, dst, lid, gid, big_list + 1);
-      sample_weighted_wave_kernel<SeedT, ColT, WeightT, kWaveRowCap / 64><<<ceil_div(n, 4), 256, 0, stream>>>(
-        row_ptr, col, weights, seeds, n, M, a.random_seed, offsets, dst, lid, gid);
-    }
+    uint32_t* slab = key_buf.device<uint32_t>(h_tot[2] > 0 ? (int64_t)blocks * slab_len : 1, WHOLEMEMORY_DT_INT);
+    weighted_sample_launch<SeedT, ColT, WeightT>(row_ptr, col, weights, seeds, dev_count{n, nullptr}, M,
+                                                 rng_plan{a.random_seed, nullptr, nullptr, nullptr}, offsets, big_list, blocks,
+                                                 slab, slab_len, dst, lid, gid, stream);
     WG_HIP_CHECK(hipGetLastError());
     WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
     return;
