@@ -216,6 +216,17 @@ void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64,
                             int64_t* edge_gid, hipStream_t stream);
 void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
                           int* big_deg, hipStream_t stream);
+// biased (A-Res) sampling, 0 < M <= 256: `big_list` (n.host + 1 ints) receives the rows too long for the one-wave
+// kernel; `slab` = kWeightedBlocks slabs of slab_len keys for the rows longer than kWeightedLdsKeys candidates
+// (slab_len >= the longest such row, e.g. the graph's maximum degree).  Weights FLOAT or DOUBLE.
+constexpr int kWeightedBlocks  = 1024;
+constexpr int kWeightedLdsKeys = 12288;
+void weighted_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
+                            int* big_list, hipStream_t stream);
+void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* weights, bool weights64,
+                             const void* seeds, bool seeds64, dev_count n, int M, rng_plan random_seed, const int* offsets,
+                             const int* big_list, uint32_t* slab, int64_t slab_len, void* dst, int* src_lid,
+                             int64_t* edge_gid, hipStream_t stream);
 // renumbering: table of `slots` (power of two >= 2*(T.host+E.host)) entries, slot_of[T.host+E.host],
 // rank[E.host+1], scan_tmp[scan_tmp_ints(E.host+1)].  unique_out may be NULL for `prepare`.
 int64_t append_unique_slots(int64_t capacity);

@@ -18,11 +18,12 @@ namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct hop_workspace {
-  size_t cnt, scan_tmp, nbr, keys, minpos, slot_of, rank, total;
-  int64_t slots;
+  size_t cnt, scan_tmp, nbr, keys, minpos, slot_of, rank, big_list, slab, total;
+  int64_t slots, slab_len;
 };
 
-hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool batched)
+// max_row_len > 0: biased hop — also the long-row list and the key slabs of the persistent workgroups
+hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool batched, int64_t max_row_len = 0)
 {
   hop_workspace w{};
   size_t off = 0;
@@ -40,11 +41,20 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
   w.minpos       = take(sizeof(int) * (size_t)w.slots);
   w.slot_of      = take(sizeof(int) * (size_t)(target_cap + edge_cap));
   w.rank         = take(sizeof(int) * (size_t)(edge_cap + 1));
+  if (max_row_len > 0) {
+    w.slab_len = max_row_len > kWeightedLdsKeys ? max_row_len : 1;
+    w.big_list = take(sizeof(int) * (size_t)(target_cap + 2));
+    w.slab     = take(sizeof(uint32_t) * (size_t)kWeightedBlocks * (size_t)w.slab_len);
+  }
   w.total        = off;
   return w;
 }
 
 struct hop_args {
+  // biased hop: per-CSR-slot weights (FLOAT | DOUBLE) and the graph's maximum degree (sizes the key slabs); null = uniform
+  const void* csr_weight  = nullptr;
+  bool weight64           = false;
+  int64_t max_row_len     = 0;
   // PyG-style walk: the sampled list (frontier) differs from the renumber target list; null = same list
   const void* sample_targets = nullptr;
   const int* n_sample_dev    = nullptr;
@@ -84,7 +94,8 @@ void run_hop(hop_args a)
   WG_REQUIRE_INPUT(a.target_cap + a.edge_cap < ((int64_t)1 << 30), "capacities too large for one call");
   const bool i64     = a.id_dtype == WHOLEMEMORY_DT_INT64;
   const bool batched = a.bv.target_batch != nullptr;
-  hop_workspace w    = plan(std::max(a.target_cap, s_cap), a.edge_cap, i64 ? 8 : 4, batched);
+  WG_REQUIRE_INPUT(a.csr_weight == nullptr || a.max_row_len > 0, "a biased hop needs max_row_len (the graph's maximum degree)");
+  hop_workspace w    = plan(std::max(a.target_cap, s_cap), a.edge_cap, i64 ? 8 : 4, batched, a.csr_weight ? a.max_row_len : 0);
   WG_REQUIRE_INPUT(a.workspace_bytes >= w.total, "workspace too small: need %zu bytes", w.total);
   WG_REQUIRE_INPUT((reinterpret_cast<uintptr_t>(a.workspace) & 255) == 0, "workspace must be 256-byte aligned");
   char* base    = static_cast<char*>(a.workspace);
@@ -99,10 +110,19 @@ void run_hop(hop_args a)
 
   dev_count T{(int)a.target_cap, a.n_targets_dev};
   dev_count S{(int)s_cap, s_n_dev};
-  sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st);
-  exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
-  uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
-                         a.edge_gid, st);
+  if (a.csr_weight != nullptr) {
+    int* big_list = reinterpret_cast<int*>(base + w.big_list);
+    weighted_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, big_list, st);
+    exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
+    weighted_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, a.csr_weight, a.weight64, s_targets, i64, S, a.M, a.rng, a.offsets,
+                            big_list, reinterpret_cast<uint32_t*>(base + w.slab), w.slab_len, nbr, a.center_row, a.edge_gid,
+                            st);
+  } else {
+    sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st);
+    exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
+    uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
+                           a.edge_gid, st);
+  }
   dev_count E{(int)a.edge_cap, a.offsets + s_cap};
   batch_view bv   = a.bv;
   bv.edge_row     = a.center_row;
@@ -116,6 +136,14 @@ void run_hop(hop_args a)
 }  // namespace wgamd
 
 extern "C" {
+
+size_t wgamd_sample_hop_weighted_workspace_bytes(int64_t target_cap, int64_t edge_cap, wholememory_dtype_t id_dtype,
+                                                 int64_t max_row_len)
+{
+  if (target_cap < 0 || edge_cap < 0 || max_row_len <= 0) return 0;
+  size_t idb = id_dtype == WHOLEMEMORY_DT_INT64 ? 8 : 4;
+  return wgamd::plan(target_cap, edge_cap, idb, true, max_row_len).total;
+}
 
 size_t wgamd_sample_hop_workspace_bytes(int64_t target_cap, int64_t edge_cap, wholememory_dtype_t id_dtype)
 {
@@ -200,6 +228,11 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
     a.offsets = p->offsets; a.neighbor_row = p->neighbor_row_scratch; a.center_row = p->center_row_scratch;
     a.edge_gid = p->edge_gid; a.edge_cap = p->edge_cap; a.unique = p->nodes_out; a.counts_dev = p->counts_dev;
     a.workspace = p->workspace; a.workspace_bytes = p->workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
+    if (p->csr_weight != nullptr) {
+      WG_REQUIRE_INPUT(p->weight_dtype == WHOLEMEMORY_DT_FLOAT || p->weight_dtype == WHOLEMEMORY_DT_DOUBLE,
+                       "csr_weight must be FLOAT or DOUBLE");
+      a.csr_weight = p->csr_weight; a.weight64 = p->weight_dtype == WHOLEMEMORY_DT_DOUBLE; a.max_row_len = p->max_row_len;
+    }
     WG_REQUIRE_INPUT(a.neighbor_row != nullptr, "neighbor_row_scratch is NULL");
     run_hop(a);
   });

@@ -344,7 +344,7 @@ __device__ __forceinline__ uint32_t key_bits(float k)
 // draw comes back 0, probability 2^-64) — and hops T/B keys at a time with a table jump, so a 100k-candidate row is
 // keyed by 1024 threads instead of 128.  A thread that does see a zero draw raises a flag and the row is redone the
 // sequential way, which keeps the result exact.  Keys live in LDS when the row fits (kLdsKeys), else in scratch.
-constexpr int kLdsKeys = 12288;  // 48 KB of the 64 KB static LDS a workgroup may declare
+constexpr int kLdsKeys = kWeightedLdsKeys;  // 48 KB of the 64 KB static LDS a workgroup may declare
 
 template <typename SeedT, typename ColT, typename WeightT, int B, int T>
 __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __restrict__ row_ptr,
@@ -616,8 +616,6 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
 // candidates, the persistent workgroup kernel the listed longer ones (long rows first: their tail then drains while the
 // wave kernel fills the GPU); otherwise (256-thread stream layout / sample-all) the workgroup kernel walks all seeds.
 // `slab` holds `blocks` slabs of slab_len keys (slab_len >= the longest row above kLdsKeys candidates).
-constexpr int kWeightedBlocks = 1024;
-
 template <typename SeedT, typename ColT, typename WeightT>
 void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const WeightT* weights, const SeedT* seeds, dev_count n,
                             int M, rng_plan rng, const int* offsets, const int* big_list, int blocks, uint32_t* slab,
@@ -753,6 +751,40 @@ void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds6
   else
     sample_count_kernel<int32_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
       row_ptr, static_cast<const int32_t*>(seeds), n, M, cnt, big_deg);
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+void weighted_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
+                            int* big_list, hipStream_t stream)
+{
+  if (n.host <= 0) return;
+  WG_HIP_CHECK(hipMemsetAsync(big_list, 0, sizeof(int), stream));
+  if (seeds64)
+    sample_count_kernel<int64_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(row_ptr, static_cast<const int64_t*>(seeds), n, M,
+                                                                           cnt, nullptr, kWaveRowCap, big_list);
+  else
+    sample_count_kernel<int32_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(row_ptr, static_cast<const int32_t*>(seeds), n, M,
+                                                                           cnt, nullptr, kWaveRowCap, big_list);
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* weights, bool weights64,
+                             const void* seeds, bool seeds64, dev_count n, int M, rng_plan random_seed, const int* offsets,
+                             const int* big_list, uint32_t* slab, int64_t slab_len, void* dst, int* src_lid,
+                             int64_t* edge_gid, hipStream_t stream)
+{
+  WG_REQUIRE_INPUT(M > 0 && M <= 256, "the no-sync biased hop needs 0 < fan-out <= 256");
+#define WG_W(ST, CT, WT)                                                                                                  \
+  weighted_sample_launch<ST, CT, WT>(row_ptr, static_cast<const CT*>(col), static_cast<const WT*>(weights),              \
+                                     static_cast<const ST*>(seeds), n, M, random_seed, offsets, big_list, kWeightedBlocks, \
+                                     slab, slab_len, static_cast<CT*>(dst), src_lid, edge_gid, stream)
+#define WG_WW(ST, CT) do { if (weights64) WG_W(ST, CT, double); else WG_W(ST, CT, float); } while (0)
+  if (seeds64 && col64) WG_WW(int64_t, int64_t);
+  else if (seeds64) WG_WW(int64_t, int32_t);
+  else if (col64) WG_WW(int32_t, int64_t);
+  else WG_WW(int32_t, int32_t);
+#undef WG_WW
+#undef WG_W
   WG_HIP_CHECK(hipGetLastError());
 }
 

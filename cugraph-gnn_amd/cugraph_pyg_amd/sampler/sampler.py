@@ -311,27 +311,33 @@ class NeighborSampler:
         self.graph, self.fanout, self.biased, self.disjoint = graph, [int(f) for f in fanout], biased, bool(disjoint)
         self.local_seeds_per_call = local_seeds_per_call
         self._walks = {}
+        self._positive_weights = None
 
     def _call_group_walk(self, batch_size: int, n_batches: int):
         from wholegraph_amd.fused import PygNoSyncWalk
         key = (batch_size, n_batches)
         if key not in self._walks:
-            self._walks[key] = PygNoSyncWalk(self.graph.row_ptr, self.graph.col, batch_size, self.fanout, n_batches)
+            self._walks[key] = PygNoSyncWalk(self.graph.row_ptr, self.graph.col, batch_size, self.fanout, n_batches,
+                                             csr_weight=self.graph.weight if self.biased else None)
         return self._walks[key]
 
     def sample_batches(self, seeds: torch.Tensor, batch_size: int, random_state: int, seed_time=None) -> Iterator:
         """Yields ``(batch index, (node, row, col, edge, num_sampled_nodes, num_sampled_edges))``.
 
-        Uniform sampling with positive fan-outs runs in CALL GROUPS (``local_seeds_per_call`` seeds per
-        launch sequence, default 16 mini-batches — the reference splits its seeds the same way,
-        sampler/distributed_sampler.py:391-410) on the no-host-sync kernels; everything else (biased,
-        fan-out -1, the ragged last batch) goes through the one-batch-at-a-time C-ABI ops.  Both routes
-        return identical results (tests/test_gpu_pyg_loader.py)."""
+        Uniform and biased (strictly positive weights, fan-outs <= 256) sampling with positive fan-outs runs in CALL
+        GROUPS (``local_seeds_per_call`` seeds per launch sequence, default 16 mini-batches — the reference splits its
+        seeds the same way, sampler/distributed_sampler.py:391-410) on the no-host-sync kernels; everything else
+        (zero weights, fan-out -1, disjoint / temporal, the ragged last batch) goes through the one-batch-at-a-time C-ABI
+        ops.  Both routes return identical results (tests/test_gpu_pyg_loader.py)."""
         n = seeds.shape[0]
         if self.temporal and seed_time is None:
             raise ValueError("temporal sampling needs input_time")
-        fast = (not self.biased) and (not self.disjoint) and (not self.temporal) and all(
-            f > 0 for f in self.fanout) and seeds.is_cuda
+        # biased call groups need strictly positive weights (the kernel copies short rows whole, zero-weight edges
+        # included, and libcugraph never returns those: the one-batch path filters them) and fan-outs <= 256
+        if self.biased and self._positive_weights is None:
+            self._positive_weights = bool((self.graph.weight > 0).all())
+        biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for f in self.fanout))
+        fast = biased_ok and (not self.disjoint) and (not self.temporal) and all(f > 0 for f in self.fanout) and seeds.is_cuda
         n_full = n // batch_size if fast else 0
         per_call = self.local_seeds_per_call or 16 * batch_size
         G = max(1, per_call // batch_size)

@@ -226,7 +226,8 @@ class _PygHop(_ct.Structure):
                 ("frontier_out", _ct.c_void_p), ("frontier_out_batch", _ct.c_void_p),
                 ("frontier_out_seg", _ct.c_void_p), ("frontier_out_local0", _ct.c_void_p),
                 ("counts_dev", _ct.c_void_p), ("neighbor_row_scratch", _ct.c_void_p),
-                ("center_row_scratch", _ct.c_void_p), ("workspace", _ct.c_void_p), ("workspace_bytes", _ct.c_size_t)]
+                ("center_row_scratch", _ct.c_void_p), ("workspace", _ct.c_void_p), ("workspace_bytes", _ct.c_size_t),
+                ("csr_weight", _ct.c_void_p), ("weight_dtype", _ct.c_int), ("max_row_len", _ct.c_int64)]
 
 
 @dataclass
@@ -275,9 +276,18 @@ class PygNoSyncWalk:
     counterpart of one ``pylibcugraph.homogeneous_uniform_neighbor_sample`` call over many batches
     (SURVEY.md §8 row a14)."""
 
-    def __init__(self, csr_row_ptr, csr_col_ind, batch_size: int, fanout: List[int], n_batches: int = 1):
+    def __init__(self, csr_row_ptr, csr_col_ind, batch_size: int, fanout: List[int], n_batches: int = 1,
+                 csr_weight: torch.Tensor = None):
+        """``csr_weight`` (float32 | float64, one per CSR slot): BIASED sampling — every hop is then what
+        ``wholegraph_csr_weighted_sample_without_replacement`` draws (fan-outs <= 256)."""
         assert csr_row_ptr.is_cuda and csr_col_ind.is_cuda and csr_col_ind.dtype in (torch.int32, torch.int64)
         assert all(0 < f for f in fanout), "the no-sync walk needs positive fan-outs"
+        self.weight, self.max_row_len = None, 0
+        if csr_weight is not None:
+            assert csr_weight.is_cuda and csr_weight.dtype in (torch.float32, torch.float64) and all(f <= 256 for f in fanout)
+            assert csr_weight.shape[0] == csr_col_ind.shape[0]
+            self.weight = csr_weight.contiguous()
+            self.max_row_len = max(int((csr_row_ptr[1:] - csr_row_ptr[:-1]).max()), 1) if csr_row_ptr.shape[0] > 1 else 1
         self.row_ptr, self.col = csr_row_ptr, csr_col_ind
         self.id_dtype, self.wm_dtype = csr_col_ind.dtype, torch_dtype_to_wm(csr_col_ind.dtype)
         self.G, self.B, self.fanout = int(n_batches), int(batch_size), [int(f) for f in fanout]
@@ -291,8 +301,12 @@ class PygNoSyncWalk:
             n, f = n + f * m, f * m
         assert n < (1 << 30), "call group too large: lower n_batches"
         lib = L.lib()
-        ws = max(lib.wgamd_sample_hop_workspace_bytes(max(nc, fc), ec, self.wm_dtype)
-                 for nc, fc, ec in zip(self.node_caps, self.frontier_caps, self.edge_caps))
+        if self.weight is None:
+            ws = max(lib.wgamd_sample_hop_workspace_bytes(max(nc, fc), ec, self.wm_dtype)
+                     for nc, fc, ec in zip(self.node_caps, self.frontier_caps, self.edge_caps))
+        else:
+            ws = max(lib.wgamd_sample_hop_weighted_workspace_bytes(max(nc, fc), ec, self.wm_dtype, self.max_row_len)
+                     for nc, fc, ec in zip(self.node_caps, self.frontier_caps, self.edge_caps))
         self.workspace = torch.empty(ws + 256, dtype=torch.uint8, device=dev)
         self.ws_off, self.ws_bytes, self.dev = (-self.workspace.data_ptr()) % 256, ws, dev
         self.seed_seg = (torch.arange(self.G + 1, dtype=torch.int32, device=dev) * self.B).contiguous()
@@ -331,7 +345,9 @@ class PygNoSyncWalk:
                         nodes_out.data_ptr(), nodes_out_batch.data_ptr(), nodes_out_seg.data_ptr(),
                         f_out.data_ptr(), f_out_batch.data_ptr(), f_out_seg.data_ptr(), f_out_l0.data_ptr(),
                         res.counts[k].data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(),
-                        self.workspace.data_ptr() + self.ws_off, self.ws_bytes)
+                        self.workspace.data_ptr() + self.ws_off, self.ws_bytes,
+                        None if self.weight is None else self.weight.data_ptr(),
+                        0 if self.weight is None else torch_dtype_to_wm(self.weight.dtype), self.max_row_len)
             L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
             res.offsets.append(offsets)
             res.row_local.append(row_l)

@@ -133,6 +133,8 @@ wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr,
  * wholegraph_csr_unweighted_sample_without_replacement followed by graph_append_unique.
  * workspace: wgamd_sample_hop_workspace_bytes(target_cap, edge_cap, id_dtype) bytes. */
 size_t wgamd_sample_hop_workspace_bytes(int64_t target_cap, int64_t edge_cap, wholememory_dtype_t id_dtype);
+size_t wgamd_sample_hop_weighted_workspace_bytes(int64_t target_cap, int64_t edge_cap, wholememory_dtype_t id_dtype,
+                                                 int64_t max_row_len);
 
 wholememory_error_code_t wgamd_sample_hop_nosync(const int64_t* csr_row_ptr,
                                                  const void* csr_col,
@@ -252,6 +254,14 @@ typedef struct wgamd_pyg_hop_t {
   int* center_row_scratch;
   void* workspace;
   size_t workspace_bytes;
+  /* biased hop (NULL = uniform): weight of every CSR slot, FLOAT | DOUBLE; fan-out <= 256; max_row_len = the graph's
+   * maximum degree (sizes the key slabs); workspace then = wgamd_sample_hop_weighted_workspace_bytes(...).  Rows with at
+   * most max_sample_count candidates are copied whole, zero-weight edges included (the reference's kernel does the same:
+   * weighted_sample_without_replacement_func.cuh:592-647).  Same results as
+   * wholegraph_csr_weighted_sample_without_replacement + graph_append_unique per mini-batch. */
+  const void* csr_weight;
+  wholememory_dtype_t weight_dtype;
+  int64_t max_row_len;
 } wgamd_pyg_hop_t;
 
 wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, void* stream);

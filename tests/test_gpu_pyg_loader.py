@@ -677,3 +677,42 @@ def test_hetero_call_group_walk_equals_single_batch_path(hiplib, G):
             assert torch.equal(row[et], ref[1][et]) and torch.equal(col[et], ref[2][et]), (b, et)
             assert torch.equal(edge[et], ref[3][et]), (b, et)
             assert list(ne[et]) == list(ref[5][et]), (b, et)
+
+
+@pytest.mark.parametrize("G,wdtype", [(1, "float32"), (4, "float32"), (6, "float64")])
+def test_biased_call_group_walk_equals_single_batch_path(hiplib, G, wdtype):
+    """The biased no-sync hop (A-Res keys inside wgamd_sample_hop_pyg_nosync) gives every mini-batch of a call group what
+    the one-batch path draws through wholegraph_csr_weighted_sample_without_replacement + graph_append_unique — incl. rows
+    on both sides of every kernel boundary (one-wave kernel, long-row workgroups with LDS / slab keys)."""
+    import torch
+    from cugraph_pyg_amd.data.graph_store import CSRGraph
+    from cugraph_pyg_amd.sampler.sampler import NeighborSampler, neighbor_sample
+    rng = np.random.default_rng(G)
+    V = 4000
+    deg = rng.integers(0, 60, V)
+    deg[:6] = [0, 1, 1024, 1025, 13000, 3000]         # hubs: every path of the biased kernels
+    row_ptr = np.zeros(V + 1, np.int64)
+    row_ptr[1:] = np.cumsum(deg)
+    E = int(row_ptr[-1])
+    col = rng.integers(0, V, E)
+    col[rng.integers(0, E, E // 10)] = rng.integers(0, 6, E // 10)   # make the hubs popular neighbours
+    w = (rng.random(E) + 0.05).astype(wdtype)
+    graph = CSRGraph(row_ptr=torch.from_numpy(row_ptr).cuda(), col=torch.from_numpy(col).cuda(),
+                     edge_id=torch.arange(E, device="cuda"), edge_type=None, weight=torch.from_numpy(w).cuda(), num_vertices=V)
+    B = 48
+    seeds = torch.from_numpy(np.concatenate([np.arange(6), rng.permutation(V)[:B * 7 + 5 - 6]])).cuda()
+    smp = NeighborSampler(graph, fanout=[8, 5], biased=True, local_seeds_per_call=G * B)
+    got = dict(smp.sample_batches(seeds, B, 77))
+    assert len(got) == 8 and smp._positive_weights is True and smp._walks
+    for b in range(8):
+        ref = neighbor_sample(graph, seeds[b * B:(b + 1) * B], [8, 5], 77 + b, biased=True)
+        for a_, r_ in zip(got[b][:4], ref[:4]):
+            assert torch.equal(a_, r_), b
+        assert list(got[b][4]) == list(ref[4]) and list(got[b][5]) == list(ref[5])
+    # a zero weight anywhere sends the sampler to the one-batch path (libcugraph never returns zero-weight edges)
+    w0 = torch.from_numpy(w).cuda()
+    w0[5] = 0
+    smp0 = NeighborSampler(CSRGraph(row_ptr=graph.row_ptr, col=graph.col, edge_id=graph.edge_id, edge_type=None, weight=w0,
+                                    num_vertices=V), fanout=[8, 5], biased=True, local_seeds_per_call=G * B)
+    list(smp0.sample_batches(seeds[:B], B, 77))
+    assert smp0._positive_weights is False and not smp0._walks
