@@ -242,6 +242,7 @@ class HeteroNeighborSampler:
                  local_seeds_per_call: Optional[int] = None, **_ignored):
         self.local_seeds_per_call = local_seeds_per_call
         self._walks = {}
+        self._positive_weights = None
         if with_replacement or disjoint:
             raise NotImplementedError("heterogeneous with_replacement / disjoint sampling are not implemented")
         if temporal and any(g.time is None for g in graphs.values()):
@@ -259,7 +260,7 @@ class HeteroNeighborSampler:
         from wholegraph_amd.fused import HeteroPygWalk
         key = (batch_size, n_batches)
         if key not in self._walks:
-            self._walks[key] = HeteroPygWalk(self.graphs, batch_size, self.fanout, n_batches)
+            self._walks[key] = HeteroPygWalk(self.graphs, batch_size, self.fanout, n_batches, biased=self.biased)
         return self._walks[key]
 
     def sample_batches(self, seed_type, seeds, batch_size, random_state, seed_time=None):
@@ -269,7 +270,10 @@ class HeteroNeighborSampler:
         if self.temporal and seed_time is None:
             raise ValueError("temporal sampling needs input_time")
         n = seeds.shape[0]
-        fast = (not self.biased) and (not self.temporal) and seeds.is_cuda and all(
+        if self.biased and self._positive_weights is None:   # see NeighborSampler.sample_batches
+            self._positive_weights = all(bool((g.weight > 0).all()) for g in self.graphs.values())
+        biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for v in self.fanout.values() for f in v))
+        fast = biased_ok and (not self.temporal) and seeds.is_cuda and all(
             g.col.dtype == torch.int64 for g in self.graphs.values())
         n_full = n // batch_size if fast else 0
         G = max(1, (self.local_seeds_per_call or 16 * batch_size) // batch_size)

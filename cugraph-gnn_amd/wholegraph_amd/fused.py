@@ -371,7 +371,8 @@ class HeteroPygWalk:
     ``pylibcugraph.heterogeneous_uniform_neighbor_sample`` call over many batches.
     No host synchronisation inside ``run``; sizes are read once in ``finalize_batches``."""
 
-    def __init__(self, graphs, batch_size: int, fanout, n_batches: int):
+    def __init__(self, graphs, batch_size: int, fanout, n_batches: int, biased: bool = False):
+        self.biased = bool(biased)
         self.etypes = sorted(graphs.keys())
         self.graphs = graphs
         self.G, self.B = int(n_batches), int(batch_size)
@@ -391,9 +392,19 @@ class HeteroPygWalk:
         self.seed_batch = torch.arange(self.G, dtype=torch.int32, device=dev).repeat_interleave(self.B).contiguous()
         self.zeros_g = torch.zeros(self.G, dtype=torch.int32, device=dev)
         self.zeros_g1 = torch.zeros(self.G + 1, dtype=torch.int32, device=dev)
+        self.max_row_len = {}
+        if self.biased:   # per edge type: weights + maximum degree (sizes the key slabs of the biased hop)
+            for et in self.etypes:
+                g = graphs[et]
+                assert g.weight is not None and g.weight.dtype in (torch.float32, torch.float64)
+                assert all(f <= 256 for f in self.fanout[et])
+                self.max_row_len[et] = max(int((g.row_ptr[1:] - g.row_ptr[:-1]).max()), 1) if g.row_ptr.shape[0] > 1 else 1
 
-    def _workspace(self, node_cap, edge_cap):
-        need = L.lib().wgamd_sample_hop_workspace_bytes(node_cap, edge_cap, self.wm_dtype)
+    def _workspace(self, node_cap, edge_cap, max_row_len=0):
+        if max_row_len > 0:
+            need = L.lib().wgamd_sample_hop_weighted_workspace_bytes(node_cap, edge_cap, self.wm_dtype, max_row_len)
+        else:
+            need = L.lib().wgamd_sample_hop_workspace_bytes(node_cap, edge_cap, self.wm_dtype)
         if self._ws is None or self._ws.numel() < need + 256:
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.dev)
         off = (-self._ws.data_ptr()) % 256
@@ -458,7 +469,8 @@ class HeteroPygWalk:
                 f_out = torch.empty(ec, dtype=torch.int64, device=dev)
                 f_out_batch, f_out_seg, f_out_l0 = torch.empty(ec, **i32), torch.empty(G + 1, **i32), torch.empty(G, **i32)
                 counts = torch.empty(2, **i32)
-                ws_ptr, ws_bytes = self._workspace(max(nc, fc), ec)
+                mrl = self.max_row_len.get(et, 0)
+                ws_ptr, ws_bytes = self._workspace(max(nc, fc), ec, mrl)
                 p = _PygHop(g.row_ptr.data_ptr(), g.col.data_ptr(), self.wm_dtype, G, m,
                             rs[h * len(self.etypes) + ti].data_ptr(),
                             st["nodes"].data_ptr(), st["batch"].data_ptr(), st["seg"].data_ptr(), nc,
@@ -466,7 +478,9 @@ class HeteroPygWalk:
                             offsets.data_ptr(), row_l.data_ptr(), col_l.data_ptr(), gid.data_ptr(), ec,
                             nodes_out.data_ptr(), nodes_out_batch.data_ptr(), nodes_out_seg.data_ptr(),
                             f_out.data_ptr(), f_out_batch.data_ptr(), f_out_seg.data_ptr(), f_out_l0.data_ptr(),
-                            counts.data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(), ws_ptr, ws_bytes)
+                            counts.data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(), ws_ptr, ws_bytes,
+                            g.weight.data_ptr() if self.biased else None,
+                            torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl)
                 L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
                 keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
                          st["nodes"], st["batch"], st["seg"]]

@@ -644,8 +644,8 @@ def test_temporal_sampling_respects_fanout_and_order_on_random_graph(hiplib):
             off += cnt
 
 
-@pytest.mark.parametrize("G", [1, 3, 8])
-def test_hetero_call_group_walk_equals_single_batch_path(hiplib, G):
+@pytest.mark.parametrize("G,biased", [(1, False), (3, False), (8, False), (4, True)])
+def test_hetero_call_group_walk_equals_single_batch_path(hiplib, G, biased):
     """HeteroPygWalk (one batched no-sync launch sequence per hop and edge type for G mini-batches) returns, batch by
     batch, exactly what hetero_neighbor_sample computes for that batch alone through the C-ABI ops."""
     import torch
@@ -657,18 +657,23 @@ def test_hetero_call_group_walk_equals_single_batch_path(hiplib, G):
            ("paper", "has_topic", "field"): 3000, ("author", "affiliated_with", "institution"): 2000,
            ("paper", "rev_writes", "author"): 8000, ("field", "rev_has_topic", "paper"): 3000}
     gs = GraphStore()
+    from cugraph_pyg_amd.data import FeatureStore
+    fs = FeatureStore()
     for (s, r, d), m in rel.items():
         gs[(s, r, d), "coo", False, (n[s], n[d])] = torch.from_numpy(np.stack([rng.integers(0, n[s], m), rng.integers(0, n[d], m)]))
+        fs[(s, r, d), "w", None] = torch.from_numpy(rng.random(m).astype(np.float32) + 0.1)
+    if biased:
+        gs._set_weight_attr((fs, "w"))
     fanout = {et: [4, 3, 2] for et in rel}
     fanout[("field", "rev_has_topic", "paper")] = [2, 0, 1]          # a zero fan-out in the middle
     fanout[("author", "affiliated_with", "institution")] = [3, 3, 3]  # destination type never reached from papers
     B = 32
     seeds = torch.from_numpy(rng.permutation(n["paper"])[:B * 8 + 5]).cuda()
-    smp = HeteroNeighborSampler(gs._hetero_graphs, fanout, local_seeds_per_call=G * B)
+    smp = HeteroNeighborSampler(gs._hetero_graphs, fanout, biased=biased, local_seeds_per_call=G * B)
     got = dict(smp.sample_batches("paper", seeds, B, 1234))
-    assert len(got) == 9
+    assert len(got) == 9 and smp._walks
     for b in range(9):
-        ref = hetero_neighbor_sample(gs._hetero_graphs, "paper", seeds[b * B:(b + 1) * B], smp.fanout, 1234 + b)
+        ref = hetero_neighbor_sample(gs._hetero_graphs, "paper", seeds[b * B:(b + 1) * B], smp.fanout, 1234 + b, biased)
         node, row, col, edge, nn, ne = got[b]
         for t in n:
             assert torch.equal(node[t], ref[0][t]), (b, t)
