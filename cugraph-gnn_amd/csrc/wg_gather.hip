@@ -18,6 +18,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "wg_common.hpp"
 
 namespace wgamd {
@@ -179,7 +181,8 @@ inline int grid_for(int64_t n_rows, int log2_lanes, int rows_per_group)
   int64_t groups_per_block = 256 >> log2_lanes;
   int64_t blocks           = (n_rows + groups_per_block * rows_per_group - 1) / (groups_per_block * rows_per_group);
   // memory-bound: cap at 8 workgroups per CU and grid-stride the rest
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  static const int per_cu = getenv("WGAMD_GATHER_WG_PER_CU") ? atoi(getenv("WGAMD_GATHER_WG_PER_CU")) : 8;
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
