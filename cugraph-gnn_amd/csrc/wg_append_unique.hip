@@ -254,6 +254,106 @@ add_self_loop_kernel(const int* __restrict__ row_ptr, const int* __restrict__ co
   for (int j = lane; j <= e - s; j += 64) out_col[s + row + j] = j == 0 ? row : col[s + j - 1];
 }
 
+// ---- packed table (call groups with a known id bound) ----------------------------------------------------------
+// One 64-bit word per slot = [ batch | id | first position ], empty = all ones.  Inserting needs ONE memory-side atomic for
+// a first occurrence (CAS empty -> word) and usually NONE for a repeat (positions are inserted roughly in increasing order,
+// so the word read while probing already holds a smaller position; otherwise one atomicMin on the word, which keeps the
+// key bits because they are equal) — against CAS + atomicMin on two arrays per key for the general table — and the slot is
+// 8 instead of 12 bytes.
+struct packed_layout {
+  int pos_bits, id_bits;
+  __host__ __device__ unsigned long long pos_mask() const { return (1ull << pos_bits) - 1ull; }
+};
+
+inline int bits_for(uint64_t v)  // smallest b with v < 2^b
+{
+  int b = 0;
+  while (b < 64 && (v >> b) != 0) b++;
+  return b;
+}
+
+inline bool packed_layout_for(int64_t capacity_positions, int G, int64_t id_bound, packed_layout& out)
+{
+  if (id_bound <= 0 || G < 1) return false;
+  out.pos_bits = bits_for((uint64_t)capacity_positions);      // positions are < capacity, so never all ones
+  out.id_bits  = bits_for((uint64_t)(id_bound - 1));
+  const int batch_bits = bits_for((uint64_t)(G - 1));
+  return out.pos_bits + out.id_bits + batch_bits <= 63;
+}
+
+__global__ void __launch_bounds__(256)
+table_clear_packed_kernel(unsigned long long* table, int64_t capacity_slots, dev_count T_, dev_count E_)
+{
+  const int64_t slots  = (int64_t)live_slot_count(T_.get() + E_.get(), capacity_slots);
+  const int64_t tid    = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int4 fill      = make_int4(-1, -1, -1, -1);
+  int4* t4             = reinterpret_cast<int4*>(table);
+  for (int64_t i = tid; i < (slots + 1) / 2; i += stride) t4[i] = fill;
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256)
+table_insert_packed_kernel(const KeyT* __restrict__ targets, dev_count T_, const KeyT* __restrict__ neighbors, dev_count E_,
+                           batch_view bv, unsigned long long* table, int64_t capacity_slots, packed_layout lay,
+                           int* __restrict__ slot_of)
+{
+  const int T = T_.get(), E = E_.get();
+  const uint32_t slots = live_slot_count(T + E, capacity_slots);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= T + E) return;
+  const KeyT id = p < T ? targets[p] : neighbors[p - T];
+  const unsigned long long key  = ((unsigned long long)batch_of(bv, p, T) << lay.id_bits) | (unsigned long long)id;
+  const unsigned long long word = (key << lay.pos_bits) | (unsigned long long)p;
+  const unsigned long long kEmpty = ~0ull;
+  uint32_t h = slot_for(hash_key(key), slots);
+  while (true) {
+    // device-scope load: the slot is only ever changed by memory-side atomics, a stale L2 line must not be trusted
+    unsigned long long cur = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kEmpty) {
+      cur = atomicCAS(table + h, kEmpty, word);
+      if (cur == kEmpty) break;  // the slot is ours, with our position
+    }
+    if ((cur >> lay.pos_bits) == key) {
+      if (word < cur) atomicMin(table + h, word);  // same key bits: the minimum is the smaller position
+      break;
+    }
+    h = h + 1 == slots ? 0u : h + 1;
+  }
+  slot_of[p] = (int)h;
+}
+
+__global__ void __launch_bounds__(256)
+first_flag_packed_kernel(const unsigned long long* __restrict__ table, int* __restrict__ slot_of, dev_count T_, dev_count E_,
+                         packed_layout lay, int* __restrict__ flag)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int E = E_.get();
+  if (e >= E_.host || e >= (E / kScanTile + 1) * kScanTile) return;
+  const int T = T_.get();
+  int first = -1;
+  if (e < E) {
+    first = (int)(__hip_atomic_load(table + slot_of[T + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & lay.pos_mask());
+    slot_of[T + e] = first;
+  }
+  flag[e] = (first == T + e) ? 1 : 0;
+}
+
+template <typename KeyT>
+void prepare_packed_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, void* keys,
+                      int64_t slots, packed_layout lay, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
+{
+  auto* table = static_cast<unsigned long long*>(keys);
+  const int P = T.host + E.host;
+  table_clear_packed_kernel<<<(int)std::min<int64_t>(ceil_div(slots, 1024), 4096), 256, 0, stream>>>(table, slots, T, E);
+  if (P > 0)
+    table_insert_packed_kernel<KeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, table, slots, lay,
+                                                                           slot_of);
+  if (E.host > 0) first_flag_packed_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(table, slot_of, T, E, lay, rank);
+  WG_HIP_CHECK(hipGetLastError());
+  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);
+}
+
 template <typename KeyT, typename TableKeyT>
 void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, TableKeyT* keys,
                int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
@@ -283,6 +383,16 @@ void append_unique_prepare_enqueue(const void* targets, dev_count T, const void*
                                    int* scan_tmp, hipStream_t stream)
 {
   const bool batched = bv.target_batch != nullptr;
+  packed_layout lay{};
+  if (batched && packed_layout_for((int64_t)T.host + E.host, bv.G, bv.id_bound, lay)) {
+    if (ids64)
+      prepare_packed_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv, keys,
+                                slots, lay, slot_of, rank, scan_tmp, stream);
+    else
+      prepare_packed_t<int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv, keys,
+                                slots, lay, slot_of, rank, scan_tmp, stream);
+    return;
+  }
   if (ids64)
     prepare_t<int64_t, int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv,
                                 static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);

@@ -238,6 +238,8 @@ struct batch_view {
   const int* edge_row;      // [E]   target row of every sampled edge (needed when G > 1)
   const int* edge_offsets;  // [T+1] sample offsets (edge_seg[b] = edge_offsets[target_seg[b]])
   int G;
+  int64_t id_bound;         // ids are < id_bound (e.g. the vertex count); 0 = unknown.  With G > 1 and a bound the renumber
+                            // table packs (batch, id, first position) into ONE 64-bit word per slot when they fit
   int* unique_batch;        // out [T+E] batch of every unique entry  (nullable)
   int* unique_seg;          // out [G+1] first unique entry of every batch (nullable)
   // PyG-style walk ("expand only the vertices discovered by the previous hop"): the SAMPLED list

@@ -179,7 +179,7 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(
   const int* target_batch, const int* target_seg, int n_batches, int64_t target_cap, int max_sample_count,
   const unsigned long long* random_seeds_dev, int* offsets, int* neighbor_row, int* center_row, int64_t* edge_gid,
   int64_t edge_cap, void* unique, int* unique_batch, int* unique_seg, int* counts_dev, void* workspace,
-  size_t workspace_bytes, void* stream)
+  size_t workspace_bytes, int64_t n_vertices, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_sample_hop_batched_nosync", [&] {
@@ -193,6 +193,7 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(
     a.target_cap = target_cap; a.M = max_sample_count;
     a.rng = rng_plan{0, random_seeds_dev, target_batch, target_seg};
     a.bv.target_batch = target_batch; a.bv.target_seg = target_seg; a.bv.G = n_batches;
+    a.bv.id_bound = n_vertices > 0 ? n_vertices : 0;
     a.bv.unique_batch = unique_batch; a.bv.unique_seg = unique_seg;
     a.offsets = offsets; a.neighbor_row = neighbor_row; a.center_row = center_row; a.edge_gid = edge_gid;
     a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
@@ -220,6 +221,7 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
     a.M = p->max_sample_count;
     a.rng = rng_plan{0, p->random_seeds_dev, p->frontier_batch, p->frontier_seg};
     a.bv.target_batch = p->node_batch; a.bv.target_seg = p->node_seg; a.bv.G = p->n_batches;
+    a.bv.id_bound = p->n_vertices > 0 ? p->n_vertices : 0;
     a.bv.sample_batch = p->frontier_batch; a.bv.sample_seg = p->frontier_seg; a.bv.sample_local0 = p->frontier_local0;
     a.bv.unique_batch = p->nodes_out_batch; a.bv.unique_seg = p->nodes_out_seg;
     a.bv.frontier_out = p->frontier_out; a.bv.frontier_batch_out = p->frontier_out_batch;

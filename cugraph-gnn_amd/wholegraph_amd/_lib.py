@@ -190,7 +190,7 @@ SYMBOLS = {
     "wgamd_sample_hop_batched_nosync": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                                 c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                                c_void_p]),
+                                                c_int64, c_void_p]),
 }
 
 _lib = None

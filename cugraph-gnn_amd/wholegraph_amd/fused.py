@@ -93,6 +93,7 @@ class NoSyncWalk:
         assert all(m > 0 for m in max_neighbors), "the no-sync walk needs positive fan-outs"
         assert csr_col_ind.dtype == id_dtype, "no-sync walk: seeds and csr_col must share a dtype"
         self.row_ptr, self.col = csr_row_ptr, csr_col_ind
+        self.n_vertices = int(csr_row_ptr.shape[0]) - 1     # every id is a row of the CSR
         self.fanouts = list(max_neighbors)
         self.id_dtype = id_dtype
         self.wm_dtype = torch_dtype_to_wm(id_dtype)
@@ -155,7 +156,7 @@ class NoSyncWalk:
                 self.row_ptr.data_ptr(), self.col.data_ptr(), self.wm_dtype, targets.data_ptr(), t_batch.data_ptr(),
                 t_seg.data_ptr(), self.G, tc, m, rs[k].data_ptr(), offsets.data_ptr(), nbr_row.data_ptr(),
                 ctr_row.data_ptr(), None, ec, unique.data_ptr(), u_batch.data_ptr(), u_seg.data_ptr(),
-                counts[k].data_ptr(), ws_ptr, self.ws_bytes, stream), "wgamd_sample_hop_batched_nosync")
+                counts[k].data_ptr(), ws_ptr, self.ws_bytes, self.n_vertices, stream), "wgamd_sample_hop_batched_nosync")
             res.unique.append(unique)
             res.unique_seg.append(u_seg)
             res.target_seg.append(t_seg)
@@ -227,7 +228,8 @@ class _PygHop(_ct.Structure):
                 ("frontier_out_seg", _ct.c_void_p), ("frontier_out_local0", _ct.c_void_p),
                 ("counts_dev", _ct.c_void_p), ("neighbor_row_scratch", _ct.c_void_p),
                 ("center_row_scratch", _ct.c_void_p), ("workspace", _ct.c_void_p), ("workspace_bytes", _ct.c_size_t),
-                ("csr_weight", _ct.c_void_p), ("weight_dtype", _ct.c_int), ("max_row_len", _ct.c_int64)]
+                ("csr_weight", _ct.c_void_p), ("weight_dtype", _ct.c_int), ("max_row_len", _ct.c_int64),
+                ("n_vertices", _ct.c_int64)]
 
 
 @dataclass
@@ -347,7 +349,8 @@ class PygNoSyncWalk:
                         res.counts[k].data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(),
                         self.workspace.data_ptr() + self.ws_off, self.ws_bytes,
                         None if self.weight is None else self.weight.data_ptr(),
-                        0 if self.weight is None else torch_dtype_to_wm(self.weight.dtype), self.max_row_len)
+                        0 if self.weight is None else torch_dtype_to_wm(self.weight.dtype), self.max_row_len,
+                        int(self.row_ptr.shape[0]) - 1)
             L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
             res.offsets.append(offsets)
             res.row_local.append(row_l)
@@ -480,7 +483,8 @@ class HeteroPygWalk:
                             f_out.data_ptr(), f_out_batch.data_ptr(), f_out_seg.data_ptr(), f_out_l0.data_ptr(),
                             counts.data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(), ws_ptr, ws_bytes,
                             g.weight.data_ptr() if self.biased else None,
-                            torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl)
+                            torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl, 0)   # hetero: type-local ids of the
+                                                                                               # SOURCE type, bound not tracked
                 L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
                 keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
                          st["nodes"], st["batch"], st["seg"]]

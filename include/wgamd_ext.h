@@ -197,6 +197,9 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(const int64_t* csr_row_
                                                          int* counts_dev,
                                                          void* workspace,
                                                          size_t workspace_bytes,
+                                                         int64_t n_vertices /* ids are < n_vertices; 0 = unknown.  A bound
+                                                           lets the renumber table pack (batch, id, first position) into
+                                                           one 64-bit word per slot (one atomic per key instead of two) */,
                                                          void* stream);
 
 /* One hop of the PyG-style walk for a call group — what cugraph_pyg's sampling call produces
@@ -262,6 +265,7 @@ typedef struct wgamd_pyg_hop_t {
   const void* csr_weight;
   wholememory_dtype_t weight_dtype;
   int64_t max_row_len;
+  int64_t n_vertices; /* ids are < n_vertices (0 = unknown): enables the packed renumber table, see above */
 } wgamd_pyg_hop_t;
 
 wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, void* stream);
