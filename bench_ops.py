@@ -67,7 +67,7 @@ def hetero_section(dev):
     fanout = {et: [25, 10] for et in rel}
     B, G, groups = 1024, 32, 6
     seeds = torch.randperm(n["paper"], generator=g, device=dev)[:B * G * groups]
-    smp = HeteroNeighborSampler(graphs, fanout, local_seeds_per_call=B * G)
+    smp = HeteroNeighborSampler(graphs, fanout, local_seeds_per_call=B * G, num_nodes=n)
     list(smp.sample_batches("paper", seeds[:B * G], B, 1))          # warm-up (allocations, workspace)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -64,7 +64,8 @@ class NeighborLoader(NodeLoader):
             core = HeteroNeighborSampler(graph_store._hetero_graphs, num_neighbors, biased=(weight_attr is not None),
                                          with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
                                          temporal_comparison=temporal_comparison,
-                                         local_seeds_per_call=local_seeds_per_call)
+                                         local_seeds_per_call=local_seeds_per_call,
+                                         num_nodes=graph_store._num_vertices())
         sampler = BaseSampler(core, (feature_store, graph_store), batch_size=batch_size)
         super().__init__((feature_store, graph_store), sampler, input_nodes=input_nodes, input_time=input_time,
                          transform=transform, transform_sampler_output=transform_sampler_output,

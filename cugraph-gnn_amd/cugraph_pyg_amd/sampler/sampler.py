@@ -239,8 +239,9 @@ class HeteroNeighborSampler:
 
     def __init__(self, graphs, fanout, biased: bool = False, with_replacement: bool = False,
                  disjoint: bool = False, temporal: bool = False, temporal_comparison: Optional[str] = None,
-                 local_seeds_per_call: Optional[int] = None, **_ignored):
+                 local_seeds_per_call: Optional[int] = None, num_nodes=None, **_ignored):
         self.local_seeds_per_call = local_seeds_per_call
+        self.num_nodes = num_nodes       # {node type: count}, optional (enables the packed renumber table)
         self._walks = {}
         self._positive_weights = None
         if with_replacement or disjoint:
@@ -260,7 +261,8 @@ class HeteroNeighborSampler:
         from wholegraph_amd.fused import HeteroPygWalk
         key = (batch_size, n_batches)
         if key not in self._walks:
-            self._walks[key] = HeteroPygWalk(self.graphs, batch_size, self.fanout, n_batches, biased=self.biased)
+            self._walks[key] = HeteroPygWalk(self.graphs, batch_size, self.fanout, n_batches, biased=self.biased,
+                                             num_nodes=self.num_nodes)
         return self._walks[key]
 
     def sample_batches(self, seed_type, seeds, batch_size, random_state, seed_time=None):

@@ -374,8 +374,11 @@ class HeteroPygWalk:
     ``pylibcugraph.heterogeneous_uniform_neighbor_sample`` call over many batches.
     No host synchronisation inside ``run``; sizes are read once in ``finalize_batches``."""
 
-    def __init__(self, graphs, batch_size: int, fanout, n_batches: int, biased: bool = False):
+    def __init__(self, graphs, batch_size: int, fanout, n_batches: int, biased: bool = False, num_nodes=None):
+        """``num_nodes``: {node type: vertex count} — with it the renumber table of every hop packs (batch, id, position)
+        into one word (ids of a type are then known to be below its count)."""
         self.biased = bool(biased)
+        self.num_nodes = dict(num_nodes) if num_nodes else {}
         self.etypes = sorted(graphs.keys())
         self.graphs = graphs
         self.G, self.B = int(n_batches), int(batch_size)
@@ -483,8 +486,8 @@ class HeteroPygWalk:
                             f_out.data_ptr(), f_out_batch.data_ptr(), f_out_seg.data_ptr(), f_out_l0.data_ptr(),
                             counts.data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(), ws_ptr, ws_bytes,
                             g.weight.data_ptr() if self.biased else None,
-                            torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl, 0)   # hetero: type-local ids of the
-                                                                                               # SOURCE type, bound not tracked
+                            torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl,
+                            int(self.num_nodes.get(src_t, 0)))   # the renumbered ids are type-local ids of the SOURCE type
                 L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
                 keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
                          st["nodes"], st["batch"], st["seg"]]

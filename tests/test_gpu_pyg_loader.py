@@ -669,7 +669,8 @@ def test_hetero_call_group_walk_equals_single_batch_path(hiplib, G, biased):
     fanout[("author", "affiliated_with", "institution")] = [3, 3, 3]  # destination type never reached from papers
     B = 32
     seeds = torch.from_numpy(rng.permutation(n["paper"])[:B * 8 + 5]).cuda()
-    smp = HeteroNeighborSampler(gs._hetero_graphs, fanout, biased=biased, local_seeds_per_call=G * B)
+    smp = HeteroNeighborSampler(gs._hetero_graphs, fanout, biased=biased, local_seeds_per_call=G * B,
+                                num_nodes=n if G != 3 else None)   # with and without the packed renumber table
     got = dict(smp.sample_batches("paper", seeds, B, 1234))
     assert len(got) == 9 and smp._walks
     for b in range(9):
