@@ -129,6 +129,24 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   const int hl   = lane & 31;         // lane inside the half
   const int hb   = lane & 32;         // first lane of my half
   const int i    = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5);  // seed index
+  // The draw of lane t depends only on (seed index, t), not on the row: it is computed FIRST, so that the ~60 ALU
+  // instructions of the table jump run under the latency of the dependent seeds -> row_ptr loads issued right after
+  // (rows that turn out to be copied whole waste the draw, which is cheaper than putting it on the critical path).
+  int32_t r_draw = 0;
+  if (i < n && hl < M) {
+    uint64_t random_seed;
+    int i_local;
+    rng.resolve(i, random_seed, i_local);
+    // stream index = i_local*32 + lane; the table jump covers every index below 2^31, the generic
+    // loop keeps the reference's sign-extension semantics beyond that
+    if (i_local < (1 << 26)) {
+      Pcg32 g(random_seed, (uint32_t)(i_local * 32 + hl), Pcg32::table_tag{});
+      r_draw = g.next_i31();
+    } else {
+      Pcg32 g(random_seed, stream_id(i_local, 32, hl));
+      r_draw = g.next_i31();
+    }
+  }
   int64_t start = 0;
   int N = 0, base = 0;
   if (i < n) {
@@ -144,22 +162,7 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
     return;
   }
   int r = 0;
-  if (pick && hl < M) {
-    uint64_t random_seed;
-    int i_local;
-    rng.resolve(i, random_seed, i_local);
-    // stream index = i_local*32 + lane; the table jump covers every index below 2^31, the generic
-    // loop keeps the reference's sign-extension semantics beyond that
-    int32_t r_draw;
-    if (i_local < (1 << 26)) {
-      Pcg32 g(random_seed, (uint32_t)(i_local * 32 + hl), Pcg32::table_tag{});
-      r_draw = g.next_i31();
-    } else {
-      Pcg32 g(random_seed, stream_id(i_local, 32, hl));
-      r_draw = g.next_i31();
-    }
-    r = r_draw % (N - hl);
-  }
+  if (pick && hl < M) r = r_draw % (N - hl);
   // Fisher-Yates:  a[t] = Q[r_t];  Q[r_t] = Q[N-t-1], resolved WITHOUT walking the M steps in order.
   // Step t writes position r_t with the value it found at position N-t-1.  For lane t let
   //   p1 = latest step s < t that wrote position r_t      (r_s == r_t),

@@ -76,8 +76,9 @@ def test_batched_block_diagonal_aggregation_matches_per_batch(oracle_mod, hiplib
     cap = res.unique[1].shape[0]
     x = torch.zeros((cap, 100), device="cuda")
     local_gather(torch.from_numpy(feat).cuda(), res.unique[1], x)          # -1 padded slack is skipped
-    agg = nn.spmm_csr_forward(res.offsets[1], res.neighbor_row[1], x, True)  # rows = all hop-2 targets
     tseg = res.target_seg[1].cpu().numpy()
+    # rows = all LIVE hop-2 targets (offsets past the live count are capacity slack the walk never writes)
+    agg = nn.spmm_csr_forward(res.offsets[1][:tseg[G] + 1], res.neighbor_row[1], x, True)
     for b in range(G):
         otg, oei, orp, oci = oracle_mod.multilayer_sample(row_ptr, col, seeds[b * B:(b + 1) * B], fan, [10 + b, 20 + b])
         ref = oracle_mod.spmm_csr(orp[0], oci[0], feat[otg[0]], mean=True, acc_double=False)
