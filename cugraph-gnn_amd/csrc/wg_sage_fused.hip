@@ -322,7 +322,8 @@ void launch(const layer_args& a, hipStream_t st)
   WG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   const size_t b_bytes  = 0;
-  const bool pingpong   = 2 * tile_bytes + b_bytes <= 160 * 1024 && getenv("WGAMD_SAGE_NO_PINGPONG") == nullptr;
+  // WGAMD_SAGE_NO_PINGPONG=1: single-team workgroups even when two tiles fit (tuning aid, F > 128 only)
+  const bool pingpong   = 2 * tile_bytes + b_bytes <= 160 * 1024 && (LG < 64 || getenv("WGAMD_SAGE_NO_PINGPONG") == nullptr);
   const size_t lds      = (pingpong ? 2 * tile_bytes : tile_bytes) + b_bytes;
   const int per_cu      = (!pingpong && 2 * lds <= 160 * 1024) ? 2 : 1;
   const int grid        = (int)std::min<int64_t>((n_tiles + (pingpong ? 1 : 0)) / (pingpong ? 2 : 1), (int64_t)cus * per_cu);
@@ -335,8 +336,12 @@ void launch(const layer_args& a, hipStream_t st)
   const bool off32 = a.x_rows > 0 && (uint64_t)a.x_rows * (uint64_t)a.ldx * 4u < (1ull << 32);
   if (pingpong && off32) go(sage_layer_fused_kernel<IdT, LG, WAVES, 2, true>, WAVES * 128);
   else if (pingpong) go(sage_layer_fused_kernel<IdT, LG, WAVES, 2, false>, WAVES * 128);
-  else if (off32) go(sage_layer_fused_kernel<IdT, LG, WAVES, 1, true>, WAVES * 64);
-  else go(sage_layer_fused_kernel<IdT, LG, WAVES, 1, false>, WAVES * 64);
+  else if constexpr (LG == 64) {  // only F > 128 can need the single-team kernel (two tiles beyond 160 KB of LDS)
+    if (off32) go(sage_layer_fused_kernel<IdT, LG, WAVES, 1, true>, WAVES * 64);
+    else go(sage_layer_fused_kernel<IdT, LG, WAVES, 1, false>, WAVES * 64);
+  } else {
+    throw logic_error("two operand tiles must fit LDS for F <= 128");  // unreachable: 2 x 64 x 260 x 4 B = 133 KB
+  }
 }
 
 template <typename IdT, int LG>
