@@ -92,6 +92,9 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
                      "entry of %zu B at offset %zu does not fit the memory entry stride %zu", file_entry_size,
                      memory_offset, memory_entry_size);
     WG_REQUIRE_INPUT(round_robin_size >= 0, "round_robin_size must be >= 0");
+    // the copies below run on a private stream: order them after everything already queued on this device (a fill or a
+    // scatter into the same memory on the caller's stream), as the reference's synchronous cudaMemcpy does implicitly
+    WG_HIP_CHECK(hipDeviceSynchronize());
     const size_t gran = wholememory_get_data_granularity(handle);
     WG_REQUIRE_INPUT(gran % memory_entry_size == 0, "memory entry stride %zu does not divide the handle granularity %zu",
                      memory_entry_size, gran);
@@ -191,6 +194,7 @@ wholememory_error_code_t wholememory_store_to_file(wholememory_handle_t handle, 
                      memory_entry_stride, gran);
     wholememory_comm_t comm = nullptr;
     WG_EXPECTS(wholememory_get_communicator(&comm, handle) == WHOLEMEMORY_SUCCESS, "no communicator");
+    WG_HIP_CHECK(hipDeviceSynchronize());  // pending writes of any stream into the handle's memory must be visible
     if (wholememory_communicator_barrier(comm) != WHOLEMEMORY_SUCCESS) throw comm_error("barrier failed");
     char* local_ptr = nullptr;
     size_t local_size = 0, local_offset = 0;
