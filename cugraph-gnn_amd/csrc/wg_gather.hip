@@ -70,10 +70,38 @@ __global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ 
   const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
   const int step      = lanes * V;
 
+  const int iters = (row_bytes + step - 1) / step;  // same trip count for every lane (row_bytes >= V)
   for (int64_t row0 = group * kRowsInFlight; row0 < n; row0 += ngroups * kRowsInFlight) {
     int64_t r[kRowsInFlight];
+    bool all_ok = true;
 #pragma unroll
-    for (int k = 0; k < kRowsInFlight; k++) r[k] = (row0 + k < n) ? (int64_t)idx[row0 + k] : -1;
+    for (int k = 0; k < kRowsInFlight; k++) {
+      const int64_t ri = row0 + k < n ? row0 + k : n - 1;  // unconditional index load
+      r[k]             = (int64_t)idx[ri];
+      if (row0 + k >= n) r[k] = -1;
+      all_ok = all_ok && r[k] >= 0;
+    }
+    if (__all(all_ok)) {
+      // Fast path (every row of every lane group of the wave is live; wave-uniform branch): NOTHING below is under a
+      // per-lane branch — a load or store behind one makes hipcc wait vmcnt(0) at every join, which put the
+      // kRowsInFlight fetches in series.  Lanes past the end of the row re-copy its last V bytes (same value twice).
+      for (int it = 0; it < iters; it++) {
+        int off = sub * V + it * step;
+        off     = off + V <= row_bytes ? off : row_bytes - V;
+        vec_t v[kRowsInFlight];
+#pragma unroll
+        for (int k = 0; k < kRowsInFlight; k++) {
+          const char* p = SCATTER ? src + (row0 + k) * src_stride + off : src + r[k] * src_stride + off;
+          v[k]          = *reinterpret_cast<const vec_t*>(p);
+        }
+#pragma unroll
+        for (int k = 0; k < kRowsInFlight; k++) {
+          char* q = SCATTER ? dst + r[k] * dst_stride + off : dst + (row0 + k) * dst_stride + off;
+          *reinterpret_cast<vec_t*>(q) = v[k];
+        }
+      }
+      continue;
+    }
     for (int off = sub * V; off < row_bytes; off += step) {
       vec_t v[kRowsInFlight];
 #pragma unroll
