@@ -111,8 +111,10 @@ __device__ __forceinline__ void emit(ColT* dst, int* src_lid, int64_t* edge_gid,
   if (edge_gid) edge_gid[out] = gid;
 }
 
-// ---- M <= 32: two seeds per wave64, everything in registers --------------------------------
-template <typename SeedT, typename ColT>
+// ---- M <= 32: LANES (32, or 16 when M <= 16) lanes per seed = 2 or 4 seeds per wave64, everything in registers ----
+// (a hop is a chain of three dependent memory latencies per seed — seeds -> row_ptr -> col — so what matters is how
+//  many seeds a wave keeps in flight; with fan-out 10 a 32-lane group would idle 22 lanes)
+template <typename SeedT, typename ColT, int LANES>
 __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int64_t* __restrict__ row_ptr,
                                                                       const ColT* __restrict__ col,
                                                                       const SeedT* __restrict__ seeds,
@@ -126,9 +128,9 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
 {
   const int n    = n_.get();
   const int lane = threadIdx.x & 63;
-  const int hl   = lane & 31;         // lane inside the half
-  const int hb   = lane & 32;         // first lane of my half
-  const int i    = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5);  // seed index
+  const int hl   = lane & (LANES - 1);   // lane inside my group
+  const int hb   = lane & ~(LANES - 1);  // first lane of my group
+  const int i    = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES);  // seed index
   // The draw of lane t depends only on (seed index, t), not on the row: it is computed FIRST, so that the ~60 ALU
   // instructions of the table jump run under the latency of the dependent seeds -> row_ptr loads issued right after
   // (rows that turn out to be copied whole waste the draw, which is cheaper than putting it on the critical path).
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
     // stream index = i_local*32 + lane; the table jump covers every index below 2^31, the generic
     // loop keeps the reference's sign-extension semantics beyond that
     if (i_local < (1 << 26)) {
-      Pcg32 g(random_seed, (uint32_t)(i_local * 32 + hl), Pcg32::table_tag{});
+      Pcg32 g(random_seed, (uint32_t)(i_local * 32 + hl), Pcg32::table_tag{});   // stream layout: 32 per seed, always
       r_draw = g.next_i31();
     } else {
       Pcg32 g(random_seed, stream_id(i_local, 32, hl));
@@ -181,9 +183,9 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   }
   int root = p2 >= 0 ? p2 : hl;
 #pragma unroll
-  for (int round = 0; round < 5; round++) root = __shfl(root, hb | root, 64);
+  for (int round = 0; round < (LANES == 32 ? 5 : 4); round++) root = __shfl(root, hb | root, 64);
   const int val = N - root - 1;
-  const int vp1 = __shfl(val, hb | (p1 & 31), 64);
+  const int vp1 = __shfl(val, hb | (p1 & (LANES - 1)), 64);
   const int a   = p1 >= 0 ? vp1 : r;
   if (pick) {
     if (hl < M) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + a], i, start + a);
@@ -601,8 +603,11 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
     // sample-all: every row is copied whole (rows can be long -> workgroup copy path)
     sample_uniform_block_kernel<SeedT, ColT><<<cap, 64, 0, stream>>>(row_ptr, col, seeds, n, 0x7fffffff, 32, 1,
                                                                      random_seed, offsets, dst, lid, gid);
+  } else if (M <= 16) {
+    sample_uniform_halfwave_kernel<SeedT, ColT, 16><<<ceil_div((int64_t)cap * 16, 256), 256, 0, stream>>>(
+      row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid);
   } else if (M <= 32) {
-    sample_uniform_halfwave_kernel<SeedT, ColT><<<ceil_div((int64_t)cap * 32, 256), 256, 0, stream>>>(
+    sample_uniform_halfwave_kernel<SeedT, ColT, 32><<<ceil_div((int64_t)cap * 32, 256), 256, 0, stream>>>(
       row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid);
   } else if (M <= 1024) {
     const int B = ref_block_threads(M);
