@@ -291,6 +291,9 @@ def main():
                     help="auto/fused: every SAGE layer whose shape allows it runs as ONE kernel (neighbour rows -> LDS operand "
                          "tile -> fp32 MFMA); split: aggregation kernel + library GEMM per layer.  The other one is timed as a "
                          "variant")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                                                            "one-GPU rehearsal of the N>1 control flow in the tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="test aid: every rank uses cuda:0 (with --dist-backend gloo)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes of the other code paths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -303,8 +306,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

@@ -1,0 +1,48 @@
+"""Rehearsal of bench.py's N > 1 control flow on ONE GPU: two ranks launched exactly like the driver launches them
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ...), sharing cuda:0 with the gloo backend (RCCL refuses two
+ranks on one device).  Checks what the driver relies on: exactly one JSON line (from rank 0), whole-job aggregation over the
+ranks, weak scaling fields, no CPU baseline at N > 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(nproc, extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "32", "--warmup", "16",
+           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--no-variants"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_control_flow(hiplib):
+    one = _run(1, ["--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"])
+    two = _run(2, ["--dist-backend", "gloo", "--share-gpu"])
+    for d, n in ((one, 1), (two, 2)):
+        assert d["n_gpus"] == n and d["steps"] == 32 and d["warmup"] == 16 and d["scaling"] == "weak"
+        assert d["unit"] == "sampled-edges/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+        assert d["roofline"]["frac"] > 0 and d["value"] > 0 and d["ms_per_step"] > 0
+        assert "workload" in d["config"]
+    assert two["cpu_baseline"] is None            # timed at N = 1 only
+    # whole-job aggregate: both ranks' edges are counted (each rank samples its own seed shard of the same graph)
+    e1 = sum(v for k, v in one["edges_per_batch"].items() if k.startswith("hop"))
+    e2 = sum(v for k, v in two["edges_per_batch"].items() if k.startswith("hop"))
+    assert abs(e1 - e2) / e1 < 0.1
+    assert 1.6 < (two["value"] * two["ms_per_step"]) / (one["value"] * one["ms_per_step"]) < 2.4
+    assert "dp2" in two["config"]["parallelism"]
+
+
+def test_partitioned_feature_store_two_ranks(hiplib):
+    """--feature-placement partitioned at N = 2: the all-to-all feature fetch over torch.distributed inside the pipeline."""
+    d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--feature-placement", "partitioned"])
+    assert "all-to-all" in d["config"]["parallelism"] and d["n_gpus"] == 2
+    assert "gather(all-to-all)" in d["stage_ms_per_call_group"]
