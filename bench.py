@@ -306,12 +306,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1 or args.force_partitioned:
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world,
+                                **({"device_id": device} if args.dist_backend == "nccl" else {}))
 
     from wholegraph_amd import WholeMemoryTensor, equal_entry_partition
     from wholegraph_amd import nn as nn_mod
@@ -333,7 +335,16 @@ def main():
         # walk + fetch need no collective at all (seeds are the independent units)
         gfeat.manual_seed(100)
         feat = WholeMemoryTensor((torch.rand((V, FEAT_DIM), generator=gfeat, device=device) * 2 - 1))
+    elif args.dist_backend == "nccl":
+        # the table is a DISTRIBUTED handle of the library: bucketing, the id / row all-to-all-v (RCCL send/recv groups)
+        # and the row kernels all run inside wholememory_gather (csrc/wg_comm.hip)
+        import wholegraph_amd as wg
+        feat = wg.create_wholememory_tensor(wg.create_group_communicator(), "distributed", "cuda", [V, FEAT_DIM],
+                                            torch.float32, [FEAT_DIM, 1])
+        local = feat.get_local_tensor()[0]
+        local.copy_(torch.rand(tuple(local.shape), generator=gfeat, device=device) * 2 - 1)
     else:
+        # torch.distributed pipeline (wholegraph_amd/dist.py); the gloo tests put two ranks on one GPU this way
         offs = equal_entry_partition(V, world)
         local = torch.rand((offs[rank + 1] - offs[rank], FEAT_DIM), generator=gfeat, device=device) * 2 - 1
         feat = WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)

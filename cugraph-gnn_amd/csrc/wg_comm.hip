@@ -98,21 +98,18 @@ rccl_api& rccl()
                                              rccl().ErrString ? rccl().ErrString(r__) : "?", #expr));          \
   } while (0)
 
-// variable all-to-all of bytes: counts in BYTES (nccl_comms.cpp:398-426: grouped ncclRecv x W then ncclSend x W)
-void alltoallv_bytes(wholememory_comm_t comm, const char* send, const std::vector<size_t>& send_bytes, char* recv,
+// variable all-to-all of bytes, explicit per-peer offsets and sizes in BYTES (nccl_comms.cpp:398-426: grouped ncclRecv x W
+// then ncclSend x W); a peer with zero bytes is skipped on that side
+void alltoallv_bytes(wholememory_comm_t comm, const char* send, const std::vector<size_t>& send_off,
+                     const std::vector<size_t>& send_bytes, char* recv, const std::vector<size_t>& recv_off,
                      const std::vector<size_t>& recv_bytes, hipStream_t stream)
 {
   auto& api = rccl();
   WG_NCCL_CHECK(api.GroupStart());
-  size_t roff = 0, soff = 0;
-  for (int r = 0; r < comm->size; r++) {
-    if (recv_bytes[r]) WG_NCCL_CHECK(api.Recv(recv + roff, recv_bytes[r], ncclInt8, r, comm->nccl, stream));
-    roff += recv_bytes[r];
-  }
-  for (int r = 0; r < comm->size; r++) {
-    if (send_bytes[r]) WG_NCCL_CHECK(api.Send(send + soff, send_bytes[r], ncclInt8, r, comm->nccl, stream));
-    soff += send_bytes[r];
-  }
+  for (int r = 0; r < comm->size; r++)
+    if (recv_bytes[r]) WG_NCCL_CHECK(api.Recv(recv + recv_off[r], recv_bytes[r], ncclInt8, r, comm->nccl, stream));
+  for (int r = 0; r < comm->size; r++)
+    if (send_bytes[r]) WG_NCCL_CHECK(api.Send(send + send_off[r], send_bytes[r], ncclInt8, r, comm->nccl, stream));
   WG_NCCL_CHECK(api.GroupEnd());
 }
 
@@ -149,21 +146,49 @@ owner_histogram_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0,
     if (local[r]) atomicAdd(&counts[r], local[r]);
 }
 
-// ids grouped by owner (any order inside a group) + the original position of every grouped id
+// ids grouped by owner (any order inside a group) + the original position of every grouped id.  A workgroup counts its
+// kBucketItems ids per owner in LDS, reserves one range per owner with ONE global atomic each, then hands out slots inside
+// its ranges with LDS atomics: a global atomic per id on W cursors serialises (3.6 M ids on one address took 40 ms).
+constexpr int kBucketItems = 8;  // ids per thread
+
 template <typename IdxT>
 __global__ void __launch_bounds__(256)
 bucket_ids_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0, const int64_t* __restrict__ entry_offsets, int W,
                   const int64_t* __restrict__ bucket_start, int* __restrict__ cursor, int64_t* __restrict__ grouped_ids,
                   int64_t* __restrict__ positions)
 {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int64_t id = (int64_t)idx[i];
-  if (id >= 0) id += row0;  // row 0 of a sub-tensor is entry `row0` of the handle
-  const int r = owner_of(id, entry_offsets, W);
-  const int64_t at = bucket_start[r] + atomicAdd(&cursor[r], 1);
-  grouped_ids[at]  = id;
-  positions[at]    = id < 0 ? -1 : i;  // a negative index leaves its dense row untouched
+  __shared__ int local[kMaxRanks];
+  __shared__ int64_t base[kMaxRanks];
+  for (int r = threadIdx.x; r < W; r += blockDim.x) local[r] = 0;
+  __syncthreads();
+  const int64_t first = (int64_t)blockIdx.x * (256 * kBucketItems) + threadIdx.x;
+  int64_t id[kBucketItems];
+  int owner[kBucketItems];
+#pragma unroll
+  for (int k = 0; k < kBucketItems; k++) {
+    const int64_t i = first + (int64_t)k * 256;
+    owner[k]        = -1;
+    if (i < n) {
+      id[k] = (int64_t)idx[i];
+      if (id[k] >= 0) id[k] += row0;  // row 0 of a sub-tensor is entry `row0` of the handle
+      owner[k] = owner_of(id[k], entry_offsets, W);
+      atomicAdd(&local[owner[k]], 1);
+    }
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < W; r += blockDim.x) {
+    const int c = local[r];
+    base[r]     = bucket_start[r] + (c ? atomicAdd(&cursor[r], c) : 0);
+    local[r]    = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kBucketItems; k++) {
+    if (owner[k] < 0) continue;
+    const int64_t at = base[owner[k]] + atomicAdd(&local[owner[k]], 1);
+    grouped_ids[at]  = id[k];
+    positions[at]    = id[k] < 0 ? -1 : first + (int64_t)k * 256;  // a negative index leaves its dense row untouched
+  }
 }
 
 __global__ void __launch_bounds__(256) localize_ids_kernel(int64_t* ids, int64_t n, int64_t local_start)
@@ -174,7 +199,6 @@ __global__ void __launch_bounds__(256) localize_ids_kernel(int64_t* ids, int64_t
 
 struct exchange_plan {
   std::vector<size_t> send_cnt, recv_cnt;  // ids per peer
-  int64_t recv_total = 0;
 };
 
 }  // namespace
@@ -226,29 +250,38 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
     auto* d_x = xcnt_b.device<int64_t>(2 * W, WHOLEMEMORY_DT_INT64);
     std::vector<int64_t> tmp(plan.send_cnt.begin(), plan.send_cnt.end());
     WG_HIP_CHECK(hipMemcpyAsync(d_x, tmp.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
-    std::vector<size_t> eight(W, sizeof(int64_t));
-    alltoallv_bytes(comm, reinterpret_cast<const char*>(d_x), eight, reinterpret_cast<char*>(d_x + W), eight, stream);
+    std::vector<size_t> eight(W, sizeof(int64_t)), at(W);
+    for (int r = 0; r < W; r++) at[r] = (size_t)r * sizeof(int64_t);
+    alltoallv_bytes(comm, reinterpret_cast<const char*>(d_x), at, eight, reinterpret_cast<char*>(d_x + W), at, eight, stream);
     WG_HIP_CHECK(hipMemcpyAsync(tmp.data(), d_x + W, sizeof(int64_t) * W, hipMemcpyDeviceToHost, stream));
     WG_HIP_CHECK(hipStreamSynchronize(stream));
     for (int r = 0; r < W; r++) {
       plan.recv_cnt[r] = (size_t)tmp[r];
-      plan.recv_total += tmp[r];
     }
   }
 
-  // ---- 3. group ids by owner -------------------------------------------------------------------
+  // ---- 3. group ids by owner: the peers' buckets first (rank order), MY bucket last -------------------------
+  // Rows I own never enter the exchange when no dtype conversion is asked for: one permuting copy moves them between my
+  // partition and the dense rows (1/W of the traffic; all of it on a single-rank communicator).
+  const int me           = comm->rank;
+  const bool self_direct = tm.dtype == dense_m.dtype;
+  const int64_t self_cnt = (int64_t)plan.send_cnt[me];
+  WG_EXPECTS(plan.recv_cnt[me] == plan.send_cnt[me], "self count mismatch");
   std::vector<int64_t> bucket_start(W);
   int64_t acc = 0;
   for (int r = 0; r < W; r++) {
+    if (r == me) continue;
     bucket_start[r] = acc;
     acc += (int64_t)plan.send_cnt[r];
   }
+  bucket_start[me]       = acc;
+  const int64_t n_remote = self_direct ? acc : n;  // leading rows of the grouped order that go through the exchange
   auto* d_start   = start_b.device<int64_t>(W, WHOLEMEMORY_DT_INT64);
   auto* d_grouped = gid_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
   auto* d_pos     = pos_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
   WG_HIP_CHECK(hipMemcpyAsync(d_start, bucket_start.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
   if (n > 0) {
-    int grid = (int)((n + 255) / 256);
+    int grid = (int)((n + 256 * kBucketItems - 1) / (256 * kBucketItems));
     if (idx_dtype == WHOLEMEMORY_DT_INT)
       bucket_ids_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_start,
                                                           d_counts + W, d_grouped, d_pos);
@@ -258,17 +291,37 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
     WG_HIP_CHECK(hipGetLastError());
   }
 
-  // ---- 4. ids all-to-all-v ----------------------------------------------------------------------
-  temp_buffer rid_b(env), rows_b(env), back_b(env);
-  auto* d_recv_ids = rid_b.device<int64_t>(plan.recv_total, WHOLEMEMORY_DT_INT64);
-  std::vector<size_t> sb(W), rb(W);
+  // ---- 4. ids all-to-all-v: what I receive is packed in rank order (without my own bucket when it stays home) ------
+  std::vector<size_t> send_n(W), recv_n(W), send_at(W), recv_at(W);  // in ids
+  int64_t recv_total = 0;
   for (int r = 0; r < W; r++) {
-    sb[r] = plan.send_cnt[r] * sizeof(int64_t);
-    rb[r] = plan.recv_cnt[r] * sizeof(int64_t);
+    const bool skip = self_direct && r == me;
+    send_n[r]  = skip ? 0 : plan.send_cnt[r];
+    recv_n[r]  = skip ? 0 : plan.recv_cnt[r];
+    send_at[r] = (size_t)bucket_start[r];
+    recv_at[r] = (size_t)recv_total;
+    recv_total += (int64_t)recv_n[r];
   }
-  alltoallv_bytes(comm, reinterpret_cast<const char*>(d_grouped), sb, reinterpret_cast<char*>(d_recv_ids), rb, stream);
-  if (plan.recv_total > 0) {
-    localize_ids_kernel<<<(int)((plan.recv_total + 255) / 256), 256, 0, stream>>>(d_recv_ids, plan.recv_total, local_start);
+  temp_buffer rid_b(env), rows_b(env), back_b(env);
+  auto* d_recv_ids = rid_b.device<int64_t>(recv_total, WHOLEMEMORY_DT_INT64);
+  std::vector<size_t> so(W), sb(W), ro(W), rb(W);
+  auto scaled = [&](size_t unit_send, size_t unit_recv, const std::vector<size_t>& s_n, const std::vector<size_t>& s_at,
+                    const std::vector<size_t>& r_n, const std::vector<size_t>& r_at) {
+    for (int r = 0; r < W; r++) {
+      so[r] = s_at[r] * unit_send; sb[r] = s_n[r] * unit_send;
+      ro[r] = r_at[r] * unit_recv; rb[r] = r_n[r] * unit_recv;
+    }
+  };
+  scaled(sizeof(int64_t), sizeof(int64_t), send_n, send_at, recv_n, recv_at);
+  alltoallv_bytes(comm, reinterpret_cast<const char*>(d_grouped), so, sb, reinterpret_cast<char*>(d_recv_ids), ro, rb, stream);
+  if (recv_total > 0) {
+    localize_ids_kernel<<<(int)((recv_total + 255) / 256), 256, 0, stream>>>(d_recv_ids, recv_total, local_start);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  int64_t* d_self_ids = d_grouped + bucket_start[me];  // not part of any send when self_direct
+  int64_t* d_self_pos = d_pos + bucket_start[me];
+  if (self_direct && self_cnt > 0) {
+    localize_ids_kernel<<<(int)((self_cnt + 255) / 256), 256, 0, stream>>>(d_self_ids, self_cnt, local_start);
     WG_HIP_CHECK(hipGetLastError());
   }
 
@@ -279,43 +332,38 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
   const char* local_base                   = static_cast<const char*>(h->local_ptr) + (size_t)col0 * tes;
   const int64_t F                          = tm.sizes[1];
   const size_t des                         = dtype_size(dense_m.dtype);
+  wholememory_matrix_description_t dense0  = dense_m;
+  dense0.storage_offset                    = 0;  // `dense` already points at the first element
   int64_t sz2[2];
 
   if (!scatter) {
     // ---- 5. local gather (table dtype -> output dtype), 6. rows back, 7. un-permute ------------
-    sz2[0] = plan.recv_total; sz2[1] = F;
+    if (self_direct) local_rows_permute(local_base, local_m, d_self_ids, d_self_pos, self_cnt, dense, dense0, stream);
+    sz2[0] = recv_total; sz2[1] = F;
     wholememory_matrix_description_t rows_m = wholememory_create_matrix_desc(sz2, F, 0, dense_m.dtype);
-    char* d_rows = static_cast<char*>(rows_b.alloc(plan.recv_total * F, dense_m.dtype));
-    local_rows_gather(local_base, local_m, d_recv_ids, WHOLEMEMORY_DT_INT64, plan.recv_total, d_rows, rows_m, stream);
-    sz2[0] = n;
+    char* d_rows = static_cast<char*>(rows_b.alloc(recv_total * F, dense_m.dtype));
+    local_rows_gather(local_base, local_m, d_recv_ids, WHOLEMEMORY_DT_INT64, recv_total, d_rows, rows_m, stream);
+    sz2[0] = n_remote;
     wholememory_matrix_description_t back_m = wholememory_create_matrix_desc(sz2, F, 0, dense_m.dtype);
-    char* d_back = static_cast<char*>(back_b.alloc(n * F, dense_m.dtype));
-    for (int r = 0; r < W; r++) {
-      sb[r] = plan.recv_cnt[r] * (size_t)F * des;  // what I gathered for peer r
-      rb[r] = plan.send_cnt[r] * (size_t)F * des;  // what peer r gathered for me
-    }
-    alltoallv_bytes(comm, d_rows, sb, d_back, rb, stream);
-    wholememory_matrix_description_t out_m = dense_m;
-    out_m.storage_offset                   = 0;  // `dense` already points at the first element
-    local_rows_scatter(d_back, back_m, d_pos, WHOLEMEMORY_DT_INT64, n, dense, out_m, stream);
+    char* d_back = static_cast<char*>(back_b.alloc(n_remote * F, dense_m.dtype));
+    // I send what I gathered for peer r and receive what peer r gathered for me, in my grouped order
+    scaled((size_t)F * des, (size_t)F * des, recv_n, recv_at, send_n, send_at);
+    alltoallv_bytes(comm, d_rows, so, sb, d_back, ro, rb, stream);
+    local_rows_scatter(d_back, back_m, d_pos, WHOLEMEMORY_DT_INT64, n_remote, dense, dense0, stream);
   } else {
     // ---- scatter: permute my rows by owner, send ids + rows, owners write them -------------------
-    sz2[0] = n; sz2[1] = F;
+    if (self_direct) local_rows_permute(dense, dense0, d_self_pos, d_self_ids, self_cnt, const_cast<char*>(local_base), local_m, stream);
+    sz2[0] = n_remote; sz2[1] = F;
     wholememory_matrix_description_t send_m = wholememory_create_matrix_desc(sz2, F, 0, tm.dtype);
-    char* d_send = static_cast<char*>(back_b.alloc(n * F, tm.dtype));
-    wholememory_matrix_description_t in_m = dense_m;
-    in_m.storage_offset                   = 0;
-    local_rows_gather(dense, in_m, d_pos, WHOLEMEMORY_DT_INT64, n, d_send, send_m, stream);  // also converts
-    sz2[0] = plan.recv_total;
+    char* d_send = static_cast<char*>(back_b.alloc(n_remote * F, tm.dtype));
+    local_rows_gather(dense, dense0, d_pos, WHOLEMEMORY_DT_INT64, n_remote, d_send, send_m, stream);  // also converts
+    sz2[0] = recv_total;
     wholememory_matrix_description_t recv_m = wholememory_create_matrix_desc(sz2, F, 0, tm.dtype);
-    char* d_recv = static_cast<char*>(rows_b.alloc(plan.recv_total * F, tm.dtype));
-    for (int r = 0; r < W; r++) {
-      sb[r] = plan.send_cnt[r] * (size_t)F * tes;
-      rb[r] = plan.recv_cnt[r] * (size_t)F * tes;
-    }
-    alltoallv_bytes(comm, d_send, sb, d_recv, rb, stream);
-    local_rows_scatter(d_recv, recv_m, d_recv_ids, WHOLEMEMORY_DT_INT64, plan.recv_total,
-                       const_cast<char*>(local_base), local_m, stream);
+    char* d_recv = static_cast<char*>(rows_b.alloc(recv_total * F, tm.dtype));
+    scaled((size_t)F * tes, (size_t)F * tes, send_n, send_at, recv_n, recv_at);
+    alltoallv_bytes(comm, d_send, so, sb, d_recv, ro, rb, stream);
+    local_rows_scatter(d_recv, recv_m, d_recv_ids, WHOLEMEMORY_DT_INT64, recv_total, const_cast<char*>(local_base), local_m,
+                       stream);
   }
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
 }

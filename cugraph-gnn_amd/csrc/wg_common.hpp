@@ -272,6 +272,9 @@ void local_rows_gather(const char* table, wholememory_matrix_description_t tm, c
 void local_rows_scatter(const char* in, wholememory_matrix_description_t im, const void* idx,
                         wholememory_dtype_t idx_dtype, int64_t n, char* table, wholememory_matrix_description_t tm,
                         hipStream_t stream);
+// dst row dst_idx[i] <- src row src_idx[i] (same dtype; a negative index on either side skips the row)
+void local_rows_permute(const char* src, wholememory_matrix_description_t sm, const int64_t* src_idx, const int64_t* dst_idx,
+                        int64_t n, char* dst, wholememory_matrix_description_t dm, hipStream_t stream);
 // gather: dense = output rows; scatter: dense = input rows.  `tm` describes the GLOBAL table (sizes[0] = all rows).
 void distributed_rows_op(bool scatter, wholememory_handle_t handle, wholememory_matrix_description_t tm, const void* idx,
                          wholememory_dtype_t idx_dtype, int64_t n, char* dense, wholememory_matrix_description_t dense_m,

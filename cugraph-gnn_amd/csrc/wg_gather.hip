@@ -50,12 +50,14 @@ struct vec_of<1> {
 
 constexpr int kRowsInFlight = 4;
 
-// GATHER : dst row i   <- src row idx[i]
-// SCATTER: dst row idx[i] <- src row i
-template <int V, typename IdxT, bool SCATTER>
+// MODE 0 (gather) : dst row i       <- src row idx[i]
+// MODE 1 (scatter): dst row idx[i]  <- src row i
+// MODE 2 (permute): dst row idx2[i] <- src row idx[i]   (the owner-is-me share of a DISTRIBUTED gather / scatter)
+template <int V, typename IdxT, int MODE>
 __global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ src,
                                                        int64_t src_stride,  // bytes
                                                        const IdxT* __restrict__ idx,
+                                                       const IdxT* __restrict__ idx2,
                                                        int64_t n,
                                                        int row_bytes,
                                                        char* __restrict__ dst,
@@ -72,13 +74,14 @@ __global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ 
 
   const int iters = (row_bytes + step - 1) / step;  // same trip count for every lane (row_bytes >= V)
   for (int64_t row0 = group * kRowsInFlight; row0 < n; row0 += ngroups * kRowsInFlight) {
-    int64_t r[kRowsInFlight];
+    int64_t r[kRowsInFlight], r2[kRowsInFlight];
     bool all_ok = true;
 #pragma unroll
     for (int k = 0; k < kRowsInFlight; k++) {
       const int64_t ri = row0 + k < n ? row0 + k : n - 1;  // unconditional index load
       r[k]             = (int64_t)idx[ri];
-      if (row0 + k >= n) r[k] = -1;
+      r2[k]            = MODE == 2 ? (int64_t)idx2[ri] : 0;
+      if (row0 + k >= n || r2[k] < 0) r[k] = -1;
       all_ok = all_ok && r[k] >= 0;
     }
     if (__all(all_ok)) {
@@ -91,12 +94,12 @@ __global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ 
         vec_t v[kRowsInFlight];
 #pragma unroll
         for (int k = 0; k < kRowsInFlight; k++) {
-          const char* p = SCATTER ? src + (row0 + k) * src_stride + off : src + r[k] * src_stride + off;
+          const char* p = MODE == 1 ? src + (row0 + k) * src_stride + off : src + r[k] * src_stride + off;
           v[k]          = *reinterpret_cast<const vec_t*>(p);
         }
 #pragma unroll
         for (int k = 0; k < kRowsInFlight; k++) {
-          char* q = SCATTER ? dst + r[k] * dst_stride + off : dst + (row0 + k) * dst_stride + off;
+          char* q = dst + (MODE == 0 ? row0 + k : MODE == 1 ? r[k] : r2[k]) * dst_stride + off;
           *reinterpret_cast<vec_t*>(q) = v[k];
         }
       }
@@ -107,14 +110,14 @@ __global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ 
 #pragma unroll
       for (int k = 0; k < kRowsInFlight; k++) {
         if (r[k] >= 0) {
-          const char* p = SCATTER ? src + (row0 + k) * src_stride + off : src + r[k] * src_stride + off;
+          const char* p = MODE == 1 ? src + (row0 + k) * src_stride + off : src + r[k] * src_stride + off;
           v[k]          = *reinterpret_cast<const vec_t*>(p);
         }
       }
 #pragma unroll
       for (int k = 0; k < kRowsInFlight; k++) {
         if (r[k] >= 0) {
-          char* q = SCATTER ? dst + r[k] * dst_stride + off : dst + (row0 + k) * dst_stride + off;
+          char* q = dst + (MODE == 0 ? row0 + k : MODE == 1 ? r[k] : r2[k]) * dst_stride + off;
           *reinterpret_cast<vec_t*>(q) = v[k];
         }
       }
@@ -215,8 +218,8 @@ inline int grid_for(int64_t n_rows, int log2_lanes, int rows_per_group)
   return (int)blocks;
 }
 
-template <typename IdxT, bool SCATTER>
-void launch_copy(const char* src, int64_t src_stride, const IdxT* idx, int64_t n, int row_bytes, char* dst,
+template <typename IdxT, int MODE>
+void launch_copy(const char* src, int64_t src_stride, const IdxT* idx, const IdxT* idx2, int64_t n, int row_bytes, char* dst,
                  int64_t dst_stride, hipStream_t stream)
 {
   int V = 16;
@@ -227,7 +230,7 @@ void launch_copy(const char* src, int64_t src_stride, const IdxT* idx, int64_t n
   int l2   = log2_ceil_lanes((row_bytes + V - 1) / V);
   int grid = grid_for(n, l2, kRowsInFlight);
 #define WG_LAUNCH(VV)                                                                                                  \
-  row_copy_kernel<VV, IdxT, SCATTER><<<grid, 256, 0, stream>>>(src, src_stride, idx, n, row_bytes, dst, dst_stride, l2)
+  row_copy_kernel<VV, IdxT, MODE><<<grid, 256, 0, stream>>>(src, src_stride, idx, idx2, n, row_bytes, dst, dst_stride, l2)
   switch (V) {
     case 16: WG_LAUNCH(16); break;
     case 8: WG_LAUNCH(8); break;
@@ -298,11 +301,11 @@ void rows_launch(const char* src, wholememory_matrix_description_t sm, const voi
   const int F      = (int)sm.sizes[1];
   if (sm.dtype == dm.dtype) {
     if (idx_dtype == WHOLEMEMORY_DT_INT)
-      launch_copy<int32_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int32_t*>(idx), n, F * (int)ses, dst,
-                                    dm.stride * (int64_t)des, stream);
+      launch_copy<int32_t, SCATTER ? 1 : 0>(src, sm.stride * (int64_t)ses, static_cast<const int32_t*>(idx), nullptr, n,
+                                            F * (int)ses, dst, dm.stride * (int64_t)des, stream);
     else
-      launch_copy<int64_t, SCATTER>(src, sm.stride * (int64_t)ses, static_cast<const int64_t*>(idx), n, F * (int)ses, dst,
-                                    dm.stride * (int64_t)des, stream);
+      launch_copy<int64_t, SCATTER ? 1 : 0>(src, sm.stride * (int64_t)ses, static_cast<const int64_t*>(idx), nullptr, n,
+                                            F * (int)ses, dst, dm.stride * (int64_t)des, stream);
   } else {
     if (idx_dtype == WHOLEMEMORY_DT_INT)
       convert_in<int32_t, SCATTER>(sm.dtype, dm.dtype, src, sm.stride, static_cast<const int32_t*>(idx), n, F, dst,
@@ -373,6 +376,16 @@ void local_rows_scatter(const char* in, wholememory_matrix_description_t im, con
                         hipStream_t stream)
 {
   rows_launch<true>(in, im, idx, idx_dtype, n, table, tm, stream);
+}
+
+void local_rows_permute(const char* src, wholememory_matrix_description_t sm, const int64_t* src_idx, const int64_t* dst_idx,
+                        int64_t n, char* dst, wholememory_matrix_description_t dm, hipStream_t stream)
+{
+  WG_EXPECTS(sm.dtype == dm.dtype, "row permute does not convert");
+  if (n == 0) return;
+  const int64_t es = (int64_t)dtype_size(sm.dtype);
+  launch_copy<int64_t, 2>(src, sm.stride * es, src_idx, dst_idx, n, (int)(sm.sizes[1] * es), dst, dm.stride * es, stream);
+  WG_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace wgamd

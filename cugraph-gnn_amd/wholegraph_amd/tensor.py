@@ -181,6 +181,10 @@ class DistributedWholeMemoryTensor(object):
     def get_comm(self):
         return self.comm
 
+    @property
+    def local_tensor(self):
+        return self.get_local_tensor()[0]
+
     def get_local_tensor(self, host_view: bool = False):
         """(torch view of this rank's rows, first global row held here) — tensor.py:106-123."""
         import ctypes

@@ -70,6 +70,12 @@ WORKER = textwrap.dedent(r"""
             want = table.to(odt)[torch.from_numpy(np.where(idx < 0, 0, idx))]
             want[torch.from_numpy(idx < 0)] = 3.0
             assert torch.equal(out.cpu(), want), f"rank {r}: gather mismatch"
+            # same dtype in and out: the rows this rank owns are copied straight from its partition (never exchanged)
+            out2 = torch.full((k, dim), 3.0, dtype=tdt, device="cuda")
+            w_o2 = wg.env.wrap_torch_tensor(out2)
+            L.check(lib.wholememory_gather(t.c, w_i.c, w_o2.c, wg.env.get_wholegraph_env_fns(), wg.env.get_stream(), -1),
+                    "wholememory_gather")
+            assert torch.equal(out2.cpu(), want.to(tdt)), f"rank {r}: same-dtype gather mismatch"
             comm.barrier()
             # file I/O: every rank stores its rows; reload (a) the part files in order into a table with a DIFFERENT
             # partition, (b) round-robin sharded (blocks of 16 rows dealt to the ranks in turn)
