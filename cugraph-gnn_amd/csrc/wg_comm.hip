@@ -197,8 +197,153 @@ __global__ void __launch_bounds__(256) localize_ids_kernel(int64_t* ids, int64_t
   if (i < n && ids[i] >= 0) ids[i] -= local_start;
 }
 
-struct exchange_plan {
-  std::vector<size_t> send_cnt, recv_cnt;  // ids per peer
+// Steps 1-4 of the pipeline, shared by gather / scatter and by the embedding gradient routing: who owns each id, how
+// many ids every pair of ranks trades, the ids grouped by owner (the peers' buckets first in rank order, MY bucket last)
+// and the ids the peers ask me for (localised to my partition).
+struct id_exchange {
+  wholememory_comm_t comm;
+  int W, me;
+  int64_t local_start = 0, local_rows = 0;
+  std::vector<size_t> send_cnt, recv_cnt;          // all ids per peer, self included
+  std::vector<int64_t> bucket_start;               // first grouped position of every owner
+  std::vector<size_t> send_n, recv_n, send_at, recv_at;  // what really crosses the wire (ids), and where it sits
+  int64_t n = 0, n_remote = 0, self_cnt = 0, recv_total = 0;
+  bool self_direct = false;
+  int64_t *d_grouped = nullptr, *d_pos = nullptr, *d_recv_ids = nullptr, *d_self_ids = nullptr, *d_self_pos = nullptr;
+  temp_buffer offs_b, cnt_b, start_b, gid_b, pos_b, xcnt_b, rid_b;
+  std::vector<size_t> so, sb, ro, rb;
+
+  explicit id_exchange(wholememory_env_func_t* env)
+    : offs_b(env), cnt_b(env), start_b(env), gid_b(env), pos_b(env), xcnt_b(env), rid_b(env)
+  {
+  }
+
+  // self_direct_: my own bucket stays out of the exchange (it is localised in place instead); d_recv_ids always has
+  // room for it behind the received ids
+  void run(wholememory_handle_t h, size_t entry_bytes, int64_t row0, const void* idx, wholememory_dtype_t idx_dtype,
+           int64_t n_, bool self_direct_, hipStream_t stream)
+  {
+    comm = h->comm;
+    W    = comm->size;
+    me   = comm->rank;
+    n    = n_;
+    self_direct = self_direct_;
+    WG_EXPECTS(W <= kMaxRanks, "too many ranks");
+    std::vector<int64_t> entry_offsets(W + 1);
+    for (int r = 0; r <= W; r++) entry_offsets[r] = (int64_t)(h->byte_offsets[r] / entry_bytes);
+    local_start = entry_offsets[me];
+    local_rows  = entry_offsets[me + 1] - local_start;
+
+    // ---- 1. owners + counts --------------------------------------------------------------------
+    auto* d_offsets = offs_b.device<int64_t>(W + 1, WHOLEMEMORY_DT_INT64);
+    int* d_counts   = cnt_b.device<int>(2 * W, WHOLEMEMORY_DT_INT);  // [counts | cursors]
+    WG_HIP_CHECK(hipMemcpyAsync(d_offsets, entry_offsets.data(), sizeof(int64_t) * (W + 1), hipMemcpyHostToDevice, stream));
+    WG_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * 2 * W, stream));
+    if (n > 0) {
+      int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+      if (idx_dtype == WHOLEMEMORY_DT_INT)
+        owner_histogram_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_counts);
+      else
+        owner_histogram_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_counts);
+      WG_HIP_CHECK(hipGetLastError());
+    }
+    std::vector<int> h_counts(W);
+    WG_HIP_CHECK(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * W, hipMemcpyDeviceToHost, stream));
+    WG_HIP_CHECK(hipStreamSynchronize(stream));
+
+    // ---- 2. counts all-to-all (W x int64; nothing to trade on a single-rank communicator) --------
+    send_cnt.assign(W, 0);
+    recv_cnt.assign(W, 0);
+    for (int r = 0; r < W; r++) send_cnt[r] = (size_t)h_counts[r];
+    if (W == 1) {
+      recv_cnt[0] = send_cnt[0];
+    } else {
+      auto* d_x = xcnt_b.device<int64_t>(2 * W, WHOLEMEMORY_DT_INT64);
+      std::vector<int64_t> tmp(send_cnt.begin(), send_cnt.end());
+      WG_HIP_CHECK(hipMemcpyAsync(d_x, tmp.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
+      std::vector<size_t> eight(W, sizeof(int64_t)), at(W);
+      for (int r = 0; r < W; r++) at[r] = (size_t)r * sizeof(int64_t);
+      alltoallv_bytes(comm, reinterpret_cast<const char*>(d_x), at, eight, reinterpret_cast<char*>(d_x + W), at, eight, stream);
+      WG_HIP_CHECK(hipMemcpyAsync(tmp.data(), d_x + W, sizeof(int64_t) * W, hipMemcpyDeviceToHost, stream));
+      WG_HIP_CHECK(hipStreamSynchronize(stream));
+      for (int r = 0; r < W; r++) recv_cnt[r] = (size_t)tmp[r];
+    }
+
+    // ---- 3. group ids by owner: the peers' buckets first (rank order), MY bucket last ------------
+    self_cnt = (int64_t)send_cnt[me];
+    WG_EXPECTS(recv_cnt[me] == send_cnt[me], "self count mismatch");
+    bucket_start.assign(W, 0);
+    int64_t acc = 0;
+    for (int r = 0; r < W; r++) {
+      if (r == me) continue;
+      bucket_start[r] = acc;
+      acc += (int64_t)send_cnt[r];
+    }
+    bucket_start[me] = acc;
+    n_remote         = self_direct ? acc : n;  // leading rows of the grouped order that go through the exchange
+    auto* d_start = start_b.device<int64_t>(W, WHOLEMEMORY_DT_INT64);
+    d_grouped     = gid_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
+    d_pos         = pos_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
+    WG_HIP_CHECK(hipMemcpyAsync(d_start, bucket_start.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
+    if (n > 0) {
+      int grid = (int)((n + 256 * kBucketItems - 1) / (256 * kBucketItems));
+      if (idx_dtype == WHOLEMEMORY_DT_INT)
+        bucket_ids_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_start,
+                                                            d_counts + W, d_grouped, d_pos);
+      else
+        bucket_ids_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_start,
+                                                            d_counts + W, d_grouped, d_pos);
+      WG_HIP_CHECK(hipGetLastError());
+    }
+
+    // ---- 4. ids all-to-all-v: what I receive is packed in rank order (without my own bucket when it stays home) ----
+    send_n.assign(W, 0); recv_n.assign(W, 0); send_at.assign(W, 0); recv_at.assign(W, 0);
+    recv_total = 0;
+    for (int r = 0; r < W; r++) {
+      const bool skip = self_direct && r == me;
+      send_n[r]  = skip ? 0 : send_cnt[r];
+      recv_n[r]  = skip ? 0 : recv_cnt[r];
+      send_at[r] = (size_t)bucket_start[r];
+      recv_at[r] = (size_t)recv_total;
+      recv_total += (int64_t)recv_n[r];
+    }
+    d_recv_ids = rid_b.device<int64_t>(recv_total + (self_direct ? self_cnt : 0), WHOLEMEMORY_DT_INT64);
+    so.resize(W); sb.resize(W); ro.resize(W); rb.resize(W);
+    scaled(sizeof(int64_t), sizeof(int64_t), send_n, send_at, recv_n, recv_at);
+    alltoallv_bytes(comm, reinterpret_cast<const char*>(d_grouped), so, sb, reinterpret_cast<char*>(d_recv_ids), ro, rb, stream);
+    if (recv_total > 0) {
+      localize_ids_kernel<<<(int)((recv_total + 255) / 256), 256, 0, stream>>>(d_recv_ids, recv_total, local_start);
+      WG_HIP_CHECK(hipGetLastError());
+    }
+    d_self_ids = d_grouped + bucket_start[me];  // not part of any send when self_direct
+    d_self_pos = d_pos + bucket_start[me];
+    if (self_direct && self_cnt > 0) {
+      localize_ids_kernel<<<(int)((self_cnt + 255) / 256), 256, 0, stream>>>(d_self_ids, self_cnt, local_start);
+      WG_HIP_CHECK(hipGetLastError());
+    }
+  }
+
+  // byte offsets / sizes of one all-to-all-v from per-peer counts and positions (units of rows or ids)
+  void scaled(size_t unit_send, size_t unit_recv, const std::vector<size_t>& s_n, const std::vector<size_t>& s_at,
+              const std::vector<size_t>& r_n, const std::vector<size_t>& r_at)
+  {
+    for (int r = 0; r < W; r++) {
+      so[r] = s_at[r] * unit_send; sb[r] = s_n[r] * unit_send;
+      ro[r] = r_at[r] * unit_recv; rb[r] = r_n[r] * unit_recv;
+    }
+  }
+  // rows travel WITH the ids (scatter direction): my grouped rows -> the owners' receive order
+  void rows_to_owners(const char* send, char* recv, size_t row_bytes, hipStream_t stream)
+  {
+    scaled(row_bytes, row_bytes, send_n, send_at, recv_n, recv_at);
+    alltoallv_bytes(comm, send, so, sb, recv, ro, rb, stream);
+  }
+  // rows travel BACK (gather direction): what I gathered for peer r -> peer r's grouped order
+  void rows_to_askers(const char* send, char* recv, size_t row_bytes, hipStream_t stream)
+  {
+    scaled(row_bytes, row_bytes, recv_n, recv_at, send_n, send_at);
+    alltoallv_bytes(comm, send, so, sb, recv, ro, rb, stream);
+  }
 };
 
 }  // namespace
@@ -208,9 +353,6 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
                          wholememory_env_func_t* env, hipStream_t stream)
 {
   WG_EXPECTS(h->type == WHOLEMEMORY_MT_DISTRIBUTED || h->comm->size == 1, "unsupported memory type");
-  wholememory_comm_t comm = h->comm;
-  const int W             = comm->size;
-  WG_EXPECTS(W <= kMaxRanks, "too many ranks");
   const size_t tes         = dtype_size(tm.dtype);
   const size_t entry_bytes = (size_t)tm.stride * tes;
   WG_EXPECTS(h->granularity == entry_bytes, "tensor row stride (%zu B) != handle granularity (%zu B)", entry_bytes,
@@ -218,116 +360,16 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
   const int64_t row0 = tm.storage_offset / tm.stride;  // sub-tensor views: first row / first column of the view
   const int64_t col0 = tm.storage_offset % tm.stride;
   WG_REQUIRE_INPUT(tm.storage_offset >= 0 && col0 + tm.sizes[1] <= tm.stride, "bad storage offset");
-  std::vector<int64_t> entry_offsets(W + 1);
-  for (int r = 0; r <= W; r++) entry_offsets[r] = (int64_t)(h->byte_offsets[r] / entry_bytes);
-  const int64_t local_start = entry_offsets[comm->rank];
-  const int64_t local_rows  = entry_offsets[comm->rank + 1] - local_start;
 
-  // ---- 1. owners + counts ----------------------------------------------------------------------
-  temp_buffer offs_b(env), cnt_b(env), start_b(env), gid_b(env), pos_b(env), xcnt_b(env);
-  auto* d_offsets = offs_b.device<int64_t>(W + 1, WHOLEMEMORY_DT_INT64);
-  int* d_counts   = cnt_b.device<int>(2 * W, WHOLEMEMORY_DT_INT);  // [counts | cursors]
-  WG_HIP_CHECK(hipMemcpyAsync(d_offsets, entry_offsets.data(), sizeof(int64_t) * (W + 1), hipMemcpyHostToDevice, stream));
-  WG_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * 2 * W, stream));
-  if (n > 0) {
-    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
-    if (idx_dtype == WHOLEMEMORY_DT_INT)
-      owner_histogram_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_counts);
-    else
-      owner_histogram_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_counts);
-    WG_HIP_CHECK(hipGetLastError());
-  }
-  std::vector<int> h_counts(W);
-  WG_HIP_CHECK(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * W, hipMemcpyDeviceToHost, stream));
-  WG_HIP_CHECK(hipStreamSynchronize(stream));
-
-  // ---- 2. counts all-to-all (W x int64) ----------------------------------------------------------
-  exchange_plan plan;
-  plan.send_cnt.assign(W, 0);
-  plan.recv_cnt.assign(W, 0);
-  for (int r = 0; r < W; r++) plan.send_cnt[r] = (size_t)h_counts[r];
-  {
-    auto* d_x = xcnt_b.device<int64_t>(2 * W, WHOLEMEMORY_DT_INT64);
-    std::vector<int64_t> tmp(plan.send_cnt.begin(), plan.send_cnt.end());
-    WG_HIP_CHECK(hipMemcpyAsync(d_x, tmp.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
-    std::vector<size_t> eight(W, sizeof(int64_t)), at(W);
-    for (int r = 0; r < W; r++) at[r] = (size_t)r * sizeof(int64_t);
-    alltoallv_bytes(comm, reinterpret_cast<const char*>(d_x), at, eight, reinterpret_cast<char*>(d_x + W), at, eight, stream);
-    WG_HIP_CHECK(hipMemcpyAsync(tmp.data(), d_x + W, sizeof(int64_t) * W, hipMemcpyDeviceToHost, stream));
-    WG_HIP_CHECK(hipStreamSynchronize(stream));
-    for (int r = 0; r < W; r++) {
-      plan.recv_cnt[r] = (size_t)tmp[r];
-    }
-  }
-
-  // ---- 3. group ids by owner: the peers' buckets first (rank order), MY bucket last -------------------------
   // Rows I own never enter the exchange when no dtype conversion is asked for: one permuting copy moves them between my
   // partition and the dense rows (1/W of the traffic; all of it on a single-rank communicator).
-  const int me           = comm->rank;
-  const bool self_direct = tm.dtype == dense_m.dtype;
-  const int64_t self_cnt = (int64_t)plan.send_cnt[me];
-  WG_EXPECTS(plan.recv_cnt[me] == plan.send_cnt[me], "self count mismatch");
-  std::vector<int64_t> bucket_start(W);
-  int64_t acc = 0;
-  for (int r = 0; r < W; r++) {
-    if (r == me) continue;
-    bucket_start[r] = acc;
-    acc += (int64_t)plan.send_cnt[r];
-  }
-  bucket_start[me]       = acc;
-  const int64_t n_remote = self_direct ? acc : n;  // leading rows of the grouped order that go through the exchange
-  auto* d_start   = start_b.device<int64_t>(W, WHOLEMEMORY_DT_INT64);
-  auto* d_grouped = gid_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
-  auto* d_pos     = pos_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
-  WG_HIP_CHECK(hipMemcpyAsync(d_start, bucket_start.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
-  if (n > 0) {
-    int grid = (int)((n + 256 * kBucketItems - 1) / (256 * kBucketItems));
-    if (idx_dtype == WHOLEMEMORY_DT_INT)
-      bucket_ids_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_start,
-                                                          d_counts + W, d_grouped, d_pos);
-    else
-      bucket_ids_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_start,
-                                                          d_counts + W, d_grouped, d_pos);
-    WG_HIP_CHECK(hipGetLastError());
-  }
-
-  // ---- 4. ids all-to-all-v: what I receive is packed in rank order (without my own bucket when it stays home) ------
-  std::vector<size_t> send_n(W), recv_n(W), send_at(W), recv_at(W);  // in ids
-  int64_t recv_total = 0;
-  for (int r = 0; r < W; r++) {
-    const bool skip = self_direct && r == me;
-    send_n[r]  = skip ? 0 : plan.send_cnt[r];
-    recv_n[r]  = skip ? 0 : plan.recv_cnt[r];
-    send_at[r] = (size_t)bucket_start[r];
-    recv_at[r] = (size_t)recv_total;
-    recv_total += (int64_t)recv_n[r];
-  }
-  temp_buffer rid_b(env), rows_b(env), back_b(env);
-  auto* d_recv_ids = rid_b.device<int64_t>(recv_total, WHOLEMEMORY_DT_INT64);
-  std::vector<size_t> so(W), sb(W), ro(W), rb(W);
-  auto scaled = [&](size_t unit_send, size_t unit_recv, const std::vector<size_t>& s_n, const std::vector<size_t>& s_at,
-                    const std::vector<size_t>& r_n, const std::vector<size_t>& r_at) {
-    for (int r = 0; r < W; r++) {
-      so[r] = s_at[r] * unit_send; sb[r] = s_n[r] * unit_send;
-      ro[r] = r_at[r] * unit_recv; rb[r] = r_n[r] * unit_recv;
-    }
-  };
-  scaled(sizeof(int64_t), sizeof(int64_t), send_n, send_at, recv_n, recv_at);
-  alltoallv_bytes(comm, reinterpret_cast<const char*>(d_grouped), so, sb, reinterpret_cast<char*>(d_recv_ids), ro, rb, stream);
-  if (recv_total > 0) {
-    localize_ids_kernel<<<(int)((recv_total + 255) / 256), 256, 0, stream>>>(d_recv_ids, recv_total, local_start);
-    WG_HIP_CHECK(hipGetLastError());
-  }
-  int64_t* d_self_ids = d_grouped + bucket_start[me];  // not part of any send when self_direct
-  int64_t* d_self_pos = d_pos + bucket_start[me];
-  if (self_direct && self_cnt > 0) {
-    localize_ids_kernel<<<(int)((self_cnt + 255) / 256), 256, 0, stream>>>(d_self_ids, self_cnt, local_start);
-    WG_HIP_CHECK(hipGetLastError());
-  }
+  id_exchange x(env);
+  x.run(h, entry_bytes, row0, idx, idx_dtype, n, tm.dtype == dense_m.dtype, stream);
+  temp_buffer rows_b(env), back_b(env);
 
   // local partition viewed as a matrix of its own rows
   wholememory_matrix_description_t local_m = tm;
-  local_m.sizes[0]                         = local_rows;
+  local_m.sizes[0]                         = x.local_rows;
   local_m.storage_offset                   = 0;  // the row kernels take a pointer to the first element
   const char* local_base                   = static_cast<const char*>(h->local_ptr) + (size_t)col0 * tes;
   const int64_t F                          = tm.sizes[1];
@@ -338,34 +380,67 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
 
   if (!scatter) {
     // ---- 5. local gather (table dtype -> output dtype), 6. rows back, 7. un-permute ------------
-    if (self_direct) local_rows_permute(local_base, local_m, d_self_ids, d_self_pos, self_cnt, dense, dense0, stream);
-    sz2[0] = recv_total; sz2[1] = F;
+    if (x.self_direct) local_rows_permute(local_base, local_m, x.d_self_ids, x.d_self_pos, x.self_cnt, dense, dense0, stream);
+    sz2[0] = x.recv_total; sz2[1] = F;
     wholememory_matrix_description_t rows_m = wholememory_create_matrix_desc(sz2, F, 0, dense_m.dtype);
-    char* d_rows = static_cast<char*>(rows_b.alloc(recv_total * F, dense_m.dtype));
-    local_rows_gather(local_base, local_m, d_recv_ids, WHOLEMEMORY_DT_INT64, recv_total, d_rows, rows_m, stream);
-    sz2[0] = n_remote;
+    char* d_rows = static_cast<char*>(rows_b.alloc(x.recv_total * F, dense_m.dtype));
+    local_rows_gather(local_base, local_m, x.d_recv_ids, WHOLEMEMORY_DT_INT64, x.recv_total, d_rows, rows_m, stream);
+    sz2[0] = x.n_remote;
     wholememory_matrix_description_t back_m = wholememory_create_matrix_desc(sz2, F, 0, dense_m.dtype);
-    char* d_back = static_cast<char*>(back_b.alloc(n_remote * F, dense_m.dtype));
-    // I send what I gathered for peer r and receive what peer r gathered for me, in my grouped order
-    scaled((size_t)F * des, (size_t)F * des, recv_n, recv_at, send_n, send_at);
-    alltoallv_bytes(comm, d_rows, so, sb, d_back, ro, rb, stream);
-    local_rows_scatter(d_back, back_m, d_pos, WHOLEMEMORY_DT_INT64, n_remote, dense, dense0, stream);
+    char* d_back = static_cast<char*>(back_b.alloc(x.n_remote * F, dense_m.dtype));
+    x.rows_to_askers(d_rows, d_back, (size_t)F * des, stream);
+    local_rows_scatter(d_back, back_m, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, dense, dense0, stream);
   } else {
     // ---- scatter: permute my rows by owner, send ids + rows, owners write them -------------------
-    if (self_direct) local_rows_permute(dense, dense0, d_self_pos, d_self_ids, self_cnt, const_cast<char*>(local_base), local_m, stream);
-    sz2[0] = n_remote; sz2[1] = F;
+    if (x.self_direct)
+      local_rows_permute(dense, dense0, x.d_self_pos, x.d_self_ids, x.self_cnt, const_cast<char*>(local_base), local_m, stream);
+    sz2[0] = x.n_remote; sz2[1] = F;
     wholememory_matrix_description_t send_m = wholememory_create_matrix_desc(sz2, F, 0, tm.dtype);
-    char* d_send = static_cast<char*>(back_b.alloc(n_remote * F, tm.dtype));
-    local_rows_gather(dense, dense0, d_pos, WHOLEMEMORY_DT_INT64, n_remote, d_send, send_m, stream);  // also converts
-    sz2[0] = recv_total;
+    char* d_send = static_cast<char*>(back_b.alloc(x.n_remote * F, tm.dtype));
+    local_rows_gather(dense, dense0, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, d_send, send_m, stream);  // also converts
+    sz2[0] = x.recv_total;
     wholememory_matrix_description_t recv_m = wholememory_create_matrix_desc(sz2, F, 0, tm.dtype);
-    char* d_recv = static_cast<char*>(rows_b.alloc(recv_total * F, tm.dtype));
-    scaled((size_t)F * tes, (size_t)F * tes, send_n, send_at, recv_n, recv_at);
-    alltoallv_bytes(comm, d_send, so, sb, d_recv, ro, rb, stream);
-    local_rows_scatter(d_recv, recv_m, d_recv_ids, WHOLEMEMORY_DT_INT64, recv_total, const_cast<char*>(local_base), local_m,
+    char* d_recv = static_cast<char*>(rows_b.alloc(x.recv_total * F, tm.dtype));
+    x.rows_to_owners(d_send, d_recv, (size_t)F * tes, stream);
+    local_rows_scatter(d_recv, recv_m, x.d_recv_ids, WHOLEMEMORY_DT_INT64, x.recv_total, const_cast<char*>(local_base), local_m,
                        stream);
   }
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
+}
+
+// Every (id, row) pair goes to the rank that owns the id (the embedding gradient path; reference
+// embedding.cpp:183-236: bucket_and_exchange_ids_func + gather_func + exchange_embeddings_nccl_func).  On return
+// ids_out[k] is a LOCAL row number of my partition (negative ids stay negative), rows_out[k, :] its row; the pairs I own
+// myself are copied straight into the tail, they never touch RCCL.  Returns the number of pairs; enqueues only.
+int64_t route_rows_to_owners(wholememory_handle_t h, size_t entry_bytes, const void* idx, wholememory_dtype_t idx_dtype,
+                             int64_t n, const char* rows, wholememory_matrix_description_t rows_m, temp_buffer& ids_out,
+                             temp_buffer& rows_out, int64_t* local_rows, wholememory_env_func_t* env, hipStream_t stream)
+{
+  id_exchange x(env);
+  x.run(h, entry_bytes, 0, idx, idx_dtype, n, true, stream);
+  const int64_t F     = rows_m.sizes[1];
+  const size_t es     = dtype_size(rows_m.dtype);
+  const int64_t total = x.recv_total + x.self_cnt;
+  rows_m.storage_offset = 0;
+  int64_t sz2[2] = {x.n_remote, F};
+  temp_buffer send_b(env);
+  wholememory_matrix_description_t packed_m = wholememory_create_matrix_desc(sz2, F, 0, rows_m.dtype);
+  char* d_send = static_cast<char*>(send_b.alloc(x.n_remote * F, rows_m.dtype));
+  char* d_recv = static_cast<char*>(rows_out.alloc(total * F, rows_m.dtype));
+  auto* d_ids  = ids_out.device<int64_t>(total, WHOLEMEMORY_DT_INT64);
+  local_rows_gather(rows, rows_m, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, d_send, packed_m, stream);
+  x.rows_to_owners(d_send, d_recv, (size_t)F * es, stream);
+  packed_m.sizes[0] = x.self_cnt;
+  local_rows_gather(rows, rows_m, x.d_self_pos, WHOLEMEMORY_DT_INT64, x.self_cnt, d_recv + (size_t)x.recv_total * F * es,
+                    packed_m, stream);
+  if (x.recv_total)
+    WG_HIP_CHECK(hipMemcpyAsync(d_ids, x.d_recv_ids, sizeof(int64_t) * x.recv_total, hipMemcpyDeviceToDevice, stream));
+  if (x.self_cnt)
+    WG_HIP_CHECK(hipMemcpyAsync(d_ids + x.recv_total, x.d_self_ids, sizeof(int64_t) * x.self_cnt, hipMemcpyDeviceToDevice,
+                                stream));
+  *local_rows = x.local_rows;
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // the exchange scratch (grouped ids, send rows) is released on return
+  return total;
 }
 
 }  // namespace wgamd

@@ -141,6 +141,7 @@ class temp_buffer {
     return static_cast<T*>(alloc(n, dt, WHOLEMEMORY_MA_DEVICE));
   }
   void* bytes(int64_t n) { return alloc(n, WHOLEMEMORY_DT_INT8, WHOLEMEMORY_MA_DEVICE); }
+  void* pointer() const { return ptr_; }
   void* pinned_bytes(int64_t n) { return alloc(n, WHOLEMEMORY_DT_INT8, WHOLEMEMORY_MA_PINNED); }
 
  private:

@@ -1,0 +1,565 @@
+// Trainable embedding tables with sparse optimizers (include/wgamd_embedding.h).
+//
+// What the reference does (cpp/src/wholememory/embedding.cpp:136-313, embedding_optimizer.cpp,
+// cpp/src/wholememory_ops/functions/embedding_optimizer_func.cu:166-1024): route every (row id, gradient row) to the rank
+// that owns the row, de-duplicate the ids there while summing their gradients into a second buffer, then run one
+// workgroup per unique row through the optimizer formula.  Here, for one MI355X partition in HBM:
+//   * routing reuses the all-to-all-v of the feature fetch (wg_comm.hip); pairs a rank owns itself are copied straight
+//     into the receive buffer, they never touch RCCL;
+//   * the received ids are radix-sorted ONCE as (local row, arrival position) pairs — only the bits a local row number
+//     needs — and a single kernel walks the sorted order: the lane group that sits on the first pair of a row sums that
+//     row's gradients (in arrival order: deterministic) and applies the update in the same pass.  No compaction, no
+//     de-duplicated gradient buffer, no host round trip for the unique count;
+//   * rows are 16-byte padded, so 4-wide vector accesses whenever the gradient rows allow it.
+// Update formulas: embedding_optimizer_func.cu:203-214 (SGD), :394-421 (LazyAdam / AdamW), :657-671 (AdaGrad),
+// :867-881 (RMSProp); the CPU twin the reference tests against is
+// cpp/tests/wholememory_ops/wholememory_embedding_gradient_apply_tests.cu:221-300.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <string>
+#include <vector>
+
+#include "wg_common.hpp"
+#include "wgamd_embedding.h"
+
+struct wholememory_embedding_cache_policy_ {
+  int unused;
+};
+
+struct wholememory_embedding_optimizer_ {
+  wholememory_optimizer_type_t type = WHOLEMEMORY_OPT_NONE;
+  float weight_decay = 0.0f, epsilon = 1e-8f, beta1 = 0.9f, beta2 = 0.999f, adam_w = 0.0f, alpha = 0.99f;
+};
+
+struct wholememory_embedding_ {
+  wholememory_tensor_t allocated = nullptr;  // [entries, padded_dim]
+  wholememory_tensor_t user      = nullptr;  // view [entries, dim]
+  wholememory_comm_t comm        = nullptr;
+  wholememory_dtype_t dtype      = WHOLEMEMORY_DT_UNKNOWN;
+  int64_t entries = 0, dim = 0, padded_dim = 0;
+  wholememory_embedding_optimizer_t optimizer = nullptr;
+  wholememory_tensor_t state_table = nullptr;  // fp32 [entries, n_states * state_dim], same row partition
+  wholememory_tensor_t row_state   = nullptr;  // fp32 [entries, 2] (LazyAdam beta1^t, beta2^t)
+  int64_t state_dim                = 0;        // dim rounded up to 4 floats
+  std::vector<std::string> state_names;
+  std::vector<wholememory_tensor_t> state_views;
+  std::vector<const char*> names_c;  // NULL-terminated
+};
+
+namespace wgamd {
+
+int64_t route_rows_to_owners(wholememory_handle_t h, size_t entry_bytes, const void* idx, wholememory_dtype_t idx_dtype,
+                             int64_t n, const char* rows, wholememory_matrix_description_t rows_m, temp_buffer& ids_out,
+                             temp_buffer& rows_out, int64_t* local_rows, wholememory_env_func_t* env, hipStream_t stream);
+
+namespace {
+
+enum { kSgd = 0, kLazyAdam, kAdaGrad, kRmsProp };
+
+struct step_params {
+  float lr, weight_decay, epsilon, beta1, beta2, alpha;
+  int adam_w;
+};
+
+template <typename T>
+__device__ __forceinline__ float emb_to_f32(T v);
+template <>
+__device__ __forceinline__ float emb_to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float emb_to_f32<__half>(__half v) { return __half2float(v); }
+template <>
+__device__ __forceinline__ float emb_to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <typename T>
+__device__ __forceinline__ T emb_from_f32(float v);
+template <>
+__device__ __forceinline__ float emb_from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half emb_from_f32<__half>(float v) { return __float2half(v); }
+template <>
+__device__ __forceinline__ __hip_bfloat16 emb_from_f32<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) pack {
+  T v[V];
+};
+
+// sort key of a routed pair: its local row, or `local_rows` (one past the last row) for ids to skip
+__global__ void __launch_bounds__(256) sort_keys_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t local_rows,
+                                                        uint64_t* __restrict__ keys, int* __restrict__ vals)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  keys[i] = (id < 0 || id >= local_rows) ? (uint64_t)local_rows : (uint64_t)id;
+  vals[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(256) fill_f32_kernel(float* p, int64_t n, float v)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// One lane group per sorted pair; only the group on the FIRST pair of a row works: it sums the row's gradients over the
+// run of equal keys and updates embedding + states.  st = [m | v] / [state_sum] / [v], each `sdim` floats wide.
+template <typename EmbT, int OPT, int V>
+__global__ void __launch_bounds__(256)
+sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int64_t n, int64_t local_rows,
+                    const float* __restrict__ grads, int64_t ldg, EmbT* __restrict__ emb, int64_t lde, float* __restrict__ st,
+                    int64_t lds, int64_t sdim, float* __restrict__ row_state, int dim, step_params p, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  for (int64_t i = tid >> log2_lanes; i < n; i += ngroups) {
+    const uint64_t key = keys[i];
+    if (key >= (uint64_t)local_rows) continue;
+    if (i > 0 && keys[i - 1] == key) continue;
+    int64_t end = i + 1;
+    while (end < n && keys[end] == key) end++;
+    float b1t = 0.f, b2t = 0.f;
+    if (OPT == kLazyAdam) {
+      b1t = row_state[key * 2] * p.beta1;
+      b2t = row_state[key * 2 + 1] * p.beta2;
+    }
+    EmbT* e_row = emb + key * lde;
+    float* s_row = OPT == kSgd ? nullptr : st + key * lds;
+    for (int c = sub * V; c < dim; c += lanes * V) {
+      float g[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) g[j] = 0.f;
+      for (int64_t k = i; k < end; k++) {
+        const pack<float, V> t = *reinterpret_cast<const pack<float, V>*>(grads + (int64_t)vals[k] * ldg + c);
+#pragma unroll
+        for (int j = 0; j < V; j++) g[j] += t.v[j];
+      }
+      pack<EmbT, V> ev = *reinterpret_cast<const pack<EmbT, V>*>(e_row + c);
+      pack<float, V> s0, s1;
+      if (OPT != kSgd) s0 = *reinterpret_cast<const pack<float, V>*>(s_row + c);
+      if (OPT == kLazyAdam) s1 = *reinterpret_cast<const pack<float, V>*>(s_row + sdim + c);
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        float x  = emb_to_f32<EmbT>(ev.v[j]);
+        float gv = g[j];
+        if (OPT == kLazyAdam && p.adam_w) {
+          x -= p.lr * p.weight_decay * x;
+        } else {
+          gv += p.weight_decay * x;
+        }
+        if (OPT == kSgd) {
+          x -= p.lr * gv;
+        } else if (OPT == kLazyAdam) {
+          const float m = p.beta1 * s0.v[j] + (1.f - p.beta1) * gv;
+          const float v = p.beta2 * s1.v[j] + (1.f - p.beta2) * gv * gv;
+          const float mhat = m / (1.f - b1t);
+          const float vhat = v / (1.f - b2t);
+          x -= p.lr * mhat / (sqrtf(vhat) + p.epsilon);
+          s0.v[j] = m;
+          s1.v[j] = v;
+        } else if (OPT == kAdaGrad) {
+          const float sum = s0.v[j] + gv * gv;
+          x -= p.lr * gv / (sqrtf(sum) + p.epsilon);
+          s0.v[j] = sum;
+        } else {
+          const float v = p.alpha * s0.v[j] + (1.f - p.alpha) * gv * gv;
+          x -= p.lr * gv / (sqrtf(v) + p.epsilon);
+          s0.v[j] = v;
+        }
+        ev.v[j] = emb_from_f32<EmbT>(x);
+      }
+      *reinterpret_cast<pack<EmbT, V>*>(e_row + c) = ev;
+      if (OPT != kSgd) *reinterpret_cast<pack<float, V>*>(s_row + c) = s0;
+      if (OPT == kLazyAdam) *reinterpret_cast<pack<float, V>*>(s_row + sdim + c) = s1;
+    }
+    if (OPT == kLazyAdam && sub == 0) {  // after every lane of the group (same wave) has read the old powers
+      row_state[key * 2]     = b1t;
+      row_state[key * 2 + 1] = b2t;
+    }
+  }
+}
+
+template <typename EmbT, int OPT>
+void launch_apply(bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* grads,
+                  int64_t ldg, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
+                  step_params p, hipStream_t stream)
+{
+  const int V      = vec4 ? 4 : 1;
+  int l2           = 0;
+  while ((1 << l2) * V < dim && l2 < 6) l2++;
+  const int64_t gpb = 256 >> l2;
+  const int grid    = (int)std::min<int64_t>((n + gpb - 1) / gpb, 256 * 16);
+  if (vec4)
+    sparse_apply_kernel<EmbT, OPT, 4><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, grads, ldg, static_cast<EmbT*>(emb),
+                                                               lde, st, lds, sdim, row_state, dim, p, l2);
+  else
+    sparse_apply_kernel<EmbT, OPT, 1><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, grads, ldg, static_cast<EmbT*>(emb),
+                                                               lde, st, lds, sdim, row_state, dim, p, l2);
+  WG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename EmbT>
+void dispatch_opt(int opt, bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* grads,
+                  int64_t ldg, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
+                  step_params p, hipStream_t stream)
+{
+  switch (opt) {
+    case kSgd: return launch_apply<EmbT, kSgd>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    case kLazyAdam: return launch_apply<EmbT, kLazyAdam>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    case kAdaGrad: return launch_apply<EmbT, kAdaGrad>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    default: return launch_apply<EmbT, kRmsProp>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+  }
+}
+
+int opt_code(wholememory_optimizer_type_t t)
+{
+  switch (t) {
+    case WHOLEMEMORY_OPT_SGD: return kSgd;
+    case WHOLEMEMORY_OPT_LAZY_ADAM: return kLazyAdam;
+    case WHOLEMEMORY_OPT_ADAGRAD: return kAdaGrad;
+    case WHOLEMEMORY_OPT_RMSPROP: return kRmsProp;
+    default: return -1;
+  }
+}
+
+void* local_pointer(wholememory_tensor_t t, size_t* local_bytes = nullptr)
+{
+  void* ptr = nullptr;
+  size_t sz = 0, off = 0;
+  if (wholememory_get_local_memory(&ptr, &sz, &off, wholememory_tensor_get_memory_handle(t)) != WHOLEMEMORY_SUCCESS)
+    throw logic_error("no local memory");
+  if (local_bytes) *local_bytes = sz;
+  return ptr;
+}
+
+std::vector<size_t> entry_partition(wholememory_tensor_t t)
+{
+  wholememory_handle_t h = wholememory_tensor_get_memory_handle(t);
+  int W                  = 1;
+  wholememory_comm_t c   = nullptr;
+  wholememory_get_communicator(&c, h);
+  wholememory_communicator_get_size(&W, c);
+  std::vector<size_t> sizes(W);
+  wholememory_get_rank_partition_sizes(sizes.data(), h);
+  const size_t g = wholememory_get_data_granularity(h);
+  for (auto& s : sizes) s /= g;
+  return sizes;
+}
+
+void destroy_states(wholememory_embedding_t e)
+{
+  for (auto v : e->state_views) wholememory_destroy_tensor(v);
+  e->state_views.clear();
+  if (e->state_table) wholememory_destroy_tensor(e->state_table);
+  if (e->row_state) wholememory_destroy_tensor(e->row_state);
+  e->state_table = e->row_state = nullptr;
+}
+
+void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_tensor_t grads, float lr,
+          wholememory_env_func_t* env, hipStream_t stream)
+{
+  WG_REQUIRE_INPUT(e && indices && grads && env, "null argument");
+  if (!e->optimizer) throw logic_error("no optimizer set on this embedding");
+  const auto* id = wholememory_tensor_get_tensor_description(indices);
+  const auto* gd = wholememory_tensor_get_tensor_description(grads);
+  WG_REQUIRE_INPUT(id->dim == 1 && (id->dtype == WHOLEMEMORY_DT_INT || id->dtype == WHOLEMEMORY_DT_INT64),
+                   "indices must be a 1-D int32 / int64 tensor");
+  WG_REQUIRE_INPUT(gd->dim == 2 && gd->dtype == WHOLEMEMORY_DT_FLOAT, "grads must be a 2-D float tensor");
+  WG_REQUIRE_INPUT(gd->sizes[0] == id->sizes[0] && gd->sizes[1] == e->dim && gd->strides[0] >= e->dim && gd->strides[1] == 1,
+                   "grads must be [len(indices), embedding_dim]");
+  WG_REQUIRE_INPUT(!wholememory_tensor_has_handle(indices) && !wholememory_tensor_has_handle(grads),
+                   "indices / grads must be plain device tensors");
+  const int64_t n  = id->sizes[0];
+  const size_t ies = dtype_size(id->dtype), es = dtype_size(e->dtype);
+  const char* idx  = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices)) + id->storage_offset * ies;
+  const char* g    = static_cast<const char*>(wholememory_tensor_get_data_pointer(grads)) + gd->storage_offset * 4;
+  int64_t sz2[2]   = {n, e->dim};
+  wholememory_matrix_description_t gm = wholememory_create_matrix_desc(sz2, gd->strides[0], 0, WHOLEMEMORY_DT_FLOAT);
+
+  temp_buffer ids_b(env), rows_b(env), keys_b(env), vals_b(env), keys2_b(env), vals2_b(env), tmp_b(env);
+  int64_t local_rows = 0;
+  const int64_t R    = route_rows_to_owners(wholememory_tensor_get_memory_handle(e->allocated), (size_t)e->padded_dim * es, idx,
+                                            id->dtype, n, g, gm, ids_b, rows_b, &local_rows, env, stream);
+  if (R > 0 && local_rows > 0) {
+    WG_EXPECTS(R < (int64_t)1 << 31, "too many gradient rows in one call");
+    auto* keys  = keys_b.device<uint64_t>(R, WHOLEMEMORY_DT_INT64);
+    auto* keys2 = keys2_b.device<uint64_t>(R, WHOLEMEMORY_DT_INT64);
+    auto* vals  = vals_b.device<int>(R, WHOLEMEMORY_DT_INT);
+    auto* vals2 = vals2_b.device<int>(R, WHOLEMEMORY_DT_INT);
+    // ids_b / rows_b were filled by route_rows_to_owners
+    const int64_t* d_ids = static_cast<const int64_t*>(ids_b.pointer());
+    const float* d_rows  = static_cast<const float*>(rows_b.pointer());
+    sort_keys_kernel<<<(int)((R + 255) / 256), 256, 0, stream>>>(d_ids, R, local_rows, keys, vals);
+    WG_HIP_CHECK(hipGetLastError());
+    unsigned bits = 1;
+    while (((uint64_t)1 << bits) <= (uint64_t)local_rows && bits < 63) bits++;  // keys are in [0, local_rows]
+    size_t tmp_bytes = 0;
+    WG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)R, 0u, bits, stream));
+    void* tmp = tmp_b.bytes((int64_t)tmp_bytes);
+    WG_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)R, 0u, bits, stream));
+
+    const auto* o = e->optimizer;
+    step_params p{lr, o->weight_decay, o->epsilon, o->beta1, o->beta2, o->alpha, o->adam_w > 0.5f ? 1 : 0};
+    void* emb        = local_pointer(e->allocated);
+    float* st        = e->state_table ? static_cast<float*>(local_pointer(e->state_table)) : nullptr;
+    float* row_state = e->row_state ? static_cast<float*>(local_pointer(e->row_state)) : nullptr;
+    const int64_t lds = (int64_t)e->state_names.size() > 0 && e->state_table
+                          ? wholememory_tensor_get_tensor_description(e->state_table)->strides[0]
+                          : 0;
+    const bool vec4 = e->dim % 4 == 0;  // routed gradient rows are packed [R, dim]: 16-byte aligned rows iff dim % 4 == 0
+    const int opt   = opt_code(o->type);
+    switch (e->dtype) {
+      case WHOLEMEMORY_DT_FLOAT:
+        dispatch_opt<float>(opt, vec4, keys2, vals2, R, local_rows, d_rows, e->dim, emb, e->padded_dim, st, lds, e->state_dim,
+                            row_state, (int)e->dim, p, stream);
+        break;
+      case WHOLEMEMORY_DT_HALF:
+        dispatch_opt<__half>(opt, vec4, keys2, vals2, R, local_rows, d_rows, e->dim, emb, e->padded_dim, st, lds, e->state_dim,
+                             row_state, (int)e->dim, p, stream);
+        break;
+      default:
+        dispatch_opt<__hip_bfloat16>(opt, vec4, keys2, vals2, R, local_rows, d_rows, e->dim, emb, e->padded_dim, st, lds,
+                                     e->state_dim, row_state, (int)e->dim, p, stream);
+        break;
+    }
+  }
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
+}
+
+}  // namespace
+}  // namespace wgamd
+
+extern "C" {
+
+using namespace wgamd;
+
+wholememory_error_code_t wholememory_create_embedding_optimizer(wholememory_embedding_optimizer_t* optimizer,
+                                                                wholememory_optimizer_type_t optimizer_type)
+{
+  if (!optimizer) return WHOLEMEMORY_INVALID_INPUT;
+  if (opt_code(optimizer_type) < 0) return WHOLEMEMORY_NOT_IMPLEMENTED;  // embedding_optimizer.cpp:496-498
+  *optimizer         = new wholememory_embedding_optimizer_();
+  (*optimizer)->type = optimizer_type;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_optimizer_set_parameter(wholememory_embedding_optimizer_t o, const char* name, void* value)
+{
+  if (!o || !name || !value) return WHOLEMEMORY_INVALID_INPUT;
+  const float v    = *static_cast<const float*>(value);
+  const auto t     = o->type;
+  const bool adam  = t == WHOLEMEMORY_OPT_LAZY_ADAM;
+  float* slot      = nullptr;
+  if (!strcmp(name, "weight_decay")) slot = &o->weight_decay;
+  else if (!strcmp(name, "epsilon") && t != WHOLEMEMORY_OPT_SGD) slot = &o->epsilon;
+  else if (!strcmp(name, "beta1") && adam) slot = &o->beta1;
+  else if (!strcmp(name, "beta2") && adam) slot = &o->beta2;
+  else if (!strcmp(name, "adam_w") && adam) slot = &o->adam_w;
+  else if (!strcmp(name, "alpha") && t == WHOLEMEMORY_OPT_RMSPROP) slot = &o->alpha;
+  if (!slot) {
+    fprintf(stderr, "[wholegraph_amd] parameter name %s is not valid for this optimizer\n", name);
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  *slot = v;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+void wholememory_destroy_embedding_optimizer(wholememory_embedding_optimizer_t optimizer) { delete optimizer; }
+
+wholememory_error_code_t wholememory_create_embedding_cache_policy(wholememory_embedding_cache_policy_t* cache_policy,
+                                                                   wholememory_comm_t, wholememory_memory_type_t,
+                                                                   wholememory_memory_location_t, wholememory_access_type_t,
+                                                                   float)
+{
+  if (cache_policy) *cache_policy = nullptr;
+  fprintf(stderr,
+          "[wholegraph_amd] embedding cache policies are not supported: tables live in HBM (DISTRIBUTED/DEVICE), there is "
+          "no slower tier to cache\n");
+  return WHOLEMEMORY_NOT_SUPPORTED;
+}
+
+wholememory_error_code_t wholememory_destroy_embedding_cache_policy(wholememory_embedding_cache_policy_t cache_policy)
+{
+  delete cache_policy;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* out, wholememory_tensor_description_t* desc,
+                                                      wholememory_comm_t comm, wholememory_memory_type_t memory_type,
+                                                      wholememory_memory_location_t memory_location,
+                                                      wholememory_embedding_cache_policy_t cache_policy,
+                                                      size_t* embedding_entry_partition, int /*user_defined_sms*/,
+                                                      int round_robin_size)
+{
+  if (!out || !desc || !comm) return WHOLEMEMORY_INVALID_INPUT;
+  if (desc->dim != 2 || desc->storage_offset != 0 || desc->sizes[1] <= 0) {
+    fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: the description must be a 2-D matrix\n");
+    return WHOLEMEMORY_INVALID_INPUT;
+  }
+  if (cache_policy != nullptr || round_robin_size != 0) {
+    fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: cache policies / round-robin sharding are not supported\n");
+    return WHOLEMEMORY_NOT_SUPPORTED;
+  }
+  const size_t es = wholememory_dtype_get_element_size(desc->dtype);
+  if (es == 0 || es > 16) return WHOLEMEMORY_INVALID_INPUT;
+  auto* e       = new wholememory_embedding_();
+  e->comm       = comm;
+  e->dtype      = desc->dtype;
+  e->entries    = desc->sizes[0];
+  e->dim        = desc->sizes[1];
+  const int64_t align = es >= 16 ? 1 : (int64_t)(16 / es);
+  e->padded_dim = (e->dim + align - 1) / align * align;
+  wholememory_tensor_description_t padded = *desc;
+  padded.sizes[1]   = e->padded_dim;
+  padded.strides[0] = e->padded_dim;
+  padded.strides[1] = 1;
+  auto rc = wholememory_create_tensor(&e->allocated, &padded, comm, memory_type, memory_location, embedding_entry_partition);
+  if (rc != WHOLEMEMORY_SUCCESS) {
+    delete e;
+    return rc;
+  }
+  int64_t starts[2] = {0, 0}, ends[2] = {-1, e->dim};
+  rc = wholememory_tensor_get_subtensor(e->allocated, starts, ends, &e->user);
+  if (rc != WHOLEMEMORY_SUCCESS) {
+    wholememory_destroy_tensor(e->allocated);
+    delete e;
+    return rc;
+  }
+  e->names_c = {nullptr};
+  *out       = e;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_destroy_embedding(wholememory_embedding_t e)
+{
+  if (!e) return WHOLEMEMORY_INVALID_INPUT;
+  destroy_states(e);
+  wholememory_destroy_tensor(e->user);
+  wholememory_destroy_tensor(e->allocated);
+  delete e;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_tensor_t wholememory_embedding_get_embedding_tensor(wholememory_embedding_t e) { return e ? e->user : nullptr; }
+
+wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embedding_t e, wholememory_embedding_optimizer_t opt)
+{
+  if (!e || !opt) return WHOLEMEMORY_INVALID_INPUT;
+  if (e->optimizer) {
+    fprintf(stderr, "[wholegraph_amd] wholememory_embedding_set_optimizer: the optimizer can only be set once\n");
+    return WHOLEMEMORY_LOGIC_ERROR;  // embedding.cpp:487-491
+  }
+  if (e->dtype != WHOLEMEMORY_DT_FLOAT && e->dtype != WHOLEMEMORY_DT_HALF && e->dtype != WHOLEMEMORY_DT_BF16) {
+    fprintf(stderr, "[wholegraph_amd] wholememory_embedding_set_optimizer: trainable tables are float / half / bf16\n");
+    return WHOLEMEMORY_INVALID_INPUT;  // embedding_optimizer_func.cu:74-76
+  }
+  return guarded("wholememory_embedding_set_optimizer", [&] {
+    switch (opt->type) {
+      case WHOLEMEMORY_OPT_LAZY_ADAM: e->state_names = {"m", "v"}; break;
+      case WHOLEMEMORY_OPT_ADAGRAD: e->state_names = {"state_sum"}; break;
+      case WHOLEMEMORY_OPT_RMSPROP: e->state_names = {"v"}; break;
+      default: e->state_names.clear(); break;
+    }
+    e->state_dim           = (e->dim + 3) / 4 * 4;
+    std::vector<size_t> pt = entry_partition(e->allocated);
+    const int n_states     = (int)e->state_names.size();
+    auto fail_if = [&](wholememory_error_code_t rc, const char* what) {
+      if (rc != WHOLEMEMORY_SUCCESS) {
+        destroy_states(e);
+        e->state_names.clear();
+        throw logic_error(fmt("%s failed (%d)", what, (int)rc));
+      }
+    };
+    if (n_states > 0) {
+      wholememory_tensor_description_t d;
+      wholememory_initialize_tensor_desc(&d);
+      d.dim        = 2;
+      d.dtype      = WHOLEMEMORY_DT_FLOAT;
+      d.sizes[0]   = e->entries;
+      d.sizes[1]   = n_states * e->state_dim;
+      d.strides[0] = d.sizes[1];
+      d.strides[1] = 1;
+      fail_if(wholememory_create_tensor(&e->state_table, &d, e->comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE,
+                                        pt.data()),
+              "state table allocation");
+      size_t bytes = 0;
+      void* p      = local_pointer(e->state_table, &bytes);
+      if (bytes) WG_HIP_CHECK(hipMemset(p, 0, bytes));  // embedding_optimizer.cpp:203-207: states start at zero
+      for (int k = 0; k < n_states; k++) {
+        int64_t starts[2] = {0, k * e->state_dim}, ends[2] = {-1, k * e->state_dim + e->dim};
+        wholememory_tensor_t view = nullptr;
+        fail_if(wholememory_tensor_get_subtensor(e->state_table, starts, ends, &view), "state view");
+        e->state_views.push_back(view);
+      }
+    }
+    if (opt->type == WHOLEMEMORY_OPT_LAZY_ADAM) {
+      wholememory_tensor_description_t d;
+      wholememory_initialize_tensor_desc(&d);
+      d.dim        = 2;
+      d.dtype      = WHOLEMEMORY_DT_FLOAT;
+      d.sizes[0]   = e->entries;
+      d.sizes[1]   = 2;
+      d.strides[0] = 2;
+      d.strides[1] = 1;
+      fail_if(wholememory_create_tensor(&e->row_state, &d, e->comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, pt.data()),
+              "per-row state allocation");
+      size_t bytes = 0;
+      auto* p      = static_cast<float*>(local_pointer(e->row_state, &bytes));
+      if (bytes) {  // embedding_optimizer.cpp:208-209: beta1^0 = beta2^0 = 1
+        fill_f32_kernel<<<256, 256, 0, nullptr>>>(p, (int64_t)(bytes / 4), 1.0f);
+        WG_HIP_CHECK(hipGetLastError());
+      }
+      e->state_names.push_back("beta12t");
+      e->state_views.push_back(nullptr);  // the whole per-row table
+    }
+    WG_HIP_CHECK(hipDeviceSynchronize());
+    e->names_c.clear();
+    for (auto& s : e->state_names) e->names_c.push_back(s.c_str());
+    e->names_c.push_back(nullptr);
+    e->optimizer = opt;
+  });
+}
+
+wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t e, wholememory_tensor_t indices,
+                                                      wholememory_tensor_t output, bool /*adjust_cache*/,
+                                                      wholememory_env_func_t* p_env_fns, int64_t stream_int)
+{
+  if (!e) return WHOLEMEMORY_INVALID_INPUT;
+  return wholememory_gather(e->user, indices, output, p_env_fns, reinterpret_cast<void*>(stream_int), -1);
+}
+
+wholememory_error_code_t wholememory_embedding_gather_gradient_apply(wholememory_embedding_t e, wholememory_tensor_t indices,
+                                                                     wholememory_tensor_t grads, bool /*adjust_cache*/,
+                                                                     float lr, wholememory_env_func_t* p_env_fns,
+                                                                     int64_t stream_int)
+{
+  return guarded("wholememory_embedding_gather_gradient_apply",
+                 [&] { step(e, indices, grads, lr, p_env_fns, reinterpret_cast<hipStream_t>(stream_int)); });
+}
+
+const char* const* wholememory_embedding_get_optimizer_state_names(wholememory_embedding_t e)
+{
+  return e ? e->names_c.data() : nullptr;
+}
+
+wholememory_tensor_t wholememory_embedding_get_optimizer_state(wholememory_embedding_t e, const char* name)
+{
+  if (!e || !name) return nullptr;
+  for (size_t k = 0; k < e->state_names.size(); k++)
+    if (e->state_names[k] == name) return e->state_views[k] ? e->state_views[k] : e->row_state;
+  return nullptr;
+}
+
+wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t e, int64_t)
+{
+  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+}
+
+wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t)
+{
+  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+}
+
+}  // extern "C"

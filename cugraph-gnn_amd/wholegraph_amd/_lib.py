@@ -164,6 +164,25 @@ SYMBOLS = {
     "wholememory_load_from_file": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, POINTER(ctypes.c_char_p), c_int,
                                            c_int]),
     "wholememory_store_to_file": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, ctypes.c_char_p]),
+    # wgamd_embedding.h
+    "wholememory_create_embedding_optimizer": (c_int, [POINTER(c_void_p), c_int]),
+    "wholememory_optimizer_set_parameter": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
+    "wholememory_destroy_embedding_optimizer": (None, [c_void_p]),
+    "wholememory_create_embedding_cache_policy": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int,
+                                                          ctypes.c_float]),
+    "wholememory_destroy_embedding_cache_policy": (c_int, [c_void_p]),
+    "wholememory_create_embedding": (c_int, [POINTER(c_void_p), POINTER(TensorDescription), c_void_p, c_int, c_int,
+                                             c_void_p, POINTER(c_size_t), c_int, c_int]),
+    "wholememory_destroy_embedding": (c_int, [c_void_p]),
+    "wholememory_embedding_get_embedding_tensor": (_T, [c_void_p]),
+    "wholememory_embedding_set_optimizer": (c_int, [c_void_p, c_void_p]),
+    "wholememory_embedding_gather": (c_int, [c_void_p, _T, _T, c_bool, c_void_p, c_int64]),
+    "wholememory_embedding_gather_gradient_apply": (c_int, [c_void_p, _T, _T, c_bool, ctypes.c_float, c_void_p,
+                                                            c_int64]),
+    "wholememory_embedding_get_optimizer_state_names": (POINTER(ctypes.c_char_p), [c_void_p]),
+    "wholememory_embedding_get_optimizer_state": (_T, [c_void_p, ctypes.c_char_p]),
+    "wholememory_embedding_writeback_cache": (c_int, [c_void_p, c_int64]),
+    "wholememory_embedding_drop_all_cache": (c_int, [c_void_p, c_int64]),
     # wgamd_ext.h
     "wgamd_spmm_csr_f32":(c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
                                    c_int, c_void_p, c_int64, c_void_p]),

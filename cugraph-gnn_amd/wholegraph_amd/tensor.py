@@ -149,12 +149,19 @@ class DistributedWholeMemoryTensor(object):
     pipeline INSIDE the library (csrc/wg_comm.hip) and are collective over the communicator.  Same methods as
     ``pylibwholegraph.torch.tensor.WholeMemoryTensor`` (tensor.py:24-123)."""
 
-    def __init__(self, c_tensor, comm, dtype, shape):
+    def __init__(self, c_tensor, comm, dtype=None, shape=None, owner=True):
         import ctypes
+        from .env import wm_dtype_to_torch
         self.c = ctypes.c_void_p(c_tensor)
         self.comm = comm
-        self._dtype = dtype
-        self._shape = tuple(int(v) for v in shape)
+        d = L.lib().wholememory_tensor_get_tensor_description(self.c).contents
+        self._dtype = dtype if dtype is not None else wm_dtype_to_torch(d.dtype)
+        self._shape = tuple(int(d.sizes[i]) for i in range(d.dim)) if shape is None else tuple(int(v) for v in shape)
+        # a view of a wider table (embedding tables are padded to 16 B; optimizer states share one table)
+        self._row_stride = int(d.strides[0]) if d.dim == 2 else 1
+        self._col0 = int(d.storage_offset) % self._row_stride if d.dim == 2 else 0
+        assert d.dim == 1 or int(d.storage_offset) < self._row_stride, "row-offset views are not exposed to torch"
+        self._owner = owner  # False: the C tensor belongs to an embedding (destroyed with it)
         self._local_view = None
 
     @property
@@ -202,9 +209,11 @@ class DistributedWholeMemoryTensor(object):
             if n.value == 0:
                 self._local_view = torch.empty(shape, dtype=self._dtype, device="cuda")
             else:
-                view = torch.as_tensor(_DevicePointerView(ptr.value, shape, _TYPESTR[self._dtype], self),
+                full = (n.value, self._row_stride) if self.dim() == 2 else shape
+                view = torch.as_tensor(_DevicePointerView(ptr.value, full, _TYPESTR[self._dtype], self),
                                        device="cuda")
-                self._local_view = view.view(self._dtype) if view.dtype != self._dtype else view
+                view = view.view(self._dtype) if view.dtype != self._dtype else view
+                self._local_view = view[:, self._col0:self._col0 + shape[1]] if self.dim() == 2 else view
         t = self._local_view
         return (t.cpu() if host_view else t), start.value
 
@@ -230,6 +239,11 @@ class DistributedWholeMemoryTensor(object):
         row = self._shape[1] if self.dim() == 2 else 1
         return row * torch.empty((), dtype=self._dtype).element_size()
 
+    def _memory_layout(self):
+        """(byte offset of column 0 inside a stored row, stored row bytes, bytes of one row of THIS tensor)."""
+        es = torch.empty((), dtype=self._dtype).element_size()
+        return self._col0 * es, self._row_stride * es, self._entry_bytes()
+
     def from_filelist(self, filelist, round_robin_size: int = 0):
         """Collective: the files, read as one concatenated array of rows, fill the tensor (rank-local rows only
         are read by each rank); ``round_robin_size`` > 0 deals blocks of that many rows to the ranks in turn."""
@@ -238,8 +252,8 @@ class DistributedWholeMemoryTensor(object):
             filelist = [filelist]
         names = (ctypes.c_char_p * len(filelist))(*[os.fsencode(f) for f in filelist])
         handle = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(self.c))
-        eb = self._entry_bytes()
-        L.check(L.lib().wholememory_load_from_file(handle, 0, eb, eb, names, len(filelist), int(round_robin_size)),
+        off, stride, eb = self._memory_layout()
+        L.check(L.lib().wholememory_load_from_file(handle, off, stride, eb, names, len(filelist), int(round_robin_size)),
                 "wholememory_load_from_file")
 
     def from_file_prefix(self, file_prefix: str, part_count: Union[int, None] = None):
@@ -251,8 +265,9 @@ class DistributedWholeMemoryTensor(object):
         """Collective: every rank writes its own rows to its own file."""
         import ctypes
         handle = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(self.c))
-        eb = self._entry_bytes()
-        L.check(L.lib().wholememory_store_to_file(handle, 0, eb, eb, os.fsencode(filename)), "wholememory_store_to_file")
+        off, stride, eb = self._memory_layout()
+        L.check(L.lib().wholememory_store_to_file(handle, off, stride, eb, os.fsencode(filename)),
+                "wholememory_store_to_file")
 
     def to_file_prefix(self, file_prefix: str):
         self.local_to_file(get_part_file_name(file_prefix, self.comm.get_rank(), self.comm.get_size()))
@@ -260,7 +275,8 @@ class DistributedWholeMemoryTensor(object):
     def destroy(self):
         if self.c is not None and self.c.value:
             self._local_view = None
-            L.check(L.lib().wholememory_destroy_tensor(self.c), "wholememory_destroy_tensor")
+            if self._owner:
+                L.check(L.lib().wholememory_destroy_tensor(self.c), "wholememory_destroy_tensor")
             self.c = None
 
 

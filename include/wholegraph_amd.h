@@ -9,6 +9,7 @@
 #ifndef WHOLEGRAPH_AMD_H_
 #define WHOLEGRAPH_AMD_H_
 #include "wgamd_comm.h"
+#include "wgamd_embedding.h"
 #include "wgamd_ext.h"
 #include "wgamd_ops.h"
 #include "wgamd_tensor.h"
