@@ -214,6 +214,30 @@ def main():
         t = timed(lambda: nn.gat_forward(hop2[0], col2, x, a_s, a_d, H, 0.2, need_alpha=True), events=True)
         add("GAT (+alpha out for backward) H=%d C=%d" % (H, C), "—", t,
             Eh * (4 * H + 4) + T * 4 * H + Eh * (4 * H * C + 4 * H + 4) + T * 4 * H * C + Eh * 4 * H, Eh, "edges")
+    # ---- (f4): trainable embedding, sparse optimizer step (world of 1: routing is a local copy) ------------------
+    comm = wg.create_group_communicator()
+    n_rows, k = 1_000_000, 1_000_000
+    for kind, n_state in (("sgd", 0), ("lazy_adam", 2)):
+        for dim in (128,):
+            emb = wg.create_embedding(comm, "distributed", "cuda", torch.float32, [n_rows, dim], random_init=True)
+            opt = wg.create_wholememory_optimizer(emb, kind, {})
+            idx = torch.randint(0, n_rows, (k,), generator=g, device=dev)
+            grads = torch.rand((k, dim), generator=g, device=dev)
+            uniq = int(torch.unique(idx).numel())
+
+            def step():
+                emb.add_gradients(idx, grads)
+                emb.apply_gradients(0.01)
+            t = timed(step, iters=10)
+            nbytes = k * (8 + 4 * dim) + uniq * dim * 4 * 2 * (1 + n_state)
+            add("embedding gather_gradient_apply %s dim=%d, %d pairs -> %d rows" % (kind, dim, k, uniq),
+                "wholememory_embedding_gather_gradient_apply (f4)", t, nbytes, k, "pairs",
+                "wall time incl. the op's host syncs; route (copy) + radix sort of (row, position) + fused sum/update kernel")
+            t = timed(lambda: emb.gather(idx), events=True)
+            add("embedding gather dim=%d (DISTRIBUTED handle, world 1)" % dim, "wholememory_embedding_gather", t,
+                k * (8 + 8 * dim), k, "rows")
+            wg.destroy_embedding(emb)
+            wg.destroy_wholememory_optimizer(opt)
     if args.hetero:
         rows.append(hetero_section(dev))
         print(rows[-1], flush=True)
