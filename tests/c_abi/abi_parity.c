@@ -6,6 +6,7 @@
  * wholegraph_csr_unweighted_sample_without_replacement_tests.cu:330-353, cpp/tests/graph_ops/append_unique_tests.cu:160-199,
  * cpp/tests/wholememory_ops/wholememory_gather_tests.cu).  Prints C_ABI_PARITY_OK on success. */
 #include <hip/hip_runtime_api.h>
+#include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -162,6 +163,73 @@ int main(void)
   wgo_gather_rows((const uint8_t*)table, stride * 4, uniq, 1, n_uniq, F * 4, (uint8_t*)out, F * 4);
   CHECK(memcmp(got, out, sizeof(float) * n_uniq * F) == 0); /* includes the untouched row of the negative index */
   printf("gather: %lld rows x %lld fp32, bit-exact\n", (long long)n_uniq, (long long)F);
+
+  /* ---- (f4) trainable embedding: SGD step with duplicate indices, closed-form answer --------------------------
+   * table[r, :] = r, every pair carries a gradient row of ones, lr = 0.5  =>  table[r, :] = r - 0.5 * (times r was hit).
+   * World of one rank over the RCCL the library finds with dlopen (embedding.h:63-198 call sequence). */
+  {
+    wholememory_unique_id_t uid;
+    wholememory_comm_t comm = NULL;
+    WM(wholememory_init(0, 0));
+    WM(wholememory_create_unique_id(&uid));
+    WM(wholememory_create_communicator(&comm, uid, 0, 1));
+    const int64_t rows = 3000, dim = 10, pairs = 7000; /* dim 10 -> rows padded to 12 floats */
+    wholememory_tensor_description_t ed;
+    wholememory_initialize_tensor_desc(&ed);
+    ed.dim = 2; ed.sizes[0] = rows; ed.sizes[1] = dim; ed.strides[0] = dim; ed.strides[1] = 1; ed.dtype = WHOLEMEMORY_DT_FLOAT;
+    wholememory_embedding_t emb = NULL;
+    WM(wholememory_create_embedding(&emb, &ed, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, NULL, NULL, -1, 0));
+    wholememory_embedding_optimizer_t opt = NULL;
+    CHECK(wholememory_create_embedding_optimizer(&opt, WHOLEMEMORY_OPT_NONE) == WHOLEMEMORY_NOT_IMPLEMENTED);
+    WM(wholememory_create_embedding_optimizer(&opt, WHOLEMEMORY_OPT_SGD));
+    float wd = 0.0f;
+    WM(wholememory_optimizer_set_parameter(opt, "weight_decay", &wd));
+    CHECK(wholememory_optimizer_set_parameter(opt, "beta1", &wd) == WHOLEMEMORY_INVALID_INPUT);
+    WM(wholememory_embedding_set_optimizer(emb, opt));
+    CHECK(wholememory_embedding_get_optimizer_state_names(emb)[0] == NULL);
+    wholememory_tensor_t t_emb = wholememory_embedding_get_embedding_tensor(emb);
+    CHECK(wholememory_tensor_get_tensor_description(t_emb)->sizes[1] == dim &&
+          wholememory_tensor_get_tensor_description(t_emb)->strides[0] == 12);
+    /* fill through wholememory_scatter, like a loader would */
+    float* init = (float*)malloc(sizeof(float) * rows * dim);
+    int64_t* all_rows = (int64_t*)malloc(sizeof(int64_t) * rows);
+    for (int64_t r = 0; r < rows; r++) {
+      all_rows[r] = r;
+      for (int64_t j = 0; j < dim; j++) init[r * dim + j] = (float)r;
+    }
+    void *d_init = to_device(init, sizeof(float) * rows * dim), *d_all = to_device(all_rows, sizeof(int64_t) * rows);
+    wholememory_tensor_t t_init = wrap2d(d_init, rows, dim, dim, WHOLEMEMORY_DT_FLOAT), t_all = wrap1d(d_all, rows, WHOLEMEMORY_DT_INT64);
+    WM(wholememory_scatter(t_init, t_all, t_emb, env, stream, -1));
+    int32_t* pidx  = (int32_t*)malloc(sizeof(int32_t) * pairs);
+    int* hits      = (int*)calloc(rows, sizeof(int));
+    float* ones    = (float*)malloc(sizeof(float) * pairs * dim);
+    for (int64_t i = 0; i < pairs; i++) {
+      pidx[i] = (i % 13 == 0) ? -1 : (int32_t)(rnd() % (rows / 2)); /* skipped pairs; the upper half is never hit */
+      if (pidx[i] >= 0) hits[pidx[i]]++;
+      for (int64_t j = 0; j < dim; j++) ones[i * dim + j] = 1.0f;
+    }
+    void *d_pidx = to_device(pidx, sizeof(int32_t) * pairs), *d_ones = to_device(ones, sizeof(float) * pairs * dim);
+    wholememory_tensor_t t_pidx = wrap1d(d_pidx, pairs, WHOLEMEMORY_DT_INT), t_ones = wrap2d(d_ones, pairs, dim, dim, WHOLEMEMORY_DT_FLOAT);
+    WM(wholememory_embedding_gather_gradient_apply(emb, t_pidx, t_ones, false, 0.5f, env, (int64_t)(intptr_t)stream));
+    WM(wholememory_embedding_gather(emb, t_all, t_init, false, env, (int64_t)(intptr_t)stream));
+    HIP(hipStreamSynchronize(stream));
+    HIP(hipMemcpy(init, d_init, sizeof(float) * rows * dim, hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < rows; r++)
+      for (int64_t j = 0; j < dim; j++) CHECK(init[r * dim + j] == (float)r - 0.5f * (float)hits[r]);
+    CHECK(wholememory_embedding_gather_gradient_apply(emb, t_pidx, t_init, false, 0.5f, env, (int64_t)(intptr_t)stream) ==
+          WHOLEMEMORY_INVALID_INPUT); /* rows != pairs */
+    wholememory_embedding_cache_policy_t pol = NULL;
+    CHECK(wholememory_create_embedding_cache_policy(&pol, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE,
+                                                    WHOLEMEMORY_AT_READONLY, 0.5f) == WHOLEMEMORY_NOT_SUPPORTED);
+    WM(wholememory_embedding_writeback_cache(emb, 0));
+    wholememory_tensor_t tmp[] = {t_init, t_all, t_pidx, t_ones};
+    for (size_t i = 0; i < 4; i++) WM(wholememory_destroy_tensor(tmp[i]));
+    WM(wholememory_destroy_embedding(emb));
+    wholememory_destroy_embedding_optimizer(opt);
+    WM(wholememory_destroy_communicator(comm));
+    printf("embedding: %lld pairs into %lld x %lld fp32 rows (SGD), closed form exact\n", (long long)pairs, (long long)rows,
+           (long long)dim);
+  }
 
   /* ---- error contract: wrong dtype -> return code + stderr line, no abort ------------------------------- */
   wholememory_tensor_t t_bad = wrap1d(d_row, V + 1, WHOLEMEMORY_DT_INT);
