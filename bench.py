@@ -471,6 +471,20 @@ def main():
                         "avg_launch_ms": round(stage_ms[dom], 5),
                         "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                   f"{G} mini-batches, averaged over {stage_n} call groups"}
+        if roofline is not None and args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we:
+            # HBM bytes per launch from the PMC passes of gpurun_prof.sh on this exact configuration (separate --pmc runs,
+            # FETCH_SIZE x 2 + WRITE_SIZE; tools/pmc_summary.py), committed under profiles/ — counters cannot be read from
+            # inside the process being timed
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
+            if os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                hit = [v for k, v in pmc["kernels"].items()
+                       if k.startswith(roofline["kernel"]) and ("<void" in k or "<long" not in k)]
+                if hit:
+                    roofline["traffic"] = hit[0]["traffic_bytes"]
+                    roofline["traffic_over_algorithmic"] = round(hit[0]["traffic_bytes"] / kernels[dom][1], 3)
+                    roofline["traffic_source"] = "profiles/r01/pmc_traffic.json (" + ", ".join(pmc["source"]) + ")"
         spmm_gbps = None
         if SPMM1 in split_ms:
             spmm_gbps = kernels[SPMM1][1] / (split_ms[SPMM1] * 1e-3) / 1e9

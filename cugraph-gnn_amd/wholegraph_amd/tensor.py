@@ -192,6 +192,19 @@ class DistributedWholeMemoryTensor(object):
     def local_tensor(self):
         return self.get_local_tensor()[0]
 
+    def get_sub_tensor(self, starts, ends):
+        """View [starts, ends) of the same storage (-1 = whole dim) — wholememory_tensor_get_subtensor,
+        binding ``PyWholeMemoryTensor.get_sub_tensor`` (wholememory_binding.pyx:1381-1404).  Column ranges only (every
+        rank keeps its row range); destroy the view before the root tensor."""
+        import ctypes
+        assert len(starts) == len(ends) == self.dim()
+        assert int(starts[0]) in (-1, 0) and int(ends[0]) in (-1, self._shape[0]), "row ranges are not supported"
+        st = (ctypes.c_int64 * self.dim())(*[max(int(v), 0) for v in starts])
+        en = (ctypes.c_int64 * self.dim())(*[int(v) for v in ends])
+        c = ctypes.c_void_p()
+        L.check(L.lib().wholememory_tensor_get_subtensor(self.c, st, en, ctypes.byref(c)), "wholememory_tensor_get_subtensor")
+        return DistributedWholeMemoryTensor(c.value, self.comm)
+
     def get_local_tensor(self, host_view: bool = False):
         """(torch view of this rank's rows, first global row held here) — tensor.py:106-123."""
         import ctypes
