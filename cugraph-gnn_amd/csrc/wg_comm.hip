@@ -6,9 +6,8 @@
 // functions/exchange_ids_nccl_func.cu:32-215, functions/exchange_embeddings_nccl_func.cu:23-65, collectives of
 // cpp/src/wholememory/nccl_comms.cpp:345-426): owner rank of every index -> counts all-to-all -> indices
 // all-to-all-v -> local gather -> rows all-to-all-v -> un-permute.  Differences by design:
-//   * the reference radix-sorts (id, position) pairs to group ids by owner; with W <= 8..64 owners a counting
-//     sort is enough: one histogram kernel + one bucket kernel with a per-owner cursor (the order inside a
-//     bucket is irrelevant because the un-permute uses the remembered positions);
+//   * ids are grouped by owner with ONE radix pass over ceil(log2 W) key bits (stable: the caller's order survives
+//     inside a bucket, so results are reproducible); the caller's own bucket is grouped last and never exchanged;
 //   * RCCL is resolved with dlopen at run time — inside a PyTorch process this shares torch's librccl, and the
 //     library still loads on a CPU-only box;
 //   * only DISTRIBUTED/DEVICE memory exists: on an 8 x MI355X node every pair of GPUs has its own xGMI link,
@@ -21,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <rocprim/rocprim.hpp>
 #include <vector>
 
 #include "wg_common.hpp"
@@ -146,49 +146,36 @@ owner_histogram_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0,
     if (local[r]) atomicAdd(&counts[r], local[r]);
 }
 
-// ids grouped by owner (any order inside a group) + the original position of every grouped id.  A workgroup counts its
-// kBucketItems ids per owner in LDS, reserves one range per owner with ONE global atomic each, then hands out slots inside
-// its ranges with LDS atomics: a global atomic per id on W cursors serialises (3.6 M ids on one address took 40 ms).
-constexpr int kBucketItems = 8;  // ids per thread
-
+// Grouping ids by owner is a STABLE partition: inside a bucket the ids keep the caller's order, so everything
+// downstream (which duplicate wins a scatter, the order gradients of one row are summed in) is reproducible run to run.
+// Sort key of id i = its owner rotated so that MY bucket comes last (me+1, me+2, ..., me-1, me); one radix pass over
+// ceil(log2 W) bits sorts (key, position) pairs; a single-rank communicator needs no sort at all.
 template <typename IdxT>
 __global__ void __launch_bounds__(256)
-bucket_ids_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0, const int64_t* __restrict__ entry_offsets, int W,
-                  const int64_t* __restrict__ bucket_start, int* __restrict__ cursor, int64_t* __restrict__ grouped_ids,
-                  int64_t* __restrict__ positions)
+owner_keys_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0, const int64_t* __restrict__ entry_offsets, int W, int me,
+                  uint32_t* __restrict__ keys, int* __restrict__ vals)
 {
-  __shared__ int local[kMaxRanks];
-  __shared__ int64_t base[kMaxRanks];
-  for (int r = threadIdx.x; r < W; r += blockDim.x) local[r] = 0;
-  __syncthreads();
-  const int64_t first = (int64_t)blockIdx.x * (256 * kBucketItems) + threadIdx.x;
-  int64_t id[kBucketItems];
-  int owner[kBucketItems];
-#pragma unroll
-  for (int k = 0; k < kBucketItems; k++) {
-    const int64_t i = first + (int64_t)k * 256;
-    owner[k]        = -1;
-    if (i < n) {
-      id[k] = (int64_t)idx[i];
-      if (id[k] >= 0) id[k] += row0;  // row 0 of a sub-tensor is entry `row0` of the handle
-      owner[k] = owner_of(id[k], entry_offsets, W);
-      atomicAdd(&local[owner[k]], 1);
-    }
-  }
-  __syncthreads();
-  for (int r = threadIdx.x; r < W; r += blockDim.x) {
-    const int c = local[r];
-    base[r]     = bucket_start[r] + (c ? atomicAdd(&cursor[r], c) : 0);
-    local[r]    = 0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kBucketItems; k++) {
-    if (owner[k] < 0) continue;
-    const int64_t at = base[owner[k]] + atomicAdd(&local[owner[k]], 1);
-    grouped_ids[at]  = id[k];
-    positions[at]    = id[k] < 0 ? -1 : first + (int64_t)k * 256;  // a negative index leaves its dense row untouched
-  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = (int64_t)idx[i];
+  const int r      = owner_of(id < 0 ? id : id + row0, entry_offsets, W);
+  keys[i]          = (uint32_t)((r - me - 1 + W) % W);
+  vals[i]          = (int)i;
+}
+
+// grouped_ids[j] = id of the j-th pair of the sorted order (`order` == nullptr: identity), positions[j] = where it came from
+template <typename IdxT>
+__global__ void __launch_bounds__(256)
+emit_grouped_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0, const int* __restrict__ order,
+                    int64_t* __restrict__ grouped_ids, int64_t* __restrict__ positions)
+{
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int64_t i = order ? (int64_t)order[j] : j;
+  int64_t id      = (int64_t)idx[i];
+  if (id >= 0) id += row0;  // row 0 of a sub-tensor is entry `row0` of the handle
+  grouped_ids[j] = id;
+  positions[j]   = id < 0 ? -1 : i;  // a negative index leaves its dense row untouched
 }
 
 __global__ void __launch_bounds__(256) localize_ids_kernel(int64_t* ids, int64_t n, int64_t local_start)
@@ -197,156 +184,156 @@ __global__ void __launch_bounds__(256) localize_ids_kernel(int64_t* ids, int64_t
   if (i < n && ids[i] >= 0) ids[i] -= local_start;
 }
 
-// Steps 1-4 of the pipeline, shared by gather / scatter and by the embedding gradient routing: who owns each id, how
-// many ids every pair of ranks trades, the ids grouped by owner (the peers' buckets first in rank order, MY bucket last)
-// and the ids the peers ask me for (localised to my partition).
-struct id_exchange {
-  wholememory_comm_t comm;
-  int W, me;
-  int64_t local_start = 0, local_rows = 0;
-  std::vector<size_t> send_cnt, recv_cnt;          // all ids per peer, self included
-  std::vector<int64_t> bucket_start;               // first grouped position of every owner
-  std::vector<size_t> send_n, recv_n, send_at, recv_at;  // what really crosses the wire (ids), and where it sits
-  int64_t n = 0, n_remote = 0, self_cnt = 0, recv_total = 0;
-  bool self_direct = false;
-  int64_t *d_grouped = nullptr, *d_pos = nullptr, *d_recv_ids = nullptr, *d_self_ids = nullptr, *d_self_pos = nullptr;
-  temp_buffer offs_b, cnt_b, start_b, gid_b, pos_b, xcnt_b, rid_b;
-  std::vector<size_t> so, sb, ro, rb;
-
-  explicit id_exchange(wholememory_env_func_t* env)
-    : offs_b(env), cnt_b(env), start_b(env), gid_b(env), pos_b(env), xcnt_b(env), rid_b(env)
-  {
-  }
-
-  // self_direct_: my own bucket stays out of the exchange (it is localised in place instead); d_recv_ids always has
-  // room for it behind the received ids
-  void run(wholememory_handle_t h, size_t entry_bytes, int64_t row0, const void* idx, wholememory_dtype_t idx_dtype,
-           int64_t n_, bool self_direct_, hipStream_t stream)
-  {
-    comm = h->comm;
-    W    = comm->size;
-    me   = comm->rank;
-    n    = n_;
-    self_direct = self_direct_;
-    WG_EXPECTS(W <= kMaxRanks, "too many ranks");
-    std::vector<int64_t> entry_offsets(W + 1);
-    for (int r = 0; r <= W; r++) entry_offsets[r] = (int64_t)(h->byte_offsets[r] / entry_bytes);
-    local_start = entry_offsets[me];
-    local_rows  = entry_offsets[me + 1] - local_start;
-
-    // ---- 1. owners + counts --------------------------------------------------------------------
-    auto* d_offsets = offs_b.device<int64_t>(W + 1, WHOLEMEMORY_DT_INT64);
-    int* d_counts   = cnt_b.device<int>(2 * W, WHOLEMEMORY_DT_INT);  // [counts | cursors]
-    WG_HIP_CHECK(hipMemcpyAsync(d_offsets, entry_offsets.data(), sizeof(int64_t) * (W + 1), hipMemcpyHostToDevice, stream));
-    WG_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * 2 * W, stream));
-    if (n > 0) {
-      int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
-      if (idx_dtype == WHOLEMEMORY_DT_INT)
-        owner_histogram_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_counts);
-      else
-        owner_histogram_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_counts);
-      WG_HIP_CHECK(hipGetLastError());
-    }
-    std::vector<int> h_counts(W);
-    WG_HIP_CHECK(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * W, hipMemcpyDeviceToHost, stream));
-    WG_HIP_CHECK(hipStreamSynchronize(stream));
-
-    // ---- 2. counts all-to-all (W x int64; nothing to trade on a single-rank communicator) --------
-    send_cnt.assign(W, 0);
-    recv_cnt.assign(W, 0);
-    for (int r = 0; r < W; r++) send_cnt[r] = (size_t)h_counts[r];
-    if (W == 1) {
-      recv_cnt[0] = send_cnt[0];
-    } else {
-      auto* d_x = xcnt_b.device<int64_t>(2 * W, WHOLEMEMORY_DT_INT64);
-      std::vector<int64_t> tmp(send_cnt.begin(), send_cnt.end());
-      WG_HIP_CHECK(hipMemcpyAsync(d_x, tmp.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
-      std::vector<size_t> eight(W, sizeof(int64_t)), at(W);
-      for (int r = 0; r < W; r++) at[r] = (size_t)r * sizeof(int64_t);
-      alltoallv_bytes(comm, reinterpret_cast<const char*>(d_x), at, eight, reinterpret_cast<char*>(d_x + W), at, eight, stream);
-      WG_HIP_CHECK(hipMemcpyAsync(tmp.data(), d_x + W, sizeof(int64_t) * W, hipMemcpyDeviceToHost, stream));
-      WG_HIP_CHECK(hipStreamSynchronize(stream));
-      for (int r = 0; r < W; r++) recv_cnt[r] = (size_t)tmp[r];
-    }
-
-    // ---- 3. group ids by owner: the peers' buckets first (rank order), MY bucket last ------------
-    self_cnt = (int64_t)send_cnt[me];
-    WG_EXPECTS(recv_cnt[me] == send_cnt[me], "self count mismatch");
-    bucket_start.assign(W, 0);
-    int64_t acc = 0;
-    for (int r = 0; r < W; r++) {
-      if (r == me) continue;
-      bucket_start[r] = acc;
-      acc += (int64_t)send_cnt[r];
-    }
-    bucket_start[me] = acc;
-    n_remote         = self_direct ? acc : n;  // leading rows of the grouped order that go through the exchange
-    auto* d_start = start_b.device<int64_t>(W, WHOLEMEMORY_DT_INT64);
-    d_grouped     = gid_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
-    d_pos         = pos_b.device<int64_t>(n, WHOLEMEMORY_DT_INT64);
-    WG_HIP_CHECK(hipMemcpyAsync(d_start, bucket_start.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
-    if (n > 0) {
-      int grid = (int)((n + 256 * kBucketItems - 1) / (256 * kBucketItems));
-      if (idx_dtype == WHOLEMEMORY_DT_INT)
-        bucket_ids_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_start,
-                                                            d_counts + W, d_grouped, d_pos);
-      else
-        bucket_ids_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_start,
-                                                            d_counts + W, d_grouped, d_pos);
-      WG_HIP_CHECK(hipGetLastError());
-    }
-
-    // ---- 4. ids all-to-all-v: what I receive is packed in rank order (without my own bucket when it stays home) ----
-    send_n.assign(W, 0); recv_n.assign(W, 0); send_at.assign(W, 0); recv_at.assign(W, 0);
-    recv_total = 0;
-    for (int r = 0; r < W; r++) {
-      const bool skip = self_direct && r == me;
-      send_n[r]  = skip ? 0 : send_cnt[r];
-      recv_n[r]  = skip ? 0 : recv_cnt[r];
-      send_at[r] = (size_t)bucket_start[r];
-      recv_at[r] = (size_t)recv_total;
-      recv_total += (int64_t)recv_n[r];
-    }
-    d_recv_ids = rid_b.device<int64_t>(recv_total + (self_direct ? self_cnt : 0), WHOLEMEMORY_DT_INT64);
-    so.resize(W); sb.resize(W); ro.resize(W); rb.resize(W);
-    scaled(sizeof(int64_t), sizeof(int64_t), send_n, send_at, recv_n, recv_at);
-    alltoallv_bytes(comm, reinterpret_cast<const char*>(d_grouped), so, sb, reinterpret_cast<char*>(d_recv_ids), ro, rb, stream);
-    if (recv_total > 0) {
-      localize_ids_kernel<<<(int)((recv_total + 255) / 256), 256, 0, stream>>>(d_recv_ids, recv_total, local_start);
-      WG_HIP_CHECK(hipGetLastError());
-    }
-    d_self_ids = d_grouped + bucket_start[me];  // not part of any send when self_direct
-    d_self_pos = d_pos + bucket_start[me];
-    if (self_direct && self_cnt > 0) {
-      localize_ids_kernel<<<(int)((self_cnt + 255) / 256), 256, 0, stream>>>(d_self_ids, self_cnt, local_start);
-      WG_HIP_CHECK(hipGetLastError());
-    }
-  }
-
-  // byte offsets / sizes of one all-to-all-v from per-peer counts and positions (units of rows or ids)
-  void scaled(size_t unit_send, size_t unit_recv, const std::vector<size_t>& s_n, const std::vector<size_t>& s_at,
-              const std::vector<size_t>& r_n, const std::vector<size_t>& r_at)
-  {
-    for (int r = 0; r < W; r++) {
-      so[r] = s_at[r] * unit_send; sb[r] = s_n[r] * unit_send;
-      ro[r] = r_at[r] * unit_recv; rb[r] = r_n[r] * unit_recv;
-    }
-  }
-  // rows travel WITH the ids (scatter direction): my grouped rows -> the owners' receive order
-  void rows_to_owners(const char* send, char* recv, size_t row_bytes, hipStream_t stream)
-  {
-    scaled(row_bytes, row_bytes, send_n, send_at, recv_n, recv_at);
-    alltoallv_bytes(comm, send, so, sb, recv, ro, rb, stream);
-  }
-  // rows travel BACK (gather direction): what I gathered for peer r -> peer r's grouped order
-  void rows_to_askers(const char* send, char* recv, size_t row_bytes, hipStream_t stream)
-  {
-    scaled(row_bytes, row_bytes, recv_n, recv_at, send_n, send_at);
-    alltoallv_bytes(comm, send, so, sb, recv, ro, rb, stream);
-  }
-};
-
 }  // namespace
+
+void id_exchange::plan(wholememory_handle_t h, size_t entry_bytes, int64_t row0, const void* idx, wholememory_dtype_t idx_dtype,
+                       int64_t n_, bool self_direct_, hipStream_t stream)
+{
+  comm = h->comm;
+  W    = comm->size;
+  me   = comm->rank;
+  n    = n_;
+  self_direct = self_direct_;
+  WG_EXPECTS(W <= kMaxRanks, "too many ranks");
+  std::vector<int64_t> entry_offsets(W + 1);
+  for (int r = 0; r <= W; r++) entry_offsets[r] = (int64_t)(h->byte_offsets[r] / entry_bytes);
+  local_start = entry_offsets[me];
+  local_rows  = entry_offsets[me + 1] - local_start;
+
+  WG_EXPECTS(n < (int64_t)1 << 31, "too many indices in one call");
+  unsigned key_bits = 0;
+  while ((1 << key_bits) < W) key_bits++;
+  size_t sort_bytes = 0;
+  const int64_t n_sort = W > 1 ? n : 0;  // a single owner: the grouped order is the caller's order
+  if (n_sort > 0)
+    WG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr,
+                                           (int*)nullptr, (size_t)n_sort, 0u, key_bits, stream));
+  const size_t o_offs = scratch.add(sizeof(int64_t) * (W + 1)), o_cnt = scratch.add(sizeof(int) * W),
+               o_x = scratch.add(sizeof(int64_t) * 2 * W), o_gid = scratch.add(sizeof(int64_t) * n),
+               o_pos = scratch.add(sizeof(int64_t) * n), o_k1 = scratch.add(sizeof(uint32_t) * n_sort),
+               o_k2 = scratch.add(sizeof(uint32_t) * n_sort), o_v1 = scratch.add(sizeof(int) * n_sort),
+               o_v2 = scratch.add(sizeof(int) * n_sort), o_tmp = scratch.add(sort_bytes);
+  scratch.commit();
+  // ---- 1. owners + counts --------------------------------------------------------------------
+  auto* d_offsets = scratch.at<int64_t>(o_offs);
+  int* d_counts   = scratch.at<int>(o_cnt);
+  WG_HIP_CHECK(hipMemcpyAsync(d_offsets, entry_offsets.data(), sizeof(int64_t) * (W + 1), hipMemcpyHostToDevice, stream));
+  WG_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * W, stream));
+  if (n > 0) {
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    if (idx_dtype == WHOLEMEMORY_DT_INT)
+      owner_histogram_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_counts);
+    else
+      owner_histogram_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_counts);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  std::vector<int> h_counts(W);
+  WG_HIP_CHECK(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * W, hipMemcpyDeviceToHost, stream));
+  WG_HIP_CHECK(hipStreamSynchronize(stream));
+
+  // ---- 2. counts all-to-all (W x int64; nothing to trade on a single-rank communicator) --------
+  send_cnt.assign(W, 0);
+  recv_cnt.assign(W, 0);
+  for (int r = 0; r < W; r++) send_cnt[r] = (size_t)h_counts[r];
+  if (W == 1) {
+    recv_cnt[0] = send_cnt[0];
+  } else {
+    auto* d_x = scratch.at<int64_t>(o_x);
+    std::vector<int64_t> tmp(send_cnt.begin(), send_cnt.end());
+    WG_HIP_CHECK(hipMemcpyAsync(d_x, tmp.data(), sizeof(int64_t) * W, hipMemcpyHostToDevice, stream));
+    std::vector<size_t> eight(W, sizeof(int64_t)), at(W);
+    for (int r = 0; r < W; r++) at[r] = (size_t)r * sizeof(int64_t);
+    alltoallv_bytes(comm, reinterpret_cast<const char*>(d_x), at, eight, reinterpret_cast<char*>(d_x + W), at, eight, stream);
+    WG_HIP_CHECK(hipMemcpyAsync(tmp.data(), d_x + W, sizeof(int64_t) * W, hipMemcpyDeviceToHost, stream));
+    WG_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int r = 0; r < W; r++) recv_cnt[r] = (size_t)tmp[r];
+  }
+
+  // ---- 3. group ids by owner, stable: the peers' buckets first (me+1, me+2, ... wrapping around), MY bucket last ----
+  self_cnt = (int64_t)send_cnt[me];
+  WG_EXPECTS(recv_cnt[me] == send_cnt[me], "self count mismatch");
+  bucket_start.assign(W, 0);
+  int64_t acc = 0;
+  for (int k = 1; k <= W; k++) {
+    const int r     = (me + k) % W;
+    bucket_start[r] = acc;
+    acc += (int64_t)send_cnt[r];
+  }
+  n_remote  = self_direct ? bucket_start[me] : n;  // leading rows of the grouped order that go through the exchange
+  d_grouped = scratch.at<int64_t>(o_gid);
+  d_pos     = scratch.at<int64_t>(o_pos);
+  if (n > 0) {
+    const int grid   = (int)((n + 255) / 256);
+    const int* order = nullptr;
+    if (n_sort > 0) {
+      auto *k1 = scratch.at<uint32_t>(o_k1), *k2 = scratch.at<uint32_t>(o_k2);
+      auto *v1 = scratch.at<int>(o_v1), *v2 = scratch.at<int>(o_v2);
+      if (idx_dtype == WHOLEMEMORY_DT_INT)
+        owner_keys_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, me, k1, v1);
+      else
+        owner_keys_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, me, k1, v1);
+      WG_HIP_CHECK(hipGetLastError());
+      WG_HIP_CHECK(rocprim::radix_sort_pairs(scratch.at<void>(o_tmp), sort_bytes, k1, k2, v1, v2, (size_t)n, 0u, key_bits, stream));
+      order = v2;
+    }
+    if (idx_dtype == WHOLEMEMORY_DT_INT)
+      emit_grouped_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, order, d_grouped, d_pos);
+    else
+      emit_grouped_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, order, d_grouped, d_pos);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  // what crosses the wire: packed in rank order on the receiving side (without my own bucket when it stays home)
+  send_n.assign(W, 0); recv_n.assign(W, 0); send_at.assign(W, 0); recv_at.assign(W, 0);
+  recv_total = 0;
+  for (int r = 0; r < W; r++) {
+    const bool skip = self_direct && r == me;
+    send_n[r]  = skip ? 0 : send_cnt[r];
+    recv_n[r]  = skip ? 0 : recv_cnt[r];
+    send_at[r] = (size_t)bucket_start[r];
+    recv_at[r] = (size_t)recv_total;
+    recv_total += (int64_t)recv_n[r];
+  }
+  so.resize(W); sb.resize(W); ro.resize(W); rb.resize(W);
+  d_self_ids = d_grouped + bucket_start[me];  // not part of any send when self_direct
+  d_self_pos = d_pos + bucket_start[me];
+}
+
+void id_exchange::exchange_ids(int64_t* recv_ids, hipStream_t stream)
+{
+  d_recv_ids = recv_ids;
+  scaled(sizeof(int64_t), sizeof(int64_t), send_n, send_at, recv_n, recv_at);
+  alltoallv_bytes(comm, reinterpret_cast<const char*>(d_grouped), so, sb, reinterpret_cast<char*>(d_recv_ids), ro, rb, stream);
+  if (recv_total > 0) {
+    localize_ids_kernel<<<(int)((recv_total + 255) / 256), 256, 0, stream>>>(d_recv_ids, recv_total, local_start);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  if (self_direct && self_cnt > 0) {
+    localize_ids_kernel<<<(int)((self_cnt + 255) / 256), 256, 0, stream>>>(d_self_ids, self_cnt, local_start);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+}
+
+// byte offsets / sizes of one all-to-all-v from per-peer counts and positions (units of rows or ids)
+void id_exchange::scaled(size_t unit_send, size_t unit_recv, const std::vector<size_t>& s_n, const std::vector<size_t>& s_at,
+                         const std::vector<size_t>& r_n, const std::vector<size_t>& r_at)
+{
+  for (int r = 0; r < W; r++) {
+    so[r] = s_at[r] * unit_send; sb[r] = s_n[r] * unit_send;
+    ro[r] = r_at[r] * unit_recv; rb[r] = r_n[r] * unit_recv;
+  }
+}
+
+void id_exchange::rows_to_owners(const char* send, char* recv, size_t row_bytes, hipStream_t stream)
+{
+  scaled(row_bytes, row_bytes, send_n, send_at, recv_n, recv_at);
+  alltoallv_bytes(comm, send, so, sb, recv, ro, rb, stream);
+}
+
+void id_exchange::rows_to_askers(const char* send, char* recv, size_t row_bytes, hipStream_t stream)
+{
+  scaled(row_bytes, row_bytes, recv_n, recv_at, send_n, send_at);
+  alltoallv_bytes(comm, send, so, sb, recv, ro, rb, stream);
+}
 
 void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matrix_description_t tm, const void* idx,
                          wholememory_dtype_t idx_dtype, int64_t n, char* dense, wholememory_matrix_description_t dense_m,
@@ -364,16 +351,23 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
   // Rows I own never enter the exchange when no dtype conversion is asked for: one permuting copy moves them between my
   // partition and the dense rows (1/W of the traffic; all of it on a single-rank communicator).
   id_exchange x(env);
-  x.run(h, entry_bytes, row0, idx, idx_dtype, n, tm.dtype == dense_m.dtype, stream);
-  temp_buffer rows_b(env), back_b(env);
+  x.plan(h, entry_bytes, row0, idx, idx_dtype, n, tm.dtype == dense_m.dtype, stream);
+  const int64_t F   = tm.sizes[1];
+  const size_t des  = dtype_size(dense_m.dtype);
+  // gather: rows I look up for the peers (output dtype) + the rows that come back; scatter: my rows grouped by owner +
+  // the rows the peers send me (table dtype)
+  const size_t recv_row = (size_t)F * (scatter ? tes : des), send_row = recv_row;
+  temp_arena arena(env);
+  const size_t o_ids = arena.add(sizeof(int64_t) * x.recv_total), o_rows = arena.add(recv_row * x.recv_total),
+               o_back = arena.add(send_row * x.n_remote);
+  arena.commit();
+  x.exchange_ids(arena.at<int64_t>(o_ids), stream);
 
   // local partition viewed as a matrix of its own rows
   wholememory_matrix_description_t local_m = tm;
   local_m.sizes[0]                         = x.local_rows;
   local_m.storage_offset                   = 0;  // the row kernels take a pointer to the first element
   const char* local_base                   = static_cast<const char*>(h->local_ptr) + (size_t)col0 * tes;
-  const int64_t F                          = tm.sizes[1];
-  const size_t des                         = dtype_size(dense_m.dtype);
   wholememory_matrix_description_t dense0  = dense_m;
   dense0.storage_offset                    = 0;  // `dense` already points at the first element
   int64_t sz2[2];
@@ -383,11 +377,11 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
     if (x.self_direct) local_rows_permute(local_base, local_m, x.d_self_ids, x.d_self_pos, x.self_cnt, dense, dense0, stream);
     sz2[0] = x.recv_total; sz2[1] = F;
     wholememory_matrix_description_t rows_m = wholememory_create_matrix_desc(sz2, F, 0, dense_m.dtype);
-    char* d_rows = static_cast<char*>(rows_b.alloc(x.recv_total * F, dense_m.dtype));
+    char* d_rows = arena.at<char>(o_rows);
     local_rows_gather(local_base, local_m, x.d_recv_ids, WHOLEMEMORY_DT_INT64, x.recv_total, d_rows, rows_m, stream);
     sz2[0] = x.n_remote;
     wholememory_matrix_description_t back_m = wholememory_create_matrix_desc(sz2, F, 0, dense_m.dtype);
-    char* d_back = static_cast<char*>(back_b.alloc(x.n_remote * F, dense_m.dtype));
+    char* d_back = arena.at<char>(o_back);
     x.rows_to_askers(d_rows, d_back, (size_t)F * des, stream);
     local_rows_scatter(d_back, back_m, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, dense, dense0, stream);
   } else {
@@ -396,51 +390,16 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
       local_rows_permute(dense, dense0, x.d_self_pos, x.d_self_ids, x.self_cnt, const_cast<char*>(local_base), local_m, stream);
     sz2[0] = x.n_remote; sz2[1] = F;
     wholememory_matrix_description_t send_m = wholememory_create_matrix_desc(sz2, F, 0, tm.dtype);
-    char* d_send = static_cast<char*>(back_b.alloc(x.n_remote * F, tm.dtype));
+    char* d_send = arena.at<char>(o_back);
     local_rows_gather(dense, dense0, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, d_send, send_m, stream);  // also converts
     sz2[0] = x.recv_total;
     wholememory_matrix_description_t recv_m = wholememory_create_matrix_desc(sz2, F, 0, tm.dtype);
-    char* d_recv = static_cast<char*>(rows_b.alloc(x.recv_total * F, tm.dtype));
+    char* d_recv = arena.at<char>(o_rows);
     x.rows_to_owners(d_send, d_recv, (size_t)F * tes, stream);
     local_rows_scatter(d_recv, recv_m, x.d_recv_ids, WHOLEMEMORY_DT_INT64, x.recv_total, const_cast<char*>(local_base), local_m,
                        stream);
   }
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
-}
-
-// Every (id, row) pair goes to the rank that owns the id (the embedding gradient path; reference
-// embedding.cpp:183-236: bucket_and_exchange_ids_func + gather_func + exchange_embeddings_nccl_func).  On return
-// ids_out[k] is a LOCAL row number of my partition (negative ids stay negative), rows_out[k, :] its row; the pairs I own
-// myself are copied straight into the tail, they never touch RCCL.  Returns the number of pairs; enqueues only.
-int64_t route_rows_to_owners(wholememory_handle_t h, size_t entry_bytes, const void* idx, wholememory_dtype_t idx_dtype,
-                             int64_t n, const char* rows, wholememory_matrix_description_t rows_m, temp_buffer& ids_out,
-                             temp_buffer& rows_out, int64_t* local_rows, wholememory_env_func_t* env, hipStream_t stream)
-{
-  id_exchange x(env);
-  x.run(h, entry_bytes, 0, idx, idx_dtype, n, true, stream);
-  const int64_t F     = rows_m.sizes[1];
-  const size_t es     = dtype_size(rows_m.dtype);
-  const int64_t total = x.recv_total + x.self_cnt;
-  rows_m.storage_offset = 0;
-  int64_t sz2[2] = {x.n_remote, F};
-  temp_buffer send_b(env);
-  wholememory_matrix_description_t packed_m = wholememory_create_matrix_desc(sz2, F, 0, rows_m.dtype);
-  char* d_send = static_cast<char*>(send_b.alloc(x.n_remote * F, rows_m.dtype));
-  char* d_recv = static_cast<char*>(rows_out.alloc(total * F, rows_m.dtype));
-  auto* d_ids  = ids_out.device<int64_t>(total, WHOLEMEMORY_DT_INT64);
-  local_rows_gather(rows, rows_m, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, d_send, packed_m, stream);
-  x.rows_to_owners(d_send, d_recv, (size_t)F * es, stream);
-  packed_m.sizes[0] = x.self_cnt;
-  local_rows_gather(rows, rows_m, x.d_self_pos, WHOLEMEMORY_DT_INT64, x.self_cnt, d_recv + (size_t)x.recv_total * F * es,
-                    packed_m, stream);
-  if (x.recv_total)
-    WG_HIP_CHECK(hipMemcpyAsync(d_ids, x.d_recv_ids, sizeof(int64_t) * x.recv_total, hipMemcpyDeviceToDevice, stream));
-  if (x.self_cnt)
-    WG_HIP_CHECK(hipMemcpyAsync(d_ids + x.recv_total, x.d_self_ids, sizeof(int64_t) * x.self_cnt, hipMemcpyDeviceToDevice,
-                                stream));
-  *local_rows = x.local_rows;
-  WG_HIP_CHECK(hipStreamSynchronize(stream));  // the exchange scratch (grouped ids, send rows) is released on return
-  return total;
 }
 
 }  // namespace wgamd

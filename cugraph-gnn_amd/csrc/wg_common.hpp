@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <vector>
 #include <string>
 
 #include "wgamd_ops.h"
@@ -150,6 +151,31 @@ class temp_buffer {
   void* ptr_ = nullptr;
 };
 
+// Several scratch pieces behind ONE env allocation: every temp_buffer costs four callbacks into the caller's allocator
+// (create context, malloc, free, destroy context) — Python callbacks in the torch binding — so an op declares its pieces,
+// commits once, and addresses them by offset.
+class temp_arena {
+ public:
+  explicit temp_arena(wholememory_env_func_t* env) : buf_(env) {}
+  size_t add(size_t bytes)
+  {
+    const size_t off = total_;
+    total_ += (bytes + 255) / 256 * 256;
+    return off;
+  }
+  void commit() { base_ = static_cast<char*>(buf_.bytes((int64_t)(total_ ? total_ : 1))); }
+  template <typename T>
+  T* at(size_t off) const
+  {
+    return reinterpret_cast<T*>(base_ + off);
+  }
+
+ private:
+  temp_buffer buf_;
+  size_t total_ = 0;
+  char* base_   = nullptr;
+};
+
 // Allocates an op OUTPUT of `elt_count` elements in the caller's memory_context (never freed here).
 inline void* output_alloc(wholememory_env_func_t* env, void* memory_context, int64_t elt_count,
                           wholememory_dtype_t dtype)
@@ -276,6 +302,39 @@ void local_rows_scatter(const char* in, wholememory_matrix_description_t im, con
 // dst row dst_idx[i] <- src row src_idx[i] (same dtype; a negative index on either side skips the row)
 void local_rows_permute(const char* src, wholememory_matrix_description_t sm, const int64_t* src_idx, const int64_t* dst_idx,
                         int64_t n, char* dst, wholememory_matrix_description_t dm, hipStream_t stream);
+// Steps 1-4 of the DISTRIBUTED row exchange (wg_comm.hip), shared by gather / scatter and by the embedding gradient
+// routing: who owns each id, how many ids every pair of ranks trades, the ids grouped by owner (the peers' buckets first
+// in rank order, MY bucket last) and the ids the peers ask me for (localised to my partition).
+struct id_exchange {
+  wholememory_comm_t comm = nullptr;
+  int W = 1, me = 0;
+  int64_t local_start = 0, local_rows = 0;
+  std::vector<size_t> send_cnt, recv_cnt;                // all ids per peer, self included
+  std::vector<int64_t> bucket_start;                     // first grouped position of every owner
+  std::vector<size_t> send_n, recv_n, send_at, recv_at;  // what really crosses the wire (ids), and where it sits
+  int64_t n = 0, n_remote = 0, self_cnt = 0, recv_total = 0;
+  bool self_direct = false;
+  int64_t *d_grouped = nullptr, *d_pos = nullptr, *d_recv_ids = nullptr, *d_self_ids = nullptr, *d_self_pos = nullptr;
+  temp_arena scratch;
+  std::vector<size_t> so, sb, ro, rb;
+
+  explicit id_exchange(wholememory_env_func_t* env) : scratch(env) {}
+  // steps 1-3 (two host syncs, one on a single-rank communicator): fills every count above.  self_direct_: my own bucket
+  // stays out of the exchange (exchange_ids localises it in place instead)
+  void plan(wholememory_handle_t h, size_t entry_bytes, int64_t row0, const void* idx, wholememory_dtype_t idx_dtype,
+            int64_t n_, bool self_direct_, hipStream_t stream);
+  // step 4: ids all-to-all-v into `recv_ids` (room for recv_total ids), localised; enqueues only
+  void exchange_ids(int64_t* recv_ids, hipStream_t stream);
+  // rows travel WITH the ids (scatter direction): my grouped rows -> the owners' receive order
+  void rows_to_owners(const char* send, char* recv, size_t row_bytes, hipStream_t stream);
+  // rows travel BACK (gather direction): what I gathered for peer r -> peer r's grouped order
+  void rows_to_askers(const char* send, char* recv, size_t row_bytes, hipStream_t stream);
+
+ private:
+  void scaled(size_t unit_send, size_t unit_recv, const std::vector<size_t>& s_n, const std::vector<size_t>& s_at,
+              const std::vector<size_t>& r_n, const std::vector<size_t>& r_at);
+};
+
 // gather: dense = output rows; scatter: dense = input rows.  `tm` describes the GLOBAL table (sizes[0] = all rows).
 void distributed_rows_op(bool scatter, wholememory_handle_t handle, wholememory_matrix_description_t tm, const void* idx,
                          wholememory_dtype_t idx_dtype, int64_t n, char* dense, wholememory_matrix_description_t dense_m,

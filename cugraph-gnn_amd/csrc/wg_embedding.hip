@@ -4,11 +4,12 @@
 // cpp/src/wholememory_ops/functions/embedding_optimizer_func.cu:166-1024): route every (row id, gradient row) to the rank
 // that owns the row, de-duplicate the ids there while summing their gradients into a second buffer, then run one
 // workgroup per unique row through the optimizer formula.  Here, for one MI355X partition in HBM:
-//   * routing reuses the all-to-all-v of the feature fetch (wg_comm.hip); pairs a rank owns itself are copied straight
-//     into the receive buffer, they never touch RCCL;
+//   * routing reuses the all-to-all-v of the feature fetch (wg_comm.hip); pairs a rank owns itself are not moved at all:
+//     the update kernel reads their gradient rows where the caller left them;
 //   * the received ids are radix-sorted ONCE as (local row, arrival position) pairs — only the bits a local row number
 //     needs — and a single kernel walks the sorted order: the lane group that sits on the first pair of a row sums that
-//     row's gradients (in arrival order: deterministic) and applies the update in the same pass.  No compaction, no
+//     row's gradients (ordered by sender rank, then by the sender's own order: reproducible, and the same order
+//     whatever the row partition is) and applies the update in the same pass.  No compaction, no
 //     de-duplicated gradient buffer, no host round trip for the unique count;
 //   * rows are 16-byte padded, so 4-wide vector accesses whenever the gradient rows allow it.
 // Update formulas: embedding_optimizer_func.cu:203-214 (SGD), :394-421 (LazyAdam / AdamW), :657-671 (AdaGrad),
@@ -51,10 +52,6 @@ struct wholememory_embedding_ {
 
 namespace wgamd {
 
-int64_t route_rows_to_owners(wholememory_handle_t h, size_t entry_bytes, const void* idx, wholememory_dtype_t idx_dtype,
-                             int64_t n, const char* rows, wholememory_matrix_description_t rows_m, temp_buffer& ids_out,
-                             temp_buffer& rows_out, int64_t* local_rows, wholememory_env_func_t* env, hipStream_t stream);
-
 namespace {
 
 enum { kSgd = 0, kLazyAdam, kAdaGrad, kRmsProp };
@@ -87,12 +84,25 @@ struct alignas(sizeof(T) * V) pack {
 };
 
 // sort key of a routed pair: its local row, or `local_rows` (one past the last row) for ids to skip
-__global__ void __launch_bounds__(256) sort_keys_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t local_rows,
+// Arrival order = sender rank, then the sender's own order: pairs [0, n_before) came from lower ranks, the next n_self are
+// my own (still in the caller's buffers), the rest came from higher ranks.  All ids are local row numbers already.
+struct arrival_map {
+  int64_t n_before, n_self;
+  // arrival position -> index into the received rows (>= 0) or ~(index into my own pairs) (< 0)
+  __host__ __device__ int64_t source(int64_t v) const
+  {
+    return v < n_before ? v : v < n_before + n_self ? ~(v - n_before) : v - n_self;
+  }
+};
+
+__global__ void __launch_bounds__(256) sort_keys_kernel(const int64_t* __restrict__ recv_ids, arrival_map am,
+                                                        const int64_t* __restrict__ self_ids, int64_t n, int64_t local_rows,
                                                         uint64_t* __restrict__ keys, int* __restrict__ vals)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int64_t id = ids[i];
+  const int64_t src = am.source(i);
+  const int64_t id  = src >= 0 ? recv_ids[src] : self_ids[~src];
   keys[i] = (id < 0 || id >= local_rows) ? (uint64_t)local_rows : (uint64_t)id;
   vals[i] = (int)i;
 }
@@ -107,7 +117,8 @@ __global__ void __launch_bounds__(256) fill_f32_kernel(float* p, int64_t n, floa
 template <typename EmbT, int OPT, int V>
 __global__ void __launch_bounds__(256)
 sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int64_t n, int64_t local_rows,
-                    const float* __restrict__ grads, int64_t ldg, EmbT* __restrict__ emb, int64_t lde, float* __restrict__ st,
+                    const float* __restrict__ recv_rows, arrival_map am, const float* __restrict__ grads, int64_t ldg,
+                    const int64_t* __restrict__ self_pos, EmbT* __restrict__ emb, int64_t lde, float* __restrict__ st,
                     int64_t lds, int64_t sdim, float* __restrict__ row_state, int dim, step_params p, int log2_lanes)
 {
   const int lanes       = 1 << log2_lanes;
@@ -132,7 +143,9 @@ sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ v
 #pragma unroll
       for (int j = 0; j < V; j++) g[j] = 0.f;
       for (int64_t k = i; k < end; k++) {
-        const pack<float, V> t = *reinterpret_cast<const pack<float, V>*>(grads + (int64_t)vals[k] * ldg + c);
+        const int64_t from = am.source(vals[k]);  // a routed row, or one of my own pairs read in place
+        const float* src   = from >= 0 ? recv_rows + from * dim : grads + self_pos[~from] * ldg;
+        const pack<float, V> t = *reinterpret_cast<const pack<float, V>*>(src + c);
 #pragma unroll
         for (int j = 0; j < V; j++) g[j] += t.v[j];
       }
@@ -182,8 +195,8 @@ sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ v
 }
 
 template <typename EmbT, int OPT>
-void launch_apply(bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* grads,
-                  int64_t ldg, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
+void launch_apply(bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* recv_rows,
+                  arrival_map am, const float* grads, int64_t ldg, const int64_t* self_pos, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
                   step_params p, hipStream_t stream)
 {
   const int V      = vec4 ? 4 : 1;
@@ -192,24 +205,24 @@ void launch_apply(bool vec4, const uint64_t* keys, const int* vals, int64_t n, i
   const int64_t gpb = 256 >> l2;
   const int grid    = (int)std::min<int64_t>((n + gpb - 1) / gpb, 256 * 16);
   if (vec4)
-    sparse_apply_kernel<EmbT, OPT, 4><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, grads, ldg, static_cast<EmbT*>(emb),
+    sparse_apply_kernel<EmbT, OPT, 4><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, static_cast<EmbT*>(emb),
                                                                lde, st, lds, sdim, row_state, dim, p, l2);
   else
-    sparse_apply_kernel<EmbT, OPT, 1><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, grads, ldg, static_cast<EmbT*>(emb),
+    sparse_apply_kernel<EmbT, OPT, 1><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, static_cast<EmbT*>(emb),
                                                                lde, st, lds, sdim, row_state, dim, p, l2);
   WG_HIP_CHECK(hipGetLastError());
 }
 
 template <typename EmbT>
-void dispatch_opt(int opt, bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* grads,
-                  int64_t ldg, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
+void dispatch_opt(int opt, bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* recv_rows,
+                  arrival_map am, const float* grads, int64_t ldg, const int64_t* self_pos, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
                   step_params p, hipStream_t stream)
 {
   switch (opt) {
-    case kSgd: return launch_apply<EmbT, kSgd>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
-    case kLazyAdam: return launch_apply<EmbT, kLazyAdam>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
-    case kAdaGrad: return launch_apply<EmbT, kAdaGrad>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
-    default: return launch_apply<EmbT, kRmsProp>(vec4, keys, vals, n, local_rows, grads, ldg, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    case kSgd: return launch_apply<EmbT, kSgd>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    case kLazyAdam: return launch_apply<EmbT, kLazyAdam>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    case kAdaGrad: return launch_apply<EmbT, kAdaGrad>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    default: return launch_apply<EmbT, kRmsProp>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
   }
 }
 
@@ -278,50 +291,63 @@ void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_t
   int64_t sz2[2]   = {n, e->dim};
   wholememory_matrix_description_t gm = wholememory_create_matrix_desc(sz2, gd->strides[0], 0, WHOLEMEMORY_DT_FLOAT);
 
-  temp_buffer ids_b(env), rows_b(env), keys_b(env), vals_b(env), keys2_b(env), vals2_b(env), tmp_b(env);
-  int64_t local_rows = 0;
-  const int64_t R    = route_rows_to_owners(wholememory_tensor_get_memory_handle(e->allocated), (size_t)e->padded_dim * es, idx,
-                                            id->dtype, n, g, gm, ids_b, rows_b, &local_rows, env, stream);
+  // (1) route: who owns each pair; remote pairs travel (ids, then gradient rows), my own stay where they are
+  id_exchange x(env);
+  x.plan(wholememory_tensor_get_memory_handle(e->allocated), (size_t)e->padded_dim * es, 0, idx, id->dtype, n, true, stream);
+  const int64_t local_rows = x.local_rows, n_recv = x.recv_total, R = x.recv_total + x.self_cnt, D = e->dim;
+  WG_EXPECTS(R < (int64_t)1 << 31, "too many gradient rows in one call");
+  unsigned bits = 1;
+  while (((uint64_t)1 << bits) <= (uint64_t)local_rows && bits < 63) bits++;  // keys are in [0, local_rows]
+  size_t sort_bytes = 0;
+  if (R > 0)
+    WG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
+                                           (int*)nullptr, (size_t)R, 0u, bits, stream));
+  temp_arena arena(env);
+  const size_t o_ids = arena.add(sizeof(int64_t) * n_recv), o_rows = arena.add(sizeof(float) * n_recv * D),
+               o_send = arena.add(sizeof(float) * x.n_remote * D), o_k1 = arena.add(sizeof(uint64_t) * R),
+               o_k2 = arena.add(sizeof(uint64_t) * R), o_v1 = arena.add(sizeof(int) * R), o_v2 = arena.add(sizeof(int) * R),
+               o_tmp = arena.add(sort_bytes);
+  arena.commit();
+  x.exchange_ids(arena.at<int64_t>(o_ids), stream);
+  gm.storage_offset = 0;
+  int64_t ps[2]     = {x.n_remote, D};
+  wholememory_matrix_description_t packed_m = wholememory_create_matrix_desc(ps, D, 0, WHOLEMEMORY_DT_FLOAT);
+  local_rows_gather(g, gm, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, arena.at<char>(o_send), packed_m, stream);
+  x.rows_to_owners(arena.at<char>(o_send), arena.at<char>(o_rows), sizeof(float) * D, stream);
   if (R > 0 && local_rows > 0) {
-    WG_EXPECTS(R < (int64_t)1 << 31, "too many gradient rows in one call");
-    auto* keys  = keys_b.device<uint64_t>(R, WHOLEMEMORY_DT_INT64);
-    auto* keys2 = keys2_b.device<uint64_t>(R, WHOLEMEMORY_DT_INT64);
-    auto* vals  = vals_b.device<int>(R, WHOLEMEMORY_DT_INT);
-    auto* vals2 = vals2_b.device<int>(R, WHOLEMEMORY_DT_INT);
-    // ids_b / rows_b were filled by route_rows_to_owners
-    const int64_t* d_ids = static_cast<const int64_t*>(ids_b.pointer());
-    const float* d_rows  = static_cast<const float*>(rows_b.pointer());
-    sort_keys_kernel<<<(int)((R + 255) / 256), 256, 0, stream>>>(d_ids, R, local_rows, keys, vals);
+    // (2) one stable sort of (local row, arrival position) over the bits a local row number needs
+    auto *keys = arena.at<uint64_t>(o_k1), *keys2 = arena.at<uint64_t>(o_k2);
+    auto *vals = arena.at<int>(o_v1), *vals2 = arena.at<int>(o_v2);
+    const arrival_map am{(int64_t)x.recv_at[x.me], x.self_cnt};
+    sort_keys_kernel<<<(int)((R + 255) / 256), 256, 0, stream>>>(x.d_recv_ids, am, x.d_self_ids, R, local_rows, keys, vals);
     WG_HIP_CHECK(hipGetLastError());
-    unsigned bits = 1;
-    while (((uint64_t)1 << bits) <= (uint64_t)local_rows && bits < 63) bits++;  // keys are in [0, local_rows]
-    size_t tmp_bytes = 0;
-    WG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)R, 0u, bits, stream));
-    void* tmp = tmp_b.bytes((int64_t)tmp_bytes);
-    WG_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)R, 0u, bits, stream));
+    WG_HIP_CHECK(rocprim::radix_sort_pairs(arena.at<void>(o_tmp), sort_bytes, keys, keys2, vals, vals2, (size_t)R, 0u, bits, stream));
 
+    // (3) sum the gradients of every row and update it, one pass
     const auto* o = e->optimizer;
     step_params p{lr, o->weight_decay, o->epsilon, o->beta1, o->beta2, o->alpha, o->adam_w > 0.5f ? 1 : 0};
     void* emb        = local_pointer(e->allocated);
     float* st        = e->state_table ? static_cast<float*>(local_pointer(e->state_table)) : nullptr;
     float* row_state = e->row_state ? static_cast<float*>(local_pointer(e->row_state)) : nullptr;
-    const int64_t lds = (int64_t)e->state_names.size() > 0 && e->state_table
-                          ? wholememory_tensor_get_tensor_description(e->state_table)->strides[0]
-                          : 0;
-    const bool vec4 = e->dim % 4 == 0;  // routed gradient rows are packed [R, dim]: 16-byte aligned rows iff dim % 4 == 0
+    const int64_t lds = e->state_table ? wholememory_tensor_get_tensor_description(e->state_table)->strides[0] : 0;
+    const float* d_rows = arena.at<float>(o_rows);
+    const float* gsrc   = reinterpret_cast<const float*>(g);
+    const int64_t ldg   = gd->strides[0];
+    // 16-byte vector reads need aligned gradient rows on both sources (routed rows are packed [n_recv, dim])
+    const bool vec4 = D % 4 == 0 && (x.self_cnt == 0 || (ldg % 4 == 0 && reinterpret_cast<uintptr_t>(gsrc) % 16 == 0));
     const int opt   = opt_code(o->type);
     switch (e->dtype) {
       case WHOLEMEMORY_DT_FLOAT:
-        dispatch_opt<float>(opt, vec4, keys2, vals2, R, local_rows, d_rows, e->dim, emb, e->padded_dim, st, lds, e->state_dim,
-                            row_state, (int)e->dim, p, stream);
+        dispatch_opt<float>(opt, vec4, keys2, vals2, R, local_rows, d_rows, am, gsrc, ldg, x.d_self_pos, emb, e->padded_dim,
+                            st, lds, e->state_dim, row_state, (int)D, p, stream);
         break;
       case WHOLEMEMORY_DT_HALF:
-        dispatch_opt<__half>(opt, vec4, keys2, vals2, R, local_rows, d_rows, e->dim, emb, e->padded_dim, st, lds, e->state_dim,
-                             row_state, (int)e->dim, p, stream);
+        dispatch_opt<__half>(opt, vec4, keys2, vals2, R, local_rows, d_rows, am, gsrc, ldg, x.d_self_pos, emb, e->padded_dim,
+                             st, lds, e->state_dim, row_state, (int)D, p, stream);
         break;
       default:
-        dispatch_opt<__hip_bfloat16>(opt, vec4, keys2, vals2, R, local_rows, d_rows, e->dim, emb, e->padded_dim, st, lds,
-                                     e->state_dim, row_state, (int)e->dim, p, stream);
+        dispatch_opt<__hip_bfloat16>(opt, vec4, keys2, vals2, R, local_rows, d_rows, am, gsrc, ldg, x.d_self_pos, emb,
+                                     e->padded_dim, st, lds, e->state_dim, row_state, (int)D, p, stream);
         break;
     }
   }
