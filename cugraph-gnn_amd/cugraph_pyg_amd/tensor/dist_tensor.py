@@ -1,90 +1,225 @@
 """``DistTensor`` / ``DistEmbedding`` — the tensors a FeatureStore keeps
-(/root/reference/python/cugraph-pyg/cugraph_pyg/tensor/dist_tensor.py:20-534: ``__getitem__`` gathers
-by global row, ``__setitem__`` scatters, ``shape``/``dtype``), over ``wholegraph_amd.WholeMemoryTensor``:
-one device tensor on a single GPU, a node-local range partition + RCCL all-to-all otherwise.
-The reference's ``backend`` ("vmm"/"nccl") and host ``device`` options do not apply: storage is HBM."""
-from typing import Optional, Sequence
+(/root/reference/python/cugraph-pyg/cugraph_pyg/tensor/dist_tensor.py:20-534; helpers of tensor/utils.py:14-170):
+``__getitem__`` gathers by global row, ``__setitem__`` scatters, sources are a tensor, a ``.pt`` / ``.npy`` file or a list
+of headerless binary part files.  Storage is ``wholegraph_amd.WholeMemoryTensor``: one device tensor on a single GPU, a
+node-local range partition + RCCL all-to-all otherwise (also runs over gloo for the CPU tests).
 
+What differs from the reference by design: every table lives in HBM, so ``device`` ("cpu" = host-pinned UVA in the
+reference, "cuda") and ``backend`` ("vmm" / "nccl" / "nvshmem" / "chunked") are accepted, remembered and reported back,
+but do not select a memory type; ``DistEmbedding`` takes ``cache_policy=None`` / ``round_robin_size=0`` only."""
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
 import torch
 
 from wholegraph_amd import dist as _dist
 from wholegraph_amd.tensor import HipLocalOps, WholeMemoryTensor, equal_entry_partition
 
 
-class DistTensor:
-    """1-D (or N-D with dim-0 partitioning) distributed tensor."""
+class _Dim(int):
+    """``tensor.dim`` is a property in the reference (dist_tensor.py:312-314) and a method on torch tensors: serve both."""
 
-    _ndim = 1
+    def __call__(self):
+        return int(self)
+
+
+def _offsets_from_book(partition_book, rows, ws):
+    if partition_book is None:
+        return equal_entry_partition(rows, ws)
+    book = [int(v) for v in partition_book]
+    if len(book) != ws or sum(book) != rows or any(v < 0 for v in book):
+        raise ValueError("partition_book must hold one entry count per rank and sum to shape[0]")
+    return [0] + np.cumsum(book).tolist()
+
+
+class DistTensor:
+    """1-D or 2-D distributed tensor, range-partitioned over dim 0."""
+
     default_local_ops = HipLocalOps   # the product's row kernels; CPU tests inject the oracle's here
 
-    def __init__(self, src: Optional[torch.Tensor] = None, shape: Optional[Sequence[int]] = None,
-                 dtype: Optional[torch.dtype] = None, device: str = "cuda", backend: Optional[str] = None,
-                 partition_offsets: Optional[Sequence[int]] = None, group=None, local_ops=None):
-        if src is None and (shape is None or dtype is None):
-            raise ValueError("Please specify shape and dtype for empty tensor.")
-        local_ops = local_ops if local_ops is not None else DistTensor.default_local_ops
+    def __init__(self, src: Optional[Union[torch.Tensor, str, List[str]]] = None, shape: Optional[Sequence[int]] = None,
+                 dtype: Optional[torch.dtype] = None, device: Optional[str] = "cuda",
+                 partition_book: Optional[Sequence[int]] = None, backend: Optional[str] = "nccl", *,
+                 partition_offsets: Optional[Sequence[int]] = None, group=None, local_ops=None, **kwargs):
+        self._tensor = None
+        self._requested_device = device
+        self._backend = backend
         self._group = group
-        ws, rk = _dist.world_size(group), _dist.rank(group)
-        dev = "cuda" if torch.cuda.is_available() else "cpu"
-        if src is not None and ws == 1:
-            t = src.to(dev)
-            t = t if t.dim() >= 1 else t.view(1)
-            self._wm = WholeMemoryTensor(t.contiguous(), local_ops=local_ops)
+        self._local_ops = local_ops if local_ops is not None else DistTensor.default_local_ops
+        self._book = partition_book
+        self._offsets_arg = partition_offsets
+        if src is None:
+            if shape is None:
+                raise ValueError("Please specify the shape of the tensor.")
+            if dtype is None:
+                raise ValueError("Please specify the dtype of the tensor.")
+            if len(shape) not in (1, 2):
+                raise ValueError("The shape of the tensor must be 1D or 2D.")
+            self._create(shape, dtype)
+        elif isinstance(src, (list, tuple)):
+            if shape is None or dtype is None:
+                raise ValueError("For now, reading from multiple files is only supported with binary format.")
+            self._create(shape, dtype)      # dist_tensor.py:82-90, utils.py:96-170
+            self._tensor.from_filelist(list(src), int(kwargs.get("round_robin_size", 0) or 0))
         else:
-            shape = tuple(int(s) for s in (shape if shape is not None else src.shape))
-            dtype = dtype or src.dtype
-            if ws == 1:
-                self._wm = WholeMemoryTensor(torch.zeros(shape, dtype=dtype, device=dev), local_ops=local_ops)
-            else:
-                offs = list(partition_offsets) if partition_offsets is not None else equal_entry_partition(shape[0], ws)
-                local = torch.zeros((offs[rk + 1] - offs[rk],) + shape[1:], dtype=dtype, device=dev)
-                self._wm = WholeMemoryTensor(local, global_rows=shape[0], partition_offsets=offs, group=group,
-                                             local_ops=local_ops)
+            self._init_from_single_source(src)
 
+    # ---- construction -----------------------------------------------------------------------------------------
+    def _create(self, shape, dtype):
+        shape = tuple(int(s) for s in shape)
+        ws, rk = _dist.world_size(self._group), _dist.rank(self._group)
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        if ws == 1:
+            self._tensor = WholeMemoryTensor(torch.zeros(shape, dtype=dtype, device=dev), local_ops=self._local_ops)
+        else:
+            offs = list(self._offsets_arg) if self._offsets_arg is not None else _offsets_from_book(self._book, shape[0], ws)
+            local = torch.zeros((offs[rk + 1] - offs[rk],) + shape[1:], dtype=dtype, device=dev)
+            self._tensor = WholeMemoryTensor(local, global_rows=shape[0], partition_offsets=offs, group=self._group,
+                                             local_ops=self._local_ops)
+        self._dtype = dtype
+
+    def _init_from_single_source(self, src):
+        """A tensor every rank holds in full, or a ``.pt`` / ``.npy`` file (dist_tensor.py:98-157): each rank copies
+        its own row range."""
+        if isinstance(src, torch.Tensor):
+            host_tensor = src if src.dim() >= 1 else src.view(1)
+        elif isinstance(src, str) and src.endswith(".pt"):
+            host_tensor = torch.load(src, mmap=True)
+        elif isinstance(src, str) and src.endswith(".npy"):
+            host_tensor = torch.from_numpy(np.load(src, mmap_mode="c"))
+        else:
+            raise ValueError("Unsupported source type. Please provide a torch.Tensor, a file path, or a list of file paths.")
+        if host_tensor.dim() not in (1, 2):
+            raise ValueError("The shape of the tensor must be 1D or 2D.")
+        if _dist.world_size(self._group) == 1:
+            # one GPU holds everything: adopt the tensor (no second copy of a table that may fill most of the HBM)
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+            self._tensor = WholeMemoryTensor(host_tensor.to(dev).contiguous(), local_ops=self._local_ops)
+            self._dtype = host_tensor.dtype
+            return
+        self._create(host_tensor.shape, host_tensor.dtype)
+        self.load_from_global_tensor(host_tensor)
+
+    def load_from_global_tensor(self, tensor):
+        """Every rank passes the WHOLE tensor and keeps its own rows (utils.py:14-19)."""
+        if self._tensor is None:
+            raise ValueError("Please create WholeGraph tensor first.")
+        local, start = self._tensor.get_local_tensor()
+        if tuple(tensor.shape) != tuple(self._tensor.shape):
+            raise ValueError("The shape of the tensor does not match the shape of the distributed tensor.")
+        local.copy_(tensor[start:start + local.shape[0]].to(local.dtype))
+
+    def load_from_local_tensor(self, tensor):
+        """Every rank passes exactly its own rows (dist_tensor.py:172-190)."""
+        if self._tensor is None:
+            raise ValueError("Please create WholeGraph tensor first.")
+        local = self._tensor.get_local_tensor()[0]
+        if tuple(local.shape) != tuple(tensor.shape):
+            raise ValueError("The shape of the tensor does not match the shape of the local tensor.")
+        if self.dtype != tensor.dtype:
+            raise ValueError("The dtype of the tensor does not match the dtype of the local tensor.")
+        local.copy_(tensor)
+
+    @classmethod
+    def from_tensor(cls, tensor: torch.Tensor, device: Optional[str] = "cuda", partition_book=None,
+                    backend: Optional[str] = "nccl", **kwargs):
+        return cls(src=tensor, device=device, partition_book=partition_book, backend=backend, **kwargs)
+
+    @classmethod
+    def from_file(cls, file_path: str, device: Optional[str] = "cuda", partition_book=None,
+                  backend: Optional[str] = "nccl", **kwargs):
+        return cls(src=file_path, device=device, partition_book=partition_book, backend=backend, **kwargs)
+
+    # ---- access (collective over the group when partitioned) -------------------------------------------------------
     @property
-    def shape(self):
-        return torch.Size(self._wm.shape)
-
-    @property
-    def dtype(self):
-        return self._wm.dtype
-
-    @property
-    def device(self):
-        return self._wm.local_tensor.device
-
-    def dim(self):
-        return self._wm.dim()
-
-    def __len__(self):
-        return self._wm.shape[0]
-
-    def get_local_tensor(self, host_view=False):
-        return self._wm.get_local_tensor(host_view)[0]
-
-    def get_local_offset(self):
-        return self._wm.get_local_tensor()[1]
+    def _wm(self):   # the name the FeatureStore used before
+        return self._tensor
 
     def _idx(self, idx):
         if isinstance(idx, slice):
-            idx = torch.arange(*idx.indices(self._wm.shape[0]))
+            idx = torch.arange(*idx.indices(self._tensor.shape[0]))
         idx = torch.as_tensor(idx)
         if idx.dtype not in (torch.int32, torch.int64):
             idx = idx.long()
-        return idx.to(self.device).contiguous().view(-1)
+        return idx.to(self._tensor.local_tensor.device).contiguous().view(-1)
 
     def __getitem__(self, idx) -> torch.Tensor:
-        return self._wm.gather(self._idx(idx))
+        assert self._tensor is not None, "Please create WholeGraph tensor first."
+        return self._tensor.gather(self._idx(idx))
 
     def __setitem__(self, idx, val: torch.Tensor):
+        assert self._tensor is not None, "Please create WholeGraph tensor first."
         idx = self._idx(idx)
-        val = val.to(device=self.device, dtype=self.dtype)
-        if val.dim() < self._wm.dim():
-            val = val.view((-1,) + tuple(self._wm.shape[1:]))
-        self._wm.scatter(val.contiguous(), idx)
+        val = val.to(device=idx.device, dtype=self.dtype)
+        if val.dim() < self._tensor.dim():
+            val = val.view((-1,) + tuple(self._tensor.shape[1:]))
+        self._tensor.scatter(val.contiguous(), idx)
+
+    def get_local_tensor(self, host_view=False):
+        return self._tensor.get_local_tensor(host_view)[0]
+
+    def get_local_offset(self):
+        return self._tensor.get_local_tensor()[1]
+
+    def get_comm(self):
+        """The process group the rows are partitioned over (``None`` = the default group)."""
+        assert self._tensor is not None, "Please create WholeGraph tensor first."
+        return self._group
+
+    @property
+    def dim(self):
+        return _Dim(self._tensor.dim())
+
+    @property
+    def shape(self):
+        return torch.Size(self._tensor.shape)
+
+    @property
+    def device(self):
+        return self._requested_device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def __len__(self):
+        return self._tensor.shape[0]
+
+    def __repr__(self):
+        if self._tensor is None:
+            return "<DistTensor: No tensor loaded>"
+        return f"DistTensor(shape={tuple(self._tensor.shape)}, dtype={self.dtype}, device='{self.device}')"
 
 
 class DistEmbedding(DistTensor):
-    """2-D [num_embeddings, embedding_dim] table (dist_tensor.py:283-534)."""
+    """2-D [num_embeddings, embedding_dim] table with a name (dist_tensor.py:340-534)."""
 
-    _ndim = 2
+    def __init__(self, src=None, shape=None, dtype=None, device: Optional[str] = "cuda", partition_book=None,
+                 backend: Optional[str] = "nccl", cache_policy=None, gather_sms: Optional[int] = -1,
+                 round_robin_size: int = 0, name: Optional[str] = None, **kwargs):
+        if cache_policy is not None:
+            raise NotImplementedError("cache policies do not exist on this target (every table lives in HBM)")
+        self._name = name
+        self._gather_sms = gather_sms
+        super().__init__(src, shape, dtype, device, partition_book, backend, round_robin_size=round_robin_size, **kwargs)
+
+    @classmethod
+    def from_tensor(cls, tensor, device: Optional[str] = "cuda", partition_book=None, name: Optional[str] = None,
+                    cache_policy=None, **kwargs):
+        return cls(src=tensor, device=device, partition_book=partition_book, name=name, cache_policy=cache_policy, **kwargs)
+
+    @classmethod
+    def from_file(cls, file_path, device: Optional[str] = "cuda", partition_book=None, name: Optional[str] = None,
+                  cache_policy=None, **kwargs):
+        return cls(src=file_path, device=device, partition_book=partition_book, name=name, cache_policy=cache_policy,
+                   **kwargs)
+
+    @property
+    def name(self):
+        return self._name
+
+    def __repr__(self):
+        if self._tensor is None:
+            return f"<DistEmbedding: No embedding loaded, Name: {self._name}>"
+        head = f"DistEmbedding(name={self._name}, " if self._name else "DistEmbedding("
+        return head + f"shape={tuple(self.shape)}, dtype={self.dtype}, device='{self.device}')"

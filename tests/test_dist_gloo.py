@@ -18,15 +18,20 @@ class OracleLocalOps:
     """test-only stand-in for wholegraph_amd.tensor.HipLocalOps, backed by the oracle"""
 
     @staticmethod
+    def _np(t, other):
+        # numpy has no bfloat16: same-dtype row copies move the 16-bit patterns
+        return t.view(torch.int16).numpy() if t.dtype == torch.bfloat16 and other.dtype == torch.bfloat16 else t.numpy()
+
+    @staticmethod
     def gather(table, idx, out):
         import oracle
-        oracle.gather(table.numpy(), idx.numpy(), out=out.numpy())
+        oracle.gather(OracleLocalOps._np(table, out), idx.numpy(), out=OracleLocalOps._np(out, table))
         return out
 
     @staticmethod
     def scatter(inp, idx, table):
         import oracle
-        oracle.scatter(inp.numpy(), idx.numpy(), table.numpy())
+        oracle.scatter(OracleLocalOps._np(inp, table), idx.numpy(), OracleLocalOps._np(table, inp))
 
 
 def _free_port():
@@ -187,6 +192,135 @@ def test_pyg_stores_world2(oracle_mod):
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _dist_tensor_worker(rank, world, port, q, tmpdir):
+    """Mirror of the reference's python/cugraph-pyg/cugraph_pyg/tests/tensor/test_dist_tensor_mg.py:19-170 and
+    test_dist_matrix_mg.py:13-120 (creation from a tensor / a .pt / a .npy / binary part files, gathers from any rank,
+    invalid cases, COO matrix get / set, even local shares) on two gloo ranks with the oracle's row kernels."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "cugraph-gnn_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from cugraph_pyg_amd.tensor import DistEmbedding, DistMatrix, DistTensor
+        DistTensor.default_local_ops = OracleLocalOps          # test-only injection (no GPU here)
+        for clx in (DistTensor, DistEmbedding):
+            for dtype in (torch.float32, torch.float16, torch.bfloat16):
+                for device in ("cpu", "cuda"):
+                    g = torch.Generator().manual_seed(3)
+                    features = torch.randn(world * 100 * 10, generator=g).to(dtype).reshape((-1, 10))
+                    t = clx.from_tensor(tensor=features, device=device)
+                    assert t.shape == features.shape and t.dtype == features.dtype and t.device == device
+                    assert t.dim == 2 and t.dim() == 2 and len(t) == features.shape[0]
+                    assert t.get_local_tensor().shape[0] == 100 and t.get_local_offset() == 100 * rank
+                    ix = torch.randint(0, features.shape[0], (10,), generator=torch.Generator().manual_seed(rank))
+                    assert torch.equal(features[ix], t[ix])
+                    assert clx.__name__ in repr(t)
+            # .pt and .npy sources: every rank keeps its own rows of the file
+            features = torch.arange(0, world * 1000).reshape((-1, 100)).to(torch.float32)
+            pt, npy = os.path.join(tmpdir, "f.pt"), os.path.join(tmpdir, "f.npy")
+            if rank == 0:
+                torch.save(features, pt)
+                np.save(npy, features.numpy())
+            dist.barrier()
+            for path in (pt, npy):
+                t = clx.from_file(path, device="cuda")
+                assert t.shape == features.shape and t.dtype == features.dtype
+                ix = torch.randperm(features.shape[0], generator=torch.Generator().manual_seed(5 + rank))[:10]
+                assert torch.equal(features[ix], t[ix])
+            # binary part files that do not line up with the row partition (utils.py:96-170)
+            parts = [os.path.join(tmpdir, "bin_part_%d_of_3" % i) for i in range(3)]
+            if rank == 0:
+                for f, blk in zip(parts, torch.split(features, [3, 11, 6], dim=0)):
+                    blk.numpy().tofile(f)
+            dist.barrier()
+            t = clx(src=parts, shape=list(features.shape), dtype=torch.float32, partition_book=[13, 7])
+            assert t.get_local_offset() == (0 if rank == 0 else 13)
+            assert torch.equal(t.get_local_tensor(), features[:13] if rank == 0 else features[13:])
+            # __setitem__ from every rank, then a global read-back; load_from_local_tensor
+            t2 = clx(shape=[20, 100], dtype=torch.float32)
+            mine = torch.arange(rank, 20, world)
+            t2[mine] = features[mine]
+            dist.barrier()
+            assert torch.equal(t2[torch.arange(20)], features)
+            t2.load_from_local_tensor(torch.full((10, 100), float(rank)))
+            dist.barrier()
+            assert torch.equal(t2[torch.tensor([0, 19])][:, 0], torch.tensor([0.0, 1.0]))
+            for bad in (torch.zeros(3, 100), torch.zeros((10, 100), dtype=torch.float64)):
+                try:
+                    t2.load_from_local_tensor(bad)
+                    raise AssertionError("shape / dtype mismatch accepted")
+                except ValueError:
+                    pass
+            dist.barrier()
+        # invalid cases (test_dist_tensor_mg.py:137-160)
+        for kwargs in (dict(shape=[1, 2, 3], dtype=torch.float32), dict(), dict(src="invalid.txt"), dict(shape=[4]),
+                       dict(src=["a", "b"])):
+            try:
+                DistTensor(**kwargs)
+                raise AssertionError("accepted %r" % (kwargs,))
+            except ValueError:
+                pass
+        try:
+            DistEmbedding(shape=[4, 4], dtype=torch.float32, cache_policy=object())
+            raise AssertionError("cache policy accepted")
+        except NotImplementedError:
+            pass
+        assert DistEmbedding(shape=[4, 4], dtype=torch.float32, name="emb").name == "emb"
+        # COO matrix
+        g = torch.Generator().manual_seed(11)
+        col, row = torch.randint(0, 100, (1001,), generator=g), torch.randint(0, 100, (1001,), generator=g)
+        m = DistMatrix(src=(col, row), device="cuda", format="coo")
+        assert m.shape == (1001, 1001) and m.dtype == torch.long and m._format == "coo"
+        idx = torch.randint(0, 1001, (10,), generator=torch.Generator().manual_seed(rank))
+        res = m[idx]
+        assert res.shape == (2, 10) and torch.equal(res[0], col[idx]) and torch.equal(res[1], row[idx])
+        lo = 0 if rank == 0 else 501                      # 1001 entries over 2 ranks: 501 + 500
+        assert torch.equal(m.local_col, col[lo:lo + (501 if rank == 0 else 500)])
+        assert torch.equal(m.local_coo, torch.stack([col, row])[:, lo:lo + (501 if rank == 0 else 500)])
+        e = DistMatrix(shape=(30, 30), dtype=torch.int64, format="coo")
+        mine = torch.arange(rank, 30, world)
+        e[mine] = torch.stack([mine * 2, mine * 3])
+        dist.barrier()
+        assert torch.equal(e[torch.arange(30)], torch.stack([torch.arange(30) * 2, torch.arange(30) * 3]))
+        e[mine] = (mine * 5, mine * 7)
+        dist.barrier()
+        assert torch.equal(e[torch.tensor([29])], torch.tensor([[145], [203]]))
+        for bad in (dict(src=(col,)), dict(src="x.bin"), dict(), dict(src=(col, row[:5])), dict(src=("a", "b")), dict(src=5)):
+            try:
+                DistMatrix(**bad)
+                raise AssertionError("accepted %r" % (list(bad),))
+            except (ValueError, NotImplementedError):
+                pass
+        for bad_val in (torch.zeros(3, 2, dtype=torch.int64), torch.zeros(2, dtype=torch.int64)):
+            try:
+                e[torch.tensor([0, 1])] = bad_val
+                raise AssertionError("bad value accepted")
+            except ValueError:
+                pass
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_tensor_embedding_matrix_world2(oracle_mod, tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_tensor_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in results:
