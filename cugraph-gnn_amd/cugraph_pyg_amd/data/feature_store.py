@@ -84,6 +84,10 @@ class FeatureStore(_PygFeatureStore):
             raise KeyError(f"no tensor for {attr}")
         return out
 
+    def __delitem__(self, key):
+        # torch_geometric.data.FeatureStore.__delitem__: `del store[group, attr, index]`
+        self.remove_tensor(self._attr(key))
+
     def put_tensor(self, tensor, *args, **kwargs) -> bool:
         attr = args[0] if args and isinstance(args[0], TensorAttr) else TensorAttr(*args, **kwargs)
         return self._put_tensor(torch.as_tensor(tensor), attr)

@@ -10,8 +10,13 @@ renumbering kernel with an empty target list does exactly that and returns the i
 
 Implemented: homogeneous and heterogeneous graphs (edge seeds of ONE edge type, endpoints of both node types
 seeded together), ``neg_sampling`` = None | "binary" | "triplet" (uniform negatives inside the endpoint types'
-id ranges), ``disjoint``, temporal seeds (``edge_label_time`` + ``time_attr``; negatives are NOT time-filtered).
+id ranges, at least one per batch — sampler_utils.py:112-116; both modes deliver ``edge_label_index`` + ``edge_label``
+with the positives first, as the reference's readers do, sampler.py:583-598 — "triplet" draws the negative sources from
+the batch's positive sources, sampler.py:833-840 — here negative k starts at the source of positive k mod n_pos), ``disjoint``, temporal seeds (``edge_label_time`` + ``time_attr``);
+with a node-level ``time_attr`` in the feature store the negatives are redrawn until both endpoints exist at the seed
+edge's time (5 attempts, then the earliest node of the type: sampler_utils.py:213-311).
 """
+from math import ceil
 import warnings
 from typing import Optional, Tuple, Union
 
@@ -33,6 +38,45 @@ def _first_occurrence(inverse, values, n_unique):
     return values[first]
 
 
+def _node_time(feature_store, node_type, time_attr, n):
+    """Per-node timestamps of ``node_type`` if the feature store holds ``(node_type, time_attr)``, else None."""
+    if time_attr is None:
+        return None
+    try:
+        t = feature_store[node_type, time_attr, None]
+    except Exception:  # noqa: BLE001 - a missing attribute raises KeyError / AttributeError depending on the store
+        return None
+    if t is None:
+        return None
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    t = t if torch.is_tensor(t) else t[torch.arange(n, device=dev)]
+    return t.to(dev).long().view(-1)
+
+
+def _draw_negatives(n_neg, num_src, num_dst, gen, dev, neg_time=None, src_time=None, dst_time=None):
+    """Uniform (src, dst) pairs; with node times, pair k is redrawn until both ends are no later than neg_time[k]."""
+    src = torch.randint(0, num_src, (n_neg,), generator=gen, device=dev)
+    dst = torch.randint(0, num_dst, (n_neg,), generator=gen, device=dev)
+    if neg_time is None or (src_time is None and dst_time is None) or n_neg == 0:
+        return src, dst
+
+    def late(ids, times):
+        return torch.zeros_like(ids, dtype=torch.bool) if times is None else times[ids] > neg_time
+
+    for _ in range(5):
+        bad = late(src, src_time) | late(dst, dst_time)
+        k = int(bad.sum())
+        if k == 0:
+            return src, dst
+        src = torch.where(bad, torch.randint(0, num_src, (n_neg,), generator=gen, device=dev), src)
+        dst = torch.where(bad, torch.randint(0, num_dst, (n_neg,), generator=gen, device=dev), dst)
+    if src_time is not None:
+        src = torch.where(late(src, src_time), src_time.argmin().expand_as(src), src)
+    if dst_time is not None:
+        dst = torch.where(late(dst, dst_time), dst_time.argmin().expand_as(dst), dst)
+    return src, dst
+
+
 def _parse_neg_sampling(neg_sampling) -> Tuple[Optional[str], float]:
     if neg_sampling is None:
         return None, 0.0
@@ -51,9 +95,10 @@ class LinkLoader:
                  edge_label_time=None, neg_sampling=None, neg_sampling_ratio=None, transform=None,
                  transform_sampler_output=None, filter_per_worker=None, custom_cls=None, input_id=None,
                  batch_size: int = 1, shuffle: bool = False, drop_last: bool = False,
-                 random_state: Optional[int] = None, **kwargs):
+                 random_state: Optional[int] = None, time_attr: Optional[str] = None, **kwargs):
         if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
+        self.__time_attr = time_attr
         if not isinstance(link_sampler, (NeighborSampler, HeteroNeighborSampler)):
             raise NotImplementedError("Must provide a cuGraph sampler")
         if neg_sampling_ratio is not None:
@@ -91,11 +136,35 @@ class LinkLoader:
         self.__data, self.__sampler = data, link_sampler
         self.__batch_size, self.__shuffle, self.__drop_last = batch_size, shuffle, drop_last
         self.__random_state = random_state
+        nv = graph_store._num_vertices()
         if self.__hetero:
-            nv = graph_store._num_vertices()
             self.__num_src, self.__num_dst = int(nv[self.__etype[0]]), int(nv[self.__etype[2]])
+            types = (self.__etype[0], self.__etype[2])
         else:
             self.__num_nodes = graph_store._graph.num_vertices
+            self.__num_src = self.__num_dst = self.__num_nodes
+            types = (sorted(nv.keys())[0],) * 2
+        # node-level timestamps gate the negatives of temporal link prediction (sampler_utils.py:213-241)
+        self.__src_time = self.__dst_time = None
+        if self.__mode is not None and self.__time is not None:
+            self.__src_time = _node_time(data[0], types[0], time_attr, self.__num_src)
+            self.__dst_time = self.__src_time if types[0] == types[1] else _node_time(data[0], types[1], time_attr,
+                                                                                      self.__num_dst)
+
+    def __with_negatives(self, src, dst, ix, gen):
+        """(src_all, dst_all, n_neg, time_all): positives first, then the negatives of the batch."""
+        n_pos, dev = ix.numel(), src.device
+        t_pos = None if self.__time is None else self.__time[ix]
+        if self.__mode is None:
+            return src, dst, 0, t_pos
+        n_neg = max(int(ceil(self.__amount * n_pos)), 1)                     # at least one negative per batch
+        t_neg = None if t_pos is None else t_pos[torch.arange(n_neg, device=dev) % n_pos]
+        neg_src, neg_dst = _draw_negatives(n_neg, self.__num_src, self.__num_dst, gen, dev, t_neg, self.__src_time,
+                                           self.__dst_time)
+        if self.__mode == "triplet":   # negative k starts at the source of "its" positive, k mod n_pos
+            neg_src = src[torch.arange(n_neg, device=dev) % n_pos]
+        t_all = None if t_pos is None else torch.cat([t_pos, t_neg])
+        return torch.cat([src, neg_src]), torch.cat([dst, neg_dst]), n_neg, t_all
 
     def __len__(self):
         n = self.__eli.shape[1]
@@ -118,22 +187,14 @@ class LinkLoader:
             src, dst = self.__eli[0, ix], self.__eli[1, ix]
             n_pos = ix.numel()
             gen = torch.Generator(device=dev).manual_seed((seed + b) & 0x7FFFFFFFFFFFFFFF)
-            n_neg = int(round(n_pos * self.__amount)) if self.__mode else 0
-            neg_dst = torch.randint(0, self.__num_nodes, (n_neg,), generator=gen, device=dev) if n_neg else None
-            if self.__mode == "binary":
-                neg_src = torch.randint(0, self.__num_nodes, (n_neg,), generator=gen, device=dev)
-                ends = torch.cat([src, neg_src, dst, neg_dst])
-            elif self.__mode == "triplet":
-                ends = torch.cat([src, dst, neg_dst])
-            else:
-                ends = torch.cat([src, dst])
+            src_all, dst_all, n_neg, t_all = self.__with_negatives(src, dst, ix, gen)
+            ends = torch.cat([src_all, dst_all])
             # first-appearance dedup + inverse map = renumbering with no targets
             uniq, inverse = graph_ops.append_unique(ends[:0].contiguous(), ends.contiguous(),
                                                     need_neighbor_raw_to_unique=True)
             seed_time = None
-            if self.__sampler.temporal:
-                reps = ends.numel() // max(n_pos, 1)   # every endpoint of seed edge i (and its negatives) starts at time i
-                seed_time = _first_occurrence(inverse.long(), self.__time[ix].repeat(reps)[:ends.numel()], uniq.numel())
+            if self.__sampler.temporal:   # every endpoint of seed edge i (and of its negatives) starts at time i
+                seed_time = _first_occurrence(inverse.long(), torch.cat([t_all, t_all]), uniq.numel())
             node, row, col, edge, nn, ne = neighbor_sample(graph, uniq, self.__sampler.fanout, seed + b,
                                                            self.__sampler.biased, self.__sampler.disjoint, seed_time,
                                                            self.__sampler.temporal_comparison)
@@ -143,19 +204,17 @@ class LinkLoader:
             data.input_id = self.__input_id[ix]
             data.batch_size = n_pos
             inverse = inverse.long()
-            if self.__mode == "triplet":
-                data.src_index = inverse[:n_pos]
-                data.dst_pos_index = inverse[n_pos:2 * n_pos]
-                data.dst_neg_index = inverse[2 * n_pos:].view(n_pos, -1) if n_neg % max(n_pos, 1) == 0 and n_neg > n_pos \
-                    else inverse[2 * n_pos:]
-            else:
-                half = n_pos + (n_neg if self.__mode == "binary" else 0)
-                data.edge_label_index = torch.stack([inverse[:half], inverse[half:]])
-                if self.__mode == "binary":
-                    pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
-                    data.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
-                elif self.__label is not None:
-                    data.edge_label = self.__label[ix]
+            half = n_pos + n_neg
+            data.edge_label_index = torch.stack([inverse[:half], inverse[half:]])
+            if self.__mode is not None:
+                pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
+                data.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
+                if self.__mode == "triplet":   # PyG's triplet view of the same batch
+                    data.src_index, data.dst_pos_index = inverse[:n_pos], inverse[half:half + n_pos]
+                    neg = inverse[half + n_pos:]
+                    data.dst_neg_index = neg.view(-1, n_pos).t() if n_neg % n_pos == 0 and n_neg > n_pos else neg
+            elif self.__label is not None:
+                data.edge_label = self.__label[ix]
             yield data
 
     def __hetero_batches(self, perm, seed):
@@ -171,15 +230,7 @@ class LinkLoader:
             src, dst = self.__eli[0, ix], self.__eli[1, ix]
             n_pos = ix.numel()
             gen = torch.Generator(device=dev).manual_seed((seed + b) & 0x7FFFFFFFFFFFFFFF)
-            n_neg = int(round(n_pos * self.__amount)) if self.__mode else 0
-            if self.__mode == "binary":
-                src_all = torch.cat([src, torch.randint(0, self.__num_src, (n_neg,), generator=gen, device=dev)])
-                dst_all = torch.cat([dst, torch.randint(0, self.__num_dst, (n_neg,), generator=gen, device=dev)])
-            elif self.__mode == "triplet":
-                src_all = torch.cat([src, src.repeat_interleave(max(n_neg // max(n_pos, 1), 1))[:n_neg]])
-                dst_all = torch.cat([dst, torch.randint(0, self.__num_dst, (n_neg,), generator=gen, device=dev)])
-            else:
-                src_all, dst_all = src, dst
+            src_all, dst_all, n_neg, t_all = self.__with_negatives(src, dst, ix, gen)
             empty = src_all[:0].contiguous()
             if src_t == dst_t:
                 uniq, inv = graph_ops.append_unique(empty, torch.cat([src_all, dst_all]).contiguous(),
@@ -193,8 +244,7 @@ class LinkLoader:
                 inv_src, inv_dst = inv_src.long(), inv_dst.long()
             seed_time = None
             if smp.temporal:
-                t_src = self.__time[ix].repeat(max(src_all.numel() // max(n_pos, 1), 1))[:src_all.numel()]
-                t_dst = self.__time[ix].repeat(max(dst_all.numel() // max(n_pos, 1), 1))[:dst_all.numel()]
+                t_src = t_dst = t_all
                 if src_t == dst_t:
                     seed_time = {src_t: _first_occurrence(torch.cat([inv_src, inv_dst]), torch.cat([t_src, t_dst]),
                                                           seeds[src_t].numel())}
@@ -265,4 +315,4 @@ class LinkNeighborLoader(LinkLoader):
                          edge_label=edge_label, edge_label_time=edge_label_time, neg_sampling=neg_sampling,
                          neg_sampling_ratio=neg_sampling_ratio, transform=transform,
                          transform_sampler_output=transform_sampler_output, filter_per_worker=filter_per_worker,
-                         batch_size=batch_size, **kwargs)
+                         batch_size=batch_size, time_attr=time_attr, **kwargs)
