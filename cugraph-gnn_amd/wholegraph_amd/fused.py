@@ -86,6 +86,43 @@ class WalkResult:
         return self.finalize_batches()[0]
 
 
+def _merge_hops_batch_major(fields_per_hop, segs_per_hop, G, dev):
+    """Per-hop arrays that are each batch-major (hop h, batch b = [segs[h][b], segs[h][b+1])) -> ONE array per field laid
+    out [batch][hop], plus the host offsets of the batches in it.  One scatter for the whole call group
+    per hop instead of a ``torch.cat`` per mini-batch and field (the per-batch loop then only takes views)."""
+    H = len(fields_per_hop)
+    n_fields = len(fields_per_hop[0]) if H else 0
+    tot, offs = [0] * G, [0] * (G + 1)
+    for s_ in segs_per_hop:
+        for b in range(G):
+            tot[b] += s_[b + 1] - s_[b]
+    for b in range(G):
+        offs[b + 1] = offs[b] + tot[b]
+    if H == 0:
+        return [], offs
+    live = [[f[s_[0]:s_[G]] for f in fs] for fs, s_ in zip(fields_per_hop, segs_per_hop)]
+    if H == 1:
+        return live[0], offs
+    # element j of hop h (batch b) lands at  j + shift[h][b],  shift = start of batch b in the merged array + what the
+    # earlier hops put there - start of the batch in the hop's own array: one scatter per hop and field, no sort
+    shift, before = [], [0] * G
+    for s_ in segs_per_hop:
+        shift.append([offs[b] + before[b] - s_[b] for b in range(G)])
+        before = [before[b] + s_[b + 1] - s_[b] for b in range(G)]
+    meta = torch.tensor([[s_[b + 1] - s_[b] for b in range(G)] for s_ in segs_per_hop] + shift, dtype=torch.int64).to(dev)
+    batches = torch.arange(G, device=dev)
+    merged = [torch.empty(offs[G], dtype=live[0][i].dtype, device=dev) for i in range(n_fields)]
+    for h in range(H):
+        n_h = segs_per_hop[h][G] - segs_per_hop[h][0]
+        if n_h == 0:
+            continue
+        b_of = torch.repeat_interleave(batches, meta[h], output_size=n_h)
+        dest = torch.arange(segs_per_hop[h][0], segs_per_hop[h][G], device=dev) + meta[H + h][b_of]
+        for i in range(n_fields):
+            merged[i][dest] = live[h][i]
+    return merged, offs
+
+
 class NoSyncWalk:
     def __init__(self, csr_row_ptr: torch.Tensor, csr_col_ind: torch.Tensor, batch_size: int,
                  max_neighbors: List[int], id_dtype=torch.int64, n_batches: int = 1):
@@ -254,22 +291,32 @@ class PygWalkResult:
         """Per mini-batch ``(node, row, col, edge, num_sampled_nodes, num_sampled_edges)`` — the tuple of
         ``cugraph_pyg_amd.sampler.neighbor_sample``.  ``edge_id`` maps CSR slots to original edge ids."""
         G, hops = self.n_batches, self.hops
-        fseg = [t.cpu().tolist() for t in self.frontier_seg]          # hops+1 lists (the last one = final new counts)
-        nseg = self.node_seg.cpu().tolist()
-        eseg = [self.offsets[k][torch.as_tensor(fseg[k], device=self.offsets[k].device).long()].cpu().tolist()
-                for k in range(hops)]
+        # one D2H copy for every size vector of the call group (each .cpu() is a stream sync)
+        pieces = list(self.frontier_seg) + [self.node_seg] + [self.offsets[k][self.frontier_seg[k].long()] for k in range(hops)]
+        flat = torch.cat([p_.reshape(-1).to(torch.int64) for p_ in pieces]).cpu().tolist()
+        host, at = [], 0
+        for p_ in pieces:
+            host.append(flat[at:at + p_.numel()])
+            at += p_.numel()
+        fseg = host[:hops + 1]                                       # hops+1 lists (the last one = final new counts)
+        nseg = host[hops + 1]
+        eseg = host[hops + 2:]
+        # dtype conversion, edge-id lookup and the hop concatenation happen ONCE for the call group
+        fields = []
+        for k in range(hops):
+            lo, hi = eseg[k][0], eseg[k][G]
+            gid = self.edge_gid[k]
+            fields.append([self.row_local[k][:hi].long(), self.col_local[k][:hi].long(),
+                           edge_id[gid[:hi]] if edge_id is not None else gid[:hi]])
+        (rows, cols, edges), offs = _merge_hops_batch_major(fields, eseg, G, self.nodes.device)
+        sizes_b = [offs[b + 1] - offs[b] for b in range(G)]
+        node_v = torch.split(self.nodes[nseg[0]:nseg[G]], [nseg[b + 1] - nseg[b] for b in range(G)])
+        row_v, col_v, edge_v = (torch.split(t[:offs[G]], sizes_b) for t in (rows, cols, edges))
         out = []
         for b in range(G):
-            rows, cols, edges, nn, ne = [], [], [], [fseg[0][b + 1] - fseg[0][b]], []
-            for k in range(hops):
-                e0, e1 = eseg[k][b], eseg[k][b + 1]
-                rows.append(self.row_local[k][e0:e1].long())
-                cols.append(self.col_local[k][e0:e1].long())
-                gid = self.edge_gid[k][e0:e1]
-                edges.append(edge_id[gid] if edge_id is not None else gid)
-                ne.append(e1 - e0)
-                nn.append(fseg[k + 1][b + 1] - fseg[k + 1][b])
-            out.append((self.nodes[nseg[b]:nseg[b + 1]], torch.cat(rows), torch.cat(cols), torch.cat(edges), nn, ne))
+            nn = [fseg[0][b + 1] - fseg[0][b]] + [fseg[k + 1][b + 1] - fseg[k + 1][b] for k in range(hops)]
+            ne = [eseg[k][b + 1] - eseg[k][b] for k in range(hops)]
+            out.append((node_v[b], row_v[b], col_v[b], edge_v[b], nn, ne))
         return out
 
 
@@ -504,36 +551,48 @@ class HeteroPygWalk:
         num_sampled_nodes{type}, num_sampled_edges{etype})."""
         G, dev = self.G, self.dev
         state = rec["state"]
-        nseg = {t: state[t]["seg"].cpu().tolist() for t in self.ntypes}
-        sizes = [{t: v.cpu().tolist() for t, v in s.items()} for s in rec["sizes"]]
-        calls = []
-        for c in rec["calls"]:
-            if c is None:
-                calls.append(None)
-                continue
-            fs = c["f_seg"].long()
-            calls.append(dict(c, eseg=c["offsets"][fs].cpu().tolist()))
+        # every small size vector of the call group goes to the host in ONE copy (each .cpu() is a stream sync)
+        pieces = [state[t]["seg"] for t in self.ntypes]
+        pieces += [s_[t] for s_ in rec["sizes"] for t in self.ntypes]
+        live_calls = [c for c in rec["calls"] if c is not None]
+        pieces += [c["offsets"][c["f_seg"].long()] for c in live_calls]
+        flat = torch.cat([p_.reshape(-1).to(torch.int64) for p_ in pieces]).cpu().tolist()
+        host, at = [], 0
+        for p_ in pieces:
+            host.append(flat[at:at + p_.numel()])
+            at += p_.numel()
+        it = iter(host)
+        nseg = {t: next(it) for t in self.ntypes}
+        sizes = [{t: next(it) for t in self.ntypes} for _ in rec["sizes"]]
+        calls = [None if c is None else dict(c, eseg=next(it)) for c in rec["calls"]]
         empty = torch.zeros(0, dtype=torch.int64, device=dev)
         n_et = len(self.etypes)
+        # per edge type: dtype conversion, edge-id lookup and the hop concatenation ONCE for the call group
+        merged, offs, num_edges_b = {}, {}, {}
+        for ti, et in enumerate(self.etypes):
+            fields, segs = [], []
+            for h in range(self.hops):
+                c = calls[h * n_et + ti]
+                if c is None:
+                    continue
+                hi = c["eseg"][G]
+                fields.append([c["row"][:hi].long(), c["col"][:hi].long(), self.graphs[et].edge_id[c["gid"][:hi]]])
+                segs.append(c["eseg"])
+            m, offs[et] = _merge_hops_batch_major(fields, segs, G, dev)
+            merged[et] = m if m else [empty, empty, empty]
+            num_edges_b[et] = [[(calls[h * n_et + ti]["eseg"][b + 1] - calls[h * n_et + ti]["eseg"][b])
+                                if calls[h * n_et + ti] is not None else 0 for h in range(self.hops)] for b in range(G)]
+        # all per-batch views of a field in one torch.split call (a Python slice per batch, type and field costs more
+        # than the kernels of the whole walk)
+        def views(t, seg):
+            return torch.split(t[seg[0]:seg[G]], [seg[b + 1] - seg[b] for b in range(G)])
+        node_v = {t: (views(state[t]["nodes"], nseg[t]) if state[t]["cap"] > 0 else (empty,) * G) for t in self.ntypes}
+        edge_v = {et: [views(merged[et][i], offs[et]) for i in range(3)] for et in self.etypes}
         out = []
         for b in range(G):
-            node = {t: (state[t]["nodes"][nseg[t][b]:nseg[t][b + 1]] if state[t]["cap"] > 0 else empty) for t in self.ntypes}
-            rows, cols, edges = {et: [] for et in self.etypes}, {et: [] for et in self.etypes}, {et: [] for et in self.etypes}
-            num_edges = {et: [] for et in self.etypes}
-            for h in range(self.hops):
-                for ti, et in enumerate(self.etypes):
-                    c = calls[h * n_et + ti]
-                    if c is None:
-                        num_edges[et].append(0)
-                        continue
-                    e0, e1 = c["eseg"][b], c["eseg"][b + 1]
-                    rows[et].append(c["row"][e0:e1].long())
-                    cols[et].append(c["col"][e0:e1].long())
-                    edges[et].append(self.graphs[et].edge_id[c["gid"][e0:e1]])
-                    num_edges[et].append(e1 - e0)
             num_nodes = {t: [sizes[0][t][b]] + [sizes[h + 1][t][b] - sizes[h][t][b] for h in range(self.hops)]
                          for t in self.ntypes}
-            cat = lambda xs: torch.cat(xs) if xs else empty  # noqa: E731
-            out.append((node, {et: cat(rows[et]) for et in self.etypes}, {et: cat(cols[et]) for et in self.etypes},
-                        {et: cat(edges[et]) for et in self.etypes}, num_nodes, num_edges))
+            out.append(({t: node_v[t][b] for t in self.ntypes}, {et: edge_v[et][0][b] for et in self.etypes},
+                        {et: edge_v[et][1][b] for et in self.etypes}, {et: edge_v[et][2][b] for et in self.etypes},
+                        num_nodes, {et: num_edges_b[et][b] for et in self.etypes}))
         return out
