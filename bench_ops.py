@@ -238,6 +238,34 @@ def main():
                 k * (8 + 8 * dim), k, "rows")
             wg.destroy_embedding(emb)
             wg.destroy_wholememory_optimizer(opt)
+    # ---- a14-a17: the cugraph_pyg-shaped loader end to end (GraphStore + FeatureStore -> NeighborLoader -> Data with x) ------
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    gs_, fs_ = GraphStore(), FeatureStore()
+    dst_ = torch.repeat_interleave(torch.arange(V, device=dev), row_ptr[1:] - row_ptr[:-1])
+    gs_[("n", "e", "n"), "coo", False, (V, V)] = torch.stack([col, dst_])
+    del dst_
+    fs_["n", "x", None] = torch.rand((V, 100), generator=g, device=dev)
+    for calls in (1, 64):
+        ld_seeds = torch.randperm(V, generator=g, device=dev)[:1024 * 64 * 3]
+        loader = NeighborLoader((fs_, gs_), [25, 10], input_nodes=ld_seeds, batch_size=1024,
+                                local_seeds_per_call=1024 * calls, shuffle=False)
+        it = iter(loader)
+        next(it)
+        torch.cuda.synchronize()
+        t0, n_e, n_b = time.perf_counter(), 0, 0
+        for batch in it:
+            n_e += int(batch.edge_index.shape[1])
+            n_b += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows.append({"op": "NeighborLoader (PyG-shaped Data per batch, x gathered) batch 1024 fan-out [25,10], call group %d" % calls,
+                     "reference": "cugraph_pyg.loader.NeighborLoader (a14-a17)", "ms_per_batch": round(dt / n_b * 1e3, 4),
+                     "edges_per_s": round(n_e / dt, 1), "edges_per_batch": round(n_e / n_b, 1),
+                     "note": "wall time of the Python iteration: sampling + renumbering in call groups, per-batch feature "
+                             "fetch and Data construction"})
+        print(rows[-1], flush=True)
+    del gs_, fs_
     if args.hetero:
         rows.append(hetero_section(dev))
         print(rows[-1], flush=True)
