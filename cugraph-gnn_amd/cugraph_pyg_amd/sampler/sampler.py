@@ -287,9 +287,13 @@ class HeteroNeighborSampler:
             rs = torch.tensor([[_as_i64(hop_seed(random_state + b + j, k)) for j in range(g)] for k in range(hops * n_et)],
                               dtype=torch.int64)
             rec = walk.run(seed_type, seeds[b * batch_size:(b + g) * batch_size].to(torch.int64).contiguous(), rs)
-            for j, out in enumerate(walk.finalize_batches(rec)):
+            outs = walk.finalize_batches(rec)
+            for j, out in enumerate(outs):
+                self.current_group = (rec["group_context"], j)   # read by the consumer right after the yield
                 yield b + j, out
+            self.current_group = None
             b += g
+        self.current_group = None
         for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
             yield bb, hetero_neighbor_sample(
                 self.graphs, seed_type, seeds[start:start + batch_size], self.fanout, random_state + bb, self.biased,
@@ -354,9 +358,13 @@ class NeighborSampler:
             walk = self._call_group_walk(batch_size, g)
             rs = [[hop_seed(random_state + b + j, k) for j in range(g)] for k in range(len(self.fanout))]
             res = walk.run(seeds[b * batch_size:(b + g) * batch_size].contiguous(), rs)
-            for j, out in enumerate(res.finalize_batches(self.graph.edge_id)):
+            outs = res.finalize_batches(self.graph.edge_id)
+            for j, out in enumerate(outs):
+                self.current_group = (res.group_context, j)   # read by the consumer right after the yield
                 yield b + j, out
+            self.current_group = None
             b += g
+        self.current_group = None
         for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
             yield bb, neighbor_sample(self.graph, seeds[start:start + batch_size], self.fanout, random_state + bb,
                                       self.biased, self.disjoint,
@@ -386,16 +394,19 @@ class BaseSampler:
                     node=node, row=row, col=col, edge=edge, batch={it: node[it][:n_seeds]},
                     num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
                     num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()},
-                    metadata=((it, ids), None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
+                    metadata=((it, ids), None if index.time is None else index.time[b * bs: b * bs + n_seeds],
+                              getattr(self.__sampler, "current_group", None)))
             return
         for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(nodes, bs, random_state,
                                                                                seed_time=index.time):
             n_seeds = nn[0]
             ids = input_id[b * bs: b * bs + n_seeds]
+            # third metadata slot: (call-group context, index of the batch in it) when the batch came out of a call group
             yield SamplerOutput(
                 node=node, row=row, col=col, edge=edge, batch=node[:n_seeds],
                 num_sampled_nodes=torch.tensor(nn), num_sampled_edges=torch.tensor(ne),
-                metadata=(ids, None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
+                metadata=(ids, None if index.time is None else index.time[b * bs: b * bs + n_seeds],
+                          getattr(self.__sampler, "current_group", None)))
 
     def sample_from_edges(self, index, neg_sampling=None, **kwargs):
         raise NotImplementedError("link loaders / negative sampling: SURVEY.md §8(f) rank 1")
@@ -415,8 +426,30 @@ def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
     return data
 
 
-def build_hetero_data(feature_store, s: HeteroSamplerOutput) -> HeteroData:
-    """HeteroSamplerOutput -> HeteroData with every stored attribute joined (sampler.py:96-165)."""
+_GROUP_FETCH_BYTES = 4 << 30
+
+
+def _group_attribute_views(feature_store, ctx):
+    """Every stored attribute gathered ONCE for a whole call group (``ctx`` of HeteroPygWalk.finalize_batches), split into
+    per-batch views; ``None`` for attributes whose group fetch would exceed _GROUP_FETCH_BYTES."""
+    views = {}
+    for attr in feature_store.get_all_tensor_attrs():
+        g = attr.group_name
+        src = ctx["edges"] if isinstance(g, tuple) else ctx["nodes"]
+        if g not in src:
+            continue
+        index, sizes = src[g]
+        t = feature_store[g, attr.attr_name, None]
+        row_bytes = torch.empty((), dtype=t.dtype).element_size()
+        for d in tuple(t.shape)[1:]:
+            row_bytes *= int(d)
+        views[g, attr.attr_name] = None if index.numel() * row_bytes > _GROUP_FETCH_BYTES else torch.split(t[index], sizes)
+    return views
+
+
+def build_hetero_data(feature_store, s: HeteroSamplerOutput, group_views=None, j: int = 0) -> HeteroData:
+    """HeteroSamplerOutput -> HeteroData with every stored attribute joined (sampler.py:96-165).  ``group_views`` (from
+    _group_attribute_views) + the batch's index in its call group replace the per-batch gathers."""
     data = HeteroData()
     for et in s.row:
         data[et].edge_index = torch.stack([s.row[et], s.col[et]], dim=0)
@@ -426,11 +459,12 @@ def build_hetero_data(feature_store, s: HeteroSamplerOutput) -> HeteroData:
         data[nt].num_nodes = ids.size(0)
     for attr in feature_store.get_all_tensor_attrs():
         g = attr.group_name
+        v = group_views.get((g, attr.attr_name)) if group_views is not None else None
         if isinstance(g, tuple):
             if g in s.edge:
-                data[g][attr.attr_name] = feature_store[g, attr.attr_name, None][s.edge[g]]
+                data[g][attr.attr_name] = v[j] if v is not None else feature_store[g, attr.attr_name, None][s.edge[g]]
         elif g in s.node:
-            data[g][attr.attr_name] = feature_store[g, attr.attr_name, None][s.node[g]]
+            data[g][attr.attr_name] = v[j] if v is not None else feature_store[g, attr.attr_name, None][s.node[g]]
     data.set_value_dict("batch", s.batch)
     data.set_value_dict("num_sampled_nodes", s.num_sampled_nodes)
     data.set_value_dict("num_sampled_edges", s.num_sampled_edges)
@@ -450,13 +484,58 @@ class SampleIterator:
         self.__output_iter = output_iter
 
     def __next_hetero(self, s):
-        return build_hetero_data(self.__feature_store, s)
+        group = s.metadata[2] if s.metadata is not None and len(s.metadata) > 2 else None
+        if group is None:
+            return build_hetero_data(self.__feature_store, s)
+        cache = getattr(self, "_SampleIterator__hetero_cache", None)
+        if cache is None or cache[0] is not group[0]:
+            cache = (group[0], _group_attribute_views(self.__feature_store, group[0]))
+            self.__hetero_cache = cache
+        return build_hetero_data(self.__feature_store, s, cache[1], group[1])
+
+    # one feature fetch per CALL GROUP instead of one per mini-batch: the batches of a group are consecutive segments of
+    # one node list / one edge list, so every stored attribute is gathered once and handed out as per-batch views
+    # (same values as filter_store; bounded so that a huge group does not hold gigabytes of features at once)
+    _GROUP_FETCH_BYTES = 4 << 30
+
+    def __filter_from_group(self, ctx, j, s) -> Data:
+        cache = getattr(self, "_SampleIterator__group_cache", None)
+        if cache is None or cache[0] is not ctx:
+            views = {}
+            for attr in self.__feature_store.get_all_tensor_attrs():
+                is_edge = isinstance(attr.group_name, tuple)
+                index, sizes = (ctx["edges"], ctx["edge_sizes"]) if is_edge else (ctx["nodes"], ctx["node_sizes"])
+                t = self.__feature_store[attr.group_name, attr.attr_name, None]
+                row_bytes = 1
+                for d in tuple(t.shape)[1:]:
+                    row_bytes *= int(d)
+                row_bytes *= torch.empty((), dtype=t.dtype).element_size()
+                if index.numel() * row_bytes > self._GROUP_FETCH_BYTES:
+                    views[attr.group_name, attr.attr_name] = None       # too big for one fetch: per batch below
+                else:
+                    views[attr.group_name, attr.attr_name] = torch.split(t[index], sizes)
+            cache = (ctx, views)
+            self.__group_cache = cache
+        data = Data()
+        data.edge_index = torch.stack([s.row, s.col], dim=0)
+        for attr in self.__feature_store.get_all_tensor_attrs():
+            is_edge = isinstance(attr.group_name, tuple)
+            v = cache[1][attr.group_name, attr.attr_name]
+            data[attr.attr_name] = (v[j] if v is not None else
+                                    self.__feature_store[attr.group_name, attr.attr_name, None][s.edge if is_edge else s.node])
+            if not is_edge:
+                data.num_nodes = s.node.size(0)
+        return data
 
     def __next__(self):
         s = next(self.__output_iter)
         if isinstance(s, HeteroSamplerOutput):
             return self.__next_hetero(s)
-        data = filter_store(self.__feature_store, self.__graph_store, s.node, s.row, s.col, s.edge)
+        group = s.metadata[2] if s.metadata is not None and len(s.metadata) > 2 else None
+        if group is not None:
+            data = self.__filter_from_group(group[0], group[1], s)
+        else:
+            data = filter_store(self.__feature_store, self.__graph_store, s.node, s.row, s.col, s.edge)
         if "n_id" not in data:
             data.n_id = s.node
         if s.edge is not None and "e_id" not in data:

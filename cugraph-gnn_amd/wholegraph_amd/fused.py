@@ -312,6 +312,10 @@ class PygWalkResult:
         sizes_b = [offs[b + 1] - offs[b] for b in range(G)]
         node_v = torch.split(self.nodes[nseg[0]:nseg[G]], [nseg[b + 1] - nseg[b] for b in range(G)])
         row_v, col_v, edge_v = (torch.split(t[:offs[G]], sizes_b) for t in (rows, cols, edges))
+        # the call group as a whole, for consumers that fetch per-node / per-edge attributes once per group: every
+        # per-batch tensor above is a view into these, batch b = [offsets[b], offsets[b+1])
+        self.group_context = dict(nodes=self.nodes[nseg[0]:nseg[G]], node_sizes=[nseg[b + 1] - nseg[b] for b in range(G)],
+                                  edges=edges[:offs[G]], edge_sizes=sizes_b)
         out = []
         for b in range(G):
             nn = [fseg[0][b + 1] - fseg[0][b]] + [fseg[k + 1][b + 1] - fseg[k + 1][b] for k in range(hops)]
@@ -588,6 +592,12 @@ class HeteroPygWalk:
             return torch.split(t[seg[0]:seg[G]], [seg[b + 1] - seg[b] for b in range(G)])
         node_v = {t: (views(state[t]["nodes"], nseg[t]) if state[t]["cap"] > 0 else (empty,) * G) for t in self.ntypes}
         edge_v = {et: [views(merged[et][i], offs[et]) for i in range(3)] for et in self.etypes}
+        # the call group as a whole (see PygWalkResult.finalize_batches): per type the concatenated ids + per-batch sizes
+        rec["group_context"] = dict(
+            nodes={t: ((state[t]["nodes"][nseg[t][0]:nseg[t][G]] if state[t]["cap"] > 0 else empty),
+                       [nseg[t][b + 1] - nseg[t][b] for b in range(G)] if state[t]["cap"] > 0 else [0] * G)
+                   for t in self.ntypes},
+            edges={et: (merged[et][2][:offs[et][G]], [offs[et][b + 1] - offs[et][b] for b in range(G)]) for et in self.etypes})
         out = []
         for b in range(G):
             num_nodes = {t: [sizes[0][t][b]] + [sizes[h + 1][t][b] - sizes[h][t][b] for h in range(self.hops)]

@@ -722,3 +722,65 @@ def test_biased_call_group_walk_equals_single_batch_path(hiplib, G, wdtype):
                                     num_vertices=V), fanout=[8, 5], biased=True, local_seeds_per_call=G * B)
     list(smp0.sample_batches(seeds[:B], B, 77))
     assert smp0._positive_weights is False and not smp0._walks
+
+
+def test_call_group_feature_fetch_equals_per_batch_fetch(hiplib):
+    """Node and edge attributes are gathered once per call group and handed out as views: every batch must carry exactly
+    what the one-batch-at-a-time loader (filter_store per batch) gives it."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    torch.manual_seed(5)
+    n, m, B = 5000, 60000, 64
+    ei = torch.stack([torch.randint(0, n, (m,)), torch.randint(0, n, (m,))])
+    gs, fs = GraphStore(), FeatureStore()
+    gs[("n", "e", "n"), "coo", False, (n, n)] = ei
+    fs["n", "x", None] = torch.randn(n, 33)
+    fs["n", "y", None] = torch.arange(n)
+    fs[("n", "e", "n"), "w", None] = torch.randn(m, 3)
+    seeds = torch.randperm(n)[:B * 11 + 7].cuda()          # 11 full batches + a ragged one
+    def run(per_call):
+        return list(NeighborLoader((fs, gs), [6, 4], input_nodes=seeds, batch_size=B, local_seeds_per_call=per_call,
+                                   shuffle=False, random_state=3))
+    one, grouped = run(B), run(B * 4)
+    assert len(one) == len(grouped) == 12
+    for a, b in zip(one, grouped):
+        for key in ("x", "y", "w", "edge_index", "n_id", "e_id", "batch", "input_id"):
+            assert torch.equal(getattr(a, key), getattr(b, key)), key
+        assert a.num_nodes == b.num_nodes and a.batch_size == b.batch_size
+        assert a.num_sampled_nodes.tolist() == b.num_sampled_nodes.tolist()
+        assert torch.equal(b.x, fs["n", "x", None][b.n_id]) and torch.equal(b.w, fs[("n", "e", "n"), "w", None][b.e_id])
+
+
+def test_hetero_call_group_feature_fetch_equals_per_batch_fetch(hiplib):
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    torch.manual_seed(9)
+    n_p, n_a, B = 3000, 1200, 32
+    cites = torch.stack([torch.randint(0, n_p, (20000,)), torch.randint(0, n_p, (20000,))])
+    writes = torch.stack([torch.randint(0, n_a, (9000,)), torch.randint(0, n_p, (9000,))])
+    gs, fs = GraphStore(), FeatureStore()
+    gs[("paper", "cites", "paper"), "coo", False, (n_p, n_p)] = cites
+    gs[("author", "writes", "paper"), "coo", False, (n_a, n_p)] = writes
+    gs[("paper", "rev_writes", "author"), "coo", False, (n_p, n_a)] = writes.flip(0)
+    fs["paper", "x", None] = torch.randn(n_p, 17)
+    fs["author", "x", None] = torch.randn(n_a, 5)
+    fs["paper", "year", None] = torch.arange(n_p)
+    fs[("author", "writes", "paper"), "w", None] = torch.randn(9000, 2)
+    seeds = torch.randperm(n_p)[:B * 7 + 3].cuda()
+    fan = {("paper", "cites", "paper"): [4, 3], ("author", "writes", "paper"): [3, 2], ("paper", "rev_writes", "author"): [2, 2]}
+    def run(per_call):
+        return list(NeighborLoader((fs, gs), fan, input_nodes=("paper", seeds), batch_size=B, local_seeds_per_call=per_call,
+                                   shuffle=False, random_state=11))
+    one, grouped = run(B), run(B * 4)
+    assert len(one) == len(grouped) == 8
+    for a, b in zip(one, grouped):
+        for nt in ("paper", "author"):
+            assert torch.equal(a[nt].n_id, b[nt].n_id) and torch.equal(a[nt].x, b[nt].x)
+            assert torch.equal(b[nt].x, fs[nt, "x", None][b[nt].n_id])
+        assert torch.equal(a["paper"].year, b["paper"].year)
+        for et in fan:
+            assert torch.equal(a[et].edge_index, b[et].edge_index) and torch.equal(a[et].e_id, b[et].e_id)
+        et = ("author", "writes", "paper")
+        assert torch.equal(a[et].w, b[et].w) and torch.equal(b[et].w, fs[et, "w", None][b[et].e_id])
