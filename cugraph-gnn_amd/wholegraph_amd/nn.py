@@ -106,17 +106,28 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     return out
 
 
+def _csr_transpose(row_ptr, col, n_src, want_perm=False, want_dst=False, want_col_t=False):
+    """wgamd_csr_transpose_i32: (row_ptr_t, edge_perm | None, edge_dst | None, col_t | None)."""
+    _check_csr(row_ptr, col)
+    n_dst, E, dev = row_ptr.shape[0] - 1, col.shape[0], col.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    row_ptr_t = torch.empty(n_src + 1, **i32)
+    perm = torch.empty(E, **i32) if want_perm else None
+    dst = torch.empty(E, **i32) if want_dst else None
+    col_t = torch.empty(E, **i32) if want_col_t else None
+    need = L.lib().wgamd_csr_transpose_workspace_bytes(E, n_src)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    L.check(L.lib().wgamd_csr_transpose_i32(row_ptr.data_ptr(), col.data_ptr(), n_dst, E, n_src, row_ptr_t.data_ptr(),
+                                            ptr(perm), ptr(dst), ptr(col_t), ws.data_ptr(), need, get_stream()),
+            "wgamd_csr_transpose_i32")
+    return row_ptr_t, perm, dst, col_t
+
+
 def csr_transpose(row_ptr, col, n_src):
-    """Destination-major hop CSR -> source-major CSR (rows = sources, entries = destination rows, in edge order:
-    a stable radix sort, so the gradient sums below are run-to-run deterministic)."""
-    n_dst = row_ptr.shape[0] - 1
-    deg = row_ptr[1:] - row_ptr[:-1]
-    dst_of_edge = torch.repeat_interleave(torch.arange(n_dst, dtype=torch.int32, device=col.device), deg.long(),
-                                          output_size=col.shape[0])
-    order = torch.sort(col, stable=True).indices
-    col_t = dst_of_edge[order].contiguous()
-    row_ptr_t = torch.zeros(n_src + 1, dtype=torch.int32, device=col.device)
-    row_ptr_t[1:] = torch.cumsum(torch.bincount(col, minlength=n_src), 0)
+    """Destination-major hop CSR -> source-major CSR (rows = sources, entries = destination rows, in edge order: a
+    stable radix sort over the bits a source row needs, so the gradient sums below are run-to-run deterministic)."""
+    row_ptr_t, _, _, col_t = _csr_transpose(row_ptr, col, n_src, want_col_t=True)
     return row_ptr_t, col_t
 
 
@@ -185,11 +196,7 @@ def gat_backward(row_ptr, col, x, a_src, a_dst, alpha, grad_out, heads, negative
     n_rows, n_src, E = row_ptr.shape[0] - 1, x.shape[0], col.shape[0]
     C = x.shape[1] // heads
     g = grad_out.contiguous()
-    deg = (row_ptr[1:] - row_ptr[:-1]).long()
-    edge_dst = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int32, device=col.device), deg, output_size=E)
-    edge_perm = torch.sort(col, stable=True).indices.to(torch.int32).contiguous()
-    row_ptr_t = torch.zeros(n_src + 1, dtype=torch.int32, device=col.device)
-    row_ptr_t[1:] = torch.cumsum(torch.bincount(col, minlength=n_src), 0)
+    row_ptr_t, edge_perm, edge_dst, _ = _csr_transpose(row_ptr, col, n_src, want_perm=True, want_dst=True)
     de = torch.empty((E, heads), dtype=torch.float32, device=x.device)
     gx = torch.empty_like(x)
     ga_src, ga_dst = torch.empty_like(a_src), torch.empty_like(a_dst)

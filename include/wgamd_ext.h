@@ -96,6 +96,28 @@ wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr,
                                                 int64_t ldx,
                                                 void* stream);
 
+/* Transpose of a sampled-hop CSR (rows = destinations, col = source rows in [0, n_src)) for the atomic-free backward
+ * passes: the edges sorted by source, STABLE (edge order inside a source = edge order of the hop, so gradient sums are
+ * reproducible).  One radix sort of (source, edge) pairs over ceil(log2 n_src) bits + two small kernels.
+ *   row_ptr_t [n_src + 1]  : CSR offsets over the sources
+ *   edge_perm [n_edges]    : edge ids in source-major order                      (may be NULL)
+ *   edge_dst  [n_edges]    : destination row of every ORIGINAL edge id           (may be NULL)
+ *   col_t     [n_edges]    : destination row of the k-th source-major edge = edge_dst[edge_perm[k]]   (may be NULL)
+ * workspace: wgamd_csr_transpose_workspace_bytes(n_edges, n_src) bytes of device scratch. */
+size_t wgamd_csr_transpose_workspace_bytes(int64_t n_edges, int64_t n_src);
+wholememory_error_code_t wgamd_csr_transpose_i32(const int* row_ptr,
+                                                 const int* col,
+                                                 int64_t n_rows,
+                                                 int64_t n_edges,
+                                                 int64_t n_src,
+                                                 int* row_ptr_t,
+                                                 int* edge_perm,
+                                                 int* edge_dst,
+                                                 int* col_t,
+                                                 void* workspace,
+                                                 size_t workspace_bytes,
+                                                 void* stream);
+
 /* GATConv message passing (edge-softmax SDDMM + weighted SpMM), H heads x C channels:
  *   s_e      = leaky_relu(a_src[col[e], h] + a_dst[i, h], negative_slope)
  *   alpha_e  = softmax over the edges e of row i (per head)

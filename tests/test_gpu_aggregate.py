@@ -256,3 +256,29 @@ def test_gat_backward_kernels_match_autograd_of_dense_formula(hiplib, H, C):
     for a, b in zip(got, (x2.grad, s2.grad, d2.grad)):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
     assert not nn.gat_backward_supported(2, 5)       # falls back to the torch-op backward (covered by the layer test)
+
+
+@pytest.mark.parametrize("n_dst,n_src,max_deg", [(1000, 5000, 12), (1, 1, 1), (257, 3, 40), (5000, 100000, 3), (64, 10, 0)])
+def test_csr_transpose_matches_stable_sort(hiplib, n_dst, n_src, max_deg):
+    """wgamd_csr_transpose_i32 (one radix sort over the bits a source row needs) against the torch formulation it replaces:
+    stable sort of the sources, bincount + cumsum, repeat_interleave.  Sources without edges, rows without edges, no edges."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator().manual_seed(n_dst * 7 + n_src)
+    deg = torch.randint(0, max_deg + 1, (n_dst,), generator=g)
+    row_ptr = torch.zeros(n_dst + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(deg, 0)
+    E = int(row_ptr[-1])
+    col = torch.randint(0, n_src, (E,), generator=g).int()
+    rp, cc = row_ptr.cuda(), col.cuda()
+    row_ptr_t, perm, dst, col_t = nn._csr_transpose(rp, cc, n_src, want_perm=True, want_dst=True, want_col_t=True)
+    want_perm = torch.sort(col, stable=True).indices
+    want_dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+    want_rpt = torch.zeros(n_src + 1, dtype=torch.int64)
+    want_rpt[1:] = torch.cumsum(torch.bincount(col.long(), minlength=n_src), 0)
+    assert torch.equal(row_ptr_t.cpu().long(), want_rpt)
+    assert torch.equal(perm.cpu().long(), want_perm)
+    assert torch.equal(dst.cpu().long(), want_dst)
+    assert torch.equal(col_t.cpu().long(), want_dst[want_perm])
+    rpt2, ct2 = nn.csr_transpose(rp, cc, n_src)
+    assert torch.equal(rpt2, row_ptr_t) and torch.equal(ct2, col_t)
