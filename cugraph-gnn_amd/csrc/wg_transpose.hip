@@ -51,6 +51,23 @@ __global__ void __launch_bounds__(256) edge_rows_kernel(const int* __restrict__ 
   if (col_t) col_t[k] = row_of_edge(row_ptr, n_rows, perm[k]);
 }
 
+// COO -> CSR helpers: 32-bit sort keys from 64-bit destination ids, and the sources in destination-major order
+__global__ void __launch_bounds__(256) coo_keys_kernel(const int64_t* __restrict__ dst, int64_t n, unsigned* __restrict__ keys,
+                                                       int* __restrict__ iota)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = (unsigned)dst[i];
+  iota[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(256) permute_sources_kernel(const int64_t* __restrict__ src, const int* __restrict__ perm,
+                                                              int64_t n, int* __restrict__ col)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) col[i] = (int)src[perm[i]];
+}
+
 unsigned key_bits(int64_t n_src)
 {
   unsigned bits = 1;
@@ -114,5 +131,45 @@ extern "C" wholememory_error_code_t wgamd_csr_transpose_i32(const int* row_ptr, 
       edge_rows_kernel<<<grid, 256, 0, st>>>(row_ptr, (int)n_rows, n_edges, perm, edge_dst, col_t);
       WG_HIP_CHECK(hipGetLastError());
     }
+  });
+}
+
+extern "C" size_t wgamd_coo_to_csr_workspace_bytes(int64_t n_edges, int64_t n_dst)
+{
+  using namespace wgamd;
+  if (n_edges < 0 || n_dst < 0) return 0;
+  return 4 * pad(sizeof(int) * (size_t)n_edges) + pad(sort_bytes(n_edges, n_dst)) + 256;
+}
+
+extern "C" wholememory_error_code_t wgamd_coo_to_csr_i64(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_dst,
+                                                         int* row_ptr, int* col, int* edge_perm, void* workspace,
+                                                         size_t workspace_bytes, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_coo_to_csr_i64", [&] {
+    WG_REQUIRE_INPUT(n_edges >= 0 && n_dst >= 0 && n_edges < ((int64_t)1 << 31) && n_dst < ((int64_t)1 << 31), "bad sizes");
+    WG_REQUIRE_INPUT(row_ptr && (n_edges == 0 || (src && dst && col)), "null pointer");
+    WG_REQUIRE_INPUT(workspace_bytes >= wgamd_coo_to_csr_workspace_bytes(n_edges, n_dst) && (workspace || n_edges == 0),
+                     "workspace too small");
+    auto st = static_cast<hipStream_t>(stream);
+    if (n_edges == 0) {
+      WG_HIP_CHECK(hipMemsetAsync(row_ptr, 0, sizeof(int) * (size_t)(n_dst + 1), st));
+      return;
+    }
+    char* ws        = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    const size_t nb = pad(sizeof(int) * (size_t)n_edges);
+    auto* keys_in   = reinterpret_cast<unsigned*>(ws);
+    auto* keys_out  = reinterpret_cast<unsigned*>(ws + nb);
+    auto* iota      = reinterpret_cast<int*>(ws + 2 * nb);
+    int* perm       = edge_perm ? edge_perm : reinterpret_cast<int*>(ws + 3 * nb);
+    void* tmp       = ws + 4 * nb;
+    size_t tmp_b    = sort_bytes(n_edges, n_dst);
+    const int grid  = (int)((n_edges + 255) / 256);
+    coo_keys_kernel<<<grid, 256, 0, st>>>(dst, n_edges, keys_in, iota);
+    WG_HIP_CHECK(hipGetLastError());
+    WG_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_b, keys_in, keys_out, iota, perm, (size_t)n_edges, 0u, key_bits(n_dst), st));
+    run_offsets_kernel<<<(int)((n_edges + 1 + 255) / 256), 256, 0, st>>>(keys_out, n_edges, n_dst, row_ptr);
+    permute_sources_kernel<<<grid, 256, 0, st>>>(src, perm, n_edges, col);
+    WG_HIP_CHECK(hipGetLastError());
   });
 }

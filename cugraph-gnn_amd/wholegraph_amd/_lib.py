@@ -187,6 +187,9 @@ SYMBOLS = {
     "wgamd_csr_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "wgamd_csr_transpose_i32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wgamd_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "wgamd_coo_to_csr_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
     "wgamd_spmm_csr_f32":(c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,
                                    c_int, c_void_p, c_int64, c_void_p]),
     "wgamd_sage_aggregate_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int,

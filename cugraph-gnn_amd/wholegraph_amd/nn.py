@@ -245,10 +245,22 @@ class _GatCsr(torch.autograd.Function):
 
 
 def _to_csr(edge_index, n_dst):
-    """edge_index [2,E] (row 0 = source j, row 1 = destination i; PyG) -> destination-major CSR."""
-    dst = edge_index[1]
+    """edge_index [2,E] (row 0 = source j, row 1 = destination i; PyG) -> destination-major CSR (edge order kept inside a
+    destination).  int64 ids on the device go through ``wgamd_coo_to_csr_i64`` (one radix sort over the bits a destination
+    id needs); anything else through the torch formulation of the same."""
+    src, dst = edge_index[0], edge_index[1]
+    if edge_index.dtype == torch.int64 and edge_index.is_cuda:
+        src, dst = src.contiguous(), dst.contiguous()
+        E, dev = dst.shape[0], dst.device
+        row_ptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(E, dtype=torch.int32, device=dev)
+        need = L.lib().wgamd_coo_to_csr_workspace_bytes(E, n_dst)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        L.check(L.lib().wgamd_coo_to_csr_i64(src.data_ptr(), dst.data_ptr(), E, n_dst, row_ptr.data_ptr(), col.data_ptr(), None,
+                                             ws.data_ptr(), need, get_stream()), "wgamd_coo_to_csr_i64")
+        return row_ptr, col
     order = torch.sort(dst, stable=True).indices
-    col = edge_index[0][order].to(torch.int32).contiguous()
+    col = src[order].to(torch.int32).contiguous()
     counts = torch.bincount(dst, minlength=n_dst)
     row_ptr = torch.zeros(n_dst + 1, dtype=torch.int32, device=dst.device)
     row_ptr[1:] = torch.cumsum(counts, 0)

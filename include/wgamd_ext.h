@@ -118,6 +118,21 @@ wholememory_error_code_t wgamd_csr_transpose_i32(const int* row_ptr,
                                                  size_t workspace_bytes,
                                                  void* stream);
 
+/* PyG COO edge_index (src, dst int64; dst ids in [0, n_dst)) -> destination-major int32 CSR for the aggregation kernels:
+ * stable radix sort of (dst, edge) over ceil(log2 n_dst) bits, row_ptr [n_dst + 1] from the run boundaries,
+ * col[k] = src of the k-th destination-major edge, edge_perm (may be NULL) = the edge ids in that order. */
+size_t wgamd_coo_to_csr_workspace_bytes(int64_t n_edges, int64_t n_dst);
+wholememory_error_code_t wgamd_coo_to_csr_i64(const int64_t* src,
+                                              const int64_t* dst,
+                                              int64_t n_edges,
+                                              int64_t n_dst,
+                                              int* row_ptr,
+                                              int* col,
+                                              int* edge_perm,
+                                              void* workspace,
+                                              size_t workspace_bytes,
+                                              void* stream);
+
 /* GATConv message passing (edge-softmax SDDMM + weighted SpMM), H heads x C channels:
  *   s_e      = leaky_relu(a_src[col[e], h] + a_dst[i, h], negative_slope)
  *   alpha_e  = softmax over the edges e of row i (per head)

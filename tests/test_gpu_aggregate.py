@@ -282,3 +282,15 @@ def test_csr_transpose_matches_stable_sort(hiplib, n_dst, n_src, max_deg):
     assert torch.equal(col_t.cpu().long(), want_dst[want_perm])
     rpt2, ct2 = nn.csr_transpose(rp, cc, n_src)
     assert torch.equal(rpt2, row_ptr_t) and torch.equal(ct2, col_t)
+
+
+@pytest.mark.parametrize("n_dst,n_src,E", [(1000, 4000, 20000), (1, 5, 9), (300, 7, 0), (70000, 70000, 400000)])
+def test_coo_to_csr_matches_torch_formulation(hiplib, n_dst, n_src, E):
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator().manual_seed(E + n_dst)
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    rp, cc = nn._to_csr(ei.cuda(), n_dst)
+    rp_ref, cc_ref = nn._to_csr(ei, n_dst)          # CPU tensors take the torch route
+    assert rp.dtype == torch.int32 and cc.dtype == torch.int32
+    assert torch.equal(rp.cpu(), rp_ref) and torch.equal(cc.cpu(), cc_ref)
