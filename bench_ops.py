@@ -265,6 +265,27 @@ def main():
                      "note": "wall time of the Python iteration: sampling + renumbering in call groups, per-batch feature "
                              "fetch and Data construction"})
         print(rows[-1], flush=True)
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    sel = torch.randint(0, E, (512 * 100,), generator=g, device=dev)
+    eli = gs_.get_edge_index(("n", "e", "n"), "coo")[:, sel]
+    for groups in (False, True):
+        loader = LinkNeighborLoader((fs_, gs_), num_neighbors=[25, 10], edge_label_index=eli, batch_size=512,
+                                    neg_sampling=("binary", 1.0), shuffle=False, call_groups=groups)
+        it = iter(loader)
+        next(it)
+        torch.cuda.synchronize()
+        t0, n_e, n_b = time.perf_counter(), 0, 0
+        for batch in it:
+            n_e += int(batch.edge_index.shape[1])
+            n_b += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows.append({"op": "LinkNeighborLoader batch 512 seed edges + 512 binary negatives, fan-out [25,10], %s"
+                           % ("call groups of 16" if groups else "one batch per call"),
+                     "reference": "cugraph_pyg.loader.LinkNeighborLoader (f1)", "ms_per_batch": round(dt / n_b * 1e3, 4),
+                     "edges_per_s": round(n_e / dt, 1), "edges_per_batch": round(n_e / n_b, 1),
+                     "note": "negatives + row-wise endpoint de-duplication + walk over ragged seed lists + feature fetch"})
+        print(rows[-1], flush=True)
     del gs_, fs_
     if args.hetero:
         rows.append(hetero_section(dev))

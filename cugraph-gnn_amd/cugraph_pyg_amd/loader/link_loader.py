@@ -26,7 +26,7 @@ from wholegraph_amd import graph_ops
 
 from ..data.graph_store import GraphStore
 from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, SampleIterator, build_hetero_data, filter_store,
-                               hetero_neighbor_sample, neighbor_sample)
+                               filter_store_from_group, group_attribute_views, hetero_neighbor_sample, neighbor_sample)
 from .._compat import Data, HeteroSamplerOutput
 from .node_loader import generate_seed
 
@@ -77,6 +77,32 @@ def _draw_negatives(n_neg, num_src, num_dst, gen, dev, neg_time=None, src_time=N
     return src, dst
 
 
+def _batched_first_unique(ends: torch.Tensor, n_ids: int):
+    """Row-wise first-appearance de-duplication of ``ends`` [G, S] (ids < n_ids), for a whole call group at once.
+    -> (unique ids of all rows back to back, padded with zeros to G*S; int32 offsets [G+1]; int32 row of every live
+    entry, padded; ``local`` [G, S] = position of every element in its row's unique list) — per row exactly what
+    ``graph_ops.append_unique`` with an empty target list returns."""
+    G, S = ends.shape
+    dev = ends.device
+    rows = torch.arange(G, device=dev).view(G, 1)
+    uk, inv = torch.unique((rows * n_ids + ends).view(-1), return_inverse=True)       # sorted by (row, id)
+    pos = torch.arange(G * S, device=dev)
+    first = torch.full((uk.numel(),), G * S, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, pos, reduce="amin")
+    order = torch.argsort(first)                       # positions are row-major, so the rows stay grouped
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel(), device=dev)
+    uk = uk[order]
+    row_of = torch.div(uk, n_ids, rounding_mode="floor")
+    seg = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    seg[1:] = torch.cumsum(torch.bincount(row_of, minlength=G), 0)
+    uniq = torch.zeros(G * S, dtype=torch.int64, device=dev)
+    uniq[:uk.numel()] = uk - row_of * n_ids
+    batch = torch.zeros(G * S, dtype=torch.int32, device=dev)
+    batch[:uk.numel()] = row_of.to(torch.int32)
+    local = (rank[inv].view(G, S) - seg[:-1].view(G, 1))
+    return uniq, seg.to(torch.int32).contiguous(), batch, local
+
+
 def _parse_neg_sampling(neg_sampling) -> Tuple[Optional[str], float]:
     if neg_sampling is None:
         return None, 0.0
@@ -95,10 +121,11 @@ class LinkLoader:
                  edge_label_time=None, neg_sampling=None, neg_sampling_ratio=None, transform=None,
                  transform_sampler_output=None, filter_per_worker=None, custom_cls=None, input_id=None,
                  batch_size: int = 1, shuffle: bool = False, drop_last: bool = False,
-                 random_state: Optional[int] = None, time_attr: Optional[str] = None, **kwargs):
+                 random_state: Optional[int] = None, time_attr: Optional[str] = None, call_groups: bool = True, **kwargs):
         if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
         self.__time_attr = time_attr
+        self.__call_groups = bool(call_groups)   # False: one batch at a time through the C-ABI ops (tuning / tests)
         if not isinstance(link_sampler, (NeighborSampler, HeteroNeighborSampler)):
             raise NotImplementedError("Must provide a cuGraph sampler")
         if neg_sampling_ratio is not None:
@@ -182,7 +209,16 @@ class LinkLoader:
             yield from self.__hetero_batches(perm, seed)
             return
         graph = self.__sampler.graph
-        for b, start in enumerate(range(0, perm.numel(), self.__batch_size)):
+        bs = self.__batch_size
+        n_full = perm.numel() // bs if (self.__call_groups and self.__sampler.call_groups_ok()) else 0
+        per_call = getattr(self.__sampler, "local_seeds_per_call", None) or 16 * bs
+        G = max(1, per_call // bs)
+        b0 = 0
+        while b0 < n_full:   # CALL GROUPS of full batches: one launch sequence per hop for g mini-batches
+            g = min(G, n_full - b0)
+            yield from self.__group(perm, seed, b0, g)
+            b0 += g
+        for b, start in enumerate(range(n_full * bs, perm.numel(), bs), start=n_full):
             ix = perm[start:start + self.__batch_size]
             src, dst = self.__eli[0, ix], self.__eli[1, ix]
             n_pos = ix.numel()
@@ -210,6 +246,46 @@ class LinkLoader:
                 pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
                 data.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
                 if self.__mode == "triplet":   # PyG's triplet view of the same batch
+                    data.src_index, data.dst_pos_index = inverse[:n_pos], inverse[half:half + n_pos]
+                    neg = inverse[half + n_pos:]
+                    data.dst_neg_index = neg.view(-1, n_pos).t() if n_neg % n_pos == 0 and n_neg > n_pos else neg
+            elif self.__label is not None:
+                data.edge_label = self.__label[ix]
+            yield data
+
+    def __group(self, perm, seed, b0, g):
+        """Batches b0 .. b0+g-1 (all full) of a homogeneous graph as one call group: negatives per batch with the batch's
+        own generator (same draws as the one-batch path), endpoints de-duplicated row-wise for the whole group, ONE walk
+        over the ragged seed lists.  Yields the same ``Data`` objects as the loop below, batch by batch."""
+        fs, gs = self.__data
+        dev, bs = self.__eli.device, self.__batch_size
+        ixs, ends, n_negs = [], [], []
+        for j in range(g):
+            ix = perm[(b0 + j) * bs:(b0 + j + 1) * bs]
+            gen = torch.Generator(device=dev).manual_seed((seed + b0 + j) & 0x7FFFFFFFFFFFFFFF)
+            src_all, dst_all, n_neg, _ = self.__with_negatives(self.__eli[0, ix], self.__eli[1, ix], ix, gen)
+            ixs.append(ix)
+            ends.append(torch.cat([src_all, dst_all]))
+            n_negs.append(n_neg)
+        ends = torch.stack(ends)                                    # [g, 2 * (bs + n_neg)]: every batch has the same n_neg
+        S = ends.shape[1]
+        uniq, seg, batch, local = _batched_first_unique(ends, self.__num_nodes)
+        outs, ctx = self.__sampler.sample_seed_lists(uniq, seg, batch, S, g, seed + b0)
+        views = group_attribute_views(fs, ctx)                      # every stored attribute: one fetch for the group
+        for j, (node, row, col, edge, nn, ne) in enumerate(outs):
+            ix, n_neg, n_pos = ixs[j], n_negs[j], bs
+            data = filter_store_from_group(fs, views, j, node, row, col, edge)
+            data.n_id, data.e_id = node, edge
+            data.num_sampled_nodes, data.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)
+            data.input_id = self.__input_id[ix]
+            data.batch_size = n_pos
+            inverse = local[j]
+            half = n_pos + n_neg
+            data.edge_label_index = torch.stack([inverse[:half], inverse[half:]])
+            if self.__mode is not None:
+                pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
+                data.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
+                if self.__mode == "triplet":
                     data.src_index, data.dst_pos_index = inverse[:n_pos], inverse[half:half + n_pos]
                     neg = inverse[half + n_pos:]
                     data.dst_neg_index = neg.view(-1, n_pos).t() if n_neg % n_pos == 0 and n_neg > n_pos else neg
@@ -300,7 +376,7 @@ class LinkNeighborLoader(LinkLoader):
         if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
             sampler = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
                                       with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
-                                      temporal_comparison=temporal_comparison)
+                                      temporal_comparison=temporal_comparison, local_seeds_per_call=local_seeds_per_call)
         else:
             etypes = [a.edge_type for a in graph_store.get_all_edge_attrs()]
             if not isinstance(num_neighbors, dict):

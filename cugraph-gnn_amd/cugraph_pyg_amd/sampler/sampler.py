@@ -331,6 +331,25 @@ class NeighborSampler:
                                              csr_weight=self.graph.weight if self.biased else None)
         return self._walks[key]
 
+    def call_groups_ok(self) -> bool:
+        """Can this configuration run on the no-host-sync call-group kernels (see ``sample_batches``)?"""
+        if self.biased and self._positive_weights is None:
+            self._positive_weights = bool((self.graph.weight > 0).all())
+        biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for f in self.fanout))
+        return biased_ok and (not self.disjoint) and (not self.temporal) and all(f > 0 for f in self.fanout)
+
+    def sample_seed_lists(self, seeds: torch.Tensor, seed_seg: torch.Tensor, seed_batch: torch.Tensor, max_seeds: int,
+                          n_batches: int, random_state: int):
+        """One call group over RAGGED per-batch seed lists (``seeds`` = the lists back to back, padded to
+        ``n_batches * max_seeds``; ``seed_seg`` / ``seed_batch`` as in ``PygNoSyncWalk.run``): batch j gets exactly
+        ``neighbor_sample(graph, its list, fanout, random_state + j)``.  Returns (list of per-batch tuples, group context
+        for ``group_attribute_views``)."""
+        walk = self._call_group_walk(max_seeds, n_batches)
+        rs = [[hop_seed(random_state + j, k) for j in range(n_batches)] for k in range(len(self.fanout))]
+        res = walk.run(seeds.to(self.graph.col.dtype).contiguous(), rs, seed_seg, seed_batch)
+        outs = res.finalize_batches(self.graph.edge_id)
+        return outs, res.group_context
+
     def sample_batches(self, seeds: torch.Tensor, batch_size: int, random_state: int, seed_time=None) -> Iterator:
         """Yields ``(batch index, (node, row, col, edge, num_sampled_nodes, num_sampled_edges))``.
 
@@ -447,6 +466,38 @@ def _group_attribute_views(feature_store, ctx):
     return views
 
 
+def group_attribute_views(feature_store, ctx):
+    """One feature fetch per CALL GROUP instead of one per mini-batch (homogeneous graphs): the batches of a group are
+    consecutive segments of one node list / one edge list (``ctx`` of PygWalkResult.finalize_batches), so every stored
+    attribute is gathered once and split into per-batch views; ``None`` for an attribute whose group fetch would exceed
+    _GROUP_FETCH_BYTES (fetched per batch then)."""
+    views = {}
+    for attr in feature_store.get_all_tensor_attrs():
+        is_edge = isinstance(attr.group_name, tuple)
+        index, sizes = (ctx["edges"], ctx["edge_sizes"]) if is_edge else (ctx["nodes"], ctx["node_sizes"])
+        t = feature_store[attr.group_name, attr.attr_name, None]
+        row_bytes = torch.empty((), dtype=t.dtype).element_size()
+        for d in tuple(t.shape)[1:]:
+            row_bytes *= int(d)
+        views[attr.group_name, attr.attr_name] = (None if index.numel() * row_bytes > _GROUP_FETCH_BYTES
+                                                  else torch.split(t[index], sizes))
+    return views
+
+
+def filter_store_from_group(feature_store, views, j, node, row, col, edge) -> Data:
+    """``filter_store`` for batch j of a call group whose attributes were fetched by ``group_attribute_views``."""
+    data = Data()
+    data.edge_index = torch.stack([row, col], dim=0)
+    for attr in feature_store.get_all_tensor_attrs():
+        is_edge = isinstance(attr.group_name, tuple)
+        v = views[attr.group_name, attr.attr_name]
+        data[attr.attr_name] = (v[j] if v is not None else
+                                feature_store[attr.group_name, attr.attr_name, None][edge if is_edge else node])
+        if not is_edge:
+            data.num_nodes = node.size(0)
+    return data
+
+
 def build_hetero_data(feature_store, s: HeteroSamplerOutput, group_views=None, j: int = 0) -> HeteroData:
     """HeteroSamplerOutput -> HeteroData with every stored attribute joined (sampler.py:96-165).  ``group_views`` (from
     _group_attribute_views) + the batch's index in its call group replace the per-batch gathers."""
@@ -493,39 +544,12 @@ class SampleIterator:
             self.__hetero_cache = cache
         return build_hetero_data(self.__feature_store, s, cache[1], group[1])
 
-    # one feature fetch per CALL GROUP instead of one per mini-batch: the batches of a group are consecutive segments of
-    # one node list / one edge list, so every stored attribute is gathered once and handed out as per-batch views
-    # (same values as filter_store; bounded so that a huge group does not hold gigabytes of features at once)
-    _GROUP_FETCH_BYTES = 4 << 30
-
     def __filter_from_group(self, ctx, j, s) -> Data:
         cache = getattr(self, "_SampleIterator__group_cache", None)
         if cache is None or cache[0] is not ctx:
-            views = {}
-            for attr in self.__feature_store.get_all_tensor_attrs():
-                is_edge = isinstance(attr.group_name, tuple)
-                index, sizes = (ctx["edges"], ctx["edge_sizes"]) if is_edge else (ctx["nodes"], ctx["node_sizes"])
-                t = self.__feature_store[attr.group_name, attr.attr_name, None]
-                row_bytes = 1
-                for d in tuple(t.shape)[1:]:
-                    row_bytes *= int(d)
-                row_bytes *= torch.empty((), dtype=t.dtype).element_size()
-                if index.numel() * row_bytes > self._GROUP_FETCH_BYTES:
-                    views[attr.group_name, attr.attr_name] = None       # too big for one fetch: per batch below
-                else:
-                    views[attr.group_name, attr.attr_name] = torch.split(t[index], sizes)
-            cache = (ctx, views)
+            cache = (ctx, group_attribute_views(self.__feature_store, ctx))
             self.__group_cache = cache
-        data = Data()
-        data.edge_index = torch.stack([s.row, s.col], dim=0)
-        for attr in self.__feature_store.get_all_tensor_attrs():
-            is_edge = isinstance(attr.group_name, tuple)
-            v = cache[1][attr.group_name, attr.attr_name]
-            data[attr.attr_name] = (v[j] if v is not None else
-                                    self.__feature_store[attr.group_name, attr.attr_name, None][s.edge if is_edge else s.node])
-            if not is_edge:
-                data.num_nodes = s.node.size(0)
-        return data
+        return filter_store_from_group(self.__feature_store, cache[1], j, s.node, s.row, s.col, s.edge)
 
     def __next__(self):
         s = next(self.__output_iter)

@@ -366,9 +366,13 @@ class PygNoSyncWalk:
         self.seed_batch = torch.arange(self.G, dtype=torch.int32, device=dev).repeat_interleave(self.B).contiguous()
         self.zeros_g = torch.zeros(self.G, dtype=torch.int32, device=dev)
 
-    def run(self, seeds: torch.Tensor, random_seeds) -> PygWalkResult:
-        """``seeds`` [G*B] (batch b = seeds[b*B:(b+1)*B]); ``random_seeds`` int64 tensor / nested list [hops, G]."""
+    def run(self, seeds: torch.Tensor, random_seeds, seed_seg: torch.Tensor = None, seed_batch: torch.Tensor = None) -> PygWalkResult:
+        """``seeds`` [G*B] (batch b = seeds[b*B:(b+1)*B]); ``random_seeds`` int64 tensor / nested list [hops, G].
+        Ragged seed lists (link prediction: the de-duplicated endpoints of a batch's seed edges): ``seeds`` holds the lists
+        back to back, padded to the capacity G*B, ``seed_seg`` int32 [G+1] their offsets and ``seed_batch`` int32 [G*B]
+        the batch of every live entry — the kernels only read below ``seed_seg[G]``."""
         assert seeds.dtype == self.id_dtype and seeds.shape[0] == self.G * self.B
+        assert (seed_seg is None) == (seed_batch is None)
         lib, dev, G = L.lib(), self.dev, self.G
         hops = len(self.fanout)
         if isinstance(random_seeds, torch.Tensor):
@@ -379,8 +383,13 @@ class PygNoSyncWalk:
         assert rs.shape == (hops, G)
         res = PygWalkResult(hops, G, self.B, counts=torch.empty((hops, 2), dtype=torch.int32, device=dev))
         res._keepalive = [rs]
-        nodes, n_batch, n_seg = seeds, self.seed_batch, self.seed_seg
-        front, f_batch, f_seg, f_local0 = seeds, self.seed_batch, self.seed_seg, self.zeros_g
+        if seed_seg is None:
+            seed_seg, seed_batch = self.seed_seg, self.seed_batch
+        else:
+            assert seed_seg.dtype == torch.int32 and seed_seg.shape[0] == G + 1 and seed_seg.is_contiguous()
+            assert seed_batch.dtype == torch.int32 and seed_batch.shape[0] == G * self.B and seed_batch.is_contiguous()
+        nodes, n_batch, n_seg = seeds, seed_batch, seed_seg
+        front, f_batch, f_seg, f_local0 = seeds, seed_batch, seed_seg, self.zeros_g
         i32 = dict(dtype=torch.int32, device=dev)
         for k, (m, fc, nc, ec) in enumerate(zip(self.fanout, self.frontier_caps, self.node_caps, self.edge_caps)):
             offsets = torch.empty(fc + 1, **i32)

@@ -784,3 +784,38 @@ def test_hetero_call_group_feature_fetch_equals_per_batch_fetch(hiplib):
             assert torch.equal(a[et].edge_index, b[et].edge_index) and torch.equal(a[et].e_id, b[et].e_id)
         et = ("author", "writes", "paper")
         assert torch.equal(a[et].w, b[et].w) and torch.equal(b[et].w, fs[et, "w", None][b[et].e_id])
+
+
+@pytest.mark.parametrize("mode,amount", [(None, 0), ("binary", 1.0), ("binary", 0.3), ("triplet", 2.0)])
+@pytest.mark.parametrize("biased", [False, True])
+def test_link_loader_call_groups_equal_one_batch_path(hiplib, mode, amount, biased):
+    """LinkNeighborLoader in call groups (row-wise endpoint de-duplication for the whole group + one walk over ragged seed
+    lists) must hand out, batch by batch, exactly what the one-batch-at-a-time path does (same negatives, same samples)."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    torch.manual_seed(21)
+    n, m, B = 3000, 50000, 48
+    ei = torch.stack([torch.randint(0, n, (m,)), torch.randint(0, n, (m,))])
+    gs, fs = GraphStore(), FeatureStore()
+    gs[("n", "e", "n"), "coo", False, (n, n)] = ei
+    fs["n", "x", None] = torch.randn(n, 9)
+    fs[("n", "e", "n"), "w", None] = torch.rand(m) + 0.05
+    eli = ei[:, torch.randperm(m)[:B * 9 + 5]]            # 9 full batches + a ragged one
+    label = None if mode == "triplet" else torch.randint(0, 3, (eli.shape[1],))
+    def run(groups, per_call=None):
+        return list(LinkNeighborLoader((fs, gs), num_neighbors=[5, 3], edge_label_index=eli, edge_label=label, batch_size=B,
+                                       neg_sampling=None if mode is None else (mode, amount), shuffle=False, random_state=17,
+                                       weight_attr="w" if biased else None, call_groups=groups, local_seeds_per_call=per_call))
+    slow, fast, fast1 = run(False), run(True, B * 4), run(True, B)
+    assert len(slow) == len(fast) == len(fast1) == 10
+    for a, b, c in zip(slow, fast, fast1):
+        for other in (b, c):
+            for key in ("n_id", "e_id", "edge_index", "edge_label_index", "x", "w", "input_id"):
+                assert torch.equal(getattr(a, key), getattr(other, key)), key
+            assert a.num_sampled_nodes.tolist() == other.num_sampled_nodes.tolist()
+            assert a.num_sampled_edges.tolist() == other.num_sampled_edges.tolist()
+            if mode is not None or label is not None:
+                assert torch.equal(a.edge_label, other.edge_label)
+            if mode == "triplet":
+                assert torch.equal(a.dst_neg_index, other.dst_neg_index) and torch.equal(a.src_index, other.src_index)
