@@ -6,7 +6,11 @@ sampler (/root/reference/python/cugraph-pyg/cugraph_pyg/sampler/sampler.py:799-8
 sampler/distributed_sampler.py:428-638, negative sampling sampler/sampler_utils.py:93-336).  Per batch:
 the endpoints of the seed edges (plus negatives) are deduplicated in first-appearance order — the
 renumbering kernel with an empty target list does exactly that and returns the inverse map, which IS
-``edge_label_index`` — then the unique endpoints are expanded like node seeds.
+``edge_label_index`` — then the unique endpoints are expanded like node seeds.  Full batches of a homogeneous graph run in
+CALL GROUPS (``local_seeds_per_call``, default 16 batches): the endpoints of all batches are de-duplicated row-wise in one
+pass, the ragged per-batch seed lists go through ONE no-host-sync walk (``NeighborSampler.sample_seed_lists``) and every
+stored attribute is fetched once for the group; batch by batch the result equals the one-batch path
+(``call_groups=False``; tests/test_gpu_pyg_loader.py).
 
 Implemented: homogeneous and heterogeneous graphs (edge seeds of ONE edge type, endpoints of both node types
 seeded together), ``neg_sampling`` = None | "binary" | "triplet" (uniform negatives inside the endpoint types'
