@@ -9,8 +9,9 @@ Follows the CPU optimizer the reference's own test compares the device against
 Device formulas it must agree with: cpp/src/wholememory_ops/functions/embedding_optimizer_func.cu:203-214, :394-421,
 :657-671, :867-881.
 
-Pinning: the reference holds no golden vectors for these (its test draws random tables); tests/test_embedding_oracle.py
-pins this restatement against ``torch.optim.{SGD,Adam,AdamW,Adagrad,RMSprop}`` on CPU, which compute the same updates
+PARITY UNPINNED against the reference itself: it holds no golden vectors for these (its test draws random tables and
+compares the device with the CPU class restated here) and cannot be built or run in this image; what
+tests/test_embedding_oracle.py can and does check is this restatement against ``torch.optim.{SGD,Adam,AdamW,Adagrad,RMSprop}`` on CPU, which compute the same updates
 when every row receives a gradient each step.
 """
 import numpy as np
