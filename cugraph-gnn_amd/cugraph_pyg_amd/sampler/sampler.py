@@ -409,26 +409,29 @@ class BaseSampler:
                                                                                    seed_time=index.time):
                 n_seeds = nn[it][0]
                 ids = input_id[b * bs: b * bs + n_seeds]
-                yield HeteroSamplerOutput(
+                out = HeteroSamplerOutput(
                     node=node, row=row, col=col, edge=edge, batch={it: node[it][:n_seeds]},
                     num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
                     num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()},
-                    metadata=((it, ids), None if index.time is None else index.time[b * bs: b * bs + n_seeds],
-                              getattr(self.__sampler, "current_group", None)))
+                    metadata=((it, ids), None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
+                # (call-group context, index of the batch in it) when the batch came out of a call group
+                out._call_group = getattr(self.__sampler, "current_group", None)
+                yield out
             return
         for b, (node, row, col, edge, nn, ne) in self.__sampler.sample_batches(nodes, bs, random_state,
                                                                                seed_time=index.time):
             n_seeds = nn[0]
             ids = input_id[b * bs: b * bs + n_seeds]
-            # third metadata slot: (call-group context, index of the batch in it) when the batch came out of a call group
-            yield SamplerOutput(
+            out = SamplerOutput(
                 node=node, row=row, col=col, edge=edge, batch=node[:n_seeds],
                 num_sampled_nodes=torch.tensor(nn), num_sampled_edges=torch.tensor(ne),
-                metadata=(ids, None if index.time is None else index.time[b * bs: b * bs + n_seeds],
-                          getattr(self.__sampler, "current_group", None)))
+                metadata=(ids, None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
+            out._call_group = getattr(self.__sampler, "current_group", None)
+            yield out
 
     def sample_from_edges(self, index, neg_sampling=None, **kwargs):
-        raise NotImplementedError("link loaders / negative sampling: SURVEY.md §8(f) rank 1")
+        raise NotImplementedError("edge seeds are served by cugraph_pyg_amd.loader.LinkLoader / LinkNeighborLoader, which "
+                                  "drive the sampler's kernels directly (negatives, endpoint de-duplication, call groups)")
 
 
 def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
@@ -535,7 +538,7 @@ class SampleIterator:
         self.__output_iter = output_iter
 
     def __next_hetero(self, s):
-        group = s.metadata[2] if s.metadata is not None and len(s.metadata) > 2 else None
+        group = getattr(s, "_call_group", None)
         if group is None:
             return build_hetero_data(self.__feature_store, s)
         cache = getattr(self, "_SampleIterator__hetero_cache", None)
@@ -555,7 +558,7 @@ class SampleIterator:
         s = next(self.__output_iter)
         if isinstance(s, HeteroSamplerOutput):
             return self.__next_hetero(s)
-        group = s.metadata[2] if s.metadata is not None and len(s.metadata) > 2 else None
+        group = getattr(s, "_call_group", None)
         if group is not None:
             data = self.__filter_from_group(group[0], group[1], s)
         else:
