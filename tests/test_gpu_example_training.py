@@ -15,3 +15,13 @@ def test_sage_example_learns(hiplib, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["x", "--nodes", "30000", "--epochs", "3", "--batch-size", "512", "--fanout", "10", "5"])
     loss, acc = ex.main()
     assert loss < 1.5 and acc > 0.6, (loss, acc)
+
+
+def test_link_prediction_example_learns(hiplib, monkeypatch):
+    """examples/sage_link_prediction.py: LinkNeighborLoader (call groups, binary negatives) -> SAGE encoder -> dot-product
+    decoder separates the planted intra-community edges from random negatives."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import sage_link_prediction as ex
+    monkeypatch.setattr(sys, "argv", ["x", "--nodes", "8000", "--epochs", "3", "--batch-size", "256"])
+    loss, acc = ex.main()
+    assert loss < 0.6 and acc > 0.7, (loss, acc)
