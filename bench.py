@@ -110,6 +110,7 @@ class SagePipeline:
         self.bias = [c.lin_l.bias for c in self.convs]
         self.fused_relu = hasattr(torch, "_addmm_activation")
         self.walk_stream = torch.cuda.Stream(device=device) if overlap_walk else None
+        self.host_wait_s = 0.0
         self.distributed = self.feat.is_distributed
         self._bufs = {}
 
@@ -160,7 +161,9 @@ class SagePipeline:
     def forward(self, res, sizes_h, ev, timers=None, mode="split"):
         """Feature fetch + L-layer SAGE forward of one call group with exact (host-known) sizes."""
         nn = self.nn
+        t_wait = time.perf_counter()
         ev.synchronize()
+        self.host_wait_s += time.perf_counter() - t_wait     # host blocked on the walk of this group (--host-profile)
         sz = sizes_h.tolist()                   # per hop (seed hop first): [edges, unique nodes after the hop]
         L = len(sz)
         n_edges, n_uniq = [v[0] for v in sz], [v[1] for v in sz]
@@ -284,6 +287,8 @@ def main():
     ap.add_argument("--feature-placement", choices=["auto", "replicated", "partitioned"], default="auto",
                     help="N>1: replicate the feature table on every GPU when it is small next to 288 GB of HBM "
                          "(auto: <= 36 GB), otherwise range-partition it and fetch remote rows by RCCL all-to-all")
+    ap.add_argument("--host-profile", action="store_true",
+                    help="print (stderr) where the HOST spends a call group: enqueueing the walk, enqueueing the forward, blocked")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
     ap.add_argument("--no-overlap", action="store_true", help="run the walk on the main stream (no second HIP stream)")
@@ -367,12 +372,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_prof = {"sample_enqueue": 0.0, "forward_enqueue": 0.0, "wait_for_walk": 0.0, "groups": 0}
+
     def run_groups(first, last, timers=None, sizes=None, mode="split"):
         """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
         pending = pipe.sample(batches[first], first)
         for g in range(first, last):
+            t0 = time.perf_counter()
             nxt = pipe.sample(batches[g + 1], g + 1) if g + 1 < last else None
+            t1 = time.perf_counter()
+            w0 = pipe.host_wait_s
             _, sz = pipe.forward(*pending, timers=timers, mode=mode)
+            host_prof["sample_enqueue"] += t1 - t0
+            host_prof["forward_enqueue"] += time.perf_counter() - t1 - (pipe.host_wait_s - w0)
+            host_prof["wait_for_walk"] += pipe.host_wait_s - w0
+            host_prof["groups"] += 1
             if sizes is not None:
                 sizes.append(sz)
             pending = nxt
@@ -383,9 +397,17 @@ def main():
         barrier()
         t_start = time.perf_counter()
         szs = []
+        for k in host_prof:
+            host_prof[k] = 0
         run_groups(warm_groups, total_groups, sizes=szs, mode=mode)
         barrier()
         secs = time.perf_counter() - t_start
+        if args.host_profile and rank == 0:
+            n_g = max(host_prof["groups"], 1)
+            print("[host-profile %s] per call group: total %.3f ms | host: walk enqueue %.3f, forward enqueue %.3f, blocked on "
+                  "the walk %.3f" % (mode, secs / n_g * 1e3, host_prof["sample_enqueue"] / n_g * 1e3,
+                                     host_prof["forward_enqueue"] / n_g * 1e3, host_prof["wait_for_walk"] / n_g * 1e3),
+                  file=sys.stderr, flush=True)
         st = torch.tensor([secs, float(sum(sum(v[0::2]) for v in szs))], dtype=torch.float64, device=device)
         if world > 1:
             tmax, esum = st[:1].clone(), st[1:].clone()
