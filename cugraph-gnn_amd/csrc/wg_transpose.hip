@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) run_offsets_kernel(const unsigned* __rest
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n) return;
   const int64_t lo = j == 0 ? 0 : (int64_t)keys[j - 1] + 1;     // sources after the previous key ...
-  const int64_t hi = j == n ? n_src : (int64_t)keys[j];          // ... up to my key start at position j
+  int64_t hi       = j == n ? n_src : (int64_t)keys[j];          // ... up to my key start at position j
+  hi               = hi < n_src ? hi : n_src;                    // an id outside [0, n_src) must not write out of bounds
   for (int64_t s = lo; s <= hi; s++) offsets[s] = (int)j;
 }
 
