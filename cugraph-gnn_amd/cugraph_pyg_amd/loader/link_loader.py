@@ -22,16 +22,16 @@ edge's time (5 attempts, then the earliest node of the type: sampler_utils.py:21
 """
 from math import ceil
 import warnings
-from typing import Optional, Tuple, Union
+from typing import Optional, Tuple
 
 import torch
 
 from wholegraph_amd import graph_ops
 
 from ..data.graph_store import GraphStore
-from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, SampleIterator, build_hetero_data, filter_store,
+from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, build_hetero_data, filter_store,
                                filter_store_from_group, group_attribute_views, hetero_neighbor_sample, neighbor_sample)
-from .._compat import Data, HeteroSamplerOutput
+from .._compat import HeteroSamplerOutput
 from .node_loader import generate_seed
 
 

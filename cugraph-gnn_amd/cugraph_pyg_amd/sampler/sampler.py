@@ -16,7 +16,7 @@ of the expanded vertex, ``edge`` = original edge id.  The random part is pinned 
 (tests/test_gpu_pyg_loader.py composes the oracle the same way), the structural invariants are
 the reference tests' own (tests/loader/test_neighbor_loader.py:20-133).
 """
-from typing import Iterator, List, Optional, Sequence
+from typing import Iterator, Optional, Sequence
 
 import torch
 

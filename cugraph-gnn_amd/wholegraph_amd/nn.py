@@ -10,10 +10,9 @@ segmented reduce / edge softmax run in hand-written gfx950 kernels, the dense ``
 plain ``torch.nn.functional.linear`` (hipBLASLt, MFMA).
 """
 import math
-from typing import Optional, Tuple, Union
+from typing import Tuple, Union
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib as L
 from .env import get_stream, torch_dtype_to_wm

@@ -3,7 +3,6 @@
 the layer-1 shape of one products call group (610 k destination rows, ~8 neighbours, F = 100 -> 256)."""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cugraph-gnn_amd")]
