@@ -43,3 +43,12 @@ def _poison_device_cache(request):
             torch.cuda.synchronize()
             del blocks
     yield
+
+
+def pytest_collection_modifyitems(config, items):
+    """WGAMD_TEST_SHUFFLE=<seed>: run the collected tests in a seeded random order (hardening runs: no test may depend
+    on allocator state, cached walks or communicators left behind by another)."""
+    seed = os.environ.get("WGAMD_TEST_SHUFFLE")
+    if seed:
+        import random
+        random.Random(int(seed)).shuffle(items)
