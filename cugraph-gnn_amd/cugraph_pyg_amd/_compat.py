@@ -15,7 +15,7 @@ try:  # pragma: no cover - not available in the build image
     from torch_geometric.data import Data, HeteroData
     from torch_geometric.data.feature_store import TensorAttr
     from torch_geometric.data.graph_store import EdgeAttr, EdgeLayout
-    from torch_geometric.sampler import HeteroSamplerOutput, NodeSamplerInput, SamplerOutput
+    from torch_geometric.sampler import EdgeSamplerInput, HeteroSamplerOutput, NodeSamplerInput, SamplerOutput
     HAS_PYG = True
 except ImportError:
     HAS_PYG = False
@@ -132,6 +132,16 @@ except ImportError:
         node: Any
         time: Any = None
         input_type: Optional[str] = None
+
+    @dataclass
+    class EdgeSamplerInput:
+        """torch_geometric.sampler.EdgeSamplerInput"""
+        input_id: Any
+        row: Any
+        col: Any
+        label: Any = None
+        time: Any = None
+        input_type: Any = None
 
     @dataclass
     class SamplerOutput:

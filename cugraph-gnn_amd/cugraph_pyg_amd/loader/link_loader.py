@@ -31,7 +31,7 @@ from wholegraph_amd import graph_ops
 from ..data.graph_store import GraphStore
 from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, build_hetero_data, filter_store,
                                filter_store_from_group, group_attribute_views, hetero_neighbor_sample, neighbor_sample)
-from .._compat import HeteroSamplerOutput
+from .._compat import HeteroSamplerOutput, SamplerOutput
 from .node_loader import generate_seed
 
 
@@ -125,11 +125,16 @@ class LinkLoader:
                  edge_label_time=None, neg_sampling=None, neg_sampling_ratio=None, transform=None,
                  transform_sampler_output=None, filter_per_worker=None, custom_cls=None, input_id=None,
                  batch_size: int = 1, shuffle: bool = False, drop_last: bool = False,
-                 random_state: Optional[int] = None, time_attr: Optional[str] = None, call_groups: bool = True, **kwargs):
+                 random_state: Optional[int] = None, time_attr: Optional[str] = None, call_groups: bool = True,
+                 as_sampler_output: bool = False, **kwargs):
         if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
         self.__time_attr = time_attr
         self.__call_groups = bool(call_groups)   # False: one batch at a time through the C-ABI ops (tuning / tests)
+        # True: yield torch_geometric-style SamplerOutput objects (metadata = (input_id, edge_label_index, edge_label,
+        # seed_time), the reference's sampler.py:621-628) instead of Data — what BaseSampler.sample_from_edges hands to a
+        # SampleIterator; features are then joined there
+        self.__raw = bool(as_sampler_output)
         if not isinstance(link_sampler, (NeighborSampler, HeteroNeighborSampler)):
             raise NotImplementedError("Must provide a cuGraph sampler")
         if neg_sampling_ratio is not None:
@@ -197,6 +202,39 @@ class LinkLoader:
         t_all = None if t_pos is None else torch.cat([t_pos, t_neg])
         return torch.cat([src, neg_src]), torch.cat([dst, neg_dst]), n_neg, t_all
 
+    def __emit(self, node, row, col, edge, nn, ne, ix, inverse, n_pos, n_neg, views=None, j=0, group=None):
+        """One homogeneous mini-batch as ``Data`` (features joined) or, in sampler mode, as ``SamplerOutput``."""
+        dev = self.__eli.device
+        half = n_pos + n_neg
+        edge_label_index = torch.stack([inverse[:half], inverse[half:]])
+        if self.__mode is not None:
+            pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
+            edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
+        else:
+            edge_label = None if self.__label is None else self.__label[ix]
+        if self.__raw:
+            out = SamplerOutput(node=node, row=row, col=col, edge=edge, batch=node[:nn[0]],
+                                num_sampled_nodes=torch.tensor(nn), num_sampled_edges=torch.tensor(ne),
+                                metadata=(self.__input_id[ix], edge_label_index, edge_label,
+                                          None if self.__time is None else self.__time[ix]))
+            out._call_group = group
+            return out
+        fs, gs = self.__data
+        data = (filter_store_from_group(fs, views, j, node, row, col, edge) if views is not None
+                else filter_store(fs, gs, node, row, col, edge))
+        data.n_id, data.e_id = node, edge
+        data.num_sampled_nodes, data.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)
+        data.input_id = self.__input_id[ix]
+        data.batch_size = n_pos
+        data.edge_label_index = edge_label_index
+        if edge_label is not None:
+            data.edge_label = edge_label
+        if self.__mode == "triplet":   # PyG's triplet view of the same batch
+            data.src_index, data.dst_pos_index = inverse[:n_pos], inverse[half:half + n_pos]
+            neg = inverse[half + n_pos:]
+            data.dst_neg_index = neg.view(-1, n_pos).t() if n_neg % n_pos == 0 and n_neg > n_pos else neg
+        return data
+
     def __len__(self):
         n = self.__eli.shape[1]
         return n // self.__batch_size if self.__drop_last else (n + self.__batch_size - 1) // self.__batch_size
@@ -238,24 +276,7 @@ class LinkLoader:
             node, row, col, edge, nn, ne = neighbor_sample(graph, uniq, self.__sampler.fanout, seed + b,
                                                            self.__sampler.biased, self.__sampler.disjoint, seed_time,
                                                            self.__sampler.temporal_comparison)
-            data = filter_store(fs, gs, node, row, col, edge)
-            data.n_id, data.e_id = node, edge
-            data.num_sampled_nodes, data.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)
-            data.input_id = self.__input_id[ix]
-            data.batch_size = n_pos
-            inverse = inverse.long()
-            half = n_pos + n_neg
-            data.edge_label_index = torch.stack([inverse[:half], inverse[half:]])
-            if self.__mode is not None:
-                pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
-                data.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
-                if self.__mode == "triplet":   # PyG's triplet view of the same batch
-                    data.src_index, data.dst_pos_index = inverse[:n_pos], inverse[half:half + n_pos]
-                    neg = inverse[half + n_pos:]
-                    data.dst_neg_index = neg.view(-1, n_pos).t() if n_neg % n_pos == 0 and n_neg > n_pos else neg
-            elif self.__label is not None:
-                data.edge_label = self.__label[ix]
-            yield data
+            yield self.__emit(node, row, col, edge, nn, ne, ix, inverse.long(), n_pos, n_neg)
 
     def __group(self, perm, seed, b0, g):
         """Batches b0 .. b0+g-1 (all full) of a homogeneous graph as one call group: negatives per batch with the batch's
@@ -275,27 +296,9 @@ class LinkLoader:
         S = ends.shape[1]
         uniq, seg, batch, local = _batched_first_unique(ends, self.__num_nodes)
         outs, ctx = self.__sampler.sample_seed_lists(uniq, seg, batch, S, g, seed + b0)
-        views = group_attribute_views(fs, ctx)                      # every stored attribute: one fetch for the group
+        views = None if self.__raw else group_attribute_views(fs, ctx)   # every stored attribute: one fetch for the group
         for j, (node, row, col, edge, nn, ne) in enumerate(outs):
-            ix, n_neg, n_pos = ixs[j], n_negs[j], bs
-            data = filter_store_from_group(fs, views, j, node, row, col, edge)
-            data.n_id, data.e_id = node, edge
-            data.num_sampled_nodes, data.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)
-            data.input_id = self.__input_id[ix]
-            data.batch_size = n_pos
-            inverse = local[j]
-            half = n_pos + n_neg
-            data.edge_label_index = torch.stack([inverse[:half], inverse[half:]])
-            if self.__mode is not None:
-                pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
-                data.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
-                if self.__mode == "triplet":
-                    data.src_index, data.dst_pos_index = inverse[:n_pos], inverse[half:half + n_pos]
-                    neg = inverse[half + n_pos:]
-                    data.dst_neg_index = neg.view(-1, n_pos).t() if n_neg % n_pos == 0 and n_neg > n_pos else neg
-            elif self.__label is not None:
-                data.edge_label = self.__label[ix]
-            yield data
+            yield self.__emit(node, row, col, edge, nn, ne, ixs[j], local[j], bs, n_negs[j], views, j, (ctx, j))
 
     def __hetero_batches(self, perm, seed):
         """Edge seeds of one edge type (src_t, rel, dst_t): the src endpoints seed type src_t, the dst endpoints type

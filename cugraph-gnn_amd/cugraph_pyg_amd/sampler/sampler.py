@@ -22,7 +22,7 @@ import torch
 
 from wholegraph_amd import graph_ops, wholegraph_ops
 
-from .._compat import Data, HeteroData, HeteroSamplerOutput, NodeSamplerInput, SamplerOutput
+from .._compat import Data, HeteroData, HeteroSamplerOutput, NodeSamplerInput, SamplerOutput  # noqa: F401
 from ..data.graph_store import CSRGraph
 
 _GOLDEN = 0x9E3779B97F4A7C15
@@ -429,9 +429,20 @@ class BaseSampler:
             out._call_group = getattr(self.__sampler, "current_group", None)
             yield out
 
-    def sample_from_edges(self, index, neg_sampling=None, **kwargs):
-        raise NotImplementedError("edge seeds are served by cugraph_pyg_amd.loader.LinkLoader / LinkNeighborLoader, which "
-                                  "drive the sampler's kernels directly (negatives, endpoint de-duplication, call groups)")
+    def sample_from_edges(self, index, neg_sampling=None, random_state: int = 62, **kwargs) -> Iterator[SamplerOutput]:
+        """``EdgeSamplerInput`` (+ optional negative sampling) -> iterator of ``SamplerOutput`` whose metadata is
+        ``(input_id, edge_label_index, edge_label, seed_time)`` (sampler.py:799-896, decode :583-628): the endpoints of a
+        batch's seed edges and of its negatives are de-duplicated, expanded like node seeds, and ``edge_label_index`` indexes
+        the batch's ``node`` list.  Homogeneous graphs; typed edge seeds go through ``LinkNeighborLoader`` directly."""
+        if isinstance(self.__sampler, HeteroNeighborSampler):
+            raise NotImplementedError("typed edge seeds are served by cugraph_pyg_amd.loader.LinkNeighborLoader")
+        from ..loader.link_loader import LinkLoader   # the batch machinery (negatives, de-duplication, call groups) lives there
+        loader = LinkLoader((self.__feature_store, self.__graph_store), self.__sampler,
+                            edge_label_index=torch.stack([torch.as_tensor(index.row), torch.as_tensor(index.col)]),
+                            edge_label=index.label, edge_label_time=index.time, neg_sampling=neg_sampling,
+                            input_id=index.input_id, batch_size=self.__batch_size, shuffle=False, random_state=random_state,
+                            as_sampler_output=True, **kwargs)
+        yield from loader
 
 
 def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
@@ -572,7 +583,12 @@ class SampleIterator:
         data.num_sampled_edges = s.num_sampled_edges
         data.input_id = s.metadata[0]
         data.batch_size = data.input_id.size(0)
-        data.seed_time = s.metadata[1]
+        if len(s.metadata) == 4:     # edge seeds (sampler.py:104-112)
+            data.edge_label_index, data.seed_time = s.metadata[1], s.metadata[3]
+            if s.metadata[2] is not None:
+                data.edge_label = s.metadata[2]
+        else:
+            data.seed_time = s.metadata[1]
         return data
 
     def __iter__(self):

@@ -819,3 +819,35 @@ def test_link_loader_call_groups_equal_one_batch_path(hiplib, mode, amount, bias
                 assert torch.equal(a.edge_label, other.edge_label)
             if mode == "triplet":
                 assert torch.equal(a.dst_neg_index, other.dst_neg_index) and torch.equal(a.src_index, other.src_index)
+
+
+@pytest.mark.parametrize("mode", [None, "binary"])
+def test_sampler_protocol_sample_from_edges(hiplib, mode):
+    """BaseSampler.sample_from_edges(EdgeSamplerInput, neg_sampling) -> SamplerOutput with the reference's 4-slot metadata
+    (sampler.py:799-896, :621-628); through SampleIterator it yields the same Data as LinkNeighborLoader."""
+    import torch
+    from cugraph_pyg_amd._compat import EdgeSamplerInput, SamplerOutput
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    from cugraph_pyg_amd.sampler.sampler import BaseSampler, NeighborSampler, SampleIterator
+    torch.manual_seed(4)
+    n, m, B = 2000, 30000, 32
+    ei = torch.stack([torch.randint(0, n, (m,)), torch.randint(0, n, (m,))])
+    gs, fs = GraphStore(), FeatureStore()
+    gs[("n", "e", "n"), "coo", False, (n, n)] = ei
+    fs["n", "x", None] = torch.randn(n, 7)
+    eli = ei[:, torch.randperm(m)[:B * 5 + 3]].cuda()
+    label = torch.randint(0, 2, (eli.shape[1],)).cuda()
+    neg = None if mode is None else (mode, 1.0)
+    want = list(LinkNeighborLoader((fs, gs), num_neighbors=[4, 3], edge_label_index=eli, edge_label=label, batch_size=B,
+                                   neg_sampling=neg, shuffle=False, random_state=62))
+    sampler = BaseSampler(NeighborSampler(gs._graph, fanout=[4, 3]), (fs, gs), batch_size=B)
+    index = EdgeSamplerInput(input_id=torch.arange(eli.shape[1], device="cuda"), row=eli[0], col=eli[1], label=label)
+    outs = list(sampler.sample_from_edges(index, neg_sampling=neg, random_state=62))
+    assert len(outs) == len(want) == 6 and all(isinstance(o, SamplerOutput) and len(o.metadata) == 4 for o in outs)
+    got = list(SampleIterator((fs, gs), iter(sampler.sample_from_edges(index, neg_sampling=neg, random_state=62))))
+    for a, b, o in zip(want, got, outs):
+        for key in ("n_id", "e_id", "edge_index", "edge_label_index", "edge_label", "x", "input_id"):
+            assert torch.equal(getattr(a, key), getattr(b, key)), key
+        assert torch.equal(o.node, a.n_id) and torch.equal(o.metadata[1], a.edge_label_index)
+        assert a.batch_size == b.batch_size
