@@ -6,8 +6,8 @@ sampler (/root/reference/python/cugraph-pyg/cugraph_pyg/sampler/sampler.py:799-8
 sampler/distributed_sampler.py:428-638, negative sampling sampler/sampler_utils.py:93-336).  Per batch:
 the endpoints of the seed edges (plus negatives) are deduplicated in first-appearance order — the
 renumbering kernel with an empty target list does exactly that and returns the inverse map, which IS
-``edge_label_index`` — then the unique endpoints are expanded like node seeds.  Full batches of a homogeneous graph run in
-CALL GROUPS (``local_seeds_per_call``, default 16 batches): the endpoints of all batches are de-duplicated row-wise in one
+``edge_label_index`` — then the unique endpoints are expanded like node seeds.  Full batches (homogeneous graphs and typed
+edge seeds of heterogeneous ones, uniform or biased, not temporal / disjoint) run in CALL GROUPS (``local_seeds_per_call``, default 16 batches): the endpoints of all batches are de-duplicated row-wise in one
 pass, the ragged per-batch seed lists go through ONE no-host-sync walk (``NeighborSampler.sample_seed_lists``) and every
 stored attribute is fetched once for the group; batch by batch the result equals the one-batch path
 (``call_groups=False``; tests/test_gpu_pyg_loader.py).
@@ -30,7 +30,8 @@ from wholegraph_amd import graph_ops
 
 from ..data.graph_store import GraphStore
 from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, build_hetero_data, filter_store,
-                               filter_store_from_group, group_attribute_views, hetero_neighbor_sample, neighbor_sample)
+                               filter_store_from_group, group_attribute_views, _group_attribute_views, hetero_neighbor_sample,
+                               neighbor_sample)
 from .._compat import HeteroSamplerOutput, SamplerOutput
 from .node_loader import generate_seed
 
@@ -308,7 +309,15 @@ class LinkLoader:
         src_t, _, dst_t = self.__etype
         dev = self.__eli.device
         smp = self.__sampler
-        for b, start in enumerate(range(0, perm.numel(), self.__batch_size)):
+        bs = self.__batch_size
+        n_full = perm.numel() // bs if (self.__call_groups and smp.call_groups_ok()) else 0
+        G = max(1, (getattr(smp, "local_seeds_per_call", None) or 16 * bs) // bs)
+        b0 = 0
+        while b0 < n_full:   # CALL GROUPS of full batches
+            g = min(G, n_full - b0)
+            yield from self.__hetero_group(perm, seed, b0, g)
+            b0 += g
+        for b, start in enumerate(range(n_full * bs, perm.numel(), bs), start=n_full):
             ix = perm[start:start + self.__batch_size]
             src, dst = self.__eli[0, ix], self.__eli[1, ix]
             n_pos = ix.numel()
@@ -340,19 +349,56 @@ class LinkLoader:
                                       batch={t: node[t][:v.numel()] for t, v in seeds.items()},
                                       num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
                                       num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()}, metadata=None)
-            data = build_hetero_data(fs, out)
-            st = data[self.__etype]
-            st.edge_label_index = torch.stack([inv_src, inv_dst])
-            st.input_id = self.__input_id[ix]
-            st.batch_size = n_pos
-            if self.__mode is not None:
-                pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
-                st.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
-                if self.__mode == "triplet":
-                    st.src_index, st.dst_pos_index, st.dst_neg_index = inv_src[:n_pos], inv_dst[:n_pos], inv_dst[n_pos:]
-            elif self.__label is not None:
-                st.edge_label = self.__label[ix]
-            yield data
+            yield self.__emit_hetero(build_hetero_data(fs, out), ix, inv_src, inv_dst, n_pos, n_neg)
+
+    def __emit_hetero(self, data, ix, inv_src, inv_dst, n_pos, n_neg):
+        dev = self.__eli.device
+        st = data[self.__etype]
+        st.edge_label_index = torch.stack([inv_src, inv_dst])
+        st.input_id = self.__input_id[ix]
+        st.batch_size = n_pos
+        if self.__mode is not None:
+            pos = torch.ones(n_pos, device=dev) if self.__label is None else (self.__label[ix] + 1)
+            st.edge_label = torch.cat([pos, torch.zeros(n_neg, device=dev, dtype=pos.dtype)])
+            if self.__mode == "triplet":
+                st.src_index, st.dst_pos_index, st.dst_neg_index = inv_src[:n_pos], inv_dst[:n_pos], inv_dst[n_pos:]
+        elif self.__label is not None:
+            st.edge_label = self.__label[ix]
+        return data
+
+    def __hetero_group(self, perm, seed, b0, g):
+        """Batches b0 .. b0+g-1 (all full) of a heterogeneous graph as one call group (see ``__group``): the source
+        endpoints seed type src_t, the destination endpoints type dst_t (one joint list when both are the same type)."""
+        fs, gs = self.__data
+        src_t, _, dst_t = self.__etype
+        dev, bs, smp = self.__eli.device, self.__batch_size, self.__sampler
+        ixs, srcs, dsts, n_negs = [], [], [], []
+        for j in range(g):
+            ix = perm[(b0 + j) * bs:(b0 + j + 1) * bs]
+            gen = torch.Generator(device=dev).manual_seed((seed + b0 + j) & 0x7FFFFFFFFFFFFFFF)
+            src_all, dst_all, n_neg, _ = self.__with_negatives(self.__eli[0, ix], self.__eli[1, ix], ix, gen)
+            ixs.append(ix)
+            srcs.append(src_all)
+            dsts.append(dst_all)
+            n_negs.append(n_neg)
+        srcs, dsts = torch.stack(srcs), torch.stack(dsts)           # [g, bs + n_neg] each
+        half = srcs.shape[1]
+        if src_t == dst_t:
+            uniq, seg, batch, local = _batched_first_unique(torch.cat([srcs, dsts], 1), self.__num_src)
+            lists = {src_t: (uniq, seg, batch)}
+            inv_src, inv_dst = local[:, :half], local[:, half:]
+        else:
+            us, sseg, sbatch, inv_src = _batched_first_unique(srcs, self.__num_src)
+            ud, dseg, dbatch, inv_dst = _batched_first_unique(dsts, self.__num_dst)
+            lists = {src_t: (us, sseg, sbatch), dst_t: (ud, dseg, dbatch)}
+        outs, ctx = smp.sample_seed_lists(lists, g, seed + b0)
+        views = _group_attribute_views(fs, ctx)
+        for j, (node, row, col, edge, nn, ne) in enumerate(outs):
+            out = HeteroSamplerOutput(node=node, row=row, col=col, edge=edge,
+                                      batch={t: node[t][:nn[t][0]] for t in lists},
+                                      num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
+                                      num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()}, metadata=None)
+            yield self.__emit_hetero(build_hetero_data(fs, out, views, j), ixs[j], inv_src[j], inv_dst[j], bs, n_negs[j])
 
     def __iter__(self):
         return self.__batches()
@@ -393,7 +439,8 @@ class LinkNeighborLoader(LinkLoader):
                 raise ValueError(f"fan-out given for unknown edge types: {unknown}")
             sampler = HeteroNeighborSampler(graph_store._hetero_graphs, num_neighbors, biased=(weight_attr is not None),
                                             with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
-                                            temporal_comparison=temporal_comparison)
+                                            temporal_comparison=temporal_comparison, local_seeds_per_call=local_seeds_per_call,
+                                            num_nodes=graph_store._num_vertices())
         super().__init__((feature_store, graph_store), sampler, edge_label_index=edge_label_index,
                          edge_label=edge_label, edge_label_time=edge_label_time, neg_sampling=neg_sampling,
                          neg_sampling_ratio=neg_sampling_ratio, transform=transform,

@@ -265,6 +265,26 @@ class HeteroNeighborSampler:
                                              num_nodes=self.num_nodes)
         return self._walks[key]
 
+    def call_groups_ok(self) -> bool:
+        """Can this configuration run on the no-host-sync call-group kernels (see ``sample_batches``)?"""
+        if self.biased and self._positive_weights is None:
+            self._positive_weights = all(bool((g.weight > 0).all()) for g in self.graphs.values())
+        biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for v in self.fanout.values() for f in v))
+        return biased_ok and (not self.temporal) and (not getattr(self, "disjoint", False)) and all(
+            g.col.dtype == torch.int64 for g in self.graphs.values())
+
+    def sample_seed_lists(self, seed_lists, n_batches: int, random_state: int):
+        """One call group over RAGGED per-batch seed lists of one or two node types (``seed_lists`` as in
+        ``HeteroPygWalk.run``): batch j gets exactly ``hetero_neighbor_sample(graphs, None, its lists, fanout,
+        random_state + j)``.  Returns (list of per-batch tuples, group context for ``_group_attribute_views``)."""
+        n_et, hops = len(self.graphs), len(next(iter(self.fanout.values())))
+        walk = self._call_group_walk(max(int(v[0].shape[0]) for v in seed_lists.values()) // max(n_batches, 1) or 1, n_batches)
+        rs = torch.tensor([[_as_i64(hop_seed(random_state + j, k)) for j in range(n_batches)] for k in range(hops * n_et)],
+                          dtype=torch.int64)
+        rec = walk.run(None, None, rs, seed_lists=seed_lists)
+        outs = walk.finalize_batches(rec)
+        return outs, rec["group_context"]
+
     def sample_batches(self, seed_type, seeds, batch_size, random_state, seed_time=None):
         """Uniform, non-temporal sampling of full mini-batches runs in CALL GROUPS of ``local_seeds_per_call`` seeds
         on the batched no-sync kernel (one launch sequence per hop and edge type for the whole group); everything else

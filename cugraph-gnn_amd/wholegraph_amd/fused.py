@@ -490,11 +490,14 @@ class HeteroPygWalk:
         ids = st["nodes"][src.clamp_(0, st["nodes"].shape[0] - 1)]
         return ids.contiguous(), b.to(torch.int32).contiguous(), f_seg, st["begin"].contiguous()
 
-    def run(self, seed_type: str, seeds: torch.Tensor, random_seeds: torch.Tensor):
+    def run(self, seed_type: str, seeds: torch.Tensor, random_seeds: torch.Tensor, seed_lists=None):
         """``seeds`` [G*B] type-local ids of ``seed_type``; ``random_seeds`` int64 [hops * n_etypes, G]: row
-        ``h * n_etypes + t`` holds the per-batch seeds of hop h / edge type t (sorted order)."""
+        ``h * n_etypes + t`` holds the per-batch seeds of hop h / edge type t (sorted order).
+        ``seed_lists`` (link prediction: both endpoint types of the seed edges start the walk, with ragged per-batch lists):
+        {node type: (ids padded to a capacity, int32 offsets [G+1], int32 batch of every live entry)} replaces
+        ``seed_type`` / ``seeds``."""
         lib, dev, G = L.lib(), self.dev, self.G
-        assert seeds.dtype == torch.int64 and seeds.shape[0] == G * self.B and seeds.is_cuda
+        assert seed_lists is not None or (seeds.dtype == torch.int64 and seeds.shape[0] == G * self.B and seeds.is_cuda)
         rs = random_seeds.to(device=dev, dtype=torch.int64).contiguous()
         assert rs.shape == (self.hops * len(self.etypes), G)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -502,8 +505,15 @@ class HeteroPygWalk:
         for t in self.ntypes:   # per node type: batch-major vertex lists, capacity, start of the current frontier
             state[t] = dict(nodes=torch.zeros(1, dtype=torch.int64, device=dev), batch=torch.zeros(1, **i32),
                             seg=self.zeros_g1, cap=0, begin=self.zeros_g, gained_cap=0)
-        state[seed_type] = dict(nodes=seeds, batch=self.seed_batch, seg=self.seed_seg, cap=G * self.B,
-                                begin=self.zeros_g, gained_cap=G * self.B)
+        if seed_lists is None:
+            state[seed_type] = dict(nodes=seeds, batch=self.seed_batch, seg=self.seed_seg, cap=G * self.B,
+                                    begin=self.zeros_g, gained_cap=G * self.B)
+        else:
+            for t, (ids, seg, batch) in seed_lists.items():
+                assert ids.dtype == torch.int64 and seg.dtype == torch.int32 and batch.dtype == torch.int32
+                assert seg.shape[0] == G + 1 and batch.shape[0] == ids.shape[0]
+                state[t] = dict(nodes=ids.contiguous(), batch=batch.contiguous(), seg=seg.contiguous(), cap=int(ids.shape[0]),
+                                begin=self.zeros_g, gained_cap=int(ids.shape[0]))
         rec = dict(calls=[], sizes=[{t: (state[t]["seg"][1:] - state[t]["seg"][:-1]) for t in self.ntypes}])
         keep = [rs]
         for h in range(self.hops):

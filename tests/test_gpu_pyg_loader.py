@@ -851,3 +851,46 @@ def test_sampler_protocol_sample_from_edges(hiplib, mode):
             assert torch.equal(getattr(a, key), getattr(b, key)), key
         assert torch.equal(o.node, a.n_id) and torch.equal(o.metadata[1], a.edge_label_index)
         assert a.batch_size == b.batch_size
+
+
+@pytest.mark.parametrize("mode,amount", [(None, 0), ("binary", 1.0), ("triplet", 2.0)])
+@pytest.mark.parametrize("etype", [("author", "writes", "paper"), ("paper", "cites", "paper")])
+def test_hetero_link_loader_call_groups_equal_one_batch_path(hiplib, mode, amount, etype):
+    """Typed edge seeds in call groups (both endpoint types seed the walk with ragged per-batch lists) against the
+    one-batch-at-a-time path: identical HeteroData, batch by batch."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import LinkNeighborLoader
+    torch.manual_seed(33)
+    n_p, n_a, B = 2500, 900, 40
+    cites = torch.stack([torch.randint(0, n_p, (15000,)), torch.randint(0, n_p, (15000,))])
+    writes = torch.stack([torch.randint(0, n_a, (7000,)), torch.randint(0, n_p, (7000,))])
+    gs, fs = GraphStore(), FeatureStore()
+    gs[("paper", "cites", "paper"), "coo", False, (n_p, n_p)] = cites
+    gs[("author", "writes", "paper"), "coo", False, (n_a, n_p)] = writes
+    gs[("paper", "rev_writes", "author"), "coo", False, (n_p, n_a)] = writes.flip(0)
+    fs["paper", "x", None] = torch.randn(n_p, 6)
+    fs["author", "x", None] = torch.randn(n_a, 4)
+    fs[("author", "writes", "paper"), "w", None] = torch.randn(7000, 2)
+    src_edges = writes if etype[0] == "author" else cites
+    eli = src_edges[:, torch.randperm(src_edges.shape[1])[:B * 6 + 9]]
+    fan = {("paper", "cites", "paper"): [3, 2], ("author", "writes", "paper"): [2, 2], ("paper", "rev_writes", "author"): [2, 1]}
+    def run(groups, per_call=None):
+        return list(LinkNeighborLoader((fs, gs), num_neighbors=fan, edge_label_index=(etype, eli), batch_size=B,
+                                       neg_sampling=None if mode is None else (mode, amount), shuffle=False, random_state=5,
+                                       call_groups=groups, local_seeds_per_call=per_call))
+    slow, fast = run(False), run(True, B * 4)
+    assert len(slow) == len(fast) == 7
+    for a, b in zip(slow, fast):
+        for nt in ("paper", "author"):
+            assert torch.equal(a[nt].n_id, b[nt].n_id), nt
+            if a[nt].n_id.numel():
+                assert torch.equal(a[nt].x, b[nt].x)
+        for et in fan:
+            assert torch.equal(a[et].edge_index, b[et].edge_index) and torch.equal(a[et].e_id, b[et].e_id), et
+            assert a[et].num_sampled_edges.tolist() == b[et].num_sampled_edges.tolist()
+        assert torch.equal(a[("author", "writes", "paper")].w, b[("author", "writes", "paper")].w)
+        assert torch.equal(a[etype].edge_label_index, b[etype].edge_label_index)
+        assert torch.equal(a[etype].input_id, b[etype].input_id)
+        if mode is not None:
+            assert torch.equal(a[etype].edge_label, b[etype].edge_label)
