@@ -123,3 +123,65 @@ def test_hop_seed_derivation_is_stable():
     assert hop_seed(62, 0) == 62
     assert hop_seed(62, 1) == (62 + 0x9E3779B97F4A7C15) % 2**64
     assert hop_seed(2**64 - 1, 2) == (2**64 - 1 + 2 * 0x9E3779B97F4A7C15) % 2**64
+
+
+def test_batched_first_unique_matches_row_by_row_first_appearance():
+    """link_loader._batched_first_unique (one pass for a whole call group) == per row what append_unique with an empty
+    target list returns: unique ids in first-appearance order + the position of every element in that list."""
+    import torch
+    from cugraph_pyg_amd.loader.link_loader import _batched_first_unique
+    g = torch.Generator().manual_seed(2)
+    for G, S, n_ids in ((1, 1, 5), (3, 17, 6), (8, 64, 1000), (5, 40, 3)):
+        ends = torch.randint(0, n_ids, (G, S), generator=g)
+        uniq, seg, batch, local = _batched_first_unique(ends, n_ids)
+        assert uniq.shape[0] == G * S and batch.shape[0] == G * S and seg.shape[0] == G + 1
+        assert seg.dtype == torch.int32 and batch.dtype == torch.int32
+        for r in range(G):
+            want, seen = [], {}
+            for v in ends[r].tolist():
+                if v not in seen:
+                    seen[v] = len(want)
+                    want.append(v)
+            lo, hi = int(seg[r]), int(seg[r + 1])
+            assert uniq[lo:hi].tolist() == want
+            assert batch[lo:hi].tolist() == [r] * len(want)
+            assert local[r].tolist() == [seen[v] for v in ends[r].tolist()]
+        assert int(seg[G]) <= G * S and bool((uniq[int(seg[G]):] == 0).all())
+
+
+def test_merge_hops_batch_major_is_the_per_batch_concatenation():
+    import torch
+    from wholegraph_amd.fused import _merge_hops_batch_major
+    g = torch.Generator().manual_seed(3)
+    G = 5
+    for H in (1, 2, 3):
+        segs, fields = [], []
+        for h in range(H):
+            cnt = torch.randint(0, 7, (G,), generator=g)
+            seg = [0] + torch.cumsum(cnt, 0).tolist()
+            segs.append(seg)
+            n = seg[-1] + 4                                   # capacity slack behind the live part
+            fields.append([torch.arange(n) + 1000 * h, torch.randint(0, 99, (n,), generator=g)])
+        merged, offs = _merge_hops_batch_major(fields, segs, G, torch.device("cpu"))
+        for i in range(2):
+            for b in range(G):
+                want = torch.cat([fields[h][i][segs[h][b]:segs[h][b + 1]] for h in range(H)])
+                assert torch.equal(merged[i][offs[b]:offs[b + 1]], want)
+        assert offs[G] == sum(s[-1] for s in segs)
+    merged, offs = _merge_hops_batch_major([], [], G, torch.device("cpu"))
+    assert merged == [] and offs == [0] * (G + 1)
+
+
+def test_temporal_negative_redraw_and_fallback():
+    """link_loader._draw_negatives: every pair ends up no later than its seed time (redraws, then the earliest node)."""
+    import torch
+    from cugraph_pyg_amd.loader.link_loader import _draw_negatives
+    gen = torch.Generator().manual_seed(0)
+    node_time = torch.cat([torch.arange(10), torch.full((990,), 10 ** 6)])      # 1 % of the nodes exist early
+    neg_time = torch.randint(0, 12, (500,), generator=gen)
+    src, dst = _draw_negatives(500, 1000, 1000, gen, torch.device("cpu"), neg_time, node_time, node_time)
+    assert bool((node_time[src] <= neg_time).all()) and bool((node_time[dst] <= neg_time).all())
+    src2, dst2 = _draw_negatives(500, 1000, 1000, gen, torch.device("cpu"))    # no times: plain uniform draws
+    assert int(src2.max()) < 1000 and int(dst2.min()) >= 0
+    s3, d3 = _draw_negatives(0, 10, 10, gen, torch.device("cpu"), neg_time[:0], node_time, node_time)
+    assert s3.numel() == 0 and d3.numel() == 0
