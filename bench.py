@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """bench.py — sampled-edges/s of the mini-batch hot path on the ogbn-products-like workload.
 
-One "step" = one mini-batch of 1024 seeds through the whole hot path with everything resident in
-HBM:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->  feature gather
-x = feat[n_id] (fp32, F=100)  ->  2-layer GraphSAGE forward (mean SpMM in HIP + hipBLASLt lin_l/lin_r).
-`value` = sampled edges of all ranks / max-over-ranks wall time of exactly K steps.
+One "step" = `batches_per_step` (default 128) mini-batches of 1024 seeds through the whole hot path with everything
+resident in HBM, processed as `--groups-per-step` (2) CALL GROUPS of `--call-group` (64) mini-batches — the launch shape
+is FIXED and does not depend on --steps:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->
+feature gather x = feat[n_id] (fp32, F=100)  ->  2-layer GraphSAGE forward (mean aggregation + lin_l/lin_r in HIP).
+`value` = sampled edges of all ranks / max-over-ranks wall time of exactly K steps (the driver's `--steps 20 --warmup 5`
+= 40 timed call groups after 10 untimed ones, a steady-state software-pipelined region of ~80 ms).
 
 Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0 with `roofline` (dominant HIP kernel, measured live with HIP
@@ -48,6 +50,7 @@ BATCH = 1024
 FANOUT = [25, 10]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
 MFMA_F32_PEAK_TFPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_16x16x4_f32), dense
+MFMA_BF16_PEAK_TFPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
 def rmat_csr(n_nodes, n_undirected, seed, device, a=0.57, b=0.19, c=0.19):
@@ -273,32 +276,54 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
                       f"(C oracle with OpenMP + torch CPU linear), {dt:.1f} s"}
 
 
+def load_pmc(kernel_prefix, want_void=True):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r02/pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS command's launch shape, FETCH_SIZE x 2 per
+    MI355X_MICROARCH.md §HBM; tools/pmc_summary.py).  Counters cannot be read from inside the timed process."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            pmc = json.load(f)
+        hit = [(k, v) for k, v in pmc["kernels"].items() if k.startswith(kernel_prefix)
+               and (not want_void or "<void" in k or "<long" not in k)]
+        if hit:
+            k, v = max(hit, key=lambda kv: kv[1]["launches"])
+            return {"kernel": k, "bytes": v["traffic_bytes"], "launches": v["launches"],
+                    "source": "profiles/%s/pmc_traffic.json (%s)" % (rnd, ", ".join(pmc["source"]))}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=640)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; one step = --groups-per-step call groups")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the timed region")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="products",
                     help="products = BASELINE configs[1] (the metric's config); papers100m = configs[2] scale on ONE GPU "
                          "(the north-star 10x-vs-CPU statement)")
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--edges", type=int, default=None, help="undirected RMAT edges before symmetrising")
-    ap.add_argument("--call-group", type=int, default=64, help="max mini-batches per launch sequence")
-    ap.add_argument("--feature-placement", choices=["auto", "replicated", "partitioned"], default="auto",
-                    help="N>1: replicate the feature table on every GPU when it is small next to 288 GB of HBM "
-                         "(auto: <= 36 GB), otherwise range-partition it and fetch remote rows by RCCL all-to-all")
+    ap.add_argument("--call-group", type=int, default=64, help="mini-batches per launch sequence (fixed launch shape)")
+    ap.add_argument("--groups-per-step", type=int, default=2, help="call groups per step (batches_per_step = G x this)")
+    ap.add_argument("--feature-placement", choices=["auto", "replicated", "partitioned", "both"], default="auto",
+                    help="N>1: 'replicated' keeps the whole table on every GPU (small next to 288 GB of HBM: no data-path "
+                         "collective); 'partitioned' range-partitions it and fetches remote rows over xGMI (RCCL "
+                         "all-to-all-v, or peer-mapped loads); auto = both for tables <= 36 GB (headline: replicated, "
+                         "the partitioned result is reported next to it), partitioned above")
     ap.add_argument("--host-profile", action="store_true",
                     help="print (stderr) where the HOST spends a call group: enqueueing the walk, enqueueing the forward, blocked")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
     ap.add_argument("--no-overlap", action="store_true", help="run the walk on the main stream (no second HIP stream)")
     ap.add_argument("--layer-kernel", choices=["auto", "fused", "split"], default="auto",
-                    help="auto/fused: every SAGE layer whose shape allows it runs as ONE kernel (neighbour rows -> LDS operand "
-                         "tile -> fp32 MFMA); split: aggregation kernel + library GEMM per layer.  The other one is timed as a "
-                         "variant")
+                    help="auto/fused: every SAGE layer whose shape allows it runs as ONE kernel (neighbour rows -> LDS "
+                         "operand tile -> MFMA); split: aggregation kernel + library GEMM per layer.  The other one is "
+                         "timed as a variant")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                                                             "one-GPU rehearsal of the N>1 control flow in the tests)")
-    ap.add_argument("--share-gpu", action="store_true", help="test aid: every rank uses cuda:0 (with --dist-backend gloo)")
+    ap.add_argument("--share-gpu", action="store_true", help="test aid: every rank uses cuda:0")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes of the other code paths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -323,7 +348,7 @@ def main():
     from wholegraph_amd import WholeMemoryTensor, equal_entry_partition
     from wholegraph_amd import nn as nn_mod
 
-    # ---- synthetic workload (replicated CSR, range-partitioned features) --------------------
+    # ---- synthetic workload (replicated CSR, replicated and/or range-partitioned features) ----
     global FEAT_DIM, CLASSES, FANOUT
     wv, we, FEAT_DIM, CLASSES, FANOUT = WORKLOADS[args.workload]
     L = len(FANOUT)
@@ -331,41 +356,51 @@ def main():
     args.edges = args.edges or we
     row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
     V, E = args.nodes, int(col.shape[0])
-    gfeat = torch.Generator(device=device).manual_seed(100 + rank)
     table_bytes = V * FEAT_DIM * 4
-    partitioned = args.force_partitioned or (world > 1 and (args.feature_placement == "partitioned" or (
-        args.feature_placement == "auto" and table_bytes > (36 << 30))))
-    if not partitioned:
-        # single GPU, or a table that is small next to 288 GB of HBM3E: every GPU keeps the whole table and the
-        # walk + fetch need no collective at all (seeds are the independent units)
-        gfeat.manual_seed(100)
-        feat = WholeMemoryTensor((torch.rand((V, FEAT_DIM), generator=gfeat, device=device) * 2 - 1))
-    elif args.dist_backend == "nccl":
-        # the table is a DISTRIBUTED handle of the library: bucketing, the id / row all-to-all-v (RCCL send/recv groups)
-        # and the row kernels all run inside wholememory_gather (csrc/wg_comm.hip)
-        import wholegraph_amd as wg
-        feat = wg.create_wholememory_tensor(wg.create_group_communicator(), "distributed", "cuda", [V, FEAT_DIM],
-                                            torch.float32, [FEAT_DIM, 1])
-        local = feat.get_local_tensor()[0]
-        local.copy_(torch.rand(tuple(local.shape), generator=gfeat, device=device) * 2 - 1)
-    else:
+    if args.force_partitioned:
+        placements = ["partitioned"]
+    elif world == 1 or args.feature_placement == "replicated":
+        placements = ["replicated"]
+    elif args.feature_placement == "partitioned" or (args.feature_placement == "auto" and table_bytes > (36 << 30)):
+        placements = ["partitioned"]
+    else:           # "both", or auto with a table that is small next to HBM: headline replicated, partitioned beside it
+        placements = ["replicated", "partitioned"]
+
+    def make_table(placement):
+        gfeat = torch.Generator(device=device)
+        if placement == "replicated":
+            # single GPU, or a table that is small next to 288 GB of HBM3E: every GPU keeps the whole table and the
+            # walk + fetch need no collective at all (seeds are the independent units)
+            gfeat.manual_seed(100)
+            return WholeMemoryTensor((torch.rand((V, FEAT_DIM), generator=gfeat, device=device) * 2 - 1))
+        gfeat.manual_seed(100 + rank)
+        if args.dist_backend == "nccl":
+            # the table is a DISTRIBUTED handle of the library: bucketing, the id / row all-to-all-v (RCCL send/recv
+            # groups) or the peer-mapped loads, and the row kernels all run inside wholememory_gather (csrc/wg_comm.hip)
+            import wholegraph_amd as wg
+            t = wg.create_wholememory_tensor(wg.create_group_communicator(), "distributed", "cuda", [V, FEAT_DIM],
+                                             torch.float32, [FEAT_DIM, 1])
+            local = t.get_local_tensor()[0]
+            local.copy_(torch.rand(tuple(local.shape), generator=gfeat, device=device) * 2 - 1)
+            return t
         # torch.distributed pipeline (wholegraph_amd/dist.py); the gloo tests put two ranks on one GPU this way
         offs = equal_entry_partition(V, world)
         local = torch.rand((offs[rank + 1] - offs[rank], FEAT_DIM), generator=gfeat, device=device) * 2 - 1
-        feat = WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)
-    # call group: the largest divisor of --steps not above --call-group
-    G = max(d for d in range(1, min(args.call_group, args.steps) + 1) if args.steps % d == 0)
-    pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap)
-    groups = args.steps // G
+        return WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)
+
+    # ---- step geometry: FIXED launch shape (G mini-batches per call group), independent of --steps ----
+    G, gps = args.call_group, args.groups_per_step
+    groups = args.steps * gps
     # at least 3 untimed call groups: sizes differ from group to group, the caching allocator and the two-stream pipeline
     # are only in steady state after a few of them (--warmup is honoured as a minimum)
-    warm_groups = max((args.warmup + G - 1) // G, 3)
+    warm_groups = max(args.warmup * gps, 3)
     total_groups = groups + warm_groups
     gseed = torch.Generator(device=device).manual_seed(7 + rank)  # every rank its own seed shard
-    need = total_groups * G * BATCH
+    distinct = min(total_groups, 48)           # seed sets are reused round-robin beyond this (RNG seeds still differ)
+    need = distinct * G * BATCH
     reps = (need + V - 1) // V
     order = torch.cat([torch.randperm(V, generator=gseed, device=device) for _ in range(reps)])
-    batches = order[:need].view(total_groups, G * BATCH).contiguous()
+    batches = order[:need].view(distinct, G * BATCH).contiguous()
 
     def barrier():
         if world > 1:
@@ -374,12 +409,12 @@ def main():
 
     host_prof = {"sample_enqueue": 0.0, "forward_enqueue": 0.0, "wait_for_walk": 0.0, "groups": 0}
 
-    def run_groups(first, last, timers=None, sizes=None, mode="split"):
+    def run_groups(pipe, first, last, timers=None, sizes=None, mode="split"):
         """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
-        pending = pipe.sample(batches[first], first)
+        pending = pipe.sample(batches[first % distinct], first)
         for g in range(first, last):
             t0 = time.perf_counter()
-            nxt = pipe.sample(batches[g + 1], g + 1) if g + 1 < last else None
+            nxt = pipe.sample(batches[(g + 1) % distinct], g + 1) if g + 1 < last else None
             t1 = time.perf_counter()
             w0 = pipe.host_wait_s
             _, sz = pipe.forward(*pending, timers=timers, mode=mode)
@@ -391,15 +426,15 @@ def main():
                 sizes.append(sz)
             pending = nxt
 
-    def measure(mode):
-        """warm-up groups, then EXACTLY args.steps mini-batches between barriers; (max seconds over ranks, total edges)"""
-        run_groups(0, warm_groups, mode=mode)
+    def measure(pipe, mode):
+        """warm-up steps, then EXACTLY args.steps steps between barriers; (max seconds over ranks, total edges)"""
+        run_groups(pipe, 0, warm_groups, mode=mode)
         barrier()
         t_start = time.perf_counter()
         szs = []
         for k in host_prof:
             host_prof[k] = 0
-        run_groups(warm_groups, total_groups, sizes=szs, mode=mode)
+        run_groups(pipe, warm_groups, total_groups, sizes=szs, mode=mode)
         barrier()
         secs = time.perf_counter() - t_start
         if args.host_profile and rank == 0:
@@ -416,30 +451,8 @@ def main():
             return float(tmax), float(esum)
         return float(st[0]), float(st[1])
 
-    # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE kernel
-    # (+7 % end to end on the products workload, +12-17 % at papers100M scale); --layer-kernel split keeps the aggregation
-    # kernel + library GEMM pair for every layer
-    fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])
-    head_mode = "fused" if (args.layer_kernel != "split" and fusable) else "split"
-    dt, edges_total = measure(head_mode)
-
-    # variants on the same groups: the other layer kernel, and the feature fetch folded into layer 1
-    variants = {}
-    others = (["split"] if head_mode == "fused" else (["fused"] if fusable else [])) + (
-        [] if partitioned else ["split_fetch"] + (["fused_fetch"] if fusable else []))
-    notes = {"split": "aggregate kernel -> [agg|x_self] in HBM -> hipBLASLt GEMM (two kernels per layer)",
-             "fused": "every SAGE layer the shape allows as ONE kernel (wgamd_sage_layer_fused_f32: neighbour rows -> LDS "
-                      "operand tile -> fp32 MFMA), explicit feature gather kept",
-             "split_fetch": "feature fetch folded into the layer-1 aggregation kernel (wgamd_sage_aggregate_fetch_f32), then GEMM",
-             "fused_fetch": "feature fetch + aggregation + fp32-MFMA transform of layer 1 in ONE kernel "
-                            "(wgamd_sage_layer_fused_f32 reading the feature table through n_id): x = feat[n_id] never exists"}
-    for m in ([] if args.no_variants else others):
-        vs, ve = measure(m)
-        variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
-    fused = variants.get("fused_fetch") or variants.get("split_fetch")
-
-    # ---- per-stage HIP-event timing pass (same pipeline, same stream; after the timed region) --
-    def probe_stages(mode, n_groups):
+    # ---- per-stage HIP-event timing pass (same pipeline, same stream; outside the timed region) --
+    def probe_stages(pipe, mode, n_groups):
         acc, sizes_p = {}, []
         for g in range(warm_groups, warm_groups + n_groups):
             timers = []
@@ -447,7 +460,7 @@ def main():
             ws = pipe.walk_stream if pipe.walk_stream is not None else torch.cuda.current_stream()
             torch.cuda.synchronize()
             w0.record(ws)
-            pend = pipe.sample(batches[g], g)
+            pend = pipe.sample(batches[g % distinct], g)
             w1.record(ws)
             _, sz = pipe.forward(*pend, timers=timers, mode=mode)
             torch.cuda.synchronize()
@@ -457,11 +470,46 @@ def main():
             sizes_p.append(sz)
         return {k: v / n_groups for k, v in acc.items()}, sizes_p      # per call group
 
-    stage_n = min(groups, 20)
-    stage_ms, psizes = probe_stages(head_mode, stage_n)
-    # the BASELINE metric also names the stand-alone SAGEConv SpMM: time it (aggregate kernel + GEMM) when the headline
-    # path runs the layer as one kernel
-    split_ms = probe_stages("split", min(groups, 10))[0] if head_mode != "split" else stage_ms
+    results = {}
+    for placement in placements:
+        partitioned = placement == "partitioned"
+        feat = make_table(placement)
+        pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap)
+        # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
+        # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
+        fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])
+        head_mode = "fused" if (args.layer_kernel != "split" and fusable) else "split"
+        dt, edges_total = measure(pipe, head_mode)
+        # variants on the same groups: the other layer kernel, and the feature fetch folded into layer 1
+        variants = {}
+        others = (["split"] if head_mode == "fused" else (["fused"] if fusable else [])) + (
+            [] if partitioned else ["split_fetch"] + (["fused_fetch"] if fusable else []))
+        notes = {"split": "aggregate kernel -> [agg|x_self] in HBM -> hipBLASLt GEMM (two kernels per layer)",
+                 "fused": "every SAGE layer the shape allows as ONE kernel (wgamd_sage_layer_fused_f32: neighbour rows -> "
+                          "LDS operand tile -> MFMA), explicit feature gather kept",
+                 "split_fetch": "feature fetch folded into the layer-1 aggregation kernel (wgamd_sage_aggregate_fetch_f32), "
+                                "then GEMM",
+                 "fused_fetch": "feature fetch + aggregation + MFMA transform of layer 1 in ONE kernel "
+                                "(wgamd_sage_layer_fused_f32 reading the feature table through n_id): x = feat[n_id] never "
+                                "exists"}
+        for m in ([] if (args.no_variants or placement != placements[0]) else others):
+            vs, ve = measure(pipe, m)
+            variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
+        stage_n = max(10, min(groups, 20))
+        stage_ms, psizes = probe_stages(pipe, head_mode, stage_n)
+        # the BASELINE metric also names the stand-alone SAGEConv SpMM: time it (aggregate kernel + GEMM) when the
+        # headline path runs the layer as one kernel
+        split_ms = probe_stages(pipe, "split", 10)[0] if head_mode != "split" else stage_ms
+        results[placement] = dict(dt=dt, edges=edges_total, variants=variants, stage_ms=stage_ms, psizes=psizes,
+                                  split_ms=split_ms, head_mode=head_mode, stage_n=stage_n, pipe=pipe, feat=feat)
+        if placement != placements[-1]:
+            results[placement]["pipe_dims"] = pipe.dims
+    head = results[placements[0]]
+    pipe, feat = head["pipe"], head["feat"]
+    partitioned = placements[0] == "partitioned"
+    dt, edges_total, variants, stage_ms, psizes, split_ms, head_mode, stage_n = (
+        head[k] for k in ("dt", "edges", "variants", "stage_ms", "psizes", "split_ms", "head_mode", "stage_n"))
+    fused = variants.get("fused_fetch") or variants.get("split_fetch")
     hop_e = [sum(s[2 * k] for s in psizes) / stage_n for k in range(L)]       # edges per call group, seed hop first
     hop_u = [sum(s[2 * k + 1] for s in psizes) / stage_n for k in range(L)]   # unique nodes after each hop
     n_src = hop_u[L - 1]
@@ -470,19 +518,21 @@ def main():
         # algorithmic bytes per launch; b = 8-byte ids, fp32 features
         F = FEAT_DIM
         kernels = {"gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F))}
+        spmm_root = {}
         for j in range(L):
             k = L - 1 - j
             fj = pipe.dims[j]
             n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            # + the root term copied next to the aggregate: one more row read and written per destination
-            kernels[spmm_label(j)] = ("spmm_csr_kernel",
-                                      hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 8) + n_dst * (8 * fj + 8))
+            # STRICT SURVEY §8(d): E(4F+4) + N_dst(4F+8).  The kernel also copies the root row next to the aggregate
+            # (one more row read and written per destination): that term is reported under its own key, never in spmm_GBps
+            kernels[spmm_label(j)] = ("spmm_csr_kernel", hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 8))
+            spmm_root[spmm_label(j)] = n_dst * (8 * fj + 8)
         for j in range(L):   # one-kernel layers: same reads minus the [agg|x_self] round trip, plus the output write
             k = L - 1 - j
             fj, nj = pipe.dims[j], pipe.dims[j + 1]
             n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            kernels["sage_layer%d(fused)" % (j + 1)] = ("sage_layer_fused_kernel",
-                                                        hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
+            kernels["sage_layer%d(fused)" % (j + 1)] = ("sage_layer_fused", hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16)
+                                                        + n_dst * 4 * nj)
         dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
         roofline = None
         if dom is not None:
@@ -493,36 +543,44 @@ def main():
                         "avg_launch_ms": round(stage_ms[dom], 5),
                         "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                   f"{G} mini-batches, averaged over {stage_n} call groups"}
-        if roofline is not None and args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we:
-            # HBM bytes per launch from the PMC passes of gpurun_prof.sh on this exact configuration (separate --pmc runs,
-            # FETCH_SIZE x 2 + WRITE_SIZE; tools/pmc_summary.py), committed under profiles/ — counters cannot be read from
-            # inside the process being timed
-            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
-            if os.path.exists(pmc_path):
-                with open(pmc_path) as f:
-                    pmc = json.load(f)
-                hit = [v for k, v in pmc["kernels"].items()
-                       if k.startswith(roofline["kernel"]) and ("<void" in k or "<long" not in k)]
-                if hit:
-                    roofline["traffic"] = hit[0]["traffic_bytes"]
-                    roofline["traffic_over_algorithmic"] = round(hit[0]["traffic_bytes"] / kernels[dom][1], 3)
-                    roofline["traffic_source"] = "profiles/r01/pmc_traffic.json (" + ", ".join(pmc["source"]) + ")"
-        spmm_gbps = None
+        std_shape = args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we
+        if roofline is not None and std_shape:
+            hit = load_pmc(roofline["kernel"])
+            if hit:
+                roofline["traffic"] = hit["bytes"]
+                roofline["traffic_over_algorithmic"] = round(hit["bytes"] / kernels[dom][1], 3)
+                roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"]
+        spmm_gbps = spmm_root_gbps = spmm_pmc = None
         if SPMM1 in split_ms:
             spmm_gbps = kernels[SPMM1][1] / (split_ms[SPMM1] * 1e-3) / 1e9
+            spmm_root_gbps = (kernels[SPMM1][1] + spmm_root[SPMM1]) / (split_ms[SPMM1] * 1e-3) / 1e9
+            hit = load_pmc("spmm_csr_kernel") if std_shape else None
+            if hit:     # real HBM utilisation of the launch: (2 x FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s
+                spmm_pmc = {"hbm_util": round(hit["bytes"] / (split_ms[SPMM1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "traffic_bytes_per_launch": hit["bytes"], "source": hit["source"] + " kernel " + hit["kernel"]}
         if roofline is not None and dom.startswith("sage_layer"):
-            # one-kernel layer: HBM-side and MFMA-side work of the same launch; the two phases share the SIMD issue port,
-            # so the launch takes about (transform + gather issue), not their max — report the larger fraction as the bound
+            # one-kernel layer: HBM-side and MFMA-side work of the same launch
             j = int(dom[len("sage_layer")]) - 1
             k = L - 1 - j
             n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            tfs = 2.0 * n_dst * 2 * pipe.dims[j] * pipe.dims[j + 1] / (stage_ms[dom] * 1e-3) / 1e12
+            flops = 2.0 * n_dst * 2 * pipe.dims[j] * pipe.dims[j + 1]
+            prec = nn_mod.sage_layer_fused_precision() if hasattr(nn_mod, "sage_layer_fused_precision") else "f32"
             roofline["hbm_frac"] = roofline["frac"]
-            roofline["mfma_TFps"] = round(tfs, 1)
-            roofline["mfma_frac"] = round(tfs / MFMA_F32_PEAK_TFPS, 4)
-            if roofline["mfma_frac"] > roofline["frac"]:
-                roofline.update(bound="mfma", achieved=round(tfs, 1), peak=MFMA_F32_PEAK_TFPS, unit="TFLOP/s",
-                                frac=roofline["mfma_frac"])
+            if prec == "f32":
+                tfs = flops / (stage_ms[dom] * 1e-3) / 1e12
+                roofline["mfma_TFps"] = round(tfs, 1)
+                roofline["mfma_frac"] = round(tfs / MFMA_F32_PEAK_TFPS, 4)
+                roofline["mfma_dtype"] = "f32 (v_mfma_f32_16x16x4_f32)"
+                if roofline["mfma_frac"] > roofline["frac"]:
+                    roofline.update(bound="mfma", achieved=round(tfs, 1), peak=MFMA_F32_PEAK_TFPS, unit="TFLOP/s",
+                                    frac=roofline["mfma_frac"])
+            else:
+                # 3-way bf16 split of both operands, 6 bf16 MFMA products per fp32 product (fp32 accumulate): the matrix
+                # work is 6 x flops on the bf16 pipe (2.5 PFLOP/s dense) -> far from binding, the launch is HBM-bound
+                tfs = 6.0 * flops / (stage_ms[dom] * 1e-3) / 1e12
+                roofline["mfma_TFps"] = round(tfs, 1)
+                roofline["mfma_frac"] = round(tfs / MFMA_BF16_PEAK_TFPS, 4)
+                roofline["mfma_dtype"] = "bf16x3 split (6 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)"
             g_ach = kernels["gather"][1] / (stage_ms["gather"] * 1e-3) / 1e9 if "gather" in stage_ms else None
             if g_ach:
                 roofline["also"] = {"kernel": "row_copy_kernel", "stage": "gather", "bound": "hbm", "achieved": round(g_ach, 1),
@@ -535,13 +593,14 @@ def main():
                 # papers100M-scale table: a lazily-zeroed host array of the same shape (only the gathered
                 # rows' pages are ever touched; values do not matter for the timing)
                 feat_h = np.zeros((V, FEAT_DIM), dtype=np.float32)
-            elif partitioned and world > 1:
+            elif partitioned:
                 feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
             else:
                 feat_h = feat.local_tensor.cpu().numpy()
             weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in pipe.convs]
             cpu = cpu_baseline(row_ptr.cpu().numpy(), col.cpu().numpy(), feat_h, cb, weights, args.cpu_budget)
         wl_name = "RMAT-26" if args.workload == "rmat26" else "ogbn-" + args.workload
+        prec = nn_mod.sage_layer_fused_precision() if hasattr(nn_mod, "sage_layer_fused_precision") else "f32"
         out = {
             "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), %s-like fan-out %s"
                       % (wl_name, FANOUT),
@@ -554,22 +613,31 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int64 ids + f32 features",
+            "dtype": "int64 ids + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
+                                                   " (SAGE lin_l/lin_r product: bf16x3-split MFMA, f32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
                                    "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, %d-layer SAGEConv(mean) %s fwd, "
-                                   "%d mini-batches per launch sequence (call group)"
-                                   % (V, E, FEAT_DIM, " range-partitioned + RCCL all-to-all" if partitioned else
+                                   "step = %d call groups of %d mini-batches"
+                                   % (V, E, FEAT_DIM, " range-partitioned + xGMI feature fetch" if partitioned else
                                       ("" if world == 1 else " replicated per GPU"),
-                                      BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), G),
+                                      BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), gps, G),
                        "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
                        else "dp%d (seeds sharded, no data-path collective)" % world},
             "call_group": G,
+            "batches_per_step": G * gps,
+            "timed_region_ms": round(dt * 1e3, 2),
+            "timed_call_groups": groups,
+            "ms_per_batch": dt / (groups * G) * 1e3,
             "edges_per_batch": dict([("hop%d" % (k + 1), hop_e[k] / G) for k in range(L)] + [("unique_nodes", n_src / G)]),
             "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
             "split_stage_ms_per_call_group": None if split_ms is stage_ms else {k: round(v, 5) for k, v in split_ms.items()},
             "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
             "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
+            "spmm_accounting": "SURVEY.md §8(d) strict: E(4F+4) + N_dst(4F+8) bytes / HIP-event time of the layer-1 "
+                               "aggregation launch (effective bandwidth: part of x is served by L2/MALL)",
+            "spmm_with_root_copy_GBps": None if spmm_root_gbps is None else round(spmm_root_gbps, 1),
+            "spmm_hbm_util_pmc": spmm_pmc,
             "layer_kernel": head_mode,
             "fused_fetch_variant": fused,
             "variants": variants,
@@ -578,6 +646,28 @@ def main():
         }
         if cpu is not None:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
+        if len(placements) > 1 or partitioned:
+            # the north-star exchange path next to the collective-free one: per-GPU xGMI bytes of the feature fetch and the
+            # fraction of the (world-1) x 153 GB/s links it sustains (SURVEY §8(d) all-to-all bytes: n_remote (b + 4F))
+            pr = results["partitioned"]
+            p_e = [sum(s[2 * k] for s in pr["psizes"]) / pr["stage_n"] for k in range(L)]
+            p_src = sum(s[2 * L - 1] for s in pr["psizes"]) / pr["stage_n"]
+            n_remote = p_src * (world - 1) / max(world, 1)
+            a2a = n_remote * (8 + 4 * F)
+            gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
+            gms = pr["stage_ms"].get(gname) if gname else None
+            link_peak = max(world - 1, 1) * 153.0
+            out["placements"] = {
+                "replicated": None if "replicated" not in results else {
+                    "value": results["replicated"]["edges"] / results["replicated"]["dt"],
+                    "ms_per_step": results["replicated"]["dt"] / args.steps * 1e3},
+                "partitioned": {"value": pr["edges"] / pr["dt"], "ms_per_step": pr["dt"] / args.steps * 1e3,
+                                "gather_stage": gname, "gather_ms_per_call_group": None if gms is None else round(gms, 4),
+                                "feature_fetch": feature_fetch_path(pr["feat"])}}
+            out["all_to_all_bytes_per_gpu"] = int(a2a)
+            out["xgmi_frac"] = None if (gms is None or world == 1) else round(a2a / (gms * 1e-3) / 1e9 / link_peak, 4)
+            out["xgmi_peak_GBps"] = link_peak
+            out["edges_per_call_group_partitioned"] = p_e
         # RCCL writes a version banner through C stdio; push it out first so the JSON is the LAST line
         import ctypes
         ctypes.CDLL(None).fflush(None)
@@ -585,6 +675,14 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def feature_fetch_path(feat):
+    """How a partitioned table's remote rows travel (reported, not chosen here)."""
+    try:
+        return feat.fetch_path()
+    except AttributeError:
+        return "all-to-all-v (RCCL send/recv groups)"
 
 
 if __name__ == "__main__":

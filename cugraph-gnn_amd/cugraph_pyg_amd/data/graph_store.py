@@ -134,6 +134,14 @@ class GraphStore(_PygGraphStore):
     def is_homogeneous(self) -> bool:
         return len(self._vertex_offsets) == 1
 
+    @property
+    def _is_single_relation(self) -> bool:
+        """The criterion the reference uses to pick its homogeneous reader (sampler.py:781-785): exactly ONE edge type
+        whose endpoints share a node type.  One node type with several relations is NOT homogeneous for sampling — edge
+        ids restart per relation and the output must keep the relations apart (HeteroData)."""
+        ets = [a.edge_type for a in self.get_all_edge_attrs()]
+        return len(ets) == 1 and ets[0][0] == ets[0][2]
+
     def finalize(self, weight_attr=None, time_attr=None):
         """Build the device CSR now and drop the COO slices; the store is read-only afterwards."""
         if self.__finalized:
@@ -153,6 +161,8 @@ class GraphStore(_PygGraphStore):
     def _set_weight_attr(self, attr):
         """``(feature_store, attr_name)``: edge weights for biased sampling (graph_store.py:430-446)."""
         if attr != self.__weight_attr:
+            if self.__finalized:   # the COO slices are gone: the CSR cannot be rebuilt with another attribute
+                raise NotImplementedError("Modifying a finalized GraphStore is not supported.")
             self.__graph = None
             self.__hetero = None
         self.__weight_attr = attr
@@ -160,6 +170,8 @@ class GraphStore(_PygGraphStore):
     def _set_time_attr(self, attr):
         """``(feature_store, attr_name)``: edge timestamps for temporal sampling (graph_store.py:448-464)."""
         if attr != self.__time_attr:
+            if self.__finalized:
+                raise NotImplementedError("Modifying a finalized GraphStore is not supported.")
             self.__graph = None
             self.__hetero = None
         self.__time_attr = attr

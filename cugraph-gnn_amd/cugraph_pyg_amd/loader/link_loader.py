@@ -130,8 +130,15 @@ class LinkLoader:
                  as_sampler_output: bool = False, **kwargs):
         if not isinstance(data, (list, tuple)) or not isinstance(data[1], GraphStore):
             raise NotImplementedError("Currently can't accept non-cugraph graphs")
+        for name, val in (("filter_per_worker", filter_per_worker), ("custom_cls", custom_cls), ("transform", transform),
+                          ("transform_sampler_output", transform_sampler_output)):
+            if val:           # same notice NodeLoader gives: these hooks are accepted for signature parity, not applied
+                warnings.warn(f"{name} is currently ignored")
+        if kwargs:
+            warnings.warn("ignored LinkLoader arguments: %s" % sorted(kwargs))
         self.__time_attr = time_attr
-        self.__call_groups = bool(call_groups)   # False: one batch at a time through the C-ABI ops (tuning / tests)
+        # False: one batch at a time through the C-ABI ops (tuning / tests); the call-group walk only exists on the GPU
+        self.__call_groups = bool(call_groups) and torch.cuda.is_available()
         # True: yield torch_geometric-style SamplerOutput objects (metadata = (input_id, edge_label_index, edge_label,
         # seed_time), the reference's sampler.py:621-628) instead of Data — what BaseSampler.sample_from_edges hands to a
         # SampleIterator; features are then joined there
@@ -426,7 +433,7 @@ class LinkNeighborLoader(LinkLoader):
             graph_store._set_time_attr((feature_store, time_attr))
         if weight_attr is not None:
             graph_store._set_weight_attr((feature_store, weight_attr))
-        if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
+        if graph_store._is_single_relation and not isinstance(num_neighbors, dict):
             sampler = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
                                       with_replacement=replace, disjoint=disjoint, temporal=is_temporal,
                                       temporal_comparison=temporal_comparison, local_seeds_per_call=local_seeds_per_call)

@@ -40,14 +40,21 @@ class NeighborLoader(NodeLoader):
             # (neighbor_loader.py:173-187)
             graph_store._set_time_attr((feature_store, time_attr))
             if input_time is None:
+                # resolve the seeds the way NodeLoader does: ('type', ids | None), a bare type name, ids, or None
+                nv = graph_store._num_vertices()
                 if isinstance(input_nodes, (tuple, list)) and len(input_nodes) == 2 and isinstance(input_nodes[0], str):
                     in_type, in_nodes = input_nodes
+                elif isinstance(input_nodes, str):
+                    in_type, in_nodes = input_nodes, None
                 else:
-                    in_type, in_nodes = sorted(graph_store._num_vertices().keys())[0], input_nodes
+                    in_type, in_nodes = sorted(nv.keys())[0], input_nodes
+                if in_nodes is None:
+                    import torch
+                    in_nodes = torch.arange(nv[in_type], dtype=torch.int64)
                 input_time = feature_store[in_type, time_attr, None][in_nodes]
         if weight_attr is not None:
             graph_store._set_weight_attr((feature_store, weight_attr))
-        if graph_store.is_homogeneous and not isinstance(num_neighbors, dict):
+        if graph_store._is_single_relation and not isinstance(num_neighbors, dict):
             core = NeighborSampler(graph_store._graph, fanout=num_neighbors, biased=(weight_attr is not None),
                                    with_replacement=replace, disjoint=disjoint, heterogeneous=False,
                                    temporal=is_temporal, temporal_comparison=temporal_comparison,

@@ -52,10 +52,14 @@ class NodeLoader:
             raise ValueError("The number of input nodes is less than the batch size and drop_last is True. "
                              "This will result in all batches being dropped. Either set drop_last to False or "
                              "increase the number of nodes in input_nodes.")
-        if input_type is not None and graph_store.is_homogeneous:
+        if input_type is not None and graph_store._is_single_relation:
             input_nodes = input_nodes + graph_store._vertex_offsets[input_type]   # (0: one vertex type)
-        if input_type is None and not graph_store.is_homogeneous:
-            raise ValueError("heterogeneous graphs need input_nodes=(node_type, ids)")
+        if input_type is None and not graph_store._is_single_relation:
+            # several relations go through the heterogeneous sampler (reference sampler.py:781-785), which needs the
+            # seed type: with one node type it is that type, otherwise the caller has to name it
+            if not graph_store.is_homogeneous:
+                raise ValueError("heterogeneous graphs need input_nodes=(node_type, ids)")
+            input_type = sorted(graph_store._num_vertices().keys())[0]
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         self.__input_data = NodeSamplerInput(
             input_id=torch.arange(len(input_nodes), dtype=torch.int64, device=dev) if input_id is None else input_id,

@@ -482,6 +482,21 @@ def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
 _GROUP_FETCH_BYTES = 4 << 30
 
 
+def _group_fetch_agreed(t, my_bytes: int) -> bool:
+    """One gather for the whole call group, or one per mini-batch?  With a multi-rank tensor every ``t[index]`` is a
+    collective, so the answer must be the SAME on every rank of the tensor's group: the byte count is MAX-reduced over
+    that group first (ranks see different frontier sizes; a per-rank decision would pair one group gather on rank A with
+    G per-batch gathers on rank B and hang or mis-route rows).  Single-rank tensors decide locally."""
+    import torch.distributed as dist
+    group = t.get_comm() if hasattr(t, "get_comm") else None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        worst = torch.tensor([int(my_bytes)], dtype=torch.int64, device=dev)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
+        my_bytes = int(worst.item())
+    return my_bytes <= _GROUP_FETCH_BYTES
+
+
 def _group_attribute_views(feature_store, ctx):
     """Every stored attribute gathered ONCE for a whole call group (``ctx`` of HeteroPygWalk.finalize_batches), split into
     per-batch views; ``None`` for attributes whose group fetch would exceed _GROUP_FETCH_BYTES."""
@@ -496,7 +511,7 @@ def _group_attribute_views(feature_store, ctx):
         row_bytes = torch.empty((), dtype=t.dtype).element_size()
         for d in tuple(t.shape)[1:]:
             row_bytes *= int(d)
-        views[g, attr.attr_name] = None if index.numel() * row_bytes > _GROUP_FETCH_BYTES else torch.split(t[index], sizes)
+        views[g, attr.attr_name] = torch.split(t[index], sizes) if _group_fetch_agreed(t, index.numel() * row_bytes) else None
     return views
 
 
@@ -513,8 +528,8 @@ def group_attribute_views(feature_store, ctx):
         row_bytes = torch.empty((), dtype=t.dtype).element_size()
         for d in tuple(t.shape)[1:]:
             row_bytes *= int(d)
-        views[attr.group_name, attr.attr_name] = (None if index.numel() * row_bytes > _GROUP_FETCH_BYTES
-                                                  else torch.split(t[index], sizes))
+        views[attr.group_name, attr.attr_name] = (torch.split(t[index], sizes)
+                                                  if _group_fetch_agreed(t, index.numel() * row_bytes) else None)
     return views
 
 

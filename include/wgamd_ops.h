@@ -49,7 +49,8 @@ wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
 
 /* Replaces wholegraph_csr_weighted_sample_without_replacement (wholegraph_op.h:61-73):
  * A-Res biased sampling, key_e = log2(u_e)/w_e, keep the M largest keys.  csr_weight
- * FLOAT|DOUBLE[E].  Order inside a seed (unspecified by the reference): key descending. */
+ * FLOAT|DOUBLE[E].  Order inside a seed (unspecified by the reference, whose tests sort per
+ * segment): CSR order of the selected edges; key ties go to the lowest neighbour index. */
 wholememory_error_code_t wholegraph_csr_weighted_sample_without_replacement(
   wholememory_tensor_t wm_csr_row_ptr_tensor,
   wholememory_tensor_t wm_csr_col_ptr_tensor,

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(nproc, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "32", "--warmup", "16",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
            "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--no-variants"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
@@ -28,10 +28,12 @@ def test_two_ranks_on_one_gpu_control_flow(hiplib):
     one = _run(1, ["--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"])
     two = _run(2, ["--dist-backend", "gloo", "--share-gpu"])
     for d, n in ((one, 1), (two, 2)):
-        assert d["n_gpus"] == n and d["steps"] == 32 and d["warmup"] == 16 and d["scaling"] == "weak"
+        assert d["n_gpus"] == n and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
         assert d["unit"] == "sampled-edges/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
         assert d["roofline"]["frac"] > 0 and d["value"] > 0 and d["ms_per_step"] > 0
         assert "workload" in d["config"]
+        # the launch shape is fixed by --call-group / --groups-per-step, never derived from --steps
+        assert d["call_group"] == 16 and d["batches_per_step"] == 32 and d["timed_call_groups"] == 6
     assert two["cpu_baseline"] is None            # timed at N = 1 only
     # whole-job aggregate: both ranks' edges are counted (each rank samples its own seed shard of the same graph)
     e1 = sum(v for k, v in one["edges_per_batch"].items() if k.startswith("hop"))
@@ -39,6 +41,10 @@ def test_two_ranks_on_one_gpu_control_flow(hiplib):
     assert abs(e1 - e2) / e1 < 0.1
     assert 1.6 < (two["value"] * two["ms_per_step"]) / (one["value"] * one["ms_per_step"]) < 2.4
     assert "dp2" in two["config"]["parallelism"]
+    # N > 1 with a small table: the headline is the collective-free replicated placement, the partitioned (exchange)
+    # result is measured in the same run and reported next to it
+    assert set(two["placements"]) == {"replicated", "partitioned"} and two["placements"]["partitioned"]["value"] > 0
+    assert two["all_to_all_bytes_per_gpu"] > 0 and two["xgmi_frac"] > 0
 
 
 def test_partitioned_feature_store_two_ranks(hiplib):
@@ -46,3 +52,4 @@ def test_partitioned_feature_store_two_ranks(hiplib):
     d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--feature-placement", "partitioned"])
     assert "all-to-all" in d["config"]["parallelism"] and d["n_gpus"] == 2
     assert "gather(all-to-all)" in d["stage_ms_per_call_group"]
+    assert d["placements"]["replicated"] is None and d["all_to_all_bytes_per_gpu"] > 0

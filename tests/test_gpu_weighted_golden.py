@@ -35,20 +35,30 @@ def test_weighted_vs_oracle(oracle_mod, hiplib, M, wdtype, col_dtype, seed_dtype
     assert np.array_equal(col[gid], dst)
     exact = np.array_equal(gid, ogid)
     if not exact:
-        # The key uses log1pf/logf: device libm and glibc may differ in the last ulp, which can swap
-        # two near-tied keys at the selection threshold (the reference compares per-seed SETS for the
-        # same reason: tests/wholegraph_torch/ops/test_wholegraph_weighted_sample_without_replacement.py:301-346).
-        # Allow a differing edge only if its key is within 4 ulp-ish of the seed's M-th key.
-        bad = 0
+        # The key uses log1pf/logf: device libm and glibc may differ in the last ulp, which can swap two near-tied keys at
+        # the selection threshold (the reference compares per-seed SETS for the same reason:
+        # tests/wholegraph_torch/ops/test_wholegraph_weighted_sample_without_replacement.py:301-346).  A differing edge is
+        # accepted ONLY if its oracle key AND the key of the edge it displaced are within 4 ulp of the seed's M-th largest
+        # key; the keys of all candidate edges of the seed are recomputed with oracle.weighted_keys (lane j of the seed's
+        # block owns neighbours j, j+B, ... on stream seed_index*B + j; B = 128, or 256 for M > 256).
+        B = 256 if M > 256 else 128
         for i in range(len(seeds)):
-            a, b = set(gid[off[i]:off[i + 1]]), set(ogid[off[i]:off[i + 1]])
+            a, b = set(gid[off[i]:off[i + 1]].tolist()), set(ogid[off[i]:off[i + 1]].tolist())
             if a == b:
                 continue
-            kth = okeys[off[i]:off[i + 1]].min()
-            allk = oracle_mod.weighted_keys  # noqa: F841  (keys of unsampled edges are not returned; bound the count instead)
-            bad += len(a ^ b)
-            assert len(a ^ b) <= 2, f"seed {i}: selections differ by more than one near-tie swap (kth key {kth})"
-        assert bad <= 4
+            start, end = int(row_ptr[seeds[i]]), int(row_ptr[seeds[i] + 1])
+            N = end - start
+            keys = np.empty(N, np.float32)
+            for j in range(min(B, N)):
+                sub = np.int64(np.int32(i * B + j))
+                keys[j::B] = oracle_mod.weighted_keys(4242 + M, int(sub), w[start + j:end:B].astype(np.float32))
+            kth = np.sort(keys)[::-1][M - 1]
+            tol = 4 * np.spacing(np.abs(kth))
+            assert len(a) == len(b)
+            for g_ in a ^ b:
+                k = keys[g_ - start]
+                assert abs(np.float64(k) - np.float64(kth)) <= tol, (
+                    f"seed {i}: edge {g_} differs and its key {k!r} is not within 4 ulp of the M-th key {kth!r}")
     # properties that hold regardless of libm: segment sizes, edges belong to their seed, no repeats, CSR order
     for i in range(len(seeds)):
         seg = gid[off[i]:off[i + 1]]
