@@ -70,21 +70,66 @@ def sage_aggregate_fetch_forward(row_ptr, col, table, src_ids, self_rows, mean=T
     return out
 
 
+_FUSED_PRECISION = "bf16x3"      # "bf16x3": 3-way bf16 split of both operands on the bf16 matrix pipe (fp32-class accuracy,
+#                                  HBM-bound); "f32": exact fp32 MFMA (v_mfma_f32_16x16x4_f32, bound by the fp32 matrix rate)
+_PLANES_CACHE = {}
+
+
+def sage_layer_fused_precision() -> str:
+    return _FUSED_PRECISION
+
+
+def set_sage_layer_fused_precision(mode: str) -> None:
+    global _FUSED_PRECISION
+    assert mode in ("bf16x3", "f32")
+    _FUSED_PRECISION = mode
+
+
+def _pick_precision(F_: int, N: int, precision) -> str:
+    mode = precision or _FUSED_PRECISION
+    if mode == "bf16x3" and not L.lib().wgamd_sage_layer_bf16x3_supported(F_, N):
+        mode = "f32"
+    return mode
+
+
 def sage_layer_fused_supported(F_: int, N: int) -> bool:
-    """Shapes ``wgamd_sage_layer_fused_f32`` is built for (include/wgamd_ext.h)."""
+    """Shapes the one-kernel SAGE layer is built for (include/wgamd_ext.h)."""
     return F_ % 4 == 0 and F_ <= 256 and N in (64, 128, 256)
 
 
 def sage_layer_fused_preferred(F_: int, N: int) -> bool:
     """Shapes where the one-kernel layer beats aggregate kernel + library GEMM: two operand tiles must fit the 160 KB of
-    LDS so that a workgroup can gather one tile while it multiplies the other (2F <= 304)."""
-    return sage_layer_fused_supported(F_, N) and F_ <= 152
+    LDS so that a workgroup can gather one tile while it multiplies the other."""
+    if not sage_layer_fused_supported(F_, N):
+        return False
+    if _FUSED_PRECISION == "bf16x3" and L.lib().wgamd_sage_layer_bf16x3_supported(F_, N):
+        return True
+    return F_ <= 152
 
 
-def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None, out=None):
+def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
+    """``w_t`` [2F, N] fp32 -> the three bf16 planes ``wgamd_sage_layer_fused_bf16x3`` multiplies with (exact 3-way split:
+    hi + mid + lo == w).  Cached per weight tensor and version, so a layer pays for it once per optimizer step."""
+    key = (w_t.data_ptr(), tuple(w_t.shape), w_t.stride(0))
+    hit = _PLANES_CACHE.get(key)
+    if hit is not None and hit[0] == w_t._version:
+        return hit[1]
+    K, N = w_t.shape
+    planes = torch.empty(L.lib().wgamd_sage_weight_planes_bytes(K, N), dtype=torch.uint8, device=w_t.device)
+    L.check(L.lib().wgamd_sage_split_weight_bf16x3(w_t.data_ptr(), w_t.stride(0), K, N, planes.data_ptr(), get_stream()),
+            "wgamd_sage_split_weight_bf16x3")
+    if len(_PLANES_CACHE) > 64:
+        _PLANES_CACHE.clear()
+    _PLANES_CACHE[key] = (w_t._version, planes)
+    return planes
+
+
+def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None, out=None,
+                             precision=None):
     """A whole SAGEConv layer over a sampled hop in ONE kernel: ``act([mean_j X[col_j] | X[self_i]] @ w_t + bias)`` with
     ``X[r] = x[src_ids[r]]`` when ``src_ids`` is given (``x`` is then the global feature table: the feature fetch is fused
-    in too).  ``w_t`` = ``cat([W_l, W_r], 1).t()`` ([2F, N], contiguous).  The ``[n_rows, 2F]`` operand never leaves LDS."""
+    in too).  ``w_t`` = ``cat([W_l, W_r], 1).t()`` ([2F, N], contiguous).  The ``[n_rows, 2F]`` operand never leaves LDS.
+    ``precision``: "bf16x3" (default where the shape allows) or "f32" — see ``_FUSED_PRECISION``."""
     _check_csr(row_ptr, col)
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
@@ -97,6 +142,13 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     if src_ids is not None:
         assert src_ids.is_contiguous()
         ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
+    if sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3":
+        planes = sage_weight_planes(w_t)
+        L.check(L.lib().wgamd_sage_layer_fused_bf16x3(
+            row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
+            self_rows.data_ptr(), int(bool(mean)), planes.data_ptr(), N, None if bias is None else bias.data_ptr(),
+            int(bool(relu)), out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_bf16x3")
+        return out
     L.check(L.lib().wgamd_sage_layer_fused_f32(
         row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
         self_rows.data_ptr(),

@@ -331,6 +331,23 @@ wholememory_error_code_t wgamd_sage_layer_fused_f32(const int* row_ptr, const in
                                                     const float* w_t, int64_t ldw, int N, const float* bias, int relu,
                                                     float* out, int64_t ldo, void* stream);
 
+/* The same layer with the dense product evaluated on the bf16 matrix pipe at fp32 accuracy: both operands are split
+ * exactly into three bf16 pieces (a = a_hi + a_mid + a_lo; 24 = 3 x 8 significand bits) and the six products of weight
+ * >= 2^-16 are accumulated in fp32 (v_mfma_f32_32x32x16_bf16); the dropped terms are <= 2^-23 |a b|, the class of fp32
+ * round-off.  Six bf16 MFMAs cost 6/16 of one fp32 MFMA, which takes the layer from the fp32-MFMA roof to the HBM roof.
+ * `w_planes` is the weight [2F, N] pre-split by wgamd_sage_split_weight_bf16x3 into wgamd_sage_weight_planes_bytes(2F, N)
+ * bytes (do it once per weight update).  Shapes: F % 4 == 0 and small enough for two 32-row tiles of 3 bf16 planes in
+ * 160 KB of LDS (F <= 208), N in {64, 128, 256}: wgamd_sage_layer_bf16x3_supported.  Inf/NaN features give NaN rows. */
+size_t wgamd_sage_weight_planes_bytes(int K, int N);
+int wgamd_sage_layer_bf16x3_supported(int F, int N);
+wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* w_t, int64_t ldw, int K, int N, void* planes,
+                                                        void* stream);
+wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                       int64_t ldx, int64_t x_rows, int F, const void* src_ids,
+                                                       wholememory_dtype_t src_ids_dtype, const int64_t* self_rows, int mean,
+                                                       const void* w_planes, int N, const float* bias, int relu, float* out,
+                                                       int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,11 +145,14 @@ def test_sage_aggregate_fused_feature_fetch(oracle_mod, hiplib):
     assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("F,N", [(100, 256), (128, 256), (64, 64), (256, 128), (4, 128), (36, 256)])
+@pytest.mark.parametrize("F,N", [(100, 256), (128, 256), (64, 64), (256, 128), (4, 128), (36, 256), (208, 128), (104, 64)])
 @pytest.mark.parametrize("with_ids", [False, True])
-def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, with_ids):
-    """wgamd_sage_layer_fused_f32 (gather -> aggregate in LDS -> fp32-MFMA transform, one kernel) against the oracle's
-    sequential fp32 SpMM + an fp64 matmul; and against the two-kernel product path (aggregate kernel + library GEMM)."""
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, with_ids, precision):
+    """The one-kernel SAGE layer (gather -> aggregate in LDS -> MFMA transform) against the oracle's sequential fp32 SpMM +
+    an fp64 matmul, and against the two-kernel product path (aggregate kernel + library GEMM).  precision = "f32":
+    wgamd_sage_layer_fused_f32 (exact fp32 MFMA); "bf16x3": wgamd_sage_layer_fused_bf16x3 (3-way bf16 split of both
+    operands, six bf16 MFMA products per fp32 product, fp32 accumulation) — SAME tolerance, 1e-5 x scale (north_star)."""
     import torch
     from wholegraph_amd import nn
     n_dst, n_src, V = 1000 + F, 2500, 40000     # n_dst not a multiple of the 64-row tile
@@ -164,7 +167,7 @@ def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, 
     cu = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
     for relu in (True, False):
         got = nn.sage_layer_fused_forward(cu(rp), cu(col), cu(table), cu(self_rows), cu(w_t), cu(bias), relu=relu, mean=True,
-                                          src_ids=cu(ids) if with_ids else None).cpu().numpy()
+                                          src_ids=cu(ids) if with_ids else None, precision=precision).cpu().numpy()
         agg = oracle_mod.spmm_csr(rp, col, x_local, mean=True, acc_double=False)
         cat = np.concatenate([agg, x_local[self_rows]], axis=1)
         ref = cat.astype(np.float64) @ w_t.astype(np.float64) + bias
@@ -210,13 +213,22 @@ def test_sage_layer_fused_64bit_offset_path_and_tiny_inputs(hiplib):
         rows = torch.randint(0, n_src, (n_dst,), generator=g, device="cuda")
         w_t = torch.randn((2 * F, N), generator=g, device="cuda") * 0.1
         bias = torch.randn(N, generator=g, device="cuda")
-        a = nn.sage_layer_fused_forward(rp, col, table, rows, w_t, bias, relu=True, src_ids=ids)
+        a = nn.sage_layer_fused_forward(rp, col, table, rows, w_t, bias, relu=True, src_ids=ids, precision="f32")
         b = torch.empty_like(a)
         L.check(L.lib().wgamd_sage_layer_fused_f32(rp.data_ptr(), col.data_ptr() if col.numel() else rp.data_ptr(), n_dst,
                                                    table.data_ptr(), table.stride(0), 0, F, ids.data_ptr(), L.DT_INT,
                                                    rows.data_ptr(), 1, w_t.data_ptr(), w_t.stride(0), N, bias.data_ptr(), 1,
                                                    b.data_ptr(), b.stride(0), get_stream()), "fused")
         assert torch.equal(a, b)
+        # the bf16x3 kernel: 32-bit vs 64-bit row offsets bit-for-bit, and within 1e-5-class distance of the fp32 kernel
+        a3 = nn.sage_layer_fused_forward(rp, col, table, rows, w_t, bias, relu=True, src_ids=ids, precision="bf16x3")
+        b3 = torch.empty_like(a3)
+        L.check(L.lib().wgamd_sage_layer_fused_bf16x3(rp.data_ptr(), col.data_ptr() if col.numel() else rp.data_ptr(), n_dst,
+                                                      table.data_ptr(), table.stride(0), 0, F, ids.data_ptr(), L.DT_INT,
+                                                      rows.data_ptr(), 1, nn.sage_weight_planes(w_t).data_ptr(), N,
+                                                      bias.data_ptr(), 1, b3.data_ptr(), b3.stride(0), get_stream()), "bf16x3")
+        assert torch.equal(a3, b3)
+        torch.testing.assert_close(a3, a, rtol=2e-5, atol=2e-5)
         x = table[ids.long()]
         cat = nn.sage_aggregate_forward(rp, col if col.numel() else torch.zeros(1, dtype=torch.int32, device="cuda")[:0].contiguous(),
                                         x, rows, True) if col.numel() else torch.cat([torch.zeros((n_dst, F), device="cuda"), x[rows]], 1)
@@ -294,3 +306,36 @@ def test_coo_to_csr_matches_torch_formulation(hiplib, n_dst, n_src, E):
     rp_ref, cc_ref = nn._to_csr(ei, n_dst)          # CPU tensors take the torch route
     assert rp.dtype == torch.int32 and cc.dtype == torch.int32
     assert torch.equal(rp.cpu(), rp_ref) and torch.equal(cc.cpu(), cc_ref)
+
+
+def test_bf16x3_split_is_exact_and_product_is_fp32_class(hiplib):
+    """The weight planes of wgamd_sage_split_weight_bf16x3 sum back to the fp32 weight EXACTLY (hi + mid + lo == w, each
+    piece a bf16), zero rows pad K to the 16-wide k-step; and the layer on adversarial magnitudes (1e-30 .. 1e30 mixed
+    signs, long rows past the 10-neighbour window, degree-0 rows) stays within 1e-5 x scale of the fp64 product."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator(device="cuda").manual_seed(5)
+    K, N = 200, 256
+    w_t = (torch.randn((K, N), generator=g, device="cuda") * torch.exp(torch.randn((K, N), generator=g, device="cuda") * 8))
+    planes = nn.sage_weight_planes(w_t).view(torch.int16).view(3, (K + 15) // 16, N, 16)
+    as_f32 = (planes.to(torch.int32) << 16).view(torch.float32)                       # bf16 -> fp32, exact
+    back = as_f32[0].double() + as_f32[1].double() + as_f32[2].double()               # [KS, N, 16]
+    want = torch.zeros(((K + 15) // 16) * 16, N, dtype=torch.float64, device="cuda")
+    want[:K] = w_t.double()
+    assert torch.equal(back.permute(0, 2, 1).reshape(-1, N), want)
+    F, n_dst, n_src = 100, 777, 3000
+    deg = torch.randint(0, 40, (n_dst,), generator=g, device="cuda")
+    deg[::7] = 0
+    rp = torch.zeros(n_dst + 1, dtype=torch.int32, device="cuda")
+    rp[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(0, n_src, (int(rp[-1]),), generator=g, device="cuda", dtype=torch.int32)
+    x = torch.randn((n_src, F), generator=g, device="cuda") * torch.exp(torch.randn((n_src, F), generator=g, device="cuda") * 4)
+    rows = torch.randint(0, n_src, (n_dst,), generator=g, device="cuda")
+    bias = torch.randn(N, generator=g, device="cuda")
+    got = nn.sage_layer_fused_forward(rp, col, x, rows, w_t, bias, relu=False, precision="bf16x3")
+    cat = nn.sage_aggregate_forward(rp, col, x, rows, True)
+    ref = cat.double() @ w_t.double() + bias.double()
+    scale = cat.double().abs() @ w_t.double().abs() + bias.double().abs()
+    assert torch.all((got.double() - ref).abs() <= 1e-5 * scale + 1e-6)
+    # and it is fp32-class, not merely inside the bound: the error is within a few fp32 ulps of the scale
+    assert ((got.double() - ref).abs() / scale).max() < 2e-6
