@@ -531,8 +531,9 @@ def main():
             k = L - 1 - j
             fj, nj = pipe.dims[j], pipe.dims[j + 1]
             n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            kernels["sage_layer%d(fused)" % (j + 1)] = ("sage_layer_fused", hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16)
-                                                        + n_dst * 4 * nj)
+            kname = "sage_layer_mfma_kernel" if (nn_mod.sage_layer_fused_precision() == "bf16x3" and nn_mod.L.lib(
+            ).wgamd_sage_layer_bf16x3_supported(fj, nj)) else "sage_layer_fused_kernel"
+            kernels["sage_layer%d(fused)" % (j + 1)] = (kname, hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
         dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
         roofline = None
         if dom is not None:
@@ -564,7 +565,7 @@ def main():
             k = L - 1 - j
             n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
             flops = 2.0 * n_dst * 2 * pipe.dims[j] * pipe.dims[j + 1]
-            prec = nn_mod.sage_layer_fused_precision() if hasattr(nn_mod, "sage_layer_fused_precision") else "f32"
+            prec = "bf16x3" if roofline["kernel"] == "sage_layer_mfma_kernel" else "f32"
             roofline["hbm_frac"] = roofline["frac"]
             if prec == "f32":
                 tfs = flops / (stage_ms[dom] * 1e-3) / 1e12

@@ -1,28 +1,37 @@
-// One kernel for a whole SAGEConv layer over a sampled hop, HBM-bound by construction:
+// One kernel for a whole SAGEConv layer over a sampled hop, built to be HBM-bound:
 //     out[i, :] = act( [ mean_{j in N(i)} x[j] | x[self(i)] ] @ [W_l | W_r]^T + b )
 // (semantics of torch_geometric.nn.SAGEConv as the reference uses it,
 //  python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59).
 //
 // Why a second one-kernel layer next to wg_sage_fused.hip: that kernel multiplies in exact fp32 on the matrix pipe
 // (v_mfma_f32_16x16x4_f32 = the fp32 VECTOR rate, 157 TF/s), so the layer can never run faster than its ~0.36 ms of
-// fp32 MFMA issue — and the gather team's VALU work queues behind those MFMAs.  Here the fp32 product is evaluated on the
-// bf16 pipe (16x the rate) with a 3-way split of BOTH operands:  a = a_hi + a_mid + a_lo  exactly (an fp32 significand
-// is 24 bits = 3 x 8, each piece is a bf16 by truncation, the residuals are exact in fp32), and
+// fp32 MFMA issue.  Here the fp32 product is evaluated on the bf16 pipe (16x the rate) with a 3-way split of BOTH
+// operands:  a = a_hi + a_mid + a_lo  EXACTLY (an fp32 significand is 24 bits = 3 x 8; each piece is a bf16 by truncation,
+// the residuals are exact in fp32), and
 //     a * b ~= a_hi b_hi + (a_hi b_mid + a_mid b_hi) + (a_mid b_mid + a_hi b_lo + a_lo b_hi)
 // — the six products of weight >= 2^-16, accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped products
-// are <= 2^-23 |a b| in total: the same class as fp32 round-off (checked against the fp64 oracle at 1e-5 x scale like the
-// fp32 kernel, tests/test_gpu_aggregate.py).  Six bf16 MFMAs cost 6/16 of one fp32 MFMA, so the matrix work is ~0.14 ms
-// of issue for the products layer-1 shape and the kernel is bound by its 2.85 GB of HBM traffic.
+// are <= 2^-23 |a b| in total: the class of fp32 round-off (checked against the fp64 oracle at 1e-5 x scale like the
+// fp32 kernel, tests/test_gpu_aggregate.py).  Six bf16 MFMAs cost 6/16 of one fp32 MFMA.
 //
-// Structure (one 512-thread workgroup per CU, persistent over 64-row tiles):
-//   * waves CW..CW+3 are PRODUCERS: they fetch CSR bounds / neighbour ids / neighbour rows with branch-free 16-B loads kept
-//     in a register ring, sum in CSR order (bit-identical to wgamd_sage_aggregate_f32), split the fp32 sums and the self
-//     row into the three bf16 planes and store them to the LDS tile of step s.  Row metadata is software-pipelined ACROSS
-//     tiles (bounds two tiles ahead, neighbour ids one tile ahead, the first rows of the next tile are requested before
-//     the barrier), so the CU's memory queue never drains at a tile boundary.
-//   * waves 0..CW-1 are CONSUMERS (one per SIMD): each owns 64 output columns = 2 x 2 accumulator tiles of 32 x 32 and
-//     multiplies the tile of step s-1: A fragments by ds_read_b128 from the planes, B fragments (the pre-split weight,
-//     L2-resident, laid out so that a wave-load is 1 KiB contiguous) one k-step ahead straight from global memory.
+// Structure (one workgroup per CU, persistent over 64-row tiles, two fp32 operand tiles in LDS):
+//   * 4 PRODUCER waves fetch CSR bounds / neighbour ids / neighbour rows with branch-free 16-B loads kept in a register
+//     ring, sum in CSR order and store the fp32 [mean | self] rows to the LDS tile of step s.  Neighbour slots past a row's
+//     degree are BUFFER loads with an out-of-range offset: the hardware returns zeros without touching memory, so the
+//     sum needs no per-element select.  Row metadata is software-pipelined ACROSS tiles (bounds at the start of the
+//     previous tile, ids half-way, offsets at its end; the first rows of the next tile are requested before the barrier).
+//   * CW = N/64 CONSUMER waves multiply the tile of step s-1: each owns 64 output columns = 2 x 2 accumulator tiles of
+//     32 x 32.  They read fp32 A fragments (2 x ds_read_b128 per row tile and k-step) and do the 3-way split themselves,
+//     in the issue slots under their own MFMAs (an MFMA holds the matrix pipe for 32 cycles but the issue port for ~4);
+//     the weight is pre-split once per update into planes laid out so that a wave-load is 1 KiB contiguous, and its
+//     fragment stream runs two k-steps ahead, continuing across tiles.
+//   * A producer and a consumer wave share each SIMD.  Measured on gfx950 (tools/tune/sage_mfma_harness.cpp, timeline of
+//     s_memtime stamps): they time-slice rather than overlap — while a consumer streams MFMAs the co-resident producer runs
+//     at ~25 % of its stand-alone speed — and the CU's vector-memory pipeline returns data in issue order across waves, so
+//     the consumers' weight fragments (L2 hits) and output stores queue behind the producers' HBM row fetches.  Putting the
+//     roles on different SIMDs (wave rank by HW_REG_HW_ID, `kRolesBySimd`) was tried: the two consumers of a SIMD then
+//     saturate its matrix pipe and the step becomes consumer-bound; it is kept as a switch, off.  What is left on the
+//     table: stand-alone the producers take 0.40 ms (5.6 TB/s of HBM traffic) and the consumers 0.27 ms for the products
+//     layer-1 call group; together 0.63-0.75 ms depending on the box (fp32-MFMA kernel: 0.84 ms).
 //   * one s_barrier per step behind an LDS-only wait (s_waitcnt lgkmcnt(0)): neither side's global loads are drained.
 #include <algorithm>
 #include <cstdlib>
@@ -37,10 +46,13 @@ namespace {
 using f32x4  = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4  = __attribute__((ext_vector_type(4))) uint32_t;
-using u32x2  = __attribute__((ext_vector_type(2))) uint32_t;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+#ifndef WG_MFMA_DEPTH
+#define WG_MFMA_DEPTH 2   // destination rows in flight per producer lane group
+#endif
 constexpr int kProducerWaves = 4;
+constexpr int kRingDepth     = WG_MFMA_DEPTH;
 
 template <typename IdT>
 __device__ __forceinline__ int64_t table_row(const IdT* ids, int64_t local)
@@ -55,6 +67,7 @@ struct mfma_args {
   int64_t n_rows;
   const float* x;
   int64_t ldx;
+  uint32_t x_bytes;          // extent of x when it is below 2 GB (32-bit offsets, buffer loads), else 0
   int F;
   const void* src_ids;
   const int64_t* self_rows;
@@ -66,7 +79,11 @@ struct mfma_args {
   int relu;
   float* out;
   int64_t ldo;
-  int SD;                    // dwords per LDS tile row and plane (>= F, = 4 * odd: conflict-free ds_read_b128)
+  int SD;                    // floats per LDS tile row (>= 2F, = 4 * odd: conflict-free ds_read_b128 across rows)
+  int debug;                 // tuning harness only, bit mask: 1 no consumers, 2 no producers, 4 no output stores,
+                             // 64 roles by SIMD instead of by wave order, 128 no epilogue stagger, 16 / 32 s_setprio 3 for
+                             // producers / consumers
+  unsigned long long* stamps;  // tuning harness only: s_memtime stamps of workgroup 0, [step][wave][begin, work done]
 };
 
 // a == hi + mid + lo exactly; every piece has <= 8 significant bits, i.e. is a bf16 (the top half of the fp32 word)
@@ -81,18 +98,14 @@ __device__ __forceinline__ void split3(float a, uint32_t& h, uint32_t& m, uint32
 // (lo word's bf16, hi word's bf16) -> one dword: bytes {a.2, a.3, b.2, b.3}
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-__device__ __forceinline__ void store_split(uint32_t* plane0, int plane_stride_dw, int dw, f32x4 v)
-{
-  uint32_t h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) split3(v[i], h[i], m[i], l[i]);
-  *reinterpret_cast<u32x2*>(plane0 + dw)                       = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
-  *reinterpret_cast<u32x2*>(plane0 + plane_stride_dw + dw)     = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
-  *reinterpret_cast<u32x2*>(plane0 + 2 * plane_stride_dw + dw) = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
-}
-
 // LDS-only wait + workgroup barrier: in-flight global loads (prefetched rows / weight fragments) and stores stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__host__ __device__ constexpr int row_stride_dw(int F)
+{
+  int sd = (2 * F + 3) / 4 * 4;
+  return (sd / 4) % 2 == 0 ? sd + 4 : sd;   // 4 * odd
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // producer side
@@ -103,8 +116,9 @@ struct bounds_t {
 };
 template <int IT>
 struct ids_t {
+  int deg[IT];     // e - s of the bounds (the bounds die when the ids are requested); -1 = row past n_rows
   int lcol[IT];
-  int64_t lself[IT];
+  int lself[IT];   // self row (a local row of x / src_ids: < 2^31)
 };
 template <int IT, typename off_t>
 struct meta_t {
@@ -120,12 +134,13 @@ struct producer {
   static constexpr int kGroups        = kGroupsPerWave * kProducerWaves;
   static constexpr int IT             = TR / kGroups;       // rows of a tile per lane group
   static constexpr int kNb            = LG < 10 ? LG : 10;  // neighbour rows prefetched per destination row (fan-out 10)
-  static constexpr int kDepth         = IT < 2 ? 1 : 2;     // rows in flight per lane group
+  static constexpr int kDepth         = IT < kRingDepth ? IT : kRingDepth;  // rows in flight per lane group
   static_assert(TR % kGroups == 0, "lane groups must tile the rows evenly");
 
   const mfma_args& a;
   const int sub, gbase, group, f0, f0c;
   const bool live;
+  __amdgpu_buffer_rsrc_t rsrc;   // x as a raw buffer (OFF32): out-of-range offsets read as zero
 
   __device__ producer(const mfma_args& a_, int pw, int lane)
     : a(a_),
@@ -134,13 +149,14 @@ struct producer {
       group(pw * kGroupsPerWave + lane / LG),
       f0((lane & (LG - 1)) * 4),
       f0c(((lane & (LG - 1)) * 4 < a_.F) ? (lane & (LG - 1)) * 4 : a_.F - 4),
-      live((lane & (LG - 1)) * 4 < a_.F)
+      live((lane & (LG - 1)) * 4 < a_.F),
+      rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_.x), 0, (int)a_.x_bytes, 0x00020000))
   {
   }
 
   __device__ __forceinline__ int64_t row_of(int64_t tile, int it) const { return tile * TR + group + it * kGroups; }
 
-  // stage A: CSR bounds (two tiles ahead of the rows being summed)
+  // stage A: CSR bounds of the next tile (requested when a tile starts)
   __device__ __forceinline__ void load_bounds(int64_t tile, bounds_t<IT>& b) const
   {
 #pragma unroll
@@ -151,67 +167,76 @@ struct producer {
       b.e[it]            = a.row_ptr[rowc + 1];
     }
   }
-  // stage B: this lane's neighbour id of every row + the self row ids (one tile ahead); unconditional loads
+  // stage B: this lane's neighbour id of every row + the self row ids (requested half-way through the tile); unconditional
   __device__ __forceinline__ void load_ids(int64_t tile, const bounds_t<IT>& b, ids_t<IT>& v) const
   {
 #pragma unroll
     for (int it = 0; it < IT; it++) {
       const int64_t row = row_of(tile, it);
+      v.deg[it]         = row < a.n_rows ? b.e[it] - b.s[it] : -1;
       const int* pc     = (sub < b.e[it] - b.s[it]) ? a.col + b.s[it] + sub : a.row_ptr;  // row_ptr[0] == 0: a valid row
       v.lcol[it]        = *pc;
-      v.lself[it]       = a.self_rows[row < a.n_rows ? row : a.n_rows - 1];
+      v.lself[it]       = (int)a.self_rows[row < a.n_rows ? row : a.n_rows - 1];
     }
   }
   // stage C: byte offsets (with the id indirection of the fused-fetch variant: one more dependent load)
-  __device__ __forceinline__ void finish(int64_t tile, const bounds_t<IT>& b, const ids_t<IT>& v, meta_t<IT, off_t>& m) const
+  __device__ __forceinline__ void finish(const ids_t<IT>& v, meta_t<IT, off_t>& m) const
   {
     const IdT* src_ids = static_cast<const IdT*>(a.src_ids);
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-      const int64_t row = row_of(tile, it);
-      m.d[it]           = row < a.n_rows ? b.e[it] - b.s[it] : -1;
-      m.src[it]         = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lcol[it]) * a.ldx * 4);
-      m.self[it]        = (off_t)(table_row<IdT>(src_ids, v.lself[it]) * a.ldx * 4);
+      m.d[it]    = v.deg[it];
+      m.src[it]  = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lcol[it]) * a.ldx * 4);
+      m.self[it] = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lself[it]) * a.ldx * 4);
     }
   }
-  // request the kNb neighbour rows + the self row of row `it` (every load unconditional: slots past the degree read row 0)
+  // request the kNb neighbour rows + the self row of row `it`; every load is unconditional
   __device__ __forceinline__ void issue(const meta_t<IT, off_t>& m, int it, f32x4* v) const
   {
-    const char* xb = reinterpret_cast<const char*>(a.x);
+    if constexpr (OFF32) {
+      // slots past the degree (and the self slot of a row past n_rows) get an out-of-range offset: zeros, no memory access
 #pragma unroll
-    for (int k = 0; k < kNb; k++) {
-      const int src_lane = gbase | (k & (LG - 1));
-      off_t off;
-      if constexpr (OFF32) {
-        off = (uint32_t)__shfl((int)m.src[it], src_lane, 64);
-      } else {
-        const int lo = __shfl((int)(m.src[it] & 0xffffffff), src_lane, 64);
-        const int hi = __shfl((int)(m.src[it] >> 32), src_lane, 64);
-        off          = ((int64_t)hi << 32) | (uint32_t)lo;
+      for (int k = 0; k < kNb; k++) {
+        const uint32_t off = (uint32_t)__shfl((int)m.src[it], gbase | (k & (LG - 1)), 64);
+        v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, k < m.d[it] ? off + f0c * 4 : a.x_bytes, 0, 0));
       }
-      off  = k < m.d[it] ? off : (off_t)0;
-      v[k] = *reinterpret_cast<const f32x4*>(xb + off + (off_t)(f0c * 4));
+      v[kNb] = __builtin_bit_cast(
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, m.d[it] >= 0 ? (uint32_t)m.self[it] + f0c * 4 : a.x_bytes, 0, 0));
+    } else {
+      const char* xb = reinterpret_cast<const char*>(a.x);
+#pragma unroll
+      for (int k = 0; k < kNb; k++) {
+        const int src_lane = gbase | (k & (LG - 1));
+        const int lo       = __shfl((int)(m.src[it] & 0xffffffff), src_lane, 64);
+        const int hi       = __shfl((int)((int64_t)m.src[it] >> 32), src_lane, 64);
+        int64_t off        = ((int64_t)hi << 32) | (uint32_t)lo;
+        off                = k < m.d[it] ? off : (int64_t)0;   // slots past the degree read row 0 (L1-resident), masked below
+        v[k]               = *reinterpret_cast<const f32x4*>(xb + off + f0c * 4);
+      }
+      v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? (int64_t)m.self[it] : (int64_t)0) + f0c * 4);
     }
-    v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? m.self[it] : (off_t)0) + (off_t)(f0c * 4));
   }
-  // sum row `it` from its ring slot and store the split planes
-  __device__ __forceinline__ void reduce_store(const meta_t<IT, off_t>& m, int it, const f32x4* v, uint32_t* tile_lds) const
+  // sum row `it` from its ring slot (CSR order) and store [mean | self] as fp32
+  __device__ __forceinline__ void reduce_store(const meta_t<IT, off_t>& m, int it, const f32x4* v, float* tile_lds) const
   {
     const int deg = m.d[it];
     f32x4 acc     = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < kNb; k++) acc += k < deg ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};  // select, never multiply by 0
-    if (a.mean && deg > 0) acc /= (float)deg;   // rows longer than the window are redone by long_rows()
+    for (int k = 0; k < kNb; k++) {
+      if constexpr (OFF32) acc += v[k];                                   // the hardware already zeroed the dead slots
+      else acc += k < deg ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};             // select, never multiply by 0
+    }
+    if (a.mean && deg > 0) acc *= __frcp_rn((float)deg);   // (rows longer than the window are redone by long_rows())
     if (live) {
-      const int r     = group + it * kGroups;
-      uint32_t* prow  = tile_lds + r * a.SD;
-      const int pl_dw = TR * a.SD;
-      store_split(prow, pl_dw, f0 >> 1, acc);
-      store_split(prow, pl_dw, (a.F + f0) >> 1, deg >= 0 ? v[kNb] : f32x4{0.f, 0.f, 0.f, 0.f});
+      float* prow = tile_lds + (group + it * kGroups) * a.SD;
+      f32x4 self  = v[kNb];
+      if constexpr (!OFF32) self = deg >= 0 ? self : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(prow + f0)       = acc;
+      *reinterpret_cast<f32x4*>(prow + a.F + f0) = self;
     }
   }
   // rows longer than the prefetched window (rare: deg > 10): the whole sum again, in CSR order, chunk by chunk
-  __device__ __forceinline__ void long_rows(int64_t tile, const meta_t<IT, off_t>& m, uint32_t* tile_lds) const
+  __device__ __forceinline__ void long_rows(int64_t tile, const meta_t<IT, off_t>& m, float* tile_lds) const
   {
     const IdT* src_ids = static_cast<const IdT*>(a.src_ids);
 #pragma unroll
@@ -237,8 +262,8 @@ struct producer {
         }
       }
       if (live && deg > kNb) {
-        if (a.mean) acc /= (float)deg;
-        store_split(tile_lds + (group + it * kGroups) * a.SD, TR * a.SD, f0 >> 1, acc);
+        if (a.mean) acc *= __frcp_rn((float)deg);
+        *reinterpret_cast<f32x4*>(tile_lds + (group + it * kGroups) * a.SD + f0) = acc;
       }
     }
   }
@@ -248,28 +273,57 @@ struct producer {
 // consumer side: wave cw multiplies the [TR x 2F] tile by columns [64 cw, 64 cw + 64) of the weight
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RT>
-struct frag_t {
-  u32x4 a[RT][3];  // [row tile][plane]
-  u32x4 b[2][3];   // [col tile][plane]
+struct araw_t {
+  f32x4 v[RT][2];  // [row tile][k 0-3 | k 4-7 of this lane's half k-step]
+};
+template <int RT>
+struct afrag_t {
+  u32x4 v[RT][3];  // [row tile][plane]
+};
+struct bfrag_t {
+  u32x4 v[2][3];  // [col tile][plane]
 };
 
 template <int RT>
-__device__ __forceinline__ void load_frags(frag_t<RT>& f, const uint32_t* a_lane, int plane_dw, int sd, const uint32_t* b_lane,
-                                           int64_t b_plane_dw, int n_cols, int ks)
+__device__ __forceinline__ void load_a_raw(araw_t<RT>& f, const float* a_lane, int sd, int ks)
 {
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++)
+  for (int rt = 0; rt < RT; rt++) {
+    f.v[rt][0] = *reinterpret_cast<const f32x4*>(a_lane + rt * 32 * sd + ks * 16);
+    f.v[rt][1] = *reinterpret_cast<const f32x4*>(a_lane + rt * 32 * sd + ks * 16 + 4);
+  }
+}
+// fp32 fragment -> the three bf16 planes (VALU work that issues under the wave's own MFMAs)
+template <int RT>
+__device__ __forceinline__ void split_a(const araw_t<RT>& r, afrag_t<RT>& f)
+{
 #pragma unroll
-    for (int p = 0; p < 3; p++) f.a[rt][p] = *reinterpret_cast<const u32x4*>(a_lane + p * plane_dw + rt * 32 * sd + ks * 8);
+  for (int rt = 0; rt < RT; rt++) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      split3(r.v[rt][0][i], h[i], m[i], l[i]);
+      split3(r.v[rt][1][i], h[4 + i], m[4 + i], l[4 + i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      f.v[rt][0][j] = pack_hi16(h[2 * j], h[2 * j + 1]);
+      f.v[rt][1][j] = pack_hi16(m[2 * j], m[2 * j + 1]);
+      f.v[rt][2][j] = pack_hi16(l[2 * j], l[2 * j + 1]);
+    }
+  }
+}
+__device__ __forceinline__ void load_b(bfrag_t& f, const uint32_t* b_lane, int64_t b_plane_dw, int n_cols, int ks)
+{
 #pragma unroll
   for (int ct = 0; ct < 2; ct++)
 #pragma unroll
     for (int p = 0; p < 3; p++)
-      f.b[ct][p] = *reinterpret_cast<const u32x4*>(b_lane + p * b_plane_dw + ((int64_t)ks * n_cols + ct * 32) * 8);
+      f.v[ct][p] = *reinterpret_cast<const u32x4*>(b_lane + p * b_plane_dw + ((int64_t)ks * n_cols + ct * 32) * 8);
 }
 
 template <int RT>
-__device__ __forceinline__ void mma_frags(f32x16 (&c)[RT][2], const frag_t<RT>& f)
+__device__ __forceinline__ void mma_frags(f32x16 (&c)[RT][2], const afrag_t<RT>& fa, const bfrag_t& fb)
 {
   // smallest terms first; per accumulator tile the six products are independent MFMAs on the same accumulator
   constexpr int pa[6] = {2, 0, 1, 1, 0, 0};
@@ -280,12 +334,56 @@ __device__ __forceinline__ void mma_frags(f32x16 (&c)[RT][2], const frag_t<RT>& 
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int ct = 0; ct < 2; ct++)
-        c[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[rt][pa[t]]),
-                                                            __builtin_bit_cast(bf16x8, f.b[ct][pb[t]]), c[rt][ct], 0, 0, 0);
+        c[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa.v[rt][pa[t]]),
+                                                            __builtin_bit_cast(bf16x8, fb.v[ct][pb[t]]), c[rt][ct], 0, 0, 0);
 }
 
+// ---- epilogue: bias, activation, 16-B stores ---------------------------------------------------------------------------
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane owns one column, so a
+// direct store is 4 B per lane (two 128-B segments per instruction, 64 instructions per wave and tile, each one a slot in
+// the CU's memory pipeline that the producers' row fetches queue behind).  The four registers 4g .. 4g+3 of all lanes are
+// the 8 consecutive rows 8g .. 8g+7 of a row tile: they go through this wave's 2 KiB LDS scratch [8][64] and leave as
+// 16 B per lane, 256 B per row and wave — 16 store instructions of 1 KiB per wave and tile.
+constexpr int kScratchDw = 8 * 64;   // per consumer wave
+
+template <int RT>
+__device__ __forceinline__ void epilogue(const mfma_args& a, f32x16 (&c)[RT][2], int64_t row0, int cw, int lane, float* scratch)
+{
+  const int lm = lane & 31, lh = lane >> 5;
+  float bj[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) bj[ct] = a.bias ? a.bias[cw * 64 + ct * 32 + lm] : 0.f;
+  if (a.debug & 4) {
+    if (c[0][0][0] == 12345.678f) a.out[0] = c[0][1][3] + c[RT - 1][1][5];
+    return;
+  }
+  const bool full = row0 + RT * 32 <= a.n_rows;
+  const int rl = lane >> 4, cl = (lane & 15) * 4;
+  float* obase = a.out + (row0 + rl) * a.ldo + cw * 64 + cl;
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const float v = c[rt][ct][4 * g + jj] + bj[ct];
+          scratch[(jj + 4 * lh) * 64 + ct * 32 + lm] = a.relu ? fmaxf(v, 0.f) : v;
+        }
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (rl + 4 * pass) * 64 + cl);
+        const int r   = rt * 32 + 8 * g + 4 * pass;   // + rl
+        if (full || row0 + r + rl < a.n_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)r * a.ldo) = v;
+      }
+    }
+}
+
+// ---- runtime shape: weight fragments one k-step ahead ------------------------------------------------------------------
 template <int TR>
-__device__ __forceinline__ void consume_tile(const mfma_args& a, int64_t tile, const uint32_t* tile_lds, int cw, int lane)
+__device__ __forceinline__ void consume_tile(const mfma_args& a, int64_t tile, const float* tile_lds, int cw, int lane,
+                                             float* scratch)
 {
   constexpr int RT = TR / 32;
   f32x16 c[RT][2];
@@ -296,117 +394,209 @@ __device__ __forceinline__ void consume_tile(const mfma_args& a, int64_t tile, c
 #pragma unroll
       for (int i = 0; i < 16; i++) c[rt][ct][i] = 0.f;
   const int lm = lane & 31, lh = lane >> 5;
-  const int plane_dw       = TR * a.SD;
-  const uint32_t* a_lane   = tile_lds + lm * a.SD + lh * 4;
+  const float* a_lane      = tile_lds + lm * a.SD + lh * 8;
   const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
   const uint32_t* b_lane   = a.w_planes + ((int64_t)(cw * 64 + lm)) * 8 + lh * 4;
-  frag_t<RT> f0, f1;
-  load_frags<RT>(f0, a_lane, plane_dw, a.SD, b_lane, b_plane_dw, a.N, 0);
+  bfrag_t b0, b1;
+  araw_t<RT> raw;
+  afrag_t<RT> fa;
+  load_b(b0, b_lane, b_plane_dw, a.N, 0);
   for (int ks = 0; ks < a.KS; ks += 2) {
-    if (ks + 1 < a.KS) load_frags<RT>(f1, a_lane, plane_dw, a.SD, b_lane, b_plane_dw, a.N, ks + 1);
-    mma_frags<RT>(c, f0);
+    load_a_raw<RT>(raw, a_lane, a.SD, ks);
+    if (ks + 1 < a.KS) load_b(b1, b_lane, b_plane_dw, a.N, ks + 1);
+    split_a<RT>(raw, fa);
+    mma_frags<RT>(c, fa, b0);
     if (ks + 1 < a.KS) {
-      if (ks + 2 < a.KS) load_frags<RT>(f0, a_lane, plane_dw, a.SD, b_lane, b_plane_dw, a.N, ks + 2);
-      mma_frags<RT>(c, f1);
+      load_a_raw<RT>(raw, a_lane, a.SD, ks + 1);
+      if (ks + 2 < a.KS) load_b(b0, b_lane, b_plane_dw, a.N, ks + 2);
+      split_a<RT>(raw, fa);
+      mma_frags<RT>(c, fa, b1);
     }
   }
-  // epilogue: bias, activation, store.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  const int64_t row0 = tile * TR;
-  float bj[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ct++) bj[ct] = a.bias ? a.bias[cw * 64 + ct * 32 + lm] : 0.f;
-  float* obase = a.out + (row0 + lh * 4) * a.ldo + cw * 64 + lm;
-  if (row0 + TR <= a.n_rows) {
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
-          const float v = c[rt][ct][i] + bj[ct];
-          obase[(int64_t)(rt * 32 + (i & 3) + 8 * (i >> 2)) * a.ldo + ct * 32] = a.relu ? fmaxf(v, 0.f) : v;
-        }
-  } else {
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
-          const int r   = rt * 32 + (i & 3) + 8 * (i >> 2);
-          const float v = c[rt][ct][i] + bj[ct];
-          if (row0 + lh * 4 + r < a.n_rows) obase[(int64_t)r * a.ldo + ct * 32] = a.relu ? fmaxf(v, 0.f) : v;
-        }
-  }
+  epilogue<RT>(a, c, tile * TR, cw, lane, scratch);
 }
 
+// ---- compile-time feature width (the BASELINE shapes): fully unrolled, weight fragments kPD k-steps ahead ---------------
+// The weight is the same for every tile, so its fragment stream simply continues across tiles: the last kPD k-steps of a
+// tile request fragments 0 .. kPD-1 of the NEXT tile into dedicated "head" registers, i.e. before this tile's output stores
+// are issued — waiting for them later never waits for a store (gfx950 retires loads and stores of a wave in order), and the
+// next tile starts multiplying the moment the barrier opens.  Under load a weight fragment takes > 1 us to come back (the
+// CU's memory pipeline is full of the producers' row fetches); two k-steps = 48 MFMAs = ~1500 cycles of cover.
+// With F a constant every LDS address is `lane base + immediate`.  The fp32 fragment of k-step ks+1 is read at the start of
+// k-step ks and split at its end: both overlap the 24 MFMAs of k-step ks.
+constexpr int kPD = 2;
+__host__ __device__ constexpr int b_slot(int ks) { return ks < kPD ? ks : kPD + (ks % kPD); }
+
+template <int TR, int FC>
+struct static_consumer {
+  static constexpr int RT = TR / 32, KSC = (2 * FC + 15) / 16, SD = row_stride_dw(FC);
+  bfrag_t bb[2 * kPD];   // [0, kPD): heads = k-steps 0 .. kPD-1 of a tile; [kPD, 2 kPD): ring for the rest
+  uint32_t b_lane_off;   // bytes
+  f32x16 c[RT][2];       // accumulators of the tile being multiplied / waiting to be stored
+
+  __device__ __forceinline__ void load_b_static(const mfma_args& a, bfrag_t& f, int ks) const
+  {
+    const char* wb       = reinterpret_cast<const char*>(a.w_planes);   // uniform: stays in SGPRs
+    const size_t plane_b = (size_t)KSC * a.N * 32;
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+        f.v[ct][p] = *reinterpret_cast<const u32x4*>(wb + (p * plane_b + ((size_t)ks * a.N + ct * 32) * 32) + b_lane_off);
+  }
+
+  __device__ __forceinline__ void prime(const mfma_args& a, int cw, int lane)
+  {
+    b_lane_off = (uint32_t)(((cw * 64 + (lane & 31)) * 8 + (lane >> 5) * 4) * 4);
+#pragma unroll
+    for (int j = 0; j < kPD; j++) load_b_static(a, bb[j], j);
+  }
+
+  __device__ __forceinline__ void multiply(const mfma_args& a, const float* tile_lds, int lane)
+  {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[rt][ct][i] = 0.f;
+    const float* a_lane = tile_lds + (lane & 31) * SD + (lane >> 5) * 8;
+    araw_t<RT> raw;
+    afrag_t<RT> fa[2];
+    load_a_raw<RT>(raw, a_lane, SD, 0);
+    split_a<RT>(raw, fa[0]);
+#pragma unroll
+    for (int ks = 0; ks < KSC; ks++) {
+      if (ks + 1 < KSC) load_a_raw<RT>(raw, a_lane, SD, ks + 1);
+      mma_frags<RT>(c, fa[ks & 1], bb[b_slot(ks)]);
+      const int nk = ks + kPD;   // the slot just multiplied from (ring) or long since consumed (head) is free again
+      if (nk < KSC) load_b_static(a, bb[b_slot(nk)], nk);
+      else load_b_static(a, bb[nk - KSC], nk - KSC);
+      if (ks + 1 < KSC) split_a<RT>(raw, fa[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distances as written (hoisted loads cost registers)
+    }
+  }
+  __device__ __forceinline__ void store(const mfma_args& a, int64_t tile, int cw, int lane, float* scratch)
+  {
+    epilogue<RT>(a, c, tile * TR, cw, lane, scratch);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
-// CW = N / 64 consumer waves + 4 producer waves; TR = rows per tile (64, or 32 when two 64-row tiles exceed the LDS)
+// CW = N / 64 consumer waves + 4 producer waves; TR = rows per tile; FC = compile-time feature width (0 = runtime a.F)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename IdT, int LG, int TR, int CW, bool OFF32>
+template <typename IdT, int LG, int TR, int CW, bool OFF32, int FC>
 __global__ void __launch_bounds__((CW + kProducerWaves) * 64)
 sage_layer_mfma_kernel(mfma_args a)
 {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [2 tiles][3 planes][TR][SD] + 16 dwords of slack
-  const int tile_dw = 3 * TR * a.SD;
-  // every word the MFMA can touch must be a finite bf16 pair: pad columns, the rows of a tile that is still being
-  // written for the first time, and the few dwords the last k-step reads past a row (times the zero rows of the weight)
-  for (int i = threadIdx.x; i < 2 * tile_dw + 16; i += blockDim.x) lds[i] = 0u;
+  // [2 tiles][TR][SD] fp32 + 16 floats of slack + [CW][8][64] epilogue scratch + role keys
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile_dw = TR * a.SD;
+  // every word the MFMA can touch must be finite: pad columns, the rows of a tile that is still being written for the
+  // first time, and the few floats the last k-step reads past a row (times the zero rows of the weight)
+  for (int i = threadIdx.x; i < 2 * tile_dw + 16; i += blockDim.x) lds[i] = 0.f;   // (scratch and role keys need no init)
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // Optional ROLES BY SIMD (see the header; off): every wave reads its SIMD id (HW_REG_HW_ID bits 5:4), the workgroup ranks
+  // its waves by (SIMD class, wave) and the CW lowest ranks multiply.  Any placement gives exactly CW consumers and 4
+  // producers; the usual 2-waves-per-SIMD placement makes SIMDs 0 and 2 multiply and SIMDs 1 and 3 fetch and sum.
+  int wave = threadIdx.x >> 6;
+  if (a.debug & 64) {
+    uint32_t* keys = reinterpret_cast<uint32_t*>(lds + 2 * tile_dw + 16 + CW * kScratchDw);   // [CW + kProducerWaves]
+    const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);                // HW_ID[5:4]
+    if (lane == 0) keys[wave] = (uint32_t)(((simd & 1) * 2 + (simd >> 1)) * 16 + wave);
+    __syncthreads();
+    const uint32_t mine_key = keys[wave];
+    int rank = 0;
+#pragma unroll
+    for (int w = 0; w < CW + kProducerWaves; w++) rank += keys[w] < mine_key ? 1 : 0;
+    wave = __builtin_amdgcn_readfirstlane(rank);
+    __syncthreads();
+  }
   const int64_t n_tiles = (a.n_rows + TR - 1) / TR;
   const int64_t mine    = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   auto tile_of          = [&](int64_t n) { return (int64_t)blockIdx.x + n * gridDim.x; };
+  auto stamp            = [&](int64_t n, int which) {
+    if (a.stamps && blockIdx.x == 0 && lane == 0 && n < 64) a.stamps[(n * 8 + wave) * 2 + which] = __builtin_readcyclecounter();
+  };
 
   if (wave >= CW) {
+    if (a.debug & 16) __builtin_amdgcn_s_setprio(3);
     using P     = producer<IdT, LG, TR, OFF32>;
     using off_t = typename P::off_t;
     constexpr int IT = P::IT, kNb = P::kNb, kDepth = P::kDepth;
     P p(a, wave - CW, lane);
-    bounds_t<IT> b_next, b_next2;   // bounds of tile n+1, n+2
-    ids_t<IT> i_next;               // neighbour / self ids of tile n+1
+    // metadata of tile n+1 is fetched WHILE tile n is summed, in three dependent stages spread over the tile so that no
+    // stage ever waits: CSR bounds at the start of the tile, neighbour / self ids (they need the bounds) half-way, byte
+    // offsets (they need the ids) at the end.  Bounds and ids are never live together.
+    bounds_t<IT> b_next;
+    ids_t<IT> i_next;
     meta_t<IT, off_t> cur;
     f32x4 buf[kDepth][kNb + 1];
-    // prologue: tile 0 completely, ids of tile 1, bounds of tile 2, first rows of tile 0 in flight
     {
-      bounds_t<IT> b0;
-      ids_t<IT> i0;
-      p.load_bounds(tile_of(0), b0);
-      p.load_bounds(tile_of(1), b_next);
-      p.load_ids(tile_of(0), b0, i0);
-      p.load_bounds(tile_of(2), b_next2);
-      p.finish(tile_of(0), b0, i0, cur);
-      p.load_ids(tile_of(1), b_next, i_next);
+      p.load_bounds(tile_of(0), b_next);
+      p.load_ids(tile_of(0), b_next, i_next);
+      p.finish(i_next, cur);
     }
 #pragma unroll
     for (int it = 0; it < kDepth - 1; it++) p.issue(cur, it, buf[it]);
+    constexpr int kHalf = IT / 2;
     for (int64_t n = 0; n <= mine; n++) {
-      if (n < mine) {
-        uint32_t* tile_lds = lds + (n & 1) * tile_dw;
+      stamp(n, 0);
+      if (n < mine && !(a.debug & 2)) {
+        float* tile_lds = lds + (n & 1) * tile_dw;
+        p.load_bounds(tile_of(n + 1), b_next);
 #pragma unroll
         for (int it = 0; it < IT; it++) {
+          if (it == kHalf) p.load_ids(tile_of(n + 1), b_next, i_next);
           if (it + kDepth - 1 < IT) p.issue(cur, it + kDepth - 1, buf[(it + kDepth - 1) % kDepth]);
           p.reduce_store(cur, it, buf[it % kDepth], tile_lds);
         }
         p.long_rows(tile_of(n), cur, tile_lds);
-        // roll the metadata pipeline one tile forward and put the first rows of tile n+1 in flight BEFORE the barrier
-        meta_t<IT, off_t> nxt;
-        p.finish(tile_of(n + 1), b_next, i_next, nxt);
-        p.load_ids(tile_of(n + 2), b_next2, i_next);
-        b_next = b_next2;
-        p.load_bounds(tile_of(n + 3), b_next2);
-        cur = nxt;
+        // offsets of tile n+1, and its first rows in flight BEFORE the barrier
+        p.finish(i_next, cur);
         if (n + 1 < mine) {
 #pragma unroll
           for (int it = 0; it < kDepth - 1; it++) p.issue(cur, it, buf[it]);
         }
       }
+      stamp(n, 1);
       lds_barrier();
     }
   } else {
-    for (int64_t n = 0; n <= mine; n++) {
-      if (n >= 1) consume_tile<TR>(a, tile_of(n - 1), lds + ((n - 1) & 1) * tile_dw, wave, lane);
-      lds_barrier();
+    if (a.debug & 32) __builtin_amdgcn_s_setprio(3);
+    float* scratch = lds + 2 * tile_dw + 16 + wave * kScratchDw;
+    if constexpr (FC > 0) {
+      static_consumer<TR, FC> cons;
+      cons.prime(a, wave, lane);
+      // Two consumer waves share a SIMD (ranks 2k, 2k+1) and one matrix pipe.  They are kept out of phase: the even one
+      // multiplies a tile and stores it in the same step, the odd one stores the PREVIOUS tile first (its accumulators stay
+      // live across the barrier) and multiplies afterwards — so one wave's epilogue (LDS transpose, stores, waits) runs
+      // under the other wave's MFMAs instead of both idling the pipe together.
+      const bool late = (wave & 1) && !(a.debug & 128);
+      int64_t pending = -1;
+      for (int64_t n = 0; n <= mine; n++) {
+        stamp(n, 0);
+        if (n >= 1 && !(a.debug & 1)) {
+          const float* tile_lds = lds + ((n - 1) & 1) * tile_dw;
+          if (late) {
+            if (pending >= 0) cons.store(a, pending, wave, lane, scratch);
+            cons.multiply(a, tile_lds, lane);
+            pending = tile_of(n - 1);
+          } else {
+            cons.multiply(a, tile_lds, lane);
+            cons.store(a, tile_of(n - 1), wave, lane, scratch);
+          }
+        }
+        stamp(n, 1);
+        lds_barrier();
+      }
+      if (late && pending >= 0) cons.store(a, pending, wave, lane, scratch);
+    } else {
+      for (int64_t n = 0; n <= mine; n++) {
+        if (n >= 1 && !(a.debug & 1)) consume_tile<TR>(a, tile_of(n - 1), lds + ((n - 1) & 1) * tile_dw, wave, lane, scratch);
+        lds_barrier();
+      }
     }
   }
 }
@@ -432,79 +622,79 @@ __global__ void split_weight_kernel(const float* __restrict__ w_t, int64_t ldw, 
   }
 }
 
-__host__ inline int row_stride_dw(int F)
-{
-  int sd = (F + 3) / 4 * 4;      // F dwords hold 2F bf16
-  if ((sd / 4) % 2 == 0) sd += 4;  // sd = 4 * odd
-  return sd;
-}
 constexpr size_t kLdsBudget = 160 * 1024;
-__host__ inline size_t lds_bytes(int F, int TR) { return (size_t)(2 * 3 * TR * row_stride_dw(F) + 16) * 4; }
+__host__ inline size_t lds_bytes(int F, int TR) { return (size_t)(2 * TR * row_stride_dw(F) + 16 + 4 * kScratchDw + 16) * 4; }
 
-template <typename IdT, int LG, int TR, int CW>
-void launch(const mfma_args& a, bool off32, hipStream_t st)
+template <typename IdT, int LG, int TR, int CW, int FC = 0>
+void launch(const mfma_args& a, hipStream_t st)
 {
   int dev = 0, cus = 256;
   WG_HIP_CHECK(hipGetDevice(&dev));
   WG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t n_tiles = (a.n_rows + TR - 1) / TR;
   const size_t lds      = lds_bytes(a.F, TR);
-  const int per_cu      = std::max<int>(1, (int)std::min<size_t>(kLdsBudget / lds, (size_t)(2048 / ((CW + kProducerWaves) * 64))));
-  const int grid        = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus * per_cu));
-  auto go               = [&](auto kern) {
+  // ONE workgroup per CU: the SIMD role split needs the CU to itself (two waves per SIMD)
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus));
+  auto go        = [&](auto kern) {
     if (lds > 64 * 1024)
       WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<grid, (CW + kProducerWaves) * 64, lds, st>>>(a);
     WG_HIP_CHECK(hipGetLastError());
   };
-  if (off32) go(sage_layer_mfma_kernel<IdT, LG, TR, CW, true>);
-  else go(sage_layer_mfma_kernel<IdT, LG, TR, CW, false>);
+  if (a.x_bytes != 0) go(sage_layer_mfma_kernel<IdT, LG, TR, CW, true, FC>);
+  else go(sage_layer_mfma_kernel<IdT, LG, TR, CW, false, FC>);
 }
 
+// the feature width is a compile-time constant for the BASELINE layer shapes (F = 100: products, F = 128: papers100M / mag)
+// with N = 256; every other shape takes the runtime-shape consumer
 template <typename IdT, int LG, int TR>
-void launch_cw(const mfma_args& a, bool off32, hipStream_t st)
+void launch_cw(const mfma_args& a, hipStream_t st)
 {
   switch (a.N / 64) {
-    case 1: launch<IdT, LG, TR, 1>(a, off32, st); break;
-    case 2: launch<IdT, LG, TR, 2>(a, off32, st); break;
-    default: launch<IdT, LG, TR, 4>(a, off32, st); break;
+    case 1: launch<IdT, LG, TR, 1>(a, st); break;
+    case 2: launch<IdT, LG, TR, 2>(a, st); break;
+    default:
+      if constexpr (LG == 32 && TR == 64) {
+        if (a.F == 100) return launch<IdT, LG, TR, 4, 100>(a, st);
+        if (a.F == 128) return launch<IdT, LG, TR, 4, 128>(a, st);
+      }
+      launch<IdT, LG, TR, 4>(a, st);
+      break;
   }
 }
 
-// 64-row tiles whenever two of them fit the LDS (F <= 100), 32-row tiles otherwise; only the (LG, TR) pairs that can
-// occur are instantiated: F <= 64 always fits, F > 128 never does
+// 64-row tiles whenever two of them fit the LDS (F <= 148), 32-row tiles otherwise; only the (LG, TR) pairs that can occur
+// are instantiated: F <= 128 always fits
 template <typename IdT, int LG>
-void launch_tr(const mfma_args& a, bool off32, hipStream_t st)
+void launch_tr(const mfma_args& a, hipStream_t st)
 {
-  const bool fits64 = lds_bytes(a.F, 64) <= kLdsBudget;
-  if constexpr (LG <= 16) {
-    launch_cw<IdT, LG, 64>(a, off32, st);
-  } else if constexpr (LG == 32) {
-    if (fits64) launch_cw<IdT, LG, 64>(a, off32, st);
-    else launch_cw<IdT, LG, 32>(a, off32, st);
+  if constexpr (LG <= 32) {
+    launch_cw<IdT, LG, 64>(a, st);
   } else {
-    launch_cw<IdT, LG, 32>(a, off32, st);
+    if (lds_bytes(a.F, 64) <= kLdsBudget) launch_cw<IdT, LG, 64>(a, st);
+    else launch_cw<IdT, LG, 32>(a, st);
   }
 }
 
 template <typename IdT>
-void launch_groups(const mfma_args& a, bool off32, hipStream_t st)
+void launch_groups(const mfma_args& a, hipStream_t st)
 {
   const int units = a.F / 4;
-  if (units <= 8) launch_tr<IdT, 8>(a, off32, st);
-  else if (units <= 16) launch_tr<IdT, 16>(a, off32, st);
-  else if (units <= 32) launch_tr<IdT, 32>(a, off32, st);
-  else launch_tr<IdT, 64>(a, off32, st);
+  if (units <= 8) launch_tr<IdT, 8>(a, st);
+  else if (units <= 16) launch_tr<IdT, 16>(a, st);
+  else if (units <= 32) launch_tr<IdT, 32>(a, st);
+  else launch_tr<IdT, 64>(a, st);
 }
 
 }  // namespace
 }  // namespace wgamd
 
+#ifndef WG_MFMA_TUNE_HARNESS
 extern "C" size_t wgamd_sage_weight_planes_bytes(int K, int N) { return (size_t)3 * ((K + 15) / 16) * (size_t)N * 32; }
 
 extern "C" int wgamd_sage_layer_bf16x3_supported(int F, int N)
 {
-  return F > 0 && F % 4 == 0 && (N == 64 || N == 128 || N == 256) && wgamd::lds_bytes(F, 32) <= wgamd::kLdsBudget;
+  return F > 0 && F % 4 == 0 && F <= 256 && (N == 64 || N == 128 || N == 256) && wgamd::lds_bytes(F, 32) <= wgamd::kLdsBudget;
 }
 
 extern "C" wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* w_t, int64_t ldw, int K, int N, void* planes,
@@ -534,16 +724,18 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row
     if (n_rows == 0) return;
     WG_REQUIRE_INPUT(row_ptr && col && x && self_rows && w_planes && out, "null pointer");
     if (!wgamd_sage_layer_bf16x3_supported(F, N) || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
-      throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, two 32-row tiles within 160 KB of LDS), N=%d (64, 128 or "
-                            "256), 16-B aligned rows", F, N));
+      throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), N=%d (64, 128 or 256), 16-B aligned rows", F, N));
     WG_REQUIRE_INPUT(ldo >= N, "leading dimension smaller than N");
-    mfma_args a{row_ptr, col, n_rows, x, ldx, F, src_ids, self_rows, mean, static_cast<const uint32_t*>(w_planes), N,
-                (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F)};
-    auto st          = static_cast<hipStream_t>(stream);
-    const bool off32 = x_rows > 0 && (uint64_t)x_rows * (uint64_t)ldx * 4u < (1ull << 32);
-    if (src_ids == nullptr) launch_groups<void>(a, off32, st);
-    else if (src_ids_dtype == WHOLEMEMORY_DT_INT) launch_groups<int32_t>(a, off32, st);
-    else if (src_ids_dtype == WHOLEMEMORY_DT_INT64) launch_groups<int64_t>(a, off32, st);
+    if (ldo % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) throw logic_error("output rows must be 16-B aligned");
+    // x below 2 GB (extent known): 32-bit row offsets and buffer loads whose out-of-range slots read as zero
+    const uint64_t xb = x_rows > 0 ? (uint64_t)x_rows * (uint64_t)ldx * 4u : 0;
+    mfma_args a{row_ptr, col, n_rows, x, ldx, (uint32_t)(xb > 0 && xb < (1ull << 31) ? xb : 0), F, src_ids, self_rows, mean,
+                static_cast<const uint32_t*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr};
+    auto st = static_cast<hipStream_t>(stream);
+    if (src_ids == nullptr) launch_groups<void>(a, st);
+    else if (src_ids_dtype == WHOLEMEMORY_DT_INT) launch_groups<int32_t>(a, st);
+    else if (src_ids_dtype == WHOLEMEMORY_DT_INT64) launch_groups<int64_t>(a, st);
     else throw invalid_input("src_ids must be INT or INT64");
   });
 }
+#endif  // WG_MFMA_TUNE_HARNESS
