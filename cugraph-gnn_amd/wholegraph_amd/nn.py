@@ -72,7 +72,6 @@ def sage_aggregate_fetch_forward(row_ptr, col, table, src_ids, self_rows, mean=T
 
 _FUSED_PRECISION = "bf16x3"      # "bf16x3": 3-way bf16 split of both operands on the bf16 matrix pipe (fp32-class accuracy,
 #                                  HBM-bound); "f32": exact fp32 MFMA (v_mfma_f32_16x16x4_f32, bound by the fp32 matrix rate)
-_PLANES_CACHE = {}
 
 
 def sage_layer_fused_precision() -> str:
@@ -109,18 +108,19 @@ def sage_layer_fused_preferred(F_: int, N: int) -> bool:
 
 def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
     """``w_t`` [2F, N] fp32 -> the three bf16 planes ``wgamd_sage_layer_fused_bf16x3`` multiplies with (exact 3-way split:
-    hi + mid + lo == w).  Cached per weight tensor and version, so a layer pays for it once per optimizer step."""
-    key = (w_t.data_ptr(), tuple(w_t.shape), w_t.stride(0))
-    hit = _PLANES_CACHE.get(key)
-    if hit is not None and hit[0] == w_t._version:
-        return hit[1]
+    hi + mid + lo == w).  Cached ON the weight tensor object together with its version counter, so a layer pays for the
+    split once per optimizer step and the cache can never outlive (or be confused with another tensor at) the same address."""
+    hit = getattr(w_t, "_wgamd_planes", None)
+    if hit is not None and hit[0] == w_t._version and hit[1] == w_t.data_ptr():
+        return hit[2]
     K, N = w_t.shape
     planes = torch.empty(L.lib().wgamd_sage_weight_planes_bytes(K, N), dtype=torch.uint8, device=w_t.device)
     L.check(L.lib().wgamd_sage_split_weight_bf16x3(w_t.data_ptr(), w_t.stride(0), K, N, planes.data_ptr(), get_stream()),
             "wgamd_sage_split_weight_bf16x3")
-    if len(_PLANES_CACHE) > 64:
-        _PLANES_CACHE.clear()
-    _PLANES_CACHE[key] = (w_t._version, planes)
+    try:
+        w_t._wgamd_planes = (w_t._version, w_t.data_ptr(), planes)
+    except AttributeError:      # a tensor subclass without a __dict__: split on every call
+        pass
     return planes
 
 
@@ -142,7 +142,8 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     if src_ids is not None:
         assert src_ids.is_contiguous()
         ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
-    if sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3":
+    if (sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3"
+            and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):      # its epilogue stores 16 B per lane
         planes = sage_weight_planes(w_t)
         L.check(L.lib().wgamd_sage_layer_fused_bf16x3(
             row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
