@@ -97,7 +97,7 @@ class SagePipeline:
         self.nn = nn
         self.device = device
         self.G = G
-        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, torch.int64, G)
+        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, col.dtype, G)   # ids take the CSR's column dtype
         self.feat = feat_table  # WholeMemoryTensor
         g = torch.Generator(device=device).manual_seed(1)
         L = len(FANOUT)
@@ -312,6 +312,10 @@ def main():
                          "collective); 'partitioned' range-partitions it and fetches remote rows over xGMI (RCCL "
                          "all-to-all-v, or peer-mapped loads); auto = both for tables <= 36 GB (headline: replicated, "
                          "the partitioned result is reported next to it), partitioned above")
+    ap.add_argument("--id-dtype", choices=["auto", "int32", "int64"], default="auto",
+                    help="dtype of csr_col / seeds / node ids: auto = int32 when V < 2^31 (the WholeGraph test default, "
+                         "cpp/tests/wholegraph_ops/wholegraph_csr_unweighted_sample_without_replacement_tests.cu:101), else "
+                         "int64 (the cugraph_pyg convention); the other one is timed as the 'ids_int64' variant")
     ap.add_argument("--host-profile", action="store_true",
                     help="print (stderr) where the HOST spends a call group: enqueueing the walk, enqueueing the forward, blocked")
     ap.add_argument("--force-partitioned", action="store_true",
@@ -356,6 +360,12 @@ def main():
     args.edges = args.edges or we
     row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
     V, E = args.nodes, int(col.shape[0])
+    id_dtype = torch.int64 if (args.id_dtype == "int64" or (args.id_dtype == "auto" and V >= (1 << 31))) else torch.int32
+    col64 = col
+    col = col.to(id_dtype)
+    if id_dtype == torch.int64 or args.no_variants or world > 1 or args.workload != "products":
+        del col64
+        col64 = None
     table_bytes = V * FEAT_DIM * 4
     if args.force_partitioned:
         placements = ["partitioned"]
@@ -400,7 +410,7 @@ def main():
     need = distinct * G * BATCH
     reps = (need + V - 1) // V
     order = torch.cat([torch.randperm(V, generator=gseed, device=device) for _ in range(reps)])
-    batches = order[:need].view(distinct, G * BATCH).contiguous()
+    batches = order[:need].view(distinct, G * BATCH).to(id_dtype).contiguous()
 
     def barrier():
         if world > 1:
@@ -495,6 +505,16 @@ def main():
         for m in ([] if (args.no_variants or placement != placements[0]) else others):
             vs, ve = measure(pipe, m)
             variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
+        if col64 is not None and placement == placements[0]:
+            # the same pipeline with int64 ids (csr_col, seeds, node lists): the cugraph_pyg convention
+            pipe64 = SagePipeline(row_ptr, col64, feat, device, G, overlap_walk=not args.no_overlap)
+            b32 = batches
+            batches = b32.to(torch.int64)
+            vs, ve = measure(pipe64, head_mode)
+            variants["ids_int64"] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3,
+                                     "note": "csr_col / seeds / node ids as int64 (headline: int32, V < 2^31)"}
+            batches = b32
+            del pipe64
         stage_n = max(10, min(groups, 20))
         stage_ms, psizes = probe_stages(pipe, head_mode, stage_n)
         # the BASELINE metric also names the stand-alone SAGEConv SpMM: time it (aggregate kernel + GEMM) when the
@@ -515,9 +535,10 @@ def main():
     n_src = hop_u[L - 1]
 
     if rank == 0:
-        # algorithmic bytes per launch; b = 8-byte ids, fp32 features
+        # algorithmic bytes per launch; b = id bytes, fp32 features
         F = FEAT_DIM
-        kernels = {"gather": ("row_copy_kernel", n_src * (8 + 2 * 4 * F))}
+        idb = 4 if id_dtype == torch.int32 else 8
+        kernels = {"gather": ("row_copy_kernel", n_src * (idb + 2 * 4 * F))}
         spmm_root = {}
         for j in range(L):
             k = L - 1 - j
@@ -589,7 +610,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only (rank 0 owns the host cores)
             nb = min(2048, order.numel() // BATCH)   # time-bounded inside cpu_baseline (--cpu-budget seconds)
-            cb = order[: nb * BATCH].view(nb, BATCH).cpu().numpy()  # same seed stream, one mini-batch at a time
+            cb = order[: nb * BATCH].view(nb, BATCH).to(id_dtype).cpu().numpy()  # same seed stream, one mini-batch at a time
             if V * FEAT_DIM * 4 > (8 << 30):
                 # papers100M-scale table: a lazily-zeroed host array of the same shape (only the gathered
                 # rows' pages are ever touched; values do not matter for the timing)
@@ -614,13 +635,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int64 ids + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
+            "dtype": ("int32" if id_dtype == torch.int32 else "int64") + " ids + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
                                                    " (SAGE lin_l/lin_r product: bf16x3-split MFMA, f32 accumulate)"),
             "data": "synthetic",
-            "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR i64/i64 replicated per GPU), "
+            "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR row_ptr i64 / col %s replicated per GPU), "
                                    "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, %d-layer SAGEConv(mean) %s fwd, "
                                    "step = %d call groups of %d mini-batches"
-                                   % (V, E, FEAT_DIM, " range-partitioned + xGMI feature fetch" if partitioned else
+                                   % (V, E, "i32" if id_dtype == torch.int32 else "i64", FEAT_DIM,
+                                      " range-partitioned + xGMI feature fetch" if partitioned else
                                       ("" if world == 1 else " replicated per GPU"),
                                       BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), gps, G),
                        "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
@@ -654,7 +676,7 @@ def main():
             p_e = [sum(s[2 * k] for s in pr["psizes"]) / pr["stage_n"] for k in range(L)]
             p_src = sum(s[2 * L - 1] for s in pr["psizes"]) / pr["stage_n"]
             n_remote = p_src * (world - 1) / max(world, 1)
-            a2a = n_remote * (8 + 4 * F)
+            a2a = n_remote * (idb + 4 * F)
             gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
             gms = pr["stage_ms"].get(gname) if gname else None
             link_peak = max(world - 1, 1) * 153.0

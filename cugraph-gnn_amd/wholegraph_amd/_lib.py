@@ -144,6 +144,10 @@ SYMBOLS = {
     "wholememory_communicator_get_rank": (c_int, [POINTER(c_int), c_void_p]),
     "wholememory_communicator_get_size": (c_int, [POINTER(c_int), c_void_p]),
     "wholememory_communicator_barrier": (c_int, [c_void_p]),
+    "wgamd_get_peer_pointers": (c_int, [POINTER(c_void_p), c_void_p]),
+    "wgamd_ipc_export": (c_int, [c_void_p, c_void_p]),
+    "wgamd_ipc_open": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "wgamd_ipc_close": (c_int, [c_void_p]),
     "wholememory_malloc": (c_int, [POINTER(c_void_p), c_size_t, c_void_p, c_int, c_int, c_size_t, POINTER(c_size_t)]),
     "wholememory_free": (c_int, [c_void_p]),
     "wholememory_get_communicator": (c_int, [POINTER(c_void_p), c_void_p]),

@@ -230,11 +230,27 @@ class DistributedWholeMemoryTensor(object):
         t = self._local_view
         return (t.cpu() if host_view else t), start.value
 
-    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None):
+    def memory_type(self) -> str:
+        import ctypes
+        handle = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(self.c))
+        code = L.lib().wholememory_get_memory_type(handle)
+        return {L.MT_CONTINUOUS: "continuous", L.MT_CHUNKED: "chunked", L.MT_DISTRIBUTED: "distributed",
+                L.MT_HIERARCHY: "hierarchy"}.get(code, "none")
+
+    def fetch_path(self) -> str:
+        """How a remote row reaches this rank (reported by bench.py next to the partitioned result)."""
+        if self.comm.get_size() == 1:
+            return "local rows only (single-rank communicator)"
+        if self.memory_type() in ("chunked", "continuous"):
+            return "peer-mapped loads over xGMI (HIP IPC, one kernel, no host sync)"
+        return "all-to-all-v (RCCL send/recv groups, one host sync)"
+
+    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None, out: torch.Tensor = None):
         assert indice.dim() == 1
         embedding_dim = self._shape[1] if self.dim() == 2 else 1
-        out = torch.empty([indice.shape[0], embedding_dim] if self.dim() == 2 else [indice.shape[0]],
-                          device=indice.device, dtype=force_dtype if force_dtype is not None else self._dtype)
+        if out is None:
+            out = torch.empty([indice.shape[0], embedding_dim] if self.dim() == 2 else [indice.shape[0]],
+                              device=indice.device, dtype=force_dtype if force_dtype is not None else self._dtype)
         w_i, w_o = wrap_torch_tensor(indice), wrap_torch_tensor(out)
         L.check(L.lib().wholememory_gather(self.c, w_i.c, w_o.c, get_wholegraph_env_fns(), get_stream(), -1),
                 "wholememory_gather")

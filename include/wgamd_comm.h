@@ -5,14 +5,19 @@
  * memory_handle.cpp:1393-1745).
  *
  * One process per GPU.  The communicator wraps an RCCL communicator (bootstrap: 128-byte unique id moved
- * by the caller, e.g. torch.distributed.broadcast — comm.py:159-166 of the reference).  The only memory
- * type implemented is WHOLEMEMORY_MT_DISTRIBUTED on WHOLEMEMORY_ML_DEVICE: every rank holds a contiguous
- * range of the entries in its own HBM and remote rows are fetched by all-to-all over xGMI
- * (wholememory_gather / wholememory_scatter accept tensors backed by such a handle).  The CUDA-VMM / IPC /
- * NVSHMEM / host-pinned mappings of the reference (CONTINUOUS, CHUNKED, HIERARCHY) are not reproduced and
- * return WHOLEMEMORY_NOT_SUPPORTED (a world_size-1 communicator accepts CONTINUOUS/CHUNKED as aliases of the
- * single local partition).  RCCL is resolved at run time (dlopen "librccl.so"), so the library loads on a
- * CPU-only box and inside a PyTorch process shares torch's RCCL.
+ * by the caller, e.g. torch.distributed.broadcast — comm.py:159-166 of the reference).  Memory types on
+ * WHOLEMEMORY_ML_DEVICE:
+ *   * WHOLEMEMORY_MT_DISTRIBUTED — every rank holds a contiguous range of the entries in its own HBM and remote rows
+ *     are fetched by all-to-all over xGMI (wholememory_gather / wholememory_scatter accept tensors backed by such a
+ *     handle; one host synchronisation per call);
+ *   * WHOLEMEMORY_MT_CHUNKED / WHOLEMEMORY_MT_CONTINUOUS — the same partition, PEER-MAPPED: available when all ranks share
+ *     a node (wholememory_communicator_support_type_location says so).  Every rank exports its partition through HIP IPC
+ *     and opens its peers'; gather / scatter are then one kernel whose loads / stores cross xGMI directly, with no host
+ *     synchronisation (the reference's mapped path, cpp/src/wholememory_ops/gather_op_impl_mapped.cu:18-67).  There is
+ *     no flat global pointer: a CONTINUOUS handle is addressed like a CHUNKED one (wgamd_get_peer_pointers).
+ * Host-pinned memory, HIERARCHY and NVSHMEM are not reproduced (every table lives in HBM) and return
+ * WHOLEMEMORY_NOT_SUPPORTED.  RCCL is resolved at run time (dlopen "librccl.so"), so the library loads on a CPU-only box
+ * and inside a PyTorch process shares torch's RCCL.  One collective per communicator at a time (as RCCL requires).
  */
 #ifndef WGAMD_COMM_H_
 #define WGAMD_COMM_H_
@@ -57,6 +62,13 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* wholememory_ha
                                             size_t data_granularity,
                                             size_t* rank_entry_partition WGAMD_DEFAULT(NULL));
 wholememory_error_code_t wholememory_free(wholememory_handle_t wholememory_handle);
+/* peer-mapped handles: pointer of every rank's partition as mapped into THIS process (the chunked view of
+ * wholememory_get_global_reference, wholememory.h:300-330); `pointers` has room for world-size entries */
+wholememory_error_code_t wgamd_get_peer_pointers(void** pointers, wholememory_handle_t wholememory_handle);
+/* the HIP IPC steps on their own: a 64-byte handle of a hipMalloc'ed block / mapping one exported by another process */
+wholememory_error_code_t wgamd_ipc_export(void* device_ptr, void* handle64);
+wholememory_error_code_t wgamd_ipc_open(const void* handle64, void** device_ptr);
+wholememory_error_code_t wgamd_ipc_close(void* device_ptr);
 /* wholememory.h:245-330 */
 wholememory_error_code_t wholememory_get_communicator(wholememory_comm_t* comm,
                                                       wholememory_handle_t wholememory_handle);

@@ -28,6 +28,7 @@ WORKER = textwrap.dedent(r"""
     from wholegraph_amd.comm import WholeMemoryCommunicator
     W, rows, dim, n = (int(v) for v in sys.argv[2:6])
     part = [int(v) for v in sys.argv[6].split(",")] if len(sys.argv) > 6 and sys.argv[6] else None
+    mtype = sys.argv[7] if len(sys.argv) > 7 else "distributed"
     tdt, odt = torch.float16, torch.float32
     lib = L.lib()
     uid = L.UniqueId()
@@ -45,7 +46,9 @@ WORKER = textwrap.dedent(r"""
             L.check(lib.wholememory_create_communicator(ctypes.byref(c), uid, r, W), "create_communicator")
             comm = WholeMemoryCommunicator(c.value)
             assert comm.get_rank() == r and comm.get_size() == W
-            t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [rows, dim], tdt, [dim, 1], part)
+            assert comm.support_type_location(mtype, "cuda") and not comm.support_type_location("hierarchy", "cuda")
+            t = wg.create_wholememory_tensor(comm, mtype, "cuda", [rows, dim], tdt, [dim, 1], part)
+            assert ("peer-mapped" in t.fetch_path()) == (mtype != "distributed"), t.fetch_path()
             local, start = t.get_local_tensor()
             offs = np.concatenate([[0], np.cumsum(part)]) if part else np.minimum(
                 np.arange(W + 1) * -(-rows // W), rows)
@@ -58,6 +61,14 @@ WORKER = textwrap.dedent(r"""
             t.scatter(table[torch.from_numpy(mine)].cuda(), torch.from_numpy(mine).int().cuda())
             comm.barrier()
             assert torch.equal(local.cpu(), table[offs[r]:offs[r + 1]]), "scatter landed wrong"
+            if mtype != "distributed":
+                # the chunked view: every rank's partition is addressable from here, mine is my own allocation
+                ptrs = (ctypes.c_void_p * W)()
+                handle = ctypes.c_void_p(lib.wholememory_tensor_get_memory_handle(t.c))
+                L.check(lib.wgamd_get_peer_pointers(ptrs, handle), "wgamd_get_peer_pointers")
+                for q in range(W):
+                    assert (ptrs[q] is not None) == (offs[q + 1] > offs[q]), (q, ptrs[q])
+                assert (ptrs[r] or 0) == (local.data_ptr() if local.numel() else 0)
             # gather with duplicates, negatives, fp16 -> fp32 conversion, a different count on every rank
             k = n + 37 * r if n else (0 if r % 2 == 0 else 5)
             idx = np.random.default_rng(100 + r).integers(0, rows, k)
@@ -129,8 +140,20 @@ def shim():
     (5, 777, 33, 0, "100,200,77,300,100"),  # some ranks gather nothing
     (8, 4096, 100, 4096, ""),
 ])
-def test_world_gt1_threads_over_fake_rccl(shim, W, rows, dim, n, part):
+@pytest.mark.parametrize("mtype", ["distributed", "chunked"])
+def test_world_gt1_threads_over_fake_rccl(shim, W, rows, dim, n, part, mtype):
+    """mtype = "chunked": the PEER-MAPPED memory type (reference: gather_op_impl_mapped.cu:18-67) — same-dtype gather and
+    scatter are one kernel that addresses every rank's partition directly (ranks of one process share the pointers; ranks
+    in different processes map them through HIP IPC, tests/test_gpu_ipc_two_processes.py); a converting gather still
+    goes through the exchange."""
     env = dict(os.environ, WGAMD_RCCL_LIBRARY=shim)
-    p = subprocess.run([sys.executable, "-c", WORKER, ROOT, str(W), str(rows), str(dim), str(n), part],
+    p = subprocess.run([sys.executable, "-c", WORKER, ROOT, str(W), str(rows), str(dim), str(n), part, mtype],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ALL_RANKS_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+def test_continuous_is_peer_mapped_too(shim):
+    env = dict(os.environ, WGAMD_RCCL_LIBRARY=shim)
+    p = subprocess.run([sys.executable, "-c", WORKER, ROOT, "3", "5000", "100", "2000", "", "continuous"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "ALL_RANKS_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
