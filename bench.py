@@ -115,6 +115,8 @@ class SagePipeline:
         self.walk_stream = torch.cuda.Stream(device=device) if overlap_walk else None
         self.host_wait_s = 0.0
         self.distributed = self.feat.is_distributed
+        path = self.feat.fetch_path() if hasattr(self.feat, "fetch_path") else "all-to-all"
+        self.fetch_tag = "peer-mapped" if "peer-mapped" in path else "all-to-all"
         self._bufs = {}
 
     def rows_buffer(self, name, n_rows, n_cols):
@@ -203,7 +205,7 @@ class SagePipeline:
         if fused_fetch:
             x = None          # never materialised: layer 1 reads the feature table through n_id
         elif self.distributed:
-            x = stage("gather(all-to-all)", lambda: self.feat.gather(n_id))
+            x = stage("gather(" + self.fetch_tag + ")", lambda: self.feat.gather(n_id))
         else:
             from wholegraph_amd.tensor import local_gather
             x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id,
@@ -316,6 +318,9 @@ def main():
                     help="dtype of csr_col / seeds / node ids: auto = int32 when V < 2^31 (the WholeGraph test default, "
                          "cpp/tests/wholegraph_ops/wholegraph_csr_unweighted_sample_without_replacement_tests.cu:101), else "
                          "int64 (the cugraph_pyg convention); the other one is timed as the 'ids_int64' variant")
+    ap.add_argument("--partitioned-fetch", choices=["auto", "mapped", "alltoall"], default="auto",
+                    help="how a partitioned table serves remote rows: mapped = peer-mapped partitions (HIP IPC, loads over xGMI "
+                         "in one kernel; single node), alltoall = RCCL all-to-all-v exchange; auto = mapped when available")
     ap.add_argument("--host-profile", action="store_true",
                     help="print (stderr) where the HOST spends a call group: enqueueing the walk, enqueueing the forward, blocked")
     ap.add_argument("--force-partitioned", action="store_true",
@@ -388,8 +393,19 @@ def main():
             # the table is a DISTRIBUTED handle of the library: bucketing, the id / row all-to-all-v (RCCL send/recv
             # groups) or the peer-mapped loads, and the row kernels all run inside wholememory_gather (csrc/wg_comm.hip)
             import wholegraph_amd as wg
-            t = wg.create_wholememory_tensor(wg.create_group_communicator(), "distributed", "cuda", [V, FEAT_DIM],
-                                             torch.float32, [FEAT_DIM, 1])
+            comm = wg.create_group_communicator()
+            # one node: the peer-mapped type (HIP IPC; remote rows are plain loads over xGMI inside ONE gather kernel);
+            # otherwise, or on request, DISTRIBUTED (bucketing + RCCL all-to-all-v)
+            mtype = "distributed"
+            if args.partitioned_fetch != "alltoall" and world > 1 and comm.support_type_location("chunked", "cuda"):
+                mtype = "chunked"
+            try:
+                t = wg.create_wholememory_tensor(comm, mtype, "cuda", [V, FEAT_DIM], torch.float32, [FEAT_DIM, 1])
+            except Exception as e:   # e.g. IPC refused by the platform: the exchange path needs nothing but RCCL
+                if mtype == "distributed" or args.partitioned_fetch == "mapped":
+                    raise
+                print("[bench] peer-mapped table unavailable (%r), using the all-to-all exchange" % (e,), file=sys.stderr)
+                t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [V, FEAT_DIM], torch.float32, [FEAT_DIM, 1])
             local = t.get_local_tensor()[0]
             local.copy_(torch.rand(tuple(local.shape), generator=gfeat, device=device) * 2 - 1)
             return t

@@ -51,5 +51,5 @@ def test_partitioned_feature_store_two_ranks(hiplib):
     """--feature-placement partitioned at N = 2: the all-to-all feature fetch over torch.distributed inside the pipeline."""
     d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--feature-placement", "partitioned"])
     assert "all-to-all" in d["config"]["parallelism"] and d["n_gpus"] == 2
-    assert "gather(all-to-all)" in d["stage_ms_per_call_group"]
+    assert any(k.startswith("gather(") for k in d["stage_ms_per_call_group"])
     assert d["placements"]["replicated"] is None and d["all_to_all_bytes_per_gpu"] > 0

@@ -30,7 +30,7 @@ CHILD = textwrap.dedent(r"""
     # a gather kernel of the library reading the PEER's memory through the mapping
     import wholegraph_amd as wg
     idx = torch.tensor([rows - 1, 0, 7, 7, 3], device="cuda")
-    got = wg.tensor.local_gather(view, idx)
+    got = wg.tensor.local_gather(view, idx, torch.empty((idx.numel(), dim), device="cuda"))
     assert torch.equal(got, want[idx])
     view[5] = -1.0                      # and a store the owner must see
     torch.cuda.synchronize()
