@@ -92,6 +92,56 @@ def hetero_section(dev):
     x = torch.rand((n_src, H * C), generator=g, device=dev)
     a_s, a_d = torch.rand((n_src, H), generator=g, device=dev), torch.rand((n_dst, H), generator=g, device=dev)
     tg = timed(lambda: nn.gat_forward(rp, cc, x, a_s, a_d, H, 0.2, need_alpha=False), events=True)
+    # roofline of the GAT kernel (single pass, online softmax): per edge the source row, its head scores and
+    # the column index; per destination its head scores and the output row
+    E_gat = int(cc.shape[0])
+    gat_bytes = E_gat * (4 * H * C + 4 * H + 4) + n_dst * (4 * H + 4 * H * C + 8)
+    gat_roof = {"bound": "hbm", "kernel": "gat_csr_kernel", "achieved": round(gat_bytes / tg / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(gat_bytes / tg / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": int(gat_bytes), "avg_launch_ms": round(tg * 1e3, 5),
+                "shape": {"E": E_gat, "n_dst": n_dst, "n_src": n_src, "heads": H, "channels": C}}
+    # CPU baseline (rank-0 host cores): the same heterogeneous composition on the C oracle, one mini-batch at a time
+    cpu = None
+    if os.environ.get("WGAMD_BENCH_NO_CPU") != "1":
+        import oracle
+        from cugraph_pyg_amd.sampler.sampler import hop_seed
+        oracle.build()
+        from bench import usable_cpus
+        oracle.set_num_threads(usable_cpus())
+        hg = {et: (gr.row_ptr.cpu().numpy(), gr.col.cpu().numpy()) for et, gr in graphs.items()}
+        etypes = sorted(hg)
+        ntypes = sorted({t for et in etypes for t in (et[0], et[2])})
+        t0, c_edges, c_b = time.perf_counter(), 0, 0
+        seeds_h = seeds.cpu().numpy()
+        while time.perf_counter() - t0 < 8.0 and (c_b + 1) * B <= len(seeds_h):
+            node = {t: np.zeros(0, np.int64) for t in ntypes}
+            node["paper"] = seeds_h[c_b * B:(c_b + 1) * B].astype(np.int64)
+            fstart = {t: 0 for t in ntypes}
+            for h in range(2):
+                begin = {t: len(node[t]) for t in ntypes}
+                for ti, et in enumerate(etypes):
+                    frontier = node[et[2]][fstart[et[2]]:begin[et[2]]]
+                    if len(frontier) == 0:
+                        continue
+                    rp_h, col_h = hg[et]
+                    _, nbr, _, _ = oracle.unweighted_sample(rp_h, col_h, frontier, fanout[et][h], hop_seed(7 + c_b, h * len(etypes) + ti))
+                    node[et[0]], _ = oracle.append_unique(node[et[0]], nbr.astype(np.int64))
+                    c_edges += int(nbr.size)
+                for t in ntypes:
+                    fstart[t] = begin[t]
+            c_b += 1
+        c_dt = time.perf_counter() - t0
+        cpu = {"value": c_edges / c_dt, "unit": "sampled-edges/s", "cores": usable_cpus(), "kind": "port",
+               "sample": f"{c_b} mini-batches of {B} paper seeds, 2-hop [25,10] x 6 edge types on the C oracle (OpenMP), {c_dt:.1f} s"}
+    line = {"metric": "sampled-edges/sec (heterogeneous 2-hop sampling + renumber, ogbn-mag-like) + GATConv edge-softmax",
+            "value": edges / dt, "unit": "sampled-edges/s", "n_gpus": 1, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64 ids + f32 features", "data": "synthetic",
+            "config": {"workload": "ogbn-mag-like hetero: 4 node types (736,389 / 1,134,649 / 8,740 / 59,965), 6 edge types "
+                                   "~35.8 M edges, 2-hop fan-out [25,10] per edge type, batch 1024, call groups of 32; "
+                                   "GATConv 4 heads x 64 on the sampled author-writes-paper relation"},
+            "ms_per_batch": dt / nb * 1e3, "edges_per_batch": edges / nb, "roofline": gat_roof, "cpu_baseline": cpu,
+            "gpu_over_cpu": None if cpu is None else round(edges / dt / cpu["value"], 2)}
+    print(json.dumps(line), flush=True)
     return {"op": "hetero (ogbn-mag-like) call-group sampling, 2-hop [25,10] x 6 edge types, batch 1024",
             "reference": "pylibcugraph.heterogeneous_uniform_neighbor_sample via cugraph_pyg (a14)",
             "ms_per_batch": round(dt / nb * 1e3, 4), "edges_per_s": round(edges / dt, 1),
@@ -108,9 +158,14 @@ def main():
     ap.add_argument("--nodes", type=int, default=V_PRODUCTS)
     ap.add_argument("--edges", type=int, default=E_UNDIRECTED)
     ap.add_argument("--hetero", action="store_true", help="add the ogbn-mag-like heterogeneous loader measurement")
+    ap.add_argument("--hetero-only", action="store_true",
+                    help="BASELINE configs[4] only: print ONE JSON line (metric, roofline of the GAT kernel, cpu_baseline)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench_ops.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", 0)
+    if args.hetero_only:
+        hetero_section(dev)
+        return
     import wholegraph_amd as wg
     from wholegraph_amd import graph_ops, nn, wholegraph_ops
     from wholegraph_amd.tensor import local_gather, local_scatter
