@@ -283,7 +283,8 @@ class LinkLoader:
                 seed_time = _first_occurrence(inverse.long(), torch.cat([t_all, t_all]), uniq.numel())
             node, row, col, edge, nn, ne = neighbor_sample(graph, uniq, self.__sampler.fanout, seed + b,
                                                            self.__sampler.biased, self.__sampler.disjoint, seed_time,
-                                                           self.__sampler.temporal_comparison)
+                                                           self.__sampler.temporal_comparison,
+                                                           getattr(self.__sampler, "with_replacement", False))
             yield self.__emit(node, row, col, edge, nn, ne, ix, inverse.long(), n_pos, n_neg)
 
     def __group(self, perm, seed, b0, g):
@@ -351,7 +352,9 @@ class LinkLoader:
                     seed_time = {src_t: _first_occurrence(inv_src, t_src, seeds[src_t].numel()),
                                  dst_t: _first_occurrence(inv_dst, t_dst, seeds[dst_t].numel())}
             node, row, col, edge, nn, ne = hetero_neighbor_sample(smp.graphs, None, seeds, smp.fanout, seed + b, smp.biased,
-                                                                  seed_time, smp.temporal_comparison)
+                                                                  seed_time, smp.temporal_comparison,
+                                                                  getattr(smp, "disjoint", False),
+                                                                  getattr(smp, "with_replacement", False))
             out = HeteroSamplerOutput(node=node, row=row, col=col, edge=edge,
                                       batch={t: node[t][:v.numel()] for t, v in seeds.items()},
                                       num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},

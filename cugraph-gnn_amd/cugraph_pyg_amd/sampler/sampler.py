@@ -86,7 +86,8 @@ def _temporal_hop(graph: CSRGraph, frontier, frontier_time, fan, seed, biased, c
 
 
 def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int], random_state: int,
-                    biased: bool = False, disjoint: bool = False, seed_time=None, temporal_comparison=None):
+                    biased: bool = False, disjoint: bool = False, seed_time=None, temporal_comparison=None,
+                    with_replacement: bool = False):
     """One mini-batch.  Returns (node, row, col, edge, num_sampled_nodes, num_sampled_edges).
 
     ``disjoint``: every seed grows its own tree and a vertex belongs to at most ONE tree of the batch — the tree of
@@ -119,6 +120,11 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
             keep = graph.weight[gid] > 0
             if not bool(keep.all()):
                 nbr, lid, gid = nbr[keep], lid[keep], gid[keep]
+        elif with_replacement:
+            # `replace=True` (reference: forwarded to libcugraph, distributed_sampler.py:775-792): exactly `fan` picks
+            # per vertex that has neighbours, repeats allowed
+            off, nbr, lid, gid = wholegraph_ops.unweighted_sample_with_replacement(
+                graph.row_ptr, graph.col, frontier, int(fan), hop_seed(random_state, k), True, True)
         else:
             off, nbr, lid, gid = wholegraph_ops.unweighted_sample_without_replacement(
                 graph.row_ptr, graph.col, frontier, int(fan), hop_seed(random_state, k), True, True)
@@ -151,9 +157,13 @@ def neighbor_sample(graph: CSRGraph, seeds: torch.Tensor, fanout: Sequence[int],
     return nodes, cat(rows), cat(cols), cat(edges), num_nodes, num_edges
 
 
-def _one_hop(graph: CSRGraph, frontier, fan, seed, biased):
+def _one_hop(graph: CSRGraph, frontier, fan, seed, biased, with_replacement=False):
     """(neighbours, row index in `frontier`, CSR slot) of one hop on one CSR; zero-weight edges dropped
     for biased sampling."""
+    if with_replacement:
+        off, nbr, lid, gid = wholegraph_ops.unweighted_sample_with_replacement(
+            graph.row_ptr, graph.col, frontier, int(fan), seed, True, True)
+        return nbr, lid, gid
     if biased:
         off, nbr, lid, gid = wholegraph_ops.weighted_sample_without_replacement(
             graph.row_ptr, graph.col, graph.weight, frontier, int(fan), seed, True, True)
@@ -167,7 +177,8 @@ def _one_hop(graph: CSRGraph, frontier, fan, seed, biased):
 
 
 def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, biased: bool = False,
-                           seed_time=None, temporal_comparison=None):
+                           seed_time=None, temporal_comparison=None, disjoint: bool = False,
+                           with_replacement: bool = False):
     """Heterogeneous PyG-style sampling: per hop, for every edge type (src_t, rel, dst_t) in sorted
     order, the frontier vertices of type ``dst_t`` draw up to ``fanout[etype][hop]`` in-neighbours of
     type ``src_t``; vertices first seen during a hop form the next hop's frontier of their type.
@@ -175,6 +186,10 @@ def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, 
     flat ``[hop * num_etypes + etype]`` indexing of the reference's fan-out array
     (loader/neighbor_loader.py:192-201).  Ids are TYPE-LOCAL throughout.  ``seeds`` may also be a dict
     ``{node type: ids}`` (``seed_type`` is then ignored): link prediction seeds both endpoint types at once.
+
+    ``disjoint``: as in ``neighbor_sample`` — every seed grows its own tree across ALL node types, a vertex joins the tree
+    of the first sampled edge that reaches it (edge types in sorted order inside a hop) and edges into another tree's
+    vertex are dropped (trees are numbered over the seed types in sorted order).  ``with_replacement``: ``replace=True``.
 
     Returns (node{type}, row{etype}, col{etype}, edge{etype}, num_sampled_nodes{type}[hops+1],
     num_sampled_edges{etype}[hops])."""
@@ -186,6 +201,12 @@ def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, 
     node = {t: empty() for t in ntypes}
     for t, ids in seed_dict.items():
         node[t] = ids.to(device=dev, dtype=torch.int64)
+    tree = None
+    if disjoint:   # tree id of every vertex of every type; seeds of the (sorted) seed types are numbered consecutively
+        tree, base = {}, 0
+        for t in ntypes:
+            tree[t] = torch.arange(base, base + int(node[t].shape[0]), device=dev)
+            base += int(node[t].shape[0])
     temporal = seed_time is not None
     if temporal:   # seed_time: tensor (single seed type) or {type: tensor}
         st = seed_time if isinstance(seed_time, dict) else {next(iter(seed_dict)): seed_time}
@@ -212,18 +233,26 @@ def hetero_neighbor_sample(graphs, seed_type, seeds, fanout, random_state: int, 
                                               fan, hop_seed(random_state, h * len(etypes) + ti), biased,
                                               temporal_comparison)
             else:
-                nbr, lid, gid = _one_hop(graphs[et], frontier, fan, hop_seed(random_state, h * len(etypes) + ti), biased)
+                nbr, lid, gid = _one_hop(graphs[et], frontier, fan, hop_seed(random_state, h * len(etypes) + ti), biased,
+                                         with_replacement)
             n_old = int(node[src_t].shape[0])
             new_nodes, mapping = graph_ops.append_unique(node[src_t], nbr, need_neighbor_raw_to_unique=True)
-            if temporal and new_nodes.shape[0] > n_old:
-                m = mapping.long()
+            m = mapping.long()
+            src_row = lid.long() + frontier_start[dst_t]
+            if (temporal or disjoint) and new_nodes.shape[0] > n_old:
                 first = torch.full((new_nodes.shape[0] - n_old,), m.shape[0], dtype=torch.int64, device=dev)
                 is_new = m >= n_old
                 first.scatter_reduce_(0, m[is_new] - n_old, torch.arange(m.shape[0], device=dev)[is_new], reduce="amin")
-                node_time[src_t] = torch.cat([node_time[src_t], graphs[et].time[gid[first]]])
+                if temporal:
+                    node_time[src_t] = torch.cat([node_time[src_t], graphs[et].time[gid[first]]])
+                if disjoint:   # the FIRST edge that reaches a new vertex decides its tree
+                    tree[src_t] = torch.cat([tree[src_t], tree[dst_t][src_row[first]]])
             node[src_t] = new_nodes
-            rows[et].append(mapping.long())
-            cols[et].append(lid.long() + frontier_start[dst_t])
+            if disjoint and nbr.shape[0] > 0:
+                keep = tree[src_t][m] == tree[dst_t][src_row]
+                m, src_row, gid, nbr = m[keep], src_row[keep], gid[keep], nbr[keep]
+            rows[et].append(m)
+            cols[et].append(src_row)
             edges[et].append(graphs[et].edge_id[gid])
             num_edges[et].append(int(nbr.shape[0]))
         for t in ntypes:
@@ -244,8 +273,9 @@ class HeteroNeighborSampler:
         self.num_nodes = num_nodes       # {node type: count}, optional (enables the packed renumber table)
         self._walks = {}
         self._positive_weights = None
-        if with_replacement or disjoint:
-            raise NotImplementedError("heterogeneous with_replacement / disjoint sampling are not implemented")
+        if with_replacement and (biased or temporal):
+            raise NotImplementedError("sampling with replacement is uniform and non-temporal")
+        self.with_replacement, self.disjoint = bool(with_replacement), bool(disjoint)
         if temporal and any(g.time is None for g in graphs.values()):
             raise ValueError("temporal sampling needs a time attribute on every edge type (time_attr=...)")
         self.temporal = bool(temporal)
@@ -270,7 +300,7 @@ class HeteroNeighborSampler:
         if self.biased and self._positive_weights is None:
             self._positive_weights = all(bool((g.weight > 0).all()) for g in self.graphs.values())
         biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for v in self.fanout.values() for f in v))
-        return biased_ok and (not self.temporal) and (not getattr(self, "disjoint", False)) and all(
+        return biased_ok and (not self.temporal) and (not self.disjoint) and (not self.with_replacement) and all(
             g.col.dtype == torch.int64 for g in self.graphs.values())
 
     def sample_seed_lists(self, seed_lists, n_batches: int, random_state: int):
@@ -295,7 +325,7 @@ class HeteroNeighborSampler:
         if self.biased and self._positive_weights is None:   # see NeighborSampler.sample_batches
             self._positive_weights = all(bool((g.weight > 0).all()) for g in self.graphs.values())
         biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for v in self.fanout.values() for f in v))
-        fast = biased_ok and (not self.temporal) and seeds.is_cuda and all(
+        fast = biased_ok and (not self.temporal) and (not self.disjoint) and (not self.with_replacement) and seeds.is_cuda and all(
             g.col.dtype == torch.int64 for g in self.graphs.values())
         n_full = n // batch_size if fast else 0
         G = max(1, (self.local_seeds_per_call or 16 * batch_size) // batch_size)
@@ -317,7 +347,8 @@ class HeteroNeighborSampler:
         for bb, start in enumerate(range(n_full * batch_size, n, batch_size), start=n_full):
             yield bb, hetero_neighbor_sample(
                 self.graphs, seed_type, seeds[start:start + batch_size], self.fanout, random_state + bb, self.biased,
-                seed_time[start:start + batch_size] if self.temporal else None, self.temporal_comparison)
+                seed_time[start:start + batch_size] if self.temporal else None, self.temporal_comparison,
+                self.disjoint, self.with_replacement)
 
 
 class NeighborSampler:
@@ -328,8 +359,9 @@ class NeighborSampler:
                  with_replacement: bool = False, disjoint: bool = False, heterogeneous: bool = False,
                  temporal: bool = False, local_seeds_per_call: Optional[int] = None,
                  temporal_comparison: Optional[str] = None, **_ignored):
-        if with_replacement:
-            raise NotImplementedError("sampling with replacement is not implemented (kernels sample without)")
+        if with_replacement and (biased or temporal):
+            raise NotImplementedError("sampling with replacement is uniform and non-temporal")
+        self.with_replacement = bool(with_replacement)
         if heterogeneous:
             raise NotImplementedError("heterogeneous graphs go through HeteroNeighborSampler")
         if temporal and graph.time is None:
@@ -356,7 +388,8 @@ class NeighborSampler:
         if self.biased and self._positive_weights is None:
             self._positive_weights = bool((self.graph.weight > 0).all())
         biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for f in self.fanout))
-        return biased_ok and (not self.disjoint) and (not self.temporal) and all(f > 0 for f in self.fanout)
+        return (biased_ok and (not self.disjoint) and (not self.temporal) and (not self.with_replacement)
+                and all(f > 0 for f in self.fanout))
 
     def sample_seed_lists(self, seeds: torch.Tensor, seed_seg: torch.Tensor, seed_batch: torch.Tensor, max_seeds: int,
                           n_batches: int, random_state: int):
@@ -386,7 +419,8 @@ class NeighborSampler:
         if self.biased and self._positive_weights is None:
             self._positive_weights = bool((self.graph.weight > 0).all())
         biased_ok = (not self.biased) or (self._positive_weights and all(f <= 256 for f in self.fanout))
-        fast = biased_ok and (not self.disjoint) and (not self.temporal) and all(f > 0 for f in self.fanout) and seeds.is_cuda
+        fast = (biased_ok and (not self.disjoint) and (not self.temporal) and (not self.with_replacement)
+                and all(f > 0 for f in self.fanout) and seeds.is_cuda)
         n_full = n // batch_size if fast else 0
         per_call = self.local_seeds_per_call or 16 * batch_size
         G = max(1, per_call // batch_size)
@@ -408,7 +442,7 @@ class NeighborSampler:
             yield bb, neighbor_sample(self.graph, seeds[start:start + batch_size], self.fanout, random_state + bb,
                                       self.biased, self.disjoint,
                                       seed_time[start:start + batch_size] if self.temporal else None,
-                                      self.temporal_comparison)
+                                      self.temporal_comparison, self.with_replacement)
 
 
 class BaseSampler:

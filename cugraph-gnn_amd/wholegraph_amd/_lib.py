@@ -126,6 +126,8 @@ SYMBOLS = {
     # wgamd_ops.h
     "wholegraph_csr_unweighted_sample_without_replacement":
         (c_int, [_T, _T, _T, c_int, _T, c_void_p, c_void_p, c_void_p, c_ulonglong, POINTER(EnvFns), c_void_p]),
+    "wgamd_csr_uniform_sample_with_replacement":
+        (c_int, [_T, _T, _T, c_int, _T, c_void_p, c_void_p, c_void_p, c_ulonglong, POINTER(EnvFns), c_void_p]),
     "wholegraph_csr_weighted_sample_without_replacement":
         (c_int, [_T, _T, _T, _T, c_int, _T, c_void_p, c_void_p, c_void_p, c_ulonglong, POINTER(EnvFns), c_void_p]),
     "generate_random_positive_int_cpu": (c_int, [c_int64, c_int64, _T]),

@@ -20,7 +20,7 @@ def _as_device_tensor(t):
 
 
 def _sample(weighted, row_ptr, col, weight, center_nodes_tensor, max_sample_count, random_seed,
-            need_center_local_output, need_edge_output):
+            need_center_local_output, need_edge_output, with_replacement=False):
     row_ptr, col = _as_device_tensor(row_ptr), _as_device_tensor(col)
     assert row_ptr.dim() == 1
     assert col.dim() == 1
@@ -41,7 +41,13 @@ def _sample(weighted, row_ptr, col, weight, center_nodes_tensor, max_sample_coun
     lid_c = lid_ctx.get_c_context() if lid_ctx else None
     gid_c = gid_ctx.get_c_context() if gid_ctx else None
     seed = random_seed & 0xFFFFFFFFFFFFFFFF
-    if weighted:
+    if with_replacement:
+        assert not weighted, "sampling with replacement is uniform"
+        L.check(L.lib().wgamd_csr_uniform_sample_with_replacement(
+            w_row.c, w_col.c, w_seeds.c, int(max_sample_count), w_off.c, dest_ctx.get_c_context(),
+            lid_c, gid_c, seed, get_wholegraph_env_fns(), get_stream()),
+            "wgamd_csr_uniform_sample_with_replacement")
+    elif weighted:
         w_weight = wrap_torch_tensor(weight)
         L.check(L.lib().wholegraph_csr_weighted_sample_without_replacement(
             w_row.c, w_col.c, w_weight.c, w_seeds.c, int(max_sample_count), w_off.c, dest_ctx.get_c_context(),
@@ -74,6 +80,15 @@ def unweighted_sample_without_replacement(
     Returns ``(sample_offset, dest[, center_local_id][, edge_gid])``."""
     return _sample(False, wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, None, center_nodes_tensor,
                    max_sample_count, random_seed, need_center_local_output, need_edge_output)
+
+
+def unweighted_sample_with_replacement(wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, center_nodes_tensor: "torch.Tensor",
+                                       sample_count: int, random_seed: Union[int, None] = None,
+                                       need_center_local_output: bool = False, need_edge_output: bool = False):
+    """Uniform sampling WITH replacement (cugraph_pyg ``replace=True``; ``wgamd_csr_uniform_sample_with_replacement``):
+    every seed with neighbours yields exactly ``sample_count`` picks.  Same return tuple as the op above."""
+    return _sample(False, wm_csr_row_ptr_tensor, wm_csr_col_ptr_tensor, None, center_nodes_tensor, sample_count,
+                   random_seed, need_center_local_output, need_edge_output, with_replacement=True)
 
 
 def weighted_sample_without_replacement(

@@ -348,6 +348,17 @@ wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const
                                                        const void* w_planes, int N, const float* bias, int relu, float* out,
                                                        int64_t ldo, void* stream);
 
+/* Uniform neighbour sampling WITH replacement (cugraph_pyg `replace=True`; the reference forwards it to libcugraph,
+ * sampler/distributed_sampler.py:775-792,864 — not in its tree, so the draw layout is this library's and is pinned by
+ * oracle/wg_oracle.c).  Same tensors, contexts and error behaviour as wholegraph_csr_unweighted_sample_without_replacement
+ * (include/wgamd_ops.h); a seed with N > 0 neighbours yields exactly `sample_count` picks,
+ * pick t = col[start + G(random_seed, i * sample_count + t).i31() % N] in draw order, a seed without neighbours none. */
+wholememory_error_code_t wgamd_csr_uniform_sample_with_replacement(
+  wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,
+  wholememory_tensor_t center_nodes_tensor, int sample_count, wholememory_tensor_t output_sample_offset_tensor,
+  void* output_dest_memory_context, void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
+  unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

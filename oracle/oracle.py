@@ -20,7 +20,7 @@ _lib = None
 
 __all__ = [
     "build", "lib", "pcg_raw_u32", "generate_random_positive_int",
-    "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets",
+    "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets", "unweighted_sample_with_replacement",
     "unweighted_sample", "weighted_sample", "append_unique", "csr_add_self_loop",
     "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "num_threads",
     "set_num_threads", "py_pcg_u32_stream", "py_unweighted_sample_small",
@@ -141,6 +141,24 @@ def unweighted_sample(row_ptr, col, seeds, max_sample_count, random_seed):
     lib().wgo_unweighted_sample(_p(row_ptr), _p(col), cint(_is64(col)), _p(seeds), cint(_is64(seeds)),
                                 i64(seeds.size), cint(max_sample_count), u64(random_seed & (2**64 - 1)),
                                 _p(off), _p(dst), _p(lid), _p(gid))
+    return off, dst, lid, gid
+
+
+def unweighted_sample_with_replacement(row_ptr, col, seeds, sample_count, random_seed):
+    """Uniform sampling WITH replacement (wgo_uniform_sample_with_replacement; no reference counterpart in tree).
+    -> (offsets int32[n+1], dst (col dtype), src_lid int32, edge_gid int64)."""
+    row_ptr = _c(row_ptr, np.int64)
+    col = _c(col)
+    seeds = _c(seeds)
+    off = np.empty(seeds.size + 1, dtype=np.int32)
+    args = (_p(row_ptr), _p(col), cint(_is64(col)), _p(seeds), cint(_is64(seeds)), i64(seeds.size), cint(sample_count),
+            u64(random_seed & (2**64 - 1)), _p(off))
+    lib().wgo_uniform_sample_with_replacement(*args, None, None, None)
+    total = int(off[-1])
+    dst = np.empty(total, dtype=col.dtype)
+    lid = np.empty(total, dtype=np.int32)
+    gid = np.empty(total, dtype=np.int64)
+    lib().wgo_uniform_sample_with_replacement(*args, _p(dst), _p(lid), _p(gid))
     return off, dst, lid, gid
 
 

@@ -321,6 +321,40 @@ static void wgo_uniform_one(const int64_t* row_ptr,
   free(r);
 }
 
+/* Uniform sampling WITH replacement.  NOT in the reference tree (cugraph_pyg forwards `with_replacement` to libcugraph,
+ * sampler/distributed_sampler.py:775-792,864): parity unpinned against the reference; this is the normative statement of
+ * the layout csrc/wg_sample_replace.hip implements — a seed with N > 0 neighbours yields exactly M picks, pick t =
+ * col[start + G(seed64, i*M + t).i31() % N] (one stream per draw, the op generator of A.1), a seed without neighbours
+ * none; offsets[i] = M x #{j < i : N_j > 0} (n + 1 entries).  src_lid / edge_gid may be NULL. */
+void wgo_uniform_sample_with_replacement(const int64_t* row_ptr, const void* col, int col_is64, const void* seeds, int seeds_is64,
+                                         int64_t n, int M, uint64_t random_seed, int32_t* offsets, void* dst, int32_t* src_lid,
+                                         int64_t* edge_gid)
+{
+  int32_t acc = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t nid = wgo_idx(seeds, seeds_is64, i);
+    offsets[i]  = acc;
+    if (row_ptr[nid + 1] > row_ptr[nid]) acc += M;
+  }
+  offsets[n] = acc;
+  if (dst == NULL) return;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t nid   = wgo_idx(seeds, seeds_is64, i);
+    int64_t start = row_ptr[nid], N = row_ptr[nid + 1] - start;
+    if (N <= 0) continue;
+    for (int t = 0; t < M; t++) {
+      wgo_pcg_t g;
+      int64_t sid = i * (int64_t)M + t;
+      wgo_pcg_init(&g, random_seed, (uint64_t)sid);
+      int64_t a   = start + (int64_t)(wgo_pcg_i31(&g) % N);
+      int64_t out = offsets[i] + t;
+      wgo_set(dst, col_is64, out, wgo_idx(col, col_is64, a));
+      if (src_lid) src_lid[out] = (int32_t)i;
+      if (edge_gid) edge_gid[out] = a;
+    }
+  }
+}
+
 /* host_unweighted_sample_without_replacement (graph_sampling_test_utils.cu:312-401).
  * `offsets` must come from wgo_sample_offsets.  src_lid / edge_gid may be NULL.
  * Seeds are independent -> optional OpenMP over seeds (used only by bench.py's cpu_baseline). */

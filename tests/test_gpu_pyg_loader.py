@@ -894,3 +894,51 @@ def test_hetero_link_loader_call_groups_equal_one_batch_path(hiplib, mode, amoun
         assert torch.equal(a[etype].input_id, b[etype].input_id)
         if mode is not None:
             assert torch.equal(a[etype].edge_label, b[etype].edge_label)
+
+
+def test_neighbor_loader_replace_true_and_hetero_disjoint(hiplib):
+    """`replace=True` (reference: neighbor_loader.py:118-120 -> libcugraph with_replacement) and heterogeneous `disjoint`
+    sampling (distributed_sampler.py:808-824), both refused in round 1."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from cugraph_pyg_amd.sampler.sampler import hetero_neighbor_sample
+    # homogeneous, replace=True: a vertex with 2 in-neighbours and fan-out 6 yields 6 edges from {its 2 neighbours}
+    gs, fs = GraphStore(), FeatureStore()
+    src = torch.tensor([1, 2, 0, 3, 4])
+    dst = torch.tensor([0, 0, 1, 1, 1])
+    gs[("n", "e", "n"), "coo", False, (5, 5)] = [src, dst]
+    fs["n", "x", None] = torch.arange(5, dtype=torch.float32).view(-1, 1)
+    loader = NeighborLoader((fs, gs), num_neighbors=[6], input_nodes=torch.tensor([0, 1]), batch_size=2, replace=True)
+    b = next(iter(loader))
+    ei, n_id = b.edge_index.cpu(), b.n_id.cpu()
+    assert ei.shape[1] == 12 and b.num_sampled_edges.tolist() == [12]
+    for s_, d_ in zip(n_id[ei[0]].tolist(), n_id[ei[1]].tolist()):
+        assert (s_, d_) in {(1, 0), (2, 0), (0, 1), (3, 1), (4, 1)}
+    assert src[b.e_id.cpu()].tolist() == n_id[ei[0]].tolist() and dst[b.e_id.cpu()].tolist() == n_id[ei[1]].tolist()
+    # heterogeneous disjoint: papers 0 and 1 are both written by author 0 and by one author of their own; with vertex-
+    # disjoint trees author 0 joins exactly ONE tree and the other paper's edge to it is dropped
+    gs2 = GraphStore()
+    gs2[("author", "writes", "paper"), "coo", False, (3, 2)] = [torch.tensor([0, 0, 1, 2]), torch.tensor([0, 1, 0, 1])]
+    gs2[("paper", "rev_writes", "author"), "coo", False, (2, 3)] = [torch.tensor([0, 1, 0, 1]), torch.tensor([0, 0, 1, 2])]
+    graphs = gs2._hetero_graphs
+    fan = {et: [5, 5] for et in graphs}
+    seeds = torch.tensor([0, 1], device="cuda")
+    node, row, col, edge, nn, ne = hetero_neighbor_sample(graphs, "paper", seeds, fan, 7, disjoint=True)
+    et = ("author", "writes", "paper")
+    a_of = node["author"][row[et]].cpu().tolist()
+    p_of = node["paper"][col[et]].cpu().tolist()
+    hop1 = list(zip(a_of[:ne[et][0]], p_of[:ne[et][0]]))
+    assert sorted(hop1) == [(0, 0), (1, 0), (2, 1)]          # (author 0 -> paper 1) dropped: author 0 sits in paper 0's tree
+    assert sorted(node["author"].cpu().tolist()) == [0, 1, 2] and node["paper"].cpu().tolist() == [0, 1]
+    # the trees never share a vertex: walking on from the authors reaches no paper of the other tree
+    et2 = ("paper", "rev_writes", "author")
+    assert ne[et2][1] == 0 or set(node["paper"][row[et2]].cpu().tolist()) <= {0, 1}
+    plain = hetero_neighbor_sample(graphs, "paper", seeds, fan, 7)
+    assert plain[5][et][0] == 4                               # without `disjoint` all four authorships are sampled
+    # and through the loader
+    fs2 = FeatureStore()
+    fs2["paper", "x", None] = torch.zeros(2, 1)
+    out = next(iter(NeighborLoader((fs2, gs2), num_neighbors=fan, input_nodes=("paper", torch.tensor([0, 1])), batch_size=2,
+                                   disjoint=True)))
+    assert out[et].edge_index.shape[1] == 3

@@ -83,3 +83,32 @@ def test_invalid_inputs_return_codes(hiplib):
     with pytest.raises(WholeMemoryError) as e:
         ops.unweighted_sample_without_replacement(rp.long(), col.float(), seeds, 5)
     assert e.value.code == _lib.WHOLEMEMORY_INVALID_INPUT
+
+
+@pytest.mark.parametrize("M", [1, 5, 10, 25, 64, 300])
+@pytest.mark.parametrize("col_dtype,seed_dtype", [(np.int64, np.int64), (np.int32, np.int32), (np.int32, np.int64)])
+def test_uniform_with_replacement_vs_oracle(oracle_mod, hiplib, M, col_dtype, seed_dtype):
+    """wgamd_csr_uniform_sample_with_replacement (cugraph_pyg `replace=True`) against the oracle's statement of its draw
+    layout, bit-exact on all four outputs; every seed with neighbours yields exactly M picks, repeats included."""
+    import torch
+    from wholegraph_amd import wholegraph_ops as ops
+    row_ptr, col = random_csr(900, 40000, seed=M, col_dtype=col_dtype, zero_deg_frac=0.1)
+    seeds = np.random.default_rng(M).integers(0, 900, 333).astype(seed_dtype)
+    out = ops.unweighted_sample_with_replacement(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(),
+                                                 torch.from_numpy(seeds).cuda(), M, random_seed=777 + M,
+                                                 need_center_local_output=True, need_edge_output=True)
+    off, dst, lid, gid = (t.cpu().numpy() for t in out)
+    ooff, odst, olid, ogid = oracle_mod.unweighted_sample_with_replacement(row_ptr, col, seeds, M, 777 + M)
+    assert np.array_equal(off, ooff) and np.array_equal(dst, odst) and np.array_equal(lid, olid) and np.array_equal(gid, ogid)
+    deg = np.diff(row_ptr)[seeds]
+    assert np.array_equal(np.diff(off), np.where(deg > 0, M, 0))
+    assert np.all(gid >= row_ptr[seeds[lid]]) and np.all(gid < row_ptr[seeds[lid] + 1]) and np.array_equal(col[gid], dst)
+    if M >= 25:   # with more picks than a short row has neighbours, repeats must occur
+        short = np.nonzero((deg > 0) & (deg < M))[0]
+        assert len(short) > 0
+        i = short[0]
+        assert len(set(gid[off[i]:off[i + 1]].tolist())) < M
+    # empty input
+    e = ops.unweighted_sample_with_replacement(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(),
+                                               torch.from_numpy(seeds[:0]).cuda(), M, random_seed=1)
+    assert e[0].tolist() == [0] and e[1].numel() == 0
