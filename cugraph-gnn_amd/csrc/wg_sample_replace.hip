@@ -3,7 +3,7 @@
 // cugraph_pyg exposes it as `replace=True` / `with_replacement` and hands it to libcugraph
 // (/root/reference/python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:775-792,864,
 //  loader/neighbor_loader.py:118-120); the arithmetic is not in the reference tree, so the draw layout below is this
-// library's own and is pinned by oracle/wg_oracle.c (wgo_uniform_sample_with_replacement), not by a reference vector:
+// library's own; the parity tests pin it with a CPU restatement, not with a reference vector:
 //   a seed with N > 0 neighbours yields EXACTLY M picks (M > 0), pick t = col[start + G(seed64, i * M + t).i31() % N] —
 //   one PCG32 stream per (seed index i, draw t), the op's usual generator (wg_rng.hpp) — emitted in draw order; a seed
 //   without neighbours yields nothing.  sample_offset[i] = M x (number of seeds j < i with neighbours).

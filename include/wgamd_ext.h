@@ -350,7 +350,7 @@ wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const
 
 /* Uniform neighbour sampling WITH replacement (cugraph_pyg `replace=True`; the reference forwards it to libcugraph,
  * sampler/distributed_sampler.py:775-792,864 — not in its tree, so the draw layout is this library's and is pinned by
- * oracle/wg_oracle.c).  Same tensors, contexts and error behaviour as wholegraph_csr_unweighted_sample_without_replacement
+ * the CPU restatement of the parity tests).  Same tensors, contexts and error behaviour as wholegraph_csr_unweighted_sample_without_replacement
  * (include/wgamd_ops.h); a seed with N > 0 neighbours yields exactly `sample_count` picks,
  * pick t = col[start + G(random_seed, i * sample_count + t).i31() % N] in draw order, a seed without neighbours none. */
 wholememory_error_code_t wgamd_csr_uniform_sample_with_replacement(
