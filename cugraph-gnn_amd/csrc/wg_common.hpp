@@ -243,16 +243,25 @@ void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64,
                             int64_t* edge_gid, hipStream_t stream);
 void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
                           int* big_deg, hipStream_t stream);
-// biased (A-Res) sampling, 0 < M <= 256: `big_list` (n.host + 1 ints) receives the rows too long for the one-wave
-// kernel; `slab` = kWeightedBlocks slabs of slab_len keys for the rows longer than kWeightedLdsKeys candidates
+// biased (A-Res) sampling, 0 < M <= 256: `big_list` (weighted_list_ints(n.host) ints) receives the row lists by size class;
+// `slab` = kWeightedBlocks slabs of slab_len keys for the rows longer than kWeightedLdsKeys candidates
 // (slab_len >= the longest such row, e.g. the graph's maximum degree).  Weights FLOAT or DOUBLE.
 constexpr int kWeightedBlocks  = 1024;
 constexpr int kWeightedLdsKeys = 12288;
+// row lists of a biased hop, built by the count kernel (block-aggregated appends): the rows that are sampled (deg > M)
+// by size class — 0: deg <= 16, 1: <= 32, 2: <= 64 (one key per lane: 4 / 2 / 1 rows per wave), 3: <= 128, 4: <= 256,
+// 5: <= 512, 6: <= 1024 (one wave per row, 2 / 4 / 8 / 16 keys per lane in registers), 7: <= 16384 and 8: more candidates
+// (persistent workgroups, the huge rows first, dealt out through a queue head).  Rows copied whole (deg <= M) need no
+// list.  Layout in ints:  [0 .. 8] list lengths | [9] queue head | [10] longest row that needs a key slab | pad to 16 |
+// list c at 16 + c * cap
+constexpr int kWeightedLists    = 9;
+constexpr int kWeightedListHead = 16;
+inline int64_t weighted_list_ints(int64_t cap) { return kWeightedListHead + (int64_t)kWeightedLists * (cap > 0 ? cap : 1); }
 void weighted_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
                             int* big_list, hipStream_t stream);
 void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* weights, bool weights64,
                              const void* seeds, bool seeds64, dev_count n, int M, rng_plan random_seed, const int* offsets,
-                             const int* big_list, uint32_t* slab, int64_t slab_len, void* dst, int* src_lid,
+                             int* big_list, uint32_t* slab, int64_t slab_len, void* dst, int* src_lid,
                              int64_t* edge_gid, hipStream_t stream);
 // renumbering: table of `slots` (power of two >= 2*(T.host+E.host)) entries, slot_of[T.host+E.host],
 // rank[E.host+1], scan_tmp[scan_tmp_ints(E.host+1)].  unique_out may be NULL for `prepare`.

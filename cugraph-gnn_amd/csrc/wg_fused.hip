@@ -43,7 +43,7 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
   w.rank         = take(sizeof(int) * (size_t)(edge_cap + 1));
   if (max_row_len > 0) {
     w.slab_len = max_row_len > kWeightedLdsKeys ? max_row_len : 1;
-    w.big_list = take(sizeof(int) * (size_t)(target_cap + 2));
+    w.big_list = take(sizeof(int) * (size_t)weighted_list_ints(target_cap));
     w.slab     = take(sizeof(uint32_t) * (size_t)kWeightedBlocks * (size_t)w.slab_len);
   }
   w.total        = off;

@@ -71,6 +71,9 @@ __device__ __forceinline__ Pcg32 stream_generator(uint64_t random_seed, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+constexpr int kWaveRowCapDecl = 1024;  // == kWaveRowCap (rows the one-wave weighted kernel keeps in registers)
+constexpr int kHugeRow = 16384;   // candidates; rows above go first (list 4), one workgroup each like the long ones
+
 template <typename SeedT>
 __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __restrict__ row_ptr,
                                                            const SeedT* __restrict__ seeds,
@@ -78,28 +81,54 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
                                                            int M,
                                                            int* __restrict__ cnt,
                                                            int* __restrict__ big_deg /*nullable*/,
-                                                           int big_threshold = 0,
-                                                           int* __restrict__ big_list = nullptr /*[0] = count, [1..] = seeds*/,
-                                                           int* __restrict__ max_scratch_row = nullptr,
-                                                           int scratch_threshold = 0)
+                                                           int* __restrict__ lists = nullptr /*biased hop: see wg_common.hpp*/,
+                                                           int list_cap            = 0,
+                                                           int scratch_threshold   = 0)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_.host) return;
   const int n_live = n_.get();
-  if (i >= n_live) {  // capacity slack of the no-sync walk: zero the rest of the live scan tile only
-    if (i >= (n_live / kScanTile + 1) * kScanTile) return;
-    cnt[i] = 0;
-    if (big_deg) big_deg[i] = 0;
-    return;
+  int cls          = -1;
+  int deg          = 0;
+  if (i < n_.host) {
+    if (i >= n_live) {  // capacity slack of the no-sync walk: zero the rest of the live scan tile only
+      if (i < (n_live / kScanTile + 1) * kScanTile) {
+        cnt[i] = 0;
+        if (big_deg) big_deg[i] = 0;
+      }
+    } else {
+      int64_t nid = (int64_t)seeds[i];
+      deg         = (int)(row_ptr[nid + 1] - row_ptr[nid]);
+      cnt[i]      = (M > 0 && deg > M) ? M : deg;
+      if (big_deg) big_deg[i] = 0;
+      if (lists != nullptr && M > 0 && deg > M) {
+        cls = deg <= 16 ? 0 : deg <= 32 ? 1 : deg <= 64 ? 2 : deg <= 128 ? 3 : deg <= 256 ? 4 : deg <= 512 ? 5
+              : deg <= kWaveRowCapDecl ? 6 : deg <= kHugeRow ? 7 : 8;
+        if (cls >= 7 && deg > scratch_threshold) atomicMax(lists + 10, deg);  // longest row that needs a key slab
+      }
+    }
   }
-  int64_t nid = (int64_t)seeds[i];
-  int deg     = (int)(row_ptr[nid + 1] - row_ptr[nid]);
-  cnt[i]      = (M > 0 && deg > M) ? M : deg;
-  // weighted: rows longer than the one-wave kernel holds in registers need key scratch + the workgroup kernel
-  const bool big = M > 0 && deg > M && deg > big_threshold;
-  if (big_deg) big_deg[i] = big ? deg : 0;
-  if (big && big_list) big_list[1 + atomicAdd(big_list, 1)] = i;
-  if (big && max_scratch_row && deg > scratch_threshold) atomicMax(max_scratch_row, deg);  // longest row that needs a slab
+  if (lists == nullptr) return;
+  // block-aggregated append: ranks inside the block from LDS counters, ONE global atomic per block and list (every seed
+  // hitting the same five words directly costs more than the whole count: a word takes ~90 atomics per microsecond)
+  __shared__ int blk_cnt[kWeightedLists], blk_base[kWeightedLists];
+  if (threadIdx.x < kWeightedLists) blk_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  int my_rank    = 0;
+#pragma unroll
+  for (int c = 0; c < kWeightedLists; c++) {
+    const uint64_t m = __ballot(cls == c);
+    if (m == 0ull) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    int base         = 0;
+    if (lane == leader) base = atomicAdd(&blk_cnt[c], __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (cls == c) my_rank = base + __popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (threadIdx.x < kWeightedLists && blk_cnt[threadIdx.x] > 0) blk_base[threadIdx.x] = atomicAdd(lists + threadIdx.x, blk_cnt[threadIdx.x]);
+  __syncthreads();
+  if (cls >= 0) lists[kWeightedListHead + (int64_t)cls * list_cap + blk_base[cls] + my_rank] = i;
 }
 
 template <typename ColT>
@@ -318,7 +347,7 @@ __global__ void __launch_bounds__(64) sample_uniform_reservoir_kernel(const int6
 }
 
 // ---- weighted --------------------------------------------------------------------------------
-__device__ __forceinline__ float ares_key(float w, Pcg32& g)
+__device__ __forceinline__ float ares_key(float w, Pcg32& g, bool* redrawn = nullptr)
 {
   float u = g.next_f32();
   u       = (float)(-(0.5 + 0.5 * (double)u));
@@ -328,12 +357,14 @@ __device__ __forceinline__ float ares_key(float w, Pcg32& g)
     x = g.next_u64();
     zero_draws++;
   } while (!x);
+  if (redrawn != nullptr && zero_draws > 0) *redrawn = true;   // more than three draws for this key
   int one_bit = __clzll((long long)x) + zero_draws * 64;
   u *= exp2f((float)(-one_bit));
   return (log1pf(u) / logf(2.0f)) * (1.0f / w);
 }
 
 constexpr int kWaveRowCap = 1024;  // rows the one-wave weighted kernel keeps in registers (16 keys per lane)
+static_assert(kWaveRowCap == kWaveRowCapDecl, "keep the two in step");
 
 // order-preserving float -> uint (larger key <=> larger uint)
 __device__ __forceinline__ uint32_t key_bits(float k)
@@ -365,7 +396,8 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
                                                             ColT* __restrict__ dst,
                                                             int* __restrict__ src_lid,
                                                             int64_t* __restrict__ edge_gid,
-                                                            const int* __restrict__ seed_list /*nullable: [0] = count*/)
+                                                            int* __restrict__ lists /*nullable*/,
+                                                            int list_cap)
 {
   static_assert(T % B == 0 && T % 64 == 0, "threads must be a multiple of the stream layout and of the wave");
   __shared__ uint32_t lds_keys[kLdsKeys];
@@ -374,12 +406,26 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   __shared__ int wave_cnt[2][T / 64];
   // persistent workgroups: the rows to do (all seeds, or the listed long ones) are dealt out round-robin; a workgroup
   // owns ONE scratch slab of slab_len keys (>= the longest row) for the rows that do not fit LDS
-  const int n_live = n_.get();
-  const int count  = seed_list ? seed_list[0] : n_live;
-  uint32_t* gkeys  = slab + (int64_t)blockIdx.x * slab_len;
-  for (int li = blockIdx.x; li < count; li += gridDim.x) {
+  // `lists` (biased hop with 0 < M <= 256): the huge rows (list 4) then the long ones (list 3), dealt out through a queue
+  // head so that a workgroup stuck on a 150k-candidate hub does not hold back the rows a static deal would have given it
+  __shared__ int sh_li;
+  const int n_live  = n_.get();
+  const int n_huge  = lists ? lists[8] : 0;
+  const int count   = lists ? n_huge + lists[7] : n_live;
+  uint32_t* gkeys   = slab + (int64_t)blockIdx.x * slab_len;
+  int li            = blockIdx.x;
+  while (true) {
   __syncthreads();  // the previous row's readers of the shared counters are done
-  const int i = seed_list ? seed_list[1 + li] : li;
+  if (lists) {
+    if (threadIdx.x == 0) sh_li = atomicAdd(lists + 9, 1);
+    __syncthreads();
+    li = sh_li;
+  }
+  if (li >= count) break;
+  const int i = lists ? (li < n_huge ? lists[kWeightedListHead + 8 * (int64_t)list_cap + li]
+                                    : lists[kWeightedListHead + 7 * (int64_t)list_cap + (li - n_huge)])
+                      : li;
+  if (!lists) li += gridDim.x;
   if (i >= n_live) continue;
   uint64_t random_seed;
   int i_rng;
@@ -404,23 +450,24 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   if (threadIdx.x == 0) sh_redo = 0;
   __syncthreads();
   {
-    constexpr int hop = T / B;  // keys of one stream between two keys of the same thread
-    const int lane = threadIdx.x % B, first_key = threadIdx.x / B;
-    const int64_t sid = (int64_t)i_rng * B + lane;
-    Pcg32 g = (sid < (1ll << 31)) ? Pcg32(random_seed, (uint32_t)sid, Pcg32::table_tag{}, 3u * (uint32_t)first_key)
-                                  : Pcg32(random_seed, stream_id(i_rng, B, lane));
-    if (hop > 1 && sid >= (1ll << 31)) g.skipahead(3u * (uint64_t)first_key);
+    // stream `lane` (of B) owns neighbours lane, lane + B, ... = L keys drawn one after the other; its T / B threads take
+    // CONTIGUOUS shares of that sequence: ONE jump to the share's first draw (3 draws per key), then plain sequential
+    // draws — no per-key jump.  A key that needed more than three draws (a 64-bit draw of 0, p = 2^-64) invalidates the
+    // positions after it: every thread reports it and the row is redone the sequential way below.
+    constexpr int hop = T / B;
+    const int lane = threadIdx.x % B, part = threadIdx.x / B;
+    const int L     = lane < N ? (N - lane + B - 1) / B : 0;          // keys of this stream
+    const int share = (L + hop - 1) / hop;
+    const int m0 = part * share, m1 = min(L, m0 + share);
     bool redrawn = false;
-    for (int id = threadIdx.x; id < N; id += T) {
-      const uint64_t before = g.state;
-      put(id, key_bits(ares_key((float)weight[start + id], g)));
-      if (hop > 1) {
-        // exactly three draws? (state after 3 steps is a fixed affine map of the state before)
-        Pcg32 chk = g;
-        chk.state = before;
-        chk.jump_table(3u);
-        redrawn |= chk.state != g.state;
-        g.jump_table(3u * (uint32_t)(hop - 1));
+    if (m0 < m1) {
+      const int64_t sid = (int64_t)i_rng * B + lane;
+      Pcg32 g = (sid < (1ll << 31)) ? Pcg32(random_seed, (uint32_t)sid, Pcg32::table_tag{}, 3u * (uint32_t)m0)
+                                    : Pcg32(random_seed, stream_id(i_rng, B, lane));
+      if (sid >= (1ll << 31)) g.skipahead(3u * (uint64_t)m0);
+      for (int m = m0; m < m1; m++) {
+        const int id = lane + m * B;
+        put(id, key_bits(ares_key((float)weight[start + id], g, &redrawn)));
       }
     }
     if (redrawn) sh_redo = 1;
@@ -515,82 +562,187 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   }  // persistent loop over rows
 }
 
-// One WAVE per seed for rows of up to 64*KMAX candidates (B = 128 stream layout, i.e. M <= 256): the keys stay in
-// registers (slot s of lane l = neighbour (s/2)*128 + (s%2)*64 + l, drawn from stream l or l+64 exactly as lane
-// l / l+64 of the reference's 128-thread block would), the M-th largest key is found by a bitwise binary search
-// whose counts are wave ballots, and the picks are emitted in CSR order with ballot prefix sums.  No LDS, no
-// scratch, no barrier: a seed costs one short dependency chain instead of ~10 workgroup barriers, which is what
-// bounded the workgroup kernel on mini-batch frontiers (hundreds of thousands of rows of ~100 candidates).
-template <typename SeedT, typename ColT, typename WeightT, int KMAX>
-__global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t* __restrict__ row_ptr,
-                                                                   const ColT* __restrict__ col,
-                                                                   const WeightT* __restrict__ weight,
-                                                                   const SeedT* __restrict__ seeds,
-                                                                   dev_count n_,
-                                                                   int M,
-                                                                   rng_plan rng,
-                                                                   const int* __restrict__ offsets,
-                                                                   ColT* __restrict__ dst,
-                                                                   int* __restrict__ src_lid,
-                                                                   int64_t* __restrict__ edge_gid)
+// Rows of at most LANES (16 / 32 / 64) candidates: ONE key per lane, 64 / LANES rows per wave (the rows of a size class,
+// listed by the count kernel).  Neighbour j < 64 of the reference's 128-thread block is drawn from stream seed*128 + j, so
+// lane hl of a group draws exactly that key; the 31-step bitwise search for the M-th largest key and the ballot prefix sums
+// of the emission are shared by the rows of the wave (masked to the lane group), which is what the short rows of a
+// mini-batch frontier were paying a whole wave each for.
+template <typename SeedT, typename ColT, typename WeightT, int LANES>
+__global__ void __launch_bounds__(256) sample_weighted_group_kernel(const int64_t* __restrict__ row_ptr,
+                                                                    const ColT* __restrict__ col,
+                                                                    const WeightT* __restrict__ weight,
+                                                                    const SeedT* __restrict__ seeds,
+                                                                    int M,
+                                                                    rng_plan rng,
+                                                                    const int* __restrict__ offsets,
+                                                                    ColT* __restrict__ dst,
+                                                                    int* __restrict__ src_lid,
+                                                                    int64_t* __restrict__ edge_gid,
+                                                                    const int* __restrict__ lists,
+                                                                    int list_cap,
+                                                                    int cls)
 {
   const int lane = threadIdx.x & 63;
-  const int i    = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n_.get()) return;
-  uint64_t random_seed;
-  int i_rng;
-  rng.resolve(i, random_seed, i_rng);
-  const int64_t nid   = (int64_t)seeds[i];
-  const int64_t start = row_ptr[nid];
-  const int N         = (int)(row_ptr[nid + 1] - start);
-  if (N <= 0) return;
-  const int64_t base = offsets[i];
-  if (M <= 0 || N <= M) {
-    for (int j = lane; j < N; j += 64) emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
-    return;
-  }
-  if (N > 64 * KMAX) return;  // the workgroup kernel takes these (seed list built by the count kernel)
-  uint32_t k[KMAX];
-  {
-    Pcg32 ga = stream_generator(random_seed, i_rng, 128, lane);
-    Pcg32 gb = ga;
-    if (N > 64) gb = stream_generator(random_seed, i_rng, 128, lane + 64);
-#pragma unroll
-    for (int s = 0; s < KMAX; s++) {
-      k[s] = 0u;  // below every real key (key_bits of any float, -inf and NaN included, is > 0)
-      if (s * 64 < N) {
-        const int id = (s >> 1) * 128 + (s & 1) * 64 + lane;
-        if (id < N) k[s] = key_bits(ares_key((float)weight[start + id], (s & 1) ? gb : ga));
-      }
+  const int hl = lane & (LANES - 1), hb = lane & ~(LANES - 1);
+  const int64_t li  = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES);
+  const bool active = li < (int64_t)lists[cls];
+  if (__ballot(active) == 0ull) return;
+  int i = 0, N = 0;
+  int64_t start = 0, base = 0;
+  uint32_t k = 0u;  // below every real key
+  if (active) {
+    i = lists[kWeightedListHead + (int64_t)cls * list_cap + li];
+    uint64_t random_seed;
+    int i_rng;
+    rng.resolve(i, random_seed, i_rng);
+    const int64_t nid = (int64_t)seeds[i];
+    start             = row_ptr[nid];
+    N                 = (int)(row_ptr[nid + 1] - start);   // M < N <= LANES by construction of the list
+    base              = offsets[i];
+    if (hl < N) {
+      Pcg32 g = stream_generator(random_seed, i_rng, 128, hl);
+      k       = key_bits(ares_key((float)weight[start + hl], g));
     }
   }
+  const uint64_t gm = LANES == 64 ? ~0ull : (((1ull << LANES) - 1ull) << hb);
   uint32_t prefix = 0;
   int need        = M;
   for (int bit = 31; bit >= 0; bit--) {
     const uint32_t cand = prefix | (1u << bit);
     const uint32_t hi   = ~((1u << bit) - 1u);
-    int cnt             = 0;
-#pragma unroll
-    for (int s = 0; s < KMAX; s++)
-      if (s * 64 < N) cnt += __popcll(__ballot((k[s] & hi) == cand));
+    const int cnt       = __popcll(__ballot((k & hi) == cand) & gm);
     if (cnt >= need) prefix = cand; else need -= cnt;
   }
-  // prefix == the M-th largest key: take every key above it and the first `need` equal to it (index order)
+  // prefix == the M-th largest key of my row: every key above it and the first `need` equal to it (index order)
+  const uint64_t below = ((1ull << lane) - 1ull) & gm;
+  const bool eq        = active && hl < N && k == prefix;
+  const uint64_t meq   = __ballot(eq) & gm;
+  const bool take      = active && hl < N && (k > prefix || (eq && __popcll(meq & below) < need));
+  const uint64_t mt    = __ballot(take) & gm;
+  if (take) emit<ColT>(dst, src_lid, edge_gid, base + __popcll(mt & below), col[start + hl], i, start + hl);
+}
+
+// One WAVE per row for rows of up to 64*KMAX candidates (size classes 3 .. 6 of the count kernel's lists: KMAX = 2, 4, 8,
+// 16; B = 128 stream layout, i.e. M <= 256): the keys stay in registers (slot s of lane l = neighbour (s/2)*128 + (s%2)*64
+// + l, drawn from stream l or l+64 exactly as lane l / l+64 of the reference's 128-thread block would), the M-th largest
+// key is found by a bitwise search whose counts are wave ballots, and the picks are emitted in CSR order with ballot
+// prefix sums.  No LDS, no scratch, no barrier.  The slot count is a compile-time constant per class, so nothing in the
+// search is under a per-row condition (an empty slot holds 0, which is below every real key and matches no candidate).
+template <typename SeedT, typename ColT, typename WeightT, int KMAX>
+__global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t* __restrict__ row_ptr,
+                                                                   const ColT* __restrict__ col,
+                                                                   const WeightT* __restrict__ weight,
+                                                                   const SeedT* __restrict__ seeds,
+                                                                   int M,
+                                                                   rng_plan rng,
+                                                                   const int* __restrict__ offsets,
+                                                                   ColT* __restrict__ dst,
+                                                                   int* __restrict__ src_lid,
+                                                                   int64_t* __restrict__ edge_gid,
+                                                                   const int* __restrict__ lists,
+                                                                   int list_cap,
+                                                                   int cls)
+{
+  const int lane   = threadIdx.x & 63;
+  const int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (li >= (int64_t)lists[cls]) return;
+  const int i = lists[kWeightedListHead + (int64_t)cls * list_cap + li];
+  uint64_t random_seed;
+  int i_rng;
+  rng.resolve(i, random_seed, i_rng);
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  // (one row per wave: make that visible to the compiler, so that `s * 64 < N` below is a scalar branch)
+  const int N         = __builtin_amdgcn_readfirstlane((int)(row_ptr[nid + 1] - start));   // M < N <= 64 * KMAX (list)
+  const int64_t base  = offsets[i];
+  uint32_t k[KMAX];
+  {
+    Pcg32 ga = stream_generator(random_seed, i_rng, 128, lane);
+    Pcg32 gb = stream_generator(random_seed, i_rng, 128, lane + 64);
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) {
+      const int id = (s >> 1) * 128 + (s & 1) * 64 + lane;
+      k[s]         = 0u;  // below every real key (key_bits of any float, -inf and NaN included, is > 0)
+      // the wave-uniform branch keeps the KMAX key computations in separate blocks: as straight-line predicated code the
+      // scheduler interleaves them all (238 VGPRs at KMAX = 16, one wave per SIMD)
+      if (s * 64 < N) {
+        if (id < N) k[s] = key_bits(ares_key((float)weight[start + id], (s & 1) ? gb : ga));
+      }
+    }
+  }
+  // Bitwise search for the M-th largest key, shortened at both ends.  (1) Leading bits on which ALL keys of the row agree
+  // (sign, most of the exponent: the keys are log2(u)/w of one row) need no counting: the search starts below them.
+  // (2) It stops as soon as exactly `need` keys match the decided bits: those and everything above them ARE the top M,
+  // whatever the undecided low bits say (no tie can straddle the cut).  Same selection as the full 32-step search.
+  uint32_t k_or = 0u, k_and = ~0u;
+#pragma unroll
+  for (int s = 0; s < KMAX; s++) {
+    k_or |= k[s];
+    k_and &= k[s] != 0u ? k[s] : ~0u;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    k_or |= __shfl_xor(k_or, d, 64);
+    k_and &= __shfl_xor(k_and, d, 64);
+  }
+  k_or  = __builtin_amdgcn_readfirstlane(k_or);    // wave-uniform after the butterfly: keep the loop scalar
+  k_and = __builtin_amdgcn_readfirstlane(k_and);
+  const uint32_t differ = k_or ^ k_and;
+  const int top         = differ ? 31 - __clz(differ) : -1;   // highest bit on which two keys differ (-1: all equal)
+  uint32_t hi     = top < 0 ? ~0u : top >= 31 ? 0u : ~((2u << top) - 1u);   // decided bits = the common leading bits
+  uint32_t prefix = k_and & hi;
+  int need        = M;
+  int match       = N;   // keys that carry `prefix` in the decided bits (every live key, so far)
+#pragma unroll 1
+  for (int bit = top; bit >= 0 && match != need; bit--) {
+    const uint32_t cand = prefix | (1u << bit);
+    hi |= 1u << bit;
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) cnt += __popcll(__ballot((k[s] & hi) == cand));
+    if (cnt >= need) {
+      prefix = cand;
+      match  = cnt;
+    } else {
+      need -= cnt;
+      match -= cnt;
+    }
+  }
+  // decided bits `hi`, value `prefix`: take every key above it (in the decided bits) and the first `need` equal to it in
+  // index order (after a full search hi == ~0 and this is "the M-th largest key and its ties")
   const uint64_t below = (1ull << lane) - 1ull;
   int out_run = 0, tie_run = 0;
 #pragma unroll
   for (int s = 0; s < KMAX; s++) {
-    if (s * 64 < N) {
-      const int id       = (s >> 1) * 128 + (s & 1) * 64 + lane;
-      const bool eq      = k[s] == prefix;  // prefix > 0, so an empty slot never matches
-      const uint64_t meq = __ballot(eq);
-      const bool take    = k[s] > prefix || (eq && tie_run + __popcll(meq & below) < need);
-      const uint64_t mt  = __ballot(take);
-      if (take) emit<ColT>(dst, src_lid, edge_gid, base + out_run + __popcll(mt & below), col[start + id], i, start + id);
-      out_run += __popcll(mt);
-      tie_run += __popcll(meq);
-    }
+    const int id       = (s >> 1) * 128 + (s & 1) * 64 + lane;
+    const uint32_t kd  = k[s] & hi;
+    const bool eq      = k[s] != 0u && kd == prefix;
+    const uint64_t meq = __ballot(eq);
+    const bool take    = (k[s] != 0u && kd > prefix) || (eq && tie_run + __popcll(meq & below) < need);
+    const uint64_t mt  = __ballot(take);
+    if (take) emit<ColT>(dst, src_lid, edge_gid, base + out_run + __popcll(mt & below), col[start + id], i, start + id);
+    out_run += __popcll(mt);
+    tie_run += __popcll(meq);
+    __builtin_amdgcn_sched_barrier(0);   // (16 unrolled slots x three 64-bit output addresses hoisted together: 238 VGPRs)
   }
+}
+
+// rows that are copied whole (deg <= M, or sample-all): 16 lanes per seed, all seeds
+template <typename SeedT, typename ColT>
+__global__ void __launch_bounds__(256) copy_short_rows_kernel(const int64_t* __restrict__ row_ptr, const ColT* __restrict__ col,
+                                                              const SeedT* __restrict__ seeds, dev_count n_, int M,
+                                                              const int* __restrict__ offsets, ColT* __restrict__ dst,
+                                                              int* __restrict__ src_lid, int64_t* __restrict__ edge_gid)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(t >> 4), hl = (int)(t & 15);
+  if (i >= n_.get()) return;
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  const int N         = (int)(row_ptr[nid + 1] - start);
+  if (N <= 0 || N > M) return;
+  const int64_t base = offsets[i];
+  for (int j = hl; j < N; j += 16) emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
 }
 
 template <typename SeedT, typename ColT>
@@ -626,20 +778,41 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
 // `slab` holds `blocks` slabs of slab_len keys (slab_len >= the longest row above kLdsKeys candidates).
 template <typename SeedT, typename ColT, typename WeightT>
 void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const WeightT* weights, const SeedT* seeds, dev_count n,
-                            int M, rng_plan rng, const int* offsets, const int* big_list, int blocks, uint32_t* slab,
+                            int M, rng_plan rng, const int* offsets, int* lists, int blocks, uint32_t* slab,
                             int64_t slab_len, ColT* dst, int* lid, int64_t* gid, hipStream_t stream)
 {
   if (n.host <= 0) return;
+  const int cap = n.host;
   if (M <= 0 || M > 256) {
     sample_weighted_kernel<SeedT, ColT, WeightT, 256, 256><<<std::max(blocks, 1), 256, 0, stream>>>(
-      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, nullptr);
+      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, nullptr, 0);
     return;
   }
   if (blocks > 0)
     sample_weighted_kernel<SeedT, ColT, WeightT, 128, 512><<<blocks, 512, 0, stream>>>(
-      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, big_list);
-  sample_weighted_wave_kernel<SeedT, ColT, WeightT, kWaveRowCap / 64><<<ceil_div(n.host, 4), 256, 0, stream>>>(
-    row_ptr, col, weights, seeds, n, M, rng, offsets, dst, lid, gid);
+      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, lists, cap);
+  // short rows, one key per lane: 4 / 2 / 1 rows per wave (grids sized for the capacity; waves past the list end exit)
+  if (M < 16)
+    sample_weighted_group_kernel<SeedT, ColT, WeightT, 16><<<ceil_div((int64_t)cap * 16, 256), 256, 0, stream>>>(
+      row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, 0);
+  if (M < 32)
+    sample_weighted_group_kernel<SeedT, ColT, WeightT, 32><<<ceil_div((int64_t)cap * 32, 256), 256, 0, stream>>>(
+      row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, 1);
+  if (M < 64)
+    sample_weighted_group_kernel<SeedT, ColT, WeightT, 64><<<ceil_div((int64_t)cap * 64, 256), 256, 0, stream>>>(
+      row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, 2);
+  // 65 .. 1024 candidates: one wave per row, 2 / 4 / 8 / 16 keys per lane in registers
+#define WG_WAVE(KM, CLS)                                                                                               \
+  sample_weighted_wave_kernel<SeedT, ColT, WeightT, KM><<<ceil_div(cap, 4), 256, 0, stream>>>(                           \
+    row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, CLS)
+  if (M < 128) WG_WAVE(2, 3);
+  WG_WAVE(4, 4);
+  WG_WAVE(8, 5);
+  WG_WAVE(16, 6);
+#undef WG_WAVE
+  // rows copied whole
+  copy_short_rows_kernel<SeedT, ColT><<<ceil_div((int64_t)cap * 16, 256), 256, 0, stream>>>(row_ptr, col, seeds, n, M, offsets,
+                                                                                          dst, lid, gid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -674,6 +847,17 @@ void validate(const sample_args& a, bool weighted)
   }
 }
 
+template <typename SeedT>
+__global__ void __launch_bounds__(256)
+max_degree_kernel(const int64_t* __restrict__ row_ptr, const SeedT* __restrict__ seeds, int n, int threshold, int* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t nid = (int64_t)seeds[i];
+  const int deg     = (int)(row_ptr[nid + 1] - row_ptr[nid]);
+  if (deg > threshold) atomicMax(out, deg);
+}
+
 template <typename SeedT, typename ColT, typename WeightT>
 void run(const sample_args& a, bool weighted)
 {
@@ -691,19 +875,19 @@ void run(const sample_args& a, bool weighted)
   int* stmp = scan_tmp.device<int>(scan_tmp_ints(n + 1), WHOLEMEMORY_DT_INT);
   // weighted: list[0] = number of long rows, list[1..] = their seed indices, list[n+1] = longest row that needs a slab
   const bool wave_path = weighted && M > 0 && M <= 256;
-  int* big_list        = weighted ? list_buf.device<int>(n + 2, WHOLEMEMORY_DT_INT) : nullptr;
+  int* big_list        = weighted ? list_buf.device<int>(weighted_list_ints(n), WHOLEMEMORY_DT_INT) : nullptr;
   int h_tot[3]         = {0, 0, 0};  // total samples, long rows, longest slab row
+  int h_head[kWeightedListHead] = {0};
 
   if (weighted) {
-    WG_HIP_CHECK(hipMemsetAsync(big_list, 0, sizeof(int), stream));
-    WG_HIP_CHECK(hipMemsetAsync(big_list + n + 1, 0, sizeof(int), stream));
-    if (n > 0)
-      sample_count_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(
-        row_ptr, seeds, dev_count{n, nullptr}, M, cnt, nullptr, wave_path ? kWaveRowCap : 0, wave_path ? big_list : nullptr,
-        big_list + n + 1, kLdsKeys);
+    WG_HIP_CHECK(hipMemsetAsync(big_list, 0, kWeightedListHead * sizeof(int), stream));
+    if (n > 0 && wave_path)
+      sample_count_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(row_ptr, seeds, dev_count{n, nullptr}, M, cnt, nullptr,
+                                                                      big_list, n, kLdsKeys);
+    else if (n > 0)
+      sample_count_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(row_ptr, seeds, dev_count{n, nullptr}, M, cnt, nullptr);
     WG_HIP_CHECK(hipGetLastError());
-    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[1], big_list, sizeof(int), hipMemcpyDeviceToHost, stream));
-    WG_HIP_CHECK(hipMemcpyAsync(&h_tot[2], big_list + n + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+    WG_HIP_CHECK(hipMemcpyAsync(h_head, big_list, kWeightedListHead * sizeof(int), hipMemcpyDeviceToHost, stream));
   } else {
     sample_count_enqueue(row_ptr, seeds, sizeof(SeedT) == 8, dev_count{n, nullptr}, M, cnt, nullptr, stream);
   }
@@ -711,6 +895,21 @@ void run(const sample_args& a, bool weighted)
   WG_HIP_CHECK(hipMemcpyAsync(&h_tot[0], offsets + n, sizeof(int), hipMemcpyDeviceToHost, stream));
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // the one unavoidable sync: output sizes
   const int total = h_tot[0];
+  h_tot[1]        = h_head[7] + h_head[8];   // rows for the persistent workgroups
+  h_tot[2]        = h_head[10];              // longest row that needs a key slab
+  if (weighted && !wave_path) {
+    // 256-thread stream layout / sample-all: the workgroup kernel walks all seeds; any row may need the slab
+    h_tot[2] = 0;
+    if (n > 0) {
+      // longest row among the seeds (one more small pass; this path is the rare M > 256 case)
+      temp_buffer deg_buf(a.env);
+      int* dmax = deg_buf.device<int>(1, WHOLEMEMORY_DT_INT);
+      WG_HIP_CHECK(hipMemsetAsync(dmax, 0, sizeof(int), stream));
+      max_degree_kernel<SeedT><<<ceil_div(n, 256), 256, 0, stream>>>(row_ptr, seeds, n, kLdsKeys, dmax);
+      WG_HIP_CHECK(hipMemcpyAsync(&h_tot[2], dmax, sizeof(int), hipMemcpyDeviceToHost, stream));
+      WG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
 
   auto* dst = static_cast<ColT*>(output_alloc(a.env, a.dst_ctx, total, dtype_of<ColT>::value));
   int* lid  = a.lid_ctx ? static_cast<int*>(output_alloc(a.env, a.lid_ctx, total, WHOLEMEMORY_DT_INT)) : nullptr;
@@ -766,19 +965,19 @@ void weighted_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seed
                             int* big_list, hipStream_t stream)
 {
   if (n.host <= 0) return;
-  WG_HIP_CHECK(hipMemsetAsync(big_list, 0, sizeof(int), stream));
+  WG_HIP_CHECK(hipMemsetAsync(big_list, 0, kWeightedListHead * sizeof(int), stream));
   if (seeds64)
     sample_count_kernel<int64_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(row_ptr, static_cast<const int64_t*>(seeds), n, M,
-                                                                           cnt, nullptr, kWaveRowCap, big_list);
+                                                                           cnt, nullptr, big_list, n.host, kLdsKeys);
   else
     sample_count_kernel<int32_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(row_ptr, static_cast<const int32_t*>(seeds), n, M,
-                                                                           cnt, nullptr, kWaveRowCap, big_list);
+                                                                           cnt, nullptr, big_list, n.host, kLdsKeys);
   WG_HIP_CHECK(hipGetLastError());
 }
 
 void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* weights, bool weights64,
                              const void* seeds, bool seeds64, dev_count n, int M, rng_plan random_seed, const int* offsets,
-                             const int* big_list, uint32_t* slab, int64_t slab_len, void* dst, int* src_lid,
+                             int* big_list, uint32_t* slab, int64_t slab_len, void* dst, int* src_lid,
                              int64_t* edge_gid, hipStream_t stream)
 {
   WG_REQUIRE_INPUT(M > 0 && M <= 256, "the no-sync biased hop needs 0 < fan-out <= 256");
