@@ -323,7 +323,8 @@ void launch(const layer_args& a, hipStream_t st)
   const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   const size_t b_bytes  = 0;
   // WGAMD_SAGE_NO_PINGPONG=1: single-team workgroups even when two tiles fit (tuning aid, F > 128 only)
-  const bool pingpong   = 2 * tile_bytes + b_bytes <= 160 * 1024 && (LG < 64 || getenv("WGAMD_SAGE_NO_PINGPONG") == nullptr);
+  static const bool no_pingpong = getenv("WGAMD_SAGE_NO_PINGPONG") != nullptr;   // read once per process, not per launch
+  const bool pingpong   = 2 * tile_bytes + b_bytes <= 160 * 1024 && (LG < 64 || !no_pingpong);
   const size_t lds      = (pingpong ? 2 * tile_bytes : tile_bytes) + b_bytes;
   const int per_cu      = (!pingpong && 2 * lds <= 160 * 1024) ? 2 : 1;
   const int grid        = (int)std::min<int64_t>((n_tiles + (pingpong ? 1 : 0)) / (pingpong ? 2 : 1), (int64_t)cus * per_cu);

@@ -19,11 +19,28 @@ def short(name):
 
 
 def load(path):
+    """{kernel: [values per dispatch, in dispatch order]}"""
     acc = defaultdict(list)
     with open(path) as f:
         for row in csv.DictReader(f):
-            acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
-    return acc
+            acc[short(row["Kernel_Name"])].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+    return {k: [v for _, v in sorted(vals)] for k, vals in acc.items()}
+
+
+def split_shapes(fetch, write):
+    """The same aggregation kernel serves layer 1 and layer 2 of a call group with the same grid: its launches fall into
+    two traffic clusters a factor of several apart.  Launches whose (fetch + write) is at least half the largest one form
+    the `#large` entry (= the layer-1 launch shape), so a per-launch figure is never an average over different shapes."""
+    out = {}
+    for k in set(fetch) & set(write):
+        f, w = fetch[k], write[k]
+        if len(f) != len(w) or len(f) < 4:
+            continue
+        tot = [a + b for a, b in zip(f, w)]
+        big = [i for i, t in enumerate(tot) if t >= 0.5 * max(tot)]
+        if 0 < len(big) < len(tot) and min(tot) < 0.4 * max(tot):
+            out[k + "#large"] = ([f[i] for i in big], [w[i] for i in big])
+    return out
 
 
 def main(folder, tag):
@@ -31,9 +48,12 @@ def main(folder, tag):
     write = load(os.path.join(folder, "%s_WRITE_SIZE_counter_collection.csv" % tag))
     out = {"source": ["%s_FETCH_SIZE_counter_collection.csv" % tag, "%s_WRITE_SIZE_counter_collection.csv" % tag],
            "fetch_correction": FETCH_CORRECTION, "unit": "bytes per launch (mean over the launches of the pass)", "kernels": {}}
-    for k in sorted(set(fetch) & set(write)):
-        fk, wk = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
-        out["kernels"][k] = {"launches": len(fetch[k]), "fetch_KB": round(fk, 1), "write_KB": round(wk, 1),
+    pairs = {k: (fetch[k], write[k]) for k in set(fetch) & set(write)}
+    pairs.update(split_shapes(fetch, write))
+    for k in sorted(pairs):
+        f, w = pairs[k]
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        out["kernels"][k] = {"launches": len(f), "fetch_KB": round(fk, 1), "write_KB": round(wk, 1),
                              "traffic_bytes": int((fk * FETCH_CORRECTION + wk) * 1024)}
     with open(os.path.join(folder, "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
