@@ -658,6 +658,8 @@ void launch_cw(const mfma_args& a, hipStream_t st)
         if (a.F == 100) return launch<IdT, LG, TR, 4, 100>(a, st);
         if (a.F == 128) return launch<IdT, LG, TR, 4, 128>(a, st);
       }
+      // (F = 256, RMAT-26's layers: a compile-time consumer was tried — 32 unrolled k-steps spill 63 VGPRs and lose 13 %;
+      //  that shape is bound by its 6 x 2 N_dst 2F N bf16 flops on time-sliced SIMDs, not by the weight prefetch)
       launch<IdT, LG, TR, 4>(a, st);
       break;
   }
