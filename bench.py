@@ -500,9 +500,27 @@ def main():
         return {k: v / n_groups for k, v in acc.items()}, sizes_p      # per call group
 
     results = {}
-    for placement in placements:
+    placement_errors = {}
+    for placement in list(placements):
         partitioned = placement == "partitioned"
-        feat = make_table(placement)
+        if partitioned and placement != placements[0]:
+            # the second, "also measured" placement must never cost the headline its JSON line: every rank agrees on
+            # whether the table could be built before anyone enters a collective of the measurement
+            try:
+                feat = make_table(placement)
+                ok = 1
+            except Exception as e:       # noqa: BLE001
+                placement_errors[placement] = repr(e)
+                feat, ok = None, 0
+            flag = torch.tensor([ok], device=device)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 0:
+                placement_errors.setdefault(placement, "another rank could not build the partitioned table")
+                placements.remove(placement)
+                continue
+        else:
+            feat = make_table(placement)
         pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap)
         # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
         # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
@@ -688,6 +706,8 @@ def main():
         }
         if cpu is not None:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
+        if placement_errors:
+            out["placement_errors"] = placement_errors
         if len(placements) > 1 or partitioned:
             # the north-star exchange path next to the collective-free one: per-GPU xGMI bytes of the feature fetch and the
             # fraction of the (world-1) x 153 GB/s links it sustains (SURVEY §8(d) all-to-all bytes: n_remote (b + 4F))

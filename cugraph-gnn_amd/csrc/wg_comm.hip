@@ -793,6 +793,10 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
           } else {
             WG_HIP_CHECK(hipIpcOpenMemHandle(&h->peer_ptr[r], rec.ipc, hipIpcMemLazyEnablePeerAccess));
             h->peer_opened[r] = 1;
+            // prove the mapping now (a 4-byte read of the peer's partition) rather than in the first gather kernel: a
+            // mapping that cannot be read fails HERE with an error code the caller can fall back from
+            uint32_t probe = 0;
+            WG_HIP_CHECK(hipMemcpy(&probe, h->peer_ptr[r], rec.bytes >= 4 ? 4 : (size_t)rec.bytes, hipMemcpyDeviceToHost));
           }
           view.base[r]      = static_cast<char*>(h->peer_ptr[r]);
           view.entry_off[r] = (int64_t)(h->byte_offsets[r] / data_granularity);
