@@ -180,10 +180,11 @@ uint64_t host_identity()
 // ---- kernels ---------------------------------------------------------------------------------------
 constexpr int kMaxRanks = 1024;
 
-// owner rank of an entry: last r with entry_offsets[r] <= id (negative ids -> last rank, they stay negative)
-__device__ __forceinline__ int owner_of(int64_t id, const int64_t* entry_offsets, int W)
+// owner rank of an entry: last r with entry_offsets[r] <= id.  Negative ids (rows to skip) stay negative and stay HOME:
+// they land in the asker's own bucket, so neither the id nor a row for it crosses the wire.
+__device__ __forceinline__ int owner_of(int64_t id, const int64_t* entry_offsets, int W, int me)
 {
-  if (id < 0) return W - 1;
+  if (id < 0) return me;
   int lo = 0, hi = W;  // invariant: offsets[lo] <= id < offsets[hi]
   while (hi - lo > 1) {
     int mid = (lo + hi) >> 1;
@@ -195,7 +196,7 @@ __device__ __forceinline__ int owner_of(int64_t id, const int64_t* entry_offsets
 template <typename IdxT>
 __global__ void __launch_bounds__(256)
 owner_histogram_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0,
-                       const int64_t* __restrict__ entry_offsets, int W, int* __restrict__ counts)
+                       const int64_t* __restrict__ entry_offsets, int W, int me, int* __restrict__ counts)
 {
   __shared__ int local[kMaxRanks];
   for (int r = threadIdx.x; r < W; r += blockDim.x) local[r] = 0;
@@ -203,7 +204,7 @@ owner_histogram_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
   {
     const int64_t id = (int64_t)idx[i];
-    atomicAdd(&local[owner_of(id < 0 ? id : id + row0, entry_offsets, W)], 1);
+    atomicAdd(&local[owner_of(id < 0 ? id : id + row0, entry_offsets, W, me)], 1);
   }
   __syncthreads();
   for (int r = threadIdx.x; r < W; r += blockDim.x)
@@ -222,7 +223,7 @@ owner_keys_kernel(const IdxT* __restrict__ idx, int64_t n, int64_t row0, const i
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t id = (int64_t)idx[i];
-  const int r      = owner_of(id < 0 ? id : id + row0, entry_offsets, W);
+  const int r      = owner_of(id < 0 ? id : id + row0, entry_offsets, W, me);
   keys[i]          = (uint32_t)((r - me - 1 + W) % W);
   vals[i]          = (int)i;
 }
@@ -286,9 +287,9 @@ void id_exchange::plan(wholememory_handle_t h, size_t entry_bytes, int64_t row0,
   if (n > 0) {
     int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
     if (idx_dtype == WHOLEMEMORY_DT_INT)
-      owner_histogram_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, d_counts);
+      owner_histogram_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(idx), n, row0, d_offsets, W, me, d_counts);
     else
-      owner_histogram_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, d_counts);
+      owner_histogram_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(idx), n, row0, d_offsets, W, me, d_counts);
     WG_HIP_CHECK(hipGetLastError());
   }
   // ---- 2. counts all-to-all ON THE DEVICE (W x int; nothing to trade on a single-rank communicator), then BOTH count

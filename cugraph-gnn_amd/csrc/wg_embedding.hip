@@ -27,8 +27,29 @@
 #include "wgamd_embedding.h"
 
 struct wholememory_embedding_cache_policy_ {
-  int unused;
+  wholememory_comm_t cache_comm                 = nullptr;
+  wholememory_memory_type_t memory_type         = WHOLEMEMORY_MT_NONE;
+  wholememory_memory_location_t memory_location = WHOLEMEMORY_ML_NONE;
+  wholememory_access_type_t access_type         = WHOLEMEMORY_AT_NONE;
+  float ratio                                   = 0.0f;
 };
+
+namespace wgamd {
+// The READONLY cache of one rank (private HBM): set-associative, kCacheWays lines per set, one 32-lane group per looked-up
+// id.  tags = cached entry id (-1: empty line), counts = hits since the line was filled (halved whenever the set refuses
+// a newcomer), locks = one try-lock per set, taken only by the insert kernel.
+constexpr int kCacheWays      = 32;
+constexpr int kCacheLockTries = 64;   // then the row is simply not cached this time
+struct cache_view {
+  int64_t* tags;
+  int* counts;
+  int* locks;
+  char* data;
+  int64_t n_sets, entries;
+  int64_t line_bytes;          // padded row
+  unsigned long long* stats;   // {hits, lookups} since creation / the last drop
+};
+}  // namespace wgamd
 
 struct wholememory_embedding_optimizer_ {
   wholememory_optimizer_type_t type = WHOLEMEMORY_OPT_NONE;
@@ -48,6 +69,9 @@ struct wholememory_embedding_ {
   std::vector<std::string> state_names;
   std::vector<wholememory_tensor_t> state_views;
   std::vector<const char*> names_c;  // NULL-terminated
+  bool cached = false;               // a READONLY local cache sits in front of `user`
+  wgamd::cache_view cache{};
+  wholememory_tensor_t cache_rows = nullptr;  // [lines, dim] view of cache.data (caller-storage tensor, no handle)
 };
 
 namespace wgamd {
@@ -82,6 +106,13 @@ template <typename T, int V>
 struct alignas(sizeof(T) * V) pack {
   T v[V];
 };
+
+template <int V> struct cvec;
+template <> struct cvec<16> { using type = uint4; };
+template <> struct cvec<8> { using type = uint2; };
+template <> struct cvec<4> { using type = uint32_t; };
+template <> struct cvec<2> { using type = uint16_t; };
+template <> struct cvec<1> { using type = uint8_t; };
 
 // sort key of a routed pair: its local row, or `local_rows` (one past the last row) for ids to skip
 // Arrival order = sender rank, then the sender's own order: pairs [0, n_before) came from lower ranks, the next n_self are
@@ -354,6 +385,244 @@ void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_t
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
 }
 
+// ---- READONLY local cache ---------------------------------------------------------------------------------------
+// What the reference does (cpp/src/wholememory/embedding.cpp:776-894 local_cached_global_readonly_embedding,
+// embedding_cache.hpp:34-163): a set-associative cache, 32 lines per set, LFU-ish replacement, held by a smaller
+// communicator in front of a table spread over a bigger one; a gather with adjust_cache first refreshes the cache with
+// the ids it is about to read, then reads through it.  Here the cache is private to one MI355X (the table already lives
+// in HBM, so what a cache can save is xGMI traffic to the peers, never a slower memory tier):
+//   1. lookup  — one 32-lane group per id reads its set's 32 tags in one 256-byte access and ballots; writes the cache
+//                line of every hit and the id of every miss (the other list gets -1 = "skip this row");
+//   2. hits    — the ordinary local row gather, cache lines -> output rows;
+//   3. misses  — the ordinary table gather with the miss list: skipped ids stay in the asker's own bucket of the
+//                exchange, so only missed rows cross the wire;
+//   4. insert  — (adjust_cache) the rows the misses just fetched are copied from the OUTPUT into the cache: no second
+//                fetch.  A set is updated under a try-lock; a group that keeps finding the lock taken, or finds every
+//                line of the set hit at least once since it was filled, gives up (the latter halves the set's counters
+//                first, so a stale hot line is displaced after log2(hits) refusals).  Best effort by design: whatever the
+//                cache holds is an exact copy of a table row, so a gather returns the same bytes with or without it.
+__device__ __forceinline__ int64_t cache_set_of(int64_t id, int64_t n_sets)
+{
+  return (int64_t)((((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 24) % (uint64_t)n_sets);
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(256)
+cache_lookup_kernel(cache_view c, const IdxT* __restrict__ idx, int64_t n, bool count_hits, int64_t* __restrict__ line_idx,
+                    int64_t* __restrict__ miss_idx)
+{
+  const int lane          = threadIdx.x & (kCacheWays - 1);
+  const int64_t group     = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups  = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  unsigned long long hits = 0, looked = 0;
+  for (int64_t i = group; i < n; i += n_groups) {
+    const int64_t id  = (int64_t)idx[i];
+    const bool valid  = id >= 0 && id < c.entries;
+    const int64_t set = valid ? cache_set_of(id, c.n_sets) : 0;
+    const int64_t tag = c.tags[set * kCacheWays + lane];
+    const uint64_t b  = __ballot(valid && tag == id);
+    const uint32_t hb = (uint32_t)(b >> (threadIdx.x & 32));
+    const int way     = hb ? __ffs(hb) - 1 : -1;
+    if (lane == 0) {
+      line_idx[i] = way >= 0 ? set * kCacheWays + way : -1;
+      miss_idx[i] = way >= 0 ? -1 : id;   // invalid ids go to the table gather as they are: same behaviour as uncached
+      looked += valid;
+      hits += way >= 0;
+    }
+    if (count_hits && way == lane) {
+      int* cnt = &c.counts[set * kCacheWays + lane];
+      if (*cnt < (1 << 24)) atomicAdd(cnt, 1);
+    }
+  }
+  if (lane == 0 && looked) {
+    atomicAdd(&c.stats[0], hits);
+    atomicAdd(&c.stats[1], looked);
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+cache_insert_kernel(cache_view c, const int64_t* __restrict__ miss_idx, int64_t n, const char* __restrict__ rows,
+                    int64_t row_stride, int row_bytes)
+{
+  using vec_t = typename cvec<V>::type;
+  const int lane         = threadIdx.x & (kCacheWays - 1);
+  const int half         = threadIdx.x & 32;
+  const int64_t group    = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  for (int64_t i = group; i < n; i += n_groups) {
+    const int64_t id = miss_idx[i];
+    if (id < 0 || id >= c.entries) continue;
+    const int64_t set  = cache_set_of(id, c.n_sets);
+    const int64_t line = set * kCacheWays + lane;
+    // Try-lock with a bounded number of retries.  The critical section sits INSIDE the retry loop: the two groups of one
+    // wave may want the same set, and the one that waits must not keep the wave inside a loop the holder has already left.
+    bool done = false;
+    for (int tries = 0; tries < kCacheLockTries && !done; tries++) {
+      int got = 0;
+      if (lane == 0) got = atomicCAS(&c.locks[set], 0, 1) == 0;
+      got = __shfl(got, half, 64);
+      if (!got) {
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      __threadfence();
+      const int64_t tag = __hip_atomic_load(&c.tags[line], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int cnt     = __hip_atomic_load(&c.counts[line], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool dup    = (uint32_t)(__ballot(tag == id) >> half) != 0;   // a duplicate of this id got here first
+      if (!dup) {
+        // victim = the empty line, else the least-hit one: min over (count + 1, lane) packed in one word
+        unsigned key = ((tag < 0 ? 0u : (unsigned)cnt + 1u) << 5) | (unsigned)lane;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+          const unsigned other = (unsigned)__shfl_xor((int)key, d, 64);
+          key                  = other < key ? other : key;
+        }
+        const int victim = (int)(key & 31u);
+        if ((key >> 5) <= 1u) {   // empty, or never hit since it was filled
+          char* dst       = c.data + (set * kCacheWays + victim) * c.line_bytes;
+          const char* src = rows + i * row_stride;
+          for (int off = lane * V; off + V <= row_bytes; off += kCacheWays * V)
+            *reinterpret_cast<vec_t*>(dst + off) = *reinterpret_cast<const vec_t*>(src + off);
+          if (lane == victim) {
+            __hip_atomic_store(&c.tags[line], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c.counts[line], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          __hip_atomic_store(&c.counts[line], cnt >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __threadfence();
+      if (lane == 0) atomicExch(&c.locks[set], 0);
+      done = true;
+    }
+  }
+}
+
+void cache_clear(const cache_view& c, hipStream_t stream)
+{
+  const size_t lines = (size_t)c.n_sets * kCacheWays;
+  WG_HIP_CHECK(hipMemsetAsync(c.tags, 0xff, lines * sizeof(int64_t), stream));
+  WG_HIP_CHECK(hipMemsetAsync(c.counts, 0, lines * sizeof(int), stream));
+  WG_HIP_CHECK(hipMemsetAsync(c.locks, 0, (size_t)c.n_sets * sizeof(int), stream));
+  WG_HIP_CHECK(hipMemsetAsync(c.stats, 0, 2 * sizeof(unsigned long long), stream));
+}
+
+void cache_release(wholememory_embedding_t e)
+{
+  if (e->cache_rows) wholememory_destroy_tensor(e->cache_rows);
+  e->cache_rows = nullptr;
+  for (void* p : {(void*)e->cache.tags, (void*)e->cache.counts, (void*)e->cache.locks, (void*)e->cache.data, (void*)e->cache.stats})
+    if (p) (void)hipFree(p);
+  e->cache  = cache_view{};
+  e->cached = false;
+}
+
+void cache_allocate(wholememory_embedding_t e, float ratio)
+{
+  cache_view& c = e->cache;
+  const size_t es = dtype_size(e->dtype);
+  c.entries    = e->entries;
+  c.line_bytes = e->padded_dim * (int64_t)es;
+  int64_t lines = (int64_t)((double)ratio * (double)e->entries);
+  c.n_sets      = std::max<int64_t>(1, (lines + kCacheWays - 1) / kCacheWays);
+  lines         = c.n_sets * kCacheWays;
+  try {
+    WG_HIP_CHECK(hipMalloc(&c.tags, (size_t)lines * sizeof(int64_t)));
+    WG_HIP_CHECK(hipMalloc(&c.counts, (size_t)lines * sizeof(int)));
+    WG_HIP_CHECK(hipMalloc(&c.locks, (size_t)c.n_sets * sizeof(int)));
+    WG_HIP_CHECK(hipMalloc(&c.data, (size_t)lines * (size_t)c.line_bytes));
+    WG_HIP_CHECK(hipMalloc(&c.stats, 2 * sizeof(unsigned long long)));
+    cache_clear(c, nullptr);
+    WG_HIP_CHECK(hipStreamSynchronize(nullptr));
+    wholememory_tensor_description_t d;
+    wholememory_initialize_tensor_desc(&d);
+    d.dim        = 2;
+    d.dtype      = e->dtype;
+    d.sizes[0]   = lines;
+    d.sizes[1]   = e->dim;
+    d.strides[0] = e->padded_dim;
+    d.strides[1] = 1;
+    if (wholememory_make_tensor_from_pointer(&e->cache_rows, c.data, &d) != WHOLEMEMORY_SUCCESS)
+      throw logic_error("cache line tensor");
+  } catch (...) {
+    cache_release(e);
+    throw;
+  }
+  e->cached = true;
+}
+
+// steps 1-4 above.  Falls back to the plain table gather when the output converts the dtype (a cache line is a byte copy
+// of a table row, and so must be what an insert reads back from the output).
+void cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_tensor_t output, bool adjust_cache,
+                   wholememory_env_func_t* env, hipStream_t stream)
+{
+  WG_REQUIRE_INPUT(indices && output && env, "null argument");
+  const auto* id = wholememory_tensor_get_tensor_description(indices);
+  const auto* od = wholememory_tensor_get_tensor_description(output);
+  WG_REQUIRE_INPUT(id->dim == 1 && (id->dtype == WHOLEMEMORY_DT_INT || id->dtype == WHOLEMEMORY_DT_INT64) && id->strides[0] == 1,
+                   "indices must be a contiguous 1-D int32 / int64 tensor");
+  WG_REQUIRE_INPUT(!wholememory_tensor_has_handle(indices) && !wholememory_tensor_has_handle(output),
+                   "indices / output must be plain device tensors");
+  const int64_t n = id->sizes[0];
+  auto plain = [&] {
+    const auto rc = wholememory_gather(e->user, indices, output, env, stream, -1);
+    if (rc != WHOLEMEMORY_SUCCESS) throw logic_error(fmt("table gather failed (%d)", (int)rc));
+  };
+  if (n == 0 || od->dim != 2 || od->dtype != e->dtype || od->sizes[1] != e->dim || od->strides[1] != 1 || od->sizes[0] < n) {
+    plain();   // (argument errors are reported by the table gather, with its own messages)
+    return;
+  }
+  temp_arena arena(env);
+  const size_t o_line = arena.add(sizeof(int64_t) * n), o_miss = arena.add(sizeof(int64_t) * n);
+  arena.commit();
+  int64_t* line_idx = arena.at<int64_t>(o_line);
+  int64_t* miss_idx = arena.at<int64_t>(o_miss);
+  const cache_view& c = e->cache;
+  const char* idx = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices)) + id->storage_offset * dtype_size(id->dtype);
+  const int grid  = (int)std::max<int64_t>(1, std::min<int64_t>((n * kCacheWays + 255) / 256, 256 * 16));
+  if (id->dtype == WHOLEMEMORY_DT_INT)
+    cache_lookup_kernel<int32_t><<<grid, 256, 0, stream>>>(c, reinterpret_cast<const int32_t*>(idx), n, adjust_cache, line_idx, miss_idx);
+  else
+    cache_lookup_kernel<int64_t><<<grid, 256, 0, stream>>>(c, reinterpret_cast<const int64_t*>(idx), n, adjust_cache, line_idx, miss_idx);
+  WG_HIP_CHECK(hipGetLastError());
+
+  wholememory_tensor_description_t ld;
+  wholememory_initialize_tensor_desc(&ld);
+  ld.dim        = 1;
+  ld.dtype      = WHOLEMEMORY_DT_INT64;
+  ld.sizes[0]   = n;
+  ld.strides[0] = 1;
+  wholememory_tensor_t line_t = nullptr, miss_t = nullptr;
+  WG_EXPECTS(wholememory_make_tensor_from_pointer(&line_t, line_idx, &ld) == WHOLEMEMORY_SUCCESS &&
+               wholememory_make_tensor_from_pointer(&miss_t, miss_idx, &ld) == WHOLEMEMORY_SUCCESS,
+             "index tensor");
+  const auto rc_hit  = wholememory_gather(e->cache_rows, line_t, output, env, stream, -1);
+  const auto rc_miss = wholememory_gather(e->user, miss_t, output, env, stream, -1);
+  wholememory_destroy_tensor(line_t);
+  wholememory_destroy_tensor(miss_t);
+  if (rc_hit != WHOLEMEMORY_SUCCESS || rc_miss != WHOLEMEMORY_SUCCESS)
+    throw logic_error(fmt("gather through the cache failed (%d, %d)", (int)rc_hit, (int)rc_miss));
+
+  if (adjust_cache) {
+    const size_t es      = dtype_size(e->dtype);
+    const char* rows     = static_cast<const char*>(wholememory_tensor_get_data_pointer(output)) + od->storage_offset * es;
+    const int64_t stride = od->strides[0] * (int64_t)es;
+    const int row_bytes  = (int)(e->dim * (int64_t)es);
+    int V = 16;
+    while (V > 1 && ((row_bytes | stride | (int64_t)reinterpret_cast<uintptr_t>(rows)) & (V - 1)) != 0) V >>= 1;
+    switch (V) {
+      case 16: cache_insert_kernel<16><<<grid, 256, 0, stream>>>(c, miss_idx, n, rows, stride, row_bytes); break;
+      case 8: cache_insert_kernel<8><<<grid, 256, 0, stream>>>(c, miss_idx, n, rows, stride, row_bytes); break;
+      case 4: cache_insert_kernel<4><<<grid, 256, 0, stream>>>(c, miss_idx, n, rows, stride, row_bytes); break;
+      case 2: cache_insert_kernel<2><<<grid, 256, 0, stream>>>(c, miss_idx, n, rows, stride, row_bytes); break;
+      default: cache_insert_kernel<1><<<grid, 256, 0, stream>>>(c, miss_idx, n, rows, stride, row_bytes); break;
+    }
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // the two index lists are released on return
+}
+
 }  // namespace
 }  // namespace wgamd
 
@@ -395,15 +664,25 @@ wholememory_error_code_t wholememory_optimizer_set_parameter(wholememory_embeddi
 void wholememory_destroy_embedding_optimizer(wholememory_embedding_optimizer_t optimizer) { delete optimizer; }
 
 wholememory_error_code_t wholememory_create_embedding_cache_policy(wholememory_embedding_cache_policy_t* cache_policy,
-                                                                   wholememory_comm_t, wholememory_memory_type_t,
-                                                                   wholememory_memory_location_t, wholememory_access_type_t,
-                                                                   float)
+                                                                   wholememory_comm_t cache_level_comm,
+                                                                   wholememory_memory_type_t memory_type,
+                                                                   wholememory_memory_location_t memory_location,
+                                                                   wholememory_access_type_t access_type, float cache_ratio)
 {
-  if (cache_policy) *cache_policy = nullptr;
-  fprintf(stderr,
-          "[wholegraph_amd] embedding cache policies are not supported: tables live in HBM (DISTRIBUTED/DEVICE), there is "
-          "no slower tier to cache\n");
-  return WHOLEMEMORY_NOT_SUPPORTED;
+  if (!cache_policy) return WHOLEMEMORY_INVALID_INPUT;
+  *cache_policy = nullptr;
+  if (cache_ratio > 1.0f || cache_ratio < 1.0f / 512) {  // embedding.cpp:917-920
+    fprintf(stderr, "[wholegraph_amd] cache_ratio should in range [1/512, 1.0]\n");
+    return WHOLEMEMORY_INVALID_VALUE;
+  }
+  auto* p            = new wholememory_embedding_cache_policy_();
+  p->cache_comm      = cache_level_comm;
+  p->memory_type     = memory_type;
+  p->memory_location = memory_location;
+  p->access_type     = access_type;
+  p->ratio           = cache_ratio;
+  *cache_policy      = p;
+  return WHOLEMEMORY_SUCCESS;
 }
 
 wholememory_error_code_t wholememory_destroy_embedding_cache_policy(wholememory_embedding_cache_policy_t cache_policy)
@@ -424,9 +703,27 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* o
     fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: the description must be a 2-D matrix\n");
     return WHOLEMEMORY_INVALID_INPUT;
   }
-  if (cache_policy != nullptr || round_robin_size != 0) {
-    fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: cache policies / round-robin sharding are not supported\n");
+  if (round_robin_size != 0) {
+    fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: round-robin sharding is not supported\n");
     return WHOLEMEMORY_NOT_SUPPORTED;
+  }
+  if (cache_policy != nullptr) {
+    // embedding.cpp:957-1009.  A READWRITE cache is the reference's device cache in front of a HOST table: every table
+    // here is in HBM, there is nothing slower to write back to.  A READONLY cache saves peer traffic and is built
+    // (per rank, in private HBM) whatever communicator / memory type the policy names for it.
+    if (cache_policy->access_type != WHOLEMEMORY_AT_READONLY) {
+      fprintf(stderr,
+              "[wholegraph_amd] wholememory_create_embedding: only WHOLEMEMORY_AT_READONLY caches exist on this target "
+              "(a READWRITE device cache fronts a host-resident table; tables live in HBM here)\n");
+      return WHOLEMEMORY_NOT_SUPPORTED;
+    }
+    if (cache_policy->cache_comm != comm && cache_policy->memory_type == WHOLEMEMORY_MT_DISTRIBUTED) {
+      fprintf(stderr,
+              "[wholegraph_amd] wholememory_create_embedding: for local cached global readonly embedding, "
+              "cache_memory_type should be chunked or continuous\n");
+      return WHOLEMEMORY_INVALID_INPUT;  // embedding.cpp:986-992
+    }
+    embedding_entry_partition = nullptr;  // embedding.cpp:1009
   }
   const size_t es = wholememory_dtype_get_element_size(desc->dtype);
   if (es == 0 || es > 16) return WHOLEMEMORY_INVALID_INPUT;
@@ -454,7 +751,16 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* o
     return rc;
   }
   e->names_c = {nullptr};
-  *out       = e;
+  if (cache_policy != nullptr) {
+    rc = guarded("wholememory_create_embedding", [&] { cache_allocate(e, cache_policy->ratio); });
+    if (rc != WHOLEMEMORY_SUCCESS) {
+      wholememory_destroy_tensor(e->user);
+      wholememory_destroy_tensor(e->allocated);
+      delete e;
+      return rc;
+    }
+  }
+  *out = e;
   return WHOLEMEMORY_SUCCESS;
 }
 
@@ -462,6 +768,7 @@ wholememory_error_code_t wholememory_destroy_embedding(wholememory_embedding_t e
 {
   if (!e) return WHOLEMEMORY_INVALID_INPUT;
   destroy_states(e);
+  cache_release(e);
   wholememory_destroy_tensor(e->user);
   wholememory_destroy_tensor(e->allocated);
   delete e;
@@ -476,6 +783,10 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
   if (e->optimizer) {
     fprintf(stderr, "[wholegraph_amd] wholememory_embedding_set_optimizer: the optimizer can only be set once\n");
     return WHOLEMEMORY_LOGIC_ERROR;  // embedding.cpp:487-491
+  }
+  if (e->cached) {
+    fprintf(stderr, "[wholegraph_amd] optimizer not supported for local cached global readonly embedding.\n");
+    return WHOLEMEMORY_INVALID_INPUT;  // embedding.cpp:55-60
   }
   if (e->dtype != WHOLEMEMORY_DT_FLOAT && e->dtype != WHOLEMEMORY_DT_HALF && e->dtype != WHOLEMEMORY_DT_BF16) {
     fprintf(stderr, "[wholegraph_amd] wholememory_embedding_set_optimizer: trainable tables are float / half / bf16\n");
@@ -549,10 +860,14 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
 }
 
 wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t e, wholememory_tensor_t indices,
-                                                      wholememory_tensor_t output, bool /*adjust_cache*/,
+                                                      wholememory_tensor_t output, bool adjust_cache,
                                                       wholememory_env_func_t* p_env_fns, int64_t stream_int)
 {
   if (!e) return WHOLEMEMORY_INVALID_INPUT;
+  if (e->cached)
+    return guarded("wholememory_embedding_gather", [&] {
+      cached_gather(e, indices, output, adjust_cache, p_env_fns, reinterpret_cast<hipStream_t>(stream_int));
+    });
   return wholememory_gather(e->user, indices, output, p_env_fns, reinterpret_cast<void*>(stream_int), -1);
 }
 
@@ -583,9 +898,30 @@ wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embed
   return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
 }
 
-wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t)
+wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t stream_int)
 {
-  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+  if (!e) return WHOLEMEMORY_INVALID_INPUT;
+  if (!e->cached) return WHOLEMEMORY_SUCCESS;
+  return guarded("wholememory_embedding_drop_all_cache", [&] {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_int);
+    cache_clear(e->cache, stream);
+    WG_HIP_CHECK(hipStreamSynchronize(stream));
+  });
+}
+
+wholememory_error_code_t wgamd_embedding_cache_stats(wholememory_embedding_t e, int64_t* hits, int64_t* lookups, int64_t* lines)
+{
+  if (!e || !hits || !lookups) return WHOLEMEMORY_INVALID_INPUT;
+  *hits = *lookups = 0;
+  if (lines) *lines = 0;
+  if (!e->cached) return WHOLEMEMORY_SUCCESS;
+  return guarded("wgamd_embedding_cache_stats", [&] {
+    unsigned long long h[2];
+    WG_HIP_CHECK(hipMemcpy(h, e->cache.stats, sizeof(h), hipMemcpyDeviceToHost));
+    *hits    = (int64_t)h[0];
+    *lookups = (int64_t)h[1];
+    if (lines) *lines = e->cache.n_sets * kCacheWays;
+  });
 }
 
 }  // extern "C"

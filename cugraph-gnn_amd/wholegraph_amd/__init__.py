@@ -12,9 +12,11 @@ from . import _lib, comm, dist, embedding, env, fused, graph_ops, nn, wholegraph
 from ._lib import WholeGraphLibraryError, WholeMemoryError  # noqa: F401
 from .graph_structure import GraphStructure  # noqa: F401
 from .comm import (WholeMemoryCommunicator, create_group_communicator,  # noqa: F401
-                   destroy_communicator, get_global_communicator)
+                   destroy_communicator, get_global_communicator, get_local_device_communicator,
+                   get_local_node_communicator)
 from .tensor import (DistributedWholeMemoryTensor, WholeMemoryTensor,  # noqa: F401
                      create_wholememory_tensor, destroy_wholememory_tensor, equal_entry_partition)
-from .embedding import (WholeMemoryEmbedding, WholeMemoryEmbeddingModule, WholeMemoryOptimizer,  # noqa: F401
-                        create_builtin_cache_policy, create_embedding, create_embedding_from_filelist,
+from .embedding import (WholeMemoryCachePolicy, WholeMemoryEmbedding, WholeMemoryEmbeddingModule,  # noqa: F401
+                        WholeMemoryOptimizer, create_builtin_cache_policy, create_wholememory_cache_policy,
+                        destroy_wholememory_cache_policy, create_embedding, create_embedding_from_filelist,
                         create_wholememory_optimizer, destroy_embedding, destroy_wholememory_optimizer)

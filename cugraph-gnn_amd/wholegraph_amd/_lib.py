@@ -189,6 +189,7 @@ SYMBOLS = {
     "wholememory_embedding_get_optimizer_state": (_T, [c_void_p, ctypes.c_char_p]),
     "wholememory_embedding_writeback_cache": (c_int, [c_void_p, c_int64]),
     "wholememory_embedding_drop_all_cache": (c_int, [c_void_p, c_int64]),
+    "wgamd_embedding_cache_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     # wgamd_ext.h
     "wgamd_csr_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "wgamd_csr_transpose_i32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

@@ -133,6 +133,24 @@ def get_global_communicator(distributed_backend="nccl"):
     return _global_communicators["nccl"]
 
 
+def get_local_node_communicator():
+    """One communicator per node (comm.py:228-246); the node size is ``LOCAL_WORLD_SIZE`` (torchrun), else the world."""
+    import os
+    import torch.distributed as dist
+    if "local_node" not in _global_communicators:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        _global_communicators["local_node"] = create_group_communicator(local if world % local == 0 else world)
+    return _global_communicators["local_node"]
+
+
+def get_local_device_communicator():
+    """A communicator of this rank alone (comm.py:249-266)."""
+    if "local_device" not in _global_communicators:
+        _global_communicators["local_device"] = create_group_communicator(1)
+    return _global_communicators["local_device"]
+
+
 def reset_communicators():
     for c in _global_communicators.values():
         c.destroy()

@@ -5,9 +5,10 @@
 The table is a DISTRIBUTED handle of the library (rows range-partitioned over the GPUs of the communicator, in
 HBM); ``gather`` is the all-to-all feature fetch, ``apply_gradients`` routes every (row, gradient) to the owner,
 sums duplicates there and runs the optimizer update in one HIP kernel (csrc/wg_embedding.hip).  There is no
-slower memory tier on this target, so the reference's device caches do not exist here:
-``create_builtin_cache_policy("none", ...)`` returns ``None`` like the reference, every other cache request
-raises ``NotImplementedError`` instead of silently training without the cache the caller asked for.
+slower memory tier on this target, so the reference's READWRITE device cache (in front of a host table) does not exist:
+asking for one raises instead of silently training without it.  A READONLY cache policy builds the reference's
+"local cached global readonly embedding": hot rows owned by peer GPUs are kept in a set-associative cache in this
+GPU's own HBM, and a gather returns the same bytes with or without it (include/wgamd_embedding.h).
 """
 import ctypes
 from typing import List, Union
@@ -15,7 +16,8 @@ from typing import List, Union
 import torch
 
 from . import _lib as L
-from .comm import WholeMemoryCommunicator, memory_location_code, memory_type_code
+from .comm import (WholeMemoryCommunicator, get_global_communicator, get_local_device_communicator,
+                   get_local_node_communicator, memory_location_code, memory_type_code)
 from .env import get_stream, get_wholegraph_env_fns, torch_dtype_to_wm, wrap_torch_tensor
 from .tensor import DistributedWholeMemoryTensor
 
@@ -65,33 +67,61 @@ class WholeMemoryOptimizer(object):
 
 
 class WholeMemoryCachePolicy(object):
-    """Exists for signature parity (embedding.py:71-80); cannot be created on this target."""
+    """embedding.py:71-80.  Use :func:`create_wholememory_cache_policy` / :func:`create_builtin_cache_policy`."""
+
+    def __init__(self, c_policy, access_type: str):
+        self.c_policy = c_policy
+        self.access_type = access_type
 
 
 def create_wholememory_cache_policy(cache_comm, *, memory_type: str = "chunked", memory_location: str = "cuda",
                                     access_type: str = "readonly", ratio: float = 0.5):
-    """embedding.py:83-110.  Asks the library, which answers WHOLEMEMORY_NOT_SUPPORTED (include/wgamd_embedding.h)."""
+    """embedding.py:83-110.  The policy is only recorded here; :func:`create_embedding` judges it (READONLY: a private
+    per-GPU cache of ``ratio * entries`` rows; READWRITE: refused, there is no host tier to write back to)."""
     c = ctypes.c_void_p()
-    rc = L.lib().wholememory_create_embedding_cache_policy(ctypes.byref(c), cache_comm.c_comm, 0, 0,
-                                                           _ACCESS_TYPES[access_type], float(ratio))
-    raise NotImplementedError("embedding cache policies do not exist on this target (every table lives in HBM); "
-                              "the library answered error code %d" % rc)
+    L.check(L.lib().wholememory_create_embedding_cache_policy(ctypes.byref(c), cache_comm.c_comm,
+                                                              memory_type_code(memory_type),
+                                                              memory_location_code(memory_location),
+                                                              _ACCESS_TYPES[access_type], float(ratio)),
+            "wholememory_create_embedding_cache_policy")
+    return WholeMemoryCachePolicy(c, access_type)
 
 
 def destroy_wholememory_cache_policy(cache_policy):
-    return None
+    """embedding.py:113-121."""
+    if cache_policy is not None and cache_policy.c_policy is not None:
+        L.check(L.lib().wholememory_destroy_embedding_cache_policy(cache_policy.c_policy), "destroy_cache_policy")
+        cache_policy.c_policy = None
 
 
 def create_builtin_cache_policy(builtin_cache_type: str, embedding_memory_type: str, embedding_memory_location: str,
-                                access_type: str, cache_ratio: float, *, cache_memory_type=None,
-                                cache_memory_location=None):
-    """embedding.py:124-216: ``"none"`` -> ``None``; the device-cache flavours are refused loudly."""
+                                access_type: str, cache_ratio: float, *, cache_memory_type: str = "",
+                                cache_memory_location: str = ""):
+    """embedding.py:124-216: ``"none"`` -> ``None``; ``"all_devices"`` / ``"local_node"`` / ``"local_device"`` name the
+    communicator the reference would spread the cache over (here every GPU keeps its own lines either way)."""
+    if embedding_memory_type not in ("continuous", "chunked", "distributed", "hierarchy"):
+        raise ValueError(f"embedding_memory_type={embedding_memory_type} is not valid")
+    if embedding_memory_location not in ("cpu", "cuda"):
+        raise ValueError(f"embedding_memory_location={embedding_memory_location} is not valid")
     if builtin_cache_type == "none":
         return None
-    if builtin_cache_type in ("local_device", "local_node", "all_devices"):
-        raise NotImplementedError("builtin_cache_type=%s: no cache tier on this target, pass 'none'" % builtin_cache_type)
-    raise ValueError(f"builtin_cache_type={builtin_cache_type} not supported, "
-                     f"should be none, local_device, local_node or all_devices")
+    if cache_memory_location not in ("", "cpu", "cuda"):
+        raise ValueError(f"cache_memory_location is {cache_memory_location}, should be empty or cpu, cuda")
+    cache_memory_location = "cuda" if cache_memory_location == "" else cache_memory_location
+    if builtin_cache_type == "all_devices":
+        cache_memory_type = embedding_memory_type if cache_memory_type == "" else cache_memory_type
+        comm = get_global_communicator()
+    elif builtin_cache_type == "local_node":
+        cache_memory_type = "chunked" if cache_memory_type == "" else cache_memory_type
+        comm = get_local_node_communicator()
+    elif builtin_cache_type == "local_device":
+        cache_memory_type = "continuous"
+        comm = get_local_device_communicator()
+    else:
+        raise ValueError(f"builtin_cache_type={builtin_cache_type} not supported, "
+                         f"should be none, local_device, local_node or all_devices")
+    return create_wholememory_cache_policy(comm, memory_type=cache_memory_type, memory_location=cache_memory_location,
+                                           access_type=access_type, ratio=cache_ratio)
 
 
 class EmbeddingLookupFn(torch.autograd.Function):
@@ -139,7 +169,14 @@ class WholeMemoryEmbedding(object):
         return self.get_embedding_tensor().shape
 
     def set_adjust_cache(self, adjust_cache: bool):
-        self.adjust_cache = False  # no cache to adjust
+        self.adjust_cache = bool(adjust_cache) and self.wmb_cache_policy is not None
+
+    def cache_stats(self):
+        """(hits, valid lookups, lines) of THIS rank's cache since creation / the last ``drop_all_cache``."""
+        h, n, lines = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        L.check(L.lib().wgamd_embedding_cache_stats(self.c_embedding, ctypes.byref(h), ctypes.byref(n), ctypes.byref(lines)),
+                "wgamd_embedding_cache_stats")
+        return h.value, n.value, lines.value
 
     def need_grad(self):
         return self.wm_optimizer is not None
@@ -221,9 +258,10 @@ class WholeMemoryEmbedding(object):
 def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_location: str, dtype: torch.dtype,
                      sizes: List[int], *, cache_policy=None, embedding_entry_partition: Union[List[int], None] = None,
                      random_init: bool = False, gather_sms: int = -1, round_robin_size: int = 0):
-    """embedding.py:410-495.  ``memory_type`` must be "distributed", ``memory_location`` "cuda"."""
-    if cache_policy is not None:
-        raise NotImplementedError("cache_policy must be None on this target")
+    """embedding.py:410-495.  ``memory_location`` "cuda"; ``cache_policy``: None or a READONLY policy."""
+    if cache_policy is not None and cache_policy.access_type != "readonly":
+        raise NotImplementedError("only access_type='readonly' cache policies exist on this target: a readwrite device "
+                                  "cache fronts a host-resident table, and every table lives in HBM here")
     assert len(sizes) == 2
     if embedding_entry_partition is not None and round_robin_size != 0:
         print("round_robin_size is ignored because embedding_entry_partition is specified")
@@ -240,9 +278,11 @@ def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_loc
     c = ctypes.c_void_p()
     L.check(L.lib().wholememory_create_embedding(ctypes.byref(c), ctypes.byref(desc), comm.c_comm,
                                                  memory_type_code(memory_type), memory_location_code(memory_location),
-                                                 None, part, int(gather_sms), int(round_robin_size)),
+                                                 cache_policy.c_policy if cache_policy is not None else None, part,
+                                                 int(gather_sms), int(round_robin_size)),
             "wholememory_create_embedding")
-    wm_embedding = WholeMemoryEmbedding(c, comm, None)
+    wm_embedding = WholeMemoryEmbedding(c, comm, cache_policy)
+    wm_embedding.adjust_cache = cache_policy is not None  # embedding.py:289: adjust_cache = cache_policy is not None
     if random_init is True:
         local_tensor, _ = wm_embedding.get_embedding_tensor().get_local_tensor()
         if local_tensor.numel():

@@ -2,10 +2,13 @@
  * wgamd_embedding.h — trainable embedding tables with sparse optimizers on top of DISTRIBUTED tensors.
  * Replaces /root/reference/cpp/include/wholememory/embedding.h:17-237 (same names, argument meaning, defaults and
  * error behaviour) for what exists on an MI355X node:
- *   * storage is WHOLEMEMORY_MT_DISTRIBUTED / WHOLEMEMORY_ML_DEVICE (one partition per GPU in HBM, wgamd_comm.h);
- *     there is no host-resident table, hence no device cache in front of one: creating a cache policy returns
- *     WHOLEMEMORY_NOT_SUPPORTED, the writeback / drop entry points succeed as no-ops (embedding.cpp:514-548 do the
- *     same when no cache is attached);
+ *   * storage is WHOLEMEMORY_ML_DEVICE (one partition per GPU in HBM, wgamd_comm.h); there is no host-resident table,
+ *     hence no READWRITE device cache in front of one (create_embedding answers WHOLEMEMORY_NOT_SUPPORTED for such a
+ *     policy).  A WHOLEMEMORY_AT_READONLY policy builds the reference's "local cached global readonly embedding"
+ *     (embedding.cpp:776-894): a set-associative cache of table rows in every rank's own HBM, so that repeated reads of
+ *     hot rows owned by peers stop crossing xGMI.  A gather returns the same bytes with or without the cache;
+ *     adjust_cache = true lets the gather insert the rows it missed; writeback is a no-op (nothing is dirty),
+ *     drop_all_cache empties it (call it after writing the table through its tensor);
  *   * round_robin_size must be 0.
  * Layout: the table rows are padded to 16 bytes (embedding.cpp:45-58, align_embedding_dim); the per-element optimizer
  * states live in ONE fp32 table [entries, n_states * padded_dim] with the same row partition, the per-row LazyAdam
@@ -51,7 +54,8 @@ wholememory_error_code_t wholememory_optimizer_set_parameter(wholememory_embeddi
                                                              const char* parameter_name, void* value);
 void wholememory_destroy_embedding_optimizer(wholememory_embedding_optimizer_t optimizer);
 
-/* embedding.h:96-110 — WHOLEMEMORY_NOT_SUPPORTED here (see the header comment); destroy accepts NULL. */
+/* embedding.h:96-110 — cache_ratio outside [1/512, 1] -> WHOLEMEMORY_INVALID_VALUE (embedding.cpp:917-920); every other
+ * combination is recorded and judged by wholememory_create_embedding.  destroy accepts NULL. */
 wholememory_error_code_t wholememory_create_embedding_cache_policy(wholememory_embedding_cache_policy_t* cache_policy,
                                                                    wholememory_comm_t cache_level_comm,
                                                                    wholememory_memory_type_t memory_type,
@@ -61,7 +65,11 @@ wholememory_error_code_t wholememory_create_embedding_cache_policy(wholememory_e
 wholememory_error_code_t wholememory_destroy_embedding_cache_policy(wholememory_embedding_cache_policy_t cache_policy);
 
 /* embedding.h:127-144.  embedding_tensor_description: 2-D, dtype FLOAT / HALF / BF16 for trainable tables (any dtype
- * for read-only ones).  cache_policy must be NULL, round_robin_size 0; embedding_entry_partition NULL = equal split. */
+ * for read-only ones).  round_robin_size 0; embedding_entry_partition NULL = equal split (ignored with a cache policy,
+ * embedding.cpp:1009).  cache_policy: NULL, or a WHOLEMEMORY_AT_READONLY policy — cache_ratio * entries lines (rounded up to
+ * sets of 32) of private HBM per rank, whatever communicator the policy names; a cache communicator other than `comm`
+ * with cache memory type DISTRIBUTED -> WHOLEMEMORY_INVALID_INPUT (embedding.cpp:986-992); READWRITE ->
+ * WHOLEMEMORY_NOT_SUPPORTED.  set_optimizer on a cached embedding -> WHOLEMEMORY_INVALID_INPUT (embedding.cpp:55-60). */
 wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* wholememory_embedding,
                                                       wholememory_tensor_description_t* embedding_tensor_description,
                                                       wholememory_comm_t comm,
@@ -79,7 +87,8 @@ wholememory_tensor_t wholememory_embedding_get_embedding_tensor(wholememory_embe
 wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embedding_t wholememory_embedding,
                                                              wholememory_embedding_optimizer_t optimizer);
 
-/* embedding.h:173-178 — wholememory_gather on the embedding tensor (adjust_cache is ignored: no cache). */
+/* embedding.h:173-178 — wholememory_gather on the embedding tensor; with a cache: hits are copied from the cache lines,
+ * only the misses go to the table (and, with adjust_cache, are then inserted).  Collective when the table is. */
 wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t wholememory_embedding,
                                                       wholememory_tensor_t indices,
                                                       wholememory_tensor_t output,
@@ -103,11 +112,17 @@ const char* const* wholememory_embedding_get_optimizer_state_names(wholememory_e
 wholememory_tensor_t wholememory_embedding_get_optimizer_state(wholememory_embedding_t wholememory_embedding,
                                                                const char* name);
 
-/* embedding.h:223-233 — no cache: nothing to write back or drop, WHOLEMEMORY_SUCCESS. */
+/* embedding.h:223-233 — writeback: nothing is ever dirty, WHOLEMEMORY_SUCCESS; drop: every line of this rank's cache is
+ * emptied and its statistics zeroed. */
 wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t wholememory_embedding,
                                                                int64_t stream_int);
 wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t wholememory_embedding,
                                                               int64_t stream_int);
+
+/* Not in the reference: hits / valid lookups since creation (or the last drop) and the number of cache lines of THIS
+ * rank's cache; all zero without a cache.  `lines` may be NULL. */
+wholememory_error_code_t wgamd_embedding_cache_stats(wholememory_embedding_t wholememory_embedding, int64_t* hits,
+                                                     int64_t* lookups, int64_t* lines);
 
 #ifdef __cplusplus
 }

@@ -209,10 +209,23 @@ def test_error_behaviour(comm):
     assert lib.wholememory_optimizer_set_parameter(c, b"nonsense", ctypes.byref(v)) == L.WHOLEMEMORY_INVALID_INPUT
     lib.wholememory_destroy_embedding_optimizer(c)
     pol = ctypes.c_void_p()
-    assert lib.wholememory_create_embedding_cache_policy(ctypes.byref(pol), comm.c_comm, 0, 0, 1,
-                                                         ctypes.c_float(0.5)) == L.WHOLEMEMORY_NOT_SUPPORTED
+    # embedding.cpp:917-920: the ratio range is the only thing a policy is judged on at creation
+    assert lib.wholememory_create_embedding_cache_policy(ctypes.byref(pol), comm.c_comm, 2, 2, 1,
+                                                         ctypes.c_float(1.5)) == L.WHOLEMEMORY_INVALID_VALUE
+    assert lib.wholememory_create_embedding_cache_policy(ctypes.byref(pol), comm.c_comm, 2, 2, 1,
+                                                         ctypes.c_float(0.001)) == L.WHOLEMEMORY_INVALID_VALUE
+    # a READWRITE device cache fronts a host table: refused when the embedding is created, loudly
+    rw = wg.create_wholememory_cache_policy(comm, memory_type="chunked", access_type="readwrite", ratio=0.5)
     with pytest.raises(NotImplementedError):
-        wg.create_builtin_cache_policy("local_device", "distributed", "cuda", "readonly", 0.5)
+        wg.create_embedding(comm, "distributed", "cuda", torch.float32, [100, 8], cache_policy=rw)
+    desc = L.TensorDescription()
+    lib.wholememory_initialize_tensor_desc(ctypes.byref(desc))
+    desc.dim, desc.dtype = 2, L.DT_FLOAT
+    desc.sizes[0], desc.sizes[1], desc.strides[0], desc.strides[1] = 100, 8, 8, 1
+    e = ctypes.c_void_p()
+    assert lib.wholememory_create_embedding(ctypes.byref(e), ctypes.byref(desc), comm.c_comm, L.MT_DISTRIBUTED, L.ML_DEVICE, rw.c_policy, None, -1,
+                                            0) == L.WHOLEMEMORY_NOT_SUPPORTED
+    wg.destroy_wholememory_cache_policy(rw)
     assert wg.create_builtin_cache_policy("none", "distributed", "cuda", "readonly", 0.5) is None
     with pytest.raises(ValueError):
         wg.create_builtin_cache_policy("bogus", "distributed", "cuda", "readonly", 0.5)
