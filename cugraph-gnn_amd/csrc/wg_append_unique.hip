@@ -354,6 +354,339 @@ void prepare_packed_t(const KeyT* targets, dev_count T, const KeyT* neighbors, d
   exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);
 }
 
+// ---- call groups, per-batch tables in LDS ----------------------------------------------------------------------------
+// A mini-batch is renumbered on its own, so its table never has to be shared across the device — and a device-wide table
+// costs one memory-side atomic per new key plus one fabric-side load per probe (gfx950: agent-scope atomics and sc1 loads
+// are resolved beyond the XCD's L2), 24 G keys/s on an MI355X however it is laid out.  Instead:
+//   1. bucket_count   block (batch, chunk): histogram of the chunk's ids over the batch's R hash ranges
+//                     (R = positions / 5,500: what one LDS table holds at load <= 0.55) -> counts[range][chunk];
+//   2. bucket_scatter same blocks: prefix of the batch's counts (no scan kernel: a batch's buckets fill exactly the
+//                     batch's own stretch of the position space) -> (id, position) pairs grouped by range, streamed;
+//   3. renumber_lds   workgroup (batch, range): its bucket goes into a 10,000-slot open-addressing table in LDS
+//                     (word = [ id | first position ], ds_cmpst / ds_min), then the bucket's neighbours look their first
+//                     positions up.  Every lane has work (the bucket is dense), no table in global memory, nothing to
+//                     clear, no global atomics.  A range whose DISTINCT ids overfill the table (a hot id repeated is
+//                     one key) is split in two and redone through a hash filter, so any id distribution terminates.
+// Cost is linear in the positions whatever the batch size.  Scratch: the pairs live where the device-wide table would
+// (8 B x slots >= 16 B per position), the counts where its positions array would.
+constexpr int kLdsSlots      = 10000;     // 80,000 B: two workgroups per CU, one computes while the other waits on its loads
+constexpr int kLdsKeysTarget = 3000;      // positions per range the range count is sized for (load <= 0.3: short probe chains)
+constexpr int kLdsProbeLimit = 256;       // probes after which a range is declared overfull and split
+constexpr int kLdsThreads    = 1024;
+constexpr int kLdsMaxRanges  = 2048;      // per batch; beyond, ranges simply start overfull and split
+constexpr int kLdsStack      = 40;        // pending hash ranges of one workgroup (a split pushes two, pops one)
+constexpr int kLdsChunks     = 16;        // blocks per batch in the two bucketing kernels
+constexpr int kBucketThreads = 256;
+constexpr int kLdsUnroll     = 6;         // pairs in flight per thread of the table kernel
+
+__device__ __forceinline__ uint32_t hash_id32(uint32_t h)   // murmur3 finaliser
+{
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  return h ^ (h >> 16);
+}
+template <typename KeyT>
+__device__ __forceinline__ uint32_t hash_id(KeyT id)
+{
+  if constexpr (sizeof(KeyT) == 4) return hash_id32((uint32_t)id);
+  else return hash_key((uint64_t)id);
+}
+
+// one mini-batch of the call group: its targets [t0, t0 + nT), its neighbours [e0, e0 + nE), its R hash ranges and where its
+// range records start (rb: every batch gets floor(positions before it / kLdsKeysTarget) + b, which leaves room for its R)
+struct batch_part {
+  int t0, nT, e0, nE, P, R, rb;
+  // keys_target: kLdsKeysTarget, or the (larger) value of a test that wants ranges to overfill and split
+  __device__ batch_part(const batch_view& bv, int b, int keys_target)
+  {
+    t0 = bv.target_seg[b];
+    nT = bv.target_seg[b + 1] - t0;
+    e0 = bv.edge_offsets[bv.sseg()[b]];
+    nE = bv.edge_offsets[bv.sseg()[b + 1]] - e0;
+    P  = nT + nE;
+    R  = min(max((P + keys_target - 1) / keys_target, 1), kLdsMaxRanges);
+    rb = (t0 + e0) / keys_target + b;
+  }
+};
+
+// Workgroup -> (batch, part).  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), and every kernel below
+// writes a batch's stretch of some array in scattered 4-byte pieces: all parts of one batch go to ONE XCD, next to each
+// other in dispatch order, so that the pieces meet in that XCD's L2 and leave it as whole lines (performance only — the
+// result does not depend on where a workgroup runs).  Grid = 8 * ceil(G / 8) * parts; returns false for the padding.
+__device__ __forceinline__ bool batch_of_block(int G, int parts, int& b, int& part)
+{
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  b    = (y / parts) * 8 + x;
+  part = y % parts;
+  return b < G;
+}
+inline int batch_grid(int G, int parts) { return 8 * ((G + 7) / 8) * parts; }
+
+// scratch behind the three kernels: counts[(rb + r) * kLdsChunks + c], then per range {first pair, pairs}
+struct bucket_scratch {
+  int keys_target;
+  int* counts;
+  int* range_start;
+  int* range_count;
+  void* ids;    // KeyT[capacity positions]
+  int* pos;     // int[capacity positions]
+};
+
+template <typename KeyT>
+__global__ void __launch_bounds__(kBucketThreads)
+bucket_count_kernel(const KeyT* __restrict__ targets, const KeyT* __restrict__ neighbors, batch_view bv, bucket_scratch sc)
+{
+  __shared__ int hist[kLdsMaxRanges];
+  int b, c;
+  if (!batch_of_block(bv.G, kLdsChunks, b, c)) return;
+  const batch_part bp(bv, b, sc.keys_target);
+  if (bp.nE <= 0) return;
+  for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) hist[r] = 0;
+  __syncthreads();
+  const int chunk = (bp.P + kLdsChunks - 1) / kLdsChunks;
+  const int end   = min(bp.P, (c + 1) * chunk);
+  for (int i = c * chunk + threadIdx.x; i < end; i += kBucketThreads) {
+    const KeyT id = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
+    atomicAdd(&hist[__umulhi(hash_id<KeyT>(id), (uint32_t)bp.R)], 1);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) sc.counts[(bp.rb + r) * kLdsChunks + c] = hist[r];
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(kBucketThreads)
+bucket_scatter_kernel(const KeyT* __restrict__ targets, dev_count T_, const KeyT* __restrict__ neighbors, batch_view bv,
+                      bucket_scratch sc)
+{
+  __shared__ int cursor[kLdsMaxRanges];   // first: pairs of the range over all chunks; then: where my next pair goes
+  __shared__ int before[kLdsMaxRanges];   // pairs of the range in the chunks before mine
+  int b, c;
+  if (!batch_of_block(bv.G, kLdsChunks, b, c)) return;
+  const batch_part bp(bv, b, sc.keys_target);
+  if (bp.nE <= 0) return;
+  const int T = T_.get();
+  for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) {
+    const int* row = sc.counts + (bp.rb + r) * kLdsChunks;
+    int tot = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < kLdsChunks; k++) {
+      const int v = row[k];
+      mine += k < c ? v : 0;
+      tot += v;
+    }
+    cursor[r] = tot;
+    before[r] = mine;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // the batch's pairs fill [t0 + e0, t0 + e0 + P) of the pair arrays, range after range
+    int at = bp.t0 + bp.e0;
+    for (int r = 0; r < bp.R; r++) {
+      const int tot = cursor[r];
+      if (c == 0) {
+        sc.range_start[bp.rb + r] = at;
+        sc.range_count[bp.rb + r] = tot;
+      }
+      cursor[r] = at + before[r];
+      at += tot;
+    }
+  }
+  __syncthreads();
+  KeyT* ids       = static_cast<KeyT*>(sc.ids);
+  const int chunk = (bp.P + kLdsChunks - 1) / kLdsChunks;
+  const int end   = min(bp.P, (c + 1) * chunk);
+  for (int i = c * chunk + threadIdx.x; i < end; i += kBucketThreads) {
+    const KeyT id = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
+    const int dst = atomicAdd(&cursor[__umulhi(hash_id<KeyT>(id), (uint32_t)bp.R)], 1);
+    ids[dst]      = id;
+    sc.pos[dst]   = i < bp.nT ? bp.t0 + i : T + bp.e0 + (i - bp.nT);
+  }
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(kLdsThreads)
+renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay, int wg_per_batch, bucket_scratch sc,
+                    int* __restrict__ slot_of, int* __restrict__ flag)
+{
+  __shared__ unsigned long long tbl[kLdsSlots];
+  __shared__ unsigned long long st_lo[kLdsStack], st_span[kLdsStack];
+  __shared__ int st_n, overfull;
+  const unsigned long long kEmpty = ~0ull;
+  const int T = T_.get(), E = E_.get();
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0) {
+    // the scan reads whole tiles: zero-fill the slack of the tile that holds the live end
+    const int end = min(E_.host, (E / kScanTile + 1) * kScanTile);
+    for (int e = E + tid; e < end; e += kLdsThreads) flag[e] = 0;
+  }
+  int b, j;
+  if (!batch_of_block(bv.G, wg_per_batch, b, j)) return;
+  const batch_part bp(bv, b, sc.keys_target);
+  if (bp.nE <= 0) return;   // no neighbour needs a first position
+  const KeyT* ids = static_cast<const KeyT*>(sc.ids);
+  const unsigned long long pos_mask = lay.pos_mask();
+  const volatile int* overfull_now  = &overfull;
+
+  for (int r = j; r < bp.R; r += wg_per_batch) {
+    const int first_pair = sc.range_start[bp.rb + r], n_pairs = sc.range_count[bp.rb + r];
+    if (n_pairs == 0) continue;
+    __syncthreads();   // the previous range's last look at the stack is over
+    if (tid == 0) {
+      // mulhi(h, R) == r  <=>  h in [ceil(r 2^32 / R), ceil((r + 1) 2^32 / R))
+      const unsigned long long lo = (((unsigned long long)r << 32) + bp.R - 1) / (unsigned)bp.R;
+      st_lo[0]   = lo;
+      st_span[0] = ((((unsigned long long)(r + 1) << 32) + bp.R - 1) / (unsigned)bp.R) - lo;
+      st_n       = 1;
+    }
+    __syncthreads();
+    while (true) {
+      const int n = st_n;
+      if (n == 0) break;
+      const unsigned long long lo = st_lo[n - 1], span = st_span[n - 1];
+      __syncthreads();   // everyone has read the top of the stack
+      {
+        uint4* t4 = reinterpret_cast<uint4*>(tbl);
+        const uint4 fill = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int i = tid; i < kLdsSlots / 2; i += kLdsThreads) t4[i] = fill;
+        if (tid == 0) {
+          st_n     = n - 1;
+          overfull = 0;
+        }
+      }
+      __syncthreads();
+      // ---- insert the pairs of the range (all of the bucket unless the range was split) -----------------------------
+      // kLdsUnroll pairs per thread are in flight before the first one is used: one load at a time leaves a
+      // 16-wave workgroup waiting on memory latency
+      for (int i0 = 0; i0 < n_pairs; i0 += kLdsThreads * kLdsUnroll) {
+        KeyT id_k[kLdsUnroll];
+        int pos_k[kLdsUnroll];
+#pragma unroll
+        for (int k = 0; k < kLdsUnroll; k++) {
+          const int i = min(i0 + k * kLdsThreads + tid, n_pairs - 1);
+          id_k[k]     = ids[first_pair + i];
+          pos_k[k]    = sc.pos[first_pair + i];
+        }
+#pragma unroll
+        for (int k = 0; k < kLdsUnroll; k++) {
+          const KeyT id    = id_k[k];
+          const uint32_t h = hash_id<KeyT>(id);
+          if (i0 + k * kLdsThreads + tid < n_pairs && (unsigned long long)h - lo < span && !*overfull_now) {
+            const unsigned long long word = ((unsigned long long)id << lay.pos_bits) | (unsigned long long)pos_k[k];
+            uint32_t s = __umulhi(h * 0x9E3779B1u, (uint32_t)kLdsSlots);
+            int probes = 0;
+            while (true) {
+              // one LDS round trip per probe: the compare-and-swap doubles as the read
+              const unsigned long long cur = atomicCAS(&tbl[s], kEmpty, word);
+              if (cur == kEmpty) break;
+              if ((cur >> lay.pos_bits) == (unsigned long long)id) {
+                if (word < cur) atomicMin(&tbl[s], word);
+                break;
+              }
+              s = s + 1 == (uint32_t)kLdsSlots ? 0u : s + 1;
+              if (++probes > kLdsProbeLimit) {   // never at the load a range is sized for: the table is (nearly) full
+                overfull = 1;
+                break;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (overfull) {
+        // split the range and redo both halves (a single hash value never holds a table full of distinct ids)
+        if (tid == 0) {
+          const unsigned long long half = span / 2;
+          const int m = st_n;
+          if (span < 2 || m + 2 > kLdsStack) __builtin_trap();
+          st_lo[m]       = lo + half;
+          st_span[m]     = span - half;
+          st_lo[m + 1]   = lo;
+          st_span[m + 1] = half;
+          st_n           = m + 2;
+        }
+        __syncthreads();
+        continue;
+      }
+      // ---- first position of every neighbour of the range --------------------------------------------------------
+      for (int i0 = 0; i0 < n_pairs; i0 += kLdsThreads * kLdsUnroll) {
+        KeyT id_k[kLdsUnroll];
+        int pos_k[kLdsUnroll];
+#pragma unroll
+        for (int k = 0; k < kLdsUnroll; k++) {
+          const int i = min(i0 + k * kLdsThreads + tid, n_pairs - 1);
+          id_k[k]     = ids[first_pair + i];
+          pos_k[k]    = sc.pos[first_pair + i];
+        }
+#pragma unroll
+        for (int k = 0; k < kLdsUnroll; k++) {
+          const KeyT id    = id_k[k];
+          const int p      = pos_k[k];
+          const uint32_t h = hash_id<KeyT>(id);
+          // (a target: nobody asks for its first position)
+          if (i0 + k * kLdsThreads + tid < n_pairs && p >= T && (unsigned long long)h - lo < span) {
+            uint32_t s = __umulhi(h * 0x9E3779B1u, (uint32_t)kLdsSlots);
+            unsigned long long cur = tbl[s];
+            while ((cur >> lay.pos_bits) != (unsigned long long)id) {
+              s   = s + 1 == (uint32_t)kLdsSlots ? 0u : s + 1;
+              cur = tbl[s];
+            }
+            const int first = (int)(cur & pos_mask);
+            slot_of[p]      = first;
+            flag[p - T]     = first == p ? 1 : 0;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// range records the three kernels address: every batch starts at floor(positions before it / kLdsKeysTarget) + b
+inline int64_t lds_range_records(int64_t capacity_positions, int G) { return capacity_positions / kLdsKeysTarget + 2 * (int64_t)G + 2; }
+// WGAMD_RENUMBER_KEYS_TARGET (tests): positions per hash range, >= kLdsKeysTarget; a value the table cannot hold makes
+// every range overfill and exercises the split path
+inline int lds_keys_target()
+{
+  static const int v = [] {
+    const char* e = getenv("WGAMD_RENUMBER_KEYS_TARGET");
+    const long t  = e ? atol(e) : 0;
+    return t > kLdsKeysTarget ? (int)std::min<long>(t, 1 << 30) : kLdsKeysTarget;
+  }();
+  return v;
+}
+inline bool lds_scratch_fits(int64_t capacity_positions, int G, int64_t slots, size_t id_bytes)
+{
+  // keys buffer: 8 B per slot holds ids + positions; positions buffer: 4 B per slot holds counts + the two range arrays
+  return (int64_t)(id_bytes + 4) * capacity_positions + 256 <= 8 * slots &&
+         lds_range_records(capacity_positions, G) * (kLdsChunks + 2) <= slots;
+}
+
+template <typename KeyT>
+void prepare_lds_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, packed_layout lay,
+                   void* keys, int* minpos, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
+{
+  if (E.host > 0) {
+    const int64_t cap = (int64_t)T.host + E.host;
+    const int64_t rec = lds_range_records(cap, bv.G);
+    bucket_scratch sc;
+    sc.keys_target = lds_keys_target();
+    sc.counts      = minpos;
+    sc.range_start = minpos + rec * kLdsChunks;
+    sc.range_count = sc.range_start + rec;
+    sc.ids         = keys;
+    sc.pos         = reinterpret_cast<int*>(static_cast<char*>(keys) + (((size_t)cap * sizeof(KeyT) + 255) / 256) * 256);
+    bucket_count_kernel<KeyT><<<batch_grid(bv.G, kLdsChunks), kBucketThreads, 0, stream>>>(targets, neighbors, bv, sc);
+    bucket_scatter_kernel<KeyT><<<batch_grid(bv.G, kLdsChunks), kBucketThreads, 0, stream>>>(targets, T, neighbors, bv, sc);
+    const int64_t per_batch = (cap + bv.G - 1) / bv.G;
+    const int wg_per_batch  = (int)std::max<int64_t>(1, std::min<int64_t>((per_batch + kLdsKeysTarget - 1) / kLdsKeysTarget, 32));
+    renumber_lds_kernel<KeyT><<<batch_grid(bv.G, wg_per_batch), kLdsThreads, 0, stream>>>(T, E, bv, lay, wg_per_batch, sc, slot_of, rank);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);
+}
+
 template <typename KeyT, typename TableKeyT>
 void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, TableKeyT* keys,
                int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
@@ -384,6 +717,18 @@ void append_unique_prepare_enqueue(const void* targets, dev_count T, const void*
 {
   const bool batched = bv.target_batch != nullptr;
   packed_layout lay{};
+  static const bool no_lds = getenv("WGAMD_RENUMBER_NO_LDS") != nullptr;
+  if (batched && !no_lds && bv.target_seg && bv.edge_offsets && bv.G > 1 &&
+      packed_layout_for((int64_t)T.host + E.host, 1, bv.id_bound, lay) &&
+      lds_scratch_fits((int64_t)T.host + E.host, bv.G, slots, ids64 ? 8 : 4)) {
+    if (ids64)
+      prepare_lds_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv, lay, keys,
+                             minpos, slot_of, rank, scan_tmp, stream);
+    else
+      prepare_lds_t<int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv, lay, keys,
+                             minpos, slot_of, rank, scan_tmp, stream);
+    return;
+  }
   if (batched && packed_layout_for((int64_t)T.host + E.host, bv.G, bv.id_bound, lay)) {
     if (ids64)
       prepare_packed_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv, keys,

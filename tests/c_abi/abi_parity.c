@@ -218,10 +218,46 @@ int main(void)
       for (int64_t j = 0; j < dim; j++) CHECK(init[r * dim + j] == (float)r - 0.5f * (float)hits[r]);
     CHECK(wholememory_embedding_gather_gradient_apply(emb, t_pidx, t_init, false, 0.5f, env, (int64_t)(intptr_t)stream) ==
           WHOLEMEMORY_INVALID_INPUT); /* rows != pairs */
-    wholememory_embedding_cache_policy_t pol = NULL;
-    CHECK(wholememory_create_embedding_cache_policy(&pol, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE,
-                                                    WHOLEMEMORY_AT_READONLY, 0.5f) == WHOLEMEMORY_NOT_SUPPORTED);
     WM(wholememory_embedding_writeback_cache(emb, 0));
+    /* READONLY cache in front of a second table (embedding.h:96-144): same rows through the cache, twice; the second
+     * pass is served from the cache lines.  Policy rules: ratio range, READWRITE refused (no host tier), no optimizer. */
+    wholememory_embedding_cache_policy_t pol = NULL, rw = NULL;
+    CHECK(wholememory_create_embedding_cache_policy(&pol, comm, WHOLEMEMORY_MT_CHUNKED, WHOLEMEMORY_ML_DEVICE,
+                                                    WHOLEMEMORY_AT_READONLY, 2.0f) == WHOLEMEMORY_INVALID_VALUE);
+    WM(wholememory_create_embedding_cache_policy(&pol, comm, WHOLEMEMORY_MT_CHUNKED, WHOLEMEMORY_ML_DEVICE,
+                                                 WHOLEMEMORY_AT_READONLY, 1.0f));
+    WM(wholememory_create_embedding_cache_policy(&rw, comm, WHOLEMEMORY_MT_CHUNKED, WHOLEMEMORY_ML_DEVICE,
+                                                 WHOLEMEMORY_AT_READWRITE, 0.5f));
+    wholememory_embedding_t cached = NULL;
+    CHECK(wholememory_create_embedding(&cached, &ed, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, rw, NULL, -1, 0) ==
+          WHOLEMEMORY_NOT_SUPPORTED);
+    WM(wholememory_create_embedding(&cached, &ed, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, pol, NULL, -1, 0));
+    CHECK(wholememory_embedding_set_optimizer(cached, opt) == WHOLEMEMORY_INVALID_INPUT);
+    for (int64_t r = 0; r < rows; r++)
+      for (int64_t j = 0; j < dim; j++) init[r * dim + j] = (float)(r * 16 + j);
+    HIP(hipMemcpy(d_init, init, sizeof(float) * rows * dim, hipMemcpyHostToDevice));
+    WM(wholememory_scatter(t_init, t_all, wholememory_embedding_get_embedding_tensor(cached), env, stream, -1));
+    float* through = (float*)malloc(sizeof(float) * rows * dim);
+    void* d_through = to_device(through, sizeof(float) * rows * dim);
+    wholememory_tensor_t t_through = wrap2d(d_through, rows, dim, dim, WHOLEMEMORY_DT_FLOAT);
+    int64_t hits_c = 0, looked = 0, lines = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      HIP(hipMemset(d_through, 0, sizeof(float) * rows * dim));
+      WM(wholememory_embedding_gather(cached, t_all, t_through, true, env, (int64_t)(intptr_t)stream));
+      HIP(hipStreamSynchronize(stream));
+      HIP(hipMemcpy(through, d_through, sizeof(float) * rows * dim, hipMemcpyDeviceToHost));
+      CHECK(memcmp(through, init, sizeof(float) * rows * dim) == 0);
+      WM(wgamd_embedding_cache_stats(cached, &hits_c, &looked, &lines));
+      CHECK(looked == rows * (pass + 1) && (pass == 0 ? hits_c == 0 : hits_c > rows / 2) && lines >= rows);
+    }
+    WM(wholememory_embedding_drop_all_cache(cached, 0));
+    WM(wgamd_embedding_cache_stats(cached, &hits_c, &looked, NULL));
+    CHECK(hits_c == 0 && looked == 0);
+    WM(wholememory_destroy_tensor(t_through));
+    WM(wholememory_destroy_embedding(cached));
+    WM(wholememory_destroy_embedding_cache_policy(pol));
+    WM(wholememory_destroy_embedding_cache_policy(rw));
+    printf("cached embedding: %lld rows through a READONLY cache, bit-exact, second pass from the cache lines\n", (long long)rows);
     wholememory_tensor_t tmp[] = {t_init, t_all, t_pidx, t_ones};
     for (size_t i = 0; i < 4; i++) WM(wholememory_destroy_tensor(tmp[i]));
     WM(wholememory_destroy_embedding(emb));

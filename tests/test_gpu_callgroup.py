@@ -112,3 +112,44 @@ def test_pyg_style_call_group_walk_vs_oracle(oracle_mod, hiplib, G, B, fanouts, 
         assert np.array_equal(g_row.cpu().numpy(), row) and np.array_equal(g_col.cpu().numpy(), colv)
         assert np.array_equal(g_edge.cpu().numpy(), edge)
         assert g_nn == nn and g_ne == ne
+
+
+_RENUMBER_WORKER = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/cugraph-gnn_amd"); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle
+from graphgen import powerlaw_csr
+from wholegraph_amd.fused import NoSyncWalk
+oracle.build()
+for dtype, G, B, fanouts in ((np.int32, 6, 256, [25, 10]), (np.int64, 3, 200, [15, 10, 5]), (np.int32, 9, 7, [5, 5])):
+    row_ptr, col = powerlaw_csr(30000, 18, seed=11, col_dtype=dtype, max_deg=3000)
+    rng = np.random.default_rng(G + B)
+    seeds = np.concatenate([rng.permutation(30000)[:B] for _ in range(G)]).astype(dtype)
+    rs = [[500 * k + b + 3 for b in range(G)] for k in range(len(fanouts))]
+    walk = NoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), B, fanouts, torch.from_numpy(seeds).dtype, G)
+    per_batch = walk.run(torch.from_numpy(seeds).cuda(), rs).finalize_batches()
+    for b in range(G):
+        want = oracle.multilayer_sample(row_ptr, col, seeds[b * B:(b + 1) * B], fanouts, [rs[k][b] for k in range(len(fanouts))])
+        for name, got_l, want_l in zip(("target_gids", "edge_indice", "csr_row_ptr", "csr_col_ind"), per_batch[b], want):
+            for lvl, (x, y) in enumerate(zip(got_l, want_l)):
+                assert np.array_equal(x.cpu().numpy(), y), (name, lvl, b, G, B)
+print("RENUMBER_OK")
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {"WGAMD_RENUMBER_KEYS_TARGET": "100000000"},   # one hash range per batch: it overfills the LDS table and must split
+    {"WGAMD_RENUMBER_KEYS_TARGET": "20000"},       # some ranges overfill, some do not
+    {"WGAMD_RENUMBER_NO_LDS": "1"},                # the device-wide packed table (what huge call groups fall back to)
+])
+def test_renumber_paths_agree_with_the_oracle(hiplib, env):
+    """The per-batch LDS renumbering splits a hash range whose keys do not fit its table; both that path and the
+    device-wide table must give the oracle's first-appearance order (the library reads the knobs once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _RENUMBER_WORKER, root], env=dict(os.environ, **env), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "RENUMBER_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
