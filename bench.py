@@ -92,7 +92,7 @@ class SagePipeline:
     block-diagonal concatenation.  Groups are software-pipelined: the walk of group g+1 is enqueued
     before the host reads the (tiny, pinned) size vector of group g, so the GPU queue never drains."""
 
-    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True):
+    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True, walk_priority=0):
         from wholegraph_amd import fused, nn
         self.nn = nn
         self.device = device
@@ -112,7 +112,9 @@ class SagePipeline:
         self.w_t = [torch.cat([c.lin_l.weight, c.lin_r.weight], dim=1).t().contiguous() for c in self.convs]
         self.bias = [c.lin_l.bias for c in self.convs]
         self.fused_relu = hasattr(torch, "_addmm_activation")
-        self.walk_stream = torch.cuda.Stream(device=device) if overlap_walk else None
+        # the walk's kernels are short and feed the NEXT group: on a high-priority stream they take the wave slots that free
+        # up between the long streaming kernels of the forward pass instead of queueing behind them
+        self.walk_stream = torch.cuda.Stream(device=device, priority=walk_priority) if overlap_walk else None
         self.host_wait_s = 0.0
         self.distributed = self.feat.is_distributed
         path = self.feat.fetch_path() if hasattr(self.feat, "fetch_path") else "all-to-all"
@@ -329,6 +331,7 @@ def main():
     ap.add_argument("--force-partitioned", action="store_true",
                     help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
     ap.add_argument("--no-overlap", action="store_true", help="run the walk on the main stream (no second HIP stream)")
+    ap.add_argument("--walk-priority", type=int, default=0, help="HIP stream priority of the walk stream (-1 = high)")
     ap.add_argument("--layer-kernel", choices=["auto", "fused", "split"], default="auto",
                     help="auto/fused: every SAGE layer whose shape allows it runs as ONE kernel (neighbour rows -> LDS "
                          "operand tile -> MFMA); split: aggregation kernel + library GEMM per layer.  The other one is "
@@ -521,7 +524,7 @@ def main():
                 continue
         else:
             feat = make_table(placement)
-        pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap)
+        pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
         # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
         # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
         fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])
@@ -544,7 +547,7 @@ def main():
             variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
         if col64 is not None and placement == placements[0]:
             # the same pipeline with int64 ids (csr_col, seeds, node lists): the cugraph_pyg convention
-            pipe64 = SagePipeline(row_ptr, col64, feat, device, G, overlap_walk=not args.no_overlap)
+            pipe64 = SagePipeline(row_ptr, col64, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
             b32 = batches
             batches = b32.to(torch.int64)
             vs, ve = measure(pipe64, head_mode)

@@ -30,6 +30,9 @@ __device__ __forceinline__ int64_t src_row<void>(const void*, int c)
   return (int64_t)c;
 }
 
+// neighbour rows a lane group has in flight before it adds them up: a row is one 16-B load per lane and ~2 us away
+constexpr int kSpmmRowsInFlight = 8;
+
 // VEC = 4 (float4 path: F % 4 == 0, 16 B aligned rows) or 1.
 template <int VEC, typename IdT>
 __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ row_ptr,
@@ -79,11 +82,11 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
         int my_c = (c0 + sub < deg) ? col[s + c0 + sub] : 0;
         int64_t my_src = (c0 + sub < deg) ? src_row<IdT>(src_ids, my_c) : 0;
         const int chunk = min(lanes, maxdeg - c0);
-        for (int j0 = 0; j0 < chunk; j0 += 4) {
-          float vals[4][VEC];
-          bool ok[4];
+        for (int j0 = 0; j0 < chunk; j0 += kSpmmRowsInFlight) {
+          float vals[kSpmmRowsInFlight][VEC];
+          bool ok[kSpmmRowsInFlight];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < kSpmmRowsInFlight; k++) {
             // broadcast neighbour (j0+k) of my group's row
             int src_lane  = gbase | ((j0 + k) & (lanes - 1));
             int lo        = __shfl((int)(my_src & 0xffffffff), src_lane, 64);
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
             }
           }
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < kSpmmRowsInFlight; k++) {
             if (ok[k]) {
 #pragma unroll
               for (int v = 0; v < VEC; v++) acc[v] += vals[k][v];

@@ -377,6 +377,7 @@ constexpr int kLdsMaxRanges  = 2048;      // per batch; beyond, ranges simply st
 constexpr int kLdsStack      = 40;        // pending hash ranges of one workgroup (a split pushes two, pops one)
 constexpr int kLdsChunks     = 16;        // blocks per batch in the two bucketing kernels
 constexpr int kBucketThreads = 256;
+constexpr int kBucketUnroll  = 4;         // ids in flight per thread of the two bucketing kernels
 constexpr int kLdsUnroll     = 6;         // pairs in flight per thread of the table kernel
 
 __device__ __forceinline__ uint32_t hash_id32(uint32_t h)   // murmur3 finaliser
@@ -447,9 +448,16 @@ bucket_count_kernel(const KeyT* __restrict__ targets, const KeyT* __restrict__ n
   __syncthreads();
   const int chunk = (bp.P + kLdsChunks - 1) / kLdsChunks;
   const int end   = min(bp.P, (c + 1) * chunk);
-  for (int i = c * chunk + threadIdx.x; i < end; i += kBucketThreads) {
-    const KeyT id = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
-    atomicAdd(&hist[__umulhi(hash_id<KeyT>(id), (uint32_t)bp.R)], 1);
+  for (int i0 = c * chunk + threadIdx.x; i0 < end; i0 += kBucketThreads * kBucketUnroll) {
+    KeyT id[kBucketUnroll];   // all loads of the trip are in flight before the first histogram update
+#pragma unroll
+    for (int k = 0; k < kBucketUnroll; k++) {
+      const int i = min(i0 + k * kBucketThreads, end - 1);
+      id[k]       = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
+    }
+#pragma unroll
+    for (int k = 0; k < kBucketUnroll; k++)
+      if (i0 + k * kBucketThreads < end) atomicAdd(&hist[__umulhi(hash_id<KeyT>(id[k]), (uint32_t)bp.R)], 1);
   }
   __syncthreads();
   for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) sc.counts[(bp.rb + r) * kLdsChunks + c] = hist[r];
@@ -497,11 +505,22 @@ bucket_scatter_kernel(const KeyT* __restrict__ targets, dev_count T_, const KeyT
   KeyT* ids       = static_cast<KeyT*>(sc.ids);
   const int chunk = (bp.P + kLdsChunks - 1) / kLdsChunks;
   const int end   = min(bp.P, (c + 1) * chunk);
-  for (int i = c * chunk + threadIdx.x; i < end; i += kBucketThreads) {
-    const KeyT id = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
-    const int dst = atomicAdd(&cursor[__umulhi(hash_id<KeyT>(id), (uint32_t)bp.R)], 1);
-    ids[dst]      = id;
-    sc.pos[dst]   = i < bp.nT ? bp.t0 + i : T + bp.e0 + (i - bp.nT);
+  for (int i0 = c * chunk + threadIdx.x; i0 < end; i0 += kBucketThreads * kBucketUnroll) {
+    KeyT id[kBucketUnroll];
+#pragma unroll
+    for (int k = 0; k < kBucketUnroll; k++) {
+      const int i = min(i0 + k * kBucketThreads, end - 1);
+      id[k]       = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
+    }
+#pragma unroll
+    for (int k = 0; k < kBucketUnroll; k++) {
+      const int i = i0 + k * kBucketThreads;
+      if (i < end) {
+        const int dst = atomicAdd(&cursor[__umulhi(hash_id<KeyT>(id[k]), (uint32_t)bp.R)], 1);
+        ids[dst]      = id[k];
+        sc.pos[dst]   = i < bp.nT ? bp.t0 + i : T + bp.e0 + (i - bp.nT);
+      }
+    }
   }
 }
 
@@ -643,6 +662,84 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
   }
 }
 
+// Emit for call groups, one block per (batch, chunk): everything that depends on the batch only (its row shift, where
+// its new vertices start, its local-id origin) is read once per block instead of chased through four dependent loads per
+// edge, and the one random read left (the rank of the first occurrence) stays inside the batch's stretch of `rank`,
+// which the XCD-affine block mapping keeps in one L2.  Same outputs as renumber_emit_kernel.
+constexpr int kEmitChunks = 16;
+constexpr int kEmitUnroll = 4;
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256)
+renumber_emit_batched_kernel(const KeyT* __restrict__ targets, const KeyT* __restrict__ neighbors,
+                             const int* __restrict__ slot_of, const int* __restrict__ rank, dev_count T_, dev_count E_,
+                             batch_view bv, KeyT* __restrict__ unique_out, int* __restrict__ map_out,
+                             int* __restrict__ counts_out)
+{
+  const int T = T_.get(), E = E_.get();
+  const int U = rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
+  if (gtid == 0 && counts_out) {
+    counts_out[0] = E;
+    counts_out[1] = T + U;
+  }
+  if (bv.unique_seg && gtid <= bv.G) {
+    const int new_before = rank[bv.edge_offsets[bv.sseg()[gtid]]];   // new vertices of batches < gtid
+    bv.unique_seg[gtid] = bv.target_seg[gtid] + new_before;
+    if (bv.frontier_seg_out) bv.frontier_seg_out[gtid] = new_before;
+    if (bv.frontier_local0_out && gtid < bv.G) bv.frontier_local0_out[gtid] = bv.target_seg[gtid + 1] - bv.target_seg[gtid];
+  }
+  // no-sync walk: the capacity slack of `unique` is padded with -1 (a capacity-sized feature gather skips those rows)
+  if (counts_out)
+    for (int p = T + U + gtid; p < T_.host + E_.host; p += gsize) unique_out[p] = (KeyT)-1;
+
+  int b, c;
+  if (!batch_of_block(bv.G, kEmitChunks, b, c)) return;
+  const int t0 = bv.target_seg[b], nT = bv.target_seg[b + 1] - t0;
+  const int s0 = bv.sseg()[b];
+  const int e0 = bv.edge_offsets[s0], nE = bv.edge_offsets[bv.sseg()[b + 1]] - e0;
+  const int shift    = rank[e0];          // rows contributed by the new vertices of earlier batches
+  const int tail_row = t0 + nT;           // first row after my batch's targets (before the shift... see below)
+  const int local0   = bv.sample_local0 ? bv.sample_local0[b] : 0;
+  {
+    const int chunk = (nT + kEmitChunks - 1) / kEmitChunks;
+    const int end   = min(nT, (c + 1) * chunk);
+    for (int i = c * chunk + threadIdx.x; i < end; i += blockDim.x) {
+      unique_out[t0 + i + shift] = targets[t0 + i];
+      if (bv.unique_batch) bv.unique_batch[t0 + i + shift] = b;
+    }
+  }
+  const int chunk = (nE + kEmitChunks - 1) / kEmitChunks;
+  const int end   = min(nE, (c + 1) * chunk);
+  for (int i0 = c * chunk + threadIdx.x; i0 < end; i0 += 256 * kEmitUnroll) {
+    // two dependent reads per edge (first position, then its rank): kEmitUnroll edges per thread keep both in flight
+    int first[kEmitUnroll], row[kEmitUnroll];
+#pragma unroll
+    for (int k = 0; k < kEmitUnroll; k++) first[k] = slot_of[T + e0 + min(i0 + k * 256, end - 1)];
+#pragma unroll
+    for (int k = 0; k < kEmitUnroll; k++) row[k] = first[k] < T ? first[k] + shift : tail_row + rank[first[k] - T];
+#pragma unroll
+    for (int k = 0; k < kEmitUnroll; k++) {
+      const int i = i0 + k * 256;
+      if (i >= end) break;
+      const int e = e0 + i;
+      if (first[k] == T + e) {
+        const KeyT id      = neighbors[e];
+        unique_out[row[k]] = id;
+        if (bv.unique_batch) bv.unique_batch[row[k]] = b;
+        if (bv.frontier_out) {  // next frontier, ordered by (batch, first appearance) == by rank
+          const int r = row[k] - tail_row;
+          static_cast<KeyT*>(bv.frontier_out)[r] = id;
+          bv.frontier_batch_out[r]               = b;
+        }
+      }
+      if (map_out) map_out[e] = row[k];
+      if (bv.neighbor_local_out) bv.neighbor_local_out[e] = row[k] - (t0 + shift);
+      if (bv.center_local_out) bv.center_local_out[e] = bv.edge_row[e] - s0 + local0;
+    }
+  }
+}
+
 // range records the three kernels address: every batch starts at floor(positions before it / kLdsKeysTarget) + b
 inline int64_t lds_range_records(int64_t capacity_positions, int G) { return capacity_positions / kLdsKeysTarget + 2 * (int64_t)G + 2; }
 // WGAMD_RENUMBER_KEYS_TARGET (tests): positions per hash range, >= kLdsKeysTarget; a value the table cannot hold makes
@@ -755,6 +852,19 @@ void append_unique_emit_enqueue(const void* targets, dev_count T, const void* ne
 {
   const int P    = T.host + E.host;
   const int grid = ceil_div(P > bv.G + 1 ? P : bv.G + 1, 256);  // thread 0 publishes the counts, threads <= G the segments
+  if (bv.target_batch != nullptr && bv.target_seg && bv.edge_offsets && bv.G > 1) {
+    const int bgrid = std::max(batch_grid(bv.G, kEmitChunks), ceil_div(bv.G + 1, 256));
+    if (ids64)
+      renumber_emit_batched_kernel<int64_t><<<bgrid, 256, 0, stream>>>(static_cast<const int64_t*>(targets),
+                                                                      static_cast<const int64_t*>(neighbors), slot_of, rank, T, E,
+                                                                      bv, static_cast<int64_t*>(unique_out), map_out, counts_out);
+    else
+      renumber_emit_batched_kernel<int32_t><<<bgrid, 256, 0, stream>>>(static_cast<const int32_t*>(targets),
+                                                                      static_cast<const int32_t*>(neighbors), slot_of, rank, T, E,
+                                                                      bv, static_cast<int32_t*>(unique_out), map_out, counts_out);
+    WG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (ids64)
     renumber_emit_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(targets),
                                                            static_cast<const int64_t*>(neighbors), minpos, slot_of, rank,
