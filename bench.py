@@ -116,6 +116,7 @@ class SagePipeline:
         # up between the long streaming kernels of the forward pass instead of queueing behind them
         self.walk_stream = torch.cuda.Stream(device=device, priority=walk_priority) if overlap_walk else None
         self.host_wait_s = 0.0
+        self.rs_base = None
         self.distributed = self.feat.is_distributed
         path = self.feat.fetch_path() if hasattr(self.feat, "fetch_path") else "all-to-all"
         self.fetch_tag = "peer-mapped" if "peer-mapped" in path else "all-to-all"
@@ -143,9 +144,10 @@ class SagePipeline:
     def sample(self, seeds, group_id):
         """Enqueue the walk of one call group + the async D2H of its sizes."""
         hops = len(FANOUT)
-        rs = (torch.arange(self.G, device=self.device, dtype=torch.int64).view(1, -1) * hops
-              + torch.arange(hops, device=self.device, dtype=torch.int64).view(-1, 1)
-              + 62 + group_id * self.G * hops)          # seed of (hop k, batch b) = 62 + hops*global_batch + k
+        if self.rs_base is None:    # seed of (hop k, batch b) = 62 + hops*global_batch + k
+            self.rs_base = (torch.arange(self.G, device=self.device, dtype=torch.int64).view(1, -1) * hops
+                            + torch.arange(hops, device=self.device, dtype=torch.int64).view(-1, 1) + 62)
+        rs = self.rs_base + group_id * self.G * hops    # one launch per call group
         if self.walk_stream is None:
             res = self.walk.run(seeds, rs)
             sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
@@ -222,7 +224,7 @@ class SagePipeline:
                 rows = res.target_rows_in_unique(k, n_dst)   # "x[:num_dst]" of the block-diagonal layout
             else:
                 n_dst = t0   # the seeds = the first BATCH rows of every batch's hop-0 unique list
-                rows = (res.unique_seg[0][:-1].long().view(-1, 1) + torch.arange(BATCH, device=self.device)).view(-1)
+                rows = res.target_rows_in_unique(0, n_dst)
             ptr, nbr = res.offsets[k][:n_dst + 1], res.neighbor_row[k][:n_edges[k]]
             if fused_layer and nn.sage_layer_fused_preferred(self.dims[j], self.dims[j + 1]):
                 fetch = j == 0 and fused_fetch

@@ -31,7 +31,7 @@ __device__ __forceinline__ int64_t src_row<void>(const void*, int c)
 }
 
 // neighbour rows a lane group has in flight before it adds them up: a row is one 16-B load per lane and ~2 us away
-constexpr int kSpmmRowsInFlight = 8;
+constexpr int kSpmmRowsInFlight = 4;   // 8 costs the F = 100 launch 6 % (registers), and buys the F = 256 one nothing
 
 // VEC = 4 (float4 path: F % 4 == 0, 16 B aligned rows) or 1.
 template <int VEC, typename IdT>

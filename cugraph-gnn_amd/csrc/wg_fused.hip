@@ -132,6 +132,16 @@ void run_hop(hop_args a)
                              a.counts_dev, st);
 }
 
+__global__ void __launch_bounds__(256)
+target_rows_kernel(const int* __restrict__ unique_seg, const int* __restrict__ target_seg, const int* __restrict__ target_batch,
+                   int n, int64_t* __restrict__ rows)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = target_batch[i];
+  rows[i]     = (int64_t)i + unique_seg[b] - target_seg[b];
+}
+
 }  // namespace
 }  // namespace wgamd
 
@@ -199,6 +209,20 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(
     a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
     a.workspace_bytes = workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
     run_hop(a);
+  });
+}
+
+wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, const int* target_seg, const int* target_batch,
+                                                      int64_t n_targets, int64_t* rows, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_call_group_target_rows", [&] {
+    WG_REQUIRE_INPUT(n_targets >= 0 && n_targets < ((int64_t)1 << 31), "bad target count");
+    if (n_targets == 0) return;
+    WG_REQUIRE_INPUT(unique_seg && target_seg && target_batch && rows, "null pointer");
+    target_rows_kernel<<<ceil_div(n_targets, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(unique_seg, target_seg, target_batch,
+                                                                                              (int)n_targets, rows);
+    WG_HIP_CHECK(hipGetLastError());
   });
 }
 

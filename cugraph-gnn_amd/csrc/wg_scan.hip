@@ -13,6 +13,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kItems   = 8;
 constexpr int kTile    = kThreads * kItems;  // 2048 ints = 8 KiB per workgroup
+constexpr int kScanGrid = 2048;              // workgroups of the two tile kernels (8 per CU), striding over the tiles
 static_assert(kTile == kScanTile, "wg_common.hpp publishes the tile size to the kernels that zero-fill scan inputs");
 
 __device__ __forceinline__ int wave_inclusive_scan(int v)
@@ -87,32 +88,36 @@ __device__ __forceinline__ bool tile_is_live(dev_count live, unsigned tile)
   return live.dev == nullptr || (int64_t)tile * kTile <= (int64_t)live.get();
 }
 
-__global__ void __launch_bounds__(kThreads) scan_tile_sums_kernel(const int* in, int64_t n, int* sums, dev_count live)
+// Both tile kernels run a bounded grid that strides over the tiles: a capacity-sized scan has thousands of tiles of which a
+// third hold live elements, and a workgroup per tile means thousands of dispatches that each wait for a wave slot when
+// another stream keeps the chip full.
+__global__ void __launch_bounds__(kThreads) scan_tile_sums_kernel(const int* in, int64_t n, int* sums, int64_t m, dev_count live)
 {
-  if (!tile_is_live(live, blockIdx.x)) {
-    if (threadIdx.x == 0) sums[blockIdx.x] = 0;
-    return;
-  }
-  int x[kItems];
-  load_tile(in, (int64_t)blockIdx.x * kTile, n, x);
-  int s = 0;
+  for (int64_t tile = blockIdx.x; tile < m; tile += gridDim.x) {
+    if (!tile_is_live(live, (unsigned)tile)) break;   // dead tiles are never read (scan_sums stops at the live count)
+    int x[kItems];
+    load_tile(in, tile * kTile, n, x);
+    int s = 0;
 #pragma unroll
-  for (int k = 0; k < kItems; k++) s += x[k];
-  int total;
-  (void)block_exclusive_scan(s, &total);
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+    for (int k = 0; k < kItems; k++) s += x[k];
+    int total;
+    (void)block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) sums[tile] = total;
+  }
 }
 
-// exclusive scan of sums[0..m) in place, sums[m] = grand total
-__global__ void __launch_bounds__(kThreads) scan_sums_kernel(int* sums, int64_t m)
+// exclusive scan of sums[0..m) in place, sums[m] = grand total.  With a live count only the tiles that hold live elements
+// are scanned (the others are never read again: their tiles skip the final pass), the total still lands at sums[m].
+__global__ void __launch_bounds__(kThreads) scan_sums_kernel(int* sums, int64_t m, dev_count live)
 {
   int carry = 0;
-  for (int64_t base = 0; base < m; base += kThreads) {
+  const int64_t m_live = live.dev == nullptr ? m : min(m, (int64_t)live.get() / kTile + 1);
+  for (int64_t base = 0; base < m_live; base += kThreads) {
     int64_t i = base + threadIdx.x;
-    int v     = i < m ? sums[i] : 0;
+    int v     = i < m_live ? sums[i] : 0;
     int total;
     int ex = block_exclusive_scan(v, &total);
-    if (i < m) sums[i] = carry + ex;
+    if (i < m_live) sums[i] = carry + ex;
     carry += total;
   }
   if (threadIdx.x == 0) sums[m] = carry;
@@ -122,20 +127,22 @@ __global__ void __launch_bounds__(kThreads)
 scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int64_t m, dev_count live)
 {
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[m];
-  if (!tile_is_live(live, blockIdx.x)) return;
-  int x[kItems];
-  int64_t base = (int64_t)blockIdx.x * kTile;
-  load_tile(in, base, n, x);
-  int s = 0;
+  for (int64_t tile = blockIdx.x; tile < m; tile += gridDim.x) {
+    if (!tile_is_live(live, (unsigned)tile)) break;
+    int x[kItems];
+    const int64_t base = tile * kTile;
+    load_tile(in, base, n, x);
+    int s = 0;
 #pragma unroll
-  for (int k = 0; k < kItems; k++) s += x[k];
-  int total;
-  int run   = block_exclusive_scan(s, &total) + sums[blockIdx.x];
-  int64_t p = base + (int64_t)threadIdx.x * kItems;
+    for (int k = 0; k < kItems; k++) s += x[k];
+    int total;
+    int run   = block_exclusive_scan(s, &total) + sums[tile];
+    int64_t p = base + (int64_t)threadIdx.x * kItems;
 #pragma unroll
-  for (int k = 0; k < kItems; k++) {
-    if (p + k < n) out[p + k] = run;
-    run += x[k];
+    for (int k = 0; k < kItems; k++) {
+      if (p + k < n) out[p + k] = run;
+      run += x[k];
+    }
   }
 }
 
@@ -150,11 +157,12 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
     scan_single_kernel<<<1, kThreads, 0, stream>>>(in, out, n);
   } else {
     int64_t m = (n + kTile - 1) / kTile;
-    scan_tile_sums_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, n, tmp, live);
-    scan_sums_kernel<<<1, kThreads, 0, stream>>>(tmp, m);
+    const unsigned grid = (unsigned)std::min<int64_t>(m, kScanGrid);
+    scan_tile_sums_kernel<<<grid, kThreads, 0, stream>>>(in, n, tmp, m, live);
+    scan_sums_kernel<<<1, kThreads, 0, stream>>>(tmp, m, live);
     // in-place is safe: every tile reads its inputs into registers before writing them back,
     // and out[n] is written from tmp, not from `in`.
-    scan_tile_final_kernel<<<(unsigned)m, kThreads, 0, stream>>>(in, out, n, tmp, m, live);
+    scan_tile_final_kernel<<<grid, kThreads, 0, stream>>>(in, out, n, tmp, m, live);
   }
   WG_HIP_CHECK(hipGetLastError());
 }

@@ -224,6 +224,7 @@ SYMBOLS = {
                                         c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "wgamd_sample_hop_pyg_nosync": (c_int, [c_void_p, c_void_p]),
+    "wgamd_call_group_target_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "wgamd_sample_hop_batched_nosync": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                                 c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

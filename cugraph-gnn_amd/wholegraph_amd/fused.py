@@ -53,8 +53,11 @@ class WalkResult:
         """Row (in ``unique[k]``) of every hop-k target: target i of batch b sits at
         ``i + (unique_seg[k][b] - target_seg[k][b])`` — the ``x[:num_dst]`` slice of the single-batch
         layout becomes this index list in the block-diagonal one."""
-        shift = (self.unique_seg[k][:-1] - self.target_seg[k][:-1]).long()
-        return torch.arange(n_targets, device=shift.device) + shift[self.target_batch[k][:n_targets].long()]
+        rows = torch.empty((n_targets,), dtype=torch.int64, device=self.unique_seg[k].device)
+        L.check(L.lib().wgamd_call_group_target_rows(self.unique_seg[k].data_ptr(), self.target_seg[k].data_ptr(),
+                                                     self.target_batch[k].data_ptr(), int(n_targets), rows.data_ptr(),
+                                                     get_stream()), "wgamd_call_group_target_rows")
+        return rows
 
     def finalize_batches(self):
         """One round of small D2H copies, then per mini-batch the reference tuple

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; c
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_$TAG -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
 cp /tmp/pt_$TAG/${TAG}_kernel_stats.csv $OUT/
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex "row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|table_insert" --output-format csv -d /tmp/pc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex "row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|table_insert|renumber_lds|bucket_scatter|renumber_emit" --output-format csv -d /tmp/pc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_$C.log 2>&1
   cp /tmp/pc_${TAG}_$C/*counter_collection.csv $OUT/
 done
 # MFMA utilisation of the dense tail (hipBLASLt fp32 GEMMs): busy cycles of the matrix pipe vs GPU-active cycles

@@ -307,6 +307,12 @@ typedef struct wgamd_pyg_hop_t {
 
 wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, void* stream);
 
+/* Rows of the hop's targets inside its block-diagonal `unique` list — the "x[:num_dst]" of a single mini-batch becomes
+ * an index list for a call group:  rows[i] = i + unique_seg[b] - target_seg[b],  b = target_batch[i],  for i < n_targets.
+ * One launch (the SAGEConv root term and the next layer's row list read it); everything is device memory. */
+wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, const int* target_seg, const int* target_batch,
+                                                      int64_t n_targets, int64_t* rows, void* stream);
+
 /* Backward of wgamd_gat_csr_f32 (csrc/wg_gat_bwd.hip): given grad_out [n_rows, H*C] and the forward's alpha [E, H], writes
  * grad_x [n_src, H*C], grad_a_src [n_src, H], grad_a_dst [n_rows, H]; de [E, H] is scratch.  Needs the hop CSR transposed:
  * row_ptr_t [n_src+1], edge_perm [E] (edge ids sorted by source, stable), edge_dst [E] (destination row of every edge).
