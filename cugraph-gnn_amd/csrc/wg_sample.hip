@@ -131,11 +131,19 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
   if (cls >= 0) lists[kWeightedListHead + (int64_t)cls * list_cap + blk_base[cls] + my_rank] = i;
 }
 
+// `col` may be NULL: the CSR columns live on other GPUs, the kernel then only produces the picked CSR positions
+// (edge_gid) and the caller fetches the columns afterwards (the distributed-CSR path of the ABI op)
+template <typename ColT>
+__device__ __forceinline__ ColT col_at(const ColT* __restrict__ col, int64_t at)
+{
+  return col ? col[at] : (ColT)0;
+}
+
 template <typename ColT>
 __device__ __forceinline__ void emit(ColT* dst, int* src_lid, int64_t* edge_gid, int64_t out, ColT v,
                                      int seed_index, int64_t gid)
 {
-  dst[out] = v;
+  if (dst) dst[out] = v;
   if (src_lid) src_lid[out] = seed_index;
   if (edge_gid) edge_gid[out] = gid;
 }
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   const bool pick = N > M;  // uniform inside a half
   // Is any half of this wave sampling?  (wave-uniform branch around the resolve loop)
   if (__ballot(pick) == 0ull) {
-    if (hl < N) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + hl], i, start + hl);
+    if (hl < N) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col_at<ColT>(col, start + hl), i, start + hl);
     return;
   }
   int r = 0;
@@ -217,9 +225,9 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   const int vp1 = __shfl(val, hb | (p1 & (LANES - 1)), 64);
   const int a   = p1 >= 0 ? vp1 : r;
   if (pick) {
-    if (hl < M) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + a], i, start + a);
+    if (hl < M) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col_at<ColT>(col, start + a), i, start + a);
   } else if (hl < N) {
-    emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col[start + hl], i, start + hl);
+    emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col_at<ColT>(col, start + hl), i, start + hl);
   }
 }
 
@@ -263,7 +271,7 @@ __global__ void __launch_bounds__(256) sample_uniform_block_kernel(const int64_t
   const int base = offsets[i];
   if (N <= M) {
     for (int j = threadIdx.x; j < N; j += blockDim.x)
-      emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + j, col[start + j], i, start + j);
+      emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + j, col_at<ColT>(col, start + j), i, start + j);
     return;
   }
   for (int h = threadIdx.x; h < kHashSlots; h += blockDim.x) hkeys[h] = -1;
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(256) sample_uniform_block_kernel(const int64_t
   }
   __syncthreads();
   for (int t = threadIdx.x; t < M; t += blockDim.x)
-    emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + t, col[start + a[t]], i, start + a[t]);
+    emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + t, col_at<ColT>(col, start + a[t]), i, start + a[t]);
 }
 
 // ---- M > 1024: reservoir, slot s keeps max{idx : draw % (idx+1) == s} ----------------------
@@ -318,7 +326,7 @@ __global__ void __launch_bounds__(64) sample_uniform_reservoir_kernel(const int6
   const int64_t base = offsets[i];
   if (N <= M) {
     for (int j = threadIdx.x; j < N; j += blockDim.x)
-      emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
+      emit<ColT>(dst, src_lid, edge_gid, base + j, col_at<ColT>(col, start + j), i, start + j);
     return;
   }
   for (int s = threadIdx.x; s < M; s += blockDim.x) dst[base + s] = (ColT)s;
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(64) sample_uniform_reservoir_kernel(const int6
   for (int s = threadIdx.x; s < M; s += blockDim.x) {
     // device-scope load: the slot was updated by L2 atomics, never trust this CU's L1 copy
     int sel = (int)__hip_atomic_load(dst + base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    emit<ColT>(dst, src_lid, edge_gid, base + s, col[start + sel], i, start + sel);
+    emit<ColT>(dst, src_lid, edge_gid, base + s, col_at<ColT>(col, start + sel), i, start + sel);
   }
 }
 
@@ -437,7 +445,7 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   const int64_t base = offsets[i];
   if (M <= 0 || N <= M) {
     for (int j = threadIdx.x; j < N; j += T)
-      emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
+      emit<ColT>(dst, src_lid, edge_gid, base + j, col_at<ColT>(col, start + j), i, start + j);
     continue;
   }
   const bool in_lds = N <= kLdsKeys;
@@ -554,7 +562,7 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
       if (w < wave) before += wave_cnt[0][w];
       total += wave_cnt[0][w];
     }
-    if (take) emit<ColT>(dst, src_lid, edge_gid, base + before, col[start + id], i, start + id);
+    if (take) emit<ColT>(dst, src_lid, edge_gid, base + before, col_at<ColT>(col, start + id), i, start + id);
     out_run += total;
     tie_run += eq_total;
     __syncthreads();
@@ -619,7 +627,7 @@ __global__ void __launch_bounds__(256) sample_weighted_group_kernel(const int64_
   const uint64_t meq   = __ballot(eq) & gm;
   const bool take      = active && hl < N && (k > prefix || (eq && __popcll(meq & below) < need));
   const uint64_t mt    = __ballot(take) & gm;
-  if (take) emit<ColT>(dst, src_lid, edge_gid, base + __popcll(mt & below), col[start + hl], i, start + hl);
+  if (take) emit<ColT>(dst, src_lid, edge_gid, base + __popcll(mt & below), col_at<ColT>(col, start + hl), i, start + hl);
 }
 
 // One WAVE per row for rows of up to 64*KMAX candidates (size classes 3 .. 6 of the count kernel's lists: KMAX = 2, 4, 8,
@@ -720,7 +728,7 @@ __global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t
     const uint64_t meq = __ballot(eq);
     const bool take    = (k[s] != 0u && kd > prefix) || (eq && tie_run + __popcll(meq & below) < need);
     const uint64_t mt  = __ballot(take);
-    if (take) emit<ColT>(dst, src_lid, edge_gid, base + out_run + __popcll(mt & below), col[start + id], i, start + id);
+    if (take) emit<ColT>(dst, src_lid, edge_gid, base + out_run + __popcll(mt & below), col_at<ColT>(col, start + id), i, start + id);
     out_run += __popcll(mt);
     tie_run += __popcll(meq);
     __builtin_amdgcn_sched_barrier(0);   // (16 unrolled slots x three 64-bit output addresses hoisted together: 238 VGPRs)
@@ -742,7 +750,7 @@ __global__ void __launch_bounds__(256) copy_short_rows_kernel(const int64_t* __r
   const int N         = (int)(row_ptr[nid + 1] - start);
   if (N <= 0 || N > M) return;
   const int64_t base = offsets[i];
-  for (int j = hl; j < N; j += 16) emit<ColT>(dst, src_lid, edge_gid, base + j, col[start + j], i, start + j);
+  for (int j = hl; j < N; j += 16) emit<ColT>(dst, src_lid, edge_gid, base + j, col_at<ColT>(col, start + j), i, start + j);
 }
 
 template <typename SeedT, typename ColT>
@@ -831,8 +839,9 @@ void validate(const sample_args& a, bool weighted)
   WG_REQUIRE_INPUT(a.dst_ctx != nullptr, "output_dest_memory_context must not be NULL");
   auto rd = a.row_ptr->desc, cd = a.col->desc, sd = a.seeds->desc, od = a.out_offsets->desc;
   WG_REQUIRE_INPUT(rd.dim == 1 && cd.dim == 1 && sd.dim == 1 && od.dim == 1, "all tensors must be 1-D");
-  WG_REQUIRE_INPUT(!a.row_ptr->handle && !a.col->handle,
-                   "CSR tensors must wrap device pointers (the CSR is replicated per GPU; DESIGN.md §multi-GPU)");
+  WG_REQUIRE_INPUT(!weighted || (!a.row_ptr->handle && !a.col->handle),
+                   "weighted sampling needs CSR tensors that wrap device pointers (a partitioned CSR is served for the "
+                   "unweighted op only, as in the reference)");
   WG_EXPECTS(rd.dtype == WHOLEMEMORY_DT_INT64, "csr_row_ptr dtype must be INT64, got %d", (int)rd.dtype);
   WG_EXPECTS(od.dtype == WHOLEMEMORY_DT_INT, "output_sample_offset dtype must be INT, got %d", (int)od.dtype);
   WG_REQUIRE_INPUT(cd.dtype == WHOLEMEMORY_DT_INT || cd.dtype == WHOLEMEMORY_DT_INT64, "csr_col dtype must be INT|INT64");
@@ -935,11 +944,100 @@ void run(const sample_args& a, bool weighted)
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // outputs complete on return (reference contract)
 }
 
+// ---- CSR partitioned over the GPUs of a communicator (DISTRIBUTED / CHUNKED handles) ------------------------------
+// What the reference does (unweighted_sample_without_replacement_nccl_func.cuh:213-372): fetch row_ptr[v] and
+// row_ptr[v + 1] of every centre with one gather, pick POSITIONS locally (same generator, same order as the local
+// kernel), fetch the columns at the picked positions with a second gather.  Here the two gathers are the library's own
+// (all-to-all for DISTRIBUTED, direct loads for peer-mapped handles), and the picks come from the ordinary sampling
+// kernels run on a two-entry-per-centre row_ptr with `col` = NULL — so a partitioned CSR samples exactly what a
+// replicated one does.  Collective: every rank of the CSR's communicator makes the call (with its own centres).
+__global__ void __launch_bounds__(256) centre_pairs_kernel(const void* __restrict__ seeds, bool seeds64, int n,
+                                                           int64_t* __restrict__ ids, int* __restrict__ twice)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = seeds64 ? static_cast<const int64_t*>(seeds)[i] : (int64_t)static_cast<const int32_t*>(seeds)[i];
+  ids[2 * i]     = v;
+  ids[2 * i + 1] = v + 1;
+  twice[i]       = 2 * i;   // "centre" i of the fetched row_ptr pairs
+}
+
+struct borrowed_tensor {   // a wholememory_tensor_t over caller-owned device memory, destroyed on scope exit
+  wholememory_tensor_t t = nullptr;
+  borrowed_tensor(void* p, int64_t n, wholememory_dtype_t dt)
+  {
+    wholememory_tensor_description_t d;
+    wholememory_initialize_tensor_desc(&d);
+    d.dim        = 1;
+    d.dtype      = dt;
+    d.sizes[0]   = n;
+    d.strides[0] = 1;
+    WG_EXPECTS(wholememory_make_tensor_from_pointer(&t, p, &d) == WHOLEMEMORY_SUCCESS, "tensor over scratch");
+  }
+  ~borrowed_tensor() { wholememory_destroy_tensor(t); }
+  borrowed_tensor(const borrowed_tensor&)            = delete;
+  borrowed_tensor& operator=(const borrowed_tensor&) = delete;
+};
+
+template <typename ColT>
+void run_partitioned(const sample_args& a)
+{
+  const int n        = (int)a.seeds->desc.sizes[0];
+  const int M        = a.M;
+  hipStream_t stream = a.stream;
+  const bool seeds64 = a.seeds->desc.dtype == WHOLEMEMORY_DT_INT64;
+  int* offsets       = static_cast<int*>(tensor_data(a.out_offsets));
+  auto fetch = [&](wholememory_tensor_t table, wholememory_tensor_t idx, wholememory_tensor_t out, const char* what) {
+    const auto rc = wholememory_gather(table, idx, out, a.env, stream, -1);
+    if (rc != WHOLEMEMORY_SUCCESS) throw logic_error(fmt("gather of %s failed (%d)", what, (int)rc));
+  };
+  temp_arena arena(a.env);
+  const size_t o_ids = arena.add(sizeof(int64_t) * 2 * n), o_ptr = arena.add(sizeof(int64_t) * 2 * n),
+               o_twice = arena.add(sizeof(int) * n), o_cnt = arena.add(sizeof(int) * (n + 1)),
+               o_scan = arena.add(sizeof(int) * scan_tmp_ints(n + 1));
+  arena.commit();
+  int64_t* ids  = arena.at<int64_t>(o_ids);
+  int64_t* ptrs = arena.at<int64_t>(o_ptr);
+  int* twice    = arena.at<int>(o_twice);
+  int* cnt      = arena.at<int>(o_cnt);
+  // (1) row_ptr[v], row_ptr[v + 1] of every centre
+  if (n > 0) {
+    centre_pairs_kernel<<<ceil_div(n, 256), 256, 0, stream>>>(tensor_data(a.seeds), seeds64, n, ids, twice);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  {
+    borrowed_tensor t_ids(ids, 2 * (int64_t)n, WHOLEMEMORY_DT_INT64), t_ptrs(ptrs, 2 * (int64_t)n, WHOLEMEMORY_DT_INT64);
+    fetch(a.row_ptr, t_ids.t, t_ptrs.t, "csr_row_ptr");
+  }
+  // (2) sample counts, offsets, total (the one host sync the output sizes need)
+  sample_count_enqueue(ptrs, twice, false, dev_count{n, nullptr}, M, cnt, nullptr, stream);
+  exclusive_scan_i32(cnt, offsets, n, arena.at<int>(o_scan), stream);
+  int total = 0;
+  WG_HIP_CHECK(hipMemcpyAsync(&total, offsets + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+  WG_HIP_CHECK(hipStreamSynchronize(stream));
+  auto* dst = static_cast<ColT*>(output_alloc(a.env, a.dst_ctx, total, dtype_of<ColT>::value));
+  int* lid  = a.lid_ctx ? static_cast<int*>(output_alloc(a.env, a.lid_ctx, total, WHOLEMEMORY_DT_INT)) : nullptr;
+  temp_buffer gid_buf(a.env);
+  auto* gid = a.gid_ctx ? static_cast<int64_t*>(output_alloc(a.env, a.gid_ctx, total, WHOLEMEMORY_DT_INT64))
+                        : gid_buf.device<int64_t>(total, WHOLEMEMORY_DT_INT64);
+  // (3) the picks, as CSR positions
+  if (n > 0 && total > 0)
+    uniform_sample_enqueue(ptrs, nullptr, sizeof(ColT) == 8, twice, false, dev_count{n, nullptr}, M,
+                           rng_plan{a.random_seed, nullptr, nullptr, nullptr}, offsets, nullptr, lid, gid, stream);
+  // (4) the columns at the picked positions (every rank takes part, also with nothing to fetch)
+  {
+    borrowed_tensor t_gid(gid, total, WHOLEMEMORY_DT_INT64), t_dst(dst, total, dtype_of<ColT>::value);
+    fetch(a.col, t_gid.t, t_dst.t, "csr_col");
+  }
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // outputs complete on return (reference contract); scratch is released
+}
+
 template <typename WeightT>
 void dispatch(const sample_args& a, bool weighted)
 {
   const bool s64 = a.seeds->desc.dtype == WHOLEMEMORY_DT_INT64;
   const bool c64 = a.col->desc.dtype == WHOLEMEMORY_DT_INT64;
+  if (!weighted && (a.row_ptr->handle || a.col->handle)) return c64 ? run_partitioned<int64_t>(a) : run_partitioned<int32_t>(a);
   if (s64 && c64) return run<int64_t, int64_t, WeightT>(a, weighted);
   if (s64 && !c64) return run<int64_t, int32_t, WeightT>(a, weighted);
   if (!s64 && c64) return run<int32_t, int64_t, WeightT>(a, weighted);

@@ -19,9 +19,27 @@ def _as_device_tensor(t):
     return t.local_tensor if hasattr(t, "local_tensor") else t
 
 
+def _is_partitioned(t):
+    """A table spread over the GPUs of a communicator (C-level handle), as opposed to a tensor this GPU holds whole."""
+    return getattr(t, "is_distributed", False) and hasattr(t, "c")
+
+
+class _Handle:
+    """Stands where ``wrap_torch_tensor`` would: the C tensor of a partitioned table is passed as it is."""
+
+    def __init__(self, t):
+        self.c = t.c
+
+
 def _sample(weighted, row_ptr, col, weight, center_nodes_tensor, max_sample_count, random_seed,
             need_center_local_output, need_edge_output, with_replacement=False):
-    row_ptr, col = _as_device_tensor(row_ptr), _as_device_tensor(col)
+    partitioned = _is_partitioned(row_ptr) or _is_partitioned(col)
+    if partitioned:
+        # the CSR itself is partitioned (wholegraph_ops.py:18-83 takes WholeMemory tensors of any memory type): the op
+        # fetches row offsets and columns from their owners; collective over the tensors' communicator
+        assert not weighted and not with_replacement, "a partitioned CSR is served by the unweighted op only"
+    else:
+        row_ptr, col = _as_device_tensor(row_ptr), _as_device_tensor(col)
     assert row_ptr.dim() == 1
     assert col.dim() == 1
     assert center_nodes_tensor.dim() == 1
@@ -35,9 +53,9 @@ def _sample(weighted, row_ptr, col, weight, center_nodes_tensor, max_sample_coun
     dest_ctx = TorchMemoryContext()
     lid_ctx = TorchMemoryContext() if need_center_local_output else None
     gid_ctx = TorchMemoryContext() if need_edge_output else None
-    w_row, w_col, w_seeds, w_off = (wrap_torch_tensor(row_ptr), wrap_torch_tensor(col),
-                                    wrap_torch_tensor(center_nodes_tensor),
-                                    wrap_torch_tensor(output_sample_offset_tensor))
+    w_row = _Handle(row_ptr) if _is_partitioned(row_ptr) else wrap_torch_tensor(_as_device_tensor(row_ptr))
+    w_col = _Handle(col) if _is_partitioned(col) else wrap_torch_tensor(_as_device_tensor(col))
+    w_seeds, w_off = wrap_torch_tensor(center_nodes_tensor), wrap_torch_tensor(output_sample_offset_tensor)
     lid_c = lid_ctx.get_c_context() if lid_ctx else None
     gid_c = gid_ctx.get_c_context() if gid_ctx else None
     seed = random_seed & 0xFFFFFFFFFFFFFFFF

@@ -33,7 +33,12 @@ extern "C" {
  * Seed i with deg<=M copies its row in CSR order; otherwise position t<M is chosen by the
  * reference's Fisher-Yates with r_t = PCG(random_seed, subsequence = i*B + lane).i31 % (deg-t)
  * (B, items-per-lane from the reference's launch table) — results are BIT-IDENTICAL to the
- * reference's host oracle (cpp/tests/wholegraph_ops/graph_sampling_test_utils.cu:312-401). */
+ * reference's host oracle (cpp/tests/wholegraph_ops/graph_sampling_test_utils.cu:312-401).
+ * csr_row_ptr / csr_col may be tensors over device pointers (a CSR this GPU holds whole) or tensors backed by a
+ * DISTRIBUTED / CHUNKED / CONTINUOUS handle (a CSR partitioned over the GPUs of a communicator): the op then fetches the
+ * row offsets of the centres and the columns at the picked positions from their owners — the reference's NCCL path,
+ * cpp/src/wholegraph_ops/unweighted_sample_without_replacement_nccl_func.cuh:213-372 — and is collective over that
+ * communicator; the result is the same either way. */
 wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
   wholememory_tensor_t wm_csr_row_ptr_tensor,
   wholememory_tensor_t wm_csr_col_ptr_tensor,
