@@ -1,6 +1,6 @@
 // int32 exclusive scan over up to 2^31 elements, wave64-native.
 //   n <= TILE        : one launch (single workgroup).
-//   otherwise        : tile sums -> single-workgroup scan of the sums -> tile rescans (3 launches).
+//   otherwise        : tile sums -> tile rescans, every workgroup adding up the sums before its own tiles (2 launches).
 // Used for sample offsets (role of thrust::exclusive_scan in
 // /root/reference/cpp/src/wholegraph_ops/unweighted_sample_without_replacement_func.cuh:323-326)
 // and for the first-appearance ranks of append_unique.
@@ -106,29 +106,34 @@ __global__ void __launch_bounds__(kThreads) scan_tile_sums_kernel(const int* in,
   }
 }
 
-// exclusive scan of sums[0..m) in place, sums[m] = grand total.  With a live count only the tiles that hold live elements
-// are scanned (the others are never read again: their tiles skip the final pass), the total still lands at sums[m].
-__global__ void __launch_bounds__(kThreads) scan_sums_kernel(int* sums, int64_t m, dev_count live)
+// sum of v over the workgroup (every thread gets it)
+__device__ __forceinline__ int block_sum(int v)
 {
-  int carry = 0;
-  const int64_t m_live = live.dev == nullptr ? m : min(m, (int64_t)live.get() / kTile + 1);
-  for (int64_t base = 0; base < m_live; base += kThreads) {
-    int64_t i = base + threadIdx.x;
-    int v     = i < m_live ? sums[i] : 0;
-    int total;
-    int ex = block_exclusive_scan(v, &total);
-    if (i < m_live) sums[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) sums[m] = carry;
+  int total;
+  (void)block_exclusive_scan(v, &total);
+  return total;
 }
 
+// Second (last) launch: workgroup b owns a CONTIGUOUS run of live tiles, adds up the tile sums before its run itself
+// (a few thousand ints out of L2 — cheaper than a third launch that scans them), then rescans its tiles with a running
+// carry.  Workgroup 0 also publishes the grand total at out[n].
 __global__ void __launch_bounds__(kThreads)
 scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int64_t m, dev_count live)
 {
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[m];
-  for (int64_t tile = blockIdx.x; tile < m; tile += gridDim.x) {
-    if (!tile_is_live(live, (unsigned)tile)) break;
+  const int64_t m_live = live.dev == nullptr ? m : min(m, (int64_t)live.get() / kTile + 1);
+  const int64_t per    = (m_live + gridDim.x - 1) / gridDim.x;
+  const int64_t first  = (int64_t)blockIdx.x * per, last = min(m_live, first + per);
+  if (blockIdx.x == 0) {
+    int part = 0;
+    for (int64_t t = threadIdx.x; t < m_live; t += kThreads) part += sums[t];
+    const int total = block_sum(part);
+    if (threadIdx.x == 0) out[n] = total;
+  }
+  if (first >= last) return;
+  int part = 0;
+  for (int64_t t = threadIdx.x; t < first; t += kThreads) part += sums[t];
+  int carry = block_sum(part);
+  for (int64_t tile = first; tile < last; tile++) {
     int x[kItems];
     const int64_t base = tile * kTile;
     load_tile(in, base, n, x);
@@ -136,13 +141,14 @@ scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int6
 #pragma unroll
     for (int k = 0; k < kItems; k++) s += x[k];
     int total;
-    int run   = block_exclusive_scan(s, &total) + sums[tile];
+    int run   = block_exclusive_scan(s, &total) + carry;
     int64_t p = base + (int64_t)threadIdx.x * kItems;
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
       if (p + k < n) out[p + k] = run;
       run += x[k];
     }
+    carry += total;
   }
 }
 
@@ -159,7 +165,6 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
     int64_t m = (n + kTile - 1) / kTile;
     const unsigned grid = (unsigned)std::min<int64_t>(m, kScanGrid);
     scan_tile_sums_kernel<<<grid, kThreads, 0, stream>>>(in, n, tmp, m, live);
-    scan_sums_kernel<<<1, kThreads, 0, stream>>>(tmp, m, live);
     // in-place is safe: every tile reads its inputs into registers before writing them back,
     // and out[n] is written from tmp, not from `in`.
     scan_tile_final_kernel<<<grid, kThreads, 0, stream>>>(in, out, n, tmp, m, live);

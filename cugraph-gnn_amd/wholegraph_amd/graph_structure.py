@@ -119,7 +119,7 @@ class GraphStructure(object):
         """The same walk without host synchronisation: returns a ``fused.WalkResult`` (capacity-sized device
         tensors + device-resident counts); ``.finalize()`` trims it to the tuple above."""
         key = (int(node_ids.shape[0]), tuple(max_neighbors), node_ids.dtype)
-        if any(getattr(t, "is_distributed", False) for t in (self.csr_row_ptr, self.csr_col_ind)):
+        if any(wholegraph_ops._is_partitioned(t) for t in (self.csr_row_ptr, self.csr_col_ind)):
             raise NotImplementedError("the no-sync walk reads the CSR with plain loads: it needs a CSR this GPU holds whole "
                                       "(multilayer_sample_without_replacement serves a partitioned one)")
         if key not in self._walk_cache:

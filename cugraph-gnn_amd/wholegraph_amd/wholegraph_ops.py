@@ -21,7 +21,7 @@ def _as_device_tensor(t):
 
 def _is_partitioned(t):
     """A table spread over the GPUs of a communicator (C-level handle), as opposed to a tensor this GPU holds whole."""
-    return getattr(t, "is_distributed", False) and hasattr(t, "c")
+    return hasattr(t, "c") and getattr(t, "is_distributed", False) is True   # (torch.Tensor.is_distributed is a method)
 
 
 class _Handle:
