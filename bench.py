@@ -342,6 +342,8 @@ def main():
                                                             "one-GPU rehearsal of the N>1 control flow in the tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test aid: every rank uses cuda:0")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes of the other code paths")
+    ap.add_argument("--extra-placement-timeout", type=int, default=180,
+                    help="seconds the also-measured feature placement may take before the headline line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -506,26 +508,10 @@ def main():
 
     results = {}
     placement_errors = {}
-    for placement in list(placements):
+    def run_placement(placement, feat):
+        """Measure one feature placement: headline pass, variants (first placement only), stage timings."""
+        nonlocal batches
         partitioned = placement == "partitioned"
-        if partitioned and placement != placements[0]:
-            # the second, "also measured" placement must never cost the headline its JSON line: every rank agrees on
-            # whether the table could be built before anyone enters a collective of the measurement
-            try:
-                feat = make_table(placement)
-                ok = 1
-            except Exception as e:       # noqa: BLE001
-                placement_errors[placement] = repr(e)
-                feat, ok = None, 0
-            flag = torch.tensor([ok], device=device)
-            if world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag) == 0:
-                placement_errors.setdefault(placement, "another rank could not build the partitioned table")
-                placements.remove(placement)
-                continue
-        else:
-            feat = make_table(placement)
         pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
         # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
         # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
@@ -566,179 +552,236 @@ def main():
                                   split_ms=split_ms, head_mode=head_mode, stage_n=stage_n, pipe=pipe, feat=feat)
         if placement != placements[-1]:
             results[placement]["pipe_dims"] = pipe.dims
-    head = results[placements[0]]
-    pipe, feat = head["pipe"], head["feat"]
-    partitioned = placements[0] == "partitioned"
-    dt, edges_total, variants, stage_ms, psizes, split_ms, head_mode, stage_n = (
-        head[k] for k in ("dt", "edges", "variants", "stage_ms", "psizes", "split_ms", "head_mode", "stage_n"))
-    fused = variants.get("fused_fetch") or variants.get("split_fetch")
-    hop_e = [sum(s[2 * k] for s in psizes) / stage_n for k in range(L)]       # edges per call group, seed hop first
-    hop_u = [sum(s[2 * k + 1] for s in psizes) / stage_n for k in range(L)]   # unique nodes after each hop
-    n_src = hop_u[L - 1]
 
-    if rank == 0:
-        # algorithmic bytes per launch; b = id bytes, fp32 features
-        F = FEAT_DIM
-        idb = 4 if id_dtype == torch.int32 else 8
-        kernels = {"gather": ("row_copy_kernel", n_src * (idb + 2 * 4 * F))}
-        spmm_root = {}
-        for j in range(L):
-            k = L - 1 - j
-            fj = pipe.dims[j]
-            n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            # STRICT SURVEY §8(d): E(4F+4) + N_dst(4F+8).  The kernel also copies the root row next to the aggregate
-            # (one more row read and written per destination): that term is reported under its own key, never in spmm_GBps
-            kernels[spmm_label(j)] = ("spmm_csr_kernel", hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 8))
-            spmm_root[spmm_label(j)] = n_dst * (8 * fj + 8)
-        for j in range(L):   # one-kernel layers: same reads minus the [agg|x_self] round trip, plus the output write
-            k = L - 1 - j
-            fj, nj = pipe.dims[j], pipe.dims[j + 1]
-            n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            kname = "sage_layer_mfma_kernel" if (nn_mod.sage_layer_fused_precision() == "bf16x3" and nn_mod.L.lib(
-            ).wgamd_sage_layer_bf16x3_supported(fj, nj)) else "sage_layer_fused_kernel"
-            kernels["sage_layer%d(fused)" % (j + 1)] = (kname, hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
-        dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
-        roofline = None
-        if dom is not None:
-            ach = kernels[dom][1] / (stage_ms[dom] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": kernels[dom][0], "stage": dom, "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                        "traffic": None, "algorithmic_bytes_per_launch": int(kernels[dom][1]),
-                        "avg_launch_ms": round(stage_ms[dom], 5),
-                        "timing": "HIP events around the launch on the launch stream, one launch per call group of "
-                                  f"{G} mini-batches, averaged over {stage_n} call groups"}
-        std_shape = args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we
-        if roofline is not None and std_shape:
-            hit = load_pmc(roofline["kernel"])
-            if hit:
-                roofline["traffic"] = hit["bytes"]
-                roofline["traffic_over_algorithmic"] = round(hit["bytes"] / kernels[dom][1], 3)
-                roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"]
-        spmm_gbps = spmm_root_gbps = spmm_pmc = None
-        if SPMM1 in split_ms:
-            spmm_gbps = kernels[SPMM1][1] / (split_ms[SPMM1] * 1e-3) / 1e9
-            spmm_root_gbps = (kernels[SPMM1][1] + spmm_root[SPMM1]) / (split_ms[SPMM1] * 1e-3) / 1e9
-            hit = load_pmc("spmm_csr_kernel") if std_shape else None
-            if hit:     # real HBM utilisation of the launch: (2 x FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s
-                spmm_pmc = {"hbm_util": round(hit["bytes"] / (split_ms[SPMM1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "traffic_bytes_per_launch": hit["bytes"], "source": hit["source"] + " kernel " + hit["kernel"]}
-        if roofline is not None and dom.startswith("sage_layer"):
-            # one-kernel layer: HBM-side and MFMA-side work of the same launch
-            j = int(dom[len("sage_layer")]) - 1
-            k = L - 1 - j
-            n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
-            flops = 2.0 * n_dst * 2 * pipe.dims[j] * pipe.dims[j + 1]
-            prec = "bf16x3" if roofline["kernel"] == "sage_layer_mfma_kernel" else "f32"
-            roofline["hbm_frac"] = roofline["frac"]
-            if prec == "f32":
-                tfs = flops / (stage_ms[dom] * 1e-3) / 1e12
-                roofline["mfma_TFps"] = round(tfs, 1)
-                roofline["mfma_frac"] = round(tfs / MFMA_F32_PEAK_TFPS, 4)
-                roofline["mfma_dtype"] = "f32 (v_mfma_f32_16x16x4_f32)"
-                if roofline["mfma_frac"] > roofline["frac"]:
-                    roofline.update(bound="mfma", achieved=round(tfs, 1), peak=MFMA_F32_PEAK_TFPS, unit="TFLOP/s",
-                                    frac=roofline["mfma_frac"])
-            else:
-                # 3-way bf16 split of both operands, 6 bf16 MFMA products per fp32 product (fp32 accumulate): the matrix
-                # work is 6 x flops on the bf16 pipe (2.5 PFLOP/s dense) -> far from binding, the launch is HBM-bound
-                tfs = 6.0 * flops / (stage_ms[dom] * 1e-3) / 1e12
-                roofline["mfma_TFps"] = round(tfs, 1)
-                roofline["mfma_frac"] = round(tfs / MFMA_BF16_PEAK_TFPS, 4)
-                roofline["mfma_dtype"] = "bf16x3 split (6 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)"
-            g_ach = kernels["gather"][1] / (stage_ms["gather"] * 1e-3) / 1e9 if "gather" in stage_ms else None
-            if g_ach:
-                roofline["also"] = {"kernel": "row_copy_kernel", "stage": "gather", "bound": "hbm", "achieved": round(g_ach, 1),
-                                    "frac": round(g_ach / HBM_PEAK_GBPS, 4), "avg_launch_ms": round(stage_ms["gather"], 5)}
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only (rank 0 owns the host cores)
-            nb = min(2048, order.numel() // BATCH)   # time-bounded inside cpu_baseline (--cpu-budget seconds)
-            cb = order[: nb * BATCH].view(nb, BATCH).to(id_dtype).cpu().numpy()  # same seed stream, one mini-batch at a time
-            if V * FEAT_DIM * 4 > (8 << 30):
-                # papers100M-scale table: a lazily-zeroed host array of the same shape (only the gathered
-                # rows' pages are ever touched; values do not matter for the timing)
-                feat_h = np.zeros((V, FEAT_DIM), dtype=np.float32)
-            elif partitioned:
-                feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
-            else:
-                feat_h = feat.local_tensor.cpu().numpy()
-            weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in pipe.convs]
-            cpu = cpu_baseline(row_ptr.cpu().numpy(), col.cpu().numpy(), feat_h, cb, weights, args.cpu_budget)
-        wl_name = "RMAT-26" if args.workload == "rmat26" else "ogbn-" + args.workload
-        prec = nn_mod.sage_layer_fused_precision() if hasattr(nn_mod, "sage_layer_fused_precision") else "f32"
-        out = {
-            "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), %s-like fan-out %s"
-                      % (wl_name, FANOUT),
-            "value": edges_total / dt,
-            "unit": "sampled-edges/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": ("int32" if id_dtype == torch.int32 else "int64") + " ids + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
-                                                   " (SAGE lin_l/lin_r product: bf16x3-split MFMA, f32 accumulate)"),
-            "data": "synthetic",
-            "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR row_ptr i64 / col %s replicated per GPU), "
-                                   "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, %d-layer SAGEConv(mean) %s fwd, "
-                                   "step = %d call groups of %d mini-batches"
-                                   % (V, E, "i32" if id_dtype == torch.int32 else "i64", FEAT_DIM,
-                                      " range-partitioned + xGMI feature fetch" if partitioned else
-                                      ("" if world == 1 else " replicated per GPU"),
-                                      BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), gps, G),
-                       "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
-                       else "dp%d (seeds sharded, no data-path collective)" % world},
-            "call_group": G,
-            "batches_per_step": G * gps,
-            "timed_region_ms": round(dt * 1e3, 2),
-            "timed_call_groups": groups,
-            "ms_per_batch": dt / (groups * G) * 1e3,
-            "edges_per_batch": dict([("hop%d" % (k + 1), hop_e[k] / G) for k in range(L)] + [("unique_nodes", n_src / G)]),
-            "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
-            "split_stage_ms_per_call_group": None if split_ms is stage_ms else {k: round(v, 5) for k, v in split_ms.items()},
-            "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
-            "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
-            "spmm_accounting": "SURVEY.md §8(d) strict: E(4F+4) + N_dst(4F+8) bytes / HIP-event time of the layer-1 "
-                               "aggregation launch (effective bandwidth: part of x is served by L2/MALL)",
-            "spmm_with_root_copy_GBps": None if spmm_root_gbps is None else round(spmm_root_gbps, 1),
-            "spmm_hbm_util_pmc": spmm_pmc,
-            "layer_kernel": head_mode,
-            "fused_fetch_variant": fused,
-            "variants": variants,
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        if cpu is not None:
-            out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
-        if placement_errors:
-            out["placement_errors"] = placement_errors
-        if len(placements) > 1 or partitioned:
-            # the north-star exchange path next to the collective-free one: per-GPU xGMI bytes of the feature fetch and the
-            # fraction of the (world-1) x 153 GB/s links it sustains (SURVEY §8(d) all-to-all bytes: n_remote (b + 4F))
-            pr = results["partitioned"]
-            p_e = [sum(s[2 * k] for s in pr["psizes"]) / pr["stage_n"] for k in range(L)]
-            p_src = sum(s[2 * L - 1] for s in pr["psizes"]) / pr["stage_n"]
-            n_remote = p_src * (world - 1) / max(world, 1)
-            a2a = n_remote * (idb + 4 * F)
-            gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
-            gms = pr["stage_ms"].get(gname) if gname else None
-            link_peak = max(world - 1, 1) * 153.0
-            out["placements"] = {
-                "replicated": None if "replicated" not in results else {
-                    "value": results["replicated"]["edges"] / results["replicated"]["dt"],
-                    "ms_per_step": results["replicated"]["dt"] / args.steps * 1e3},
-                "partitioned": {"value": pr["edges"] / pr["dt"], "ms_per_step": pr["dt"] / args.steps * 1e3,
-                                "gather_stage": gname, "gather_ms_per_call_group": None if gms is None else round(gms, 4),
-                                "feature_fetch": feature_fetch_path(pr["feat"])}}
-            out["all_to_all_bytes_per_gpu"] = int(a2a)
-            out["xgmi_frac"] = None if (gms is None or world == 1) else round(a2a / (gms * 1e-3) / 1e9 / link_peak, 4)
-            out["xgmi_peak_GBps"] = link_peak
-            out["edges_per_call_group_partitioned"] = p_e
-        # RCCL writes a version banner through C stdio; push it out first so the JSON is the LAST line
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+    def emit_line():
+        """Rank 0 prints the ONE JSON line from whatever placements were measured (headline = placements[0])."""
+        head = results[placements[0]]
+        pipe, feat = head["pipe"], head["feat"]
+        partitioned = placements[0] == "partitioned"
+        dt, edges_total, variants, stage_ms, psizes, split_ms, head_mode, stage_n = (
+            head[k] for k in ("dt", "edges", "variants", "stage_ms", "psizes", "split_ms", "head_mode", "stage_n"))
+        fused = variants.get("fused_fetch") or variants.get("split_fetch")
+        hop_e = [sum(s[2 * k] for s in psizes) / stage_n for k in range(L)]       # edges per call group, seed hop first
+        hop_u = [sum(s[2 * k + 1] for s in psizes) / stage_n for k in range(L)]   # unique nodes after each hop
+        n_src = hop_u[L - 1]
+
+        if rank == 0:
+            # algorithmic bytes per launch (SURVEY.md §8(d)); b = id bytes, fp32 features
+            F = FEAT_DIM
+            idb = 4 if id_dtype == torch.int32 else 8
+            kernels = {"gather": ("row_copy_kernel", n_src * (idb + 2 * 4 * F))}
+            spmm_root = {}
+            for j in range(L):
+                k = L - 1 - j
+                fj = pipe.dims[j]
+                n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
+                # STRICT SURVEY §8(d): E(4F+4) + N_dst(4F+8).  The kernel also copies the root row next to the aggregate
+                # (one more row read and written per destination): that term is reported under its own key, never in spmm_GBps
+                kernels[spmm_label(j)] = ("spmm_csr_kernel", hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 8))
+                spmm_root[spmm_label(j)] = n_dst * (8 * fj + 8)
+            for j in range(L):   # one-kernel layers: same reads minus the [agg|x_self] round trip, plus the output write
+                k = L - 1 - j
+                fj, nj = pipe.dims[j], pipe.dims[j + 1]
+                n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
+                kname = "sage_layer_mfma_kernel" if (nn_mod.sage_layer_fused_precision() == "bf16x3" and nn_mod.L.lib(
+                ).wgamd_sage_layer_bf16x3_supported(fj, nj)) else "sage_layer_fused_kernel"
+                kernels["sage_layer%d(fused)" % (j + 1)] = (kname, hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
+            dom = max((k for k in kernels if k in stage_ms), key=lambda k: stage_ms[k], default=None)
+            roofline = None
+            if dom is not None:
+                ach = kernels[dom][1] / (stage_ms[dom] * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": kernels[dom][0], "stage": dom, "achieved": round(ach, 1),
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                            "traffic": None, "algorithmic_bytes_per_launch": int(kernels[dom][1]),
+                            "avg_launch_ms": round(stage_ms[dom], 5),
+                            "timing": "HIP events around the launch on the launch stream, one launch per call group of "
+                                      f"{G} mini-batches, averaged over {stage_n} call groups"}
+            std_shape = args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we
+            if roofline is not None and std_shape:
+                hit = load_pmc(roofline["kernel"])
+                if hit:
+                    roofline["traffic"] = hit["bytes"]
+                    roofline["traffic_over_algorithmic"] = round(hit["bytes"] / kernels[dom][1], 3)
+                    roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"]
+            spmm_gbps = spmm_root_gbps = spmm_pmc = None
+            if SPMM1 in split_ms:
+                spmm_gbps = kernels[SPMM1][1] / (split_ms[SPMM1] * 1e-3) / 1e9
+                spmm_root_gbps = (kernels[SPMM1][1] + spmm_root[SPMM1]) / (split_ms[SPMM1] * 1e-3) / 1e9
+                hit = load_pmc("spmm_csr_kernel") if std_shape else None
+                if hit:     # real HBM utilisation of the launch: (2 x FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s
+                    spmm_pmc = {"hbm_util": round(hit["bytes"] / (split_ms[SPMM1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                "traffic_bytes_per_launch": hit["bytes"], "source": hit["source"] + " kernel " + hit["kernel"]}
+            if roofline is not None and dom.startswith("sage_layer"):
+                # one-kernel layer: HBM-side and MFMA-side work of the same launch
+                j = int(dom[len("sage_layer")]) - 1
+                k = L - 1 - j
+                n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
+                flops = 2.0 * n_dst * 2 * pipe.dims[j] * pipe.dims[j + 1]
+                prec = "bf16x3" if roofline["kernel"] == "sage_layer_mfma_kernel" else "f32"
+                roofline["hbm_frac"] = roofline["frac"]
+                if prec == "f32":
+                    tfs = flops / (stage_ms[dom] * 1e-3) / 1e12
+                    roofline["mfma_TFps"] = round(tfs, 1)
+                    roofline["mfma_frac"] = round(tfs / MFMA_F32_PEAK_TFPS, 4)
+                    roofline["mfma_dtype"] = "f32 (v_mfma_f32_16x16x4_f32)"
+                    if roofline["mfma_frac"] > roofline["frac"]:
+                        roofline.update(bound="mfma", achieved=round(tfs, 1), peak=MFMA_F32_PEAK_TFPS, unit="TFLOP/s",
+                                        frac=roofline["mfma_frac"])
+                else:
+                    # 3-way bf16 split of both operands, 6 bf16 MFMA products per fp32 product (fp32 accumulate): the matrix
+                    # work is 6 x flops on the bf16 pipe (2.5 PFLOP/s dense) -> far from binding, the launch is HBM-bound
+                    tfs = 6.0 * flops / (stage_ms[dom] * 1e-3) / 1e12
+                    roofline["mfma_TFps"] = round(tfs, 1)
+                    roofline["mfma_frac"] = round(tfs / MFMA_BF16_PEAK_TFPS, 4)
+                    roofline["mfma_dtype"] = "bf16x3 split (6 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)"
+                g_ach = kernels["gather"][1] / (stage_ms["gather"] * 1e-3) / 1e9 if "gather" in stage_ms else None
+                if g_ach:
+                    roofline["also"] = {"kernel": "row_copy_kernel", "stage": "gather", "bound": "hbm", "achieved": round(g_ach, 1),
+                                        "frac": round(g_ach / HBM_PEAK_GBPS, 4), "avg_launch_ms": round(stage_ms["gather"], 5)}
+            cpu = None
+            if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only (rank 0 owns the host cores)
+                nb = min(2048, order.numel() // BATCH)   # time-bounded inside cpu_baseline (--cpu-budget seconds)
+                cb = order[: nb * BATCH].view(nb, BATCH).to(id_dtype).cpu().numpy()  # same seed stream, one mini-batch at a time
+                if V * FEAT_DIM * 4 > (8 << 30):
+                    # papers100M-scale table: a lazily-zeroed host array of the same shape (only the gathered
+                    # rows' pages are ever touched; values do not matter for the timing)
+                    feat_h = np.zeros((V, FEAT_DIM), dtype=np.float32)
+                elif partitioned:
+                    feat_h = np.random.default_rng(0).random((V, FEAT_DIM), dtype=np.float32) * 2 - 1
+                else:
+                    feat_h = feat.local_tensor.cpu().numpy()
+                weights = [(c.lin_l.weight.cpu(), c.lin_l.bias.cpu(), c.lin_r.weight.cpu()) for c in pipe.convs]
+                cpu = cpu_baseline(row_ptr.cpu().numpy(), col.cpu().numpy(), feat_h, cb, weights, args.cpu_budget)
+            wl_name = "RMAT-26" if args.workload == "rmat26" else "ogbn-" + args.workload
+            prec = nn_mod.sage_layer_fused_precision() if hasattr(nn_mod, "sage_layer_fused_precision") else "f32"
+            out = {
+                "metric": "sampled-edges/sec (sample+renumber+feature-gather+SAGEConv fwd), %s-like fan-out %s"
+                          % (wl_name, FANOUT),
+                "value": edges_total / dt,
+                "unit": "sampled-edges/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": ("int32" if id_dtype == torch.int32 else "int64") + " ids + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
+                                                       " (SAGE lin_l/lin_r product: bf16x3-split MFMA, f32 accumulate)"),
+                "data": "synthetic",
+                "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR row_ptr i64 / col %s replicated per GPU), "
+                                       "feat fp32 [V,%d]%s, batch %d/GPU, fan-out %s, %d-layer SAGEConv(mean) %s fwd, "
+                                       "step = %d call groups of %d mini-batches"
+                                       % (V, E, "i32" if id_dtype == torch.int32 else "i64", FEAT_DIM,
+                                          " range-partitioned + xGMI feature fetch" if partitioned else
+                                          ("" if world == 1 else " replicated per GPU"),
+                                          BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), gps, G),
+                           "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
+                           else "dp%d (seeds sharded, no data-path collective)" % world},
+                "call_group": G,
+                "batches_per_step": G * gps,
+                "timed_region_ms": round(dt * 1e3, 2),
+                "timed_call_groups": groups,
+                "ms_per_batch": dt / (groups * G) * 1e3,
+                "edges_per_batch": dict([("hop%d" % (k + 1), hop_e[k] / G) for k in range(L)] + [("unique_nodes", n_src / G)]),
+                "stage_ms_per_call_group": {k: round(v, 5) for k, v in stage_ms.items()},
+                "split_stage_ms_per_call_group": None if split_ms is stage_ms else {k: round(v, 5) for k, v in split_ms.items()},
+                "spmm_GBps": None if spmm_gbps is None else round(spmm_gbps, 1),
+                "spmm_frac_of_hbm_peak": None if spmm_gbps is None else round(spmm_gbps / HBM_PEAK_GBPS, 4),
+                "spmm_accounting": "SURVEY.md §8(d) strict: E(4F+4) + N_dst(4F+8) bytes / HIP-event time of the layer-1 "
+                                   "aggregation launch (effective bandwidth: part of x is served by L2/MALL)",
+                "spmm_with_root_copy_GBps": None if spmm_root_gbps is None else round(spmm_root_gbps, 1),
+                "spmm_hbm_util_pmc": spmm_pmc,
+                "layer_kernel": head_mode,
+                "fused_fetch_variant": fused,
+                "variants": variants,
+                "roofline": roofline,
+                "cpu_baseline": cpu,
+            }
+            if cpu is not None:
+                out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
+            if placement_errors:
+                out["placement_errors"] = placement_errors
+            if len(placements) > 1 or partitioned:
+                # the north-star exchange path next to the collective-free one: per-GPU xGMI bytes of the feature fetch and the
+                # fraction of the (world-1) x 153 GB/s links it sustains (SURVEY §8(d) all-to-all bytes: n_remote (b + 4F))
+                pr = results["partitioned"]
+                p_e = [sum(s[2 * k] for s in pr["psizes"]) / pr["stage_n"] for k in range(L)]
+                p_src = sum(s[2 * L - 1] for s in pr["psizes"]) / pr["stage_n"]
+                n_remote = p_src * (world - 1) / max(world, 1)
+                a2a = n_remote * (idb + 4 * F)
+                gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
+                gms = pr["stage_ms"].get(gname) if gname else None
+                link_peak = max(world - 1, 1) * 153.0
+                out["placements"] = {
+                    "replicated": None if "replicated" not in results else {
+                        "value": results["replicated"]["edges"] / results["replicated"]["dt"],
+                        "ms_per_step": results["replicated"]["dt"] / args.steps * 1e3},
+                    "partitioned": {"value": pr["edges"] / pr["dt"], "ms_per_step": pr["dt"] / args.steps * 1e3,
+                                    "gather_stage": gname, "gather_ms_per_call_group": None if gms is None else round(gms, 4),
+                                    "feature_fetch": feature_fetch_path(pr["feat"])}}
+                out["all_to_all_bytes_per_gpu"] = int(a2a)
+                out["xgmi_frac"] = None if (gms is None or world == 1) else round(a2a / (gms * 1e-3) / 1e9 / link_peak, 4)
+                out["xgmi_peak_GBps"] = link_peak
+                out["edges_per_call_group_partitioned"] = p_e
+            # RCCL writes a version banner through C stdio; push it out first so the JSON is the LAST line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(out), flush=True)
+
+    def arm_watchdog(seconds, what):
+        """The also-measured placement runs collectives this build has only ever run on one GPU: if it has not finished
+        in time (a rank threw inside a collective and left the others waiting), the headline line is printed from what
+        IS measured and the process ends — a scaling run never loses its line to the extra pass."""
+        import threading
+
+        def fire():
+            placement_errors[what] = "timed out after %d s (watchdog); headline unaffected" % seconds
+            while len(placements) > 1:
+                placements.pop()
+            try:
+                emit_line()
+            finally:
+                os._exit(0)
+        t = threading.Timer(seconds, fire)
+        t.daemon = True
+        t.start()
+        return t
+
+    for placement in list(placements):
+        if placement != placements[0]:
+            # the second, "also measured" placement must never cost the headline its JSON line: every rank agrees on
+            # whether the table could be built before anyone enters a collective of the measurement, the measurement itself
+            # runs under a watchdog, and every rank agrees again on whether it went through
+            dog = arm_watchdog(args.extra_placement_timeout, placement)
+            try:
+                feat = make_table(placement)
+                ok = 1
+            except Exception as e:       # noqa: BLE001
+                placement_errors[placement] = repr(e)
+                feat, ok = None, 0
+            flag = torch.tensor([ok], device=device)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 1:
+                try:
+                    if os.environ.get("WGAMD_BENCH_TEST_STALL") and rank == world - 1:
+                        time.sleep(10 ** 6)      # test hook: one rank never reaches the collectives of the extra pass
+                    run_placement(placement, feat)
+                except Exception as e:   # noqa: BLE001
+                    placement_errors[placement] = repr(e)
+                    ok = 0
+                flag = torch.tensor([ok], device=device)
+                if world > 1:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            dog.cancel()
+            if int(flag) == 0:
+                placement_errors.setdefault(placement, "another rank could not build / measure the partitioned table")
+                placements.remove(placement)
+                results.pop(placement, None)
+        else:
+            run_placement(placement, make_table(placement))
+    emit_line()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(nproc, extra):
+def _run(nproc, extra, env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
            "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--no-variants"] + extra
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -53,3 +53,11 @@ def test_partitioned_feature_store_two_ranks(hiplib):
     assert "all-to-all" in d["config"]["parallelism"] and d["n_gpus"] == 2
     assert any(k.startswith("gather(") for k in d["stage_ms_per_call_group"])
     assert d["placements"]["replicated"] is None and d["all_to_all_bytes_per_gpu"] > 0
+
+
+def test_stalled_extra_placement_does_not_cost_the_headline(hiplib):
+    """One rank never enters the collectives of the also-measured partitioned pass: the watchdog prints the headline line
+    (replicated placement) with the reason, every rank exits 0."""
+    d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--extra-placement-timeout", "20"], env={"WGAMD_BENCH_TEST_STALL": "1"})
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "replicated" in d["config"]["parallelism"] or "dp2" in d["config"]["parallelism"]
+    assert "timed out" in d["placement_errors"]["partitioned"] and "placements" not in d
