@@ -256,7 +256,15 @@ constexpr int kWeightedLdsKeys = 12288;
 // list c at 16 + c * cap
 constexpr int kWeightedLists    = 9;
 constexpr int kWeightedListHead = 16;
-inline int64_t weighted_list_ints(int64_t cap) { return kWeightedListHead + (int64_t)kWeightedLists * (cap > 0 ? cap : 1); }
+// one more list region behind the nine: rows a pruned kernel (wg_sample.hip, "threshold pruning") hands back to the exact
+// workgroup kernel — [11] its length, [12] its queue head
+constexpr int kWeightedRedoList  = 9;
+constexpr int kWeightedRedoCount = 11;
+constexpr int kWeightedRedoHead  = 12;
+inline int64_t weighted_list_ints(int64_t cap)
+{
+  return kWeightedListHead + (int64_t)(kWeightedLists + 1) * (cap > 0 ? cap : 1);
+}
 void weighted_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
                             int* big_list, hipStream_t stream);
 void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* weights, bool weights64,

@@ -368,6 +368,9 @@ __device__ __forceinline__ float ares_key(float w, Pcg32& g, bool* redrawn = nul
   if (redrawn != nullptr && zero_draws > 0) *redrawn = true;   // more than three draws for this key
   int one_bit = __clzll((long long)x) + zero_draws * 64;
   u *= exp2f((float)(-one_bit));
+#ifdef WG_TUNE_CHEAP_KEY   // sizing experiment only: what the hop costs without log1pf and the two IEEE divisions
+  return u * 1.442695f * __builtin_amdgcn_rcpf(w);
+#endif
   return (log1pf(u) / logf(2.0f)) * (1.0f / w);
 }
 
@@ -405,7 +408,8 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
                                                             int* __restrict__ src_lid,
                                                             int64_t* __restrict__ edge_gid,
                                                             int* __restrict__ lists /*nullable*/,
-                                                            int list_cap)
+                                                            int list_cap,
+                                                            int redo = 0 /*1: the rows the pruned kernels handed back*/)
 {
   static_assert(T % B == 0 && T % 64 == 0, "threads must be a multiple of the stream layout and of the wave");
   __shared__ uint32_t lds_keys[kLdsKeys];
@@ -418,20 +422,21 @@ __global__ void __launch_bounds__(T) sample_weighted_kernel(const int64_t* __res
   // head so that a workgroup stuck on a 150k-candidate hub does not hold back the rows a static deal would have given it
   __shared__ int sh_li;
   const int n_live  = n_.get();
-  const int n_huge  = lists ? lists[8] : 0;
-  const int count   = lists ? n_huge + lists[7] : n_live;
+  const int n_huge  = lists && !redo ? lists[8] : 0;
+  const int count   = lists ? (redo ? lists[kWeightedRedoCount] : n_huge + lists[7]) : n_live;
   uint32_t* gkeys   = slab + (int64_t)blockIdx.x * slab_len;
   int li            = blockIdx.x;
   while (true) {
   __syncthreads();  // the previous row's readers of the shared counters are done
   if (lists) {
-    if (threadIdx.x == 0) sh_li = atomicAdd(lists + 9, 1);
+    if (threadIdx.x == 0) sh_li = atomicAdd(lists + (redo ? kWeightedRedoHead : 9), 1);
     __syncthreads();
     li = sh_li;
   }
   if (li >= count) break;
-  const int i = lists ? (li < n_huge ? lists[kWeightedListHead + 8 * (int64_t)list_cap + li]
-                                    : lists[kWeightedListHead + 7 * (int64_t)list_cap + (li - n_huge)])
+  const int i = lists ? (redo ? lists[kWeightedListHead + (int64_t)kWeightedRedoList * list_cap + li]
+                         : li < n_huge ? lists[kWeightedListHead + 8 * (int64_t)list_cap + li]
+                                       : lists[kWeightedListHead + 7 * (int64_t)list_cap + (li - n_huge)])
                       : li;
   if (!lists) li += gridDim.x;
   if (i >= n_live) continue;
@@ -735,6 +740,544 @@ __global__ void __launch_bounds__(256) sample_weighted_wave_kernel(const int64_t
   }
 }
 
+// ---- threshold pruning (M <= 32) ---------------------------------------------------------------------------------------
+// The key of a candidate is  K = log1pf(-a) / logf(2) * (1 / w)  with  a = |u| 2^-one_bit  taken from draws 1 and 3 of
+// the candidate's three (the middle draw only matters when the third one is 0, p = 2^-32).  K costs ~130 instructions
+// (log1pf, two IEEE divisions); what decides whether a candidate can be among the M largest keys does not:
+//     |K| >= a / (ln 2 * w)            (log1p(x) <= x),
+// so  magU = a * rcp(w) * log2(e) * (1 - 2^-16)  is a lower bound of |K| AS COMPUTED (the margin covers v_rcp_f32's ulp
+// and the <= 4 ulp of the exact expression).  A row is then sampled in three moves:
+//   1. magU of every candidate (two independent 64-bit multiplies per key: state -> state of draw 3 and -> next key,
+//      A^2 and A^3 jumps with per-stream constants, instead of three dependent steps);
+//   2. the ~M candidates of smallest magU (bitwise search that stops as soon as <= 64 are left) get their EXACT keys, one
+//      per lane; the M-th largest of those, m*, is a key that M candidates reach;
+//   3. every candidate with magU > |m*| is out (|K| >= magU > |m*|: strictly below M others, ties included); the few
+//      left — almost always the same ones — are selected exactly as before (M largest keys, ties to the lowest index,
+//      CSR order).
+// Same result as computing every key.  Rows where this does not apply — a third draw of 0, a weight that is not a
+// positive normal float, more than 64 candidates left — are appended to the redo list and done by the exact workgroup
+// kernel afterwards.
+constexpr uint64_t kPcgA  = Pcg32::kMult;
+constexpr uint64_t kPcgA2 = kPcgA * kPcgA;
+constexpr uint64_t kPcgA3 = kPcgA2 * kPcgA;
+constexpr float kMagScale = 1.4426950408889634f * (1.0f - 1.0f / 65536.0f);
+
+__device__ __forceinline__ uint32_t pcg_output(uint64_t old)
+{
+  const uint32_t x   = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+  const uint32_t rot = (uint32_t)(old >> 59u);
+  return (x >> rot) | (x << ((0u - rot) & 31u));
+}
+
+struct KeyStream {   // a PCG32 stream consumed one A-Res key (three draws) at a time
+  uint64_t s, c2, c3;
+  __device__ __forceinline__ explicit KeyStream(const Pcg32& g)
+    : s(g.state), c2(g.inc * (kPcgA + 1u)), c3(g.inc * (kPcgA2 + kPcgA + 1u))
+  {
+  }
+  // a = |u| 2^-one_bit of the next key; `rare` is raised when the third draw is 0 (the exact path must look at the
+  // second draw, and at further ones if that is 0 too)
+  __device__ __forceinline__ float next_mag(bool& rare)
+  {
+    const uint64_t s0 = s;
+    const uint64_t s2 = s0 * kPcgA2 + c2;
+    s                 = s0 * kPcgA3 + c3;
+    const uint32_t d1 = pcg_output(s0), d3 = pcg_output(s2);
+    rare |= d3 == 0u;
+    // (float)(-(0.5 + 0.5 * (double)f)), f = (d1 >> 8) / 2^24  ==  -(float)(2^24 + (d1 >> 8)) / 2^25 (one RNE rounding of
+    // the same 25-bit integer), then the exact scaling by 2^-clz
+    return ldexpf((float)((d1 >> 8u) + (1u << 24)), -25 - __clz((int)d3));
+  }
+};
+
+__device__ __forceinline__ float ares_key_exact(float a, float w) { return (log1pf(-a) / logf(2.0f)) * (1.0f / w); }
+// weights the bound arithmetic is safe for: positive, normal, far from overflow of a * rcp(w)
+__device__ __forceinline__ bool weight_is_odd(float w) { return ((__float_as_uint(w) >> 23u) - 27u) > 200u; }
+
+__device__ __forceinline__ void redo_append(int* lists, int list_cap, int i)
+{
+  const int p = atomicAdd(lists + kWeightedRedoCount, 1);
+  lists[kWeightedListHead + (int64_t)kWeightedRedoList * list_cap + p] = i;
+}
+
+// M-th largest of one key per lane (0 = no key): decided bits `hi`, their value `prefix`, and how many keys equal to it
+// (in the decided bits) are still to be taken; stops as soon as that is all of them
+__device__ __forceinline__ void lane_select(uint32_t kb, int n_keys, int M, uint32_t& prefix, uint32_t& hi, int& need)
+{
+  prefix    = 0u;
+  hi        = 0u;
+  need      = M;
+  int match = n_keys;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0 && match != need; bit--) {
+    const uint32_t cand = prefix | (1u << bit);
+    hi |= 1u << bit;
+    const int cnt = __popcll(__ballot(kb != 0u && (kb & hi) == cand));
+    if (cnt >= need) {
+      prefix = cand;
+      match  = cnt;
+    } else {
+      need -= cnt;
+      match -= cnt;
+    }
+  }
+}
+
+// One WAVE per row of up to 64 * KMAX candidates, M <= 32 (same size classes and stream layout as
+// sample_weighted_wave_kernel: slot s of lane l = neighbour 64 s + l, drawn from stream l or l + 64).
+template <typename SeedT, typename ColT, typename WeightT, int KMAX>
+__global__ void __launch_bounds__(256) sample_weighted_wave_pruned_kernel(const int64_t* __restrict__ row_ptr,
+                                                                          const ColT* __restrict__ col,
+                                                                          const WeightT* __restrict__ weight,
+                                                                          const SeedT* __restrict__ seeds,
+                                                                          int M,
+                                                                          rng_plan rng,
+                                                                          const int* __restrict__ offsets,
+                                                                          ColT* __restrict__ dst,
+                                                                          int* __restrict__ src_lid,
+                                                                          int64_t* __restrict__ edge_gid,
+                                                                          int* __restrict__ lists,
+                                                                          int list_cap,
+                                                                          int cls,
+                                                                          int force_redo)
+{
+  __shared__ int sh_id[4][64];
+  __shared__ float sh_a[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t li = (int64_t)blockIdx.x * 4 + wv;
+  if (li >= (int64_t)lists[cls]) return;
+  const int i = lists[kWeightedListHead + (int64_t)cls * list_cap + li];
+  uint64_t random_seed;
+  int i_rng;
+  rng.resolve(i, random_seed, i_rng);
+  const int64_t nid   = (int64_t)seeds[i];
+  const int64_t start = row_ptr[nid];
+  const int N         = __builtin_amdgcn_readfirstlane((int)(row_ptr[nid + 1] - start));   // M < N <= 64 * KMAX (list)
+  const int64_t base  = offsets[i];
+  uint32_t k[KMAX];   // magU bits (positive floats order like their bits); ~0 = no candidate
+  float av[KMAX];
+  bool rare = force_redo != 0;
+  {
+    // all weights of the row first, as one batch of unconditional loads (a load under the per-slot branch is waited for
+    // before the next one is issued: KMAX memory latencies in a row, which is what the kernel then takes)
+    float wv[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) wv[s] = (float)weight[start + min(s * 64 + lane, N - 1)];
+    KeyStream ga(stream_generator(random_seed, i_rng, 128, lane));
+    KeyStream gb(stream_generator(random_seed, i_rng, 128, lane + 64));
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) {
+      const int id = s * 64 + lane;
+      k[s]         = ~0u;
+      av[s]        = 0.f;
+      if (s * 64 < N) {   // wave-uniform
+        if (id < N) {
+          const float w = wv[s];
+          const float a = ((s & 1) ? gb : ga).next_mag(rare);
+          rare |= weight_is_odd(w);
+          av[s] = a;
+          k[s]  = __float_as_uint(a * __builtin_amdgcn_rcpf(w) * kMagScale);
+        }
+      }
+    }
+  }
+  if (__ballot(rare) != 0ull) {
+    if (lane == 0) redo_append(lists, list_cap, i);
+    return;
+  }
+  const uint64_t below = (1ull << lane) - 1ull;
+  // (1) the candidates of smallest magU: bitwise search for the M-th smallest, from the highest bit on which two keys
+  // differ, until at most 64 candidates are at or below the decided prefix
+  uint32_t k_or = 0u, k_and = ~0u;
+#pragma unroll
+  for (int s = 0; s < KMAX; s++) {
+    k_or |= k[s] != ~0u ? k[s] : 0u;
+    k_and &= k[s];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    k_or |= __shfl_xor(k_or, d, 64);
+    k_and &= __shfl_xor(k_and, d, 64);
+  }
+  k_or  = __builtin_amdgcn_readfirstlane(k_or);
+  k_and = __builtin_amdgcn_readfirstlane(k_and);
+  const uint32_t differ = k_or ^ k_and;
+  const int top         = differ ? 31 - __clz(differ) : -1;
+  uint32_t hi     = top < 0 ? ~0u : top >= 31 ? 0u : ~((2u << top) - 1u);
+  uint32_t prefix = k_and & hi;
+  int need = M, match = N, under = 0;   // under: candidates strictly below the prefix range
+#pragma unroll 1
+  for (int bit = top; bit >= 0 && match != need && under + match > 64; bit--) {
+    hi |= 1u << bit;
+    int cnt0 = 0;   // candidates in the prefix range with this bit clear
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) cnt0 += __popcll(__ballot((k[s] & hi) == prefix));
+    if (cnt0 >= need) {
+      match = cnt0;
+    } else {
+      need -= cnt0;
+      under += cnt0;
+      match -= cnt0;
+      prefix |= 1u << bit;
+    }
+  }
+  if (under + match > 64) {   // (equal bounds en masse)
+    if (lane == 0) redo_append(lists, list_cap, i);
+    return;
+  }
+  uint32_t bound = prefix | ~hi;   // candidates with magU <= bound: under + match of them, at least M
+  uint32_t kb = 0u, sel_prefix = 0u, sel_hi = 0u;
+  int cid = 0, sel_need = 0, n_sel = 0;
+#pragma unroll 1
+  for (int round = 0; round < 2; round++) {
+    // compaction in CSR order: slot-major == neighbour index order
+    n_sel = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) {
+      const bool in    = k[s] <= bound && k[s] != ~0u;
+      const uint64_t m = __ballot(in);
+      if (in) {
+        const int p  = n_sel + __popcll(m & below);
+        sh_id[wv][p] = s * 64 + lane;
+        sh_a[wv][p]  = av[s];
+      }
+      n_sel += __popcll(m);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its own LDS writes are visible once they are done
+    kb = 0u;
+    if (lane < n_sel) {
+      cid           = sh_id[wv][lane];
+      const float a = sh_a[wv][lane];
+      kb            = key_bits(ares_key_exact(a, (float)weight[start + cid]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next round overwrites the scratch)
+    lane_select(kb, n_sel, M, sel_prefix, sel_hi, sel_need);
+    if (round == 1) break;
+    // (2) |m*|: magnitude of the smallest key the selection takes (the M-th largest, or a tie of it); keys are negative
+    // and key_bits = ~bits, so it is ~(smallest taken key_bits) without the sign.  (3) Who else could reach it?
+    uint32_t kmin = (kb != 0u && (kb & sel_hi) >= sel_prefix) ? kb : ~0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
+    const uint32_t mstar = (~kmin) & 0x7fffffffu;
+    int extra = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) extra += __popcll(__ballot(k[s] > bound && k[s] <= mstar));
+    if (extra == 0) break;   // nobody: the selection over the first set stands
+    int total = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) total += __popcll(__ballot(k[s] <= mstar));   // (~0 is above every magnitude)
+    if (total > 64) {
+      if (lane == 0) redo_append(lists, list_cap, i);
+      return;
+    }
+    bound = mstar;
+  }
+  const uint32_t kd  = kb & sel_hi;
+  const bool eq      = kb != 0u && kd == sel_prefix;
+  const uint64_t meq = __ballot(eq);
+  const bool take    = (kb != 0u && kd > sel_prefix) || (eq && __popcll(meq & below) < sel_need);
+  const uint64_t mt  = __ballot(take);
+  if (take) emit<ColT>(dst, src_lid, edge_gid, base + __popcll(mt & below), col_at<ColT>(col, start + cid), i, start + cid);
+}
+
+// Rows of more than 1024 candidates, M <= 32 (size classes 7 and 8: persistent 512-thread workgroups fed by the queue
+// head, the huge rows first; stream layout B = 128, a stream's four threads take contiguous shares of its key sequence as
+// in sample_weighted_kernel).  The same three moves as the one-wave kernel, streamed: a CANDIDATE LIST in LDS holds
+// (neighbour, a) of everything that can still be among the M largest keys, `thr` is the magnitude of a key that M
+// candidates are known to reach.  Round 0 (one key per thread): every wave finds the M-th smallest bound among its own 64,
+// the smallest of those eight values admits the first candidates, their exact keys give thr.  Then the rest of the row
+// streams by — bound, compare, append the rare survivor — and whenever the list could overflow it is COMPRESSED: exact
+// keys of the listed candidates, the M largest stay, thr tightens.  The last compression emits.  No key slab, no pass
+// over all N keys, ~60 instructions per candidate instead of ~290.
+constexpr int kCandCap     = 4096;   // candidate list entries (id, a, key bits: 48 KB of LDS)
+constexpr int kChunkRounds = 8;      // rounds of 512 candidates between two looks at the list's fill level; the weights
+                                     // of a chunk are requested together (one memory latency per chunk, not per key)
+constexpr int kEqCap       = 64;     // candidates tied with the M-th key that the tie-break can rank
+
+template <typename SeedT, typename ColT, typename WeightT>
+__global__ void __launch_bounds__(512) sample_weighted_block_pruned_kernel(const int64_t* __restrict__ row_ptr,
+                                                                           const ColT* __restrict__ col,
+                                                                           const WeightT* __restrict__ weight,
+                                                                           const SeedT* __restrict__ seeds,
+                                                                           dev_count n_,
+                                                                           int M,
+                                                                           rng_plan rng,
+                                                                           const int* __restrict__ offsets,
+                                                                           ColT* __restrict__ dst,
+                                                                           int* __restrict__ src_lid,
+                                                                           int64_t* __restrict__ edge_gid,
+                                                                           int* __restrict__ lists,
+                                                                           int list_cap,
+                                                                           int force_redo)
+{
+  constexpr int T = 512, B = 128, W = T / 64;
+  __shared__ int c_id[kCandCap];
+  __shared__ float c_a[kCandCap];
+  __shared__ uint32_t c_kb[kCandCap];
+  __shared__ int hist[256];
+  __shared__ int sh_li, sh_count, sh_rare, sh_digit, sh_need, sh_keep, sh_eq;
+  __shared__ uint32_t sh_thr, sh_kmin, sh_sel[2];
+  __shared__ uint32_t sh_wthr[W];
+  __shared__ int keep_id[32], eq_id[kEqCap];
+  __shared__ float keep_a[32], eq_a[kEqCap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_live = n_.get();
+  const int n_huge = lists[8];
+  const int count  = n_huge + lists[7];
+
+  auto append = [&](int id, float a) {
+    const int p = atomicAdd(&sh_count, 1);
+    if (p < kCandCap) {
+      c_id[p] = id;
+      c_a[p]  = a;
+    } else {
+      sh_rare = 1;   // overflow between two looks at the fill level: the row goes to the exact kernel.  (After round 0
+                     // the threshold is a key M of the first 512 candidates reach: a chunk of 4096 more adds ~2 M.)
+    }
+  };
+
+  while (true) {
+    __syncthreads();   // the previous row's readers of the shared words are done
+    if (tid == 0) sh_li = atomicAdd(lists + 9, 1);
+    __syncthreads();
+    const int li = sh_li;
+    if (li >= count) break;
+    const int i = li < n_huge ? lists[kWeightedListHead + 8 * (int64_t)list_cap + li]
+                              : lists[kWeightedListHead + 7 * (int64_t)list_cap + (li - n_huge)];
+    if (i >= n_live) continue;
+    uint64_t random_seed;
+    int i_rng;
+    rng.resolve(i, random_seed, i_rng);
+    const int64_t nid   = (int64_t)seeds[i];
+    const int64_t start = row_ptr[nid];
+    const int N         = (int)(row_ptr[nid + 1] - start);   // > 1024 >= M (list)
+    const int64_t base  = offsets[i];
+    if (tid == 0) {
+      sh_count = 0;
+      sh_rare  = force_redo;
+      sh_thr   = 0x7f800000u;
+    }
+    // COMPRESS: exact keys of the listed candidates, keep the M largest (ties: lowest neighbour index), thr = |smallest
+    // kept key|; `last` emits them in CSR order instead of restarting the list with them
+    auto compress = [&](bool last) {
+      __syncthreads();
+      const int n = min(sh_count, kCandCap);   // >= M
+      for (int e = tid; e < n; e += T) c_kb[e] = key_bits(ares_key_exact(c_a[e], (float)weight[start + c_id[e]]));
+      if (tid == 0) {
+        sh_keep = 0;
+        sh_eq   = 0;
+        sh_kmin = ~0u;
+      }
+      __syncthreads();
+      // the M-th largest key: decided bits `hi`, their value `prefix`, `need` of the keys equal to it (in those bits)
+      uint32_t prefix = 0u, hi = 0u;
+      int need = M;
+      if (n <= 256) {   // one wave, four keys per lane, ballots
+        if (wave == 0) {
+          uint32_t kb[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) kb[j] = lane + 64 * j < n ? c_kb[lane + 64 * j] : 0u;
+          int match = n;
+#pragma unroll 1
+          for (int bit = 31; bit >= 0 && match != need; bit--) {
+            const uint32_t cand = prefix | (1u << bit);
+            hi |= 1u << bit;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += __popcll(__ballot(kb[j] != 0u && (kb[j] & hi) == cand));
+            if (cnt >= need) {
+              prefix = cand;
+              match  = cnt;
+            } else {
+              need -= cnt;
+              match -= cnt;
+            }
+          }
+          if (lane == 0) {
+            sh_sel[0] = prefix;
+            sh_sel[1] = hi;
+            sh_need   = need;
+          }
+        }
+        __syncthreads();
+        prefix = sh_sel[0];
+        hi     = sh_sel[1];
+        need   = sh_need;
+      } else {          // 4-pass radix select over the list
+        for (int shift = 24; shift >= 0; shift -= 8) {
+          for (int h = tid; h < 256; h += T) hist[h] = 0;
+          __syncthreads();
+          for (int e = tid; e < n; e += T) {
+            const uint32_t kk = c_kb[e];
+            if ((kk & hi) == prefix) atomicAdd(&hist[(kk >> shift) & 255], 1);
+          }
+          __syncthreads();
+          if (tid < 64) {
+            const int l  = tid;
+            const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            const int own = h0 + h1 + h2 + h3;
+            int inc = own;
+            for (int off = 1; off < 64; off <<= 1) {
+              int v = __shfl_down(inc, off);
+              if (l + off < 64) inc += v;
+            }
+            int acc = inc - own;
+            if (acc < need && need <= inc) {
+              int d = 4 * l + 3;
+              if (acc + h3 < need) {
+                acc += h3;
+                d = 4 * l + 2;
+                if (acc + h2 < need) {
+                  acc += h2;
+                  d = 4 * l + 1;
+                  if (acc + h1 < need) {
+                    acc += h1;
+                    d = 4 * l;
+                  }
+                }
+              }
+              sh_digit = d;
+              sh_need  = need - acc;
+            }
+          }
+          __syncthreads();
+          prefix |= (uint32_t)sh_digit << shift;
+          hi |= 255u << shift;
+          need = sh_need;
+          __syncthreads();
+        }
+      }
+      // keep what is above the cut; what sits on it goes to the tie list
+      for (int e = tid; e < n; e += T) {
+        const uint32_t kk = c_kb[e], kd = kk & hi;
+        if (kk != 0u && kd > prefix) {
+          const int p = atomicAdd(&sh_keep, 1);
+          keep_id[p]  = c_id[e];
+          keep_a[p]   = c_a[e];
+          atomicMin(&sh_kmin, kk);
+        } else if (kk != 0u && kd == prefix) {
+          const int q = atomicAdd(&sh_eq, 1);
+          if (q < kEqCap) {
+            eq_id[q] = c_id[e];
+            eq_a[q]  = c_a[e];
+            atomicMin(&sh_kmin, kk);   // (an untaken tie has the same decided bits: still a key M candidates reach)
+          } else {
+            sh_rare = 1;
+          }
+        }
+      }
+      __syncthreads();
+      const int eqc = min(sh_eq, kEqCap);
+      if (tid < eqc) {   // the `need` ties of lowest neighbour index
+        int rank = 0;
+        for (int j = 0; j < eqc; j++) rank += eq_id[j] < eq_id[tid] ? 1 : 0;
+        if (rank < need) {
+          const int p = atomicAdd(&sh_keep, 1);
+          keep_id[p]  = eq_id[tid];
+          keep_a[p]   = eq_a[tid];
+        }
+      }
+      __syncthreads();   // sh_keep == M
+      if (last) {
+        if (tid < M && !sh_rare) {
+          const int mine = keep_id[tid];
+          int rank = 0;
+          for (int j = 0; j < M; j++) rank += keep_id[j] < mine ? 1 : 0;
+          emit<ColT>(dst, src_lid, edge_gid, base + rank, col_at<ColT>(col, start + mine), i, start + mine);
+        }
+      } else {
+        if (tid < M) {
+          c_id[tid] = keep_id[tid];
+          c_a[tid]  = keep_a[tid];
+        }
+        if (tid == 0) {
+          sh_count = M;
+          sh_thr   = (~sh_kmin) & 0x7fffffffu;
+        }
+      }
+      __syncthreads();
+    };
+
+    // this thread's keys: m0 .. m1 of stream `sl` (neighbours sl + m * B)
+    const int sl = tid % B, part = tid / B;
+    const int L     = (N - sl + B - 1) / B;
+    const int share = (L + 3) / 4;
+    const int m0 = part * share, m1 = min(L, m0 + share);
+    const int rounds = (((N + B - 1) / B) + 3) / 4;   // the longest share
+    const int64_t sid = (int64_t)i_rng * B + sl;
+    Pcg32 g0 = (sid < (1ll << 31)) ? Pcg32(random_seed, (uint32_t)sid, Pcg32::table_tag{}, 3u * (uint32_t)m0)
+                                   : Pcg32(random_seed, stream_id(i_rng, B, sl));
+    if (sid >= (1ll << 31)) g0.skipahead(3u * (uint64_t)m0);
+    KeyStream g(g0);
+    bool rare = false;
+    auto next = [&](float w, float& a, uint32_t& k) {   // bound of the stream's next key, candidate weight w
+      a = g.next_mag(rare);
+      rare |= weight_is_odd(w);
+      k = __float_as_uint(a * __builtin_amdgcn_rcpf(w) * kMagScale);
+    };
+    auto weight_of = [&](int m) { return (float)weight[start + sl + (int64_t)min(m, m1 - 1) * B]; };   // (m1 >= 1)
+    // ---- round 0 ----
+    const bool has0 = m0 < m1;
+    float a0    = 0.f;
+    uint32_t k0 = ~0u;
+    if (has0) next(weight_of(m0), a0, k0);
+    {
+      // M-th smallest bound of this wave's keys (or +inf when it has fewer than M)
+      const int nvalid = __popcll(__ballot(has0));
+      uint32_t v = 0x7f800000u;
+      if (nvalid >= M) {
+        uint32_t prefix = 0u, hi = 0u;
+        int need = M, match = nvalid;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0 && match != need; bit--) {
+          hi |= 1u << bit;
+          const int cnt0 = __popcll(__ballot(has0 && (k0 & hi) == prefix));
+          if (cnt0 >= need) {
+            match = cnt0;
+          } else {
+            need -= cnt0;
+            match -= cnt0;
+            prefix |= 1u << bit;
+          }
+        }
+        v = prefix | ~hi;
+      }
+      if (lane == 0) sh_wthr[wave] = v;
+    }
+    __syncthreads();
+    uint32_t thr0 = sh_wthr[0];
+#pragma unroll
+    for (int w = 1; w < W; w++) thr0 = min(thr0, sh_wthr[w]);
+    if (has0 && k0 <= thr0) append(m0 * B + sl, a0);
+    compress(false);
+    uint32_t thr = sh_thr;
+    if (has0 && k0 > thr0 && k0 <= thr) append(m0 * B + sl, a0);
+    // ---- the rest of the row ----
+    for (int r = 1; r < rounds;) {
+      // (one decision for the workgroup: a thread that is through the barrier may already be appending again)
+      if (__syncthreads_or(sh_count > kCandCap / 2)) compress(false);
+      thr = sh_thr;
+      float wv[kChunkRounds];
+#pragma unroll
+      for (int c = 0; c < kChunkRounds; c++) wv[c] = weight_of(m0 + r + c);
+#pragma unroll
+      for (int c = 0; c < kChunkRounds; c++) {
+        const int m = m0 + r + c;
+        if (m < m1) {
+          float a;
+          uint32_t k;
+          next(wv[c], a, k);
+          if (k <= thr) append(m * B + sl, a);
+        }
+      }
+      r += kChunkRounds;
+    }
+    if (rare) sh_rare = 1;
+    compress(true);
+    if (tid == 0 && sh_rare) redo_append(lists, list_cap, i);
+  }
+}
+
 // rows that are copied whole (deg <= M, or sample-all): 16 lanes per seed, all seeds
 template <typename SeedT, typename ColT>
 __global__ void __launch_bounds__(256) copy_short_rows_kernel(const int64_t* __restrict__ row_ptr, const ColT* __restrict__ col,
@@ -784,6 +1327,42 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
 // candidates, the persistent workgroup kernel the listed longer ones (long rows first: their tail then drains while the
 // wave kernel fills the GPU); otherwise (256-thread stream layout / sample-all) the workgroup kernel walks all seeds.
 // `slab` holds `blocks` slabs of slab_len keys (slab_len >= the longest row above kLdsKeys candidates).
+// switches of the biased sampler (wgamd_set_weighted_sampling_mode; initial values from the environment, read once)
+inline int& weighted_mode(int which)
+{
+  static int mode[2] = {[] { const char* e = getenv("WGAMD_WEIGHTED_PRUNING"); return e && e[0] == '0' ? 0 : 1; }(),
+                        [] { const char* e = getenv("WGAMD_WEIGHTED_FORCE_REDO"); return e && e[0] == '1' ? 1 : 0; }()};
+  return mode[which];
+}
+inline bool weighted_pruning_off() { return weighted_mode(0) == 0; }
+inline int weighted_force_redo() { return weighted_mode(1); }
+
+// A side stream for the persistent workgroup kernel of the long rows: its last hub row (one workgroup walking 100k+
+// candidates) keeps the kernel alive long after the other workgroups have run dry, and in stream order everything behind
+// it would wait.  Forked off the caller's stream and joined before the redo pass, the one-wave kernels fill the machine
+// under that tail.  One per host thread and device (ranks of a test may be threads sharing a GPU).
+struct side_stream {
+  int device         = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  void ensure()
+  {
+    int dev = 0;
+    WG_HIP_CHECK(hipGetDevice(&dev));
+    if (stream != nullptr && dev == device) return;
+    device = dev;   // (a thread that moves to another device gets fresh objects; the old ones live as long as the process)
+    WG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    WG_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    WG_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  }
+};
+inline side_stream& weighted_side_stream()
+{
+  static thread_local side_stream s;
+  s.ensure();
+  return s;
+}
+
 template <typename SeedT, typename ColT, typename WeightT>
 void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const WeightT* weights, const SeedT* seeds, dev_count n,
                             int M, rng_plan rng, const int* offsets, int* lists, int blocks, uint32_t* slab,
@@ -796,7 +1375,18 @@ void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const Weigh
       row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, nullptr, 0);
     return;
   }
-  if (blocks > 0)
+  const bool pruned = M <= 32 && !weighted_pruning_off();   // threshold pruning: exact keys only for the candidates near the cut
+  bool forked = false;
+  side_stream* side = nullptr;
+  if (blocks > 0 && pruned) {
+    side = &weighted_side_stream();
+    WG_HIP_CHECK(hipEventRecord(side->fork, stream));
+    WG_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    sample_weighted_block_pruned_kernel<SeedT, ColT, WeightT><<<blocks, 512, 0, side->stream>>>(
+      row_ptr, col, weights, seeds, n, M, rng, offsets, dst, lid, gid, lists, cap, weighted_force_redo());
+    WG_HIP_CHECK(hipEventRecord(side->join, side->stream));
+    forked = true;
+  } else if (blocks > 0)
     sample_weighted_kernel<SeedT, ColT, WeightT, 128, 512><<<blocks, 512, 0, stream>>>(
       row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, lists, cap);
   // short rows, one key per lane: 4 / 2 / 1 rows per wave (grids sized for the capacity; waves past the list end exit)
@@ -811,8 +1401,14 @@ void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const Weigh
       row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, 2);
   // 65 .. 1024 candidates: one wave per row, 2 / 4 / 8 / 16 keys per lane in registers
 #define WG_WAVE(KM, CLS)                                                                                               \
-  sample_weighted_wave_kernel<SeedT, ColT, WeightT, KM><<<ceil_div(cap, 4), 256, 0, stream>>>(                           \
-    row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, CLS)
+  do {                                                                                                                 \
+    if (pruned)                                                                                                        \
+      sample_weighted_wave_pruned_kernel<SeedT, ColT, WeightT, KM><<<ceil_div(cap, 4), 256, 0, stream>>>(              \
+        row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, CLS, weighted_force_redo());          \
+    else                                                                                                               \
+      sample_weighted_wave_kernel<SeedT, ColT, WeightT, KM><<<ceil_div(cap, 4), 256, 0, stream>>>(                     \
+        row_ptr, col, weights, seeds, M, rng, offsets, dst, lid, gid, lists, cap, CLS);                                \
+  } while (0)
   if (M < 128) WG_WAVE(2, 3);
   WG_WAVE(4, 4);
   WG_WAVE(8, 5);
@@ -821,6 +1417,12 @@ void weighted_sample_launch(const int64_t* row_ptr, const ColT* col, const Weigh
   // rows copied whole
   copy_short_rows_kernel<SeedT, ColT><<<ceil_div((int64_t)cap * 16, 256), 256, 0, stream>>>(row_ptr, col, seeds, n, M, offsets,
                                                                                           dst, lid, gid);
+  // rows the pruned kernels handed back (a third draw of 0, odd weights, too many candidates near the cut): exact
+  // workgroup kernel, fed from the redo list; a slab exists whenever a row longer than the LDS key array does
+  if (forked) WG_HIP_CHECK(hipStreamWaitEvent(stream, side->join, 0));
+  if (pruned)
+    sample_weighted_kernel<SeedT, ColT, WeightT, 128, 512><<<blocks > 0 ? std::min(blocks, 128) : 64, 512, 0, stream>>>(
+      row_ptr, col, weights, seeds, n, M, rng, offsets, slab, slab_len, dst, lid, gid, lists, cap, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1110,6 +1712,12 @@ void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64,
 }  // namespace wgamd
 
 extern "C" {
+
+void wgamd_set_weighted_sampling_mode(int pruning, int force_redo)
+{
+  if (pruning >= 0) wgamd::weighted_mode(0) = pruning ? 1 : 0;
+  if (force_redo >= 0) wgamd::weighted_mode(1) = force_redo ? 1 : 0;
+}
 
 wholememory_error_code_t wholegraph_csr_unweighted_sample_without_replacement(
   wholememory_tensor_t wm_csr_row_ptr_tensor, wholememory_tensor_t wm_csr_col_ptr_tensor,

@@ -354,6 +354,14 @@ wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const
                                                        const void* w_planes, int N, const float* bias, int relu, float* out,
                                                        int64_t ldo, void* stream);
 
+/* Biased (A-Res) sampling, fan-out <= 32: how wholegraph_csr_weighted_sample_without_replacement and the biased call-group
+ * hop find the M largest keys.  pruning = 1 (default; env WGAMD_WEIGHTED_PRUNING=0 turns it off): a cheap lower bound of
+ * every |key| first, exact keys (log1pf, two divisions) only for the candidates that can still reach the M-th largest one —
+ * same picks as computing every key (csrc/wg_sample.hip, "threshold pruning").  force_redo = 1 (env
+ * WGAMD_WEIGHTED_FORCE_REDO=1) sends every row through the hand-back path the pruned kernels take for a row they cannot
+ * decide: a test switch.  A negative argument leaves that setting as it is. */
+void wgamd_set_weighted_sampling_mode(int pruning, int force_redo);
+
 /* Uniform neighbour sampling WITH replacement (cugraph_pyg `replace=True`; the reference forwards it to libcugraph,
  * sampler/distributed_sampler.py:775-792,864 — not in its tree, so the draw layout is this library's and is pinned by
  * the CPU restatement of the parity tests).  Same tensors, contexts and error behaviour as wholegraph_csr_unweighted_sample_without_replacement

@@ -177,3 +177,45 @@ def test_weighted_long_rows_all_kernel_paths(oracle_mod, hiplib, M):
         assert np.all(np.diff(a) > 0) and a.size == min(M, degs[seeds[i]])
         diff += len(set(a) ^ set(b))       # device libm vs glibc may swap one near-tied pair at the threshold
     assert diff <= 4, diff
+
+
+@pytest.mark.parametrize("M", [1, 10, 32])
+@pytest.mark.parametrize("weights", ["uniform", "heavy_tail", "constant", "some_zero", "some_negative", "tiny_and_huge"])
+def test_weighted_pruning_changes_nothing(hiplib, M, weights):
+    """Threshold pruning (exact keys only for the candidates that can still reach the M-th largest key, csrc/wg_sample.hip)
+    must return exactly the picks of the every-key kernels, and so must the hand-back path (rows a pruned kernel cannot
+    decide go to the exact workgroup kernel through the redo list): same device key function in all three, so the
+    comparison is bit for bit."""
+    from wholegraph_amd import _lib
+    degs = np.array([0, 3, M, M + 1, 40, 64, 65, 100, 128, 129, 255, 256, 257, 511, 512, 513, 900, 1024, 1025, 2000, 5000,
+                     12288, 12289, 20000, 70000], np.int64)
+    rng = np.random.default_rng(100 * M + len(weights))
+    row_ptr = np.zeros(len(degs) + 1, np.int64)
+    row_ptr[1:] = np.cumsum(degs)
+    col = rng.integers(0, len(degs), row_ptr[-1])
+    w = (rng.random(col.size) + 0.01).astype(np.float32)
+    if weights == "heavy_tail":
+        w = rng.pareto(0.7, col.size).astype(np.float32) + 1e-3
+    elif weights == "constant":
+        w[:] = 0.5
+    elif weights == "some_zero":
+        w[rng.random(col.size) < 0.3] = 0.0
+    elif weights == "some_negative":
+        w[rng.random(col.size) < 0.01] *= -1.0
+    elif weights == "tiny_and_huge":
+        w[rng.random(col.size) < 0.2] = 1e-36
+        w[rng.random(col.size) < 0.2] = 1e30
+    seeds = np.concatenate([np.arange(len(degs)), rng.integers(0, len(degs), 60)]).astype(np.int64)
+    lib = _lib.lib()
+    results = []
+    try:
+        for pruning, force_redo in ((0, 0), (1, 0), (1, 1)):
+            lib.wgamd_set_weighted_sampling_mode(pruning, force_redo)
+            results.append(_weighted(row_ptr, col, w, seeds, M, 321))
+    finally:
+        lib.wgamd_set_weighted_sampling_mode(1, 0)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert np.array_equal(a, b)
+    off, dst, lid, gid = results[0]
+    assert np.array_equal(np.diff(off), np.minimum(degs[seeds], M))
