@@ -107,6 +107,14 @@ __host__ __device__ constexpr int row_stride_dw(int F)
   return (sd / 4) % 2 == 0 ? sd + 4 : sd;   // 4 * odd
 }
 
+// HALF mode (two 64-row tiles of [mean | self] do not fit the LDS: F > 148): the two LDS buffers hold the MEAN half and the
+// SELF half of ONE 64-row tile, F floats per row each; a row stride of 4 * odd >= F keeps ds_read_b128 conflict-free
+__host__ __device__ constexpr int row_stride_half_dw(int F)
+{
+  int sd = (F + 3) / 4 * 4;
+  return (sd / 4) % 2 == 0 ? sd + 4 : sd;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // producer side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -127,7 +135,7 @@ struct meta_t {
   off_t self[IT];  // byte offset of the self row
 };
 
-template <typename IdT, int LG, int TR, bool OFF32>
+template <typename IdT, int LG, int TR, bool OFF32, bool HALF = false>
 struct producer {
   using off_t                         = typename std::conditional<OFF32, uint32_t, int64_t>::type;
   static constexpr int kGroupsPerWave = 64 / LG;
@@ -200,8 +208,9 @@ struct producer {
         const uint32_t off = (uint32_t)__shfl((int)m.src[it], gbase | (k & (LG - 1)), 64);
         v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, k < m.d[it] ? off + f0c * 4 : a.x_bytes, 0, 0));
       }
-      v[kNb] = __builtin_bit_cast(
-        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, m.d[it] >= 0 ? (uint32_t)m.self[it] + f0c * 4 : a.x_bytes, 0, 0));
+      if constexpr (!HALF)
+        v[kNb] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, m.d[it] >= 0 ? (uint32_t)m.self[it] + f0c * 4 : a.x_bytes, 0, 0));
     } else {
       const char* xb = reinterpret_cast<const char*>(a.x);
 #pragma unroll
@@ -213,7 +222,30 @@ struct producer {
         off                = k < m.d[it] ? off : (int64_t)0;   // slots past the degree read row 0 (L1-resident), masked below
         v[k]               = *reinterpret_cast<const f32x4*>(xb + off + f0c * 4);
       }
-      v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? (int64_t)m.self[it] : (int64_t)0) + f0c * 4);
+      if constexpr (!HALF)
+        v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? (int64_t)m.self[it] : (int64_t)0) + f0c * 4);
+    }
+  }
+  // HALF mode: the self rows of one 32-row sub-tile (offsets saved when its metadata was current; bit `it` of `valid` =
+  // the row exists), requested together, into the SELF buffer
+  __device__ __forceinline__ void self_rows(const off_t (&so)[IT], uint32_t valid, float* self_lds) const
+  {
+    f32x4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const bool ok = (valid >> it) & 1u;
+      if constexpr (OFF32) {
+        v[it] = __builtin_bit_cast(f32x4,
+                                   __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (uint32_t)so[it] + f0c * 4 : a.x_bytes, 0, 0));
+      } else {
+        v[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + (ok ? (int64_t)so[it] : (int64_t)0) + f0c * 4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      f32x4 self = v[it];
+      if constexpr (!OFF32) self = ((valid >> it) & 1u) ? self : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live) *reinterpret_cast<f32x4*>(self_lds + (group + it * kGroups) * a.SD + f0) = self;
     }
   }
   // sum row `it` from its ring slot (CSR order) and store [mean | self] as fp32
@@ -229,10 +261,12 @@ struct producer {
     if (a.mean && deg > 0) acc *= __frcp_rn((float)deg);   // (rows longer than the window are redone by long_rows())
     if (live) {
       float* prow = tile_lds + (group + it * kGroups) * a.SD;
-      f32x4 self  = v[kNb];
-      if constexpr (!OFF32) self = deg >= 0 ? self : f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(prow + f0)       = acc;
-      *reinterpret_cast<f32x4*>(prow + a.F + f0) = self;
+      *reinterpret_cast<f32x4*>(prow + f0) = acc;
+      if constexpr (!HALF) {
+        f32x4 self = v[kNb];
+        if constexpr (!OFF32) self = deg >= 0 ? self : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(prow + a.F + f0) = self;
+      }
     }
   }
   // rows longer than the prefetched window (rare: deg > 10): the whole sum again, in CSR order, chunk by chunk
@@ -416,6 +450,35 @@ __device__ __forceinline__ void consume_tile(const mfma_args& a, int64_t tile, c
   epilogue<RT>(a, c, tile * TR, cw, lane, scratch);
 }
 
+// ---- HALF mode: k-steps [ks0, ks1) of the tile from ONE buffer (column 0 of the buffer = k-step ks0); b0 holds the weight
+// fragments of k-step ks0 on entry and those of the NEXT half's first k-step on return (requested before the barrier) -----
+template <int RT>
+__device__ __forceinline__ void consume_half(const mfma_args& a, f32x16 (&c)[RT][2], const float* buf, int ks0, int ks1,
+                                             int ks_next, int cw, int lane, bfrag_t& b0)
+{
+  const int lm = lane & 31, lh = lane >> 5;
+  const float* a_lane      = buf + lm * a.SD + lh * 8 - ks0 * 16;
+  const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
+  const uint32_t* b_lane   = a.w_planes + ((int64_t)(cw * 64 + lm)) * 8 + lh * 4;
+  bfrag_t b1;
+  araw_t<RT> raw;
+  afrag_t<RT> fa;
+  for (int ks = ks0; ks < ks1; ks += 2) {
+    load_a_raw<RT>(raw, a_lane, a.SD, ks);
+    load_b(b1, b_lane, b_plane_dw, a.N, ks + 1 < ks1 ? ks + 1 : ks_next);
+    split_a<RT>(raw, fa);
+    mma_frags<RT>(c, fa, b0);
+    if (ks + 1 < ks1) {
+      load_a_raw<RT>(raw, a_lane, a.SD, ks + 1);
+      load_b(b0, b_lane, b_plane_dw, a.N, ks + 2 < ks1 ? ks + 2 : ks_next);
+      split_a<RT>(raw, fa);
+      mma_frags<RT>(c, fa, b1);
+    } else {
+      b0 = b1;
+    }
+  }
+}
+
 // ---- compile-time feature width (the BASELINE shapes): fully unrolled, weight fragments kPD k-steps ahead ---------------
 // The weight is the same for every tile, so its fragment stream simply continues across tiles: the last kPD k-steps of a
 // tile request fragments 0 .. kPD-1 of the NEXT tile into dedicated "head" registers, i.e. before this tile's output stores
@@ -485,10 +548,11 @@ struct static_consumer {
 // ---------------------------------------------------------------------------------------------------------------------
 // CW = N / 64 consumer waves + 4 producer waves; TR = rows per tile; FC = compile-time feature width (0 = runtime a.F)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename IdT, int LG, int TR, int CW, bool OFF32, int FC>
+template <typename IdT, int LG, int TR, int CW, bool OFF32, int FC, bool HALF = false>
 __global__ void __launch_bounds__((CW + kProducerWaves) * 64)
 sage_layer_mfma_kernel(mfma_args a)
 {
+  static_assert(!HALF || FC == 0, "the half-tile mode runs the runtime-shape consumer");
   // [2 tiles][TR][SD] fp32 + 16 floats of slack + [CW][8][64] epilogue scratch + role keys
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile_dw = TR * a.SD;
@@ -520,7 +584,98 @@ sage_layer_mfma_kernel(mfma_args a)
     if (a.stamps && blockIdx.x == 0 && lane == 0 && n < 64) a.stamps[(n * 8 + wave) * 2 + which] = __builtin_readcyclecounter();
   };
 
-  if (wave >= CW) {
+  if constexpr (HALF) {
+    // Two steps per tile.  Step 2n: the producers sum the MEAN half of tile n into buffer 0 while the consumers multiply
+    // the SELF half of tile n-1 from buffer 1 and store it.  Step 2n+1: the producers copy the SELF rows of tile n into
+    // buffer 1 (and request the first rows of tile n+1) while the consumers multiply the MEAN half of tile n.  The
+    // accumulators of a tile live across the barrier between its halves; the weight stream continues across both.
+    float* buf0   = lds;
+    float* buf1   = lds + tile_dw;
+    const int KSh = a.KS / 2;   // F % 16 == 0: k-steps [0, KSh) = mean half (W_l rows), [KSh, KS) = self half (W_r rows)
+    if (wave >= CW) {
+      // the 64-row tile is produced as two 32-row SUB-TILES (sub-tile 2 t + h = rows 32 (2 t + h) ...): eight rows of
+      // metadata per lane group in registers instead of sixteen (which spilled 120 VGPRs); the metadata pipeline simply
+      // runs across the sub-tiles, and only the self-row offsets of both are kept for the second step
+      using P     = producer<IdT, LG, 32, OFF32, true>;
+      using off_t = typename P::off_t;
+      constexpr int IT = P::IT, kNb = P::kNb, kDepth = P::kDepth;
+      static_assert(TR == 64, "two 32-row sub-tiles per tile");
+      P p(a, wave - CW, lane);
+      bounds_t<IT> b_next;
+      ids_t<IT> i_next;
+      meta_t<IT, off_t> cur;
+      f32x4 buf[kDepth][kNb + 1];
+      off_t self_off[2][IT];
+      uint32_t self_ok[2] = {0u, 0u};
+      auto sub_of = [&](int64_t j) { return 2 * tile_of(j >> 1) + (j & 1); };
+      p.load_bounds(sub_of(0), b_next);
+      p.load_ids(sub_of(0), b_next, i_next);
+      p.finish(i_next, cur);
+#pragma unroll
+      for (int it = 0; it < kDepth - 1; it++) p.issue(cur, it, buf[it]);
+      constexpr int kHalf = IT / 2;
+      for (int64_t n = 0; n <= mine; n++) {
+        if (n < mine && !(a.debug & 2)) {
+#pragma unroll
+          for (int sub = 0; sub < 2; sub++) {
+            const int64_t j = 2 * n + sub;
+            float* rows_lds = buf0 + sub * 32 * a.SD;
+            p.load_bounds(sub_of(j + 1), b_next);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+              if (it == kHalf) p.load_ids(sub_of(j + 1), b_next, i_next);
+              if (it + kDepth - 1 < IT) p.issue(cur, it + kDepth - 1, buf[(it + kDepth - 1) % kDepth]);
+              p.reduce_store(cur, it, buf[it % kDepth], rows_lds);
+            }
+            p.long_rows(sub_of(j), cur, rows_lds);
+            self_ok[sub] = 0u;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+              self_off[sub][it] = cur.self[it];
+              self_ok[sub] |= cur.d[it] >= 0 ? 1u << it : 0u;
+            }
+            p.finish(i_next, cur);
+            if (j + 1 < 2 * mine) {
+#pragma unroll
+              for (int it = 0; it < kDepth - 1; it++) p.issue(cur, it, buf[it]);
+            }
+          }
+        }
+        lds_barrier();
+        if (n < mine && !(a.debug & 2)) {
+#pragma unroll
+          for (int sub = 0; sub < 2; sub++) p.self_rows(self_off[sub], self_ok[sub], buf1 + sub * 32 * a.SD);
+        }
+        lds_barrier();
+      }
+    } else {
+      constexpr int RT = TR / 32;
+      float* scratch = lds + 2 * tile_dw + 16 + wave * kScratchDw;
+      f32x16 c[RT][2];
+      bfrag_t b0;
+      {
+        const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
+        load_b(b0, a.w_planes + ((int64_t)(wave * 64 + (lane & 31))) * 8 + (lane >> 5) * 4, b_plane_dw, a.N, 0);
+      }
+      for (int64_t n = 0; n <= mine; n++) {
+        if (n >= 1 && !(a.debug & 1)) {
+          consume_half<RT>(a, c, buf1, KSh, a.KS, 0, wave, lane, b0);
+          epilogue<RT>(a, c, tile_of(n - 1) * TR, wave, lane, scratch);
+        }
+        lds_barrier();
+        if (n < mine && !(a.debug & 1)) {
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+              for (int i = 0; i < 16; i++) c[rt][ct][i] = 0.f;
+          consume_half<RT>(a, c, buf0, 0, KSh, KSh, wave, lane, b0);
+        }
+        lds_barrier();
+      }
+    }
+  } else if (wave >= CW) {
     if (a.debug & 16) __builtin_amdgcn_s_setprio(3);
     using P     = producer<IdT, LG, TR, OFF32>;
     using off_t = typename P::off_t;
@@ -624,6 +779,33 @@ __global__ void split_weight_kernel(const float* __restrict__ w_t, int64_t ldw, 
 
 constexpr size_t kLdsBudget = 160 * 1024;
 __host__ inline size_t lds_bytes(int F, int TR) { return (size_t)(2 * TR * row_stride_dw(F) + 16 + 4 * kScratchDw + 16) * 4; }
+__host__ inline size_t lds_bytes_half(int F) { return (size_t)(2 * 64 * row_stride_half_dw(F) + 16 + 4 * kScratchDw + 16) * 4; }
+// 64-row tiles in two halves: when two whole 64-row tiles do not fit but the halves of one do, and the halves are whole
+// k-steps (WGAMD_SAGE_HALF_TILES=0 keeps the 32-row tiles)
+__host__ inline bool use_half_tiles(int F)
+{
+  static const bool off = [] { const char* e = getenv("WGAMD_SAGE_HALF_TILES"); return e && e[0] == '0'; }();
+  return !off && F % 16 == 0 && lds_bytes(F, 64) > kLdsBudget && lds_bytes_half(F) <= kLdsBudget;
+}
+
+template <typename IdT, int LG, int CW>
+void launch_half(mfma_args a, hipStream_t st)
+{
+  int dev = 0, cus = 256;
+  WG_HIP_CHECK(hipGetDevice(&dev));
+  WG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  a.SD                  = row_stride_half_dw(a.F);
+  const int64_t n_tiles = (a.n_rows + 63) / 64;
+  const size_t lds      = lds_bytes_half(a.F);
+  const int grid        = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus));
+  auto go               = [&](auto kern) {
+    WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<grid, (CW + kProducerWaves) * 64, lds, st>>>(a);
+    WG_HIP_CHECK(hipGetLastError());
+  };
+  if (a.x_bytes != 0) go(sage_layer_mfma_kernel<IdT, LG, 64, CW, true, 0, true>);
+  else go(sage_layer_mfma_kernel<IdT, LG, 64, CW, false, 0, true>);
+}
 
 template <typename IdT, int LG, int TR, int CW, int FC = 0>
 void launch(const mfma_args& a, hipStream_t st)
@@ -674,7 +856,13 @@ void launch_tr(const mfma_args& a, hipStream_t st)
     launch_cw<IdT, LG, 64>(a, st);
   } else {
     if (lds_bytes(a.F, 64) <= kLdsBudget) launch_cw<IdT, LG, 64>(a, st);
-    else launch_cw<IdT, LG, 32>(a, st);
+    else if (use_half_tiles(a.F)) {
+      switch (a.N / 64) {
+        case 1: launch_half<IdT, LG, 1>(a, st); break;
+        case 2: launch_half<IdT, LG, 2>(a, st); break;
+        default: launch_half<IdT, LG, 4>(a, st); break;
+      }
+    } else launch_cw<IdT, LG, 32>(a, st);
   }
 }
 
