@@ -230,7 +230,9 @@ class SagePipeline:
                 fetch = j == 0 and fused_fetch
                 h = stage(("fetch+" if fetch else "") + "sage_layer%d(fused)" % (j + 1), lambda: nn.sage_layer_fused_forward(
                     ptr, nbr, self.feat.local_tensor if fetch else h, rows, self.w_t[j], self.bias[j], relu=j < L - 1,
-                    mean=True, src_ids=n_id if fetch else None, out=self.rows_buffer("h%d" % j, n_dst, self.dims[j + 1])))
+                    mean=True, src_ids=n_id if fetch else None,
+                    # (row stride = the width the kernel runs at: a 47-class head is computed as 64 zero-padded columns)
+                    out=self.rows_buffer("h%d" % j, n_dst, -(-self.dims[j + 1] // 64) * 64)[:, :self.dims[j + 1]]))
                 continue
             if j == 0 and fused_fetch:
                 cat = stage("fetch+" + spmm_label(0), lambda: nn.sage_aggregate_fetch_forward(

@@ -86,24 +86,51 @@ def set_sage_layer_fused_precision(mode: str) -> None:
 
 def _pick_precision(F_: int, N: int, precision) -> str:
     mode = precision or _FUSED_PRECISION
-    if mode == "bf16x3" and not L.lib().wgamd_sage_layer_bf16x3_supported(F_, N):
+    if mode == "bf16x3" and not L.lib().wgamd_sage_layer_bf16x3_supported(F_, _padded_width(N)):
         mode = "f32"
     return mode
 
 
+def _padded_width(N: int) -> int:
+    """Output width the one-kernel layer runs at: its consumer waves own 64 columns each, so N is rounded up to 64, 128 or
+    256 with zero weight columns (a 47-class head runs as N = 64; the caller sees the first N columns)."""
+    return 64 if N <= 64 else 128 if N <= 128 else 256
+
+
 def sage_layer_fused_supported(F_: int, N: int) -> bool:
-    """Shapes the one-kernel SAGE layer is built for (include/wgamd_ext.h)."""
-    return F_ % 4 == 0 and F_ <= 256 and N in (64, 128, 256)
+    """Shapes the one-kernel SAGE layer is built for (include/wgamd_ext.h); N is padded to 64 / 128 / 256 on the way in."""
+    return F_ % 4 == 0 and 0 < F_ <= 256 and 0 < N <= 256
 
 
 def sage_layer_fused_preferred(F_: int, N: int) -> bool:
     """Shapes where the one-kernel layer beats aggregate kernel + library GEMM: two operand tiles must fit the 160 KB of
     LDS so that a workgroup can gather one tile while it multiplies the other."""
-    if not sage_layer_fused_supported(F_, N):
+    if not sage_layer_fused_supported(F_, N) or N != _padded_width(N):
+        # (a padded head — the 47-class layer of the products model runs as N = 64 — is supported but not preferred: one
+        #  consumer wave per CU and a handful of tiles per CU, measured 0.46 ms against 0.20 ms for aggregate + GEMM)
         return False
-    if _FUSED_PRECISION == "bf16x3" and L.lib().wgamd_sage_layer_bf16x3_supported(F_, N):
+    if _FUSED_PRECISION == "bf16x3" and L.lib().wgamd_sage_layer_bf16x3_supported(F_, _padded_width(N)):
         return True
     return F_ <= 152
+
+
+def _padded_head(w_t: torch.Tensor, bias, Np: int):
+    """``w_t`` [2F, N] and ``bias`` [N] with zero columns up to Np, cached on the weight tensor (version-checked)."""
+    hit = getattr(w_t, "_wgamd_padded", None)
+    key = (w_t._version, w_t.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), Np)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    wp = torch.zeros((w_t.shape[0], Np), dtype=w_t.dtype, device=w_t.device)
+    wp[:, :w_t.shape[1]] = w_t
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(Np, dtype=bias.dtype, device=bias.device)
+        bp[:bias.shape[0]] = bias
+    try:
+        w_t._wgamd_padded = (key, wp, bp)
+    except AttributeError:
+        pass
+    return wp, bp
 
 
 def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
@@ -135,9 +162,17 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
     assert self_rows.dtype == torch.int64 and self_rows.is_contiguous()
     n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], w_t.shape[1]
+    Np = _padded_width(N) if sage_layer_fused_supported(F_, N) else N
+    if Np != N:
+        # zero weight columns / bias entries up to the width the kernel runs at (cached on the weight like its planes); the
+        # kernel then writes Np columns per row: `out` must leave room for them in its row stride
+        w_t, bias = _padded_head(w_t, bias, Np)
+        if out is not None and out.stride(0) < Np:
+            out = None
     if out is None:
-        out = torch.empty((n_rows, N), dtype=torch.float32, device=x.device)
+        out = torch.empty((n_rows, Np), dtype=torch.float32, device=x.device)[:, :N]
     assert out.shape == (n_rows, N) and out.dtype == torch.float32 and out.stride(1) == 1
+    N = Np
     ids_ptr, ids_dt = None, 0
     if src_ids is not None:
         assert src_ids.is_contiguous()

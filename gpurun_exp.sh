@@ -1,6 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_aggregate.py -x -q -k fused 2>&1 | tail -3
-for D in 0 1 2; do
-echo "products F=100 debug=$D: $(WGAMD_SAGE_DEBUG=$D python tools/bench_sage_fused.py 2>&1 | grep -v amdgpu.ids | sed 's/.*gemm = //')"
-echo "papers F=128 debug=$D: $(WGAMD_SAGE_DEBUG=$D F=128 python tools/bench_sage_fused.py 2>&1 | grep -v amdgpu.ids | sed 's/.*gemm = //')"
-done
+timeout 900 python -m pytest tests/test_gpu_aggregate.py -x -q -k "fused" 2>&1 | tail -4
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms_per_call_group'])"

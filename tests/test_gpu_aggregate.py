@@ -147,7 +147,8 @@ def test_sage_aggregate_fused_feature_fetch(oracle_mod, hiplib):
 
 # (F > 148 with F % 16 == 0: the bf16x3 kernel runs 64-row tiles in two halves; 152 and 204: its 32-row tiles)
 @pytest.mark.parametrize("F,N", [(100, 256), (128, 256), (64, 64), (256, 128), (4, 128), (36, 256), (208, 128), (104, 64),
-                                 (256, 256), (256, 64), (176, 256), (160, 64), (152, 128), (204, 256)])
+                                 (256, 256), (256, 64), (176, 256), (160, 64), (152, 128), (204, 256),
+                                 (256, 47), (100, 172), (128, 1)])   # widths padded to 64 / 256 / 64 on the way in
 @pytest.mark.parametrize("with_ids", [False, True])
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, with_ids, precision):
@@ -191,9 +192,10 @@ def test_sage_layer_fused_rejects_unsupported_shapes(hiplib):
     rp = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
     col = torch.zeros(1, dtype=torch.int32, device="cuda")
     x = torch.zeros((1, 100), device="cuda")
-    with pytest.raises(wg.WholeMemoryError):       # N = 47 is not a multiple of 64
-        nn.sage_layer_fused_forward(rp, col, x, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros((200, 47), device="cuda"))
-    assert not nn.sage_layer_fused_supported(100, 47) and not nn.sage_layer_fused_supported(102, 256)
+    with pytest.raises(wg.WholeMemoryError):       # more than 256 output columns
+        nn.sage_layer_fused_forward(rp, col, x, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros((200, 320), device="cuda"))
+    assert not nn.sage_layer_fused_supported(100, 320) and not nn.sage_layer_fused_supported(102, 256)
+    assert nn.sage_layer_fused_supported(100, 47)  # a 47-class head runs as 64 zero-padded columns
 
 
 def test_sage_layer_fused_64bit_offset_path_and_tiny_inputs(hiplib):
