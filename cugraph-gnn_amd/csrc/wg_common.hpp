@@ -240,9 +240,12 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
 // uniform sampling of `n` targets (n.host = capacity): cnt/offsets have n.host+1 entries
 void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
                             dev_count n, int M, rng_plan random_seed, const int* offsets, void* dst, int* src_lid,
-                            int64_t* edge_gid, hipStream_t stream);
+                            int64_t* edge_gid, hipStream_t stream,
+                            const int64_t* row_start = nullptr, const int* row_deg = nullptr);
+// row_start / row_deg (nullable): first CSR slot and degree of every live seed, written next to the counts — the sampling
+// kernel then reads them by seed index (coalesced) instead of chasing seeds -> row_ptr again
 void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
-                          int* big_deg, hipStream_t stream);
+                          int* big_deg, hipStream_t stream, int64_t* row_start = nullptr, int* row_deg = nullptr);
 // biased (A-Res) sampling, 0 < M <= 256: `big_list` (weighted_list_ints(n.host) ints) receives the row lists by size class;
 // `slab` = kWeightedBlocks slabs of slab_len keys for the rows longer than kWeightedLdsKeys candidates
 // (slab_len >= the longest such row, e.g. the graph's maximum degree).  Weights FLOAT or DOUBLE.

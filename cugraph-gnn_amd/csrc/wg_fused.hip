@@ -18,7 +18,7 @@ namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct hop_workspace {
-  size_t cnt, scan_tmp, nbr, keys, minpos, slot_of, rank, big_list, slab, total;
+  size_t cnt, scan_tmp, nbr, keys, minpos, slot_of, rank, big_list, slab, row_start, row_deg, total;
   int64_t slots, slab_len;
 };
 
@@ -41,6 +41,8 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
   w.minpos       = take(sizeof(int) * (size_t)w.slots);
   w.slot_of      = take(sizeof(int) * (size_t)(target_cap + edge_cap));
   w.rank         = take(sizeof(int) * (size_t)(edge_cap + 1));
+  w.row_start    = take(sizeof(int64_t) * (size_t)target_cap);   // first CSR slot / degree of every sampled row (count -> sample)
+  w.row_deg      = take(sizeof(int) * (size_t)target_cap);
   if (max_row_len > 0) {
     w.slab_len = max_row_len > kWeightedLdsKeys ? max_row_len : 1;
     w.big_list = take(sizeof(int) * (size_t)weighted_list_ints(target_cap));
@@ -118,10 +120,12 @@ void run_hop(hop_args a)
                             big_list, reinterpret_cast<uint32_t*>(base + w.slab), w.slab_len, nbr, a.center_row, a.edge_gid,
                             st);
   } else {
-    sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st);
+    int64_t* row_start = reinterpret_cast<int64_t*>(base + w.row_start);
+    int* row_deg       = reinterpret_cast<int*>(base + w.row_deg);
+    sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st, row_start, row_deg);
     exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
     uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
-                           a.edge_gid, st);
+                           a.edge_gid, st, row_start, row_deg);
   }
   dev_count E{(int)a.edge_cap, a.offsets + s_cap};
   batch_view bv   = a.bv;

@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
                                                            int* __restrict__ big_deg /*nullable*/,
                                                            int* __restrict__ lists = nullptr /*biased hop: see wg_common.hpp*/,
                                                            int list_cap            = 0,
-                                                           int scratch_threshold   = 0)
+                                                           int scratch_threshold   = 0,
+                                                           int64_t* __restrict__ row_start = nullptr,
+                                                           int* __restrict__ row_deg       = nullptr)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_live = n_.get();
@@ -96,9 +98,14 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
         if (big_deg) big_deg[i] = 0;
       }
     } else {
-      int64_t nid = (int64_t)seeds[i];
-      deg         = (int)(row_ptr[nid + 1] - row_ptr[nid]);
-      cnt[i]      = (M > 0 && deg > M) ? M : deg;
+      int64_t nid         = (int64_t)seeds[i];
+      const int64_t first = row_ptr[nid];
+      deg                 = (int)(row_ptr[nid + 1] - first);
+      cnt[i]              = (M > 0 && deg > M) ? M : deg;
+      if (row_start) {   // what the sampling kernel needs of this row, by seed index
+        row_start[i] = first;
+        row_deg[i]   = deg;
+      }
       if (big_deg) big_deg[i] = 0;
       if (lists != nullptr && M > 0 && deg > M) {
         cls = deg <= 16 ? 0 : deg <= 32 ? 1 : deg <= 64 ? 2 : deg <= 128 ? 3 : deg <= 256 ? 4 : deg <= 512 ? 5
@@ -161,7 +168,9 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
                                                                       const int* __restrict__ offsets,
                                                                       ColT* __restrict__ dst,
                                                                       int* __restrict__ src_lid,
-                                                                      int64_t* __restrict__ edge_gid)
+                                                                      int64_t* __restrict__ edge_gid,
+                                                                      const int64_t* __restrict__ row_start,
+                                                                      const int* __restrict__ row_deg)
 {
   const int n    = n_.get();
   const int lane = threadIdx.x & 63;
@@ -189,10 +198,15 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   int64_t start = 0;
   int N = 0, base = 0;
   if (i < n) {
-    int64_t nid = (int64_t)seeds[i];
-    start       = row_ptr[nid];
-    N           = (int)(row_ptr[nid + 1] - start);
-    base        = offsets[i];
+    if (row_start) {   // written by the count kernel: one coalesced read instead of the seeds -> row_ptr chain
+      start = row_start[i];
+      N     = row_deg[i];
+    } else {
+      int64_t nid = (int64_t)seeds[i];
+      start       = row_ptr[nid];
+      N           = (int)(row_ptr[nid + 1] - start);
+    }
+    base = offsets[i];
   }
   const bool pick = N > M;  // uniform inside a half
   // Is any half of this wave sampling?  (wave-uniform branch around the resolve loop)
@@ -1298,7 +1312,8 @@ __global__ void __launch_bounds__(256) copy_short_rows_kernel(const int64_t* __r
 
 template <typename SeedT, typename ColT>
 void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds, dev_count n, int M,
-                    rng_plan random_seed, const int* offsets, ColT* dst, int* lid, int64_t* gid, hipStream_t stream)
+                    rng_plan random_seed, const int* offsets, ColT* dst, int* lid, int64_t* gid, hipStream_t stream,
+                    const int64_t* row_start = nullptr, const int* row_deg = nullptr)
 {
   const int cap = n.host;
   if (cap <= 0) return;
@@ -1308,10 +1323,10 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
                                                                      random_seed, offsets, dst, lid, gid);
   } else if (M <= 16) {
     sample_uniform_halfwave_kernel<SeedT, ColT, 16><<<ceil_div((int64_t)cap * 16, 256), 256, 0, stream>>>(
-      row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid);
+      row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg);
   } else if (M <= 32) {
     sample_uniform_halfwave_kernel<SeedT, ColT, 32><<<ceil_div((int64_t)cap * 32, 256), 256, 0, stream>>>(
-      row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid);
+      row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg);
   } else if (M <= 1024) {
     const int B = ref_block_threads(M);
     sample_uniform_block_kernel<SeedT, ColT><<<cap, B < 64 ? 64 : B, 0, stream>>>(
@@ -1649,15 +1664,15 @@ void dispatch(const sample_args& a, bool weighted)
 }  // namespace
 
 void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
-                          int* big_deg, hipStream_t stream)
+                          int* big_deg, hipStream_t stream, int64_t* row_start, int* row_deg)
 {
   if (n.host <= 0) return;
   if (seeds64)
     sample_count_kernel<int64_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
-      row_ptr, static_cast<const int64_t*>(seeds), n, M, cnt, big_deg);
+      row_ptr, static_cast<const int64_t*>(seeds), n, M, cnt, big_deg, nullptr, 0, 0, row_start, row_deg);
   else
     sample_count_kernel<int32_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
-      row_ptr, static_cast<const int32_t*>(seeds), n, M, cnt, big_deg);
+      row_ptr, static_cast<const int32_t*>(seeds), n, M, cnt, big_deg, nullptr, 0, 0, row_start, row_deg);
   WG_HIP_CHECK(hipGetLastError());
 }
 
@@ -1697,11 +1712,12 @@ void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64
 
 void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
                             dev_count n, int M, rng_plan random_seed, const int* offsets, void* dst, int* src_lid,
-                            int64_t* edge_gid, hipStream_t stream)
+                            int64_t* edge_gid, hipStream_t stream, const int64_t* row_start,
+                            const int* row_deg)
 {
 #define WG_U(ST, CT)                                                                                               \
   uniform_launch<ST, CT>(row_ptr, static_cast<const CT*>(col), static_cast<const ST*>(seeds), n, M, random_seed, \
-                         offsets, static_cast<CT*>(dst), src_lid, edge_gid, stream)
+                         offsets, static_cast<CT*>(dst), src_lid, edge_gid, stream, row_start, row_deg)
   if (seeds64 && col64) WG_U(int64_t, int64_t);
   else if (seeds64) WG_U(int64_t, int32_t);
   else if (col64) WG_U(int32_t, int64_t);
