@@ -756,6 +756,19 @@ def main():
             # whether the table could be built before anyone enters a collective of the measurement, the measurement itself
             # runs under a watchdog, and every rank agrees again on whether it went through
             dog = arm_watchdog(args.extra_placement_timeout, placement)
+            # ... and if another rank DIES in it (a fault is not an exception), the launcher sends SIGTERM to the rest: rank 0
+            # answers with the line it already has instead of going down with it
+            import signal
+
+            def on_term(signum, _frame, what=placement):
+                placement_errors[what] = "a rank died during the also-measured placement (signal %d); headline unaffected" % signum
+                while len(placements) > 1:
+                    placements.pop()
+                try:
+                    emit_line()
+                finally:
+                    os._exit(0)
+            old_term = signal.signal(signal.SIGTERM, on_term) if world > 1 else None
             try:
                 feat = make_table(placement)
                 ok = 1
@@ -769,6 +782,8 @@ def main():
                 try:
                     if os.environ.get("WGAMD_BENCH_TEST_STALL") and rank == world - 1:
                         time.sleep(10 ** 6)      # test hook: one rank never reaches the collectives of the extra pass
+                    if os.environ.get("WGAMD_BENCH_TEST_DIE") and rank == world - 1:
+                        os.kill(os.getpid(), signal.SIGKILL)   # test hook: one rank dies in the extra pass
                     run_placement(placement, feat)
                 except Exception as e:   # noqa: BLE001
                     placement_errors[placement] = repr(e)
@@ -777,6 +792,8 @@ def main():
                 if world > 1:
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             dog.cancel()
+            if world > 1:
+                signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
             if int(flag) == 0:
                 placement_errors.setdefault(placement, "another rank could not build / measure the partitioned table")
                 placements.remove(placement)

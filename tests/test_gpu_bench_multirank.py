@@ -61,3 +61,16 @@ def test_stalled_extra_placement_does_not_cost_the_headline(hiplib):
     d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--extra-placement-timeout", "20"], env={"WGAMD_BENCH_TEST_STALL": "1"})
     assert d["n_gpus"] == 2 and d["value"] > 0 and "replicated" in d["config"]["parallelism"] or "dp2" in d["config"]["parallelism"]
     assert "timed out" in d["placement_errors"]["partitioned"] and "placements" not in d
+
+
+def test_rank_dying_in_the_extra_placement_does_not_cost_the_headline(hiplib):
+    """A rank that DIES in the also-measured partitioned pass (a GPU fault is not an exception): the launcher sends SIGTERM to
+    the others and rank 0 answers with the headline line it already has (the launcher itself then reports the failed worker)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--no-variants", "--dist-backend", "gloo", "--share-gpu"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGAMD_BENCH_TEST_DIE="1"))
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "died" in d["placement_errors"]["partitioned"]
