@@ -33,8 +33,60 @@ __device__ __forceinline__ int64_t src_row<void>(const void*, int c)
 // neighbour rows a lane group has in flight before it adds them up: a row is one 16-B load per lane and ~2 us away
 constexpr int kSpmmRowsInFlight = 4;   // 8 costs the F = 100 launch 6 % (registers), and buys the F = 256 one nothing
 
+// Segmented mode (the backward pass gathers over the TRANSPOSED hop, which is power-law: a hub source is a neighbour of
+// thousands of sampled rows, and a row is walked by one lane group — the launch would last as long as its longest row).
+// Row r < n_main sums only its first `seg` entries; every further piece of a long row is an EXTRA row n_main + x with its
+// own [start, end) and its sum goes to partial[x]; segment_addup_kernel then adds the pieces of a long row to its first one
+// in order — deterministic whatever slots the plan kernel's atomics hand out.
+struct spmm_segments {
+  int seg;                  // entries per piece; 0 = plain CSR
+  int64_t n_main;
+  const int* extra_start;
+  const int* extra_end;
+  const int* n_extra_dev;   // extras in use
+  float* partial;
+  int64_t ldp;
+};
+struct long_row {
+  int row, base, pieces;
+};
+
+__global__ void __launch_bounds__(256) segment_plan_kernel(const int* __restrict__ row_ptr, int64_t n_rows, int seg,
+                                                           int* __restrict__ counters /*[0] extras, [1] long rows*/,
+                                                           int* __restrict__ extra_start, int* __restrict__ extra_end,
+                                                           long_row* __restrict__ long_rows)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const int s = row_ptr[r], e = row_ptr[r + 1];
+  if (e - s <= seg) return;
+  const int pieces = (e - s + seg - 1) / seg - 1;   // beyond the first
+  const int base   = atomicAdd(counters, pieces);
+  long_rows[atomicAdd(counters + 1, 1)] = long_row{(int)r, base, pieces};
+  for (int j = 0; j < pieces; j++) {
+    extra_start[base + j] = s + (j + 1) * seg;
+    extra_end[base + j]   = min(e, s + (j + 2) * seg);
+  }
+}
+
+// one wave per long row: out[row, :] += partial[base, :] + partial[base + 1, :] + ... (in this order)
+__global__ void __launch_bounds__(256) segment_addup_kernel(const long_row* __restrict__ long_rows, const int* __restrict__ counters,
+                                                            const float* __restrict__ partial, int64_t ldp, int F,
+                                                            float* __restrict__ out, int64_t ldo)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < counters[1]; k += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const long_row lr = long_rows[k];
+    for (int f = lane; f < F; f += 64) {
+      float acc = out[(int64_t)lr.row * ldo + f];
+      for (int j = 0; j < lr.pieces; j++) acc += partial[(int64_t)(lr.base + j) * ldp + f];
+      out[(int64_t)lr.row * ldo + f] = acc;
+    }
+  }
+}
+
 // VEC = 4 (float4 path: F % 4 == 0, 16 B aligned rows) or 1.
-template <int VEC, typename IdT>
+template <int VEC, typename IdT, bool SEG = false>
 __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ row_ptr,
                                                        const int* __restrict__ col,
                                                        int64_t n_rows,
@@ -46,7 +98,8 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
                                                        float* __restrict__ out,
                                                        int64_t ldo,
                                                        int log2_lanes,
-                                                       const int64_t* __restrict__ self_rows)
+                                                       const int64_t* __restrict__ self_rows,
+                                                       spmm_segments sg)
 {
   const int lanes       = 1 << log2_lanes;
   const int lane        = threadIdx.x & 63;
@@ -63,9 +116,20 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
   for (int64_t it = 0; it < iters; it++) {
     const int64_t row = group + it * rows_per_iter;
     int s = 0, e = 0;
+    bool writes = row < n_rows;
     if (row < n_rows) {
-      s = row_ptr[row];
-      e = row_ptr[row + 1];
+      if (!SEG || row < sg.n_main) {
+        s = row_ptr[row];
+        e = row_ptr[row + 1];
+        if constexpr (SEG) e = min(e, s + sg.seg);   // segmented: the first piece of the row; the rest are extra "rows"
+      } else {
+        const int64_t xs = row - sg.n_main;
+        writes           = xs < (int64_t)*sg.n_extra_dev;
+        if (writes) {
+          s = sg.extra_start[xs];
+          e = sg.extra_end[xs];
+        }
+      }
     }
     const int deg = e - s;
     for (int f0 = sub * VEC; f0 < ((F + lanes * VEC - 1) / (lanes * VEC)) * (lanes * VEC); f0 += lanes * VEC) {
@@ -112,9 +176,9 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int* __restrict__ r
           }
         }
       }
-      if (live && row < n_rows) {
+      if (live && writes) {
         const float denom = (mean && deg > 0) ? (float)deg : 1.0f;
-        float* q          = out + row * ldo + f0;
+        float* q          = (SEG && row >= sg.n_main) ? sg.partial + (row - sg.n_main) * sg.ldp + f0 : out + row * ldo + f0;
         if constexpr (VEC == 4) {
           *reinterpret_cast<float4*>(q) = make_float4(acc[0] / denom, acc[1] / denom, acc[2] / denom, acc[3] / denom);
         } else {
@@ -287,7 +351,8 @@ static wholememory_error_code_t spmm_entry(const char* name, const int* row_ptr,
     const int l2   = lanes_log2_for(v4 ? F / 4 : F);
     const int grid = grid_rows(n_rows, l2);
 #define WG_SPMM(VEC, IDT, IDP) \
-  spmm_csr_kernel<VEC, IDT><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, IDP, mean, out, ldo, l2, self_rows)
+  spmm_csr_kernel<VEC, IDT><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, IDP, mean, out, ldo, l2, self_rows, \
+                                                  spmm_segments{})
     if (src_ids == nullptr) {
       if (v4) WG_SPMM(4, void, (const void*)nullptr); else WG_SPMM(1, void, (const void*)nullptr);
     } else if (src_ids_dtype == WHOLEMEMORY_DT_INT) {
@@ -332,6 +397,54 @@ wholememory_error_code_t wgamd_sage_aggregate_f32(const int* row_ptr, const int*
   }
   return spmm_entry("wgamd_sage_aggregate_f32", row_ptr, col, n_rows, x, ldx, F, nullptr, WHOLEMEMORY_DT_UNKNOWN,
                     mean, out, ldo, self_rows, stream);
+}
+
+constexpr int kSegmentEntries = 64;   // entries per piece of a long row
+
+size_t wgamd_spmm_csr_segmented_workspace_bytes(int64_t n_entries, int F)
+{
+  if (n_entries < 0 || F <= 0) return 0;
+  const size_t cap = (size_t)(n_entries / kSegmentEntries) + 1;   // pieces beyond the first, over all rows
+  const size_t ldp = ((size_t)F + 3) / 4 * 4;
+  return 256 + 2 * ((cap * sizeof(int) + 255) / 256 * 256) + (cap * sizeof(wgamd::long_row) + 255) / 256 * 256 +
+         cap * ldp * sizeof(float) + 256;
+}
+
+wholememory_error_code_t wgamd_spmm_csr_segmented_f32(const int* row_ptr, const int* col, int64_t n_rows, int64_t n_entries,
+                                                      const float* x, int64_t ldx, int F, float* out, int64_t ldo,
+                                                      void* workspace, size_t workspace_bytes, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_spmm_csr_segmented_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && n_entries >= 0 && F > 0, "bad sizes");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(row_ptr && (col || n_entries == 0) && x && out && workspace, "null pointer");
+    WG_REQUIRE_INPUT(workspace_bytes >= wgamd_spmm_csr_segmented_workspace_bytes(n_entries, F), "workspace too small");
+    auto st           = static_cast<hipStream_t>(stream);
+    const size_t cap  = (size_t)(n_entries / kSegmentEntries) + 1;
+    const size_t ib   = (cap * sizeof(int) + 255) / 256 * 256;
+    const int64_t ldp = ((int64_t)F + 3) / 4 * 4;
+    char* ws          = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    int* counters     = reinterpret_cast<int*>(ws);
+    int* extra_start  = reinterpret_cast<int*>(ws + 256);
+    int* extra_end    = reinterpret_cast<int*>(ws + 256 + ib);
+    auto* long_rows   = reinterpret_cast<long_row*>(ws + 256 + 2 * ib);
+    float* partial    = reinterpret_cast<float*>(ws + 256 + 2 * ib + (cap * sizeof(long_row) + 255) / 256 * 256);
+    WG_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+    segment_plan_kernel<<<ceil_div(n_rows, 256), 256, 0, st>>>(row_ptr, n_rows, kSegmentEntries, counters, extra_start,
+                                                               extra_end, long_rows);
+    const bool v4  = vec4_ok(x, ldx, out, ldo, F);
+    const int l2   = lanes_log2_for(v4 ? F / 4 : F);
+    const int64_t n_all = n_rows + (int64_t)cap;
+    const int grid = grid_rows(n_all, l2);
+    spmm_segments sg{kSegmentEntries, n_rows, extra_start, extra_end, counters, partial, ldp};
+    if (v4)
+      spmm_csr_kernel<4, void, true><<<grid, 256, 0, st>>>(row_ptr, col, n_all, x, ldx, F, nullptr, 0, out, ldo, l2, nullptr, sg);
+    else
+      spmm_csr_kernel<1, void, true><<<grid, 256, 0, st>>>(row_ptr, col, n_all, x, ldx, F, nullptr, 0, out, ldo, l2, nullptr, sg);
+    segment_addup_kernel<<<(int)std::min<size_t>((cap + 3) / 4, 4096), 256, 0, st>>>(long_rows, counters, partial, ldp, F, out, ldo);
+    WG_HIP_CHECK(hipGetLastError());
+  });
 }
 
 wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows,

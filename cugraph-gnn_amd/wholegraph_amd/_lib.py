@@ -216,6 +216,9 @@ SYMBOLS = {
     "wgamd_sage_layer_bf16x3_supported": (c_int, [c_int, c_int]),
     "wgamd_spmm_csr_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_int64, c_void_p]),
+    "wgamd_spmm_csr_segmented_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "wgamd_spmm_csr_segmented_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                             c_void_p, c_size_t, c_void_p]),
     "wgamd_gat_csr_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int,
                                   c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_set_weighted_sampling_mode": (None, [c_int, c_int]),

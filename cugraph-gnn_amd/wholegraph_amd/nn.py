@@ -10,6 +10,7 @@ segmented reduce / edge softmax run in hand-written gfx950 kernels, the dense ``
 plain ``torch.nn.functional.linear`` (hipBLASLt, MFMA).
 """
 import math
+import os
 from typing import Tuple, Union
 
 import torch
@@ -234,7 +235,23 @@ def spmm_csr_backward(row_ptr, col, grad_out, n_src, mean=True, atomic=False):
         deg = (row_ptr[1:] - row_ptr[:-1]).clamp_(min=1)
         g = g / deg.unsqueeze(1)
     row_ptr_t, col_t = csr_transpose(row_ptr, col, n_src)
-    return spmm_csr_forward(row_ptr_t, col_t, g, mean=False)
+    if not _BWD_SEGMENTS:
+        return spmm_csr_forward(row_ptr_t, col_t, g, mean=False)
+    # The transposed hop is power-law (a hub is a neighbour of thousands of sampled rows) while the gather kernel walks a
+    # row with one lane group: the launch would last as long as its longest row.  wgamd_spmm_csr_segmented_f32 sums rows
+    # in pieces of 64 entries and adds the pieces of a row up in order (deterministic, nothing read back).
+    E, F_ = col_t.shape[0], g.shape[1]
+    out = torch.empty((n_src, F_), dtype=torch.float32, device=g.device)
+    need = L.lib().wgamd_spmm_csr_segmented_workspace_bytes(E, F_)
+    ws = torch.empty(need, dtype=torch.uint8, device=g.device)
+    L.check(L.lib().wgamd_spmm_csr_segmented_f32(row_ptr_t.data_ptr(), col_t.data_ptr(), n_src, E, g.data_ptr(), g.stride(0), F_,
+                                                 out.data_ptr(), out.stride(0), ws.data_ptr(), need, get_stream()),
+            "wgamd_spmm_csr_segmented_f32")
+    return out
+
+
+_BWD_SEGMENTS = os.environ.get("WGAMD_SPMM_BWD_SEGMENTS", "1") != "0"
+
 
 
 class _SpmmCsr(torch.autograd.Function):

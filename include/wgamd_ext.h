@@ -82,6 +82,16 @@ wholememory_error_code_t wgamd_sage_aggregate_fetch_f32(const int* row_ptr,
                                                         int64_t ldo,
                                                         void* stream);
 
+/* Sum aggregation over a CSR whose rows may be very long — the TRANSPOSED sampled hop of the backward pass, where a hub
+ * source is a neighbour of thousands of rows.  Rows are summed in pieces of 64 entries by different lane groups and the
+ * pieces of a row are then added up in order: same values from run to run (no atomics on the data), no launch that lasts as
+ * long as its longest row.  out[r, :] = sum_{e in row r} x[col[e], :].  Workspace: wgamd_spmm_csr_segmented_workspace_bytes
+ * (n_entries = row_ptr[n_rows], known to the caller). */
+size_t wgamd_spmm_csr_segmented_workspace_bytes(int64_t n_entries, int F);
+wholememory_error_code_t wgamd_spmm_csr_segmented_f32(const int* row_ptr, const int* col, int64_t n_rows, int64_t n_entries,
+                                                      const float* x, int64_t ldx, int F, float* out, int64_t ldo,
+                                                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of the above w.r.t. x (src_ids == NULL form):
  *   grad_x[col[e], :] += grad_out[i, :] * (mean ? 1/max(deg_i,1) : 1)   for every edge e of row i.
  * grad_x must be zero-initialised (or hold the gradient to accumulate into) by the caller. */

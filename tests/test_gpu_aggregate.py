@@ -73,6 +73,35 @@ def test_spmm_backward_matches_torch(hiplib):
     assert rpt_t[-1].item() == ct.shape[0] and torch.equal(torch.diff(rpt_t).long(), torch.bincount(ct, minlength=800))
 
 
+def test_spmm_backward_with_hub_sources(hiplib):
+    """A power-law hop seen from the sources: a handful of them are neighbours of thousands of rows.  The backward gathers
+    over the transposed hop in segments of at most 64 entries (then adds the segments of a row up in order): same values as
+    the scatter-add and as torch's index_add_, bit-identical from run to run, empty sources included."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n_dst, n_src, F = 6000, 3000, 100
+    deg = torch.randint(0, 11, (n_dst,), generator=g, device="cuda")
+    rp = torch.zeros(n_dst + 1, dtype=torch.int32, device="cuda")
+    rp[1:] = torch.cumsum(deg, 0)
+    E = int(rp[-1])
+    col = torch.randint(0, n_src - 500, (E,), generator=g, device="cuda", dtype=torch.int32)   # the last 500 sources: unused
+    hub = torch.rand(E, generator=g, device="cuda")
+    col[hub < 0.25] = 7            # ~ E / 4 entries on one source
+    col[(hub >= 0.25) & (hub < 0.30)] = 1234
+    gout = torch.randn((n_dst, F), generator=g, device="cuda")
+    for mean in (True, False):
+        a = nn.spmm_csr_backward(rp, col, gout, n_src, mean)
+        assert torch.equal(a, nn.spmm_csr_backward(rp, col, gout, n_src, mean))
+        b = nn.spmm_csr_backward(rp, col, gout, n_src, mean, atomic=True)
+        scale = gout / deg.clamp(min=1).unsqueeze(1) if mean else gout
+        dst = torch.repeat_interleave(torch.arange(n_dst, device="cuda"), deg.long())
+        ref = torch.zeros((n_src, F), dtype=torch.float64, device="cuda").index_add_(0, col.long(), scale[dst].double())
+        torch.testing.assert_close(a.double(), ref, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3)
+        assert torch.count_nonzero(a[n_src - 500:]) == 0
+
+
 @pytest.mark.parametrize("H,C", [(1, 8), (4, 32), (4, 16), (2, 5), (8, 64)])
 def test_gat_vs_oracle(oracle_mod, hiplib, H, C):
     import torch
