@@ -80,11 +80,50 @@ gat_bwd_dst_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
   }
 }
 
+// The source-major pass walks the TRANSPOSED hop, which is power-law (a hub source is a neighbour of thousands of sampled
+// rows): with one lane group per source and one dependent load chain per entry a 3,800-entry row alone took milliseconds.
+// Rows are therefore summed in PIECES of kSegEntries entries (as in wgamd_spmm_csr_segmented_f32): row r < n_main sums its
+// first piece, every further piece of a long row is an extra "row" n_main + x handed out by gat_plan_kernel whose sums go
+// to partial buffers, and gat_addup_kernel adds the pieces of a row up in order — deterministic.  Four entries are in
+// flight per lane group (edge id -> alpha / destination -> gradient row is a chain of dependent loads).
+constexpr int kSegEntries = 64;
+struct gat_segments {
+  int seg;                  // 0 = plain rows
+  int64_t n_main;
+  const int* extra_start;
+  const int* extra_end;
+  const int* n_extra_dev;
+  float* partial_gx;        // [extras, ldp]
+  int64_t ldp;
+  float* partial_gas;       // [extras, H]
+};
+struct gat_long_row {
+  int row, base, pieces;
+};
+
+__global__ void __launch_bounds__(256) gat_plan_kernel(const int* __restrict__ row_ptr_t, int64_t n_src, int seg,
+                                                       int* __restrict__ counters, int* __restrict__ extra_start,
+                                                       int* __restrict__ extra_end, gat_long_row* __restrict__ long_rows)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_src) return;
+  const int s = row_ptr_t[r], e = row_ptr_t[r + 1];
+  if (e - s <= seg) return;
+  const int pieces = (e - s + seg - 1) / seg - 1;
+  const int base   = atomicAdd(counters, pieces);
+  long_rows[atomicAdd(counters + 1, 1)] = gat_long_row{(int)r, base, pieces};
+  for (int j = 0; j < pieces; j++) {
+    extra_start[base + j] = s + (j + 1) * seg;
+    extra_end[base + j]   = min(e, s + (j + 2) * seg);
+  }
+}
+
+template <bool SEG>
 __global__ void __launch_bounds__(256)
 gat_bwd_src_kernel(const int* __restrict__ row_ptr_t, const int* __restrict__ edge_perm, const int* __restrict__ edge_dst,
-                   int64_t n_src, int H, int C, const float* __restrict__ alpha, const float* __restrict__ de,
+                   int64_t n_rows, int H, int C, const float* __restrict__ alpha, const float* __restrict__ de,
                    const float* __restrict__ g, int64_t ldg, float* __restrict__ gx, int64_t ldgx,
-                   float* __restrict__ ga_src, int log2_lanes)
+                   float* __restrict__ ga_src, int log2_lanes, gat_segments sg)
 {
   const int lanes       = 1 << log2_lanes;
   const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,22 +134,73 @@ gat_bwd_src_kernel(const int* __restrict__ row_ptr_t, const int* __restrict__ ed
   const int f0 = sub * 4;
   if (f0 >= HC) return;
   const int h = f0 / C;
-  for (int64_t row = group; row < n_src; row += ngroups) {
-    const int s = row_ptr_t[row], e = row_ptr_t[row + 1];
+  for (int64_t row = group; row < n_rows; row += ngroups) {
+    int s, e;
+    float* gx_row;
+    float* gas_row;
+    if (!SEG || row < sg.n_main) {
+      s = row_ptr_t[row];
+      e = row_ptr_t[row + 1];
+      if constexpr (SEG) e = min(e, s + sg.seg);
+      gx_row  = gx + row * ldgx;
+      gas_row = ga_src + row * H;
+    } else {
+      const int64_t xs = row - sg.n_main;
+      if (xs >= (int64_t)*sg.n_extra_dev) break;   // extras are handed out from 0: nothing further for this lane group
+      s       = sg.extra_start[xs];
+      e       = sg.extra_end[xs];
+      gx_row  = sg.partial_gx + xs * sg.ldp;
+      gas_row = sg.partial_gas + xs * H;
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float gas  = 0.f;
-    for (int j = s; j < e; j++) {
-      const int eid   = edge_perm[j];
-      const float al  = alpha[(int64_t)eid * H + h];
-      const float4 t4 = *reinterpret_cast<const float4*>(g + (int64_t)edge_dst[eid] * ldg + f0);
-      acc.x += al * t4.x;
-      acc.y += al * t4.y;
-      acc.z += al * t4.z;
-      acc.w += al * t4.w;
-      gas += de[(int64_t)eid * H + h];
+    for (int j = s; j < e; j += 4) {
+      int eid[4];
+      float al[4], dv[4];
+      float4 t4[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) eid[k] = edge_perm[min(j + k, e - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        al[k] = alpha[(int64_t)eid[k] * H + h];
+        dv[k] = de[(int64_t)eid[k] * H + h];
+        t4[k] = *reinterpret_cast<const float4*>(g + (int64_t)edge_dst[eid[k]] * ldg + f0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (j + k < e) {
+          acc.x += al[k] * t4[k].x;
+          acc.y += al[k] * t4[k].y;
+          acc.z += al[k] * t4[k].z;
+          acc.w += al[k] * t4[k].w;
+          gas += dv[k];
+        }
+      }
     }
-    *reinterpret_cast<float4*>(gx + row * ldgx + f0) = acc;
-    if ((f0 % C) == 0) ga_src[row * H + h] = gas;
+    *reinterpret_cast<float4*>(gx_row + f0) = acc;
+    if ((f0 % C) == 0) gas_row[h] = gas;
+  }
+}
+
+// one wave per long row: grad_x[row] += its pieces, grad_a_src[row] += its pieces, in piece order
+__global__ void __launch_bounds__(256)
+gat_addup_kernel(const gat_long_row* __restrict__ long_rows, const int* __restrict__ counters, const float* __restrict__ partial_gx,
+                 int64_t ldp, const float* __restrict__ partial_gas, int H, int HC, float* __restrict__ gx, int64_t ldgx,
+                 float* __restrict__ ga_src)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < counters[1]; k += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const gat_long_row lr = long_rows[k];
+    for (int f = lane; f < HC; f += 64) {
+      float acc = gx[(int64_t)lr.row * ldgx + f];
+      for (int j = 0; j < lr.pieces; j++) acc += partial_gx[(int64_t)(lr.base + j) * ldp + f];
+      gx[(int64_t)lr.row * ldgx + f] = acc;
+    }
+    if (lane < H) {
+      float acc = ga_src[(int64_t)lr.row * H + lane];
+      for (int j = 0; j < lr.pieces; j++) acc += partial_gas[(int64_t)(lr.base + j) * H + lane];
+      ga_src[(int64_t)lr.row * H + lane] = acc;
+    }
   }
 }
 
@@ -124,12 +214,22 @@ inline int log2_ceil(int v)
 }  // namespace
 }  // namespace wgamd
 
+extern "C" size_t wgamd_gat_csr_bwd_workspace_bytes(int64_t n_entries, int H, int C)
+{
+  if (n_entries < 0 || H <= 0 || C <= 0) return 0;
+  // one slot per piece of a long source row beyond its first: at most n_entries / 64 of them
+  const size_t cap       = (size_t)(n_entries / wgamd::kSegEntries) + 1;
+  const size_t per_extra = 2 * sizeof(int) + sizeof(wgamd::gat_long_row) + (size_t)H * C * sizeof(float) + (size_t)H * sizeof(float);
+  return 1024 + cap * (per_extra + 16);
+}
+
 extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
                                                           int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
                                                           float negative_slope, const float* alpha, const float* grad_out,
                                                           int64_t ldg, const int* row_ptr_t, const int* edge_perm,
                                                           const int* edge_dst, int64_t n_src, float* de, float* grad_x,
-                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, void* stream)
+                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, void* workspace,
+                                                          size_t workspace_bytes, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_gat_csr_bwd_f32", [&] {
@@ -148,10 +248,38 @@ extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, co
       gat_bwd_dst_kernel<<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, alpha,
                                                grad_out, ldg, de, grad_a_dst, l2);
     }
-    if (n_src > 0) {
+    if (n_src > 0 && workspace == nullptr) {   // plain rows (a caller without scratch)
       const int grid = (int)std::min<int64_t>((n_src + gpb - 1) / gpb, 256 * 16);
-      gat_bwd_src_kernel<<<grid, 256, 0, st>>>(row_ptr_t, edge_perm, edge_dst, n_src, H, C, alpha, de, grad_out, ldg, grad_x,
-                                               ldgx, grad_a_src, l2);
+      gat_bwd_src_kernel<false><<<grid, 256, 0, st>>>(row_ptr_t, edge_perm, edge_dst, n_src, H, C, alpha, de, grad_out, ldg,
+                                                      grad_x, ldgx, grad_a_src, l2, gat_segments{});
+    } else if (n_src > 0) {
+      // n_entries is not an argument: the scratch is sized by the caller from it (wgamd_gat_csr_bwd_workspace_bytes), and
+      // the number of extra pieces it can hold is recovered from its size
+      const size_t per_extra = 2 * sizeof(int) + sizeof(gat_long_row) + (size_t)HC * sizeof(float) + (size_t)H * sizeof(float);
+      WG_REQUIRE_INPUT(workspace_bytes >= 1024 + per_extra, "workspace too small");
+      const size_t cap = (workspace_bytes - 1024) / (per_extra + 16);
+      char* ws         = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+      auto carve       = [&](size_t bytes) {
+        char* at = ws;
+        ws += (bytes + 15) / 16 * 16;
+        return at;
+      };
+      int* counters    = reinterpret_cast<int*>(carve(256));
+      int* extra_start = reinterpret_cast<int*>(carve(cap * sizeof(int)));
+      int* extra_end   = reinterpret_cast<int*>(carve(cap * sizeof(int)));
+      auto* long_rows  = reinterpret_cast<gat_long_row*>(carve(cap * sizeof(gat_long_row)));
+      float* pgx       = reinterpret_cast<float*>(carve(cap * (size_t)HC * sizeof(float)));
+      float* pgas      = reinterpret_cast<float*>(carve(cap * (size_t)H * sizeof(float)));
+      WG_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+      gat_plan_kernel<<<(int)((n_src + 255) / 256), 256, 0, st>>>(row_ptr_t, n_src, kSegEntries, counters, extra_start, extra_end,
+                                                                   long_rows);
+      const int64_t n_all = n_src + (int64_t)cap;
+      const int grid      = (int)std::min<int64_t>((n_all + gpb - 1) / gpb, 256 * 16);
+      gat_segments sg{kSegEntries, n_src, extra_start, extra_end, counters, pgx, HC, pgas};
+      gat_bwd_src_kernel<true><<<grid, 256, 0, st>>>(row_ptr_t, edge_perm, edge_dst, n_all, H, C, alpha, de, grad_out, ldg,
+                                                     grad_x, ldgx, grad_a_src, l2, sg);
+      gat_addup_kernel<<<(int)std::min<size_t>((cap + 3) / 4, 4096), 256, 0, st>>>(long_rows, counters, pgx, HC, pgas, H, HC,
+                                                                                    grad_x, ldgx, grad_a_src);
     }
     WG_HIP_CHECK(hipGetLastError());
   });

@@ -269,12 +269,19 @@ def test_sage_layer_fused_64bit_offset_path_and_tiny_inputs(hiplib):
         torch.testing.assert_close(a, ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("hubs", [False, True])
 @pytest.mark.parametrize("H,C", [(4, 64), (1, 256), (4, 16), (8, 8), (2, 4), (1, 32)])
-def test_gat_backward_kernels_match_autograd_of_dense_formula(hiplib, H, C):
-    """wgamd_gat_csr_bwd_f32 against torch autograd on the plain edge-wise formulation of GAT attention."""
+def test_gat_backward_kernels_match_autograd_of_dense_formula(hiplib, H, C, hubs):
+    """wgamd_gat_csr_bwd_f32 against torch autograd on the plain edge-wise formulation of GAT attention; ``hubs``: a
+    quarter of all edges leave ONE source (and 5 % another), so the source-major pass sums those rows in pieces."""
     import torch
     from wholegraph_amd import nn
     rp, col = _csr(700, 1500, 18, H * C)
+    if hubs:
+        r = np.random.default_rng(H + C).random(col.size)
+        col = col.copy()
+        col[r < 0.25] = 3
+        col[(r >= 0.25) & (r < 0.30)] = 777
     rpt, ct = torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda()
     g = torch.Generator(device="cuda").manual_seed(H * 100 + C)
     x = torch.randn((1500, H * C), generator=g, device="cuda", requires_grad=True)
