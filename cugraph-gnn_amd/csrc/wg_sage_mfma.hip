@@ -847,16 +847,17 @@ void launch_cw(const mfma_args& a, hipStream_t st)
   }
 }
 
-// 64-row tiles whenever two of them fit the LDS (F <= 148), 32-row tiles otherwise; only the (LG, TR) pairs that can occur
-// are instantiated: F <= 128 always fits
+// F <= 128: two whole 64-row tiles; wider rows: 64-row tiles in two halves when the halves are whole k-steps and fit, 32-row
+// tiles otherwise; only the (LG, TR) pairs that can occur are instantiated
 template <typename IdT, int LG>
 void launch_tr(const mfma_args& a, hipStream_t st)
 {
   if constexpr (LG <= 32) {
     launch_cw<IdT, LG, 64>(a, st);
   } else {
-    if (lds_bytes(a.F, 64) <= kLdsBudget) launch_cw<IdT, LG, 64>(a, st);
-    else if (use_half_tiles(a.F)) {
+    // (128 < F <= 148: two whole 64-row tiles would fit, but a 64-lane group then carries sixteen rows of metadata per tile
+    //  and the kernel spills ~100 VGPRs; 32-row tiles do not)
+    if (use_half_tiles(a.F)) {
       switch (a.N / 64) {
         case 1: launch_half<IdT, LG, 1>(a, st); break;
         case 2: launch_half<IdT, LG, 2>(a, st); break;

@@ -177,7 +177,8 @@ def test_sage_aggregate_fused_feature_fetch(oracle_mod, hiplib):
 # (F > 148 with F % 16 == 0: the bf16x3 kernel runs 64-row tiles in two halves; 152 and 204: its 32-row tiles)
 @pytest.mark.parametrize("F,N", [(100, 256), (128, 256), (64, 64), (256, 128), (4, 128), (36, 256), (208, 128), (104, 64),
                                  (256, 256), (256, 64), (176, 256), (160, 64), (152, 128), (204, 256),
-                                 (256, 47), (100, 172), (128, 1)])   # widths padded to 64 / 256 / 64 on the way in
+                                 (256, 47), (100, 172), (128, 1),    # widths padded to 64 / 256 / 64 on the way in
+                                 (140, 128)])
 @pytest.mark.parametrize("with_ids", [False, True])
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, with_ids, precision):
