@@ -319,7 +319,8 @@ inline int grid_rows(int64_t n_rows, int log2_lanes)
 {
   int64_t groups_per_block = 256 >> log2_lanes;
   int64_t blocks           = (n_rows + groups_per_block - 1) / groups_per_block;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  static const int per_cu = getenv("WGAMD_SPMM_WG_PER_CU") ? atoi(getenv("WGAMD_SPMM_WG_PER_CU")) : 16;
+  if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
