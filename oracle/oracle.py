@@ -23,7 +23,7 @@ __all__ = [
     "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets", "unweighted_sample_with_replacement",
     "unweighted_sample", "weighted_sample", "append_unique", "csr_add_self_loop",
     "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "num_threads",
-    "set_num_threads", "py_pcg_u32_stream", "py_unweighted_sample_small",
+    "set_num_threads", "py_pcg_u32_stream",
 ]
 
 
@@ -181,49 +181,6 @@ def weighted_sample(row_ptr, col, weights, seeds, max_sample_count, random_seed,
     if return_keys:
         return off, dst, lid, gid, keys
     return off, dst, lid, gid
-
-
-def py_unweighted_sample_small(row_ptr, col, seeds, M, random_seed):
-    """Pure-Python twin of the uniform sampler for tiny cases (M <= 1024), mirroring the
-    reference's Python test restatement
-    (python/pylibwholegraph/pylibwholegraph/tests/wholegraph_torch/ops/
-    test_wholegraph_unweighted_sample_without_replacement.py:22-160), drawing its random
-    numbers from ``generate_random_positive_int`` exactly as that test draws them from the
-    C helper."""
-    warp_count = [1, 1, 1, 2, 2, 2, 4, 4, 4, 4, 4, 4] + [8] * 20
-    items = [1, 2, 3, 2, 3, 3, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2] + [3] * 8 + [4] * 8
-    off = [0]
-    for s in seeds:
-        d = int(row_ptr[s + 1] - row_ptr[s])
-        off.append(off[-1] + (min(d, M) if M > 0 else d))
-    dst, lid, gid = [], [], []
-    if M > 0:
-        f = (M - 1) // 32
-        B, it = warp_count[f] * 32, items[f]
-    for i, s in enumerate(seeds):
-        start, end = int(row_ptr[s]), int(row_ptr[s + 1])
-        N = end - start
-        if M <= 0 or N <= M:
-            sel = list(range(N))
-        else:
-            r = [0] * max(N, B * it)
-            for j in range(B):
-                nums = generate_random_positive_int(random_seed, i * B + j, it)
-                for k in range(it):
-                    idx = k * B + j
-                    if idx < N:
-                        r[idx] = int(nums[k]) % (N - idx) if idx < M else N
-            Q = list(range(N))
-            sel = []
-            for t in range(M):
-                sel.append(Q[r[t]])
-                Q[r[t]] = Q[N - t - 1]
-        for a in sel:
-            dst.append(int(col[start + a]))
-            lid.append(i)
-            gid.append(start + a)
-    return (np.array(off, np.int32), np.array(dst, dtype=np.asarray(col).dtype),
-            np.array(lid, np.int32), np.array(gid, np.int64))
 
 
 # ---------------------------------------------------------------------------- renumber
