@@ -440,13 +440,14 @@ mapped_rows_kernel(const mapped_view* __restrict__ view, int64_t row0, int64_t e
     for (int k = 0; k < kMappedRows; k++) {
       const int64_t ri = r0 + k < n ? r0 + k : n - 1;   // unconditional index load
       int64_t id       = (int64_t)idx[ri];
-      const bool ok    = r0 + k < n && id >= 0;
+      bool ok          = r0 + k < n && id >= 0 && id + row0 < s_off[W];   // past the last entry: skipped like a negative id
       id               = ok ? id + row0 : s_off[0];     // a dead slot points at some valid row and is never stored
       int lo = 0, hi = W;                               // owner: last r with entry_off[r] <= id
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (s_off[mid] <= id) lo = mid; else hi = mid;
       }
+      ok     = ok && s_base[lo] != nullptr;             // an owner without an allocation cannot hold the row
       tp[k]  = ok ? s_base[lo] + (id - s_off[lo]) * entry_bytes + col0_bytes : nullptr;
       all_ok = all_ok && ok;
     }
@@ -727,6 +728,8 @@ wholememory_error_code_t wholememory_equal_entry_partition_plan(size_t* entry_pe
   return WHOLEMEMORY_SUCCESS;
 }
 
+static void release_handle(wholememory_handle_t h, bool collective);
+
 wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, size_t total_size, wholememory_comm_t comm,
                                             wholememory_memory_type_t memory_type,
                                             wholememory_memory_location_t memory_location, size_t data_granularity,
@@ -772,7 +775,11 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         int64_t pid;
         uint64_t ptr;
         uint64_t bytes;
+        int64_t device;
       } mine{};
+      int my_device = 0;
+      WG_HIP_CHECK(hipGetDevice(&my_device));
+      mine.device = my_device;
       mine.pid   = (int64_t)getpid();
       mine.ptr   = reinterpret_cast<uint64_t>(h->local_ptr);
       mine.bytes = local;
@@ -790,6 +797,16 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
           if (r == comm->rank || rec.bytes == 0) {
             h->peer_ptr[r] = r == comm->rank ? h->local_ptr : nullptr;
           } else if (rec.pid == mine.pid) {
+            // a rank of this very process: its pointer is valid here, but if it sits on ANOTHER device the kernel's loads
+            // need peer access between the two devices
+            if ((int)rec.device != my_device) {
+              int can = 0;
+              WG_HIP_CHECK(hipDeviceCanAccessPeer(&can, my_device, (int)rec.device));
+              if (!can) throw logic_error("peer-mapped memory type: no peer access between two devices of this process");
+              hipError_t pe = hipDeviceEnablePeerAccess((int)rec.device, 0);
+              if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+              else WG_HIP_CHECK(pe);
+            }
             h->peer_ptr[r] = reinterpret_cast<void*>(rec.ptr);
           } else {
             WG_HIP_CHECK(hipIpcOpenMemHandle(&h->peer_ptr[r], rec.ipc, hipIpcMemLazyEnablePeerAccess));
@@ -806,7 +823,7 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         WG_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_view), sizeof(mapped_view)));
         WG_HIP_CHECK(hipMemcpy(h->d_view, &view, sizeof(view), hipMemcpyHostToDevice));
       } catch (...) {
-        wholememory_free(h);
+        release_handle(h, /*collective=*/false);
         throw;
       }
     }
@@ -814,14 +831,30 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
   });
 }
 
-wholememory_error_code_t wholememory_free(wholememory_handle_t h)
+/* Releases a handle.  For a PEER-MAPPED handle (CHUNKED / CONTINUOUS over more than one rank) the release is COLLECTIVE when
+ * `collective` is set, as in the reference (memory_handle.cpp:1007-1029: barrier, unmap, barrier, release, barrier): a peer's
+ * mapped_rows_kernel may still be reading or writing THIS rank's partition over xGMI, so every rank first drains its own
+ * device, all ranks meet, the mappings are closed, all ranks meet again, and only then is the partition handed back.
+ * `collective = false` is for the error path of wholememory_malloc, where the other ranks cannot be assumed to follow. */
+static void release_handle(wholememory_handle_t h, bool collective)
 {
-  if (h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  const bool mapped = !h->peer_ptr.empty();
+  if (mapped) {
+    (void)hipDeviceSynchronize();
+    if (collective) (void)wholememory_communicator_barrier(h->comm);
+  }
   for (size_t r = 0; r < h->peer_ptr.size(); r++)
     if (h->peer_opened[r] && h->peer_ptr[r]) (void)hipIpcCloseMemHandle(h->peer_ptr[r]);
   if (h->d_view) (void)hipFree(h->d_view);
+  if (mapped && collective) (void)wholememory_communicator_barrier(h->comm);
   if (h->local_ptr) (void)hipFree(h->local_ptr);
   delete h;
+}
+
+wholememory_error_code_t wholememory_free(wholememory_handle_t h)
+{
+  if (h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  release_handle(h, /*collective=*/true);
   return WHOLEMEMORY_SUCCESS;
 }
 

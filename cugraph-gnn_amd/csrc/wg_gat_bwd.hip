@@ -228,8 +228,8 @@ extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, co
                                                           float negative_slope, const float* alpha, const float* grad_out,
                                                           int64_t ldg, const int* row_ptr_t, const int* edge_perm,
                                                           const int* edge_dst, int64_t n_src, float* de, float* grad_x,
-                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, void* workspace,
-                                                          size_t workspace_bytes, void* stream)
+                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, int64_t n_entries,
+                                                          void* workspace, size_t workspace_bytes, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_gat_csr_bwd_f32", [&] {
@@ -253,11 +253,12 @@ extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, co
       gat_bwd_src_kernel<false><<<grid, 256, 0, st>>>(row_ptr_t, edge_perm, edge_dst, n_src, H, C, alpha, de, grad_out, ldg,
                                                       grad_x, ldgx, grad_a_src, l2, gat_segments{});
     } else if (n_src > 0) {
-      // n_entries is not an argument: the scratch is sized by the caller from it (wgamd_gat_csr_bwd_workspace_bytes), and
-      // the number of extra pieces it can hold is recovered from its size
-      const size_t per_extra = 2 * sizeof(int) + sizeof(gat_long_row) + (size_t)HC * sizeof(float) + (size_t)H * sizeof(float);
-      WG_REQUIRE_INPUT(workspace_bytes >= 1024 + per_extra, "workspace too small");
-      const size_t cap = (workspace_bytes - 1024) / (per_extra + 16);
+      // every further piece of a long row needs a slot: at most n_entries / kSegEntries of them, which is what the
+      // workspace must hold — the plan kernel hands slots out with atomics and has no other bound
+      WG_REQUIRE_INPUT(n_entries >= 0, "n_entries < 0");
+      WG_REQUIRE_INPUT(workspace_bytes >= wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C),
+                       "workspace smaller than wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C)");
+      const size_t cap = (size_t)(n_entries / kSegEntries) + 1;
       char* ws         = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
       auto carve       = [&](size_t bytes) {
         char* at = ws;

@@ -164,15 +164,26 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     assert self_rows.dtype == torch.int64 and self_rows.is_contiguous()
     n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], w_t.shape[1]
     Np = _padded_width(N) if sage_layer_fused_supported(F_, N) else N
+    user_out = None
     if Np != N:
         # zero weight columns / bias entries up to the width the kernel runs at (cached on the weight like its planes); the
-        # kernel then writes Np columns per row: `out` must leave room for them in its row stride
+        # kernel then WRITES Np columns per row.  A caller's `out` is written in place only when it is the [:, :N] view of
+        # an explicit [n_rows, Np] scratch (row stride == Np: columns N..Np-1 are the caller's padding by construction);
+        # any other `out` is filled from a temporary, so neither a wider buffer's own columns are overwritten nor a
+        # narrower one silently dropped.
         w_t, bias = _padded_head(w_t, bias, Np)
-        if out is not None and out.stride(0) < Np:
-            out = None
+        if out is not None and out.stride(0) != Np:
+            assert out.shape == (n_rows, N) and out.dtype == torch.float32, "out must be float32 [n_rows, N]"
+            user_out, out = out, None
     if out is None:
         out = torch.empty((n_rows, Np), dtype=torch.float32, device=x.device)[:, :N]
     assert out.shape == (n_rows, N) and out.dtype == torch.float32 and out.stride(1) == 1
+
+    def done(res):
+        if user_out is None:
+            return res
+        user_out.copy_(res)
+        return user_out
     N = Np
     ids_ptr, ids_dt = None, 0
     if src_ids is not None:
@@ -185,13 +196,13 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
             row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
             self_rows.data_ptr(), int(bool(mean)), planes.data_ptr(), N, None if bias is None else bias.data_ptr(),
             int(bool(relu)), out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_bf16x3")
-        return out
+        return done(out)
     L.check(L.lib().wgamd_sage_layer_fused_f32(
         row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
         self_rows.data_ptr(),
         int(bool(mean)), w_t.data_ptr(), w_t.stride(0), N, None if bias is None else bias.data_ptr(), int(bool(relu)),
         out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_f32")
-    return out
+    return done(out)
 
 
 def _csr_transpose(row_ptr, col, n_src, want_perm=False, want_dst=False, want_col_t=False):
@@ -310,7 +321,7 @@ def gat_backward(row_ptr, col, x, a_src, a_dst, alpha, grad_out, heads, negative
         row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), a_src.data_ptr(), a_dst.data_ptr(), heads, C,
         float(negative_slope), alpha.data_ptr(), g.data_ptr(), g.stride(0), row_ptr_t.data_ptr(), edge_perm.data_ptr(),
         edge_dst.data_ptr(), n_src, de.data_ptr(), gx.data_ptr(), gx.stride(0), ga_src.data_ptr(), ga_dst.data_ptr(),
-        ws.data_ptr(), need, get_stream()), "wgamd_gat_csr_bwd_f32")
+        E, ws.data_ptr(), need, get_stream()), "wgamd_gat_csr_bwd_f32")
     return gx, ga_src, ga_dst
 
 

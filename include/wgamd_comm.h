@@ -17,7 +17,18 @@
  *     no flat global pointer: a CONTINUOUS handle is addressed like a CHUNKED one (wgamd_get_peer_pointers).
  * Host-pinned memory, HIERARCHY and NVSHMEM are not reproduced (every table lives in HBM) and return
  * WHOLEMEMORY_NOT_SUPPORTED.  RCCL is resolved at run time (dlopen "librccl.so"), so the library loads on a CPU-only box
- * and inside a PyTorch process shares torch's RCCL.  One collective per communicator at a time (as RCCL requires).
+ * and inside a PyTorch process shares torch's RCCL.  One collective per communicator at a time (as RCCL requires): the
+ * communicator's pinned count buffer is shared by its calls, so two gathers on ONE communicator from two host threads race.
+ *
+ * Scratch and streams: a gather / scatter on a DISTRIBUTED handle synchronises the stream ONCE (the count read-back) and NOT
+ * at its end — its scratch (RCCL send / receive buffers included) goes back to p_env_fns->temporary_fns while the last
+ * kernels are still in flight.  The temporary allocator must therefore be STREAM-ORDERED ON THE `stream` ARGUMENT: a
+ * caching allocator that reuses a block only for work enqueued later on that same stream (torch's, when `stream` is torch's
+ * current stream — what wholegraph_amd.env hands over: get_stream() and the allocator callbacks both use the current
+ * stream), or one that synchronises on free (the library default: hipFree).  An allocator keyed to another stream, or a
+ * free that returns memory to other streams at once, needs an event wait in its free callback.
+ * wholememory_free of a peer-mapped handle is COLLECTIVE (device sync + barrier before the mappings are closed, barrier
+ * before the partition is released; memory_handle.cpp:1007-1029): call it on every rank, in the same order.
  */
 #ifndef WGAMD_COMM_H_
 #define WGAMD_COMM_H_

@@ -327,15 +327,18 @@ wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, con
  * grad_x [n_src, H*C], grad_a_src [n_src, H], grad_a_dst [n_rows, H]; de [E, H] is scratch.  Needs the hop CSR transposed:
  * row_ptr_t [n_src+1], edge_perm [E] (edge ids sorted by source, stable), edge_dst [E] (destination row of every edge).
  * Shapes: C % 4 == 0, C/4 a power of two, H*C <= 256 — anything else returns WHOLEMEMORY_LOGIC_ERROR.
- * workspace (wgamd_gat_csr_bwd_workspace_bytes(E, H, C) bytes; NULL = none): with it the source-major pass sums long source rows
- * in pieces of 64 entries and adds the pieces up in order (a power-law hop has hub sources with thousands of entries). */
+ * workspace (wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C) bytes; NULL = none): with it the source-major pass sums long
+ * source rows in pieces of 64 entries and adds the pieces up in order (a power-law hop has hub sources with thousands of
+ * entries).  n_entries = E, the entry count of the transposed hop (row_ptr_t[n_src]): the piece capacity is derived from it
+ * and a non-NULL workspace smaller than wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C) returns WHOLEMEMORY_INVALID_INPUT
+ * (as wgamd_spmm_csr_segmented_f32 does). */
 size_t wgamd_gat_csr_bwd_workspace_bytes(int64_t n_entries, int H, int C);
 wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x, int64_t ldx,
                                                const float* a_src, const float* a_dst, int H, int C, float negative_slope,
                                                const float* alpha, const float* grad_out, int64_t ldg, const int* row_ptr_t,
                                                const int* edge_perm, const int* edge_dst, int64_t n_src, float* de,
-                                               float* grad_x, int64_t ldgx, float* grad_a_src, float* grad_a_dst, void* workspace,
-                                               size_t workspace_bytes, void* stream);
+                                               float* grad_x, int64_t ldgx, float* grad_a_src, float* grad_a_dst,
+                                               int64_t n_entries, void* workspace, size_t workspace_bytes, void* stream);
 
 /* A whole SAGEConv layer over a sampled hop in ONE kernel (csrc/wg_sage_fused.hip):
  *   out[i,:] = act( [ mean|sum_{e in row i} X[col[e]] | X[self_rows[i]] ] @ w_t + bias ),  X[r] = x[src_ids ? src_ids[r] : r]

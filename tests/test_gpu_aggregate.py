@@ -380,3 +380,48 @@ def test_bf16x3_split_is_exact_and_product_is_fp32_class(hiplib):
     assert torch.all((got.double() - ref).abs() <= 1e-5 * scale + 1e-6)
     # and it is fp32-class, not merely inside the bound: the error is within a few fp32 ulps of the scale
     assert ((got.double() - ref).abs() / scale).max() < 2e-6
+
+
+def test_gat_backward_refuses_a_workspace_smaller_than_the_hop_needs(hiplib):
+    """The plan kernel hands out piece slots with atomics: the only bound is the workspace the entry point validated
+    (a scratch sized for fewer entries than the transposed hop holds must be refused, not overrun)."""
+    import torch
+    from wholegraph_amd import _lib as L
+    E, H, C = 5000, 4, 16
+    need = hiplib.wgamd_gat_csr_bwd_workspace_bytes(E, H, C)
+    assert need > hiplib.wgamd_gat_csr_bwd_workspace_bytes(E // 4, H, C)
+    d = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
+    i = torch.zeros(1 << 14, dtype=torch.int32, device="cuda")
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    p, q = d.data_ptr(), i.data_ptr()
+    rc = hiplib.wgamd_gat_csr_bwd_f32(q, q, 0, p, 64, p, p, H, C, 0.2, p, p, 64, q, q, q, 10, p, p, 64, p, p, E, ws.data_ptr(),
+                                      hiplib.wgamd_gat_csr_bwd_workspace_bytes(E // 4, H, C), None)
+    assert rc == L.WHOLEMEMORY_INVALID_INPUT
+    rc = hiplib.wgamd_gat_csr_bwd_f32(q, q, 0, p, 64, p, p, H, C, 0.2, p, p, 64, q, q, q, 10, p, p, 64, p, p, 0, ws.data_ptr(),
+                                      need, None)      # empty hop, full-size scratch: fine
+    assert rc == L.WHOLEMEMORY_SUCCESS
+    torch.cuda.synchronize()
+
+
+def test_sage_layer_fused_padded_head_respects_the_callers_out(hiplib):
+    """A 47-column head runs as 64 zero-padded columns.  `out` is written in place only when it is the [:, :47] view of a
+    [n, 64] scratch; a wider buffer keeps its own columns 47.. untouched and a compact [n, 47] buffer IS filled."""
+    import torch
+    from wholegraph_amd import nn
+    rp, col = _csr(300, 900, 12, 100)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((900, 100), generator=g, device="cuda")
+    w_t = torch.randn((200, 47), generator=g, device="cuda") * 0.1
+    bias = torch.randn(47, generator=g, device="cuda")
+    rows = torch.arange(300, dtype=torch.int64, device="cuda")
+    rpt, ct = torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda()
+    ref = nn.sage_layer_fused_forward(rpt, ct, x, rows, w_t, bias, relu=True)
+    scratch = torch.full((300, 64), 7.0, device="cuda")
+    a = nn.sage_layer_fused_forward(rpt, ct, x, rows, w_t, bias, relu=True, out=scratch[:, :47])
+    assert a.data_ptr() == scratch.data_ptr() and torch.equal(a, ref)
+    wide = torch.full((300, 128), 7.0, device="cuda")
+    b = nn.sage_layer_fused_forward(rpt, ct, x, rows, w_t, bias, relu=True, out=wide[:, :47])
+    assert b.data_ptr() == wide.data_ptr() and torch.equal(b, ref) and bool((wide[:, 47:] == 7.0).all())
+    compact = torch.full((300, 47), 7.0, device="cuda")
+    c = nn.sage_layer_fused_forward(rpt, ct, x, rows, w_t, bias, relu=True, out=compact)
+    assert c.data_ptr() == compact.data_ptr() and torch.equal(compact, ref)
