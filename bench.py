@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """bench.py — sampled-edges/s of the mini-batch hot path on the ogbn-products-like workload.
 
-One "step" = `batches_per_step` (default 128) mini-batches of 1024 seeds through the whole hot path with everything
-resident in HBM, processed as `--groups-per-step` (2) CALL GROUPS of `--call-group` (64) mini-batches — the launch shape
+One "step" = `batches_per_step` (default 512) mini-batches of 1024 seeds through the whole hot path with everything
+resident in HBM, processed as `--groups-per-step` (8) CALL GROUPS of `--call-group` (64) mini-batches — the launch shape
 is FIXED and does not depend on --steps:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->
 feature gather x = feat[n_id] (fp32, F=100)  ->  2-layer GraphSAGE forward (mean aggregation + lin_l/lin_r in HIP).
 `value` = sampled edges of all ranks / max-over-ranks wall time of exactly K steps (the driver's `--steps 20 --warmup 5`
-= 40 timed call groups after 10 untimed ones, a steady-state software-pipelined region of ~80 ms).
+= 160 timed call groups after 40 untimed ones, a steady-state software-pipelined region of ~0.25 s).
+
+N > 1 (one process per GPU, seeds sharded, CSR replicated): the HEADLINE is the north-star multi-GPU path — the feature table
+range-partitioned over the ranks (per = ceil(V/W)) and fetched by the RCCL all-to-all-v pipeline of wholememory_gather
+(csrc/wg_comm.hip; reference gather_op_impl_nccl.cu:23-171).  The peer-mapped fetch (HIP IPC loads over xGMI) and the
+collective-free replicated table are measured in the same run and reported under `placements`.  Before anything is timed a
+pre-flight (`selftest`) sends a known-answer table through the same exchange on every rank and compares bit for bit.
 
 Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0 with `roofline` (dominant HIP kernel, measured live with HIP
@@ -288,7 +294,7 @@ def load_pmc(kernel_prefix, want_void=True):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r02/pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS command's launch shape, FETCH_SIZE x 2 per
     MI355X_MICROARCH.md §HBM; tools/pmc_summary.py).  Counters cannot be read from inside the timed process."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if not os.path.exists(path):
             continue
@@ -306,6 +312,27 @@ def load_pmc(kernel_prefix, want_void=True):
     return None
 
 
+def load_profiled_avg(kernel):
+    """Average launch duration (ns) of the dominant kernel in the COMMITTED rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/rNN/rNN_kernel_stats.csv, newest round first).  A kernel that serves two layers appears as two template
+    instantiations; the dominant stage is the longer one.  Lets the line carry `frac_profiled` next to the live HIP-event
+    `frac`, so the two cannot drift apart unnoticed."""
+    import csv
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, rnd + "_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        with open(path, newline="") as f:
+            rows = [r for r in csv.DictReader(f) if kernel + "<" in r["Name"] or kernel + "(" in r["Name"]]
+        plain = [r for r in rows if kernel + "<void" in r["Name"]]   # not the fetch-folded variant (ids type != void)
+        rows = plain or rows
+        if rows:
+            r = max(rows, key=lambda r: float(r["AverageNs"]))
+            return {"avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"]), "min_ns": float(r["MinNs"]),
+                    "source": "profiles/%s/%s_kernel_stats.csv" % (rnd, rnd)}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,19 +344,24 @@ def main():
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--edges", type=int, default=None, help="undirected RMAT edges before symmetrising")
     ap.add_argument("--call-group", type=int, default=64, help="mini-batches per launch sequence (fixed launch shape)")
-    ap.add_argument("--groups-per-step", type=int, default=2, help="call groups per step (batches_per_step = G x this)")
+    ap.add_argument("--groups-per-step", type=int, default=8, help="call groups per step (batches_per_step = G x this)")
     ap.add_argument("--feature-placement", choices=["auto", "replicated", "partitioned", "both"], default="auto",
-                    help="N>1: 'replicated' keeps the whole table on every GPU (small next to 288 GB of HBM: no data-path "
-                         "collective); 'partitioned' range-partitions it and fetches remote rows over xGMI (RCCL "
-                         "all-to-all-v, or peer-mapped loads); auto = both for tables <= 36 GB (headline: replicated, "
-                         "the partitioned result is reported next to it), partitioned above")
+                    help="N>1: 'partitioned' range-partitions the table and fetches remote rows over xGMI (RCCL all-to-all-v = "
+                         "the HEADLINE, peer-mapped loads next to it); 'replicated' keeps the whole table on every GPU (no "
+                         "data-path collective); auto/both = all of them for tables <= 36 GB (the replicated one is measured "
+                         "first because it cannot hang, and reported under `placements`), partitioned only above")
     ap.add_argument("--id-dtype", choices=["auto", "int32", "int64"], default="auto",
-                    help="dtype of csr_col / seeds / node ids: auto = int32 when V < 2^31 (the WholeGraph test default, "
-                         "cpp/tests/wholegraph_ops/wholegraph_csr_unweighted_sample_without_replacement_tests.cu:101), else "
-                         "int64 (the cugraph_pyg convention); the other one is timed as the 'ids_int64' variant")
+                    help="dtype of csr_col / seeds / node ids: auto = int64 (the cugraph_pyg convention, data/graph_store.py:298-299 "
+                         "— the interface north_star names); int32 (the WholeGraph test default, "
+                         "cpp/tests/wholegraph_ops/wholegraph_csr_unweighted_sample_without_replacement_tests.cu:101) is timed as "
+                         "the 'ids_int32' variant when V < 2^31")
     ap.add_argument("--partitioned-fetch", choices=["auto", "mapped", "alltoall"], default="auto",
-                    help="how a partitioned table serves remote rows: mapped = peer-mapped partitions (HIP IPC, loads over xGMI "
-                         "in one kernel; single node), alltoall = RCCL all-to-all-v exchange; auto = mapped when available")
+                    help="how a partitioned table serves remote rows: alltoall = RCCL all-to-all-v exchange only; mapped = "
+                         "peer-mapped partitions only (HIP IPC, loads over xGMI in one kernel; single node); auto = both "
+                         "(headline: all-to-all)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="run the known-answer pre-flight of the feature exchange even on a single-rank communicator (it always "
+                         "runs for partitioned placements at N > 1)")
     ap.add_argument("--host-profile", action="store_true",
                     help="print (stderr) where the HOST spends a call group: enqueueing the walk, enqueueing the forward, blocked")
     ap.add_argument("--force-partitioned", action="store_true",
@@ -377,21 +409,61 @@ def main():
     args.edges = args.edges or we
     row_ptr, col = rmat_csr(args.nodes, args.edges, seed=0, device=device)
     V, E = args.nodes, int(col.shape[0])
-    id_dtype = torch.int64 if (args.id_dtype == "int64" or (args.id_dtype == "auto" and V >= (1 << 31))) else torch.int32
-    col64 = col
+    id_dtype = torch.int32 if (args.id_dtype == "int32" and V < (1 << 31)) else torch.int64
+    col_alt = None                      # the other id width, timed as a variant (single-GPU products runs only)
+    if id_dtype == torch.int64 and V < (1 << 31) and not (args.no_variants or world > 1 or args.workload != "products"):
+        col_alt = col.to(torch.int32)
     col = col.to(id_dtype)
-    if id_dtype == torch.int64 or args.no_variants or world > 1 or args.workload != "products":
-        del col64
-        col64 = None
     table_bytes = V * FEAT_DIM * 4
+    # Placements of the feature table, in MEASUREMENT order (what cannot hang first) — the headline is picked afterwards
+    # by HEAD_PREF: the range-partitioned table fetched by the RCCL all-to-all-v pipeline (north_star), then the peer-mapped
+    # fetch, then the collective-free replicated table.
+    #   "partitioned"        = WHOLEMEMORY_MT_DISTRIBUTED handle, bucketing + two all-to-all-v over RCCL
+    #   "partitioned_mapped" = WHOLEMEMORY_MT_CHUNKED handle, peer partitions mapped through HIP IPC, one gather kernel
+    #   "replicated"         = the whole table on every GPU
+    HEAD_PREF = ["partitioned", "partitioned_mapped", "replicated"]
     if args.force_partitioned:
         placements = ["partitioned"]
     elif world == 1 or args.feature_placement == "replicated":
         placements = ["replicated"]
-    elif args.feature_placement == "partitioned" or (args.feature_placement == "auto" and table_bytes > (36 << 30)):
-        placements = ["partitioned"]
-    else:           # "both", or auto with a table that is small next to HBM: headline replicated, partitioned beside it
-        placements = ["replicated", "partitioned"]
+    else:
+        part = {"auto": ["partitioned", "partitioned_mapped"], "alltoall": ["partitioned"],
+                "mapped": ["partitioned_mapped"]}[args.partitioned_fetch]
+        if args.dist_backend != "nccl":
+            part = ["partitioned"]       # the torch.distributed rehearsal path has one exchange implementation
+        if args.feature_placement == "partitioned" or (args.feature_placement == "auto" and table_bytes > (36 << 30)):
+            placements = part
+        else:
+            placements = ["replicated"] + part
+    wm_comm = None
+
+    def library_comm():
+        """ONE RCCL communicator of libwholegraph_amd for every table of this run (created on first use, collectively)."""
+        nonlocal wm_comm
+        if wm_comm is None:
+            import wholegraph_amd as wg
+            wm_comm = wg.create_group_communicator()
+        return wm_comm
+
+    def make_partitioned(placement, rows, dim, fill):
+        """A [rows, dim] fp32 table range-partitioned over the ranks; `fill(local, first_row)` writes this rank's rows."""
+        if args.dist_backend == "nccl":
+            # the table is a handle of the library: bucketing, the id / row all-to-all-v (RCCL send/recv groups) or the
+            # peer-mapped loads, and the row kernels all run inside wholememory_gather (csrc/wg_comm.hip)
+            import wholegraph_amd as wg
+            comm = library_comm()
+            mtype = "chunked" if placement == "partitioned_mapped" else "distributed"
+            if mtype == "chunked" and not (world > 1 and comm.support_type_location("chunked", "cuda")):
+                raise RuntimeError("peer-mapped memory type not available on this communicator (ranks do not share a node)")
+            t = wg.create_wholememory_tensor(comm, mtype, "cuda", [rows, dim], torch.float32, [dim, 1])
+            local, first = t.get_local_tensor()
+            fill(local, first)
+            return t
+        # torch.distributed pipeline (wholegraph_amd/dist.py); the gloo tests put two ranks on one GPU this way
+        offs = equal_entry_partition(rows, world)
+        local = torch.empty((offs[rank + 1] - offs[rank], dim), dtype=torch.float32, device=device)
+        fill(local, offs[rank])
+        return WholeMemoryTensor(local, global_rows=rows, partition_offsets=offs)
 
     def make_table(placement):
         gfeat = torch.Generator(device=device)
@@ -401,30 +473,46 @@ def main():
             gfeat.manual_seed(100)
             return WholeMemoryTensor((torch.rand((V, FEAT_DIM), generator=gfeat, device=device) * 2 - 1))
         gfeat.manual_seed(100 + rank)
-        if args.dist_backend == "nccl":
-            # the table is a DISTRIBUTED handle of the library: bucketing, the id / row all-to-all-v (RCCL send/recv
-            # groups) or the peer-mapped loads, and the row kernels all run inside wholememory_gather (csrc/wg_comm.hip)
-            import wholegraph_amd as wg
-            comm = wg.create_group_communicator()
-            # one node: the peer-mapped type (HIP IPC; remote rows are plain loads over xGMI inside ONE gather kernel);
-            # otherwise, or on request, DISTRIBUTED (bucketing + RCCL all-to-all-v)
-            mtype = "distributed"
-            if args.partitioned_fetch != "alltoall" and world > 1 and comm.support_type_location("chunked", "cuda"):
-                mtype = "chunked"
-            try:
-                t = wg.create_wholememory_tensor(comm, mtype, "cuda", [V, FEAT_DIM], torch.float32, [FEAT_DIM, 1])
-            except Exception as e:   # e.g. IPC refused by the platform: the exchange path needs nothing but RCCL
-                if mtype == "distributed" or args.partitioned_fetch == "mapped":
-                    raise
-                print("[bench] peer-mapped table unavailable (%r), using the all-to-all exchange" % (e,), file=sys.stderr)
-                t = wg.create_wholememory_tensor(comm, "distributed", "cuda", [V, FEAT_DIM], torch.float32, [FEAT_DIM, 1])
-            local = t.get_local_tensor()[0]
-            local.copy_(torch.rand(tuple(local.shape), generator=gfeat, device=device) * 2 - 1)
-            return t
-        # torch.distributed pipeline (wholegraph_amd/dist.py); the gloo tests put two ranks on one GPU this way
-        offs = equal_entry_partition(V, world)
-        local = torch.rand((offs[rank + 1] - offs[rank], FEAT_DIM), generator=gfeat, device=device) * 2 - 1
-        return WholeMemoryTensor(local, global_rows=V, partition_offsets=offs)
+        return make_partitioned(placement, V, FEAT_DIM,
+                                lambda local, first: local.copy_(torch.rand(tuple(local.shape), generator=gfeat, device=device) * 2 - 1))
+
+    def selftest(placement):
+        """Pre-flight of the exchange, before anything is timed: a KNOWN-ANSWER table (row i, column j holds
+        (3 i + j) mod 2^20, exact in fp32 — the reference pytest's `table[i,j] = i + j` idea,
+        tests/wholegraph_torch/ops/test_wholegraph_gather_scatter.py:12-27) partitioned exactly like the feature table goes
+        through the SAME gather path on every rank with 100,001 random ids (+ negatives, + both ends of every partition) and
+        must come back bit for bit; ids < 0 must leave their output rows untouched.  Returns a dict for the JSON line;
+        raises on mismatch (every rank learns the verdict through the all-reduce in the caller)."""
+        rows = 65_537 * world + 3
+        cols = torch.arange(FEAT_DIM, device=device, dtype=torch.int64).view(1, -1)
+
+        def kat(ids):
+            return ((ids.view(-1, 1) * 3 + cols) & 0xFFFFF).to(torch.float32)
+
+        t = make_partitioned(placement, rows, FEAT_DIM, lambda local, first: local.copy_(
+            kat(torch.arange(first, first + local.shape[0], device=device, dtype=torch.int64))))
+        g = torch.Generator(device=device).manual_seed(4242 + rank)
+        ids = torch.randint(0, rows, (100_001,), generator=g, device=device)
+        edges = torch.tensor(equal_entry_partition(rows, world), device=device)
+        ids[:2 * world] = torch.cat([edges[:-1], edges[1:] - 1]).clamp_(0, rows - 1)   # first / last row of every rank
+        ids[5000:5007] = -1
+        ids = ids.to(id_dtype)
+        got = t.gather(ids)
+        torch.cuda.synchronize()
+        if os.environ.get("WGAMD_BENCH_TEST_CORRUPT"):
+            got[777, 3] += 1.0        # test hook: the pre-flight must notice ONE wrong element
+        want = kat(ids.to(torch.int64))
+        live = (ids >= 0)
+        ok = bool(torch.equal(got[live], want[live]))
+        info = {"rows": rows, "ids_per_rank": int(ids.numel()), "bit_exact": ok, "path": feature_fetch_path(t)}
+        if hasattr(t, "comm") and hasattr(t.comm, "rccl_info"):
+            info["rccl_ranks"], info["rccl_version"] = t.comm.rccl_info()
+        if hasattr(t, "destroy"):
+            t.destroy()        # collective for a peer-mapped handle (every rank is here)
+        if not ok:
+            bad = int((got[live] != want[live]).any(dim=1).sum())
+            raise RuntimeError("selftest: %d of %d gathered rows differ from the known answer (%s)" % (bad, int(live.sum()), info["path"]))
+        return info
 
     # ---- step geometry: FIXED launch shape (G mini-batches per call group), independent of --steps ----
     G, gps = args.call_group, args.groups_per_step
@@ -446,6 +534,7 @@ def main():
         torch.cuda.synchronize()
 
     host_prof = {"sample_enqueue": 0.0, "forward_enqueue": 0.0, "wait_for_walk": 0.0, "groups": 0}
+    last_per_rank = []
 
     def run_groups(pipe, first, last, timers=None, sizes=None, mode="split"):
         """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
@@ -483,11 +572,13 @@ def main():
                   file=sys.stderr, flush=True)
         st = torch.tensor([secs, float(sum(sum(v[0::2]) for v in szs))], dtype=torch.float64, device=device)
         if world > 1:
-            tmax, esum = st[:1].clone(), st[1:].clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-            return float(tmax), float(esum)
-        return float(st[0]), float(st[1])
+            every = [torch.zeros_like(st) for _ in range(world)]
+            dist.all_gather(every, st)
+            per_rank = [(float(t[0]), float(t[1])) for t in every]
+        else:
+            per_rank = [(float(st[0]), float(st[1]))]
+        last_per_rank[:] = per_rank      # (seconds, edges) of every rank for the pass just measured
+        return max(t for t, _ in per_rank), sum(e for _, e in per_rank)
 
     # ---- per-stage HIP-event timing pass (same pipeline, same stream; outside the timed region) --
     def probe_stages(pipe, mode, n_groups):
@@ -510,16 +601,18 @@ def main():
 
     results = {}
     placement_errors = {}
+    selftests = {}
     def run_placement(placement, feat):
         """Measure one feature placement: headline pass, variants (first placement only), stage timings."""
         nonlocal batches
-        partitioned = placement == "partitioned"
+        partitioned = placement != "replicated"
         pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
         # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
         # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
         fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])
         head_mode = "fused" if (args.layer_kernel != "split" and fusable) else "split"
         dt, edges_total = measure(pipe, head_mode)
+        per_rank = list(last_per_rank)
         # variants on the same groups: the other layer kernel, and the feature fetch folded into layer 1
         variants = {}
         others = (["split"] if head_mode == "fused" else (["fused"] if fusable else [])) + (
@@ -532,34 +625,43 @@ def main():
                  "fused_fetch": "feature fetch + aggregation + MFMA transform of layer 1 in ONE kernel "
                                 "(wgamd_sage_layer_fused_f32 reading the feature table through n_id): x = feat[n_id] never "
                                 "exists"}
-        for m in ([] if (args.no_variants or placement != placements[0]) else others):
+        for m in ([] if (args.no_variants or world > 1) else others):
             vs, ve = measure(pipe, m)
             variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
-        if col64 is not None and placement == placements[0]:
-            # the same pipeline with int64 ids (csr_col, seeds, node lists): the cugraph_pyg convention
-            pipe64 = SagePipeline(row_ptr, col64, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
-            b32 = batches
-            batches = b32.to(torch.int64)
-            vs, ve = measure(pipe64, head_mode)
-            variants["ids_int64"] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3,
-                                     "note": "csr_col / seeds / node ids as int64 (headline: int32, V < 2^31)"}
-            batches = b32
-            del pipe64
+        if col_alt is not None and world == 1:
+            # the same pipeline with int32 ids (csr_col, seeds, node lists): the WholeGraph test default
+            pipe32 = SagePipeline(row_ptr, col_alt, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
+            b64 = batches
+            batches = b64.to(torch.int32)
+            vs, ve = measure(pipe32, head_mode)
+            variants["ids_int32"] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3,
+                                     "note": "csr_col / seeds / node ids as int32 (V < 2^31: the WholeGraph test default; "
+                                             "headline: int64, the cugraph_pyg convention)"}
+            batches = b64
+            del pipe32
         stage_n = max(10, min(groups, 20))
         stage_ms, psizes = probe_stages(pipe, head_mode, stage_n)
         # the BASELINE metric also names the stand-alone SAGEConv SpMM: time it (aggregate kernel + GEMM) when the
         # headline path runs the layer as one kernel
         split_ms = probe_stages(pipe, "split", 10)[0] if head_mode != "split" else stage_ms
         results[placement] = dict(dt=dt, edges=edges_total, variants=variants, stage_ms=stage_ms, psizes=psizes,
-                                  split_ms=split_ms, head_mode=head_mode, stage_n=stage_n, pipe=pipe, feat=feat)
-        if placement != placements[-1]:
-            results[placement]["pipe_dims"] = pipe.dims
+                                  split_ms=split_ms, head_mode=head_mode, stage_n=stage_n, pipe=pipe, feat=feat,
+                                  per_rank=per_rank)
 
     def emit_line():
-        """Rank 0 prints the ONE JSON line from whatever placements were measured (headline = placements[0])."""
-        head = results[placements[0]]
+        """Rank 0 prints the ONE JSON line from whatever placements were measured; the headline is the first of HEAD_PREF
+        that went through (N > 1: the RCCL all-to-all-v exchange).  Nothing measured = an error line, exit code 1."""
+        measured = [p_ for p_ in HEAD_PREF if p_ in results]
+        if not measured:
+            if rank == 0:
+                print(json.dumps({"metric": "sampled-edges/sec", "value": None, "unit": "sampled-edges/s", "n_gpus": world,
+                                  "error": "no feature placement could be measured", "placement_errors": placement_errors,
+                                  "selftest": selftests}), flush=True)
+            return False
+        head_name = measured[0]
+        head = results[head_name]
         pipe, feat = head["pipe"], head["feat"]
-        partitioned = placements[0] == "partitioned"
+        partitioned = head_name != "replicated"
         dt, edges_total, variants, stage_ms, psizes, split_ms, head_mode, stage_n = (
             head[k] for k in ("dt", "edges", "variants", "stage_ms", "psizes", "split_ms", "head_mode", "stage_n"))
         fused = variants.get("fused_fetch") or variants.get("split_fetch")
@@ -599,6 +701,12 @@ def main():
                             "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                       f"{G} mini-batches, averaged over {stage_n} call groups"}
             std_shape = args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we
+            if roofline is not None and std_shape:
+                prof = load_profiled_avg(roofline["kernel"])
+                if prof:    # the same algorithmic bytes over the committed profile's average launch duration
+                    roofline["frac_profiled"] = round(kernels[dom][1] / (prof["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)
+                    roofline["profiled_avg_launch_ms"] = round(prof["avg_ns"] * 1e-6, 5)
+                    roofline["profiled_source"] = "%s (%d launches, min %.1f us)" % (prof["source"], prof["calls"], prof["min_ns"] * 1e-3)
             if roofline is not None and std_shape:
                 hit = load_pmc(roofline["kernel"])
                 if hit:
@@ -668,7 +776,7 @@ def main():
                 "higher_is_better": True,
                 "scaling": "weak",
                 "vs_baseline": None,
-                "dtype": ("int32" if id_dtype == torch.int32 else "int64") + " ids + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
+                "dtype": ("int32" if id_dtype == torch.int32 else "int64") + " ids (int32 timed as a variant) + f32 features" + ("" if head_mode != "fused" or prec == "f32" else
                                                        " (SAGE lin_l/lin_r product: bf16x3-split MFMA, f32 accumulate)"),
                 "data": "synthetic",
                 "config": {"workload": wl_name + "-like RMAT: V=%d, E=%d directed (CSR row_ptr i64 / col %s replicated per GPU), "
@@ -678,7 +786,7 @@ def main():
                                           " range-partitioned + xGMI feature fetch" if partitioned else
                                           ("" if world == 1 else " replicated per GPU"),
                                           BATCH, FANOUT, L, "-".join(str(d) for d in pipe.dims), gps, G),
-                           "parallelism": ("dp%d seeds + feature all-to-all" % world) if partitioned
+                           "parallelism": ("dp%d seeds + feature all-to-all (%s)" % (world, feature_fetch_path(feat))) if partitioned
                            else "dp%d (seeds sharded, no data-path collective)" % world},
                 "call_group": G,
                 "batches_per_step": G * gps,
@@ -704,106 +812,124 @@ def main():
                 out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
             if placement_errors:
                 out["placement_errors"] = placement_errors
-            if len(placements) > 1 or partitioned:
-                # the north-star exchange path next to the collective-free one: per-GPU xGMI bytes of the feature fetch and the
-                # fraction of the (world-1) x 153 GB/s links it sustains (SURVEY §8(d) all-to-all bytes: n_remote (b + 4F))
-                pr = results["partitioned"]
-                p_e = [sum(s[2 * k] for s in pr["psizes"]) / pr["stage_n"] for k in range(L)]
-                p_src = sum(s[2 * L - 1] for s in pr["psizes"]) / pr["stage_n"]
-                n_remote = p_src * (world - 1) / max(world, 1)
-                a2a = n_remote * (idb + 4 * F)
-                gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
-                gms = pr["stage_ms"].get(gname) if gname else None
+            if world > 1 or partitioned:
+                # every measured placement side by side; for the partitioned ones the per-GPU xGMI bytes of the feature fetch
+                # (SURVEY §8(d) all-to-all bytes: n_remote (b + 4F)) and the fraction of the (world-1) x 153 GB/s links they
+                # sustain during the gather stage
                 link_peak = max(world - 1, 1) * 153.0
-                out["placements"] = {
-                    "replicated": None if "replicated" not in results else {
-                        "value": results["replicated"]["edges"] / results["replicated"]["dt"],
-                        "ms_per_step": results["replicated"]["dt"] / args.steps * 1e3},
-                    "partitioned": {"value": pr["edges"] / pr["dt"], "ms_per_step": pr["dt"] / args.steps * 1e3,
-                                    "gather_stage": gname, "gather_ms_per_call_group": None if gms is None else round(gms, 4),
-                                    "feature_fetch": feature_fetch_path(pr["feat"])}}
-                out["all_to_all_bytes_per_gpu"] = int(a2a)
-                out["xgmi_frac"] = None if (gms is None or world == 1) else round(a2a / (gms * 1e-3) / 1e9 / link_peak, 4)
+
+                def report(name):
+                    pr = results[name]
+                    rep = {"value": pr["edges"] / pr["dt"], "ms_per_step": pr["dt"] / args.steps * 1e3,
+                           "per_rank_value": [round(e_ / t_, 1) for t_, e_ in pr["per_rank"]]}
+                    if name != "replicated":
+                        p_src = sum(s_[2 * L - 1] for s_ in pr["psizes"]) / pr["stage_n"]
+                        a2a = p_src * (world - 1) / max(world, 1) * (idb + 4 * F)
+                        gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
+                        gms = pr["stage_ms"].get(gname) if gname else None
+                        rep.update(gather_stage=gname, gather_ms_per_call_group=None if gms is None else round(gms, 4),
+                                   feature_fetch=feature_fetch_path(pr["feat"]), all_to_all_bytes_per_gpu=int(a2a),
+                                   xgmi_frac=None if (gms is None or world == 1) else round(a2a / (gms * 1e-3) / 1e9 / link_peak, 4))
+                    return rep
+                out["headline_placement"] = head_name
+                out["placements"] = {name: report(name) for name in HEAD_PREF if name in results}
+                out["per_rank_value"] = out["placements"][head_name]["per_rank_value"]
                 out["xgmi_peak_GBps"] = link_peak
-                out["edges_per_call_group_partitioned"] = p_e
+                if partitioned:
+                    out["all_to_all_bytes_per_gpu"] = out["placements"][head_name]["all_to_all_bytes_per_gpu"]
+                    out["xgmi_frac"] = out["placements"][head_name]["xgmi_frac"]
+                st = selftests.get(head_name) or {}
+                out["rccl_ranks"] = st.get("rccl_ranks")
+                out["rccl_version"] = st.get("rccl_version")
+            if selftests:
+                out["selftest"] = selftests
             # RCCL writes a version banner through C stdio; push it out first so the JSON is the LAST line
             import ctypes
             ctypes.CDLL(None).fflush(None)
             print(json.dumps(out), flush=True)
+        return True
 
     def arm_watchdog(seconds, what):
-        """The also-measured placement runs collectives this build has only ever run on one GPU: if it has not finished
-        in time (a rank threw inside a collective and left the others waiting), the headline line is printed from what
-        IS measured and the process ends — a scaling run never loses its line to the extra pass."""
+        """A placement with collectives in it runs under a watchdog: if it has not finished in time (a rank threw inside a
+        collective and left the others waiting), the line is printed from what IS measured — the placements are measured
+        safest first — and the process ends: a scaling run never loses its line to a path that hangs."""
         import threading
 
         def fire():
-            placement_errors[what] = "timed out after %d s (watchdog); headline unaffected" % seconds
-            while len(placements) > 1:
-                placements.pop()
+            placement_errors[what] = "timed out after %d s (watchdog)" % seconds
+            results.pop(what, None)
+            ok = False
             try:
-                emit_line()
+                ok = emit_line()
             finally:
-                os._exit(0)
+                os._exit(0 if ok else 1)
         t = threading.Timer(seconds, fire)
         t.daemon = True
         t.start()
         return t
 
+    import signal
     for placement in list(placements):
-        if placement != placements[0]:
-            # the second, "also measured" placement must never cost the headline its JSON line: every rank agrees on
-            # whether the table could be built before anyone enters a collective of the measurement, the measurement itself
-            # runs under a watchdog, and every rank agrees again on whether it went through
-            dog = arm_watchdog(args.extra_placement_timeout, placement)
-            # ... and if another rank DIES in it (a fault is not an exception), the launcher sends SIGTERM to the rest: rank 0
-            # answers with the line it already has instead of going down with it
-            import signal
+        protected = world > 1 or placement != "replicated"
+        if not protected:
+            run_placement(placement, make_table(placement))
+            continue
+        # Every rank agrees on whether the table could be built and the pre-flight passed before anyone enters a collective
+        # of the measurement; the measurement runs under the watchdog; every rank agrees again on whether it went through.
+        dog = arm_watchdog(args.extra_placement_timeout, placement)
 
-            def on_term(signum, _frame, what=placement):
-                placement_errors[what] = "a rank died during the also-measured placement (signal %d); headline unaffected" % signum
-                while len(placements) > 1:
-                    placements.pop()
-                try:
-                    emit_line()
-                finally:
-                    os._exit(0)
-            old_term = signal.signal(signal.SIGTERM, on_term) if world > 1 else None
+        # ... and if another rank DIES in it (a fault is not an exception), the launcher sends SIGTERM to the rest: rank 0
+        # answers with the line it already has instead of going down with it
+        def on_term(signum, _frame, what=placement):
+            placement_errors[what] = "a rank died during this placement (signal %d)" % signum
+            results.pop(what, None)
+            ok = False
             try:
-                feat = make_table(placement)
-                ok = 1
-            except Exception as e:       # noqa: BLE001
+                ok = emit_line()
+            finally:
+                os._exit(0 if ok else 1)
+        old_term = signal.signal(signal.SIGTERM, on_term) if world > 1 else None
+        hooks = placement != placements[0]       # test hooks act on the first placement after the first
+        feat, ok = None, 1
+        try:
+            if placement != "replicated" and (world > 1 or args.selftest):
+                selftests[placement] = selftest(placement)
+            feat = make_table(placement)
+        except Exception as e:       # noqa: BLE001
+            placement_errors[placement] = repr(e)
+            if placement in selftests or placement == "replicated":
+                pass
+            else:
+                selftests[placement] = {"bit_exact": False, "error": repr(e)}
+            ok = 0
+        flag = torch.tensor([ok], device=device)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag) == 1:
+            try:
+                if hooks and os.environ.get("WGAMD_BENCH_TEST_STALL") and rank == world - 1:
+                    time.sleep(10 ** 6)      # test hook: one rank never reaches the collectives of this pass
+                if hooks and os.environ.get("WGAMD_BENCH_TEST_DIE") and rank == world - 1:
+                    os.kill(os.getpid(), signal.SIGKILL)   # test hook: one rank dies in this pass
+                run_placement(placement, feat)
+            except Exception as e:   # noqa: BLE001
                 placement_errors[placement] = repr(e)
-                feat, ok = None, 0
+                ok = 0
             flag = torch.tensor([ok], device=device)
             if world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag) == 1:
-                try:
-                    if os.environ.get("WGAMD_BENCH_TEST_STALL") and rank == world - 1:
-                        time.sleep(10 ** 6)      # test hook: one rank never reaches the collectives of the extra pass
-                    if os.environ.get("WGAMD_BENCH_TEST_DIE") and rank == world - 1:
-                        os.kill(os.getpid(), signal.SIGKILL)   # test hook: one rank dies in the extra pass
-                    run_placement(placement, feat)
-                except Exception as e:   # noqa: BLE001
-                    placement_errors[placement] = repr(e)
-                    ok = 0
-                flag = torch.tensor([ok], device=device)
-                if world > 1:
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            dog.cancel()
-            if world > 1:
-                signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
-            if int(flag) == 0:
-                placement_errors.setdefault(placement, "another rank could not build / measure the partitioned table")
-                placements.remove(placement)
-                results.pop(placement, None)
-        else:
-            run_placement(placement, make_table(placement))
-    emit_line()
+        dog.cancel()
+        if world > 1:
+            signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
+        if int(flag) == 0:
+            placement_errors.setdefault(placement, "another rank could not build / verify / measure this placement")
+            results.pop(placement, None)
+    ok = emit_line()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 def feature_fetch_path(feat):

@@ -78,6 +78,8 @@ struct rccl_api {
   decltype(&ncclGroupStart) GroupStart     = nullptr;
   decltype(&ncclGroupEnd) GroupEnd         = nullptr;
   decltype(&ncclGetErrorString) ErrString  = nullptr;
+  decltype(&ncclCommCount) CommCount       = nullptr;   // optional: only the rccl_info accessor uses it
+  decltype(&ncclGetVersion) GetVersion     = nullptr;   // optional
   bool ok                                  = false;
 };
 
@@ -108,6 +110,8 @@ rccl_api& rccl()
     api.GroupStart   = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
     api.GroupEnd     = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
     api.ErrString    = reinterpret_cast<decltype(api.ErrString)>(sym("ncclGetErrorString"));
+    api.CommCount    = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+    api.GetVersion   = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Send && api.Recv &&
              api.GroupStart && api.GroupEnd;
   });
@@ -702,6 +706,21 @@ wholememory_error_code_t wholememory_communicator_get_size(int* size, wholememor
   if (!size || !comm) return WHOLEMEMORY_INVALID_INPUT;
   *size = comm->size;
   return WHOLEMEMORY_SUCCESS;
+}
+
+/* What the collective library itself says about this communicator: ncclCommCount (number of ranks RCCL joined) and
+ * ncclGetVersion.  bench.py prints both so a scaling line shows that RCCL — not a stand-in — carried the exchange. */
+wholememory_error_code_t wgamd_communicator_rccl_info(wholememory_comm_t comm, int* rccl_ranks, int* rccl_version)
+{
+  return guarded("wgamd_communicator_rccl_info", [&] {
+    WG_REQUIRE_INPUT(comm != nullptr && rccl_ranks != nullptr, "null argument");
+    *rccl_ranks = -1;
+    if (rccl_version) *rccl_version = -1;
+    auto& api = rccl();
+    if (!api.ok) throw comm_error("RCCL not loaded");
+    if (api.CommCount) WG_NCCL_CHECK(api.CommCount(comm->nccl, rccl_ranks));
+    if (rccl_version && api.GetVersion) WG_NCCL_CHECK(api.GetVersion(rccl_version));
+  });
 }
 
 wholememory_error_code_t wholememory_communicator_barrier(wholememory_comm_t comm)

@@ -146,6 +146,7 @@ SYMBOLS = {
     "wholememory_communicator_get_rank": (c_int, [POINTER(c_int), c_void_p]),
     "wholememory_communicator_get_size": (c_int, [POINTER(c_int), c_void_p]),
     "wholememory_communicator_barrier": (c_int, [c_void_p]),
+    "wgamd_communicator_rccl_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "wgamd_get_peer_pointers": (c_int, [POINTER(c_void_p), c_void_p]),
     "wgamd_ipc_export": (c_int, [c_void_p, c_void_p]),
     "wgamd_ipc_open": (c_int, [c_void_p, POINTER(c_void_p)]),

@@ -52,6 +52,13 @@ class WholeMemoryCommunicator(object):
         """Device-side 1-int all-reduce + host sync on the default stream (comm.py:95-104)."""
         L.check(L.lib().wholememory_communicator_barrier(self.c_comm), "communicator_barrier")
 
+    def rccl_info(self):
+        """(ranks, version) as RCCL itself reports them for this communicator (ncclCommCount / ncclGetVersion; -1 where the
+        loaded library has no such symbol)."""
+        n, v = ctypes.c_int(-1), ctypes.c_int(-1)
+        L.check(L.lib().wgamd_communicator_rccl_info(self.c_comm, ctypes.byref(n), ctypes.byref(v)), "communicator_rccl_info")
+        return n.value, v.value
+
     def support_type_location(self, memory_type: str, memory_location: str) -> bool:
         rc = L.lib().wholememory_communicator_support_type_location(
             self.c_comm, memory_type_code(memory_type), memory_location_code(memory_location))

@@ -62,6 +62,9 @@ wholememory_error_code_t wholememory_communicator_support_type_location(
 wholememory_error_code_t wholememory_communicator_get_rank(int* rank, wholememory_comm_t comm);
 wholememory_error_code_t wholememory_communicator_get_size(int* size, wholememory_comm_t comm);
 wholememory_error_code_t wholememory_communicator_barrier(wholememory_comm_t comm);
+/* (no reference counterpart) what RCCL itself reports for the communicator: ncclCommCount and ncclGetVersion (-1 where the
+ * loaded library lacks the symbol) — evidence in bench.py's line that the exchange ran over RCCL with that many ranks */
+wholememory_error_code_t wgamd_communicator_rccl_info(wholememory_comm_t comm, int* rccl_ranks, int* rccl_version);
 
 /* wholememory.h:225-236 — total_size bytes split into entries of data_granularity bytes; rank_entry_partition
  * (entries per rank, nullable) overrides the equal split of wholememory_equal_entry_partition_plan. */

@@ -179,6 +179,11 @@ ncclResult_t ncclAllReduce(const void* in, void* out, size_t count, ncclDataType
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const comm* c, int* count)
+{
+  *count = c->w->size;
+  return ncclSuccess;
+}
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : "fake-rccl error"; }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(nproc, extra, env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
-           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--no-variants"] + extra
+           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--groups-per-step", "2", "--no-variants"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -40,11 +40,18 @@ def test_two_ranks_on_one_gpu_control_flow(hiplib):
     e2 = sum(v for k, v in two["edges_per_batch"].items() if k.startswith("hop"))
     assert abs(e1 - e2) / e1 < 0.1
     assert 1.6 < (two["value"] * two["ms_per_step"]) / (one["value"] * one["ms_per_step"]) < 2.4
-    assert "dp2" in two["config"]["parallelism"]
-    # N > 1 with a small table: the headline is the collective-free replicated placement, the partitioned (exchange)
-    # result is measured in the same run and reported next to it
-    assert set(two["placements"]) == {"replicated", "partitioned"} and two["placements"]["partitioned"]["value"] > 0
+    assert "dp2" in two["config"]["parallelism"] and "all-to-all" in two["config"]["parallelism"]
+    # N > 1: the HEADLINE is the north-star path — range-partitioned table + all-to-all exchange; the collective-free replicated
+    # placement is measured first (it cannot hang) and reported next to it
+    assert two["headline_placement"] == "partitioned"
+    assert set(two["placements"]) == {"replicated", "partitioned"} and two["placements"]["replicated"]["value"] > 0
+    assert two["value"] == two["placements"]["partitioned"]["value"]
     assert two["all_to_all_bytes_per_gpu"] > 0 and two["xgmi_frac"] > 0
+    # per-rank values (so that N = 1 can be compared with a rank of N > 1) and the pre-flight's verdict
+    assert len(two["per_rank_value"]) == 2 and all(v > 0 for v in two["per_rank_value"])
+    assert sum(two["per_rank_value"]) >= two["value"] * 0.999
+    assert two["selftest"]["partitioned"]["bit_exact"] is True and two["selftest"]["partitioned"]["ids_per_rank"] == 100001
+    assert "rccl_ranks" in two      # None here: the gloo rehearsal has no RCCL communicator
 
 
 def test_partitioned_feature_store_two_ranks(hiplib):
@@ -52,7 +59,7 @@ def test_partitioned_feature_store_two_ranks(hiplib):
     d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--feature-placement", "partitioned"])
     assert "all-to-all" in d["config"]["parallelism"] and d["n_gpus"] == 2
     assert any(k.startswith("gather(") for k in d["stage_ms_per_call_group"])
-    assert d["placements"]["replicated"] is None and d["all_to_all_bytes_per_gpu"] > 0
+    assert set(d["placements"]) == {"partitioned"} and d["all_to_all_bytes_per_gpu"] > 0 and d["headline_placement"] == "partitioned"
 
 
 def test_stalled_extra_placement_does_not_cost_the_headline(hiplib):
@@ -60,7 +67,8 @@ def test_stalled_extra_placement_does_not_cost_the_headline(hiplib):
     (replicated placement) with the reason, every rank exits 0."""
     d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--extra-placement-timeout", "20"], env={"WGAMD_BENCH_TEST_STALL": "1"})
     assert d["n_gpus"] == 2 and d["value"] > 0 and "replicated" in d["config"]["parallelism"] or "dp2" in d["config"]["parallelism"]
-    assert "timed out" in d["placement_errors"]["partitioned"] and "placements" not in d
+    assert "timed out" in d["placement_errors"]["partitioned"] and set(d["placements"]) == {"replicated"}
+    assert d["headline_placement"] == "replicated"
 
 
 def test_rank_dying_in_the_extra_placement_does_not_cost_the_headline(hiplib):
@@ -68,9 +76,29 @@ def test_rank_dying_in_the_extra_placement_does_not_cost_the_headline(hiplib):
     the others and rank 0 answers with the headline line it already has (the launcher itself then reports the failed worker)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--no-variants", "--dist-backend", "gloo", "--share-gpu"]
+           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--groups-per-step", "2", "--no-variants", "--dist-backend", "gloo",
+           "--share-gpu"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGAMD_BENCH_TEST_DIE="1"))
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "died" in d["placement_errors"]["partitioned"]
+    assert d["headline_placement"] == "replicated"
+
+
+def test_single_rank_rccl_exchange_with_selftest(hiplib):
+    """--force-partitioned at N = 1: the library's DISTRIBUTED handle over a REAL (single-rank) RCCL communicator, with the
+    known-answer pre-flight; the line carries what RCCL itself reports (ncclCommCount)."""
+    d = _run(1, ["--force-partitioned", "--selftest", "--no-cpu-baseline"])
+    assert d["headline_placement"] == "partitioned" and d["rccl_ranks"] == 1
+    assert d["selftest"]["partitioned"]["bit_exact"] is True and d["value"] > 0
+
+
+def test_a_failing_selftest_is_loud(hiplib):
+    """A pre-flight that does not come back bit-exact takes the placement out (here: the only one) — error line, exit code 1."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nodes", "100000", "--edges", "1000000",
+           "--call-group", "8", "--groups-per-step", "1", "--no-variants", "--force-partitioned", "--selftest", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGAMD_BENCH_TEST_CORRUPT="1"))
+    assert p.returncode == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert d["value"] is None and "selftest" in d["placement_errors"]["partitioned"]
