@@ -98,7 +98,7 @@ class SagePipeline:
     block-diagonal concatenation.  Groups are software-pipelined: the walk of group g+1 is enqueued
     before the host reads the (tiny, pinned) size vector of group g, so the GPU queue never drains."""
 
-    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True, walk_priority=0):
+    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True, walk_priority=0, walk_stream=None):
         from wholegraph_amd import fused, nn
         self.nn = nn
         self.device = device
@@ -120,7 +120,8 @@ class SagePipeline:
         self.fused_relu = hasattr(torch, "_addmm_activation")
         # the walk's kernels are short and feed the NEXT group: on a high-priority stream they take the wave slots that free
         # up between the long streaming kernels of the forward pass instead of queueing behind them
-        self.walk_stream = torch.cuda.Stream(device=device, priority=walk_priority) if overlap_walk else None
+        self.walk_stream = walk_stream if walk_stream is not None else (
+            torch.cuda.Stream(device=device, priority=walk_priority) if overlap_walk else None)
         self.host_wait_s = 0.0
         self.rs_base = None
         self.distributed = self.feat.is_distributed
@@ -249,6 +250,22 @@ class SagePipeline:
         return h, tuple(v for pair in sz for v in pair)
 
 
+def masked_stream(device, first_cu, n_cus):
+    """A HIP stream whose kernels may only occupy CUs [first_cu, first_cu + n_cus) of the CU-mask enumeration
+    (hipExtStreamCreateWithCUMask), wrapped for torch.  The runtime spreads the bits of the mask over the XCDs, so a
+    contiguous bit range is an equal share of every XCD."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * 16)()
+    for cu in range(first_cu, first_cu + n_cus):
+        words[cu // 32] |= 1 << (cu % 32)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 16, words)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 def usable_cpus():
     """CPUs this process may really use: affinity mask capped by the cgroup quota (a container that
     reports 128 cores but is throttled to a few makes spinning OpenMP threads stall for tens of ms)."""
@@ -368,6 +385,10 @@ def main():
                     help="test aid: take the N>1 code path (RCCL all-to-all feature store) with a single rank")
     ap.add_argument("--no-overlap", action="store_true", help="run the walk on the main stream (no second HIP stream)")
     ap.add_argument("--walk-priority", type=int, default=0, help="HIP stream priority of the walk stream (-1 = high)")
+    ap.add_argument("--walk-cus", type=int, default=0,
+                    help="> 0: SPATIAL partition of the chip — the walk stream may only occupy this many CUs and the forward "
+                         "pass (gather, SAGE layers) only the others (hipExtStreamCreateWithCUMask), so the walk's chain of "
+                         "small dependent kernels is always resident instead of waiting for the persistent layer kernel")
     ap.add_argument("--layer-kernel", choices=["auto", "fused", "split"], default="auto",
                     help="auto/fused: every SAGE layer whose shape allows it runs as ONE kernel (neighbour rows -> LDS "
                          "operand tile -> MFMA); split: aggregation kernel + library GEMM per layer.  The other one is "
@@ -554,6 +575,12 @@ def main():
             pending = nxt
 
     def measure(pipe, mode):
+        if fwd_masked is not None:
+            with torch.cuda.stream(fwd_masked):
+                return measure_(pipe, mode)
+        return measure_(pipe, mode)
+
+    def measure_(pipe, mode):
         """warm-up steps, then EXACTLY args.steps steps between barriers; (max seconds over ranks, total edges)"""
         run_groups(pipe, 0, warm_groups, mode=mode)
         barrier()
@@ -582,6 +609,12 @@ def main():
 
     # ---- per-stage HIP-event timing pass (same pipeline, same stream; outside the timed region) --
     def probe_stages(pipe, mode, n_groups):
+        if fwd_masked is not None:
+            with torch.cuda.stream(fwd_masked):
+                return probe_stages_(pipe, mode, n_groups)
+        return probe_stages_(pipe, mode, n_groups)
+
+    def probe_stages_(pipe, mode, n_groups):
         acc, sizes_p = {}, []
         for g in range(warm_groups, warm_groups + n_groups):
             timers = []
@@ -602,11 +635,17 @@ def main():
     results = {}
     placement_errors = {}
     selftests = {}
+    walk_masked = fwd_masked = None
+    if args.walk_cus > 0:
+        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        walk_masked = masked_stream(device, n_cu - args.walk_cus, args.walk_cus)
+        fwd_masked = masked_stream(device, 0, n_cu - args.walk_cus)
     def run_placement(placement, feat):
         """Measure one feature placement: headline pass, variants (first placement only), stage timings."""
         nonlocal batches
         partitioned = placement != "replicated"
-        pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
+        pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority,
+                            walk_stream=walk_masked)
         # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
         # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
         fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <stdexcept>
 #include <vector>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "wgamd_ops.h"
 #include "wgamd_tensor.h"
@@ -193,6 +195,39 @@ inline void* output_alloc(wholememory_env_func_t* env, void* memory_context, int
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Compute units a launch on `stream` can occupy: the popcount of the stream's CU mask (hipExtStreamCreateWithCUMask:
+// a caller may give the walk and the forward pass disjoint slices of the chip), else the device's CU count.  Kernels that
+// run ONE persistent workgroup per CU size their grid from this, so a masked stream never queues a second round of
+// workgroups behind the first.  Cached per stream handle (the query is a runtime call).
+inline int stream_cu_count(hipStream_t stream)
+{
+  static std::mutex m;
+  static std::unordered_map<void*, int> cache;
+  {
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find(static_cast<void*>(stream));
+    if (it != cache.end()) return it->second;
+  }
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int n = cus;
+  if (stream != nullptr) {
+    uint32_t mask[32] = {0};
+    if (hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
+      int bits = 0;
+      for (uint32_t w : mask) bits += __builtin_popcount(w);
+      if (bits > 0 && bits < cus) n = bits;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  std::lock_guard<std::mutex> g(m);
+  if (cache.size() > 256) cache.clear();   // stream handles can be recycled by the runtime: keep the table small
+  cache[static_cast<void*>(stream)] = n;
+  return n;
+}
 
 // A size that lives either on the host (ABI ops: the value is known) or on the device (no-sync
 // walk: `dev` points at it and `host` is only the capacity used to size the grid).

@@ -317,9 +317,7 @@ template <typename IdT, int LG, int WAVES>
 void launch(const layer_args& a, hipStream_t st)
 {
   const size_t tile_bytes = sizeof(float) * (size_t)kTileRows * (size_t)tile_stride(a.F);
-  int dev = 0, cus = 256;
-  WG_HIP_CHECK(hipGetDevice(&dev));
-  WG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int cus         = stream_cu_count(st);
   const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   const size_t b_bytes  = 0;
   // WGAMD_SAGE_NO_PINGPONG=1: single-team workgroups even when two tiles fit (tuning aid, F > 128 only)

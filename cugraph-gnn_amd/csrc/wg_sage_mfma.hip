@@ -48,6 +48,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4  = __attribute__((ext_vector_type(4))) uint32_t;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+#ifndef WG_MFMA_PRODUCTS
+#define WG_MFMA_PRODUCTS 6   // (tuning only: fewer products = wrong results, used to price the matrix work)
+#endif
 #ifndef WG_MFMA_DEPTH
 #define WG_MFMA_DEPTH 2   // destination rows in flight per producer lane group
 #endif
@@ -363,7 +366,7 @@ __device__ __forceinline__ void mma_frags(f32x16 (&c)[RT][2], const afrag_t<RT>&
   constexpr int pa[6] = {2, 0, 1, 1, 0, 0};
   constexpr int pb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-  for (int t = 0; t < 6; t++)
+  for (int t = 0; t < WG_MFMA_PRODUCTS; t++)
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -791,9 +794,7 @@ __host__ inline bool use_half_tiles(int F)
 template <typename IdT, int LG, int CW>
 void launch_half(mfma_args a, hipStream_t st)
 {
-  int dev = 0, cus = 256;
-  WG_HIP_CHECK(hipGetDevice(&dev));
-  WG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int cus         = stream_cu_count(st);
   a.SD                  = row_stride_half_dw(a.F);
   const int64_t n_tiles = (a.n_rows + 63) / 64;
   const size_t lds      = lds_bytes_half(a.F);
@@ -810,9 +811,7 @@ void launch_half(mfma_args a, hipStream_t st)
 template <typename IdT, int LG, int TR, int CW, int FC = 0>
 void launch(const mfma_args& a, hipStream_t st)
 {
-  int dev = 0, cus = 256;
-  WG_HIP_CHECK(hipGetDevice(&dev));
-  WG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int cus         = stream_cu_count(st);
   const int64_t n_tiles = (a.n_rows + TR - 1) / TR;
   const size_t lds      = lds_bytes(a.F, TR);
   // ONE workgroup per CU: the SIMD role split needs the CU to itself (two waves per SIMD)

@@ -11,7 +11,8 @@ from ctypes import (CFUNCTYPE, POINTER, Structure, c_bool, c_float, c_int, c_int
                     c_ulonglong, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libwholegraph_amd.so"))
+# WGAMD_LIBRARY_PATH: another build of the same library (kernel tuning A/B runs); it must exist — there is no fallback
+LIB_PATH = os.environ.get("WGAMD_LIBRARY_PATH") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libwholegraph_amd.so"))
 
 WHOLEMEMORY_MAX_TENSOR_DIM = 8
 
