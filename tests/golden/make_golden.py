@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle  # noqa: E402
-from graphgen import powerlaw_csr, random_csr  # noqa: E402
+from graphgen import powerlaw_csr, random_csr, sage_layer_case  # noqa: E402
 
 
 def karate_csr():
@@ -73,6 +73,32 @@ def main():
     out["pl_csr_row_ptr_1"], out["pl_csr_col_ind_1"] = orp[1], oci[1]
     np.savez_compressed(os.path.join(HERE, "hotpath_golden.npz"), **out)
     print("wrote", len(out), "arrays")
+    sage_layer_golden()
+
+
+def sage_layer_golden():
+    """Freezes a SAGE layer (F=100 -> 256, ReLU, mean) at the products shape: fp64 expectations for 512 sampled rows of a
+    block-diagonal 8-batch hop, so that fp32 results stay put across kernel rewrites (tests/test_gpu_aggregate.py).  The
+    inputs are regenerated from the seed by tests/graphgen.sage_layer_case; their checksum is stored with the fixture."""
+    import hashlib
+    rp, col, self_rows, x, w_t, bias = sage_layer_case()
+    n_dst = rp.size - 1
+    rng = np.random.default_rng(7)
+    rows = np.unique(np.concatenate([rng.integers(0, n_dst, 500), [0, n_dst - 1], np.nonzero(np.diff(rp) == 0)[0][:10]]))
+    cat = np.zeros((rows.size, 2 * x.shape[1]), np.float64)
+    for j, r in enumerate(rows):
+        nb = col[rp[r]:rp[r + 1]]
+        if nb.size:
+            cat[j, :x.shape[1]] = x[nb].astype(np.float64).sum(0) / nb.size
+        cat[j, x.shape[1]:] = x[self_rows[r]]
+    pre = cat @ w_t.astype(np.float64) + bias
+    scale = np.abs(cat) @ np.abs(w_t).astype(np.float64) + np.abs(bias)
+    h = hashlib.sha256()
+    for a in (rp, col, self_rows, x, w_t, bias):
+        h.update(np.ascontiguousarray(a).tobytes())
+    np.savez_compressed(os.path.join(HERE, "sage_layer_golden.npz"), rows=rows, pre_activation=pre, scale=scale,
+                        inputs_sha256=np.array(h.hexdigest()))
+    print("sage layer golden:", rows.size, "rows of", n_dst, "; inputs sha256", h.hexdigest()[:16])
 
 
 if __name__ == "__main__":

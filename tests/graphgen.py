@@ -38,3 +38,32 @@ def powerlaw_csr(n_nodes, avg_deg, seed, col_dtype=np.int64, max_deg=None, alpha
     col[half:] = rng.integers(0, n_nodes, E - half)
     rng.shuffle(col)
     return row_ptr, col.astype(col_dtype)
+
+
+def sage_layer_case(seed=2026, G=8, F=100, N=256, fanout=10):
+    """A SAGE layer-1 input shaped like the products call group of bench.py, scaled to G mini-batches: a block-diagonal hop
+    (batch b's destination rows only reference batch b's segment of x; the targets are the first rows of the segment, so
+    self_rows[i] = segment start + i), degrees min(power-law, fan-out) with empty rows, x ~ U(-1, 1), weights ~ U(-.05, .05)
+    as bench.py initialises them.  Shared by tests/golden/make_golden.py (freezes fp64 expectations) and the GPU test."""
+    rng = np.random.default_rng(seed)
+    n_dst_b = rng.integers(2000, 2800, G)
+    n_src_b = n_dst_b + rng.integers(5000, 8000, G)
+    src_off = np.concatenate([[0], np.cumsum(n_src_b)])
+    deg, cols, self_rows = [], [], []
+    for b in range(G):
+        d = np.minimum(rng.zipf(1.6, n_dst_b[b]), fanout)
+        d[rng.random(n_dst_b[b]) < 0.03] = 0
+        deg.append(d)
+        hub = rng.integers(0, n_src_b[b], 32)                        # a few hub sources are everyone's neighbour
+        c = np.where(rng.random(d.sum()) < 0.3, hub[rng.integers(0, 32, d.sum())], rng.integers(0, n_src_b[b], d.sum()))
+        cols.append(c + src_off[b])
+        self_rows.append(np.arange(n_dst_b[b]) + src_off[b])
+    deg = np.concatenate(deg)
+    rp = np.zeros(deg.size + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate(cols).astype(np.int32)
+    self_rows = np.concatenate(self_rows).astype(np.int64)
+    x = (rng.random((int(src_off[-1]), F), dtype=np.float32) * 2 - 1)
+    w_t = ((rng.random((2 * F, N), dtype=np.float32) - 0.5) * 0.1)
+    bias = ((rng.random(N, dtype=np.float32) - 0.5) * 0.1)
+    return rp, col, self_rows, x, w_t, bias
