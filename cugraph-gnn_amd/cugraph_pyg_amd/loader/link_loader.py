@@ -7,7 +7,7 @@ sampler/distributed_sampler.py:428-638, negative sampling sampler/sampler_utils.
 the endpoints of the seed edges (plus negatives) are deduplicated in first-appearance order — the
 renumbering kernel with an empty target list does exactly that and returns the inverse map, which IS
 ``edge_label_index`` — then the unique endpoints are expanded like node seeds.  Full batches (homogeneous graphs and typed
-edge seeds of heterogeneous ones, uniform or biased, not temporal / disjoint) run in CALL GROUPS (``local_seeds_per_call``, default 16 batches): the endpoints of all batches are de-duplicated row-wise in one
+edge seeds of heterogeneous ones, uniform or biased, not temporal / disjoint) run in CALL GROUPS (``local_seeds_per_call``, by default sized from device memory): the endpoints of all batches are de-duplicated row-wise in one
 pass, the ragged per-batch seed lists go through ONE no-host-sync walk (``NeighborSampler.sample_seed_lists``) and every
 stored attribute is fetched once for the group; batch by batch the result equals the one-batch path
 (``call_groups=False``; tests/test_gpu_pyg_loader.py).
@@ -29,11 +29,18 @@ import torch
 from wholegraph_amd import graph_ops
 
 from ..data.graph_store import GraphStore
-from ..sampler.sampler import (HeteroNeighborSampler, NeighborSampler, build_hetero_data, filter_store,
+from ..sampler.sampler import (FetchPadder, HeteroNeighborSampler, NeighborSampler, build_hetero_data, filter_store,
                                filter_store_from_group, group_attribute_views, _group_attribute_views, hetero_neighbor_sample,
                                neighbor_sample)
 from .._compat import HeteroSamplerOutput, SamplerOutput
 from .node_loader import generate_seed
+
+
+class _NoStore:
+    """A feature store with nothing in it (sampler-output mode: the loader fetches no features)."""
+
+    def get_all_tensor_attrs(self):
+        return []
 
 
 def _first_occurrence(inverse, values, n_unique):
@@ -261,14 +268,17 @@ class LinkLoader:
         graph = self.__sampler.graph
         bs = self.__batch_size
         n_full = perm.numel() // bs if (self.__call_groups and self.__sampler.call_groups_ok()) else 0
-        per_call = getattr(self.__sampler, "local_seeds_per_call", None) or 16 * bs
-        G = max(1, per_call // bs)
+        G = self.__batches_per_group(bs)
+        pad = self.__padder(n_full, G, perm.numel(), bs)
         b0 = 0
         while b0 < n_full:   # CALL GROUPS of full batches: one launch sequence per hop for g mini-batches
             g = min(G, n_full - b0)
             yield from self.__group(perm, seed, b0, g)
+            pad.group_done()
             b0 += g
+        pad.pad_groups()     # a rank with fewer call groups than the others makes empty fetches until it has as many
         for b, start in enumerate(range(n_full * bs, perm.numel(), bs), start=n_full):
+            pad.single_done()
             ix = perm[start:start + self.__batch_size]
             src, dst = self.__eli[0, ix], self.__eli[1, ix]
             n_pos = ix.numel()
@@ -286,6 +296,26 @@ class LinkLoader:
                                                            self.__sampler.temporal_comparison,
                                                            getattr(self.__sampler, "with_replacement", False))
             yield self.__emit(node, row, col, edge, nn, ne, ix, inverse.long(), n_pos, n_neg)
+        pad.pad_singles()
+
+    def __batches_per_group(self, bs):
+        """Mini-batches per call group: the sampler's seeds-per-call budget over the seeds a batch of ``bs`` seed edges
+        really brings (both endpoints of the positives and of the negatives)."""
+        n_neg = max(int(ceil(self.__amount * bs)), 1) if self.__mode is not None else 0
+        seeds_per_batch = 2 * (bs + n_neg)
+        return max(1, self.__sampler.seeds_per_call(seeds_per_batch) // seeds_per_batch)
+
+    def __padder(self, n_full, G, n, bs):
+        """The epoch's fetch plan (``FetchPadder``): call groups, batches outside a group, batches.  In sampler-output mode
+        nothing is fetched here, so nothing is padded."""
+        n_batches = -(-n // bs) if n else 0
+        if self.__raw:
+            return FetchPadder(_NoStore(), 0, 0, n_batches)
+        ctx = None
+        if self.__hetero:
+            smp = self.__sampler
+            ctx = {"nodes": {t for et in smp.graphs for t in (et[0], et[2])}, "edges": set(smp.graphs)}
+        return FetchPadder(self.__data[0], -(-n_full // G), n_batches - n_full, n_batches, ctx, self.__hetero)
 
     def __group(self, perm, seed, b0, g):
         """Batches b0 .. b0+g-1 (all full) of a homogeneous graph as one call group: negatives per batch with the batch's
@@ -319,13 +349,17 @@ class LinkLoader:
         smp = self.__sampler
         bs = self.__batch_size
         n_full = perm.numel() // bs if (self.__call_groups and smp.call_groups_ok()) else 0
-        G = max(1, (getattr(smp, "local_seeds_per_call", None) or 16 * bs) // bs)
+        G = self.__batches_per_group(bs)
+        pad = self.__padder(n_full, G, perm.numel(), bs)
         b0 = 0
         while b0 < n_full:   # CALL GROUPS of full batches
             g = min(G, n_full - b0)
             yield from self.__hetero_group(perm, seed, b0, g)
+            pad.group_done()
             b0 += g
+        pad.pad_groups()
         for b, start in enumerate(range(n_full * bs, perm.numel(), bs), start=n_full):
+            pad.single_done()
             ix = perm[start:start + self.__batch_size]
             src, dst = self.__eli[0, ix], self.__eli[1, ix]
             n_pos = ix.numel()
@@ -360,6 +394,7 @@ class LinkLoader:
                                       num_sampled_nodes={k: torch.tensor(v) for k, v in nn.items()},
                                       num_sampled_edges={k: torch.tensor(v) for k, v in ne.items()}, metadata=None)
             yield self.__emit_hetero(build_hetero_data(fs, out), ix, inv_src, inv_dst, n_pos, n_neg)
+        pad.pad_singles()
 
     def __emit_hetero(self, data, ix, inv_src, inv_dst, n_pos, n_neg):
         dev = self.__eli.device

@@ -41,6 +41,155 @@ def hop_seed(random_state: int, hop: int) -> int:
     return (int(random_state) + hop * _GOLDEN) & _MASK
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# call-group sizing (the role of DistributedNeighborSampler.__calc_local_seeds_per_call,
+# sampler/distributed_sampler.py:757,837-875)
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference sizes a call from the device's total memory (0.11 output vertices per byte, measured on its own buffers)
+# and falls back to 32,768 seeds when a fan-out is not positive.  Re-derived here for the buffers of THIS walk and for
+# 288 GB of HBM3E: a call group may take CALL_GROUP_MEMORY_FRACTION of the device memory; what a seed costs is counted
+# from the capacity-sized arrays of PygNoSyncWalk (per hop: 5 int32 + edge id + frontier id per sampled-edge slot, id +
+# batch per node slot) plus the library's own workspace figure for the largest hop.
+CALL_GROUP_MEMORY_FRACTION = 0.02
+UNKNOWN_VERTICES_DEFAULT = 32768        # distributed_sampler.py:761-763
+_CALL_GROUP_CAPACITY = (1 << 30) - 1    # node + edge slots one call may address (int32 rows inside the kernels)
+
+
+def call_group_bytes_per_seed(fanout: Sequence[int], id_bytes: int = 8, disjoint: bool = False) -> float:
+    """Device bytes one seed of a call group costs (capacity-sized buffers + workspace of the largest hop)."""
+    from wholegraph_amd import _lib as L
+    frontier, nodes, total = 1, 1, 0.0
+    ws = 0
+    wm_dtype = L.DT_INT64 if id_bytes == 8 else L.DT_INT
+    for m in fanout:
+        edges = frontier * m
+        total += edges * (5 * 4 + 8 + id_bytes + 4) + (nodes + edges) * (id_bytes + 4) + (frontier + 1) * 4
+        # workspace is shared by the hops: the largest one counts (queried at 4096 seeds, it is linear in the capacities)
+        ws = max(ws, L.lib().wgamd_sample_hop_workspace_bytes(4096 * max(nodes, frontier), 4096 * edges, wm_dtype) / 4096.0)
+        nodes, frontier = nodes + edges, edges
+    total += ws
+    if disjoint:   # no cross-seed de-duplication: every seed keeps its own tree (the reference scales by fanout[0] too)
+        total *= max(int(fanout[0]), 1)
+    return total
+
+
+def default_local_seeds_per_call(fanout: Sequence[int], batch_size: int, id_bytes: int = 8, disjoint: bool = False,
+                                 total_memory: Optional[int] = None) -> int:
+    """Seeds per call group when the user gives none: the memory budget above, never less than one mini-batch, never more
+    slots than one call can address, a whole number of mini-batches.  On a 288 GB MI355X, fan-out [25, 10], int64 ids:
+    about 140 mini-batches of 1024 seeds (bench.py runs 64 and measures 256 as 5 % faster still)."""
+    fanout = [int(f) for f in fanout]
+    if any(f <= 0 for f in fanout):
+        per_call = UNKNOWN_VERTICES_DEFAULT
+    else:
+        if total_memory is None:
+            total_memory = (torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+                            if torch.cuda.is_available() else 16 << 30)
+        slots = 1
+        frontier, nodes = 1, 1
+        for m in fanout:
+            nodes, frontier = nodes + frontier * m, frontier * m
+            slots = nodes + frontier
+        per_call = int(CALL_GROUP_MEMORY_FRACTION * total_memory / call_group_bytes_per_seed(fanout, id_bytes, disjoint))
+        per_call = min(per_call, _CALL_GROUP_CAPACITY // max(slots, 1))
+    return max(batch_size, per_call // batch_size * batch_size)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# keeping the ranks of a partitioned FeatureStore in step (distributed_sampler.py:200-214,305-329)
+# ---------------------------------------------------------------------------------------------------------------------
+def _store_is_collective(feature_store) -> bool:
+    """Is a fetch from this store a collective (some tensor partitioned over more than one rank)?"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return False
+    for attr in feature_store.get_all_tensor_attrs():
+        t = feature_store[attr.group_name, attr.attr_name, None]
+        group = t.get_comm() if hasattr(t, "get_comm") else None
+        if dist.get_world_size(group) > 1:
+            return True
+    return False
+
+
+class FetchPadder:
+    """With a FeatureStore partitioned over the ranks every feature fetch is a collective, and a loader makes one per call
+    group plus one per mini-batch outside a group.  Ranks whose seed shards differ in size would make different numbers of
+    them and leave each other waiting — the reference pads its call groups with empties for the same reason
+    (``num_call_groups`` MAX-reduced, distributed_sampler.py:305-329) and warns about uneven batch counts (:200-214).
+    Here the loader states how many fetches of either kind it WILL make, the counts are MAX-reduced once per epoch, and the
+    rank that runs out first issues empty fetches (zero ids, same attributes, same collectives) until it has made as many."""
+
+    def __init__(self, feature_store, n_group_fetches: int, n_single_fetches: int, n_batches: int, empty_group_ctx=None,
+                 hetero: bool = False):
+        import torch.distributed as dist
+        self.fs, self.hetero, self.empty_ctx = feature_store, hetero, empty_group_ctx
+        self.groups_done = self.singles_done = 0
+        self.max_groups, self.max_singles = int(n_group_fetches), int(n_single_fetches)
+        self.active = _store_is_collective(feature_store)
+        if not self.active:
+            return
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([n_group_fetches, n_single_fetches, n_batches], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        table = torch.stack(every).cpu()
+        self.max_groups, self.max_singles = int(table[:, 0].max()), int(table[:, 1].max())
+        if dist.get_rank() == 0 and bool((table[:, 2] != table[0, 2]).any()):
+            import warnings
+            warnings.warn("Not all ranks received the same number of batches. Ranks with fewer batches are padded with "
+                          "empty feature fetches so the collective fetches stay matched; a training loop with its own "
+                          "collectives (gradient all-reduce) may still hang on uneven inputs. Batches per rank: "
+                          f"{table[:, 2].tolist()}.")
+
+    def group_done(self):
+        self.groups_done += 1
+
+    def single_done(self):
+        self.singles_done += 1
+
+    def _empty_index(self):
+        return torch.empty(0, dtype=torch.int64, device="cuda" if torch.cuda.is_available() else "cpu")
+
+    def _attrs(self):
+        """The attributes a real fetch of this loader touches: all of them (homogeneous), or those stored under a node /
+        edge type of the sampled graph (heterogeneous: ``empty_ctx`` = {"nodes": types, "edges": types})."""
+        for attr in self.fs.get_all_tensor_attrs():
+            g = attr.group_name
+            if self.hetero and g not in self.empty_ctx["edges" if isinstance(g, tuple) else "nodes"]:
+                continue
+            yield attr
+
+    def pad_groups(self):
+        """Called when this rank has no call group left (before its first single fetch, or at the end)."""
+        while self.active and self.groups_done < self.max_groups:
+            for attr in self._attrs():
+                _fetch_rows_agreed(self.fs[attr.group_name, attr.attr_name, None], self._empty_index())
+            self.groups_done += 1
+
+    def pad_singles(self):
+        while self.active and self.singles_done < self.max_singles:
+            for attr in self._attrs():
+                self.fs[attr.group_name, attr.attr_name, None][self._empty_index()]
+            self.singles_done += 1
+
+    def finish(self):
+        self.pad_groups()
+        self.pad_singles()
+
+
+class _BatchStream:
+    """The sampler's batch generator + the fetch plan of the epoch (read by SampleIterator)."""
+
+    def __init__(self, gen, fetch_padder=None):
+        self._gen, self.fetch_padder = gen, fetch_padder
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+
 _TEMPORAL_OK = {
     # candidate edge (time t_e) of a vertex reached at time t_v qualifies when ...
     "strictly_increasing": lambda te, tv: te > tv,
@@ -303,6 +452,23 @@ class HeteroNeighborSampler:
         return biased_ok and (not self.temporal) and (not self.disjoint) and (not self.with_replacement) and all(
             g.col.dtype == torch.int64 for g in self.graphs.values())
 
+    def seeds_per_call(self, batch_size: int) -> int:
+        """``local_seeds_per_call`` as given, else sized from device memory with the per-hop fan-outs summed over the edge
+        types (distributed_sampler.py:848-856)."""
+        if self.local_seeds_per_call:
+            return int(self.local_seeds_per_call)
+        hops = len(next(iter(self.fanout.values())))
+        per_hop = [sum(max(v[h], 0) for v in self.fanout.values()) if all(v[h] > 0 for v in self.fanout.values()) else -1
+                   for h in range(hops)]
+        return default_local_seeds_per_call(per_hop, batch_size, 8, self.disjoint)
+
+    def fetch_plan(self, n: int, batch_size: int, on_device: bool = True):
+        """(call groups, batches outside a group, batches) ``sample_batches`` will produce for ``n`` seeds."""
+        n_batches = -(-n // batch_size) if n else 0
+        n_full = n // batch_size if (self.call_groups_ok() and on_device) else 0
+        G = max(1, self.seeds_per_call(batch_size) // batch_size)
+        return -(-n_full // G), n_batches - n_full, n_batches
+
     def sample_seed_lists(self, seed_lists, n_batches: int, random_state: int):
         """One call group over RAGGED per-batch seed lists of one or two node types (``seed_lists`` as in
         ``HeteroPygWalk.run``): batch j gets exactly ``hetero_neighbor_sample(graphs, None, its lists, fanout,
@@ -328,7 +494,7 @@ class HeteroNeighborSampler:
         fast = biased_ok and (not self.temporal) and (not self.disjoint) and (not self.with_replacement) and seeds.is_cuda and all(
             g.col.dtype == torch.int64 for g in self.graphs.values())
         n_full = n // batch_size if fast else 0
-        G = max(1, (self.local_seeds_per_call or 16 * batch_size) // batch_size)
+        G = max(1, self.seeds_per_call(batch_size) // batch_size)
         n_et, hops = len(self.graphs), len(next(iter(self.fanout.values())))
         b = 0
         while b < n_full:
@@ -391,6 +557,19 @@ class NeighborSampler:
         return (biased_ok and (not self.disjoint) and (not self.temporal) and (not self.with_replacement)
                 and all(f > 0 for f in self.fanout))
 
+    def seeds_per_call(self, batch_size: int) -> int:
+        """``local_seeds_per_call`` as given, else sized from device memory (``default_local_seeds_per_call``)."""
+        if self.local_seeds_per_call:
+            return int(self.local_seeds_per_call)
+        return default_local_seeds_per_call(self.fanout, batch_size, self.graph.col.element_size(), self.disjoint)
+
+    def fetch_plan(self, n: int, batch_size: int, on_device: bool = True):
+        """(call groups, batches outside a group, batches) ``sample_batches`` will produce for ``n`` seeds."""
+        n_batches = -(-n // batch_size) if n else 0
+        n_full = n // batch_size if (self.call_groups_ok() and on_device) else 0
+        G = max(1, self.seeds_per_call(batch_size) // batch_size)
+        return -(-n_full // G), n_batches - n_full, n_batches
+
     def sample_seed_lists(self, seeds: torch.Tensor, seed_seg: torch.Tensor, seed_batch: torch.Tensor, max_seeds: int,
                           n_batches: int, random_state: int):
         """One call group over RAGGED per-batch seed lists (``seeds`` = the lists back to back, padded to
@@ -407,8 +586,9 @@ class NeighborSampler:
         """Yields ``(batch index, (node, row, col, edge, num_sampled_nodes, num_sampled_edges))``.
 
         Uniform and biased (strictly positive weights, fan-outs <= 256) sampling with positive fan-outs runs in CALL
-        GROUPS (``local_seeds_per_call`` seeds per launch sequence, default 16 mini-batches — the reference splits its
-        seeds the same way, sampler/distributed_sampler.py:391-410) on the no-host-sync kernels; everything else
+        GROUPS (``local_seeds_per_call`` seeds per launch sequence, by default sized from the device memory like the
+        reference's, ``default_local_seeds_per_call`` — the reference splits its seeds the same way,
+        sampler/distributed_sampler.py:391-410) on the no-host-sync kernels; everything else
         (zero weights, fan-out -1, disjoint / temporal, the ragged last batch) goes through the one-batch-at-a-time C-ABI
         ops.  Both routes return identical results (tests/test_gpu_pyg_loader.py)."""
         n = seeds.shape[0]
@@ -422,8 +602,7 @@ class NeighborSampler:
         fast = (biased_ok and (not self.disjoint) and (not self.temporal) and (not self.with_replacement)
                 and all(f > 0 for f in self.fanout) and seeds.is_cuda)
         n_full = n // batch_size if fast else 0
-        per_call = self.local_seeds_per_call or 16 * batch_size
-        G = max(1, per_call // batch_size)
+        G = max(1, self.seeds_per_call(batch_size) // batch_size)
         seeds = seeds.to(self.graph.col.dtype)
         b = 0
         while b < n_full:
@@ -454,6 +633,20 @@ class BaseSampler:
         self.__batch_size = batch_size
 
     def sample_from_nodes(self, index: NodeSamplerInput, random_state: int = 62, **kwargs) -> Iterator[SamplerOutput]:
+        """Iterator of ``SamplerOutput`` (sampler.py:756-797).  It also carries the epoch's FETCH PLAN: how many feature
+        fetches per call group / per single batch this rank will make, MAX-reduced over the ranks when the FeatureStore is
+        partitioned, so that ``SampleIterator`` can pad a rank that runs out of batches early (``FetchPadder``)."""
+        smp = self.__sampler
+        hetero = isinstance(smp, HeteroNeighborSampler)
+        n_groups, n_singles, n_batches = smp.fetch_plan(int(index.node.shape[0]), self.__batch_size, index.node.is_cuda)
+        ctx = None
+        if hetero:
+            ntypes = {t for et in smp.graphs for t in (et[0], et[2])}
+            ctx = {"nodes": ntypes, "edges": set(smp.graphs)}
+        padder = FetchPadder(self.__feature_store, n_groups, n_singles, n_batches, ctx, hetero)
+        return _BatchStream(self.__sample_from_nodes(index, random_state), padder)
+
+    def __sample_from_nodes(self, index: NodeSamplerInput, random_state: int):
         nodes = index.node
         input_id = index.input_id
         bs = self.__batch_size
@@ -516,24 +709,30 @@ def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
 _GROUP_FETCH_BYTES = 4 << 30
 
 
-def _group_fetch_agreed(t, my_bytes: int) -> bool:
-    """One gather for the whole call group, or one per mini-batch?  With a multi-rank tensor every ``t[index]`` is a
-    collective, so the answer must be the SAME on every rank of the tensor's group: the byte count is MAX-reduced over
-    that group first (ranks see different frontier sizes; a per-rank decision would pair one group gather on rank A with
-    G per-batch gathers on rank B and hang or mis-route rows).  Single-rank tensors decide locally."""
+def _fetch_rows_agreed(t, index):
+    """``t[index]`` for a whole call group, in pieces of at most _GROUP_FETCH_BYTES.  With a multi-rank tensor every
+    ``t[...]`` is a collective, so the NUMBER of pieces must be the same on every rank of the tensor's group: it is
+    MAX-reduced over that group first (ranks see different frontier sizes; a per-rank decision would pair one fetch on rank
+    A with several on rank B and hang or mis-route rows).  Single-rank tensors decide locally."""
     import torch.distributed as dist
+    row_bytes = torch.empty((), dtype=t.dtype).element_size()
+    for d in tuple(t.shape)[1:]:
+        row_bytes *= int(d)
+    pieces = max(1, -(-int(index.numel()) * row_bytes // _GROUP_FETCH_BYTES))
     group = t.get_comm() if hasattr(t, "get_comm") else None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-        worst = torch.tensor([int(my_bytes)], dtype=torch.int64, device=dev)
+        worst = torch.tensor([pieces], dtype=torch.int64, device=dev)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
-        my_bytes = int(worst.item())
-    return my_bytes <= _GROUP_FETCH_BYTES
+        pieces = int(worst.item())
+    if pieces == 1:
+        return t[index]
+    return torch.cat([t[part] for part in torch.tensor_split(index, pieces)])
 
 
 def _group_attribute_views(feature_store, ctx):
     """Every stored attribute gathered ONCE for a whole call group (``ctx`` of HeteroPygWalk.finalize_batches), split into
-    per-batch views; ``None`` for attributes whose group fetch would exceed _GROUP_FETCH_BYTES."""
+    per-batch views."""
     views = {}
     for attr in feature_store.get_all_tensor_attrs():
         g = attr.group_name
@@ -541,29 +740,20 @@ def _group_attribute_views(feature_store, ctx):
         if g not in src:
             continue
         index, sizes = src[g]
-        t = feature_store[g, attr.attr_name, None]
-        row_bytes = torch.empty((), dtype=t.dtype).element_size()
-        for d in tuple(t.shape)[1:]:
-            row_bytes *= int(d)
-        views[g, attr.attr_name] = torch.split(t[index], sizes) if _group_fetch_agreed(t, index.numel() * row_bytes) else None
+        views[g, attr.attr_name] = torch.split(_fetch_rows_agreed(feature_store[g, attr.attr_name, None], index), sizes)
     return views
 
 
 def group_attribute_views(feature_store, ctx):
     """One feature fetch per CALL GROUP instead of one per mini-batch (homogeneous graphs): the batches of a group are
     consecutive segments of one node list / one edge list (``ctx`` of PygWalkResult.finalize_batches), so every stored
-    attribute is gathered once and split into per-batch views; ``None`` for an attribute whose group fetch would exceed
-    _GROUP_FETCH_BYTES (fetched per batch then)."""
+    attribute is gathered once and split into per-batch views."""
     views = {}
     for attr in feature_store.get_all_tensor_attrs():
         is_edge = isinstance(attr.group_name, tuple)
         index, sizes = (ctx["edges"], ctx["edge_sizes"]) if is_edge else (ctx["nodes"], ctx["node_sizes"])
-        t = feature_store[attr.group_name, attr.attr_name, None]
-        row_bytes = torch.empty((), dtype=t.dtype).element_size()
-        for d in tuple(t.shape)[1:]:
-            row_bytes *= int(d)
-        views[attr.group_name, attr.attr_name] = (torch.split(t[index], sizes)
-                                                  if _group_fetch_agreed(t, index.numel() * row_bytes) else None)
+        views[attr.group_name, attr.attr_name] = torch.split(
+            _fetch_rows_agreed(feature_store[attr.group_name, attr.attr_name, None], index), sizes)
     return views
 
 
@@ -616,6 +806,8 @@ class SampleIterator:
     def __init__(self, data, output_iter: Iterator[SamplerOutput]):
         self.__feature_store, self.__graph_store = data
         self.__output_iter = output_iter
+        # the epoch's fetch plan, when the batches come from BaseSampler.sample_from_nodes (see FetchPadder)
+        self.__padder = getattr(output_iter, "fetch_padder", None)
 
     def __next_hetero(self, s):
         group = getattr(s, "_call_group", None)
@@ -625,6 +817,8 @@ class SampleIterator:
         if cache is None or cache[0] is not group[0]:
             cache = (group[0], _group_attribute_views(self.__feature_store, group[0]))
             self.__hetero_cache = cache
+            if self.__padder is not None:
+                self.__padder.group_done()
         return build_hetero_data(self.__feature_store, s, cache[1], group[1])
 
     def __filter_from_group(self, ctx, j, s) -> Data:
@@ -632,10 +826,21 @@ class SampleIterator:
         if cache is None or cache[0] is not ctx:
             cache = (ctx, group_attribute_views(self.__feature_store, ctx))
             self.__group_cache = cache
+            if self.__padder is not None:
+                self.__padder.group_done()
         return filter_store_from_group(self.__feature_store, cache[1], j, s.node, s.row, s.col, s.edge)
 
     def __next__(self):
-        s = next(self.__output_iter)
+        pad = self.__padder
+        try:
+            s = next(self.__output_iter)
+        except StopIteration:
+            if pad is not None:     # this rank is out of batches: match the fetches the others still make
+                pad.finish()
+            raise
+        if pad is not None and getattr(s, "_call_group", None) is None:
+            pad.pad_groups()        # batches outside a call group come last: the group phase of this rank is over
+            pad.single_done()
         if isinstance(s, HeteroSamplerOutput):
             return self.__next_hetero(s)
         group = getattr(s, "_call_group", None)

