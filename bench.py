@@ -355,9 +355,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="timed steps; one step = --groups-per-step call groups")
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the timed region")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="products",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mag"], default="products",
                     help="products = BASELINE configs[1] (the metric's config); papers100m = configs[2] scale on ONE GPU "
-                         "(the north-star 10x-vs-CPU statement)")
+                         "(the north-star 10x-vs-CPU statement); rmat26 = configs[3]; mag = configs[4], the heterogeneous "
+                         "2-hop walk + HeteroConv(GATConv) pipeline of bench_mag.py")
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--edges", type=int, default=None, help="undirected RMAT edges before symmetrising")
     ap.add_argument("--call-group", type=int, default=64, help="mini-batches per launch sequence (fixed launch shape)")
@@ -402,6 +403,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
+    if args.workload == "mag":
+        import bench_mag
+        return bench_mag.main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -308,6 +308,184 @@ __global__ void __launch_bounds__(256) gat_csr_kernel(const int* __restrict__ ro
   }
 }
 
+// GAT, HBM-bound version (H*C % 4 == 0, H*C <= 256): one lane group per destination row, one float4 of the H*C row per
+// lane.  The row's neighbour ids are fetched with ONE coalesced load per group of edges and broadcast by shuffle (no
+// col -> a_src / x dependent chain per edge), and FOUR neighbour rows + their head scores are in flight per lane group;
+// the online softmax takes the four scores in one update (one rescale per four edges).
+// ROWS: the rows of this launch are a subset of a larger destination list (a heterogeneous hop: the frontier entries of one
+// hop and edge type) — `dst_rows[i]` is row i's place in a_dst / out; `accumulate`: out += (HeteroConv sums the relations
+// that end in one node type; launches are stream-ordered, so no two of them touch a row at the same time).
+template <bool ROWS>
+__global__ void __launch_bounds__(256)
+gat_csr_v4_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows, const float* __restrict__ x,
+                  int64_t ldx, const float* __restrict__ a_src, const float* __restrict__ a_dst, int H, int C, float slope,
+                  const int64_t* __restrict__ dst_rows, int accumulate, float* __restrict__ alpha_out,
+                  float* __restrict__ out, int64_t ldo, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int gbase       = (int)(threadIdx.x & 63) & ~(lanes - 1);
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const int HC          = H * C;
+  const bool live       = sub * 4 < HC;
+  const int f0          = live ? sub * 4 : 0;
+  const int h           = f0 / C;
+  for (int64_t row = group; row < n_rows; row += ngroups) {
+    const int s = row_ptr[row], e = row_ptr[row + 1];
+    const int64_t orow = ROWS ? dst_rows[row] : row;
+    const float ad     = a_dst[orow * H + h];
+    float m = -INFINITY, d = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = s; c0 < e; c0 += lanes) {
+      const int mine = c0 + sub < e ? col[c0 + sub] : 0;
+      const int cnt  = min(lanes, e - c0);
+      for (int k = 0; k < cnt; k += 4) {
+        int idx[4];
+        float4 t[4];
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) idx[u] = __shfl(mine, gbase | min(k + u, cnt - 1), 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          t[u]  = *reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx + f0);
+          sc[u] = a_src[(int64_t)idx[u] * H + h];
+        }
+        float mn = m;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          float v = sc[u] + ad;
+          v       = v > 0.f ? v : v * slope;
+          sc[u]   = k + u < cnt ? v : -INFINITY;   // a slot past the chunk repeats its last edge: weight exp(-inf) = 0
+          mn      = fmaxf(mn, sc[u]);
+        }
+        const float rescale = expf(m - mn);      // exp(-inf) = 0 on the first edges
+        float psum = 0.f;
+        acc.x *= rescale; acc.y *= rescale; acc.z *= rescale; acc.w *= rescale;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float pu = expf(sc[u] - mn);
+          psum += pu;
+          acc.x += pu * t[u].x; acc.y += pu * t[u].y; acc.z += pu * t[u].z; acc.w += pu * t[u].w;
+        }
+        d = d * rescale + psum;
+        m = mn;
+      }
+    }
+    const float inv = e > s ? 1.0f / d : 0.f;
+    if (live) {
+      float4* q = reinterpret_cast<float4*>(out + orow * ldo + f0);
+      float4 r  = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      if (accumulate) {
+        const float4 o = *q;
+        r = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w);
+      }
+      *q = r;
+      // the first lane of every head also writes the attention coefficients
+      if (alpha_out != nullptr && (f0 % C) == 0) {
+        for (int j = s; j < e; j++) {
+          float v = a_src[(int64_t)col[j] * H + h] + ad;
+          v       = v > 0.f ? v : v * slope;
+          alpha_out[(int64_t)j * H + h] = expf(v - m) * inv;
+        }
+      }
+    }
+  }
+}
+
+// GAT, AGGREGATE-FIRST (sampled hops: far fewer destination rows than source rows).  The attention-weighted sum is linear,
+//   out[i, h, :] = sum_e alpha_e^h (W_h x_src(e)) = W_h (sum_e alpha_e^h x_src(e)),
+// so the kernel aggregates the UNTRANSFORMED source rows per head — agg[i, h, :] = sum_e alpha_e^h x[col[e], :], F floats per
+// head — and the dense transform runs afterwards over the destination rows only (H small [n_rows, F] x [F, C] GEMMs).  A
+// mini-batch hop has 10-20x fewer destinations than sources, so the lin GEMM over every source row — the dominant cost of the
+// transform-first formulation — disappears, and an edge moves F floats instead of H*C.
+// One lane group (F/4 lanes, one float4 of the row per lane) per destination row; neighbour ids by one coalesced load per
+// chunk + shuffle; EIF neighbour rows and their H scores in flight; one online softmax per head.
+template <int H, int EIF>
+__global__ void __launch_bounds__(256)
+gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows,
+                           const float* __restrict__ x, int64_t ldx, int F, const float* __restrict__ a_src,
+                           const float* __restrict__ a_dst, float slope, const int64_t* __restrict__ dst_rows,
+                           float* __restrict__ out, int64_t ldo, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int gbase       = (int)(threadIdx.x & 63) & ~(lanes - 1);
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const bool live       = sub * 4 < F;
+  const int f0          = live ? sub * 4 : 0;
+  for (int64_t row = group; row < n_rows; row += ngroups) {
+    const int s = row_ptr[row], e = row_ptr[row + 1];
+    const int64_t arow = dst_rows ? dst_rows[row] : row;
+    float ad[H], m[H], d[H];
+    float4 acc[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      ad[h]  = a_dst[arow * H + h];
+      m[h]   = -INFINITY;
+      d[h]   = 0.f;
+      acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int c0 = s; c0 < e; c0 += lanes) {
+      const int mine = c0 + sub < e ? col[c0 + sub] : 0;
+      const int cnt  = min(lanes, e - c0);
+      for (int k = 0; k < cnt; k += EIF) {
+        int idx[EIF];
+        float4 t[EIF];
+        float sc[EIF][H];
+#pragma unroll
+        for (int u = 0; u < EIF; u++) idx[u] = __shfl(mine, gbase | min(k + u, cnt - 1), 64);
+#pragma unroll
+        for (int u = 0; u < EIF; u++) {
+          t[u] = *reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx + f0);
+          if constexpr (H == 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(a_src + (int64_t)idx[u] * 4);
+            sc[u][0] = a4.x; sc[u][1] = a4.y; sc[u][2] = a4.z; sc[u][3] = a4.w;
+          } else {
+#pragma unroll
+            for (int h = 0; h < H; h++) sc[u][h] = a_src[(int64_t)idx[u] * H + h];
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          float mn = m[h];
+#pragma unroll
+          for (int u = 0; u < EIF; u++) {
+            float v  = sc[u][h] + ad[h];
+            v        = v > 0.f ? v : v * slope;
+            sc[u][h] = k + u < cnt ? v : -INFINITY;   // a slot past the chunk repeats its last edge with weight exp(-inf) = 0
+            mn       = fmaxf(mn, sc[u][h]);
+          }
+          const float rescale = expf(m[h] - mn);
+          float psum = 0.f;
+          float4 a   = acc[h];
+          a.x *= rescale; a.y *= rescale; a.z *= rescale; a.w *= rescale;
+#pragma unroll
+          for (int u = 0; u < EIF; u++) {
+            const float pu = expf(sc[u][h] - mn);
+            psum += pu;
+            a.x += pu * t[u].x; a.y += pu * t[u].y; a.z += pu * t[u].z; a.w += pu * t[u].w;
+          }
+          acc[h] = a;
+          d[h]   = d[h] * rescale + psum;
+          m[h]   = mn;
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const float inv = e > s ? 1.0f / d[h] : 0.f;
+        *reinterpret_cast<float4*>(out + row * ldo + (int64_t)h * F + f0) =
+          make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
+      }
+    }
+  }
+}
+
 inline int lanes_log2_for(int units)
 {
   int l = 0;
@@ -469,13 +647,44 @@ wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr, const int* c
   });
 }
 
-wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                           int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
-                                           float negative_slope, float* alpha_out, float* out, int64_t ldo,
-                                           void* stream)
+wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                       int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
+                                                       float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
+                                                       void* stream)
 {
   using namespace wgamd;
-  return guarded("wgamd_gat_csr_f32", [&] {
+  return guarded("wgamd_gat_aggregate_heads_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && H > 0 && F > 0, "bad sizes");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && out, "null pointer");
+    if (F % 4 != 0 || F > 256 || !(H == 1 || H == 2 || H == 4 || H == 8) || !vec4_ok(x, ldx, out, ldo, F) ||
+        (H == 4 && (reinterpret_cast<uintptr_t>(a_src) & 15) != 0))
+      throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), H=%d (1, 2, 4 or 8), 16-B aligned rows", F, H));
+    WG_REQUIRE_INPUT(ldo >= (int64_t)H * F, "output rows hold H * F floats");
+    auto st        = static_cast<hipStream_t>(stream);
+    const int l2   = lanes_log2_for(F / 4);
+    const int grid = grid_rows(n_rows, l2);
+#define WG_GAT_AGG(HH, EE)                                                                                                 \
+  gat_aggregate_heads_kernel<HH, EE><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope,     \
+                                                          dst_rows, out, ldo, l2)
+    switch (H) {
+      case 1: WG_GAT_AGG(1, 4); break;
+      case 2: WG_GAT_AGG(2, 4); break;
+      case 4: WG_GAT_AGG(4, 4); break;
+      default: WG_GAT_AGG(8, 2); break;
+    }
+#undef WG_GAT_AGG
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_gat_csr_rows_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
+                                                float negative_slope, const int64_t* dst_rows, int accumulate,
+                                                float* alpha_out, float* out, int64_t ldo, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gat_csr_rows_f32", [&] {
     WG_REQUIRE_INPUT(n_rows >= 0 && H > 0 && C > 0, "bad sizes");
     if (n_rows == 0) return;
     WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && out, "null pointer");
@@ -484,14 +693,34 @@ wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr, const int* col, i
     const bool v4  = (C % 4 == 0) && vec4_ok(x, ldx, out, ldo, HC);
     const int l2   = lanes_log2_for(v4 ? HC / 4 : HC);
     const int grid = grid_rows(n_rows, l2);
-    if (v4)
-      gat_csr_kernel<4><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope,
-                                              alpha_out, out, ldo, l2);
-    else
-      gat_csr_kernel<1><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope,
-                                              alpha_out, out, ldo, l2);
+    if (v4 && HC <= 256) {
+      if (dst_rows)
+        gat_csr_v4_kernel<true><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, dst_rows,
+                                                      accumulate, alpha_out, out, ldo, l2);
+      else
+        gat_csr_v4_kernel<false><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, nullptr,
+                                                       accumulate, alpha_out, out, ldo, l2);
+    } else {
+      if (dst_rows != nullptr || accumulate)
+        throw logic_error("row indirection / accumulation need H*C % 4 == 0, H*C <= 256 and 16-B aligned rows");
+      if (v4)
+        gat_csr_kernel<4><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope,
+                                                alpha_out, out, ldo, l2);
+      else
+        gat_csr_kernel<1><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope,
+                                                alpha_out, out, ldo, l2);
+    }
     WG_HIP_CHECK(hipGetLastError());
   });
+}
+
+wholememory_error_code_t wgamd_gat_csr_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                           int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
+                                           float negative_slope, float* alpha_out, float* out, int64_t ldo,
+                                           void* stream)
+{
+  return wgamd_gat_csr_rows_f32(row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, nullptr, 0, alpha_out, out,
+                                ldo, stream);
 }
 
 }  // extern "C"

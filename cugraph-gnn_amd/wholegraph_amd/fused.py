@@ -564,7 +564,10 @@ class HeteroPygWalk:
                 L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
                 keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
                          st["nodes"], st["batch"], st["seg"]]
-                rec["calls"].append(dict(et=et, offsets=offsets, row=row_l, col=col_l, gid=gid, f_seg=f_seg))
+                # (f_batch / f_local0 / frontier_cap: what a call-group consumer needs to place the hop's rows in the node list
+                #  of the destination type without going through per-batch views — bench_mag.py)
+                rec["calls"].append(dict(et=et, offsets=offsets, row=row_l, col=col_l, gid=gid, f_seg=f_seg, f_batch=f_batch,
+                                         f_local0=f_l0, frontier_cap=fc, hop=h))
                 st["nodes"], st["batch"], st["seg"] = nodes_out, nodes_out_batch, nodes_out_seg
                 st["cap"] = nc + ec
                 st["gained_cap"] += ec

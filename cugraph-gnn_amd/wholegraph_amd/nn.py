@@ -299,6 +299,48 @@ def gat_forward(row_ptr, col, x, a_src, a_dst, heads, negative_slope=0.2, need_a
     return out, alpha
 
 
+def gat_forward_rows(row_ptr, col, x, a_src, a_dst, heads, out, dst_rows=None, accumulate=False, negative_slope=0.2):
+    """``gat_forward`` for the rows of ONE hop and edge type of a heterogeneous call group: row i of the launch reads
+    ``a_dst[dst_rows[i]]`` and writes (``accumulate``: adds to) ``out[dst_rows[i]]`` — see wgamd_gat_csr_rows_f32."""
+    _check_csr(row_ptr, col)
+    n_rows = row_ptr.shape[0] - 1
+    C = x.shape[1] // heads
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[1] == x.shape[1]
+    assert dst_rows is None or (dst_rows.dtype == torch.int64 and dst_rows.is_contiguous() and dst_rows.shape[0] >= n_rows)
+    L.check(L.lib().wgamd_gat_csr_rows_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0),
+                                           a_src.data_ptr(), a_dst.data_ptr(), heads, C, float(negative_slope),
+                                           None if dst_rows is None else dst_rows.data_ptr(), int(bool(accumulate)), None,
+                                           out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_csr_rows_f32")
+    return out
+
+
+def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=None, negative_slope=0.2, out=None):
+    """Aggregate-first GAT (wgamd_gat_aggregate_heads_f32): ``agg[i, h, :] = sum_e alpha_e^h x[col[e], :]`` with x
+    untransformed ([N_src, F]); returns ``[n_rows, heads * F]``.  ``gat_transform_heads`` applies the per-head weights."""
+    _check_csr(row_ptr, col)
+    n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, heads * F_), dtype=torch.float32, device=x.device)
+    assert a_src.is_contiguous() and a_dst.is_contiguous() and a_src.shape[1] == heads
+    L.check(L.lib().wgamd_gat_aggregate_heads_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_,
+                                                  a_src.data_ptr(), a_dst.data_ptr(), heads, float(negative_slope),
+                                                  None if dst_rows is None else dst_rows.data_ptr(), out.data_ptr(),
+                                                  out.stride(0), get_stream()), "wgamd_gat_aggregate_heads_f32")
+    return out
+
+
+def gat_transform_heads(agg, w, heads, out=None):
+    """``out[i, h*C:(h+1)*C] (+)= agg[i, h, :] @ w[:, h*C:(h+1)*C]`` — the H small GEMMs after ``gat_aggregate_heads``
+    (one strided batched GEMM, MFMA through hipBLASLt).  ``out`` given: accumulated into (HeteroConv's sum)."""
+    n, F_ = agg.shape[0], agg.shape[1] // heads
+    C = w.shape[1] // heads
+    res = torch.bmm(agg.view(n, heads, F_).permute(1, 0, 2), w.view(F_, heads, C).permute(1, 0, 2))     # [H, n, C]
+    if out is None:
+        return res.permute(1, 0, 2).reshape(n, heads * C)
+    out.view(n, heads, C).add_(res.permute(1, 0, 2))
+    return out
+
+
 def gat_backward_supported(H: int, C: int) -> bool:
     """Shapes ``wgamd_gat_csr_bwd_f32`` is built for (include/wgamd_ext.h)."""
     return C % 4 == 0 and ((C // 4) & (C // 4 - 1)) == 0 and H * C <= 256

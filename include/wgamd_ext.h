@@ -323,6 +323,29 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
 wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, const int* target_seg, const int* target_batch,
                                                       int64_t n_targets, int64_t* rows, void* stream);
 
+/* wgamd_gat_csr_f32 over a SUBSET of a larger destination list, optionally accumulating: row i of this launch reads
+ * a_dst[dst_rows[i], :] and writes (accumulate: adds to) out[dst_rows[i], :].  This is one hop and edge type of a
+ * heterogeneous call group: its rows are the frontier entries of that hop, dst_rows their places in the node list of the
+ * destination type, and HeteroConv's sum over the relations ending in one node type is accumulate = 1 on stream-ordered
+ * launches.  dst_rows = NULL, accumulate = 0: exactly wgamd_gat_csr_f32.  Row indirection / accumulation need H*C % 4 == 0,
+ * H*C <= 256 and 16-byte aligned rows (WHOLEMEMORY_LOGIC_ERROR otherwise). */
+wholememory_error_code_t wgamd_gat_csr_rows_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x, int64_t ldx,
+                                                const float* a_src, const float* a_dst, int H, int C, float negative_slope,
+                                                const int64_t* dst_rows, int accumulate, float* alpha_out, float* out,
+                                                int64_t ldo, void* stream);
+
+/* GAT aggregation BEFORE the dense transform (csrc/wg_aggregate.hip) — for sampled hops, where destinations are 10-20x
+ * fewer than sources.  The attention-weighted sum is linear in the source rows, so
+ *   agg[i, h, :] = sum_{e in row i} alpha_e^h x[col[e], :]          (x UNTRANSFORMED, F floats; out row i = [H][F])
+ * followed by H small GEMMs  out[i, h, :] = agg[i, h, :] @ W[:, h*C:(h+1)*C]  over the destination rows only equals
+ * GATConv's  sum_e alpha_e^h (x W)[col[e], h, :]  up to fp32 reassociation, without the lin GEMM over every source row.
+ * alpha as in wgamd_gat_csr_f32 from a_src [N_src, H] (= x_src @ fold(W, att_src)) and a_dst[dst_rows ? dst_rows[i] : i, :].
+ * Shapes: F % 4 == 0, F <= 256, H in {1, 2, 4, 8}, 16-byte aligned rows, ldo >= H * F. */
+wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                       int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
+                                                       float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
+                                                       void* stream);
+
 /* Backward of wgamd_gat_csr_f32 (csrc/wg_gat_bwd.hip): given grad_out [n_rows, H*C] and the forward's alpha [E, H], writes
  * grad_x [n_src, H*C], grad_a_src [n_src, H], grad_a_dst [n_rows, H]; de [E, H] is scratch.  Needs the hop CSR transposed:
  * row_ptr_t [n_src+1], edge_perm [E] (edge ids sorted by source, stable), edge_dst [E] (destination row of every edge).

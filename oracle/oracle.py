@@ -22,7 +22,7 @@ __all__ = [
     "build", "lib", "pcg_raw_u32", "generate_random_positive_int",
     "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets", "unweighted_sample_with_replacement",
     "unweighted_sample", "weighted_sample", "append_unique", "csr_add_self_loop",
-    "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "num_threads",
+    "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "gat_aggregate_heads", "num_threads",
     "set_num_threads", "py_pcg_u32_stream",
 ]
 
@@ -292,6 +292,18 @@ def gat_csr(row_ptr, col, x, a_src, a_dst, slope=0.2):
     lib().wgo_gat_csr(_p(row_ptr), _p(col), i64(n), _p(x), _p(a_src), _p(a_dst), i64(H), i64(C),
                       ctypes.c_float(slope), _p(alpha), _p(out))
     return out, alpha
+
+
+def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, dst_rows=None, slope=0.2):
+    """x [N_src, F] untransformed, a_src [N_src, H], a_dst [*, H] (row ``dst_rows[i]`` or i) -> agg [n_rows, H, F]."""
+    row_ptr, col = _c(row_ptr, np.int32), _c(col, np.int32)
+    x, a_src, a_dst = _c(x, np.float32), _c(a_src, np.float32), _c(a_dst, np.float32)
+    dr = None if dst_rows is None else _c(dst_rows, np.int64)
+    n, H, F = row_ptr.size - 1, a_src.shape[1], x.shape[1]
+    out = np.empty((n, H, F), dtype=np.float32)
+    lib().wgo_gat_aggregate_heads(_p(row_ptr), _p(col), i64(n), _p(x), i64(F), _p(a_src), _p(a_dst),
+                                  None if dr is None else _p(dr), i64(H), ctypes.c_float(slope), _p(out))
+    return out
 
 
 def num_threads():

@@ -680,6 +680,60 @@ void wgo_gat_csr(const int32_t* row_ptr,
   }
 }
 
+/* GAT aggregation BEFORE the dense transform (the restatement wgamd_gat_aggregate_heads_f32 is checked against; also what the
+ * CPU baseline of bench_mag.py runs).  Same attention as wgo_gat_csr (torch_geometric.nn.GATConv semantics, SURVEY.md §8 row
+ * a18: e = leaky_relu(a_src[j] + a_dst[i]), alpha = softmax over the row's edges, per head), but the weighted sum runs over
+ * the UNTRANSFORMED source rows x [N_src, F]:  out[i, h, :] = sum_e alpha_e^h x[col[e], :]  — the attention-weighted sum is
+ * linear, so W_h applied afterwards to out[i, h, :] gives GATConv's sum_e alpha_e^h (W x)[col[e], h, :].  fp64 accumulation.
+ * a_dst row of output row i: dst_rows ? dst_rows[i] : i. */
+void wgo_gat_aggregate_heads(const int32_t* row_ptr, const int32_t* col, int64_t n_rows, const float* x, int64_t F,
+                             const float* a_src, const float* a_dst, const int64_t* dst_rows, int64_t H, float slope,
+                             float* out /* [n_rows, H, F] */)
+{
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    int64_t cap   = 64;
+    double* alpha = (double*)malloc(sizeof(double) * (size_t)cap);
+    double* acc   = (double*)malloc(sizeof(double) * (size_t)F);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+    for (int64_t i = 0; i < n_rows; i++) {
+      const int32_t s = row_ptr[i], e = row_ptr[i + 1];
+      const int64_t ar = dst_rows ? dst_rows[i] : i;
+      if (e - s > cap) {
+        cap   = 2 * (int64_t)(e - s);
+        alpha = (double*)realloc(alpha, sizeof(double) * (size_t)cap);
+      }
+      for (int64_t h = 0; h < H; h++) {
+        double mx = -INFINITY, den = 0.0;
+        for (int32_t j = s; j < e; j++) {
+          double v = (double)a_src[(int64_t)col[j] * H + h] + (double)a_dst[ar * H + h];
+          v        = v > 0 ? v : v * (double)slope;
+          alpha[j - s] = v;
+          if (v > mx) mx = v;
+        }
+        for (int32_t j = s; j < e; j++) {
+          alpha[j - s] = exp(alpha[j - s] - mx);
+          den += alpha[j - s];
+        }
+        for (int64_t c = 0; c < F; c++) acc[c] = 0.0;
+        for (int32_t j = s; j < e; j++) {
+          const double a  = alpha[j - s] / den;
+          const float* xr = x + (int64_t)col[j] * F;
+          for (int64_t c = 0; c < F; c++) acc[c] += a * (double)xr[c];
+        }
+        float* o = out + (i * H + h) * F;
+        for (int64_t c = 0; c < F; c++) o[c] = (float)acc[c];
+      }
+    }
+    free(alpha);
+    free(acc);
+  }
+}
+
 int wgo_num_threads(void)
 {
 #ifdef _OPENMP
