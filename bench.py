@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """bench.py — sampled-edges/s of the mini-batch hot path on the ogbn-products-like workload.
 
-One "step" = `batches_per_step` (default 512) mini-batches of 1024 seeds through the whole hot path with everything
-resident in HBM, processed as `--groups-per-step` (8) CALL GROUPS of `--call-group` (64) mini-batches — the launch shape
-is FIXED and does not depend on --steps:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->
+One "step" = `batches_per_step` (default 8 x 191) mini-batches of 1024 seeds through the whole hot path with everything
+resident in HBM, processed as `--groups-per-step` (8) CALL GROUPS of `--call-group` mini-batches (default: the loaders' own
+memory-sized call group, 191 on a 288 GB MI355X) — the launch shape is FIXED and does not depend on --steps:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->
 feature gather x = feat[n_id] (fp32, F=100)  ->  2-layer GraphSAGE forward (mean aggregation + lin_l/lin_r in HIP).
 `value` = sampled edges of all ranks / max-over-ranks wall time of exactly K steps (the driver's `--steps 20 --warmup 5`
-= 160 timed call groups after 40 untimed ones, a steady-state software-pipelined region of ~0.25 s).
+= 160 timed call groups after 40 untimed ones, a steady-state software-pipelined region of ~0.7 s).
 
 N > 1 (one process per GPU, seeds sharded, CSR replicated): the HEADLINE is the north-star multi-GPU path — the feature table
 range-partitioned over the ranks (per = ceil(V/W)) and fetched by the RCCL all-to-all-v pipeline of wholememory_gather
@@ -361,7 +361,10 @@ def main():
                          "2-hop walk + HeteroConv(GATConv) pipeline of bench_mag.py")
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--edges", type=int, default=None, help="undirected RMAT edges before symmetrising")
-    ap.add_argument("--call-group", type=int, default=64, help="mini-batches per launch sequence (fixed launch shape)")
+    ap.add_argument("--call-group", type=int, default=0,
+                    help="mini-batches per launch sequence (fixed launch shape); 0 = what the loaders use by default: the "
+                         "memory-sized call group of cugraph_pyg_amd.sampler.default_local_seeds_per_call (2 %% of the device "
+                         "memory: 191 mini-batches for fan-out [25, 10] with int64 ids on a 288 GB MI355X)")
     ap.add_argument("--groups-per-step", type=int, default=8, help="call groups per step (batches_per_step = G x this)")
     ap.add_argument("--feature-placement", choices=["auto", "replicated", "partitioned", "both"], default="auto",
                     help="N>1: 'partitioned' range-partitions the table and fetches remote rows over xGMI (RCCL all-to-all-v = "
@@ -540,7 +543,12 @@ def main():
         return info
 
     # ---- step geometry: FIXED launch shape (G mini-batches per call group), independent of --steps ----
+    auto_group = args.call_group <= 0
+    if auto_group:
+        from cugraph_pyg_amd.sampler.sampler import default_local_seeds_per_call
+        args.call_group = max(1, default_local_seeds_per_call(FANOUT, BATCH, 8 if id_dtype == torch.int64 else 4) // BATCH)
     G, gps = args.call_group, args.groups_per_step
+    std_call_group = G if auto_group else -1     # the committed profiles / PMC passes are of the default launch shape
     groups = args.steps * gps
     # at least 3 untimed call groups: sizes differ from group to group, the caching allocator and the two-stream pipeline
     # are only in steady state after a few of them (--warmup is honoured as a minimum)
@@ -743,7 +751,7 @@ def main():
                             "avg_launch_ms": round(stage_ms[dom], 5),
                             "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                       f"{G} mini-batches, averaged over {stage_n} call groups"}
-            std_shape = args.workload == "products" and G == 64 and args.nodes == wv and args.edges == we
+            std_shape = args.workload == "products" and G == std_call_group and args.nodes == wv and args.edges == we
             if roofline is not None and std_shape:
                 prof = load_profiled_avg(roofline["kernel"])
                 if prof:    # the same algorithmic bytes over the committed profile's average launch duration
