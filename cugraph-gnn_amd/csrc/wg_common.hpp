@@ -269,6 +269,16 @@ int64_t scan_tmp_ints(int64_t n);
 constexpr int kScanTile = 2048;
 void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream,
                         const int* n_live_dev = nullptr);
+// State of one single-pass (chained) scan launch — see wg_scan_chain.hpp.  The buffers are library-owned, one set per
+// (device, stream); `scan_chain_acquire` hands out the next epoch of that set (host side, no device work after the first
+// call on a stream).  At most kScanChainTiles tiles per launch.
+struct scan_chain {
+  unsigned long long* tiles;   // [tile]: epoch:30 | flag:2 | value:32
+  unsigned int* counters;      // [0] ticket, [1] workgroups done; zero between launches
+  unsigned int epoch;
+};
+constexpr int64_t kScanChainTiles = (int64_t)1 << 20;   // 2^31 elements / kScanTile
+scan_chain scan_chain_acquire(hipStream_t stream);
 
 
 // ---- building blocks shared by the ABI ops and the no-sync walk (wg_fused.hip) -----------------

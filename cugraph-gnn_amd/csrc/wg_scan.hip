@@ -1,12 +1,49 @@
 // int32 exclusive scan over up to 2^31 elements, wave64-native.
 //   n <= TILE        : one launch (single workgroup).
 //   otherwise        : tile sums -> tile rescans, every workgroup adding up the sums before its own tiles (2 launches).
+//   WGAMD_SCAN_CHAINED=1: ONE launch instead, single pass with decoupled look-back over library-owned tile states
+//                      (wg_scan_chain.hpp).  Built for round 3's "fewer launches per walk" and MEASURED SLOWER on gfx950: the
+//                      ~3000 tiles of a hop-2 scan all run at once, so hardly any tile finds a finished prefix nearby and the
+//                      look-back walks back 64 agent-scope words at a time (each a trip beyond the XCD's L2): 40 us per scan
+//                      against 14 us for the two launches, walk 0.51 -> 0.62 ms per call group, -5 % end to end
+//                      (A/B on one box).  Kept as a switch; the tests run both.
 // Used for sample offsets (role of thrust::exclusive_scan in
 // /root/reference/cpp/src/wholegraph_ops/unweighted_sample_without_replacement_func.cuh:323-326)
 // and for the first-appearance ranks of append_unique.
+#include <map>
+
 #include "wg_common.hpp"
+#include "wg_scan_chain.hpp"
 
 namespace wgamd {
+
+scan_chain scan_chain_acquire(hipStream_t stream)
+{
+  struct state {
+    unsigned long long* tiles = nullptr;
+    unsigned int* counters    = nullptr;
+    unsigned int epoch        = 0;
+  };
+  static std::mutex m;
+  static std::map<std::pair<int, void*>, state> table;
+  int dev = 0;
+  WG_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(m);
+  state& s = table[{dev, static_cast<void*>(stream)}];
+  if (s.tiles == nullptr) {
+    // first scan on this stream: 8 MiB of tile words (any n up to 2^31) + the two counters, zeroed once
+    void* p = nullptr;
+    WG_HIP_CHECK(hipMalloc(&p, sizeof(unsigned long long) * (size_t)kScanChainTiles + 256));
+    WG_HIP_CHECK(hipMemsetAsync(p, 0, sizeof(unsigned long long) * (size_t)kScanChainTiles + 256, stream));
+    s.tiles    = static_cast<unsigned long long*>(p);
+    s.counters = reinterpret_cast<unsigned int*>(static_cast<char*>(p) + sizeof(unsigned long long) * (size_t)kScanChainTiles);
+  }
+  if (++s.epoch >= (1u << 30)) {   // the epoch field is 30 bits: start over on a cleared buffer (stream-ordered)
+    WG_HIP_CHECK(hipMemsetAsync(s.tiles, 0, sizeof(unsigned long long) * (size_t)kScanChainTiles, stream));
+    s.epoch = 1;
+  }
+  return scan_chain{s.tiles, s.counters, s.epoch};
+}
 
 namespace {
 
@@ -152,6 +189,36 @@ scan_tile_final_kernel(const int* in, int* out, int64_t n, const int* sums, int6
   }
 }
 
+// ONE launch: workgroups take tiles by ticket, reduce, chain the prefixes through the library-owned state words and write
+// their tile.  `live` as above: tiles past the live count are never touched; the last live tile publishes the total at out[n].
+__global__ void __launch_bounds__(kThreads)
+scan_chained_kernel(const int* in, int* out, int64_t n, int64_t m, dev_count live, scan_chain chain)
+{
+  const int64_t m_live = live.dev == nullptr ? m : min(m, (int64_t)live.get() / kTile + 1);
+  while (true) {
+    const unsigned tile = chain_next_tile(chain);
+    if ((int64_t)tile >= m_live) break;
+    int x[kItems];
+    const int64_t base = (int64_t)tile * kTile;
+    load_tile(in, base, n, x);
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) s += x[k];
+    int total;
+    int run = chain_block_exclusive_scan(s, &total);
+    const int prefix = chain_exclusive_prefix(chain, tile, total);
+    run += prefix;
+    int64_t p = base + (int64_t)threadIdx.x * kItems;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+      if (p + k < n) out[p + k] = run;
+      run += x[k];
+    }
+    if ((int64_t)tile == m_live - 1 && threadIdx.x == 0) out[n] = prefix + total;
+  }
+  chain_finish(chain);
+}
+
 }  // namespace
 
 int64_t scan_tmp_ints(int64_t n) { return (n + kTile - 1) / kTile + 2; }
@@ -164,6 +231,12 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
   } else {
     int64_t m = (n + kTile - 1) / kTile;
     const unsigned grid = (unsigned)std::min<int64_t>(m, kScanGrid);
+    static const bool chained = getenv("WGAMD_SCAN_CHAINED") != nullptr;
+    if (chained && m <= kScanChainTiles) {
+      scan_chained_kernel<<<grid, kThreads, 0, stream>>>(in, out, n, m, live, scan_chain_acquire(stream));
+      WG_HIP_CHECK(hipGetLastError());
+      return;
+    }
     scan_tile_sums_kernel<<<grid, kThreads, 0, stream>>>(in, n, tmp, m, live);
     // in-place is safe: every tile reads its inputs into registers before writing them back,
     // and out[n] is written from tmp, not from `in`.

@@ -128,3 +128,17 @@ def test_multilayer_walk_sync_and_nosync(oracle_mod, hiplib, col_dtype, fanouts)
     assert np.array_equal(tg[0][: len(seeds)].cpu().numpy(), seeds)
     for i in range(len(fanouts)):
         assert rp[i].shape[0] == tg[i + 1].shape[0] + 1 and int(ci[i].max()) < tg[i].shape[0]
+
+
+def test_walk_is_identical_with_the_single_launch_scan(hiplib):
+    """WGAMD_SCAN_CHAINED=1 swaps every multi-tile exclusive scan for the single-pass (decoupled look-back) kernel of
+    wg_scan_chain.hpp — slower on gfx950 (wg_scan.hip header) and therefore off by default, but it must stay correct: the
+    walk / call-group / sampling parity tests pass under it unchanged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_callgroup.py",
+                        "tests/test_gpu_renumber_gather.py", "-k", "not single_launch_scan"],
+                       cwd=root, env=dict(os.environ, WGAMD_SCAN_CHAINED="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
