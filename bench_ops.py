@@ -202,8 +202,10 @@ def main():
     outw = wholegraph_ops.weighted_sample_without_replacement(row_ptr, col, weight, frontier, 10, random_seed=62)
     fdeg = row_ptr[frontier + 1] - row_ptr[frontier]
     deg_sum = int(fdeg.sum())
+    # (a dozen untimed calls: the caching allocator settles on this op's block sizes only after ~10 of them — with 3 the timed
+    #  loop still paid device allocations and read 4-5 ms for a 0.7 ms op)
     t = timed(lambda: wholegraph_ops.weighted_sample_without_replacement(row_ptr, col, weight, frontier, 10, random_seed=62),
-              iters=10)
+              iters=10, warm=14)
     add("weighted_sample hop2 M=10", "wholegraph_op.h:61-73", t,
         frontier.shape[0] * (b + 16 + 4) + deg_sum * 4 + outw[1].shape[0] * (2 * b + 4), outw[1].shape[0], "edges",
         "reads every candidate weight (Σdeg = %d) to key it; %d rows > 1024 candidates (Σ = %d, max %d)"

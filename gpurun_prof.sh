@@ -2,7 +2,7 @@
 # Every pass runs the DRIVER'S command (python bench.py --steps 20 --warmup 5): the launch shape is fixed (G=64).
 # kernel trace + stats first, then SEPARATE --pmc passes (never combined with a trace option).
 set -x
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_$TAG -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
 cp /tmp/pt_$TAG/${TAG}_kernel_stats.csv $OUT/
 for C in FETCH_SIZE WRITE_SIZE; do
