@@ -22,8 +22,9 @@
 //   * CW = N/64 CONSUMER waves multiply the tile of step s-1: each owns 64 output columns = 2 x 2 accumulator tiles of
 //     32 x 32.  They read fp32 A fragments (2 x ds_read_b128 per row tile and k-step) and do the 3-way split themselves,
 //     in the issue slots under their own MFMAs (an MFMA holds the matrix pipe for 32 cycles but the issue port for ~4);
-//     the weight is pre-split once per update into planes laid out so that a wave-load is 1 KiB contiguous, and its
-//     fragment stream runs two k-steps ahead, continuing across tiles.
+//     the weight travels as fp32 tiles laid out so that a wave-load is 2 x 1 KiB contiguous (split into its bf16 planes in
+//     registers too: 4 B per element instead of the 6 of pre-split planes), and its fragment stream runs two k-steps ahead,
+//     continuing across tiles.
 //   * A producer and a consumer wave share each SIMD.  Measured on gfx950 (tools/tune/sage_mfma_harness.cpp, timeline of
 //     s_memtime stamps): they time-slice rather than overlap — while a consumer streams MFMAs the co-resident producer runs
 //     at ~25 % of its stand-alone speed — and the CU's vector-memory pipeline returns data in issue order across waves, so
@@ -32,6 +33,10 @@
 //     saturate its matrix pipe and the step becomes consumer-bound; it is kept as a switch, off.  What is left on the
 //     table: stand-alone the producers take 0.40 ms (5.6 TB/s of HBM traffic) and the consumers 0.27 ms for the products
 //     layer-1 call group; together 0.63-0.75 ms depending on the box (fp32-MFMA kernel: 0.84 ms).
+//   * Round 3, compile-time ablations inside bench.py: the multiplying waves' MATRIX work is free (half the
+//     MFMAs: 0.572 -> 0.564 ms); what they cost is their MEMORY instructions, which share the CU's vector-memory pipeline
+//     with the row fetches — no weight loads: 0.422, no output stores: 0.470, neither: 0.338 = the fetching waves alone
+//     (0.332).  Hence the fp32 weight tiles (two thirds of the bytes of pre-split planes): 0.570 -> 0.516 ms.
 //   * one s_barrier per step behind an LDS-only wait (s_waitcnt lgkmcnt(0)): neither side's global loads are drained.
 #include <algorithm>
 #include <cstdlib>
@@ -75,7 +80,8 @@ struct mfma_args {
   const void* src_ids;
   const int64_t* self_rows;
   int mean;
-  const uint32_t* w_planes;  // [3][KS][N][8 dwords]: bf16 plane p, k-step s, column n, 16 consecutive k
+  const float* w_tiles;      // [KS][N][16] fp32: k-step s, column n, 16 consecutive k (wgamd_sage_split_weight_bf16x3);
+                             // HALF mode (F > 148): pre-split bf16 planes [3][KS][N][8 dwords] behind the same pointer
   int N;
   int KS;                    // ceil(2F / 16)
   const float* bias;
@@ -320,6 +326,9 @@ struct afrag_t {
 struct bfrag_t {
   u32x4 v[2][3];  // [col tile][plane]
 };
+struct braw_t {
+  f32x4 v[2][2];  // [col tile][k 0-3 | k 4-7 of this lane's half k-step]: the fp32 weight as it travels
+};
 
 template <int RT>
 __device__ __forceinline__ void load_a_raw(araw_t<RT>& f, const float* a_lane, int sd, int ks)
@@ -350,13 +359,47 @@ __device__ __forceinline__ void split_a(const araw_t<RT>& r, afrag_t<RT>& f)
     }
   }
 }
-__device__ __forceinline__ void load_b(bfrag_t& f, const uint32_t* b_lane, int64_t b_plane_dw, int n_cols, int ks)
+// The weight travels as fp32 (4 B per element) and is split into its three bf16 planes by the multiplying wave, in the issue
+// slots under its own MFMAs — the pre-split planes of round 2 were 6 B per element, and the weight stream (once per 64-row
+// tile per CU, through the same vector-memory pipeline as the row fetches) is what the layer's time is most sensitive to:
+// each third of it costs 0.045 ms of the 0.55 ms layer-1 launch (compile-time ablations).  Same products,
+// bit-identical results.
+__device__ __forceinline__ void load_b(braw_t& f, const float* b_lane, int n_cols, int ks)
+{
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) {
+    const float* p = b_lane + ((int64_t)ks * n_cols + ct * 32) * 16;
+    f.v[ct][0]     = *reinterpret_cast<const f32x4*>(p);
+    f.v[ct][1]     = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+}
+// HALF mode (F > 148, K = 512: the multiplying waves are the busier side there and the split of the weight in registers
+// costs more than the bytes it saves: 1.74 vs 1.69 ms at 256 -> 256) keeps the pre-split planes [3][KS][N][8 dwords]
+__device__ __forceinline__ void load_b_planes(bfrag_t& f, const uint32_t* b_lane, int64_t b_plane_dw, int n_cols, int ks)
 {
 #pragma unroll
   for (int ct = 0; ct < 2; ct++)
 #pragma unroll
     for (int p = 0; p < 3; p++)
       f.v[ct][p] = *reinterpret_cast<const u32x4*>(b_lane + p * b_plane_dw + ((int64_t)ks * n_cols + ct * 32) * 8);
+}
+__device__ __forceinline__ void split_b(const braw_t& r, bfrag_t& f)
+{
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      split3(r.v[ct][0][i], h[i], m[i], l[i]);
+      split3(r.v[ct][1][i], h[4 + i], m[4 + i], l[4 + i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      f.v[ct][0][j] = pack_hi16(h[2 * j], h[2 * j + 1]);
+      f.v[ct][1][j] = pack_hi16(m[2 * j], m[2 * j + 1]);
+      f.v[ct][2][j] = pack_hi16(l[2 * j], l[2 * j + 1]);
+    }
+  }
 }
 
 template <int RT>
@@ -412,6 +455,7 @@ __device__ __forceinline__ void epilogue(const mfma_args& a, f32x16 (&c)[RT][2],
       for (int pass = 0; pass < 2; pass++) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (rl + 4 * pass) * 64 + cl);
         const int r   = rt * 32 + 8 * g + 4 * pass;   // + rl
+        // (non-temporal stores here: 0.518 -> 0.514 ms, inside the noise — not taken)
         if (full || row0 + r + rl < a.n_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)r * a.ldo) = v;
       }
     }
@@ -432,22 +476,24 @@ __device__ __forceinline__ void consume_tile(const mfma_args& a, int64_t tile, c
       for (int i = 0; i < 16; i++) c[rt][ct][i] = 0.f;
   const int lm = lane & 31, lh = lane >> 5;
   const float* a_lane      = tile_lds + lm * a.SD + lh * 8;
-  const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
-  const uint32_t* b_lane   = a.w_planes + ((int64_t)(cw * 64 + lm)) * 8 + lh * 4;
-  bfrag_t b0, b1;
+  const float* b_lane = a.w_tiles + ((int64_t)(cw * 64 + lm)) * 16 + lh * 8;
+  braw_t b0, b1;
+  bfrag_t fb;
   araw_t<RT> raw;
   afrag_t<RT> fa;
-  load_b(b0, b_lane, b_plane_dw, a.N, 0);
+  load_b(b0, b_lane, a.N, 0);
   for (int ks = 0; ks < a.KS; ks += 2) {
     load_a_raw<RT>(raw, a_lane, a.SD, ks);
-    if (ks + 1 < a.KS) load_b(b1, b_lane, b_plane_dw, a.N, ks + 1);
+    if (ks + 1 < a.KS) load_b(b1, b_lane, a.N, ks + 1);
     split_a<RT>(raw, fa);
-    mma_frags<RT>(c, fa, b0);
+    split_b(b0, fb);
+    mma_frags<RT>(c, fa, fb);
     if (ks + 1 < a.KS) {
       load_a_raw<RT>(raw, a_lane, a.SD, ks + 1);
-      if (ks + 2 < a.KS) load_b(b0, b_lane, b_plane_dw, a.N, ks + 2);
+      if (ks + 2 < a.KS) load_b(b0, b_lane, a.N, ks + 2);
       split_a<RT>(raw, fa);
-      mma_frags<RT>(c, fa, b1);
+      split_b(b1, fb);
+      mma_frags<RT>(c, fa, fb);
     }
   }
   epilogue<RT>(a, c, tile * TR, cw, lane, scratch);
@@ -462,18 +508,18 @@ __device__ __forceinline__ void consume_half(const mfma_args& a, f32x16 (&c)[RT]
   const int lm = lane & 31, lh = lane >> 5;
   const float* a_lane      = buf + lm * a.SD + lh * 8 - ks0 * 16;
   const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
-  const uint32_t* b_lane   = a.w_planes + ((int64_t)(cw * 64 + lm)) * 8 + lh * 4;
+  const uint32_t* b_lane   = reinterpret_cast<const uint32_t*>(a.w_tiles) + ((int64_t)(cw * 64 + lm)) * 8 + lh * 4;
   bfrag_t b1;
   araw_t<RT> raw;
   afrag_t<RT> fa;
   for (int ks = ks0; ks < ks1; ks += 2) {
     load_a_raw<RT>(raw, a_lane, a.SD, ks);
-    load_b(b1, b_lane, b_plane_dw, a.N, ks + 1 < ks1 ? ks + 1 : ks_next);
+    load_b_planes(b1, b_lane, b_plane_dw, a.N, ks + 1 < ks1 ? ks + 1 : ks_next);
     split_a<RT>(raw, fa);
     mma_frags<RT>(c, fa, b0);
     if (ks + 1 < ks1) {
       load_a_raw<RT>(raw, a_lane, a.SD, ks + 1);
-      load_b(b0, b_lane, b_plane_dw, a.N, ks + 2 < ks1 ? ks + 2 : ks_next);
+      load_b_planes(b0, b_lane, b_plane_dw, a.N, ks + 2 < ks1 ? ks + 2 : ks_next);
       split_a<RT>(raw, fa);
       mma_frags<RT>(c, fa, b1);
     } else {
@@ -496,24 +542,30 @@ __host__ __device__ constexpr int b_slot(int ks) { return ks < kPD ? ks : kPD + 
 template <int TR, int FC>
 struct static_consumer {
   static constexpr int RT = TR / 32, KSC = (2 * FC + 15) / 16, SD = row_stride_dw(FC);
-  bfrag_t bb[2 * kPD];   // [0, kPD): heads = k-steps 0 .. kPD-1 of a tile; [kPD, 2 kPD): ring for the rest
+  braw_t bb[2 * kPD];    // fp32 fragments: [0, kPD): heads = k-steps 0 .. kPD-1 of a tile; [kPD, 2 kPD): ring for the rest
   uint32_t b_lane_off;   // bytes
   f32x16 c[RT][2];       // accumulators of the tile being multiplied / waiting to be stored
 
-  __device__ __forceinline__ void load_b_static(const mfma_args& a, bfrag_t& f, int ks) const
+  __device__ __forceinline__ void load_b_static(const mfma_args& a, braw_t& f, int ks) const
   {
-    const char* wb       = reinterpret_cast<const char*>(a.w_planes);   // uniform: stays in SGPRs
-    const size_t plane_b = (size_t)KSC * a.N * 32;
+#ifdef WG_ABL_NO_B   // tuning build: no weight loads (stale registers, wrong results) — prices the weight stream
+    return;
+#endif
+#ifdef WG_ABL_HALF_B   // tuning build: every other k-step's weight fragments only — prices HALF the weight stream
+    if (ks & 1) return;
+#endif
+    const char* wb = reinterpret_cast<const char*>(a.w_tiles);   // uniform: stays in SGPRs
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-      for (int p = 0; p < 3; p++)
-        f.v[ct][p] = *reinterpret_cast<const u32x4*>(wb + (p * plane_b + ((size_t)ks * a.N + ct * 32) * 32) + b_lane_off);
+    for (int ct = 0; ct < 2; ct++) {
+      const size_t at = ((size_t)ks * a.N + ct * 32) * 64 + b_lane_off;
+      f.v[ct][0]      = *reinterpret_cast<const f32x4*>(wb + at);
+      f.v[ct][1]      = *reinterpret_cast<const f32x4*>(wb + at + 16);
+    }
   }
 
   __device__ __forceinline__ void prime(const mfma_args& a, int cw, int lane)
   {
-    b_lane_off = (uint32_t)(((cw * 64 + (lane & 31)) * 8 + (lane >> 5) * 4) * 4);
+    b_lane_off = (uint32_t)(((cw * 64 + (lane & 31)) * 16 + (lane >> 5) * 8) * 4);
 #pragma unroll
     for (int j = 0; j < kPD; j++) load_b_static(a, bb[j], j);
   }
@@ -534,7 +586,9 @@ struct static_consumer {
 #pragma unroll
     for (int ks = 0; ks < KSC; ks++) {
       if (ks + 1 < KSC) load_a_raw<RT>(raw, a_lane, SD, ks + 1);
-      mma_frags<RT>(c, fa[ks & 1], bb[b_slot(ks)]);
+      bfrag_t fb;
+      split_b(bb[b_slot(ks)], fb);
+      mma_frags<RT>(c, fa[ks & 1], fb);
       const int nk = ks + kPD;   // the slot just multiplied from (ring) or long since consumed (head) is free again
       if (nk < KSC) load_b_static(a, bb[b_slot(nk)], nk);
       else load_b_static(a, bb[nk - KSC], nk - KSC);
@@ -656,10 +710,8 @@ sage_layer_mfma_kernel(mfma_args a)
       float* scratch = lds + 2 * tile_dw + 16 + wave * kScratchDw;
       f32x16 c[RT][2];
       bfrag_t b0;
-      {
-        const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
-        load_b(b0, a.w_planes + ((int64_t)(wave * 64 + (lane & 31))) * 8 + (lane >> 5) * 4, b_plane_dw, a.N, 0);
-      }
+      load_b_planes(b0, reinterpret_cast<const uint32_t*>(a.w_tiles) + ((int64_t)(wave * 64 + (lane & 31))) * 8 + (lane >> 5) * 4,
+                    (int64_t)a.KS * a.N * 8, a.N, 0);
       for (int64_t n = 0; n <= mine; n++) {
         if (n >= 1 && !(a.debug & 1)) {
           consume_half<RT>(a, c, buf1, KSh, a.KS, 0, wave, lane, b0);
@@ -759,8 +811,8 @@ sage_layer_mfma_kernel(mfma_args a)
   }
 }
 
-// ---- pre-split weight ------------------------------------------------------------------------------------------------
-// w_t [K, N] fp32 row-major (ldw)  ->  planes [3][KS][N][16] bf16, rows K .. 16 KS - 1 zero
+// ---- weight in the order the multiplying waves read it -----------------------------------------------------------------
+// HALF mode: w_t [K, N] fp32 row-major (ldw)  ->  planes [3][KS][N][16] bf16, rows K .. 16 KS - 1 zero
 __global__ void split_weight_kernel(const float* __restrict__ w_t, int64_t ldw, int K, int N, int KS, uint32_t* __restrict__ planes)
 {
   const int64_t total = (int64_t)KS * N * 8;  // dwords per plane
@@ -777,6 +829,20 @@ __global__ void split_weight_kernel(const float* __restrict__ w_t, int64_t ldw, 
     planes[i]             = pack_hi16(h0, h1);
     planes[total + i]     = pack_hi16(m0, m1);
     planes[2 * total + i] = pack_hi16(l0, l1);
+  }
+}
+
+// w_t [K, N] fp32 row-major (ldw)  ->  tiles [KS][N][16] fp32 (k-step, column, 16 consecutive k), rows K .. 16 KS - 1 zero:
+// a lane's half k-step of one column is 32 contiguous bytes, a wave's load 1 KiB + 1 KiB contiguous
+__global__ void tile_weight_kernel(const float* __restrict__ w_t, int64_t ldw, int K, int N, int KS, float* __restrict__ tiles)
+{
+  const int64_t total = (int64_t)KS * N * 16;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 15);
+    const int n  = (int)((i >> 4) % N);
+    const int ks = (int)((i >> 4) / N);
+    const int k  = ks * 16 + kk;
+    tiles[i]     = k < K ? w_t[(int64_t)k * ldw + n] : 0.f;
   }
 }
 
@@ -880,6 +946,7 @@ void launch_groups(const mfma_args& a, hipStream_t st)
 }  // namespace wgamd
 
 #ifndef WG_MFMA_TUNE_HARNESS
+// (sized for the larger of the two formats: bf16 planes are 96 B per (k-step, column), fp32 tiles 64 B)
 extern "C" size_t wgamd_sage_weight_planes_bytes(int K, int N) { return (size_t)3 * ((K + 15) / 16) * (size_t)N * 32; }
 
 extern "C" int wgamd_sage_layer_bf16x3_supported(int F, int N)
@@ -894,9 +961,13 @@ extern "C" wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* 
   return guarded("wgamd_sage_split_weight_bf16x3", [&] {
     WG_REQUIRE_INPUT(w_t && planes && K > 0 && N > 0 && ldw >= N, "bad weight");
     const int KS        = (K + 15) / 16;
-    const int64_t total = (int64_t)KS * N * 8;
+    const int64_t total = (int64_t)KS * N * 16;
     const int grid      = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    split_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_t, ldw, K, N, KS, static_cast<uint32_t*>(planes));
+    // K = 2F: the layer kernel of this F decides the format (half-tile mode reads pre-split planes, the others fp32 tiles)
+    if (K % 2 == 0 && use_half_tiles(K / 2))
+      split_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_t, ldw, K, N, KS, static_cast<uint32_t*>(planes));
+    else
+      tile_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_t, ldw, K, N, KS, static_cast<float*>(planes));
     WG_HIP_CHECK(hipGetLastError());
   });
 }
@@ -920,7 +991,10 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row
     // x below 2 GB (extent known): 32-bit row offsets and buffer loads whose out-of-range slots read as zero
     const uint64_t xb = x_rows > 0 ? (uint64_t)x_rows * (uint64_t)ldx * 4u : 0;
     mfma_args a{row_ptr, col, n_rows, x, ldx, (uint32_t)(xb > 0 && xb < (1ull << 31) ? xb : 0), F, src_ids, self_rows, mean,
-                static_cast<const uint32_t*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr};
+                static_cast<const float*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr};
+    // WGAMD_SAGE_DEBUG=<bits> (tuning only; results are WRONG with 4 / 8): the ablation switches of mfma_args::debug
+    static const int dbg = [] { const char* e = getenv("WGAMD_SAGE_DEBUG"); return e ? atoi(e) : 0; }();
+    a.debug = dbg;
     auto st = static_cast<hipStream_t>(stream);
     if (src_ids == nullptr) launch_groups<void>(a, st);
     else if (src_ids_dtype == WHOLEMEMORY_DT_INT) launch_groups<int32_t>(a, st);

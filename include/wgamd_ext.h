@@ -381,8 +381,10 @@ wholememory_error_code_t wgamd_sage_layer_fused_f32(const int* row_ptr, const in
  * exactly into three bf16 pieces (a = a_hi + a_mid + a_lo; 24 = 3 x 8 significand bits) and the six products of weight
  * >= 2^-16 are accumulated in fp32 (v_mfma_f32_32x32x16_bf16); the dropped terms are <= 2^-23 |a b|, the class of fp32
  * round-off.  Six bf16 MFMAs cost 6/16 of one fp32 MFMA, which takes the layer from the fp32-MFMA roof to the HBM roof.
- * `w_planes` is the weight [2F, N] pre-split by wgamd_sage_split_weight_bf16x3 into wgamd_sage_weight_planes_bytes(2F, N)
- * bytes (do it once per weight update).  Shapes: F % 4 == 0 and small enough for two 32-row tiles of 3 bf16 planes in
+ * `w_planes` is the weight [2F, N] re-ordered by wgamd_sage_split_weight_bf16x3 into wgamd_sage_weight_planes_bytes(2F, N)
+ * bytes (do it once per weight update): since round 3 fp32 tiles [k-step][column][16 consecutive k] — the weight travels as
+ * 4 bytes per element and the multiplying waves split it in registers (the pre-split planes were 6; the weight stream is what
+ * the layer's time is most sensitive to).  The buffer is opaque to callers; the entry-point names are kept.  Shapes: F % 4 == 0 and small enough for two 32-row tiles of 3 bf16 planes in
  * 160 KB of LDS (F <= 208), N in {64, 128, 256}: wgamd_sage_layer_bf16x3_supported.  Inf/NaN features give NaN rows. */
 size_t wgamd_sage_weight_planes_bytes(int K, int N);
 int wgamd_sage_layer_bf16x3_supported(int F, int N);

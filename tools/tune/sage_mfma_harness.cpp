@@ -28,16 +28,16 @@ int main(int argc, char** argv)
   std::vector<float> x((size_t)n_src * F), w((size_t)2 * F * N), bias(N, 0.1f);
   for (auto& v : x) v = (float)((rng() >> 40) * (1.0 / (1 << 24))) - 0.5f;
   for (auto& v : w) v = (float)((rng() >> 40) * (1.0 / (1 << 24))) - 0.5f;
-  int *d_rp, *d_col; int64_t* d_self; float *d_x, *d_w, *d_bias, *d_out; uint32_t* d_planes;
+  int *d_rp, *d_col; int64_t* d_self; float *d_x, *d_w, *d_bias, *d_out; float* d_planes;
   const int KS = (2 * F + 15) / 16;
-  const size_t planes_bytes = (size_t)3 * KS * N * 32;
+  const size_t planes_bytes = (size_t)KS * N * 64;
   hipMalloc(&d_rp, rp.size() * 4); hipMalloc(&d_col, col.size() * 4); hipMalloc(&d_self, self.size() * 8);
   hipMalloc(&d_x, x.size() * 4); hipMalloc(&d_w, w.size() * 4); hipMalloc(&d_bias, N * 4);
   hipMalloc(&d_out, (size_t)n_dst * N * 4); hipMalloc(&d_planes, planes_bytes);
   hipMemcpy(d_rp, rp.data(), rp.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_col, col.data(), col.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_self, self.data(), self.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_bias, bias.data(), N * 4, hipMemcpyHostToDevice);
-  split_weight_kernel<<<1024, 256>>>(d_w, N, 2 * F, N, KS, d_planes);
+  tile_weight_kernel<<<1024, 256>>>(d_w, N, 2 * F, N, KS, d_planes);
   mfma_args a{d_rp, d_col, n_dst, d_x, F, (uint32_t)(x.size() * 4), F, nullptr, d_self, 1, d_planes, N, KS, d_bias, 1, d_out, N, row_stride_dw(F), 0, nullptr};
   unsigned long long* d_stamps; hipMalloc(&d_stamps, 64 * 16 * 8); hipMemset(d_stamps, 0, 64 * 16 * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
