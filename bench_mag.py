@@ -161,25 +161,30 @@ class MagPipeline:
         cseg = rec["cseg"]
 
         def prep():
+            from wholegraph_amd import _lib as L
+            from wholegraph_amd.env import get_stream
             out = []
             for c, lv in zip(rec["calls"], live):
-                if c is None or lv[1] == 0:
+                if c is None or lv[0] == 0:
                     out.append(None)
                     continue
-                n_f, n_e = lv
+                n_f, n_e = lv      # (a hop with frontier entries but no sampled edge stays: its rows still get relu(bias))
                 src_t, _, dst_t = c["et"]
                 for k in ("offsets", "row", "f_batch", "f_seg", "f_local0"):
                     c[k].record_stream(main)
-                off = c["offsets"][:n_f + 1].contiguous()
-                fb = c["f_batch"][:n_f].long()
-                local = c["f_local0"].long()[fb] + (torch.arange(n_f, device=self.dev) - c["f_seg"].long()[fb])
-                e_batch = torch.repeat_interleave(fb, (off[1:] - off[:-1]).long(), output_size=n_e)
-                row_l = c["row"][:n_e].long()
-                out.append(dict(et=c["et"], hop=c["hop"], off=off, n_f=n_f, n_e=n_e,
-                                dst_full=(state[dst_t]["seg"].long()[fb] + local).contiguous(),
-                                dst_c=(cseg[dst_t][fb] + local).contiguous(),
-                                col_full=(row_l + state[src_t]["seg"].long()[e_batch]).to(torch.int32),
-                                col_c=(row_l + cseg[src_t][e_batch]).to(torch.int32) if c["hop"] == 0 else None))
+                first_hop = c["hop"] == 0
+                dst_full = torch.empty(n_f, dtype=torch.int64, device=self.dev)
+                dst_c = torch.empty(n_f, dtype=torch.int64, device=self.dev)
+                col_full = torch.empty(max(n_e, 1), dtype=torch.int32, device=self.dev)
+                col_c = torch.empty(max(n_e, 1), dtype=torch.int32, device=self.dev) if first_hop else None
+                # one launch per hop and edge type (wgamd_call_group_hop_rows) instead of a dozen torch index ops
+                L.check(L.lib().wgamd_call_group_hop_rows(
+                    c["offsets"].data_ptr(), c["f_batch"].data_ptr(), c["f_seg"].data_ptr(), c["f_local0"].data_ptr(),
+                    c["row"].data_ptr(), n_f, state[dst_t]["seg"].data_ptr(), cseg[dst_t].data_ptr(), state[src_t]["seg"].data_ptr(),
+                    cseg[src_t].data_ptr() if first_hop else None, dst_full.data_ptr(), dst_c.data_ptr(), col_full.data_ptr(),
+                    col_c.data_ptr() if first_hop else None, get_stream()), "wgamd_call_group_hop_rows")
+                out.append(dict(et=c["et"], hop=c["hop"], off=c["offsets"][:n_f + 1], n_f=n_f, n_e=n_e, dst_full=dst_full,
+                                dst_c=dst_c, col_full=col_full, col_c=col_c))
             return out
         calls = [c for c in stage("index_prep", prep) if c is not None]
         edges = sum(lv[1] for lv in live if lv is not None)
@@ -198,6 +203,8 @@ class MagPipeline:
                         mats.append(p["rel"][et]["v_dst"]); keys.append((a_dst, et))
                 if not mats:
                     continue
+                # (a hand-written narrow-matmul kernel — 64-row LDS tiles, K <= 32 — was built and measured: no faster than the
+                #  library GEMM at F = 128, slower at F = 256; taken out again)
                 both = xs[t] @ torch.cat(mats, 1)
                 for k, (dst, et) in enumerate(keys):
                     dst[et] = both[:, k * HEADS:(k + 1) * HEADS].contiguous()
@@ -207,8 +214,8 @@ class MagPipeline:
             """One HeteroConv{GATConv} layer for the frontier rows of the hops in ``hop_set``; returns {type: compact rows}."""
             p = self.params[layer]
             a_src, a_dst = stage("attn_terms%d" % (layer + 1), lambda: attention_terms(xs, p))
-            # (rows no relation reaches — a frontier vertex without in-edges of any type — hold HeteroConv's empty sum)
-            out = {t: torch.relu(p["bias"][t]).expand(n_out[t], HC).contiguous() for t in self.ntypes if n_out[t] > 0}
+            # every compact row is a frontier entry of exactly one hop of its type, so the index_copy below writes all of them
+            out = {t: torch.empty((n_out[t], HC), dtype=torch.float32, device=self.dev) for t in self.ntypes if n_out[t] > 0}
             for h in hop_set:
                 for dt in self.ntypes:
                     mine = [c for c in calls if c["hop"] == h and c["et"][2] == dt]
@@ -217,6 +224,8 @@ class MagPipeline:
                     acc = torch.zeros((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
                     for c in mine:
                         et = c["et"]
+                        if c["n_e"] == 0:
+                            continue      # nothing sampled for this relation: it adds nothing to HeteroConv's sum
                         agg = stage("gat%d:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
                                     lambda: nn.gat_aggregate_heads(c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], HEADS,
                                                                    dst_rows=c[dst_key]))

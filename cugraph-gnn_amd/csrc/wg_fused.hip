@@ -146,6 +146,38 @@ target_rows_kernel(const int* __restrict__ unique_seg, const int* __restrict__ t
   rows[i]     = (int64_t)i + unique_seg[b] - target_seg[b];
 }
 
+// One (hop, edge type) of a HETEROGENEOUS call group, as the layers consume it: where the hop's frontier entries sit in the
+// destination type's node list (batch-major lists: row = segment start of the batch + local id) and the source rows of its
+// edges in the source type's list — in the FULL numbering (all vertices of the walk) and in the COMPACT one (the vertices
+// discovered by hops 0-1 only: what layer 1 has to produce and layer 2 reads).  One 16-lane group per frontier entry walks
+// the entry's edges; replaces a dozen torch index ops per hop and edge type.
+__global__ void __launch_bounds__(256)
+hetero_hop_rows_kernel(const int* __restrict__ offsets, const int* __restrict__ f_batch, const int* __restrict__ f_seg,
+                       const int* __restrict__ f_local0, const int* __restrict__ row_local, int n_f,
+                       const int* __restrict__ seg_dst, const int64_t* __restrict__ cseg_dst, const int* __restrict__ seg_src,
+                       const int64_t* __restrict__ cseg_src, int64_t* __restrict__ dst_full, int64_t* __restrict__ dst_compact,
+                       int* __restrict__ col_full, int* __restrict__ col_compact)
+{
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j   = tid >> 4;
+  const int sub     = (int)(tid & 15);
+  if (j >= n_f) return;
+  const int b     = f_batch[j];
+  const int local = f_local0[b] + ((int)j - f_seg[b]);
+  if (sub == 0) {
+    dst_full[j] = (int64_t)seg_dst[b] + local;
+    if (dst_compact) dst_compact[j] = cseg_dst[b] + local;
+  }
+  const int s = offsets[j], e = offsets[j + 1];
+  const int add_full = seg_src[b];
+  const int add_c    = col_compact ? (int)cseg_src[b] : 0;
+  for (int i = s + sub; i < e; i += 16) {
+    const int r = row_local[i];
+    col_full[i] = r + add_full;
+    if (col_compact) col_compact[i] = r + add_c;
+  }
+}
+
 }  // namespace
 }  // namespace wgamd
 
@@ -226,6 +258,28 @@ wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, con
     WG_REQUIRE_INPUT(unique_seg && target_seg && target_batch && rows, "null pointer");
     target_rows_kernel<<<ceil_div(n_targets, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(unique_seg, target_seg, target_batch,
                                                                                               (int)n_targets, rows);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_call_group_hop_rows(const int* offsets, const int* frontier_batch, const int* frontier_seg,
+                                                   const int* frontier_local0, const int* row_local, int64_t n_frontier,
+                                                   const int* seg_dst, const int64_t* compact_seg_dst, const int* seg_src,
+                                                   const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
+                                                   int* col_full, int* col_compact, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_call_group_hop_rows", [&] {
+    WG_REQUIRE_INPUT(n_frontier >= 0 && n_frontier < ((int64_t)1 << 27), "bad frontier count");
+    if (n_frontier == 0) return;
+    WG_REQUIRE_INPUT(offsets && frontier_batch && frontier_seg && frontier_local0 && row_local && seg_dst && seg_src && dst_full &&
+                       col_full,
+                     "null pointer");
+    WG_REQUIRE_INPUT((dst_compact == nullptr) == (compact_seg_dst == nullptr) && (col_compact == nullptr) == (compact_seg_src == nullptr),
+                     "a compact output needs its compact segment array (and the other way round)");
+    hetero_hop_rows_kernel<<<ceil_div(n_frontier * 16, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      offsets, frontier_batch, frontier_seg, frontier_local0, row_local, (int)n_frontier, seg_dst, compact_seg_dst, seg_src,
+      compact_seg_src, dst_full, dst_compact, col_full, col_compact);
     WG_HIP_CHECK(hipGetLastError());
   });
 }

@@ -323,6 +323,17 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
 wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, const int* target_seg, const int* target_batch,
                                                       int64_t n_targets, int64_t* rows, void* stream);
 
+/* One (hop, edge type) of a heterogeneous call group (wgamd_sample_hop_pyg_nosync outputs) in the form the layers consume:
+ * dst_full[j] / dst_compact[j] = row of frontier entry j in the destination type's batch-major node list — all vertices of
+ * the walk (segments seg_dst [G+1]) / the vertices discovered by hops 0-1 only (compact_seg_dst [G+1], int64; NULL with
+ * dst_compact NULL) — and col_full[e] / col_compact[e] = row of edge e's source in the source type's list, the same two ways
+ * (row_local = the hop's `neighbor_local`).  Entry j of batch b has local id frontier_local0[b] + (j - frontier_seg[b]). */
+wholememory_error_code_t wgamd_call_group_hop_rows(const int* offsets, const int* frontier_batch, const int* frontier_seg,
+                                                   const int* frontier_local0, const int* row_local, int64_t n_frontier,
+                                                   const int* seg_dst, const int64_t* compact_seg_dst, const int* seg_src,
+                                                   const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
+                                                   int* col_full, int* col_compact, void* stream);
+
 /* wgamd_gat_csr_f32 over a SUBSET of a larger destination list, optionally accumulating: row i of this launch reads
  * a_dst[dst_rows[i], :] and writes (accumulate: adds to) out[dst_rows[i], :].  This is one hop and edge type of a
  * heterogeneous call group: its rows are the frontier entries of that hop, dst_rows their places in the node list of the

@@ -108,3 +108,34 @@ def test_mag_pipeline_matches_cpu_port(oracle_mod, hiplib):
         total += e
         np.testing.assert_allclose(out[b * B:(b + 1) * B].cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
     assert total == edges        # bit-exact sampling: the same edges on both sides
+
+
+def test_call_group_hop_rows_matches_the_index_formulas(hiplib):
+    """wgamd_call_group_hop_rows against the torch index arithmetic it replaces (full and compact numbering)."""
+    import torch
+    from wholegraph_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(4)
+    G = 7
+    cnt = torch.randint(0, 40, (G,), generator=g, device="cuda")                       # frontier entries per batch
+    f_seg = torch.zeros(G + 1, dtype=torch.int32, device="cuda"); f_seg[1:] = torch.cumsum(cnt, 0)
+    n_f = int(f_seg[-1])
+    f_batch = torch.repeat_interleave(torch.arange(G, device="cuda"), cnt).int()
+    f_local0 = torch.randint(0, 50, (G,), generator=g, device="cuda").int()
+    deg = torch.randint(0, 30, (n_f,), generator=g, device="cuda")
+    off = torch.zeros(n_f + 1, dtype=torch.int32, device="cuda"); off[1:] = torch.cumsum(deg, 0)
+    n_e = int(off[-1])
+    row_l = torch.randint(0, 500, (n_e,), generator=g, device="cuda").int()
+    seg_d = (torch.arange(G + 1, device="cuda") * 1000).int(); seg_s = (torch.arange(G + 1, device="cuda") * 3000).int()
+    cseg_d = torch.arange(G + 1, device="cuda") * 300; cseg_s = torch.arange(G + 1, device="cuda") * 700
+    dst_full, dst_c = torch.empty(n_f, dtype=torch.int64, device="cuda"), torch.empty(n_f, dtype=torch.int64, device="cuda")
+    col_full, col_c = torch.empty(n_e, dtype=torch.int32, device="cuda"), torch.empty(n_e, dtype=torch.int32, device="cuda")
+    rc = hiplib.wgamd_call_group_hop_rows(off.data_ptr(), f_batch.data_ptr(), f_seg.data_ptr(), f_local0.data_ptr(), row_l.data_ptr(),
+                                          n_f, seg_d.data_ptr(), cseg_d.data_ptr(), seg_s.data_ptr(), cseg_s.data_ptr(),
+                                          dst_full.data_ptr(), dst_c.data_ptr(), col_full.data_ptr(), col_c.data_ptr(), None)
+    assert rc == L.WHOLEMEMORY_SUCCESS
+    torch.cuda.synchronize()
+    fb = f_batch.long()
+    local = f_local0.long()[fb] + (torch.arange(n_f, device="cuda") - f_seg.long()[fb])
+    eb = torch.repeat_interleave(fb, deg)
+    assert torch.equal(dst_full, seg_d.long()[fb] + local) and torch.equal(dst_c, cseg_d[fb] + local)
+    assert torch.equal(col_full.long(), row_l.long() + seg_s.long()[eb]) and torch.equal(col_c.long(), row_l.long() + cseg_s[eb])
