@@ -377,6 +377,9 @@ __device__ __forceinline__ void load_b(braw_t& f, const float* b_lane, int n_col
 // costs more than the bytes it saves: 1.74 vs 1.69 ms at 256 -> 256) keeps the pre-split planes [3][KS][N][8 dwords]
 __device__ __forceinline__ void load_b_planes(bfrag_t& f, const uint32_t* b_lane, int64_t b_plane_dw, int n_cols, int ks)
 {
+#ifdef WG_ABL_NO_B
+  return;
+#endif
 #pragma unroll
   for (int ct = 0; ct < 2; ct++)
 #pragma unroll
