@@ -108,6 +108,27 @@ UNEVEN_WORKER = textwrap.dedent(r"""
         assert torch.equal(batch.x.cpu(), x[batch.n_id.cpu()])
         nb += 1
     assert nb == (2 if rank == 0 else 5), (rank, nb)
+    # heterogeneous store (two node types, two relations), seeds of type "a": 2 vs 4 batches + ragged
+    hs, hf = GraphStore(), FeatureStore()
+    na, nb_ = 3000, 2000
+    e_ab = torch.stack([torch.randint(0, na, (30000,), generator=g), torch.randint(0, nb_, (30000,), generator=g)])
+    e_ba = torch.stack([torch.randint(0, nb_, (30000,), generator=g), torch.randint(0, na, (30000,), generator=g)])
+    half = 15000
+    sl = slice(0, half) if rank == 0 else slice(half, 30000)
+    hs.put_edge_index(e_ab[:, sl].cuda(), ("a", "to", "b"), "coo", False, (na, nb_))
+    hs.put_edge_index(e_ba[:, sl].cuda(), ("b", "back", "a"), "coo", False, (nb_, na))
+    xa, xb = torch.randn(na, 6, generator=g), torch.randn(nb_, 5, generator=g)
+    ca, cb = (0, 1200, na), (0, 900, nb_)
+    hf["a", "x", None] = xa[ca[rank]:ca[rank + 1]].cuda()
+    hf["b", "x", None] = xb[cb[rank]:cb[rank + 1]].cuda()
+    hseeds = (torch.arange(2 * B) if rank == 0 else torch.arange(500, 500 + 4 * B + 5)).cuda()
+    hl = NeighborLoader((hf, hs), {("a", "to", "b"): [3, 2], ("b", "back", "a"): [3, 2]}, input_nodes=("a", hseeds), batch_size=B,
+                        shuffle=False, random_state=5, local_seeds_per_call=2 * B)
+    nb = 0
+    for batch in hl:
+        assert torch.equal(batch["a"].x.cpu(), xa[batch["a"].n_id.cpu()]) and torch.equal(batch["b"].x.cpu(), xb[batch["b"].n_id.cpu()])
+        nb += 1
+    assert nb == (2 if rank == 0 else 5), (rank, nb)
     # defaults: the call group is sized from device memory (>= 64 mini-batches of 1024 seeds for fan-out [25, 10] on 288 GB)
     from cugraph_pyg_amd.sampler.sampler import default_local_seeds_per_call
     assert default_local_seeds_per_call([25, 10], 1024) >= 64 * 1024
