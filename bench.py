@@ -308,7 +308,7 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
 
 
 def load_pmc(kernel_prefix, want_void=True):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r02/pmc_traffic.json: separate
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/rNN/pmc_traffic.json, newest round first: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS command's launch shape, FETCH_SIZE x 2 per
     MI355X_MICROARCH.md §HBM; tools/pmc_summary.py).  Counters cannot be read from inside the timed process."""
     for rnd in ("r03", "r02", "r01"):
