@@ -232,11 +232,11 @@ class MagPipeline:
                         stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads(agg, p["rel"][et]["w"], HEADS, out=acc))
                         if launches is not None:
                             launches.append((et, h, c["n_f"], c["n_e"], xs[et[0]].shape[1]))
-                    res = stage("bias_relu", lambda: torch.relu_(acc.add_(p["bias"][dt])))
+                    # bias + ReLU (+ the placement of the hop's rows in the compact list of layer 1) in one pass
                     if layer == 0:
-                        stage("bias_relu", lambda: out[dt].index_copy_(0, mine[0]["dst_c"], res))
+                        stage("bias_relu", lambda: nn.bias_act_rows(acc, p["bias"][dt], True, mine[0]["dst_c"], out[dt]))
                     else:
-                        out[dt] = res
+                        out[dt] = stage("bias_relu", lambda: nn.bias_act_rows(acc, p["bias"][dt], True))
             return out
 
         launches = []

@@ -486,6 +486,27 @@ gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restric
   }
 }
 
+// out[dst_rows ? dst_rows[i] : i, :] = act(in[i, :] + bias): the tail of a HeteroConv layer (sum over relations done, bias,
+// ReLU, rows placed in the destination type's compact list) in ONE pass instead of three torch passes + an index_copy.
+__global__ void __launch_bounds__(256)
+bias_act_rows_kernel(const float* __restrict__ in, int64_t ldi, int64_t n_rows, int C, const float* __restrict__ bias, int relu,
+                     const int64_t* __restrict__ dst_rows, float* __restrict__ out, int64_t ldo)
+{
+  const int c4n = C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * c4n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c     = (int)(i % c4n) * 4;
+    float4 v        = *reinterpret_cast<const float4*>(in + r * ldi + c);
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    const int64_t o = dst_rows ? dst_rows[r] : r;
+    *reinterpret_cast<float4*>(out + o * ldo + c) = v;
+  }
+}
+
 inline int lanes_log2_for(int units)
 {
   int l = 0;
@@ -643,6 +664,23 @@ wholememory_error_code_t wgamd_spmm_csr_bwd_f32(const int* row_ptr, const int* c
       spmm_csr_bwd_kernel<4><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, grad_out, ldg, F, mean, grad_x, ldx, l2);
     else
       spmm_csr_bwd_kernel<1><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, grad_out, ldg, F, mean, grad_x, ldx, l2);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_bias_act_rows_f32(const float* in, int64_t ldi, int64_t n_rows, int C, const float* bias, int relu,
+                                                 const int64_t* dst_rows, float* out, int64_t ldo, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_bias_act_rows_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && C > 0, "bad sizes");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(in && out && ldi >= C && ldo >= C, "null pointer / leading dimension smaller than C");
+    if (!vec4_ok(in, ldi, out, ldo, C) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15) != 0))
+      throw logic_error("rows must be 16-byte aligned and C a multiple of 4");
+    const int64_t work = n_rows * (C / 4);
+    const int grid     = (int)std::min<int64_t>((work + 255) / 256, 256 * 32);
+    bias_act_rows_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(in, ldi, n_rows, C, bias, relu, dst_rows, out, ldo);
     WG_HIP_CHECK(hipGetLastError());
   });
 }

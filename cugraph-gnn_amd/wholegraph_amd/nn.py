@@ -341,6 +341,18 @@ def gat_transform_heads(agg, w, heads, out=None):
     return out
 
 
+def bias_act_rows(x, bias=None, relu=True, dst_rows=None, out=None):
+    """``out[dst_rows[i]] = act(x[i] + bias)`` in one pass (wgamd_bias_act_rows_f32); ``out`` defaults to a fresh [n, C]."""
+    n, C = x.shape
+    if out is None:
+        assert dst_rows is None
+        out = torch.empty((n, C), dtype=torch.float32, device=x.device)
+    L.check(L.lib().wgamd_bias_act_rows_f32(x.data_ptr(), x.stride(0), n, C, None if bias is None else bias.data_ptr(), int(bool(relu)),
+                                            None if dst_rows is None else dst_rows.data_ptr(), out.data_ptr(), out.stride(0),
+                                            get_stream()), "wgamd_bias_act_rows_f32")
+    return out
+
+
 def gat_backward_supported(H: int, C: int) -> bool:
     """Shapes ``wgamd_gat_csr_bwd_f32`` is built for (include/wgamd_ext.h)."""
     return C % 4 == 0 and ((C // 4) & (C // 4 - 1)) == 0 and H * C <= 256

@@ -345,6 +345,11 @@ wholememory_error_code_t wgamd_gat_csr_rows_f32(const int* row_ptr, const int* c
                                                 const int64_t* dst_rows, int accumulate, float* alpha_out, float* out,
                                                 int64_t ldo, void* stream);
 
+/* out[dst_rows ? dst_rows[i] : i, 0:C] = act(in[i, 0:C] + bias)  (bias nullable, relu 0/1; C % 4 == 0, 16-byte aligned rows):
+ * the tail of a HeteroConv layer — bias, ReLU and the placement of a hop's rows in the destination type's list — in one pass. */
+wholememory_error_code_t wgamd_bias_act_rows_f32(const float* in, int64_t ldi, int64_t n_rows, int C, const float* bias, int relu,
+                                                 const int64_t* dst_rows, float* out, int64_t ldo, void* stream);
+
 /* GAT aggregation BEFORE the dense transform (csrc/wg_aggregate.hip) — for sampled hops, where destinations are 10-20x
  * fewer than sources.  The attention-weighted sum is linear in the source rows, so
  *   agg[i, h, :] = sum_{e in row i} alpha_e^h x[col[e], :]          (x UNTRANSFORMED, F floats; out row i = [H][F])

@@ -139,3 +139,18 @@ def test_call_group_hop_rows_matches_the_index_formulas(hiplib):
     eb = torch.repeat_interleave(fb, deg)
     assert torch.equal(dst_full, seg_d.long()[fb] + local) and torch.equal(dst_c, cseg_d[fb] + local)
     assert torch.equal(col_full.long(), row_l.long() + seg_s.long()[eb]) and torch.equal(col_c.long(), row_l.long() + cseg_s[eb])
+
+
+def test_bias_act_rows(hiplib):
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn((1000, 256), generator=g, device="cuda")
+    b = torch.randn(256, generator=g, device="cuda")
+    assert torch.equal(nn.bias_act_rows(x, b, True), torch.relu(x + b)) and torch.equal(nn.bias_act_rows(x, None, False), x)
+    rows = torch.randperm(5000, generator=g, device="cuda")[:1000]
+    out = torch.full((5000, 256), 7.0, device="cuda")
+    nn.bias_act_rows(x, b, True, rows, out)
+    want = torch.full((5000, 256), 7.0, device="cuda")
+    want[rows] = torch.relu(x + b)
+    assert torch.equal(out, want)
