@@ -37,6 +37,11 @@
 //     MFMAs: 0.572 -> 0.564 ms); what they cost is their MEMORY instructions, which share the CU's vector-memory pipeline
 //     with the row fetches — no weight loads: 0.422, no output stores: 0.470, neither: 0.338 = the fetching waves alone
 //     (0.332).  Hence the fp32 weight tiles (two thirds of the bytes of pre-split planes): 0.570 -> 0.516 ms.
+//   * F > 148 (two [mean | self] tiles do not fit the LDS; the hidden-256 layers): only the MEAN half goes through the LDS,
+//     the multiplying waves read the SELF half of A from global memory, their loop is software-pipelined (split of k-step
+//     ks+1 dealt between the MFMAs of k-step ks by sched_group_barrier) and the weight planes run two k-steps ahead:
+//     256 -> 256 layer 1.69 -> 1.51 ms (no weight loads at all: 1.34; the multiplying waves alone: 0.90, of which 0.43 is
+//     the matrix pipe; the fetching waves alone: 0.73 = the HBM floor of the shape).
 //   * one s_barrier per step behind an LDS-only wait (s_waitcnt lgkmcnt(0)): neither side's global loads are drained.
 #include <algorithm>
 #include <cstdlib>
@@ -116,8 +121,9 @@ __host__ __device__ constexpr int row_stride_dw(int F)
   return (sd / 4) % 2 == 0 ? sd + 4 : sd;   // 4 * odd
 }
 
-// HALF mode (two 64-row tiles of [mean | self] do not fit the LDS: F > 148): the two LDS buffers hold the MEAN half and the
-// SELF half of ONE 64-row tile, F floats per row each; a row stride of 4 * odd >= F keeps ds_read_b128 conflict-free
+// HALF mode (two 64-row tiles of [mean | self] do not fit the LDS: F > 148): the two LDS buffers hold the MEAN halves of two
+// consecutive 64-row tiles, F floats per row (the self half is read from global memory by the multiplying waves); a row
+// stride of 4 * odd >= F keeps ds_read_b128 conflict-free
 __host__ __device__ constexpr int row_stride_half_dw(int F)
 {
   int sd = (F + 3) / 4 * 4;
@@ -235,28 +241,6 @@ struct producer {
         v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? (int64_t)m.self[it] : (int64_t)0) + f0c * 4);
     }
   }
-  // HALF mode: the self rows of one 32-row sub-tile (offsets saved when its metadata was current; bit `it` of `valid` =
-  // the row exists), requested together, into the SELF buffer
-  __device__ __forceinline__ void self_rows(const off_t (&so)[IT], uint32_t valid, float* self_lds) const
-  {
-    f32x4 v[IT];
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-      const bool ok = (valid >> it) & 1u;
-      if constexpr (OFF32) {
-        v[it] = __builtin_bit_cast(f32x4,
-                                   __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (uint32_t)so[it] + f0c * 4 : a.x_bytes, 0, 0));
-      } else {
-        v[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + (ok ? (int64_t)so[it] : (int64_t)0) + f0c * 4);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-      f32x4 self = v[it];
-      if constexpr (!OFF32) self = ((valid >> it) & 1u) ? self : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (live) *reinterpret_cast<f32x4*>(self_lds + (group + it * kGroups) * a.SD + f0) = self;
-    }
-  }
   // sum row `it` from its ring slot (CSR order) and store [mean | self] as fp32
   __device__ __forceinline__ void reduce_store(const meta_t<IT, off_t>& m, int it, const f32x4* v, float* tile_lds) const
   {
@@ -345,6 +329,15 @@ __device__ __forceinline__ void split_a(const araw_t<RT>& r, afrag_t<RT>& f)
 {
 #pragma unroll
   for (int rt = 0; rt < RT; rt++) {
+#ifdef WG_ABL_NO_SPLIT   // tuning build: no split work (wrong results) — prices the VALU side of the multiplying waves
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      f.v[rt][0][j] = __float_as_uint(r.v[rt][0][j]);
+      f.v[rt][1][j] = __float_as_uint(r.v[rt][1][j]);
+      f.v[rt][2][j] = __float_as_uint(r.v[rt][0][j]);
+    }
+    continue;
+#endif
     uint32_t h[8], m[8], l[8];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -374,7 +367,8 @@ __device__ __forceinline__ void load_b(braw_t& f, const float* b_lane, int n_col
   }
 }
 // HALF mode (F > 148, K = 512: the multiplying waves are the busier side there and the split of the weight in registers
-// costs more than the bytes it saves: 1.74 vs 1.69 ms at 256 -> 256) keeps the pre-split planes [3][KS][N][8 dwords]
+// costs more than the bytes it saves: 1.74 vs 1.69 ms at 256 -> 256 in round 2; with the round-3 loop there are no
+// registers left for fp32 fragments two k-steps ahead AND split planes) keeps the pre-split planes [3][KS][N][8 dwords]
 __device__ __forceinline__ void load_b_planes(bfrag_t& f, const uint32_t* b_lane, int64_t b_plane_dw, int n_cols, int ks)
 {
 #ifdef WG_ABL_NO_B
@@ -502,32 +496,72 @@ __device__ __forceinline__ void consume_tile(const mfma_args& a, int64_t tile, c
   epilogue<RT>(a, c, tile * TR, cw, lane, scratch);
 }
 
-// ---- HALF mode: k-steps [ks0, ks1) of the tile from ONE buffer (column 0 of the buffer = k-step ks0); b0 holds the weight
-// fragments of k-step ks0 on entry and those of the NEXT half's first k-step on return (requested before the barrier) -----
-template <int RT>
-__device__ __forceinline__ void consume_half(const mfma_args& a, f32x16 (&c)[RT][2], const float* buf, int ks0, int ks1,
-                                             int ks_next, int cw, int lane, bfrag_t& b0)
+// Issue-order hint for one software-pipelined k-step of the runtime-shape multiplying loops: the 24 MFMAs of k-step ks with
+// the VALU work of the NEXT k-step's fragment split dealt between them.  A wave issues in order and an MFMA blocks issue
+// while the matrix pipe is busy with the one before (32 cycles each here); written as "24 MFMAs, then the split" the pipe
+// idles for the whole split (~90 VALU instructions), as "MFMA, 5 VALU, MFMA, ..." the split is free.
+template <int HEAD, int BODY, int VALU_PER>
+__device__ __forceinline__ void mfma_valu_interleave()
+{
+#pragma unroll
+  for (int i = 0; i < HEAD; i++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+  for (int i = 0; i < BODY; i++) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);
+  }
+}
+
+// ---- HALF mode, one range of k-steps with the weight fragments TWO k-steps ahead (ring of three) ---------------------------
+// load_a(dst, ks) requests the fp32 A fragment of k-step ks (LDS: AD = 1 k-step ahead; global self rows: AD = 2).  The
+// weight stream is one sequence over the whole kernel — k-step (ks + 2) mod KS is requested in step ks — and the ring is
+// rotated back to position 0 when a range ends, so every range starts with b[0] = its first k-step, b[1] = its second.
+template <int RT, int AD, typename LoadA>
+__device__ __forceinline__ void consume_range(const mfma_args& a, f32x16 (&c)[RT][2], bfrag_t (&b)[3], int ks0, int ks1, int cw,
+                                              int lane, LoadA load_a)
 {
   const int lm = lane & 31, lh = lane >> 5;
-  const float* a_lane      = buf + lm * a.SD + lh * 8 - ks0 * 16;
   const int64_t b_plane_dw = (int64_t)a.KS * a.N * 8;
   const uint32_t* b_lane   = reinterpret_cast<const uint32_t*>(a.w_tiles) + ((int64_t)(cw * 64 + lm)) * 8 + lh * 4;
-  bfrag_t b1;
-  araw_t<RT> raw;
-  afrag_t<RT> fa;
-  for (int ks = ks0; ks < ks1; ks += 2) {
-    load_a_raw<RT>(raw, a_lane, a.SD, ks);
-    load_b_planes(b1, b_lane, b_plane_dw, a.N, ks + 1 < ks1 ? ks + 1 : ks_next);
-    split_a<RT>(raw, fa);
-    mma_frags<RT>(c, fa, b0);
-    if (ks + 1 < ks1) {
-      load_a_raw<RT>(raw, a_lane, a.SD, ks + 1);
-      load_b_planes(b0, b_lane, b_plane_dw, a.N, ks + 2 < ks1 ? ks + 2 : ks_next);
-      split_a<RT>(raw, fa);
-      mma_frags<RT>(c, fa, b1);
-    } else {
-      b0 = b1;
-    }
+  araw_t<RT> raw[AD];
+  afrag_t<RT> fa[2];
+  const int kl = ks1 - 1;
+  load_a(raw[0], ks0);
+  if constexpr (AD == 2) load_a(raw[1], ks0 + 1 < kl ? ks0 + 1 : kl);
+  split_a<RT>(raw[0], fa[0]);
+  auto step = [&](auto I, int ks) {
+    constexpr int i = decltype(I)::value;
+    load_a(raw[i % AD], ks + AD < kl ? ks + AD : kl);
+    int kb = ks + 2;
+    kb     = kb >= a.KS ? kb - a.KS : kb;
+    load_b_planes(b[(i + 2) % 3], b_lane, b_plane_dw, a.N, kb);
+    mma_frags<RT>(c, fa[i & 1], b[i % 3]);
+    split_a<RT>(raw[(i + 1) % AD], fa[(i + 1) & 1]);
+    mfma_valu_interleave<4, 6 * RT * 2 - 4, 5>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int ks = ks0;
+  for (; ks + 5 < ks1; ks += 6) {
+    step(std::integral_constant<int, 0>{}, ks);
+    step(std::integral_constant<int, 1>{}, ks + 1);
+    step(std::integral_constant<int, 2>{}, ks + 2);
+    step(std::integral_constant<int, 3>{}, ks + 3);
+    step(std::integral_constant<int, 4>{}, ks + 4);
+    step(std::integral_constant<int, 5>{}, ks + 5);
+  }
+  const int r = ks1 - ks;
+  if (r > 0) step(std::integral_constant<int, 0>{}, ks);
+  if (r > 1) step(std::integral_constant<int, 1>{}, ks + 1);
+  if (r > 2) step(std::integral_constant<int, 2>{}, ks + 2);
+  if (r > 3) step(std::integral_constant<int, 3>{}, ks + 3);
+  if (r > 4) step(std::integral_constant<int, 4>{}, ks + 4);
+  const int rot = (ks1 - ks0) % 3;
+  if (rot == 1) {
+    const bfrag_t t = b[0];
+    b[0] = b[1], b[1] = b[2], b[2] = t;
+  } else if (rot == 2) {
+    const bfrag_t t = b[0];
+    b[0] = b[2], b[2] = b[1], b[1] = t;
   }
 }
 
@@ -645,17 +679,18 @@ sage_layer_mfma_kernel(mfma_args a)
   };
 
   if constexpr (HALF) {
-    // Two steps per tile.  Step 2n: the producers sum the MEAN half of tile n into buffer 0 while the consumers multiply
-    // the SELF half of tile n-1 from buffer 1 and store it.  Step 2n+1: the producers copy the SELF rows of tile n into
-    // buffer 1 (and request the first rows of tile n+1) while the consumers multiply the MEAN half of tile n.  The
-    // accumulators of a tile live across the barrier between its halves; the weight stream continues across both.
-    float* buf0   = lds;
-    float* buf1   = lds + tile_dw;
+    // The LDS holds only the MEAN halves, double-buffered (buffer n & 1 = tile n, F floats per row); the SELF half of the A
+    // operand never passes through it: the multiplying waves read their self rows x[self(i)] straight from global memory
+    // (a lane's half k-step of its row is 32 contiguous bytes).  One step per tile: the fetching waves sum the mean rows of
+    // tile n into buffer n & 1 while the multiplying waves run tile n - 1 — the MEAN k-steps [0, KS/2) from the other
+    // buffer, then the SELF k-steps [KS/2, KS) from global memory — and store it.  (Round 2 kept [mean | self] of ONE tile
+    // in the two buffers and took two steps per tile, the second with the fetching waves only copying self rows while half
+    // the K was multiplied: 1.69 ms at 256 -> 256 against 1.51 ms this way.  Self k-steps first, before the barrier:
+    // 1.516 vs 1.505 — their first row loads then have nothing in front of them to hide behind.)
     const int KSh = a.KS / 2;   // F % 16 == 0: k-steps [0, KSh) = mean half (W_l rows), [KSh, KS) = self half (W_r rows)
     if (wave >= CW) {
       // the 64-row tile is produced as two 32-row SUB-TILES (sub-tile 2 t + h = rows 32 (2 t + h) ...): eight rows of
-      // metadata per lane group in registers instead of sixteen (which spilled 120 VGPRs); the metadata pipeline simply
-      // runs across the sub-tiles, and only the self-row offsets of both are kept for the second step
+      // metadata per lane group in registers instead of sixteen; the metadata pipeline simply runs across the sub-tiles
       using P     = producer<IdT, LG, 32, OFF32, true>;
       using off_t = typename P::off_t;
       constexpr int IT = P::IT, kNb = P::kNb, kDepth = P::kDepth;
@@ -665,8 +700,6 @@ sage_layer_mfma_kernel(mfma_args a)
       ids_t<IT> i_next;
       meta_t<IT, off_t> cur;
       f32x4 buf[kDepth][kNb + 1];
-      off_t self_off[2][IT];
-      uint32_t self_ok[2] = {0u, 0u};
       auto sub_of = [&](int64_t j) { return 2 * tile_of(j >> 1) + (j & 1); };
       p.load_bounds(sub_of(0), b_next);
       p.load_ids(sub_of(0), b_next, i_next);
@@ -676,10 +709,11 @@ sage_layer_mfma_kernel(mfma_args a)
       constexpr int kHalf = IT / 2;
       for (int64_t n = 0; n <= mine; n++) {
         if (n < mine && !(a.debug & 2)) {
+          float* tile_lds = lds + (n & 1) * tile_dw;
 #pragma unroll
           for (int sub = 0; sub < 2; sub++) {
             const int64_t j = 2 * n + sub;
-            float* rows_lds = buf0 + sub * 32 * a.SD;
+            float* rows_lds = tile_lds + sub * 32 * a.SD;
             p.load_bounds(sub_of(j + 1), b_next);
 #pragma unroll
             for (int it = 0; it < IT; it++) {
@@ -688,12 +722,6 @@ sage_layer_mfma_kernel(mfma_args a)
               p.reduce_store(cur, it, buf[it % kDepth], rows_lds);
             }
             p.long_rows(sub_of(j), cur, rows_lds);
-            self_ok[sub] = 0u;
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-              self_off[sub][it] = cur.self[it];
-              self_ok[sub] |= cur.d[it] >= 0 ? 1u << it : 0u;
-            }
             p.finish(i_next, cur);
             if (j + 1 < 2 * mine) {
 #pragma unroll
@@ -702,33 +730,48 @@ sage_layer_mfma_kernel(mfma_args a)
           }
         }
         lds_barrier();
-        if (n < mine && !(a.debug & 2)) {
-#pragma unroll
-          for (int sub = 0; sub < 2; sub++) p.self_rows(self_off[sub], self_ok[sub], buf1 + sub * 32 * a.SD);
-        }
-        lds_barrier();
       }
     } else {
       constexpr int RT = TR / 32;
       float* scratch = lds + 2 * tile_dw + 16 + wave * kScratchDw;
       f32x16 c[RT][2];
-      bfrag_t b0;
-      load_b_planes(b0, reinterpret_cast<const uint32_t*>(a.w_tiles) + ((int64_t)(wave * 64 + (lane & 31))) * 8 + (lane >> 5) * 4,
-                    (int64_t)a.KS * a.N * 8, a.N, 0);
+      bfrag_t b[3];   // the weight stream, two k-steps ahead (consume_range)
+      {
+        const uint32_t* b_lane =
+          reinterpret_cast<const uint32_t*>(a.w_tiles) + ((int64_t)(wave * 64 + (lane & 31))) * 8 + (lane >> 5) * 4;
+        load_b_planes(b[0], b_lane, (int64_t)a.KS * a.N * 8, a.N, 0);
+        load_b_planes(b[1], b_lane, (int64_t)a.KS * a.N * 8, a.N, 1);
+      }
+      const IdT* src_ids = static_cast<const IdT*>(a.src_ids);
       for (int64_t n = 0; n <= mine; n++) {
         if (n >= 1 && !(a.debug & 1)) {
-          consume_half<RT>(a, c, buf1, KSh, a.KS, 0, wave, lane, b0);
-          epilogue<RT>(a, c, tile_of(n - 1) * TR, wave, lane, scratch);
-        }
-        lds_barrier();
-        if (n < mine && !(a.debug & 1)) {
+          const int64_t row0 = tile_of(n - 1) * TR;
+          // this lane's self row of every row tile (rows past the end: any row, never stored); the two dependent loads
+          // are requested here and waited for after the mean half
+          const float* self_ptr[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) {
+            const int64_t row  = row0 + rt * 32 + (lane & 31);
+            const int64_t srow = a.self_rows[row < a.n_rows ? row : a.n_rows - 1];
+            self_ptr[rt]       = a.x + table_row<IdT>(src_ids, srow) * a.ldx + (lane >> 5) * 8;
+          }
 #pragma unroll
           for (int rt = 0; rt < RT; rt++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)
 #pragma unroll
               for (int i = 0; i < 16; i++) c[rt][ct][i] = 0.f;
-          consume_half<RT>(a, c, buf0, 0, KSh, KSh, wave, lane, b0);
+          const float* a_lane = lds + ((n - 1) & 1) * tile_dw + (lane & 31) * a.SD + (lane >> 5) * 8;
+          consume_range<RT, 1>(a, c, b, 0, KSh, wave, lane, [&](araw_t<RT>& f, int ks) { load_a_raw<RT>(f, a_lane, a.SD, ks); });
+          consume_range<RT, 2>(a, c, b, KSh, a.KS, wave, lane, [&](araw_t<RT>& f, int ks) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+              const float* p = self_ptr[rt] + (ks - KSh) * 16;
+              f.v[rt][0]     = *reinterpret_cast<const f32x4*>(p);
+              f.v[rt][1]     = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+          });
+          epilogue<RT>(a, c, row0, wave, lane, scratch);
         }
         lds_barrier();
       }
