@@ -103,7 +103,7 @@ class SagePipeline:
         self.nn = nn
         self.device = device
         self.G = G
-        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, col.dtype, G)   # ids take the CSR's column dtype
+        self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, col.dtype, G, pad_unique=False)   # ids take the CSR's column dtype
         self.feat = feat_table  # WholeMemoryTensor
         g = torch.Generator(device=device).manual_seed(1)
         L = len(FANOUT)

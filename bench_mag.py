@@ -79,7 +79,7 @@ class MagPipeline:
         self.ntypes = sorted({t for et in self.etypes for t in (et[0], et[2])})
         self.fanout = {et: list(fanout) for et in self.etypes}
         self.hops = len(fanout)
-        self.walk = fused.HeteroPygWalk(graphs, B, self.fanout, G, num_nodes=num_nodes)
+        self.walk = fused.HeteroPygWalk(graphs, B, self.fanout, G, num_nodes=num_nodes, pad_unique=False)
         self.tables, self.params = tables, params
         self.walk_stream = torch.cuda.Stream(device=dev)
         self._rs = None

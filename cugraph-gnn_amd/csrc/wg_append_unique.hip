@@ -372,7 +372,8 @@ void prepare_packed_t(const KeyT* targets, dev_count T, const KeyT* neighbors, d
 constexpr int kLdsSlots      = 10000;     // 80,000 B: two workgroups per CU, one computes while the other waits on its loads
 constexpr int kLdsKeysTarget = 3000;      // positions per range the range count is sized for (load <= 0.3: short probe chains)
 constexpr int kLdsProbeLimit = 256;       // probes after which a range is declared overfull and split
-constexpr int kLdsThreads    = 1024;
+constexpr int kLdsThreads    = 512;       // 6 pairs per thread = one trip of kLdsUnroll per range (1024: walk 1.227 -> 1.19 ms per call group of 191;
+                                          // half / quarter-size tables with 512 / 256 threads: 1.28 / 1.48 — more ranges cost more to bucket)
 constexpr int kLdsMaxRanges  = 2048;      // per batch; beyond, ranges simply start overfull and split
 constexpr int kLdsStack      = 40;        // pending hash ranges of one workgroup (a split pushes two, pops one)
 constexpr int kLdsChunks     = 16;        // blocks per batch in the two bucketing kernels
@@ -689,8 +690,10 @@ renumber_emit_batched_kernel(const KeyT* __restrict__ targets, const KeyT* __res
     if (bv.frontier_seg_out) bv.frontier_seg_out[gtid] = new_before;
     if (bv.frontier_local0_out && gtid < bv.G) bv.frontier_local0_out[gtid] = bv.target_seg[gtid + 1] - bv.target_seg[gtid];
   }
-  // no-sync walk: the capacity slack of `unique` is padded with -1 (a capacity-sized feature gather skips those rows)
-  if (counts_out)
+  // no-sync walk: the capacity slack of `unique` is padded with -1 (a capacity-sized feature gather skips those rows) unless
+  // the caller reads the sizes anyway (WGAMD_HOP_NO_UNIQUE_PAD): the capacity is the worst case — every seed with fan-out^hops
+  // DISTINCT neighbours —, 3-4x the live size on the products-like graph: 347 MB of -1 per hop-2 call group of 191
+  if (counts_out && !bv.no_pad)
     for (int p = T + U + gtid; p < T_.host + E_.host; p += gsize) unique_out[p] = (KeyT)-1;
 
   int b, c;

@@ -345,6 +345,7 @@ struct batch_view {
   int* frontier_local0_out; // out [G]   local id of the next frontier's first vertex = batch size before this hop
   int* neighbor_local_out;  // out [E]   per-batch LOCAL id of every edge's neighbour
   int* center_local_out;    // out [E]   per-batch LOCAL id of every edge's expanded vertex
+  int no_pad;               // 1: leave the capacity slack of the unique list unwritten (WGAMD_HOP_NO_UNIQUE_PAD)
   __host__ __device__ const int* sbatch() const { return sample_batch ? sample_batch : target_batch; }
   __host__ __device__ const int* sseg() const { return sample_seg ? sample_seg : target_seg; }
 };

@@ -227,8 +227,22 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(
   int64_t edge_cap, void* unique, int* unique_batch, int* unique_seg, int* counts_dev, void* workspace,
   size_t workspace_bytes, int64_t n_vertices, void* stream)
 {
+  return wgamd_sample_hop_batched_nosync_ex(csr_row_ptr, csr_col, id_dtype, targets, target_batch, target_seg, n_batches,
+                                            target_cap, max_sample_count, random_seeds_dev, offsets, neighbor_row, center_row,
+                                            edge_gid, edge_cap, unique, unique_batch, unique_seg, counts_dev, workspace,
+                                            workspace_bytes, n_vertices, 0u, stream);
+}
+
+wholememory_error_code_t wgamd_sample_hop_batched_nosync_ex(
+  const int64_t* csr_row_ptr, const void* csr_col, wholememory_dtype_t id_dtype, const void* targets,
+  const int* target_batch, const int* target_seg, int n_batches, int64_t target_cap, int max_sample_count,
+  const unsigned long long* random_seeds_dev, int* offsets, int* neighbor_row, int* center_row, int64_t* edge_gid,
+  int64_t edge_cap, void* unique, int* unique_batch, int* unique_seg, int* counts_dev, void* workspace,
+  size_t workspace_bytes, int64_t n_vertices, unsigned flags, void* stream)
+{
   using namespace wgamd;
   return guarded("wgamd_sample_hop_batched_nosync", [&] {
+    WG_REQUIRE_INPUT((flags & ~WGAMD_HOP_NO_UNIQUE_PAD) == 0, "unknown flag bits");
     WG_REQUIRE_INPUT(target_batch && target_seg && random_seeds_dev && center_row && unique_batch && unique_seg &&
                        counts_dev,
                      "null pointer");
@@ -241,6 +255,7 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(
     a.bv.target_batch = target_batch; a.bv.target_seg = target_seg; a.bv.G = n_batches;
     a.bv.id_bound = n_vertices > 0 ? n_vertices : 0;
     a.bv.unique_batch = unique_batch; a.bv.unique_seg = unique_seg;
+    a.bv.no_pad = (flags & WGAMD_HOP_NO_UNIQUE_PAD) ? 1 : 0;
     a.offsets = offsets; a.neighbor_row = neighbor_row; a.center_row = center_row; a.edge_gid = edge_gid;
     a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
     a.workspace_bytes = workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
@@ -309,6 +324,8 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
     a.bv.frontier_out = p->frontier_out; a.bv.frontier_batch_out = p->frontier_out_batch;
     a.bv.frontier_seg_out = p->frontier_out_seg; a.bv.frontier_local0_out = p->frontier_out_local0;
     a.bv.neighbor_local_out = p->neighbor_local; a.bv.center_local_out = p->center_local;
+    WG_REQUIRE_INPUT((p->flags & ~WGAMD_HOP_NO_UNIQUE_PAD) == 0, "unknown flag bits");
+    a.bv.no_pad = (p->flags & WGAMD_HOP_NO_UNIQUE_PAD) ? 1 : 0;
     a.offsets = p->offsets; a.neighbor_row = p->neighbor_row_scratch; a.center_row = p->center_row_scratch;
     a.edge_gid = p->edge_gid; a.edge_cap = p->edge_cap; a.unique = p->nodes_out; a.counts_dev = p->counts_dev;
     a.workspace = p->workspace; a.workspace_bytes = p->workspace_bytes; a.stream = static_cast<hipStream_t>(stream);

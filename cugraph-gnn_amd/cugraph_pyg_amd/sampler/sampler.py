@@ -440,8 +440,9 @@ class HeteroNeighborSampler:
         from wholegraph_amd.fused import HeteroPygWalk
         key = (batch_size, n_batches)
         if key not in self._walks:
+            # (the readers slice every list by the sizes read back: no -1 padding of the capacity slack)
             self._walks[key] = HeteroPygWalk(self.graphs, batch_size, self.fanout, n_batches, biased=self.biased,
-                                             num_nodes=self.num_nodes)
+                                             num_nodes=self.num_nodes, pad_unique=False)
         return self._walks[key]
 
     def call_groups_ok(self) -> bool:
@@ -546,7 +547,7 @@ class NeighborSampler:
         key = (batch_size, n_batches)
         if key not in self._walks:
             self._walks[key] = PygNoSyncWalk(self.graph.row_ptr, self.graph.col, batch_size, self.fanout, n_batches,
-                                             csr_weight=self.graph.weight if self.biased else None)
+                                             csr_weight=self.graph.weight if self.biased else None, pad_unique=False)
         return self._walks[key]
 
     def call_groups_ok(self) -> bool:

@@ -242,6 +242,10 @@ SYMBOLS = {
                                                 c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                 c_int64, c_void_p]),
+    "wgamd_sample_hop_batched_nosync_ex": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                                   c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                   c_int64, ctypes.c_uint, c_void_p]),
 }
 
 _lib = None

@@ -128,9 +128,13 @@ def _merge_hops_batch_major(fields_per_hop, segs_per_hop, G, dev):
 
 class NoSyncWalk:
     def __init__(self, csr_row_ptr: torch.Tensor, csr_col_ind: torch.Tensor, batch_size: int,
-                 max_neighbors: List[int], id_dtype=torch.int64, n_batches: int = 1):
+                 max_neighbors: List[int], id_dtype=torch.int64, n_batches: int = 1, pad_unique: bool = True):
+        """``pad_unique=False``: the capacity slack of every hop's ``unique`` list is left unwritten instead of padded with
+        -1 (``WGAMD_HOP_NO_UNIQUE_PAD``) — for consumers that slice by ``counts`` / ``unique_seg``; the capacity is 3-4x the
+        live size, so the padding is most of what the renumber step writes."""
         assert csr_row_ptr.is_cuda and csr_col_ind.is_cuda
         assert all(m > 0 for m in max_neighbors), "the no-sync walk needs positive fan-outs"
+        self.flags = 0 if pad_unique else HOP_NO_UNIQUE_PAD
         assert csr_col_ind.dtype == id_dtype, "no-sync walk: seeds and csr_col must share a dtype"
         self.row_ptr, self.col = csr_row_ptr, csr_col_ind
         self.n_vertices = int(csr_row_ptr.shape[0]) - 1     # every id is a row of the CSR
@@ -192,11 +196,12 @@ class NoSyncWalk:
             unique = torch.empty(tc + ec, dtype=self.id_dtype, device=dev)
             u_batch = torch.empty(tc + ec, dtype=torch.int32, device=dev)
             u_seg = torch.empty(self.G + 1, dtype=torch.int32, device=dev)
-            L.check(lib.wgamd_sample_hop_batched_nosync(
+            L.check(lib.wgamd_sample_hop_batched_nosync_ex(
                 self.row_ptr.data_ptr(), self.col.data_ptr(), self.wm_dtype, targets.data_ptr(), t_batch.data_ptr(),
                 t_seg.data_ptr(), self.G, tc, m, rs[k].data_ptr(), offsets.data_ptr(), nbr_row.data_ptr(),
                 ctr_row.data_ptr(), None, ec, unique.data_ptr(), u_batch.data_ptr(), u_seg.data_ptr(),
-                counts[k].data_ptr(), ws_ptr, self.ws_bytes, self.n_vertices, stream), "wgamd_sample_hop_batched_nosync")
+                counts[k].data_ptr(), ws_ptr, self.ws_bytes, self.n_vertices, self.flags, stream),
+                "wgamd_sample_hop_batched_nosync_ex")
             res.unique.append(unique)
             res.unique_seg.append(u_seg)
             res.target_seg.append(t_seg)
@@ -253,6 +258,9 @@ class SingleBatchNoSyncWalk:
 import ctypes as _ct
 
 
+HOP_NO_UNIQUE_PAD = 1   # WGAMD_HOP_NO_UNIQUE_PAD (include/wgamd_ext.h)
+
+
 class _PygHop(_ct.Structure):
     """ctypes mirror of ``wgamd_pyg_hop_t`` (include/wgamd_ext.h)."""
     _fields_ = [("csr_row_ptr", _ct.c_void_p), ("csr_col", _ct.c_void_p), ("id_dtype", _ct.c_int),
@@ -269,7 +277,7 @@ class _PygHop(_ct.Structure):
                 ("counts_dev", _ct.c_void_p), ("neighbor_row_scratch", _ct.c_void_p),
                 ("center_row_scratch", _ct.c_void_p), ("workspace", _ct.c_void_p), ("workspace_bytes", _ct.c_size_t),
                 ("csr_weight", _ct.c_void_p), ("weight_dtype", _ct.c_int), ("max_row_len", _ct.c_int64),
-                ("n_vertices", _ct.c_int64)]
+                ("n_vertices", _ct.c_int64), ("flags", _ct.c_uint)]
 
 
 @dataclass
@@ -333,9 +341,10 @@ class PygNoSyncWalk:
     (SURVEY.md §8 row a14)."""
 
     def __init__(self, csr_row_ptr, csr_col_ind, batch_size: int, fanout: List[int], n_batches: int = 1,
-                 csr_weight: torch.Tensor = None):
+                 csr_weight: torch.Tensor = None, pad_unique: bool = True):
         """``csr_weight`` (float32 | float64, one per CSR slot): BIASED sampling — every hop is then what
-        ``wholegraph_csr_weighted_sample_without_replacement`` draws (fan-outs <= 256)."""
+        ``wholegraph_csr_weighted_sample_without_replacement`` draws (fan-outs <= 256).  ``pad_unique``: see ``NoSyncWalk``."""
+        self.flags = 0 if pad_unique else HOP_NO_UNIQUE_PAD
         assert csr_row_ptr.is_cuda and csr_col_ind.is_cuda and csr_col_ind.dtype in (torch.int32, torch.int64)
         assert all(0 < f for f in fanout), "the no-sync walk needs positive fan-outs"
         self.weight, self.max_row_len = None, 0
@@ -413,7 +422,7 @@ class PygNoSyncWalk:
                         self.workspace.data_ptr() + self.ws_off, self.ws_bytes,
                         None if self.weight is None else self.weight.data_ptr(),
                         0 if self.weight is None else torch_dtype_to_wm(self.weight.dtype), self.max_row_len,
-                        int(self.row_ptr.shape[0]) - 1)
+                        int(self.row_ptr.shape[0]) - 1, self.flags)
             L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
             res.offsets.append(offsets)
             res.row_local.append(row_l)
@@ -437,9 +446,11 @@ class HeteroPygWalk:
     ``pylibcugraph.heterogeneous_uniform_neighbor_sample`` call over many batches.
     No host synchronisation inside ``run``; sizes are read once in ``finalize_batches``."""
 
-    def __init__(self, graphs, batch_size: int, fanout, n_batches: int, biased: bool = False, num_nodes=None):
+    def __init__(self, graphs, batch_size: int, fanout, n_batches: int, biased: bool = False, num_nodes=None,
+                 pad_unique: bool = True):
         """``num_nodes``: {node type: vertex count} — with it the renumber table of every hop packs (batch, id, position)
-        into one word (ids of a type are then known to be below its count)."""
+        into one word (ids of a type are then known to be below its count).  ``pad_unique``: see ``NoSyncWalk``."""
+        self.flags = 0 if pad_unique else HOP_NO_UNIQUE_PAD
         self.biased = bool(biased)
         self.num_nodes = dict(num_nodes) if num_nodes else {}
         self.etypes = sorted(graphs.keys())
@@ -560,7 +571,8 @@ class HeteroPygWalk:
                             counts.data_ptr(), scratch_r.data_ptr(), scratch_c.data_ptr(), ws_ptr, ws_bytes,
                             g.weight.data_ptr() if self.biased else None,
                             torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl,
-                            int(self.num_nodes.get(src_t, 0)))   # the renumbered ids are type-local ids of the SOURCE type
+                            int(self.num_nodes.get(src_t, 0)),   # the renumbered ids are type-local ids of the SOURCE type
+                            self.flags)
                 L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
                 keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
                          st["nodes"], st["batch"], st["seg"]]

@@ -49,6 +49,44 @@ def test_call_group_equals_per_batch_oracle(oracle_mod, hiplib, G, B, fanouts, d
         assert torch.equal(res.neighbor_row[k][:n_e], res2.neighbor_row[k][:n_e])
 
 
+def test_unpadded_unique_lists_are_identical_below_the_live_end(oracle_mod, hiplib):
+    """WGAMD_HOP_NO_UNIQUE_PAD (pad_unique=False): the capacity slack of `unique` is left alone, everything a consumer that
+    reads the sizes can see is what the padded walk and the oracle give."""
+    import torch
+    from wholegraph_amd.fused import NoSyncWalk
+    G, B, fanouts = 7, 96, [25, 10]
+    row_ptr, col = powerlaw_csr(20000, 18, seed=4, max_deg=3000)
+    rng = np.random.default_rng(5)
+    seeds = np.concatenate([rng.permutation(20000)[:B] for _ in range(G)]).astype(np.int64)
+    rs = [[31 * k + b + 7 for b in range(G)] for k in range(len(fanouts))]
+    rp_d, col_d = torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda()
+    padded = NoSyncWalk(rp_d, col_d, B, fanouts, torch.int64, G).run(torch.from_numpy(seeds).cuda(), rs)
+    walk = NoSyncWalk(rp_d, col_d, B, fanouts, torch.int64, G, pad_unique=False)
+    res = walk.run(torch.from_numpy(seeds).cuda(), rs)
+    for k in range(len(fanouts)):
+        n_e, n_u = res.counts[k].cpu().numpy()
+        assert torch.equal(res.counts[k], padded.counts[k]) and torch.equal(res.unique_seg[k], padded.unique_seg[k])
+        assert torch.equal(res.unique[k][:n_u], padded.unique[k][:n_u])
+        if k + 1 < len(fanouts):   # the batch of every unique entry = target_batch of the next hop
+            assert torch.equal(res.target_batch[k + 1][:n_u], padded.target_batch[k + 1][:n_u])
+        assert torch.equal(res.neighbor_row[k][:n_e], padded.neighbor_row[k][:n_e])
+        assert np.all(padded.unique[k][n_u:].cpu().numpy() == -1)
+    per_batch = res.finalize_batches()
+    for b in range(G):
+        _check(oracle_mod, row_ptr, col, seeds[b * B:(b + 1) * B], fanouts, [rs[k][b] for k in range(len(fanouts))], per_batch[b])
+
+
+def test_unknown_hop_flag_bits_are_refused(hiplib):
+    import torch
+    import wholegraph_amd._lib as L
+    from wholegraph_amd.fused import NoSyncWalk
+    row_ptr, col = powerlaw_csr(2000, 8, seed=1, max_deg=300)
+    walk = NoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), 16, [5], torch.int64, 2)
+    walk.flags = 6
+    with pytest.raises(L.WholeMemoryError):
+        walk.run(torch.arange(32, dtype=torch.int64).cuda(), [[1, 2]])
+
+
 def test_single_batch_scalar_seed_entry(oracle_mod, hiplib):
     import torch
     from wholegraph_amd.fused import SingleBatchNoSyncWalk
