@@ -251,7 +251,7 @@ struct producer {
       if constexpr (OFF32) acc += v[k];                                   // the hardware already zeroed the dead slots
       else acc += k < deg ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};             // select, never multiply by 0
     }
-    if (a.mean && deg > 0) acc *= __frcp_rn((float)deg);   // (rows longer than the window are redone by long_rows())
+    if (a.mean && deg > 0 && deg <= kNb) acc *= __frcp_rn((float)deg);   // (longer rows: long_rows() continues this sum)
     if (live) {
       float* prow = tile_lds + (group + it * kGroups) * a.SD;
       *reinterpret_cast<f32x4*>(prow + f0) = acc;
@@ -262,7 +262,11 @@ struct producer {
       }
     }
   }
-  // rows longer than the prefetched window (rare: deg > 10): the whole sum again, in CSR order, chunk by chunk
+  // rows longer than the prefetched window (deg > 10: rare behind a fan-out of 10, the rule behind one of 25): reduce_store
+  // left the UNSCALED sum of the first kNb neighbours in the tile; the rest is added to it in CSR order, kLongUnroll row
+  // loads in flight at a time (one at a time — a dependent round trip per neighbour — made the 47-class head of the products
+  // model, whose hop has fan-out 25, three times slower than aggregate + GEMM)
+  static constexpr int kLongUnroll = 8;
   __device__ __forceinline__ void long_rows(int64_t tile, const meta_t<IT, off_t>& m, float* tile_lds) const
   {
     const IdT* src_ids = static_cast<const IdT*>(a.src_ids);
@@ -270,27 +274,40 @@ struct producer {
     for (int it = 0; it < IT; it++) {
       const int deg = m.d[it];
       if (__ballot(deg > kNb) == 0ull) continue;
+      const bool mine    = live && deg > kNb;
       const int64_t row  = row_of(tile, it);
       const int64_t rowc = row < a.n_rows ? row : a.n_rows - 1;
       const int s        = a.row_ptr[rowc];
+      float* prow        = tile_lds + (group + it * kGroups) * a.SD + f0;
       f32x4 acc          = {0.f, 0.f, 0.f, 0.f};
-      int maxdeg         = deg > kNb ? deg : 0;
+      if (mine) acc = *reinterpret_cast<const f32x4*>(prow);
+      int maxdeg = deg > kNb ? deg : 0;
 #pragma unroll
       for (int dd = 32; dd >= LG; dd >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, dd, 64));
-      for (int c0 = 0; c0 < maxdeg; c0 += LG) {
+      for (int c0 = kNb; c0 < maxdeg; c0 += LG) {
         const int64_t my_src = (deg > kNb && c0 + sub < deg) ? table_row<IdT>(src_ids, (int64_t)a.col[s + c0 + sub]) : 0;
         const int chunk      = min(LG, maxdeg - c0);
-        for (int j = 0; j < chunk; j++) {
-          const int src_lane = gbase | (j & (LG - 1));
-          const int lo       = __shfl((int)(my_src & 0xffffffff), src_lane, 64);
-          const int hi       = __shfl((int)(my_src >> 32), src_lane, 64);
-          const int64_t rr   = ((int64_t)hi << 32) | (uint32_t)lo;
-          if (live && deg > kNb && c0 + j < deg) acc += *reinterpret_cast<const f32x4*>(a.x + rr * a.ldx + f0);
+        for (int j0 = 0; j0 < chunk; j0 += kLongUnroll) {
+          f32x4 v[kLongUnroll];
+#pragma unroll
+          for (int u = 0; u < kLongUnroll; u++) {
+            const int j        = j0 + u;
+            const int src_lane = gbase | (j & (LG - 1));
+            const int lo       = __shfl((int)(my_src & 0xffffffff), src_lane, 64);
+            const int hi       = __shfl((int)(my_src >> 32), src_lane, 64);
+            const int64_t rr   = (mine && j < chunk && c0 + j < deg) ? (((int64_t)hi << 32) | (uint32_t)lo) : (int64_t)0;
+            v[u]               = *reinterpret_cast<const f32x4*>(a.x + rr * a.ldx + f0c);   // dead slots read row 0, masked below
+          }
+#pragma unroll
+          for (int u = 0; u < kLongUnroll; u++) {
+            const int j = j0 + u;
+            acc += (mine && j < chunk && c0 + j < deg) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
-      if (live && deg > kNb) {
+      if (mine) {
         if (a.mean) acc *= __frcp_rn((float)deg);
-        *reinterpret_cast<f32x4*>(tile_lds + (group + it * kGroups) * a.SD + f0) = acc;
+        *reinterpret_cast<f32x4*>(prow) = acc;
       }
     }
   }

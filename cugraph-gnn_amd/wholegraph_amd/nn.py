@@ -104,15 +104,16 @@ def sage_layer_fused_supported(F_: int, N: int) -> bool:
 
 
 def sage_layer_fused_preferred(F_: int, N: int) -> bool:
-    """Shapes where the one-kernel layer beats aggregate kernel + library GEMM: two operand tiles must fit the 160 KB of
-    LDS so that a workgroup can gather one tile while it multiplies the other."""
-    if not sage_layer_fused_supported(F_, N) or N != _padded_width(N):
-        # (a padded head — the 47-class layer of the products model runs as N = 64 — is supported but not preferred: one
-        #  consumer wave per CU and a handful of tiles per CU, measured 0.46 ms against 0.20 ms for aggregate + GEMM)
+    """Shapes where the one-kernel layer beats aggregate kernel + library GEMM.  bf16x3 kernel: every shape it supports,
+    a padded head included (the 47-class layer of the products model runs as N = 64 with one multiplying wave per CU: with
+    the round-3 half-tile kernel 0.38 ms against 0.54 ms for aggregate + GEMM at 196 k rows, 256 -> 64; 0.043 against 0.052
+    at 16 k rows; the round-2 kernel lost there, 0.46 against 0.20 at 65 k rows).  fp32-MFMA kernel: only when two operand
+    tiles fit the 160 KB of LDS and the width needs no padding."""
+    if not sage_layer_fused_supported(F_, N):
         return False
     if _FUSED_PRECISION == "bf16x3" and L.lib().wgamd_sage_layer_bf16x3_supported(F_, _padded_width(N)):
         return True
-    return F_ <= 152
+    return N == _padded_width(N) and F_ <= 152
 
 
 def _padded_head(w_t: torch.Tensor, bias, Np: int):

@@ -357,6 +357,46 @@ def test_coo_to_csr_matches_torch_formulation(hiplib, n_dst, n_src, E):
     assert torch.equal(rp.cpu(), rp_ref) and torch.equal(cc.cpu(), cc_ref)
 
 
+@pytest.mark.parametrize("F,N", [(4, 128), (36, 256), (100, 256), (128, 64), (256, 47), (256, 256)])
+@pytest.mark.parametrize("mean", [True, False])
+def test_sage_layer_fused_long_rows(hiplib, F, N, mean):
+    """Rows far past the 10-neighbour register window (a hop with fan-out 25 makes them the rule; hubs of 90 neighbours span
+    several id chunks of the narrow lane groups): the fetching waves continue the window's partial sum in CSR order, several
+    row loads in flight.  Against the aggregate kernel + fp64 product, 1e-5 x scale."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator(device="cuda").manual_seed(F * 3 + N)
+    n_dst, n_src = 1500 + F, 4000
+    deg = torch.randint(0, 26, (n_dst,), generator=g, device="cuda")
+    deg[::5] = 25
+    deg[3::97] = 90
+    deg[1::11] = 0
+    deg[-1] = 11
+    rp = torch.zeros(n_dst + 1, dtype=torch.int32, device="cuda")
+    rp[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(0, n_src, (int(rp[-1]),), generator=g, device="cuda", dtype=torch.int32)
+    x = torch.randn((n_src, F), generator=g, device="cuda")
+    rows = torch.randint(0, n_src, (n_dst,), generator=g, device="cuda")
+    w_t = torch.randn((2 * F, N), generator=g, device="cuda") * 0.2
+    bias = torch.randn(N, generator=g, device="cuda")
+    cat = nn.sage_aggregate_forward(rp, col, x, rows, mean)
+    ref = cat.double() @ w_t.double() + bias.double()
+    scale = cat.double().abs() @ w_t.double().abs() + bias.double().abs()
+    for precision in ("bf16x3", "f32"):
+        got = nn.sage_layer_fused_forward(rp, col, x, rows, w_t, bias, relu=False, mean=mean, precision=precision)
+        assert got.shape == (n_dst, N)
+        assert torch.all((got.double() - ref).abs() <= 1e-5 * scale + 1e-6), precision
+    # the feature fetch folded in takes the same path through an id indirection
+    V = 9000
+    table = torch.randn((V, F), generator=g, device="cuda")
+    ids = torch.randperm(V, generator=g, device="cuda")[:n_src]
+    cat = nn.sage_aggregate_forward(rp, col, table[ids].contiguous(), rows, mean)
+    ref = cat.double() @ w_t.double() + bias.double()
+    scale = cat.double().abs() @ w_t.double().abs() + bias.double().abs()
+    got = nn.sage_layer_fused_forward(rp, col, table, rows, w_t, bias, relu=False, mean=mean, src_ids=ids)
+    assert torch.all((got.double() - ref).abs() <= 1e-5 * scale + 1e-6)
+
+
 def test_bf16x3_split_is_exact_and_product_is_fp32_class(hiplib):
     """The weight planes of wgamd_sage_split_weight_bf16x3 sum back to the fp32 weight EXACTLY (hi + mid + lo == w, each
     piece a bf16), zero rows pad K to the 16-wide k-step; and the layer on adversarial magnitudes (1e-30 .. 1e30 mixed

@@ -27,7 +27,7 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     F, N = int(os.environ.get("F", 100)), int(os.environ.get("N", 256))
-    n_dst, n_src, V = 610_000, 3_650_000, 2_449_029
+    n_dst, n_src, V = int(os.environ.get("ND", 610_000)), int(os.environ.get("NS", 3_650_000)), 2_449_029
     deg = torch.randint(5, 11, (n_dst,), generator=g, device=dev)   # hop-2 rows: fan-out 10, mean ~8
     rp = torch.zeros(n_dst + 1, dtype=torch.int32, device=dev)
     rp[1:] = torch.cumsum(deg, 0)
