@@ -103,6 +103,7 @@ class SagePipeline:
         self.nn = nn
         self.device = device
         self.G = G
+        self.distinct_rows = []
         self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, col.dtype, G, pad_unique=False)   # ids take the CSR's column dtype
         self.feat = feat_table  # WholeMemoryTensor
         g = torch.Generator(device=device).manual_seed(1)
@@ -216,6 +217,8 @@ class SagePipeline:
         if fused_fetch:
             x = None          # never materialised: layer 1 reads the feature table through n_id
         elif self.distributed:
+            if timers is not None:   # stage probe only (untimed here): what the de-duplicated fetch puts on the wire
+                self.distinct_rows.append(int(torch.unique(n_id).numel()))
             x = stage("gather(" + self.fetch_tag + ")", lambda: self.feat.gather(n_id))
         else:
             from wholegraph_amd.tensor import local_gather
@@ -876,7 +879,15 @@ def main():
                            "per_rank_value": [round(e_ / t_, 1) for t_, e_ in pr["per_rank"]]}
                     if name != "replicated":
                         p_src = sum(s_[2 * L - 1] for s_ in pr["psizes"]) / pr["stage_n"]
-                        a2a = p_src * (world - 1) / max(world, 1) * (idb + 4 * F)
+                        # the partitioned fetch sends every DISTINCT row of the call group once (gather(dedup="auto"),
+                        # wholegraph_amd/tensor.py) and expands locally; ids travel as int64
+                        from wholegraph_amd.tensor import dedup_pays
+                        dd = pr["pipe"].distinct_rows
+                        deduped = bool(dd) and dedup_pays(int(p_src), V, world)
+                        wire_rows = sum(dd) / len(dd) if deduped else p_src
+                        a2a = wire_rows * (world - 1) / max(world, 1) * (8 + 4 * F)
+                        rep.update(requested_rows_per_call_group=int(p_src), deduplicated=deduped,
+                                   wire_rows_per_call_group=int(wire_rows))
                         gname = next((k for k in pr["stage_ms"] if k.startswith("gather")), None)
                         gms = pr["stage_ms"].get(gname) if gname else None
                         rep.update(gather_stage=gname, gather_ms_per_call_group=None if gms is None else round(gms, 4),

@@ -36,6 +36,51 @@ def local_scatter(input_tensor: torch.Tensor, indice: torch.Tensor, table: torch
             "wholememory_scatter")
 
 
+def unique_bounded(indice: torch.Tensor, id_bound: int):
+    """``-> (distinct, inverse)``: the distinct non-negative ids of ``indice`` ASCENDING (int64) and, for every entry, its
+    position in that list (int32; -1 for a negative id = a row to skip) — ``wgamd_unique_bounded`` (mark, scan over the
+    bound, compact, look up; include/wgamd_ext.h).  One host synchronisation (the count).  An id >= ``id_bound`` raises."""
+    from .env import torch_dtype_to_wm
+    assert indice.is_cuda and indice.dim() == 1 and indice.dtype in (torch.int32, torch.int64) and indice.is_contiguous()
+    lib, dev, n = L.lib(), indice.device, int(indice.shape[0])
+    nbytes = lib.wgamd_unique_bounded_workspace_bytes(int(id_bound))
+    if nbytes == 0:
+        raise ValueError("unique_bounded: id_bound %d is outside (0, 2^31 - 4096)" % id_bound)
+    buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)   # (the caching allocator hands the same block back)
+    ws = (buf, (-buf.data_ptr()) % 256, nbytes)
+    distinct = torch.empty(min(n, int(id_bound)), dtype=torch.int64, device=dev)
+    inverse = torch.empty(n, dtype=torch.int32, device=dev)
+    info = torch.empty(2, dtype=torch.int32, device=dev)    # {distinct count, any id out of bound}
+    L.check(lib.wgamd_unique_bounded(indice.data_ptr(), torch_dtype_to_wm(indice.dtype), n, int(id_bound), distinct.data_ptr(),
+                                     inverse.data_ptr(), info.data_ptr(), info.data_ptr() + 4, ws[0].data_ptr() + ws[1], ws[2],
+                                     get_stream()), "wgamd_unique_bounded")
+    n_d, bad = (int(v) for v in info.cpu())
+    if bad:
+        raise IndexError("gather: an index is >= the table's %d rows" % id_bound)
+    return distinct[:n_d], inverse
+
+
+def dedup_pays(n: int, rows: int, world: int) -> bool:
+    """The ``dedup="auto"`` rule of the partitioned gathers: more than one rank (a repeat costs wire bytes only then) and
+    an id list that is large next to the table (a call group of mini-batches: 10.9 M ids into the 2.45 M rows of products —
+    at most a quarter of them can be distinct; the scan over the bound is then noise next to the exchange it shortens)."""
+    import os
+    force = os.environ.get("WGAMD_GATHER_DEDUP")   # "0" / "1": measurement switch, overrides the rule for every rank
+    if force in ("0", "1"):
+        return force == "1" and 0 < rows < (1 << 31) - 4096 and n > 0
+    return world > 1 and 0 < rows < (1 << 31) - 4096 and n >= max(rows // 8, 1024)
+
+
+def gather_distinct(gather_rows, indice: torch.Tensor, rows: int, out: torch.Tensor):
+    """``out[i] = table[indice[i]]`` fetching every DISTINCT row once: ``gather_rows(ids) -> [len(ids), dim]`` is the
+    (collective) fetch, the expansion ``out[i] = fetched[inverse[i]]`` a local row copy (negative ids leave their row alone)."""
+    distinct, inverse = unique_bounded(indice, rows)
+    fetched = gather_rows(distinct)
+    if indice.shape[0] > 0 and fetched.shape[0] > 0:
+        local_gather(fetched if fetched.dim() == 2 else fetched.unsqueeze(1), inverse, out if out.dim() == 2 else out.unsqueeze(1))
+    return out
+
+
 class HipLocalOps:
     """Local row kernels used by the distributed pipeline (product default: the HIP library)."""
 
@@ -90,13 +135,20 @@ class WholeMemoryTensor(object):
         return (self.local_tensor.cpu() if host_view else self.local_tensor), start
 
     # ---- ops -----------------------------------------------------------------------------
-    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None):
+    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None, dedup="auto"):
+        """``dedup`` (partitioned tables): fetch every DISTINCT row once and expand locally — True / False / "auto"
+        (``dedup_pays``).  Same result either way; every rank still makes exactly one collective fetch."""
         assert indice.dim() == 1
         embedding_dim = self.shape[1] if self.dim() == 2 else 1
         output_dtype = force_dtype if force_dtype is not None else self.dtype
         output_tensor = torch.empty([indice.shape[0], embedding_dim], device=indice.device, dtype=output_dtype,
                                     requires_grad=False)
         table2d = self.local_tensor if self.dim() == 2 else self.local_tensor.unsqueeze(1)
+        if self.is_distributed and indice.is_cuda and self.local_ops is HipLocalOps and (
+                dedup is True or (dedup == "auto" and dedup_pays(indice.shape[0], self._rows, _dist.world_size(self.group)))):
+            gather_distinct(lambda ids: self.gather(ids, force_dtype=force_dtype, dedup=False), indice.contiguous(), self._rows,
+                            output_tensor)
+            return output_tensor.view(-1) if self.dim() == 1 else output_tensor
         if self.is_distributed:
             _dist.distributed_gather(table2d, self.partition_offsets, indice, output_tensor, group=self.group,
                                      local_ops=self.local_ops)
@@ -245,12 +297,19 @@ class DistributedWholeMemoryTensor(object):
             return "peer-mapped loads over xGMI (HIP IPC, one kernel, no host sync)"
         return "all-to-all-v (RCCL send/recv groups, one host sync)"
 
-    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None, out: torch.Tensor = None):
+    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None, out: torch.Tensor = None,
+               dedup="auto"):
+        """``dedup``: fetch every DISTINCT row through the exchange once and expand locally (``gather_distinct``) — True /
+        False / "auto" (``dedup_pays``: more than one rank and an id list that is large next to the table, i.e. a call
+        group).  Same result; still exactly one collective ``wholememory_gather`` per rank and call."""
         assert indice.dim() == 1
         embedding_dim = self._shape[1] if self.dim() == 2 else 1
         if out is None:
             out = torch.empty([indice.shape[0], embedding_dim] if self.dim() == 2 else [indice.shape[0]],
                               device=indice.device, dtype=force_dtype if force_dtype is not None else self._dtype)
+        if dedup is True or (dedup == "auto" and dedup_pays(indice.shape[0], self._shape[0], self.comm.get_size())):
+            return gather_distinct(lambda ids: self.gather(ids, force_dtype=out.dtype, dedup=False), indice.contiguous(),
+                                   self._shape[0], out)
         w_i, w_o = wrap_torch_tensor(indice), wrap_torch_tensor(out)
         L.check(L.lib().wholememory_gather(self.c, w_i.c, w_o.c, get_wholegraph_env_fns(), get_stream(), -1),
                 "wholememory_gather")

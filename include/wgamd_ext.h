@@ -466,6 +466,21 @@ wholememory_error_code_t wgamd_csr_uniform_sample_with_replacement(
   void* output_dest_memory_context, void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
   unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream);
 
+/* De-duplication of an id list with a known bound (ids < id_bound, e.g. the vertex count of the table they index):
+ *   distinct[0 .. *n_distinct_dev)  the distinct non-negative ids, ASCENDING (so already grouped by owner rank of a
+ *                                   range-partitioned table); capacity min(n, id_bound) entries
+ *   inverse[i]                      position of ids[i] in `distinct`; -1 for a negative id (a row to skip) and for an id
+ *                                   >= id_bound (then *out_of_bound_dev = 1, nullable)
+ * Mark -> scan over the bound -> compact -> look up: no sort, no hash table, no host synchronisation.
+ * Used by the partitioned FeatureStore to send each distinct row of a call group over xGMI ONCE
+ * (wholegraph_amd/tensor.py, DistributedWholeMemoryTensor.gather(dedup=...)): the reference's
+ * wholememory_gather_nccl exchanges every requested id (/root/reference/cpp/src/wholememory_ops/gather_op_impl_nccl.cu:23-171).
+ * Workspace: wgamd_unique_bounded_workspace_bytes(id_bound) (0 = bound not supported: must be in (0, 2^31 - 4096)), 256-byte aligned. */
+size_t wgamd_unique_bounded_workspace_bytes(int64_t id_bound);
+wholememory_error_code_t wgamd_unique_bounded(const void* ids, wholememory_dtype_t id_dtype, int64_t n, int64_t id_bound,
+                                              int64_t* distinct, int* inverse, int* n_distinct_dev, int* out_of_bound_dev,
+                                              void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

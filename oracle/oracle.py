@@ -23,7 +23,7 @@ __all__ = [
     "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets", "unweighted_sample_with_replacement",
     "unweighted_sample", "weighted_sample", "append_unique", "csr_add_self_loop",
     "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "gat_aggregate_heads", "num_threads",
-    "set_num_threads", "py_pcg_u32_stream",
+    "set_num_threads", "py_pcg_u32_stream", "unique_bounded",
 ]
 
 
@@ -312,3 +312,16 @@ def num_threads():
 
 def set_num_threads(n):
     lib().wgo_set_num_threads(cint(n))
+
+
+def unique_bounded(ids, id_bound):
+    """CPU statement of wgamd_unique_bounded (include/wgamd_ext.h; this library's own op — the reference's NCCL gather
+    exchanges every id, gather_op_impl_nccl.cu:23-171): -> (distinct non-negative ids ascending, int32 position of every id
+    in that list, -1 for negative ids).  Test infrastructure only."""
+    import numpy as np
+    ids = np.asarray(ids).astype(np.int64)
+    assert ids.size == 0 or ids.max() < id_bound
+    distinct = np.unique(ids[ids >= 0])
+    inverse = np.full(ids.shape, -1, np.int32)
+    inverse[ids >= 0] = np.searchsorted(distinct, ids[ids >= 0]).astype(np.int32)
+    return distinct, inverse

@@ -87,6 +87,18 @@ WORKER = textwrap.dedent(r"""
             L.check(lib.wholememory_gather(t.c, w_i.c, w_o2.c, wg.env.get_wholegraph_env_fns(), wg.env.get_stream(), -1),
                     "wholememory_gather")
             assert torch.equal(out2.cpu(), want.to(tdt)), f"rank {r}: same-dtype gather mismatch"
+            # every DISTINCT row through the exchange once, expanded locally (gather(dedup=True)): same rows, and the rows
+            # of negative ids are left alone; a rank may take this path while another takes the plain one (one collective each)
+            from wholegraph_amd.tensor import dedup_pays
+            idx_d = torch.from_numpy(idx).cuda()
+            out3 = torch.full((k, dim), 3.0, dtype=odt, device="cuda")
+            t.gather(idx_d, force_dtype=odt, out=out3, dedup=(r % 2 == 0))
+            assert torch.equal(out3.cpu(), want), f"rank {r}: de-duplicated gather mismatch"
+            out4 = torch.full((k, dim), 3.0, dtype=tdt, device="cuda")
+            t.gather(idx_d.int(), out=out4, dedup="auto")
+            assert torch.equal(out4.cpu(), want.to(tdt)), f"rank {r}: auto gather mismatch"
+            assert dedup_pays(10_900_000, 2_449_029, 8) and not dedup_pays(10_900_000, 2_449_029, 1)
+            assert not dedup_pays(1000, 2_449_029, 8) and not dedup_pays(10**7, 1 << 31, 8)
             comm.barrier()
             # file I/O: every rank stores its rows; reload (a) the part files in order into a table with a DIFFERENT
             # partition, (b) round-robin sharded (blocks of 16 rows dealt to the ranks in turn)

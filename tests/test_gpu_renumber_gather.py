@@ -142,3 +142,33 @@ def test_walk_is_identical_with_the_single_launch_scan(hiplib):
                         "tests/test_gpu_renumber_gather.py", "-k", "not single_launch_scan"],
                        cwd=root, env=dict(os.environ, WGAMD_SCAN_CHAINED="1"), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n,bound,dtype", [(0, 10, np.int64), (1, 1, np.int64), (5000, 300, np.int32), (300, 5000, np.int64),
+                                           (200000, 70001, np.int64), (4097, 4096, np.int32)])
+def test_unique_bounded_matches_numpy(oracle_mod, hiplib, n, bound, dtype):
+    """wgamd_unique_bounded: distinct ids ascending + the position of every id (mark / scan / compact / look up)."""
+    import torch
+    from wholegraph_amd.tensor import unique_bounded
+    rng = np.random.default_rng(n + bound)
+    ids = (rng.zipf(1.3, n) % bound).astype(dtype) if n else np.zeros(0, dtype)
+    if n > 10:
+        ids[::7] = -1          # rows to skip
+        ids[1] = bound - 1     # the largest legal id
+        ids[2] = 0
+    want_d, want_i = oracle_mod.unique_bounded(ids, bound)
+    d, inv = unique_bounded(torch.from_numpy(ids).cuda(), bound)
+    assert d.dtype == torch.int64 and inv.dtype == torch.int32
+    assert np.array_equal(d.cpu().numpy(), want_d) and np.array_equal(inv.cpu().numpy(), want_i)
+    if n > 10:
+        bad = ids.copy()
+        bad[3] = bound
+        with pytest.raises(IndexError):
+            unique_bounded(torch.from_numpy(bad).cuda(), bound)
+
+
+def test_unique_bounded_refuses_an_unsupported_bound(hiplib):
+    import torch
+    from wholegraph_amd.tensor import unique_bounded
+    with pytest.raises(ValueError):
+        unique_bounded(torch.zeros(4, dtype=torch.int64, device="cuda"), 1 << 31)
