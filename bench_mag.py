@@ -126,6 +126,24 @@ class MagPipeline:
         return n_nodes, live
 
     # ---- forward ----------------------------------------------------------------------------------------------
+    def _terms_keys(self, t):
+        """Relation ends whose attention logit reads node type t, in the column order of ``_terms_matrix``."""
+        keys = []
+        for et in self.etypes:
+            if et[0] == t:
+                keys.append(("src", et))
+            if et[2] == t:
+                keys.append(("dst", et))
+        return keys
+
+    def _terms_matrix(self, layer, t):
+        """[in, HEADS * relation ends of t]: the folded attention vectors of every relation end of node type t, side by side."""
+        cache = self.__dict__.setdefault("_terms_cache", {})
+        if (layer, t) not in cache:
+            mats = [self.params[layer]["rel"][et]["v_src" if end == "src" else "v_dst"] for end, et in self._terms_keys(t)]
+            cache[(layer, t)] = torch.cat(mats, 1).contiguous() if mats else None
+        return cache[(layer, t)]
+
     def forward(self, rec, sizes_h, ev, timers=None):
         nn, G = self.nn, self.G
         ev.synchronize()
@@ -148,11 +166,19 @@ class MagPipeline:
 
         # feature fetch: one row gather per node type for the whole call group
         from wholegraph_amd.tensor import local_gather
-        x = {}
+        # Layer 1's attention logits need x_t @ [fold(W_r, att_src) | fold(W_r, att_dst) ...] for every gathered row: folded into
+        # the gather (wgamd_gather_terms_f32: the rows pass through registers once and feed an exact-fp32 MFMA) instead of a
+        # second pass over x (library GEMM with N = 8..20: 1.9 ms per call group next to the 1.4 ms gather).
+        x, terms1 = {}, {}
         for t in self.ntypes:
             ids = state[t]["nodes"][:n_nodes[t]]
-            x[t] = stage("gather", lambda: local_gather(self.tables[t], ids,
-                                                        torch.empty((n_nodes[t], F_IN), dtype=torch.float32, device=self.dev)))
+            v_t = self._terms_matrix(0, t)
+            buf = torch.empty((n_nodes[t], F_IN), dtype=torch.float32, device=self.dev)
+            if v_t is not None and n_nodes[t] > 0 and nn.gather_terms_supported(F_IN, v_t.shape[1]):
+                x[t], terms1[t] = stage("gather+attn_terms1", lambda: nn.gather_with_terms(self.tables[t], ids, v_t, out=buf,
+                                                                                           heads=HEADS if HEADS == 4 else 0))
+            else:
+                x[t] = stage("gather", lambda: local_gather(self.tables[t], ids, buf))
 
         # per (hop, edge type): where the hop's rows sit in the destination type's node list (full numbering for the
         # attention terms of layer 1, compact numbering for the layer-1 output), and the source rows of its edges (local
@@ -189,23 +215,23 @@ class MagPipeline:
         calls = [c for c in stage("index_prep", prep) if c is not None]
         edges = sum(lv[1] for lv in live if lv is not None)
 
-        def attention_terms(xs, p):
-            """alpha's inputs for every relation: x_t @ [fold(W_r, att_src) | fold(W_r, att_dst) ...] — ONE pass over x_t."""
+        def attention_terms(layer, xs, p, ready=None):
+            """alpha's inputs for every relation: x_t @ [fold(W_r, att_src) | fold(W_r, att_dst) ...] — ONE pass over x_t
+            (``ready[t]``: the product already made by the gather)."""
             a_src, a_dst = {}, {}
             for t in self.ntypes:
                 if xs[t].shape[0] == 0:
                     continue
-                mats, keys = [], []
-                for et in self.etypes:
-                    if et[0] == t:
-                        mats.append(p["rel"][et]["v_src"]); keys.append((a_src, et))
-                    if et[2] == t:
-                        mats.append(p["rel"][et]["v_dst"]); keys.append((a_dst, et))
-                if not mats:
+                keys = [(a_src if end == "src" else a_dst, et) for end, et in self._terms_keys(t)]
+                if not keys:
                     continue
-                # (a hand-written narrow-matmul kernel — 64-row LDS tiles, K <= 32 — was built and measured: no faster than the
+                # (a stand-alone narrow-matmul kernel — 64-row LDS tiles, K <= 32 — was built and measured: no faster than the
                 #  library GEMM at F = 128, slower at F = 256; taken out again)
-                both = xs[t] @ torch.cat(mats, 1)
+                if ready is not None and t in ready and ready[t].dim() == 3:     # [relation end][n][H] slabs from the gather
+                    for k, (dst, et) in enumerate(keys):
+                        dst[et] = ready[t][k]
+                    continue
+                both = ready[t] if (ready is not None and t in ready) else xs[t] @ self._terms_matrix(layer, t)
                 for k, (dst, et) in enumerate(keys):
                     dst[et] = both[:, k * HEADS:(k + 1) * HEADS].contiguous()
             return a_src, a_dst
@@ -213,7 +239,7 @@ class MagPipeline:
         def hetero_layer(layer, xs, hop_set, col_key, dst_key, n_out, launches):
             """One HeteroConv{GATConv} layer for the frontier rows of the hops in ``hop_set``; returns {type: compact rows}."""
             p = self.params[layer]
-            a_src, a_dst = stage("attn_terms%d" % (layer + 1), lambda: attention_terms(xs, p))
+            a_src, a_dst = stage("attn_terms%d" % (layer + 1), lambda: attention_terms(layer, xs, p, terms1 if layer == 0 else None))
             # every compact row is a frontier entry of exactly one hop of its type, so the index_copy below writes all of them
             out = {t: torch.empty((n_out[t], HC), dtype=torch.float32, device=self.dev) for t in self.ntypes if n_out[t] > 0}
             for h in hop_set:

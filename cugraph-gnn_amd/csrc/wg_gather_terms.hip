@@ -1,0 +1,156 @@
+// Feature gather with a narrow product folded in:
+//     out_x[i, :]     = table[ids[i], :]                      (the row gather of wholememory_gather, fp32)
+//     out_terms[i, :] = table[ids[i], :] @ V                  (V [F, T], T <= 32)
+// in ONE pass over the gathered rows.  What it is for: the attention logits of GATConv,
+//     alpha_src[j, h] = ((x_j W).view(H, C) * att_src).sum(-1) = x_j . fold(W, att_src)[:, h]
+// (torch_geometric.nn.GATConv as the reference's models use it, /root/reference/python/pylibwholegraph/pylibwholegraph/torch/
+// gnn_model.py:45-59), need one [F, H] product per relation end and node type over EVERY gathered row: for the ogbn-mag
+// call group (BASELINE configs[4], bench_mag.py) that was a second pass over 4 GB of x — a library GEMM with N = 8..20,
+// 1.9 ms next to the 1.4 ms gather.  Here the rows pass through registers once.
+//
+// The product runs on the matrix pipe in exact fp32 (v_mfma_f32_16x16x4_f32), computed TRANSPOSED so that the row gather
+// itself produces the operand layout: out^T [T x rows] = V^T [T x F] . x^T [F x rows].  A wave takes 16 rows at a time, four
+// lanes per row; lane (r, q) loads the 16-byte chunks q, q + 4, q + 8, ... of row r (64 contiguous bytes of a row per
+// load instruction) and stores them to out_x as they are.  The B operand of a 16x16x4 MFMA wants B[k = lane / 16][col = lane % 16]:
+// with col = the row r and the k-order of step (m, i) chosen as k = 16 m + 4 q + i, that is exactly float i of the lane's
+// chunk m — no shuffle, no LDS.  The A operand (V^T in the same k-order) sits in registers for the whole launch.  The
+// accumulator tile D[t = 4 (lane / 16) + v][r = lane % 16] leaves as one 16-byte store per lane: out_terms[r, 4 q' .. 4 q' + 3].
+#include "wg_common.hpp"
+#include "wgamd_ext.h"
+
+namespace wgamd {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// KM = F / 16 chunks per lane, TT = 16-term tiles (T <= 16 TT)
+template <typename IdT, int KM, int TT>
+__global__ void __launch_bounds__(256)
+gather_terms_kernel(const float* __restrict__ table, int64_t ldt, const IdT* __restrict__ ids, int64_t n, const float* __restrict__ v,
+                    int T, float* __restrict__ out_x, int64_t ldx, float* __restrict__ out_terms, int64_t ldo, int group)
+{
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  // A operand: a[tt][m][i] = V[16 m + 4 q + i][16 tt + r]  (zero past T)
+  float a[TT][KM][4];
+#pragma unroll
+  for (int tt = 0; tt < TT; tt++) {
+    const int t = tt * 16 + r;
+#pragma unroll
+    for (int m = 0; m < KM; m++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[tt][m][i] = t < T ? v[(int64_t)(16 * m + 4 * q + i) * T + t] : 0.f;
+  }
+  const int64_t n_tiles  = (n + 15) / 16;
+  const int64_t wave     = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves  = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // the id of the NEXT tile's row is requested before this tile's rows are waited for: one dependent round trip per tile, not two
+  int64_t id_next = (wave < n_tiles && wave * 16 + r < n) ? (int64_t)ids[wave * 16 + r] : -1;
+  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const int64_t row  = tile * 16 + r;
+    const bool in      = row < n;
+    const int64_t id   = id_next;
+    {
+      const int64_t nrow = (tile + n_waves) * 16 + r;
+      id_next            = (tile + n_waves < n_tiles && nrow < n) ? (int64_t)ids[nrow] : -1;
+    }
+    const bool live    = id >= 0;                         // a negative id: the row is skipped, its terms are zero
+    const float* src   = table + (live ? id : 0) * ldt + 4 * q;
+    f32x4 x[KM];
+#pragma unroll
+    for (int m = 0; m < KM; m++) x[m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
+    if (live) {
+      float* dst = out_x + row * ldx + 4 * q;
+#pragma unroll
+      for (int m = 0; m < KM; m++) *reinterpret_cast<f32x4*>(dst + 16 * m) = x[m];
+    }
+    f32x4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < KM; m++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float b = live ? x[m][i] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][m][i], b, acc[tt], 0, 0, 0);
+      }
+    // D[t = 16 tt + 4 q + v][row r]: four consecutive terms of one row per lane
+    if (in) {
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) {
+        const int t0 = tt * 16 + 4 * q;
+        if (group == 4) {   // slabs [T / 4][n][4]: the four terms of one (row, relation end) are one 16-byte store
+          if (t0 < T) *reinterpret_cast<f32x4*>(out_terms + ((int64_t)(t0 >> 2) * n + row) * 4) = acc[tt];
+          continue;
+        }
+        float* o = out_terms + row * ldo + t0;
+        if (t0 + 4 <= T && (ldo & 3) == 0) {
+          *reinterpret_cast<f32x4*>(o) = acc[tt];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (t0 + i < T) o[i] = acc[tt][i];
+        }
+      }
+    }
+  }
+}
+
+template <typename IdT, int KM>
+void launch_tt(int TT, int grid, hipStream_t st, const float* table, int64_t ldt, const IdT* ids, int64_t n, const float* v, int T,
+               float* out_x, int64_t ldx, float* out_terms, int64_t ldo, int group)
+{
+  if (TT == 1) gather_terms_kernel<IdT, KM, 1><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
+  else gather_terms_kernel<IdT, KM, 2><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
+}
+
+template <typename IdT>
+void launch_km(int KM, int TT, int grid, hipStream_t st, const float* table, int64_t ldt, const IdT* ids, int64_t n, const float* v,
+               int T, float* out_x, int64_t ldx, float* out_terms, int64_t ldo, int group)
+{
+  switch (KM) {
+    case 2: launch_tt<IdT, 2>(TT, grid, st, table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group); break;
+    case 4: launch_tt<IdT, 4>(TT, grid, st, table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group); break;
+    case 8: launch_tt<IdT, 8>(TT, grid, st, table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group); break;
+    default: launch_tt<IdT, 16>(TT, grid, st, table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group); break;
+  }
+}
+
+}  // namespace
+}  // namespace wgamd
+
+extern "C" {
+
+int wgamd_gather_terms_supported(int F, int T) { return (F == 32 || F == 64 || F == 128 || F == 256) && T > 0 && T <= 32; }
+
+wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt, const void* ids, wholememory_dtype_t id_dtype,
+                                                int64_t n, int F, const float* v, int T, float* out_x, int64_t ldx,
+                                                float* out_terms, int64_t ldo, int term_group, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gather_terms_f32", [&] {
+    WG_REQUIRE_INPUT(id_dtype == WHOLEMEMORY_DT_INT || id_dtype == WHOLEMEMORY_DT_INT64, "id dtype must be INT|INT64");
+    WG_REQUIRE_INPUT(n >= 0 && n < ((int64_t)1 << 40), "bad row count");
+    if (!wgamd_gather_terms_supported(F, T)) throw logic_error("gather_terms: F must be 32 | 64 | 128 | 256 and 0 < T <= 32");
+    if (n == 0) return;
+    WG_REQUIRE_INPUT(table && ids && v && out_x && out_terms, "null pointer");
+    WG_REQUIRE_INPUT(term_group == 0 || (term_group == 4 && T % 4 == 0), "term_group must be 0 (rows [n, T]) or 4 (slabs [T/4][n][4])");
+    WG_REQUIRE_INPUT(ldt >= F && ldx >= F && (term_group != 0 || ldo >= T), "leading dimension smaller than the row");
+    if (((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out_x)) & 15) != 0 || (ldt & 3) != 0 || (ldx & 3) != 0 ||
+        (reinterpret_cast<uintptr_t>(out_terms) & 15) != 0)
+      throw logic_error("gather_terms: rows must be 16-byte aligned");
+    hipStream_t st        = static_cast<hipStream_t>(stream);
+    const int64_t n_tiles = (n + 15) / 16;
+    const int cus         = stream_cu_count(st);
+    const int grid        = (int)std::min<int64_t>((n_tiles + 3) / 4, (int64_t)cus * 8);
+    const int KM = F / 16, TT = (T + 15) / 16;
+    if (id_dtype == WHOLEMEMORY_DT_INT)
+      launch_km<int32_t>(KM, TT, grid, st, table, ldt, static_cast<const int32_t*>(ids), n, v, T, out_x, ldx, out_terms, ldo, term_group);
+    else
+      launch_km<int64_t>(KM, TT, grid, st, table, ldt, static_cast<const int64_t*>(ids), n, v, T, out_x, ldx, out_terms, ldo, term_group);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

@@ -242,6 +242,9 @@ SYMBOLS = {
                                                 c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                 c_int64, c_void_p]),
+    "wgamd_gather_terms_supported": (c_int, [c_int, c_int]),
+    "wgamd_gather_terms_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,
+                                       c_void_p, c_int64, c_int, c_void_p]),
     "wgamd_unique_bounded_workspace_bytes": (c_size_t, [c_int64]),
     "wgamd_unique_bounded": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

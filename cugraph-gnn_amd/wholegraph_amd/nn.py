@@ -335,11 +335,37 @@ def gat_transform_heads(agg, w, heads, out=None):
     (one strided batched GEMM, MFMA through hipBLASLt).  ``out`` given: accumulated into (HeteroConv's sum)."""
     n, F_ = agg.shape[0], agg.shape[1] // heads
     C = w.shape[1] // heads
-    res = torch.bmm(agg.view(n, heads, F_).permute(1, 0, 2), w.view(F_, heads, C).permute(1, 0, 2))     # [H, n, C]
+    a, b = agg.view(n, heads, F_).permute(1, 0, 2), w.view(F_, heads, C).permute(1, 0, 2)
     if out is None:
-        return res.permute(1, 0, 2).reshape(n, heads * C)
-    out.view(n, heads, C).add_(res.permute(1, 0, 2))
+        return torch.bmm(a, b).permute(1, 0, 2).reshape(n, heads * C)                                    # [H, n, C] -> [n, H C]
+    # accumulate in place through the strided view (beta = 1): no [H, n, C] temporary and no separate add pass — same bits,
+    # 1.48 -> 1.15 ms at 1 M rows, 4 x 128 -> 4 x 64
+    acc = out.view(n, heads, C).permute(1, 0, 2)
+    torch.baddbmm(acc, a, b, out=acc)
     return out
+
+
+def gather_terms_supported(F_: int, T: int) -> bool:
+    return bool(L.lib().wgamd_gather_terms_supported(int(F_), int(T)))
+
+
+def gather_with_terms(table: torch.Tensor, ids: torch.Tensor, v: torch.Tensor, out: torch.Tensor = None, heads: int = 0):
+    """``-> (x, terms)``: ``x = table[ids]`` and ``terms = x @ v`` (``v`` [F, T], T <= 32) in ONE pass over the gathered rows
+    (``wgamd_gather_terms_f32``: the row gather feeds an exact-fp32 MFMA).  For GATConv's attention logits, whose folded
+    [F, H] matrices of every relation end of a node type are concatenated into ``v``.  ``heads=4``: ``terms`` comes back as
+    [T / 4, n, 4] — one contiguous [n, 4] slab per relation end — instead of [n, T]."""
+    assert table.dtype == torch.float32 and table.dim() == 2 and table.stride(1) == 1 and v.dtype == torch.float32
+    assert ids.dim() == 1 and ids.is_contiguous() and ids.dtype in (torch.int32, torch.int64)
+    n, F_, T = int(ids.shape[0]), int(table.shape[1]), int(v.shape[1])
+    assert v.shape[0] == F_ and v.is_contiguous()
+    if out is None:
+        out = torch.empty((n, F_), dtype=torch.float32, device=table.device)
+    assert heads in (0, 4) and (heads == 0 or T % 4 == 0)
+    terms = torch.empty((T // 4, n, 4) if heads else (n, T), dtype=torch.float32, device=table.device)
+    L.check(L.lib().wgamd_gather_terms_f32(table.data_ptr(), table.stride(0), ids.data_ptr(), torch_dtype_to_wm(ids.dtype), n, F_,
+                                           v.data_ptr(), T, out.data_ptr(), out.stride(0), terms.data_ptr(), T, heads,
+                                           get_stream()), "wgamd_gather_terms_f32")
+    return out, terms
 
 
 def bias_act_rows(x, bias=None, relu=True, dst_rows=None, out=None):

@@ -466,6 +466,20 @@ wholememory_error_code_t wgamd_csr_uniform_sample_with_replacement(
   void* output_dest_memory_context, void* output_center_localid_memory_context, void* output_edge_gid_memory_context,
   unsigned long long random_seed, wholememory_env_func_t* p_env_fns, void* stream);
 
+/* Feature gather with a narrow product folded in, one pass over the gathered rows:
+ *   out_x[i, :] = table[ids[i], :]          out_terms[i, :] = table[ids[i], :] @ v       (v [F, T] row-major, T <= 32)
+ * fp32 in, exact-fp32 MFMA products, fp32 accumulation.  A negative id skips the row (out_x[i] untouched) and yields zero terms.
+ * For the attention logits of GATConv (x_j . fold(W, att) per relation end — the reference's models build
+ * torch_geometric.nn.GATConv, /root/reference/python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:45-59): the second pass
+ * over every gathered row that a separate [n, F] x [F, T] GEMM costs disappears.
+ * term_group = 0: out_terms is [n, T] rows (ldo floats apart).  term_group = 4 (T % 4 == 0): slabs [T / 4][n][4] — the four
+ * terms of relation end k for all rows are contiguous (what a GAT kernel with H = 4 heads reads), ldo unused.
+ * Shapes: F in {32, 64, 128, 256} (wgamd_gather_terms_supported), rows 16-byte aligned; others: WHOLEMEMORY_LOGIC_ERROR. */
+int wgamd_gather_terms_supported(int F, int T);
+wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt, const void* ids, wholememory_dtype_t id_dtype,
+                                                int64_t n, int F, const float* v, int T, float* out_x, int64_t ldx,
+                                                float* out_terms, int64_t ldo, int term_group, void* stream);
+
 /* De-duplication of an id list with a known bound (ids < id_bound, e.g. the vertex count of the table they index):
  *   distinct[0 .. *n_distinct_dev)  the distinct non-negative ids, ASCENDING (so already grouped by owner rank of a
  *                                   range-partitioned table); capacity min(n, id_bound) entries

@@ -154,3 +154,45 @@ def test_bias_act_rows(hiplib):
     want = torch.full((5000, 256), 7.0, device="cuda")
     want[rows] = torch.relu(x + b)
     assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("F,T,n,dtype", [(128, 20, 5000, "int64"), (128, 8, 33, "int32"), (64, 32, 1000, "int64"), (256, 17, 777, "int64"),
+                                         (32, 1, 100, "int32"), (128, 16, 16, "int64"), (128, 12, 0, "int64")])
+def test_gather_with_terms_matches_gather_and_fp64_product(oracle_mod, hiplib, F, T, n, dtype):
+    """wgamd_gather_terms_f32: out_x is the plain row gather bit for bit (the oracle's gather), out_terms = x @ v within fp32
+    round-off of the fp64 product (1e-5 x scale); negative ids skip their row and give zero terms."""
+    import numpy as np
+    import torch
+    from wholegraph_amd import nn
+    rng = np.random.default_rng(F * 100 + T)
+    V_rows = 4000
+    table = rng.standard_normal((V_rows, F)).astype(np.float32)
+    v = (rng.standard_normal((F, T)) * 0.3).astype(np.float32)
+    ids = rng.integers(0, V_rows, n).astype(dtype)
+    if n > 20:
+        ids[::9] = -1
+    assert nn.gather_terms_supported(F, T) and not nn.gather_terms_supported(100, 8) and not nn.gather_terms_supported(128, 33)
+    out = torch.full((n, F), 7.0, dtype=torch.float32, device="cuda")
+    x, terms = nn.gather_with_terms(torch.from_numpy(table).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(v).cuda(), out=out)
+    want_x = oracle_mod.gather_rows(table, np.where(ids < 0, 0, ids)) if n else np.zeros((0, F), np.float32)
+    want_x[ids < 0] = 7.0
+    assert np.array_equal(x.cpu().numpy(), want_x)
+    live = want_x.astype(np.float64) * (ids >= 0)[:, None]
+    ref = live @ v.astype(np.float64)
+    scale = np.abs(live) @ np.abs(v.astype(np.float64))
+    assert terms.shape == (n, T)
+    assert np.all(np.abs(terms.cpu().numpy() - ref) <= 1e-5 * scale + 1e-7)
+    assert np.all(terms.cpu().numpy()[ids < 0] == 0)
+    if T % 4 == 0:   # the slab layout [T / 4][n][4]: same numbers, one contiguous [n, 4] block per relation end
+        _, slabs = nn.gather_with_terms(torch.from_numpy(table).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(v).cuda(), heads=4)
+        assert slabs.shape == (T // 4, n, 4)
+        assert torch.equal(slabs.permute(1, 0, 2).reshape(n, T), terms)
+
+
+def test_gather_with_terms_refuses_unsupported_widths(hiplib):
+    import torch
+    import wholegraph_amd._lib as L
+    from wholegraph_amd import nn
+    t = torch.zeros((10, 100), device="cuda")
+    with pytest.raises(L.WholeMemoryError):
+        nn.gather_with_terms(t, torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros((100, 8), device="cuda"))
