@@ -100,7 +100,14 @@ __global__ void __launch_bounds__(256) row_copy_kernel(const char* __restrict__ 
 #pragma unroll
         for (int k = 0; k < kRowsInFlight; k++) {
           char* q = dst + (MODE == 0 ? row0 + k : MODE == 1 ? r[k] : r2[k]) * dst_stride + off;
-          *reinterpret_cast<vec_t*>(q) = v[k];
+          // gathered rows are written once and read by a later kernel: a streaming store keeps them from pushing table rows
+          // (re-read by the next mini-batches of the call group) out of the caches — gather 1.47 -> 1.44 ms, products group
+          if constexpr (MODE == 0 && V == 16) {
+            using nt_t = __attribute__((ext_vector_type(4))) unsigned int;
+            __builtin_nontemporal_store(__builtin_bit_cast(nt_t, v[k]), reinterpret_cast<nt_t*>(q));
+          } else {
+            *reinterpret_cast<vec_t*>(q) = v[k];
+          }
         }
       }
       continue;
