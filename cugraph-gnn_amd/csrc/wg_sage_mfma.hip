@@ -262,8 +262,51 @@ struct producer {
       }
     }
   }
-  // rows longer than the prefetched window (deg > 10: rare behind a fan-out of 10, the rule behind one of 25): reduce_store
-  // left the UNSCALED sum of the first kNb neighbours in the tile; the rest is added to it in CSR order, kLongUnroll row
+  // SECOND WINDOW: neighbours kNb .. kNb + kW2 - 1 of the rows that have them.  Their byte offsets are already in registers —
+  // load_ids / finish gave lane `sub` of the group the offset of neighbour `sub`, whatever the degree — so a row behind a
+  // fan-out of 25 needs no further id loads: kW2 row loads go out together and continue the window's UNSCALED partial sum
+  // (left in the tile by reduce_store) in CSR order.  Rows with deg <= kNb + kW2 are finished here.
+  static constexpr int kW2 = LG >= 32 ? 16 : (LG > kNb ? LG - kNb : 0);
+  __device__ __forceinline__ void second_window(const meta_t<IT, off_t>& m, float* tile_lds) const
+  {
+    if constexpr (kW2 > 0) {
+#pragma unroll
+      for (int it = 0; it < IT; it++) {
+        const int deg = m.d[it];
+        if (__ballot(deg > kNb) == 0ull) continue;
+        const bool mine = live && deg > kNb;
+        f32x4 v[kW2];
+#pragma unroll
+        for (int k = 0; k < kW2; k++) {
+          const int kk = kNb + k;
+          if constexpr (OFF32) {
+            const uint32_t off = (uint32_t)__shfl((int)m.src[it], gbase | kk, 64);
+            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kk < deg ? off + f0c * 4 : a.x_bytes, 0, 0));
+          } else {
+            const int lo = __shfl((int)(m.src[it] & 0xffffffff), gbase | kk, 64);
+            const int hi = __shfl((int)((int64_t)m.src[it] >> 32), gbase | kk, 64);
+            int64_t off  = ((int64_t)hi << 32) | (uint32_t)lo;
+            off          = kk < deg ? off : (int64_t)0;
+            v[k]         = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + off + f0c * 4);
+          }
+        }
+        float* prow = tile_lds + (group + it * kGroups) * a.SD + f0;
+        f32x4 acc   = {0.f, 0.f, 0.f, 0.f};
+        if (mine) acc = *reinterpret_cast<const f32x4*>(prow);
+#pragma unroll
+        for (int k = 0; k < kW2; k++) {
+          if constexpr (OFF32) acc += v[k];
+          else acc += kNb + k < deg ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (mine) {
+          if (a.mean && deg <= kNb + kW2) acc *= __frcp_rn((float)deg);
+          *reinterpret_cast<f32x4*>(prow) = acc;
+        }
+      }
+    }
+  }
+  // rows longer than BOTH windows (deg > 26 at F >= 100): the tile holds the UNSCALED sum of their first kNb + kW2 neighbours;
+  // the rest is added to it in CSR order, kLongUnroll row
   // loads in flight at a time (one at a time — a dependent round trip per neighbour — made the 47-class head of the products
   // model, whose hop has fan-out 25, three times slower than aggregate + GEMM)
   static constexpr int kLongUnroll = 8;
@@ -273,19 +316,19 @@ struct producer {
 #pragma unroll
     for (int it = 0; it < IT; it++) {
       const int deg = m.d[it];
-      if (__ballot(deg > kNb) == 0ull) continue;
-      const bool mine    = live && deg > kNb;
+      if (__ballot(deg > kNb + kW2) == 0ull) continue;
+      const bool mine    = live && deg > kNb + kW2;
       const int64_t row  = row_of(tile, it);
       const int64_t rowc = row < a.n_rows ? row : a.n_rows - 1;
       const int s        = a.row_ptr[rowc];
       float* prow        = tile_lds + (group + it * kGroups) * a.SD + f0;
       f32x4 acc          = {0.f, 0.f, 0.f, 0.f};
       if (mine) acc = *reinterpret_cast<const f32x4*>(prow);
-      int maxdeg = deg > kNb ? deg : 0;
+      int maxdeg = deg > kNb + kW2 ? deg : 0;
 #pragma unroll
       for (int dd = 32; dd >= LG; dd >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, dd, 64));
-      for (int c0 = kNb; c0 < maxdeg; c0 += LG) {
-        const int64_t my_src = (deg > kNb && c0 + sub < deg) ? table_row<IdT>(src_ids, (int64_t)a.col[s + c0 + sub]) : 0;
+      for (int c0 = kNb + kW2; c0 < maxdeg; c0 += LG) {
+        const int64_t my_src = (deg > kNb + kW2 && c0 + sub < deg) ? table_row<IdT>(src_ids, (int64_t)a.col[s + c0 + sub]) : 0;
         const int chunk      = min(LG, maxdeg - c0);
         for (int j0 = 0; j0 < chunk; j0 += kLongUnroll) {
           f32x4 v[kLongUnroll];
@@ -738,6 +781,7 @@ sage_layer_mfma_kernel(mfma_args a)
               if (it + kDepth - 1 < IT) p.issue(cur, it + kDepth - 1, buf[(it + kDepth - 1) % kDepth]);
               p.reduce_store(cur, it, buf[it % kDepth], rows_lds);
             }
+            p.second_window(cur, rows_lds);
             p.long_rows(sub_of(j), cur, rows_lds);
             p.finish(i_next, cur);
             if (j + 1 < 2 * mine) {
@@ -825,6 +869,7 @@ sage_layer_mfma_kernel(mfma_args a)
           if (it + kDepth - 1 < IT) p.issue(cur, it + kDepth - 1, buf[(it + kDepth - 1) % kDepth]);
           p.reduce_store(cur, it, buf[it % kDepth], tile_lds);
         }
+        p.second_window(cur, tile_lds);
         p.long_rows(tile_of(n), cur, tile_lds);
         // offsets of tile n+1, and its first rows in flight BEFORE the barrier
         p.finish(i_next, cur);
