@@ -535,7 +535,13 @@ def main():
         want = kat(ids.to(torch.int64))
         live = (ids >= 0)
         ok = bool(torch.equal(got[live], want[live]))
-        info = {"rows": rows, "ids_per_rank": int(ids.numel()), "bit_exact": ok, "path": feature_fetch_path(t)}
+        # the timed groups take the DE-DUPLICATED form of the same fetch (every distinct row through the exchange once, expanded
+        # locally: gather(dedup=...), wholegraph_amd/tensor.py) — the known answer must come back through it as well
+        got_d = t.gather(ids, dedup=True)
+        torch.cuda.synchronize()
+        ok_d = bool(torch.equal(got_d[live], want[live]))
+        ok = ok and ok_d
+        info = {"rows": rows, "ids_per_rank": int(ids.numel()), "bit_exact": ok, "dedup_bit_exact": ok_d, "path": feature_fetch_path(t)}
         if hasattr(t, "comm") and hasattr(t.comm, "rccl_info"):
             info["rccl_ranks"], info["rccl_version"] = t.comm.rccl_info()
         if hasattr(t, "destroy"):
