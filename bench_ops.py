@@ -25,23 +25,31 @@ import torch  # noqa: E402
 from bench import HBM_PEAK_GBPS, V_PRODUCTS, E_UNDIRECTED, rmat_csr  # noqa: E402
 
 
-def timed(fn, iters=20, warm=3, events=False):
+def timed(fn, iters=20, warm=14, events=False):
+    """Seconds per call: MEDIAN of five timed chunks after `warm` untimed calls (the caching allocator settles on an op's
+    block sizes after ~10 calls; a one-off 40 ms stall of the runtime still lands in one op's loop now and then — the median of
+    chunks keeps it out of the table, a mean over one loop read 2 ms for a 0.1 ms op)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    if events:
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(iters):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) * 1e-3 / iters
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
+    per = max(iters // 5, 2)
+    chunks = []
+    for _ in range(5):
+        if events:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(per):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            chunks.append(s.elapsed_time(e) * 1e-3 / per)
+        else:
+            t0 = time.perf_counter()
+            for _ in range(per):
+                fn()
+            torch.cuda.synchronize()
+            chunks.append((time.perf_counter() - t0) / per)
+    return sorted(chunks)[2]
 
 
 def hetero_section(dev):
