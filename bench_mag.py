@@ -247,7 +247,9 @@ class MagPipeline:
                     mine = [c for c in calls if c["hop"] == h and c["et"][2] == dt]
                     if not mine:
                         continue
-                    acc = torch.zeros((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
+                    # HeteroConv's sum over the relations into `acc`: the first relation with edges WRITES it (beta = 0)
+                    acc = torch.empty((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
+                    first = True
                     for c in mine:
                         et = c["et"]
                         if c["n_e"] == 0:
@@ -255,9 +257,13 @@ class MagPipeline:
                         agg = stage("gat%d:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
                                     lambda: nn.gat_aggregate_heads(c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], HEADS,
                                                                    dst_rows=c[dst_key]))
-                        stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads(agg, p["rel"][et]["w"], HEADS, out=acc))
+                        stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads(agg, p["rel"][et]["w"], HEADS, out=acc,
+                                                                                          overwrite=first))
+                        first = False
                         if launches is not None:
                             launches.append((et, h, c["n_f"], c["n_e"], xs[et[0]].shape[1]))
+                    if first:
+                        acc.zero_()       # no relation of this type sampled an edge in this hop: relu(bias) rows
                     # bias + ReLU (+ the placement of the hop's rows in the compact list of layer 1) in one pass
                     if layer == 0:
                         stage("bias_relu", lambda: nn.bias_act_rows(acc, p["bias"][dt], True, mine[0]["dst_c"], out[dt]))
