@@ -232,8 +232,10 @@ class MagPipeline:
                         dst[et] = ready[t][k]
                     continue
                 both = ready[t] if (ready is not None and t in ready) else xs[t] @ self._terms_matrix(layer, t)
+                # one [relation end][n][H] copy per node type instead of one slice copy per relation end
+                slabs = both.view(both.shape[0], len(keys), HEADS).permute(1, 0, 2).contiguous()
                 for k, (dst, et) in enumerate(keys):
-                    dst[et] = both[:, k * HEADS:(k + 1) * HEADS].contiguous()
+                    dst[et] = slabs[k]
             return a_src, a_dst
 
         def hetero_layer(layer, xs, hop_set, col_key, dst_key, n_out, launches):
