@@ -21,13 +21,18 @@
 //     Host-pinned and HIERARCHY memory do not exist here: every table lives in HBM.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <algorithm>
 
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <rocprim/rocprim.hpp>
+#include <unordered_set>
 #include <vector>
 
 #include "wg_common.hpp"
@@ -38,6 +43,9 @@ struct wholememory_comm_ {
   int rank = 0, size = 1;
   bool intra_node = true;   // every rank runs on this host: peer-mapped memory types are available
   int* h_counts   = nullptr;  // pinned [2 * size]: send / receive counts of an exchange, read back together
+  int distributed_backend = 1;   // WHOLEMEMORY_DB_NCCL (= RCCL here); NVSHMEM is refused
+  std::mutex handles_mu;
+  std::vector<wholememory_handle_*> live_handles;  // creation order; destroy_communicator releases what is left
 };
 
 namespace wgamd {
@@ -93,6 +101,7 @@ rccl_api& rccl()
     if (const char* forced = getenv("WGAMD_RCCL_LIBRARY")) {
       h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
       if (!h) fprintf(stderr, "[wholegraph_amd] WGAMD_RCCL_LIBRARY=%s: %s\n", forced, dlerror());
+      else fprintf(stderr, "[wholegraph_amd] WGAMD_RCCL_LIBRARY is set: collectives go through %s INSTEAD of librccl.so\n", forced);
     } else {
       for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -603,6 +612,12 @@ using namespace wgamd;
 
 static std::atomic<int> g_log_level{3};
 
+// every handle wholememory_malloc has returned and nobody has released yet: wholememory_free of anything else (a handle
+// already released together with its communicator) is refused instead of touching freed memory
+static std::mutex g_handles_mu;
+static std::unordered_set<wholememory_handle_t> g_handles;
+
+
 wholememory_error_code_t wholememory_init(unsigned int /*flags*/, int log_level)
 {
   g_log_level = log_level;
@@ -671,9 +686,24 @@ wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* com
   return WHOLEMEMORY_SUCCESS;
 }
 
+static void release_handle(wholememory_handle_t h, bool collective);
+
 wholememory_error_code_t wholememory_destroy_communicator(wholememory_comm_t comm)
 {
   if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  // handles still alive are released first, oldest first (memory_handle.cpp destroy_all_wholememory): every rank created
+  // them in the same order, so the collective frees of peer-mapped handles pair up; a handle can therefore never outlive
+  // its communicator and dereference a freed one
+  for (;;) {
+    wholememory_handle_t h = nullptr;
+    {
+      std::lock_guard<std::mutex> g(comm->handles_mu);
+      if (!comm->live_handles.empty()) h = comm->live_handles.front();
+    }
+    if (!h) break;
+    fprintf(stderr, "[wholegraph_amd] wholememory_destroy_communicator: releasing a handle that was never freed\n");
+    release_handle(h, /*collective=*/true);
+  }
   if (comm->nccl) rccl().CommDestroy(comm->nccl);
   if (comm->h_counts) (void)hipHostFree(comm->h_counts);
   delete comm;
@@ -846,6 +876,14 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         throw;
       }
     }
+    {
+      std::lock_guard<std::mutex> g(comm->handles_mu);
+      comm->live_handles.push_back(h);
+    }
+    {
+      std::lock_guard<std::mutex> g(g_handles_mu);
+      g_handles.insert(h);
+    }
     *handle_ptr = h;
   });
 }
@@ -857,15 +895,34 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
  * `collective = false` is for the error path of wholememory_malloc, where the other ranks cannot be assumed to follow. */
 static void release_handle(wholememory_handle_t h, bool collective)
 {
+  {
+    std::lock_guard<std::mutex> g(g_handles_mu);
+    g_handles.erase(h);
+  }
+  {
+    std::lock_guard<std::mutex> g(h->comm->handles_mu);
+    auto& v = h->comm->live_handles;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i] == h) {
+        v.erase(v.begin() + (long)i);
+        break;
+      }
+  }
   const bool mapped = !h->peer_ptr.empty();
+  auto meet = [&](const char* when) {
+    auto rc = wholememory_communicator_barrier(h->comm);
+    if (rc != WHOLEMEMORY_SUCCESS)
+      fprintf(stderr, "[wholegraph_amd] wholememory_free: barrier %s failed (%d): a peer may still be using this partition\n",
+              when, (int)rc);
+  };
   if (mapped) {
     (void)hipDeviceSynchronize();
-    if (collective) (void)wholememory_communicator_barrier(h->comm);
+    if (collective) meet("before closing the peer mappings");
   }
   for (size_t r = 0; r < h->peer_ptr.size(); r++)
     if (h->peer_opened[r] && h->peer_ptr[r]) (void)hipIpcCloseMemHandle(h->peer_ptr[r]);
   if (h->d_view) (void)hipFree(h->d_view);
-  if (mapped && collective) (void)wholememory_communicator_barrier(h->comm);
+  if (mapped && collective) meet("before releasing the partition");
   if (h->local_ptr) (void)hipFree(h->local_ptr);
   delete h;
 }
@@ -873,6 +930,13 @@ static void release_handle(wholememory_handle_t h, bool collective)
 wholememory_error_code_t wholememory_free(wholememory_handle_t h)
 {
   if (h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  {
+    std::lock_guard<std::mutex> g(g_handles_mu);
+    if (!g_handles.count(h)) {
+      fprintf(stderr, "[wholegraph_amd] wholememory_free: not a live handle (already released with its communicator?)\n");
+      return WHOLEMEMORY_INVALID_INPUT;
+    }
+  }
   release_handle(h, /*collective=*/true);
   return WHOLEMEMORY_SUCCESS;
 }
@@ -988,7 +1052,7 @@ wholememory_error_code_t wholememory_create_tensor(wholememory_tensor_t* out, wh
   if (rc != WHOLEMEMORY_SUCCESS) return rc;
   rc = wholememory_make_tensor_from_handle(out, h, desc);
   if (rc != WHOLEMEMORY_SUCCESS) {
-    wholememory_free(h);
+    release_handle(h, /*collective=*/false);  // local failure: the peers are not in a matching free
     return rc;
   }
   (*out)->owns_handle = true;
@@ -1018,6 +1082,211 @@ wholememory_error_code_t wholememory_tensor_map_local_tensor(wholememory_tensor_
   wholememory_tensor_description_t d = t->desc;
   d.sizes[0]                         = (int64_t)n;
   return wholememory_make_tensor_from_pointer(local_tensor, t->handle->local_ptr, &d);
+}
+
+
+// ---- the rest of the surface the reference's Cython binding links against (wholememory_binding.pyx:31-262,501-565): on this
+// design — one node-local RCCL communicator per group, no NVSHMEM, no HIERARCHY type — most have one-line answers ------------
+
+wholememory_error_code_t wholememory_get_local_size(size_t* local_size, wholememory_handle_t h)
+{
+  if (!h || !local_size) return WHOLEMEMORY_INVALID_INPUT;
+  *local_size = h->byte_offsets[h->comm->rank + 1] - h->byte_offsets[h->comm->rank];
+  return WHOLEMEMORY_SUCCESS;
+}
+
+wholememory_error_code_t wholememory_get_local_offset(size_t* local_offset, wholememory_handle_t h)
+{
+  if (!h || !local_offset) return WHOLEMEMORY_INVALID_INPUT;
+  *local_offset = h->byte_offsets[h->comm->rank];
+  return WHOLEMEMORY_SUCCESS;
+}
+
+/* memory of rank `rank` as THIS process can address it (memory_handle.cpp:2052-2069): always for the caller's own rank; for
+ * a peer only through a peer-mapped (CHUNKED / CONTINUOUS) handle — a DISTRIBUTED handle has no pointer to a peer's rows. */
+wholememory_error_code_t wholememory_get_rank_memory(void** rank_memory_ptr, size_t* rank_memory_size,
+                                                     size_t* rank_memory_offset, int rank, wholememory_handle_t h)
+{
+  if (!h || !rank_memory_ptr || !rank_memory_size || !rank_memory_offset) return WHOLEMEMORY_INVALID_INPUT;
+  if (rank < 0 || rank >= h->comm->size) return WHOLEMEMORY_INVALID_INPUT;
+  void* p = nullptr;
+  if (rank == h->comm->rank) p = h->local_ptr;
+  else if (!h->peer_ptr.empty()) p = h->peer_ptr[rank];
+  else return WHOLEMEMORY_INVALID_INPUT;
+  *rank_memory_ptr    = p;
+  *rank_memory_offset = h->byte_offsets[rank];
+  *rank_memory_size   = h->byte_offsets[rank + 1] - h->byte_offsets[rank];
+  return WHOLEMEMORY_SUCCESS;
+}
+
+/* one flat pointer over ALL ranks' rows (memory_handle.cpp:2071-2079; the reference maps the partitions back to back in a
+ * reserved virtual range).  Here partitions are mapped one by one (wgamd_get_peer_pointers), so the flat pointer exists
+ * exactly when one rank holds everything; otherwise INVALID_INPUT, the reference's answer for "no continuous mapping". */
+wholememory_error_code_t wholememory_get_global_pointer(void** global_ptr, wholememory_handle_t h)
+{
+  if (!h || !global_ptr) return WHOLEMEMORY_INVALID_INPUT;
+  *global_ptr = nullptr;
+  if (h->type != WHOLEMEMORY_MT_CONTINUOUS && h->type != WHOLEMEMORY_MT_CHUNKED) return WHOLEMEMORY_INVALID_INPUT;
+  const size_t mine = h->byte_offsets[h->comm->rank + 1] - h->byte_offsets[h->comm->rank];
+  if (h->comm->size == 1 || mine == h->total_size) *global_ptr = h->local_ptr;
+  return *global_ptr ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+}
+
+/* HIERARCHY handles only (memory_handle.cpp:1983-2011) — that type does not exist here */
+wholememory_error_code_t wholememory_get_local_communicator(wholememory_comm_t* comm, wholememory_handle_t h)
+{
+  if (!h || !comm) return WHOLEMEMORY_INVALID_INPUT;
+  return WHOLEMEMORY_NOT_SUPPORTED;
+}
+wholememory_error_code_t wholememory_get_cross_communicator(wholememory_comm_t* comm, wholememory_handle_t h)
+{
+  if (!h || !comm) return WHOLEMEMORY_INVALID_INPUT;
+  return WHOLEMEMORY_NOT_SUPPORTED;
+}
+
+wholememory_error_code_t wholememory_communicator_get_local_size(int* local_size, wholememory_comm_t comm)
+{
+  if (!local_size || !comm) return WHOLEMEMORY_INVALID_INPUT;
+  *local_size = comm->intra_node ? comm->size : 1;  // ranks of this communicator on the caller's node
+  return WHOLEMEMORY_SUCCESS;
+}
+
+/* MNNVL cliques (multi-node NVLink domains) have no counterpart on an xGMI node: nobody is in one (communicator.cpp:920-925) */
+wholememory_error_code_t wholememory_communicator_get_clique_info(clique_info_t* clique_info, wholememory_comm_t comm)
+{
+  if (!clique_info || !comm) return WHOLEMEMORY_INVALID_INPUT;
+  clique_info->is_in_clique      = 0;
+  clique_info->clique_first_rank = -1;
+  clique_info->clique_rank       = -1;
+  clique_info->clique_rank_num   = 0;
+  clique_info->clique_id         = -1;
+  clique_info->clique_num        = 0;
+  return WHOLEMEMORY_SUCCESS;
+}
+
+bool wholememory_communicator_is_bind_to_nvshmem(wholememory_comm_t) { return false; }
+
+/* communicator.cpp:1045-1076 — only the collective-library backend (NCCL there, RCCL here) exists */
+wholememory_error_code_t wholememory_communicator_set_distributed_backend(wholememory_comm_t comm,
+                                                                          wholememory_distributed_backend_t backend)
+{
+  if (!comm) return WHOLEMEMORY_INVALID_INPUT;
+  if (backend == WHOLEMEMORY_DB_NCCL) {
+    comm->distributed_backend = (int)backend;
+    return WHOLEMEMORY_SUCCESS;
+  }
+  fprintf(stderr, "[wholegraph_amd] wholememory_communicator_set_distributed_backend: only WHOLEMEMORY_DB_NCCL (RCCL)\n");
+  return backend == WHOLEMEMORY_DB_NVSHMEM ? WHOLEMEMORY_NOT_SUPPORTED : WHOLEMEMORY_INVALID_INPUT;
+}
+wholememory_distributed_backend_t wholememory_communicator_get_distributed_backend(wholememory_comm_t comm)
+{
+  return comm ? (wholememory_distributed_backend_t)comm->distributed_backend : WHOLEMEMORY_DB_NONE;
+}
+wholememory_distributed_backend_t wholememory_get_distributed_backend(wholememory_handle_t h)
+{
+  return h ? (wholememory_distributed_backend_t)h->comm->distributed_backend : WHOLEMEMORY_DB_NONE;
+}
+
+bool wholememory_is_intranode_communicator(wholememory_comm_t comm) { return comm ? comm->intra_node : false; }
+bool wholememory_is_intra_mnnvl_communicator(wholememory_comm_t) { return false; }
+bool wholememory_is_build_with_nvshmem(void) { return false; }
+
+/* Device count asked of a CHILD process, so the caller's process has not initialised the runtime when it forks its workers
+ * afterwards (system_info.cpp ForkGetDeviceCount); -1 on error. */
+int fork_get_device_count(void)
+{
+  int fd[2];
+  if (pipe(fd) != 0) return -1;
+  const pid_t pid = fork();
+  if (pid < 0) {
+    close(fd[0]);
+    close(fd[1]);
+    return -1;
+  }
+  if (pid == 0) {
+    close(fd[0]);
+    int n = -1;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = -1;
+    ssize_t w = write(fd[1], &n, sizeof(n));
+    (void)w;
+    close(fd[1]);
+    _exit(0);
+  }
+  close(fd[1]);
+  int n          = -1;
+  const ssize_t r = read(fd[0], &n, sizeof(n));
+  close(fd[0]);
+  int status = 0;
+  (void)waitpid(pid, &status, 0);
+  return r == (ssize_t)sizeof(n) ? n : -1;
+}
+
+/* communicator.cpp:753-830 (ncclCommSplit there).  Built from calls every RCCL has: the members of the parent trade
+ * (color, key), the member of every colour that comes first in (key, parent rank) order makes a unique id, the ids are traded,
+ * and every colour runs its own ncclCommInitRank.  COLLECTIVE over the parent; color < 0 (WHOLEMEMORY_SPLIT_NOCOLOR) takes
+ * part in the two trades and gets NULL. */
+wholememory_error_code_t wholememory_split_communicator(wholememory_comm_t* new_comm, wholememory_comm_t comm, int color,
+                                                        int key)
+{
+  if (!new_comm || !comm) return WHOLEMEMORY_INVALID_INPUT;
+  *new_comm = nullptr;
+  return guarded("wholememory_split_communicator", [&] {
+    const int W = comm->size;
+    struct ck { int color, key; } mine{color, key};
+    std::vector<char> all;
+    allgather_host(comm, &mine, sizeof(mine), all);
+    std::vector<ck> v(W);
+    memcpy(v.data(), all.data(), sizeof(ck) * (size_t)W);
+    // my group in (key, parent rank) order
+    std::vector<int> members;
+    if (color >= 0) {
+      for (int r = 0; r < W; r++)
+        if (v[r].color == color) members.push_back(r);
+      std::stable_sort(members.begin(), members.end(), [&](int a, int b) { return v[a].key < v[b].key; });
+    }
+    const bool leader = color >= 0 && members[0] == comm->rank;
+    wholememory_unique_id_t uid;
+    memset(&uid, 0, sizeof(uid));
+    if (leader && wholememory_create_unique_id(&uid) != WHOLEMEMORY_SUCCESS) throw comm_error("unique id for the split");
+    std::vector<char> ids;
+    allgather_host(comm, &uid, sizeof(uid), ids);
+    if (color < 0) return;
+    memcpy(&uid, ids.data() + (size_t)members[0] * sizeof(uid), sizeof(uid));
+    int new_rank = 0;
+    while (members[new_rank] != comm->rank) new_rank++;
+    auto rc = wholememory_create_communicator(new_comm, uid, new_rank, (int)members.size());
+    if (rc != WHOLEMEMORY_SUCCESS) throw comm_error("communicator of the split");
+  });
+}
+
+/* wholememory_tensor.cpp:285-346 — partition of a tensor's dim 0 over the ranks, in ENTRIES (rows); a tensor over plain
+ * memory is one partition */
+wholememory_error_code_t wholememory_tensor_get_entry_offsets(size_t* entry_offsets, wholememory_tensor_t t)
+{
+  if (!entry_offsets || !t) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_tensor_t root = wholememory_tensor_get_root(t);
+  if (root->desc.dim != 1 && root->desc.dim != 2) return WHOLEMEMORY_INVALID_VALUE;
+  if (!root->handle) {
+    entry_offsets[0] = 0;
+    entry_offsets[1] = (size_t)root->desc.sizes[0];
+    return WHOLEMEMORY_SUCCESS;
+  }
+  auto* h = root->handle;
+  for (int r = 0; r <= h->comm->size; r++) entry_offsets[r] = h->byte_offsets[r] / h->granularity;
+  return WHOLEMEMORY_SUCCESS;
+}
+wholememory_error_code_t wholememory_tensor_get_entry_partition_sizes(size_t* entry_partition, wholememory_tensor_t t)
+{
+  if (!entry_partition || !t) return WHOLEMEMORY_INVALID_INPUT;
+  wholememory_tensor_t root = wholememory_tensor_get_root(t);
+  if (root->desc.dim != 1 && root->desc.dim != 2) return WHOLEMEMORY_INVALID_VALUE;
+  if (!root->handle) {
+    entry_partition[0] = (size_t)root->desc.sizes[0];
+    return WHOLEMEMORY_SUCCESS;
+  }
+  auto* h = root->handle;
+  for (int r = 0; r < h->comm->size; r++) entry_partition[r] = (h->byte_offsets[r + 1] - h->byte_offsets[r]) / h->granularity;
+  return WHOLEMEMORY_SUCCESS;
 }
 
 }  // extern "C"

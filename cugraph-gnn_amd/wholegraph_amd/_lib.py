@@ -84,6 +84,12 @@ class UniqueId(Structure):
     _fields_ = [("internal", ctypes.c_char * 128)]
 
 
+class CliqueInfo(Structure):
+    """clique_info_t (include/wgamd_comm.h; wholememory.h:106-113)."""
+    _fields_ = [(n, c_int) for n in ("is_in_clique", "clique_first_rank", "clique_rank", "clique_rank_num", "clique_id",
+                                     "clique_num")]
+
+
 # wholememory_memory_type_t / wholememory_memory_location_t
 MT_NONE, MT_CONTINUOUS, MT_CHUNKED, MT_DISTRIBUTED, MT_HIERARCHY = range(5)
 ML_NONE, ML_DEVICE, ML_HOST = range(3)
@@ -137,6 +143,7 @@ SYMBOLS = {
     "csr_add_self_loop": (c_int, [_T, _T, _T, _T, c_void_p]),
     "wholememory_gather": (c_int, [_T, _T, _T, POINTER(EnvFns), c_void_p, c_int]),
     "wholememory_scatter": (c_int, [_T, _T, _T, POINTER(EnvFns), c_void_p, c_int]),
+    "wholememory_env_test_op": (c_int, [_T, _T, c_void_p, c_void_p, c_void_p, c_int64, POINTER(EnvFns), c_void_p]),
     # wgamd_comm.h
     "wholememory_init": (c_int, [ctypes.c_uint, c_int]),
     "wholememory_finalize": (c_int, []),
@@ -172,6 +179,25 @@ SYMBOLS = {
     "wholememory_load_from_file": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, POINTER(ctypes.c_char_p), c_int,
                                            c_int]),
     "wholememory_store_to_file": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, ctypes.c_char_p]),
+    "wholememory_split_communicator": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "wholememory_communicator_get_local_size": (c_int, [POINTER(c_int), c_void_p]),
+    "wholememory_communicator_get_clique_info": (c_int, [POINTER(CliqueInfo), c_void_p]),
+    "wholememory_communicator_is_bind_to_nvshmem": (c_bool, [c_void_p]),
+    "wholememory_communicator_set_distributed_backend": (c_int, [c_void_p, c_int]),
+    "wholememory_communicator_get_distributed_backend": (c_int, [c_void_p]),
+    "wholememory_is_intranode_communicator": (c_bool, [c_void_p]),
+    "wholememory_is_intra_mnnvl_communicator": (c_bool, [c_void_p]),
+    "wholememory_is_build_with_nvshmem": (c_bool, []),
+    "fork_get_device_count": (c_int, []),
+    "wholememory_get_local_communicator": (c_int, [POINTER(c_void_p), c_void_p]),
+    "wholememory_get_cross_communicator": (c_int, [POINTER(c_void_p), c_void_p]),
+    "wholememory_get_distributed_backend": (c_int, [c_void_p]),
+    "wholememory_get_local_size": (c_int, [POINTER(c_size_t), c_void_p]),
+    "wholememory_get_local_offset": (c_int, [POINTER(c_size_t), c_void_p]),
+    "wholememory_get_rank_memory": (c_int, [POINTER(c_void_p), POINTER(c_size_t), POINTER(c_size_t), c_int, c_void_p]),
+    "wholememory_get_global_pointer": (c_int, [POINTER(c_void_p), c_void_p]),
+    "wholememory_tensor_get_entry_offsets": (c_int, [POINTER(c_size_t), _T]),
+    "wholememory_tensor_get_entry_partition_sizes": (c_int, [POINTER(c_size_t), _T]),
     # wgamd_embedding.h
     "wholememory_create_embedding_optimizer": (c_int, [POINTER(c_void_p), c_int]),
     "wholememory_optimizer_set_parameter": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),

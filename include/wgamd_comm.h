@@ -56,12 +56,47 @@ wholememory_error_code_t wholememory_create_communicator(wholememory_comm_t* com
                                                          int rank,
                                                          int size);
 wholememory_error_code_t wholememory_destroy_communicator(wholememory_comm_t comm);
+/* wholememory.h:136-163 — COLLECTIVE over `comm`: ranks passing the same color >= 0 form one new communicator, ordered by
+ * (key, rank in comm); color < 0 (WHOLEMEMORY_SPLIT_NOCOLOR) takes part and receives NULL.  Built from ncclGetUniqueId +
+ * ncclCommInitRank per colour (the reference calls ncclCommSplit, communicator.cpp:753-830). */
+#define WHOLEMEMORY_SPLIT_NOCOLOR (-1)
+wholememory_error_code_t wholememory_split_communicator(wholememory_comm_t* new_comm,
+                                                        wholememory_comm_t comm,
+                                                        int color,
+                                                        int key);
 /* wholememory.h:160-205 */
 wholememory_error_code_t wholememory_communicator_support_type_location(
   wholememory_comm_t comm, wholememory_memory_type_t memory_type, wholememory_memory_location_t memory_location);
 wholememory_error_code_t wholememory_communicator_get_rank(int* rank, wholememory_comm_t comm);
 wholememory_error_code_t wholememory_communicator_get_size(int* size, wholememory_comm_t comm);
 wholememory_error_code_t wholememory_communicator_barrier(wholememory_comm_t comm);
+/* wholememory.h:199-225.  Single node, RCCL only: local size = size (1 when the ranks span hosts), nobody is in an MNNVL
+ * clique, the only backend is WHOLEMEMORY_DB_NCCL (= RCCL; NVSHMEM -> NOT_SUPPORTED). */
+typedef enum wholememory_distributed_backend_t {
+  WHOLEMEMORY_DB_NONE = 0,
+  WHOLEMEMORY_DB_NCCL,
+  WHOLEMEMORY_DB_NVSHMEM
+} wholememory_distributed_backend_t;
+typedef struct clique_info_t {
+  int is_in_clique;
+  int clique_first_rank;
+  int clique_rank;
+  int clique_rank_num;
+  int clique_id;
+  int clique_num;
+} clique_info_t;
+wholememory_error_code_t wholememory_communicator_get_local_size(int* local_size, wholememory_comm_t comm);
+wholememory_error_code_t wholememory_communicator_get_clique_info(clique_info_t* clique_info, wholememory_comm_t comm);
+bool wholememory_communicator_is_bind_to_nvshmem(wholememory_comm_t comm);
+wholememory_error_code_t wholememory_communicator_set_distributed_backend(
+  wholememory_comm_t comm, wholememory_distributed_backend_t distributed_backend);
+wholememory_distributed_backend_t wholememory_communicator_get_distributed_backend(wholememory_comm_t comm);
+/* wholememory.h:467-470 */
+bool wholememory_is_intranode_communicator(wholememory_comm_t comm);
+bool wholememory_is_intra_mnnvl_communicator(wholememory_comm_t comm);
+bool wholememory_is_build_with_nvshmem(void);
+/* wholememory.h:426 — device count asked of a forked child, so the caller can still fork its workers; -1 on error */
+int fork_get_device_count(void);
 /* (no reference counterpart) what RCCL itself reports for the communicator: ncclCommCount and ncclGetVersion (-1 where the
  * loaded library lacks the symbol) — evidence in bench.py's line that the exchange ran over RCCL with that many ranks */
 wholememory_error_code_t wgamd_communicator_rccl_info(wholememory_comm_t comm, int* rccl_ranks, int* rccl_version);
@@ -94,6 +129,22 @@ wholememory_error_code_t wholememory_get_local_memory(void** local_ptr,
                                                       size_t* local_size,
                                                       size_t* local_offset,
                                                       wholememory_handle_t wholememory_handle);
+/* wholememory.h:281-309,346-392.  local/cross communicators exist for HIERARCHY handles only (-> NOT_SUPPORTED);
+ * get_rank_memory answers for the caller's own rank and, on a peer-mapped handle, for every rank; the flat global pointer
+ * exists when one rank holds all rows (partitions are mapped one by one here: wgamd_get_peer_pointers), else INVALID_INPUT. */
+wholememory_error_code_t wholememory_get_local_communicator(wholememory_comm_t* comm,
+                                                            wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_cross_communicator(wholememory_comm_t* comm,
+                                                            wholememory_handle_t wholememory_handle);
+wholememory_distributed_backend_t wholememory_get_distributed_backend(wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_local_size(size_t* local_size, wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_local_offset(size_t* local_offset, wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_rank_memory(void** rank_memory_ptr,
+                                                     size_t* rank_memory_size,
+                                                     size_t* rank_memory_offset,
+                                                     int rank,
+                                                     wholememory_handle_t wholememory_handle);
+wholememory_error_code_t wholememory_get_global_pointer(void** global_ptr, wholememory_handle_t wholememory_handle);
 /* wholememory.h:380-420 — equal split: per = ceil(total / world); rank r owns [min(r*per,total), min((r+1)*per,total)) */
 wholememory_error_code_t wholememory_equal_entry_partition_plan(size_t* entry_per_rank,
                                                                 size_t total_entry_count,
@@ -114,6 +165,12 @@ wholememory_error_code_t wholememory_make_tensor_from_handle(
   wholememory_tensor_t* wholememory_tensor,
   wholememory_handle_t wholememory_handle,
   wholememory_tensor_description_t* tensor_description);
+/* wholememory_tensor.h:124-140 — partition of dim 0 over the ranks in entries: offsets has world_size + 1 values, sizes
+ * world_size; a tensor over plain memory is one partition ({0, n} / {n}) */
+wholememory_error_code_t wholememory_tensor_get_entry_offsets(size_t* entry_offsets,
+                                                              wholememory_tensor_t wholememory_tensor);
+wholememory_error_code_t wholememory_tensor_get_entry_partition_sizes(size_t* entry_partition,
+                                                                      wholememory_tensor_t wholememory_tensor);
 /* wholememory_tensor.h:132-160 */
 wholememory_error_code_t wholememory_tensor_get_local_entry_count(size_t* local_entry_count,
                                                                   wholememory_tensor_t wholememory_tensor);

@@ -125,6 +125,19 @@ wholememory_error_code_t wholememory_scatter(wholememory_tensor_t input_tensor,
                                              void* stream,
                                              int scatter_sms WGAMD_DEFAULT(-1));
 
+/* Replaces wholememory_env_test_op (wholememory_op.h:61-68; cpp/src/wholememory_ops/wholememory_test_op.cu:53-140): the
+ * self-test a binding runs on its allocator callbacks.  out[i, j] = (T)(float)i + input[j] for i < entry_count is computed
+ * into scratch from temporary_fns, copied into output_fixed_tensor ([entry_count, dim], caller-allocated) and into one
+ * output allocated through output_fns for every non-NULL context: DEVICE, PINNED and HOST allocation types. */
+wholememory_error_code_t wholememory_env_test_op(wholememory_tensor_t input_tensor,
+                                                 wholememory_tensor_t output_fixed_tensor,
+                                                 void* output_variable_device_tensor_handle,
+                                                 void* output_variable_pinned_tensor_handle,
+                                                 void* output_variable_host_tensor_handle,
+                                                 int64_t output_variable_entry_count,
+                                                 wholememory_env_func_t* p_env_fns,
+                                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

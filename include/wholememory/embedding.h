@@ -1,0 +1,2 @@
+/* forwarding header: lets a binding written against libwholegraph (#include <wholememory/embedding.h>) compile against libwholegraph_amd */
+#include "../wholegraph_amd.h"

@@ -144,3 +144,54 @@ def test_equal_entry_partition_plan_matches_python_mirror():
         assert offs[-1] == total and all(b - a <= per.value for a, b in zip(offs, offs[1:]))
     assert lib.wholememory_equal_entry_partition_plan(None, 10, 2) != 0
     assert lib.wholememory_equal_entry_partition_plan(ctypes.byref(per), 10, 0) != 0
+
+
+def _binding_symbols():
+    path = os.path.join(ROOT, "tests", "golden", "reference_binding_symbols.txt")
+    return [l.strip() for l in open(path) if l.strip() and not l.startswith("#")]
+
+
+def test_every_symbol_the_reference_binding_links_is_exported(hiplib):
+    """INTEGRATION.md §1's claim, held: the C functions the reference's Cython binding declares
+    (python/pylibwholegraph/pylibwholegraph/binding/wholememory_binding.pyx, `cdef extern from "wholememory/*.h"` blocks;
+    listed by tests/golden/make_binding_symbols.py) are all dynamic symbols of libwholegraph_amd.so — the module would load."""
+    from wholegraph_amd import _lib
+    wanted = _binding_symbols()
+    assert len(wanted) >= 70
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [n for n in wanted if n not in exported]
+    assert not missing, f"the reference binding needs these, libwholegraph_amd.so does not export them: {missing}"
+
+
+def test_binding_symbols_link_from_plain_c(hiplib, tmp_path):
+    """A gcc-compiled C file that takes the address of every one of those functions — through the reference's own include
+    paths (<wholememory/...>, the forwarding headers) — links against the library with no unresolved symbol."""
+    from wholegraph_amd import _lib
+    wanted = _binding_symbols()
+    src = ['#include <wholememory/wholememory.h>', '#include <wholememory/tensor_description.h>',
+           '#include <wholememory/env_func_ptrs.h>', '#include <wholememory/wholememory_tensor.h>',
+           '#include <wholememory/embedding.h>', '#include <wholememory/wholememory_op.h>',
+           '#include <wholememory/wholegraph_op.h>', '#include <wholememory/graph_op.h>',
+           'typedef void (*fn_t)(void);', 'static fn_t table[] = {']
+    src += [f"  (fn_t){n}," for n in wanted]
+    src += ['};', 'int main(void) { return table[0] == 0; }', '']
+    c = tmp_path / "link_all.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "link_all"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-Wno-cast-function-type", "-I", INC, str(c), "-o", str(exe),
+                           "-L", libdir, "-lwholegraph_amd", "-Wl,--no-undefined", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+
+
+def test_host_only_answers_of_the_binding_surface(hiplib):
+    """The entry points with a fixed answer on this design (no NVSHMEM, no MNNVL) — callable without a GPU."""
+    assert hiplib.wholememory_is_build_with_nvshmem() is False
+    assert hiplib.wholememory_is_intra_mnnvl_communicator(None) is False
+    assert hiplib.wholememory_is_intranode_communicator(None) is False
+    assert hiplib.wholememory_communicator_get_distributed_backend(None) == 0      # WHOLEMEMORY_DB_NONE
+    assert hiplib.wholememory_get_local_size(None, None) != 0
+    assert hiplib.wholememory_get_global_pointer(None, None) != 0
+    assert hiplib.wholememory_split_communicator(None, None, 0, 0) != 0
+    assert hiplib.fork_get_device_count() in (-1, 0) or hiplib.fork_get_device_count() > 0

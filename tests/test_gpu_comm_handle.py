@@ -158,3 +158,32 @@ def test_handle_file_roundtrip(comm, tmp_path, dtype, dim):
     finally:
         wg.destroy_wholememory_tensor(t)
         wg.destroy_wholememory_tensor(t2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.int32, torch.int64,
+                                   torch.int16, torch.int8])
+@pytest.mark.parametrize("entries,dim", [(13, 7), (0, 5), (1000, 128)])
+def test_env_test_op_exercises_every_allocation_type(dtype, entries, dim):
+    """wholememory_env_test_op (wholememory_op.h:61-68, wholememory_test_op.cu:53-140): out[i, j] = (T)(float)i + input[j]
+    through temporary memory into the fixed output and one output per allocation type (device / pinned / host) — the
+    self-test `wholememory_env_test_cython_op` of the reference binding runs on its allocator callbacks."""
+    import wholegraph_amd as wg
+    from wholegraph_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(entries + dim)
+    inp = (torch.randint(-5, 5, (dim,), generator=g).to(dtype) if not dtype.is_floating_point
+           else torch.randn(dim, generator=g).to(dtype)).cuda()
+    fixed = torch.zeros(entries, dim + 3, dtype=dtype, device="cuda")[:, :dim]      # strided rows
+    ctxs = [wg.env.TorchMemoryContext() for _ in range(3)]
+    w_i, w_f = wg.env.wrap_torch_tensor(inp), wg.env.wrap_torch_tensor(fixed)
+    L.check(lib.wholememory_env_test_op(w_i.c, w_f.c, *[c.get_c_context() for c in ctxs], entries,
+                                        wg.env.get_wholegraph_env_fns(), wg.env.get_stream()), "env_test_op")
+    tag = torch.arange(entries, dtype=torch.float32).to(dtype)[:, None]
+    want = (tag + inp.cpu()[None, :]).to(dtype)
+    assert torch.equal(fixed.cpu(), want)
+    kinds = ["cuda", "cpu", "cpu"]
+    for c, kind in zip(ctxs, kinds):
+        t = c.get_tensor()
+        assert t is not None and tuple(t.shape) == (entries, dim) and t.dtype == dtype and t.device.type == kind
+        assert torch.equal(t.cpu(), want)
+    assert ctxs[1].get_tensor().is_pinned() or entries == 0

@@ -69,6 +69,67 @@ WORKER = textwrap.dedent(r"""
                 for q in range(W):
                     assert (ptrs[q] is not None) == (offs[q + 1] > offs[q]), (q, ptrs[q])
                 assert (ptrs[r] or 0) == (local.data_ptr() if local.numel() else 0)
+            # the handle / tensor queries the reference's Cython binding makes (wholememory_binding.pyx:31-262,501-565)
+            handle = ctypes.c_void_p(lib.wholememory_tensor_get_memory_handle(t.c))
+            eo, ep = (ctypes.c_size_t * (W + 1))(), (ctypes.c_size_t * W)()
+            L.check(lib.wholememory_tensor_get_entry_offsets(eo, t.c), "entry_offsets")
+            L.check(lib.wholememory_tensor_get_entry_partition_sizes(ep, t.c), "entry_partition_sizes")
+            assert list(eo) == [int(v) for v in offs] and list(ep) == [int(b - a) for a, b in zip(offs, offs[1:])]
+            ls, lo = ctypes.c_size_t(), ctypes.c_size_t()
+            L.check(lib.wholememory_get_local_size(ctypes.byref(ls), handle), "local_size")
+            L.check(lib.wholememory_get_local_offset(ctypes.byref(lo), handle), "local_offset")
+            row_b = dim * 2
+            assert ls.value == (offs[r + 1] - offs[r]) * row_b and lo.value == offs[r] * row_b
+            for q in range(W):
+                pq, sq, oq = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+                rc = lib.wholememory_get_rank_memory(ctypes.byref(pq), ctypes.byref(sq), ctypes.byref(oq), q, handle)
+                if q == r or mtype != "distributed":
+                    assert rc == 0 and sq.value == (offs[q + 1] - offs[q]) * row_b and oq.value == offs[q] * row_b
+                    if q == r:
+                        assert (pq.value or 0) == (local.data_ptr() if local.numel() else 0)
+                else:
+                    assert rc == L.WHOLEMEMORY_INVALID_INPUT      # a DISTRIBUTED handle cannot address a peer's rows
+            assert lib.wholememory_get_rank_memory(ctypes.byref(pq), ctypes.byref(sq), ctypes.byref(oq), W, handle) != 0
+            gp = ctypes.c_void_p()
+            assert lib.wholememory_get_global_pointer(ctypes.byref(gp), handle) == L.WHOLEMEMORY_INVALID_INPUT or W == 1 \
+                or (offs[r + 1] - offs[r]) == rows
+            sub_c = ctypes.c_void_p()
+            assert lib.wholememory_get_local_communicator(ctypes.byref(sub_c), handle) == L.WHOLEMEMORY_NOT_SUPPORTED
+            assert lib.wholememory_get_cross_communicator(ctypes.byref(sub_c), handle) == L.WHOLEMEMORY_NOT_SUPPORTED
+            assert lib.wholememory_is_intranode_communicator(c) and not lib.wholememory_is_intra_mnnvl_communicator(c)
+            assert lib.wholememory_communicator_get_distributed_backend(c) == 1
+            assert lib.wholememory_communicator_set_distributed_backend(c, 2) == L.WHOLEMEMORY_NOT_SUPPORTED
+            assert lib.wholememory_communicator_set_distributed_backend(c, 1) == 0
+            ci = L.CliqueInfo()
+            L.check(lib.wholememory_communicator_get_clique_info(ctypes.byref(ci), c), "clique_info")
+            assert ci.is_in_clique == 0 and ci.clique_num == 0
+            # split (collective): even / odd ranks, ordered by DESCENDING parent rank (key = -r); the last rank of an odd
+            # world sits out (WHOLEMEMORY_SPLIT_NOCOLOR) and gets NULL
+            sits_out = W % 2 == 1 and r == W - 1 and W > 1
+            color = -1 if sits_out else r % 2
+            L.check(lib.wholememory_split_communicator(ctypes.byref(sub_c), c, color, -r), "split")
+            if sits_out:
+                assert not sub_c.value
+            else:
+                group = [q for q in range(W) if q % 2 == color and not (W % 2 == 1 and q == W - 1 and W > 1)][::-1]
+                sr, ss = ctypes.c_int(), ctypes.c_int()
+                L.check(lib.wholememory_communicator_get_rank(ctypes.byref(sr), sub_c), "rank")
+                L.check(lib.wholememory_communicator_get_size(ctypes.byref(ss), sub_c), "size")
+                assert ss.value == len(group) and group[sr.value] == r, (r, group, sr.value, ss.value)
+                # the new communicator carries a table of its own: partitioned over the group only
+                ts = wg.create_wholememory_tensor(WholeMemoryCommunicator(sub_c.value), "distributed", "cuda",
+                                                  [64, 4], torch.float32, [4, 1])
+                lt, st = ts.get_local_tensor()
+                per = -(-64 // len(group))
+                assert st == min(64, per * sr.value) and lt.shape[0] == min(64, per * (sr.value + 1)) - st
+                lt.copy_(torch.arange(st, st + lt.shape[0], device="cuda", dtype=torch.float32)[:, None].expand(-1, 4))
+                L.check(lib.wholememory_communicator_barrier(sub_c), "sub barrier")
+                got = ts.gather(torch.arange(63, -1, -1, device="cuda"))
+                assert torch.equal(got[:, 0].cpu(), torch.arange(63, -1, -1, dtype=torch.float32)), "gather over the split"
+                L.check(lib.wholememory_communicator_barrier(sub_c), "sub barrier")
+                wg.destroy_wholememory_tensor(ts)
+                L.check(lib.wholememory_destroy_communicator(sub_c), "destroy sub")
+            comm.barrier()
             # gather with duplicates, negatives, fp16 -> fp32 conversion, a different count on every rank
             k = n + 37 * r if n else (0 if r % 2 == 0 else 5)
             idx = np.random.default_rng(100 + r).integers(0, rows, k)
