@@ -199,34 +199,34 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Compute units a launch on `stream` can occupy: the popcount of the stream's CU mask (hipExtStreamCreateWithCUMask:
 // a caller may give the walk and the forward pass disjoint slices of the chip), else the device's CU count.  Kernels that
 // run ONE persistent workgroup per CU size their grid from this, so a masked stream never queues a second round of
-// workgroups behind the first.  Cached per stream handle (the query is a runtime call).
+// workgroups behind the first.  The device's CU count is cached per device; a non-null stream's mask is asked for on
+// every call (a stream handle can be recycled by the runtime for a stream with another mask, so it is no cache key).
 inline int stream_cu_count(hipStream_t stream)
 {
   static std::mutex m;
-  static std::unordered_map<void*, int> cache;
+  static std::unordered_map<int, int> device_cus;
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
   {
     std::lock_guard<std::mutex> g(m);
-    auto it = cache.find(static_cast<void*>(stream));
-    if (it != cache.end()) return it->second;
+    auto it = device_cus.find(dev);
+    if (it != device_cus.end()) cus = it->second;
   }
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int n = cus;
-  if (stream != nullptr) {
-    uint32_t mask[32] = {0};
-    if (hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
-      int bits = 0;
-      for (uint32_t w : mask) bits += __builtin_popcount(w);
-      if (bits > 0 && bits < cus) n = bits;
-    } else {
-      (void)hipGetLastError();
-    }
+  if (cus == 0) {
+    cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    std::lock_guard<std::mutex> g(m);
+    device_cus[dev] = cus;
   }
-  std::lock_guard<std::mutex> g(m);
-  if (cache.size() > 256) cache.clear();   // stream handles can be recycled by the runtime: keep the table small
-  cache[static_cast<void*>(stream)] = n;
-  return n;
+  if (stream == nullptr) return cus;
+  uint32_t mask[32] = {0};
+  if (hipExtStreamGetCUMask(stream, 32, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return cus;
+  }
+  int bits = 0;
+  for (uint32_t w : mask) bits += __builtin_popcount(w);
+  return (bits > 0 && bits < cus) ? bits : cus;
 }
 
 // A size that lives either on the host (ABI ops: the value is known) or on the device (no-sync

@@ -101,7 +101,11 @@ struct gat_long_row {
   int row, base, pieces;
 };
 
-__global__ void __launch_bounds__(256) gat_plan_kernel(const int* __restrict__ row_ptr_t, int64_t n_src, int seg,
+// counters: [0] extra slots handed out, [1] long rows, [2] OVERFLOW flag — a long row whose pieces did not fit the `cap` slots
+// of the workspace gets none (its gradient then misses the entries past its first piece) and raises the flag instead of
+// writing past the buffers; with a workspace sized by wgamd_gat_csr_bwd_workspace_bytes(row_ptr_t[n_src], H, C) it cannot
+// happen (at most E / 64 further pieces exist).
+__global__ void __launch_bounds__(256) gat_plan_kernel(const int* __restrict__ row_ptr_t, int64_t n_src, int seg, int cap,
                                                        int* __restrict__ counters, int* __restrict__ extra_start,
                                                        int* __restrict__ extra_end, gat_long_row* __restrict__ long_rows)
 {
@@ -111,6 +115,11 @@ __global__ void __launch_bounds__(256) gat_plan_kernel(const int* __restrict__ r
   if (e - s <= seg) return;
   const int pieces = (e - s + seg - 1) / seg - 1;
   const int base   = atomicAdd(counters, pieces);
+  if (base + pieces > cap) {
+    atomicSub(counters, pieces);   // hand the slots back: later rows may still fit, and the count stays <= cap
+    counters[2] = 1;
+    return;
+  }
   long_rows[atomicAdd(counters + 1, 1)] = gat_long_row{(int)r, base, pieces};
   for (int j = 0; j < pieces; j++) {
     extra_start[base + j] = s + (j + 1) * seg;
@@ -223,16 +232,23 @@ extern "C" size_t wgamd_gat_csr_bwd_workspace_bytes(int64_t n_entries, int H, in
   return 1024 + cap * (per_extra + 16);
 }
 
-extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                          int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
-                                                          float negative_slope, const float* alpha, const float* grad_out,
-                                                          int64_t ldg, const int* row_ptr_t, const int* edge_perm,
-                                                          const int* edge_dst, int64_t n_src, float* de, float* grad_x,
-                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, int64_t n_entries,
-                                                          void* workspace, size_t workspace_bytes, void* stream)
+namespace wgamd {
+namespace {
+// piece slots a workspace of `bytes` holds (the inverse of wgamd_gat_csr_bwd_workspace_bytes)
+size_t gat_bwd_slots(size_t bytes, int H, int C)
 {
-  using namespace wgamd;
-  return guarded("wgamd_gat_csr_bwd_f32", [&] {
+  const size_t per_extra = 2 * sizeof(int) + sizeof(gat_long_row) + (size_t)H * C * sizeof(float) + (size_t)H * sizeof(float) + 16;
+  return bytes > 1024 + per_extra ? (bytes - 1024) / per_extra : 0;
+}
+
+// n_entries < 0: the capacity comes from the workspace size alone (the entry point without n_entries)
+wholememory_error_code_t gat_csr_bwd(const char* op, const int* row_ptr, const int* col, int64_t n_rows, const float* x, int64_t ldx,
+                                     const float* a_src, const float* a_dst, int H, int C, float negative_slope, const float* alpha,
+                                     const float* grad_out, int64_t ldg, const int* row_ptr_t, const int* edge_perm,
+                                     const int* edge_dst, int64_t n_src, float* de, float* grad_x, int64_t ldgx, float* grad_a_src,
+                                     float* grad_a_dst, int64_t n_entries, void* workspace, size_t workspace_bytes, void* stream)
+{
+  return guarded(op, [&] {
     WG_REQUIRE_INPUT(n_rows >= 0 && n_src >= 0 && H > 0 && C > 0, "bad sizes");
     const int HC = H * C, LH = C / 4;
     if (C % 4 != 0 || (LH & (LH - 1)) != 0 || HC > 256 || ldx % 4 != 0 || ldg % 4 != 0 || ldgx % 4 != 0)
@@ -255,10 +271,11 @@ extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, co
     } else if (n_src > 0) {
       // every further piece of a long row needs a slot: at most n_entries / kSegEntries of them, which is what the
       // workspace must hold — the plan kernel hands slots out with atomics and has no other bound
-      WG_REQUIRE_INPUT(n_entries >= 0, "n_entries < 0");
-      WG_REQUIRE_INPUT(workspace_bytes >= wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C),
-                       "workspace smaller than wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C)");
-      const size_t cap = (size_t)(n_entries / kSegEntries) + 1;
+      if (n_entries >= 0)
+        WG_REQUIRE_INPUT(workspace_bytes >= wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C),
+                         "workspace smaller than wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C)");
+      const size_t cap = n_entries >= 0 ? (size_t)(n_entries / kSegEntries) + 1 : gat_bwd_slots(workspace_bytes, H, C);
+      WG_REQUIRE_INPUT(cap >= 1 && cap < ((size_t)1 << 31), "workspace too small for a single piece slot");
       char* ws         = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
       auto carve       = [&](size_t bytes) {
         char* at = ws;
@@ -271,9 +288,9 @@ extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, co
       auto* long_rows  = reinterpret_cast<gat_long_row*>(carve(cap * sizeof(gat_long_row)));
       float* pgx       = reinterpret_cast<float*>(carve(cap * (size_t)HC * sizeof(float)));
       float* pgas      = reinterpret_cast<float*>(carve(cap * (size_t)H * sizeof(float)));
-      WG_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
-      gat_plan_kernel<<<(int)((n_src + 255) / 256), 256, 0, st>>>(row_ptr_t, n_src, kSegEntries, counters, extra_start, extra_end,
-                                                                   long_rows);
+      WG_HIP_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+      gat_plan_kernel<<<(int)((n_src + 255) / 256), 256, 0, st>>>(row_ptr_t, n_src, kSegEntries, (int)cap, counters, extra_start,
+                                                                   extra_end, long_rows);
       const int64_t n_all = n_src + (int64_t)cap;
       const int grid      = (int)std::min<int64_t>((n_all + gpb - 1) / gpb, 256 * 16);
       gat_segments sg{kSegEntries, n_src, extra_start, extra_end, counters, pgx, HC, pgas};
@@ -284,4 +301,35 @@ extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, co
     }
     WG_HIP_CHECK(hipGetLastError());
   });
+}
+}  // namespace
+}  // namespace wgamd
+
+/* the entry point of rounds 1-2 (no n_entries): the piece capacity is whatever the workspace holds */
+extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                          int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
+                                                          float negative_slope, const float* alpha, const float* grad_out,
+                                                          int64_t ldg, const int* row_ptr_t, const int* edge_perm,
+                                                          const int* edge_dst, int64_t n_src, float* de, float* grad_x,
+                                                          int64_t ldgx, float* grad_a_src, float* grad_a_dst, void* workspace,
+                                                          size_t workspace_bytes, void* stream)
+{
+  return wgamd::gat_csr_bwd("wgamd_gat_csr_bwd_f32", row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, alpha,
+                            grad_out, ldg, row_ptr_t, edge_perm, edge_dst, n_src, de, grad_x, ldgx, grad_a_src, grad_a_dst,
+                            /*n_entries=*/-1, workspace, workspace_bytes, stream);
+}
+
+extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32_v2(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                             int64_t ldx, const float* a_src, const float* a_dst, int H, int C,
+                                                             float negative_slope, const float* alpha, const float* grad_out,
+                                                             int64_t ldg, const int* row_ptr_t, const int* edge_perm,
+                                                             const int* edge_dst, int64_t n_src, float* de, float* grad_x,
+                                                             int64_t ldgx, float* grad_a_src, float* grad_a_dst,
+                                                             int64_t n_entries, void* workspace, size_t workspace_bytes,
+                                                             void* stream)
+{
+  if (n_entries < 0) return WHOLEMEMORY_INVALID_INPUT;
+  return wgamd::gat_csr_bwd("wgamd_gat_csr_bwd_f32_v2", row_ptr, col, n_rows, x, ldx, a_src, a_dst, H, C, negative_slope, alpha,
+                            grad_out, ldg, row_ptr_t, edge_perm, edge_dst, n_src, de, grad_x, ldgx, grad_a_src, grad_a_dst,
+                            n_entries, workspace, workspace_bytes, stream);
 }

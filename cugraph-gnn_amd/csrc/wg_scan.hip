@@ -6,7 +6,10 @@
 //                      ~3000 tiles of a hop-2 scan all run at once, so hardly any tile finds a finished prefix nearby and the
 //                      look-back walks back 64 agent-scope words at a time (each a trip beyond the XCD's L2): 40 us per scan
 //                      against 14 us for the two launches, walk 0.51 -> 0.62 ms per call group, -5 % end to end
-//                      (A/B on one box).  Kept as a switch; the tests run both.
+//                      (A/B on one box).  Kept as an OPT-IN switch; the tests run both.  NOT graph-capture
+//                      safe (first use allocates, and the epoch travels as a kernel argument, so a replayed graph would
+//                      reuse an epoch): a capturing stream always takes the two-launch path.  State: one 8 MiB buffer per
+//                      (device, stream), at most kChainStates of them alive — older ones are freed (hipFree synchronises).
 // Used for sample offsets (role of thrust::exclusive_scan in
 // /root/reference/cpp/src/wholegraph_ops/unweighted_sample_without_replacement_func.cuh:323-326)
 // and for the first-appearance ranks of append_unique.
@@ -26,10 +29,19 @@ scan_chain scan_chain_acquire(hipStream_t stream)
   };
   static std::mutex m;
   static std::map<std::pair<int, void*>, state> table;
+  constexpr size_t kChainStates = 8;
   int dev = 0;
   WG_HIP_CHECK(hipGetDevice(&dev));
   std::lock_guard<std::mutex> g(m);
-  state& s = table[{dev, static_cast<void*>(stream)}];
+  const std::pair<int, void*> key{dev, static_cast<void*>(stream)};
+  if (table.find(key) == table.end() && table.size() >= kChainStates) {
+    // streams come and go (handles are recycled by the runtime): never more than kChainStates buffers alive.  hipFree waits
+    // for the device, so no scan still reads the state it frees; the survivor set starts over.
+    for (auto& kv : table)
+      if (kv.second.tiles) (void)hipFree(kv.second.tiles);
+    table.clear();
+  }
+  state& s = table[key];
   if (s.tiles == nullptr) {
     // first scan on this stream: 8 MiB of tile words (any n up to 2^31) + the two counters, zeroed once
     void* p = nullptr;
@@ -232,7 +244,9 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
     int64_t m = (n + kTile - 1) / kTile;
     const unsigned grid = (unsigned)std::min<int64_t>(m, kScanGrid);
     static const bool chained = getenv("WGAMD_SCAN_CHAINED") != nullptr;
-    if (chained && m <= kScanChainTiles) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (chained && hipStreamIsCapturing(stream, &capturing) != hipSuccess) (void)hipGetLastError();
+    if (chained && capturing == hipStreamCaptureStatusNone && m <= kScanChainTiles) {
       scan_chained_kernel<<<grid, kThreads, 0, stream>>>(in, out, n, m, live, scan_chain_acquire(stream));
       WG_HIP_CHECK(hipGetLastError());
       return;

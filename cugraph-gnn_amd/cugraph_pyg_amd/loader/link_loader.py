@@ -185,6 +185,9 @@ class LinkLoader:
         if n < batch_size and drop_last:
             raise ValueError("The number of input edges is less than the batch size and drop_last is True.")
         self.__data, self.__sampler = data, link_sampler
+        if data[0] is not None and hasattr(link_sampler, "feature_row_bytes"):   # the group fetch counts in the group size
+            from ..sampler.sampler import store_row_bytes
+            link_sampler.feature_row_bytes = store_row_bytes(data[0])
         self.__batch_size, self.__shuffle, self.__drop_last = batch_size, shuffle, drop_last
         self.__random_state = random_state
         nv = graph_store._num_vertices()

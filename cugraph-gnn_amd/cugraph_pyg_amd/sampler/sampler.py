@@ -51,6 +51,11 @@ def hop_seed(random_state: int, hop: int) -> int:
 # from the capacity-sized arrays of PygNoSyncWalk (per hop: 5 int32 + edge id + frontier id per sampled-edge slot, id +
 # batch per node slot) plus the library's own workspace figure for the largest hop.
 CALL_GROUP_MEMORY_FRACTION = 0.02
+# The rows a call group FETCHES are not walk buffers but they are alive with them: one gather per stored attribute for all
+# batches of the group.  Their worst case (every seed with fan-out^hops distinct neighbours) may take this fraction of the
+# device memory — with 400-byte rows (products) that allows 255 mini-batches and the walk budget decides; with 4 KB rows it is
+# 24 mini-batches instead of 191 and the group fetch stays a few GB instead of tens.
+CALL_GROUP_FEATURE_FRACTION = 0.10
 UNKNOWN_VERTICES_DEFAULT = 32768        # distributed_sampler.py:761-763
 _CALL_GROUP_CAPACITY = (1 << 30) - 1    # node + edge slots one call may address (int32 rows inside the kernels)
 
@@ -73,8 +78,22 @@ def call_group_bytes_per_seed(fanout: Sequence[int], id_bytes: int = 8, disjoint
     return total
 
 
+def store_row_bytes(feature_store):
+    """``(node_row_bytes, edge_row_bytes)``: bytes of all stored attributes per node / per edge — the widest node type and
+    edge type of a heterogeneous store (a call group's fetch is sized for its worst type)."""
+    node, edge = {}, {}
+    for attr in feature_store.get_all_tensor_attrs():
+        t = feature_store[attr.group_name, attr.attr_name, None]
+        b = torch.empty((), dtype=t.dtype).element_size()
+        for d in tuple(t.shape)[1:]:
+            b *= int(d)
+        side = edge if isinstance(attr.group_name, tuple) else node
+        side[attr.group_name] = side.get(attr.group_name, 0) + b
+    return max(node.values(), default=0), max(edge.values(), default=0)
+
+
 def default_local_seeds_per_call(fanout: Sequence[int], batch_size: int, id_bytes: int = 8, disjoint: bool = False,
-                                 total_memory: Optional[int] = None) -> int:
+                                 total_memory: Optional[int] = None, feature_row_bytes=(0, 0)) -> int:
     """Seeds per call group when the user gives none: the memory budget above, never less than one mini-batch, never more
     slots than one call can address, a whole number of mini-batches.  On a 288 GB MI355X, fan-out [25, 10], int64 ids:
     about 140 mini-batches of 1024 seeds (bench.py runs 64 and measures 256 as 5 % faster still)."""
@@ -92,6 +111,9 @@ def default_local_seeds_per_call(fanout: Sequence[int], batch_size: int, id_byte
             slots = nodes + frontier
         per_call = int(CALL_GROUP_MEMORY_FRACTION * total_memory / call_group_bytes_per_seed(fanout, id_bytes, disjoint))
         per_call = min(per_call, _CALL_GROUP_CAPACITY // max(slots, 1))
+        fetched = nodes * int(feature_row_bytes[0]) + (nodes - 1) * int(feature_row_bytes[1])   # rows a seed can pull in
+        if fetched > 0:
+            per_call = min(per_call, int(CALL_GROUP_FEATURE_FRACTION * total_memory / fetched))
     return max(batch_size, per_call // batch_size * batch_size)
 
 
@@ -419,6 +441,7 @@ class HeteroNeighborSampler:
                  disjoint: bool = False, temporal: bool = False, temporal_comparison: Optional[str] = None,
                  local_seeds_per_call: Optional[int] = None, num_nodes=None, **_ignored):
         self.local_seeds_per_call = local_seeds_per_call
+        self.feature_row_bytes = (0, 0)   # (node, edge) row bytes of the FeatureStore the loader joins; set by BaseSampler
         self.num_nodes = num_nodes       # {node type: count}, optional (enables the packed renumber table)
         self._walks = {}
         self._positive_weights = None
@@ -461,7 +484,7 @@ class HeteroNeighborSampler:
         hops = len(next(iter(self.fanout.values())))
         per_hop = [sum(max(v[h], 0) for v in self.fanout.values()) if all(v[h] > 0 for v in self.fanout.values()) else -1
                    for h in range(hops)]
-        return default_local_seeds_per_call(per_hop, batch_size, 8, self.disjoint)
+        return default_local_seeds_per_call(per_hop, batch_size, 8, self.disjoint, feature_row_bytes=self.feature_row_bytes)
 
     def fetch_plan(self, n: int, batch_size: int, on_device: bool = True):
         """(call groups, batches outside a group, batches) ``sample_batches`` will produce for ``n`` seeds."""
@@ -539,6 +562,7 @@ class NeighborSampler:
             raise ValueError("biased sampling needs a weight attribute (weight_attr=...)")
         self.graph, self.fanout, self.biased, self.disjoint = graph, [int(f) for f in fanout], biased, bool(disjoint)
         self.local_seeds_per_call = local_seeds_per_call
+        self.feature_row_bytes = (0, 0)   # (node, edge) row bytes of the FeatureStore the loader joins; set by BaseSampler
         self._walks = {}
         self._positive_weights = None
 
@@ -562,7 +586,8 @@ class NeighborSampler:
         """``local_seeds_per_call`` as given, else sized from device memory (``default_local_seeds_per_call``)."""
         if self.local_seeds_per_call:
             return int(self.local_seeds_per_call)
-        return default_local_seeds_per_call(self.fanout, batch_size, self.graph.col.element_size(), self.disjoint)
+        return default_local_seeds_per_call(self.fanout, batch_size, self.graph.col.element_size(), self.disjoint,
+                                            feature_row_bytes=self.feature_row_bytes)
 
     def fetch_plan(self, n: int, batch_size: int, on_device: bool = True):
         """(call groups, batches outside a group, batches) ``sample_batches`` will produce for ``n`` seeds."""
@@ -632,6 +657,9 @@ class BaseSampler:
         self.__sampler = sampler
         self.__feature_store, self.__graph_store = data
         self.__batch_size = batch_size
+        # the call-group size also answers for the rows a group fetches (sampler.default_local_seeds_per_call)
+        if self.__feature_store is not None and hasattr(sampler, "feature_row_bytes"):
+            sampler.feature_row_bytes = store_row_bytes(self.__feature_store)
 
     def sample_from_nodes(self, index: NodeSamplerInput, random_state: int = 62, **kwargs) -> Iterator[SamplerOutput]:
         """Iterator of ``SamplerOutput`` (sampler.py:756-797).  It also carries the epoch's FETCH PLAN: how many feature
@@ -728,7 +756,24 @@ def _fetch_rows_agreed(t, index):
         pieces = int(worst.item())
     if pieces == 1:
         return t[index]
-    return torch.cat([t[part] for part in torch.tensor_split(index, pieces)])
+    # ONE output for the whole group, filled piece by piece: a torch.cat of the pieces would hold the group's rows twice
+    parts = torch.tensor_split(index, pieces)
+    if hasattr(t, "gather_into"):
+        out = torch.empty((int(index.numel()),) + tuple(t.shape)[1:], dtype=t.dtype, device=index.device)
+        at = 0
+        for part in parts:
+            t.gather_into(part, out[at:at + part.numel()])
+            at += part.numel()
+        return out
+    first = t[parts[0]]
+    out = torch.empty((int(index.numel()),) + tuple(first.shape)[1:], dtype=first.dtype, device=first.device)
+    out[:parts[0].numel()] = first
+    del first
+    at = parts[0].numel()
+    for part in parts[1:]:
+        out[at:at + part.numel()] = t[part]
+        at += part.numel()
+    return out
 
 
 def _group_attribute_views(feature_store, ctx):

@@ -147,6 +147,12 @@ class DistTensor:
         assert self._tensor is not None, "Please create WholeGraph tensor first."
         return self._tensor.gather(self._idx(idx))
 
+    def gather_into(self, idx, out: torch.Tensor) -> torch.Tensor:
+        """``out[:] = self[idx]`` without a fresh allocation (``out``: contiguous, ``len(idx)`` rows, the tensor's dtype) —
+        what the loaders use to fill one preallocated call-group buffer piece by piece.  Collective like ``__getitem__``."""
+        assert self._tensor is not None, "Please create WholeGraph tensor first."
+        return self._tensor.gather(self._idx(idx), out=out)
+
     def __setitem__(self, idx, val: torch.Tensor):
         assert self._tensor is not None, "Please create WholeGraph tensor first."
         idx = self._idx(idx)

@@ -233,7 +233,10 @@ SYMBOLS = {
                                                c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_csr_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_float,
                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                      c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+                                      c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wgamd_gat_csr_bwd_f32_v2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_float,
+                                         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                         c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "wgamd_gat_csr_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "wgamd_sage_layer_fused_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
                                            c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,

@@ -400,11 +400,11 @@ def gat_backward(row_ptr, col, x, a_src, a_dst, alpha, grad_out, heads, negative
     ga_src, ga_dst = torch.empty_like(a_src), torch.empty_like(a_dst)
     need = L.lib().wgamd_gat_csr_bwd_workspace_bytes(E, heads, C)      # pieces of long source rows (hubs of the hop)
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    L.check(L.lib().wgamd_gat_csr_bwd_f32(
+    L.check(L.lib().wgamd_gat_csr_bwd_f32_v2(
         row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), a_src.data_ptr(), a_dst.data_ptr(), heads, C,
         float(negative_slope), alpha.data_ptr(), g.data_ptr(), g.stride(0), row_ptr_t.data_ptr(), edge_perm.data_ptr(),
         edge_dst.data_ptr(), n_src, de.data_ptr(), gx.data_ptr(), gx.stride(0), ga_src.data_ptr(), ga_dst.data_ptr(),
-        E, ws.data_ptr(), need, get_stream()), "wgamd_gat_csr_bwd_f32")
+        E, ws.data_ptr(), need, get_stream()), "wgamd_gat_csr_bwd_f32_v2")
     return gx, ga_src, ga_dst
 
 

@@ -36,10 +36,12 @@ def local_scatter(input_tensor: torch.Tensor, indice: torch.Tensor, table: torch
             "wholememory_scatter")
 
 
-def unique_bounded(indice: torch.Tensor, id_bound: int):
+def unique_bounded(indice: torch.Tensor, id_bound: int, *, report_out_of_bound: bool = False):
     """``-> (distinct, inverse)``: the distinct non-negative ids of ``indice`` ASCENDING (int64) and, for every entry, its
     position in that list (int32; -1 for a negative id = a row to skip) — ``wgamd_unique_bounded`` (mark, scan over the
-    bound, compact, look up; include/wgamd_ext.h).  One host synchronisation (the count).  An id >= ``id_bound`` raises."""
+    bound, compact, look up; include/wgamd_ext.h).  One host synchronisation (the count).  An id >= ``id_bound`` raises —
+    unless ``report_out_of_bound``: then such ids are left out of ``distinct`` (their ``inverse`` is -1) and the call
+    returns ``(distinct, inverse, any_out_of_bound)``, for callers that must reach a collective before they may raise."""
     from .env import torch_dtype_to_wm
     assert indice.is_cuda and indice.dim() == 1 and indice.dtype in (torch.int32, torch.int64) and indice.is_contiguous()
     lib, dev, n = L.lib(), indice.device, int(indice.shape[0])
@@ -55,6 +57,8 @@ def unique_bounded(indice: torch.Tensor, id_bound: int):
                                      inverse.data_ptr(), info.data_ptr(), info.data_ptr() + 4, ws[0].data_ptr() + ws[1], ws[2],
                                      get_stream()), "wgamd_unique_bounded")
     n_d, bad = (int(v) for v in info.cpu())
+    if report_out_of_bound:
+        return distinct[:n_d], inverse, bool(bad)
     if bad:
         raise IndexError("gather: an index is >= the table's %d rows" % id_bound)
     return distinct[:n_d], inverse
@@ -74,8 +78,13 @@ def dedup_pays(n: int, rows: int, world: int) -> bool:
 def gather_distinct(gather_rows, indice: torch.Tensor, rows: int, out: torch.Tensor):
     """``out[i] = table[indice[i]]`` fetching every DISTINCT row once: ``gather_rows(ids) -> [len(ids), dim]`` is the
     (collective) fetch, the expansion ``out[i] = fetched[inverse[i]]`` a local row copy (negative ids leave their row alone)."""
-    distinct, inverse = unique_bounded(indice, rows)
+    # ``gather_rows`` is a COLLECTIVE on a partitioned table: a rank holding a bad id must still enter it (with the bad ids
+    # left out), or every other rank waits in the exchange for ever; it raises afterwards, like the plain path, which
+    # also meets the error inside / behind the collective.
+    distinct, inverse, bad = unique_bounded(indice, rows, report_out_of_bound=True)
     fetched = gather_rows(distinct)
+    if bad:
+        raise IndexError("gather: an index is >= the table's %d rows" % rows)
     if indice.shape[0] > 0 and fetched.shape[0] > 0:
         local_gather(fetched if fetched.dim() == 2 else fetched.unsqueeze(1), inverse, out if out.dim() == 2 else out.unsqueeze(1))
     return out
@@ -135,14 +144,20 @@ class WholeMemoryTensor(object):
         return (self.local_tensor.cpu() if host_view else self.local_tensor), start
 
     # ---- ops -----------------------------------------------------------------------------
-    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None, dedup="auto"):
+    def gather(self, indice: torch.Tensor, *, force_dtype: Union[torch.dtype, None] = None, dedup="auto",
+               out: Optional[torch.Tensor] = None):
         """``dedup`` (partitioned tables): fetch every DISTINCT row once and expand locally — True / False / "auto"
-        (``dedup_pays``).  Same result either way; every rank still makes exactly one collective fetch."""
+        (``dedup_pays``).  Same result either way; every rank still makes exactly one collective fetch.  ``out``: a
+        contiguous ``[len(indice), dim]`` (or ``[len(indice)]``) tensor to fill instead of a fresh allocation."""
         assert indice.dim() == 1
         embedding_dim = self.shape[1] if self.dim() == 2 else 1
         output_dtype = force_dtype if force_dtype is not None else self.dtype
-        output_tensor = torch.empty([indice.shape[0], embedding_dim], device=indice.device, dtype=output_dtype,
-                                    requires_grad=False)
+        if out is not None:
+            assert out.is_contiguous() and out.shape[0] == indice.shape[0] and out.numel() == indice.shape[0] * embedding_dim
+            output_tensor = out.view(indice.shape[0], embedding_dim)
+        else:
+            output_tensor = torch.empty([indice.shape[0], embedding_dim], device=indice.device, dtype=output_dtype,
+                                        requires_grad=False)
         table2d = self.local_tensor if self.dim() == 2 else self.local_tensor.unsqueeze(1)
         if self.is_distributed and indice.is_cuda and self.local_ops is HipLocalOps and (
                 dedup is True or (dedup == "auto" and dedup_pays(indice.shape[0], self._rows, _dist.world_size(self.group)))):

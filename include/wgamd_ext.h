@@ -403,16 +403,27 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
  * Shapes: C % 4 == 0, C/4 a power of two, H*C <= 256 — anything else returns WHOLEMEMORY_LOGIC_ERROR.
  * workspace (wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C) bytes; NULL = none): with it the source-major pass sums long
  * source rows in pieces of 64 entries and adds the pieces up in order (a power-law hop has hub sources with thousands of
- * entries).  n_entries = E, the entry count of the transposed hop (row_ptr_t[n_src]): the piece capacity is derived from it
- * and a non-NULL workspace smaller than wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C) returns WHOLEMEMORY_INVALID_INPUT
- * (as wgamd_spmm_csr_segmented_f32 does). */
+ * entries).  Two entry points, one algorithm:
+ *   wgamd_gat_csr_bwd_f32     — the signature of rounds 1-2 (no n_entries): the piece capacity is what the workspace holds;
+ *   wgamd_gat_csr_bwd_f32_v2  — n_entries = E, the entry count of the transposed hop (row_ptr_t[n_src]): a non-NULL workspace
+ *                               smaller than wgamd_gat_csr_bwd_workspace_bytes(n_entries, H, C) returns
+ *                               WHOLEMEMORY_INVALID_INPUT (as wgamd_spmm_csr_segmented_f32 does).
+ * Either way the slots are bounded on the device: a long row whose pieces do not fit gets none, nothing is written past the
+ * workspace, and the int at byte 8 of the (256-byte aligned) workspace is set to 1 — the gradients of that row are then
+ * incomplete; with the workspace size the query returns for the true E it cannot happen. */
 size_t wgamd_gat_csr_bwd_workspace_bytes(int64_t n_entries, int H, int C);
 wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x, int64_t ldx,
                                                const float* a_src, const float* a_dst, int H, int C, float negative_slope,
                                                const float* alpha, const float* grad_out, int64_t ldg, const int* row_ptr_t,
                                                const int* edge_perm, const int* edge_dst, int64_t n_src, float* de,
                                                float* grad_x, int64_t ldgx, float* grad_a_src, float* grad_a_dst,
-                                               int64_t n_entries, void* workspace, size_t workspace_bytes, void* stream);
+                                               void* workspace, size_t workspace_bytes, void* stream);
+wholememory_error_code_t wgamd_gat_csr_bwd_f32_v2(const int* row_ptr, const int* col, int64_t n_rows, const float* x, int64_t ldx,
+                                                  const float* a_src, const float* a_dst, int H, int C, float negative_slope,
+                                                  const float* alpha, const float* grad_out, int64_t ldg, const int* row_ptr_t,
+                                                  const int* edge_perm, const int* edge_dst, int64_t n_src, float* de,
+                                                  float* grad_x, int64_t ldgx, float* grad_a_src, float* grad_a_dst,
+                                                  int64_t n_entries, void* workspace, size_t workspace_bytes, void* stream);
 
 /* A whole SAGEConv layer over a sampled hop in ONE kernel (csrc/wg_sage_fused.hip):
  *   out[i,:] = act( [ mean|sum_{e in row i} X[col[e]] | X[self_rows[i]] ] @ w_t + bias ),  X[r] = x[src_ids ? src_ids[r] : r]

@@ -445,13 +445,63 @@ def test_gat_backward_refuses_a_workspace_smaller_than_the_hop_needs(hiplib):
     i = torch.zeros(1 << 14, dtype=torch.int32, device="cuda")
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     p, q = d.data_ptr(), i.data_ptr()
-    rc = hiplib.wgamd_gat_csr_bwd_f32(q, q, 0, p, 64, p, p, H, C, 0.2, p, p, 64, q, q, q, 10, p, p, 64, p, p, E, ws.data_ptr(),
-                                      hiplib.wgamd_gat_csr_bwd_workspace_bytes(E // 4, H, C), None)
+    rc = hiplib.wgamd_gat_csr_bwd_f32_v2(q, q, 0, p, 64, p, p, H, C, 0.2, p, p, 64, q, q, q, 10, p, p, 64, p, p, E, ws.data_ptr(),
+                                         hiplib.wgamd_gat_csr_bwd_workspace_bytes(E // 4, H, C), None)
     assert rc == L.WHOLEMEMORY_INVALID_INPUT
-    rc = hiplib.wgamd_gat_csr_bwd_f32(q, q, 0, p, 64, p, p, H, C, 0.2, p, p, 64, q, q, q, 10, p, p, 64, p, p, 0, ws.data_ptr(),
-                                      need, None)      # empty hop, full-size scratch: fine
+    rc = hiplib.wgamd_gat_csr_bwd_f32_v2(q, q, 0, p, 64, p, p, H, C, 0.2, p, p, 64, q, q, q, 10, p, p, 64, p, p, 0, ws.data_ptr(),
+                                         need, None)      # empty hop, full-size scratch: fine
     assert rc == L.WHOLEMEMORY_SUCCESS
     torch.cuda.synchronize()
+
+
+def test_gat_backward_old_entry_point_is_bounded_by_its_workspace(hiplib):
+    """`wgamd_gat_csr_bwd_f32` keeps its round-1/2 signature (no n_entries; ADVICE r3: a caller built against the old header
+    must not have its workspace pointer read as a count).  Its piece capacity is what the workspace holds, the plan kernel
+    checks it ON THE DEVICE: with a full-size workspace the result equals the v2 entry point's bit for bit; with room for
+    fewer pieces than the hub rows need nothing is written past the scratch and the overflow flag (int at byte 8) is set."""
+    import numpy as np
+    import torch
+    from wholegraph_amd import nn
+    H, C, n_dst, n_src = 2, 8, 40, 6
+    g = torch.Generator().manual_seed(3)
+    deg = torch.full((n_dst,), 30, dtype=torch.int64)
+    row_ptr = torch.zeros(n_dst + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(deg, 0)
+    E = int(row_ptr[-1])
+    col = torch.randint(0, n_src, (E,), generator=g).int()           # 6 sources x 200 entries each: every source row is long
+    x = torch.randn(n_src, H * C, generator=g).cuda()
+    a_s, a_d = torch.randn(n_src, H, generator=g).cuda(), torch.randn(n_dst, H, generator=g).cuda()
+    go = torch.randn(n_dst, H * C, generator=g).cuda()
+    rp, ci = row_ptr.cuda(), col.cuda()
+    out, alpha = nn.gat_forward(rp, ci, x, a_s, a_d, H, 0.2, need_alpha=True)
+    want = nn.gat_backward(rp, ci, x, a_s, a_d, alpha, go, H, 0.2)
+    row_ptr_t, edge_perm, edge_dst, _ = nn._csr_transpose(rp, ci, n_src, want_perm=True, want_dst=True)
+
+    def run(ws_bytes):
+        de = torch.empty((E, H), dtype=torch.float32, device="cuda")
+        gx, gs, gd = torch.empty_like(x), torch.empty_like(a_s), torch.empty_like(a_d)
+        buf = torch.full((ws_bytes + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
+        off = (-buf.data_ptr()) % 256
+        rc = hiplib.wgamd_gat_csr_bwd_f32(rp.data_ptr(), ci.data_ptr(), n_dst, x.data_ptr(), x.stride(0), a_s.data_ptr(),
+                                          a_d.data_ptr(), H, C, 0.2, alpha.data_ptr(), go.data_ptr(), go.stride(0),
+                                          row_ptr_t.data_ptr(), edge_perm.data_ptr(), edge_dst.data_ptr(), n_src, de.data_ptr(),
+                                          gx.data_ptr(), gx.stride(0), gs.data_ptr(), gd.data_ptr(), buf.data_ptr() + off,
+                                          ws_bytes, None)
+        torch.cuda.synchronize()
+        flag = int(buf[off + 8:off + 12].view(torch.int32).item())
+        guard = buf[off + ws_bytes:].cpu()
+        return rc, (gx, gs, gd), flag, guard
+
+    full = hiplib.wgamd_gat_csr_bwd_workspace_bytes(E, H, C)
+    rc, got, flag, guard = run(full)
+    assert rc == 0 and flag == 0 and bool((guard == 0x5A).all())
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    small = hiplib.wgamd_gat_csr_bwd_workspace_bytes(64 * 3, H, C)      # 4 slots; the hop needs 6 rows x 3 further pieces
+    rc, got, flag, guard = run(small)
+    assert rc == 0 and flag == 1, (rc, flag)
+    assert bool((guard == 0x5A).all()), "the plan kernel wrote past its workspace"
+    assert torch.equal(got[2], want[2])                                   # the destination-major part does not use it
 
 
 def test_sage_layer_fused_padded_head_respects_the_callers_out(hiplib):

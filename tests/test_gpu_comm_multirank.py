@@ -158,6 +158,19 @@ WORKER = textwrap.dedent(r"""
             out4 = torch.full((k, dim), 3.0, dtype=tdt, device="cuda")
             t.gather(idx_d.int(), out=out4, dedup="auto")
             assert torch.equal(out4.cpu(), want.to(tdt)), f"rank {r}: auto gather mismatch"
+            # an id past the table on ONE rank: it still enters the collective (bad ids left out) and raises AFTER it; the
+            # other ranks finish their fetch instead of hanging in the exchange (tensor.gather_distinct)
+            idx_bad = idx_d.clone()
+            if r == 0 and k > 0:
+                idx_bad[k - 1] = rows + 5
+            try:
+                t.gather(idx_bad, force_dtype=odt, out=out3, dedup=True)
+                raised = False
+            except IndexError:
+                raised = True
+            assert raised == (r == 0 and k > 0), (r, k, raised)
+            if not raised:
+                assert torch.equal(out3.cpu(), want), f"rank {r}: gather next to a failing rank"
             assert dedup_pays(10_900_000, 2_449_029, 8) and not dedup_pays(10_900_000, 2_449_029, 1)
             assert not dedup_pays(1000, 2_449_029, 8) and not dedup_pays(10**7, 1 << 31, 8)
             comm.barrier()

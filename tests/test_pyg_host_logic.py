@@ -185,3 +185,48 @@ def test_temporal_negative_redraw_and_fallback():
     assert int(src2.max()) < 1000 and int(dst2.min()) >= 0
     s3, d3 = _draw_negatives(0, 10, 10, gen, torch.device("cpu"), neg_time[:0], node_time, node_time)
     assert s3.numel() == 0 and d3.numel() == 0
+
+
+def test_call_group_size_answers_for_the_rows_it_fetches(hiplib):
+    """The default call group is sized from device memory (distributed_sampler.py:757,837-875): the walk's capacity-sized
+    buffers AND the worst case of the feature rows the group fetches in one go (round-3 advice: 191 mini-batches of wide
+    rows were tens of GB).  Narrow rows leave the walk budget in charge, wide rows shorten the group."""
+    from cugraph_pyg_amd.sampler.sampler import default_local_seeds_per_call as per_call
+    T = 288 << 30
+    base = per_call([25, 10], 1024, 8, False, T)
+    assert base // 1024 >= 128
+    assert per_call([25, 10], 1024, 8, False, T, feature_row_bytes=(400, 0)) == base       # products: 400-byte rows
+    wide = per_call([25, 10], 1024, 8, False, T, feature_row_bytes=(4096, 0))
+    assert 1024 <= wide < base // 4 and wide % 1024 == 0
+    worst_nodes = 1 + 25 + 250
+    assert wide * worst_nodes * 4096 <= 0.10 * T                                           # the stated budget holds
+    assert per_call([25, 10], 1024, 8, False, T, feature_row_bytes=(0, 4096)) < base       # edge attributes count too
+    assert per_call([25, 10], 1024, 8, False, 1 << 30, feature_row_bytes=(1 << 20, 0)) == 1024   # never below one batch
+
+
+def test_group_fetch_fills_one_preallocated_output(monkeypatch):
+    """A call group's fetch larger than _GROUP_FETCH_BYTES is made in pieces into ONE output (no torch.cat copy)."""
+    from cugraph_pyg_amd.sampler import sampler as S
+    from cugraph_pyg_amd.data import FeatureStore
+    table = torch.arange(200 * 6, dtype=torch.float32).view(200, 6)
+    index = torch.randint(0, 200, (1000,), generator=torch.Generator().manual_seed(1))
+    monkeypatch.setattr(S, "_GROUP_FETCH_BYTES", 5000)            # 1000 rows x 24 B -> 5 pieces
+    assert torch.equal(S._fetch_rows_agreed(table, index), table[index])
+
+    class Pieces:                                                 # a store tensor with the loaders' gather_into hook
+        shape, dtype, calls = table.shape, table.dtype, []
+
+        def gather_into(self, idx, out):
+            Pieces.calls.append(int(idx.numel()))
+            out.copy_(table[idx])
+
+        def __getitem__(self, idx):
+            raise AssertionError("the preallocated path must be taken")
+
+    got = S._fetch_rows_agreed(Pieces(), index)
+    assert torch.equal(got, table[index]) and len(Pieces.calls) == 5 and sum(Pieces.calls) == 1000
+    fs = FeatureStore()
+    fs["paper", "x", None] = table
+    fs["paper", "y", None] = torch.zeros(200, dtype=torch.int64)
+    fs[("paper", "cites", "paper"), "w", None] = torch.zeros(50, 3, dtype=torch.float16)
+    assert S.store_row_bytes(fs) == (24 + 8, 6)
