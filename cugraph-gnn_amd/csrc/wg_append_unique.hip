@@ -21,6 +21,7 @@
 // unique lists:  row(target i of batch b) = i + rank[edge_seg[b]],
 //                row(new node first seen at edge e of batch b) = target_seg[b+1] + rank[e].
 #include <algorithm>
+#include <type_traits>
 
 #include "wg_common.hpp"
 
@@ -93,11 +94,20 @@ __device__ __forceinline__ int batch_of(const batch_view& bv, int p, int T)
   return p < T ? bv.target_batch[p] : bv.sbatch()[bv.edge_row[p - T]];
 }
 
+// id of position p of  targets ++ neighbours.  The two lists may differ in width: the API's ids (targets, unique) are
+// INT64 while the sampled neighbours come out of a 32-bit column array (a graph with fewer than 2^31 vertices keeps its
+// columns in 32 bits behind the int64 API: half the sector footprint for the sampler, half the bytes for every pass here).
+template <typename TgtT, typename NbrT>
+__device__ __forceinline__ int64_t id_at(const TgtT* __restrict__ targets, const NbrT* __restrict__ neighbors, int p, int T)
+{
+  return p < T ? (int64_t)targets[p] : (int64_t)neighbors[p - T];
+}
+
 // thread p < T inserts target p, thread T+e inserts neighbour e; remembers its slot.
-template <typename KeyT, typename TableKeyT>
-__global__ void __launch_bounds__(256) table_insert_kernel(const KeyT* __restrict__ targets,
+template <typename TgtT, typename NbrT, typename TableKeyT>
+__global__ void __launch_bounds__(256) table_insert_kernel(const TgtT* __restrict__ targets,
                                                            dev_count T_,
-                                                           const KeyT* __restrict__ neighbors,
+                                                           const NbrT* __restrict__ neighbors,
                                                            dev_count E_,
                                                            batch_view bv,
                                                            TableKeyT* keys,
@@ -110,8 +120,8 @@ __global__ void __launch_bounds__(256) table_insert_kernel(const KeyT* __restric
   const uint32_t slots = live_slot_count(T + E, capacity_slots);
   int p       = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= T + E) return;
-  KeyT id       = p < T ? targets[p] : neighbors[p - T];
-  TableKeyT key = (TableKeyT)id;
+  const int64_t id = id_at(targets, neighbors, p, T);
+  TableKeyT key    = (TableKeyT)id;
   if constexpr (sizeof(TableKeyT) == 8) {
     if (bv.target_batch != nullptr) key = (TableKeyT)(((int64_t)batch_of(bv, p, T) << 40) | (int64_t)id);
   }
@@ -150,19 +160,20 @@ first_flag_kernel(const int* __restrict__ minpos, int* __restrict__ slot_of, dev
   flag[e] = (first == T + e) ? 1 : 0;
 }
 
-template <typename KeyT>
-__global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restrict__ targets,
-                                                            const KeyT* __restrict__ neighbors,
+template <typename TgtT, typename NbrT>
+__global__ void __launch_bounds__(256) renumber_emit_kernel(const TgtT* __restrict__ targets,
+                                                            const NbrT* __restrict__ neighbors,
                                                             const int* __restrict__ minpos,
                                                             const int* __restrict__ slot_of,
                                                             const int* __restrict__ rank,  // exclusive scan of flag, [E.host+1]
                                                             dev_count T_,
                                                             dev_count E_,
                                                             batch_view bv,
-                                                            KeyT* __restrict__ unique_out,
+                                                            TgtT* __restrict__ unique_out,
                                                             int* __restrict__ map_out,
                                                             int* __restrict__ counts_out)
 {
+  using KeyT = TgtT;
   const int T = T_.get(), E = E_.get();
   const int U = rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
   int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,10 +206,10 @@ __global__ void __launch_bounds__(256) renumber_emit_kernel(const KeyT* __restri
   const int first = slot_of[p];  // first position of the id in targets ++ neighbours (memoised by the flag kernel)
   const int row   = first < T ? first + shift : tail_row + rank[first - T];
   if (first == p) {
-    unique_out[row] = neighbors[e];
+    unique_out[row] = (KeyT)neighbors[e];
     if (bv.unique_batch) bv.unique_batch[row] = b;
     if (bv.frontier_out) {  // next frontier, ordered by (batch, first appearance) == by rank
-      static_cast<KeyT*>(bv.frontier_out)[rank[e]] = neighbors[e];
+      static_cast<KeyT*>(bv.frontier_out)[rank[e]] = (KeyT)neighbors[e];
       bv.frontier_batch_out[rank[e]]               = b;
     }
   }
@@ -227,13 +238,13 @@ void append_unique_impl(const KeyT* targets, int T, const KeyT* neighbors, int E
   batch_view one{};
   one.G = 1;
 
-  append_unique_prepare_enqueue(targets, Tc, neighbors, Ec, k64, one, keys, minpos, slots, slot_of, rank, stmp, stream);
+  append_unique_prepare_enqueue(targets, Tc, k64, neighbors, Ec, k64, one, keys, minpos, slots, slot_of, rank, stmp, stream);
   int U = 0;
   WG_HIP_CHECK(hipMemcpyAsync(&U, rank + E, sizeof(int), hipMemcpyDeviceToHost, stream));
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // output size
 
   KeyT* unique_out = static_cast<KeyT*>(output_alloc(env, unique_ctx, (int64_t)T + U, key_traits<KeyT>::dt));
-  append_unique_emit_enqueue(targets, Tc, neighbors, Ec, k64, one, minpos, slot_of, rank, unique_out, map_out, nullptr,
+  append_unique_emit_enqueue(targets, Tc, k64, neighbors, Ec, k64, one, minpos, slot_of, rank, unique_out, map_out, nullptr,
                              stream);
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
 }
@@ -292,9 +303,9 @@ table_clear_packed_kernel(unsigned long long* table, int64_t capacity_slots, dev
   for (int64_t i = tid; i < (slots + 1) / 2; i += stride) t4[i] = fill;
 }
 
-template <typename KeyT>
+template <typename TgtT, typename NbrT>
 __global__ void __launch_bounds__(256)
-table_insert_packed_kernel(const KeyT* __restrict__ targets, dev_count T_, const KeyT* __restrict__ neighbors, dev_count E_,
+table_insert_packed_kernel(const TgtT* __restrict__ targets, dev_count T_, const NbrT* __restrict__ neighbors, dev_count E_,
                            batch_view bv, unsigned long long* table, int64_t capacity_slots, packed_layout lay,
                            int* __restrict__ slot_of)
 {
@@ -302,7 +313,7 @@ table_insert_packed_kernel(const KeyT* __restrict__ targets, dev_count T_, const
   const uint32_t slots = live_slot_count(T + E, capacity_slots);
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= T + E) return;
-  const KeyT id = p < T ? targets[p] : neighbors[p - T];
+  const int64_t id = id_at(targets, neighbors, p, T);
   const unsigned long long key  = ((unsigned long long)batch_of(bv, p, T) << lay.id_bits) | (unsigned long long)id;
   const unsigned long long word = (key << lay.pos_bits) | (unsigned long long)p;
   const unsigned long long kEmpty = ~0ull;
@@ -339,16 +350,16 @@ first_flag_packed_kernel(const unsigned long long* __restrict__ table, int* __re
   flag[e] = (first == T + e) ? 1 : 0;
 }
 
-template <typename KeyT>
-void prepare_packed_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, void* keys,
+template <typename TgtT, typename NbrT>
+void prepare_packed_t(const TgtT* targets, dev_count T, const NbrT* neighbors, dev_count E, batch_view bv, void* keys,
                       int64_t slots, packed_layout lay, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
 {
   auto* table = static_cast<unsigned long long*>(keys);
   const int P = T.host + E.host;
   table_clear_packed_kernel<<<(int)std::min<int64_t>(ceil_div(slots, 1024), 4096), 256, 0, stream>>>(table, slots, T, E);
   if (P > 0)
-    table_insert_packed_kernel<KeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, table, slots, lay,
-                                                                           slot_of);
+    table_insert_packed_kernel<TgtT, NbrT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, table, slots, lay,
+                                                                                 slot_of);
   if (E.host > 0) first_flag_packed_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(table, slot_of, T, E, lay, rank);
   WG_HIP_CHECK(hipGetLastError());
   exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);
@@ -357,29 +368,34 @@ void prepare_packed_t(const KeyT* targets, dev_count T, const KeyT* neighbors, d
 // ---- call groups, per-batch tables in LDS ----------------------------------------------------------------------------
 // A mini-batch is renumbered on its own, so its table never has to be shared across the device — and a device-wide table
 // costs one memory-side atomic per new key plus one fabric-side load per probe (gfx950: agent-scope atomics and sc1 loads
-// are resolved beyond the XCD's L2), 24 G keys/s on an MI355X however it is laid out.  Instead:
-//   1. bucket_count   block (batch, chunk): histogram of the chunk's ids over the batch's R hash ranges
-//                     (R = positions / 5,500: what one LDS table holds at load <= 0.55) -> counts[range][chunk];
-//   2. bucket_scatter same blocks: prefix of the batch's counts (no scan kernel: a batch's buckets fill exactly the
-//                     batch's own stretch of the position space) -> (id, position) pairs grouped by range, streamed;
-//   3. renumber_lds   workgroup (batch, range): its bucket goes into a 10,000-slot open-addressing table in LDS
-//                     (word = [ id | first position ], ds_cmpst / ds_min), then the bucket's neighbours look their first
-//                     positions up.  Every lane has work (the bucket is dense), no table in global memory, nothing to
-//                     clear, no global atomics.  A range whose DISTINCT ids overfill the table (a hot id repeated is
-//                     one key) is split in two and redone through a hash filter, so any id distribution terminates.
-// Cost is linear in the positions whatever the batch size.  Scratch: the pairs live where the device-wide table would
-// (8 B x slots >= 16 B per position), the counts where its positions array would.
+// are resolved beyond the XCD's L2), 24 G keys/s on an MI355X however it is laid out.  Instead, two kernels:
+//   1. bucket_sort    block (batch, chunk): the chunk's (id, position) pairs SORTED BY HASH RANGE inside the chunk's own
+//                     stretch of the pair array (R = positions / 3,000 ranges per batch: what one LDS table holds at load
+//                     <= 0.3).  Histogram over the chunk, block-wide exclusive scan, scatter — the second read of the chunk's
+//                     ids is an L2 hit (22-44 KB read a microsecond earlier by the same workgroup).  A pair is ONE 64-bit
+//                     word [ id | position ] — the word the LDS table stores — and because every chunk sorts into its own
+//                     stretch no block needs another block's counts: round 3 took a count kernel, a scatter kernel (the ids
+//                     read from HBM twice) and 12-byte pairs for the same job.  Per chunk the range boundaries go to seg_off.
+//   2. renumber_lds   workgroup (batch, range): the range's pairs — one segment per chunk — go into a 10,000-slot
+//                     open-addressing table in LDS (ds_cmpst / ds_min on the pair word itself), then the range's neighbours
+//                     look their first positions up.  The pairs stay IN REGISTERS between the two passes (one trip of
+//                     kLdsUnroll pairs per thread covers a range; longer ranges reload).  No table in global memory,
+//                     nothing to clear, no global atomics.  A range whose DISTINCT ids overfill the table (a hot id
+//                     repeated is one key) is split in two and redone through a hash filter, so any id distribution
+//                     terminates.
+// Cost is linear in the positions whatever the batch size.  Scratch: the pair words live where the device-wide table would
+// (8 B x slots >= 16 B per position), the segment boundaries where its positions array would.
 constexpr int kLdsSlots      = 10000;     // 80,000 B: two workgroups per CU, one computes while the other waits on its loads
 constexpr int kLdsKeysTarget = 3000;      // positions per range the range count is sized for (load <= 0.3: short probe chains)
 constexpr int kLdsProbeLimit = 256;       // probes after which a range is declared overfull and split
-constexpr int kLdsThreads    = 512;       // 6 pairs per thread = one trip of kLdsUnroll per range (1024: walk 1.227 -> 1.19 ms per call group of 191;
-                                          // half / quarter-size tables with 512 / 256 threads: 1.28 / 1.48 — more ranges cost more to bucket)
+constexpr int kLdsThreads    = 512;       // one trip of kLdsUnroll pairs per thread covers a range (1024 threads: walk 1.227 -> 1.19 ms per call
+                                          // group of 191; half / quarter-size tables with 512 / 256 threads: 1.28 / 1.48 — more ranges cost more to bucket)
 constexpr int kLdsMaxRanges  = 2048;      // per batch; beyond, ranges simply start overfull and split
 constexpr int kLdsStack      = 40;        // pending hash ranges of one workgroup (a split pushes two, pops one)
-constexpr int kLdsChunks     = 16;        // blocks per batch in the two bucketing kernels
+constexpr int kLdsChunks     = 16;        // blocks per batch in the bucketing kernel = segments of a range
 constexpr int kBucketThreads = 256;
-constexpr int kBucketUnroll  = 4;         // ids in flight per thread of the two bucketing kernels
-constexpr int kLdsUnroll     = 6;         // pairs in flight per thread of the table kernel
+constexpr int kBucketUnroll  = 4;         // ids in flight per thread of the bucketing kernel
+constexpr int kLdsUnroll     = 7;         // pairs per thread of the table kernel: 3,584 per trip (a range holds 3,000 on average)
 
 __device__ __forceinline__ uint32_t hash_id32(uint32_t h)   // murmur3 finaliser
 {
@@ -389,17 +405,19 @@ __device__ __forceinline__ uint32_t hash_id32(uint32_t h)   // murmur3 finaliser
   h *= 0xc2b2ae35u;
   return h ^ (h >> 16);
 }
-template <typename KeyT>
-__device__ __forceinline__ uint32_t hash_id(KeyT id)
+// ID32: every id of the call fits 32 bits (the neighbours come from a 32-bit column array)
+template <bool ID32>
+__device__ __forceinline__ uint32_t hash_id(int64_t id)
 {
-  if constexpr (sizeof(KeyT) == 4) return hash_id32((uint32_t)id);
+  if constexpr (ID32) return hash_id32((uint32_t)id);
   else return hash_key((uint64_t)id);
 }
 
-// one mini-batch of the call group: its targets [t0, t0 + nT), its neighbours [e0, e0 + nE), its R hash ranges and where its
-// range records start (rb: every batch gets floor(positions before it / kLdsKeysTarget) + b, which leaves room for its R)
+// one mini-batch of the call group: its targets [t0, t0 + nT), its neighbours [e0, e0 + nE), its R hash ranges, where its
+// boundary records start (rb: every batch gets floor(positions before it / kLdsKeysTarget) + 2 b, which leaves room for the
+// R + 1 rows of the batches before it) and the positions one bucketing block takes
 struct batch_part {
-  int t0, nT, e0, nE, P, R, rb;
+  int t0, nT, e0, nE, P, R, rb, chunk;
   // keys_target: kLdsKeysTarget, or the (larger) value of a test that wants ranges to overfill and split
   __device__ batch_part(const batch_view& bv, int b, int keys_target)
   {
@@ -409,7 +427,8 @@ struct batch_part {
     nE = bv.edge_offsets[bv.sseg()[b + 1]] - e0;
     P  = nT + nE;
     R  = min(max((P + keys_target - 1) / keys_target, 1), kLdsMaxRanges);
-    rb = (t0 + e0) / keys_target + b;
+    rb = (t0 + e0) / keys_target + 2 * b;
+    chunk = (P + kLdsChunks - 1) / kLdsChunks;
   }
 };
 
@@ -426,113 +445,108 @@ __device__ __forceinline__ bool batch_of_block(int G, int parts, int& b, int& pa
 }
 inline int batch_grid(int G, int parts) { return 8 * ((G + 7) / 8) * parts; }
 
-// scratch behind the three kernels: counts[(rb + r) * kLdsChunks + c], then per range {first pair, pairs}
-struct bucket_scratch {
+// scratch behind the two kernels
+struct sort_scratch {
   int keys_target;
-  int* counts;
-  int* range_start;
-  int* range_count;
-  void* ids;    // KeyT[capacity positions]
-  int* pos;     // int[capacity positions]
+  int* seg_off;                 // [(rb + r) * kLdsChunks + c], r <= R: first pair of range r inside chunk c's stretch
+  unsigned long long* words;    // [capacity positions]: batch b's chunk c owns [t0 + e0 + c * chunk, ...), sorted by range
 };
 
-template <typename KeyT>
+template <typename TgtT, typename NbrT>
 __global__ void __launch_bounds__(kBucketThreads)
-bucket_count_kernel(const KeyT* __restrict__ targets, const KeyT* __restrict__ neighbors, batch_view bv, bucket_scratch sc)
+bucket_sort_kernel(const TgtT* __restrict__ targets, dev_count T_, const NbrT* __restrict__ neighbors, batch_view bv,
+                   packed_layout lay, sort_scratch sc)
 {
-  __shared__ int hist[kLdsMaxRanges];
+  constexpr bool ID32  = sizeof(NbrT) == 4;
+  constexpr int kItems = kLdsMaxRanges / kBucketThreads;   // histogram entries a thread scans
+  __shared__ int hist[kLdsMaxRanges];   // counts of the chunk per range, then the write cursors
+  __shared__ int wave_tot[kBucketThreads / 64];
   int b, c;
   if (!batch_of_block(bv.G, kLdsChunks, b, c)) return;
   const batch_part bp(bv, b, sc.keys_target);
   if (bp.nE <= 0) return;
-  for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) hist[r] = 0;
+  const int T = T_.get(), tid = threadIdx.x;
+  for (int r = tid; r < bp.R; r += kBucketThreads) hist[r] = 0;
   __syncthreads();
-  const int chunk = (bp.P + kLdsChunks - 1) / kLdsChunks;
-  const int end   = min(bp.P, (c + 1) * chunk);
-  for (int i0 = c * chunk + threadIdx.x; i0 < end; i0 += kBucketThreads * kBucketUnroll) {
-    KeyT id[kBucketUnroll];   // all loads of the trip are in flight before the first histogram update
+  const int begin = c * bp.chunk, end = min(bp.P, begin + bp.chunk);
+  const TgtT* tg = targets + bp.t0;
+  const NbrT* nb = neighbors + bp.e0 - bp.nT;   // neighbour of batch position i >= nT: nb[i]
+  // ---- pass 1: the chunk's histogram over the batch's R hash ranges ------------------------------------------------
+  for (int i0 = begin + tid; i0 < end; i0 += kBucketThreads * kBucketUnroll) {
+    int64_t id[kBucketUnroll];   // all loads of the trip are in flight before the first histogram update
 #pragma unroll
     for (int k = 0; k < kBucketUnroll; k++) {
       const int i = min(i0 + k * kBucketThreads, end - 1);
-      id[k]       = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
+      id[k]       = i < bp.nT ? (int64_t)tg[i] : (int64_t)nb[i];
     }
 #pragma unroll
     for (int k = 0; k < kBucketUnroll; k++)
-      if (i0 + k * kBucketThreads < end) atomicAdd(&hist[__umulhi(hash_id<KeyT>(id[k]), (uint32_t)bp.R)], 1);
+      if (i0 + k * kBucketThreads < end) atomicAdd(&hist[__umulhi(hash_id<ID32>(id[k]), (uint32_t)bp.R)], 1);
   }
   __syncthreads();
-  for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) sc.counts[(bp.rb + r) * kLdsChunks + c] = hist[r];
-}
-
-template <typename KeyT>
-__global__ void __launch_bounds__(kBucketThreads)
-bucket_scatter_kernel(const KeyT* __restrict__ targets, dev_count T_, const KeyT* __restrict__ neighbors, batch_view bv,
-                      bucket_scratch sc)
-{
-  __shared__ int cursor[kLdsMaxRanges];   // first: pairs of the range over all chunks; then: where my next pair goes
-  __shared__ int before[kLdsMaxRanges];   // pairs of the range in the chunks before mine
-  int b, c;
-  if (!batch_of_block(bv.G, kLdsChunks, b, c)) return;
-  const batch_part bp(bv, b, sc.keys_target);
-  if (bp.nE <= 0) return;
-  const int T = T_.get();
-  for (int r = threadIdx.x; r < bp.R; r += kBucketThreads) {
-    const int* row = sc.counts + (bp.rb + r) * kLdsChunks;
-    int tot = 0, mine = 0;
+  // ---- exclusive scan of the histogram (thread t owns entries [t * kItems, (t + 1) * kItems)) -----------------------
+  {
+    int v[kItems], sum = 0;
 #pragma unroll
-    for (int k = 0; k < kLdsChunks; k++) {
-      const int v = row[k];
-      mine += k < c ? v : 0;
-      tot += v;
+    for (int k = 0; k < kItems; k++) {
+      const int r = tid * kItems + k;
+      v[k]        = r < bp.R ? hist[r] : 0;
+      sum += v[k];
     }
-    cursor[r] = tot;
-    before[r] = mine;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // the batch's pairs fill [t0 + e0, t0 + e0 + P) of the pair arrays, range after range
-    int at = bp.t0 + bp.e0;
-    for (int r = 0; r < bp.R; r++) {
-      const int tot = cursor[r];
-      if (c == 0) {
-        sc.range_start[bp.rb + r] = at;
-        sc.range_count[bp.rb + r] = tot;
+    int inc = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += up;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wave; w++) run += wave_tot[w];
+    int* bounds = sc.seg_off + (int64_t)bp.rb * kLdsChunks + c;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+      const int r = tid * kItems + k;
+      if (r < bp.R) {
+        hist[r]                         = run;   // from here on: where the next pair of range r goes
+        bounds[(int64_t)r * kLdsChunks] = run;
       }
-      cursor[r] = at + before[r];
-      at += tot;
+      run += v[k];
     }
+    if (tid == 0) bounds[(int64_t)bp.R * kLdsChunks] = end - begin;
   }
   __syncthreads();
-  KeyT* ids       = static_cast<KeyT*>(sc.ids);
-  const int chunk = (bp.P + kLdsChunks - 1) / kLdsChunks;
-  const int end   = min(bp.P, (c + 1) * chunk);
-  for (int i0 = c * chunk + threadIdx.x; i0 < end; i0 += kBucketThreads * kBucketUnroll) {
-    KeyT id[kBucketUnroll];
+  // ---- pass 2: the pairs, grouped by range, into the chunk's own stretch (ids re-read: L2 hits) ----------------------
+  unsigned long long* out = sc.words + (bp.t0 + bp.e0) + begin;
+  for (int i0 = begin + tid; i0 < end; i0 += kBucketThreads * kBucketUnroll) {
+    int64_t id[kBucketUnroll];
 #pragma unroll
     for (int k = 0; k < kBucketUnroll; k++) {
       const int i = min(i0 + k * kBucketThreads, end - 1);
-      id[k]       = i < bp.nT ? targets[bp.t0 + i] : neighbors[bp.e0 + i - bp.nT];
+      id[k]       = i < bp.nT ? (int64_t)tg[i] : (int64_t)nb[i];
     }
 #pragma unroll
     for (int k = 0; k < kBucketUnroll; k++) {
       const int i = i0 + k * kBucketThreads;
       if (i < end) {
-        const int dst = atomicAdd(&cursor[__umulhi(hash_id<KeyT>(id[k]), (uint32_t)bp.R)], 1);
-        ids[dst]      = id[k];
-        sc.pos[dst]   = i < bp.nT ? bp.t0 + i : T + bp.e0 + (i - bp.nT);
+        const int dst = atomicAdd(&hist[__umulhi(hash_id<ID32>(id[k]), (uint32_t)bp.R)], 1);
+        const int pos = i < bp.nT ? bp.t0 + i : T + bp.e0 + (i - bp.nT);
+        out[dst]      = ((unsigned long long)id[k] << lay.pos_bits) | (unsigned long long)pos;
       }
     }
   }
 }
 
-template <typename KeyT>
+template <bool ID32>
 __global__ void __launch_bounds__(kLdsThreads)
-renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay, int wg_per_batch, bucket_scratch sc,
+renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay, int wg_per_batch, sort_scratch sc,
                     int* __restrict__ slot_of, int* __restrict__ flag)
 {
   __shared__ unsigned long long tbl[kLdsSlots];
   __shared__ unsigned long long st_lo[kLdsStack], st_span[kLdsStack];
   __shared__ int st_n, overfull;
+  __shared__ int seg_base[kLdsChunks], seg_pre[kLdsChunks + 1];
   const unsigned long long kEmpty = ~0ull;
   const int T = T_.get(), E = E_.get();
   const int tid = threadIdx.x;
@@ -545,22 +559,53 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
   if (!batch_of_block(bv.G, wg_per_batch, b, j)) return;
   const batch_part bp(bv, b, sc.keys_target);
   if (bp.nE <= 0) return;   // no neighbour needs a first position
-  const KeyT* ids = static_cast<const KeyT*>(sc.ids);
   const unsigned long long pos_mask = lay.pos_mask();
   const volatile int* overfull_now  = &overfull;
+  static_assert(kLdsChunks == 16, "the segment search below is written for 16 segments");
 
   for (int r = j; r < bp.R; r += wg_per_batch) {
-    const int first_pair = sc.range_start[bp.rb + r], n_pairs = sc.range_count[bp.rb + r];
-    if (n_pairs == 0) continue;
-    __syncthreads();   // the previous range's last look at the stack is over
-    if (tid == 0) {
-      // mulhi(h, R) == r  <=>  h in [ceil(r 2^32 / R), ceil((r + 1) 2^32 / R))
-      const unsigned long long lo = (((unsigned long long)r << 32) + bp.R - 1) / (unsigned)bp.R;
-      st_lo[0]   = lo;
-      st_span[0] = ((((unsigned long long)(r + 1) << 32) + bp.R - 1) / (unsigned)bp.R) - lo;
-      st_n       = 1;
+    __syncthreads();   // the previous range's last look at the stack and the segment table is over
+    if (tid < kLdsChunks) {
+      // range r of the batch = one segment per bucketing chunk
+      const int* row = sc.seg_off + (int64_t)(bp.rb + r) * kLdsChunks;
+      const int lo = row[tid], n = row[kLdsChunks + tid] - lo;
+      seg_base[tid] = bp.t0 + bp.e0 + tid * bp.chunk + lo;
+      int inc = n;
+#pragma unroll
+      for (int d = 1; d < kLdsChunks; d <<= 1) {
+        const int up = __shfl_up(inc, d, 64);
+        if (tid >= d) inc += up;
+      }
+      seg_pre[tid + 1] = inc;
+      if (tid == 0) {
+        seg_pre[0] = 0;
+        // mulhi(h, R) == r  <=>  h in [ceil(r 2^32 / R), ceil((r + 1) 2^32 / R))
+        const unsigned long long lo_h = (((unsigned long long)r << 32) + bp.R - 1) / (unsigned)bp.R;
+        st_lo[0]   = lo_h;
+        st_span[0] = ((((unsigned long long)(r + 1) << 32) + bp.R - 1) / (unsigned)bp.R) - lo_h;
+        st_n       = 1;
+      }
     }
     __syncthreads();
+    const int n_pairs = seg_pre[kLdsChunks];
+    if (n_pairs == 0) continue;   // (the same value in every thread)
+    // pair i of the range: the segment holding it by binary search over the 17 prefix values
+    auto pair_at = [&](int i) -> unsigned long long {
+      if (i >= n_pairs) return kEmpty;
+      int c = i >= seg_pre[8] ? 8 : 0;
+      c += i >= seg_pre[c + 4] ? 4 : 0;
+      c += i >= seg_pre[c + 2] ? 2 : 0;
+      c += i >= seg_pre[c + 1] ? 1 : 0;
+      return sc.words[seg_base[c] + (i - seg_pre[c])];
+    };
+    // one trip of kLdsUnroll pairs per thread are in flight at once (one load at a time leaves a 8-wave workgroup waiting
+    // on memory latency); a range that fits one trip — nearly all — keeps its pairs in registers for both passes
+    const bool one_trip = n_pairs <= kLdsThreads * kLdsUnroll;
+    unsigned long long w[kLdsUnroll];
+    if (one_trip) {
+#pragma unroll
+      for (int k = 0; k < kLdsUnroll; k++) w[k] = pair_at(k * kLdsThreads + tid);
+    }
     while (true) {
       const int n = st_n;
       if (n == 0) break;
@@ -576,31 +621,25 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
         }
       }
       __syncthreads();
-      // ---- insert the pairs of the range (all of the bucket unless the range was split) -----------------------------
-      // kLdsUnroll pairs per thread are in flight before the first one is used: one load at a time leaves a
-      // 16-wave workgroup waiting on memory latency
+      // ---- insert the pairs of the range (all of them unless the range was split) -----------------------------------
       for (int i0 = 0; i0 < n_pairs; i0 += kLdsThreads * kLdsUnroll) {
-        KeyT id_k[kLdsUnroll];
-        int pos_k[kLdsUnroll];
+        if (!one_trip) {
 #pragma unroll
-        for (int k = 0; k < kLdsUnroll; k++) {
-          const int i = min(i0 + k * kLdsThreads + tid, n_pairs - 1);
-          id_k[k]     = ids[first_pair + i];
-          pos_k[k]    = sc.pos[first_pair + i];
+          for (int k = 0; k < kLdsUnroll; k++) w[k] = pair_at(i0 + k * kLdsThreads + tid);
         }
 #pragma unroll
         for (int k = 0; k < kLdsUnroll; k++) {
-          const KeyT id    = id_k[k];
-          const uint32_t h = hash_id<KeyT>(id);
-          if (i0 + k * kLdsThreads + tid < n_pairs && (unsigned long long)h - lo < span && !*overfull_now) {
-            const unsigned long long word = ((unsigned long long)id << lay.pos_bits) | (unsigned long long)pos_k[k];
+          const unsigned long long word = w[k];
+          const unsigned long long id   = word >> lay.pos_bits;
+          const uint32_t h              = hash_id<ID32>((int64_t)id);
+          if (word != kEmpty && (unsigned long long)h - lo < span && !*overfull_now) {
             uint32_t s = __umulhi(h * 0x9E3779B1u, (uint32_t)kLdsSlots);
             int probes = 0;
             while (true) {
               // one LDS round trip per probe: the compare-and-swap doubles as the read
               const unsigned long long cur = atomicCAS(&tbl[s], kEmpty, word);
               if (cur == kEmpty) break;
-              if ((cur >> lay.pos_bits) == (unsigned long long)id) {
+              if ((cur >> lay.pos_bits) == id) {
                 if (word < cur) atomicMin(&tbl[s], word);
                 break;
               }
@@ -629,26 +668,23 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
         __syncthreads();
         continue;
       }
-      // ---- first position of every neighbour of the range --------------------------------------------------------
+      // ---- first position of every neighbour of the range ----------------------------------------------------------
       for (int i0 = 0; i0 < n_pairs; i0 += kLdsThreads * kLdsUnroll) {
-        KeyT id_k[kLdsUnroll];
-        int pos_k[kLdsUnroll];
+        if (!one_trip) {
 #pragma unroll
-        for (int k = 0; k < kLdsUnroll; k++) {
-          const int i = min(i0 + k * kLdsThreads + tid, n_pairs - 1);
-          id_k[k]     = ids[first_pair + i];
-          pos_k[k]    = sc.pos[first_pair + i];
+          for (int k = 0; k < kLdsUnroll; k++) w[k] = pair_at(i0 + k * kLdsThreads + tid);
         }
 #pragma unroll
         for (int k = 0; k < kLdsUnroll; k++) {
-          const KeyT id    = id_k[k];
-          const int p      = pos_k[k];
-          const uint32_t h = hash_id<KeyT>(id);
+          const unsigned long long word = w[k];
+          const unsigned long long id   = word >> lay.pos_bits;
+          const int p                   = (int)(word & pos_mask);
+          const uint32_t h              = hash_id<ID32>((int64_t)id);
           // (a target: nobody asks for its first position)
-          if (i0 + k * kLdsThreads + tid < n_pairs && p >= T && (unsigned long long)h - lo < span) {
+          if (word != kEmpty && p >= T && (unsigned long long)h - lo < span) {
             uint32_t s = __umulhi(h * 0x9E3779B1u, (uint32_t)kLdsSlots);
             unsigned long long cur = tbl[s];
-            while ((cur >> lay.pos_bits) != (unsigned long long)id) {
+            while ((cur >> lay.pos_bits) != id) {
               s   = s + 1 == (uint32_t)kLdsSlots ? 0u : s + 1;
               cur = tbl[s];
             }
@@ -666,17 +702,19 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
 // Emit for call groups, one block per (batch, chunk): everything that depends on the batch only (its row shift, where
 // its new vertices start, its local-id origin) is read once per block instead of chased through four dependent loads per
 // edge, and the one random read left (the rank of the first occurrence) stays inside the batch's stretch of `rank`,
-// which the XCD-affine block mapping keeps in one L2.  Same outputs as renumber_emit_kernel.
+// which the XCD-affine block mapping keeps in one L2.  Same outputs as renumber_emit_kernel.  The unique / frontier lists
+// are written in the TARGET (API) id type whatever the width of the sampled neighbours.
 constexpr int kEmitChunks = 16;
 constexpr int kEmitUnroll = 4;
 
-template <typename KeyT>
+template <typename TgtT, typename NbrT>
 __global__ void __launch_bounds__(256)
-renumber_emit_batched_kernel(const KeyT* __restrict__ targets, const KeyT* __restrict__ neighbors,
+renumber_emit_batched_kernel(const TgtT* __restrict__ targets, const NbrT* __restrict__ neighbors,
                              const int* __restrict__ slot_of, const int* __restrict__ rank, dev_count T_, dev_count E_,
-                             batch_view bv, KeyT* __restrict__ unique_out, int* __restrict__ map_out,
+                             batch_view bv, TgtT* __restrict__ unique_out, int* __restrict__ map_out,
                              int* __restrict__ counts_out)
 {
+  using KeyT = TgtT;
   const int T = T_.get(), E = E_.get();
   const int U = rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
@@ -727,7 +765,7 @@ renumber_emit_batched_kernel(const KeyT* __restrict__ targets, const KeyT* __res
       if (i >= end) break;
       const int e = e0 + i;
       if (first[k] == T + e) {
-        const KeyT id      = neighbors[e];
+        const KeyT id      = (KeyT)neighbors[e];
         unique_out[row[k]] = id;
         if (bv.unique_batch) bv.unique_batch[row[k]] = b;
         if (bv.frontier_out) {  // next frontier, ordered by (batch, first appearance) == by rank
@@ -743,10 +781,11 @@ renumber_emit_batched_kernel(const KeyT* __restrict__ targets, const KeyT* __res
   }
 }
 
-// range records the three kernels address: every batch starts at floor(positions before it / kLdsKeysTarget) + b
-inline int64_t lds_range_records(int64_t capacity_positions, int G) { return capacity_positions / kLdsKeysTarget + 2 * (int64_t)G + 2; }
+// boundary records the two kernels address: every batch starts at floor(positions before it / kLdsKeysTarget) + 2 b and
+// owns R + 1 rows of kLdsChunks ints
+inline int64_t lds_range_records(int64_t capacity_positions, int G) { return capacity_positions / kLdsKeysTarget + 3 * (int64_t)G + 2; }
 // WGAMD_RENUMBER_KEYS_TARGET (tests): positions per hash range, >= kLdsKeysTarget; a value the table cannot hold makes
-// every range overfill and exercises the split path
+// every range overfill and exercises the split path (and ranges longer than one trip of the table kernel)
 inline int lds_keys_target()
 {
   static const int v = [] {
@@ -756,50 +795,55 @@ inline int lds_keys_target()
   }();
   return v;
 }
-inline bool lds_scratch_fits(int64_t capacity_positions, int G, int64_t slots, size_t id_bytes)
+inline bool lds_scratch_fits(int64_t capacity_positions, int G, int64_t slots)
 {
-  // keys buffer: 8 B per slot holds ids + positions; positions buffer: 4 B per slot holds counts + the two range arrays
-  return (int64_t)(id_bytes + 4) * capacity_positions + 256 <= 8 * slots &&
-         lds_range_records(capacity_positions, G) * (kLdsChunks + 2) <= slots;
+  // keys buffer: 8 B per slot holds one pair word per position; positions buffer: 4 B per slot holds the boundary rows
+  return 8 * capacity_positions + 256 <= 8 * slots && lds_range_records(capacity_positions, G) * kLdsChunks <= slots;
 }
 
-template <typename KeyT>
-void prepare_lds_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, packed_layout lay,
+template <typename TgtT, typename NbrT>
+void prepare_lds_t(const TgtT* targets, dev_count T, const NbrT* neighbors, dev_count E, batch_view bv, packed_layout lay,
                    void* keys, int* minpos, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
 {
   if (E.host > 0) {
     const int64_t cap = (int64_t)T.host + E.host;
-    const int64_t rec = lds_range_records(cap, bv.G);
-    bucket_scratch sc;
+    sort_scratch sc;
     sc.keys_target = lds_keys_target();
-    sc.counts      = minpos;
-    sc.range_start = minpos + rec * kLdsChunks;
-    sc.range_count = sc.range_start + rec;
-    sc.ids         = keys;
-    sc.pos         = reinterpret_cast<int*>(static_cast<char*>(keys) + (((size_t)cap * sizeof(KeyT) + 255) / 256) * 256);
-    bucket_count_kernel<KeyT><<<batch_grid(bv.G, kLdsChunks), kBucketThreads, 0, stream>>>(targets, neighbors, bv, sc);
-    bucket_scatter_kernel<KeyT><<<batch_grid(bv.G, kLdsChunks), kBucketThreads, 0, stream>>>(targets, T, neighbors, bv, sc);
+    sc.seg_off     = minpos;
+    sc.words       = static_cast<unsigned long long*>(keys);
+    bucket_sort_kernel<TgtT, NbrT><<<batch_grid(bv.G, kLdsChunks), kBucketThreads, 0, stream>>>(targets, T, neighbors, bv, lay, sc);
     const int64_t per_batch = (cap + bv.G - 1) / bv.G;
     const int wg_per_batch  = (int)std::max<int64_t>(1, std::min<int64_t>((per_batch + kLdsKeysTarget - 1) / kLdsKeysTarget, 32));
-    renumber_lds_kernel<KeyT><<<batch_grid(bv.G, wg_per_batch), kLdsThreads, 0, stream>>>(T, E, bv, lay, wg_per_batch, sc, slot_of, rank);
+    renumber_lds_kernel<sizeof(NbrT) == 4><<<batch_grid(bv.G, wg_per_batch), kLdsThreads, 0, stream>>>(T, E, bv, lay, wg_per_batch, sc,
+                                                                                                     slot_of, rank);
     WG_HIP_CHECK(hipGetLastError());
   }
   exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);
 }
 
-template <typename KeyT, typename TableKeyT>
-void prepare_t(const KeyT* targets, dev_count T, const KeyT* neighbors, dev_count E, batch_view bv, TableKeyT* keys,
+template <typename TgtT, typename NbrT, typename TableKeyT>
+void prepare_t(const TgtT* targets, dev_count T, const NbrT* neighbors, dev_count E, batch_view bv, TableKeyT* keys,
                int* minpos, int64_t slots, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
 {
   const int P = T.host + E.host;
   table_clear_kernel<TableKeyT><<<(int)std::min<int64_t>(ceil_div(slots, 1024), 4096), 256, 0, stream>>>(keys, minpos, slots, T,
                                                                                                    E);
   if (P > 0)
-    table_insert_kernel<KeyT, TableKeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, keys,
-                                                                              minpos, slots, slot_of);
+    table_insert_kernel<TgtT, NbrT, TableKeyT><<<ceil_div(P, 256), 256, 0, stream>>>(targets, T, neighbors, E, bv, keys,
+                                                                                    minpos, slots, slot_of);
   if (E.host > 0) first_flag_kernel<<<ceil_div(E.host, 256), 256, 0, stream>>>(minpos, slot_of, T, E, rank);
   WG_HIP_CHECK(hipGetLastError());
   exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);  // flags -> ranks, rank[E.host] = #new nodes
+}
+
+// the three id-width combinations a call can have: both lists INT64, both INT, or INT64 targets with INT neighbours
+template <typename F>
+void with_id_types(bool tgt64, bool nbr64, const void* targets, const void* neighbors, F&& f)
+{
+  if (tgt64 && nbr64) f(static_cast<const int64_t*>(targets), static_cast<const int64_t*>(neighbors));
+  else if (tgt64) f(static_cast<const int64_t*>(targets), static_cast<const int32_t*>(neighbors));
+  else if (!nbr64) f(static_cast<const int32_t*>(targets), static_cast<const int32_t*>(neighbors));
+  else throw logic_error("INT targets with INT64 neighbours: not a combination a hop produces");
 }
 
 }  // namespace
@@ -811,71 +855,58 @@ int64_t append_unique_slots(int64_t capacity)
   return slots;
 }
 
-void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+void append_unique_prepare_enqueue(const void* targets, dev_count T, bool tgt64, const void* neighbors, dev_count E, bool nbr64,
                                    batch_view bv, void* keys, int* minpos, int64_t slots, int* slot_of, int* rank,
                                    int* scan_tmp, hipStream_t stream)
 {
   const bool batched = bv.target_batch != nullptr;
   packed_layout lay{};
   static const bool no_lds = getenv("WGAMD_RENUMBER_NO_LDS") != nullptr;
+  // 32-bit neighbours promise ids below 2^31 whatever bound the caller stated
+  const int64_t bound = bv.id_bound > 0 ? bv.id_bound : (nbr64 ? 0 : ((int64_t)1 << 31));
   if (batched && !no_lds && bv.target_seg && bv.edge_offsets && bv.G > 1 &&
-      packed_layout_for((int64_t)T.host + E.host, 1, bv.id_bound, lay) &&
-      lds_scratch_fits((int64_t)T.host + E.host, bv.G, slots, ids64 ? 8 : 4)) {
-    if (ids64)
-      prepare_lds_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv, lay, keys,
-                             minpos, slot_of, rank, scan_tmp, stream);
-    else
-      prepare_lds_t<int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv, lay, keys,
-                             minpos, slot_of, rank, scan_tmp, stream);
+      packed_layout_for((int64_t)T.host + E.host, 1, bound, lay) && lds_scratch_fits((int64_t)T.host + E.host, bv.G, slots)) {
+    with_id_types(tgt64, nbr64, targets, neighbors, [&](auto* t, auto* n) {
+      prepare_lds_t(t, T, n, E, bv, lay, keys, minpos, slot_of, rank, scan_tmp, stream);
+    });
     return;
   }
-  if (batched && packed_layout_for((int64_t)T.host + E.host, bv.G, bv.id_bound, lay)) {
-    if (ids64)
-      prepare_packed_t<int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv, keys,
-                                slots, lay, slot_of, rank, scan_tmp, stream);
-    else
-      prepare_packed_t<int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv, keys,
-                                slots, lay, slot_of, rank, scan_tmp, stream);
+  if (batched && packed_layout_for((int64_t)T.host + E.host, bv.G, bound, lay)) {
+    with_id_types(tgt64, nbr64, targets, neighbors, [&](auto* t, auto* n) {
+      prepare_packed_t(t, T, n, E, bv, keys, slots, lay, slot_of, rank, scan_tmp, stream);
+    });
     return;
   }
-  if (ids64)
-    prepare_t<int64_t, int64_t>(static_cast<const int64_t*>(targets), T, static_cast<const int64_t*>(neighbors), E, bv,
-                                static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
-  else if (batched)
-    prepare_t<int32_t, int64_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv,
-                                static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
-  else
-    prepare_t<int32_t, int32_t>(static_cast<const int32_t*>(targets), T, static_cast<const int32_t*>(neighbors), E, bv,
-                                static_cast<int32_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+  with_id_types(tgt64, nbr64, targets, neighbors, [&](auto* t, auto* n) {
+    using TgtT = std::remove_cv_t<std::remove_pointer_t<decltype(t)>>;
+    if constexpr (sizeof(TgtT) == 4) {
+      if (!batched) {
+        prepare_t<int32_t, int32_t, int32_t>(t, T, n, E, bv, static_cast<int32_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+        return;
+      }
+    }
+    prepare_t(t, T, n, E, bv, static_cast<int64_t*>(keys), minpos, slots, slot_of, rank, scan_tmp, stream);
+  });
 }
 
-void append_unique_emit_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+void append_unique_emit_enqueue(const void* targets, dev_count T, bool tgt64, const void* neighbors, dev_count E, bool nbr64,
                                 batch_view bv, const int* minpos, const int* slot_of, const int* rank,
                                 void* unique_out, int* map_out, int* counts_out, hipStream_t stream)
 {
   const int P    = T.host + E.host;
   const int grid = ceil_div(P > bv.G + 1 ? P : bv.G + 1, 256);  // thread 0 publishes the counts, threads <= G the segments
-  if (bv.target_batch != nullptr && bv.target_seg && bv.edge_offsets && bv.G > 1) {
-    const int bgrid = std::max(batch_grid(bv.G, kEmitChunks), ceil_div(bv.G + 1, 256));
-    if (ids64)
-      renumber_emit_batched_kernel<int64_t><<<bgrid, 256, 0, stream>>>(static_cast<const int64_t*>(targets),
-                                                                      static_cast<const int64_t*>(neighbors), slot_of, rank, T, E,
-                                                                      bv, static_cast<int64_t*>(unique_out), map_out, counts_out);
+  const bool per_batch = bv.target_batch != nullptr && bv.target_seg && bv.edge_offsets && bv.G > 1;
+  const int bgrid = std::max(batch_grid(bv.G, kEmitChunks), ceil_div(bv.G + 1, 256));
+  with_id_types(tgt64, nbr64, targets, neighbors, [&](auto* t, auto* n) {
+    using TgtT = std::remove_cv_t<std::remove_pointer_t<decltype(t)>>;
+    using NbrT = std::remove_cv_t<std::remove_pointer_t<decltype(n)>>;
+    if (per_batch)
+      renumber_emit_batched_kernel<TgtT, NbrT><<<bgrid, 256, 0, stream>>>(t, n, slot_of, rank, T, E, bv, static_cast<TgtT*>(unique_out),
+                                                                         map_out, counts_out);
     else
-      renumber_emit_batched_kernel<int32_t><<<bgrid, 256, 0, stream>>>(static_cast<const int32_t*>(targets),
-                                                                      static_cast<const int32_t*>(neighbors), slot_of, rank, T, E,
-                                                                      bv, static_cast<int32_t*>(unique_out), map_out, counts_out);
-    WG_HIP_CHECK(hipGetLastError());
-    return;
-  }
-  if (ids64)
-    renumber_emit_kernel<int64_t><<<grid, 256, 0, stream>>>(static_cast<const int64_t*>(targets),
-                                                           static_cast<const int64_t*>(neighbors), minpos, slot_of, rank,
-                                                           T, E, bv, static_cast<int64_t*>(unique_out), map_out, counts_out);
-  else
-    renumber_emit_kernel<int32_t><<<grid, 256, 0, stream>>>(static_cast<const int32_t*>(targets),
-                                                           static_cast<const int32_t*>(neighbors), minpos, slot_of, rank,
-                                                           T, E, bv, static_cast<int32_t*>(unique_out), map_out, counts_out);
+      renumber_emit_kernel<TgtT, NbrT><<<grid, 256, 0, stream>>>(t, n, minpos, slot_of, rank, T, E, bv, static_cast<TgtT*>(unique_out),
+                                                                map_out, counts_out);
+  });
   WG_HIP_CHECK(hipGetLastError());
 }
 

@@ -349,10 +349,12 @@ struct batch_view {
   __host__ __device__ const int* sbatch() const { return sample_batch ? sample_batch : target_batch; }
   __host__ __device__ const int* sseg() const { return sample_seg ? sample_seg : target_seg; }
 };
-void append_unique_prepare_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+// `tgt64` / `nbr64`: width of the target (= unique, frontier: the API's id type) and of the neighbour list (the sampled
+// columns: INT when the CSR keeps 32-bit columns behind an INT64 API).  INT targets with INT64 neighbours are refused.
+void append_unique_prepare_enqueue(const void* targets, dev_count T, bool tgt64, const void* neighbors, dev_count E, bool nbr64,
                                    batch_view bv, void* keys, int* minpos, int64_t slots, int* slot_of, int* rank,
                                    int* scan_tmp, hipStream_t stream);
-void append_unique_emit_enqueue(const void* targets, dev_count T, const void* neighbors, dev_count E, bool ids64,
+void append_unique_emit_enqueue(const void* targets, dev_count T, bool tgt64, const void* neighbors, dev_count E, bool nbr64,
                                 batch_view bv, const int* minpos, const int* slot_of, const int* rank,
                                 void* unique_out, int* map_out, int* counts_out /*nullable: {E, T+U}*/,
                                 hipStream_t stream);

@@ -64,6 +64,7 @@ struct hop_args {
   const int64_t* csr_row_ptr;
   const void* csr_col;
   wholememory_dtype_t id_dtype;
+  bool col32 = false;   // WGAMD_HOP_COL_INT32: csr_col holds INT entries although id_dtype is INT64
   const void* targets;
   const int* n_targets_dev;
   int64_t target_cap;
@@ -95,8 +96,10 @@ void run_hop(hop_args a)
   WG_REQUIRE_INPUT(a.target_cap > 0 && s_cap > 0 && a.edge_cap >= s_cap * (int64_t)a.M, "edge_cap < sampled_cap * M");
   WG_REQUIRE_INPUT(a.target_cap + a.edge_cap < ((int64_t)1 << 30), "capacities too large for one call");
   const bool i64     = a.id_dtype == WHOLEMEMORY_DT_INT64;
+  const bool col64   = i64 && !a.col32;   // width of the column array = width of the sampled neighbour list
   const bool batched = a.bv.target_batch != nullptr;
   WG_REQUIRE_INPUT(a.csr_weight == nullptr || a.max_row_len > 0, "a biased hop needs max_row_len (the graph's maximum degree)");
+  // (the plan is sized for the id width whatever the column width: a caller need not know which one a hop will take)
   hop_workspace w    = plan(std::max(a.target_cap, s_cap), a.edge_cap, i64 ? 8 : 4, batched, a.csr_weight ? a.max_row_len : 0);
   WG_REQUIRE_INPUT(a.workspace_bytes >= w.total, "workspace too small: need %zu bytes", w.total);
   WG_REQUIRE_INPUT((reinterpret_cast<uintptr_t>(a.workspace) & 255) == 0, "workspace must be 256-byte aligned");
@@ -116,7 +119,7 @@ void run_hop(hop_args a)
     int* big_list = reinterpret_cast<int*>(base + w.big_list);
     weighted_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, big_list, st);
     exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
-    weighted_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, a.csr_weight, a.weight64, s_targets, i64, S, a.M, a.rng, a.offsets,
+    weighted_sample_enqueue(a.csr_row_ptr, a.csr_col, col64, a.csr_weight, a.weight64, s_targets, i64, S, a.M, a.rng, a.offsets,
                             big_list, reinterpret_cast<uint32_t*>(base + w.slab), w.slab_len, nbr, a.center_row, a.edge_gid,
                             st);
   } else {
@@ -124,15 +127,15 @@ void run_hop(hop_args a)
     int* row_deg       = reinterpret_cast<int*>(base + w.row_deg);
     sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st, row_start, row_deg);
     exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
-    uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, i64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
+    uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, col64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
                            a.edge_gid, st, row_start, row_deg);
   }
   dev_count E{(int)a.edge_cap, a.offsets + s_cap};
   batch_view bv   = a.bv;
   bv.edge_row     = a.center_row;
   bv.edge_offsets = a.offsets;
-  append_unique_prepare_enqueue(a.targets, T, nbr, E, i64, bv, keys, minpos, w.slots, slot_of, rank, scan_tmp, st);
-  append_unique_emit_enqueue(a.targets, T, nbr, E, i64, bv, minpos, slot_of, rank, a.unique, a.neighbor_row,
+  append_unique_prepare_enqueue(a.targets, T, i64, nbr, E, col64, bv, keys, minpos, w.slots, slot_of, rank, scan_tmp, st);
+  append_unique_emit_enqueue(a.targets, T, i64, nbr, E, col64, bv, minpos, slot_of, rank, a.unique, a.neighbor_row,
                              a.counts_dev, st);
 }
 
@@ -242,9 +245,12 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync_ex(
 {
   using namespace wgamd;
   return guarded("wgamd_sample_hop_batched_nosync", [&] {
-    WG_REQUIRE_INPUT((flags & ~WGAMD_HOP_NO_UNIQUE_PAD) == 0, "unknown flag bits");
-    WG_REQUIRE_INPUT(target_batch && target_seg && random_seeds_dev && center_row && unique_batch && unique_seg &&
-                       counts_dev,
+    WG_REQUIRE_INPUT((flags & ~(WGAMD_HOP_NO_UNIQUE_PAD | WGAMD_HOP_COL_INT32)) == 0, "unknown flag bits");
+    WG_REQUIRE_INPUT(!(flags & WGAMD_HOP_COL_INT32) || (id_dtype == WHOLEMEMORY_DT_INT64 && n_vertices > 0 &&
+                                                        n_vertices < ((int64_t)1 << 31)),
+                     "WGAMD_HOP_COL_INT32 needs INT64 ids and 0 < n_vertices < 2^31");
+    // unique_batch may be NULL: the batch of every unique entry is then not produced (the last hop of a walk)
+    WG_REQUIRE_INPUT(target_batch && target_seg && random_seeds_dev && center_row && unique_seg && counts_dev,
                      "null pointer");
     WG_REQUIRE_INPUT(n_batches >= 1 && n_batches < (1 << 20), "bad batch count");
     hop_args a{};
@@ -256,6 +262,7 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync_ex(
     a.bv.id_bound = n_vertices > 0 ? n_vertices : 0;
     a.bv.unique_batch = unique_batch; a.bv.unique_seg = unique_seg;
     a.bv.no_pad = (flags & WGAMD_HOP_NO_UNIQUE_PAD) ? 1 : 0;
+    a.col32     = (flags & WGAMD_HOP_COL_INT32) != 0;
     a.offsets = offsets; a.neighbor_row = neighbor_row; a.center_row = center_row; a.edge_gid = edge_gid;
     a.edge_cap = edge_cap; a.unique = unique; a.counts_dev = counts_dev; a.workspace = workspace;
     a.workspace_bytes = workspace_bytes; a.stream = static_cast<hipStream_t>(stream);
@@ -324,8 +331,12 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
     a.bv.frontier_out = p->frontier_out; a.bv.frontier_batch_out = p->frontier_out_batch;
     a.bv.frontier_seg_out = p->frontier_out_seg; a.bv.frontier_local0_out = p->frontier_out_local0;
     a.bv.neighbor_local_out = p->neighbor_local; a.bv.center_local_out = p->center_local;
-    WG_REQUIRE_INPUT((p->flags & ~WGAMD_HOP_NO_UNIQUE_PAD) == 0, "unknown flag bits");
+    WG_REQUIRE_INPUT((p->flags & ~(WGAMD_HOP_NO_UNIQUE_PAD | WGAMD_HOP_COL_INT32)) == 0, "unknown flag bits");
+    WG_REQUIRE_INPUT(!(p->flags & WGAMD_HOP_COL_INT32) || (p->id_dtype == WHOLEMEMORY_DT_INT64 && p->n_vertices > 0 &&
+                                                           p->n_vertices < ((int64_t)1 << 31)),
+                     "WGAMD_HOP_COL_INT32 needs INT64 ids and 0 < n_vertices < 2^31");
     a.bv.no_pad = (p->flags & WGAMD_HOP_NO_UNIQUE_PAD) ? 1 : 0;
+    a.col32     = (p->flags & WGAMD_HOP_COL_INT32) != 0;
     a.offsets = p->offsets; a.neighbor_row = p->neighbor_row_scratch; a.center_row = p->center_row_scratch;
     a.edge_gid = p->edge_gid; a.edge_cap = p->edge_cap; a.unique = p->nodes_out; a.counts_dev = p->counts_dev;
     a.workspace = p->workspace; a.workspace_bytes = p->workspace_bytes; a.stream = static_cast<hipStream_t>(stream);

@@ -15,6 +15,33 @@ from . import _lib as L
 from .env import get_stream, torch_dtype_to_wm
 
 
+HOP_NO_UNIQUE_PAD = 1   # WGAMD_HOP_NO_UNIQUE_PAD (include/wgamd_ext.h)
+HOP_COL_INT32 = 2       # WGAMD_HOP_COL_INT32
+
+_COL32 = {}             # (data_ptr, numel) -> (weakref to the int64 column tensor, its int32 copy)
+
+
+def compact_columns(col: torch.Tensor, n_vertices: int):
+    """The 32-bit twin of an int64 CSR column array whose ids all fit (``n_vertices < 2^31``: every BASELINE graph), made
+    once per column tensor and shared by every walk over it; ``None`` when there is nothing to compact.  The int64 API
+    stays what callers see (seeds, ``unique``, ``n_id`` are int64): the walk's kernels read the columns — 15 M random picks
+    per products call group, each its own 64-byte sector — from half the footprint and carry the sampled neighbours through
+    the renumber passes as 32-bit values (``WGAMD_HOP_COL_INT32``).  Costs 4 bytes per edge of extra HBM; the tensor must not
+    be modified in place afterwards."""
+    import weakref
+    if col.dtype != torch.int64 or not (0 < int(n_vertices) < (1 << 31)) or not col.is_cuda:
+        return None
+    key = (col.data_ptr(), col.numel())
+    hit = _COL32.get(key)
+    if hit is not None and hit[0]() is col:
+        return hit[1]
+    for k in [k for k, v in _COL32.items() if v[0]() is None]:
+        del _COL32[k]
+    c32 = col.to(torch.int32)
+    _COL32[key] = (weakref.ref(col), c32)
+    return c32
+
+
 @dataclass
 class WalkResult:
     """Capacity-sized outputs of one walk over a call group of ``n_batches`` mini-batches.
@@ -128,16 +155,21 @@ def _merge_hops_batch_major(fields_per_hop, segs_per_hop, G, dev):
 
 class NoSyncWalk:
     def __init__(self, csr_row_ptr: torch.Tensor, csr_col_ind: torch.Tensor, batch_size: int,
-                 max_neighbors: List[int], id_dtype=torch.int64, n_batches: int = 1, pad_unique: bool = True):
+                 max_neighbors: List[int], id_dtype=torch.int64, n_batches: int = 1, pad_unique: bool = True,
+                 compact_col: bool = True):
         """``pad_unique=False``: the capacity slack of every hop's ``unique`` list is left unwritten instead of padded with
         -1 (``WGAMD_HOP_NO_UNIQUE_PAD``) — for consumers that slice by ``counts`` / ``unique_seg``; the capacity is 3-4x the
-        live size, so the padding is most of what the renumber step writes."""
+        live size, so the padding is most of what the renumber step writes.  ``compact_col``: int64 columns of a graph
+        with fewer than 2^31 vertices are read through their 32-bit twin (``compact_columns``); same results."""
         assert csr_row_ptr.is_cuda and csr_col_ind.is_cuda
         assert all(m > 0 for m in max_neighbors), "the no-sync walk needs positive fan-outs"
         self.flags = 0 if pad_unique else HOP_NO_UNIQUE_PAD
         assert csr_col_ind.dtype == id_dtype, "no-sync walk: seeds and csr_col must share a dtype"
         self.row_ptr, self.col = csr_row_ptr, csr_col_ind
         self.n_vertices = int(csr_row_ptr.shape[0]) - 1     # every id is a row of the CSR
+        c32 = compact_columns(csr_col_ind, self.n_vertices) if compact_col else None
+        if c32 is not None:
+            self.col, self.flags = c32, self.flags | HOP_COL_INT32
         self.fanouts = list(max_neighbors)
         self.id_dtype = id_dtype
         self.wm_dtype = torch_dtype_to_wm(id_dtype)
@@ -194,12 +226,14 @@ class NoSyncWalk:
             nbr_row = torch.empty(ec, dtype=torch.int32, device=dev)
             ctr_row = torch.empty(ec, dtype=torch.int32, device=dev)
             unique = torch.empty(tc + ec, dtype=self.id_dtype, device=dev)
-            u_batch = torch.empty(tc + ec, dtype=torch.int32, device=dev)
+            # (the batch of every unique entry is the next hop's target_batch: the last hop's list has no reader)
+            u_batch = torch.empty(tc + ec, dtype=torch.int32, device=dev) if k + 1 < hops else None
             u_seg = torch.empty(self.G + 1, dtype=torch.int32, device=dev)
             L.check(lib.wgamd_sample_hop_batched_nosync_ex(
                 self.row_ptr.data_ptr(), self.col.data_ptr(), self.wm_dtype, targets.data_ptr(), t_batch.data_ptr(),
                 t_seg.data_ptr(), self.G, tc, m, rs[k].data_ptr(), offsets.data_ptr(), nbr_row.data_ptr(),
-                ctr_row.data_ptr(), None, ec, unique.data_ptr(), u_batch.data_ptr(), u_seg.data_ptr(),
+                ctr_row.data_ptr(), None, ec, unique.data_ptr(), None if u_batch is None else u_batch.data_ptr(),
+                u_seg.data_ptr(),
                 counts[k].data_ptr(), ws_ptr, self.ws_bytes, self.n_vertices, self.flags, stream),
                 "wgamd_sample_hop_batched_nosync_ex")
             res.unique.append(unique)
@@ -256,9 +290,6 @@ class SingleBatchNoSyncWalk:
 # PyG-style call-group walk (expand only the vertices first seen by the previous hop)
 # --------------------------------------------------------------------------------------------------
 import ctypes as _ct
-
-
-HOP_NO_UNIQUE_PAD = 1   # WGAMD_HOP_NO_UNIQUE_PAD (include/wgamd_ext.h)
 
 
 class _PygHop(_ct.Structure):
@@ -341,9 +372,10 @@ class PygNoSyncWalk:
     (SURVEY.md §8 row a14)."""
 
     def __init__(self, csr_row_ptr, csr_col_ind, batch_size: int, fanout: List[int], n_batches: int = 1,
-                 csr_weight: torch.Tensor = None, pad_unique: bool = True):
+                 csr_weight: torch.Tensor = None, pad_unique: bool = True, compact_col: bool = True):
         """``csr_weight`` (float32 | float64, one per CSR slot): BIASED sampling — every hop is then what
-        ``wholegraph_csr_weighted_sample_without_replacement`` draws (fan-outs <= 256).  ``pad_unique``: see ``NoSyncWalk``."""
+        ``wholegraph_csr_weighted_sample_without_replacement`` draws (fan-outs <= 256).  ``pad_unique`` / ``compact_col``:
+        see ``NoSyncWalk``."""
         self.flags = 0 if pad_unique else HOP_NO_UNIQUE_PAD
         assert csr_row_ptr.is_cuda and csr_col_ind.is_cuda and csr_col_ind.dtype in (torch.int32, torch.int64)
         assert all(0 < f for f in fanout), "the no-sync walk needs positive fan-outs"
@@ -355,6 +387,9 @@ class PygNoSyncWalk:
             self.max_row_len = max(int((csr_row_ptr[1:] - csr_row_ptr[:-1]).max()), 1) if csr_row_ptr.shape[0] > 1 else 1
         self.row_ptr, self.col = csr_row_ptr, csr_col_ind
         self.id_dtype, self.wm_dtype = csr_col_ind.dtype, torch_dtype_to_wm(csr_col_ind.dtype)
+        c32 = compact_columns(csr_col_ind, int(csr_row_ptr.shape[0]) - 1) if compact_col else None
+        if c32 is not None:
+            self.col, self.flags = c32, self.flags | HOP_COL_INT32
         self.G, self.B, self.fanout = int(n_batches), int(batch_size), [int(f) for f in fanout]
         dev = csr_row_ptr.device
         self.frontier_caps, self.edge_caps, self.node_caps = [], [], []
@@ -472,6 +507,8 @@ class HeteroPygWalk:
         self.seed_batch = torch.arange(self.G, dtype=torch.int32, device=dev).repeat_interleave(self.B).contiguous()
         self.zeros_g = torch.zeros(self.G, dtype=torch.int32, device=dev)
         self.zeros_g1 = torch.zeros(self.G + 1, dtype=torch.int32, device=dev)
+        # 32-bit twins of the column arrays (type-local ids of the SOURCE type) where that type's vertex count is known
+        self.col32 = {et: compact_columns(graphs[et].col, int(self.num_nodes.get(et[0], 0))) for et in self.etypes}
         self.max_row_len = {}
         if self.biased:   # per edge type: weights + maximum degree (sizes the key slabs of the biased hop)
             for et in self.etypes:
@@ -561,7 +598,8 @@ class HeteroPygWalk:
                 counts = torch.empty(2, **i32)
                 mrl = self.max_row_len.get(et, 0)
                 ws_ptr, ws_bytes = self._workspace(max(nc, fc), ec, mrl)
-                p = _PygHop(g.row_ptr.data_ptr(), g.col.data_ptr(), self.wm_dtype, G, m,
+                c32 = self.col32[et]
+                p = _PygHop(g.row_ptr.data_ptr(), (g.col if c32 is None else c32).data_ptr(), self.wm_dtype, G, m,
                             rs[h * len(self.etypes) + ti].data_ptr(),
                             st["nodes"].data_ptr(), st["batch"].data_ptr(), st["seg"].data_ptr(), nc,
                             f_ids.data_ptr(), f_batch.data_ptr(), f_seg.data_ptr(), f_l0.data_ptr(), fc,
@@ -572,7 +610,7 @@ class HeteroPygWalk:
                             g.weight.data_ptr() if self.biased else None,
                             torch_dtype_to_wm(g.weight.dtype) if self.biased else 0, mrl,
                             int(self.num_nodes.get(src_t, 0)),   # the renumbered ids are type-local ids of the SOURCE type
-                            self.flags)
+                            self.flags | (0 if c32 is None else HOP_COL_INT32))
                 L.check(lib.wgamd_sample_hop_pyg_nosync(_ct.byref(p), get_stream()), "wgamd_sample_hop_pyg_nosync")
                 keep += [scratch_r, scratch_c, f_out, f_out_batch, f_out_seg, f_out_l0, counts, f_ids, f_batch, f_l0,
                          st["nodes"], st["batch"], st["seg"]]

@@ -255,6 +255,12 @@ wholememory_error_code_t wgamd_sample_hop_batched_nosync(const int64_t* csr_row_
  * the padding is most of what the renumber step writes: walk 1.18 -> 1.09 ms per call group of 191 on the products-like graph.
  * Everything below the live end is identical with and without the flag. */
 #define WGAMD_HOP_NO_UNIQUE_PAD 1u
+/* WGAMD_HOP_COL_INT32: `csr_col` holds INT (32-bit) entries although id_dtype is WHOLEMEMORY_DT_INT64 — a graph with fewer
+ * than 2^31 vertices kept compact behind an INT64 API (needs 0 < n_vertices < 2^31).  Targets, `unique` and the frontier
+ * lists stay INT64; the sampled neighbours travel through the hop as 32-bit values (half the sector footprint of the
+ * sampler's random column picks, half the bytes of every renumber pass) and are widened where `unique` is written.  Same
+ * results as the INT64 column array, bit for bit.  In the _ex entry point `unique_batch` may be NULL (not produced). */
+#define WGAMD_HOP_COL_INT32 2u
 
 wholememory_error_code_t wgamd_sample_hop_batched_nosync_ex(const int64_t* csr_row_ptr,
                                                          const void* csr_col,
