@@ -468,7 +468,7 @@ bucket_sort_kernel(const TgtT* __restrict__ targets, dev_count T_, const NbrT* _
   const int T = T_.get(), tid = threadIdx.x;
   for (int r = tid; r < bp.R; r += kBucketThreads) hist[r] = 0;
   __syncthreads();
-  const int begin = c * bp.chunk, end = min(bp.P, begin + bp.chunk);
+  const int begin = min(c * bp.chunk, bp.P), end = min(bp.P, begin + bp.chunk);   // (a tiny batch leaves the last chunks empty)
   const TgtT* tg = targets + bp.t0;
   const NbrT* nb = neighbors + bp.e0 - bp.nT;   // neighbour of batch position i >= nT: nb[i]
   // ---- pass 1: the chunk's histogram over the batch's R hash ranges ------------------------------------------------

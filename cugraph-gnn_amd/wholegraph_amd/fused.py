@@ -252,7 +252,8 @@ class SingleBatchNoSyncWalk:
     C-ABI form of the walk and exercised by the tests next to the batched one."""
 
     def __init__(self, csr_row_ptr, csr_col_ind, batch_size, max_neighbors, id_dtype=torch.int64):
-        self.inner = NoSyncWalk(csr_row_ptr, csr_col_ind, batch_size, max_neighbors, id_dtype, 1)
+        # (the scalar-seed entry point has no flags argument: it reads the columns in the ids' own width)
+        self.inner = NoSyncWalk(csr_row_ptr, csr_col_ind, batch_size, max_neighbors, id_dtype, 1, compact_col=False)
 
     def run(self, seeds, random_seeds: Sequence[int]) -> WalkResult:
         w = self.inner

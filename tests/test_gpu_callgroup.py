@@ -19,16 +19,22 @@ def _check(oracle_mod, row_ptr, col, seeds_b, fanouts, rs_b, got):
 
 @pytest.mark.parametrize("G,B", [(1, 256), (5, 128), (16, 64), (3, 1)])
 @pytest.mark.parametrize("fanouts", [[25, 10], [15, 10, 5], [5]])
-@pytest.mark.parametrize("dtype", [np.int64, np.int32])
-def test_call_group_equals_per_batch_oracle(oracle_mod, hiplib, G, B, fanouts, dtype):
+@pytest.mark.parametrize("dtype,compact", [(np.int64, True), (np.int64, False), (np.int32, True)])
+def test_call_group_equals_per_batch_oracle(oracle_mod, hiplib, G, B, fanouts, dtype, compact):
+    """``compact``: int64 ids over the 32-bit twin of the column array (WGAMD_HOP_COL_INT32, the default for graphs below
+    2^31 vertices) — the same bits as the int64 columns and as the oracle."""
     import torch
-    from wholegraph_amd.fused import NoSyncWalk
+    from wholegraph_amd.fused import NoSyncWalk, HOP_COL_INT32
     row_ptr, col = powerlaw_csr(20000, 18, seed=4, col_dtype=dtype, max_deg=3000)
     rng = np.random.default_rng(G * 100 + B)
     seeds = np.concatenate([rng.permutation(20000)[:B] for _ in range(G)]).astype(dtype)  # batches overlap on purpose
     rs = [[1000 * k + b + 62 for b in range(G)] for k in range(len(fanouts))]
-    walk = NoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), B, fanouts, torch.from_numpy(seeds).dtype, G)
+    walk = NoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), B, fanouts, torch.from_numpy(seeds).dtype, G,
+                      compact_col=compact)
+    assert bool(walk.flags & HOP_COL_INT32) == (compact and dtype == np.int64)
+    assert walk.col.dtype == (torch.int32 if (compact or dtype == np.int32) else torch.int64)
     res = walk.run(torch.from_numpy(seeds).cuda(), rs)
+    assert all(u.dtype == torch.from_numpy(seeds).dtype for u in res.unique)      # the API's id width, whatever the columns'
     per_batch = res.finalize_batches()
     assert len(per_batch) == G
     for b in range(G):
@@ -160,12 +166,14 @@ import oracle
 from graphgen import powerlaw_csr
 from wholegraph_amd.fused import NoSyncWalk
 oracle.build()
-for dtype, G, B, fanouts in ((np.int32, 6, 256, [25, 10]), (np.int64, 3, 200, [15, 10, 5]), (np.int32, 9, 7, [5, 5])):
+for dtype, G, B, fanouts, compact in ((np.int32, 6, 256, [25, 10], True), (np.int64, 3, 200, [15, 10, 5], True),
+                                      (np.int64, 5, 300, [25, 10], False), (np.int32, 9, 7, [5, 5], True)):
     row_ptr, col = powerlaw_csr(30000, 18, seed=11, col_dtype=dtype, max_deg=3000)
     rng = np.random.default_rng(G + B)
     seeds = np.concatenate([rng.permutation(30000)[:B] for _ in range(G)]).astype(dtype)
     rs = [[500 * k + b + 3 for b in range(G)] for k in range(len(fanouts))]
-    walk = NoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), B, fanouts, torch.from_numpy(seeds).dtype, G)
+    walk = NoSyncWalk(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda(), B, fanouts, torch.from_numpy(seeds).dtype, G,
+                      compact_col=compact)
     per_batch = walk.run(torch.from_numpy(seeds).cuda(), rs).finalize_batches()
     for b in range(G):
         want = oracle.multilayer_sample(row_ptr, col, seeds[b * B:(b + 1) * B], fanouts, [rs[k][b] for k in range(len(fanouts))])
