@@ -253,6 +253,76 @@ class SagePipeline:
         return h, tuple(v for pair in sz for v in pair)
 
 
+def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, lazy_only=False):
+    """The same workload through the DROP-IN API: GraphStore + FeatureStore -> cugraph_pyg_amd NeighborLoader ->
+    wholegraph_amd.nn.SAGEConv x L forward (the surface of python/cugraph-pyg/cugraph_pyg/loader/node_loader.py:16-178 and
+    sampler/sampler.py:51-165).  `loader_api`: the epoch iterated in call groups (loader.call_groups(): one block-diagonal
+    graph per `local_seeds_per_call` seeds, lazy x — the table is read through n_id inside the first layer's kernel);
+    `loader_api_materialised`: the same with x = feat[n_id] gathered; `loader_api_per_batch`: the classic loop, one Data per
+    1024 seeds, x / edge_index into SAGEConv (every layer over all sampled edges, as plain PyG code does).  PyG sampling
+    semantics (a hop expands only the vertices the previous hop discovered), so a mini-batch has somewhat fewer edges than the
+    WholeGraph-style walk of the headline; values are its own sampled edges per second."""
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    dev, V = row_ptr.device, int(row_ptr.shape[0]) - 1
+    L = len(FANOUT)
+    gs, fs = GraphStore(), FeatureStore()
+    dst = torch.repeat_interleave(torch.arange(V, device=dev), row_ptr[1:] - row_ptr[:-1])
+    gs[("n", "e", "n"), "coo", False, (V, V)] = torch.stack([col.to(torch.int64), dst])   # PyG: row 0 = source (the neighbour)
+    del dst
+    fs["n", "x", None] = table
+    out = {}
+
+    def group_pass(lazy, n_warm=2):
+        loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_groups + n_warm) * G * BATCH], batch_size=BATCH,
+                                shuffle=False, random_state=62)
+        edges, t0, n = 0, None, 0
+        with torch.no_grad():
+            for grp in loader.call_groups():
+                if n == n_warm:
+                    torch.cuda.synchronize()
+                    t0, edges = time.perf_counter(), 0
+                h = grp.x if lazy else grp.node_attr("x", lazy=False)
+                for j, c in enumerate(convs):
+                    h = c(h, grp.layer_graph(j), act="relu" if j < L - 1 else None)
+                edges += grp.num_edges
+                n += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return edges / dt, dt / max(n - n_warm, 1) * 1e3, edges / max(n - n_warm, 1) / G
+
+    v, ms, epb = group_pass(True)
+    out["loader_api"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
+                         "note": "GraphStore + FeatureStore -> NeighborLoader.call_groups() (%d mini-batches per group, the loader's "
+                                 "default) -> nn.SAGEConv x %d forward; x lazy (table read through n_id in the layer-1 kernel)" % (G, L)}
+    if lazy_only:
+        return out
+    v, ms, epb = group_pass(False)
+    out["loader_api_materialised"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
+                                      "note": "the same loop with x = feat[n_id] gathered once per call group (wholememory_gather)"}
+    n_b, n_warm = 96, 16
+    loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_b + n_warm) * BATCH], batch_size=BATCH, shuffle=False,
+                            random_state=62)
+    edges, n, t0 = 0, 0, None
+    with torch.no_grad():
+        for batch in loader:
+            if n == n_warm:
+                torch.cuda.synchronize()
+                t0, edges = time.perf_counter(), 0
+            h = batch.x
+            for j, c in enumerate(convs):
+                h = c(h, batch.edge_index, act="relu" if j < L - 1 else None)
+            _ = h[:batch.batch_size]
+            edges += int(batch.edge_index.shape[1])
+            n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["loader_api_per_batch"] = {"value": edges / dt, "ms_per_batch": dt / max(n - n_warm, 1) * 1e3,
+                                   "note": "for batch in NeighborLoader: SAGEConv(batch.x, batch.edge_index) x %d, one Data per %d "
+                                           "seeds (%d timed mini-batches): bound by per-batch host work, not by the device" % (L, BATCH, n - n_warm)}
+    return out
+
+
 def masked_stream(device, first_cu, n_cus):
     """A HIP stream whose kernels may only occupy CUs [first_cu, first_cu + n_cus) of the CU-mask enumeration
     (hipExtStreamCreateWithCUMask), wrapped for torch.  The runtime spreads the bits of the mask over the XCDs, so a
@@ -699,6 +769,12 @@ def main():
                                              "headline: int64, the cugraph_pyg convention)"}
             batches = b64
             del pipe32
+        if world == 1 and not partitioned and not args.no_variants:
+            # the drop-in loader API on the same graph, table, weights and seed stream
+            try:
+                variants.update(loader_api_variants(row_ptr, col, feat.local_tensor, pipe.convs, order, min(groups, 24), G))
+            except Exception as exc:   # a variant must never cost the headline line
+                variants["loader_api"] = {"value": None, "error": repr(exc)[:300]}
         stage_n = max(10, min(groups, 20))
         stage_ms, psizes = probe_stages(pipe, head_mode, stage_n)
         # the BASELINE metric also names the stand-alone SAGEConv SpMM: time it (aggregate kernel + GEMM) when the

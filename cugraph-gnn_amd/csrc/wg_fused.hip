@@ -181,10 +181,57 @@ hetero_hop_rows_kernel(const int* __restrict__ offsets, const int* __restrict__ 
   }
 }
 
+// One hop of a homogeneous (or one edge type of a) PyG-style call group, renumbered for the LAYER that consumes it.  The
+// layer's input rows are laid out as `n_seg` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at
+// rows base[s] + start[s][b] + (local id - local0[s][b]) — one segment (start = the node-list offsets) is the batch-major
+// list of ALL vertices (x = feat[n_id]); the output of a trimmed layer is one segment per hop it ran (the hop's frontier
+// list, batch-major).  For frontier entry j of batch b the kernel writes the input row of the entry itself (self_rows[j]) and
+// of every one of its sampled neighbours (col[e]).  seg_tab: int32 [2 * n_seg, G + 1], row 2 s = local0[s], row 2 s + 1 =
+// start[s]; one 16-lane group per frontier entry.
+__global__ void __launch_bounds__(256)
+layer_cols_kernel(const int* __restrict__ offsets, const int* __restrict__ f_batch, const int* __restrict__ f_seg,
+                  const int* __restrict__ f_local0, const int* __restrict__ row_local, int n_f, int G, int n_seg,
+                  const int* __restrict__ seg_tab, const int64_t* __restrict__ seg_base, int64_t* __restrict__ self_rows,
+                  int* __restrict__ col)
+{
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j   = tid >> 4;
+  const int sub     = (int)(tid & 15);
+  if (j >= n_f) return;
+  const int b = f_batch[j];
+  auto row_of = [&](int local) -> int64_t {
+    int s = 0;
+    for (int k = 1; k < n_seg; k++) s = seg_tab[(int64_t)(2 * k) * (G + 1) + b] <= local ? k : s;
+    return seg_base[s] + seg_tab[(int64_t)(2 * s + 1) * (G + 1) + b] + (local - seg_tab[(int64_t)(2 * s) * (G + 1) + b]);
+  };
+  if (sub == 0 && self_rows) self_rows[j] = row_of(f_local0[b] + ((int)j - f_seg[b]));
+  const int s0 = offsets[j], e0 = offsets[j + 1];
+  for (int i = s0 + sub; i < e0; i += 16) col[i] = (int)row_of(row_local[i]);
+}
+
 }  // namespace
 }  // namespace wgamd
 
 extern "C" {
+
+wholememory_error_code_t wgamd_call_group_layer_cols(const int* offsets, const int* frontier_batch, const int* frontier_seg,
+                                                     const int* frontier_local0, const int* row_local, int64_t n_frontier,
+                                                     int n_batches, int n_segments, const int* seg_tab, const int64_t* seg_base,
+                                                     int64_t* self_rows, int* col, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_call_group_layer_cols", [&] {
+    WG_REQUIRE_INPUT(n_frontier >= 0 && n_frontier < ((int64_t)1 << 27), "bad frontier count");
+    WG_REQUIRE_INPUT(n_batches >= 1 && n_segments >= 1 && n_segments <= 16, "bad batch / segment count");
+    if (n_frontier == 0) return;
+    WG_REQUIRE_INPUT(offsets && frontier_batch && frontier_seg && frontier_local0 && row_local && seg_tab && seg_base && col,
+                     "null pointer");
+    layer_cols_kernel<<<ceil_div(n_frontier * 16, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      offsets, frontier_batch, frontier_seg, frontier_local0, row_local, (int)n_frontier, n_batches, n_segments, seg_tab,
+      seg_base, self_rows, col);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
 
 size_t wgamd_sample_hop_weighted_workspace_bytes(int64_t target_cap, int64_t edge_cap, wholememory_dtype_t id_dtype,
                                                  int64_t max_row_len)

@@ -1,0 +1,303 @@
+"""Call-group iteration of a ``NeighborLoader`` epoch: G mini-batches at a time as ONE block-diagonal graph.
+
+``cugraph_pyg`` already samples ``local_seeds_per_call`` seeds per library call and only then cuts the result into
+mini-batches (/root/reference/python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:279-343,391-410;
+sampler/sampler.py:51-165 hands them out one ``Data`` at a time).  On an MI355X a mini-batch of 1024 seeds is ~25 us of
+device work — less than the Python it takes to build its ``Data`` — so a loop that wants the device's speed consumes the call
+group as a whole, the way PyG batches small graphs (``torch_geometric.data.Batch``: node lists back to back, edge indices
+shifted): ``loader.call_groups()`` yields ``CallGroup`` objects whose ``x`` / ``edge_index`` / ``n_id`` cover all G
+mini-batches, ``batch_ptr`` says which rows belong to which mini-batch, and ``layer_graph(j)`` is the TRIMMED graph of layer j
+(what ``torch_geometric.utils.trim_to_layer`` computes from ``num_sampled_nodes`` / ``num_sampled_edges``) in the CSR form
+``wholegraph_amd.nn.SAGEConv`` takes.  Every mini-batch inside is bit for bit what ``for batch in loader`` yields
+(``to_data_list()``; tests/test_gpu_call_group_loader.py).
+
+``x`` is LAZY when the feature table lives whole on this device: a ``wholegraph_amd.nn.LazyRows`` (table + ``n_id``) that
+``nn.SAGEConv`` reads through directly, so the gathered ``[N, F]`` copy — the largest tensor of a mini-batch — never exists;
+any other use gathers it once.
+"""
+from typing import List, Optional
+
+import torch
+
+from wholegraph_amd import _lib as L
+from wholegraph_amd.env import get_stream
+from wholegraph_amd.nn import HopGraph, LayerGraph, LazyRows
+
+
+class CallGroup:
+    """G consecutive mini-batches of an epoch (``n_batches``), homogeneous graph, PyG sampling semantics.
+
+    Node rows are batch-major: mini-batch b owns rows ``[node_ptr[b], node_ptr[b+1])`` of ``n_id`` / ``x`` and its seeds are
+    the first rows of that stretch.  The model's output for the seeds is batch-major too: mini-batch b's seeds are rows
+    ``[batch_ptr[b], batch_ptr[b+1])`` of the last layer's output."""
+
+    def __init__(self, walk_result, feature_store, graph, first_batch: int, input_id: torch.Tensor, sizes_h: torch.Tensor,
+                 event, walk_stream):
+        self._res, self._fs, self._graph = walk_result, feature_store, graph
+        self.first_batch, self.n_batches, self.hops = first_batch, walk_result.n_batches, walk_result.hops
+        self.input_id = input_id
+        self._sizes_h, self._event, self._walk_stream = sizes_h, event, walk_stream
+        self._ready = False
+        self._layers = {}
+        self._edge_index = self._e_id = None
+
+    # ---- sizes: one pinned read-back per call group ----------------------------------------------------------------
+    def _wait(self):
+        if self._ready:
+            return
+        self._event.synchronize()
+        v = self._sizes_h.tolist()
+        H = self.hops
+        self.num_nodes = v[0]
+        self._n_front = v[1:2 + H]            # live entries of frontier k (k = 0: the seeds); [H]: new vertices of the last hop
+        self._n_edges = v[2 + H:2 + 2 * H]
+        self.num_edges = sum(self._n_edges)
+        self.num_seeds = self._n_front[0]
+        if self._walk_stream is not None:     # allocated on the walk stream, consumed on the caller's
+            main = torch.cuda.current_stream()
+            r = self._res
+            for t in [r.nodes, r.node_seg] + r.offsets + r.row_local + r.col_local + r.edge_gid + r.frontier_seg + \
+                    r.frontier_batch + r.frontier_local0:
+                t.record_stream(main)
+        self._ready = True
+
+    # ---- nodes -----------------------------------------------------------------------------------------------------
+    @property
+    def n_id(self) -> torch.Tensor:
+        self._wait()
+        return self._res.nodes[:self.num_nodes]
+
+    @property
+    def node_ptr(self) -> torch.Tensor:
+        """int32 [G + 1]: rows of mini-batch b in ``n_id`` / ``x``."""
+        return self._res.node_seg
+
+    @property
+    def batch_ptr(self) -> torch.Tensor:
+        """int32 [G + 1]: rows of mini-batch b's seeds in the model output (and in ``input_id``)."""
+        return self._res.frontier_seg[0]
+
+    @property
+    def batch(self) -> torch.Tensor:
+        """The seeds of all mini-batches (global ids), batch-major — ``Data.batch`` of every mini-batch back to back."""
+        self._wait()
+        seg = self._res.node_seg[:-1].long()
+        cnt = (self._res.frontier_seg[0][1:] - self._res.frontier_seg[0][:-1]).long()
+        rows = torch.repeat_interleave(seg - self._res.frontier_seg[0][:-1].long(), cnt, output_size=self.num_seeds) + \
+            torch.arange(self.num_seeds, device=seg.device)
+        return self._res.nodes[rows]
+
+    def node_attr(self, name: str, group_name=None, lazy: bool = True):
+        """A stored node attribute for all rows of the call group: ``LazyRows`` (table + ``n_id``, nothing gathered) when
+        the table is a float32 matrix held whole on this device and ``lazy``; the gathered rows otherwise (one fetch per
+        call group — a collective when the FeatureStore is partitioned)."""
+        from ..sampler.sampler import _fetch_rows_agreed
+        self._wait()
+        if group_name is None:
+            names = sorted({a.group_name for a in self._fs.get_all_tensor_attrs()
+                            if a.attr_name == name and not isinstance(a.group_name, tuple)})
+            if len(names) != 1:
+                raise KeyError(f"node attribute {name!r}: found in groups {names}")
+            group_name = names[0]
+        t = self._fs[group_name, name, None]
+        wm = getattr(t, "_tensor", None)
+        table = getattr(wm, "local_tensor", None)
+        if (lazy and table is not None and not getattr(wm, "is_distributed", True) and table.is_cuda and table.dim() == 2
+                and table.dtype == torch.float32 and table.stride(1) == 1):
+            return LazyRows(table, self.n_id)
+        return _fetch_rows_agreed(t, self.n_id)
+
+    @property
+    def x(self):
+        return self.node_attr("x")
+
+    @property
+    def y(self):
+        return self.node_attr("y", lazy=False)
+
+    # ---- edges -----------------------------------------------------------------------------------------------------
+    def layer_graph(self, layer: int) -> LayerGraph:
+        """The hops layer ``layer`` (0 = the one that reads ``x``) of an H-layer model runs over, trimmed: layer j
+        computes rows only for the vertices the seeds can still see through the layers after it — the vertices discovered
+        by hops < H - j — from the edges of hops <= H - 1 - j (``trim_to_layer``).  Its output rows: the seeds of all
+        mini-batches first (batch-major), then the vertices discovered by hop 0, hop 1, ... (each batch-major); the LAST
+        layer's output is exactly the seeds' rows.  ``col`` / ``self_rows`` of a hop index the layer's input: ``x`` for layer
+        0, the previous layer's output otherwise."""
+        self._wait()
+        H, G, res = self.hops, self.n_batches, self._res
+        if not 0 <= layer < H:
+            raise IndexError(f"layer {layer} of a {H}-hop call group")
+        if layer in self._layers:
+            return self._layers[layer]
+        dev = res.nodes.device
+        if layer == 0:
+            zeros = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+            seg_tab = torch.stack([zeros, res.node_seg.to(torch.int32)]).contiguous()
+            seg_base = torch.zeros(1, dtype=torch.int64, device=dev)
+            n_seg = 1
+        else:
+            ran = list(range(H - layer + 1))              # the hops the previous layer ran = the segments of its output
+            rows, base, at = [], [], 0
+            for k in ran:
+                l0 = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+                l0[:G] = res.frontier_local0[k]
+                rows += [l0, res.frontier_seg[k].to(torch.int32)]
+                base.append(at)
+                at += self._n_front[k]
+            seg_tab = torch.stack(rows).contiguous()
+            seg_base = torch.tensor(base, dtype=torch.int64, device=dev)
+            n_seg = len(ran)
+        hops = []
+        for k in range(H - layer):
+            n_f, n_e = self._n_front[k], self._n_edges[k]
+            self_rows = torch.empty(n_f, dtype=torch.int64, device=dev)
+            col = torch.empty(max(n_e, 1), dtype=torch.int32, device=dev)
+            L.check(L.lib().wgamd_call_group_layer_cols(
+                res.offsets[k].data_ptr(), res.frontier_batch[k].data_ptr(), res.frontier_seg[k].data_ptr(),
+                res.frontier_local0[k].data_ptr(), res.row_local[k].data_ptr(), n_f, G, n_seg, seg_tab.data_ptr(),
+                seg_base.data_ptr(), self_rows.data_ptr(), col.data_ptr(), get_stream()), "wgamd_call_group_layer_cols")
+            hops.append(HopGraph(res.offsets[k][:n_f + 1], col[:n_e], self_rows))
+        lg = LayerGraph(hops)
+        lg._keep = (seg_tab, seg_base)
+        self._layers[layer] = lg
+        return lg
+
+    def _coo(self):
+        """All sampled edges, hop-major, as rows of ``n_id``: (source row, destination row, CSR slot)."""
+        self._wait()
+        if self._edge_index is None:
+            res, G = self._res, self.n_batches
+            src, dst, gid = [], [], []
+            node0 = res.node_seg[:-1].long()
+            for k in range(self.hops):
+                n_f, n_e = self._n_front[k], self._n_edges[k]
+                deg = (res.offsets[k][1:n_f + 1] - res.offsets[k][:n_f]).long()
+                b_of_e = torch.repeat_interleave(res.frontier_batch[k][:n_f].long(), deg, output_size=n_e)
+                src.append(res.row_local[k][:n_e].long() + node0[b_of_e])
+                dst.append(res.col_local[k][:n_e].long() + node0[b_of_e])
+                gid.append(res.edge_gid[k][:n_e])
+            self._edge_index = torch.stack([torch.cat(src), torch.cat(dst)])
+            g = torch.cat(gid)
+            self._e_id = self._graph.edge_id[g] if self._graph.edge_id is not None else g
+        return self._edge_index, self._e_id
+
+    @property
+    def edge_index(self) -> torch.Tensor:
+        """int64 [2, E]: PyG convention (row 0 = source = the sampled neighbour, row 1 = destination), rows of ``n_id``, all
+        mini-batches, hop-major — the block-diagonal union of every mini-batch's ``edge_index``."""
+        return self._coo()[0]
+
+    @property
+    def e_id(self) -> torch.Tensor:
+        return self._coo()[1]
+
+    @property
+    def num_sampled_edges(self) -> List[int]:
+        """Edges per hop, summed over the mini-batches."""
+        self._wait()
+        return list(self._n_edges)
+
+    @property
+    def num_sampled_nodes(self) -> List[int]:
+        """Vertices per hop (seeds first), summed over the mini-batches."""
+        self._wait()
+        return list(self._n_front)
+
+    # ---- the mini-batches one at a time --------------------------------------------------------------------------------
+    def to_data_list(self):
+        """The G mini-batches as the ``Data`` objects ``for batch in loader`` yields (same tensors, bit for bit)."""
+        from ..sampler.sampler import filter_store_from_group, group_attribute_views
+        self._wait()
+        outs = self._res.finalize_batches(self._graph.edge_id)
+        views = group_attribute_views(self._fs, self._res.group_context)
+        datas, seed_ptr = [], self._res.frontier_seg[0].tolist()
+        for j, (node, row, col, edge, nn, ne) in enumerate(outs):
+            d = filter_store_from_group(self._fs, views, j, node, row, col, edge)
+            d.n_id, d.e_id = node, edge.to(torch.long)
+            d.batch = node[:nn[0]]
+            d.num_sampled_nodes, d.num_sampled_edges = torch.tensor(nn), torch.tensor(ne)
+            d.input_id = self.input_id[seed_ptr[j]:seed_ptr[j + 1]]
+            d.batch_size = d.input_id.size(0)
+            datas.append(d)
+        return datas
+
+
+class CallGroupIterator:
+    """Software-pipelined: the walk of call group g + 1 is enqueued (on its own HIP stream) before group g is handed out, so
+    the device never waits for the host's read-back of group g's sizes."""
+
+    def __init__(self, data, core_sampler, input_data, random_state: int, batch_size: int, overlap: bool = True):
+        from ..sampler.sampler import HeteroNeighborSampler
+        self._fs, self._gs = data
+        self._smp, self._B, self._rs = core_sampler, int(batch_size), int(random_state)
+        if isinstance(core_sampler, HeteroNeighborSampler):
+            raise NotImplementedError("call_groups(): homogeneous graphs (heterogeneous loaders iterate per mini-batch)")
+        if input_data.time is not None or not core_sampler.call_groups_ok() or not input_data.node.is_cuda:
+            raise NotImplementedError("call_groups(): uniform or positively-weighted sampling with positive fan-outs, no "
+                                      "replacement, not disjoint / temporal, seeds on the device")
+        self._seeds = input_data.node.to(core_sampler.graph.col.dtype)
+        self._input_id = input_data.input_id
+        n, B = int(self._seeds.shape[0]), self._B
+        G = max(1, core_sampler.seeds_per_call(B) // B)
+        n_full = n // B
+        # (first batch, batches, seeds of the ragged last one or None)
+        self._plan = [(b, min(G, n_full - b), None) for b in range(0, n_full, G)]
+        if n % B:
+            self._plan.append((n_full, 1, n - n_full * B))
+        self._stream = torch.cuda.Stream(device=self._seeds.device) if overlap else None
+        self._at, self._pending = 0, None
+
+    def __len__(self):
+        return len(self._plan)
+
+    def __iter__(self):
+        return self
+
+    def _launch(self, i) -> Optional[CallGroup]:
+        from ..sampler.sampler import hop_seed
+        if i >= len(self._plan):
+            return None
+        b0, g, ragged = self._plan[i]
+        smp, B, dev = self._smp, self._B, self._seeds.device
+        H = len(smp.fanout)
+        rs = [[hop_seed(self._rs + b0 + j, k) for j in range(g)] for k in range(H)]
+        walk = smp._call_group_walk(B, g)
+
+        def enqueue():
+            if ragged is None:
+                res = walk.run(self._seeds[b0 * B:(b0 + g) * B].contiguous(), rs)
+                n_seeds = g * B
+            else:   # the last, short mini-batch: a one-batch group over a ragged seed list
+                ids = torch.zeros(B, dtype=self._seeds.dtype, device=dev)
+                ids[:ragged] = self._seeds[b0 * B:b0 * B + ragged]
+                seg = torch.tensor([0, ragged], dtype=torch.int32, device=dev)
+                res = walk.run(ids, rs, seg, torch.zeros(B, dtype=torch.int32, device=dev))
+                n_seeds = ragged
+            G_ = res.n_batches
+            pieces = [res.node_seg[G_:G_ + 1]] + [res.frontier_seg[k][G_:G_ + 1] for k in range(H + 1)]
+            pieces += [res.offsets[k][res.frontier_seg[k][G_:G_ + 1].long()] for k in range(H)]
+            sizes_d = torch.cat([p.to(torch.int32).reshape(-1) for p in pieces])
+            sizes_h = torch.empty(sizes_d.shape, dtype=torch.int32, pin_memory=True)
+            sizes_h.copy_(sizes_d, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return res, sizes_h, ev, n_seeds
+
+        if self._stream is None:
+            res, sizes_h, ev, n_seeds = enqueue()
+        else:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                res, sizes_h, ev, n_seeds = enqueue()
+        return CallGroup(res, self._fs, smp.graph, b0, self._input_id[b0 * B:b0 * B + n_seeds], sizes_h, ev, self._stream)
+
+    def __next__(self) -> CallGroup:
+        if self._at == 0 and self._pending is None:
+            self._pending = self._launch(0)
+        cur = self._pending
+        if cur is None:
+            raise StopIteration
+        self._at += 1
+        self._pending = self._launch(self._at)     # group g + 1 is on the device before the host blocks on group g
+        cur._wait()
+        return cur

@@ -82,6 +82,24 @@ class NodeLoader:
         seed = self.__random_state if self.__random_state is not None else generate_seed()
         return SampleIterator(self.__data, self.__node_sampler.sample_from_nodes(input_data, random_state=seed))
 
+    def call_groups(self, overlap: bool = True):
+        """The same epoch as ``iter(self)`` — same shuffle, same seeds, same samples — handed out in CALL GROUPS:
+        ``local_seeds_per_call`` seeds (by default sized from device memory) per ``CallGroup``, each the block-diagonal
+        union of its mini-batches with a lazy ``x`` and per-layer trimmed graphs (``loader/call_group.py``).  For loops
+        that want the device's speed rather than one ``Data`` per 1024 seeds.  Homogeneous graphs."""
+        from .call_group import CallGroupIterator
+        n = self.__input_data.node.numel()
+        perm = torch.randperm(n) if self.__shuffle else torch.arange(n)
+        if self.__drop_last and n % self.__batch_size > 0:
+            perm = perm[: n - n % self.__batch_size]
+        perm = perm.to(self.__input_data.node.device)
+        input_data = NodeSamplerInput(
+            input_id=self.__input_data.input_id[perm], node=self.__input_data.node[perm],
+            time=None if self.__input_data.time is None else self.__input_data.time[perm],
+            input_type=self.__input_data.input_type)
+        seed = self.__random_state if self.__random_state is not None else generate_seed()
+        return CallGroupIterator(self.__data, self.__node_sampler.core, input_data, seed, self.__batch_size, overlap=overlap)
+
     def __len__(self):
         if not self.__has_explicit_input_nodes:
             raise ValueError("len(loader) is only supported when the loader was constructed with an explicit "

@@ -661,6 +661,11 @@ class BaseSampler:
         if self.__feature_store is not None and hasattr(sampler, "feature_row_bytes"):
             sampler.feature_row_bytes = store_row_bytes(self.__feature_store)
 
+    @property
+    def core(self):
+        """The sampler that does the work (``NeighborSampler`` / ``HeteroNeighborSampler``)."""
+        return self.__sampler
+
     def sample_from_nodes(self, index: NodeSamplerInput, random_state: int = 62, **kwargs) -> Iterator[SamplerOutput]:
         """Iterator of ``SamplerOutput`` (sampler.py:756-797).  It also carries the epoch's FETCH PLAN: how many feature
         fetches per call group / per single batch this rank will make, MAX-reduced over the ranks when the FeatureStore is

@@ -254,6 +254,7 @@ SYMBOLS = {
     "wgamd_gat_csr_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int,
                                   c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_call_group_hop_rows": (c_int, [c_void_p] * 5 + [c_int64] + [c_void_p] * 8 + [c_void_p]),
+    "wgamd_call_group_layer_cols": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 5),
     "wgamd_bias_act_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_aggregate_heads_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                               c_float, c_void_p, c_void_p, c_int64, c_void_p]),

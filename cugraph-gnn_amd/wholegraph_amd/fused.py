@@ -328,6 +328,8 @@ class PygWalkResult:
     col_local: List[torch.Tensor] = field(default_factory=list)
     edge_gid: List[torch.Tensor] = field(default_factory=list)
     frontier_seg: List[torch.Tensor] = field(default_factory=list)
+    frontier_batch: List[torch.Tensor] = field(default_factory=list)    # int32 [frontier_cap] batch of every frontier entry
+    frontier_local0: List[torch.Tensor] = field(default_factory=list)   # int32 [G] local id of a batch's first frontier entry
     counts: torch.Tensor = None
 
     def finalize_batches(self, edge_id: torch.Tensor = None):
@@ -465,6 +467,8 @@ class PygNoSyncWalk:
             res.col_local.append(col_l)
             res.edge_gid.append(gid)
             res.frontier_seg.append(f_seg)
+            res.frontier_batch.append(f_batch)
+            res.frontier_local0.append(f_local0)
             res._keepalive += [scratch_r, scratch_c, f_batch, n_batch, front, f_local0]
             nodes, n_batch, n_seg = nodes_out, nodes_out_batch, nodes_out_seg
             front, f_batch, f_seg, f_local0 = f_out, f_out_batch, f_out_seg, f_out_l0

@@ -473,8 +473,85 @@ def _split_graph(graph, n_dst):
     return _to_csr(graph, n_dst)           # COO edge_index
 
 
+class LazyRows:
+    """``table[ids]`` that has not been gathered: what ``batch.x`` of a loader call group is when the feature table lives
+    whole on this device (single GPU, or replicated).  ``nn.SAGEConv`` consumes it as it is — its first-layer kernel reads
+    the table through ``ids`` (``src_ids`` of ``wgamd_sage_layer_fused_*``), so the ``[n, F]`` copy of the rows, the
+    largest tensor of a mini-batch, is never written to HBM nor read back.  Anything else calls ``materialize()`` (one
+    ``wholememory_gather``) or just uses it as a tensor: ``torch`` functions receive the gathered rows."""
+
+    def __init__(self, table: torch.Tensor, ids: torch.Tensor):
+        assert table.dim() == 2 and ids.dim() == 1 and ids.dtype in (torch.int32, torch.int64)
+        self.table, self.ids, self._rows = table, ids.contiguous(), None
+
+    @property
+    def shape(self):
+        return torch.Size((self.ids.shape[0], self.table.shape[1]))
+
+    @property
+    def dtype(self):
+        return self.table.dtype
+
+    @property
+    def device(self):
+        return self.table.device
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    def materialize(self) -> torch.Tensor:
+        if self._rows is None:
+            from .tensor import local_gather
+            self._rows = local_gather(self.table, self.ids, torch.empty(tuple(self.shape), dtype=self.table.dtype,
+                                                                        device=self.table.device))
+        return self._rows
+
+    def __getitem__(self, index):
+        return self.materialize()[index]
+
+    def __len__(self):
+        return int(self.ids.shape[0])
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        conv = lambda v: v.materialize() if isinstance(v, LazyRows) else v   # noqa: E731
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+
+class HopGraph:
+    """One sampled hop as a layer consumes it: CSR over the hop's destination rows (``row_ptr`` int32 [n + 1]), ``col`` int32
+    = row of every edge's source IN THE LAYER'S INPUT, ``self_rows`` int64 [n] = input row of every destination itself."""
+
+    def __init__(self, row_ptr, col, self_rows):
+        self.row_ptr, self.col, self.self_rows = row_ptr, col, self_rows
+
+    @property
+    def n_rows(self):
+        return int(self.row_ptr.shape[0]) - 1
+
+
+class LayerGraph:
+    """The hops ONE layer of a trimmed GNN runs over (``cugraph_pyg_amd.loader.CallGroup.layer_graph``): the layer's output
+    is the hops' destination lists back to back — hop h's rows start at ``sum(n_rows of the hops before it)``."""
+
+    def __init__(self, hops):
+        self.hops = list(hops)
+
+    @property
+    def n_rows(self):
+        return sum(h.n_rows for h in self.hops)
+
+
 class SAGEConv(torch.nn.Module):
-    """``out = lin_l(mean_{j in N(i)} x_j) + lin_r(x_i)`` (PyG ``SAGEConv``, aggr mean|sum)."""
+    """``out = lin_l(mean_{j in N(i)} x_j) + lin_r(x_i)`` (PyG ``SAGEConv``, aggr mean|sum).
+
+    ``forward(x, graph)``: ``graph`` = the hop's ``[csr_row_ptr, csr_col_ind]`` or a COO ``edge_index`` (the reference's call
+    shapes, gnn_model.py:178-199), or a ``LayerGraph`` of a loader call group — then the whole layer (feature fetch when
+    ``x`` is a ``LazyRows``, aggregation, both linear maps, bias and the optional ``act="relu"``) is ONE kernel per hop
+    (``wgamd_sage_layer_fused_*``) where the shape allows it, aggregation kernel + library GEMM otherwise."""
 
     def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int, aggr: str = "mean",
                  root_weight: bool = True, bias: bool = True):
@@ -484,14 +561,58 @@ class SAGEConv(torch.nn.Module):
         self.in_channels, self.out_channels, self.aggr, self.root_weight = in_channels, out_channels, aggr, root_weight
         self.lin_l = torch.nn.Linear(in_channels[0], out_channels, bias=bias)
         self.lin_r = torch.nn.Linear(in_channels[1], out_channels, bias=False) if root_weight else None
+        self._w_t = None
 
-    def forward(self, x, graph):
+    def _weight_t(self):
+        """``cat([W_l, W_r], 1).t()`` ([2F, N]) for the one-kernel layer, rebuilt when a weight changed."""
+        wl, wr = self.lin_l.weight, self.lin_r.weight
+        key = (wl._version, wl.data_ptr(), wr._version, wr.data_ptr())
+        if self._w_t is None or self._w_t[0] != key:
+            self._w_t = (key, torch.cat([wl.detach(), wr.detach()], dim=1).t().contiguous())
+        return self._w_t[1]
+
+    def _forward_layer(self, x, graph: LayerGraph, act=None):
+        lazy = isinstance(x, LazyRows)
+        src = x.table if lazy else x
+        F_, N = src.shape[1], self.out_channels
+        relu = act == "relu"
+        assert act in (None, "relu"), "act: None or 'relu'"
+        one_kernel = (self.lin_r is not None and self.aggr in ("mean", "sum") and src.dtype == torch.float32 and src.is_cuda
+                      and not torch.is_grad_enabled() and sage_layer_fused_preferred(F_, N))
+        if not one_kernel:
+            # aggregation kernel(s) + library GEMM: every hop's [mean | self] rows, then lin_l / lin_r as torch modules
+            xd = x.materialize() if lazy else x
+            outs = []
+            for h in graph.hops:
+                agg = spmm_csr(xd, h.row_ptr, h.col, self.aggr)
+                o = self.lin_l(agg)
+                if self.lin_r is not None:
+                    o = o + self.lin_r(xd[h.self_rows])
+                outs.append(o)
+            out = outs[0] if len(outs) == 1 else torch.cat(outs)
+            return torch.relu_(out) if relu else out
+        Np = _padded_width(N)
+        buf = torch.empty((graph.n_rows, Np), dtype=torch.float32, device=src.device)
+        w_t, at = self._weight_t(), 0
+        for h in graph.hops:
+            n = h.n_rows
+            if n > 0:
+                sage_layer_fused_forward(h.row_ptr, h.col, src, h.self_rows, w_t, self.lin_l.bias, relu=relu,
+                                         mean=self.aggr == "mean", src_ids=x.ids if lazy else None, out=buf[at:at + n, :N])
+            at += n
+        return buf[:, :N]
+
+    def forward(self, x, graph, act=None):
+        if isinstance(graph, LayerGraph):
+            return self._forward_layer(x, graph, act)
+        if isinstance(x, LazyRows):
+            x = x.materialize()
         x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
         row_ptr, col = _split_graph(graph, x_dst.shape[0])
         out = self.lin_l(spmm_csr(x_src, row_ptr, col, self.aggr))
         if self.lin_r is not None:
             out = out + self.lin_r(x_dst[: out.shape[0]])
-        return out
+        return torch.relu_(out) if act == "relu" else out
 
 
 class GATConv(torch.nn.Module):

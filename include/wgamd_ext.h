@@ -375,6 +375,18 @@ wholememory_error_code_t wgamd_call_group_hop_rows(const int* offsets, const int
                                                    const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
                                                    int* col_full, int* col_compact, void* stream);
 
+/* One hop of a PyG-style call group renumbered for the LAYER that consumes it (cugraph_pyg_amd.loader.CallGroup).  The
+ * layer's input rows are `n_segments` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at rows
+ * seg_base[s] + start[s][b] + (local id - local0[s][b]); seg_tab is int32 [2 n_segments, n_batches + 1] with row 2s =
+ * local0[s], row 2s + 1 = start[s].  One segment whose start = the node-list offsets is the batch-major list of all
+ * vertices (x = feat[n_id]); the output of a trimmed layer is one segment per hop it ran (that hop's frontier list).
+ * Writes self_rows[j] (int64, nullable) = input row of frontier entry j itself (local id frontier_local0[b] + j -
+ * frontier_seg[b]) and col[e] = input row of edge e's sampled neighbour (row_local[e] = the hop's `neighbor_local`). */
+wholememory_error_code_t wgamd_call_group_layer_cols(const int* offsets, const int* frontier_batch, const int* frontier_seg,
+                                                     const int* frontier_local0, const int* row_local, int64_t n_frontier,
+                                                     int n_batches, int n_segments, const int* seg_tab, const int64_t* seg_base,
+                                                     int64_t* self_rows, int* col, void* stream);
+
 /* wgamd_gat_csr_f32 over a SUBSET of a larger destination list, optionally accumulating: row i of this launch reads
  * a_dst[dst_rows[i], :] and writes (accumulate: adds to) out[dst_rows[i], :].  This is one hop and edge type of a
  * heterogeneous call group: its rows are the frontier entries of that hop, dst_rows their places in the node list of the

@@ -1,0 +1,159 @@
+"""GPU: ``NeighborLoader.call_groups()`` — an epoch handed out as block-diagonal call groups
+(cugraph_pyg_amd/loader/call_group.py; the reference samples ``local_seeds_per_call`` seeds per library call and hands out one
+``Data`` per mini-batch, python/cugraph-pyg/cugraph_pyg/loader/node_loader.py:16-178, sampler/sampler.py:51-165).
+
+* every mini-batch inside a call group is bit for bit what ``for batch in loader`` yields (and what the oracle gives);
+* the LAZY ``x`` (table + ``n_id``, never gathered) through ``nn.SAGEConv`` equals the gathered ``x`` bit for bit;
+* the trimmed two- and three-layer forward over a call group equals, for every seed, the plain PyG formulation — each layer
+  over ALL sampled edges of that seed's mini-batch, untrimmed — computed in float64 on the CPU (rtol 1e-5)."""
+import numpy as np
+import pytest
+
+from graphgen import powerlaw_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _stores(V, deg, F, seed=3):
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    row_ptr, col = powerlaw_csr(V, deg, seed=seed, max_deg=600)
+    dst = np.repeat(np.arange(V), np.diff(row_ptr))
+    gs, fs = GraphStore(), FeatureStore()
+    gs[("n", "e", "n"), "coo", False, (V, V)] = torch.stack([torch.from_numpy(col.astype(np.int64)), torch.from_numpy(dst)]).cuda()
+    feat = torch.from_numpy(np.random.default_rng(seed).standard_normal((V, F)).astype(np.float32))
+    fs["n", "x", None] = feat.cuda()
+    fs["n", "y", None] = torch.arange(V, dtype=torch.int64).cuda()
+    return gs, fs, feat
+
+
+def _model(dims, dev, seed=5):
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator().manual_seed(seed)
+    convs = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        c = nn.SAGEConv(a, b)
+        for p in c.parameters():
+            p.data = (torch.rand(p.shape, generator=g) - 0.5) * 0.4
+        convs.append(c.to(dev))
+    return convs
+
+
+def _forward(convs, group, x):
+    import torch
+    with torch.no_grad():
+        h = x
+        for j, c in enumerate(convs):
+            h = c(h, group.layer_graph(j), act="relu" if j + 1 < len(convs) else None)
+    return h
+
+
+def _reference_seed_outputs(convs, data):
+    """PyG's plain formulation on ONE mini-batch, float64 on the host: every layer over all sampled edges and all nodes,
+    mean over a node's in-edges, ReLU between layers; the seeds' rows of the result."""
+    import torch
+    x = data.x.double().cpu()
+    src, dst = data.edge_index[0].cpu(), data.edge_index[1].cpu()
+    n = x.shape[0]
+    deg = torch.zeros(n, dtype=torch.float64).index_add_(0, dst, torch.ones(dst.shape[0], dtype=torch.float64))
+    h = x
+    for j, c in enumerate(convs):
+        agg = torch.zeros((n, h.shape[1]), dtype=torch.float64).index_add_(0, dst, h[src]) / deg.clamp(min=1).unsqueeze(1)
+        h = agg @ c.lin_l.weight.double().cpu().t() + c.lin_l.bias.double().cpu() + h @ c.lin_r.weight.double().cpu().t()
+        if j + 1 < len(convs):
+            h = torch.relu(h)
+    return h[:data.batch_size]
+
+
+@pytest.mark.parametrize("fanout,dims", [([25, 10], [100, 256, 47]), ([10, 5, 3], [64, 128, 64, 16]), ([7], [32, 64])])
+@pytest.mark.parametrize("per_call", [4, 1])
+def test_call_groups_equal_the_per_batch_loader_and_the_dense_formulation(hiplib, fanout, dims, per_call):
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd.nn import LazyRows
+    V, B = 6000, 96
+    gs, fs, feat = _stores(V, 14, dims[0])
+    seeds = torch.from_numpy(np.random.default_rng(1).permutation(V)[:B * 9 + 17])       # 9 full batches + a short one
+    make = lambda: NeighborLoader((fs, gs), fanout, input_nodes=seeds, batch_size=B, local_seeds_per_call=B * per_call,  # noqa: E731
+                                  random_state=77)
+    per_batch = list(make())
+    groups = list(make().call_groups())
+    assert sum(g.n_batches for g in groups) == len(per_batch) == 10
+    assert [g.n_batches for g in groups] == [per_call] * (9 // per_call) + ([9 % per_call] if 9 % per_call else []) + [1]
+    convs = _model(dims, "cuda")
+    at = 0
+    for g in groups:
+        datas = g.to_data_list()
+        # ---- every mini-batch of the group == the loader's own Data ------------------------------------------------
+        node_ptr, batch_ptr = g.node_ptr.tolist(), g.batch_ptr.tolist()
+        for j, d in enumerate(datas):
+            ref = per_batch[at + j]
+            assert torch.equal(d.n_id, ref.n_id) and torch.equal(d.edge_index, ref.edge_index) and torch.equal(d.e_id, ref.e_id)
+            assert torch.equal(d.x, ref.x) and torch.equal(d.y, ref.y) and torch.equal(d.input_id, ref.input_id)
+            assert d.num_sampled_nodes.tolist() == ref.num_sampled_nodes.tolist()
+            assert d.num_sampled_edges.tolist() == ref.num_sampled_edges.tolist()
+            assert torch.equal(g.n_id[node_ptr[j]:node_ptr[j + 1]], ref.n_id)
+        assert g.num_nodes == sum(d.n_id.numel() for d in datas) and g.num_edges == sum(d.edge_index.shape[1] for d in datas)
+        assert g.num_sampled_edges == [sum(int(d.num_sampled_edges[k]) for d in datas) for k in range(len(fanout))]
+        assert torch.equal(g.batch, torch.cat([d.batch for d in datas])) and torch.equal(g.input_id, torch.cat([d.input_id for d in datas]))
+        # block-diagonal COO of the group == the batches' edge lists shifted by their node offsets (as multisets per hop)
+        ei = g.edge_index
+        assert ei.shape[1] == g.num_edges and int(ei.max()) < g.num_nodes
+        want = torch.cat([d.edge_index + node_ptr[j] for j, d in enumerate(datas)], dim=1)
+        key = lambda e: torch.sort(e[0] * g.num_nodes + e[1]).values    # noqa: E731
+        assert torch.equal(key(ei), key(want))
+        # ---- lazy x == gathered x, bit for bit, through the model ----------------------------------------------------
+        x_lazy = g.x
+        assert isinstance(x_lazy, LazyRows) and tuple(x_lazy.shape) == (g.num_nodes, dims[0])
+        x_dense = g.node_attr("x", lazy=False)
+        assert isinstance(x_dense, torch.Tensor) and torch.equal(x_dense, feat[g.n_id.cpu()].cuda())
+        out_lazy, out_dense = _forward(convs, g, x_lazy), _forward(convs, g, x_dense)
+        assert out_lazy.shape == (g.num_seeds, dims[-1]) and torch.equal(out_lazy, out_dense)
+        assert torch.equal(x_lazy.materialize(), x_dense) and torch.equal(x_lazy[3:5], x_dense[3:5])
+        assert torch.equal(torch.relu(x_lazy), torch.relu(x_dense))         # any torch function sees the gathered rows
+        # ---- the trimmed group forward == the plain per-batch formulation in float64 ---------------------------------------
+        for j, d in enumerate(datas):
+            want = _reference_seed_outputs(convs, d)
+            got = out_lazy[batch_ptr[j]:batch_ptr[j + 1]].double().cpu()
+            scale = float(want.abs().max()) + 1e-30
+            assert float((got - want).abs().max()) <= 1e-5 * scale, (j, float((got - want).abs().max()), scale)
+        at += g.n_batches
+    assert at == len(per_batch)
+
+
+def test_call_groups_refuse_what_they_cannot_do(hiplib):
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    gs, fs, _ = _stores(500, 6, 8)
+    with pytest.raises(NotImplementedError):
+        NeighborLoader((fs, gs), [-1, 3], input_nodes=torch.arange(64), batch_size=16).call_groups()
+    with pytest.raises(NotImplementedError):
+        NeighborLoader((fs, gs), [3, 3], input_nodes=torch.arange(64), batch_size=16, replace=True).call_groups()
+
+
+def test_sageconv_layer_graph_falls_back_to_two_kernels_with_the_same_result(hiplib):
+    """Shapes the one-kernel layer is not built for (F % 4 != 0), and training mode (autograd on): aggregation kernel +
+    library GEMM — same call, same result up to fp32 reassociation."""
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    gs, fs, feat = _stores(3000, 10, 30)        # F = 30: not a multiple of 4
+    loader = NeighborLoader((fs, gs), [6, 4], input_nodes=torch.arange(3000)[:256], batch_size=64, local_seeds_per_call=128,
+                            random_state=5)
+    convs = _model([30, 50, 7], "cuda")
+    for g in loader.call_groups():
+        out = _forward(convs, g, g.x)
+        datas = g.to_data_list()
+        bp = g.batch_ptr.tolist()
+        for j, d in enumerate(datas):
+            want = _reference_seed_outputs(convs, d)
+            got = out[bp[j]:bp[j + 1]].double().cpu()
+            assert float((got - want).abs().max()) <= 2e-5 * (float(want.abs().max()) + 1e-30)
+        with torch.enable_grad():               # training: the autograd-capable path, gradients reach the weights
+            h = g.x
+            for j, c in enumerate(convs):
+                h = c(h, g.layer_graph(j), act="relu" if j == 0 else None)
+            h.sum().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for c in convs for p in c.parameters())
+        for c in convs:
+            c.zero_grad()
