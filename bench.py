@@ -380,12 +380,17 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
                       f"(C oracle with OpenMP + torch CPU linear), {dt:.1f} s"}
 
 
-def load_pmc(kernel_prefix, want_void=True):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/rNN/pmc_traffic.json, newest round first: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS command's launch shape, FETCH_SIZE x 2 per
-    MI355X_MICROARCH.md §HBM; tools/pmc_summary.py).  Counters cannot be read from inside the timed process."""
-    for rnd in ("r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")
+
+
+def load_pmc(kernel_prefix, want_void=True, workload="products"):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/rNN/pmc_traffic.json — pmc_traffic_<workload>.json
+    for the other BASELINE configurations —, newest round first: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS
+    command's launch shape, FETCH_SIZE x 2 per MI355X_MICROARCH.md §HBM; tools/pmc_summary.py).  Counters cannot be read from
+    inside the timed process."""
+    fname = "pmc_traffic.json" if workload == "products" else "pmc_traffic_%s.json" % workload
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, fname)
         if not os.path.exists(path):
             continue
         with open(path) as f:
@@ -398,18 +403,18 @@ def load_pmc(kernel_prefix, want_void=True):
         if hit:
             k, v = max(hit, key=lambda kv: kv[1]["launches"])
             return {"kernel": k, "bytes": v["traffic_bytes"], "launches": v["launches"],
-                    "source": "profiles/%s/pmc_traffic.json (%s)" % (rnd, ", ".join(pmc["source"]))}
+                    "source": "profiles/%s/%s (%s)" % (rnd, fname, ", ".join(pmc["source"]))}
     return None
 
 
-def load_profiled_avg(kernel):
+def load_profiled_avg(kernel, workload="products"):
     """Average launch duration (ns) of the dominant kernel in the COMMITTED rocprofv3 --kernel-trace --stats summary of this
-    command (profiles/rNN/rNN_kernel_stats.csv, newest round first).  A kernel that serves two layers appears as two template
+    command (profiles/rNN/rNN_kernel_stats.csv — <workload>_kernel_stats.csv for the other configurations —, newest round first).  A kernel that serves two layers appears as two template
     instantiations; the dominant stage is the longer one.  Lets the line carry `frac_profiled` next to the live HIP-event
     `frac`, so the two cannot drift apart unnoticed."""
     import csv
-    for rnd in ("r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, rnd + "_kernel_stats.csv")
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, (rnd if workload == "products" else workload) + "_kernel_stats.csv")
         if not os.path.exists(path):
             continue
         with open(path, newline="") as f:
@@ -419,7 +424,7 @@ def load_profiled_avg(kernel):
         if rows:
             r = max(rows, key=lambda r: float(r["AverageNs"]))
             return {"avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"]), "min_ns": float(r["MinNs"]),
-                    "source": "profiles/%s/%s_kernel_stats.csv" % (rnd, rnd)}
+                    "source": "profiles/%s/%s" % (rnd, os.path.basename(path))}
     return None
 
 
@@ -826,7 +831,7 @@ def main():
                 kname = "sage_layer_mfma_kernel" if (nn_mod.sage_layer_fused_precision() == "bf16x3" and nn_mod.L.lib(
                 ).wgamd_sage_layer_bf16x3_supported(fj, nj)) else "sage_layer_fused_kernel"
                 kernels["sage_layer%d(fused)" % (j + 1)] = (kname, hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
-            std_shape = args.workload == "products" and G == std_call_group and args.nodes == wv and args.edges == we
+            std_shape = G == std_call_group and args.nodes == wv and args.edges == we   # the shape the committed profiles are of
 
             def roof_entry(st):
                 """The roofline of one stage's kernel: algorithmic bytes over the live HIP-event time (`frac`), over the committed
@@ -839,12 +844,12 @@ def main():
                      "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                f"{G} mini-batches, averaged over {stage_n} call groups"}
                 if std_shape:
-                    prof = load_profiled_avg(r["kernel"])
+                    prof = load_profiled_avg(r["kernel"], args.workload)
                     if prof:    # the same algorithmic bytes over the committed profile's average launch duration
                         r["frac_profiled"] = round(kernels[st][1] / (prof["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)
                         r["profiled_avg_launch_ms"] = round(prof["avg_ns"] * 1e-6, 5)
                         r["profiled_source"] = "%s (%d launches, min %.1f us)" % (prof["source"], prof["calls"], prof["min_ns"] * 1e-3)
-                    hit = load_pmc(r["kernel"])
+                    hit = load_pmc(r["kernel"], workload=args.workload)
                     if hit:
                         r["traffic"] = hit["bytes"]
                         r["traffic_over_algorithmic"] = round(hit["bytes"] / kernels[st][1], 3)
@@ -881,7 +886,7 @@ def main():
             if SPMM1 in split_ms:
                 spmm_gbps = kernels[SPMM1][1] / (split_ms[SPMM1] * 1e-3) / 1e9
                 spmm_root_gbps = (kernels[SPMM1][1] + spmm_root[SPMM1]) / (split_ms[SPMM1] * 1e-3) / 1e9
-                hit = load_pmc("spmm_csr_kernel") if std_shape else None
+                hit = load_pmc("spmm_csr_kernel", workload=args.workload) if std_shape else None
                 if hit:     # real HBM utilisation of the launch: (2 x FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s
                     spmm_pmc = {"hbm_util": round(hit["bytes"] / (split_ms[SPMM1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                 "traffic_bytes_per_launch": hit["bytes"], "source": hit["source"] + " kernel " + hit["kernel"]}

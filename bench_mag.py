@@ -283,9 +283,11 @@ class MagPipeline:
         return y2["paper"], edges, n_nodes, launches
 
 
-def cpu_port_batch(hg, tables_h, params_h, seeds, fanout, hops, etypes, ntypes, batch_seed):
+def cpu_port_batch(hg, tables_h, params_h, seeds, fanout, hops, etypes, ntypes, batch_seed, fp64=False):
     """One mini-batch of the same path on the host — the same trimmed, aggregate-first computation: C oracle (sampling,
-    renumbering, wgo_gat_aggregate_heads with OpenMP) + torch CPU GEMMs.  Returns (seed-row outputs [B, HC], sampled edges)."""
+    renumbering, wgo_gat_aggregate_heads with OpenMP) + torch CPU GEMMs.  Returns (seed-row outputs [B, HC], sampled edges).
+    ``fp64``: every floating-point step in float64 (features, attention terms, softmax, aggregation, transforms, bias) —
+    the reference the pipeline's 1e-5 parity is asserted against (the fp32 port is what `cpu_baseline` times)."""
     import oracle
     from cugraph_pyg_amd.sampler.sampler import hop_seed
     node = {t: np.zeros(0, np.int64) for t in ntypes}
@@ -309,23 +311,28 @@ def cpu_port_batch(hg, tables_h, params_h, seeds, fanout, hops, etypes, ntypes, 
             size1 = {t: len(node[t]) for t in ntypes}
     x = {t: oracle.gather_rows(tables_h[t], node[t]) for t in ntypes}
     n1 = {t: size1[t] for t in ntypes}                                    # vertices after hop 1 = rows layer 1 produces
+    ft = np.float64 if fp64 else np.float32
+    if fp64:
+        x = {t: v.astype(np.float64) for t, v in x.items()}
+    tt = lambda v: v.double() if fp64 else v      # noqa: E731
+    aggregate = oracle.gat_aggregate_heads_f64 if fp64 else oracle.gat_aggregate_heads
 
     def layer(p, xs, hop_set, n_out):
         a = {}
         for et in etypes:
-            a[et] = ((torch.from_numpy(xs[et[0]]) @ p["rel"][et]["v_src"]).numpy(), (torch.from_numpy(xs[et[2]]) @ p["rel"][et]["v_dst"]).numpy())
-        out = {t: np.zeros((n_out[t], HC), np.float32) for t in ntypes}
+            a[et] = ((torch.from_numpy(xs[et[0]]) @ tt(p["rel"][et]["v_src"])).numpy(), (torch.from_numpy(xs[et[2]]) @ tt(p["rel"][et]["v_dst"])).numpy())
+        out = {t: np.zeros((n_out[t], HC), ft) for t in ntypes}
         for et, hop, first, off, mp in calls:
             if hop not in hop_set:
                 continue
             n_f = off.size - 1
             rows = np.arange(first, first + n_f, dtype=np.int64)
-            agg = oracle.gat_aggregate_heads(off, mp, xs[et[0]], a[et][0], a[et][1], dst_rows=rows)      # [n_f, H, F]
-            w = p["rel"][et]["w"]
+            agg = aggregate(off, mp, xs[et[0]], a[et][0], a[et][1], dst_rows=rows)      # [n_f, H, F]
+            w = tt(p["rel"][et]["w"])
             F_ = agg.shape[2]
             res = torch.bmm(torch.from_numpy(agg).permute(1, 0, 2), w.view(F_, HEADS, CH).permute(1, 0, 2))   # [H, n_f, C]
             out[et[2]][first:first + n_f] += res.permute(1, 0, 2).reshape(n_f, HC).numpy()
-        return {t: np.maximum(out[t] + p["bias"][t].numpy(), 0) for t in ntypes}
+        return {t: np.maximum(out[t] + tt(p["bias"][t]).numpy(), 0) for t in ntypes}
 
     y1 = layer(params_h[0], x, (0, 1), n1)           # layer 1: the vertices of hops 0-1 (local ids = a prefix of every list)
     y2 = layer(params_h[1], y1, (0,), {t: (len(seeds) if t == "paper" else 0) for t in ntypes})
@@ -430,6 +437,18 @@ def main(args):
                     "bytes_formula": "SURVEY §8(d) GAT, single pass, aggregate-first row widths: E (4F + 4H + 4) + N_dst (4HF + 4H "
                                      "+ 8) with F = %d source floats per edge, H = 4 heads" % F_,
                     "timing": "HIP events around the launch on the launch stream (one launch per hop and edge type per call group)"}
+    if roofline is not None and G == 64 and args.call_group <= 0:
+        # HBM traffic and average duration of that launch shape from the committed profile of this command
+        # (profiles/rNN/pmc_traffic_mag.json: the `#large` cluster = the largest launch of every call group; mag_kernel_stats.csv)
+        from bench import load_pmc, load_profiled_avg
+        hit = load_pmc("gat_aggregate_heads_kernel", want_void=False, workload="mag")
+        if hit:
+            roofline["traffic"] = hit["bytes"]
+            roofline["traffic_over_algorithmic"] = round(hit["bytes"] / roofline["algorithmic_bytes_per_launch"], 3)
+            roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"]
+        prof = load_profiled_avg("gat_aggregate_heads_kernel", "mag")
+        if prof:   # (the summary averages ALL launches of the kernel, 11 shapes per call group: the max is the dominant launch)
+            roofline["profiled_source"] = "%s (%d launches of all shapes, avg %.1f us)" % (prof["source"], prof["calls"], prof["avg_ns"] * 1e-3)
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(graphs, tables, params, order[:min(order.numel(), 256 * B)].cpu().numpy(), B, pipe.fanout, pipe.hops,

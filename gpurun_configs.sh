@@ -1,17 +1,27 @@
-# BASELINE configs[2..4] on ONE MI355X, each as one JSON line carrying roofline + cpu_baseline, plus a rocprofv3
-# kernel-trace summary of a short profiled pass of the same command -> gpurun_out/configs_<tag>/
+# BASELINE configs[2..4] on ONE MI355X, each as one JSON line carrying roofline + cpu_baseline, a rocprofv3 kernel-trace
+# summary of a short profiled pass of the same command, and SEPARATE --pmc FETCH_SIZE / WRITE_SIZE passes (never combined with
+# a trace option) of its hot kernels -> gpurun_out/configs_<tag>/ ; tools/pmc_summary.py turns the counter CSVs into
+# pmc_traffic_<workload>.json, which the bench lines then quote as roofline.traffic / frac_profiled.
 set -x
-R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; OUT=$R/gpurun_out/configs_$TAG; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --workload papers100m --steps 10 --warmup 3 --cpu-budget 10 > $OUT/papers100m.log 2> $OUT/papers100m.err
-grep '^{"metric' $OUT/papers100m.log | tail -1 > $OUT/bench_papers100m_n1.json
-python $R/bench.py --workload rmat26 --steps 6 --warmup 2 --cpu-budget 10 > $OUT/rmat26.log 2> $OUT/rmat26.err
-grep '^{"metric' $OUT/rmat26.log | tail -1 > $OUT/bench_rmat26_n1.json
-python $R/bench.py --workload mag --steps 6 --warmup 2 --cpu-budget 10 > $OUT/mag.log 2> $OUT/mag.err
-grep '^{"metric' $OUT/mag.log | tail -1 > $OUT/bench_mag_hetero_n1.json
-for W in papers100m rmat26; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_$W -o $W -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-variants > $OUT/prof_$W.log 2>&1
+R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; OUT=$R/gpurun_out/configs_$TAG; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
+HOT="row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|renumber_lds|bucket_sort|renumber_emit|gat_aggregate_heads|gather_terms|gat_csr"
+for W in papers100m rmat26 mag; do
+  EXTRA="--no-variants"; [ $W = mag ] && EXTRA=""
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_$W -o $W -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/prof_$W.log 2>&1
   cp /tmp/pc_$W/${W}_kernel_stats.csv $OUT/
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-include-regex "$HOT" --output-format csv -d /tmp/pm_${W}_$C -o ${W}_$C -- python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/pmc_${W}_$C.log 2>&1
+    cp /tmp/pm_${W}_$C/*counter_collection.csv $OUT/
+  done
+  python $R/tools/pmc_summary.py $OUT $W pmc_traffic_$W.json > $OUT/pmc_summary_$W.txt 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_mag -o mag -- python $R/bench.py --workload mag --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_mag.log 2>&1
-cp /tmp/pc_mag/mag_kernel_stats.csv $OUT/
-ls -la $OUT; tail -c 600 $OUT/*.err
+# the lines themselves, AFTER the profiles exist next to the repo's committed ones (copy them in so the lines can quote them)
+mkdir -p $R/profiles/$TAG; cp $OUT/*_kernel_stats.csv $OUT/pmc_traffic_*.json $R/profiles/$TAG/ 2>/dev/null
+cd $R
+python bench.py --workload papers100m --steps 10 --warmup 3 --cpu-budget 10 > $OUT/papers100m.log 2> $OUT/papers100m.err
+grep '^{"metric' $OUT/papers100m.log | tail -1 > $OUT/bench_papers100m_n1.json
+python bench.py --workload rmat26 --steps 6 --warmup 2 --cpu-budget 10 > $OUT/rmat26.log 2> $OUT/rmat26.err
+grep '^{"metric' $OUT/rmat26.log | tail -1 > $OUT/bench_rmat26_n1.json
+python bench.py --workload mag --steps 6 --warmup 2 --cpu-budget 10 > $OUT/mag.log 2> $OUT/mag.err
+grep '^{"metric' $OUT/mag.log | tail -1 > $OUT/bench_mag_hetero_n1.json
+ls -la $OUT; tail -c 400 $OUT/*.err; head -c 600 $OUT/bench_*_n1.json

@@ -22,7 +22,8 @@ __all__ = [
     "build", "lib", "pcg_raw_u32", "generate_random_positive_int",
     "generate_exponential_distribution_negative_float", "weighted_keys", "sample_offsets", "unweighted_sample_with_replacement",
     "unweighted_sample", "weighted_sample", "append_unique", "csr_add_self_loop",
-    "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "gat_aggregate_heads", "num_threads",
+    "multilayer_sample", "gather", "gather_rows", "scatter", "spmm_csr", "gat_csr", "gat_aggregate_heads", "gat_aggregate_heads_f64",
+    "num_threads",
     "set_num_threads", "py_pcg_u32_stream", "unique_bounded",
 ]
 
@@ -303,6 +304,35 @@ def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, dst_rows=None, slope=0.2)
     out = np.empty((n, H, F), dtype=np.float32)
     lib().wgo_gat_aggregate_heads(_p(row_ptr), _p(col), i64(n), _p(x), i64(F), _p(a_src), _p(a_dst),
                                   None if dr is None else _p(dr), i64(H), ctypes.c_float(slope), _p(out))
+    return out
+
+
+def gat_aggregate_heads_f64(row_ptr, col, x, a_src, a_dst, dst_rows=None, slope=0.2):
+    """``gat_aggregate_heads`` with EVERY step in float64 (numpy, no C): scores, LeakyReLU, per-destination softmax, the
+    attention-weighted sum of the untransformed source rows — the restatement of PyG's GATConv formulas
+    that the 1e-5 parity of the BASELINE config-5 pipeline is held against.  Inputs may be float32 or float64."""
+    row_ptr = np.asarray(row_ptr).astype(np.int64)
+    col = np.asarray(col).astype(np.int64)
+    x, a_src, a_dst = (np.asarray(v, dtype=np.float64) for v in (x, a_src, a_dst))
+    n, H, F = row_ptr.size - 1, a_src.shape[1], x.shape[1]
+    out = np.zeros((n, H, F), dtype=np.float64)
+    deg = np.diff(row_ptr)
+    E = int(row_ptr[-1])
+    if E == 0:
+        return out
+    dst = np.repeat(np.arange(n), deg)
+    ad = a_dst[np.asarray(dst_rows, dtype=np.int64)[dst]] if dst_rows is not None else a_dst[dst]
+    sc = a_src[col[:E]] + ad
+    sc = np.where(sc > 0, sc, sc * slope)                                   # [E, H]
+    live = deg > 0
+    starts = row_ptr[:-1][live]
+    mx = np.maximum.reduceat(sc, starts, axis=0)                            # per destination with at least one edge
+    row_of_live = np.cumsum(live) - 1
+    p = np.exp(sc - mx[row_of_live[dst]])
+    den = np.add.reduceat(p, starts, axis=0)
+    alpha = p / den[row_of_live[dst]]
+    contrib = alpha[:, :, None] * x[col[:E]][:, None, :]                    # [E, H, F]
+    out[live] = np.add.reduceat(contrib, starts, axis=0)
     return out
 
 

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle  # noqa: E402
-from graphgen import powerlaw_csr, random_csr, sage_layer_case  # noqa: E402
+from graphgen import gat_layer_case, powerlaw_csr, random_csr, sage_layer_case  # noqa: E402
 
 
 def karate_csr():
@@ -74,6 +74,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "hotpath_golden.npz"), **out)
     print("wrote", len(out), "arrays")
     sage_layer_golden()
+    gat_layer_golden()
 
 
 def sage_layer_golden():
@@ -101,5 +102,44 @@ def sage_layer_golden():
     print("sage layer golden:", rows.size, "rows of", n_dst, "; inputs sha256", h.hexdigest()[:16])
 
 
+def gat_layer_golden():
+    """Freezes a GATConv layer (F = 128 -> 4 heads x 64, LeakyReLU 0.2, per-destination softmax, bias, ReLU) at the shape of
+    one launch of the ogbn-mag-like pipeline (BASELINE configs[4]): float64 expectations, computed in GATConv's OWN order
+    (transform every source row, scores from the transformed rows and the attention vectors, softmax, weighted sum) for 400
+    sampled rows.  tests/test_gpu_mag_pipeline.py holds the device's aggregate-first formulation to it at 1e-5."""
+    import hashlib
+    rp, col, dst_rows, x, x_dst, w, att_s, att_d, bias = gat_layer_case()
+    F, (H, C) = x.shape[1], att_s.shape
+    n_rows = rp.size - 1
+    rng = np.random.default_rng(11)
+    rows = np.unique(np.concatenate([rng.integers(0, n_rows, 400), [0, n_rows - 1], np.nonzero(np.diff(rp) == 0)[0][:8]]))
+    w64 = w.astype(np.float64).reshape(F, H, C)
+    pre = np.zeros((rows.size, H, C))
+    scale = np.zeros((rows.size, H, C))
+    for j, r in enumerate(rows):
+        nb = col[rp[r]:rp[r + 1]]
+        if nb.size == 0:
+            continue
+        hs = np.einsum("ef,fhc->ehc", x[nb].astype(np.float64), w64)                       # lin(x_j)          [e, H, C]
+        hd = np.einsum("f,fhc->hc", x_dst[dst_rows[r]].astype(np.float64), w64)            # lin(x_i)          [H, C]
+        sc = (hs * att_s.astype(np.float64)).sum(-1) + (hd * att_d.astype(np.float64)).sum(-1)   # [e, H]
+        sc = np.where(sc > 0, sc, 0.2 * sc)
+        p = np.exp(sc - sc.max(0))
+        alpha = p / p.sum(0)
+        pre[j] = np.einsum("eh,ehc->hc", alpha, hs)
+        scale[j] = np.einsum("eh,ehc->hc", alpha, np.einsum("ef,fhc->ehc", np.abs(x[nb]).astype(np.float64), np.abs(w64)))
+    pre = pre.reshape(rows.size, H * C) + bias
+    scale = scale.reshape(rows.size, H * C) + np.abs(bias)
+    h = hashlib.sha256()
+    for a in (rp, col, dst_rows, x, x_dst, w, att_s, att_d, bias):
+        h.update(np.ascontiguousarray(a).tobytes())
+    np.savez_compressed(os.path.join(HERE, "gat_layer_golden.npz"), rows=rows, pre_activation=pre, scale=scale,
+                        inputs_sha256=np.array(h.hexdigest()))
+    print("gat layer golden:", rows.size, "rows of", n_rows, "; inputs sha256", h.hexdigest()[:16])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gat":
+        gat_layer_golden()          # only the GAT layer fixture (the others stay byte-identical)
+    else:
+        main()

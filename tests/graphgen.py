@@ -67,3 +67,37 @@ def sage_layer_case(seed=2026, G=8, F=100, N=256, fanout=10):
     w_t = ((rng.random((2 * F, N), dtype=np.float32) - 0.5) * 0.1)
     bias = ((rng.random(N, dtype=np.float32) - 0.5) * 0.1)
     return rp, col, self_rows, x, w_t, bias
+
+
+def gat_layer_case(seed=2027, G=6, F=128, H=4, C=64, fanout=10):
+    """A GATConv layer shaped like one (hop, edge type) launch of the ogbn-mag-like call group of bench_mag.py, scaled to G
+    mini-batches: block-diagonal hop with hub sources and empty rows, the launch's rows a SUBSET of a larger destination
+    list (``dst_rows``), x ~ U(-1, 1), lin weight ~ U(-a, a) with a = 1 / sqrt(F), attention vectors ~ U(-.25, .25) folded into
+    the [F, H] matrices the pipeline multiplies x by (bench_mag.make_params).  Shared by tests/golden/make_golden.py (freezes
+    float64 expectations) and the GPU test."""
+    rng = np.random.default_rng(seed)
+    n_dst_b = rng.integers(700, 1100, G)
+    n_src_b = n_dst_b + rng.integers(2500, 4000, G)
+    src_off = np.concatenate([[0], np.cumsum(n_src_b)])
+    deg, cols = [], []
+    for b in range(G):
+        d = np.minimum(rng.zipf(1.5, n_dst_b[b]), fanout)
+        d[rng.random(n_dst_b[b]) < 0.05] = 0
+        deg.append(d)
+        hub = rng.integers(0, n_src_b[b], 16)
+        c = np.where(rng.random(d.sum()) < 0.3, hub[rng.integers(0, 16, d.sum())], rng.integers(0, n_src_b[b], d.sum()))
+        cols.append(c + src_off[b])
+    deg = np.concatenate(deg)
+    rp = np.zeros(deg.size + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate(cols).astype(np.int32)
+    n_rows, n_src = deg.size, int(src_off[-1])
+    n_all = n_rows + 1500
+    dst_rows = np.sort(rng.permutation(n_all)[:n_rows]).astype(np.int64)
+    x = rng.random((n_src, F), dtype=np.float32) * 2 - 1
+    x_dst = rng.random((n_all, F), dtype=np.float32) * 2 - 1
+    w = ((rng.random((F, H * C), dtype=np.float32) - 0.5) * (2.0 / np.sqrt(F))).astype(np.float32)
+    att_s = ((rng.random((H, C), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    att_d = ((rng.random((H, C), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    bias = ((rng.random(H * C, dtype=np.float32) - 0.5) * 0.1).astype(np.float32)
+    return rp, col, dst_rows, x, x_dst, w, att_s, att_d, bias

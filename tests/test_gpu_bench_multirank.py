@@ -13,10 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(nproc, extra, env=None):
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def _run(nproc, extra, env=None, shape=("200000", "3000000", "16")):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
-           "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--groups-per-step", "2", "--no-variants"] + extra
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--nodes", shape[0], "--edges", shape[1], "--call-group", shape[2], "--groups-per-step", "2", "--no-variants"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -54,6 +61,32 @@ def test_two_ranks_on_one_gpu_control_flow(hiplib):
     assert "rccl_ranks" in two      # None here: the gloo rehearsal has no RCCL communicator
 
 
+@pytest.mark.parametrize("dedup", ["0", "1"])
+def test_eight_ranks_control_flow_at_reduced_size(hiplib, dedup):
+    """The line the driver's N = 8 run will produce, rehearsed with eight processes on ONE GPU (gloo; RCCL refuses several ranks
+    per device, and eight processes time-slice the chip, so speeds mean nothing here): every rank joins the pre-flight and both
+    placements, the whole-job value is the sum over eight seed shards, and the partitioned fetch is exercised with the
+    de-duplicated exchange forced on and off (WGAMD_GATHER_DEDUP).  World sizes 2-8 of the C-level exchange itself — both
+    memory types, split communicators, empty partitions — run as threads over the RCCL stand-in in
+    tests/test_gpu_comm_multirank.py."""
+    d = _run(8, ["--dist-backend", "gloo", "--share-gpu"], env={"WGAMD_GATHER_DEDUP": dedup}, shape=("120000", "1500000", "4"))
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["headline_placement"] == "partitioned" and set(d["placements"]) == {"replicated", "partitioned"}
+    assert "dp8" in d["config"]["parallelism"] and "all-to-all" in d["config"]["parallelism"]
+    assert d["selftest"]["partitioned"]["bit_exact"] is True and d["selftest"]["partitioned"]["dedup_bit_exact"] is True
+    assert d["selftest"]["partitioned"]["rows"] == 65537 * 8 + 3
+    for name in ("replicated", "partitioned"):
+        pr = d["placements"][name]["per_rank_value"]
+        assert len(pr) == 8 and all(v > 0 for v in pr)
+        # the whole-job value = all ranks' edges over the SLOWEST rank's time: never above the sum of the per-rank rates,
+        # and (same work per rank) not far below it
+        assert sum(pr) * 0.5 <= d["placements"][name]["value"] <= sum(pr) * 1.001
+    part = d["placements"]["partitioned"]
+    assert part["requested_rows_per_call_group"] > 0 and part["wire_rows_per_call_group"] <= part["requested_rows_per_call_group"]
+    assert part["all_to_all_bytes_per_gpu"] > 0 and d["xgmi_peak_GBps"] == 7 * 153.0
+    assert d["call_group"] == 4 and d["batches_per_step"] == 8 and d["timed_call_groups"] == 6
+
+
 def test_partitioned_feature_store_two_ranks(hiplib):
     """--feature-placement partitioned at N = 2: the all-to-all feature fetch over torch.distributed inside the pipeline."""
     d = _run(2, ["--dist-backend", "gloo", "--share-gpu", "--feature-placement", "partitioned"])
@@ -75,7 +108,7 @@ def test_rank_dying_in_the_extra_placement_does_not_cost_the_headline(hiplib):
     """A rank that DIES in the also-measured partitioned pass (a GPU fault is not an exception): the launcher sends SIGTERM to
     the others and rank 0 answers with the headline line it already has (the launcher itself then reports the failed worker)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--groups-per-step", "2", "--no-variants", "--dist-backend", "gloo",
            "--share-gpu"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGAMD_BENCH_TEST_DIE="1"))

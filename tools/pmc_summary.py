@@ -3,7 +3,8 @@ dispatch).  gfx950 correction per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_
 moves 128-byte requests, so read bytes = FETCH_SIZE x 2 (checked on a pure copy kernel: 2 x FETCH + WRITE = 2 x bytes copied).
 Writes profiles/<round>/pmc_traffic.json, which bench.py quotes as roofline.traffic for the same workload.
 
-usage: python tools/pmc_summary.py profiles/r01 r01i
+usage: python tools/pmc_summary.py profiles/r01 r01i [pmc_traffic_rmat26.json]
+(third argument: output file name inside the folder; default pmc_traffic.json = the products workload of the driver's command)
 """
 import csv, json, os, re, sys
 from collections import defaultdict
@@ -43,7 +44,7 @@ def split_shapes(fetch, write):
     return out
 
 
-def main(folder, tag):
+def main(folder, tag, out_name="pmc_traffic.json"):
     fetch = load(os.path.join(folder, "%s_FETCH_SIZE_counter_collection.csv" % tag))
     write = load(os.path.join(folder, "%s_WRITE_SIZE_counter_collection.csv" % tag))
     out = {"source": ["%s_FETCH_SIZE_counter_collection.csv" % tag, "%s_WRITE_SIZE_counter_collection.csv" % tag],
@@ -55,11 +56,11 @@ def main(folder, tag):
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         out["kernels"][k] = {"launches": len(f), "fetch_KB": round(fk, 1), "write_KB": round(wk, 1),
                              "traffic_bytes": int((fk * FETCH_CORRECTION + wk) * 1024)}
-    with open(os.path.join(folder, "pmc_traffic.json"), "w") as f:
+    with open(os.path.join(folder, out_name), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out["kernels"].items():
         print("%-70s %4d launches  %8.1f MB" % (k[:70], v["launches"], v["traffic_bytes"] / 1e6))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
