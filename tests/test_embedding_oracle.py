@@ -83,3 +83,77 @@ def test_low_precision_tables_round_after_every_step(dtype):
     rng = np.random.default_rng(0)
     big = rng.uniform(-100, 100, (1000,)).astype(np.float32)
     np.testing.assert_array_equal(eo._round_trip(big, dtype), torch.from_numpy(big).to(tdt).float().numpy())
+
+
+def _reference_apply(kind, p, dtype, lr, indices, grads, embs, states, per_row):
+    """The reference test's host optimizer followed STATEMENT BY STATEMENT in scalar Python on np.float32 values — `Apply` and
+    `ApplyLazyAdam / ApplyAdaGrad / ApplyRMSProp / ApplySGD` of
+    cpp/tests/wholememory_ops/wholememory_embedding_gradient_apply_tests.cu:180-300 (the caller hands it de-duplicated
+    indices with summed gradients, :450-481).  Deliberately NOT vectorised and NOT sharing a line with the oracle."""
+    f = np.float32
+    rt = (lambda v: f(np.float16(v))) if dtype == "half" else (lambda v: eo._round_trip(np.array([v], f), "bf16")[0]) \
+        if dtype == "bf16" else (lambda v: v)
+    beta1, beta2, eps, alpha, wd = (f(p[k]) for k in ("beta1", "beta2", "epsilon", "alpha", "weight_decay"))
+    one = f(1)
+    for i, index in enumerate(indices):
+        grad_vec, emb_vec = grads[i], embs[index]
+        if kind == "lazy_adam":
+            beta1t, beta2t = per_row[0][index] * beta1, per_row[1][index] * beta2
+            per_row[0][index], per_row[1][index] = beta1t, beta2t
+        for d in range(len(emb_vec)):
+            grad_value, emb_value = f(grad_vec[d]), f(emb_vec[d])
+            if kind == "lazy_adam":
+                if p["adam_w"] > 0.5:
+                    emb_value = f(emb_value - f(f(lr * wd) * emb_value))
+                else:
+                    grad_value = f(grad_value + f(wd * emb_value))
+                m = f(f(beta1 * states[0][index][d]) + f(f(one - beta1) * grad_value))
+                v = f(f(beta2 * states[1][index][d]) + f(f(f(one - beta2) * grad_value) * grad_value))
+                mhat, vhat = f(m / f(one - beta1t)), f(v / f(one - beta2t))
+                emb_value = f(emb_value - f(f(lr * mhat) / f(f(np.sqrt(vhat)) + eps)))
+                states[0][index][d], states[1][index][d] = m, v
+            else:
+                grad_value = f(grad_value + f(wd * emb_value))
+                if kind == "adagrad":
+                    state_sum = f(states[0][index][d] + f(grad_value * grad_value))
+                    emb_value = f(emb_value - f(f(lr * grad_value) / f(f(np.sqrt(state_sum)) + eps)))
+                    states[0][index][d] = state_sum
+                elif kind == "rmsprop":
+                    v = f(f(alpha * states[0][index][d]) + f(f(f(one - alpha) * grad_value) * grad_value))
+                    emb_value = f(emb_value - f(f(lr * grad_value) / f(f(np.sqrt(v)) + eps)))
+                    states[0][index][d] = v
+                else:
+                    emb_value = f(emb_value - f(lr * grad_value))
+            emb_vec[d] = rt(emb_value)
+
+
+@pytest.mark.parametrize("dtype", ["float", "half", "bf16"])
+@pytest.mark.parametrize("kind,params", [("sgd", {"weight_decay": 0.01}), ("lazy_adam", {}), ("lazy_adam", {"adam_w": 1.0, "weight_decay": 0.05}),
+                                         ("adagrad", {"weight_decay": 0.01}), ("rmsprop", {"alpha": 0.9})])
+def test_oracle_follows_the_reference_host_optimizer_statement_by_statement(kind, params, dtype):
+    """The vectorised oracle against a scalar transcription of the reference test's `CPUOptimizer` (the class the reference
+    holds its device kernels to): sparse, duplicate-heavy index sets, three steps, all table dtypes.  fp32 arithmetic is
+    the same operations in the same order on both sides up to the association of `lr * x / y` (ulp-level), so values agree
+    to a few ulp and the optimizer states too."""
+    rng = np.random.default_rng(11)
+    n, dim, lr = 40, 7, np.float32(0.05)
+    table = eo._round_trip(rng.uniform(-4, 4, (n, dim)).astype(np.float32), dtype)
+    ref = [list(r) for r in table.copy()]
+    p = dict(eo.DEFAULTS)
+    p.update(params)
+    n_states = {"sgd": 0, "lazy_adam": 2, "adagrad": 1, "rmsprop": 1}[kind]
+    states = [[[np.float32(0)] * dim for _ in range(n)] for _ in range(n_states)]
+    per_row = [[np.float32(1)] * n, [np.float32(1)] * n]
+    opt = eo.SparseOptimizer(kind, n, dim, table_dtype=dtype, **params)
+    for step in range(3):
+        idx = rng.integers(-1, n // 2, 25)                       # duplicates and "skip" entries (-1)
+        grads = rng.uniform(-2, 2, (25, dim)).astype(np.float32)
+        opt.step(table, idx, grads, lr)
+        rows, summed = eo.dedup(idx, grads)                      # the reference's test de-duplicates the same way (:450-481)
+        _reference_apply(kind, p, dtype, lr, rows.tolist(), summed, ref, states, per_row)
+        tol = dict(rtol=3e-6, atol=1e-6) if dtype == "float" else dict(rtol=1e-2 if dtype == "bf16" else 1e-3, atol=1e-3)
+        np.testing.assert_allclose(table, np.array(ref, np.float32), **tol)
+    for s, name in enumerate(eo.STATE_NAMES[kind][:n_states]):
+        np.testing.assert_allclose(opt.states[name], np.array(states[s], np.float32), rtol=3e-6, atol=1e-7)
+    if kind == "lazy_adam":
+        np.testing.assert_allclose(opt.states["beta12t"], np.array(per_row, np.float32).T, rtol=1e-6)
