@@ -401,8 +401,10 @@ def load_pmc(kernel_prefix, want_void=True, workload="products"):
         if per_shape:     # one kernel, two launch shapes per call group: `#large` is the layer-1 launch
             hit = per_shape
         if hit:
-            k, v = max(hit, key=lambda kv: kv[1]["launches"])
-            return {"kernel": k, "bytes": v["traffic_bytes"], "launches": v["launches"],
+            # several instantiations of one kernel (a 3-layer model: one per layer shape): the dominant stage is the one that
+            # moves the most bytes
+            k, v = max(hit, key=lambda kv: kv[1]["traffic_bytes"])
+            return {"kernel": k, "bytes": v["traffic_bytes"], "launches": v["launches"], "max_bytes": v.get("max_traffic_bytes"),
                     "source": "profiles/%s/%s (%s)" % (rnd, fname, ", ".join(pmc["source"]))}
     return None
 

@@ -442,10 +442,11 @@ def main(args):
         # (profiles/rNN/pmc_traffic_mag.json: the `#large` cluster = the largest launch of every call group; mag_kernel_stats.csv)
         from bench import load_pmc, load_profiled_avg
         hit = load_pmc("gat_aggregate_heads_kernel", want_void=False, workload="mag")
-        if hit:
-            roofline["traffic"] = hit["bytes"]
-            roofline["traffic_over_algorithmic"] = round(hit["bytes"] / roofline["algorithmic_bytes_per_launch"], 3)
-            roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"]
+        if hit and hit.get("max_bytes"):
+            # eleven launch shapes per call group: the dominant launch is the LARGEST single launch of the kernel in the PMC passes
+            roofline["traffic"] = hit["max_bytes"]
+            roofline["traffic_over_algorithmic"] = round(hit["max_bytes"] / roofline["algorithmic_bytes_per_launch"], 3)
+            roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"] + " (largest launch)"
         prof = load_profiled_avg("gat_aggregate_heads_kernel", "mag")
         if prof:   # (the summary averages ALL launches of the kernel, 11 shapes per call group: the max is the dominant launch)
             roofline["profiled_source"] = "%s (%d launches of all shapes, avg %.1f us)" % (prof["source"], prof["calls"], prof["avg_ns"] * 1e-3)

@@ -385,17 +385,23 @@ void prepare_packed_t(const TgtT* targets, dev_count T, const NbrT* neighbors, d
 //                     terminates.
 // Cost is linear in the positions whatever the batch size.  Scratch: the pair words live where the device-wide table would
 // (8 B x slots >= 16 B per position), the segment boundaries where its positions array would.
-constexpr int kLdsSlots      = 10000;     // 80,000 B: two workgroups per CU, one computes while the other waits on its loads
-constexpr int kLdsKeysTarget = 3000;      // positions per range the range count is sized for (load <= 0.3: short probe chains)
+#ifndef WG_LDS_SLOTS      // (tuning: -DWG_LDS_SLOTS / WG_LDS_KEYS / WG_LDS_THREADS / WG_LDS_UNROLL)
+#define WG_LDS_SLOTS 10000
+#define WG_LDS_KEYS 3000
+#define WG_LDS_THREADS 512
+#define WG_LDS_UNROLL 7
+#endif
+constexpr int kLdsSlots      = WG_LDS_SLOTS;     // 80,000 B: two workgroups per CU, one computes while the other waits on its loads
+constexpr int kLdsKeysTarget = WG_LDS_KEYS;      // positions per range the range count is sized for (load <= 0.3: short probe chains)
 constexpr int kLdsProbeLimit = 256;       // probes after which a range is declared overfull and split
-constexpr int kLdsThreads    = 512;       // one trip of kLdsUnroll pairs per thread covers a range (1024 threads: walk 1.227 -> 1.19 ms per call
+constexpr int kLdsThreads    = WG_LDS_THREADS;   // one trip of kLdsUnroll pairs per thread covers a range (1024 threads: walk 1.227 -> 1.19 ms per call
                                           // group of 191; half / quarter-size tables with 512 / 256 threads: 1.28 / 1.48 — more ranges cost more to bucket)
 constexpr int kLdsMaxRanges  = 2048;      // per batch; beyond, ranges simply start overfull and split
 constexpr int kLdsStack      = 40;        // pending hash ranges of one workgroup (a split pushes two, pops one)
 constexpr int kLdsChunks     = 16;        // blocks per batch in the bucketing kernel = segments of a range
 constexpr int kBucketThreads = 256;
 constexpr int kBucketUnroll  = 4;         // ids in flight per thread of the bucketing kernel
-constexpr int kLdsUnroll     = 7;         // pairs per thread of the table kernel: 3,584 per trip (a range holds 3,000 on average)
+constexpr int kLdsUnroll     = WG_LDS_UNROLL;    // pairs per thread of the table kernel: 3,584 per trip (a range holds 3,000 on average)
 
 __device__ __forceinline__ uint32_t hash_id32(uint32_t h)   // murmur3 finaliser
 {

@@ -115,6 +115,27 @@ class WalkResult:
         assert self.n_batches == 1
         return self.finalize_batches()[0]
 
+    def finalize_single(self, copy: bool = False):
+        """``finalize()`` for one mini-batch with ONE host read-back (the ``counts`` vector: a single batch's segments are
+        ``[0, n]``, so every size follows from it).  ``copy``: return fresh tensors instead of views of the walk's buffers
+        (a captured walk overwrites them on its next run)."""
+        assert self.n_batches == 1
+        hops = self.hops
+        sz = self.counts.cpu().tolist()                       # per hop: [edges, unique vertices after the hop]
+        keep = (lambda t: t.clone()) if copy else (lambda t: t)
+        target_gids = [None] * hops + [self.seeds]
+        edge_indice, csr_row_ptr, csr_col_ind = [None] * hops, [None] * hops, [None] * hops
+        n_t = int(self.seeds.shape[0])
+        for k in range(hops):
+            i = hops - 1 - k
+            n_e, n_u = sz[k]
+            csr_row_ptr[i] = keep(self.offsets[k][:n_t + 1])
+            csr_col_ind[i] = keep(self.neighbor_row[k][:n_e])
+            edge_indice[i] = torch.stack([csr_col_ind[i], self.center_row[k][:n_e]])
+            target_gids[i] = keep(self.unique[k][:n_u])
+            n_t = n_u
+        return target_gids, edge_indice, csr_row_ptr, csr_col_ind
+
 
 def _merge_hops_batch_major(fields_per_hop, segs_per_hop, G, dev):
     """Per-hop arrays that are each batch-major (hop h, batch b = [segs[h][b], segs[h][b+1])) -> ONE array per field laid
@@ -245,6 +266,49 @@ class NoSyncWalk:
             res.center_row.append(ctr_row)
             targets, t_batch, t_seg = unique, u_batch, u_seg
         return res
+
+
+class CapturedWalk:
+    """A ``NoSyncWalk`` whose launch sequence (~11 kernels per hop) is captured ONCE into a HIP graph
+    (``torch.cuda.CUDAGraph``) and replayed: a single mini-batch is a few tens of microseconds of device work behind
+    ~0.2 ms of launch calls, so the reference's one-batch calling convention (``GraphStructure.multilayer_sample_without_
+    replacement``, graph_structure.py:136-196) is bound by the host — one graph launch instead of 22 kernel launches takes
+    that away.  Inputs are copied into static buffers, the result lives in static buffers until the next ``run`` (callers
+    copy what they keep).  Uniform sampling over a CSR this GPU holds whole; identical results (the same kernels)."""
+
+    def __init__(self, walk: NoSyncWalk):
+        self.walk = walk
+        self._graph = self._res = None
+        hops = len(walk.fanouts)
+        self._seeds = torch.zeros(walk.G * walk.B, dtype=walk.id_dtype, device=walk.dev)
+        self._rs = torch.zeros((hops, walk.G), dtype=torch.int64, device=walk.dev)
+        self._rs_host = torch.zeros((hops, walk.G), dtype=torch.int64).pin_memory()
+
+    def run(self, seeds: torch.Tensor, random_seeds) -> WalkResult:
+        w = self.walk
+        if isinstance(random_seeds, torch.Tensor):
+            self._rs.copy_(random_seeds.to(torch.int64).view_as(self._rs), non_blocking=True)
+        else:
+            for k, per_hop in enumerate(random_seeds):
+                vals = [per_hop] * w.G if isinstance(per_hop, int) else list(per_hop)
+                for b, v in enumerate(vals):
+                    v = int(v) & 0xFFFFFFFFFFFFFFFF
+                    self._rs_host[k, b] = v - (1 << 64) if v & (1 << 63) else v
+            self._rs.copy_(self._rs_host, non_blocking=True)
+        self._seeds.copy_(seeds, non_blocking=True)
+        if self._graph is None:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=w.dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):          # an eager pass first (library and allocator warm-up), as capture requires
+                w.run(self._seeds, self._rs)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._res = w.run(self._seeds, self._rs)
+            self._graph = g
+        self._graph.replay()
+        return self._res
 
 
 class SingleBatchNoSyncWalk:

@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Union
 import torch
 
 from . import graph_ops, wholegraph_ops
-from .fused import NoSyncWalk
+from .fused import CapturedWalk, NoSyncWalk
 from .tensor import WholeMemoryTensor
 
 
@@ -34,6 +34,7 @@ class GraphStructure(object):
         self.csr_row_ptr = self.csr_col_ind = None
         self.node_attributes, self.edge_attributes = {}, {}
         self._walk_cache = {}
+        self._captured_ok = True
 
     # ---- graph + attributes ----------------------------------------------------------------
     def set_csr_graph(self, csr_row_ptr, csr_col_ind):
@@ -100,6 +101,28 @@ class GraphStructure(object):
         :return: target_gids, edge_indice, csr_row_ptr, csr_col_ind
         """
         hops = len(max_neighbors)
+        if (weight_name is None and hops > 0 and all(int(m) > 0 for m in max_neighbors) and node_ids.is_cuda
+                and node_ids.shape[0] > 0 and self._captured_ok
+                and not any(wholegraph_ops._is_partitioned(t) for t in (self.csr_row_ptr, self.csr_col_ind))
+                and node_ids.dtype == _device_tensor(self.csr_col_ind).dtype):
+            # the walk's ~11 launches per hop replayed from ONE captured HIP graph, one host read-back for all sizes: the
+            # same kernels, the same results as the op-by-op loop below (tests/test_gpu_renumber_gather.py), a third of its
+            # host time.  Anything the capture cannot serve (biased hops, fan-out -1, a partitioned CSR) takes the loop.
+            key = ("captured", int(node_ids.shape[0]), tuple(int(m) for m in max_neighbors), node_ids.dtype)
+            try:
+                if key not in self._walk_cache:
+                    self._walk_cache[key] = CapturedWalk(NoSyncWalk(
+                        _device_tensor(self.csr_row_ptr), _device_tensor(self.csr_col_ind), key[1], list(key[2]), node_ids.dtype))
+                seeds = random_seeds if random_seeds is not None else [random.getrandbits(64) for _ in max_neighbors]
+                res = self._walk_cache[key].run(node_ids.contiguous(), list(seeds))
+                tg, ei, rp, ci = res.finalize_single(copy=True)
+                tg[hops] = node_ids
+                return tg, ei, rp, ci
+            except RuntimeError as exc:      # graph capture refused by the runtime: remember, and take the op-by-op loop
+                import warnings
+                warnings.warn("captured walk unavailable (%s): using the op-by-op walk" % (str(exc).splitlines()[0][:200],))
+                self._captured_ok = False
+                self._walk_cache.pop(key, None)
         levels = {name: [None] * hops for name in ("edge", "rowptr", "col")}
         target_gids = [None] * hops + [node_ids]
         for k, fanout in enumerate(max_neighbors):

@@ -117,7 +117,15 @@ def test_multilayer_walk_sync_and_nosync(oracle_mod, hiplib, col_dtype, fanouts)
     g = GraphStructure()
     g.set_csr_graph(torch.from_numpy(row_ptr).cuda(), torch.from_numpy(col).cuda())
     otg, oei, orp, oci = oracle_mod.multilayer_sample(row_ptr, col, seeds, fanouts, rs)
-    for result in (g.multilayer_sample_without_replacement(torch.from_numpy(seeds).cuda(), fanouts, random_seeds=rs),
+    seeds_d = torch.from_numpy(seeds).cuda()
+    captured = g.multilayer_sample_without_replacement(seeds_d, fanouts, random_seeds=rs)   # HIP-graph replay of the walk
+    assert g._captured_ok and any(k[0] == "captured" for k in g._walk_cache if isinstance(k[0], str))
+    again = g.multilayer_sample_without_replacement(seeds_d, fanouts, random_seeds=[r + 1000 for r in rs])   # replays reuse buffers:
+    assert not torch.equal(again[0][0], captured[0][0])                               # ... the first result must be its own copy
+    g._captured_ok = False                                                            # the op-by-op loop over the C-ABI ops
+    op_by_op = g.multilayer_sample_without_replacement(seeds_d, fanouts, random_seeds=rs)
+    g._captured_ok = True
+    for result in (captured, op_by_op,
                    g.multilayer_sample_nosync(torch.from_numpy(seeds).cuda(), fanouts, random_seeds=rs).finalize()):
         tg, ei, rp, ci = result
         for name, got, want in (("target_gids", tg, otg), ("edge_indice", ei, oei), ("csr_row_ptr", rp, orp),

@@ -54,8 +54,12 @@ def main(folder, tag, out_name="pmc_traffic.json"):
     for k in sorted(pairs):
         f, w = pairs[k]
         fk, wk = sum(f) / len(f), sum(w) / len(w)
+        # (the two passes run the same command: launch i of one is launch i of the other, so the largest single launch is
+        #  the largest pairwise sum — what a pipeline with many launch shapes per kernel quotes for its dominant launch)
+        biggest = max(a * FETCH_CORRECTION + b for a, b in zip(f, w)) if len(f) == len(w) else None
         out["kernels"][k] = {"launches": len(f), "fetch_KB": round(fk, 1), "write_KB": round(wk, 1),
-                             "traffic_bytes": int((fk * FETCH_CORRECTION + wk) * 1024)}
+                             "traffic_bytes": int((fk * FETCH_CORRECTION + wk) * 1024),
+                             "max_traffic_bytes": None if biggest is None else int(biggest * 1024)}
     with open(os.path.join(folder, out_name), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out["kernels"].items():
