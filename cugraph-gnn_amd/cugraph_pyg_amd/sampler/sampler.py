@@ -812,6 +812,9 @@ def filter_store_from_group(feature_store, views, j, node, row, col, edge) -> Da
     """``filter_store`` for batch j of a call group whose attributes were fetched by ``group_attribute_views``."""
     data = Data()
     data.edge_index = torch.stack([row, col], dim=0)
+    # a call-group walk emits hop after hop, a hop's edges in the CSR order of its frontier, every hop's destinations behind
+    # the previous hop's: destination-major (wholegraph_amd.nn._to_csr then skips its sort)
+    data.edge_index._wgamd_dst_sorted = True
     for attr in feature_store.get_all_tensor_attrs():
         is_edge = isinstance(attr.group_name, tuple)
         v = views[attr.group_name, attr.attr_name]

@@ -449,6 +449,12 @@ def _to_csr(edge_index, n_dst):
     destination).  int64 ids on the device go through ``wgamd_coo_to_csr_i64`` (one radix sort over the bits a destination
     id needs); anything else through the torch formulation of the same."""
     src, dst = edge_index[0], edge_index[1]
+    if getattr(edge_index, "_wgamd_dst_sorted", False) and edge_index.is_cuda:
+        # the loaders' own edge lists are destination-major already (hop after hop, a hop's edges in the CSR order of its
+        # frontier, every hop's destinations after the previous hop's): the CSR is a search for the run boundaries and a cast
+        # — no sort (0.77 ms per 88 k-edge mini-batch through the radix sort below, most of it launch latency)
+        row_ptr = torch.searchsorted(dst.contiguous(), torch.arange(n_dst + 1, device=dst.device, dtype=dst.dtype)).to(torch.int32)
+        return row_ptr, src.to(torch.int32).contiguous()
     if edge_index.dtype == torch.int64 and edge_index.is_cuda:
         src, dst = src.contiguous(), dst.contiguous()
         E, dev = dst.shape[0], dst.device
@@ -609,6 +615,14 @@ class SAGEConv(torch.nn.Module):
             x = x.materialize()
         x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
         row_ptr, col = _split_graph(graph, x_dst.shape[0])
+        if (x_src is x_dst and not torch.is_grad_enabled() and x_src.is_cuda and x_src.dtype == torch.float32
+                and self.lin_r is not None and self.aggr in ("mean", "sum") and act in (None, "relu")
+                and x_src.stride(1) == 1 and sage_layer_fused_preferred(x_src.shape[1], self.out_channels)):
+            # inference over one sampled (sub)graph whose destinations are the first rows of x: the whole layer as ONE kernel
+            # (no library GEMM — whose shape heuristics alone cost ~1 ms for every new row count a mini-batch brings)
+            n = row_ptr.shape[0] - 1
+            hop = HopGraph(row_ptr, col, torch.arange(n, dtype=torch.int64, device=x_src.device))
+            return self._forward_layer(x_src, LayerGraph([hop]), act)
         out = self.lin_l(spmm_csr(x_src, row_ptr, col, self.aggr))
         if self.lin_r is not None:
             out = out + self.lin_r(x_dst[: out.shape[0]])

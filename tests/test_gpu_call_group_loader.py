@@ -157,3 +157,35 @@ def test_sageconv_layer_graph_falls_back_to_two_kernels_with_the_same_result(hip
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for c in convs for p in c.parameters())
         for c in convs:
             c.zero_grad()
+
+
+def test_per_batch_loop_takes_the_sorted_edge_list_and_the_one_kernel_layer(hiplib):
+    """The classic loop — `for batch in loader: conv(batch.x, batch.edge_index)` — in inference: the loader's edge list is
+    destination-major and says so (no radix sort to build the CSR), and the layer runs as one kernel; same numbers as the
+    sort + aggregate + library-GEMM route (bit-equal CSR, outputs to fp32 reassociation) and as the float64 formulation."""
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd import nn
+    gs, fs, feat = _stores(5000, 12, 100)
+    loader = NeighborLoader((fs, gs), [10, 5], input_nodes=torch.arange(5000)[:640], batch_size=128, local_seeds_per_call=256,
+                            random_state=9)
+    convs = _model([100, 256, 47], "cuda")
+    n = 0
+    for batch in loader:
+        ei = batch.edge_index
+        assert getattr(ei, "_wgamd_dst_sorted", False) and bool((ei[1][1:] >= ei[1][:-1]).all())
+        fast = nn._to_csr(ei, batch.x.shape[0])
+        slow = nn._to_csr(ei.clone(), batch.x.shape[0])              # a plain tensor: the radix-sort route (stable)
+        assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+        with torch.no_grad():
+            h = convs[0](batch.x, ei, act="relu")
+            out = convs[1](h, ei)[:batch.batch_size]
+        with torch.enable_grad():                                    # the autograd route: aggregation kernel + torch Linear
+            h2 = torch.relu(convs[0](batch.x, ei))
+            out2 = convs[1](h2, ei)[:batch.batch_size]
+        want = _reference_seed_outputs(convs, batch)
+        scale = float(want.abs().max())
+        assert float((out.double().cpu() - want).abs().max()) <= 1e-5 * scale
+        assert float((out2.detach().double().cpu() - want).abs().max()) <= 2e-5 * scale
+        n += 1
+    assert n == 5
