@@ -416,7 +416,10 @@ def load_profiled_avg(kernel, workload="products"):
     `frac`, so the two cannot drift apart unnoticed."""
     import csv
     for rnd in PROFILE_ROUNDS:
-        path = os.path.join(ROOT, "profiles", rnd, (rnd if workload == "products" else workload) + "_kernel_stats.csv")
+        base = os.path.join(ROOT, "profiles", rnd, (rnd if workload == "products" else workload) + "_kernel_stats")
+        # the dominant-launch-shape statistics of the same trace where they exist (tools/trace_large_launches.py: the plain
+        # average of a kernel mixes the call-group launches with the 1024-seed launches of the per-batch variant)
+        path = base + "_large.csv" if os.path.exists(base + "_large.csv") else base + ".csv"
         if not os.path.exists(path):
             continue
         with open(path, newline="") as f:
