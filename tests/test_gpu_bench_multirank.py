@@ -78,9 +78,9 @@ def test_eight_ranks_control_flow_at_reduced_size(hiplib, dedup):
     for name in ("replicated", "partitioned"):
         pr = d["placements"][name]["per_rank_value"]
         assert len(pr) == 8 and all(v > 0 for v in pr)
-        # the whole-job value = all ranks' edges over the SLOWEST rank's time: never above the sum of the per-rank rates,
-        # and (same work per rank) not far below it
-        assert sum(pr) * 0.5 <= d["placements"][name]["value"] <= sum(pr) * 1.001
+        # the whole-job value = all ranks' edges over the SLOWEST rank's time: never above the sum of the per-rank rates (how far
+        # below says nothing here: eight processes time-slice one GPU and finish at very different times)
+        assert 0 < d["placements"][name]["value"] <= sum(pr) * 1.001
     part = d["placements"]["partitioned"]
     assert part["requested_rows_per_call_group"] > 0 and part["wire_rows_per_call_group"] <= part["requested_rows_per_call_group"]
     assert part["all_to_all_bytes_per_gpu"] > 0 and d["xgmi_peak_GBps"] == 7 * 153.0
