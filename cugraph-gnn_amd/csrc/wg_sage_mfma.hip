@@ -43,480 +43,11 @@
 //     256 -> 256 layer 1.69 -> 1.51 ms (no weight loads at all: 1.34; the multiplying waves alone: 0.90, of which 0.43 is
 //     the matrix pipe; the fetching waves alone: 0.73 = the HBM floor of the shape).
 //   * one s_barrier per step behind an LDS-only wait (s_waitcnt lgkmcnt(0)): neither side's global loads are drained.
-#include <algorithm>
-#include <cstdlib>
-#include <type_traits>
-
-#include "wg_common.hpp"
-#include "wgamd_ext.h"
+#include "wg_sage_mfma_parts.hpp"
 
 namespace wgamd {
 namespace {
-
-using f32x4  = __attribute__((ext_vector_type(4))) float;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using u32x4  = __attribute__((ext_vector_type(4))) uint32_t;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-
-#ifndef WG_MFMA_PRODUCTS
-#define WG_MFMA_PRODUCTS 6   // (tuning only: fewer products = wrong results, used to price the matrix work)
-#endif
-#ifndef WG_MFMA_DEPTH
-#define WG_MFMA_DEPTH 2   // destination rows in flight per producer lane group
-#endif
-constexpr int kProducerWaves = 4;
-constexpr int kRingDepth     = WG_MFMA_DEPTH;
-
-template <typename IdT>
-__device__ __forceinline__ int64_t table_row(const IdT* ids, int64_t local)
-{
-  if constexpr (std::is_same<IdT, void>::value) return local;
-  else return (int64_t)ids[local];
-}
-
-struct mfma_args {
-  const int* row_ptr;
-  const int* col;
-  int64_t n_rows;
-  const float* x;
-  int64_t ldx;
-  uint32_t x_bytes;          // extent of x when it is below 2 GB (32-bit offsets, buffer loads), else 0
-  int F;
-  const void* src_ids;
-  const int64_t* self_rows;
-  int mean;
-  const float* w_tiles;      // [KS][N][16] fp32: k-step s, column n, 16 consecutive k (wgamd_sage_split_weight_bf16x3);
-                             // HALF mode (F > 148): pre-split bf16 planes [3][KS][N][8 dwords] behind the same pointer
-  int N;
-  int KS;                    // ceil(2F / 16)
-  const float* bias;
-  int relu;
-  float* out;
-  int64_t ldo;
-  int SD;                    // floats per LDS tile row (>= 2F, = 4 * odd: conflict-free ds_read_b128 across rows)
-  int debug;                 // tuning harness only, bit mask: 1 no consumers, 2 no producers, 4 no output stores,
-                             // 64 roles by SIMD instead of by wave order, 128 no epilogue stagger, 16 / 32 s_setprio 3 for
-                             // producers / consumers
-  unsigned long long* stamps;  // tuning harness only: s_memtime stamps of workgroup 0, [step][wave][begin, work done]
-};
-
-// a == hi + mid + lo exactly; every piece has <= 8 significant bits, i.e. is a bf16 (the top half of the fp32 word)
-__device__ __forceinline__ void split3(float a, uint32_t& h, uint32_t& m, uint32_t& l)
-{
-  h              = __float_as_uint(a) & 0xffff0000u;
-  const float r1 = a - __uint_as_float(h);
-  m              = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(m);
-  l              = __float_as_uint(r2);
-}
-// (lo word's bf16, hi word's bf16) -> one dword: bytes {a.2, a.3, b.2, b.3}
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-
-// LDS-only wait + workgroup barrier: in-flight global loads (prefetched rows / weight fragments) and stores stay in flight
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__host__ __device__ constexpr int row_stride_dw(int F)
-{
-  int sd = (2 * F + 3) / 4 * 4;
-  return (sd / 4) % 2 == 0 ? sd + 4 : sd;   // 4 * odd
-}
-
-// HALF mode (two 64-row tiles of [mean | self] do not fit the LDS: F > 148): the two LDS buffers hold the MEAN halves of two
-// consecutive 64-row tiles, F floats per row (the self half is read from global memory by the multiplying waves); a row
-// stride of 4 * odd >= F keeps ds_read_b128 conflict-free
-__host__ __device__ constexpr int row_stride_half_dw(int F)
-{
-  int sd = (F + 3) / 4 * 4;
-  return (sd / 4) % 2 == 0 ? sd + 4 : sd;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// producer side
-// ---------------------------------------------------------------------------------------------------------------------
-template <int IT>
-struct bounds_t {
-  int s[IT], e[IT];
-};
-template <int IT>
-struct ids_t {
-  int deg[IT];     // e - s of the bounds (the bounds die when the ids are requested); -1 = row past n_rows
-  int lcol[IT];
-  int lself[IT];   // self row (a local row of x / src_ids: < 2^31)
-};
-template <int IT, typename off_t>
-struct meta_t {
-  int d[IT];       // degree; -1 = row past n_rows (no neighbours, zero self row)
-  off_t src[IT];   // byte offset of THIS lane's neighbour row (lane `sub` holds neighbour `sub` of the row)
-  off_t self[IT];  // byte offset of the self row
-};
-
-template <typename IdT, int LG, int TR, bool OFF32, bool HALF = false>
-struct producer {
-  using off_t                         = typename std::conditional<OFF32, uint32_t, int64_t>::type;
-  static constexpr int kGroupsPerWave = 64 / LG;
-  static constexpr int kGroups        = kGroupsPerWave * kProducerWaves;
-  static constexpr int IT             = TR / kGroups;       // rows of a tile per lane group
-  static constexpr int kNb            = LG < 10 ? LG : 10;  // neighbour rows prefetched per destination row (fan-out 10)
-  static constexpr int kDepth         = IT < kRingDepth ? IT : kRingDepth;  // rows in flight per lane group
-  static_assert(TR % kGroups == 0, "lane groups must tile the rows evenly");
-
-  const mfma_args& a;
-  const int sub, gbase, group, f0, f0c;
-  const bool live;
-  __amdgpu_buffer_rsrc_t rsrc;   // x as a raw buffer (OFF32): out-of-range offsets read as zero
-
-  __device__ producer(const mfma_args& a_, int pw, int lane)
-    : a(a_),
-      sub(lane & (LG - 1)),
-      gbase(lane & ~(LG - 1)),
-      group(pw * kGroupsPerWave + lane / LG),
-      f0((lane & (LG - 1)) * 4),
-      f0c(((lane & (LG - 1)) * 4 < a_.F) ? (lane & (LG - 1)) * 4 : a_.F - 4),
-      live((lane & (LG - 1)) * 4 < a_.F),
-      rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_.x), 0, (int)a_.x_bytes, 0x00020000))
-  {
-  }
-
-  __device__ __forceinline__ int64_t row_of(int64_t tile, int it) const { return tile * TR + group + it * kGroups; }
-
-  // stage A: CSR bounds of the next tile (requested when a tile starts)
-  __device__ __forceinline__ void load_bounds(int64_t tile, bounds_t<IT>& b) const
-  {
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-      const int64_t row  = row_of(tile, it);
-      const int64_t rowc = row < a.n_rows ? row : a.n_rows - 1;
-      b.s[it]            = a.row_ptr[rowc];
-      b.e[it]            = a.row_ptr[rowc + 1];
-    }
-  }
-  // stage B: this lane's neighbour id of every row + the self row ids (requested half-way through the tile); unconditional
-  __device__ __forceinline__ void load_ids(int64_t tile, const bounds_t<IT>& b, ids_t<IT>& v) const
-  {
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-      const int64_t row = row_of(tile, it);
-      v.deg[it]         = row < a.n_rows ? b.e[it] - b.s[it] : -1;
-      const int* pc     = (sub < b.e[it] - b.s[it]) ? a.col + b.s[it] + sub : a.row_ptr;  // row_ptr[0] == 0: a valid row
-      v.lcol[it]        = *pc;
-      v.lself[it]       = (int)a.self_rows[row < a.n_rows ? row : a.n_rows - 1];
-    }
-  }
-  // stage C: byte offsets (with the id indirection of the fused-fetch variant: one more dependent load)
-  __device__ __forceinline__ void finish(const ids_t<IT>& v, meta_t<IT, off_t>& m) const
-  {
-    const IdT* src_ids = static_cast<const IdT*>(a.src_ids);
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-      m.d[it]    = v.deg[it];
-      m.src[it]  = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lcol[it]) * a.ldx * 4);
-      m.self[it] = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lself[it]) * a.ldx * 4);
-    }
-  }
-  // request the kNb neighbour rows + the self row of row `it`; every load is unconditional
-  __device__ __forceinline__ void issue(const meta_t<IT, off_t>& m, int it, f32x4* v) const
-  {
-    if constexpr (OFF32) {
-      // slots past the degree (and the self slot of a row past n_rows) get an out-of-range offset: zeros, no memory access
-#pragma unroll
-      for (int k = 0; k < kNb; k++) {
-        const uint32_t off = (uint32_t)__shfl((int)m.src[it], gbase | (k & (LG - 1)), 64);
-        v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, k < m.d[it] ? off + f0c * 4 : a.x_bytes, 0, 0));
-      }
-      if constexpr (!HALF)
-        v[kNb] = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, m.d[it] >= 0 ? (uint32_t)m.self[it] + f0c * 4 : a.x_bytes, 0, 0));
-    } else {
-      const char* xb = reinterpret_cast<const char*>(a.x);
-#pragma unroll
-      for (int k = 0; k < kNb; k++) {
-        const int src_lane = gbase | (k & (LG - 1));
-        const int lo       = __shfl((int)(m.src[it] & 0xffffffff), src_lane, 64);
-        const int hi       = __shfl((int)((int64_t)m.src[it] >> 32), src_lane, 64);
-        int64_t off        = ((int64_t)hi << 32) | (uint32_t)lo;
-        off                = k < m.d[it] ? off : (int64_t)0;   // slots past the degree read row 0 (L1-resident), masked below
-        v[k]               = *reinterpret_cast<const f32x4*>(xb + off + f0c * 4);
-      }
-      if constexpr (!HALF)
-        v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? (int64_t)m.self[it] : (int64_t)0) + f0c * 4);
-    }
-  }
-  // sum row `it` from its ring slot (CSR order) and store [mean | self] as fp32
-  __device__ __forceinline__ void reduce_store(const meta_t<IT, off_t>& m, int it, const f32x4* v, float* tile_lds) const
-  {
-    const int deg = m.d[it];
-    f32x4 acc     = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < kNb; k++) {
-      if constexpr (OFF32) acc += v[k];                                   // the hardware already zeroed the dead slots
-      else acc += k < deg ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};             // select, never multiply by 0
-    }
-    if (a.mean && deg > 0 && deg <= kNb) acc *= __frcp_rn((float)deg);   // (longer rows: long_rows() continues this sum)
-    if (live) {
-      float* prow = tile_lds + (group + it * kGroups) * a.SD;
-      *reinterpret_cast<f32x4*>(prow + f0) = acc;
-      if constexpr (!HALF) {
-        f32x4 self = v[kNb];
-        if constexpr (!OFF32) self = deg >= 0 ? self : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(prow + a.F + f0) = self;
-      }
-    }
-  }
-  // SECOND WINDOW: neighbours kNb .. kNb + kW2 - 1 of the rows that have them.  Their byte offsets are already in registers —
-  // load_ids / finish gave lane `sub` of the group the offset of neighbour `sub`, whatever the degree — so a row behind a
-  // fan-out of 25 needs no further id loads: kW2 row loads go out together and continue the window's UNSCALED partial sum
-  // (left in the tile by reduce_store) in CSR order.  Rows with deg <= kNb + kW2 are finished here.
-  static constexpr int kW2 = LG >= 32 ? 16 : (LG > kNb ? LG - kNb : 0);
-  __device__ __forceinline__ void second_window(const meta_t<IT, off_t>& m, float* tile_lds) const
-  {
-    if constexpr (kW2 > 0) {
-#pragma unroll
-      for (int it = 0; it < IT; it++) {
-        const int deg = m.d[it];
-        if (__ballot(deg > kNb) == 0ull) continue;
-        const bool mine = live && deg > kNb;
-        f32x4 v[kW2];
-#pragma unroll
-        for (int k = 0; k < kW2; k++) {
-          const int kk = kNb + k;
-          if constexpr (OFF32) {
-            const uint32_t off = (uint32_t)__shfl((int)m.src[it], gbase | kk, 64);
-            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kk < deg ? off + f0c * 4 : a.x_bytes, 0, 0));
-          } else {
-            const int lo = __shfl((int)(m.src[it] & 0xffffffff), gbase | kk, 64);
-            const int hi = __shfl((int)((int64_t)m.src[it] >> 32), gbase | kk, 64);
-            int64_t off  = ((int64_t)hi << 32) | (uint32_t)lo;
-            off          = kk < deg ? off : (int64_t)0;
-            v[k]         = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + off + f0c * 4);
-          }
-        }
-        float* prow = tile_lds + (group + it * kGroups) * a.SD + f0;
-        f32x4 acc   = {0.f, 0.f, 0.f, 0.f};
-        if (mine) acc = *reinterpret_cast<const f32x4*>(prow);
-#pragma unroll
-        for (int k = 0; k < kW2; k++) {
-          if constexpr (OFF32) acc += v[k];
-          else acc += kNb + k < deg ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (mine) {
-          if (a.mean && deg <= kNb + kW2) acc *= __frcp_rn((float)deg);
-          *reinterpret_cast<f32x4*>(prow) = acc;
-        }
-      }
-    }
-  }
-  // rows longer than BOTH windows (deg > 26 at F >= 100): the tile holds the UNSCALED sum of their first kNb + kW2 neighbours;
-  // the rest is added to it in CSR order, kLongUnroll row
-  // loads in flight at a time (one at a time — a dependent round trip per neighbour — made the 47-class head of the products
-  // model, whose hop has fan-out 25, three times slower than aggregate + GEMM)
-  static constexpr int kLongUnroll = 8;
-  __device__ __forceinline__ void long_rows(int64_t tile, const meta_t<IT, off_t>& m, float* tile_lds) const
-  {
-    const IdT* src_ids = static_cast<const IdT*>(a.src_ids);
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-      const int deg = m.d[it];
-      if (__ballot(deg > kNb + kW2) == 0ull) continue;
-      const bool mine    = live && deg > kNb + kW2;
-      const int64_t row  = row_of(tile, it);
-      const int64_t rowc = row < a.n_rows ? row : a.n_rows - 1;
-      const int s        = a.row_ptr[rowc];
-      float* prow        = tile_lds + (group + it * kGroups) * a.SD + f0;
-      f32x4 acc          = {0.f, 0.f, 0.f, 0.f};
-      if (mine) acc = *reinterpret_cast<const f32x4*>(prow);
-      int maxdeg = deg > kNb + kW2 ? deg : 0;
-#pragma unroll
-      for (int dd = 32; dd >= LG; dd >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, dd, 64));
-      for (int c0 = kNb + kW2; c0 < maxdeg; c0 += LG) {
-        const int64_t my_src = (deg > kNb + kW2 && c0 + sub < deg) ? table_row<IdT>(src_ids, (int64_t)a.col[s + c0 + sub]) : 0;
-        const int chunk      = min(LG, maxdeg - c0);
-        for (int j0 = 0; j0 < chunk; j0 += kLongUnroll) {
-          f32x4 v[kLongUnroll];
-#pragma unroll
-          for (int u = 0; u < kLongUnroll; u++) {
-            const int j        = j0 + u;
-            const int src_lane = gbase | (j & (LG - 1));
-            const int lo       = __shfl((int)(my_src & 0xffffffff), src_lane, 64);
-            const int hi       = __shfl((int)(my_src >> 32), src_lane, 64);
-            const int64_t rr   = (mine && j < chunk && c0 + j < deg) ? (((int64_t)hi << 32) | (uint32_t)lo) : (int64_t)0;
-            v[u]               = *reinterpret_cast<const f32x4*>(a.x + rr * a.ldx + f0c);   // dead slots read row 0, masked below
-          }
-#pragma unroll
-          for (int u = 0; u < kLongUnroll; u++) {
-            const int j = j0 + u;
-            acc += (mine && j < chunk && c0 + j < deg) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-      }
-      if (mine) {
-        if (a.mean) acc *= __frcp_rn((float)deg);
-        *reinterpret_cast<f32x4*>(prow) = acc;
-      }
-    }
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------------------------
-// consumer side: wave cw multiplies the [TR x 2F] tile by columns [64 cw, 64 cw + 64) of the weight
-// ---------------------------------------------------------------------------------------------------------------------
-template <int RT>
-struct araw_t {
-  f32x4 v[RT][2];  // [row tile][k 0-3 | k 4-7 of this lane's half k-step]
-};
-template <int RT>
-struct afrag_t {
-  u32x4 v[RT][3];  // [row tile][plane]
-};
-struct bfrag_t {
-  u32x4 v[2][3];  // [col tile][plane]
-};
-struct braw_t {
-  f32x4 v[2][2];  // [col tile][k 0-3 | k 4-7 of this lane's half k-step]: the fp32 weight as it travels
-};
-
-template <int RT>
-__device__ __forceinline__ void load_a_raw(araw_t<RT>& f, const float* a_lane, int sd, int ks)
-{
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-    f.v[rt][0] = *reinterpret_cast<const f32x4*>(a_lane + rt * 32 * sd + ks * 16);
-    f.v[rt][1] = *reinterpret_cast<const f32x4*>(a_lane + rt * 32 * sd + ks * 16 + 4);
-  }
-}
-// fp32 fragment -> the three bf16 planes (VALU work that issues under the wave's own MFMAs)
-template <int RT>
-__device__ __forceinline__ void split_a(const araw_t<RT>& r, afrag_t<RT>& f)
-{
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-#ifdef WG_ABL_NO_SPLIT   // tuning build: no split work (wrong results) — prices the VALU side of the multiplying waves
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      f.v[rt][0][j] = __float_as_uint(r.v[rt][0][j]);
-      f.v[rt][1][j] = __float_as_uint(r.v[rt][1][j]);
-      f.v[rt][2][j] = __float_as_uint(r.v[rt][0][j]);
-    }
-    continue;
-#endif
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      split3(r.v[rt][0][i], h[i], m[i], l[i]);
-      split3(r.v[rt][1][i], h[4 + i], m[4 + i], l[4 + i]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      f.v[rt][0][j] = pack_hi16(h[2 * j], h[2 * j + 1]);
-      f.v[rt][1][j] = pack_hi16(m[2 * j], m[2 * j + 1]);
-      f.v[rt][2][j] = pack_hi16(l[2 * j], l[2 * j + 1]);
-    }
-  }
-}
-// The weight travels as fp32 (4 B per element) and is split into its three bf16 planes by the multiplying wave, in the issue
-// slots under its own MFMAs — the pre-split planes of round 2 were 6 B per element, and the weight stream (once per 64-row
-// tile per CU, through the same vector-memory pipeline as the row fetches) is what the layer's time is most sensitive to:
-// each third of it costs 0.045 ms of the 0.55 ms layer-1 launch (compile-time ablations).  Same products,
-// bit-identical results.
-__device__ __forceinline__ void load_b(braw_t& f, const float* b_lane, int n_cols, int ks)
-{
-#pragma unroll
-  for (int ct = 0; ct < 2; ct++) {
-    const float* p = b_lane + ((int64_t)ks * n_cols + ct * 32) * 16;
-    f.v[ct][0]     = *reinterpret_cast<const f32x4*>(p);
-    f.v[ct][1]     = *reinterpret_cast<const f32x4*>(p + 4);
-  }
-}
-// HALF mode (F > 148, K = 512: the multiplying waves are the busier side there and the split of the weight in registers
-// costs more than the bytes it saves: 1.74 vs 1.69 ms at 256 -> 256 in round 2; with the round-3 loop there are no
-// registers left for fp32 fragments two k-steps ahead AND split planes) keeps the pre-split planes [3][KS][N][8 dwords]
-__device__ __forceinline__ void load_b_planes(bfrag_t& f, const uint32_t* b_lane, int64_t b_plane_dw, int n_cols, int ks)
-{
-#ifdef WG_ABL_NO_B
-  return;
-#endif
-#pragma unroll
-  for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-      f.v[ct][p] = *reinterpret_cast<const u32x4*>(b_lane + p * b_plane_dw + ((int64_t)ks * n_cols + ct * 32) * 8);
-}
-__device__ __forceinline__ void split_b(const braw_t& r, bfrag_t& f)
-{
-#pragma unroll
-  for (int ct = 0; ct < 2; ct++) {
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      split3(r.v[ct][0][i], h[i], m[i], l[i]);
-      split3(r.v[ct][1][i], h[4 + i], m[4 + i], l[4 + i]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      f.v[ct][0][j] = pack_hi16(h[2 * j], h[2 * j + 1]);
-      f.v[ct][1][j] = pack_hi16(m[2 * j], m[2 * j + 1]);
-      f.v[ct][2][j] = pack_hi16(l[2 * j], l[2 * j + 1]);
-    }
-  }
-}
-
-template <int RT>
-__device__ __forceinline__ void mma_frags(f32x16 (&c)[RT][2], const afrag_t<RT>& fa, const bfrag_t& fb)
-{
-  // smallest terms first; per accumulator tile the six products are independent MFMAs on the same accumulator
-  constexpr int pa[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int pb[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-  for (int t = 0; t < WG_MFMA_PRODUCTS; t++)
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-      for (int ct = 0; ct < 2; ct++)
-        c[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa.v[rt][pa[t]]),
-                                                            __builtin_bit_cast(bf16x8, fb.v[ct][pb[t]]), c[rt][ct], 0, 0, 0);
-}
-
-// ---- epilogue: bias, activation, 16-B stores ---------------------------------------------------------------------------
-// C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane owns one column, so a
-// direct store is 4 B per lane (two 128-B segments per instruction, 64 instructions per wave and tile, each one a slot in
-// the CU's memory pipeline that the producers' row fetches queue behind).  The four registers 4g .. 4g+3 of all lanes are
-// the 8 consecutive rows 8g .. 8g+7 of a row tile: they go through this wave's 2 KiB LDS scratch [8][64] and leave as
-// 16 B per lane, 256 B per row and wave — 16 store instructions of 1 KiB per wave and tile.
-constexpr int kScratchDw = 8 * 64;   // per consumer wave
-
-template <int RT>
-__device__ __forceinline__ void epilogue(const mfma_args& a, f32x16 (&c)[RT][2], int64_t row0, int cw, int lane, float* scratch)
-{
-  const int lm = lane & 31, lh = lane >> 5;
-  float bj[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ct++) bj[ct] = a.bias ? a.bias[cw * 64 + ct * 32 + lm] : 0.f;
-  if (a.debug & 4) {
-    if (c[0][0][0] == 12345.678f) a.out[0] = c[0][1][3] + c[RT - 1][1][5];
-    return;
-  }
-  const bool full = row0 + RT * 32 <= a.n_rows;
-  const int rl = lane >> 4, cl = (lane & 15) * 4;
-  float* obase = a.out + (row0 + rl) * a.ldo + cw * 64 + cl;
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          const float v = c[rt][ct][4 * g + jj] + bj[ct];
-          scratch[(jj + 4 * lh) * 64 + ct * 32 + lm] = a.relu ? fmaxf(v, 0.f) : v;
-        }
-#pragma unroll
-      for (int pass = 0; pass < 2; pass++) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (rl + 4 * pass) * 64 + cl);
-        const int r   = rt * 32 + 8 * g + 4 * pass;   // + rl
-        // (non-temporal stores here: 0.518 -> 0.514 ms, inside the noise — not taken)
-        if (full || row0 + r + rl < a.n_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)r * a.ldo) = v;
-      }
-    }
-}
+using namespace sage_mfma;
 
 // ---- runtime shape: weight fragments one k-step ahead ------------------------------------------------------------------
 template <int TR>
@@ -635,12 +166,28 @@ __device__ __forceinline__ void consume_range(const mfma_args& a, f32x16 (&c)[RT
 // k-step ks and split at its end: both overlap the 24 MFMAs of k-step ks.
 constexpr int kPD = 2;
 __host__ __device__ constexpr int b_slot(int ks) { return ks < kPD ? ks : kPD + (ks % kPD); }
+// Round 4: the LAST k-steps of the weight wait in the LDS the two operand tiles leave free (F = 100: 48 KB = 3 of 13 k-steps,
+// F = 128: 1 of 16), written once per launch by the multiplying waves in the order they read it (lane-linear 16-B chunks) —
+// that share of the weight stream leaves the CU's vector-memory pipeline, where each third of it was priced at 0.045 ms of the
+// 0.55 ms layer-1 launch; the fragments still arrive kPD k-steps ahead, from ds_read_b128 instead of L2.
+__host__ __device__ constexpr int w_lds_ksteps(int FC)
+{
+#ifdef WG_NO_WLDS   // (tuning build: the round-3 kernel)
+  return 0;
+#endif
+  const int tiles = (2 * 64 * row_stride_dw(FC) + 16 + 4 * kScratchDw + 16) * 4;
+  const int free_ = 160 * 1024 - tiles;
+  const int ks    = free_ / (256 * 64);
+  return ks < 0 ? 0 : (ks > 4 ? 4 : ks);
+}
 
 template <int TR, int FC>
 struct static_consumer {
   static constexpr int RT = TR / 32, KSC = (2 * FC + 15) / 16, SD = row_stride_dw(FC);
+  static constexpr int KL = TR == 64 ? w_lds_ksteps(FC) : 0;   // k-steps [KSC - KL, KSC) are read from the LDS
   braw_t bb[2 * kPD];    // fp32 fragments: [0, kPD): heads = k-steps 0 .. kPD-1 of a tile; [kPD, 2 kPD): ring for the rest
   uint32_t b_lane_off;   // bytes
+  const float* w_lds;    // this lane's 16-B chunk of [k-step - (KSC - KL)][col tile][half] x 64 lanes in the wave's LDS slice
   f32x16 c[RT][2];       // accumulators of the tile being multiplied / waiting to be stored
 
   __device__ __forceinline__ void load_b_static(const mfma_args& a, braw_t& f, int ks) const
@@ -651,6 +198,14 @@ struct static_consumer {
 #ifdef WG_ABL_HALF_B   // tuning build: every other k-step's weight fragments only — prices HALF the weight stream
     if (ks & 1) return;
 #endif
+    if (ks >= KSC - KL) {   // (ks is a compile-time constant at every call site)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+          f.v[ct][h] = *reinterpret_cast<const f32x4*>(w_lds + (((ks - (KSC - KL)) * 2 + ct) * 2 + h) * 256);
+      return;
+    }
     const char* wb = reinterpret_cast<const char*>(a.w_tiles);   // uniform: stays in SGPRs
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
@@ -660,9 +215,22 @@ struct static_consumer {
     }
   }
 
-  __device__ __forceinline__ void prime(const mfma_args& a, int cw, int lane)
+  __device__ __forceinline__ void prime(const mfma_args& a, int cw, int lane, float* w_lds_wave)
   {
     b_lane_off = (uint32_t)(((cw * 64 + (lane & 31)) * 16 + (lane >> 5) * 8) * 4);
+    w_lds      = w_lds_wave + lane * 4;
+    if constexpr (KL > 0) {
+      const char* wb = reinterpret_cast<const char*>(a.w_tiles);
+#pragma unroll
+      for (int ks = KSC - KL; ks < KSC; ks++)
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+            *reinterpret_cast<f32x4*>(const_cast<float*>(w_lds) + (((ks - (KSC - KL)) * 2 + ct) * 2 + h) * 256) =
+              *reinterpret_cast<const f32x4*>(wb + ((size_t)ks * a.N + ct * 32) * 64 + b_lane_off + h * 16);
+      // (read back by this wave only: the LDS executes a wave's operations in order)
+    }
 #pragma unroll
     for (int j = 0; j < kPD; j++) load_b_static(a, bb[j], j);
   }
@@ -886,7 +454,7 @@ sage_layer_mfma_kernel(mfma_args a)
     float* scratch = lds + 2 * tile_dw + 16 + wave * kScratchDw;
     if constexpr (FC > 0) {
       static_consumer<TR, FC> cons;
-      cons.prime(a, wave, lane);
+      cons.prime(a, wave, lane, lds + 2 * tile_dw + 16 + CW * kScratchDw + 16 + wave * (decltype(cons)::KL * 16 * 64));
       // Two consumer waves share a SIMD (ranks 2k, 2k+1) and one matrix pipe.  They are kept out of phase: the even one
       // multiplies a tile and stores it in the same step, the odd one stores the PREVIOUS tile first (its accumulators stay
       // live across the barrier) and multiplies afterwards — so one wave's epilogue (LDS transpose, stores, waits) runs
@@ -987,7 +555,7 @@ void launch(const mfma_args& a, hipStream_t st)
 {
   const int cus         = stream_cu_count(st);
   const int64_t n_tiles = (a.n_rows + TR - 1) / TR;
-  const size_t lds      = lds_bytes(a.F, TR);
+  const size_t lds      = lds_bytes(a.F, TR) + (FC > 0 && TR == 64 ? (size_t)w_lds_ksteps(FC) * CW * 64 * 64 : 0);
   // ONE workgroup per CU: the SIMD role split needs the CU to itself (two waves per SIMD)
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus));
   auto go        = [&](auto kern) {
@@ -1104,6 +672,11 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row
     static const int dbg = [] { const char* e = getenv("WGAMD_SAGE_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug = dbg;
     auto st = static_cast<hipStream_t>(stream);
+    if (sage_ws_supported(F, N)) {
+      if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64)
+        throw invalid_input("src_ids must be INT or INT64");
+      return sage_ws_launch(a, src_ids == nullptr ? 0 : (src_ids_dtype == WHOLEMEMORY_DT_INT ? 1 : 2), st);
+    }
     if (src_ids == nullptr) launch_groups<void>(a, st);
     else if (src_ids_dtype == WHOLEMEMORY_DT_INT) launch_groups<int32_t>(a, st);
     else if (src_ids_dtype == WHOLEMEMORY_DT_INT64) launch_groups<int64_t>(a, st);
