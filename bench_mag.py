@@ -75,6 +75,7 @@ class MagPipeline:
     def __init__(self, graphs, num_nodes, tables, params, dev, B, G, fanout=(25, 10)):
         from wholegraph_amd import fused, nn
         self.nn, self.dev, self.B, self.G = nn, dev, B, G
+        self.fused_tail = os.environ.get("WGAMD_GAT_TRANSFORM", "bf16x3") != "library"
         self.etypes = sorted(graphs)
         self.ntypes = sorted({t for et in self.etypes for t in (et[0], et[2])})
         self.fanout = {et: list(fanout) for et in self.etypes}
@@ -251,20 +252,33 @@ class MagPipeline:
                         continue
                     # HeteroConv's sum over the relations into `acc`: the first relation with edges WRITES it (beta = 0)
                     acc = torch.empty((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
-                    first = True
-                    for c in mine:
+                    live_rel = [c for c in mine if c["n_e"] > 0]   # (nothing sampled for a relation: it adds nothing to the sum)
+                    # one-pass tail (wgamd_gat_transform_heads_bf16x3): the LAST relation's transform also adds the bias, applies
+                    # the ReLU and places the hop's rows — no separate bias / ReLU pass over the layer output
+                    one_pass = self.fused_tail and bool(live_rel) and \
+                        nn.gat_transform_supported(xs[live_rel[0]["et"][0]].shape[1], HEADS, HC // HEADS)
+                    if one_pass and layer == 1:
+                        out[dt] = torch.empty((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
+                    for j, c in enumerate(live_rel):
                         et = c["et"]
-                        if c["n_e"] == 0:
-                            continue      # nothing sampled for this relation: it adds nothing to HeteroConv's sum
                         agg = stage("gat%d:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
                                     lambda: nn.gat_aggregate_heads(c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], HEADS,
                                                                    dst_rows=c[dst_key]))
-                        stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads(agg, p["rel"][et]["w"], HEADS, out=acc,
-                                                                                          overwrite=first))
-                        first = False
+                        if one_pass:
+                            last = j == len(live_rel) - 1
+                            stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads_fused(
+                                agg, p["rel"][et]["w"], HEADS, acc_in=acc if j > 0 else None,
+                                bias=p["bias"][dt] if last else None, relu=last,
+                                out_rows=mine[0]["dst_c"] if (last and layer == 0) else None,
+                                out=out[dt] if last else acc))
+                        else:
+                            stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads(agg, p["rel"][et]["w"], HEADS, out=acc,
+                                                                                              overwrite=j == 0))
                         if launches is not None:
                             launches.append((et, h, c["n_f"], c["n_e"], xs[et[0]].shape[1]))
-                    if first:
+                    if one_pass:
+                        continue
+                    if not live_rel:
                         acc.zero_()       # no relation of this type sampled an edge in this hop: relu(bias) rows
                     # bias + ReLU (+ the placement of the hop's rows in the compact list of layer 1) in one pass
                     if layer == 0:

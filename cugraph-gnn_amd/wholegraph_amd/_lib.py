@@ -256,6 +256,11 @@ SYMBOLS = {
     "wgamd_call_group_hop_rows": (c_int, [c_void_p] * 5 + [c_int64] + [c_void_p] * 8 + [c_void_p]),
     "wgamd_call_group_layer_cols": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 5),
     "wgamd_bias_act_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wgamd_gat_transform_heads_supported": (c_int, [c_int, c_int, c_int]),
+    "wgamd_gat_transform_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "wgamd_gat_transform_weight_tiles": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wgamd_gat_transform_heads_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
+                                                 c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_aggregate_heads_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                               c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_csr_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_float,

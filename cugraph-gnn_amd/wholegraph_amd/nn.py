@@ -330,12 +330,19 @@ def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=None, neg
     return out
 
 
-def gat_transform_heads(agg, w, heads, out=None, overwrite=False):
-    """``out[i, h*C:(h+1)*C] (+)= agg[i, h, :] @ w[:, h*C:(h+1)*C]`` — the H small GEMMs after ``gat_aggregate_heads``
-    (one strided batched GEMM, MFMA through hipBLASLt).  ``out`` given: accumulated into (HeteroConv's sum), or written
-    (``overwrite``)."""
+def gat_transform_heads(agg, w, heads, out=None, overwrite=False, fused=None):
+    """``out[i, h*C:(h+1)*C] (+)= agg[i, h, :] @ w[:, h*C:(h+1)*C]`` — the H small GEMMs after ``gat_aggregate_heads``.
+    ``out`` given: accumulated into (HeteroConv's sum), or written (``overwrite``).  Shapes
+    ``wgamd_gat_transform_heads_bf16x3`` is built for (C = 64, F in {64, 128, 256}) run on it (``gat_transform_heads_fused``:
+    the bf16 matrix pipe at fp32 accuracy, one pass); ``fused=False`` or any other shape: one strided batched library GEMM
+    (fp32 MFMA through hipBLASLt)."""
     n, F_ = agg.shape[0], agg.shape[1] // heads
     C = w.shape[1] // heads
+    if fused is None:
+        fused = _GAT_TRANSFORM_FUSED
+    if fused and n > 0 and agg.is_cuda and agg.stride(1) == 1 and w.stride(1) == 1 and gat_transform_supported(F_, heads, C) \
+            and (out is None or out.stride(1) == 1):
+        return gat_transform_heads_fused(agg, w, heads, acc_in=None if (out is None or overwrite) else out, out=out)
     a, b = agg.view(n, heads, F_).permute(1, 0, 2), w.view(F_, heads, C).permute(1, 0, 2)
     if out is None:
         return torch.bmm(a, b).permute(1, 0, 2).reshape(n, heads * C)                                    # [H, n, C] -> [n, H C]
@@ -344,6 +351,48 @@ def gat_transform_heads(agg, w, heads, out=None, overwrite=False):
     # ``overwrite``: beta = 0 — ``out`` need not be initialised (the first relation of HeteroConv's sum: no zero-fill, no read)
     acc = out.view(n, heads, C).permute(1, 0, 2)
     torch.baddbmm(acc, a, b, beta=0 if overwrite else 1, out=acc)
+    return out
+
+
+_GAT_TRANSFORM_FUSED = os.environ.get("WGAMD_GAT_TRANSFORM", "bf16x3") != "library"
+
+
+def gat_transform_supported(F_: int, heads: int, C: int) -> bool:
+    return bool(L.lib().wgamd_gat_transform_heads_supported(int(F_), int(heads), int(C)))
+
+
+def _gat_weight_tiles(w: torch.Tensor, heads: int) -> torch.Tensor:
+    """``w`` [F, H C] in the order ``wgamd_gat_transform_heads_bf16x3`` reads it; cached on the weight like ``sage_weight_planes``."""
+    hit = getattr(w, "_wgamd_gat_tiles", None)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        return hit[2]
+    F_, C = w.shape[0], w.shape[1] // heads
+    tiles = torch.empty(L.lib().wgamd_gat_transform_weight_bytes(F_, heads, C), dtype=torch.uint8, device=w.device)
+    L.check(L.lib().wgamd_gat_transform_weight_tiles(w.data_ptr(), w.stride(0), F_, heads, C, tiles.data_ptr(), get_stream()),
+            "wgamd_gat_transform_weight_tiles")
+    try:
+        w._wgamd_gat_tiles = (w._version, w.data_ptr(), tiles)
+    except AttributeError:
+        pass
+    return tiles
+
+
+def gat_transform_heads_fused(agg, w, heads, acc_in=None, bias=None, relu=False, out_rows=None, out=None):
+    """``out[out_rows[i]] = act(agg[i, h, :] @ w[:, h C:(h+1) C] + acc_in[i] + bias)`` in ONE kernel
+    (``wgamd_gat_transform_heads_bf16x3``: the per-head GEMMs on the bf16 matrix pipe at fp32 accuracy, HeteroConv's running sum,
+    bias, ReLU and the row placement).  ``acc_in`` may be ``out`` itself when ``out_rows`` is None."""
+    n, F_ = agg.shape[0], agg.shape[1] // heads
+    C = w.shape[1] // heads
+    assert agg.dtype == torch.float32 and agg.stride(1) == 1 and w.dtype == torch.float32 and w.stride(1) == 1 and w.shape[0] == F_
+    if out is None:
+        assert out_rows is None
+        out = torch.empty((n, heads * C), dtype=torch.float32, device=agg.device)
+    assert out.stride(1) == 1 and (acc_in is None or acc_in.stride(1) == 1)
+    L.check(L.lib().wgamd_gat_transform_heads_bf16x3(
+        agg.data_ptr(), agg.stride(0), n, F_, heads, C, _gat_weight_tiles(w, heads).data_ptr(),
+        None if acc_in is None else acc_in.data_ptr(), 0 if acc_in is None else acc_in.stride(0),
+        None if bias is None else bias.data_ptr(), int(bool(relu)), None if out_rows is None else out_rows.data_ptr(),
+        out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_transform_heads_bf16x3")
     return out
 
 

@@ -415,6 +415,22 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
                                                        float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
                                                        void* stream);
 
+/* The dense tail after wgamd_gat_aggregate_heads_f32 on the matrix pipe at fp32 accuracy (csrc/wg_gat_transform.hip):
+ *   out[out_rows ? out_rows[i] : i, h C + c] = act( sum_k agg[i, h F + k] W[k, h C + c] (+ acc_in[i, h C + c]) (+ bias[h C + c]) )
+ * — the H per-head GEMMs, HeteroConv's sum over the relations of a destination type (`acc_in`, may alias `out` when
+ * out_rows is null) and the layer's bias / ReLU / row placement in one pass.  The product is the exact 3-way bf16 split of
+ * wgamd_sage_layer_fused_bf16x3 (six bf16 MFMAs per fp32 product, fp32 accumulate).  `w_tiles` = W [F, H C] row-major
+ * re-ordered by wgamd_gat_transform_weight_tiles into wgamd_gat_transform_weight_bytes(F, H, C) bytes.
+ * Shapes (wgamd_gat_transform_heads_supported): C == 64, F in {64, 128, 256}; rows and the bias 16-byte aligned. */
+int wgamd_gat_transform_heads_supported(int F, int H, int C);
+size_t wgamd_gat_transform_weight_bytes(int F, int H, int C);
+wholememory_error_code_t wgamd_gat_transform_weight_tiles(const float* w, int64_t ldw, int F, int H, int C, void* tiles,
+                                                          void* stream);
+wholememory_error_code_t wgamd_gat_transform_heads_bf16x3(const float* agg, int64_t ld_agg, int64_t n_rows, int F, int H, int C,
+                                                          const void* w_tiles, const float* acc_in, int64_t ld_acc,
+                                                          const float* bias, int relu, const int64_t* out_rows, float* out,
+                                                          int64_t ldo, void* stream);
+
 /* Backward of wgamd_gat_csr_f32 (csrc/wg_gat_bwd.hip): given grad_out [n_rows, H*C] and the forward's alpha [E, H], writes
  * grad_x [n_src, H*C], grad_a_src [n_src, H], grad_a_dst [n_rows, H]; de [E, H] is scratch.  Needs the hop CSR transposed:
  * row_ptr_t [n_src+1], edge_perm [E] (edge ids sorted by source, stable), edge_dst [E] (destination row of every edge).
