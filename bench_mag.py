@@ -76,6 +76,7 @@ class MagPipeline:
         from wholegraph_amd import fused, nn
         self.nn, self.dev, self.B, self.G = nn, dev, B, G
         self.fused_tail = os.environ.get("WGAMD_GAT_TRANSFORM", "bf16x3") != "library"
+        self.fused_layer = os.environ.get("WGAMD_GAT_LAYER", "fused") != "split"
         self.etypes = sorted(graphs)
         self.ntypes = sorted({t for et in self.etypes for t in (et[0], et[2])})
         self.fanout = {et: list(fanout) for et in self.etypes}
@@ -261,11 +262,23 @@ class MagPipeline:
                         out[dt] = torch.empty((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
                     for j, c in enumerate(live_rel):
                         et = c["et"]
+                        last = j == len(live_rel) - 1
+                        # deep hop (fan-out <= 10) of layer 1: aggregation + dense tail as ONE kernel, the aggregate stays in LDS
+                        if one_pass and self.fused_layer and self.fanout[et][h] <= 10 and \
+                                nn.gat_layer_fused_supported(xs[et[0]].shape[1], HEADS, HC // HEADS):
+                            stage("gat%d+transform:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
+                                  lambda: nn.gat_layer_fused(
+                                      c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], p["rel"][et]["w"], HEADS,
+                                      dst_rows=c[dst_key], acc_in=acc if j > 0 else None, bias=p["bias"][dt] if last else None,
+                                      relu=last, out_rows=mine[0]["dst_c"] if (last and layer == 0) else None,
+                                      out=out[dt] if last else acc))
+                            if launches is not None:
+                                launches.append((et, h, c["n_f"], c["n_e"], xs[et[0]].shape[1]))
+                            continue
                         agg = stage("gat%d:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
                                     lambda: nn.gat_aggregate_heads(c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], HEADS,
                                                                    dst_rows=c[dst_key]))
                         if one_pass:
-                            last = j == len(live_rel) - 1
                             stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads_fused(
                                 agg, p["rel"][et]["w"], HEADS, acc_in=acc if j > 0 else None,
                                 bias=p["bias"][dt] if last else None, relu=last,

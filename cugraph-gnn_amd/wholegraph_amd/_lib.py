@@ -261,6 +261,10 @@ SYMBOLS = {
     "wgamd_gat_transform_weight_tiles": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wgamd_gat_transform_heads_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                                                  c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wgamd_gat_layer_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "wgamd_gat_layer_fused_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
+                                             c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                             c_int64, c_void_p]),
     "wgamd_gat_aggregate_heads_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                               c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_csr_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_float,

@@ -396,6 +396,31 @@ def gat_transform_heads_fused(agg, w, heads, acc_in=None, bias=None, relu=False,
     return out
 
 
+def gat_layer_fused_supported(F_: int, heads: int, C: int) -> bool:
+    return bool(L.lib().wgamd_gat_layer_fused_supported(int(F_), int(heads), int(C)))
+
+
+def gat_layer_fused(row_ptr, col, x, a_src, a_dst, w, heads, dst_rows=None, negative_slope=0.2, acc_in=None, bias=None, relu=False,
+                    out_rows=None, out=None):
+    """``gat_aggregate_heads`` + ``gat_transform_heads_fused`` as ONE kernel (``wgamd_gat_layer_fused_bf16x3``): the
+    [n_rows, heads * F] aggregate never leaves the CU.  For hops with a fan-out of at most 10 (longer rows are correct, slow)."""
+    _check_csr(row_ptr, col)
+    n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
+    C = w.shape[1] // heads
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and a_src.is_contiguous() and a_dst.is_contiguous() and a_src.shape[1] == heads
+    if out is None:
+        assert out_rows is None
+        out = torch.empty((n_rows, heads * C), dtype=torch.float32, device=x.device)
+    assert col.numel() > 0 and out.stride(1) == 1 and (acc_in is None or acc_in.stride(1) == 1)
+    L.check(L.lib().wgamd_gat_layer_fused_bf16x3(
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_, a_src.data_ptr(), a_dst.data_ptr(), heads, C,
+        float(negative_slope), None if dst_rows is None else dst_rows.data_ptr(), _gat_weight_tiles(w, heads).data_ptr(),
+        None if acc_in is None else acc_in.data_ptr(), 0 if acc_in is None else acc_in.stride(0),
+        None if bias is None else bias.data_ptr(), int(bool(relu)), None if out_rows is None else out_rows.data_ptr(),
+        out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_layer_fused_bf16x3")
+    return out
+
+
 def gather_terms_supported(F_: int, T: int) -> bool:
     return bool(L.lib().wgamd_gather_terms_supported(int(F_), int(T)))
 

@@ -431,6 +431,18 @@ wholememory_error_code_t wgamd_gat_transform_heads_bf16x3(const float* agg, int6
                                                           const float* bias, int relu, const int64_t* out_rows, float* out,
                                                           int64_t ldo, void* stream);
 
+/* wgamd_gat_aggregate_heads_f32 + wgamd_gat_transform_heads_bf16x3 as ONE kernel (csrc/wg_gat_fused.hip): the [n_rows, H F]
+ * aggregate stays in LDS.  Same arguments and semantics as the two calls (a_src [N_src, H], a_dst row dst_rows ? dst_rows[i] : i,
+ * leaky-ReLU slope, then acc_in / bias / relu / out_rows / out of the transform).  Built for the deep hop of a sampled walk:
+ * rows of up to 10 neighbours run from registers, longer rows are correct but slow.
+ * Shapes (wgamd_gat_layer_fused_supported): F == 128, H == 4, C == 64; 16-byte aligned rows, terms and bias. */
+int wgamd_gat_layer_fused_supported(int F, int H, int C);
+wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x, int64_t ldx,
+                                                      int F, const float* a_src, const float* a_dst, int H, int C,
+                                                      float negative_slope, const int64_t* dst_rows, const void* w_tiles,
+                                                      const float* acc_in, int64_t ld_acc, const float* bias, int relu,
+                                                      const int64_t* out_rows, float* out, int64_t ldo, void* stream);
+
 /* Backward of wgamd_gat_csr_f32 (csrc/wg_gat_bwd.hip): given grad_out [n_rows, H*C] and the forward's alpha [E, H], writes
  * grad_x [n_src, H*C], grad_a_src [n_src, H], grad_a_dst [n_rows, H]; de [E, H] is scratch.  Needs the hop CSR transposed:
  * row_ptr_t [n_src+1], edge_perm [E] (edge ids sorted by source, stable), edge_dst [E] (destination row of every edge).

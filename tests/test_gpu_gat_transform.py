@@ -95,3 +95,70 @@ def test_adversarial_magnitudes(hiplib):
     got = nn.gat_transform_heads_fused(agg.cuda(), w.cuda(), H)
     ref, mag = _ref64(agg, w, H)
     assert float(((got.cpu().double() - ref).abs() / mag).max()) < 2e-6
+
+
+def _gat_ref64(rp, col, x, a_src, a_dst, w, H, slope, dst_rows=None):
+    """float64: aggregate-first GATConv relation, row by row."""
+    n, F = rp.shape[0] - 1, x.shape[1]
+    out = np.zeros((n, H * 64))
+    mag = np.zeros((n, H * 64))
+    x64, w64 = x.double().numpy(), w.double().numpy().reshape(F, H, 64)
+    a_s, a_d = a_src.double().numpy(), a_dst.double().numpy()
+    for i in range(n):
+        s, e = int(rp[i]), int(rp[i + 1])
+        if e == s:
+            continue
+        nb = col[s:e].numpy()
+        sc = a_s[nb] + a_d[int(dst_rows[i]) if dst_rows is not None else i][None, :]
+        sc = np.where(sc > 0, sc, sc * slope)
+        p = np.exp(sc - sc.max(0, keepdims=True))
+        alpha = p / p.sum(0, keepdims=True)                      # [deg, H]
+        agg = np.einsum("eh,ef->hf", alpha, x64[nb])             # [H, F]
+        out[i] = np.einsum("hf,fhc->hc", agg, w64).reshape(-1)
+        mag[i] = np.einsum("hf,fhc->hc", np.einsum("eh,ef->hf", alpha, np.abs(x64[nb])), np.abs(w64)).reshape(-1)
+    return out, mag
+
+
+@pytest.mark.parametrize("n,maxdeg", [(1, 10), (31, 10), (32, 10), (33, 10), (3000, 10), (9000, 10), (700, 25), (300, 70)])
+def test_gat_layer_fused_matches_float64_and_two_kernels(hiplib, n, maxdeg):
+    """wgamd_gat_layer_fused_bf16x3 against float64 and against the two kernels it fuses (empty rows, rows past the register
+    window, dst_rows indirection, the HeteroConv tail)."""
+    from wholegraph_amd import nn
+    F, H, n_src = 128, 4, 5000
+    g = torch.Generator().manual_seed(n + maxdeg)
+    deg = torch.randint(0, maxdeg + 1, (n,), generator=g)
+    if n > 2:
+        deg[1] = 0
+    rp = torch.zeros(n + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(deg, 0)
+    E = int(rp[-1])
+    if E == 0:
+        deg[0] = 3
+        rp[1:] = torch.cumsum(deg, 0)
+        E = int(rp[-1])
+    col = torch.randint(0, n_src, (E,), generator=g, dtype=torch.int32)
+    x = torch.rand((n_src, F), generator=g) - 0.5
+    a_src = (torch.rand((n_src, H), generator=g) - 0.5) * 4
+    a_dst = (torch.rand((2 * n, H), generator=g) - 0.5) * 4
+    dst_rows = torch.randperm(2 * n, generator=g)[:n]
+    w = (torch.rand((F, H * 64), generator=g) - 0.5) * 0.2
+    acc = torch.rand((n, H * 64), generator=g) - 0.5
+    bias = torch.rand(H * 64, generator=g) - 0.5
+    out_rows = torch.randperm(n + 7, generator=g)[:n]
+    cu = lambda t: t.cuda()
+    ref, mag = _gat_ref64(rp, col, x, a_src, a_dst, w, H, 0.2, dst_rows)
+    got = nn.gat_layer_fused(cu(rp), cu(col), cu(x), cu(a_src), cu(a_dst), cu(w), H, dst_rows=cu(dst_rows))
+    err = np.abs(got.cpu().double().numpy() - ref)
+    assert float((err / np.maximum(mag, 1e-30)).max()) < 1e-5, "fused vs float64"
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * float(mag.max()) * 0.1)
+    # the two kernels it replaces (their softmax is the online one: fp32 reassociation apart)
+    agg = nn.gat_aggregate_heads(cu(rp), cu(col), cu(x), cu(a_src), cu(a_dst), H, dst_rows=cu(dst_rows))
+    two = nn.gat_transform_heads_fused(agg, cu(w), H)
+    torch.testing.assert_close(got, two, rtol=1e-5, atol=1e-5 * float(mag.max()))
+    # the HeteroConv tail: running sum, bias, ReLU, row placement
+    want = torch.zeros((n + 7, H * 64)).cuda()
+    nn.gat_transform_heads_fused(agg, cu(w), H, acc_in=cu(acc), bias=cu(bias), relu=True, out_rows=cu(out_rows), out=want)
+    full = torch.zeros((n + 7, H * 64)).cuda()
+    nn.gat_layer_fused(cu(rp), cu(col), cu(x), cu(a_src), cu(a_dst), cu(w), H, dst_rows=cu(dst_rows), acc_in=cu(acc), bias=cu(bias),
+                       relu=True, out_rows=cu(out_rows), out=full)
+    torch.testing.assert_close(full, want, rtol=1e-5, atol=1e-5 * float(mag.max()))
