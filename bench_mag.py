@@ -456,25 +456,31 @@ def main(args):
         n_f, n_e = (int(v) for v in re.search(r"\((\d+) rows, (\d+) edges\)", name).groups())
         F_ = F_IN if name.startswith("gat1") else HC
         ms = gat[name]       # this exact shape occurred once (its own group)
-        by = n_e * (4 * F_ + 4 * HEADS + 4) + n_f * (4 * HEADS * F_ + 4 * HEADS + 8)
-        roofline = {"bound": "hbm", "kernel": "gat_aggregate_heads_kernel", "stage": name,
+        one_kernel = "+transform" in name.split(":")[0]
+        # one-kernel relation (wg_gat_fused.hip): the [N_dst, H F] aggregate never reaches HBM — what a destination row costs
+        # is its OUTPUT row (H C floats) instead; the running HeteroConv sum a later relation reads back is not counted
+        by = n_e * (4 * F_ + 4 * HEADS + 4) + n_f * ((4 * HC if one_kernel else 4 * HEADS * F_) + 4 * HEADS + 8)
+        roofline = {"bound": "hbm", "kernel": "gat_layer_fused_kernel" if one_kernel else "gat_aggregate_heads_kernel", "stage": name,
                     "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(by), "avg_launch_ms": round(ms, 5),
-                    "bytes_formula": "SURVEY §8(d) GAT, single pass, aggregate-first row widths: E (4F + 4H + 4) + N_dst (4HF + 4H "
-                                     "+ 8) with F = %d source floats per edge, H = 4 heads" % F_,
+                    "bytes_formula": ("SURVEY §8(d) GAT, single pass, aggregate-first, aggregation + dense tail in one kernel: "
+                                      "E (4F + 4H + 4) + N_dst (4HC + 4H + 8) with F = %d source floats per edge, H = 4 heads, C = 64"
+                                      if one_kernel else
+                                      "SURVEY §8(d) GAT, single pass, aggregate-first row widths: E (4F + 4H + 4) + N_dst (4HF + 4H "
+                                      "+ 8) with F = %d source floats per edge, H = 4 heads") % F_,
                     "timing": "HIP events around the launch on the launch stream (one launch per hop and edge type per call group)"}
     if roofline is not None and G == 64 and args.call_group <= 0:
         # HBM traffic and average duration of that launch shape from the committed profile of this command
         # (profiles/rNN/pmc_traffic_mag.json: the `#large` cluster = the largest launch of every call group; mag_kernel_stats.csv)
         from bench import load_pmc, load_profiled_avg
-        hit = load_pmc("gat_aggregate_heads_kernel", want_void=False, workload="mag")
+        hit = load_pmc(roofline["kernel"], want_void=False, workload="mag")
         if hit and hit.get("max_bytes"):
             # eleven launch shapes per call group: the dominant launch is the LARGEST single launch of the kernel in the PMC passes
             roofline["traffic"] = hit["max_bytes"]
             roofline["traffic_over_algorithmic"] = round(hit["max_bytes"] / roofline["algorithmic_bytes_per_launch"], 3)
             roofline["traffic_source"] = hit["source"] + " kernel " + hit["kernel"] + " (largest launch)"
-        prof = load_profiled_avg("gat_aggregate_heads_kernel", "mag")
+        prof = load_profiled_avg(roofline["kernel"], "mag")
         if prof:   # (the summary averages ALL launches of the kernel, 11 shapes per call group: the max is the dominant launch)
             roofline["profiled_source"] = "%s (%d launches of all shapes, avg %.1f us)" % (prof["source"], prof["calls"], prof["avg_ns"] * 1e-3)
     cpu = None

@@ -50,6 +50,15 @@ constexpr int kF     = 128, kH = 4, kKS = kF / 16;
 constexpr int kSDA   = kH * kF + 4;   // floats per LDS tile row: 4 * odd -> conflict-free ds_read_b128 across rows
 constexpr int kTileDw = 32 * kSDA;
 
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f)
+{
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 struct st_a { int s, e, valid; };
 struct st_b { int deg, s, colk; int64_t dst; };
 struct st_c { int deg, s; f32x4 asrc, adst; int64_t off; };
@@ -93,6 +102,8 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
     st_b rb[2];
     st_c rc[4];
     f32x4 v[2][kNbG];
+    // lane k of this lane's 16-lane row (DPP row_newbcast: one instruction, folded into its consumer where the ISA allows)
+#define WG_ROW_BCAST(val, k) __builtin_amdgcn_update_dpp(0, (val), 0x150 + (k), 0xf, 0xf, false)
     auto bcast = [&](int val, int k) __attribute__((always_inline)) {
       const int lo = __builtin_amdgcn_readlane(val, k), hi = __builtin_amdgcn_readlane(val, 32 + k);
       return gbase ? hi : lo;
@@ -115,7 +126,7 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
       const int64_t rc_ = row >= 0 ? row : 0;
       o.deg  = i.valid ? i.e - i.s : -1;
       o.s    = i.s;
-      o.colk = a.col[sub < o.deg ? i.s + sub : 0];
+      o.colk = a.col[(sub & 15) < o.deg ? i.s + (sub & 15) : 0];   // neighbour k in lane k of BOTH 16-lane rows of the group
       o.dst  = a.dst_rows ? a.dst_rows[rc_] : rc_;
     };
     auto stage_c = [&](st_c& o, const st_b& i) __attribute__((always_inline)) {
@@ -126,13 +137,13 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
       o.off  = (int64_t)i.colk * a.ldx * 4;
     };
     auto issue = [&](const st_c& m, f32x4* vv) __attribute__((always_inline)) {
-#pragma unroll
-      for (int k = 0; k < kNbG; k++) {
-        const int lo = bcast((int)(m.off & 0xffffffff), k), hi = bcast((int)(m.off >> 32), k);
+      static_for<0, kNbG>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const int lo = WG_ROW_BCAST((int)(m.off & 0xffffffff), k), hi = WG_ROW_BCAST((int)(m.off >> 32), k);
         int64_t off  = ((int64_t)hi << 32) | (uint32_t)lo;
         off          = k < m.deg ? off : (int64_t)0;   // slots past the degree read row 0 (cache-resident), weight 0 below
         vv[k]        = *reinterpret_cast<const f32x4*>(xb + off + f0 * 4);
-      }
+      });
     };
     auto reduce = [&](const st_c& m, const f32x4* vv, float* row_lds) __attribute__((always_inline)) {
       const int deg = m.deg;
@@ -142,7 +153,7 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
       // DPP butterfly over the 16-lane row (lanes past the window / the degree carry -inf / 0), then the ten weights of a head
       // are broadcast (v_readlane) for the weighted sum — 40 exponentials per row instead of 40 per LANE
       float sl[kH], pl[kH];
-      const bool mine_k = sub < kNbG && sub < deg;
+      const bool mine_k = (sub & 15) < kNbG && (sub & 15) < deg;
 #pragma unroll
       for (int h = 0; h < kH; h++) {
         float t = m.asrc[h] + m.adst[h];
@@ -168,11 +179,13 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
         const float mh = row_max(sl[h]);                       // (lanes 0 .. 15 of the group hold it; lane 0 is read below)
         pl[h]          = mine_k ? __expf(sl[h] - mh) : 0.f;
         const float dh = row_sum(pl[h]);
-        mx[h]          = __int_as_float(bcast(__float_as_int(mh), 0));
-        den[h]         = __int_as_float(bcast(__float_as_int(dh), 0));
+        mx[h]          = mh;      // (every lane of the row holds the row's value)
+        den[h]         = dh;
         f32x4 ah       = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < kNbG; k++) ah += __int_as_float(bcast(__float_as_int(pl[h]), k)) * vv[k];
+        static_for<0, kNbG>([&](auto K) {
+          constexpr int k = decltype(K)::value;
+          ah += __int_as_float(WG_ROW_BCAST(__float_as_int(pl[h]), k)) * vv[k];
+        });
         acc[h] = ah;
       }
       if (__ballot(deg > kNbG) != 0ull) {

@@ -4,7 +4,7 @@
 # pmc_traffic_<workload>.json, which the bench lines then quote as roofline.traffic / frac_profiled.
 set -x
 R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; OUT=$R/gpurun_out/configs_$TAG; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-HOT="row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|renumber_lds|bucket_sort|renumber_emit|gat_aggregate_heads|gather_terms|gat_csr"
+HOT="row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|renumber_lds|bucket_sort|renumber_emit|gat_aggregate_heads|gat_layer_fused|gat_transform|gather_terms|gat_csr"
 for W in papers100m rmat26 mag; do
   EXTRA="--no-variants"; [ $W = mag ] && EXTRA=""
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_$W -o $W -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/prof_$W.log 2>&1
