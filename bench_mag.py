@@ -491,7 +491,8 @@ def main(args):
                      "ogbn-mag-like fan-out [25, 10] x 6 edge types",
            "value": edges / dt, "unit": "sampled-edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "int64 ids + f32 features (GATConv lin: hipBLASLt f32 GEMM; edge softmax + aggregation: f32 HIP kernel)",
+           "dtype": "int64 ids + f32 features (edge softmax + aggregation: f32 HIP kernels; GATConv per-head lin: bf16x3-split MFMA, "
+                    "f32 accumulate — the one-kernel relation / wgamd_gat_transform_heads_bf16x3)",
            "data": "synthetic",
            "config": {"workload": "ogbn-mag-like hetero (BASELINE configs[4]): 4 node types (736,389 / 1,134,649 / 8,740 / 59,965), "
                                   "6 edge types ~35.8 M edges, feat fp32 [n_t, 128] per type, batch 1024 paper seeds, 2-hop fan-out "

@@ -175,6 +175,14 @@ struct producer {
   // request the kNb neighbour rows + the self row of row `it`; every load is unconditional
   __device__ __forceinline__ void issue(const meta_t<IT, off_t>& m, int it, f32x4* v) const
   {
+#ifndef WG_ISSUE_BPERMUTE   // (tuning build: the round-3 form below for every lane-group width)
+    // 32-lane groups: a neighbour's offset reaches the group through two v_readlane + a select instead of ds_bpermute —
+    // no LDS round trip next to the multiplying waves' fragment reads (bench.py: 3.92 -> 4.02 G edges/s on one box, two runs each)
+    if constexpr (LG == 32) {
+      issue_all<0>(m, it, v);
+      return;
+    }
+#endif
     if constexpr (OFF32) {
       // slots past the degree (and the self slot of a row past n_rows) get an out-of-range offset: zeros, no memory access
 #pragma unroll
@@ -210,6 +218,14 @@ struct producer {
       return gbase ? hi : lo;
     } else {
       return __shfl(v, gbase | (k & (LG - 1)), 64);
+    }
+  }
+  template <int k>
+  __device__ __forceinline__ void issue_all(const meta_t<IT, off_t>& m, int it, f32x4* v) const
+  {
+    if constexpr (k < kNb + (HALF ? 0 : 1)) {
+      issue_one<k>(m, it, v);
+      issue_all<k + 1>(m, it, v);
     }
   }
   // ONE of the kNb + 1 loads of issue(): load k of row `it` (k == kNb: the self row)
