@@ -175,10 +175,13 @@ struct producer {
   // request the kNb neighbour rows + the self row of row `it`; every load is unconditional
   __device__ __forceinline__ void issue(const meta_t<IT, off_t>& m, int it, f32x4* v) const
   {
+#ifndef WG_ISSUE_READLANE64
+#define WG_ISSUE_READLANE64 1
+#endif
 #ifndef WG_ISSUE_BPERMUTE   // (tuning build: the round-3 form below for every lane-group width)
     // 32-lane groups: a neighbour's offset reaches the group through two v_readlane + a select instead of ds_bpermute —
     // no LDS round trip next to the multiplying waves' fragment reads (bench.py: 3.92 -> 4.02 G edges/s on one box, two runs each)
-    if constexpr (LG == 32) {
+    if constexpr (LG == 32 || (LG == 64 && WG_ISSUE_READLANE64)) {
       issue_all<0>(m, it, v);
       return;
     }
@@ -216,6 +219,8 @@ struct producer {
     if constexpr (LG == 32) {
       const int lo = __builtin_amdgcn_readlane(v, k), hi = __builtin_amdgcn_readlane(v, 32 + k);
       return gbase ? hi : lo;
+    } else if constexpr (LG == 64) {
+      return __builtin_amdgcn_readlane(v, k);   // one group per wave: the offset is wave-uniform
     } else {
       return __shfl(v, gbase | (k & (LG - 1)), 64);
     }
