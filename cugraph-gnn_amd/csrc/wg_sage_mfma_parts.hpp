@@ -178,9 +178,16 @@ struct producer {
 #ifndef WG_ISSUE_READLANE64
 #define WG_ISSUE_READLANE64 1
 #endif
+#ifndef WG_ISSUE_DPP
+#define WG_ISSUE_DPP 1
+#endif
 #ifndef WG_ISSUE_BPERMUTE   // (tuning build: the round-3 form below for every lane-group width)
     // 32-lane groups: a neighbour's offset reaches the group through two v_readlane + a select instead of ds_bpermute —
     // no LDS round trip next to the multiplying waves' fragment reads (bench.py: 3.92 -> 4.02 G edges/s on one box, two runs each)
+    if constexpr (LG == 32 && WG_ISSUE_DPP) {
+      issue_dpp(m, it, v);
+      return;
+    }
     if constexpr (LG == 32 || (LG == 64 && WG_ISSUE_READLANE64)) {
       issue_all<0>(m, it, v);
       return;
@@ -210,6 +217,43 @@ struct producer {
       if constexpr (!HALF)
         v[kNb] = *reinterpret_cast<const f32x4*>(xb + (m.d[it] >= 0 ? (int64_t)m.self[it] : (int64_t)0) + f0c * 4);
     }
+  }
+  // 32-lane groups, the cheapest form: ONE v_permlane16_swap (gfx950) of the offset register with itself yields the register
+  // with its even 16-lane rows duplicated into the odd ones — lane k < 16 of a group is then in BOTH rows of the group and a DPP
+  // row_newbcast:k hands it to all 32 lanes in one instruction (two v_readlane + a select before).  The fetching waves are
+  // issue-bound next to the multiplying waves of their SIMD: per destination row this removes ~40 of their instructions, and the
+  // wide-x path drops its per-load select as well (a slot past the degree reads the offset of a lane that holds row 0's; the sum
+  // masks it).  Layer-1 launch of bench.py 1.607 -> 1.561 ms, 4.00 -> 4.02 G edges/s (same box, four runs each).
+  // (Also tried on top of it: dead slots pointing at a ZERO row so that the sum needs no per-slot select either — 40 fewer
+  //  instructions per row and SLOWER, 1.57 -> 1.615 ms; not kept.)
+  template <int k>
+  __device__ __forceinline__ void issue_dpp_one(const meta_t<IT, off_t>& m, int it, f32x4* v, int dlo, int dhi) const
+  {
+    if constexpr (k < kNb) {
+      const int lo = __builtin_amdgcn_update_dpp(0, dlo, 0x150 + k, 0xf, 0xf, false);
+      if constexpr (OFF32) {
+        v[k] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, k < m.d[it] ? (uint32_t)lo + f0c * 4 : a.x_bytes, 0, 0));
+      } else {
+        const int hi      = __builtin_amdgcn_update_dpp(0, dhi, 0x150 + k, 0xf, 0xf, false);
+        const int64_t off = ((int64_t)hi << 32) | (uint32_t)lo;   // (lanes past the degree hold a valid row's offset: masked in reduce_store)
+        v[k]              = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + off + f0c * 4);
+      }
+      issue_dpp_one<k + 1>(m, it, v, dlo, dhi);
+    }
+  }
+  __device__ __forceinline__ void issue_dpp(const meta_t<IT, off_t>& m, int it, f32x4* v) const
+  {
+    static_assert(kNb <= 16, "the first window sits in the even row of the group");
+    const int slo = (int)((uint64_t)m.src[it] & 0xffffffffu);
+    const int dlo = __builtin_amdgcn_permlane16_swap(slo, slo, false, false)[0];
+    int dhi       = 0;
+    if constexpr (!OFF32) {
+      const int shi = (int)((uint64_t)m.src[it] >> 32);
+      dhi           = __builtin_amdgcn_permlane16_swap(shi, shi, false, false)[0];
+    }
+    issue_dpp_one<0>(m, it, v, dlo, dhi);
+    if constexpr (!HALF) issue_one<kNb>(m, it, v);
   }
   // value of lane k of this lane's group.  Two 32-lane groups per wave: two v_readlane + a select — no LDS round trip
   // (ds_bpermute) and no lgkmcnt wait, which an in-order wave with MFMAs queued behind it cannot afford eleven times per row
