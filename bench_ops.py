@@ -279,6 +279,29 @@ def main():
         t = timed(lambda: nn.gat_forward(hop2[0], col2, x, a_s, a_d, H, 0.2, need_alpha=True), events=True)
         add("GAT (+alpha out for backward) H=%d C=%d" % (H, C), "—", t,
             Eh * (4 * H + 4) + T * 4 * H + Eh * (4 * H * C + 4 * H + 4) + T * 4 * H * C + Eh * 4 * H, Eh, "edges")
+    # ---- aggregate-first GATConv relation on the products hop-2 shape (F = 128 source floats, 4 heads x 64): two kernels / one
+    Fg, Hg, Cg = 128, 4, 64
+    xg = torch.rand((n_src, Fg), generator=g, device=dev) - 0.5
+    a_s = torch.rand((n_src, Hg), generator=g, device=dev)
+    a_d = torch.rand((T, Hg), generator=g, device=dev)
+    wg_ = (torch.rand((Fg, Hg * Cg), generator=g, device=dev) - 0.5) * 0.2
+    bias_g = torch.rand(Hg * Cg, generator=g, device=dev)
+    agg_bytes = Eh * (4 * Fg + 4 * Hg + 4) + T * (4 * Hg * Fg + 4 * Hg + 8)
+    t = timed(lambda: nn.gat_aggregate_heads(hop2[0], col2, xg, a_s, a_d, Hg), events=True)
+    add("GAT aggregate-first: aggregation H=4 F=128", "torch_geometric GATConv (external)", t, agg_bytes, Eh, "edges",
+        "wgamd_gat_aggregate_heads_f32: agg[i, h, :] = sum_e alpha_e^h x[col[e], :]")
+    agg = nn.gat_aggregate_heads(hop2[0], col2, xg, a_s, a_d, Hg)
+    t = timed(lambda: nn.gat_transform_heads_fused(agg, wg_, Hg, bias=bias_g, relu=True), events=True)
+    add("GAT aggregate-first: per-head transform + bias + ReLU, 4 x (128 -> 64)", "torch_geometric GATConv lin (external)", t,
+        T * (4 * Hg * Fg + 4 * Hg * Cg), T, "rows", "wgamd_gat_transform_heads_bf16x3 (bf16x3-split MFMA, fp32 accumulate)")
+    t = timed(lambda: nn.gat_transform_heads(agg, wg_, Hg, fused=False), events=True)
+    add("GAT aggregate-first: per-head transform, library strided batched GEMM", "—", t, T * (4 * Hg * Fg + 4 * Hg * Cg), T,
+        "rows", "torch.bmm through hipBLASLt (fp32 MFMA), no bias / ReLU")
+    if nn.gat_layer_fused_supported(Fg, Hg, Cg):
+        t = timed(lambda: nn.gat_layer_fused(hop2[0], col2, xg, a_s, a_d, wg_, Hg, bias=bias_g, relu=True), events=True)
+        add("GAT aggregate-first relation as ONE kernel (aggregation + transform + bias + ReLU)", "torch_geometric GATConv (external)", t,
+            Eh * (4 * Fg + 4 * Hg + 4) + T * (4 * Hg * Cg + 4 * Hg + 8), Eh, "edges",
+            "wgamd_gat_layer_fused_bf16x3: the [rows, 4 x 128] aggregate stays in LDS")
     # ---- (f4): trainable embedding, sparse optimizer step (world of 1: routing is a local copy) ------------------
     comm = wg.create_group_communicator()
     n_rows, k = 1_000_000, 1_000_000
