@@ -20,6 +20,8 @@
 //     host synchronisation at all.  (No flat global pointer: a CONTINUOUS handle is addressed like a CHUNKED one.)
 //     Host-pinned and HIERARCHY memory do not exist here: every table lives in HBM.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <rccl/rccl.h>
 #include <sys/types.h>
 #include <sys/wait.h>
@@ -70,6 +72,13 @@ struct wholememory_handle_ {
   std::vector<void*> peer_ptr;         // [W]; peer_ptr[me] == local_ptr
   std::vector<char> peer_opened;       // [W]; 1 = came from hipIpcOpenMemHandle (closed by wholememory_free)
   wgamd::mapped_view* d_view = nullptr;
+  // WHOLEMEMORY_ML_HOST: the partition is pinned host memory the GPU reads and writes in place over PCIe.  A partition
+  // that other PROCESSES map (peer-mapped types) is a POSIX shared-memory segment registered with the runtime on
+  // both sides; everything else is a hipHostMalloc block.
+  bool host_shm = false;                // local_ptr is an mmap'ed + registered segment of `local_map_bytes`
+  size_t local_map_bytes = 0;
+  std::vector<void*> peer_host_map;     // [W]; the peers' segments as mapped into THIS process (unregistered + unmapped on free)
+  std::vector<size_t> peer_map_bytes;   // [W]
 };
 
 namespace wgamd {
@@ -715,7 +724,7 @@ wholememory_error_code_t wholememory_communicator_support_type_location(wholemem
                                                                         wholememory_memory_location_t memory_location)
 {
   if (comm == nullptr) return WHOLEMEMORY_INVALID_INPUT;
-  if (memory_location != WHOLEMEMORY_ML_DEVICE) return WHOLEMEMORY_NOT_SUPPORTED;
+  if (memory_location != WHOLEMEMORY_ML_DEVICE && memory_location != WHOLEMEMORY_ML_HOST) return WHOLEMEMORY_NOT_SUPPORTED;
   if (memory_type == WHOLEMEMORY_MT_DISTRIBUTED) return WHOLEMEMORY_SUCCESS;
   // peer-mapped types: all ranks on one node (HIP IPC + xGMI peer access), at most kMaxMappedRanks of them
   if ((memory_type == WHOLEMEMORY_MT_CONTINUOUS || memory_type == WHOLEMEMORY_MT_CHUNKED) &&
@@ -811,9 +820,45 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
       for (int r = 0; r <= comm->size; r++) h->byte_offsets[r] = std::min(entries, per * (size_t)r) * data_granularity;
     }
     size_t local = h->byte_offsets[comm->rank + 1] - h->byte_offsets[comm->rank];
-    if (local > 0 && hipMalloc(&h->local_ptr, local) != hipSuccess) {
+    const bool host   = memory_location == WHOLEMEMORY_ML_HOST;
+    const bool mapped = memory_type != WHOLEMEMORY_MT_DISTRIBUTED && comm->size > 1;
+    char shm_name[48] = {0};
+    if (local > 0 && !host && hipMalloc(&h->local_ptr, local) != hipSuccess) {
       delete h;
       throw std::bad_alloc();
+    }
+    if (local > 0 && host) {
+      // memory_handle.cpp:432-520 (host memory of the mapped types = one shared segment every process maps) /
+      // :233-262 (distributed host memory = pinned memory of the owning process).  Pinned either way, so the GPU's loads
+      // and stores reach it in place.
+      bool ok = true;
+      if (mapped) {
+        static std::atomic<unsigned> seq{0};
+        snprintf(shm_name, sizeof(shm_name), "/wgamd.%ld.%u", (long)getpid(), seq.fetch_add(1));
+        const int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        ok           = fd >= 0 && ftruncate(fd, (off_t)local) == 0;
+        void* m      = ok ? mmap(nullptr, local, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+        if (fd >= 0) close(fd);
+        ok = ok && m != MAP_FAILED;
+        if (ok && hipHostRegister(m, local, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+          munmap(m, local);
+          ok = false;
+        }
+        if (ok) {
+          h->local_ptr       = m;
+          h->host_shm        = true;
+          h->local_map_bytes = local;
+        } else {
+          shm_unlink(shm_name);
+        }
+      } else {
+        ok = hipHostMalloc(&h->local_ptr, local, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess;
+      }
+      if (!ok) {
+        (void)hipGetLastError();
+        delete h;
+        throw std::bad_alloc();
+      }
     }
     if (memory_type != WHOLEMEMORY_MT_DISTRIBUTED && comm->size > 1) {
       // PEER MAPPING (collective): every rank publishes {HIP IPC handle, pid, pointer} of its partition and opens the
@@ -825,7 +870,9 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         uint64_t ptr;
         uint64_t bytes;
         int64_t device;
+        char shm[48];   // host location: name of the rank's shared-memory segment
       } mine{};
+      memcpy(mine.shm, shm_name, sizeof(shm_name));
       int my_device = 0;
       WG_HIP_CHECK(hipGetDevice(&my_device));
       mine.device = my_device;
@@ -833,11 +880,13 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
       mine.ptr   = reinterpret_cast<uint64_t>(h->local_ptr);
       mine.bytes = local;
       try {
-        if (local > 0) WG_HIP_CHECK(hipIpcGetMemHandle(&mine.ipc, h->local_ptr));
+        if (local > 0 && !host) WG_HIP_CHECK(hipIpcGetMemHandle(&mine.ipc, h->local_ptr));
         std::vector<char> all;
         allgather_host(comm, &mine, sizeof(mine), all);
         h->peer_ptr.assign(comm->size, nullptr);
         h->peer_opened.assign(comm->size, 0);
+        h->peer_host_map.assign(comm->size, nullptr);
+        h->peer_map_bytes.assign(comm->size, 0);
         mapped_view view{};
         view.W = comm->size;
         for (int r = 0; r < comm->size; r++) {
@@ -845,6 +894,21 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
           memcpy(&rec, all.data() + (size_t)r * sizeof(rec), sizeof(rec));
           if (r == comm->rank || rec.bytes == 0) {
             h->peer_ptr[r] = r == comm->rank ? h->local_ptr : nullptr;
+          } else if (rec.pid == mine.pid && host) {
+            h->peer_ptr[r] = reinterpret_cast<void*>(rec.ptr);   // registered portable by its owner, in this process
+          } else if (host) {
+            // the peer's segment, mapped and registered here as well
+            const int fd = shm_open(rec.shm, O_RDWR, 0600);
+            void* m      = fd >= 0 ? mmap(nullptr, rec.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+            if (fd >= 0) close(fd);
+            if (m == MAP_FAILED) throw logic_error("host peer mapping: the shared-memory segment of a peer cannot be mapped");
+            h->peer_host_map[r]  = m;
+            h->peer_map_bytes[r] = rec.bytes;
+            WG_HIP_CHECK(hipHostRegister(m, rec.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+            h->peer_opened[r] = 2;
+            void* dp          = nullptr;
+            WG_HIP_CHECK(hipHostGetDevicePointer(&dp, m, 0));
+            h->peer_ptr[r] = dp;
           } else if (rec.pid == mine.pid) {
             // a rank of this very process: its pointer is valid here, but if it sits on ANOTHER device the kernel's loads
             // need peer access between the two devices
@@ -871,7 +935,15 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         view.entry_off[comm->size] = (int64_t)(h->byte_offsets[comm->size] / data_granularity);
         WG_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_view), sizeof(mapped_view)));
         WG_HIP_CHECK(hipMemcpy(h->d_view, &view, sizeof(view), hipMemcpyHostToDevice));
+        if (host) {
+          // every process holds its mappings now: the names can go (the memory lives until the last unmap)
+          std::vector<char> seen;
+          char done = 1;
+          allgather_host(comm, &done, 1, seen);
+          if (shm_name[0]) shm_unlink(shm_name);
+        }
       } catch (...) {
+        if (shm_name[0]) shm_unlink(shm_name);
         release_handle(h, /*collective=*/false);
         throw;
       }
@@ -919,11 +991,25 @@ static void release_handle(wholememory_handle_t h, bool collective)
     (void)hipDeviceSynchronize();
     if (collective) meet("before closing the peer mappings");
   }
-  for (size_t r = 0; r < h->peer_ptr.size(); r++)
-    if (h->peer_opened[r] && h->peer_ptr[r]) (void)hipIpcCloseMemHandle(h->peer_ptr[r]);
+  for (size_t r = 0; r < h->peer_ptr.size(); r++) {
+    if (h->peer_opened[r] == 1 && h->peer_ptr[r]) (void)hipIpcCloseMemHandle(h->peer_ptr[r]);
+    if (h->peer_opened[r] == 2 && h->peer_host_map[r]) {
+      (void)hipHostUnregister(h->peer_host_map[r]);
+      munmap(h->peer_host_map[r], h->peer_map_bytes[r]);
+    }
+  }
   if (h->d_view) (void)hipFree(h->d_view);
   if (mapped && collective) meet("before releasing the partition");
-  if (h->local_ptr) (void)hipFree(h->local_ptr);
+  if (h->local_ptr) {
+    if (h->host_shm) {
+      (void)hipHostUnregister(h->local_ptr);
+      munmap(h->local_ptr, h->local_map_bytes);
+    } else if (h->location == WHOLEMEMORY_ML_HOST) {
+      (void)hipHostFree(h->local_ptr);
+    } else {
+      (void)hipFree(h->local_ptr);
+    }
+  }
   delete h;
 }
 

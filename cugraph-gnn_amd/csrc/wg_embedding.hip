@@ -48,6 +48,11 @@ struct cache_view {
   int64_t n_sets, entries;
   int64_t line_bytes;          // padded row
   unsigned long long* stats;   // {hits, lookups} since creation / the last drop
+  // READWRITE (write-back) cache only — see "READWRITE device cache" below
+  int* dirty;                  // per line: the line is newer than its table row
+  float* st;                   // per line: the row's optimizer state [n_states * state_dim | beta1^t beta2^t], or null
+  int64_t st_stride;           // floats per state line
+  int st_floats, rs_off;       // state floats copied per line; offset of the per-row pair in a state line (-1: none)
 };
 }  // namespace wgamd
 
@@ -69,7 +74,9 @@ struct wholememory_embedding_ {
   std::vector<std::string> state_names;
   std::vector<wholememory_tensor_t> state_views;
   std::vector<const char*> names_c;  // NULL-terminated
-  bool cached = false;               // a READONLY local cache sits in front of `user`
+  bool cached = false;               // a cache sits in front of `user` (READONLY: asker-side; READWRITE: owner-side)
+  bool cache_rw = false;             // ... and it is the write-back cache of this rank's own rows
+  wholememory_memory_location_t location = WHOLEMEMORY_ML_DEVICE;
   wgamd::cache_view cache{};
   wholememory_tensor_t cache_rows = nullptr;  // [lines, dim] view of cache.data (caller-storage tensor, no handle)
 };
@@ -83,6 +90,17 @@ enum { kSgd = 0, kLazyAdam, kAdaGrad, kRmsProp };
 struct step_params {
   float lr, weight_decay, epsilon, beta1, beta2, alpha;
   int adam_w;
+};
+
+// where the update kernel finds a row that sits in the write-back cache: line_of[i] = cache line of the row whose first
+// sorted pair is i (-1: not resident, update the table row); line_of == nullptr: no write-back cache
+struct cache_redirect {
+  const int* line_of = nullptr;
+  char* data         = nullptr;
+  int64_t line_bytes = 0;
+  float* st          = nullptr;
+  int64_t st_stride  = 0;
+  int rs_off         = 0;
 };
 
 template <typename T>
@@ -150,7 +168,8 @@ __global__ void __launch_bounds__(256)
 sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int64_t n, int64_t local_rows,
                     const float* __restrict__ recv_rows, arrival_map am, const float* __restrict__ grads, int64_t ldg,
                     const int64_t* __restrict__ self_pos, EmbT* __restrict__ emb, int64_t lde, float* __restrict__ st,
-                    int64_t lds, int64_t sdim, float* __restrict__ row_state, int dim, step_params p, int log2_lanes)
+                    int64_t lds, int64_t sdim, float* __restrict__ row_state, int dim, step_params p, int log2_lanes,
+                    cache_redirect cr)
 {
   const int lanes       = 1 << log2_lanes;
   const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,13 +181,22 @@ sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ v
     if (i > 0 && keys[i - 1] == key) continue;
     int64_t end = i + 1;
     while (end < n && keys[end] == key) end++;
+    EmbT* e_row  = emb + key * lde;
+    float* s_row = OPT == kSgd ? nullptr : st + key * lds;
+    float* rs    = OPT == kLazyAdam ? row_state + key * 2 : nullptr;
+    if (cr.line_of != nullptr) {   // write-back cache: a resident row is updated in its line (marked dirty by the locate pass)
+      const int64_t ln = cr.line_of[i];
+      if (ln >= 0) {
+        e_row = reinterpret_cast<EmbT*>(cr.data + ln * cr.line_bytes);
+        if (OPT != kSgd) s_row = cr.st + ln * cr.st_stride;
+        if (OPT == kLazyAdam) rs = cr.st + ln * cr.st_stride + cr.rs_off;
+      }
+    }
     float b1t = 0.f, b2t = 0.f;
     if (OPT == kLazyAdam) {
-      b1t = row_state[key * 2] * p.beta1;
-      b2t = row_state[key * 2 + 1] * p.beta2;
+      b1t = rs[0] * p.beta1;
+      b2t = rs[1] * p.beta2;
     }
-    EmbT* e_row = emb + key * lde;
-    float* s_row = OPT == kSgd ? nullptr : st + key * lds;
     for (int c = sub * V; c < dim; c += lanes * V) {
       float g[V];
 #pragma unroll
@@ -219,8 +247,8 @@ sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ v
       if (OPT == kLazyAdam) *reinterpret_cast<pack<float, V>*>(s_row + sdim + c) = s1;
     }
     if (OPT == kLazyAdam && sub == 0) {  // after every lane of the group (same wave) has read the old powers
-      row_state[key * 2]     = b1t;
-      row_state[key * 2 + 1] = b2t;
+      rs[0] = b1t;
+      rs[1] = b2t;
     }
   }
 }
@@ -228,7 +256,7 @@ sparse_apply_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ v
 template <typename EmbT, int OPT>
 void launch_apply(bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* recv_rows,
                   arrival_map am, const float* grads, int64_t ldg, const int64_t* self_pos, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
-                  step_params p, hipStream_t stream)
+                  step_params p, cache_redirect cr, hipStream_t stream)
 {
   const int V      = vec4 ? 4 : 1;
   int l2           = 0;
@@ -237,23 +265,23 @@ void launch_apply(bool vec4, const uint64_t* keys, const int* vals, int64_t n, i
   const int grid    = (int)std::min<int64_t>((n + gpb - 1) / gpb, 256 * 16);
   if (vec4)
     sparse_apply_kernel<EmbT, OPT, 4><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, static_cast<EmbT*>(emb),
-                                                               lde, st, lds, sdim, row_state, dim, p, l2);
+                                                               lde, st, lds, sdim, row_state, dim, p, l2, cr);
   else
     sparse_apply_kernel<EmbT, OPT, 1><<<grid, 256, 0, stream>>>(keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, static_cast<EmbT*>(emb),
-                                                               lde, st, lds, sdim, row_state, dim, p, l2);
+                                                               lde, st, lds, sdim, row_state, dim, p, l2, cr);
   WG_HIP_CHECK(hipGetLastError());
 }
 
 template <typename EmbT>
 void dispatch_opt(int opt, bool vec4, const uint64_t* keys, const int* vals, int64_t n, int64_t local_rows, const float* recv_rows,
                   arrival_map am, const float* grads, int64_t ldg, const int64_t* self_pos, void* emb, int64_t lde, float* st, int64_t lds, int64_t sdim, float* row_state, int dim,
-                  step_params p, hipStream_t stream)
+                  step_params p, cache_redirect cr, hipStream_t stream)
 {
   switch (opt) {
-    case kSgd: return launch_apply<EmbT, kSgd>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
-    case kLazyAdam: return launch_apply<EmbT, kLazyAdam>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
-    case kAdaGrad: return launch_apply<EmbT, kAdaGrad>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
-    default: return launch_apply<EmbT, kRmsProp>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, stream);
+    case kSgd: return launch_apply<EmbT, kSgd>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, cr, stream);
+    case kLazyAdam: return launch_apply<EmbT, kLazyAdam>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, cr, stream);
+    case kAdaGrad: return launch_apply<EmbT, kAdaGrad>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, cr, stream);
+    default: return launch_apply<EmbT, kRmsProp>(vec4, keys, vals, n, local_rows, recv_rows, am, grads, ldg, self_pos, emb, lde, st, lds, sdim, row_state, dim, p, cr, stream);
   }
 }
 
@@ -301,7 +329,12 @@ void destroy_states(wholememory_embedding_t e)
   e->state_table = e->row_state = nullptr;
 }
 
-void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_tensor_t grads, float lr,
+// write-back cache (defined with the cache kernels below): bring the step's rows in (adjust), find the resident ones, mark
+// them dirty; returns what the update kernel needs to reach their lines
+cache_redirect rw_prepare_step(wholememory_embedding_t e, const uint64_t* sorted_keys, int64_t n, bool adjust_cache,
+                               int* line_of, hipStream_t stream);
+
+void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_tensor_t grads, bool adjust_cache, float lr,
           wholememory_env_func_t* env, hipStream_t stream)
 {
   WG_REQUIRE_INPUT(e && indices && grads && env, "null argument");
@@ -337,7 +370,7 @@ void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_t
   const size_t o_ids = arena.add(sizeof(int64_t) * n_recv), o_rows = arena.add(sizeof(float) * n_recv * D),
                o_send = arena.add(sizeof(float) * x.n_remote * D), o_k1 = arena.add(sizeof(uint64_t) * R),
                o_k2 = arena.add(sizeof(uint64_t) * R), o_v1 = arena.add(sizeof(int) * R), o_v2 = arena.add(sizeof(int) * R),
-               o_tmp = arena.add(sort_bytes);
+               o_tmp = arena.add(sort_bytes), o_line = arena.add(sizeof(int) * (e->cache_rw ? R : 0));
   arena.commit();
   x.exchange_ids(arena.at<int64_t>(o_ids), stream);
   gm.storage_offset = 0;
@@ -367,18 +400,20 @@ void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_t
     // 16-byte vector reads need aligned gradient rows on both sources (routed rows are packed [n_recv, dim])
     const bool vec4 = D % 4 == 0 && (x.self_cnt == 0 || (ldg % 4 == 0 && reinterpret_cast<uintptr_t>(gsrc) % 16 == 0));
     const int opt   = opt_code(o->type);
+    cache_redirect cr;
+    if (e->cache_rw) cr = rw_prepare_step(e, keys2, R, adjust_cache, arena.at<int>(o_line), stream);
     switch (e->dtype) {
       case WHOLEMEMORY_DT_FLOAT:
         dispatch_opt<float>(opt, vec4, keys2, vals2, R, local_rows, d_rows, am, gsrc, ldg, x.d_self_pos, emb, e->padded_dim,
-                            st, lds, e->state_dim, row_state, (int)D, p, stream);
+                            st, lds, e->state_dim, row_state, (int)D, p, cr, stream);
         break;
       case WHOLEMEMORY_DT_HALF:
         dispatch_opt<__half>(opt, vec4, keys2, vals2, R, local_rows, d_rows, am, gsrc, ldg, x.d_self_pos, emb, e->padded_dim,
-                             st, lds, e->state_dim, row_state, (int)D, p, stream);
+                             st, lds, e->state_dim, row_state, (int)D, p, cr, stream);
         break;
       default:
         dispatch_opt<__hip_bfloat16>(opt, vec4, keys2, vals2, R, local_rows, d_rows, am, gsrc, ldg, x.d_self_pos, emb,
-                                     e->padded_dim, st, lds, e->state_dim, row_state, (int)D, p, stream);
+                                     e->padded_dim, st, lds, e->state_dim, row_state, (int)D, p, cr, stream);
         break;
     }
   }
@@ -506,25 +541,33 @@ void cache_clear(const cache_view& c, hipStream_t stream)
   WG_HIP_CHECK(hipMemsetAsync(c.counts, 0, lines * sizeof(int), stream));
   WG_HIP_CHECK(hipMemsetAsync(c.locks, 0, (size_t)c.n_sets * sizeof(int), stream));
   WG_HIP_CHECK(hipMemsetAsync(c.stats, 0, 2 * sizeof(unsigned long long), stream));
+  if (c.dirty) WG_HIP_CHECK(hipMemsetAsync(c.dirty, 0, lines * sizeof(int), stream));
 }
 
 void cache_release(wholememory_embedding_t e)
 {
   if (e->cache_rows) wholememory_destroy_tensor(e->cache_rows);
   e->cache_rows = nullptr;
-  for (void* p : {(void*)e->cache.tags, (void*)e->cache.counts, (void*)e->cache.locks, (void*)e->cache.data, (void*)e->cache.stats})
+  for (void* p : {(void*)e->cache.tags, (void*)e->cache.counts, (void*)e->cache.locks, (void*)e->cache.data, (void*)e->cache.stats,
+                  (void*)e->cache.dirty, (void*)e->cache.st})
     if (p) (void)hipFree(p);
   e->cache  = cache_view{};
-  e->cached = false;
+  e->cached = e->cache_rw = false;
 }
 
-void cache_allocate(wholememory_embedding_t e, float ratio)
+void cache_allocate(wholememory_embedding_t e, float ratio, bool readwrite)
 {
   cache_view& c = e->cache;
   const size_t es = dtype_size(e->dtype);
   c.entries    = e->entries;
+  if (readwrite) {   // the write-back cache covers this rank's own rows, tagged by local row number
+    size_t bytes = 0;
+    (void)local_pointer(e->allocated, &bytes);
+    c.entries = (int64_t)(bytes / ((size_t)e->padded_dim * es));
+  }
+  c.rs_off     = -1;
   c.line_bytes = e->padded_dim * (int64_t)es;
-  int64_t lines = (int64_t)((double)ratio * (double)e->entries);
+  int64_t lines = (int64_t)((double)ratio * (double)c.entries);
   c.n_sets      = std::max<int64_t>(1, (lines + kCacheWays - 1) / kCacheWays);
   lines         = c.n_sets * kCacheWays;
   try {
@@ -533,6 +576,7 @@ void cache_allocate(wholememory_embedding_t e, float ratio)
     WG_HIP_CHECK(hipMalloc(&c.locks, (size_t)c.n_sets * sizeof(int)));
     WG_HIP_CHECK(hipMalloc(&c.data, (size_t)lines * (size_t)c.line_bytes));
     WG_HIP_CHECK(hipMalloc(&c.stats, 2 * sizeof(unsigned long long)));
+    if (readwrite) WG_HIP_CHECK(hipMalloc(&c.dirty, (size_t)lines * sizeof(int)));
     cache_clear(c, nullptr);
     WG_HIP_CHECK(hipStreamSynchronize(nullptr));
     wholememory_tensor_description_t d;
@@ -549,7 +593,8 @@ void cache_allocate(wholememory_embedding_t e, float ratio)
     cache_release(e);
     throw;
   }
-  e->cached = true;
+  e->cached   = true;
+  e->cache_rw = readwrite;
 }
 
 // steps 1-4 above.  Falls back to the plain table gather when the output converts the dtype (a cache line is a byte copy
@@ -621,6 +666,313 @@ void cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, whol
     WG_HIP_CHECK(hipGetLastError());
   }
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // the two index lists are released on return
+}
+
+// ---- READWRITE device cache over this rank's own rows ------------------------------------------------------------
+// What the reference does (cpp/src/wholememory/embedding.cpp:556-759 device_cached_host_embedding, :136-313 the training
+// step with adjust_cache, embedding_cache.cpp:256-331, functions/embedding_cache_func.cu:107-723): the table — typically
+// in HOST memory — is fronted by a device cache held by the SAME communicator; a gather or a training step with
+// adjust_cache first brings the rows it touches into the cache of the rank that OWNS them (writing displaced modified
+// lines back), reads and optimizer updates go to the cache line when the row is resident and to the table row when it
+// is not, and writeback_all_cache / drop_all_cache flush the modified lines.
+// Here: the cache of a rank covers exactly its own partition (tags = LOCAL row numbers), in private HBM; the table
+// partition may be pinned host memory the kernels reach over PCIe (wholememory_malloc, WHOLEMEMORY_ML_HOST) or HBM.
+//   * every id is routed to its owner by the feature-fetch exchange (id_exchange); only the owner touches its cache, in
+//     stream order, so lookups need no lock and an insert serialises on its set's try-lock only against the other
+//     groups of the same kernel;
+//   * a cache line holds the padded embedding row AND, once an optimizer is set, the row's optimizer state (m / v /
+//     state_sum and LazyAdam's beta powers) behind the same tag: one lookup per row per step, and a step on a resident
+//     row moves no byte over PCIe;
+//   * replacement = LFU with ageing: a line enters with count 1, a newcomer takes an empty line or one whose count has
+//     aged to 0, otherwise it halves the set's counts and stays out (it is served from the table: caching is best
+//     effort, the valid copy of a row is its line when resident and its table row otherwise — always).
+struct rw_table {
+  char* emb;            // this rank's partition
+  int64_t emb_stride;   // bytes between rows (= line_bytes)
+  float* st;            // state table partition [rows, st_floats] or null
+  int64_t st_stride;    // floats
+  float* rs;            // [rows, 2] or null
+};
+
+__device__ __forceinline__ void line_copy16(char* dst, const char* src, int bytes, int lane)
+{
+  for (int off = lane * 16; off < bytes; off += kCacheWays * 16)
+    *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
+}
+
+// moves one row (embedding + state) between its line and its table row; 32 lanes
+template <bool TO_TABLE>
+__device__ __forceinline__ void rw_move_row(const cache_view& c, const rw_table& t, int64_t line, int64_t row, int lane)
+{
+  char* l_emb = c.data + line * c.line_bytes;
+  char* t_emb = t.emb + row * t.emb_stride;
+  if (TO_TABLE) line_copy16(t_emb, l_emb, (int)c.line_bytes, lane); else line_copy16(l_emb, t_emb, (int)c.line_bytes, lane);
+  if (c.st != nullptr) {
+    float* l_st = c.st + line * c.st_stride;
+    if (c.st_floats > 0) {
+      float* t_st = t.st + row * t.st_stride;
+      if (TO_TABLE) line_copy16((char*)t_st, (const char*)l_st, c.st_floats * 4, lane);
+      else line_copy16((char*)l_st, (const char*)t_st, c.st_floats * 4, lane);
+    }
+    if (c.rs_off >= 0 && lane < 2) {
+      if (TO_TABLE) t.rs[row * 2 + lane] = l_st[c.rs_off + lane]; else l_st[c.rs_off + lane] = t.rs[row * 2 + lane];
+    }
+  }
+}
+
+// (adjust_cache) one 32-lane group per id: resident -> count the use; else insert under the set's try-lock, writing a
+// displaced modified line back first.  skip_repeats: `ids` is sorted, only the first of a run works.
+__global__ void __launch_bounds__(256)
+rw_fill_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_t n, bool skip_repeats, bool count_stats)
+{
+  const int lane         = threadIdx.x & (kCacheWays - 1);
+  const int half         = threadIdx.x & 32;
+  const int64_t group    = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  unsigned long long hits = 0, looked = 0;   // a hit = the row was resident BEFORE this call brought it in
+  for (int64_t i = group; i < n; i += n_groups) {
+    const int64_t id = ids[i];
+    if (id < 0 || id >= c.entries) continue;
+    if (skip_repeats && i > 0 && ids[i - 1] == id) continue;
+    looked++;
+    const int64_t set  = cache_set_of(id, c.n_sets);
+    const int64_t line = set * kCacheWays + lane;
+    {
+      // resident already (the common case once the cache is warm): count the use, no lock.  A neighbour that displaces the
+      // line a moment later only makes the bump land on the newcomer's count.
+      const int64_t tag0 = __hip_atomic_load(&c.tags[line], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t hb0 = (uint32_t)(__ballot(tag0 == id) >> half);
+      if (hb0) {
+        hits++;
+        if (lane == __ffs(hb0) - 1 && __hip_atomic_load(&c.counts[line], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (1 << 24))
+          atomicAdd(&c.counts[line], 1);
+        continue;
+      }
+    }
+    bool done = false;
+    for (int tries = 0; tries < kCacheLockTries && !done; tries++) {
+      int got = 0;
+      if (lane == 0) got = atomicCAS(&c.locks[set], 0, 1) == 0;
+      got = __shfl(got, half, 64);
+      if (!got) {
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      __threadfence();
+      const int64_t tag = __hip_atomic_load(&c.tags[line], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int cnt     = __hip_atomic_load(&c.counts[line], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t hb = (uint32_t)(__ballot(tag == id) >> half);
+      if (hb) {
+        // a duplicate of this id (same call) got here first: nothing to do
+      } else {
+        unsigned key = ((tag < 0 ? 0u : (unsigned)cnt + 1u) << 5) | (unsigned)lane;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+          const unsigned other = (unsigned)__shfl_xor((int)key, d, 64);
+          key                  = other < key ? other : key;
+        }
+        const int victim = (int)(key & 31u);
+        if ((key >> 5) <= 1u) {   // empty, or aged to count 0
+          const int64_t vline = set * kCacheWays + victim;
+          const int64_t vtag  = __shfl(tag, half + victim, 64);
+          int vdirty          = 0;
+          if (lane == victim && vtag >= 0) vdirty = __hip_atomic_load(&c.dirty[vline], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          vdirty = __shfl(vdirty, half + victim, 64);
+          if (vdirty) rw_move_row<true>(c, t, vline, vtag, lane);
+          rw_move_row<false>(c, t, vline, id, lane);
+          if (lane == victim) {
+            __hip_atomic_store(&c.tags[line], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c.counts[line], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c.dirty[line], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          __hip_atomic_store(&c.counts[line], cnt >> 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __threadfence();
+      if (lane == 0) atomicExch(&c.locks[set], 0);
+      done = true;
+    }
+  }
+  if (count_stats && lane == 0 && looked) {
+    atomicAdd(&c.stats[0], hits);
+    atomicAdd(&c.stats[1], looked);
+  }
+}
+
+// owner-side read: row i of `out` (padded rows, 16-byte multiples) = the line of ids[i] when resident, its table row when
+// not, zeros for an id outside this partition
+__global__ void __launch_bounds__(256)
+rw_read_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_t n, char* __restrict__ out, bool count_stats)
+{
+  const int lane          = threadIdx.x & (kCacheWays - 1);
+  const int64_t group     = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups  = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  unsigned long long hits = 0, looked = 0;
+  for (int64_t i = group; i < n; i += n_groups) {
+    const int64_t id  = ids[i];
+    const bool valid  = id >= 0 && id < c.entries;
+    const int64_t set = valid ? cache_set_of(id, c.n_sets) : 0;
+    const int64_t tag = c.tags[set * kCacheWays + lane];
+    const uint32_t hb = (uint32_t)(__ballot(valid && tag == id) >> (threadIdx.x & 32));
+    char* dst         = out + i * c.line_bytes;
+    if (!valid) {
+      for (int off = lane * 16; off < (int)c.line_bytes; off += kCacheWays * 16) *reinterpret_cast<uint4*>(dst + off) = uint4{0, 0, 0, 0};
+      continue;
+    }
+    const char* src = hb ? c.data + (set * kCacheWays + __ffs(hb) - 1) * c.line_bytes : t.emb + id * t.emb_stride;
+    line_copy16(dst, src, (int)c.line_bytes, lane);
+    if (lane == 0) {
+      looked++;
+      hits += hb != 0;
+    }
+  }
+  if (count_stats && lane == 0 && looked) {
+    atomicAdd(&c.stats[0], hits);
+    atomicAdd(&c.stats[1], looked);
+  }
+}
+
+// training step: for the first sorted pair of every row, the line the row sits in (or -1); resident rows become dirty
+__global__ void __launch_bounds__(256)
+rw_locate_kernel(cache_view c, const uint64_t* __restrict__ keys, int64_t n, int* __restrict__ line_of)
+{
+  const int lane         = threadIdx.x & (kCacheWays - 1);
+  const int64_t group    = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  for (int64_t i = group; i < n; i += n_groups) {
+    const uint64_t key = keys[i];
+    const bool first   = key < (uint64_t)c.entries && (i == 0 || keys[i - 1] != key);
+    if (!first) {
+      if (lane == 0) line_of[i] = -1;
+      continue;
+    }
+    const int64_t set = cache_set_of((int64_t)key, c.n_sets);
+    const int64_t tag = c.tags[set * kCacheWays + lane];
+    const uint32_t hb = (uint32_t)(__ballot(tag == (int64_t)key) >> (threadIdx.x & 32));
+    const int way     = hb ? __ffs(hb) - 1 : -1;
+    if (lane == 0) line_of[i] = way >= 0 ? (int)(set * kCacheWays + way) : -1;
+    if (lane == way) c.dirty[set * kCacheWays + lane] = 1;
+  }
+}
+
+// writeback_all_cache / drop_all_cache: one group per line
+__global__ void __launch_bounds__(256) rw_writeback_kernel(cache_view c, rw_table t, bool drop)
+{
+  const int lane         = threadIdx.x & (kCacheWays - 1);
+  const int64_t group    = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  const int64_t lines    = c.n_sets * kCacheWays;
+  for (int64_t l = group; l < lines; l += n_groups) {
+    const int64_t tag = c.tags[l];
+    if (tag < 0) continue;
+    if (c.dirty[l]) rw_move_row<true>(c, t, l, tag, lane);
+    if (lane == 0) {
+      c.dirty[l] = 0;
+      if (drop) {
+        c.tags[l]   = -1;
+        c.counts[l] = 0;
+      }
+    }
+  }
+}
+
+rw_table rw_table_of(wholememory_embedding_t e)
+{
+  rw_table t{};
+  t.emb        = static_cast<char*>(local_pointer(e->allocated));
+  t.emb_stride = e->cache.line_bytes;
+  if (e->state_table) {
+    t.st        = static_cast<float*>(local_pointer(e->state_table));
+    t.st_stride = wholememory_tensor_get_tensor_description(e->state_table)->strides[0];
+  }
+  if (e->row_state) t.rs = static_cast<float*>(local_pointer(e->row_state));
+  return t;
+}
+
+int rw_grid(int64_t groups) { return (int)std::max<int64_t>(1, std::min<int64_t>((groups * kCacheWays + 255) / 256, 256 * 16)); }
+
+void rw_writeback(wholememory_embedding_t e, bool drop, hipStream_t stream)
+{
+  const cache_view& c = e->cache;
+  if (c.entries > 0) {
+    rw_writeback_kernel<<<rw_grid(c.n_sets * kCacheWays), 256, 0, stream>>>(c, rw_table_of(e), drop);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  if (drop) WG_HIP_CHECK(hipMemsetAsync(c.stats, 0, 2 * sizeof(unsigned long long), stream));
+  WG_HIP_CHECK(hipStreamSynchronize(stream));
+  // embedding_cache.cpp:313-317: the flush is complete on every rank when the call returns
+  const auto rc = wholememory_communicator_barrier(e->comm);
+  if (rc != WHOLEMEMORY_SUCCESS) throw logic_error(fmt("barrier after the cache write-back failed (%d)", (int)rc));
+}
+
+cache_redirect rw_prepare_step(wholememory_embedding_t e, const uint64_t* sorted_keys, int64_t n, bool adjust_cache,
+                               int* line_of, hipStream_t stream)
+{
+  const cache_view& c = e->cache;
+  cache_redirect cr;
+  if (n == 0 || c.entries == 0) return cr;
+  if (adjust_cache) {
+    rw_fill_kernel<<<rw_grid(n), 256, 0, stream>>>(c, rw_table_of(e), reinterpret_cast<const int64_t*>(sorted_keys), n, true, false);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  rw_locate_kernel<<<rw_grid(n), 256, 0, stream>>>(c, sorted_keys, n, line_of);
+  WG_HIP_CHECK(hipGetLastError());
+  cr.line_of    = line_of;
+  cr.data       = c.data;
+  cr.line_bytes = c.line_bytes;
+  cr.st         = c.st;
+  cr.st_stride  = c.st_stride;
+  cr.rs_off     = c.rs_off;
+  return cr;
+}
+
+// gather through the write-back cache: ids -> owners, (adjust_cache: owners bring the rows in), owners read line-or-row,
+// rows -> askers, un-permute (+ dtype conversion) into the output
+void rw_cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_tensor_t output, bool adjust_cache,
+                      wholememory_env_func_t* env, hipStream_t stream)
+{
+  WG_REQUIRE_INPUT(indices && output && env, "null argument");
+  const auto* id = wholememory_tensor_get_tensor_description(indices);
+  const auto* od = wholememory_tensor_get_tensor_description(output);
+  WG_REQUIRE_INPUT(id->dim == 1 && (id->dtype == WHOLEMEMORY_DT_INT || id->dtype == WHOLEMEMORY_DT_INT64) && id->strides[0] == 1,
+                   "indices must be a contiguous 1-D int32 / int64 tensor");
+  WG_REQUIRE_INPUT(!wholememory_tensor_has_handle(indices) && !wholememory_tensor_has_handle(output),
+                   "indices / output must be plain device tensors");
+  WG_REQUIRE_INPUT(od->dim == 2 && od->sizes[1] == e->dim && od->strides[1] == 1 && od->strides[0] >= e->dim,
+                   "output must be [len(indices), embedding_dim]");
+  const int64_t n = id->sizes[0];
+  WG_REQUIRE_INPUT(od->sizes[0] >= n, "output has fewer rows than there are indices");
+  const size_t es = dtype_size(e->dtype), oes = dtype_size(od->dtype);
+  WG_REQUIRE_INPUT(oes != 0, "bad output dtype");
+  const cache_view& c = e->cache;
+  const char* idx = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices)) + id->storage_offset * dtype_size(id->dtype);
+  char* out       = static_cast<char*>(wholememory_tensor_get_data_pointer(output)) + od->storage_offset * oes;
+
+  id_exchange x(env);
+  x.plan(wholememory_tensor_get_memory_handle(e->allocated), (size_t)c.line_bytes, 0, idx, id->dtype, n, false, stream);
+  temp_arena arena(env);
+  const size_t o_ids = arena.add(sizeof(int64_t) * x.recv_total), o_rows = arena.add((size_t)c.line_bytes * x.recv_total),
+               o_back = arena.add((size_t)c.line_bytes * x.n_remote);
+  arena.commit();
+  x.exchange_ids(arena.at<int64_t>(o_ids), stream);
+  if (x.recv_total > 0 && c.entries > 0) {
+    const rw_table t = rw_table_of(e);
+    if (adjust_cache) {
+      rw_fill_kernel<<<rw_grid(x.recv_total), 256, 0, stream>>>(c, t, x.d_recv_ids, x.recv_total, false, true);
+      WG_HIP_CHECK(hipGetLastError());
+    }
+    rw_read_kernel<<<rw_grid(x.recv_total), 256, 0, stream>>>(c, t, x.d_recv_ids, x.recv_total, arena.at<char>(o_rows), !adjust_cache);
+    WG_HIP_CHECK(hipGetLastError());
+  }
+  x.rows_to_askers(arena.at<char>(o_rows), arena.at<char>(o_back), (size_t)c.line_bytes, stream);
+  int64_t sz2[2] = {x.n_remote, e->dim};
+  wholememory_matrix_description_t back_m = wholememory_create_matrix_desc(sz2, e->padded_dim, 0, e->dtype);
+  sz2[0] = od->sizes[0];
+  wholememory_matrix_description_t out_m = wholememory_create_matrix_desc(sz2, od->strides[0], 0, od->dtype);
+  local_rows_scatter(arena.at<char>(o_back), back_m, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, out, out_m, stream);
+  (void)es;
+  WG_HIP_CHECK(hipStreamSynchronize(stream));  // the scratch is released on return
 }
 
 }  // namespace
@@ -707,17 +1059,34 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* o
     fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: round-robin sharding is not supported\n");
     return WHOLEMEMORY_NOT_SUPPORTED;
   }
+  bool readwrite = false;
   if (cache_policy != nullptr) {
-    // embedding.cpp:957-1009.  A READWRITE cache is the reference's device cache in front of a HOST table: every table
-    // here is in HBM, there is nothing slower to write back to.  A READONLY cache saves peer traffic and is built
-    // (per rank, in private HBM) whatever communicator / memory type the policy names for it.
-    if (cache_policy->access_type != WHOLEMEMORY_AT_READONLY) {
-      fprintf(stderr,
-              "[wholegraph_amd] wholememory_create_embedding: only WHOLEMEMORY_AT_READONLY caches exist on this target "
-              "(a READWRITE device cache fronts a host-resident table; tables live in HBM here)\n");
-      return WHOLEMEMORY_NOT_SUPPORTED;
+    // embedding.cpp:957-1009.  Two kinds of cache:
+    //   * READWRITE, held by the table's own communicator (the reference's device_cached_host_embedding): the write-back
+    //     cache of every rank's own rows, in HBM, in front of a table partition in pinned host memory (or HBM);
+    //   * READONLY (the reference's local_cached_global_readonly_embedding, and here also a READONLY policy on the
+    //     table's communicator): a private per-rank cache of the rows a rank asks for, saving peer traffic.
+    if (cache_policy->access_type == WHOLEMEMORY_AT_READWRITE) {
+      if (cache_policy->cache_comm != comm) {
+        fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: Only ReadOnly access type supported for local "
+                        "cached global readonly embedding.\n");
+        return WHOLEMEMORY_INVALID_INPUT;  // embedding.cpp:1000-1004
+      }
+      if (cache_policy->memory_location != WHOLEMEMORY_ML_DEVICE) {
+        fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: Cache has same communicator with raw embedding, "
+                        "should be device cached host embedding, but cache memory location is not WHOLEMEMORY_ML_DEVICE.\n");
+        return WHOLEMEMORY_INVALID_INPUT;  // embedding.cpp:962-967
+      }
+      if (cache_policy->memory_type < memory_type) {
+        fprintf(stderr, "[wholegraph_amd] wholememory_create_embedding: For device cached host memory, raw embedding "
+                        "should cover cache's address modes.\n");
+        return WHOLEMEMORY_INVALID_INPUT;  // embedding.cpp:968-972
+      }
+      readwrite = true;
+    } else if (cache_policy->access_type != WHOLEMEMORY_AT_READONLY) {
+      return WHOLEMEMORY_INVALID_INPUT;
     }
-    if (cache_policy->cache_comm != comm && cache_policy->memory_type == WHOLEMEMORY_MT_DISTRIBUTED) {
+    if (!readwrite && cache_policy->cache_comm != comm && cache_policy->memory_type == WHOLEMEMORY_MT_DISTRIBUTED) {
       fprintf(stderr,
               "[wholegraph_amd] wholememory_create_embedding: for local cached global readonly embedding, "
               "cache_memory_type should be chunked or continuous\n");
@@ -729,6 +1098,7 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* o
   if (es == 0 || es > 16) return WHOLEMEMORY_INVALID_INPUT;
   auto* e       = new wholememory_embedding_();
   e->comm       = comm;
+  e->location   = memory_location;
   e->dtype      = desc->dtype;
   e->entries    = desc->sizes[0];
   e->dim        = desc->sizes[1];
@@ -752,7 +1122,7 @@ wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* o
   }
   e->names_c = {nullptr};
   if (cache_policy != nullptr) {
-    rc = guarded("wholememory_create_embedding", [&] { cache_allocate(e, cache_policy->ratio); });
+    rc = guarded("wholememory_create_embedding", [&] { cache_allocate(e, cache_policy->ratio, readwrite); });
     if (rc != WHOLEMEMORY_SUCCESS) {
       wholememory_destroy_tensor(e->user);
       wholememory_destroy_tensor(e->allocated);
@@ -784,7 +1154,7 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
     fprintf(stderr, "[wholegraph_amd] wholememory_embedding_set_optimizer: the optimizer can only be set once\n");
     return WHOLEMEMORY_LOGIC_ERROR;  // embedding.cpp:487-491
   }
-  if (e->cached) {
+  if (e->cached && !e->cache_rw) {
     fprintf(stderr, "[wholegraph_amd] optimizer not supported for local cached global readonly embedding.\n");
     return WHOLEMEMORY_INVALID_INPUT;  // embedding.cpp:55-60
   }
@@ -818,12 +1188,11 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
       d.sizes[1]   = n_states * e->state_dim;
       d.strides[0] = d.sizes[1];
       d.strides[1] = 1;
-      fail_if(wholememory_create_tensor(&e->state_table, &d, e->comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE,
-                                        pt.data()),
+      fail_if(wholememory_create_tensor(&e->state_table, &d, e->comm, WHOLEMEMORY_MT_DISTRIBUTED, e->location, pt.data()),
               "state table allocation");
       size_t bytes = 0;
       void* p      = local_pointer(e->state_table, &bytes);
-      if (bytes) WG_HIP_CHECK(hipMemset(p, 0, bytes));  // embedding_optimizer.cpp:203-207: states start at zero
+      if (bytes) WG_HIP_CHECK(hipMemsetAsync(p, 0, bytes, nullptr));  // embedding_optimizer.cpp:203-207: states start at zero
       for (int k = 0; k < n_states; k++) {
         int64_t starts[2] = {0, k * e->state_dim}, ends[2] = {-1, k * e->state_dim + e->dim};
         wholememory_tensor_t view = nullptr;
@@ -840,7 +1209,7 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
       d.sizes[1]   = 2;
       d.strides[0] = 2;
       d.strides[1] = 1;
-      fail_if(wholememory_create_tensor(&e->row_state, &d, e->comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, pt.data()),
+      fail_if(wholememory_create_tensor(&e->row_state, &d, e->comm, WHOLEMEMORY_MT_DISTRIBUTED, e->location, pt.data()),
               "per-row state allocation");
       size_t bytes = 0;
       auto* p      = static_cast<float*>(local_pointer(e->row_state, &bytes));
@@ -852,6 +1221,16 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
       e->state_views.push_back(nullptr);  // the whole per-row table
     }
     WG_HIP_CHECK(hipDeviceSynchronize());
+    if (e->cache_rw) {
+      // the cache lines grow a state part behind the same tags (embedding.cpp:437-470: the reference's state embedding is
+      // created with the embedding's cache policy).  Lines resident now have no state loaded: start from an empty cache.
+      cache_view& c = e->cache;
+      rw_writeback(e, /*drop=*/true, nullptr);
+      c.st_floats = n_states * (int)e->state_dim;
+      c.rs_off    = opt->type == WHOLEMEMORY_OPT_LAZY_ADAM ? c.st_floats : -1;
+      c.st_stride = c.st_floats + (c.rs_off >= 0 ? 4 : 0);
+      if (c.st_stride > 0) WG_HIP_CHECK(hipMalloc(&c.st, (size_t)c.n_sets * kCacheWays * (size_t)c.st_stride * sizeof(float)));
+    }
     e->names_c.clear();
     for (auto& s : e->state_names) e->names_c.push_back(s.c_str());
     e->names_c.push_back(nullptr);
@@ -864,6 +1243,10 @@ wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t e,
                                                       wholememory_env_func_t* p_env_fns, int64_t stream_int)
 {
   if (!e) return WHOLEMEMORY_INVALID_INPUT;
+  if (e->cache_rw)
+    return guarded("wholememory_embedding_gather", [&] {
+      rw_cached_gather(e, indices, output, adjust_cache, p_env_fns, reinterpret_cast<hipStream_t>(stream_int));
+    });
   if (e->cached)
     return guarded("wholememory_embedding_gather", [&] {
       cached_gather(e, indices, output, adjust_cache, p_env_fns, reinterpret_cast<hipStream_t>(stream_int));
@@ -872,12 +1255,12 @@ wholememory_error_code_t wholememory_embedding_gather(wholememory_embedding_t e,
 }
 
 wholememory_error_code_t wholememory_embedding_gather_gradient_apply(wholememory_embedding_t e, wholememory_tensor_t indices,
-                                                                     wholememory_tensor_t grads, bool /*adjust_cache*/,
+                                                                     wholememory_tensor_t grads, bool adjust_cache,
                                                                      float lr, wholememory_env_func_t* p_env_fns,
                                                                      int64_t stream_int)
 {
   return guarded("wholememory_embedding_gather_gradient_apply",
-                 [&] { step(e, indices, grads, lr, p_env_fns, reinterpret_cast<hipStream_t>(stream_int)); });
+                 [&] { step(e, indices, grads, adjust_cache, lr, p_env_fns, reinterpret_cast<hipStream_t>(stream_int)); });
 }
 
 const char* const* wholememory_embedding_get_optimizer_state_names(wholememory_embedding_t e)
@@ -893,15 +1276,21 @@ wholememory_tensor_t wholememory_embedding_get_optimizer_state(wholememory_embed
   return nullptr;
 }
 
-wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t e, int64_t)
+wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t e, int64_t stream_int)
 {
-  return e ? WHOLEMEMORY_SUCCESS : WHOLEMEMORY_INVALID_INPUT;
+  if (!e) return WHOLEMEMORY_INVALID_INPUT;
+  if (!e->cache_rw) return WHOLEMEMORY_SUCCESS;   // a READONLY cache holds copies only
+  return guarded("wholememory_embedding_writeback_cache",
+                 [&] { rw_writeback(e, /*drop=*/false, reinterpret_cast<hipStream_t>(stream_int)); });
 }
 
 wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t e, int64_t stream_int)
 {
   if (!e) return WHOLEMEMORY_INVALID_INPUT;
   if (!e->cached) return WHOLEMEMORY_SUCCESS;
+  if (e->cache_rw)   // embedding_cache.cpp:321-331: write the modified lines back, then empty the cache
+    return guarded("wholememory_embedding_drop_all_cache",
+                   [&] { rw_writeback(e, /*drop=*/true, reinterpret_cast<hipStream_t>(stream_int)); });
   return guarded("wholememory_embedding_drop_all_cache", [&] {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_int);
     cache_clear(e->cache, stream);

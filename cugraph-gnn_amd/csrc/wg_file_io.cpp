@@ -168,7 +168,7 @@ wholememory_error_code_t wholememory_load_from_file(wholememory_handle_t handle,
         }
         char* dst = local_ptr + (r.local_entry + done) * memory_entry_size + memory_offset;
         WG_HIP_CHECK(hipMemcpy2DAsync(dst, memory_entry_size, stage.buf[which], file_entry_size, file_entry_size, n,
-                                      hipMemcpyHostToDevice, stage.stream));
+                                      hipMemcpyDefault, stage.stream));
         WG_HIP_CHECK(hipEventRecord(stage.done[which], stage.stream));
         used[which] = true;
         which ^= 1;
@@ -213,7 +213,7 @@ wholememory_error_code_t wholememory_store_to_file(wholememory_handle_t handle, 
         n_in[b] = std::min(chunk_entries, entries - issued);
         if (n_in[b] == 0) return;
         WG_HIP_CHECK(hipMemcpy2DAsync(stage.buf[b], file_entry_size, local_ptr + issued * memory_entry_stride + memory_offset,
-                                      memory_entry_stride, file_entry_size, n_in[b], hipMemcpyDeviceToHost, stage.stream));
+                                      memory_entry_stride, file_entry_size, n_in[b], hipMemcpyDefault, stage.stream));
         WG_HIP_CHECK(hipEventRecord(stage.done[b], stage.stream));
         issued += n_in[b];
       };

@@ -12,9 +12,12 @@ functions), written from that contract over the C entry points of include/wgamd_
 * what autograd hands back between two optimizer steps is parked in a ``_PendingGradients`` buffer — one pre-sized
   (indices, rows) pair that contributions are copied into, a single contribution is kept as it came — and leaves it
   in one piece at ``step``;
-* a cache policy is a NAME for "keep hot remote rows in my own HBM": the resolution from the reference's builtin names
-  to (communicator, memory type) is the table ``_BUILTIN_CACHES``.  There is no slower tier than a peer's HBM on this
-  target, so a READWRITE policy (a device cache in front of a host table) is refused instead of silently ignored.
+* a READONLY cache policy is a NAME for "keep hot remote rows in my own HBM": the resolution from the reference's
+  builtin names to (communicator, memory type) is the table ``_BUILTIN_CACHES``;
+* a READWRITE policy on the table's own communicator is the reference's device cache in front of a host-resident table
+  (``memory_location="cpu"``: pinned host memory the GPU reads in place): every rank keeps a write-back cache of ITS OWN
+  rows — embedding row and optimizer state behind one tag — in HBM; ``writeback_all_cache`` / ``drop_all_cache`` flush it
+  (csrc/wg_embedding.hip, "READWRITE device cache").
 """
 import ctypes
 import os
@@ -124,7 +127,8 @@ class WholeMemoryCachePolicy:
 def create_wholememory_cache_policy(cache_comm: WholeMemoryCommunicator, *, memory_type: str = "chunked",
                                     memory_location: str = "cuda", access_type: str = "readonly", ratio: float = 0.5):
     """Reference embedding.py:83-110.  Only records the request; :func:`create_embedding` decides what it means here
-    (READONLY: a private per-GPU cache of ``ratio * entries`` rows; READWRITE: refused)."""
+    (READONLY: a private per-GPU cache of ``ratio * entries`` rows; READWRITE, on the table's communicator with
+    ``memory_location="cuda"``: the write-back cache of every rank's own rows)."""
     handle = ctypes.c_void_p()
     _call("wholememory_create_embedding_cache_policy", ctypes.byref(handle), cache_comm.c_comm,
           memory_type_code(memory_type), memory_location_code(memory_location), _ACCESS_CODE[access_type], float(ratio))
@@ -326,11 +330,9 @@ def create_embedding(comm: WholeMemoryCommunicator, memory_type: str, memory_loc
                      sizes: Sequence[int], *, cache_policy: Optional[WholeMemoryCachePolicy] = None,
                      embedding_entry_partition: Optional[Sequence[int]] = None, random_init: bool = False,
                      gather_sms: int = -1, round_robin_size: int = 0) -> WholeMemoryEmbedding:
-    """Reference embedding.py:410-495.  ``memory_location`` "cuda"; ``cache_policy``: ``None`` or a READONLY policy;
-    ``random_init``: Xavier-uniform on every rank's own rows; collective (ends with a barrier)."""
-    if cache_policy is not None and cache_policy.access_type != "readonly":
-        raise NotImplementedError("only access_type='readonly' cache policies exist on this target: a readwrite device "
-                                  "cache fronts a host-resident table, and every table lives in HBM here")
+    """Reference embedding.py:410-495.  ``memory_location`` "cuda" or "cpu" (pinned host memory); ``cache_policy``:
+    ``None``, a READONLY policy, or a READWRITE policy on ``comm`` itself; ``random_init``: Xavier-uniform on every rank's
+    own rows; collective (ends with a barrier)."""
     if len(sizes) != 2:
         raise ValueError("an embedding is a 2-D table: sizes = [entries, dim]")
     if embedding_entry_partition is not None and round_robin_size != 0:

@@ -288,6 +288,15 @@ class DistributedWholeMemoryTensor(object):
             shape = (n.value,) + self._shape[1:]
             if n.value == 0:
                 self._local_view = torch.empty(shape, dtype=self._dtype, device="cuda")
+            elif lib.wholememory_get_memory_location(handle) == L.ML_HOST:
+                # pinned host partition (WHOLEMEMORY_ML_HOST): a CPU tensor over the very bytes the GPU reads in place
+                full = (n.value, self._row_stride) if self.dim() == 2 else shape
+                es = torch.empty((), dtype=self._dtype).element_size()
+                count = full[0] * (full[1] if self.dim() == 2 else 1)
+                raw = (ctypes.c_char * (count * es)).from_address(ptr.value)
+                view = torch.frombuffer(raw, dtype=self._dtype, count=count).view(full)
+                view._wg_owner = self
+                self._local_view = view[:, self._col0:self._col0 + shape[1]] if self.dim() == 2 else view
             else:
                 full = (n.value, self._row_stride) if self.dim() == 2 else shape
                 view = torch.as_tensor(_DevicePointerView(ptr.value, full, _TYPESTR[self._dtype], self),
@@ -296,6 +305,11 @@ class DistributedWholeMemoryTensor(object):
                 self._local_view = view[:, self._col0:self._col0 + shape[1]] if self.dim() == 2 else view
         t = self._local_view
         return (t.cpu() if host_view else t), start.value
+
+    def memory_location(self) -> str:
+        import ctypes
+        handle = ctypes.c_void_p(L.lib().wholememory_tensor_get_memory_handle(self.c))
+        return "cpu" if L.lib().wholememory_get_memory_location(handle) == L.ML_HOST else "cuda"
 
     def memory_type(self) -> str:
         import ctypes

@@ -15,8 +15,11 @@
  *     and opens its peers'; gather / scatter are then one kernel whose loads / stores cross xGMI directly, with no host
  *     synchronisation (the reference's mapped path, cpp/src/wholememory_ops/gather_op_impl_mapped.cu:18-67).  There is
  *     no flat global pointer: a CONTINUOUS handle is addressed like a CHUNKED one (wgamd_get_peer_pointers).
- * Host-pinned memory, HIERARCHY and NVSHMEM are not reproduced (every table lives in HBM) and return
- * WHOLEMEMORY_NOT_SUPPORTED.  RCCL is resolved at run time (dlopen "librccl.so"), so the library loads on a CPU-only box
+ * WHOLEMEMORY_ML_HOST (memory_handle.cpp:233-262, :432-520): the same three types with every partition in PINNED HOST
+ * memory, which the GPU's loads and stores reach in place over PCIe — a hipHostMalloc block of the owning process for
+ * DISTRIBUTED (and for any type on a single-rank communicator), a POSIX shared-memory segment mapped and registered by
+ * every process for the peer-mapped types.  Meant for tables that outgrow HBM, behind the READWRITE device cache of
+ * wgamd_embedding.h.  HIERARCHY and NVSHMEM are not reproduced and return WHOLEMEMORY_NOT_SUPPORTED.  RCCL is resolved at run time (dlopen "librccl.so"), so the library loads on a CPU-only box
  * and inside a PyTorch process shares torch's RCCL.  One collective per communicator at a time (as RCCL requires): the
  * communicator's pinned count buffer is shared by its calls, so two gathers on ONE communicator from two host threads race.
  *

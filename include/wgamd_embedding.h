@@ -2,9 +2,17 @@
  * wgamd_embedding.h — trainable embedding tables with sparse optimizers on top of DISTRIBUTED tensors.
  * Replaces /root/reference/cpp/include/wholememory/embedding.h:17-237 (same names, argument meaning, defaults and
  * error behaviour) for what exists on an MI355X node:
- *   * storage is WHOLEMEMORY_ML_DEVICE (one partition per GPU in HBM, wgamd_comm.h); there is no host-resident table,
- *     hence no READWRITE device cache in front of one (create_embedding answers WHOLEMEMORY_NOT_SUPPORTED for such a
- *     policy).  A WHOLEMEMORY_AT_READONLY policy builds the reference's "local cached global readonly embedding"
+ *   * storage is WHOLEMEMORY_ML_DEVICE (one partition per GPU in HBM, wgamd_comm.h) or WHOLEMEMORY_ML_HOST (one partition
+ *     per rank in pinned host memory, which the GPU reads and writes in place over PCIe);
+ *   * a WHOLEMEMORY_AT_READWRITE policy on the table's own communicator is the reference's "device cached host
+ *     embedding" (embedding.cpp:556-759): every rank keeps a set-associative WRITE-BACK cache of ITS OWN rows in private
+ *     HBM — a line holds the padded embedding row and, once an optimizer is set, the row's optimizer state behind the
+ *     same tag.  Ids are routed to their owner; with adjust_cache the owner first brings the rows in (writing displaced
+ *     modified lines back); reads and optimizer updates go to the line when the row is resident and to the table row
+ *     when it is not; writeback_cache flushes the modified lines (and keeps them), drop_all_cache flushes and empties.
+ *     The table seen through wholememory_embedding_get_embedding_tensor is stale between an update and the next
+ *     write-back, as in the reference;
+ *   * a WHOLEMEMORY_AT_READONLY policy builds the reference's "local cached global readonly embedding"
  *     (embedding.cpp:776-894): a set-associative cache of table rows in every rank's own HBM, so that repeated reads of
  *     hot rows owned by peers stop crossing xGMI.  A gather returns the same bytes with or without the cache;
  *     adjust_cache = true lets the gather insert the rows it missed; writeback is a no-op (nothing is dirty),
@@ -66,10 +74,13 @@ wholememory_error_code_t wholememory_destroy_embedding_cache_policy(wholememory_
 
 /* embedding.h:127-144.  embedding_tensor_description: 2-D, dtype FLOAT / HALF / BF16 for trainable tables (any dtype
  * for read-only ones).  round_robin_size 0; embedding_entry_partition NULL = equal split (ignored with a cache policy,
- * embedding.cpp:1009).  cache_policy: NULL, or a WHOLEMEMORY_AT_READONLY policy — cache_ratio * entries lines (rounded up to
- * sets of 32) of private HBM per rank, whatever communicator the policy names; a cache communicator other than `comm`
- * with cache memory type DISTRIBUTED -> WHOLEMEMORY_INVALID_INPUT (embedding.cpp:986-992); READWRITE ->
- * WHOLEMEMORY_NOT_SUPPORTED.  set_optimizer on a cached embedding -> WHOLEMEMORY_INVALID_INPUT (embedding.cpp:55-60). */
+ * embedding.cpp:1009).  cache_policy: NULL; or a WHOLEMEMORY_AT_READONLY policy — cache_ratio * entries lines (rounded up
+ * to sets of 32) of private HBM per rank, whatever communicator the policy names; a cache communicator other than `comm`
+ * with cache memory type DISTRIBUTED -> WHOLEMEMORY_INVALID_INPUT (embedding.cpp:986-992); or a WHOLEMEMORY_AT_READWRITE
+ * policy — cache_ratio * (rows of the rank) lines of write-back cache per rank; its communicator must be `comm`
+ * (embedding.cpp:1000-1004), its location WHOLEMEMORY_ML_DEVICE (:962-967) and its memory type not below the table's
+ * (:968-972), else WHOLEMEMORY_INVALID_INPUT.  set_optimizer on a READONLY-cached embedding -> WHOLEMEMORY_INVALID_INPUT
+ * (embedding.cpp:55-60). */
 wholememory_error_code_t wholememory_create_embedding(wholememory_embedding_t* wholememory_embedding,
                                                       wholememory_tensor_description_t* embedding_tensor_description,
                                                       wholememory_comm_t comm,
@@ -112,8 +123,9 @@ const char* const* wholememory_embedding_get_optimizer_state_names(wholememory_e
 wholememory_tensor_t wholememory_embedding_get_optimizer_state(wholememory_embedding_t wholememory_embedding,
                                                                const char* name);
 
-/* embedding.h:223-233 — writeback: nothing is ever dirty, WHOLEMEMORY_SUCCESS; drop: every line of this rank's cache is
- * emptied and its statistics zeroed. */
+/* embedding.h:223-233 — READONLY cache: writeback has nothing to do; drop empties every line of this rank's cache and
+ * zeroes its statistics.  READWRITE cache (collective, ends with a barrier): writeback copies every modified line —
+ * embedding row and optimizer state — to its table row and keeps the lines; drop does the same and empties the cache. */
 wholememory_error_code_t wholememory_embedding_writeback_cache(wholememory_embedding_t wholememory_embedding,
                                                                int64_t stream_int);
 wholememory_error_code_t wholememory_embedding_drop_all_cache(wholememory_embedding_t wholememory_embedding,

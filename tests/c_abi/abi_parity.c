@@ -220,7 +220,8 @@ int main(void)
           WHOLEMEMORY_INVALID_INPUT); /* rows != pairs */
     WM(wholememory_embedding_writeback_cache(emb, 0));
     /* READONLY cache in front of a second table (embedding.h:96-144): same rows through the cache, twice; the second
-     * pass is served from the cache lines.  Policy rules: ratio range, READWRITE refused (no host tier), no optimizer. */
+     * pass is served from the cache lines.  Policy rules: ratio range, a READWRITE cache the table's addressing does not
+     * cover (embedding.cpp:968-972), no optimizer on a READONLY cache. */
     wholememory_embedding_cache_policy_t pol = NULL, rw = NULL;
     CHECK(wholememory_create_embedding_cache_policy(&pol, comm, WHOLEMEMORY_MT_CHUNKED, WHOLEMEMORY_ML_DEVICE,
                                                     WHOLEMEMORY_AT_READONLY, 2.0f) == WHOLEMEMORY_INVALID_VALUE);
@@ -230,7 +231,7 @@ int main(void)
                                                  WHOLEMEMORY_AT_READWRITE, 0.5f));
     wholememory_embedding_t cached = NULL;
     CHECK(wholememory_create_embedding(&cached, &ed, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, rw, NULL, -1, 0) ==
-          WHOLEMEMORY_NOT_SUPPORTED);
+          WHOLEMEMORY_INVALID_INPUT);
     WM(wholememory_create_embedding(&cached, &ed, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE, pol, NULL, -1, 0));
     CHECK(wholememory_embedding_set_optimizer(cached, opt) == WHOLEMEMORY_INVALID_INPUT);
     for (int64_t r = 0; r < rows; r++)

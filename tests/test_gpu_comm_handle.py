@@ -26,7 +26,7 @@ def comm():
 def test_communicator_queries(comm):
     assert comm.get_rank() == 0 and comm.get_size() == 1
     assert comm.support_type_location("distributed", "cuda")
-    assert not comm.support_type_location("distributed", "cpu")
+    assert comm.support_type_location("distributed", "cpu")      # pinned host partitions (tests/test_gpu_embedding_rw_cache.py)
     assert not comm.support_type_location("hierarchy", "cuda")
     comm.barrier()
 
@@ -110,8 +110,6 @@ def test_unsupported_memory_types_are_refused(comm):
     import wholegraph_amd as wg
     with pytest.raises(wg.WholeMemoryError):
         wg.create_wholememory_tensor(comm, "hierarchy", "cuda", [16, 4], torch.float32, [4, 1])
-    with pytest.raises(wg.WholeMemoryError):
-        wg.create_wholememory_tensor(comm, "distributed", "cpu", [16, 4], torch.float32, [4, 1])
     with pytest.raises(wg.WholeMemoryError):  # partition that does not add up
         wg.create_wholememory_tensor(comm, "distributed", "cuda", [16, 4], torch.float32, [4, 1], [15])
 

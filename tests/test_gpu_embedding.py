@@ -214,9 +214,10 @@ def test_error_behaviour(comm):
                                                          ctypes.c_float(1.5)) == L.WHOLEMEMORY_INVALID_VALUE
     assert lib.wholememory_create_embedding_cache_policy(ctypes.byref(pol), comm.c_comm, 2, 2, 1,
                                                          ctypes.c_float(0.001)) == L.WHOLEMEMORY_INVALID_VALUE
-    # a READWRITE device cache fronts a host table: refused when the embedding is created, loudly
+    # a READWRITE cache whose addressing the table does not cover (cache CHUNKED over a DISTRIBUTED table) is refused
+    # (embedding.cpp:968-972); the accepted combinations are tests/test_gpu_embedding_rw_cache.py
     rw = wg.create_wholememory_cache_policy(comm, memory_type="chunked", access_type="readwrite", ratio=0.5)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(L.WholeMemoryError):
         wg.create_embedding(comm, "distributed", "cuda", torch.float32, [100, 8], cache_policy=rw)
     desc = L.TensorDescription()
     lib.wholememory_initialize_tensor_desc(ctypes.byref(desc))
@@ -224,7 +225,7 @@ def test_error_behaviour(comm):
     desc.sizes[0], desc.sizes[1], desc.strides[0], desc.strides[1] = 100, 8, 8, 1
     e = ctypes.c_void_p()
     assert lib.wholememory_create_embedding(ctypes.byref(e), ctypes.byref(desc), comm.c_comm, L.MT_DISTRIBUTED, L.ML_DEVICE, rw.c_policy, None, -1,
-                                            0) == L.WHOLEMEMORY_NOT_SUPPORTED
+                                            0) == L.WHOLEMEMORY_INVALID_INPUT
     wg.destroy_wholememory_cache_policy(rw)
     assert wg.create_builtin_cache_policy("none", "distributed", "cuda", "readonly", 0.5) is None
     with pytest.raises(ValueError):
