@@ -894,8 +894,10 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
           memcpy(&rec, all.data() + (size_t)r * sizeof(rec), sizeof(rec));
           if (r == comm->rank || rec.bytes == 0) {
             h->peer_ptr[r] = r == comm->rank ? h->local_ptr : nullptr;
-          } else if (rec.pid == mine.pid && host) {
-            h->peer_ptr[r] = reinterpret_cast<void*>(rec.ptr);   // registered portable by its owner, in this process
+          } else if (rec.pid == mine.pid && host && getenv("WGAMD_HOST_SHM_MAP_ALWAYS") == nullptr) {
+            // registered portable by its owner, in this process.  (WGAMD_HOST_SHM_MAP_ALWAYS: a test switch — ranks that are
+            // threads of one process map each other's segments the way separate processes do, branch below.)
+            h->peer_ptr[r] = reinterpret_cast<void*>(rec.ptr);
           } else if (host) {
             // the peer's segment, mapped and registered here as well
             const int fd = shm_open(rec.shm, O_RDWR, 0600);

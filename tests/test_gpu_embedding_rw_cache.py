@@ -372,9 +372,12 @@ def shim():
     (3, 9001, 100, "distributed", 0.5, "adagrad"),
     (4, 30000, 32, "chunked", 0.05, "sgd"),
     (2, 4000, 128, "continuous", 1.0, "rmsprop"),
+    (3, 12000, 64, "chunked+shm", 0.2, "lazy_adam"),    # thread ranks map each other's segments the way processes do
 ])
 def test_rw_cache_world_gt1(shim, W, n, dim, mtype, ratio, kind):
     env = dict(os.environ, WGAMD_RCCL_LIBRARY=shim)
+    if mtype.endswith("+shm"):
+        mtype, env["WGAMD_HOST_SHM_MAP_ALWAYS"] = mtype[:-4], "1"
     p = subprocess.run([sys.executable, "-c", WORKER, ROOT, str(W), str(n), str(dim), mtype, str(ratio), kind],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "ALL_RANKS_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
