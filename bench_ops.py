@@ -326,6 +326,42 @@ def main():
                 k * (8 + 8 * dim), k, "rows")
             wg.destroy_embedding(emb)
             wg.destroy_wholememory_optimizer(opt)
+    # ---- (f4): a table in pinned HOST memory, read and trained in place over PCIe and through the READWRITE device cache ----
+    n_host, dim, k = 4_000_000, 128, 500_000
+    hot = (torch.empty(k, device=dev).exponential_(1.0, generator=g) * (n_host * 0.01)).long().clamp_(max=n_host - 1)
+    for ratio in (None, 0.05):
+        pol = None if ratio is None else wg.create_wholememory_cache_policy(comm, memory_type="distributed", memory_location="cuda",
+                                                                            access_type="readwrite", ratio=ratio)
+        emb = wg.create_embedding(comm, "distributed", "cpu", torch.float32, [n_host, dim], cache_policy=pol)
+        emb.get_embedding_tensor().get_local_tensor()[0].normal_()
+        opt = wg.create_wholememory_optimizer(emb, "lazy_adam", {})
+        grads = torch.rand((k, dim), generator=g, device=dev)
+        uniq = int(torch.unique(hot).numel())
+        what = "host table [%d, %d] fp32 (pinned, %.1f GB), ids ~ exp(mean 1 %% of the rows), %d distinct of %d" % (
+            n_host, dim, n_host * dim * 4 / 1e9, uniq, k)
+        label = "no cache: every row crosses PCIe" if ratio is None else "READWRITE device cache, ratio %.2f (%d lines)" % (
+            ratio, emb.cache_stats()[2])
+
+        def step():
+            emb.add_gradients(hot, grads)
+            emb.apply_gradients(0.01)
+        t = timed(lambda: emb.gather(hot), iters=10, warm=4)
+        h0, l0, _ = emb.cache_stats()
+        emb.gather(hot)
+        h1, l1, _ = emb.cache_stats()
+        add("embedding gather, %s" % label, "wholememory_embedding_gather (f4, device_cached_host_embedding)", t,
+            k * (8 + 8 * dim), k, "rows", what + ("" if ratio is None else "; warm hit rate %.3f" % ((h1 - h0) / max(1, l1 - l0))))
+        t = timed(step, iters=10, warm=4)
+        add("embedding gather_gradient_apply lazy_adam, %s" % label, "wholememory_embedding_gather_gradient_apply (f4)", t,
+            k * (8 + 4 * dim) + uniq * dim * 4 * 2 * 3, k, "pairs", what)
+        if ratio is not None:
+            t = timed(lambda: emb.writeback_all_cache(), iters=3, warm=1)
+            add("embedding writeback_all_cache (%d lines, row + m + v)" % emb.cache_stats()[2], "wholememory_embedding_writeback_cache", t,
+                0, emb.cache_stats()[2], "lines", "after the first call nothing is dirty: the scan of the tags")
+        wg.destroy_embedding(emb)
+        wg.destroy_wholememory_optimizer(opt)
+        if pol is not None:
+            wg.destroy_wholememory_cache_policy(pol)
     # ---- a14-a17: the cugraph_pyg-shaped loader end to end (GraphStore + FeatureStore -> NeighborLoader -> Data with x) ------
     from cugraph_pyg_amd.data import FeatureStore, GraphStore
     from cugraph_pyg_amd.loader import NeighborLoader
