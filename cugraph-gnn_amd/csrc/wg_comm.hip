@@ -32,6 +32,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <rocprim/rocprim.hpp>
 #include <unordered_set>
@@ -834,7 +835,10 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
       bool ok = true;
       if (mapped) {
         static std::atomic<unsigned> seq{0};
-        snprintf(shm_name, sizeof(shm_name), "/wgamd.%ld.%u", (long)getpid(), seq.fetch_add(1));
+        timespec now{};
+        clock_gettime(CLOCK_MONOTONIC, &now);   // pid + counter + time: containers that share /dev/shm may share pids
+        snprintf(shm_name, sizeof(shm_name), "/wgamd.%ld.%u.%lx", (long)getpid(), seq.fetch_add(1),
+                 (unsigned long)now.tv_nsec ^ ((unsigned long)now.tv_sec << 20));
         const int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
         ok           = fd >= 0 && ftruncate(fd, (off_t)local) == 0;
         void* m      = ok ? mmap(nullptr, local, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;

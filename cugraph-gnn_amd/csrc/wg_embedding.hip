@@ -833,6 +833,44 @@ rw_read_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_
   }
 }
 
+// the same read for ids THIS rank owns itself, straight into the caller's output rows (pos[i] < 0: the row is skipped)
+template <int V>
+__global__ void __launch_bounds__(256)
+rw_read_direct_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos, int64_t n,
+                      char* __restrict__ out, int64_t out_stride, int row_bytes, bool count_stats)
+{
+  using vec_t             = typename cvec<V>::type;
+  const int lane          = threadIdx.x & (kCacheWays - 1);
+  const int64_t group     = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kCacheWays;
+  const int64_t n_groups  = (int64_t)gridDim.x * blockDim.x / kCacheWays;
+  unsigned long long hits = 0, looked = 0;
+  for (int64_t i = group; i < n; i += n_groups) {
+    const int64_t p = pos[i];
+    if (p < 0) continue;
+    const int64_t id  = ids[i];
+    const bool valid  = id >= 0 && id < c.entries;
+    const int64_t set = valid ? cache_set_of(id, c.n_sets) : 0;
+    const int64_t tag = c.tags[set * kCacheWays + lane];
+    const uint32_t hb = (uint32_t)(__ballot(valid && tag == id) >> (threadIdx.x & 32));
+    char* dst         = out + p * out_stride;
+    if (!valid) {
+      for (int off = lane * V; off + V <= row_bytes; off += kCacheWays * V) *reinterpret_cast<vec_t*>(dst + off) = vec_t{};
+      continue;
+    }
+    const char* src = hb ? c.data + (set * kCacheWays + __ffs(hb) - 1) * c.line_bytes : t.emb + id * t.emb_stride;
+    for (int off = lane * V; off + V <= row_bytes; off += kCacheWays * V)
+      *reinterpret_cast<vec_t*>(dst + off) = *reinterpret_cast<const vec_t*>(src + off);
+    if (lane == 0) {
+      looked++;
+      hits += hb != 0;
+    }
+  }
+  if (count_stats && lane == 0 && looked) {
+    atomicAdd(&c.stats[0], hits);
+    atomicAdd(&c.stats[1], looked);
+  }
+}
+
 // training step: for the first sorted pair of every row, the line the row sits in (or -1); resident rows become dirty
 __global__ void __launch_bounds__(256)
 rw_locate_kernel(cache_view c, const uint64_t* __restrict__ keys, int64_t n, int* __restrict__ line_of)
@@ -949,13 +987,39 @@ void rw_cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, w
   const char* idx = static_cast<const char*>(wholememory_tensor_get_data_pointer(indices)) + id->storage_offset * dtype_size(id->dtype);
   char* out       = static_cast<char*>(wholememory_tensor_get_data_pointer(output)) + od->storage_offset * oes;
 
+  // ids this rank owns itself stay out of the exchange when the output keeps the table's dtype: one lookup-and-copy kernel
+  // takes them from line-or-row straight to their output rows (all of the call on a single-rank communicator)
+  const bool direct = od->dtype == e->dtype;
   id_exchange x(env);
-  x.plan(wholememory_tensor_get_memory_handle(e->allocated), (size_t)c.line_bytes, 0, idx, id->dtype, n, false, stream);
+  x.plan(wholememory_tensor_get_memory_handle(e->allocated), (size_t)c.line_bytes, 0, idx, id->dtype, n, direct, stream);
   temp_arena arena(env);
   const size_t o_ids = arena.add(sizeof(int64_t) * x.recv_total), o_rows = arena.add((size_t)c.line_bytes * x.recv_total),
                o_back = arena.add((size_t)c.line_bytes * x.n_remote);
   arena.commit();
   x.exchange_ids(arena.at<int64_t>(o_ids), stream);
+  if (direct && x.self_cnt > 0 && c.entries > 0) {
+    const rw_table t = rw_table_of(e);
+    if (adjust_cache) {
+      rw_fill_kernel<<<rw_grid(x.self_cnt), 256, 0, stream>>>(c, t, x.d_self_ids, x.self_cnt, false, true);
+      WG_HIP_CHECK(hipGetLastError());
+    }
+    const int64_t ostride = od->strides[0] * (int64_t)oes;
+    const int row_bytes   = (int)(e->dim * (int64_t)es);
+    int V = 16;
+    while (V > 1 && ((row_bytes | ostride | (int64_t)reinterpret_cast<uintptr_t>(out)) & (V - 1)) != 0) V >>= 1;
+    const int grid = rw_grid(x.self_cnt);
+#define WG_RW_DIRECT(VV) \
+  rw_read_direct_kernel<VV><<<grid, 256, 0, stream>>>(c, t, x.d_self_ids, x.d_self_pos, x.self_cnt, out, ostride, row_bytes, !adjust_cache)
+    switch (V) {
+      case 16: WG_RW_DIRECT(16); break;
+      case 8: WG_RW_DIRECT(8); break;
+      case 4: WG_RW_DIRECT(4); break;
+      case 2: WG_RW_DIRECT(2); break;
+      default: WG_RW_DIRECT(1); break;
+    }
+#undef WG_RW_DIRECT
+    WG_HIP_CHECK(hipGetLastError());
+  }
   if (x.recv_total > 0 && c.entries > 0) {
     const rw_table t = rw_table_of(e);
     if (adjust_cache) {
@@ -971,7 +1035,6 @@ void rw_cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, w
   sz2[0] = od->sizes[0];
   wholememory_matrix_description_t out_m = wholememory_create_matrix_desc(sz2, od->strides[0], 0, od->dtype);
   local_rows_scatter(arena.at<char>(o_back), back_m, x.d_pos, WHOLEMEMORY_DT_INT64, x.n_remote, out, out_m, stream);
-  (void)es;
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // the scratch is released on return
 }
 
@@ -1221,7 +1284,7 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
       e->state_views.push_back(nullptr);  // the whole per-row table
     }
     WG_HIP_CHECK(hipDeviceSynchronize());
-    if (e->cache_rw) {
+    if (e->cache_rw) try {
       // the cache lines grow a state part behind the same tags (embedding.cpp:437-470: the reference's state embedding is
       // created with the embedding's cache policy).  Lines resident now have no state loaded: start from an empty cache.
       cache_view& c = e->cache;
@@ -1230,6 +1293,11 @@ wholememory_error_code_t wholememory_embedding_set_optimizer(wholememory_embeddi
       c.rs_off    = opt->type == WHOLEMEMORY_OPT_LAZY_ADAM ? c.st_floats : -1;
       c.st_stride = c.st_floats + (c.rs_off >= 0 ? 4 : 0);
       if (c.st_stride > 0) WG_HIP_CHECK(hipMalloc(&c.st, (size_t)c.n_sets * kCacheWays * (size_t)c.st_stride * sizeof(float)));
+    } catch (...) {
+      destroy_states(e);
+      e->state_names.clear();
+      e->cache.st_floats = 0, e->cache.st_stride = 0, e->cache.rs_off = -1;
+      throw;
     }
     e->names_c.clear();
     for (auto& s : e->state_names) e->names_c.push_back(s.c_str());
