@@ -15,6 +15,8 @@
 // with col = the row r and the k-order of step (m, i) chosen as k = 16 m + 4 q + i, that is exactly float i of the lane's
 // chunk m — no shuffle, no LDS.  The A operand (V^T in the same k-order) sits in registers for the whole launch.  The
 // accumulator tile D[t = 4 (lane / 16) + v][r = lane % 16] leaves as one 16-byte store per lane: out_terms[r, 4 q' .. 4 q' + 3].
+#include <cstdlib>
+
 #include "wg_common.hpp"
 #include "wgamd_ext.h"
 
@@ -97,10 +99,126 @@ gather_terms_kernel(const float* __restrict__ table, int64_t ldt, const IdT* __r
   }
 }
 
+// The same tile step, software-pipelined: the A operand (V^T) lives in LDS (one ds_read_b128 per (term tile, chunk) — 64
+// registers back for F = 128, T > 16), which pays for a SECOND set of row registers: the loads of tile t + 1 are in flight
+// while tile t is stored and multiplied (112-115 registers, four waves per SIMD with two tiles each).  Same MFMA order,
+// bit-identical results; the default (WGAMD_GATHER_TERMS_PIPELINED=0 selects the kernel above).  Same box, ogbn-mag call
+// group (tools/bench_gather_terms.py): paper rows (10.0 M, T = 24) 2.35 -> 2.12 ms, author (3.85 M, T = 12) 0.85 -> 0.79,
+// field_of_study (2.25 M, T = 8) 0.46 -> 0.43.  Measured without effect on top: non-temporal stores of the rows, 4 / 6 / 16
+// workgroups per CU instead of 8.
+template <typename IdT, int KM, int TT>
+__global__ void __launch_bounds__(256)
+gather_terms_pipelined_kernel(const float* __restrict__ table, int64_t ldt, const IdT* __restrict__ ids, int64_t n,
+                              const float* __restrict__ v, int T, float* __restrict__ out_x, int64_t ldx,
+                              float* __restrict__ out_terms, int64_t ldo, int group)
+{
+  __shared__ f32x4 a_lds[TT * KM * 64];
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  if (threadIdx.x < 64) {   // a_lds[(tt KM + m) 64 + lane] = V[16 m + 4 q + 0..3][16 tt + r]  (zero past T)
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++) {
+      const int t = tt * 16 + r;
+#pragma unroll
+      for (int m = 0; m < KM; m++) {
+        f32x4 a;
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = t < T ? v[(int64_t)(16 * m + 4 * q + i) * T + t] : 0.f;
+        a_lds[(tt * KM + m) * 64 + lane] = a;
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t n_tiles = (n + 15) / 16;
+  const int64_t wave    = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  auto id_of = [&](int64_t tile) -> int64_t {
+    const int64_t row = tile * 16 + r;
+    return (tile < n_tiles && row < n) ? (int64_t)ids[row] : -1;
+  };
+  auto fetch = [&](int64_t id, f32x4 (&x)[KM]) {
+    const float* src = table + (id >= 0 ? id : 0) * ldt + 4 * q;
+#pragma unroll
+    for (int m = 0; m < KM; m++) x[m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
+  };
+  auto finish = [&](int64_t tile, int64_t id, const f32x4 (&x)[KM]) {
+    const int64_t row = tile * 16 + r;
+    const bool live   = id >= 0;
+    if (live) {
+      float* dst = out_x + row * ldx + 4 * q;
+#pragma unroll
+      for (int m = 0; m < KM; m++) *reinterpret_cast<f32x4*>(dst + 16 * m) = x[m];
+    }
+    f32x4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int slot = lane;
+    asm volatile("" : "+v"(slot));   // opaque per tile: the operand is re-read from LDS, not hoisted back into 64 registers
+#pragma unroll
+    for (int m = 0; m < KM; m++) {
+      f32x4 a[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) a[tt] = a_lds[(tt * KM + m) * 64 + slot];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float b = live ? x[m][i] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][i], b, acc[tt], 0, 0, 0);
+      }
+    }
+    if (row < n) {
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) {
+        const int t0 = tt * 16 + 4 * q;
+        if (group == 4) {
+          if (t0 < T) *reinterpret_cast<f32x4*>(out_terms + ((int64_t)(t0 >> 2) * n + row) * 4) = acc[tt];
+          continue;
+        }
+        float* o = out_terms + row * ldo + t0;
+        if (t0 + 4 <= T && (ldo & 3) == 0) {
+          *reinterpret_cast<f32x4*>(o) = acc[tt];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (t0 + i < T) o[i] = acc[tt][i];
+        }
+      }
+    }
+  };
+  // tiles wave, wave + n_waves, ...: rows of tile k + 1 are requested before tile k is stored and multiplied; the ids run
+  // one more tile ahead of the rows
+  f32x4 x0[KM], x1[KM];
+  int64_t tile = wave;
+  int64_t id0 = id_of(tile), id1 = id_of(tile + n_waves);
+  if (tile < n_tiles) fetch(id0, x0);
+  while (tile < n_tiles) {
+    int64_t id2 = id_of(tile + 2 * n_waves);
+    if (tile + n_waves < n_tiles) fetch(id1, x1);
+    finish(tile, id0, x0);
+    tile += n_waves;
+    if (tile >= n_tiles) break;
+    id0 = id_of(tile + 2 * n_waves);
+    if (tile + n_waves < n_tiles) fetch(id2, x0);
+    finish(tile, id1, x1);
+    tile += n_waves;
+    id1 = id0;
+    id0 = id2;
+  }
+}
+
 template <typename IdT, int KM>
 void launch_tt(int TT, int grid, hipStream_t st, const float* table, int64_t ldt, const IdT* ids, int64_t n, const float* v, int T,
                float* out_x, int64_t ldx, float* out_terms, int64_t ldo, int group)
 {
+  static const bool pipelined = [] {
+    const char* e = getenv("WGAMD_GATHER_TERMS_PIPELINED");
+    return e == nullptr || e[0] != '0';
+  }();
+  if (pipelined) {
+    if (TT == 1) gather_terms_pipelined_kernel<IdT, KM, 1><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
+    else gather_terms_pipelined_kernel<IdT, KM, 2><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
+    return;
+  }
   if (TT == 1) gather_terms_kernel<IdT, KM, 1><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
   else gather_terms_kernel<IdT, KM, 2><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
 }
