@@ -259,6 +259,51 @@ int main(void)
     WM(wholememory_destroy_embedding_cache_policy(pol));
     WM(wholememory_destroy_embedding_cache_policy(rw));
     printf("cached embedding: %lld rows through a READONLY cache, bit-exact, second pass from the cache lines\n", (long long)rows);
+    /* READWRITE device cache in front of a HOST-resident table (embedding.cpp:556-759): the table partition is pinned host
+     * memory this C client writes with plain stores; gather -> SGD step through the cache -> the host table is stale until
+     * writeback_cache and holds the closed form after it. */
+    {
+      wholememory_embedding_cache_policy_t rwp = NULL;
+      WM(wholememory_create_embedding_cache_policy(&rwp, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_DEVICE,
+                                                   WHOLEMEMORY_AT_READWRITE, 1.0f));
+      CHECK(wholememory_communicator_support_type_location(comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_HOST) == WHOLEMEMORY_SUCCESS);
+      wholememory_embedding_t hemb = NULL;
+      WM(wholememory_create_embedding(&hemb, &ed, comm, WHOLEMEMORY_MT_DISTRIBUTED, WHOLEMEMORY_ML_HOST, rwp, NULL, -1, 0));
+      wholememory_tensor_t t_h = wholememory_embedding_get_embedding_tensor(hemb);
+      CHECK(wholememory_get_memory_location(wholememory_tensor_get_memory_handle(t_h)) == WHOLEMEMORY_ML_HOST);
+      void* hp = NULL; size_t hbytes = 0, hoff = 0;
+      WM(wholememory_get_local_memory(&hp, &hbytes, &hoff, wholememory_tensor_get_memory_handle(t_h)));
+      const int64_t hstride = wholememory_tensor_get_tensor_description(t_h)->strides[0];
+      CHECK(hp != NULL && hbytes == sizeof(float) * (size_t)(rows * hstride));
+      float* host_table = (float*)hp;   /* a HOST pointer: written and read by the CPU below */
+      for (int64_t r = 0; r < rows; r++)
+        for (int64_t j = 0; j < dim; j++) host_table[r * hstride + j] = (float)r;
+      WM(wholememory_embedding_set_optimizer(hemb, opt));
+      float* through2 = (float*)malloc(sizeof(float) * rows * dim);
+      void* d_through2 = to_device(through2, sizeof(float) * rows * dim);
+      wholememory_tensor_t t_through2 = wrap2d(d_through2, rows, dim, dim, WHOLEMEMORY_DT_FLOAT);
+      WM(wholememory_embedding_gather(hemb, t_all, t_through2, true, env, (int64_t)(intptr_t)stream));   /* rows enter the cache */
+      WM(wholememory_embedding_gather_gradient_apply(hemb, t_pidx, t_ones, true, 0.5f, env, (int64_t)(intptr_t)stream));
+      HIP(hipStreamSynchronize(stream));
+      int64_t stale = 0;
+      for (int64_t r = 0; r < rows; r++) stale += hits[r] > 0 && host_table[r * hstride] == (float)r;
+      CHECK(stale > 0);   /* resident rows were updated in their lines only */
+      WM(wholememory_embedding_gather(hemb, t_all, t_through2, true, env, (int64_t)(intptr_t)stream));
+      HIP(hipStreamSynchronize(stream));
+      HIP(hipMemcpy(through2, d_through2, sizeof(float) * rows * dim, hipMemcpyDeviceToHost));
+      for (int64_t r = 0; r < rows; r++)
+        for (int64_t j = 0; j < dim; j++) CHECK(through2[r * dim + j] == (float)r - 0.5f * (float)hits[r]);
+      WM(wholememory_embedding_writeback_cache(hemb, (int64_t)(intptr_t)stream));
+      for (int64_t r = 0; r < rows; r++)
+        for (int64_t j = 0; j < dim; j++) CHECK(host_table[r * hstride + j] == (float)r - 0.5f * (float)hits[r]);
+      WM(wholememory_embedding_drop_all_cache(hemb, (int64_t)(intptr_t)stream));
+      WM(wholememory_destroy_tensor(t_through2));
+      WM(wholememory_destroy_embedding(hemb));
+      WM(wholememory_destroy_embedding_cache_policy(rwp));
+      free(through2);
+      printf("host embedding: %lld rows in pinned host memory behind a READWRITE device cache, %lld stale until the write-back, "
+             "closed form exact after it\n", (long long)rows, (long long)stale);
+    }
     wholememory_tensor_t tmp[] = {t_init, t_all, t_pidx, t_ones};
     for (size_t i = 0; i < 4; i++) WM(wholememory_destroy_tensor(tmp[i]));
     WM(wholememory_destroy_embedding(emb));
