@@ -227,12 +227,17 @@ void append_unique_impl(const KeyT* targets, int T, const KeyT* neighbors, int E
 {
   const int P         = T + E;
   const int64_t slots = append_unique_slots(P);
-  temp_buffer keys_b(env), pos_b(env), slot_b(env), flag_b(env), tmp_b(env);
-  KeyT* keys   = static_cast<KeyT*>(keys_b.alloc(slots, key_traits<KeyT>::dt));
-  int* minpos  = pos_b.device<int>(slots, WHOLEMEMORY_DT_INT);
-  int* slot_of = slot_b.device<int>(P, WHOLEMEMORY_DT_INT);
-  int* rank    = flag_b.device<int>(E + 1, WHOLEMEMORY_DT_INT);
-  int* stmp    = tmp_b.device<int>(scan_tmp_ints(E + 1), WHOLEMEMORY_DT_INT);
+  // one scratch block from the caller's allocator instead of five (each request is four callbacks in the torch binding)
+  temp_arena arena(env);
+  const size_t o_keys = arena.add(sizeof(KeyT) * (size_t)slots), o_pos = arena.add(sizeof(int) * (size_t)slots),
+               o_slot = arena.add(sizeof(int) * (size_t)P), o_rank = arena.add(sizeof(int) * ((size_t)E + 1)),
+               o_tmp = arena.add(sizeof(int) * (size_t)scan_tmp_ints(E + 1));
+  arena.commit();
+  KeyT* keys   = arena.at<KeyT>(o_keys);
+  int* minpos  = arena.at<int>(o_pos);
+  int* slot_of = arena.at<int>(o_slot);
+  int* rank    = arena.at<int>(o_rank);
+  int* stmp    = arena.at<int>(o_tmp);
   const bool k64 = sizeof(KeyT) == 8;
   dev_count Tc{T, nullptr}, Ec{E, nullptr};
   batch_view one{};
