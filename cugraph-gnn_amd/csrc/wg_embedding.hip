@@ -21,6 +21,7 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "wg_common.hpp"
@@ -436,6 +437,24 @@ void step(wholememory_embedding_t e, wholememory_tensor_t indices, wholememory_t
 //                line of the set hit at least once since it was filled, gives up (the latter halves the set's counters
 //                first, so a stale hot line is displaced after log2(hits) refusals).  Best effort by design: whatever the
 //                cache holds is an exact copy of a table row, so a gather returns the same bytes with or without it.
+// hits / lookups of a launch reach the two global counters as ONE pair of atomics per workgroup (a pair per lane group
+// was 64 k same-address atomics for 500 k ids — 0.3 ms of a 0.4 ms kernel)
+__device__ __forceinline__ void stats_flush(unsigned long long* stats, unsigned long long hits, unsigned long long looked, bool count)
+{
+  __shared__ unsigned long long sh[2];
+  if (threadIdx.x == 0) sh[0] = sh[1] = 0;
+  __syncthreads();
+  if (count && (threadIdx.x & (kCacheWays - 1)) == 0 && looked) {
+    atomicAdd(&sh[0], hits);
+    atomicAdd(&sh[1], looked);
+  }
+  __syncthreads();
+  if (count && threadIdx.x == 0 && sh[1]) {
+    atomicAdd(&stats[0], sh[0]);
+    atomicAdd(&stats[1], sh[1]);
+  }
+}
+
 __device__ __forceinline__ int64_t cache_set_of(int64_t id, int64_t n_sets)
 {
   return (int64_t)((((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 24) % (uint64_t)n_sets);
@@ -469,10 +488,7 @@ cache_lookup_kernel(cache_view c, const IdxT* __restrict__ idx, int64_t n, bool 
       if (*cnt < (1 << 24)) atomicAdd(cnt, 1);
     }
   }
-  if (lane == 0 && looked) {
-    atomicAdd(&c.stats[0], hits);
-    atomicAdd(&c.stats[1], looked);
-  }
+  stats_flush(c.stats, hits, looked, true);
 }
 
 template <int V>
@@ -722,8 +738,9 @@ __device__ __forceinline__ void rw_move_row(const cache_view& c, const rw_table&
 
 // (adjust_cache) one 32-lane group per id: resident -> count the use; else insert under the set's try-lock, writing a
 // displaced modified line back first.  skip_repeats: `ids` is sorted, only the first of a run works.
+template <typename IdT>
 __global__ void __launch_bounds__(256)
-rw_fill_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_t n, bool skip_repeats, bool count_stats)
+rw_fill_kernel(cache_view c, rw_table t, const IdT* __restrict__ ids, int64_t n, bool skip_repeats, bool count_stats)
 {
   const int lane         = threadIdx.x & (kCacheWays - 1);
   const int half         = threadIdx.x & 32;
@@ -731,9 +748,9 @@ rw_fill_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_
   const int64_t n_groups = (int64_t)gridDim.x * blockDim.x / kCacheWays;
   unsigned long long hits = 0, looked = 0;   // a hit = the row was resident BEFORE this call brought it in
   for (int64_t i = group; i < n; i += n_groups) {
-    const int64_t id = ids[i];
+    const int64_t id = (int64_t)ids[i];
     if (id < 0 || id >= c.entries) continue;
-    if (skip_repeats && i > 0 && ids[i - 1] == id) continue;
+    if (skip_repeats && i > 0 && (int64_t)ids[i - 1] == id) continue;
     looked++;
     const int64_t set  = cache_set_of(id, c.n_sets);
     const int64_t line = set * kCacheWays + lane;
@@ -794,10 +811,7 @@ rw_fill_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_
       done = true;
     }
   }
-  if (count_stats && lane == 0 && looked) {
-    atomicAdd(&c.stats[0], hits);
-    atomicAdd(&c.stats[1], looked);
-  }
+  stats_flush(c.stats, hits, looked, count_stats);
 }
 
 // owner-side read: row i of `out` (padded rows, 16-byte multiples) = the line of ids[i] when resident, its table row when
@@ -827,16 +841,13 @@ rw_read_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, int64_
       hits += hb != 0;
     }
   }
-  if (count_stats && lane == 0 && looked) {
-    atomicAdd(&c.stats[0], hits);
-    atomicAdd(&c.stats[1], looked);
-  }
+  stats_flush(c.stats, hits, looked, count_stats);
 }
 
 // the same read for ids THIS rank owns itself, straight into the caller's output rows (pos[i] < 0: the row is skipped)
-template <int V>
+template <int V, typename IdT>
 __global__ void __launch_bounds__(256)
-rw_read_direct_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos, int64_t n,
+rw_read_direct_kernel(cache_view c, rw_table t, const IdT* __restrict__ ids, const int64_t* __restrict__ pos, int64_t n,
                       char* __restrict__ out, int64_t out_stride, int row_bytes, bool count_stats)
 {
   using vec_t             = typename cvec<V>::type;
@@ -845,9 +856,9 @@ rw_read_direct_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids,
   const int64_t n_groups  = (int64_t)gridDim.x * blockDim.x / kCacheWays;
   unsigned long long hits = 0, looked = 0;
   for (int64_t i = group; i < n; i += n_groups) {
-    const int64_t p = pos[i];
+    const int64_t id = (int64_t)ids[i];
+    const int64_t p  = pos != nullptr ? pos[i] : (id < 0 ? -1 : i);   // no position list: the caller's own order, ids < 0 skipped
     if (p < 0) continue;
-    const int64_t id  = ids[i];
     const bool valid  = id >= 0 && id < c.entries;
     const int64_t set = valid ? cache_set_of(id, c.n_sets) : 0;
     const int64_t tag = c.tags[set * kCacheWays + lane];
@@ -865,10 +876,7 @@ rw_read_direct_kernel(cache_view c, rw_table t, const int64_t* __restrict__ ids,
       hits += hb != 0;
     }
   }
-  if (count_stats && lane == 0 && looked) {
-    atomicAdd(&c.stats[0], hits);
-    atomicAdd(&c.stats[1], looked);
-  }
+  stats_flush(c.stats, hits, looked, count_stats);
 }
 
 // training step: for the first sorted pair of every row, the line the row sits in (or -1); resident rows become dirty
@@ -951,7 +959,7 @@ cache_redirect rw_prepare_step(wholememory_embedding_t e, const uint64_t* sorted
   cache_redirect cr;
   if (n == 0 || c.entries == 0) return cr;
   if (adjust_cache) {
-    rw_fill_kernel<<<rw_grid(n), 256, 0, stream>>>(c, rw_table_of(e), reinterpret_cast<const int64_t*>(sorted_keys), n, true, false);
+    rw_fill_kernel<int64_t><<<rw_grid(n), 256, 0, stream>>>(c, rw_table_of(e), reinterpret_cast<const int64_t*>(sorted_keys), n, true, false);
     WG_HIP_CHECK(hipGetLastError());
   }
   rw_locate_kernel<<<rw_grid(n), 256, 0, stream>>>(c, sorted_keys, n, line_of);
@@ -988,28 +996,23 @@ void rw_cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, w
   char* out       = static_cast<char*>(wholememory_tensor_get_data_pointer(output)) + od->storage_offset * oes;
 
   // ids this rank owns itself stay out of the exchange when the output keeps the table's dtype: one lookup-and-copy kernel
-  // takes them from line-or-row straight to their output rows (all of the call on a single-rank communicator)
+  // takes them from line-or-row straight to their output rows.  On a single-rank communicator that is the whole call, and
+  // the ids are used where the caller left them: no plan, no host synchronisation, no scratch.
   const bool direct = od->dtype == e->dtype;
-  id_exchange x(env);
-  x.plan(wholememory_tensor_get_memory_handle(e->allocated), (size_t)c.line_bytes, 0, idx, id->dtype, n, direct, stream);
-  temp_arena arena(env);
-  const size_t o_ids = arena.add(sizeof(int64_t) * x.recv_total), o_rows = arena.add((size_t)c.line_bytes * x.recv_total),
-               o_back = arena.add((size_t)c.line_bytes * x.n_remote);
-  arena.commit();
-  x.exchange_ids(arena.at<int64_t>(o_ids), stream);
-  if (direct && x.self_cnt > 0 && c.entries > 0) {
+  const int64_t ostride = od->strides[0] * (int64_t)oes;
+  const int row_bytes   = (int)(e->dim * (int64_t)es);
+  int V = 16;
+  while (V > 1 && ((row_bytes | ostride | (int64_t)reinterpret_cast<uintptr_t>(out)) & (V - 1)) != 0) V >>= 1;
+  auto read_direct = [&](auto* ids_p, const int64_t* pos_p, int64_t cnt) {
+    using IdT = std::remove_cv_t<std::remove_pointer_t<decltype(ids_p)>>;
     const rw_table t = rw_table_of(e);
     if (adjust_cache) {
-      rw_fill_kernel<<<rw_grid(x.self_cnt), 256, 0, stream>>>(c, t, x.d_self_ids, x.self_cnt, false, true);
+      rw_fill_kernel<IdT><<<rw_grid(cnt), 256, 0, stream>>>(c, t, ids_p, cnt, false, true);
       WG_HIP_CHECK(hipGetLastError());
     }
-    const int64_t ostride = od->strides[0] * (int64_t)oes;
-    const int row_bytes   = (int)(e->dim * (int64_t)es);
-    int V = 16;
-    while (V > 1 && ((row_bytes | ostride | (int64_t)reinterpret_cast<uintptr_t>(out)) & (V - 1)) != 0) V >>= 1;
-    const int grid = rw_grid(x.self_cnt);
+    const int grid = rw_grid(cnt);
 #define WG_RW_DIRECT(VV) \
-  rw_read_direct_kernel<VV><<<grid, 256, 0, stream>>>(c, t, x.d_self_ids, x.d_self_pos, x.self_cnt, out, ostride, row_bytes, !adjust_cache)
+  rw_read_direct_kernel<VV, IdT><<<grid, 256, 0, stream>>>(c, t, ids_p, pos_p, cnt, out, ostride, row_bytes, !adjust_cache)
     switch (V) {
       case 16: WG_RW_DIRECT(16); break;
       case 8: WG_RW_DIRECT(8); break;
@@ -1019,11 +1022,28 @@ void rw_cached_gather(wholememory_embedding_t e, wholememory_tensor_t indices, w
     }
 #undef WG_RW_DIRECT
     WG_HIP_CHECK(hipGetLastError());
+  };
+  int world = 1;
+  wholememory_communicator_get_size(&world, e->comm);
+  if (world == 1 && direct) {
+    if (n > 0 && c.entries > 0) {
+      if (id->dtype == WHOLEMEMORY_DT_INT) read_direct(reinterpret_cast<const int32_t*>(idx), nullptr, n);
+      else read_direct(reinterpret_cast<const int64_t*>(idx), nullptr, n);
+    }
+    return;
   }
+  id_exchange x(env);
+  x.plan(wholememory_tensor_get_memory_handle(e->allocated), (size_t)c.line_bytes, 0, idx, id->dtype, n, direct, stream);
+  temp_arena arena(env);
+  const size_t o_ids = arena.add(sizeof(int64_t) * x.recv_total), o_rows = arena.add((size_t)c.line_bytes * x.recv_total),
+               o_back = arena.add((size_t)c.line_bytes * x.n_remote);
+  arena.commit();
+  x.exchange_ids(arena.at<int64_t>(o_ids), stream);
+  if (direct && x.self_cnt > 0 && c.entries > 0) read_direct(static_cast<const int64_t*>(x.d_self_ids), x.d_self_pos, x.self_cnt);
   if (x.recv_total > 0 && c.entries > 0) {
     const rw_table t = rw_table_of(e);
     if (adjust_cache) {
-      rw_fill_kernel<<<rw_grid(x.recv_total), 256, 0, stream>>>(c, t, x.d_recv_ids, x.recv_total, false, true);
+      rw_fill_kernel<int64_t><<<rw_grid(x.recv_total), 256, 0, stream>>>(c, t, x.d_recv_ids, x.recv_total, false, true);
       WG_HIP_CHECK(hipGetLastError());
     }
     rw_read_kernel<<<rw_grid(x.recv_total), 256, 0, stream>>>(c, t, x.d_recv_ids, x.recv_total, arena.at<char>(o_rows), !adjust_cache);
