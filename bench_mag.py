@@ -233,7 +233,16 @@ class MagPipeline:
                     for k, (dst, et) in enumerate(keys):
                         dst[et] = ready[t][k]
                     continue
-                both = ready[t] if (ready is not None and t in ready) else xs[t] @ self._terms_matrix(layer, t)
+                vt = self._terms_matrix(layer, t)
+                if not (ready is not None and t in ready) and xs[t].stride(1) == 1 and xs[t].stride(0) % 4 == 0 \
+                        and xs[t].data_ptr() % 16 == 0 and nn.gather_terms_supported(int(xs[t].shape[1]), int(vt.shape[1])):
+                    # hidden state of the previous layer: one streaming pass, slabs come out of the kernel (no library GEMM +
+                    # transposing copy)
+                    slabs = nn.rows_terms(xs[t], vt, heads=HEADS)
+                    for k, (dst, et) in enumerate(keys):
+                        dst[et] = slabs[k]
+                    continue
+                both = ready[t] if (ready is not None and t in ready) else xs[t] @ vt
                 # one [relation end][n][H] copy per node type instead of one slice copy per relation end
                 slabs = both.view(both.shape[0], len(keys), HEADS).permute(1, 0, 2).contiguous()
                 for k, (dst, et) in enumerate(keys):

@@ -134,7 +134,7 @@ gather_terms_pipelined_kernel(const float* __restrict__ table, int64_t ldt, cons
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
   auto id_of = [&](int64_t tile) -> int64_t {
     const int64_t row = tile * 16 + r;
-    return (tile < n_tiles && row < n) ? (int64_t)ids[row] : -1;
+    return (tile < n_tiles && row < n) ? (ids != nullptr ? (int64_t)ids[row] : row) : -1;   // no id list: the rows as they lie
   };
   auto fetch = [&](int64_t id, f32x4 (&x)[KM]) {
     const float* src = table + (id >= 0 ? id : 0) * ldt + 4 * q;
@@ -144,7 +144,7 @@ gather_terms_pipelined_kernel(const float* __restrict__ table, int64_t ldt, cons
   auto finish = [&](int64_t tile, int64_t id, const f32x4 (&x)[KM]) {
     const int64_t row = tile * 16 + r;
     const bool live   = id >= 0;
-    if (live) {
+    if (live && out_x != nullptr) {   // (no out_x: only the terms are wanted)
       float* dst = out_x + row * ldx + 4 * q;
 #pragma unroll
       for (int m = 0; m < KM; m++) *reinterpret_cast<f32x4*>(dst + 16 * m) = x[m];
@@ -214,7 +214,7 @@ void launch_tt(int TT, int grid, hipStream_t st, const float* table, int64_t ldt
     const char* e = getenv("WGAMD_GATHER_TERMS_PIPELINED");
     return e == nullptr || e[0] != '0';
   }();
-  if (pipelined) {
+  if (pipelined || ids == nullptr || out_x == nullptr) {
     if (TT == 1) gather_terms_pipelined_kernel<IdT, KM, 1><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
     else gather_terms_pipelined_kernel<IdT, KM, 2><<<grid, 256, 0, st>>>(table, ldt, ids, n, v, T, out_x, ldx, out_terms, ldo, group);
     return;
@@ -252,9 +252,10 @@ wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt,
     WG_REQUIRE_INPUT(n >= 0 && n < ((int64_t)1 << 40), "bad row count");
     if (!wgamd_gather_terms_supported(F, T)) throw logic_error("gather_terms: F must be 32 | 64 | 128 | 256 and 0 < T <= 32");
     if (n == 0) return;
-    WG_REQUIRE_INPUT(table && ids && v && out_x && out_terms, "null pointer");
+    WG_REQUIRE_INPUT(table && v && out_terms, "null pointer");   // ids NULL: rows 0 .. n-1; out_x NULL: terms only
     WG_REQUIRE_INPUT(term_group == 0 || (term_group == 4 && T % 4 == 0), "term_group must be 0 (rows [n, T]) or 4 (slabs [T/4][n][4])");
-    WG_REQUIRE_INPUT(ldt >= F && ldx >= F && (term_group != 0 || ldo >= T), "leading dimension smaller than the row");
+    WG_REQUIRE_INPUT(ldt >= F && (out_x == nullptr || ldx >= F) && (term_group != 0 || ldo >= T), "leading dimension smaller than the row");
+    if (out_x == nullptr) ldx = 4;
     if (((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out_x)) & 15) != 0 || (ldt & 3) != 0 || (ldx & 3) != 0 ||
         (reinterpret_cast<uintptr_t>(out_terms) & 15) != 0)
       throw logic_error("gather_terms: rows must be 16-byte aligned");

@@ -444,6 +444,20 @@ def gather_with_terms(table: torch.Tensor, ids: torch.Tensor, v: torch.Tensor, o
     return out, terms
 
 
+def rows_terms(x: torch.Tensor, v: torch.Tensor, heads: int = 0):
+    """``terms = x @ v`` for a resident [n, F] matrix and a narrow ``v`` [F, T] (T <= 32) in ONE streaming pass over ``x``
+    (``wgamd_gather_terms_f32`` without an id list and without a row copy: exact-fp32 MFMA, rows through registers once).
+    ``heads=4``: [T / 4, n, 4] slabs — one contiguous [n, 4] block per relation end, what the GAT kernels read — instead of
+    [n, T]: no transposing copy after a library GEMM."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and v.dtype == torch.float32 and v.is_contiguous()
+    n, F_, T = int(x.shape[0]), int(x.shape[1]), int(v.shape[1])
+    assert v.shape[0] == F_ and heads in (0, 4) and (heads == 0 or T % 4 == 0)
+    terms = torch.empty((T // 4, n, 4) if heads else (n, T), dtype=torch.float32, device=x.device)
+    L.check(L.lib().wgamd_gather_terms_f32(x.data_ptr(), x.stride(0), None, torch_dtype_to_wm(torch.int64), n, F_, v.data_ptr(), T,
+                                           None, 0, terms.data_ptr(), T, heads, get_stream()), "wgamd_gather_terms_f32")
+    return terms
+
+
 def bias_act_rows(x, bias=None, relu=True, dst_rows=None, out=None):
     """``out[dst_rows[i]] = act(x[i] + bias)`` in one pass (wgamd_bias_act_rows_f32); ``out`` defaults to a fresh [n, C]."""
     n, C = x.shape

@@ -531,6 +531,8 @@ wholememory_error_code_t wgamd_csr_uniform_sample_with_replacement(
  * over every gathered row that a separate [n, F] x [F, T] GEMM costs disappears.
  * term_group = 0: out_terms is [n, T] rows (ldo floats apart).  term_group = 4 (T % 4 == 0): slabs [T / 4][n][4] — the four
  * terms of relation end k for all rows are contiguous (what a GAT kernel with H = 4 heads reads), ldo unused.
+ * ids = NULL: the rows 0 .. n-1 of `table` as they lie; out_x = NULL: only the terms are produced (both: the narrow product
+ * of a resident [n, F] matrix in one streaming pass — the layer-2 attention logits of a hidden state).
  * Shapes: F in {32, 64, 128, 256} (wgamd_gather_terms_supported), rows 16-byte aligned; others: WHOLEMEMORY_LOGIC_ERROR. */
 int wgamd_gather_terms_supported(int F, int T);
 wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt, const void* ids, wholememory_dtype_t id_dtype,

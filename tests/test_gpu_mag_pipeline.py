@@ -255,6 +255,30 @@ def test_gather_with_terms_matches_gather_and_fp64_product(oracle_mod, hiplib, F
         assert torch.equal(slabs.permute(1, 0, 2).reshape(n, T), terms)
 
 
+@pytest.mark.parametrize("F,T,n", [(256, 24, 70001), (256, 8, 15), (128, 12, 4096), (64, 5, 1000), (256, 20, 0)])
+def test_rows_terms_is_the_gathers_product_without_ids(hiplib, F, T, n):
+    """nn.rows_terms (wgamd_gather_terms_f32 with ids = NULL, out_x = NULL): bit-identical to the terms the gather produces
+    for ids = 0 .. n-1 (same kernel, same MFMA order), within 1e-5 x scale of the fp64 product; x is not written; a strided
+    view of a wider matrix works."""
+    import numpy as np
+    import torch
+    from wholegraph_amd import nn
+    rng = np.random.default_rng(F + T + n)
+    wide = torch.from_numpy(rng.standard_normal((max(n, 1), F + 8)).astype(np.float32)).cuda()[:n]   # (n = 0: an empty view)
+    x = wide[:, 4:4 + F]                                   # row stride F + 8, 16-byte aligned start
+    v = torch.from_numpy((rng.standard_normal((F, T)) * 0.3).astype(np.float32)).cuda()
+    terms = nn.rows_terms(x, v)
+    assert terms.shape == (n, T)
+    _, via_gather = nn.gather_with_terms(x, torch.arange(n, device="cuda"), v)
+    assert torch.equal(terms, via_gather)
+    ref = x.double().cpu().numpy() @ v.double().cpu().numpy()
+    scale = np.abs(x.double().cpu().numpy()) @ np.abs(v.double().cpu().numpy())
+    assert np.all(np.abs(terms.cpu().numpy() - ref) <= 1e-5 * scale + 1e-7)
+    if T % 4 == 0:
+        slabs = nn.rows_terms(x, v, heads=4)
+        assert slabs.shape == (T // 4, n, 4) and torch.equal(slabs.permute(1, 0, 2).reshape(n, T), terms)
+
+
 def test_gather_with_terms_refuses_unsupported_widths(hiplib):
     import torch
     import wholegraph_amd._lib as L
