@@ -209,10 +209,68 @@ layer_cols_kernel(const int* __restrict__ offsets, const int* __restrict__ f_bat
   for (int i = s0 + sub; i < e0; i += 16) col[i] = (int)row_of(row_local[i]);
 }
 
+// Frontier of a node type between two hops of the heterogeneous call-group walk (HeteroPygWalk._frontier): batch b gained the
+// vertices [begin[b], seg[b+1] - seg[b]) of its list since the previous hop; they are laid out batch-major in `ids` with their
+// batch and the per-batch offsets f_seg.  One launch instead of thirteen framework ops per node type and hop; every workgroup
+// rebuilds the (short) offset table in LDS and binary-searches it.  Slots past the live total are padding with the same
+// (clamped) values the framework formulation produced.
+constexpr int kFrontierMaxG = 4095;
+__global__ void __launch_bounds__(256)
+frontier_list_kernel(const int64_t* __restrict__ nodes, int64_t n_nodes, const int* __restrict__ seg, const int* __restrict__ begin,
+                     int G, int64_t cap, int64_t* __restrict__ ids, int* __restrict__ batch, int* __restrict__ f_seg)
+{
+  __shared__ int s_seg[kFrontierMaxG + 1];
+  if (threadIdx.x < 64) {   // one wave scans the G counts, 64 at a time
+    int carry = 0;
+    for (int b0 = 0; b0 < G; b0 += 64) {
+      const int b = b0 + (int)threadIdx.x;
+      int v       = b < G ? (seg[b + 1] - seg[b]) - begin[b] : 0;
+      int incl    = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if ((int)threadIdx.x >= d) incl += o;
+      }
+      if (b < G) s_seg[b] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (threadIdx.x == 0) s_seg[G] = carry;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b <= G; b += blockDim.x) f_seg[b] = s_seg[b];
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = G - 1;   // largest b < G with s_seg[b] <= p (s_seg[0] = 0)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int64_t)s_seg[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    int64_t src = (int64_t)seg[lo] + begin[lo] + (p - s_seg[lo]);
+    src         = src < 0 ? 0 : (src >= n_nodes ? n_nodes - 1 : src);
+    ids[p]      = nodes[src];
+    batch[p]    = lo;
+  }
+}
+
 }  // namespace
 }  // namespace wgamd
 
 extern "C" {
+
+wholememory_error_code_t wgamd_frontier_list(const int64_t* nodes, int64_t n_nodes, const int* seg, const int* begin, int n_batches,
+                                             int64_t capacity, int64_t* ids, int* batch, int* f_seg, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_frontier_list", [&] {
+    WG_REQUIRE_INPUT(n_batches >= 1 && n_batches <= kFrontierMaxG, "1 <= n_batches <= 4095");
+    WG_REQUIRE_INPUT(capacity >= 0 && n_nodes >= 1, "bad capacity / empty node list");
+    WG_REQUIRE_INPUT(nodes && seg && begin && f_seg && (capacity == 0 || (ids && batch)), "null pointer");
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 255) / 256, 256 * 8));
+    frontier_list_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(nodes, n_nodes, seg, begin, n_batches, capacity, ids,
+                                                                              batch, f_seg);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
 
 wholememory_error_code_t wgamd_call_group_layer_cols(const int* offsets, const int* frontier_batch, const int* frontier_seg,
                                                      const int* frontier_local0, const int* row_local, int64_t n_frontier,

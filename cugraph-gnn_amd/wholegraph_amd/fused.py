@@ -600,6 +600,15 @@ class HeteroPygWalk:
         """Batch-major list of the vertices a type gained since ``st['begin']`` (per-batch local index), capacity
         ``cap``: (ids, batch, seg, local0).  Entries past the live total are padding the kernels never read."""
         G, dev = self.G, self.dev
+        if G <= 4095 and st["nodes"].shape[0] >= 1 and st["seg"].dtype == torch.int32 and st["begin"].dtype == torch.int32:
+            # one kernel (wgamd_frontier_list) instead of the thirteen framework ops below
+            nodes, seg, begin = st["nodes"].contiguous(), st["seg"].contiguous(), st["begin"].contiguous()
+            ids = torch.empty(cap, dtype=torch.int64, device=dev)
+            b = torch.empty(cap, dtype=torch.int32, device=dev)
+            f_seg = torch.empty(G + 1, dtype=torch.int32, device=dev)
+            L.check(L.lib().wgamd_frontier_list(nodes.data_ptr(), int(nodes.shape[0]), seg.data_ptr(), begin.data_ptr(), G, int(cap),
+                                                ids.data_ptr(), b.data_ptr(), f_seg.data_ptr(), get_stream()), "wgamd_frontier_list")
+            return ids, b, f_seg, begin
         size_b = st["seg"][1:] - st["seg"][:-1]
         cnt = (size_b - st["begin"]).to(torch.int32)
         f_seg = torch.zeros(G + 1, dtype=torch.int32, device=dev)

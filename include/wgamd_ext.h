@@ -364,6 +364,14 @@ wholememory_error_code_t wgamd_sample_hop_pyg_nosync(const wgamd_pyg_hop_t* p, v
 wholememory_error_code_t wgamd_call_group_target_rows(const int* unique_seg, const int* target_seg, const int* target_batch,
                                                       int64_t n_targets, int64_t* rows, void* stream);
 
+/* Frontier of a node type between two hops of a heterogeneous call-group walk: batch b (of n_batches <= 4095) gained the
+ * vertices [begin[b], seg[b+1] - seg[b]) of its batch-major list `nodes` (n_nodes entries, offsets seg [n_batches + 1]) since
+ * the previous hop.  Writes them batch-major into ids[capacity] with their batch[capacity] and the offsets f_seg [n_batches + 1];
+ * slots past f_seg[n_batches] are padding no consumer reads.  (The per-hop frontier the reference's distributed sampler keeps
+ * per batch, python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:808-824, for a whole call group.) */
+wholememory_error_code_t wgamd_frontier_list(const int64_t* nodes, int64_t n_nodes, const int* seg, const int* begin, int n_batches,
+                                             int64_t capacity, int64_t* ids, int* batch, int* f_seg, void* stream);
+
 /* One (hop, edge type) of a heterogeneous call group (wgamd_sample_hop_pyg_nosync outputs) in the form the layers consume:
  * dst_full[j] / dst_compact[j] = row of frontier entry j in the destination type's batch-major node list — all vertices of
  * the walk (segments seg_dst [G+1]) / the vertices discovered by hops 0-1 only (compact_seg_dst [G+1], int64; NULL with
