@@ -73,6 +73,47 @@ def test_host_table_gather_scatter(comm, mtype, n, dim, dtype):
     t.destroy()
 
 
+def test_host_table_file_roundtrip_and_embedding_save_load(comm, tmp_path):
+    """Binary file I/O (wholememory_store_to_file / load_from_file) on a pinned-host partition, and save / load of a
+    host-resident embedding with its optimizer states after a write-back (reference embedding.py:378-407)."""
+    import wholegraph_amd as wg
+    n, dim = 3001, 33
+    t = wg.create_wholememory_tensor(comm, "distributed", "cpu", [n, dim], torch.float32, None, None)
+    local, _ = t.get_local_tensor()
+    table = torch.randn(n, dim)
+    local.copy_(table)
+    t.to_file_prefix(str(tmp_path / "host_tensor"))
+    local.zero_()
+    t.from_file_prefix(str(tmp_path / "host_tensor"))
+    torch.cuda.synchronize()
+    assert torch.equal(local, table)
+    t.destroy()
+    emb, pol = _make(comm, n, dim, torch.float32, 0.25)
+    opt = wg.create_wholememory_optimizer(emb, "adagrad", {})
+    e_local = emb.get_embedding_tensor().get_local_tensor()[0]
+    e_local.copy_(table)
+    idx = torch.randint(0, n, (2000,), device="cuda")
+    emb.add_gradients(idx, torch.ones(2000, dim, device="cuda"))
+    emb.need_apply = True
+    opt.step(0.1)
+    emb.writeback_all_cache()
+    trained = e_local.clone()
+    state = emb.get_optimizer_state("state_sum").get_local_tensor()[0].clone()
+    assert not torch.equal(trained, table) and float(state.abs().sum()) > 0
+    emb.save(str(tmp_path / "host_emb"))
+    emb.drop_all_cache()
+    e_local.zero_()
+    emb.get_optimizer_state("state_sum").get_local_tensor()[0].zero_()
+    emb.load(str(tmp_path / "host_emb"))
+    torch.cuda.synchronize()
+    assert torch.equal(e_local, trained)
+    assert torch.equal(emb.get_optimizer_state("state_sum").get_local_tensor()[0], state)
+    assert torch.equal(emb.gather(idx).cpu(), trained[idx.cpu()])
+    wg.destroy_embedding(emb)
+    wg.destroy_wholememory_optimizer(opt)
+    wg.destroy_wholememory_cache_policy(pol)
+
+
 # ---- READWRITE cache: gather ---------------------------------------------------------------------------------------
 def _make(comm, n, dim, dtype, ratio, location="cpu", mtype="distributed", cache_mtype="distributed"):
     import wholegraph_amd as wg
