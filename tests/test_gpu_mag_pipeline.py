@@ -255,6 +255,40 @@ def test_gather_with_terms_matches_gather_and_fp64_product(oracle_mod, hiplib, F
         assert torch.equal(slabs.permute(1, 0, 2).reshape(n, T), terms)
 
 
+@pytest.mark.parametrize("G,cap_extra", [(1, 0), (7, 13), (64, 0), (191, 1000), (1000, 5)])
+def test_frontier_list_equals_the_framework_formulation(hiplib, G, cap_extra):
+    """wgamd_frontier_list against the torch index arithmetic it replaces (HeteroPygWalk._frontier): ids, batch and f_seg are
+    equal everywhere, padding slots included; batches that gained nothing and batches that gained everything."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(G)
+    sizes = torch.randint(0, 50, (G,), generator=g, device="cuda", dtype=torch.int32)
+    seg = torch.zeros(G + 1, dtype=torch.int32, device="cuda")
+    seg[1:] = torch.cumsum(sizes, 0)
+    begin = (torch.rand(G, generator=g, device="cuda") * (sizes + 1)).to(torch.int32).clamp_(max=sizes)
+    begin[::5] = 0
+    begin[1::7] = sizes[1::7]
+    n_nodes = max(int(seg[-1]), 1)
+    nodes = torch.randint(0, 10 ** 9, (n_nodes,), generator=g, device="cuda")
+    total = int((sizes - begin).sum())
+    cap = total + cap_extra
+    ids = torch.full((max(cap, 1),), -7, dtype=torch.int64, device="cuda")
+    batch = torch.full((max(cap, 1),), -7, dtype=torch.int32, device="cuda")
+    f_seg = torch.empty(G + 1, dtype=torch.int32, device="cuda")
+    rc = hiplib.wgamd_frontier_list(nodes.data_ptr(), n_nodes, seg.data_ptr(), begin.data_ptr(), G, cap, ids.data_ptr(),
+                                    batch.data_ptr(), f_seg.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    cnt = (seg[1:] - seg[:-1] - begin).to(torch.int32)
+    want_seg = torch.zeros(G + 1, dtype=torch.int32, device="cuda")
+    want_seg[1:] = torch.cumsum(cnt, 0)
+    p = torch.arange(cap, dtype=torch.int32, device="cuda")
+    b = torch.searchsorted(want_seg[1:].contiguous(), p, right=True).clamp_(max=G - 1)
+    src = seg[:-1][b].long() + begin[b].long() + (p - want_seg[:-1][b]).long()
+    want_ids = nodes[src.clamp_(0, n_nodes - 1)]
+    assert torch.equal(f_seg, want_seg)
+    assert torch.equal(ids[:cap], want_ids) and torch.equal(batch[:cap], b.to(torch.int32))
+
+
 @pytest.mark.parametrize("F,T,n", [(256, 24, 70001), (256, 8, 15), (128, 12, 4096), (64, 5, 1000), (256, 20, 0)])
 def test_rows_terms_is_the_gathers_product_without_ids(hiplib, F, T, n):
     """nn.rows_terms (wgamd_gather_terms_f32 with ids = NULL, out_x = NULL): bit-identical to the terms the gather produces
