@@ -479,6 +479,21 @@ def main(args):
                                       "SURVEY §8(d) GAT, single pass, aggregate-first row widths: E (4F + 4H + 4) + N_dst (4HF + 4H "
                                       "+ 8) with F = %d source floats per edge, H = 4 heads") % F_,
                     "timing": "HIP events around the launch on the launch stream (one launch per hop and edge type per call group)"}
+    if roofline is not None:
+        # the same kernel over ALL its launches of the probed groups (sum of algorithmic bytes / sum of launch times): the
+        # dominant launch flips between two relations whose launches last within 3 % of each other but move different bytes
+        same, tot_by, tot_ms = roofline["stage"].split(":")[0], 0.0, 0.0
+        for k, ms_k in gat.items():
+            if k.split(":")[0] != same:
+                continue
+            r_, e_ = (int(v) for v in re.search(r"\((\d+) rows, (\d+) edges\)", k).groups())
+            f_k = F_IN if k.startswith("gat1") else HC
+            tot_by += e_ * (4 * f_k + 4 * HEADS + 4) + r_ * ((4 * HC if "+transform" in same else 4 * HEADS * f_k) + 4 * HEADS + 8)
+            tot_ms += ms_k
+        if tot_ms > 0:
+            roofline["kernel_all_launches"] = {"stage": same, "launches": sum(1 for k in gat if k.split(":")[0] == same),
+                                               "algorithmic_bytes": int(tot_by), "ms": round(tot_ms, 4),
+                                               "frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if roofline is not None and G == 64 and args.call_group <= 0:
         # HBM traffic and average duration of that launch shape from the committed profile of this command
         # (profiles/rNN/pmc_traffic_mag.json: the `#large` cluster = the largest launch of every call group; mag_kernel_stats.csv)
