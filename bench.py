@@ -129,6 +129,33 @@ class SagePipeline:
         path = self.feat.fetch_path() if hasattr(self.feat, "fetch_path") else "all-to-all"
         self.fetch_tag = "peer-mapped" if "peer-mapped" in path else "all-to-all"
         self._bufs = {}
+        # Schedule switch (WGAMD_BENCH_GATHER_AHEAD=1, off by default): the feature gather of group g+1 is enqueued on the WALK
+        # stream right behind the walk of g+1, so that it runs next to the layers of group g on the main stream instead of in
+        # front of the layers of g+1 (two x buffers; same kernels, same results).  Measured (one box, two runs each): 3.85 /
+        # 3.87 G edges/s without, 3.72 / 3.71 with — two HBM-bound kernels side by side take longer than one after the other.
+        self.gather_ahead = (os.environ.get("WGAMD_BENCH_GATHER_AHEAD", "0") == "1" and self.walk_stream is not None
+                             and not self.distributed)
+        self._x_flip = 0
+
+    def prefetch(self, pending):
+        """gather_ahead: x = feat[n_id] of an already sampled group, on the walk stream (the host waits for the group's sizes
+        first — the GPU has the layers of the previous group queued meanwhile)."""
+        from wholegraph_amd.tensor import local_gather
+        res, sizes_h, ev = pending
+        t_wait = time.perf_counter()
+        ev.synchronize()
+        self.host_wait_s += time.perf_counter() - t_wait
+        sz = sizes_h.tolist()
+        u_last = sz[len(sz) - 1][1]
+        name = "x%d" % self._x_flip
+        self._x_flip ^= 1
+        buf = self.rows_buffer(name, u_last, FEAT_DIM)
+        self._bufs[name].record_stream(self.walk_stream)
+        with torch.cuda.stream(self.walk_stream):
+            x = local_gather(self.feat.local_tensor, res.unique[len(sz) - 1][:u_last], buf)
+            evx = torch.cuda.Event()
+            evx.record(self.walk_stream)
+        res.x_prefetched = (x, evx)
 
     def rows_buffer(self, name, n_rows, n_cols):
         """[n_rows, n_cols] view of a per-purpose buffer that only ever grows (by 12 % steps): the sizes of a call group
@@ -220,6 +247,9 @@ class SagePipeline:
             if timers is not None:   # stage probe only (untimed here): what the de-duplicated fetch puts on the wire
                 self.distinct_rows.append(int(torch.unique(n_id).numel()))
             x = stage("gather(" + self.fetch_tag + ")", lambda: self.feat.gather(n_id))
+        elif timers is None and getattr(res, "x_prefetched", None) is not None:
+            x, evx = res.x_prefetched     # gathered on the walk stream while the previous group's layers ran here
+            torch.cuda.current_stream().wait_event(evx)
         else:
             from wholegraph_amd.tensor import local_gather
             x = stage("gather", lambda: local_gather(self.feat.local_tensor, n_id,
@@ -673,6 +703,8 @@ def main():
             host_prof["groups"] += 1
             if sizes is not None:
                 sizes.append(sz)
+            if nxt is not None and timers is None and pipe.gather_ahead and not mode.endswith("_fetch"):
+                pipe.prefetch(nxt)
             pending = nxt
 
     def measure(pipe, mode):
