@@ -1,4 +1,6 @@
-"""``FeatureStore`` — PyG FeatureStore over HBM-resident (optionally range-partitioned) tables.
+"""``FeatureStore`` — PyG FeatureStore over HBM-resident (optionally range-partitioned) tables; ``location="cpu"`` keeps
+the rows in pinned host memory instead (the reference's default placement, feature_store.py:42-58), read in place by the same
+kernels.
 
 Behavioural spec: /root/reference/python/cugraph-pyg/cugraph_pyg/data/feature_store.py:24-239 —
 ``store[group, attr, None] = tensor`` stores this rank's slice (ranks' slices are concatenated in
@@ -30,6 +32,9 @@ class FeatureStore(_PygFeatureStore):
         if HAS_PYG:  # pragma: no cover
             super().__init__()
         self.__features = {}
+        if location not in ("cpu", "cuda"):
+            raise ValueError("location must be 'cpu' or 'cuda'")
+        self.__location = location
         if memory_type is not None:
             warnings.warn("The memory_type argument is deprecated. Memory type is now automatically inferred.")
 
@@ -40,7 +45,7 @@ class FeatureStore(_PygFeatureStore):
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         cls = DistTensor if tensor.dim() == 1 else DistEmbedding
         if ws == 1 and ix is None:
-            return cls(tensor)
+            return cls(tensor, device=self.__location)
         n_local = torch.tensor([tensor.shape[0], tensor.dim(), tensor.shape[1] if tensor.dim() == 2 else 1],
                                dtype=torch.int64, device=dev)
         meta = torch.empty((ws, 3), dtype=torch.int64, device=dev)
@@ -56,7 +61,7 @@ class FeatureStore(_PygFeatureStore):
         sizes = [m[0] for m in meta_h]
         total = int(ix.max()) + 1 if ix is not None and ws == 1 else sum(sizes)
         shape = (total,) if tensor.dim() == 1 else (total, tensor.shape[1])
-        tx = cls(None, shape=shape, dtype=tensor.dtype)
+        tx = cls(None, shape=shape, dtype=tensor.dtype, device=self.__location)
         if ix is None:
             off = sum(sizes[:rank])
             ix = torch.arange(off, off + tensor.shape[0], dtype=torch.int64, device=dev)

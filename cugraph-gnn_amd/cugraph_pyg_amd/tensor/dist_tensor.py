@@ -4,9 +4,12 @@
 of headerless binary part files.  Storage is ``wholegraph_amd.WholeMemoryTensor``: one device tensor on a single GPU, a
 node-local range partition + RCCL all-to-all otherwise (also runs over gloo for the CPU tests).
 
-What differs from the reference by design: every table lives in HBM, so ``device`` ("cpu" = host-pinned UVA in the
-reference, "cuda") and ``backend`` ("vmm" / "nccl" / "nvshmem" / "chunked") are accepted, remembered and reported back,
-but do not select a memory type; ``DistEmbedding`` takes ``cache_policy=None`` / ``round_robin_size=0`` only."""
+``device``: "cuda" (the default here: 288 GB of HBM per GPU hold every BASELINE table) keeps a rank's rows in HBM; "cpu"
+is the reference's host-pinned placement (dist_tensor.py:60-75: pinned host memory the GPU reads through UVA) — the rows live
+in PINNED HOST memory and the same HIP row kernels read and write them in place over PCIe (for tables that outgrow HBM;
+on a box without a GPU it is plain host memory).  ``backend`` ("vmm" / "nccl" / "nvshmem" / "chunked") is accepted,
+remembered and reported back, but does not select a memory type; ``DistEmbedding`` takes ``cache_policy=None`` /
+``round_robin_size=0`` only."""
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -43,6 +46,8 @@ class DistTensor:
                  partition_offsets: Optional[Sequence[int]] = None, group=None, local_ops=None, **kwargs):
         self._tensor = None
         self._requested_device = device
+        # "cpu" with a GPU present: pinned host rows, indices and results stay on the GPU
+        self._host_rows = str(device).startswith("cpu") and torch.cuda.is_available()
         self._backend = backend
         self._group = group
         self._local_ops = local_ops if local_ops is not None else DistTensor.default_local_ops
@@ -69,11 +74,14 @@ class DistTensor:
         shape = tuple(int(s) for s in shape)
         ws, rk = _dist.world_size(self._group), _dist.rank(self._group)
         dev = "cuda" if torch.cuda.is_available() else "cpu"
+
+        def zeros(sz):
+            return torch.zeros(sz, dtype=dtype, pin_memory=True) if self._host_rows else torch.zeros(sz, dtype=dtype, device=dev)
         if ws == 1:
-            self._tensor = WholeMemoryTensor(torch.zeros(shape, dtype=dtype, device=dev), local_ops=self._local_ops)
+            self._tensor = WholeMemoryTensor(zeros(shape), local_ops=self._local_ops)
         else:
             offs = list(self._offsets_arg) if self._offsets_arg is not None else _offsets_from_book(self._book, shape[0], ws)
-            local = torch.zeros((offs[rk + 1] - offs[rk],) + shape[1:], dtype=dtype, device=dev)
+            local = zeros((offs[rk + 1] - offs[rk],) + shape[1:])
             self._tensor = WholeMemoryTensor(local, global_rows=shape[0], partition_offsets=offs, group=self._group,
                                              local_ops=self._local_ops)
         self._dtype = dtype
@@ -94,7 +102,8 @@ class DistTensor:
         if _dist.world_size(self._group) == 1:
             # one GPU holds everything: adopt the tensor (no second copy of a table that may fill most of the HBM)
             dev = "cuda" if torch.cuda.is_available() else "cpu"
-            self._tensor = WholeMemoryTensor(host_tensor.to(dev).contiguous(), local_ops=self._local_ops)
+            rows = host_tensor.cpu().contiguous().pin_memory() if self._host_rows else host_tensor.to(dev).contiguous()
+            self._tensor = WholeMemoryTensor(rows, local_ops=self._local_ops)
             self._dtype = host_tensor.dtype
             return
         self._create(host_tensor.shape, host_tensor.dtype)
@@ -141,7 +150,8 @@ class DistTensor:
         idx = torch.as_tensor(idx)
         if idx.dtype not in (torch.int32, torch.int64):
             idx = idx.long()
-        return idx.to(self._tensor.local_tensor.device).contiguous().view(-1)
+        where = "cuda" if self._host_rows else self._tensor.local_tensor.device   # pinned host rows: the kernels run on the GPU
+        return idx.to(where).contiguous().view(-1)
 
     def __getitem__(self, idx) -> torch.Tensor:
         assert self._tensor is not None, "Please create WholeGraph tensor first."

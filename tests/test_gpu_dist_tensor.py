@@ -39,6 +39,39 @@ def test_dist_tensor_creation_and_files(tmp_path, clx_name, device, dtype):
     assert bool((t[torch.tensor([3])] == 1).all()) and torch.equal(t[torch.tensor([2])].cpu(), full[2:3])
 
 
+def test_host_pinned_rows_are_read_and_written_in_place():
+    """device="cpu" / FeatureStore(location="cpu") — the reference's default placement (feature_store.py:42-58,
+    dist_tensor.py:60-75): the rows live in pinned host memory, indices and results on the GPU, and the HIP row kernels read
+    and write the host rows in place."""
+    import cugraph_pyg_amd.tensor as T
+    from cugraph_pyg_amd.data import FeatureStore
+    feats = torch.randn(5000, 64)
+    t = T.DistEmbedding.from_tensor(feats, device="cpu")
+    local = t.get_local_tensor()
+    assert local.device.type == "cpu" and local.is_pinned() and t.device == "cpu"
+    ix = torch.randint(0, 5000, (2000,), device="cuda")
+    out = t[ix]
+    assert out.is_cuda and torch.equal(out.cpu(), feats[ix.cpu()])
+    local[7] = 5.0                                            # a host write: the next gather sees it
+    assert bool((t[torch.tensor([7])] == 5.0).all())
+    t[torch.tensor([9, 11])] = torch.full((2, 64), 3.0)       # a GPU scatter into the host rows
+    torch.cuda.synchronize()
+    assert bool((local[[9, 11]] == 3.0).all())
+    ids = T.DistTensor(shape=[1000], dtype=torch.int64, device="cpu")
+    ids[torch.arange(1000)] = torch.arange(1000) * 3
+    assert ids.get_local_tensor().is_pinned() and torch.equal(ids[torch.tensor([0, 10, 999])].cpu(), torch.tensor([0, 30, 2997]))
+    fs = FeatureStore(location="cpu")
+    fs["n", "x", None] = feats
+    held = fs["n", "x", None]
+    assert held.get_local_tensor().is_pinned() and torch.equal(held[ix].cpu(), feats[ix.cpu()])
+    assert torch.equal(fs["n", "x", ix].cpu(), feats[ix.cpu()])
+    dev_fs = FeatureStore()                                   # the default here: HBM
+    dev_fs["n", "x", None] = feats
+    assert dev_fs["n", "x", None].get_local_tensor().is_cuda
+    with pytest.raises(ValueError):
+        FeatureStore(location="disk")
+
+
 def test_dist_tensor_invalid_cases():
     from cugraph_pyg_amd.tensor import DistEmbedding, DistTensor
     for kwargs in (dict(shape=[1, 2, 3], dtype=torch.float32), dict(), dict(src="invalid.txt"), dict(shape=[4])):

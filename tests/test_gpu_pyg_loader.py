@@ -44,7 +44,8 @@ def _karate():
     return e[:, 0], e[:, 1]
 
 
-def test_neighbor_loader_karate_e2e(oracle_mod, hiplib):
+@pytest.mark.parametrize("location", ["cuda", "cpu"])   # "cpu": the reference's default, rows in pinned host memory
+def test_neighbor_loader_karate_e2e(oracle_mod, hiplib, location):
     import torch
     from cugraph_pyg_amd.data import FeatureStore, GraphStore
     from cugraph_pyg_amd.loader import NeighborLoader
@@ -52,7 +53,7 @@ def test_neighbor_loader_karate_e2e(oracle_mod, hiplib):
     ei = torch.stack([torch.from_numpy(dst), torch.from_numpy(src)]).cuda()     # as the reference test builds it
     graph_store = GraphStore()
     graph_store.put_edge_index(ei, ("person", "knows", "person"), "coo", False, (34, 34))
-    feature_store = FeatureStore()
+    feature_store = FeatureStore(location=location)
     feat = torch.randint(128, (34, 16), generator=torch.Generator().manual_seed(0))
     feature_store["person", "feat", None] = feat
     loader = NeighborLoader((feature_store, graph_store), [5, 5], input_nodes=torch.arange(34), batch_size=16,
