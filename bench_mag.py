@@ -77,6 +77,10 @@ class MagPipeline:
         self.nn, self.dev, self.B, self.G = nn, dev, B, G
         self.fused_tail = os.environ.get("WGAMD_GAT_TRANSFORM", "bf16x3") != "library"
         self.fused_layer = os.environ.get("WGAMD_GAT_LAYER", "fused") != "split"
+        # the one-kernel relation keeps 10 neighbours of a row in registers and continues longer rows online, one neighbour
+        # at a time: hops with a larger fan-out take the two-kernel path unless this says otherwise (measurement switch; the
+        # fan-out-25 hop through the one-kernel relation: 0.77 ms instead of 0.39 + 0.16 per call group, 2.03 vs 2.06 G edges/s)
+        self.fused_max_fanout = int(os.environ.get("WGAMD_GAT_FUSED_MAX_FANOUT", "10"))
         self.etypes = sorted(graphs)
         self.ntypes = sorted({t for et in self.etypes for t in (et[0], et[2])})
         self.fanout = {et: list(fanout) for et in self.etypes}
@@ -273,7 +277,7 @@ class MagPipeline:
                         et = c["et"]
                         last = j == len(live_rel) - 1
                         # deep hop (fan-out <= 10) of layer 1: aggregation + dense tail as ONE kernel, the aggregate stays in LDS
-                        if one_pass and self.fused_layer and self.fanout[et][h] <= 10 and \
+                        if one_pass and self.fused_layer and self.fanout[et][h] <= self.fused_max_fanout and \
                                 nn.gat_layer_fused_supported(xs[et[0]].shape[1], HEADS, HC // HEADS):
                             stage("gat%d+transform:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
                                   lambda: nn.gat_layer_fused(
