@@ -189,3 +189,43 @@ def test_per_batch_loop_takes_the_sorted_edge_list_and_the_one_kernel_layer(hipl
         assert float((out2.detach().double().cpu() - want).abs().max()) <= 2e-5 * scale
         n += 1
     assert n == 5
+
+
+def test_call_groups_over_host_pinned_features_equal_the_hbm_placement():
+    """FeatureStore(location="cpu") — the reference's default placement: the call-group path (lazy x read through n_id inside
+    the layer-1 kernel, and the gathered x) gives bit for bit what the HBM placement gives."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd import nn
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    V, E, F = 20000, 300000, 100
+    src = torch.randint(0, V, (E,), generator=g, device=dev)
+    dst = torch.randint(0, V, (E,), generator=g, device=dev)
+    feat = torch.randn(V, F)
+    convs = [nn.SAGEConv(F, 64).to(dev), nn.SAGEConv(64, 16).to(dev)]
+    for c in convs:
+        for p in c.parameters():
+            p.data = torch.randn(p.shape, generator=g, device=dev) * 0.1
+            p.requires_grad_(False)
+    outs = {}
+    for loc in ("cuda", "cpu"):
+        gs, fs = GraphStore(), FeatureStore(location=loc)
+        gs[("n", "e", "n"), "coo", False, (V, V)] = torch.stack([src, dst])
+        fs["n", "x", None] = feat
+        assert fs["n", "x", None].get_local_tensor().device.type == loc
+        loader = NeighborLoader((fs, gs), [10, 5], input_nodes=torch.arange(8192, device=dev), batch_size=1024, shuffle=False,
+                                random_state=3)
+        res = []
+        with torch.no_grad():
+            for grp in loader.call_groups():
+                for lazy in (True, False):
+                    h = grp.x if lazy else grp.node_attr("x", lazy=False)
+                    for j, c in enumerate(convs):
+                        h = c(h, grp.layer_graph(j), act="relu" if j == 0 else None)
+                    res.append(h.clone())
+        assert all(torch.equal(res[i], res[i + 1]) for i in range(0, len(res), 2)), "lazy x != gathered x (%s)" % loc
+        outs[loc] = res
+    assert len(outs["cpu"]) == len(outs["cuda"]) > 0
+    assert all(torch.equal(a, b) for a, b in zip(outs["cuda"], outs["cpu"]))
