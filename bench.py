@@ -1089,10 +1089,26 @@ def main():
             else:
                 selftests[placement] = {"bit_exact": False, "error": repr(e)}
             ok = 0
-        flag = torch.tensor([ok], device=device)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag) == 1:
+        def agree(ok_here, what=placement):
+            """min over the ranks of "this placement went through here".  If the agreement ITSELF fails a peer is gone (a dead
+            rank raises nothing over there, but its closed connections do here — and an uncaught exception would end this rank
+            before the launcher's SIGTERM reaches the handler above): answer with the line already measured, as on_term does."""
+            flag_ = torch.tensor([ok_here], device=device)
+            if world > 1:
+                try:
+                    dist.all_reduce(flag_, op=dist.ReduceOp.MIN)
+                except Exception as e:   # noqa: BLE001
+                    placement_errors[what] = "a rank died during this placement (%s)" % (repr(e)[:200],)
+                    results.pop(what, None)
+                    done = False
+                    try:
+                        done = emit_line()
+                    finally:
+                        os._exit(0 if done else 1)
+            return int(flag_)
+
+        flag = agree(ok)
+        if flag == 1:
             try:
                 if hooks and os.environ.get("WGAMD_BENCH_TEST_STALL") and rank == world - 1:
                     time.sleep(10 ** 6)      # test hook: one rank never reaches the collectives of this pass
@@ -1102,13 +1118,11 @@ def main():
             except Exception as e:   # noqa: BLE001
                 placement_errors[placement] = repr(e)
                 ok = 0
-            flag = torch.tensor([ok], device=device)
-            if world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            flag = agree(ok)
         dog.cancel()
         if world > 1:
             signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
-        if int(flag) == 0:
+        if flag == 0:
             placement_errors.setdefault(placement, "another rank could not build / verify / measure this placement")
             results.pop(placement, None)
     ok = emit_line()
