@@ -283,7 +283,7 @@ class SagePipeline:
         return h, tuple(v for pair in sz for v in pair)
 
 
-def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, lazy_only=False):
+def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("loader_api", "train_step", "loader_api_materialised", "loader_api_per_batch")):
     """The same workload through the DROP-IN API: GraphStore + FeatureStore -> cugraph_pyg_amd NeighborLoader ->
     wholegraph_amd.nn.SAGEConv x L forward (the surface of python/cugraph-pyg/cugraph_pyg/loader/node_loader.py:16-178 and
     sampler/sampler.py:51-165).  `loader_api`: the epoch iterated in call groups (loader.call_groups(): one block-diagonal
@@ -321,15 +321,77 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, lazy_onl
         dt = time.perf_counter() - t0
         return edges / dt, dt / max(n - n_warm, 1) * 1e3, edges / max(n - n_warm, 1) / G
 
-    v, ms, epb = group_pass(True)
-    out["loader_api"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
-                         "note": "GraphStore + FeatureStore -> NeighborLoader.call_groups() (%d mini-batches per group, the loader's "
-                                 "default) -> nn.SAGEConv x %d forward; x lazy (table read through n_id in the layer-1 kernel)" % (G, L)}
-    if lazy_only:
+    if "loader_api" in which:
+        v, ms, epb = group_pass(True)
+        out["loader_api"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
+                             "note": "GraphStore + FeatureStore -> NeighborLoader.call_groups() (%d mini-batches per group, the loader's "
+                                     "default) -> nn.SAGEConv x %d forward; x lazy (table read through n_id in the layer-1 kernel)" % (G, L)}
+
+    def train_pass(n_warm=3):
+        """The same loop TRAINING: forward (x lazy) -> cross-entropy on synthetic labels -> backward -> SGD step, every call
+        group — what the reference's examples do per mini-batch (python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:
+        119-125 + examples/*: loss.backward(); optimizer.step()).  Forward and backward run on the one-kernel layer
+        (wholegraph_amd.nn._SageLayer: wgamd_sage_layer_fused_bf16x3_train / wgamd_sage_wgrad_bf16x3 / the layer kernel over the
+        transposed hop for the hidden state's gradient)."""
+        from wholegraph_amd import nn as wnn
+        model = torch.nn.ModuleList([wnn.SAGEConv(c.in_channels[0], c.out_channels) for c in convs]).to(dev)
+        with torch.no_grad():
+            for m, c in zip(model, convs):
+                for pm, pc in zip(m.parameters(), c.parameters()):
+                    pm.copy_(pc)
+        opt = torch.optim.SGD(model.parameters(), lr=0.01)
+        labels = torch.randint(0, CLASSES, (V,), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+        loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_groups + n_warm) * G * BATCH], batch_size=BATCH,
+                                shuffle=False, random_state=62)
+        edges, t0, n, losses = 0, None, 0, []
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        fwd_ms = bwd_ms = 0.0
+        for grp in loader.call_groups():
+            if n == n_warm:
+                torch.cuda.synchronize()
+                t0, edges = time.perf_counter(), 0
+            probe = n == n_warm + n_groups - 1      # the last group: forward / backward+step split by events
+            if probe:
+                ev[0].record()
+            h = grp.x
+            for j, c in enumerate(model):
+                h = c(h, grp.layer_graph(j), act="relu" if j < L - 1 else None)
+            loss = torch.nn.functional.cross_entropy(h, labels[grp.batch])
+            if probe:
+                ev[1].record()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            if probe:
+                ev[2].record()
+            if n in (0, n_warm + n_groups - 1):
+                losses.append(loss.detach())
+            edges += grp.num_edges
+            n += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fwd_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        return edges / dt, dt / max(n - n_warm, 1) * 1e3, fwd_ms, bwd_ms, [round(float(v), 4) for v in losses]
+
+    try:
+        if "train_step" not in which:
+            raise KeyError
+        v, ms, fwd_ms, bwd_ms, losses = train_pass()
+        out["train_step"] = {"value": v, "ms_per_call_group": ms, "forward_loss_ms": round(fwd_ms, 3),
+                             "backward_step_ms": round(bwd_ms, 3), "loss_first_last": losses,
+                             "note": "NeighborLoader.call_groups() -> nn.SAGEConv x %d (x lazy) -> cross-entropy -> backward -> SGD step "
+                                     "per call group of %d mini-batches; value = sampled edges per second of the whole training "
+                                     "loop (walk overlapped on its own stream as in loader_api)" % (L, G)}
+    except KeyError:
+        pass
+    except Exception as exc:   # noqa: BLE001
+        out["train_step"] = {"value": None, "error": repr(exc)[:300]}
+    if "loader_api_materialised" in which:
+        v, ms, epb = group_pass(False)
+        out["loader_api_materialised"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
+                                          "note": "the same loop with x = feat[n_id] gathered once per call group (wholememory_gather)"}
+    if "loader_api_per_batch" not in which:
         return out
-    v, ms, epb = group_pass(False)
-    out["loader_api_materialised"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
-                                      "note": "the same loop with x = feat[n_id] gathered once per call group (wholememory_gather)"}
     n_b, n_warm = 96, 16
     loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_b + n_warm) * BATCH], batch_size=BATCH, shuffle=False,
                             random_state=62)

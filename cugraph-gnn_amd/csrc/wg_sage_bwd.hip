@@ -1,0 +1,360 @@
+// Weight gradient of the one-kernel SAGEConv layer (wg_sage_mfma.hip) over a sampled hop:
+//     dW_t [2F, N] = [ agg | X[self] ]^T (n_rows x 2F)  @  dZ (n_rows x N),       dZ = grad_out masked by the layer's ReLU
+// — the training half of what the reference's models do with torch_geometric.nn.SAGEConv
+// (python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59,119-125: forward, loss.backward(), optimizer step).
+//
+// Why its own kernel: the product is a "TN" GEMM whose reduction runs over the ROWS of the hop (1.8 M per call group of the
+// products workload) with a small [2F, N] = [200, 256] result — a library fp32 GEMM of that shape is bound by the fp32 matrix
+// rate (180 GFLOP at ~110 TF/s: 1.6 ms) and needs the [n_rows, 2F] operand materialised first.  Here:
+//   * the aggregate half comes from the forward launch (wgamd_sage_layer_fused_bf16x3_train keeps it: n_rows F 4 bytes written
+//     once, instead of E F 4 bytes of neighbour rows fetched a second time), the self half is gathered through self_rows /
+//     src_ids like the forward does;
+//   * split-K: every workgroup owns a contiguous range of rows and keeps its whole [2F, N-block] partial sum in MFMA
+//     accumulators (8 waves x up to 8 tiles of 32 x 32) for its whole life; it is written once, and a second launch adds the
+//     partial sums in workgroup order (no atomics: same bits from run to run);
+//   * the product is the exact 3-way bf16 split of the forward (six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32
+//     accumulate).  Both MFMA operands are K-major here (K = hop rows): the A side ([agg | self] rows) is split ONCE per
+//     element by the thread that loaded it and stored TRANSPOSED into LDS as three bf16 planes [feature][row] (a fragment is
+//     one ds_read_b128); the B side (dZ) never touches the LDS — a wave owns 32 output columns, so its fragment is 8 rows of
+//     one column per lane: eight 4-byte loads whose wave-wide footprint is two 128-B segments each, split in registers by the
+//     only wave that needs them;
+//   * double-buffered over 32-row (F <= 128) or 16-row tiles, one barrier per tile: the loads of tile t+1 are in flight
+//     during the MFMAs of tile t, their split + LDS store follows, the row ids of the self half run two tiles ahead.
+#include "wg_sage_mfma_parts.hpp"
+
+namespace wgamd {
+namespace {
+using namespace sage_mfma;
+
+struct wgrad_args {
+  const float* agg;
+  int64_t ld_agg;
+  const float* x;
+  int64_t ldx;
+  int F;
+  const int64_t* self_global;   // row of x holding destination i itself (self_rows with the src_ids indirection applied)
+  int64_t n_rows;
+  const float* g;
+  int64_t ldg;
+  const float* act;             // nullable: the layer's ReLU output — dZ = g where act > 0
+  int64_t ld_act;
+  int N;
+  float* part;                  // [gridDim.y][gridDim.x][KL + 1][NB]: partial sums, row KL = the bias gradient
+  int64_t rows_per_block;       // multiple of TR
+  int KL;                       // feature rows of the LDS planes and of a partial sum: 2F rounded up to 32
+};
+
+__global__ void compose_self_kernel(const int64_t* __restrict__ self_rows, const void* __restrict__ src_ids, int ids_int32,
+                                    int64_t n, int64_t* __restrict__ out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = self_rows[i];
+    out[i]          = ids_int32 ? (int64_t) static_cast<const int32_t*>(src_ids)[s] : static_cast<const int64_t*>(src_ids)[s];
+  }
+}
+
+// TR rows per tile; wave w owns columns [32 (w % WN), +32) of the workgroup's N-block and the (up to) MT feature tiles
+// [MT (w / WN), +MT) of 32 that exist (a.KL / 32 of them)
+// MASK: a.act is given (a runtime test inside the unrolled load loops made the compiler peel the mask loads into a rolled loop
+// over a stack array, every load waited for on the spot: 14 us per 32-row tile instead of 3)
+template <int TR, int MT, int WN, bool MASK>
+__global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
+{
+  constexpr int TRP = TR + 8, KS = TR / 16, NB = WN * 32;
+  constexpr int RG = TR / 4, QG = 16 / RG;   // staging: 4-row groups per tile, quads (4 features) per 16-lane group
+  const int kPlane = a.KL * TRP, kBuf = 3 * kPlane;   // bf16 elements
+  extern __shared__ __attribute__((aligned(16))) uint16_t planes[];   // [2][3][KL][TRP]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave % WN, wm = wave / WN, lm = lane & 31, lh = lane >> 5;
+  for (int i = t; i < kBuf; i += 512) reinterpret_cast<uint32_t*>(planes)[i] = 0u;   // 2 kBuf bf16 = kBuf dwords
+  __syncthreads();
+
+  const int mt_live = min(MT, a.KL / 32 - wm * MT);   // (<= 0: this wave only helps staging)
+  const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
+  const int64_t r_end   = min(a.n_rows, r_begin + a.rows_per_block);
+  const int64_t n_tiles = r_begin < r_end ? (r_end - r_begin + TR - 1) / TR : 0;
+
+  // ---- staging task of this thread: quad q (features 4q .. 4q+3 of [agg | self]) x rows 4 rg .. 4 rg + 3 of the tile ----
+  const int l16 = t & 15, rg = l16 & (RG - 1), q = (t >> 4) * QG + l16 / RG;
+  const int FQ = a.F >> 2;
+  const bool stage = q < 2 * FQ, self_half = q >= FQ;
+  f32x4 st[4];
+  int64_t idx_next[4];   // self half: rows of x for the tile after the one being staged
+  auto load_idx = [&](int64_t tile) {
+    if (!(stage && self_half)) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t row = r_begin + tile * TR + rg * 4 + j;
+      idx_next[j]       = a.self_global[row < r_end ? row : r_begin];
+    }
+  };
+  auto load_stage = [&](int64_t tile) {
+    if (!stage) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t row  = r_begin + tile * TR + rg * 4 + j;
+      const int64_t rowc = row < r_end ? row : r_begin;
+      const float* p     = self_half ? a.x + idx_next[j] * a.ldx + (q - FQ) * 4 : a.agg + rowc * a.ld_agg + q * 4;
+      st[j]              = *reinterpret_cast<const f32x4*>(p);
+    }
+  };
+  auto store_stage = [&](int64_t tile, uint16_t* buf) {
+    if (!stage) return;
+    uint32_t h[4][4], m[4][4], l[4][4];   // [row j][feature i]
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool ok = r_begin + tile * TR + rg * 4 + j < r_end;
+#pragma unroll
+      for (int i = 0; i < 4; i++) split3(ok ? st[j][i] : 0.f, h[j][i], m[j][i], l[j][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint16_t* dst = buf + (q * 4 + i) * TRP + rg * 4;
+      using u32x2   = __attribute__((ext_vector_type(2))) uint32_t;
+      *reinterpret_cast<u32x2*>(dst)              = u32x2{pack_hi16(h[0][i], h[1][i]), pack_hi16(h[2][i], h[3][i])};
+      *reinterpret_cast<u32x2*>(dst + kPlane)     = u32x2{pack_hi16(m[0][i], m[1][i]), pack_hi16(m[2][i], m[3][i])};
+      *reinterpret_cast<u32x2*>(dst + 2 * kPlane) = u32x2{pack_hi16(l[0][i], l[1][i]), pack_hi16(l[2][i], l[3][i])};
+    }
+  };
+
+  // ---- dZ fragments of this wave: column `col`, rows 16 ks + 8 lh + j ----------------------------------------------------
+  const int col      = blockIdx.y * NB + wn * 32 + lm;
+  const bool col_ok  = col < a.N;
+  const int colc     = col_ok ? col : 0;
+  const bool z_wave  = mt_live > 0;   // (a wave without live feature tiles needs no dZ; wm == 0 always has some)
+  float zr[KS][8], zm[KS][8];
+  u32x4 zf[KS][3];
+  float bsum = 0.f;
+  auto load_z = [&](int64_t tile) {
+    if (!z_wave) return;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int64_t row  = r_begin + tile * TR + ks * 16 + lh * 8 + j;
+        const int64_t rowc = row < r_end ? row : r_begin;
+        zr[ks][j]          = a.g[rowc * a.ldg + colc];
+        if constexpr (MASK) zm[ks][j] = a.act[rowc * a.ld_act + colc];
+        else zm[ks][j] = 1.f;
+      }
+  };
+  auto split_z = [&](int64_t tile) {
+    if (!z_wave) return;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      uint32_t h[8], m[8], l[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool ok = col_ok && r_begin + tile * TR + ks * 16 + lh * 8 + j < r_end && (!MASK || zm[ks][j] > 0.f);
+        const float v = ok ? zr[ks][j] : 0.f;
+        if (wm == 0) bsum += v;
+        split3(v, h[j], m[j], l[j]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        zf[ks][0][jj] = pack_hi16(h[2 * jj], h[2 * jj + 1]);
+        zf[ks][1][jj] = pack_hi16(m[2 * jj], m[2 * jj + 1]);
+        zf[ks][2][jj] = pack_hi16(l[2 * jj], l[2 * jj + 1]);
+      }
+    }
+  };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[m][i] = 0.f;
+
+  if (n_tiles > 0) {
+    // prologue: tile 0 staged and stored, tile 1's row ids known
+    load_idx(0);
+    load_stage(0);
+    load_z(0);
+    load_idx(1);
+    store_stage(0, planes);
+    split_z(0);
+    __syncthreads();
+    for (int64_t tile = 0; tile < n_tiles; tile++) {
+      const bool more = tile + 1 < n_tiles;
+      if (more) {
+        load_stage(tile + 1);   // (uses the ids requested one iteration ago)
+        load_idx(tile + 2);
+      }
+      if (more) load_z(tile + 1);
+      const uint16_t* pb = planes + (tile & 1) * kBuf + ((wm * MT) * 32 + lm) * TRP + lh * 8;
+      constexpr int pa_[6] = {2, 0, 1, 1, 0, 0};   // smallest terms first (as the forward)
+      constexpr int pb_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+          if (m < mt_live) {
+            const uint16_t* ap = pb + m * 32 * TRP + ks * 16;
+            u32x4 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) fa[p] = *reinterpret_cast<const u32x4*>(ap + p * kPlane);
+#pragma unroll
+            for (int k6 = 0; k6 < 6; k6++)
+              acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa_[k6]]),
+                                                               __builtin_bit_cast(bf16x8, zf[ks][pb_[k6]]), acc[m], 0, 0, 0);
+          }
+      if (more) {
+        store_stage(tile + 1, planes + ((tile + 1) & 1) * kBuf);
+        split_z(tile + 1);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- partial sums: [KM + 1][NB] of this workgroup; C/D map: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* mine = a.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(a.KL + 1) * NB;
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+    if (m < mt_live) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int f = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        mine[(int64_t)f * NB + wn * 32 + lm] = acc[m][r];
+      }
+    }
+  if (wm == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lh == 0) mine[(int64_t)a.KL * NB + wn * 32 + lm] = bsum;
+  }
+}
+
+// grad_w_l [N, F], grad_w_r [N, F], grad_bias [N]  (+)=  sum over the workgroups, in workgroup order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int grid_x, int KL, int NB, int F, int N,
+                                    float* __restrict__ gwl, float* __restrict__ gwr, float* __restrict__ gb, int accumulate)
+{
+  const int64_t total = (int64_t)(2 * F + 1) * N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N), f = (int)(i / N);   // f == 2F: the bias row
+    const int y = n / NB, nl = n - y * NB;
+    const float* p = part + ((int64_t)y * grid_x * (KL + 1) + (f == 2 * F ? KL : f)) * NB + nl;
+    float s = 0.f;
+    for (int b = 0; b < grid_x; b++) s += p[(int64_t)b * (KL + 1) * NB];
+    float* dst = f == 2 * F ? (gb ? gb + n : nullptr) : (f < F ? gwl + (int64_t)n * F + f : gwr + (int64_t)n * F + (f - F));
+    if (dst) *dst = accumulate ? *dst + s : s;
+  }
+}
+
+struct wgrad_plan {
+  int TR, MT, WN, KL, NB, grid_y;
+};
+__host__ inline wgrad_plan plan_for(int F, int N)
+{
+  const int n_ct = (N + 31) / 32, mtiles = (2 * F + 31) / 32;
+  int WN = 2;   // (N <= 32 runs with one dead column wave: no instances for a single one)
+  while (WN < n_ct && WN < 8) WN *= 2;
+  while (WN > 2 && (mtiles + (8 / WN) - 1) / (8 / WN) > 8) WN /= 2;   // at most 8 accumulator tiles per wave
+  const int WM = 8 / WN, mt = (mtiles + WM - 1) / WM, TR = F <= 128 ? 32 : 16;
+  // (accumulator tiles per wave are a template parameter: 4, 8, and 7 for the products layer-1 shape, whose 16 registers
+  //  fewer keep that instance clear of spills)
+  const int MT = mt <= 4 ? 4 : (mt == 7 && TR == 32 && WN == 8 ? 7 : 8);
+  return {TR, MT, WN, mtiles * 32, WN * 32, (n_ct + WN - 1) / WN};
+}
+__host__ inline size_t part_bytes(const wgrad_plan& p, int grid_x) { return (size_t)p.grid_y * grid_x * (p.KL + 1) * p.NB * 4; }
+// workgroups along the rows: one per CU of the DEVICE at most (the workspace query does not know the stream's CU mask)
+__host__ inline int max_grid_x(const wgrad_plan& p) { return std::max(1, stream_cu_count(nullptr) / p.grid_y); }
+
+template <int TR, int MT>
+void launch_wn(const wgrad_plan& p, const wgrad_args& a, dim3 grid, hipStream_t st)
+{
+  const size_t lds = (size_t)2 * 3 * p.KL * (TR + 8) * 2;
+  auto go = [&](auto kern) {
+    WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<grid, 512, lds, st>>>(a);
+    WG_HIP_CHECK(hipGetLastError());
+  };
+  const bool mask = a.act != nullptr;
+  switch (p.WN) {
+    case 2: mask ? go(sage_wgrad_kernel<TR, MT, 2, true>) : go(sage_wgrad_kernel<TR, MT, 2, false>); break;
+    case 4: mask ? go(sage_wgrad_kernel<TR, MT, 4, true>) : go(sage_wgrad_kernel<TR, MT, 4, false>); break;
+    default: mask ? go(sage_wgrad_kernel<TR, MT, 8, true>) : go(sage_wgrad_kernel<TR, MT, 8, false>); break;
+  }
+}
+template <int TR>
+void launch_mt(const wgrad_plan& p, const wgrad_args& a, dim3 grid, hipStream_t st)
+{
+  if (p.MT == 4) return launch_wn<TR, 4>(p, a, grid, st);
+  if constexpr (TR == 32) {
+    if (p.MT == 7) {
+      const size_t lds = (size_t)2 * 3 * p.KL * (TR + 8) * 2;
+      auto go          = [&](auto kern) {
+        WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, 512, lds, st>>>(a);
+        WG_HIP_CHECK(hipGetLastError());
+      };
+      a.act != nullptr ? go(sage_wgrad_kernel<32, 7, 8, true>) : go(sage_wgrad_kernel<32, 7, 8, false>);
+      return;
+    }
+  }
+  launch_wn<TR, 8>(p, a, grid, st);
+}
+
+}  // namespace
+}  // namespace wgamd
+
+extern "C" size_t wgamd_sage_wgrad_workspace_bytes(int64_t n_rows, int F, int N)
+{
+  using namespace wgamd;
+  if (F <= 0 || N <= 0 || F > 256 || N > 256) return 0;
+  const wgrad_plan p = plan_for(F, N);
+  return ((part_bytes(p, max_grid_x(p)) + 255) & ~(size_t)255) + (size_t)std::max<int64_t>(n_rows, 0) * 8 + 256;
+}
+
+extern "C" wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, int64_t ld_agg, const float* x, int64_t ldx, int F,
+                                                            const void* src_ids, wholememory_dtype_t src_ids_dtype,
+                                                            const int64_t* self_rows, int64_t n_rows, const float* grad_out,
+                                                            int64_t ldg, const float* act_out, int64_t ld_act, int N,
+                                                            float* grad_w_l, float* grad_w_r, float* grad_bias, int accumulate,
+                                                            void* workspace, size_t workspace_bytes, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_sage_wgrad_bf16x3", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && F > 0 && N > 0, "bad sizes");
+    if (F % 4 != 0 || F > 256 || N > 256) throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), N=%d (<= 256)", F, N));
+    WG_REQUIRE_INPUT(grad_w_l && grad_w_r && workspace, "null pointer");
+    WG_REQUIRE_INPUT(workspace_bytes >= wgamd_sage_wgrad_workspace_bytes(n_rows, F, N), "workspace too small");
+    auto st = static_cast<hipStream_t>(stream);
+    if (n_rows == 0) {
+      if (!accumulate) {
+        WG_HIP_CHECK(hipMemsetAsync(grad_w_l, 0, (size_t)N * F * 4, st));
+        WG_HIP_CHECK(hipMemsetAsync(grad_w_r, 0, (size_t)N * F * 4, st));
+        if (grad_bias) WG_HIP_CHECK(hipMemsetAsync(grad_bias, 0, (size_t)N * 4, st));
+      }
+      return;
+    }
+    WG_REQUIRE_INPUT(agg && x && self_rows && grad_out, "null pointer");
+    WG_REQUIRE_INPUT(ld_agg >= F && ldx >= F && ldg >= N && (act_out == nullptr || ld_act >= N), "leading dimension too small");
+    if (ld_agg % 4 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(agg) & 15) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
+      throw logic_error("agg / x rows must be 16-B aligned");
+    if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64)
+      throw invalid_input("src_ids must be INT or INT64");
+    const wgrad_plan p = plan_for(F, N);
+    const int cus      = stream_cu_count(st);
+    const int64_t tiles = (n_rows + p.TR - 1) / p.TR;
+    const int grid_x   = (int)std::max<int64_t>(1, std::min<int64_t>({tiles, (int64_t)std::max(1, cus / p.grid_y), (int64_t)max_grid_x(p)}));
+    char* ws           = static_cast<char*>(workspace);
+    ws                 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    float* part        = reinterpret_cast<float*>(ws);
+    const int64_t* self_global = self_rows;
+    if (src_ids != nullptr) {
+      int64_t* composed = reinterpret_cast<int64_t*>(ws + ((part_bytes(p, max_grid_x(p)) + 255) & ~(size_t)255));
+      compose_self_kernel<<<(int)std::min<int64_t>((n_rows + 255) / 256, 4096), 256, 0, st>>>(
+        self_rows, src_ids, src_ids_dtype == WHOLEMEMORY_DT_INT, n_rows, composed);
+      WG_HIP_CHECK(hipGetLastError());
+      self_global = composed;
+    }
+    wgrad_args a{agg, ld_agg, x, ldx, F, self_global, n_rows, grad_out, ldg, act_out, ld_act, N, part,
+                 (tiles + grid_x - 1) / grid_x * p.TR, p.KL};
+    const dim3 grid(grid_x, p.grid_y);
+    if (p.TR == 32) launch_mt<32>(p, a, grid, st);
+    else launch_mt<16>(p, a, grid, st);
+    const int64_t total = (int64_t)(2 * F + 1) * N;
+    wgrad_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(part, grid_x, p.KL, p.NB, F, N, grad_w_l, grad_w_r, grad_bias,
+                                                                     accumulate);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}

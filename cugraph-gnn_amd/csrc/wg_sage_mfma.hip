@@ -390,6 +390,7 @@ sage_layer_mfma_kernel(mfma_args a)
             for (int ct = 0; ct < 2; ct++)
 #pragma unroll
               for (int i = 0; i < 16; i++) c[rt][ct][i] = 0.f;
+          store_agg<TR, CW>(a, lds + ((n - 1) & 1) * tile_dw, row0, wave, lane);
           const float* a_lane = lds + ((n - 1) & 1) * tile_dw + (lane & 31) * a.SD + (lane >> 5) * 8;
           consume_range<RT, 1>(a, c, b, 0, KSh, wave, lane, [&](araw_t<RT>& f, int ks) { load_a_raw<RT>(f, a_lane, a.SD, ks); });
           consume_range<RT, 2>(a, c, b, KSh, a.KS, wave, lane, [&](araw_t<RT>& f, int ks) {
@@ -465,6 +466,7 @@ sage_layer_mfma_kernel(mfma_args a)
         stamp(n, 0);
         if (n >= 1 && !(a.debug & 1)) {
           const float* tile_lds = lds + ((n - 1) & 1) * tile_dw;
+          store_agg<TR, CW>(a, tile_lds, tile_of(n - 1) * TR, wave, lane);
           if (late) {
             if (pending >= 0) cons.store(a, pending, wave, lane, scratch);
             cons.multiply(a, tile_lds, lane);
@@ -480,7 +482,10 @@ sage_layer_mfma_kernel(mfma_args a)
       if (late && pending >= 0) cons.store(a, pending, wave, lane, scratch);
     } else {
       for (int64_t n = 0; n <= mine; n++) {
-        if (n >= 1 && !(a.debug & 1)) consume_tile<TR>(a, tile_of(n - 1), lds + ((n - 1) & 1) * tile_dw, wave, lane, scratch);
+        if (n >= 1 && !(a.debug & 1)) {
+          store_agg<TR, CW>(a, lds + ((n - 1) & 1) * tile_dw, tile_of(n - 1) * TR, wave, lane);
+          consume_tile<TR>(a, tile_of(n - 1), lds + ((n - 1) & 1) * tile_dw, wave, lane, scratch);
+        }
         lds_barrier();
       }
     }
@@ -655,6 +660,17 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row
                                                                   int N, const float* bias, int relu, float* out, int64_t ldo,
                                                                   void* stream)
 {
+  return wgamd_sage_layer_fused_bf16x3_train(row_ptr, col, n_rows, x, ldx, x_rows, F, src_ids, src_ids_dtype, self_rows, mean,
+                                             w_planes, N, bias, relu, out, ldo, nullptr, 0, stream);
+}
+
+extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3_train(const int* row_ptr, const int* col, int64_t n_rows,
+                                                                        const float* x, int64_t ldx, int64_t x_rows, int F,
+                                                                        const void* src_ids, wholememory_dtype_t src_ids_dtype,
+                                                                        const int64_t* self_rows, int mean, const void* w_planes,
+                                                                        int N, const float* bias, int relu, float* out,
+                                                                        int64_t ldo, float* agg_out, int64_t ld_agg, void* stream)
+{
   using namespace wgamd;
   return guarded("wgamd_sage_layer_fused_bf16x3", [&] {
     WG_REQUIRE_INPUT(n_rows >= 0 && F > 0 && N > 0, "bad sizes");
@@ -664,15 +680,18 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row
       throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), N=%d (64, 128 or 256), 16-B aligned rows", F, N));
     WG_REQUIRE_INPUT(ldo >= N, "leading dimension smaller than N");
     if (ldo % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) throw logic_error("output rows must be 16-B aligned");
+    if (agg_out != nullptr && (ld_agg < F || ld_agg % 4 != 0 || (reinterpret_cast<uintptr_t>(agg_out) & 15) != 0))
+      throw logic_error("agg_out rows must hold F floats and be 16-B aligned");
     // x below 2 GB (extent known): 32-bit row offsets and buffer loads whose out-of-range slots read as zero
     const uint64_t xb = x_rows > 0 ? (uint64_t)x_rows * (uint64_t)ldx * 4u : 0;
     mfma_args a{row_ptr, col, n_rows, x, ldx, (uint32_t)(xb > 0 && xb < (1ull << 31) ? xb : 0), F, src_ids, self_rows, mean,
-                static_cast<const float*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr};
+                static_cast<const float*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr,
+                agg_out, ld_agg};
     // WGAMD_SAGE_DEBUG=<bits> (tuning only; results are WRONG with 4 / 8): the ablation switches of mfma_args::debug
     static const int dbg = [] { const char* e = getenv("WGAMD_SAGE_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug = dbg;
     auto st = static_cast<hipStream_t>(stream);
-    if (sage_ws_supported(F, N)) {
+    if (agg_out == nullptr && sage_ws_supported(F, N)) {
       if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64)
         throw invalid_input("src_ids must be INT or INT64");
       return sage_ws_launch(a, src_ids == nullptr ? 0 : (src_ids_dtype == WHOLEMEMORY_DT_INT ? 1 : 2), st);

@@ -57,6 +57,8 @@ struct mfma_args {
                              // 64 roles by SIMD instead of by wave order, 128 no epilogue stagger, 16 / 32 s_setprio 3 for
                              // producers / consumers
   unsigned long long* stamps;  // tuning harness only: s_memtime stamps of workgroup 0, [step][wave][begin, work done]
+  float* agg_out;            // training (nullable): the finished mean / sum rows [n_rows, F] also go to HBM — the weight-gradient
+  int64_t ld_agg;            // kernel (wg_sage_bwd.hip) reads them back instead of fetching every neighbour row a second time
 };
 
 // a == hi + mid + lo exactly; every piece has <= 8 significant bits, i.e. is a bf16 (the top half of the fp32 word)
@@ -585,6 +587,24 @@ __device__ __forceinline__ void epilogue(const mfma_args& a, f32x16 (&c)[RT][2],
         if (full || row0 + r + rl < a.n_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)r * a.ldo) = v;
       }
     }
+}
+
+// Training: the multiplying waves copy the aggregate half of the tile they are about to multiply (complete behind the barrier,
+// scaled) to a.agg_out — wave cw of CW the rows [cw TR / CW, (cw + 1) TR / CW), 16 B per lane.  Nothing else changes: the
+// forward result is bit for bit the one of the inference launch.
+template <int TR, int CW>
+__device__ __forceinline__ void store_agg(const mfma_args& a, const float* tile_lds, int64_t row0, int cw, int lane)
+{
+  if (a.agg_out == nullptr) return;
+  constexpr int kRows = TR / CW;
+  const int q_row = a.F >> 2, total = kRows * q_row;
+  for (int i = lane; i < total; i += 64) {
+    const int r = i / q_row, q = i - r * q_row;
+    const int64_t row = row0 + cw * kRows + r;
+    if (row < a.n_rows)
+      *reinterpret_cast<f32x4*>(a.agg_out + row * a.ld_agg + q * 4) =
+        *reinterpret_cast<const f32x4*>(tile_lds + (cw * kRows + r) * a.SD + q * 4);
+  }
 }
 
 // The same epilogue in eight pieces — piece (rt, g) = the 8 rows 32 rt + 8 g .. + 7 — for a caller that spreads the stores

@@ -243,6 +243,13 @@ SYMBOLS = {
                                            c_void_p]),
     "wgamd_sage_layer_fused_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
                                               c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "wgamd_sage_layer_fused_bf16x3_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
+                                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64,
+                                                    c_void_p, c_int64, c_void_p]),
+    "wgamd_sage_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "wgamd_sage_wgrad_bf16x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p,
+                                        c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                        c_void_p]),
     "wgamd_sage_split_weight_bf16x3": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "wgamd_sage_weight_planes_bytes": (c_size_t, [c_int, c_int]),
     "wgamd_sage_layer_bf16x3_supported": (c_int, [c_int, c_int]),

@@ -154,11 +154,13 @@ def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
 
 
 def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None, out=None,
-                             precision=None):
+                             precision=None, agg_out=None):
     """A whole SAGEConv layer over a sampled hop in ONE kernel: ``act([mean_j X[col_j] | X[self_i]] @ w_t + bias)`` with
     ``X[r] = x[src_ids[r]]`` when ``src_ids`` is given (``x`` is then the global feature table: the feature fetch is fused
     in too).  ``w_t`` = ``cat([W_l, W_r], 1).t()`` ([2F, N], contiguous).  The ``[n_rows, 2F]`` operand never leaves LDS.
-    ``precision``: "bf16x3" (default where the shape allows) or "f32" — see ``_FUSED_PRECISION``."""
+    ``precision``: "bf16x3" (default where the shape allows) or "f32" — see ``_FUSED_PRECISION``.
+    ``agg_out`` ([n_rows, F] fp32, training): the launch also keeps the aggregate half of its operand there
+    (``wgamd_sage_layer_fused_bf16x3_train``; same bits in ``out``) — needs ``sage_layer_train_supported``."""
     _check_csr(row_ptr, col)
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
@@ -193,17 +195,74 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     if (sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3"
             and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):      # its epilogue stores 16 B per lane
         planes = sage_weight_planes(w_t)
+        if agg_out is not None:
+            assert agg_out.shape == (n_rows, F_) and agg_out.dtype == torch.float32 and agg_out.stride(1) == 1
+            L.check(L.lib().wgamd_sage_layer_fused_bf16x3_train(
+                row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
+                self_rows.data_ptr(), int(bool(mean)), planes.data_ptr(), N, None if bias is None else bias.data_ptr(),
+                int(bool(relu)), out.data_ptr(), out.stride(0), agg_out.data_ptr(), agg_out.stride(0), get_stream()),
+                "wgamd_sage_layer_fused_bf16x3_train")
+            return done(out)
         L.check(L.lib().wgamd_sage_layer_fused_bf16x3(
             row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
             self_rows.data_ptr(), int(bool(mean)), planes.data_ptr(), N, None if bias is None else bias.data_ptr(),
             int(bool(relu)), out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_bf16x3")
         return done(out)
+    assert agg_out is None, "agg_out: only the bf16x3 layer kernel keeps the aggregate (sage_layer_train_supported)"
     L.check(L.lib().wgamd_sage_layer_fused_f32(
         row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
         self_rows.data_ptr(),
         int(bool(mean)), w_t.data_ptr(), w_t.stride(0), N, None if bias is None else bias.data_ptr(), int(bool(relu)),
         out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_f32")
     return done(out)
+
+
+def sage_layer_train_supported(F_: int, N: int) -> bool:
+    """Shapes whose one-kernel layer has a backward pass on the HIP kernels: the bf16x3 layer kernel (it is the one that keeps
+    the aggregate for the backward) and ``wgamd_sage_wgrad_bf16x3``."""
+    return (sage_layer_fused_supported(F_, N) and _FUSED_PRECISION == "bf16x3"
+            and bool(L.lib().wgamd_sage_layer_bf16x3_supported(F_, _padded_width(N)))
+            and L.lib().wgamd_sage_wgrad_workspace_bytes(1, F_, N) > 0)
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(n_rows: int, F_: int, N: int, device) -> torch.Tensor:
+    """Scratch of the weight-gradient launches (the workgroups' partial sums + the composed self rows), grown on demand and
+    kept per device: every use is stream-ordered on the caller's stream."""
+    need = L.lib().wgamd_sage_wgrad_workspace_bytes(int(n_rows), F_, N)
+    ws = _WGRAD_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need * 1.15) + 4096, dtype=torch.uint8, device=device)
+        _WGRAD_WS[device] = ws
+    return ws
+
+
+def sage_wgrad(agg, x, self_rows, grad_out, grad_w_l, grad_w_r, grad_bias=None, act_out=None, src_ids=None, accumulate=False):
+    """Weight gradient of the one-kernel SAGE layer over one hop (``wgamd_sage_wgrad_bf16x3``):
+    ``grad_w_l (+)= dZ^T agg``, ``grad_w_r (+)= dZ^T X[self_rows]``, ``grad_bias (+)= sum_i dZ[i]`` with
+    ``dZ = grad_out * (act_out > 0)`` (``act_out`` = the layer's ReLU output, None = no activation) and
+    ``X[r] = x[src_ids[r]]`` when ``src_ids`` is given.  ``grad_w_*`` are [N, F] contiguous fp32."""
+    n, F_ = agg.shape
+    N = grad_out.shape[1]
+    assert agg.dtype == torch.float32 and agg.stride(1) == 1 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] == F_
+    assert grad_out.dtype == torch.float32 and grad_out.stride(1) == 1 and grad_out.shape[0] == n
+    assert self_rows.dtype == torch.int64 and self_rows.is_contiguous() and self_rows.shape[0] == n
+    assert grad_w_l.shape == (N, F_) and grad_w_l.is_contiguous() and grad_w_r.shape == (N, F_) and grad_w_r.is_contiguous()
+    assert act_out is None or (act_out.shape == grad_out.shape and act_out.stride(1) == 1)
+    assert grad_bias is None or (grad_bias.shape == (N,) and grad_bias.is_contiguous())
+    ids_ptr, ids_dt = None, 0
+    if src_ids is not None:
+        assert src_ids.is_contiguous()
+        ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
+    ws = _wgrad_workspace(n, F_, N, agg.device)
+    L.check(L.lib().wgamd_sage_wgrad_bf16x3(
+        agg.data_ptr(), agg.stride(0), x.data_ptr(), x.stride(0), F_, ids_ptr, ids_dt, self_rows.data_ptr(), n,
+        grad_out.data_ptr(), grad_out.stride(0), None if act_out is None else act_out.data_ptr(),
+        0 if act_out is None else act_out.stride(0), N, grad_w_l.data_ptr(), grad_w_r.data_ptr(),
+        None if grad_bias is None else grad_bias.data_ptr(), int(bool(accumulate)), ws.data_ptr(), ws.numel(), get_stream()),
+        "wgamd_sage_wgrad_bf16x3")
 
 
 def _csr_transpose(row_ptr, col, n_src, want_perm=False, want_dst=False, want_col_t=False):
@@ -621,10 +680,29 @@ class HopGraph:
 
     def __init__(self, row_ptr, col, self_rows):
         self.row_ptr, self.col, self.self_rows = row_ptr, col, self_rows
+        self._t = None
 
     @property
     def n_rows(self):
         return int(self.row_ptr.shape[0]) - 1
+
+    def transposed(self, n_src: int):
+        """The hop seen from its ``n_src`` input rows, for the backward pass — computed once per hop and kept, whichever layers
+        and however many backward calls use it: ``(row_ptr_t, col_t, self_t)`` with the source-major CSR of
+        ``wgamd_csr_transpose_i32`` (entries = destination rows, hop order inside a source: deterministic sums) and
+        ``self_t[j]`` = ``n_rows + i`` where input row j is destination i itself (``self_rows`` is injective: every
+        destination is a different vertex of its mini-batch), ``2 n_rows`` otherwise — the row indices ``_sage_dx`` reads its
+        stacked gradient through."""
+        if self._t is None or self._t[0] != n_src:
+            n, dev = self.n_rows, self.row_ptr.device
+            if self.col.shape[0] > 0:
+                row_ptr_t, _, _, col_t = _csr_transpose(self.row_ptr, self.col, n_src, want_col_t=True)
+            else:
+                row_ptr_t, col_t = torch.zeros(n_src + 1, dtype=torch.int32, device=dev), self.col
+            self_t = torch.full((n_src,), 2 * n, dtype=torch.int64, device=dev)
+            self_t[self.self_rows] = torch.arange(n, 2 * n, dtype=torch.int64, device=dev)
+            self._t = (n_src, row_ptr_t, col_t, self_t)
+        return self._t[1:]
 
 
 class LayerGraph:
@@ -637,6 +715,96 @@ class LayerGraph:
     @property
     def n_rows(self):
         return sum(h.n_rows for h in self.hops)
+
+
+def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tensor, w_bwd, mean: bool, n_src: int):
+    """Gradient of one hop of the SAGE layer w.r.t. its input rows:
+    ``dX[j] = sum_{edges (i, j)} dZ[i] W_l / (deg_i if mean) + [j == self(i)] dZ[i] W_r``.
+    This is the one-kernel layer itself run over the TRANSPOSED hop — sum aggregation of the destination gradients an input
+    row feeds, "self" = its own destination's gradient, weight ``[W_l ; W_r]`` — so it runs on the same kernel
+    (``wgamd_sage_layer_fused_*``): the stacked operand ``[dZ / deg ; dZ ; 0]`` is the only tensor built for it.  Shapes
+    that kernel does not take go through the segmented transposed SpMM + library GEMMs."""
+    n, N = gz.shape
+    F_ = w_l.shape[1]
+    Nq = (N + 3) // 4 * 4
+    row_ptr_t, col_t, self_t = hop.transposed(n_src)
+    if w_bwd is not None and sage_layer_fused_supported(Nq, F_) and n > 0:
+        xs = torch.zeros((2 * n + 1, Nq), dtype=torch.float32, device=gz.device)
+        if mean:
+            deg = (hop.row_ptr[1:] - hop.row_ptr[:-1]).clamp_(min=1).unsqueeze(1)
+            torch.div(gz, deg, out=xs[:n, :N])
+        else:
+            xs[:n, :N] = gz
+        xs[n:2 * n, :N] = gz
+        return sage_layer_fused_forward(row_ptr_t, col_t, xs, self_t, w_bwd, None, relu=False, mean=False)
+    gx = spmm_csr_backward(hop.row_ptr, hop.col, gz @ w_l, n_src, mean)
+    return gx.index_add_(0, hop.self_rows, gz @ w_r)
+
+
+class _SageLayer(torch.autograd.Function):
+    """The one-kernel SAGE layer over a ``LayerGraph`` with its backward pass on the HIP kernels.  Forward: the inference
+    launch (``wgamd_sage_layer_fused_bf16x3``), which under autograd also keeps the aggregate half of its operand (same
+    bits in the output).  Backward: ``sage_wgrad`` per hop (ReLU mask folded in when the input needs no gradient) and, when
+    the input rows need a gradient (every layer but the one that reads the features), ``_sage_dx`` over the hop's
+    transpose — computed once per hop (``HopGraph.transposed``)."""
+
+    @staticmethod
+    def forward(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean):
+        N, F_ = w_l.shape
+        Np = _padded_width(N)
+        keep = any(ctx.needs_input_grad[:4])
+        buf = torch.empty((graph.n_rows, Np), dtype=torch.float32, device=src.device)
+        w_t, aggs, at = conv._weight_t(), [], 0
+        for h in graph.hops:
+            n = h.n_rows
+            agg = torch.empty((n, F_), dtype=torch.float32, device=src.device) if keep and n > 0 else None
+            if n > 0:
+                sage_layer_fused_forward(h.row_ptr, h.col, src, h.self_rows, w_t, bias, relu=relu, mean=mean, src_ids=ids,
+                                         out=buf[at:at + n, :N], agg_out=agg)
+            aggs.append(agg)
+            at += n
+        out = buf[:, :N]
+        if keep:
+            if ctx.needs_input_grad[0] and ids is not None:
+                raise NotImplementedError("gradient w.r.t. a feature table read through ids (LazyRows): trainable node "
+                                          "embeddings go through wholegraph_amd.embedding")
+            ctx.save_for_backward(src, w_l, w_r, out)
+            ctx.conv, ctx.graph, ctx.ids, ctx.relu, ctx.mean, ctx.aggs, ctx.has_bias = conv, graph, ids, relu, mean, aggs, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, w_l, w_r, out = ctx.saved_tensors
+        graph, ids, relu, mean = ctx.graph, ctx.ids, ctx.relu, ctx.mean
+        N, F_ = w_l.shape
+        need_x = ctx.needs_input_grad[0]
+        if g.stride(1) != 1 or g.dtype != torch.float32:
+            g = g.contiguous().float()
+        act = out if relu else None
+        if relu and need_x:
+            g, act = torch.ops.aten.threshold_backward(g, out, 0), None      # dZ once, read by both gradients
+        gwl, gwr = torch.empty_like(w_l, memory_format=torch.contiguous_format), torch.empty_like(w_r, memory_format=torch.contiguous_format)
+        gb = torch.empty(N, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+        w_bwd = ctx.conv._weight_bwd() if need_x else None
+        gx, at, first = None, 0, True
+        for h, agg in zip(graph.hops, ctx.aggs):
+            n = h.n_rows
+            if n > 0:
+                sage_wgrad(agg, src, h.self_rows, g[at:at + n], gwl, gwr, gb, None if act is None else act[at:at + n],
+                           src_ids=ids, accumulate=not first)
+                first = False
+                if need_x:
+                    gh = _sage_dx(h, g[at:at + n], w_l, w_r, w_bwd, mean, src.shape[0])
+                    gx = gh if gx is None else gx.add_(gh)
+            at += n
+        if first:
+            gwl.zero_(), gwr.zero_()
+            if gb is not None:
+                gb.zero_()
+        if need_x and gx is None:
+            gx = torch.zeros_like(src)
+        ctx.aggs = None
+        return gx, gwl, gwr, gb, None, None, None, None, None
 
 
 class SAGEConv(torch.nn.Module):
@@ -655,7 +823,22 @@ class SAGEConv(torch.nn.Module):
         self.in_channels, self.out_channels, self.aggr, self.root_weight = in_channels, out_channels, aggr, root_weight
         self.lin_l = torch.nn.Linear(in_channels[0], out_channels, bias=bias)
         self.lin_r = torch.nn.Linear(in_channels[1], out_channels, bias=False) if root_weight else None
-        self._w_t = None
+        self._w_t = self._w_bwd = None
+
+    def _weight_bwd(self):
+        """``[W_l ; W_r]`` ([2 Nq, F], Nq = N rounded up to 4, zero rows between) — the weight of the layer kernel when it runs
+        the input gradient over the transposed hop (``_sage_dx``); None when that kernel does not take the shape."""
+        wl, wr = self.lin_l.weight, self.lin_r.weight
+        N, F_ = wl.shape
+        Nq = (N + 3) // 4 * 4
+        if not sage_layer_fused_supported(Nq, F_):
+            return None
+        key = (wl._version, wl.data_ptr(), wr._version, wr.data_ptr())
+        if self._w_bwd is None or self._w_bwd[0] != key:
+            w = torch.zeros((2 * Nq, F_), dtype=torch.float32, device=wl.device)
+            w[:N], w[Nq:Nq + N] = wl.detach(), wr.detach()
+            self._w_bwd = (key, w)
+        return self._w_bwd[1]
 
     def _weight_t(self):
         """``cat([W_l, W_r], 1).t()`` ([2F, N]) for the one-kernel layer, rebuilt when a weight changed."""
@@ -672,29 +855,26 @@ class SAGEConv(torch.nn.Module):
         relu = act == "relu"
         assert act in (None, "relu"), "act: None or 'relu'"
         one_kernel = (self.lin_r is not None and self.aggr in ("mean", "sum") and src.dtype == torch.float32 and src.is_cuda
-                      and not torch.is_grad_enabled() and sage_layer_fused_preferred(F_, N))
-        if not one_kernel:
-            # aggregation kernel(s) + library GEMM: every hop's [mean | self] rows, then lin_l / lin_r as torch modules
-            xd = x.materialize() if lazy else x
-            outs = []
-            for h in graph.hops:
-                agg = spmm_csr(xd, h.row_ptr, h.col, self.aggr)
-                o = self.lin_l(agg)
-                if self.lin_r is not None:
-                    o = o + self.lin_r(xd[h.self_rows])
-                outs.append(o)
-            out = outs[0] if len(outs) == 1 else torch.cat(outs)
-            return torch.relu_(out) if relu else out
-        Np = _padded_width(N)
-        buf = torch.empty((graph.n_rows, Np), dtype=torch.float32, device=src.device)
-        w_t, at = self._weight_t(), 0
+                      and src.stride(1) == 1 and sage_layer_fused_preferred(F_, N))
+        if one_kernel and not sage_layer_train_supported(F_, N):
+            # (a shape only the fp32-MFMA layer kernel takes has no backward kernels: under autograd it runs as aggregation
+            #  kernel + library GEMM, whose autograd pieces exist for every shape)
+            one_kernel = not (torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                           or (not lazy and x.requires_grad)))
+        if one_kernel:
+            return _SageLayer.apply(src, self.lin_l.weight, self.lin_r.weight, self.lin_l.bias, self, graph,
+                                    x.ids if lazy else None, relu, self.aggr == "mean")
+        # aggregation kernel(s) + library GEMM: every hop's [mean | self] rows, then lin_l / lin_r as torch modules
+        xd = x.materialize() if lazy else x
+        outs = []
         for h in graph.hops:
-            n = h.n_rows
-            if n > 0:
-                sage_layer_fused_forward(h.row_ptr, h.col, src, h.self_rows, w_t, self.lin_l.bias, relu=relu,
-                                         mean=self.aggr == "mean", src_ids=x.ids if lazy else None, out=buf[at:at + n, :N])
-            at += n
-        return buf[:, :N]
+            agg = spmm_csr(xd, h.row_ptr, h.col, self.aggr)
+            o = self.lin_l(agg)
+            if self.lin_r is not None:
+                o = o + self.lin_r(xd[h.self_rows])
+            outs.append(o)
+        out = outs[0] if len(outs) == 1 else torch.cat(outs)
+        return torch.relu_(out) if relu else out
 
     def forward(self, x, graph, act=None):
         if isinstance(graph, LayerGraph):
@@ -703,11 +883,13 @@ class SAGEConv(torch.nn.Module):
             x = x.materialize()
         x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
         row_ptr, col = _split_graph(graph, x_dst.shape[0])
-        if (x_src is x_dst and not torch.is_grad_enabled() and x_src.is_cuda and x_src.dtype == torch.float32
+        # ((x, x_target) with x_target = x[:n], the reference's call shape gnn_model.py:178-199: the same rows)
+        same = x_src is x_dst or (x_dst.data_ptr() == x_src.data_ptr() and x_dst.stride() == x_src.stride())
+        if (same and x_src.is_cuda and x_src.dtype == torch.float32
                 and self.lin_r is not None and self.aggr in ("mean", "sum") and act in (None, "relu")
                 and x_src.stride(1) == 1 and sage_layer_fused_preferred(x_src.shape[1], self.out_channels)):
-            # inference over one sampled (sub)graph whose destinations are the first rows of x: the whole layer as ONE kernel
-            # (no library GEMM — whose shape heuristics alone cost ~1 ms for every new row count a mini-batch brings)
+            # one sampled (sub)graph whose destinations are the first rows of x: the whole layer as ONE kernel, forward and
+            # backward (no library GEMM — whose shape heuristics alone cost ~1 ms for every new row count a mini-batch brings)
             n = row_ptr.shape[0] - 1
             hop = HopGraph(row_ptr, col, torch.arange(n, dtype=torch.int64, device=x_src.device))
             return self._forward_layer(x_src, LayerGraph([hop]), act)

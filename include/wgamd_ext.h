@@ -512,6 +512,40 @@ wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const
                                                        const void* w_planes, int N, const float* bias, int relu, float* out,
                                                        int64_t ldo, void* stream);
 
+/* ---- training: the one-kernel layer's forward with the aggregate kept, and its weight gradient ------------------------------
+ * The reference's models train (python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:25-59,119-125; every example ends in
+ * loss.backward()): these two entry points are what the autograd.Function of wholegraph_amd.nn binds.
+ *
+ * wgamd_sage_layer_fused_bf16x3_train: wgamd_sage_layer_fused_bf16x3 (same launch, same bits in `out`) that also writes the
+ * aggregate half of its operand, agg_out[i, 0:F] = mean|sum_{e in row i} X[col[e]] (fp32, ld_agg >= F floats, rows 16-B
+ * aligned; NULL = not kept): n_rows F 4 bytes written once instead of E F 4 bytes of neighbour rows fetched again in the
+ * backward pass. */
+wholememory_error_code_t wgamd_sage_layer_fused_bf16x3_train(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                             int64_t ldx, int64_t x_rows, int F, const void* src_ids,
+                                                             wholememory_dtype_t src_ids_dtype, const int64_t* self_rows,
+                                                             int mean, const void* w_planes, int N, const float* bias, int relu,
+                                                             float* out, int64_t ldo, float* agg_out, int64_t ld_agg,
+                                                             void* stream);
+
+/* Weight gradient of the layer  out = act([agg | X[self_rows]] @ [W_l | W_r]^T + b)  over one hop (csrc/wg_sage_bwd.hip):
+ *   dZ[i, :]      = grad_out[i, :]  where  act_out == NULL or act_out[i, :] > 0,  else 0        (ReLU mask folded in)
+ *   grad_w_l[n,f] (+)= sum_i dZ[i, n] agg[i, f]          grad_w_r[n,f] (+)= sum_i dZ[i, n] X[self_rows[i], f]
+ *   grad_bias[n]  (+)= sum_i dZ[i, n]                                                           (nullable)
+ * X[r] = x[src_ids ? src_ids[r] : r] as in the forward; grad_w_l / grad_w_r are [N, F] row-major contiguous (the layout of
+ * torch.nn.Linear.weight); accumulate != 0 adds to what they hold (a layer that ran over several hops).  A split-K product on
+ * the bf16 matrix pipe at fp32 accuracy (the exact 3-way split of the forward, six products per term, fp32 accumulate): every
+ * workgroup owns a contiguous range of rows, keeps its [2F, N] partial sum in registers and writes it once; the partial sums
+ * are added in workgroup order by a second launch — no atomics, the same bits from run to run.
+ * Shapes: F % 4 == 0, F <= 256, N <= 256; x / agg rows 16-B aligned.  workspace: wgamd_sage_wgrad_workspace_bytes(n_rows, F, N)
+ * bytes of device scratch (0 = shape not supported). */
+size_t wgamd_sage_wgrad_workspace_bytes(int64_t n_rows, int F, int N);
+wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, int64_t ld_agg, const float* x, int64_t ldx, int F,
+                                                 const void* src_ids, wholememory_dtype_t src_ids_dtype,
+                                                 const int64_t* self_rows, int64_t n_rows, const float* grad_out, int64_t ldg,
+                                                 const float* act_out, int64_t ld_act, int N, float* grad_w_l,
+                                                 float* grad_w_r, float* grad_bias, int accumulate, void* workspace,
+                                                 size_t workspace_bytes, void* stream);
+
 /* Biased (A-Res) sampling, fan-out <= 32: how wholegraph_csr_weighted_sample_without_replacement and the biased call-group
  * hop find the M largest keys.  pruning = 1 (default; env WGAMD_WEIGHTED_PRUNING=0 turns it off): a cheap lower bound of
  * every |key| first, exact keys (log1pf, two divisions) only for the candidates that can still reach the M-th largest one —
