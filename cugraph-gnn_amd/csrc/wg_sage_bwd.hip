@@ -88,14 +88,27 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
       idx_next[j]       = a.self_global[row < r_end ? row : r_begin];
     }
   };
+  // Tile rows are read as RAW BUFFER loads: the descriptor is the tile (wave-uniform base, rows that exist as its extent),
+  // the lane part of the address is one 32-bit register fixed for the whole launch — one VALU add per load, and a row past
+  // the end of the matrix reads as zero without a select (64-bit per-load addresses made the compiler keep 32 pointers live
+  // and spill them).
+  auto tile_rsrc = [&](const float* base, int64_t ld, int64_t row0) {
+    const int64_t rows = min((int64_t)TR, a.n_rows - row0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + row0 * ld), 0, (int)(rows * ld * 4), 0x00020000);
+  };
+  const uint32_t agg_lane = ((uint32_t)(rg * 4) * (uint32_t)a.ld_agg + (uint32_t)q * 4u) * 4u;   // bytes
   auto load_stage = [&](int64_t tile) {
     if (!stage) return;
+    if (self_half) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int64_t row  = r_begin + tile * TR + rg * 4 + j;
-      const int64_t rowc = row < r_end ? row : r_begin;
-      const float* p     = self_half ? a.x + idx_next[j] * a.ldx + (q - FQ) * 4 : a.agg + rowc * a.ld_agg + q * 4;
-      st[j]              = *reinterpret_cast<const f32x4*>(p);
+      for (int j = 0; j < 4; j++) st[j] = *reinterpret_cast<const f32x4*>(a.x + idx_next[j] * a.ldx + (q - FQ) * 4);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(a.agg, a.ld_agg, r_begin + tile * TR);
+      uint32_t al = agg_lane;
+      asm volatile("" : "+v"(al));
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, al + (uint32_t)(j * 4) * (uint32_t)a.ld_agg, 0, 0));
     }
   };
   auto store_stage = [&](int64_t tile, uint16_t* buf) {
@@ -125,27 +138,38 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
   float zr[KS][8], zm[KS][8];
   u32x4 zf[KS][3];
   float bsum = 0.f;
+  const uint32_t g_lane = ((uint32_t)(lh * 8) * (uint32_t)a.ldg + (uint32_t)colc) * 4u;      // bytes
+  const uint32_t m_lane = ((uint32_t)(lh * 8) * (uint32_t)a.ld_act + (uint32_t)colc) * 4u;
   auto load_z = [&](int64_t tile) {
     if (!z_wave) return;
+    const __amdgpu_buffer_rsrc_t rg_ = tile_rsrc(a.g, a.ldg, r_begin + tile * TR);
+    // (opaque to the optimiser: the 16 + 16 per-load offsets are then one add each per tile, not 32 registers kept live
+    //  across the whole loop next to 112 accumulators)
+    uint32_t gl = g_lane, ml = m_lane;
+    asm volatile("" : "+v"(gl), "+v"(ml));
 #pragma unroll
     for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int64_t row  = r_begin + tile * TR + ks * 16 + lh * 8 + j;
-        const int64_t rowc = row < r_end ? row : r_begin;
-        zr[ks][j]          = a.g[rowc * a.ldg + colc];
-        if constexpr (MASK) zm[ks][j] = a.act[rowc * a.ld_act + colc];
-        else zm[ks][j] = 1.f;
-      }
+      for (int j = 0; j < 8; j++)
+        zr[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg_, gl + (uint32_t)((ks * 16 + j) * 4) * (uint32_t)a.ldg, 0, 0));
+    if constexpr (MASK) {
+      const __amdgpu_buffer_rsrc_t rm_ = tile_rsrc(a.act, a.ld_act, r_begin + tile * TR);
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          zm[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm_, ml + (uint32_t)((ks * 16 + j) * 4) * (uint32_t)a.ld_act, 0, 0));
+    }
   };
   auto split_z = [&](int64_t tile) {
     if (!z_wave) return;
+    const int lim = (int)min((int64_t)TR, r_end - (r_begin + tile * TR)) - lh * 8;   // rows of this lane's half inside the block
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       uint32_t h[8], m[8], l[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const bool ok = col_ok && r_begin + tile * TR + ks * 16 + lh * 8 + j < r_end && (!MASK || zm[ks][j] > 0.f);
+        const bool ok = col_ok && ks * 16 + j < lim && (!MASK || zm[ks][j] > 0.f);
         const float v = ok ? zr[ks][j] : 0.f;
         if (wm == 0) bsum += v;
         split3(v, h[j], m[j], l[j]);
@@ -173,7 +197,7 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
     load_idx(1);
     store_stage(0, planes);
     split_z(0);
-    __syncthreads();
+    lds_barrier();
     for (int64_t tile = 0; tile < n_tiles; tile++) {
       const bool more = tile + 1 < n_tiles;
       if (more) {
@@ -202,7 +226,7 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
         store_stage(tile + 1, planes + ((tile + 1) & 1) * kBuf);
         split_z(tile + 1);
       }
-      __syncthreads();
+      lds_barrier();   // (LDS-only wait: the row ids requested for tile + 2 stay in flight)
     }
   }
 
