@@ -743,11 +743,48 @@ def filter_store(feature_store, graph_store, node, row, col, edge) -> Data:
 _GROUP_FETCH_BYTES = 4 << 30
 
 
+class _GroupRowsPool:
+    """Buffers for the rows a call group fetches (``x = feat[n_id]`` of 191 mini-batches is 4.4 GB on the products workload and
+    its size changes by a per cent from group to group: a fresh block from the caching allocator per group is a
+    hipMalloc / hipFree pair in the middle of the epoch — 11 of the 15 ms such a group took).  A buffer only ever grows (12 %
+    steps) and is handed out again once NOTHING refers to its storage any more — neither the tensor that was returned, nor a
+    view of it, nor a tensor autograd saved: the storage's own use count says so, the caller releases nothing."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    @staticmethod
+    def _idle(buf):
+        return torch._C._storage_Use_Count(buf.untyped_storage()._cdata) <= 2     # the pool's tensor + this query's handle
+
+    def take(self, shape, dtype, device):
+        nbytes = torch.empty((), dtype=dtype).element_size()
+        for d in shape:
+            nbytes *= int(d)
+        bufs = self._bufs.setdefault(torch.device(device), [])
+        idle = [b for b in bufs if self._idle(b)]
+        fit = [b for b in idle if b.numel() >= nbytes]
+        if fit:
+            buf = min(fit, key=lambda b: b.numel())
+        else:
+            for b in idle:          # too small for this workload's groups: back to the allocator
+                bufs.remove(b)
+            buf = torch.empty(int(nbytes * 1.12) + (1 << 20), dtype=torch.uint8, device=device)
+            bufs.append(buf)
+        return buf[:nbytes].view(dtype).view(tuple(int(d) for d in shape))
+
+    def clear(self):
+        self._bufs.clear()
+
+
+_group_rows = _GroupRowsPool()
+
+
 def _fetch_rows_agreed(t, index):
-    """``t[index]`` for a whole call group, in pieces of at most _GROUP_FETCH_BYTES.  With a multi-rank tensor every
-    ``t[...]`` is a collective, so the NUMBER of pieces must be the same on every rank of the tensor's group: it is
-    MAX-reduced over that group first (ranks see different frontier sizes; a per-rank decision would pair one fetch on rank
-    A with several on rank B and hang or mis-route rows).  Single-rank tensors decide locally."""
+    """``t[index]`` for a whole call group, in pieces of at most _GROUP_FETCH_BYTES, into a buffer of ``_group_rows``.  With a
+    multi-rank tensor every ``t[...]`` is a collective, so the NUMBER of pieces must be the same on every rank of the
+    tensor's group: it is MAX-reduced over that group first (ranks see different frontier sizes; a per-rank decision would
+    pair one fetch on rank A with several on rank B and hang or mis-route rows).  Single-rank tensors decide locally."""
     import torch.distributed as dist
     row_bytes = torch.empty((), dtype=t.dtype).element_size()
     for d in tuple(t.shape)[1:]:
@@ -759,17 +796,17 @@ def _fetch_rows_agreed(t, index):
         worst = torch.tensor([pieces], dtype=torch.int64, device=dev)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
         pieces = int(worst.item())
-    if pieces == 1:
-        return t[index]
-    # ONE output for the whole group, filled piece by piece: a torch.cat of the pieces would hold the group's rows twice
-    parts = torch.tensor_split(index, pieces)
-    if hasattr(t, "gather_into"):
-        out = torch.empty((int(index.numel()),) + tuple(t.shape)[1:], dtype=t.dtype, device=index.device)
+    if hasattr(t, "gather_into") and index.is_cuda:
+        # ONE output for the whole group, filled piece by piece (a torch.cat of pieces would hold the group's rows twice)
+        out = _group_rows.take((int(index.numel()),) + tuple(t.shape)[1:], t.dtype, index.device)
         at = 0
-        for part in parts:
+        for part in ([index] if pieces == 1 else torch.tensor_split(index, pieces)):
             t.gather_into(part, out[at:at + part.numel()])
             at += part.numel()
         return out
+    if pieces == 1:
+        return t[index]
+    parts = torch.tensor_split(index, pieces)
     first = t[parts[0]]
     out = torch.empty((int(index.numel()),) + tuple(first.shape)[1:], dtype=first.dtype, device=first.device)
     out[:parts[0].numel()] = first
@@ -814,7 +851,7 @@ def filter_store_from_group(feature_store, views, j, node, row, col, edge) -> Da
     data.edge_index = torch.stack([row, col], dim=0)
     # a call-group walk emits hop after hop, a hop's edges in the CSR order of its frontier, every hop's destinations behind
     # the previous hop's: destination-major (wholegraph_amd.nn._to_csr then skips its sort)
-    data.edge_index._wgamd_dst_sorted = True
+    data.edge_index._wgamd_dst_sorted = data.edge_index._version     # (nn._to_csr: valid while the tensor is not edited in place)
     for attr in feature_store.get_all_tensor_attrs():
         is_edge = isinstance(attr.group_name, tuple)
         v = views[attr.group_name, attr.attr_name]

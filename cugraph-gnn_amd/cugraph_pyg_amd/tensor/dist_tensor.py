@@ -8,8 +8,12 @@ node-local range partition + RCCL all-to-all otherwise (also runs over gloo for 
 is the reference's host-pinned placement (dist_tensor.py:60-75: pinned host memory the GPU reads through UVA) — the rows live
 in PINNED HOST memory and the same HIP row kernels read and write them in place over PCIe (for tables that outgrow HBM;
 on a box without a GPU it is plain host memory).  ``backend`` ("vmm" / "nccl" / "nvshmem" / "chunked") is accepted,
-remembered and reported back, but does not select a memory type; ``DistEmbedding`` takes ``cache_policy=None`` /
-``round_robin_size=0`` only."""
+remembered and reported back, but does not select a memory type.  ``DistEmbedding(cache_policy=...)`` forwards the policy to
+``wholegraph_amd.embedding.create_embedding`` like the reference (dist_tensor.py:385-399): the table is then a handle of the HIP
+library (device or pinned-host partitions) behind its READONLY / READWRITE device cache.
+
+Pinned-host placement and the stream: the row kernels write the pinned tensor on the current HIP stream; every method that
+hands the host memory out, or copies into it from the host, waits for that stream first."""
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -116,6 +120,7 @@ class DistTensor:
         local, start = self._tensor.get_local_tensor()
         if tuple(tensor.shape) != tuple(self._tensor.shape):
             raise ValueError("The shape of the tensor does not match the shape of the distributed tensor.")
+        self._host_fence()
         local.copy_(tensor[start:start + local.shape[0]].to(local.dtype))
 
     def load_from_local_tensor(self, tensor):
@@ -127,6 +132,7 @@ class DistTensor:
             raise ValueError("The shape of the tensor does not match the shape of the local tensor.")
         if self.dtype != tensor.dtype:
             raise ValueError("The dtype of the tensor does not match the dtype of the local tensor.")
+        self._host_fence()
         local.copy_(tensor)
 
     @classmethod
@@ -171,7 +177,15 @@ class DistTensor:
             val = val.view((-1,) + tuple(self._tensor.shape[1:]))
         self._tensor.scatter(val.contiguous(), idx)
 
+    def _host_fence(self):
+        """Pinned-host rows are written by kernels queued on the current stream (``__setitem__``) and read or copied by the
+        HOST here: wait for the stream, or a host read sees rows from before a scatter and a host copy races a queued
+        kernel.  (Rows in HBM need nothing: torch orders every access on the stream.)"""
+        if self._host_rows and torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+
     def get_local_tensor(self, host_view=False):
+        self._host_fence()
         return self._tensor.get_local_tensor(host_view)[0]
 
     def get_local_offset(self):
@@ -213,11 +227,94 @@ class DistEmbedding(DistTensor):
     def __init__(self, src=None, shape=None, dtype=None, device: Optional[str] = "cuda", partition_book=None,
                  backend: Optional[str] = "nccl", cache_policy=None, gather_sms: Optional[int] = -1,
                  round_robin_size: int = 0, name: Optional[str] = None, **kwargs):
-        if cache_policy is not None:
-            raise NotImplementedError("cache policies do not exist on this target (every table lives in HBM)")
         self._name = name
         self._gather_sms = gather_sms
-        super().__init__(src, shape, dtype, device, partition_book, backend, round_robin_size=round_robin_size, **kwargs)
+        self._embedding = None
+        if cache_policy is None:
+            super().__init__(src, shape, dtype, device, partition_book, backend, round_robin_size=round_robin_size, **kwargs)
+            return
+        # A cached embedding is a handle of the HIP library (reference dist_tensor.py:385-399 hands the policy to
+        # create_wg_dist_tensor -> pylibwholegraph create_embedding, tensor/utils.py:21-93): partitions in HBM or pinned host
+        # memory, lookups through the policy's device cache, writes as scatters into the table.
+        from wholegraph_amd import embedding as wge
+        from wholegraph_amd.comm import get_global_communicator
+        if not torch.cuda.is_available():
+            raise RuntimeError("DistEmbedding(cache_policy=...) needs the HIP library's communicator (a GPU)")
+        self._tensor, self._requested_device, self._backend, self._group = None, device, backend, kwargs.get("group")
+        self._host_rows = False        # (the library owns the placement; indices and results live on the GPU)
+        self._local_ops, self._book, self._offsets_arg = None, partition_book, None
+        host = None
+        if isinstance(src, (list, tuple)):
+            if shape is None or dtype is None:
+                raise ValueError("For now, reading from multiple files is only supported with binary format.")
+        elif src is not None:
+            if isinstance(src, torch.Tensor):
+                host = src
+            elif isinstance(src, str) and src.endswith(".pt"):
+                host = torch.load(src, mmap=True)
+            elif isinstance(src, str) and src.endswith(".npy"):
+                host = torch.from_numpy(np.load(src, mmap_mode="c"))
+            else:
+                raise ValueError("Unsupported source type. Please provide a torch.Tensor, a file path, or a list of file paths.")
+            shape, dtype = tuple(host.shape), host.dtype
+        if shape is None or dtype is None:
+            raise ValueError("Please specify the shape and dtype of the embedding.")
+        if len(shape) != 2:
+            raise ValueError("an embedding is a 2-D table")
+        memory_type = "chunked" if backend in ("vmm", "chunked") else "distributed"
+        location = "cpu" if str(device).startswith("cpu") else "cuda"
+        self._embedding = wge.create_embedding(get_global_communicator(), memory_type, location, dtype, list(shape),
+                                               cache_policy=cache_policy, embedding_entry_partition=partition_book,
+                                               gather_sms=-1 if gather_sms is None else int(gather_sms),
+                                               round_robin_size=int(round_robin_size or 0))
+        self._tensor = self._embedding.get_embedding_tensor()
+        self._dtype = dtype
+        if isinstance(src, (list, tuple)):
+            self._tensor.from_filelist(list(src), int(round_robin_size or 0))
+        elif host is not None:
+            local, start = self._tensor.get_local_tensor()
+            local.copy_(host[start:start + local.shape[0]].to(local.dtype))
+            if torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
+
+    def __getitem__(self, idx) -> torch.Tensor:
+        if self._embedding is None:
+            return super().__getitem__(idx)
+        return self._embedding.gather(self._idx(idx))          # through the policy's cache
+
+    def gather_into(self, idx, out: torch.Tensor) -> torch.Tensor:
+        if self._embedding is None:
+            return super().gather_into(idx, out)
+        out.copy_(self._embedding.gather(self._idx(idx)).view(out.shape))
+        return out
+
+    def __setitem__(self, idx, val: torch.Tensor):
+        if self._embedding is None:
+            return super().__setitem__(idx, val)
+        idx = self._idx(idx)
+        self._embedding.get_embedding_tensor().scatter(val.to(device=idx.device, dtype=self.dtype).contiguous(), idx)
+        if self._embedding.wmb_cache_policy is not None:
+            self._embedding.drop_all_cache()                   # resident lines must not shadow the rows just written
+
+    def _idx(self, idx):
+        if self._embedding is None:
+            return super()._idx(idx)
+        if isinstance(idx, slice):
+            idx = torch.arange(*idx.indices(self._tensor.shape[0]))
+        idx = torch.as_tensor(idx)
+        if idx.dtype not in (torch.int32, torch.int64):
+            idx = idx.long()
+        return idx.cuda().contiguous().view(-1)
+
+    def get_local_tensor(self, host_view=False):
+        if self._embedding is None:
+            return super().get_local_tensor(host_view)
+        return self._tensor.get_local_tensor(host_view)[0]
+
+    def get_local_offset(self):
+        if self._embedding is None:
+            return super().get_local_offset()
+        return self._tensor.get_local_tensor()[1]
 
     @classmethod
     def from_tensor(cls, tensor, device: Optional[str] = "cuda", partition_book=None, name: Optional[str] = None,

@@ -300,15 +300,30 @@ class WholeMemoryEmbedding:
         for name in self.get_optimizer_state_names():
             yield name, self.get_optimizer_state(name)
 
+    def _readwrite_cache(self) -> bool:
+        return self.wmb_cache_policy is not None and self.wmb_cache_policy.access_type == "readwrite"
+
     def save(self, file_prefix: str):
+        """(A READWRITE cache holds the newest rows and optimizer states in its dirty lines: they are written back first, or
+        the files would hold rows from before the last steps.)"""
+        if self._readwrite_cache():
+            self.writeback_all_cache()
         for suffix, tensor in self._parts():
             tensor.to_file_prefix(f"{file_prefix}_{suffix}")
 
     def load(self, file_prefix: str, *, ignore_embedding: bool = False, part_count: Optional[int] = None):
+        """(Resident cache lines would shadow the loaded rows, and dirty ones overwrite them at the next write-back: the cache
+        is written back and emptied before the load and emptied again after it.)"""
+        if self.wmb_cache_policy is not None:
+            if self._readwrite_cache():
+                self.writeback_all_cache()
+            self.drop_all_cache()
         for suffix, tensor in self._parts():
             if suffix == "embedding_tensor" and ignore_embedding:
                 continue
             tensor.from_file_prefix(f"{file_prefix}_{suffix}", part_count)
+        if self.wmb_cache_policy is not None:
+            self.drop_all_cache()
 
     def _release_views(self):
         for tensor in self._views.values():

@@ -596,7 +596,9 @@ def _to_csr(edge_index, n_dst):
     destination).  int64 ids on the device go through ``wgamd_coo_to_csr_i64`` (one radix sort over the bits a destination
     id needs); anything else through the torch formulation of the same."""
     src, dst = edge_index[0], edge_index[1]
-    if getattr(edge_index, "_wgamd_dst_sorted", False) and edge_index.is_cuda:
+    # (the flag is the tensor's version counter at the time the loader vouched for the order: an in-place edit of the
+    #  edge list afterwards — a permutation, self loops written into the same storage — bumps the counter and the sort runs)
+    if getattr(edge_index, "_wgamd_dst_sorted", None) == edge_index._version and edge_index.is_cuda:
         # the loaders' own edge lists are destination-major already (hop after hop, a hop's edges in the CSR order of its
         # frontier, every hop's destinations after the previous hop's): the CSR is a search for the run boundaries and a cast
         # — no sort (0.77 ms per 88 k-edge mini-batch through the radix sort below, most of it launch latency)

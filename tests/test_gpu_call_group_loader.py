@@ -173,10 +173,17 @@ def test_per_batch_loop_takes_the_sorted_edge_list_and_the_one_kernel_layer(hipl
     n = 0
     for batch in loader:
         ei = batch.edge_index
-        assert getattr(ei, "_wgamd_dst_sorted", False) and bool((ei[1][1:] >= ei[1][:-1]).all())
+        assert getattr(ei, "_wgamd_dst_sorted", None) == ei._version and bool((ei[1][1:] >= ei[1][:-1]).all())
         fast = nn._to_csr(ei, batch.x.shape[0])
         slow = nn._to_csr(ei.clone(), batch.x.shape[0])              # a plain tensor: the radix-sort route (stable)
         assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+        if n == 0:      # an in-place edit of the edge list voids the loader's "destination-sorted" promise
+            ej = ei.clone()
+            ej._wgamd_dst_sorted = ej._version
+            ej[:, :ej.shape[1] // 2] = ej[:, :ej.shape[1] // 2].flip(1)      # no longer sorted by destination
+            assert ej._wgamd_dst_sorted != ej._version
+            redo, ref = nn._to_csr(ej, batch.x.shape[0]), nn._to_csr(ej.clone(), batch.x.shape[0])
+            assert torch.equal(redo[0], ref[0]) and torch.equal(redo[1], ref[1])
         with torch.no_grad():
             h = convs[0](batch.x, ei, act="relu")
             out = convs[1](h, ei)[:batch.batch_size]
@@ -229,3 +236,26 @@ def test_call_groups_over_host_pinned_features_equal_the_hbm_placement():
         outs[loc] = res
     assert len(outs["cpu"]) == len(outs["cuda"]) > 0
     assert all(torch.equal(a, b) for a, b in zip(outs["cuda"], outs["cpu"]))
+
+
+def test_group_rows_pool_reuses_a_buffer_only_when_nothing_refers_to_it():
+    """The materialised ``x = feat[n_id]`` of a call group comes from a grow-only pool (no hipMalloc per group): a buffer is
+    handed out again only when neither the returned tensor, nor a view of it, nor anything autograd saved is alive."""
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from cugraph_pyg_amd.sampler import sampler as smp
+    gs, fs, feat = _stores(5000, 12, 100)
+    smp._group_rows.clear()
+    loader = NeighborLoader((fs, gs), [10, 5], input_nodes=torch.arange(5000)[:1280], batch_size=128, local_seeds_per_call=256,
+                            random_state=9)
+    ptrs, kept = [], None
+    for k, grp in enumerate(loader.call_groups()):
+        x = grp.node_attr("x", lazy=False)
+        assert torch.equal(x, feat.cuda()[grp.n_id])
+        ptrs.append(x.untyped_storage().data_ptr())
+        if k == 1:
+            kept = x[5:7]             # a VIEW kept alive: its buffer must not come back
+        del x
+    assert len(ptrs) == 5 and ptrs[0] == ptrs[1], ptrs              # released -> reused
+    assert ptrs[2] != ptrs[1] and ptrs[3] not in (ptrs[1],) and ptrs[4] not in (ptrs[1],), ptrs
+    assert kept is not None and torch.equal(kept.cpu(), feat[list(loader.call_groups())[1].n_id.cpu()][5:7])

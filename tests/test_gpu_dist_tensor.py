@@ -77,12 +77,62 @@ def test_dist_tensor_invalid_cases():
     for kwargs in (dict(shape=[1, 2, 3], dtype=torch.float32), dict(), dict(src="invalid.txt"), dict(shape=[4])):
         with pytest.raises(ValueError):
             DistTensor(**kwargs)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception):      # a policy that is not one of wholegraph_amd's is refused by create_embedding
         DistEmbedding(shape=[4, 4], dtype=torch.float32, cache_policy=object())
     t = DistTensor(shape=[5], dtype=torch.int64)
     assert "DistTensor(" in repr(t) and t.dim == 1
     t[torch.arange(5)] = torch.arange(5) * 2
     assert t[torch.tensor([4, 0])].tolist() == [8, 0]
+
+
+@pytest.mark.parametrize("device", ["cuda", "cpu"])
+@pytest.mark.parametrize("access", ["readonly", "readwrite"])
+def test_dist_embedding_forwards_its_cache_policy(device, access):
+    """``DistEmbedding(cache_policy=...)`` (reference dist_tensor.py:385-399 hands the policy to pylibwholegraph's
+    create_embedding): the table is a handle of the HIP library behind the policy's device cache; lookups are bit-exact, are
+    served from cache lines on the second pass, and a write through ``__setitem__`` is what the next lookup returns."""
+    import wholegraph_amd as wg
+    from cugraph_pyg_amd.tensor import DistEmbedding
+    comm = wg.get_global_communicator()
+    pol = wg.create_wholememory_cache_policy(comm, memory_type="chunked" if access == "readonly" else "distributed",
+                                             memory_location="cuda", access_type=access, ratio=0.25)
+    table = torch.randn((20011, 64))
+    emb = DistEmbedding.from_tensor(table, device=device, name="emb", cache_policy=pol)
+    assert "DistEmbedding(name=emb" in repr(emb) and tuple(emb.shape) == (20011, 64) and emb.dtype == torch.float32
+    g = torch.Generator().manual_seed(3)
+    hot = torch.randint(0, 500, (30000,), generator=g)
+    idx = torch.where(torch.rand(30000, generator=g) < 0.7, hot, torch.randint(0, 20011, (30000,), generator=g))
+    for _ in range(2):
+        got = emb[idx]
+        assert got.is_cuda and torch.equal(got.cpu(), table[idx])
+    hits, misses, _ = emb._embedding.cache_stats()
+    assert hits > 0
+    rows = torch.tensor([3, 17, 20010])
+    emb[rows] = torch.full((3, 64), 9.0)
+    table[rows] = 9.0
+    assert torch.equal(emb[idx].cpu(), table[idx]) and torch.equal(emb[rows].cpu(), table[rows])
+    out = torch.empty((100, 64), device="cuda")
+    assert torch.equal(emb.gather_into(idx[:100], out).cpu(), table[idx[:100]])
+    wg.destroy_embedding(emb._embedding)
+    wg.destroy_wholememory_cache_policy(pol)
+
+
+def test_pinned_host_rows_are_fenced_before_the_host_sees_them():
+    """A scatter into pinned-host rows runs on the current stream; ``get_local_tensor`` / ``load_from_*`` wait for it
+    (a host read straight after ``__setitem__`` used to be able to see the rows from before it)."""
+    from cugraph_pyg_amd.tensor import DistTensor
+    t = DistTensor(shape=[200000, 64], dtype=torch.float32, device="cpu")
+    idx = torch.randperm(200000, device="cuda")
+    for k in range(5):
+        torch.cuda._sleep(20_000_000)                         # the scatter waits behind this on the stream
+        t[idx] = torch.full((200000, 64), float(k + 1), device="cuda")
+        local = t.get_local_tensor()
+        assert not local.is_cuda and float(local.min()) == k + 1 and float(local.max()) == k + 1
+    torch.cuda._sleep(20_000_000)
+    t[idx[:1000]] = torch.zeros((1000, 64), device="cuda")
+    t.load_from_local_tensor(torch.full((200000, 64), 7.0))   # must land AFTER the queued scatter
+    torch.cuda.synchronize()
+    assert float(t.get_local_tensor().min()) == 7.0
 
 
 def test_dist_matrix():
