@@ -1,14 +1,18 @@
 """bench.py --workload mag — BASELINE configs[4]: ogbn-mag-like heterogeneous 2-hop sampling + GATConv, one MI355X.
 
 One "step" = `--groups-per-step` CALL GROUPS of `--call-group` mini-batches of 1024 paper seeds through the whole path:
-  heterogeneous 2-hop walk over 6 edge types, fan-out [25, 10] each (HeteroPygWalk: one launch sequence per hop and edge
-  type for the whole call group, no host sync)                                   [reference: cugraph_pyg NeighborLoader on
+  heterogeneous 2-hop walk over 6 edge types, fan-out [25, 10] each (wholegraph_amd.fused.HeteroPygWalk behind the loader: one
+  launch sequence per hop and edge type for the whole call group, no host sync)                                   [reference: cugraph_pyg NeighborLoader on
   a heterogeneous GraphStore, examples/mag_lp_mnmg.py:141; sampler/distributed_sampler.py:877-908]
   -> feature gather for every node type (fp32 [n_t, 128]; paper = the dataset's features, the other types = embedding
   tables, as examples/mag_lp_mnmg.py:120-136 does with learn_embeddings)
   -> 2 layers of HeteroConv{edge type: GATConv(in, 64, heads = 4)}, aggr = "sum", ReLU       [GATConv as the reference
   builds it: pylibwholegraph/torch/gnn_model.py:45-59; semantics SURVEY.md §8 row a18]
-How the layers are computed (same outputs for the seeds as PyG's formulation, up to fp32 reassociation):
+The whole path runs through the PACKAGE: GraphStore + FeatureStore -> cugraph_pyg_amd.loader.NeighborLoader.call_groups()
+(HeteroCallGroup: lazy x_dict, trimmed per-layer relation hops) -> 2 x wholegraph_amd.nn.HeteroConv{GATConv}; this file holds
+the workload, the timing and the CPU port only.
+How the layers are computed (wholegraph_amd.nn.HeteroConv._forward_layer; same outputs for the seeds as PyG's formulation, up
+to fp32 reassociation):
   * TRIMMED: layer 1 produces rows only for the vertices the seeds can see through layer 2 (those discovered by hops 0-1,
     kept in a compact per-type array), layer 2 only for the seeds (what torch_geometric.utils.trim_to_layer does);
   * AGGREGATE-FIRST: the attention-weighted sum is linear, so every (hop, edge type) is ONE launch of
@@ -47,6 +51,7 @@ def build_mag_like(dev, nodes=None, rels=None, seed=11):
         src = (torch.rand(m, generator=g, device=dev) ** 2 * nodes[s_]).long().clamp_(max=nodes[s_] - 1)
         dst = (torch.rand(m, generator=g, device=dev) ** 2 * nodes[d_]).long().clamp_(max=nodes[d_] - 1)
         gs[(s_, r_, d_), "coo", False, (nodes[s_], nodes[d_])] = torch.stack([src, dst])
+    build_mag_like.graph_store = gs           # (the loader path needs the store itself)
     return gs._hetero_graphs, dict(nodes)
 
 
@@ -63,264 +68,57 @@ def make_params(etypes, ntypes, dev, seed=3):
             # alpha_src = ((x W).view(H, C) * att).sum(-1) = x (W . att): the [in, H] matrices are folded once
             v_s = (w.view(fin, HEADS, CH) * att_s).sum(-1)
             v_d = (w.view(fin, HEADS, CH) * att_d).sum(-1)
-            rel[et] = {k: v.to(dev).contiguous() for k, v in dict(w=w, v_src=v_s, v_dst=v_d).items()}
+            rel[et] = {k: v.to(dev).contiguous() for k, v in dict(w=w, v_src=v_s, v_dst=v_d, att_src=att_s, att_dst=att_d).items()}
         bias = {t: ((torch.rand(HC, generator=g) - 0.5) * 0.1).to(dev) for t in ntypes}
         params.append(dict(rel=rel, bias=bias))
     return params
 
 
-class MagPipeline:
-    """The measured path for one rank: call-group walk, per-type feature gather, two HeteroConv(GATConv) layers."""
+def build_model(params, etypes, ntypes, dev):
+    """The measured model out of the package's own layers: 2 x ``wholegraph_amd.nn.HeteroConv({edge type: GATConv(in, 64,
+    heads=4, add_self_loops=False)})`` holding exactly the parameters of ``make_params`` (a node type's bias sits in the first
+    relation ending in it, the others carry none: HeteroConv adds the relations' outputs)."""
+    from wholegraph_amd import nn
+    layers = []
+    for layer, fin in enumerate((F_IN, HC)):
+        convs, seen = {}, set()
+        for et in etypes:
+            p = params[layer]["rel"][et]
+            c = nn.GATConv(fin, CH, heads=HEADS, add_self_loops=False, bias=et[2] not in seen).to(dev)
+            with torch.no_grad():
+                c.lin.weight.copy_(p["w"].t())
+                c.att_src.copy_(p["att_src"].view(1, HEADS, CH))
+                c.att_dst.copy_(p["att_dst"].view(1, HEADS, CH))
+                if c.bias is not None:
+                    c.bias.copy_(params[layer]["bias"][et[2]])
+            seen.add(et[2])
+            convs[et] = c
+        layers.append(nn.HeteroConv(convs, aggr="sum").to(dev))
+    for m in layers:
+        for q in m.parameters():
+            q.requires_grad_(False)
+    return layers
 
-    def __init__(self, graphs, num_nodes, tables, params, dev, B, G, fanout=(25, 10)):
-        from wholegraph_amd import fused, nn
-        self.nn, self.dev, self.B, self.G = nn, dev, B, G
-        self.fused_tail = os.environ.get("WGAMD_GAT_TRANSFORM", "bf16x3") != "library"
-        self.fused_layer = os.environ.get("WGAMD_GAT_LAYER", "fused") != "split"
-        # the one-kernel relation keeps 10 neighbours of a row in registers and continues longer rows online, one neighbour
-        # at a time: hops with a larger fan-out take the two-kernel path unless this says otherwise (measurement switch; the
-        # fan-out-25 hop through the one-kernel relation: 0.77 ms instead of 0.39 + 0.16 per call group, 2.03 vs 2.06 G edges/s)
-        self.fused_max_fanout = int(os.environ.get("WGAMD_GAT_FUSED_MAX_FANOUT", "10"))
-        self.etypes = sorted(graphs)
-        self.ntypes = sorted({t for et in self.etypes for t in (et[0], et[2])})
-        self.fanout = {et: list(fanout) for et in self.etypes}
-        self.hops = len(fanout)
-        self.walk = fused.HeteroPygWalk(graphs, B, self.fanout, G, num_nodes=num_nodes, pad_unique=False)
-        self.tables, self.params = tables, params
-        self.walk_stream = torch.cuda.Stream(device=dev)
-        self._rs = None
 
-    # ---- walk -------------------------------------------------------------------------------------------------
-    def sample(self, seeds, group_id):
-        """Enqueue the walk of one call group on its own stream + ONE async D2H of every size the forward pass needs."""
-        n_et = len(self.etypes)
-        if self._rs is None:
-            from cugraph_pyg_amd.sampler.sampler import _as_i64, hop_seed
-            self._rs_base = torch.tensor([[_as_i64(hop_seed(7 + j, k)) for j in range(self.G)] for k in range(self.hops * n_et)],
-                                         dtype=torch.int64, device=self.dev)
-            self._rs = True
-        self.walk_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.walk_stream):
-            rec = self.walk.run("paper", seeds, self._rs_base + group_id * self.G)
-            G = self.G
-            pieces = [rec["state"][t]["seg"][G:G + 1] for t in self.ntypes]
-            # vertices per type after hop 1 (the rows layer 1 has to produce), as a compact batch-major numbering
-            rec["cseg"] = {}
-            for t in self.ntypes:
-                cs = torch.zeros(G + 1, dtype=torch.int64, device=self.dev)
-                cs[1:] = torch.cumsum(rec["sizes"][1][t].long(), 0)
-                rec["cseg"][t] = cs
-                pieces.append(cs[G:G + 1])
-            for c in rec["calls"]:
-                if c is not None:
-                    n_f = c["f_seg"][G:G + 1]
-                    pieces += [n_f, c["offsets"][n_f.long()]]
-            sizes_d = torch.cat([p.to(torch.int32) for p in pieces])
-            sizes_h = torch.empty(sizes_d.shape, dtype=torch.int32, pin_memory=True)
-            sizes_h.copy_(sizes_d, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.walk_stream)
-        return rec, sizes_h, ev
+def make_loader(gs, tables, seeds, B, G, fanout=(25, 10), random_state=7):
+    """GraphStore + FeatureStore -> ``cugraph_pyg_amd.loader.NeighborLoader`` over the paper seeds, call groups of G mini-batches
+    (the reference's surface: loader/neighbor_loader.py:173-201 with a dict fan-out, sampler/sampler.py:231-502)."""
+    from cugraph_pyg_amd.data import FeatureStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    fs = FeatureStore()
+    for t, tab in tables.items():
+        fs[t, "x", None] = tab
+    return NeighborLoader((fs, gs), {et: list(fanout) for et in sorted(gs._hetero_graphs)}, input_nodes=("paper", seeds),
+                          batch_size=B, shuffle=False, random_state=random_state, local_seeds_per_call=G * B)
 
-    def _sizes(self, rec, sizes_h):
-        it = iter(sizes_h.tolist())
-        n_nodes = {t: next(it) for t in self.ntypes}
-        self._n_compact = {t: next(it) for t in self.ntypes}
-        live = []
-        for c in rec["calls"]:
-            live.append(None if c is None else (next(it), next(it)))      # (frontier entries, edges)
-        return n_nodes, live
 
-    # ---- forward ----------------------------------------------------------------------------------------------
-    def _terms_keys(self, t):
-        """Relation ends whose attention logit reads node type t, in the column order of ``_terms_matrix``."""
-        keys = []
-        for et in self.etypes:
-            if et[0] == t:
-                keys.append(("src", et))
-            if et[2] == t:
-                keys.append(("dst", et))
-        return keys
-
-    def _terms_matrix(self, layer, t):
-        """[in, HEADS * relation ends of t]: the folded attention vectors of every relation end of node type t, side by side."""
-        cache = self.__dict__.setdefault("_terms_cache", {})
-        if (layer, t) not in cache:
-            mats = [self.params[layer]["rel"][et]["v_src" if end == "src" else "v_dst"] for end, et in self._terms_keys(t)]
-            cache[(layer, t)] = torch.cat(mats, 1).contiguous() if mats else None
-        return cache[(layer, t)]
-
-    def forward(self, rec, sizes_h, ev, timers=None):
-        nn, G = self.nn, self.G
-        ev.synchronize()
-        n_nodes, live = self._sizes(rec, sizes_h)
-        main = torch.cuda.current_stream()
-        state = rec["state"]
-        for t in self.ntypes:
-            for k in ("nodes", "seg"):
-                state[t][k].record_stream(main)
-
-        def stage(name, fn):
-            if timers is None:
-                return fn()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = fn()
-            e.record()
-            timers.append((name, s, e))
-            return out
-
-        # feature fetch: one row gather per node type for the whole call group
-        from wholegraph_amd.tensor import local_gather
-        # Layer 1's attention logits need x_t @ [fold(W_r, att_src) | fold(W_r, att_dst) ...] for every gathered row: folded into
-        # the gather (wgamd_gather_terms_f32: the rows pass through registers once and feed an exact-fp32 MFMA) instead of a
-        # second pass over x (library GEMM with N = 8..20: 1.9 ms per call group next to the 1.4 ms gather).
-        x, terms1 = {}, {}
-        for t in self.ntypes:
-            ids = state[t]["nodes"][:n_nodes[t]]
-            v_t = self._terms_matrix(0, t)
-            buf = torch.empty((n_nodes[t], F_IN), dtype=torch.float32, device=self.dev)
-            if v_t is not None and n_nodes[t] > 0 and nn.gather_terms_supported(F_IN, v_t.shape[1]):
-                x[t], terms1[t] = stage("gather+attn_terms1", lambda: nn.gather_with_terms(self.tables[t], ids, v_t, out=buf,
-                                                                                           heads=HEADS if HEADS == 4 else 0))
-            else:
-                x[t] = stage("gather", lambda: local_gather(self.tables[t], ids, buf))
-
-        # per (hop, edge type): where the hop's rows sit in the destination type's node list (full numbering for the
-        # attention terms of layer 1, compact numbering for the layer-1 output), and the source rows of its edges (local
-        # ids are per mini-batch; the lists are batch-major)
-        n_c = self._n_compact
-        cseg = rec["cseg"]
-
-        def prep():
-            from wholegraph_amd import _lib as L
-            from wholegraph_amd.env import get_stream
-            out = []
-            for c, lv in zip(rec["calls"], live):
-                if c is None or lv[0] == 0:
-                    out.append(None)
-                    continue
-                n_f, n_e = lv      # (a hop with frontier entries but no sampled edge stays: its rows still get relu(bias))
-                src_t, _, dst_t = c["et"]
-                for k in ("offsets", "row", "f_batch", "f_seg", "f_local0"):
-                    c[k].record_stream(main)
-                first_hop = c["hop"] == 0
-                dst_full = torch.empty(n_f, dtype=torch.int64, device=self.dev)
-                dst_c = torch.empty(n_f, dtype=torch.int64, device=self.dev)
-                col_full = torch.empty(max(n_e, 1), dtype=torch.int32, device=self.dev)
-                col_c = torch.empty(max(n_e, 1), dtype=torch.int32, device=self.dev) if first_hop else None
-                # one launch per hop and edge type (wgamd_call_group_hop_rows) instead of a dozen torch index ops
-                L.check(L.lib().wgamd_call_group_hop_rows(
-                    c["offsets"].data_ptr(), c["f_batch"].data_ptr(), c["f_seg"].data_ptr(), c["f_local0"].data_ptr(),
-                    c["row"].data_ptr(), n_f, state[dst_t]["seg"].data_ptr(), cseg[dst_t].data_ptr(), state[src_t]["seg"].data_ptr(),
-                    cseg[src_t].data_ptr() if first_hop else None, dst_full.data_ptr(), dst_c.data_ptr(), col_full.data_ptr(),
-                    col_c.data_ptr() if first_hop else None, get_stream()), "wgamd_call_group_hop_rows")
-                out.append(dict(et=c["et"], hop=c["hop"], off=c["offsets"][:n_f + 1], n_f=n_f, n_e=n_e, dst_full=dst_full,
-                                dst_c=dst_c, col_full=col_full, col_c=col_c))
-            return out
-        calls = [c for c in stage("index_prep", prep) if c is not None]
-        edges = sum(lv[1] for lv in live if lv is not None)
-
-        def attention_terms(layer, xs, p, ready=None):
-            """alpha's inputs for every relation: x_t @ [fold(W_r, att_src) | fold(W_r, att_dst) ...] — ONE pass over x_t
-            (``ready[t]``: the product already made by the gather)."""
-            a_src, a_dst = {}, {}
-            for t in self.ntypes:
-                if xs[t].shape[0] == 0:
-                    continue
-                keys = [(a_src if end == "src" else a_dst, et) for end, et in self._terms_keys(t)]
-                if not keys:
-                    continue
-                # (a stand-alone narrow-matmul kernel — 64-row LDS tiles, K <= 32 — was built and measured: no faster than the
-                #  library GEMM at F = 128, slower at F = 256; taken out again)
-                if ready is not None and t in ready and ready[t].dim() == 3:     # [relation end][n][H] slabs from the gather
-                    for k, (dst, et) in enumerate(keys):
-                        dst[et] = ready[t][k]
-                    continue
-                vt = self._terms_matrix(layer, t)
-                if not (ready is not None and t in ready) and xs[t].stride(1) == 1 and xs[t].stride(0) % 4 == 0 \
-                        and xs[t].data_ptr() % 16 == 0 and nn.gather_terms_supported(int(xs[t].shape[1]), int(vt.shape[1])):
-                    # hidden state of the previous layer: one streaming pass, slabs come out of the kernel (no library GEMM +
-                    # transposing copy)
-                    slabs = nn.rows_terms(xs[t], vt, heads=HEADS)
-                    for k, (dst, et) in enumerate(keys):
-                        dst[et] = slabs[k]
-                    continue
-                both = ready[t] if (ready is not None and t in ready) else xs[t] @ vt
-                # one [relation end][n][H] copy per node type instead of one slice copy per relation end
-                slabs = both.view(both.shape[0], len(keys), HEADS).permute(1, 0, 2).contiguous()
-                for k, (dst, et) in enumerate(keys):
-                    dst[et] = slabs[k]
-            return a_src, a_dst
-
-        def hetero_layer(layer, xs, hop_set, col_key, dst_key, n_out, launches):
-            """One HeteroConv{GATConv} layer for the frontier rows of the hops in ``hop_set``; returns {type: compact rows}."""
-            p = self.params[layer]
-            a_src, a_dst = stage("attn_terms%d" % (layer + 1), lambda: attention_terms(layer, xs, p, terms1 if layer == 0 else None))
-            # every compact row is a frontier entry of exactly one hop of its type, so the index_copy below writes all of them
-            out = {t: torch.empty((n_out[t], HC), dtype=torch.float32, device=self.dev) for t in self.ntypes if n_out[t] > 0}
-            for h in hop_set:
-                for dt in self.ntypes:
-                    mine = [c for c in calls if c["hop"] == h and c["et"][2] == dt]
-                    if not mine:
-                        continue
-                    # HeteroConv's sum over the relations into `acc`: the first relation with edges WRITES it (beta = 0)
-                    acc = torch.empty((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
-                    live_rel = [c for c in mine if c["n_e"] > 0]   # (nothing sampled for a relation: it adds nothing to the sum)
-                    # one-pass tail (wgamd_gat_transform_heads_bf16x3): the LAST relation's transform also adds the bias, applies
-                    # the ReLU and places the hop's rows — no separate bias / ReLU pass over the layer output
-                    one_pass = self.fused_tail and bool(live_rel) and \
-                        nn.gat_transform_supported(xs[live_rel[0]["et"][0]].shape[1], HEADS, HC // HEADS)
-                    if one_pass and layer == 1:
-                        out[dt] = torch.empty((mine[0]["n_f"], HC), dtype=torch.float32, device=self.dev)
-                    for j, c in enumerate(live_rel):
-                        et = c["et"]
-                        last = j == len(live_rel) - 1
-                        # deep hop (fan-out <= 10) of layer 1: aggregation + dense tail as ONE kernel, the aggregate stays in LDS
-                        if one_pass and self.fused_layer and self.fanout[et][h] <= self.fused_max_fanout and \
-                                nn.gat_layer_fused_supported(xs[et[0]].shape[1], HEADS, HC // HEADS):
-                            stage("gat%d+transform:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
-                                  lambda: nn.gat_layer_fused(
-                                      c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], p["rel"][et]["w"], HEADS,
-                                      dst_rows=c[dst_key], acc_in=acc if j > 0 else None, bias=p["bias"][dt] if last else None,
-                                      relu=last, out_rows=mine[0]["dst_c"] if (last and layer == 0) else None,
-                                      out=out[dt] if last else acc))
-                            if launches is not None:
-                                launches.append((et, h, c["n_f"], c["n_e"], xs[et[0]].shape[1]))
-                            continue
-                        agg = stage("gat%d:%s hop %d (%d rows, %d edges)" % (layer + 1, et[1], h + 1, c["n_f"], c["n_e"]),
-                                    lambda: nn.gat_aggregate_heads(c["off"], c[col_key], xs[et[0]], a_src[et], a_dst[et], HEADS,
-                                                                   dst_rows=c[dst_key]))
-                        if one_pass:
-                            stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads_fused(
-                                agg, p["rel"][et]["w"], HEADS, acc_in=acc if j > 0 else None,
-                                bias=p["bias"][dt] if last else None, relu=last,
-                                out_rows=mine[0]["dst_c"] if (last and layer == 0) else None,
-                                out=out[dt] if last else acc))
-                        else:
-                            stage("transform%d" % (layer + 1), lambda: nn.gat_transform_heads(agg, p["rel"][et]["w"], HEADS, out=acc,
-                                                                                              overwrite=j == 0))
-                        if launches is not None:
-                            launches.append((et, h, c["n_f"], c["n_e"], xs[et[0]].shape[1]))
-                    if one_pass:
-                        continue
-                    if not live_rel:
-                        acc.zero_()       # no relation of this type sampled an edge in this hop: relu(bias) rows
-                    # bias + ReLU (+ the placement of the hop's rows in the compact list of layer 1) in one pass
-                    if layer == 0:
-                        stage("bias_relu", lambda: nn.bias_act_rows(acc, p["bias"][dt], True, mine[0]["dst_c"], out[dt]))
-                    else:
-                        out[dt] = stage("bias_relu", lambda: nn.bias_act_rows(acc, p["bias"][dt], True))
-            return out
-
-        launches = []
-        # layer 1: rows for every vertex discovered by hops 0-1 (the frontiers of hops 1 and 2), sources = all vertices
-        y1 = hetero_layer(0, x, (0, 1), "col_full", "dst_full", n_c, launches)
-        for t in self.ntypes:
-            y1.setdefault(t, torch.empty((0, HC), dtype=torch.float32, device=self.dev))
-        # layer 2: rows for the seeds only (hop-1 frontier), sources = the compact layer-1 rows
-        y2 = hetero_layer(1, y1, (0,), "col_c", "dst_c", {t: (G * self.B if t == "paper" else 0) for t in self.ntypes}, launches)
-        return y2["paper"], edges, n_nodes, launches
+def forward_group(model, grp):
+    """Both layers over one call group -> the seeds' rows [G * B, HC] (x lazy: the first layer's gather makes its attention
+    logits in the same pass)."""
+    h = grp.x_dict
+    for j, layer in enumerate(model):
+        h = layer(h, grp.layer_graph(j), act="relu")
+    return h["paper"]
 
 
 def cpu_port_batch(hg, tables_h, params_h, seeds, fanout, hops, etypes, ntypes, batch_seed, fp64=False):
@@ -415,51 +213,84 @@ def main(args):
     # call groups of 64 mini-batches (measured: 32 -> 1.31, 64 -> 1.40, 96 -> 1.39 G edges/s; the walk's ~120 launches per group
     # are what a larger group amortises)
     B, G, gps = 1024, args.call_group if args.call_group > 0 else 64, args.groups_per_step
-    pipe = MagPipeline(graphs, num_nodes, tables, params, dev, B, G)
+    from wholegraph_amd import nn
+    model = build_model(params, etypes, ntypes, dev)
+    for j, m in enumerate(model):
+        m.stage_tag = str(j + 1)        # stage names of the probe pass: gat1... = layer 1 (reads x), gat2... = layer 2
     groups = args.steps * gps
     warm = max(args.warmup * gps, 2)
-    distinct = min(groups + warm, 16)
+    n_probe = min(groups, 6)
     gs_ = torch.Generator(device=dev).manual_seed(7)
-    reps = -(-distinct * G * B // num_nodes["paper"])
+    need = (groups + warm + n_probe) * G * B
+    reps = -(-need // num_nodes["paper"])
     order = torch.cat([torch.randperm(num_nodes["paper"], generator=gs_, device=dev) for _ in range(reps)])
-    batches = order[:distinct * G * B].view(distinct, G * B).contiguous()
+    fanout = {et: [25, 10] for et in etypes}
+    hops = 2
 
-    def run(first, last, timers=None):
-        edges = 0
-        pending = pipe.sample(batches[first % distinct], first)
-        for gi in range(first, last):
-            nxt = pipe.sample(batches[(gi + 1) % distinct], gi + 1) if gi + 1 < last else None
-            _, e, _, _ = pipe.forward(*pending, timers=timers)
-            edges += e
-            pending = nxt
-        return edges
-
-    run(0, warm)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    edges = run(warm, warm + groups)
+    # ---- the timed region: the package API end to end (NeighborLoader.call_groups() -> HeteroConv x 2) --------------------
+    loader = make_loader(build_mag_like.graph_store, tables, order[:(groups + warm) * G * B], B, G)
+    edges, n, t0 = 0, 0, None
+    with torch.no_grad():
+        for grp in loader.call_groups():
+            if n == warm:
+                torch.cuda.synchronize()
+                t0, edges = time.perf_counter(), 0
+            forward_group(model, grp)
+            edges += grp.num_edges
+            n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert n == groups + warm
 
-    # per-stage HIP-event pass (outside the timed region): one call group at a time, the walk alone on its stream
-    acc, n_probe, launches, nn_sizes = {}, min(groups, 6), None, None
-    per_shape = {}
-    for gi in range(warm, warm + n_probe):
-        timers = []
-        torch.cuda.synchronize()
-        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        w0.record(pipe.walk_stream)
-        pend = pipe.sample(batches[gi % distinct], gi)
-        w1.record(pipe.walk_stream)
-        _, _, nn_sizes, launches = pipe.forward(*pend, timers=timers)
-        torch.cuda.synchronize()
-        timers.append(("walk(2 hops x 6 edge types)", w0, w1))
-        for name, a, b in timers:
-            key = name.split(":")[0]
-            acc[key] = acc.get(key, 0.0) + a.elapsed_time(b)
-            if ":" in name:
-                acc[name] = acc.get(name, 0.0) + a.elapsed_time(b)
+    # per-stage HIP-event pass (outside the timed region): the layers' stages through nn.set_stage_hook, one call group at a
+    # time; the walk alone (the loader's own walk object) between events on the main stream
+    acc, launches, nn_sizes = {}, None, None
+    timers, walk_ms = [], []
+
+    def hook(name, fn):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        out_ = fn()
+        e_.record()
+        timers.append((name, s_, e_))
+        return out_
+    probe = make_loader(build_mag_like.graph_store, tables, order[(groups + warm) * G * B:need], B, G, random_state=7 + (groups + warm) * G)
+    nn.set_stage_hook(hook)
+    try:
+        with torch.no_grad():
+            it = probe.call_groups(overlap=False)
+            for gi in range(n_probe):
+                torch.cuda.synchronize()
+                del timers[:]
+                # (overlap=False: next() enqueues the walk of the FOLLOWING group on this stream — two of them on the first
+                #  call, none on the last)
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record()
+                grp = next(it)
+                w1.record()
+                walk_groups = 1 if 0 < gi < n_probe - 1 else 0
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                lg = [grp.layer_graph(j) for j in range(hops)]
+                e_.record()
+                timers.append(("index_prep", s_, e_))
+                forward_group(model, grp)
+                torch.cuda.synchronize()
+                if walk_groups:
+                    walk_ms.append(w0.elapsed_time(w1))
+                for name, a_, b_ in timers:
+                    key = name.split(":")[0]
+                    acc[key] = acc.get(key, 0.0) + a_.elapsed_time(b_)
+                    if ":" in name:
+                        acc[name] = acc.get(name, 0.0) + a_.elapsed_time(b_)
+                nn_sizes = dict(grp.num_nodes)
+                launches = [(r.edge_type, r.hop, r.n_rows, r.n_edges, F_IN if j == 0 else HC) for j in range(hops)
+                            for r in lg[j].relations if r.n_edges > 0]
+    finally:
+        nn.set_stage_hook(None)
     stage_ms = {k: v / n_probe for k, v in acc.items() if ":" not in k}
+    if walk_ms:
+        stage_ms["walk(2 hops x 6 edge types)"] = sum(walk_ms) / len(walk_ms)
     # dominant GAT launch over the probed groups (shapes differ by a per cent between groups: the stage name carries the shape)
     import re
     gat = {k: v for k, v in acc.items() if k.startswith("gat") and ":" in k}
@@ -513,7 +344,7 @@ def main(args):
             roofline["profiled_source"] = "%s (%d launches of all shapes, avg %.1f us)" % (prof["source"], prof["calls"], prof["avg_ns"] * 1e-3)
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline(graphs, tables, params, order[:min(order.numel(), 256 * B)].cpu().numpy(), B, pipe.fanout, pipe.hops,
+        cpu = cpu_baseline(graphs, tables, params, order[:min(order.numel(), 256 * B)].cpu().numpy(), B, fanout, hops,
                            etypes, ntypes, args.cpu_budget)
     out = {"metric": "sampled-edges/sec (hetero 2-hop sample+renumber + feature gather + 2-layer HeteroConv(GATConv 4x64) fwd), "
                      "ogbn-mag-like fan-out [25, 10] x 6 edge types",

@@ -21,7 +21,7 @@ import torch
 
 from wholegraph_amd import _lib as L
 from wholegraph_amd.env import get_stream
-from wholegraph_amd.nn import HopGraph, LayerGraph, LazyRows
+from wholegraph_amd.nn import HeteroLayerGraph, HopGraph, LayerGraph, LazyRows, RelationHop
 
 
 class CallGroup:
@@ -222,6 +222,166 @@ class CallGroup:
         return datas
 
 
+class HeteroCallGroup:
+    """G consecutive mini-batches of a HETEROGENEOUS loader epoch as one block-diagonal graph (BASELINE configs[4]; the
+    reference's surface: ``NeighborLoader`` over a heterogeneous ``GraphStore``, loader/neighbor_loader.py:173-201,
+    sampler/sampler.py:231-502, call shape examples/mag_lp_mnmg.py:141).  Per node type the vertices of all mini-batches are
+    batch-major (``n_id[t]``, offsets ``node_ptr[t]``), a batch's vertices in discovery order — so "the vertices the seeds can
+    still see through k more layers" is a per-batch PREFIX of every list, which is what the trimmed ``layer_graph(j)``
+    renumbers against.  Every mini-batch inside equals what ``for batch in loader`` yields (same walk, same seeds)."""
+
+    def __init__(self, rec, walk, feature_store, seed_type, first_batch: int, input_id, sizes_h, event, walk_stream, cseg):
+        self._rec, self._walk, self._fs, self.seed_type = rec, walk, feature_store, seed_type
+        self.first_batch, self.n_batches, self.hops = first_batch, walk.G, walk.hops
+        self.input_id, self._sizes_h, self._event, self._walk_stream, self._cseg = input_id, sizes_h, event, walk_stream, cseg
+        self.node_types, self.edge_types = list(walk.ntypes), list(walk.etypes)
+        self._ready = False
+        self._rows, self._layers, self._cseg32 = {}, {}, {}
+
+    def _wait(self):
+        if self._ready:
+            return
+        self._event.synchronize()
+        it = iter(self._sizes_h.tolist())
+        self.num_nodes = {t: next(it) for t in self.node_types}
+        # vertices per type after k hops (k = 0: the seeds), summed over the mini-batches
+        self._n_level = [{t: next(it) for t in self.node_types} for _ in range(self.hops)] + [dict(self.num_nodes)]
+        self._live = [None if c is None else (next(it), next(it)) for c in self._rec["calls"]]   # (frontier entries, edges)
+        self.num_edges = sum(lv[1] for lv in self._live if lv is not None)
+        self.num_seeds = self._n_level[0][self.seed_type]
+        if self._walk_stream is not None:      # allocated on the walk stream, consumed on the caller's
+            main = torch.cuda.current_stream()
+            for t in self.node_types:
+                for k in ("nodes", "seg"):
+                    self._rec["state"][t][k].record_stream(main)
+            for c in self._rec["calls"]:
+                if c is not None:
+                    for k in ("offsets", "row", "f_batch", "f_seg", "f_local0"):
+                        c[k].record_stream(main)
+            for lvl in self._cseg:
+                for v in lvl.values():
+                    v.record_stream(main)
+        self._ready = True
+
+    # ---- nodes -----------------------------------------------------------------------------------------------------
+    @property
+    def n_id(self):
+        """{node type: global (type-local) ids of the vertices of all mini-batches, batch-major}."""
+        self._wait()
+        return {t: self._rec["state"][t]["nodes"][:self.num_nodes[t]] for t in self.node_types}
+
+    @property
+    def node_ptr(self):
+        return {t: self._rec["state"][t]["seg"] for t in self.node_types}
+
+    def node_attr(self, name: str, lazy: bool = True):
+        """{node type: attribute rows of its vertices} — ``LazyRows`` (table + ids, nothing gathered: the first layer's
+        gather makes its attention logits in the same pass) where the table lives whole on this device, gathered otherwise."""
+        from ..sampler.sampler import _fetch_rows_agreed
+        self._wait()
+        have = {a.group_name for a in self._fs.get_all_tensor_attrs() if a.attr_name == name and not isinstance(a.group_name, tuple)}
+        out, ids = {}, self.n_id
+        for t in self.node_types:
+            if t not in have:
+                continue
+            ten = self._fs[t, name, None]
+            wm = getattr(ten, "_tensor", None)
+            table = getattr(wm, "local_tensor", None)
+            if (lazy and table is not None and not getattr(wm, "is_distributed", True) and table.is_cuda and table.dim() == 2
+                    and table.dtype == torch.float32 and table.stride(1) == 1):
+                out[t] = LazyRows(table, ids[t])
+            else:
+                out[t] = _fetch_rows_agreed(ten, ids[t])
+        return out
+
+    @property
+    def x_dict(self):
+        return self.node_attr("x")
+
+    @property
+    def batch_ptr(self) -> torch.Tensor:
+        """int32 [G + 1]: rows of mini-batch b's seeds in the last layer's output of the seed type."""
+        return self._rec["calls_seed_seg"]
+
+    @property
+    def num_sampled_nodes(self):
+        """{node type: vertices per hop (seeds first), summed over the mini-batches}."""
+        self._wait()
+        return {t: [self._n_level[0][t]] + [self._n_level[k + 1][t] - self._n_level[k][t] for k in range(self.hops)]
+                for t in self.node_types}
+
+    @property
+    def num_sampled_edges(self):
+        """{edge type: edges per hop, summed over the mini-batches}."""
+        self._wait()
+        n_et = len(self.edge_types)
+        return {et: [(self._live[h * n_et + ti] or (0, 0))[1] for h in range(self.hops)] for ti, et in enumerate(self.edge_types)}
+
+    # ---- edges -----------------------------------------------------------------------------------------------------
+    def _seg(self, level: int, t: str, as32: bool):
+        """Per-batch offsets of the numbering "vertices of type t discovered by the first ``level`` hops" (level == hops: all)."""
+        if level == self.hops:
+            seg = self._rec["state"][t]["seg"]
+            return seg if as32 else seg.long()
+        if not as32:
+            return self._cseg[level][t]
+        key = (level, t)
+        if key not in self._cseg32:
+            self._cseg32[key] = self._cseg[level][t].to(torch.int32)
+        return self._cseg32[key]
+
+    def _numbered(self, ci: int, level_a: int, level_b: int, want_col_b: bool):
+        """Rows of call ``ci``'s frontier entries / edge sources in the numberings of two levels — ONE launch
+        (``wgamd_call_group_hop_rows``) for both, cached: the output numbering of layer j is the input numbering of layer j + 1."""
+        c, (n_f, n_e) = self._rec["calls"][ci], self._live[ci]
+        got = self._rows.setdefault(ci, {})
+        if level_a in got and (level_b in got or level_b == 0) and (not want_col_b or got.get(level_b, (None, None))[1] is not None):
+            return got
+        dev = c["offsets"].device
+        src_t, _, dst_t = c["et"]
+        dst_a = torch.empty(n_f, dtype=torch.int64, device=dev)
+        col_a = torch.empty(max(n_e, 1), dtype=torch.int32, device=dev)
+        need_b = level_b != 0 or want_col_b
+        dst_b = torch.empty(n_f, dtype=torch.int64, device=dev) if need_b else None
+        col_b = torch.empty(max(n_e, 1), dtype=torch.int32, device=dev) if want_col_b else None
+        state = self._rec["state"]
+        L.check(L.lib().wgamd_call_group_hop_rows(
+            c["offsets"].data_ptr(), c["f_batch"].data_ptr(), c["f_seg"].data_ptr(), c["f_local0"].data_ptr(), c["row"].data_ptr(),
+            n_f, self._seg(level_a, dst_t, True).data_ptr(), self._seg(level_b, dst_t, False).data_ptr() if need_b else None,
+            self._seg(level_a, src_t, True).data_ptr(), self._seg(level_b, src_t, False).data_ptr() if want_col_b else None,
+            dst_a.data_ptr(), dst_b.data_ptr() if need_b else None, col_a.data_ptr(), col_b.data_ptr() if want_col_b else None,
+            get_stream()), "wgamd_call_group_hop_rows")
+        got[level_a] = (dst_a, col_a[:n_e])
+        if need_b:
+            got[level_b] = (dst_b, col_b[:n_e] if want_col_b else None)
+        return got
+
+    def layer_graph(self, layer: int) -> HeteroLayerGraph:
+        """The relation hops layer ``layer`` (0 = the one that reads ``x_dict``) of an H-layer model runs over, trimmed
+        (``torch_geometric.utils.trim_to_layer`` per node / edge type): it computes rows for the vertices discovered by the
+        first ``H - 1 - layer`` hops from the edges of hops ``<= H - 1 - layer``; the LAST layer's output of the seed type is
+        exactly the seeds' rows, batch-major."""
+        self._wait()
+        H = self.hops
+        if not 0 <= layer < H:
+            raise IndexError(f"layer {layer} of a {H}-hop call group")
+        if layer in self._layers:
+            return self._layers[layer]
+        lvl_in, lvl_out = H - layer, H - 1 - layer
+        rels = []
+        for ci, (c, lv) in enumerate(zip(self._rec["calls"], self._live)):
+            if c is None or lv[0] == 0 or c["hop"] > lvl_out:
+                continue            # (a hop with frontier entries but no sampled edge stays: its rows still get act(bias))
+            n_f, n_e = lv
+            got = self._numbered(ci, lvl_in, lvl_out, want_col_b=c["hop"] < lvl_out)
+            dst_in, col_in = got[lvl_in]
+            rels.append(RelationHop(c["et"], c["hop"], c["offsets"][:n_f + 1], col_in, dst_in,
+                                    None if lvl_out == 0 else got[lvl_out][0], n_e, self._walk.fanout[c["et"]][c["hop"]]))
+        lg = HeteroLayerGraph(rels, {t: self._n_level[lvl_out][t] for t in self.node_types}, self.node_types)
+        self._layers[layer] = lg
+        return lg
+
+
 class CallGroupIterator:
     """Software-pipelined: the walk of call group g + 1 is enqueued (on its own HIP stream) before group g is handed out, so
     the device never waits for the host's read-back of group g's sizes."""
@@ -230,12 +390,12 @@ class CallGroupIterator:
         from ..sampler.sampler import HeteroNeighborSampler
         self._fs, self._gs = data
         self._smp, self._B, self._rs = core_sampler, int(batch_size), int(random_state)
-        if isinstance(core_sampler, HeteroNeighborSampler):
-            raise NotImplementedError("call_groups(): homogeneous graphs (heterogeneous loaders iterate per mini-batch)")
+        self._hetero = isinstance(core_sampler, HeteroNeighborSampler)
         if input_data.time is not None or not core_sampler.call_groups_ok() or not input_data.node.is_cuda:
             raise NotImplementedError("call_groups(): uniform or positively-weighted sampling with positive fan-outs, no "
                                       "replacement, not disjoint / temporal, seeds on the device")
-        self._seeds = input_data.node.to(core_sampler.graph.col.dtype)
+        self._seed_type = input_data.input_type
+        self._seeds = input_data.node.to(torch.int64 if self._hetero else core_sampler.graph.col.dtype)
         self._input_id = input_data.input_id
         n, B = int(self._seeds.shape[0]), self._B
         G = max(1, core_sampler.seeds_per_call(B) // B)
@@ -253,7 +413,60 @@ class CallGroupIterator:
     def __iter__(self):
         return self
 
-    def _launch(self, i) -> Optional[CallGroup]:
+    def _launch_hetero(self, i) -> Optional[HeteroCallGroup]:
+        from ..sampler.sampler import _as_i64, hop_seed
+        if i >= len(self._plan):
+            return None
+        b0, g, ragged = self._plan[i]
+        smp, B, dev = self._smp, self._B, self._seeds.device
+        H, n_et = len(next(iter(smp.fanout.values()))), len(smp.graphs)
+        rs = torch.tensor([[_as_i64(hop_seed(self._rs + b0 + j, k)) for j in range(g)] for k in range(H * n_et)], dtype=torch.int64)
+        walk = smp._call_group_walk(B if ragged is None else ragged, g)
+
+        def enqueue():
+            if ragged is None:
+                rec = walk.run(self._seed_type, self._seeds[b0 * B:(b0 + g) * B].contiguous(), rs)
+                n_seeds = g * B
+            else:   # the last, short mini-batch: a one-batch group over its own seed list
+                ids = self._seeds[b0 * B:b0 * B + ragged].contiguous()
+                rec = walk.run(None, None, rs, seed_lists={self._seed_type: (
+                    ids, torch.tensor([0, ragged], dtype=torch.int32, device=dev), torch.zeros(ragged, dtype=torch.int32, device=dev))})
+                n_seeds = ragged
+            state, G_ = rec["state"], walk.G
+            pieces = [state[t]["seg"][G_:G_ + 1] for t in walk.ntypes]
+            cseg = []
+            for k in range(H):      # vertices per type after k hops: a batch-major compact numbering per level
+                lvl = {}
+                for t in walk.ntypes:
+                    cs = torch.zeros(G_ + 1, dtype=torch.int64, device=dev)
+                    cs[1:] = torch.cumsum(rec["sizes"][k][t].long(), 0)
+                    lvl[t] = cs
+                    pieces.append(cs[G_:G_ + 1])
+                cseg.append(lvl)
+            for c in rec["calls"]:
+                if c is not None:
+                    n_f = c["f_seg"][G_:G_ + 1]
+                    pieces += [n_f, c["offsets"][n_f.long()]]
+            rec["calls_seed_seg"] = cseg[0][self._seed_type].to(torch.int32)
+            sizes_d = torch.cat([p.to(torch.int32).reshape(-1) for p in pieces])
+            sizes_h = torch.empty(sizes_d.shape, dtype=torch.int32, pin_memory=True)
+            sizes_h.copy_(sizes_d, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return rec, sizes_h, ev, n_seeds, cseg
+
+        if self._stream is None:
+            rec, sizes_h, ev, n_seeds, cseg = enqueue()
+        else:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                rec, sizes_h, ev, n_seeds, cseg = enqueue()
+        return HeteroCallGroup(rec, walk, self._fs, self._seed_type, b0, self._input_id[b0 * B:b0 * B + n_seeds], sizes_h, ev,
+                               self._stream, cseg)
+
+    def _launch(self, i):
+        if self._hetero:
+            return self._launch_hetero(i)
         from ..sampler.sampler import hop_seed
         if i >= len(self._plan):
             return None
@@ -291,7 +504,7 @@ class CallGroupIterator:
                 res, sizes_h, ev, n_seeds = enqueue()
         return CallGroup(res, self._fs, smp.graph, b0, self._input_id[b0 * B:b0 * B + n_seeds], sizes_h, ev, self._stream)
 
-    def __next__(self) -> CallGroup:
+    def __next__(self):
         if self._at == 0 and self._pending is None:
             self._pending = self._launch(0)
         cur = self._pending

@@ -414,6 +414,7 @@ def gat_transform_heads(agg, w, heads, out=None, overwrite=False, fused=None):
 
 
 _GAT_TRANSFORM_FUSED = os.environ.get("WGAMD_GAT_TRANSFORM", "bf16x3") != "library"
+_GAT_LAYER_FUSED = os.environ.get("WGAMD_GAT_LAYER", "fused") != "split"      # one-kernel relation for hops of fan-out <= 10
 
 
 def gat_transform_supported(F_: int, heads: int, C: int) -> bool:
@@ -937,3 +938,250 @@ class GATConv(torch.nn.Module):
         if self.bias is not None:
             out = out + self.bias
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# heterogeneous layers over a call group (BASELINE configs[4]: ogbn-mag-like 2-hop walk + HeteroConv{GATConv})
+# ---------------------------------------------------------------------------------------------------------------------
+_stage_hook = None
+
+
+def set_stage_hook(hook):
+    """``hook(name, fn) -> fn()`` wraps every device stage of the call-group layers (bench_mag.py times them with HIP events);
+    ``None`` = plain calls."""
+    global _stage_hook
+    _stage_hook = hook
+
+
+def _stage(name, fn):
+    return fn() if _stage_hook is None else _stage_hook(name, fn)
+
+
+class RelationHop:
+    """One (hop, edge type) of a heterogeneous call group as a layer consumes it: CSR over the hop's frontier entries of the
+    destination type (``row_ptr`` int32 [n + 1]); ``col`` int32 = row of every edge's source in the layer's INPUT of the source
+    type; ``dst_rows`` int64 [n] = row of every frontier entry in the layer's input of the destination type (its attention
+    term); ``out_rows`` int64 [n] = its row in the layer's OUTPUT of the destination type (None: entry j is output row j)."""
+
+    def __init__(self, edge_type, hop, row_ptr, col, dst_rows, out_rows, n_edges, fanout):
+        self.edge_type, self.hop, self.row_ptr, self.col = edge_type, hop, row_ptr, col
+        self.dst_rows, self.out_rows, self.n_edges, self.fanout = dst_rows, out_rows, int(n_edges), int(fanout)
+
+    @property
+    def n_rows(self):
+        return int(self.row_ptr.shape[0]) - 1
+
+
+class HeteroLayerGraph:
+    """What ONE layer of a trimmed heterogeneous GNN runs over (``cugraph_pyg_amd.loader.HeteroCallGroup.layer_graph``): the
+    relation hops, and per node type the number of output rows (every output row of a type is a frontier entry of exactly one
+    hop of that type)."""
+
+    def __init__(self, relations, n_out, node_types):
+        self.relations, self.n_out, self.node_types = list(relations), dict(n_out), list(node_types)
+
+    @property
+    def num_edges(self):
+        return sum(r.n_edges for r in self.relations)
+
+
+class HeteroConv(torch.nn.Module):
+    """``torch_geometric.nn.HeteroConv({edge_type: conv}, aggr="sum")`` for ``GATConv`` relations: the output of a node type
+    is the sum over the relations ending in it (examples/mag_lp_mnmg.py:141 builds this stack; GATConv as
+    pylibwholegraph/torch/gnn_model.py:45-59).
+
+    ``forward(x_dict, graph, act=None)``
+      * ``graph`` a ``HeteroLayerGraph`` of a loader call group (no autograd): every (hop, edge type) is ONE launch —
+        AGGREGATE-FIRST (the attention-weighted sum is linear, so it runs over the UNTRANSFORMED source rows and the per-head
+        weights are applied to the few destination rows afterwards: the ``lin`` GEMM over every source row, 10-20x more rows,
+        never runs), attention logits ``x @ fold(W, att)`` made by the feature gather itself when ``x_dict[t]`` is a
+        ``LazyRows`` (``wgamd_gather_terms_f32``), HeteroConv's running sum, bias, ReLU and the row placement folded into the
+        last relation's launch (``wgamd_gat_layer_fused_bf16x3`` / ``wgamd_gat_transform_heads_bf16x3``).
+      * ``graph`` a dict ``{edge_type: edge_index | [csr_row_ptr, csr_col_ind]}`` (a mini-batch ``HeteroData``; autograd):
+        ``convs[edge_type]((x_src, x_dst), graph[edge_type])`` summed per destination type — PyG's own formulation."""
+
+    def __init__(self, convs, aggr: str = "sum"):
+        super().__init__()
+        assert aggr in ("sum", "add"), "aggr: sum"
+        self.edge_types = sorted(convs)
+        self.convs = torch.nn.ModuleDict({"__".join(et): convs[et] for et in self.edge_types})
+        self._folded = {}
+        self.stage_tag = ""        # suffix of this layer's stage names under set_stage_hook ("1": gat1:..., transform1, ...)
+        # the one-kernel relation keeps 10 neighbours of a row in registers and continues longer rows one neighbour at a time:
+        # hops with a larger fan-out take the two-kernel path (the fan-out-25 hop of the mag workload through the one-kernel
+        # relation: 0.77 ms instead of 0.39 + 0.16 per call group)
+        self.fused_max_fanout = int(os.environ.get("WGAMD_GAT_FUSED_MAX_FANOUT", "10"))
+
+    def conv(self, edge_type):
+        return self.convs["__".join(edge_type)]
+
+    # ---- parameters in the form the kernels read -----------------------------------------------------------------------
+    def _rel(self, et):
+        """(w [in, H C] contiguous, fold(w, att_src) [in, H], fold(w, att_dst) [in, H]) of a relation, rebuilt when a parameter
+        changed: ``alpha_src = ((x W).view(H, C) * att).sum(-1) = x (W . att)``."""
+        c = self.conv(et)
+        key = tuple((p._version, p.data_ptr()) for p in (c.lin.weight, c.att_src, c.att_dst))
+        hit = self._folded.get(et)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = c.lin.weight.t().contiguous()
+                w3 = w.view(w.shape[0], c.heads, c.out_channels)
+                hit = (key, w, (w3 * c.att_src.view(1, c.heads, c.out_channels)).sum(-1).contiguous(),
+                       (w3 * c.att_dst.view(1, c.heads, c.out_channels)).sum(-1).contiguous())
+            self._folded[et] = hit
+            self._folded.pop(("terms", et[0]), None), self._folded.pop(("terms", et[2]), None)
+            self._folded.pop(("bias", et[2]), None)
+        return hit[1:]
+
+    def _term_keys(self, t):
+        keys = []
+        for et in self.edge_types:
+            if et[0] == t:
+                keys.append(("src", et))
+            if et[2] == t:
+                keys.append(("dst", et))
+        return keys
+
+    def _terms_matrix(self, t):
+        """[in, H x relation ends of node type t]: the folded attention vectors of every relation end reading type t."""
+        mats = [self._rel(et)[1 if end == "src" else 2] for end, et in self._term_keys(t)]      # (refreshes stale folds first)
+        hit = self._folded.get(("terms", t))
+        if hit is None:
+            hit = torch.cat(mats, 1).contiguous() if mats else None
+            self._folded[("terms", t)] = hit
+        return hit
+
+    def _bias(self, dt):
+        """Sum of the biases of the relations ending in ``dt`` (HeteroConv adds the relations' outputs, bias included)."""
+        rels = [et for et in self.edge_types if et[2] == dt]
+        for et in rels:
+            self._rel(et)
+        hit = self._folded.get(("bias", dt))
+        if hit is None:
+            bs = [self.conv(et).bias.detach() for et in rels if self.conv(et).bias is not None]
+            hit = (torch.stack(bs).sum(0).contiguous() if bs else None,)
+            self._folded[("bias", dt)] = hit
+        return hit[0]
+
+    # ---- call-group layer ----------------------------------------------------------------------------------------------
+    def _attention_terms(self, xs, graph):
+        """-> (x tensors, a_src{et}, a_dst{et}): ``x_t @ [fold(W_r, att_src) | fold(W_r, att_dst) ...]`` in ONE pass over the
+        rows of every node type — inside the row gather for a ``LazyRows`` input, a streaming pass over a resident one."""
+        from .tensor import local_gather
+        x, a_src, a_dst = {}, {}, {}
+        for t in graph.node_types:
+            v = xs.get(t)
+            if v is None:
+                continue
+            keys = [(a_src if end == "src" else a_dst, et) for end, et in self._term_keys(t)]
+            vt = self._terms_matrix(t)
+            H = self.conv(keys[0][1]).heads if keys else 0
+            slabs = None
+            if isinstance(v, LazyRows):
+                n, F_ = len(v), v.table.shape[1]
+                buf = torch.empty((n, F_), dtype=torch.float32, device=v.table.device)
+                if vt is not None and n > 0 and H == 4 and v.table.dtype == torch.float32 and gather_terms_supported(F_, vt.shape[1]):
+                    x[t], slabs = _stage("gather+attn_terms" + self.stage_tag, lambda: gather_with_terms(v.table, v.ids, vt, out=buf, heads=4))
+                else:
+                    x[t] = _stage("gather", lambda: local_gather(v.table, v.ids, buf))
+            else:
+                x[t] = v
+            if not keys or x[t].shape[0] == 0:
+                continue
+            if slabs is None:
+                xt = x[t]
+                if H == 4 and xt.stride(1) == 1 and xt.stride(0) % 4 == 0 and xt.data_ptr() % 16 == 0 \
+                        and gather_terms_supported(int(xt.shape[1]), int(vt.shape[1])):
+                    slabs = _stage("attn_terms" + self.stage_tag, lambda: rows_terms(xt, vt, heads=4))
+                else:
+                    both = _stage("attn_terms" + self.stage_tag, lambda: xt @ vt)
+                    slabs = both.view(both.shape[0], len(keys), H).permute(1, 0, 2).contiguous()
+            for k, (dst, et) in enumerate(keys):
+                dst[et] = slabs[k]
+        return x, a_src, a_dst
+
+    def _forward_layer(self, xs, graph: HeteroLayerGraph, act=None):
+        assert act in (None, "relu")
+        relu = act == "relu"
+        x, a_src, a_dst = self._attention_terms(xs, graph)
+        dev = next(iter(x.values())).device
+        out = {}
+        groups = {}
+        for r in graph.relations:
+            groups.setdefault((r.hop, r.edge_type[2]), []).append(r)
+        for t, n in graph.n_out.items():
+            if n > 0 and any(dt == t for _, dt in groups):
+                out[t] = torch.empty((n, self._width(t)), dtype=torch.float32, device=dev)
+        for (hop, dt), mine in sorted(groups.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+            n_f, HC = mine[0].n_rows, self._width(dt)
+            if n_f == 0:
+                continue
+            bias, place = self._bias(dt), mine[0].out_rows
+            live = [r for r in mine if r.n_edges > 0]      # (a relation that sampled nothing adds nothing to the sum)
+            acc = torch.empty((n_f, HC), dtype=torch.float32, device=dev)
+            c0 = self.conv(mine[0].edge_type)
+            H, C = c0.heads, c0.out_channels
+            one_pass = bool(live) and _GAT_TRANSFORM_FUSED and all(
+                gat_transform_supported(x[r.edge_type[0]].shape[1], H, C) for r in live)
+            target = out[dt] if place is not None else None
+            if one_pass and place is None:
+                out[dt] = target = torch.empty((n_f, HC), dtype=torch.float32, device=dev)
+            for j, r in enumerate(live):
+                et = r.edge_type
+                w = self._rel(et)[0]
+                xsrc, last = x[et[0]], j == len(live) - 1
+                tail = dict(acc_in=acc if j > 0 else None, bias=bias if (last and one_pass) else None, relu=last and one_pass and relu,
+                            out_rows=place if (last and one_pass) else None, out=target if (last and one_pass) else acc)
+                name = "%s hop %d (%d rows, %d edges)" % (et[1], hop + 1, n_f, r.n_edges)
+                if one_pass and _GAT_LAYER_FUSED and r.fanout <= self.fused_max_fanout and gat_layer_fused_supported(xsrc.shape[1], H, C):
+                    # deep hop (fan-out <= 10): aggregation + dense tail as ONE kernel, the aggregate stays in LDS
+                    _stage("gat%s+transform:" % self.stage_tag + name, lambda: gat_layer_fused(r.row_ptr, r.col, xsrc, a_src[et], a_dst[et], w, H,
+                                                                            dst_rows=r.dst_rows, **tail))
+                    continue
+                agg = _stage("gat%s:" % self.stage_tag + name, lambda: gat_aggregate_heads(r.row_ptr, r.col, xsrc, a_src[et], a_dst[et], H,
+                                                                       dst_rows=r.dst_rows))
+                if one_pass:
+                    _stage("transform" + self.stage_tag, lambda: gat_transform_heads_fused(agg, w, H, **tail))
+                else:
+                    _stage("transform" + self.stage_tag, lambda: gat_transform_heads(agg, w, H, out=acc, overwrite=j == 0))
+            if one_pass:
+                continue
+            if not live:
+                acc.zero_()        # no relation of this type sampled an edge in this hop: act(bias) rows
+            if place is not None:
+                _stage("bias_act", lambda: bias_act_rows(acc, bias, relu, place, out[dt]))
+            else:
+                out[dt] = _stage("bias_act", lambda: bias_act_rows(acc, bias, relu))
+        return out
+
+    def _width(self, dt):
+        c = next(self.conv(et) for et in self.edge_types if et[2] == dt)
+        return c.heads * c.out_channels if c.concat else c.out_channels
+
+    def forward(self, x_dict, graph, act=None):
+        if isinstance(graph, HeteroLayerGraph):
+            needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            if not needs_grad and all(self.conv(et).concat and not self.conv(et).add_self_loops for et in self.edge_types):
+                return self._forward_layer(x_dict, graph, act)
+            return self._forward_relations(x_dict, graph, act)
+        out = {}
+        for et in self.edge_types:
+            if et not in graph or x_dict.get(et[0]) is None or x_dict.get(et[2]) is None:
+                continue
+            y = self.conv(et)((x_dict[et[0]], x_dict[et[2]]), graph[et])
+            out[et[2]] = y if et[2] not in out else out[et[2]] + y
+        return {t: torch.relu(v) for t, v in out.items()} if act == "relu" else out
+
+    def _forward_relations(self, xs, graph: HeteroLayerGraph, act=None):
+        """The same layer relation by relation through ``GATConv`` (autograd: the training route of a call group)."""
+        x = {t: (v.materialize() if isinstance(v, LazyRows) else v) for t, v in xs.items()}
+        dev = next(iter(x.values())).device
+        out = {t: torch.zeros((n, self._width(t)), dtype=torch.float32, device=dev) for t, n in graph.n_out.items() if n > 0}
+        for r in graph.relations:
+            if r.n_rows == 0:
+                continue
+            et = r.edge_type
+            y = self.conv(et)((x[et[0]], x[et[2]][r.dst_rows]), [r.row_ptr, r.col])
+            rows = r.out_rows if r.out_rows is not None else torch.arange(r.n_rows, device=dev)
+            out[et[2]] = out[et[2]].index_add(0, rows, y)
+        return {t: torch.relu(v) for t, v in out.items()} if act == "relu" else out

@@ -90,6 +90,8 @@ def test_gat_aggregate_heads_matches_oracle_and_transform_first(oracle_mod, hipl
 
 
 def test_mag_pipeline_matches_cpu_port(oracle_mod, hiplib):
+    """The config-5 path through the PACKAGE — GraphStore + FeatureStore -> NeighborLoader.call_groups() (HeteroCallGroup) ->
+    2 x nn.HeteroConv{GATConv(., 64, heads=4)} — against the float64 composition on the C oracle, mini-batch by mini-batch."""
     import torch
     import bench_mag as bm
     dev = torch.device("cuda", 0)
@@ -100,12 +102,30 @@ def test_mag_pipeline_matches_cpu_port(oracle_mod, hiplib):
     g = torch.Generator(device=dev).manual_seed(1)
     tables = {t: torch.rand((num_nodes[t], bm.F_IN), generator=g, device=dev) * 2 - 1 for t in ntypes}
     params = bm.make_params(etypes, ntypes, dev)
+    model = bm.build_model(params, etypes, ntypes, dev)
     B, G = 64, 4
-    pipe = bm.MagPipeline(graphs, num_nodes, tables, params, dev, B, G)
     seeds = torch.randperm(num_nodes["paper"], generator=g, device=dev)[:B * G]
-    out, edges, n_nodes, launches = pipe.forward(*pipe.sample(seeds, 0))
+    loader = bm.make_loader(bm.build_mag_like.graph_store, tables, seeds, B, G)
+    groups = list(loader.call_groups())
+    assert len(groups) == 1
+    grp = groups[0]
+    with torch.no_grad():
+        out = bm.forward_group(model, grp)
+        # the relation-by-relation route (GATConv modules, transform-first: what trains) computes the same layer
+        h = grp.node_attr("x", lazy=False)
+        for j, layer in enumerate(model):
+            h = layer._forward_relations(h, grp.layer_graph(j), act="relu")
     torch.cuda.synchronize()
+    edges = grp.num_edges
+    launches = [r for j in range(2) for r in grp.layer_graph(j).relations]
     assert out.shape == (B * G, bm.HC) and edges > 0 and len(launches) >= 8
+    assert float((h["paper"] - out).abs().max()) <= 2e-5 * float(out.abs().max())
+    assert sum(sum(v) for v in grp.num_sampled_edges.values()) == edges
+    fanout, hops = {et: [25, 10] for et in etypes}, 2
+
+    class pipe:      # (names the checks below were written against)
+        pass
+    pipe.fanout, pipe.hops = fanout, hops
     hg = {et: (gr.row_ptr.cpu().numpy(), gr.col.cpu().numpy()) for et, gr in graphs.items()}
     tables_h = {t: v.cpu().numpy() for t, v in tables.items()}
     params_h = [dict(rel={et: {k: v.cpu() for k, v in w.items()} for et, w in p["rel"].items()},
