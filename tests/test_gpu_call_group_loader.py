@@ -259,3 +259,82 @@ def test_group_rows_pool_reuses_a_buffer_only_when_nothing_refers_to_it():
     assert len(ptrs) == 5 and ptrs[0] == ptrs[1], ptrs              # released -> reused
     assert ptrs[2] != ptrs[1] and ptrs[3] not in (ptrs[1],) and ptrs[4] not in (ptrs[1],), ptrs
     assert kept is not None and torch.equal(kept.cpu(), feat[list(loader.call_groups())[1].n_id.cpu()][5:7])
+
+
+@pytest.mark.parametrize("hops", [2, 3])
+def test_hetero_call_groups_equal_the_per_batch_loader(hiplib, hops):
+    """``NeighborLoader.call_groups()`` on a heterogeneous graph: every mini-batch inside a ``HeteroCallGroup`` is the
+    ``HeteroData`` ``for batch in loader`` yields (node lists, counts), and a stack of ``nn.HeteroConv{GATConv}`` layers over the
+    group's TRIMMED per-layer relation hops (one-kernel relations, aggregate-first) gives the seeds the outputs of PyG's own
+    formulation — every layer over all sampled edges of the mini-batch, transform-first, in float64 — for 2 and 3 hops, a ragged
+    last mini-batch included."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import HeteroCallGroup, NeighborLoader
+    from wholegraph_amd import nn
+    torch.manual_seed(4 + hops)
+    n = {"paper": 3000, "author": 1500, "venue": 40}
+    rel = {("paper", "cites", "paper"): 20000, ("author", "writes", "paper"): 9000, ("paper", "rev_writes", "author"): 9000,
+           ("venue", "publishes", "paper"): 3000, ("paper", "rev_publishes", "venue"): 3000}
+    gs, fs = GraphStore(), FeatureStore()
+    for (s, r, d), m in rel.items():
+        gs[(s, r, d), "coo", False, (n[s], n[d])] = torch.stack([torch.randint(0, n[s], (m,)), torch.randint(0, n[d], (m,))])
+    feat = {t: torch.randn(n[t], 128) for t in n}
+    for t in n:
+        fs[t, "x", None] = feat[t].cuda()
+    B = 32
+    seeds = torch.randperm(n["paper"])[:B * 5 + 7].cuda()
+    fan = {et: [4, 3, 2][:hops] for et in rel}
+    mk = lambda per_call: NeighborLoader((fs, gs), fan, input_nodes=("paper", seeds), batch_size=B, shuffle=False,      # noqa: E731
+                                         random_state=3, local_seeds_per_call=per_call)
+    batches = list(mk(B))
+    layers = []
+    for j in range(hops):
+        layers.append(nn.HeteroConv({et: nn.GATConv(128 if j == 0 else 256, 64, heads=4, add_self_loops=False) for et in rel}).cuda())
+    groups = list(mk(B * 2).call_groups())
+    assert all(isinstance(g, HeteroCallGroup) for g in groups) and [g.n_batches for g in groups] == [2, 2, 1, 1]
+    assert sum(g.num_edges for g in groups) == sum(int(b[et].edge_index.shape[1]) for b in batches for et in rel)
+    b0 = 0
+    for grp in groups:
+        with torch.no_grad():
+            h = grp.x_dict
+            for j, layer in enumerate(layers):
+                h = layer(h, grp.layer_graph(j), act="relu")
+        out = h["paper"]
+        assert out.shape == (grp.num_seeds, 256)
+        ptr = {t: grp.node_ptr[t].tolist() for t in n}
+        seed_ptr = grp.batch_ptr.tolist()
+        for j in range(grp.n_batches):
+            batch = batches[b0 + j]
+            for t in n:
+                assert torch.equal(grp.n_id[t][ptr[t][j]:ptr[t][j + 1]], batch[t].n_id), (b0 + j, t)
+            # PyG's formulation on the mini-batch alone, float64: every layer over ALL its sampled edges
+            x = {t: feat[t][batch[t].n_id.cpu()].double().cuda() for t in n}
+            for layer in layers:
+                y = {}
+                for et in rel:
+                    c = layer.conv(et)
+                    ei = batch[et].edge_index
+                    if ei.shape[1] == 0 and et[2] not in y:
+                        y.setdefault(et[2], torch.zeros((x[et[2]].shape[0], 256), dtype=torch.float64, device="cuda"))
+                        continue
+                    w = c.lin.weight.double().t()
+                    hs, hd = (x[et[0]] @ w).view(-1, 4, 64), (x[et[2]] @ w).view(-1, 4, 64)
+                    a_s, a_d = (hs * c.att_src.double()).sum(-1), (hd * c.att_dst.double()).sum(-1)
+                    e = torch.nn.functional.leaky_relu(a_s[ei[0]] + a_d[ei[1]], 0.2)
+                    e = e - torch.zeros((x[et[2]].shape[0], 4), dtype=torch.float64, device="cuda").index_reduce_(
+                        0, ei[1], e, "amax", include_self=False)[ei[1]]
+                    p = e.exp()
+                    den = torch.zeros((x[et[2]].shape[0], 4), dtype=torch.float64, device="cuda").index_add_(0, ei[1], p)
+                    alpha = p / den[ei[1]]
+                    msg = torch.zeros((x[et[2]].shape[0], 4, 64), dtype=torch.float64, device="cuda").index_add_(
+                        0, ei[1], alpha.unsqueeze(-1) * hs[ei[0]])
+                    res = msg.view(-1, 256) + (c.bias.double() if c.bias is not None else 0)
+                    y[et[2]] = res if et[2] not in y else y[et[2]] + res
+                x = {t: torch.relu(v) for t, v in y.items()}
+            want = x["paper"][:batch["paper"].batch_size]
+            got = out[seed_ptr[j]:seed_ptr[j + 1]].double()
+            scale = want.abs().amax(dim=1, keepdim=True).clamp_(min=1e-30)
+            assert bool(((got - want).abs() <= 1e-5 * scale + 1e-7).all()), (b0 + j, float(((got - want).abs() / scale).max()))
+        b0 += grp.n_batches
+    assert b0 == len(batches) == 6
