@@ -703,11 +703,14 @@ class BaseSampler:
                                                                                seed_time=index.time):
             n_seeds = nn[0]
             ids = input_id[b * bs: b * bs + n_seeds]
+            grp = getattr(self.__sampler, "current_group", None)
+            ready = grp is not None and "num_sampled_nodes" in grp[0]
             out = SamplerOutput(
                 node=node, row=row, col=col, edge=edge, batch=node[:n_seeds],
-                num_sampled_nodes=torch.tensor(nn), num_sampled_edges=torch.tensor(ne),
+                num_sampled_nodes=grp[0]["num_sampled_nodes"][grp[1]] if ready else torch.tensor(nn),
+                num_sampled_edges=grp[0]["num_sampled_edges"][grp[1]] if ready else torch.tensor(ne),
                 metadata=(ids, None if index.time is None else index.time[b * bs: b * bs + n_seeds]))
-            out._call_group = getattr(self.__sampler, "current_group", None)
+            out._call_group = grp
             yield out
 
     def sample_from_edges(self, index, neg_sampling=None, random_state: int = 62, **kwargs) -> Iterator[SamplerOutput]:
@@ -845,13 +848,18 @@ def group_attribute_views(feature_store, ctx):
     return views
 
 
-def filter_store_from_group(feature_store, views, j, node, row, col, edge) -> Data:
-    """``filter_store`` for batch j of a call group whose attributes were fetched by ``group_attribute_views``."""
+def filter_store_from_group(feature_store, views, j, node, row, col, edge, ctx=None) -> Data:
+    """``filter_store`` for batch j of a call group whose attributes were fetched by ``group_attribute_views``.  ``ctx``: the
+    group's context — its ``edge_index`` / ``csr`` lists hold every batch's edge list and destination-major CSR as views of
+    arrays made once for the group."""
     data = Data()
-    data.edge_index = torch.stack([row, col], dim=0)
+    ready = ctx.get("edge_index") if ctx is not None else None
+    data.edge_index = ready[j] if ready is not None else torch.stack([row, col], dim=0)
     # a call-group walk emits hop after hop, a hop's edges in the CSR order of its frontier, every hop's destinations behind
     # the previous hop's: destination-major (wholegraph_amd.nn._to_csr then skips its sort)
     data.edge_index._wgamd_dst_sorted = data.edge_index._version     # (nn._to_csr: valid while the tensor is not edited in place)
+    if ready is not None:
+        data.edge_index._wgamd_csr = (data.edge_index._version, int(node.size(0))) + ctx["csr"][j]
     for attr in feature_store.get_all_tensor_attrs():
         is_edge = isinstance(attr.group_name, tuple)
         v = views[attr.group_name, attr.attr_name]
@@ -919,7 +927,7 @@ class SampleIterator:
             self.__group_cache = cache
             if self.__padder is not None:
                 self.__padder.group_done()
-        return filter_store_from_group(self.__feature_store, cache[1], j, s.node, s.row, s.col, s.edge)
+        return filter_store_from_group(self.__feature_store, cache[1], j, s.node, s.row, s.col, s.edge, ctx)
 
     def __next__(self):
         pad = self.__padder

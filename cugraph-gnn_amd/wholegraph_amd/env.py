@@ -33,10 +33,18 @@ def wm_dtype_to_torch(code):
     return _WM_TO_TORCH[code]
 
 
+_HAVE_GPU = None
+
+
 def get_stream():
-    """Current HIP stream of torch as the ``void* stream`` argument (wholegraph_env.py:20-27)."""
-    if torch.cuda.is_available():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Current HIP stream of torch as the ``void* stream`` argument (wholegraph_env.py:20-27).  (Through torch's raw-stream
+    entry point: ``torch.cuda.current_stream()`` builds a Stream object and resolves the device index in Python, 13 us per
+    call — every op of a per-mini-batch loop pays it.)"""
+    global _HAVE_GPU
+    if _HAVE_GPU is None:
+        _HAVE_GPU = torch.cuda.is_available()
+    if _HAVE_GPU:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
     return ctypes.c_void_p(0)
 
 

@@ -596,6 +596,9 @@ def _to_csr(edge_index, n_dst):
     """edge_index [2,E] (row 0 = source j, row 1 = destination i; PyG) -> destination-major CSR (edge order kept inside a
     destination).  int64 ids on the device go through ``wgamd_coo_to_csr_i64`` (one radix sort over the bits a destination
     id needs); anything else through the torch formulation of the same."""
+    ready = getattr(edge_index, "_wgamd_csr", None)      # (version, n_dst, row_ptr, col): made by the loader for its call group
+    if ready is not None and ready[0] == edge_index._version and ready[1] == n_dst:
+        return ready[2], ready[3]
     src, dst = edge_index[0], edge_index[1]
     # (the flag is the tensor's version counter at the time the loader vouched for the order: an in-place edit of the
     #  edge list afterwards — a permutation, self loops written into the same storage — bumps the counter and the sort runs)
@@ -621,6 +624,19 @@ def _to_csr(edge_index, n_dst):
     row_ptr = torch.zeros(n_dst + 1, dtype=torch.int32, device=dst.device)
     row_ptr[1:] = torch.cumsum(counts, 0)
     return row_ptr, col
+
+
+_ARANGE = {}
+
+
+def _arange(n: int, device) -> torch.Tensor:
+    """``arange(n)`` int64 on ``device`` as a view of one grow-only buffer (the "self rows" of a mini-batch graph whose
+    destinations are the first rows of x)."""
+    buf = _ARANGE.get(device)
+    if buf is None or buf.shape[0] < n:
+        buf = torch.arange(max(n * 2, 1 << 16), dtype=torch.int64, device=device)
+        _ARANGE[device] = buf
+    return buf[:n]
 
 
 def _split_graph(graph, n_dst):
@@ -744,6 +760,32 @@ def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tens
     return gx.index_add_(0, hop.self_rows, gz @ w_r)
 
 
+def _sage_layer_launch(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean):
+    """The layer's launches (one per hop of ``graph``); ``ctx`` = the autograd context of ``_SageLayer`` (then the aggregate is
+    kept wherever a gradient is needed) or None."""
+    N, F_ = w_l.shape
+    Np = _padded_width(N)
+    keep = ctx is not None and any(ctx.needs_input_grad[:4])
+    buf = torch.empty((graph.n_rows, Np), dtype=torch.float32, device=src.device)
+    w_t, aggs, at = conv._weight_t(), [], 0
+    for h in graph.hops:
+        n = h.n_rows
+        agg = torch.empty((n, F_), dtype=torch.float32, device=src.device) if keep and n > 0 else None
+        if n > 0:
+            sage_layer_fused_forward(h.row_ptr, h.col, src, h.self_rows, w_t, bias, relu=relu, mean=mean, src_ids=ids,
+                                     out=buf[at:at + n, :N], agg_out=agg)
+        aggs.append(agg)
+        at += n
+    out = buf[:, :N]
+    if keep:
+        if ctx.needs_input_grad[0] and ids is not None:
+            raise NotImplementedError("gradient w.r.t. a feature table read through ids (LazyRows): trainable node "
+                                      "embeddings go through wholegraph_amd.embedding")
+        ctx.save_for_backward(src, w_l, w_r, out)
+        ctx.conv, ctx.graph, ctx.ids, ctx.relu, ctx.mean, ctx.aggs, ctx.has_bias = conv, graph, ids, relu, mean, aggs, bias is not None
+    return out
+
+
 class _SageLayer(torch.autograd.Function):
     """The one-kernel SAGE layer over a ``LayerGraph`` with its backward pass on the HIP kernels.  Forward: the inference
     launch (``wgamd_sage_layer_fused_bf16x3``), which under autograd also keeps the aggregate half of its operand (same
@@ -753,27 +795,7 @@ class _SageLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean):
-        N, F_ = w_l.shape
-        Np = _padded_width(N)
-        keep = any(ctx.needs_input_grad[:4])
-        buf = torch.empty((graph.n_rows, Np), dtype=torch.float32, device=src.device)
-        w_t, aggs, at = conv._weight_t(), [], 0
-        for h in graph.hops:
-            n = h.n_rows
-            agg = torch.empty((n, F_), dtype=torch.float32, device=src.device) if keep and n > 0 else None
-            if n > 0:
-                sage_layer_fused_forward(h.row_ptr, h.col, src, h.self_rows, w_t, bias, relu=relu, mean=mean, src_ids=ids,
-                                         out=buf[at:at + n, :N], agg_out=agg)
-            aggs.append(agg)
-            at += n
-        out = buf[:, :N]
-        if keep:
-            if ctx.needs_input_grad[0] and ids is not None:
-                raise NotImplementedError("gradient w.r.t. a feature table read through ids (LazyRows): trainable node "
-                                          "embeddings go through wholegraph_amd.embedding")
-            ctx.save_for_backward(src, w_l, w_r, out)
-            ctx.conv, ctx.graph, ctx.ids, ctx.relu, ctx.mean, ctx.aggs, ctx.has_bias = conv, graph, ids, relu, mean, aggs, bias is not None
-        return out
+        return _sage_layer_launch(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean)
 
     @staticmethod
     def backward(ctx, g):
@@ -865,8 +887,12 @@ class SAGEConv(torch.nn.Module):
             one_kernel = not (torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                                            or (not lazy and x.requires_grad)))
         if one_kernel:
-            return _SageLayer.apply(src, self.lin_l.weight, self.lin_r.weight, self.lin_l.bias, self, graph,
-                                    x.ids if lazy else None, relu, self.aggr == "mean")
+            args = (src, self.lin_l.weight, self.lin_r.weight, self.lin_l.bias, self, graph, x.ids if lazy else None, relu,
+                    self.aggr == "mean")
+            if not (torch.is_grad_enabled() and (self.lin_l.weight.requires_grad or self.lin_r.weight.requires_grad
+                                                 or (not lazy and x.requires_grad))):
+                return _sage_layer_launch(None, *args)       # same launches; no autograd node to build (~10 us per call)
+            return _SageLayer.apply(*args)
         # aggregation kernel(s) + library GEMM: every hop's [mean | self] rows, then lin_l / lin_r as torch modules
         xd = x.materialize() if lazy else x
         outs = []
@@ -894,8 +920,19 @@ class SAGEConv(torch.nn.Module):
             # one sampled (sub)graph whose destinations are the first rows of x: the whole layer as ONE kernel, forward and
             # backward (no library GEMM — whose shape heuristics alone cost ~1 ms for every new row count a mini-batch brings)
             n = row_ptr.shape[0] - 1
-            hop = HopGraph(row_ptr, col, torch.arange(n, dtype=torch.int64, device=x_src.device))
-            return self._forward_layer(x_src, LayerGraph([hop]), act)
+            # the hop (and with it its transpose, for the backward pass) belongs to the GRAPH, not to the layer: every layer a
+            # model runs over one edge_index shares it
+            keep = getattr(graph, "_wgamd_hop", None) if isinstance(graph, torch.Tensor) else None
+            if keep is not None and keep[0] == graph._version and keep[1] == n and keep[2].row_ptr is row_ptr:
+                lg = keep[3]
+            else:
+                lg = LayerGraph([HopGraph(row_ptr, col, _arange(n, x_src.device))])
+                if isinstance(graph, torch.Tensor):
+                    try:
+                        graph._wgamd_hop = (graph._version, n, lg.hops[0], lg)
+                    except AttributeError:
+                        pass
+            return self._forward_layer(x_src, lg, act)
         out = self.lin_l(spmm_csr(x_src, row_ptr, col, self.aggr))
         if self.lin_r is not None:
             out = out + self.lin_r(x_dst[: out.shape[0]])
