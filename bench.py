@@ -241,7 +241,13 @@ class SagePipeline:
         fused_layer = mode.startswith("fused")
         u_last = n_uniq[L - 1]
         n_id = res.unique[L - 1][:u_last]
-        if fused_fetch:
+        lazy = None
+        if fused_fetch and self.distributed:
+            # a PEER-MAPPED partitioned table: layer 1 reads every rank's partition itself through byte offsets over this
+            # process's mapping (wgamd_mapped_row_offsets): remote rows cross xGMI inside the layer kernel, no gathered copy
+            lazy = stage("row_offsets(peer-mapped)", lambda: nn.mapped_lazy_rows(self.feat, n_id))
+            x = None
+        elif fused_fetch:
             x = None          # never materialised: layer 1 reads the feature table through n_id
         elif self.distributed:
             if timers is not None:   # stage probe only (untimed here): what the de-duplicated fetch puts on the wire
@@ -268,9 +274,10 @@ class SagePipeline:
             ptr, nbr = res.offsets[k][:n_dst + 1], res.neighbor_row[k][:n_edges[k]]
             if fused_layer and nn.sage_layer_fused_preferred(self.dims[j], self.dims[j + 1]):
                 fetch = j == 0 and fused_fetch
+                table = (lazy.table if lazy is not None else self.feat.local_tensor) if fetch else h
                 h = stage(("fetch+" if fetch else "") + "sage_layer%d(fused)" % (j + 1), lambda: nn.sage_layer_fused_forward(
-                    ptr, nbr, self.feat.local_tensor if fetch else h, rows, self.w_t[j], self.bias[j], relu=j < L - 1,
-                    mean=True, src_ids=n_id if fetch else None,
+                    ptr, nbr, table, rows, self.w_t[j], self.bias[j], relu=j < L - 1,
+                    mean=True, src_ids=(lazy.ids if lazy is not None else n_id) if fetch else None,
                     # (row stride = the width the kernel runs at: a 47-class head is computed as 64 zero-padded columns)
                     out=self.rows_buffer("h%d" % j, n_dst, -(-self.dims[j + 1] // 64) * 64)[:, :self.dims[j + 1]]))
                 continue
@@ -862,6 +869,14 @@ def main():
         for m in ([] if (args.no_variants or world > 1) else others):
             vs, ve = measure(pipe, m)
             variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
+        lazy_pass = None
+        if placement == "partitioned_mapped" and fusable and not args.no_variants:
+            # the same groups with the fetch folded into layer 1 OVER THE MAPPING (no gather, remote rows read by the layer
+            # kernel across xGMI): every rank runs it (measure() is collective), reported next to the placement's gather value
+            vs, ve = measure(pipe, "fused_fetch")
+            lazy_pass = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3,
+                         "note": "layer 1 reads the peer-mapped partitions itself (wgamd_mapped_row_offsets + "
+                                 "WGAMD_IDS_BYTE_OFFSETS): x = feat[n_id] never exists"}
         if col_alt is not None and world == 1:
             # the same pipeline with int32 ids (csr_col, seeds, node lists): the WholeGraph test default
             pipe32 = SagePipeline(row_ptr, col_alt, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
@@ -886,7 +901,7 @@ def main():
         split_ms = probe_stages(pipe, "split", 10)[0] if head_mode != "split" else stage_ms
         results[placement] = dict(dt=dt, edges=edges_total, variants=variants, stage_ms=stage_ms, psizes=psizes,
                                   split_ms=split_ms, head_mode=head_mode, stage_n=stage_n, pipe=pipe, feat=feat,
-                                  per_rank=per_rank)
+                                  per_rank=per_rank, lazy_pass=lazy_pass)
 
     def emit_line():
         """Rank 0 prints the ONE JSON line from whatever placements were measured; the headline is the first of HEAD_PREF
@@ -1063,6 +1078,8 @@ def main():
                     pr = results[name]
                     rep = {"value": pr["edges"] / pr["dt"], "ms_per_step": pr["dt"] / args.steps * 1e3,
                            "per_rank_value": [round(e_ / t_, 1) for t_, e_ in pr["per_rank"]]}
+                    if pr.get("lazy_pass"):
+                        rep["fetch_in_layer"] = pr["lazy_pass"]
                     if name != "replicated":
                         p_src = sum(s_[2 * L - 1] for s_ in pr["psizes"]) / pr["stage_n"]
                         # the partitioned fetch sends every DISTINCT row of the call group once (gather(dedup="auto"),

@@ -616,6 +616,37 @@ void distributed_rows_op(bool scatter, wholememory_handle_t h, wholememory_matri
 }  // namespace wgamd
 
 // ------------------------------------------------------------------------------------------------------
+// ids of a peer-mapped table -> where their rows start, as byte offsets from the lowest partition base
+namespace wgamd {
+namespace {
+template <typename IdxT>
+__global__ void mapped_offsets_kernel(const mapped_view* __restrict__ view, const char* base0, int64_t row0, int64_t entry_bytes,
+                                      int64_t col0_bytes, const IdxT* __restrict__ idx, int64_t n, int64_t* __restrict__ out)
+{
+  __shared__ int64_t s_off[kMaxMappedRanks + 1];
+  __shared__ char* s_base[kMaxMappedRanks];
+  const int W = view->W;
+  for (int r = threadIdx.x; r <= W; r += blockDim.x) {
+    s_off[r] = view->entry_off[r];
+    if (r < W) s_base[r] = view->base[r];
+  }
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t id    = (int64_t)idx[i] + row0;
+    const bool ok = idx[i] >= 0 && id < s_off[W];
+    id            = ok ? id : s_off[0];
+    int lo = 0, hi = W;   // owner: last r with entry_off[r] <= id
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_off[mid] <= id) lo = mid;
+      else hi = mid;
+    }
+    out[i] = ok ? (s_base[lo] - base0) + (id - s_off[lo]) * entry_bytes + col0_bytes : (int64_t)-1;
+  }
+}
+}  // namespace
+}  // namespace wgamd
+
 extern "C" {
 
 using namespace wgamd;
@@ -1045,6 +1076,50 @@ wholememory_error_code_t wgamd_get_peer_pointers(void** pointers, wholememory_ha
   if (h->peer_ptr.empty()) return WHOLEMEMORY_NOT_SUPPORTED;
   for (int r = 0; r < h->comm->size; r++) pointers[r] = h->peer_ptr[r];
   return WHOLEMEMORY_SUCCESS;
+}
+
+/* Row addresses of a peer-mapped (CHUNKED / CONTINUOUS) 2-D table for a kernel that reads the rows ITSELF — the one-kernel
+ * SAGE layer with the feature fetch folded in, now over xGMI (the reference's mapped gather reads the partitions through
+ * global references the same way: wholememory_ops/functions/gather_scatter_func.cuh:242-505, gather_op_impl_mapped.cu):
+ * offsets[i] = byte distance of row ids[i] from *base (the lowest partition base of this process's mapping); -1 for an id
+ * that is negative or past the last row.  A single-rank handle answers with its own partition.  Not collective. */
+wholememory_error_code_t wgamd_mapped_row_offsets(wholememory_tensor_t table, const void* ids, wholememory_dtype_t ids_dtype,
+                                                  int64_t n, int64_t* offsets, void** base, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_mapped_row_offsets", [&] {
+    WG_REQUIRE_INPUT(table && base && n >= 0 && (n == 0 || (ids && offsets)), "null pointer");
+    WG_REQUIRE_INPUT(ids_dtype == WHOLEMEMORY_DT_INT || ids_dtype == WHOLEMEMORY_DT_INT64, "ids must be INT or INT64");
+    wholememory_handle_t h = static_cast<wholememory_handle_t>(wholememory_tensor_get_memory_handle(table));
+    if (h == nullptr) throw invalid_input("not a handle-backed tensor");
+    const wholememory_tensor_description_t* d = wholememory_tensor_get_tensor_description(table);
+    WG_REQUIRE_INPUT(d->dim == 2, "a 2-D table");
+    const int64_t tes = (int64_t)dtype_size(d->dtype), stride = d->strides[0];
+    const int64_t entry_bytes = stride * tes;
+    WG_EXPECTS((int64_t)h->granularity == entry_bytes, "tensor row stride != handle granularity");
+    const int64_t row0 = d->storage_offset / stride, col0 = d->storage_offset % stride;
+    auto st = static_cast<hipStream_t>(stream);
+    mapped_view single{};
+    const mapped_view* d_view = h->d_view;
+    const char* base0         = nullptr;
+    if (d_view == nullptr) {
+      if (h->comm->size != 1 && h->peer_ptr.empty()) throw logic_error("not a peer-mapped handle (DISTRIBUTED rows are not addressable)");
+      throw logic_error("single-partition handle: read the local tensor directly");
+    }
+    for (int r = 0; r < h->comm->size; r++) {
+      const char* p = static_cast<const char*>(h->peer_ptr[r]);
+      if (p != nullptr && (base0 == nullptr || p < base0)) base0 = p;
+    }
+    *base = const_cast<char*>(base0);
+    if (n == 0) return;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    if (ids_dtype == WHOLEMEMORY_DT_INT)
+      mapped_offsets_kernel<int32_t><<<grid, 256, 0, st>>>(d_view, base0, row0, entry_bytes, col0 * tes, static_cast<const int32_t*>(ids), n, offsets);
+    else
+      mapped_offsets_kernel<int64_t><<<grid, 256, 0, st>>>(d_view, base0, row0, entry_bytes, col0 * tes, static_cast<const int64_t*>(ids), n, offsets);
+    WG_HIP_CHECK(hipGetLastError());
+    (void)single;
+  });
 }
 
 /* the two HIP IPC steps on their own (what wholememory_malloc does per peer): a 64-byte handle of a hipMalloc'ed block,

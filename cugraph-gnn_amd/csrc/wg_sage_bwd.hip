@@ -30,7 +30,7 @@ struct wgrad_args {
   const float* agg;
   int64_t ld_agg;
   const float* x;
-  int64_t ldx;
+  int64_t ldx;                  // floats per unit of self_global: the row stride — or 1 when the rows were given as byte offsets
   int F;
   const int64_t* self_global;   // row of x holding destination i itself (self_rows with the src_ids indirection applied)
   int64_t n_rows;
@@ -44,12 +44,14 @@ struct wgrad_args {
   int KL;                       // feature rows of the LDS planes and of a partial sum: 2F rounded up to 32
 };
 
-__global__ void compose_self_kernel(const int64_t* __restrict__ self_rows, const void* __restrict__ src_ids, int ids_int32,
+// kind: 1 int32 row numbers, 2 int64 row numbers, 3 int64 BYTE offsets (-> float offsets: rows are 16-B aligned)
+__global__ void compose_self_kernel(const int64_t* __restrict__ self_rows, const void* __restrict__ src_ids, int kind,
                                     int64_t n, int64_t* __restrict__ out)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t s = self_rows[i];
-    out[i]          = ids_int32 ? (int64_t) static_cast<const int32_t*>(src_ids)[s] : static_cast<const int64_t*>(src_ids)[s];
+    const int64_t v = kind == 1 ? (int64_t) static_cast<const int32_t*>(src_ids)[s] : static_cast<const int64_t*>(src_ids)[s];
+    out[i]          = kind == 3 ? v >> 2 : v;
   }
 }
 
@@ -354,8 +356,9 @@ extern "C" wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, in
     WG_REQUIRE_INPUT(ld_agg >= F && ldx >= F && ldg >= N && (act_out == nullptr || ld_act >= N), "leading dimension too small");
     if (ld_agg % 4 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(agg) & 15) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
       throw logic_error("agg / x rows must be 16-B aligned");
-    if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64)
-      throw invalid_input("src_ids must be INT or INT64");
+    const bool byte_offsets = src_ids != nullptr && src_ids_dtype == WGAMD_IDS_BYTE_OFFSETS;
+    if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64 && !byte_offsets)
+      throw invalid_input("src_ids must be INT, INT64 or WGAMD_IDS_BYTE_OFFSETS");
     const wgrad_plan p = plan_for(F, N);
     const int cus      = stream_cu_count(st);
     const int64_t tiles = (n_rows + p.TR - 1) / p.TR;
@@ -367,11 +370,11 @@ extern "C" wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, in
     if (src_ids != nullptr) {
       int64_t* composed = reinterpret_cast<int64_t*>(ws + ((part_bytes(p, max_grid_x(p)) + 255) & ~(size_t)255));
       compose_self_kernel<<<(int)std::min<int64_t>((n_rows + 255) / 256, 4096), 256, 0, st>>>(
-        self_rows, src_ids, src_ids_dtype == WHOLEMEMORY_DT_INT, n_rows, composed);
+        self_rows, src_ids, byte_offsets ? 3 : (src_ids_dtype == WHOLEMEMORY_DT_INT ? 1 : 2), n_rows, composed);
       WG_HIP_CHECK(hipGetLastError());
       self_global = composed;
     }
-    wgrad_args a{agg, ld_agg, x, ldx, F, self_global, n_rows, grad_out, ldg, act_out, ld_act, N, part,
+    wgrad_args a{agg, ld_agg, x, byte_offsets ? (int64_t)1 : ldx, F, self_global, n_rows, grad_out, ldg, act_out, ld_act, N, part,
                  (tiles + grid_x - 1) / grid_x * p.TR, p.KL};
     const dim3 grid(grid_x, p.grid_y);
     if (p.TR == 32) launch_mt<32>(p, a, grid, st);

@@ -382,7 +382,8 @@ sage_layer_mfma_kernel(mfma_args a)
           for (int rt = 0; rt < RT; rt++) {
             const int64_t row  = row0 + rt * 32 + (lane & 31);
             const int64_t srow = a.self_rows[row < a.n_rows ? row : a.n_rows - 1];
-            self_ptr[rt]       = a.x + table_row<IdT>(src_ids, srow) * a.ldx + (lane >> 5) * 8;
+            self_ptr[rt]       = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + table_row<IdT>(src_ids, srow) * a.row_scale) +
+                           (lane >> 5) * 8;
           }
 #pragma unroll
           for (int rt = 0; rt < RT; rt++)
@@ -686,20 +687,25 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3_train(const in
     const uint64_t xb = x_rows > 0 ? (uint64_t)x_rows * (uint64_t)ldx * 4u : 0;
     mfma_args a{row_ptr, col, n_rows, x, ldx, (uint32_t)(xb > 0 && xb < (1ull << 31) ? xb : 0), F, src_ids, self_rows, mean,
                 static_cast<const float*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr,
-                agg_out, ld_agg};
+                ldx * 4, agg_out, ld_agg};
+    const bool byte_offsets = src_ids != nullptr && src_ids_dtype == WGAMD_IDS_BYTE_OFFSETS;
+    if (byte_offsets) {      // rows addressed by byte offsets from x (a peer-mapped table): 64-bit addressing, no extent
+      a.row_scale = 1;
+      a.x_bytes   = 0;
+    }
     // WGAMD_SAGE_DEBUG=<bits> (tuning only; results are WRONG with 4 / 8): the ablation switches of mfma_args::debug
     static const int dbg = [] { const char* e = getenv("WGAMD_SAGE_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug = dbg;
     auto st = static_cast<hipStream_t>(stream);
-    if (agg_out == nullptr && sage_ws_supported(F, N)) {
+    if (agg_out == nullptr && !byte_offsets && sage_ws_supported(F, N)) {
       if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64)
         throw invalid_input("src_ids must be INT or INT64");
       return sage_ws_launch(a, src_ids == nullptr ? 0 : (src_ids_dtype == WHOLEMEMORY_DT_INT ? 1 : 2), st);
     }
     if (src_ids == nullptr) launch_groups<void>(a, st);
     else if (src_ids_dtype == WHOLEMEMORY_DT_INT) launch_groups<int32_t>(a, st);
-    else if (src_ids_dtype == WHOLEMEMORY_DT_INT64) launch_groups<int64_t>(a, st);
-    else throw invalid_input("src_ids must be INT or INT64");
+    else if (src_ids_dtype == WHOLEMEMORY_DT_INT64 || byte_offsets) launch_groups<int64_t>(a, st);
+    else throw invalid_input("src_ids must be INT, INT64 or WGAMD_IDS_BYTE_OFFSETS");
   });
 }
 #endif  // WG_MFMA_TUNE_HARNESS

@@ -57,6 +57,7 @@ struct mfma_args {
                              // 64 roles by SIMD instead of by wave order, 128 no epilogue stagger, 16 / 32 s_setprio 3 for
                              // producers / consumers
   unsigned long long* stamps;  // tuning harness only: s_memtime stamps of workgroup 0, [step][wave][begin, work done]
+  int64_t row_scale;         // bytes per unit of a row number: 4 ldx — or 1 when src_ids holds BYTE offsets (a peer-mapped table)
   float* agg_out;            // training (nullable): the finished mean / sum rows [n_rows, F] also go to HBM — the weight-gradient
   int64_t ld_agg;            // kernel (wg_sage_bwd.hip) reads them back instead of fetching every neighbour row a second time
 };
@@ -170,8 +171,8 @@ struct producer {
 #pragma unroll
     for (int it = 0; it < IT; it++) {
       m.d[it]    = v.deg[it];
-      m.src[it]  = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lcol[it]) * a.ldx * 4);
-      m.self[it] = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lself[it]) * a.ldx * 4);
+      m.src[it]  = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lcol[it]) * a.row_scale);
+      m.self[it] = (off_t)(table_row<IdT>(src_ids, (int64_t)v.lself[it]) * a.row_scale);
     }
   }
   // request the kNb neighbour rows + the self row of row `it`; every load is unconditional
@@ -410,7 +411,8 @@ struct producer {
             const int lo       = __shfl((int)(my_src & 0xffffffff), src_lane, 64);
             const int hi       = __shfl((int)(my_src >> 32), src_lane, 64);
             const int64_t rr   = (mine && j < chunk && c0 + j < deg) ? (((int64_t)hi << 32) | (uint32_t)lo) : (int64_t)0;
-            v[u]               = *reinterpret_cast<const f32x4*>(a.x + rr * a.ldx + f0c);   // dead slots read row 0, masked below
+            // (dead slots read row 0, masked below)
+            v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + rr * a.row_scale + f0c * 4);
           }
 #pragma unroll
           for (int u = 0; u < kUnroll; u++) {

@@ -21,7 +21,18 @@ import torch
 
 from wholegraph_amd import _lib as L
 from wholegraph_amd.env import get_stream
-from wholegraph_amd.nn import HeteroLayerGraph, HopGraph, LayerGraph, LazyRows, RelationHop
+from wholegraph_amd.nn import HeteroLayerGraph, HopGraph, LayerGraph, LazyRows, RelationHop, mapped_lazy_rows
+
+
+def _peer_mapped_f32(wm) -> bool:
+    """A handle-backed float32 [rows, F] table whose partitions are all addressable from this GPU (CHUNKED / CONTINUOUS over
+    more than one rank of a node)."""
+    path = getattr(wm, "fetch_path", None)
+    try:
+        return (path is not None and "peer-mapped" in path() and wm.dtype == torch.float32 and wm.dim() == 2
+                and wm.comm.get_size() > 1)
+    except Exception:      # noqa: BLE001  (a tensor class without these queries)
+        return False
 
 
 class CallGroup:
@@ -105,6 +116,8 @@ class CallGroup:
         if (lazy and table is not None and not getattr(wm, "is_distributed", True) and table.is_cuda and table.dim() == 2
                 and table.dtype == torch.float32 and table.stride(1) == 1):
             return LazyRows(table, self.n_id)
+        if lazy and _peer_mapped_f32(wm):
+            return mapped_lazy_rows(wm, self.n_id)      # partitions on several GPUs, every one mapped here: read in the layer
         return _fetch_rows_agreed(t, self.n_id)
 
     @property

@@ -30,6 +30,8 @@ _ERROR_NAMES = ["SUCCESS", "UNKNOW_ERROR", "NOT_IMPLEMENTED", "LOGIC_ERROR", "CU
 (DT_UNKNOWN, DT_FLOAT, DT_HALF, DT_DOUBLE, DT_BF16, DT_INT, DT_INT64, DT_INT16, DT_INT8,
  DT_COUNT) = range(10)
 
+IDS_BYTE_OFFSETS = 64   # WGAMD_IDS_BYTE_OFFSETS (include/wgamd_ext.h): src_ids = int64 byte offsets from x
+
 # wholememory_memory_allocation_type_t
 MA_NONE, MA_DEVICE, MA_HOST, MA_PINNED = range(4)
 
@@ -156,6 +158,7 @@ SYMBOLS = {
     "wholememory_communicator_barrier": (c_int, [c_void_p]),
     "wgamd_communicator_rccl_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "wgamd_get_peer_pointers": (c_int, [POINTER(c_void_p), c_void_p]),
+    "wgamd_mapped_row_offsets": (c_int, [_T, c_void_p, c_int, c_int64, c_void_p, POINTER(c_void_p), c_void_p]),
     "wgamd_ipc_export": (c_int, [c_void_p, c_void_p]),
     "wgamd_ipc_open": (c_int, [c_void_p, POINTER(c_void_p)]),
     "wgamd_ipc_close": (c_int, [c_void_p]),

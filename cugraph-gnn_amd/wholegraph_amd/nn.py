@@ -19,6 +19,12 @@ from . import _lib as L
 from .env import get_stream, torch_dtype_to_wm
 
 
+def _ids_code(x, src_ids) -> int:
+    """``src_ids_dtype`` of the layer kernels: the ids' integer type, or WGAMD_IDS_BYTE_OFFSETS when ``x`` is the address space of
+    a peer-mapped table (``MappedTable``) and ``src_ids`` holds byte offsets into it."""
+    return L.IDS_BYTE_OFFSETS if getattr(x, "byte_offset_ids", False) else torch_dtype_to_wm(src_ids.dtype)
+
+
 def _check_csr(row_ptr, col):
     assert row_ptr.dtype == torch.int32 and col.dtype == torch.int32, "per-hop CSR is int32 (sampler output)"
     assert row_ptr.is_cuda and col.is_cuda and row_ptr.is_contiguous() and col.is_contiguous()
@@ -191,7 +197,9 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     ids_ptr, ids_dt = None, 0
     if src_ids is not None:
         assert src_ids.is_contiguous()
-        ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
+        ids_ptr, ids_dt = src_ids.data_ptr(), _ids_code(x, src_ids)
+    assert ids_dt != L.IDS_BYTE_OFFSETS or (sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3"), \
+        "a peer-mapped table is read by the bf16x3 layer kernel only"
     if (sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3"
             and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):      # its epilogue stores 16 B per lane
         planes = sage_weight_planes(w_t)
@@ -255,7 +263,7 @@ def sage_wgrad(agg, x, self_rows, grad_out, grad_w_l, grad_w_r, grad_bias=None, 
     ids_ptr, ids_dt = None, 0
     if src_ids is not None:
         assert src_ids.is_contiguous()
-        ids_ptr, ids_dt = src_ids.data_ptr(), torch_dtype_to_wm(src_ids.dtype)
+        ids_ptr, ids_dt = src_ids.data_ptr(), _ids_code(x, src_ids)
     ws = _wgrad_workspace(n, F_, N, agg.device)
     L.check(L.lib().wgamd_sage_wgrad_bf16x3(
         agg.data_ptr(), agg.stride(0), x.data_ptr(), x.stride(0), F_, ids_ptr, ids_dt, self_rows.data_ptr(), n,
@@ -675,6 +683,8 @@ class LazyRows:
         return 2
 
     def materialize(self) -> torch.Tensor:
+        if self._rows is None and getattr(self, "_gather", None) is not None:
+            self._rows = self._gather()           # (a peer-mapped table: wholememory_gather over the mapping)
         if self._rows is None:
             from .tensor import local_gather
             self._rows = local_gather(self.table, self.ids, torch.empty(tuple(self.shape), dtype=self.table.dtype,
@@ -691,6 +701,45 @@ class LazyRows:
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         conv = lambda v: v.materialize() if isinstance(v, LazyRows) else v   # noqa: E731
         return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+
+class MappedTable:
+    """The address space of a PEER-MAPPED feature table (CHUNKED / CONTINUOUS handle whose partitions live on several GPUs of a
+    node, each mapped into this process) as the layer kernels take it: a base pointer, the row width, and rows given as BYTE
+    offsets from the base (``wgamd_mapped_row_offsets``).  Quacks like the [rows, F] float32 tensor the wrappers expect; it is
+    never indexed from Python."""
+    byte_offset_ids = True
+    dtype, is_cuda, requires_grad = torch.float32, True, False
+
+    def __init__(self, base_ptr: int, width: int, device):
+        self._ptr, self.shape, self.device = int(base_ptr), torch.Size((0, int(width))), device
+
+    def data_ptr(self):
+        return self._ptr
+
+    def dim(self):
+        return 2
+
+    def stride(self, d=None):
+        st = (int(self.shape[1]), 1)
+        return st if d is None else st[d]
+
+
+def mapped_lazy_rows(wm_tensor, ids: torch.Tensor) -> LazyRows:
+    """``table[ids]`` of a peer-mapped ``DistributedWholeMemoryTensor`` (float32 [rows, F]) as ``LazyRows`` the first SAGE layer
+    reads through: one small launch turns the ids into byte offsets over this process's mapping of every rank's partition, the
+    layer kernel then loads remote rows over xGMI itself (the reference's mapped gather addresses the partitions the same way,
+    gather_scatter_func.cuh:242-505) — the gathered ``[n, F]`` copy never exists.  Anything else that touches it gathers."""
+    import ctypes
+    assert wm_tensor.dtype == torch.float32 and wm_tensor.dim() == 2 and ids.dim() == 1 and ids.dtype in (torch.int32, torch.int64)
+    ids = ids.contiguous()
+    offs = torch.empty(ids.shape[0], dtype=torch.int64, device=ids.device)
+    base = ctypes.c_void_p()
+    L.check(L.lib().wgamd_mapped_row_offsets(wm_tensor.c, ids.data_ptr(), torch_dtype_to_wm(ids.dtype), int(ids.shape[0]),
+                                             offs.data_ptr(), ctypes.byref(base), get_stream()), "wgamd_mapped_row_offsets")
+    lazy = LazyRows(MappedTable(base.value, wm_tensor.shape[1], ids.device), offs)
+    lazy._gather = lambda: wm_tensor.gather(ids)
+    return lazy
 
 
 class HopGraph:
@@ -781,7 +830,11 @@ def _sage_layer_launch(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean):
         if ctx.needs_input_grad[0] and ids is not None:
             raise NotImplementedError("gradient w.r.t. a feature table read through ids (LazyRows): trainable node "
                                       "embeddings go through wholegraph_amd.embedding")
-        ctx.save_for_backward(src, w_l, w_r, out)
+        if isinstance(src, torch.Tensor):
+            ctx.save_for_backward(src, w_l, w_r, out)
+        else:                                     # (a MappedTable: an address space, not a tensor)
+            ctx.save_for_backward(w_l, w_r, out)
+            ctx.src_obj = src
         ctx.conv, ctx.graph, ctx.ids, ctx.relu, ctx.mean, ctx.aggs, ctx.has_bias = conv, graph, ids, relu, mean, aggs, bias is not None
     return out
 
@@ -799,7 +852,7 @@ class _SageLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        src, w_l, w_r, out = ctx.saved_tensors
+        src, w_l, w_r, out = ctx.saved_tensors if len(ctx.saved_tensors) == 4 else (ctx.src_obj,) + tuple(ctx.saved_tensors)
         graph, ids, relu, mean = ctx.graph, ctx.ids, ctx.relu, ctx.mean
         N, F_ = w_l.shape
         need_x = ctx.needs_input_grad[0]

@@ -117,6 +117,14 @@ wholememory_error_code_t wholememory_free(wholememory_handle_t wholememory_handl
 /* peer-mapped handles: pointer of every rank's partition as mapped into THIS process (the chunked view of
  * wholememory_get_global_reference, wholememory.h:300-330); `pointers` has room for world-size entries */
 wholememory_error_code_t wgamd_get_peer_pointers(void** pointers, wholememory_handle_t wholememory_handle);
+
+/* Row addresses of a peer-mapped (CHUNKED / CONTINUOUS, more than one rank) 2-D table, for kernels that read the rows
+ * themselves (the one-kernel SAGE layer with the fetch folded in; src_ids_dtype = WGAMD_IDS_BYTE_OFFSETS, wgamd_ext.h):
+ * offsets[i] = byte distance of row ids[i] (INT | INT64) from *base, the lowest partition base of this process's mapping;
+ * -1 for a negative id or one past the last row.  Not collective.  WHOLEMEMORY_LOGIC_ERROR for a handle that is not
+ * peer-mapped (DISTRIBUTED rows are not addressable; a single-partition handle is read through its local tensor). */
+wholememory_error_code_t wgamd_mapped_row_offsets(wholememory_tensor_t table, const void* ids, wholememory_dtype_t ids_dtype,
+                                                  int64_t n, int64_t* offsets, void** base, void* stream);
 /* the HIP IPC steps on their own: a 64-byte handle of a hipMalloc'ed block / mapping one exported by another process */
 wholememory_error_code_t wgamd_ipc_export(void* device_ptr, void* handle64);
 wholememory_error_code_t wgamd_ipc_open(const void* handle64, void** device_ptr);

@@ -546,6 +546,13 @@ wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, int64_t ld_ag
                                                  float* grad_w_r, float* grad_bias, int accumulate, void* workspace,
                                                  size_t workspace_bytes, void* stream);
 
+/* ---- the feature fetch of the one-kernel layer over a PEER-MAPPED table ------------------------------------------------------
+ * src_ids_dtype = WGAMD_IDS_BYTE_OFFSETS in wgamd_sage_layer_fused_bf16x3(_train) / wgamd_sage_wgrad_bf16x3: `src_ids` is then
+ * an int64 list of BYTE offsets from `x` (row r of the layer's input starts at (char*)x + src_ids[r]) instead of row numbers —
+ * what wgamd_mapped_row_offsets (include/wgamd_comm.h) makes of a call group's node ids for a CHUNKED / CONTINUOUS table whose
+ * partitions live on several GPUs: the layer kernel then reads remote rows over xGMI itself, x = table[n_id] never exists. */
+#define WGAMD_IDS_BYTE_OFFSETS ((wholememory_dtype_t)64)
+
 /* Biased (A-Res) sampling, fan-out <= 32: how wholegraph_csr_weighted_sample_without_replacement and the biased call-group
  * hop find the M largest keys.  pruning = 1 (default; env WGAMD_WEIGHTED_PRUNING=0 turns it off): a cheap lower bound of
  * every |key| first, exact keys (log1pf, two divisions) only for the candidates that can still reach the M-th largest one —

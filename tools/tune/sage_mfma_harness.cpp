@@ -38,7 +38,7 @@ int main(int argc, char** argv)
   hipMemcpy(d_self, self.data(), self.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_bias, bias.data(), N * 4, hipMemcpyHostToDevice);
   tile_weight_kernel<<<1024, 256>>>(d_w, N, 2 * F, N, KS, d_planes);
-  mfma_args a{d_rp, d_col, n_dst, d_x, F, (uint32_t)(x.size() * 4), F, nullptr, d_self, 1, d_planes, N, KS, d_bias, 1, d_out, N, row_stride_dw(F), 0, nullptr};
+  mfma_args a{d_rp, d_col, n_dst, d_x, F, (uint32_t)(x.size() * 4), F, nullptr, d_self, 1, d_planes, N, KS, d_bias, 1, d_out, N, row_stride_dw(F), 0, nullptr, (int64_t)F * 4, nullptr, 0};
   unsigned long long* d_stamps; hipMalloc(&d_stamps, 64 * 16 * 8); hipMemset(d_stamps, 0, 64 * 16 * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double bytes = (double)E * (4 * F + 4) + (double)n_dst * (4 * F + 16) + (double)n_dst * 4 * N;
