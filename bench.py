@@ -350,7 +350,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
         labels = torch.randint(0, CLASSES, (V,), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
         loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_groups + n_warm) * G * BATCH], batch_size=BATCH,
                                 shuffle=False, random_state=62)
-        edges, t0, n, losses = 0, None, 0, []
+        edges, t0, n, losses, wgrad_calls = 0, None, 0, [], []
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         fwd_ms = bwd_ms = 0.0
         for grp in loader.call_groups():
@@ -359,6 +359,18 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
                 t0, edges = time.perf_counter(), 0
             probe = n == n_warm + n_groups - 1      # the last group: forward / backward+step split by events
             if probe:
+                # ... and every weight-gradient launch of its backward pass between its own HIP events (the roofline of the
+                # backward's dominant kernel: algorithmic bytes = rows x (2F x 4 + 8 + N x 4 x (2 with the ReLU mask)))
+                real_wgrad = wnn.sage_wgrad
+
+                def timed_wgrad(agg, x, self_rows, grad_out, *a, **kw):
+                    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_.record()
+                    real_wgrad(agg, x, self_rows, grad_out, *a, **kw)
+                    e_.record()
+                    wgrad_calls.append((int(agg.shape[0]), int(agg.shape[1]), int(grad_out.shape[1]),
+                                        (len(a) > 3 and a[3] is not None) or kw.get("act_out") is not None, s_, e_))
+                wnn.sage_wgrad = timed_wgrad
                 ev[0].record()
             h = grp.x
             for j, c in enumerate(model):
@@ -371,6 +383,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
             opt.step()
             if probe:
                 ev[2].record()
+                wnn.sage_wgrad = real_wgrad
             if n in (0, n_warm + n_groups - 1):
                 losses.append(loss.detach())
             edges += grp.num_edges
@@ -378,14 +391,29 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         fwd_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-        return edges / dt, dt / max(n - n_warm, 1) * 1e3, fwd_ms, bwd_ms, [round(float(v), 4) for v in losses]
+        roof = None
+        if wgrad_calls:
+            rows, F_, N_, masked, s_, e_ = max(wgrad_calls, key=lambda c: c[0] * c[2])
+            ms_ = s_.elapsed_time(e_)
+            by = rows * (2 * F_ * 4 + 8 + N_ * 4 * (2 if masked else 1))
+            roof = {"bound": "hbm", "kernel": "sage_wgrad_kernel", "rows": rows, "F": F_, "N": N_, "relu_mask": masked,
+                    "avg_launch_ms": round(ms_, 4), "algorithmic_bytes_per_launch": int(by), "achieved": round(by / ms_ / 1e6, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(by / ms_ / 1e6 / HBM_PEAK_GBPS, 4),
+                    "mfma_TFps": round(6 * 2.0 * rows * 2 * F_ * N_ / ms_ / 1e9, 1),
+                    "mfma_frac": round(6 * 2.0 * rows * 2 * F_ * N_ / ms_ / 1e9 / MFMA_BF16_PEAK_TFPS, 4),
+                    "timing": "HIP events around the launch + its partial-sum reduction, largest hop of the last timed call group"}
+            hit = load_pmc("sage_wgrad_kernel", want_void=False, workload="train")
+            if hit:
+                roof["traffic"] = hit["bytes"]
+                roof["traffic_source"] = hit["source"] + " kernel " + hit["kernel"]
+        return edges / dt, dt / max(n - n_warm, 1) * 1e3, fwd_ms, bwd_ms, [round(float(v), 4) for v in losses], roof
 
     try:
         if "train_step" not in which:
             raise KeyError
-        v, ms, fwd_ms, bwd_ms, losses = train_pass()
+        v, ms, fwd_ms, bwd_ms, losses, wroof = train_pass()
         out["train_step"] = {"value": v, "ms_per_call_group": ms, "forward_loss_ms": round(fwd_ms, 3),
-                             "backward_step_ms": round(bwd_ms, 3), "loss_first_last": losses,
+                             "backward_step_ms": round(bwd_ms, 3), "loss_first_last": losses, "wgrad_roofline": wroof,
                              "note": "NeighborLoader.call_groups() -> nn.SAGEConv x %d (x lazy) -> cross-entropy -> backward -> SGD step "
                                      "per call group of %d mini-batches; value = sampled edges per second of the whole training "
                                      "loop (walk overlapped on its own stream as in loader_api)" % (L, G)}
@@ -479,7 +507,7 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
                       f"(C oracle with OpenMP + torch CPU linear), {dt:.1f} s"}
 
 
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
 
 
 def load_pmc(kernel_prefix, want_void=True, workload="products"):

@@ -1,0 +1,33 @@
+# round 5 profiles: rocprofv3 passes of the DRIVER's command (python bench.py --steps 20 --warmup 5), of the training loop
+# (tools/profile_train_groups.py) and of the mag workload; kernel trace + stats first, then SEPARATE --pmc passes.
+set -x
+R=$GRAFT_REPO_ROOT; TAG=${1:-r05}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
+# (0) the un-profiled line
+python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_plain.log 2>&1; grep "^{\"metric" $OUT/bench_plain.log | tail -1 > $OUT/bench_n1.json
+# (1) driver command under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_$TAG -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+cp /tmp/pt_$TAG/${TAG}_kernel_stats.csv $OUT/
+python $R/tools/trace_large_launches.py /tmp/pt_$TAG/${TAG}_kernel_trace.csv $OUT/${TAG}_kernel_stats_large.csv
+grep "^{\"metric" $OUT/bench_trace.log | tail -1 > $OUT/bench_under_rocprof.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-include-regex "row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|renumber_lds|bucket_sort|renumber_emit|scan_tile|sample_count" --output-format csv -d /tmp/pc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_$C.log 2>&1
+  cp /tmp/pc_${TAG}_$C/*counter_collection.csv $OUT/
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "Cijk|sage_layer_fused|sage_layer_mfma" --output-format csv -d /tmp/pc_${TAG}_MFMA -o ${TAG}_MFMA -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_MFMA.log 2>&1
+cp /tmp/pc_${TAG}_MFMA/*counter_collection.csv $OUT/
+# (2) the training loop (bench.py's train_step variant alone)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_train -o train -- python $R/tools/profile_train_groups.py 16 > $OUT/train_trace.log 2>&1
+cp /tmp/pt_train/train_kernel_stats.csv $OUT/
+python $R/tools/trace_large_launches.py /tmp/pt_train/train_kernel_trace.csv $OUT/train_kernel_stats_large.csv
+tail -1 $OUT/train_trace.log | grep "^{" > $OUT/train_under_rocprof.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-include-regex "sage_wgrad|wgrad_reduce|sage_layer_mfma" --output-format csv -d /tmp/pc_train_$C -o train_$C -- python $R/tools/profile_train_groups.py 8 > $OUT/train_$C.log 2>&1
+  cp /tmp/pc_train_$C/*counter_collection.csv $OUT/
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "sage_wgrad" --output-format csv -d /tmp/pc_train_MFMA -o train_MFMA -- python $R/tools/profile_train_groups.py 8 > $OUT/train_MFMA.log 2>&1
+cp /tmp/pc_train_MFMA/*counter_collection.csv $OUT/
+# (3) mag (BASELINE configs[4]) through the package API
+python $R/bench.py --workload mag --steps 6 --warmup 2 > $OUT/bench_mag_plain.log 2>&1; grep "^{\"metric" $OUT/bench_mag_plain.log | tail -1 > $OUT/bench_mag_hetero_n1.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_mag -o mag -- python $R/bench.py --workload mag --steps 6 --warmup 2 --no-cpu-baseline > $OUT/mag_trace.log 2>&1
+cp /tmp/pt_mag/mag_kernel_stats.csv $OUT/
+ls -la $OUT
