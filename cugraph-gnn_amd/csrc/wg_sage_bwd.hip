@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
   const uint32_t agg_lane = ((uint32_t)(rg * 4) * (uint32_t)a.ld_agg + (uint32_t)q * 4u) * 4u;   // bytes
   auto load_stage = [&](int64_t tile) {
     if (!stage) return;
+#ifdef WG_ABL_NO_STAGE   // tuning build (wrong results): no [agg | self] row loads
+    return;
+#endif
     if (self_half) {
 #pragma unroll
       for (int j = 0; j < 4; j++) st[j] = *reinterpret_cast<const f32x4*>(a.x + idx_next[j] * a.ldx + (q - FQ) * 4);
@@ -115,6 +118,9 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
   };
   auto store_stage = [&](int64_t tile, uint16_t* buf) {
     if (!stage) return;
+#ifdef WG_ABL_NO_STORE   // tuning build (wrong results): no split + transposed LDS store of the A side
+    return;
+#endif
     uint32_t h[4][4], m[4][4], l[4][4];   // [row j][feature i]
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -144,6 +150,9 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
   const uint32_t m_lane = ((uint32_t)(lh * 8) * (uint32_t)a.ld_act + (uint32_t)colc) * 4u;
   auto load_z = [&](int64_t tile) {
     if (!z_wave) return;
+#ifdef WG_ABL_NO_Z   // tuning build (wrong results): no dZ / mask loads — prices the B side's memory instructions
+    return;
+#endif
     const __amdgpu_buffer_rsrc_t rg_ = tile_rsrc(a.g, a.ldg, r_begin + tile * TR);
     // (opaque to the optimiser: the 16 + 16 per-load offsets are then one add each per tile, not 32 registers kept live
     //  across the whole loop next to 112 accumulators)
@@ -200,30 +209,100 @@ __global__ void __launch_bounds__(512) sage_wgrad_kernel(wgrad_args a)
     store_stage(0, planes);
     split_z(0);
     lds_barrier();
+    // Where a tile's time goes (compile-time ablations WG_ABL_*, products layer-1 hop, 1.38 ms): no dZ loads -0.47 ms, no
+    // [agg | self] loads -0.35, no MFMAs -0.44 — the parts ADD; without MFMAs the loads alone run at 4.9 TB/s.  Loading and
+    // multiplying on the same SIMD time-slice on this chip instead of overlapping (wg_sage_mfma.hip measured the same between
+    // its fetching and multiplying waves).  What was tried against it, in this order: the two waves of a SIMD out of phase
+    // (one requests then multiplies, the other the reverse): +3 % at F = 100, -13 % at F = 256; the dZ loads of tile t + 1
+    // dealt BETWEEN the MFMA blocks of tile t with a VALU-computed offset: +14 % (the register allocator reused destinations
+    // of loads in flight for the offsets and put vmcnt(0) before every group); the same with the row part of the address in
+    // the instruction's scalar offset (no VALU temporary): -1 % / -15 %.  Kept: the last one.
+    constexpr int pa_[6] = {2, 0, 1, 1, 0, 0};   // smallest terms first (as the forward)
+    constexpr int pb_[6] = {0, 2, 1, 0, 1, 0};
+    auto frags = [&](const uint16_t* ap, u32x4 (&fa)[3]) {
+#pragma unroll
+      for (int p = 0; p < 3; p++) fa[p] = *reinterpret_cast<const u32x4*>(ap + p * kPlane);
+    };
+    constexpr int kBlocks = KS * ((MT + 1) / 2), kEntries = KS * 8;       // MFMA blocks per tile; (k-step, row) pairs of dZ
+    constexpr int kPerBlock = (kEntries + kBlocks - 1) / kBlocks;
+    // all MT tiles of this wave exist (every launch shape of the BASELINE models): straight-line code, feature tiles in PAIRS so
+    // that consecutive MFMAs go to different accumulators
+    auto multiply_full = [&](const uint16_t* pb, bool more, int64_t tile) {
+      __amdgpu_buffer_rsrc_t rg_ = tile_rsrc(a.g, a.ldg, r_begin + (tile + 1) * TR), rm_ = rg_;
+      if constexpr (MASK) rm_ = tile_rsrc(a.act, a.ld_act, r_begin + (tile + 1) * TR);
+      uint32_t gl = g_lane, ml = m_lane;
+      asm volatile("" : "+v"(gl), "+v"(ml));
+      // (the row part of the address rides in the instruction's SCALAR offset: no VALU temporary per load — with one, the
+      //  register allocator reused the destinations of loads still in flight for it and put a vmcnt(0) before every group.
+      //  The scalar offset is outside the descriptor's range check, so the one tile that crosses the end of the matrix takes
+      //  load_z() up front instead.)
+      const bool inside = r_begin + (tile + 2) * TR <= a.n_rows;
+      if (more && !inside) load_z(tile + 1);
+      more = more && inside;
+      auto zload = [&](int e) {
+        const int ks = e / 8, j = e % 8;
+#ifndef WG_ABL_NO_Z
+        zr[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg_, gl, (ks * 16 + j) * 4 * (int)a.ldg, 0));
+        if constexpr (MASK)
+          zm[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm_, ml, (ks * 16 + j) * 4 * (int)a.ld_act, 0));
+#endif
+      };
+      int blk = 0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+        for (int m = 0; m < MT; m += 2) {
+          u32x4 fa[3], fb[3];
+          frags(pb + m * 32 * TRP + ks * 16, fa);
+          if (m + 1 < MT) frags(pb + (m + 1) * 32 * TRP + ks * 16, fb);
+#ifdef WG_ABL_NO_MFMA   // tuning build (wrong results): fragments are read, nothing is multiplied
+          acc[m][0] += __uint_as_float(fa[0][0] ^ fa[1][1] ^ fa[2][2]);
+#else
+#pragma unroll
+          for (int k6 = 0; k6 < 6; k6++) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa_[k6]]),
+                                                             __builtin_bit_cast(bf16x8, zf[ks][pb_[k6]]), acc[m], 0, 0, 0);
+            if (m + 1 < MT)
+              acc[m + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[pa_[k6]]),
+                                                                   __builtin_bit_cast(bf16x8, zf[ks][pb_[k6]]), acc[m + 1], 0, 0, 0);
+          }
+#endif
+          if (more) {
+#pragma unroll
+            for (int e = 0; e < kPerBlock; e++)
+              if (blk * kPerBlock + e < kEntries) zload(blk * kPerBlock + e);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          blk++;
+        }
+      }
+    };
+    auto multiply_some = [&](const uint16_t* pb) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+          if (m < mt_live) {
+            u32x4 fa[3];
+            frags(pb + m * 32 * TRP + ks * 16, fa);
+#pragma unroll
+            for (int k6 = 0; k6 < 6; k6++)
+              acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa_[k6]]),
+                                                               __builtin_bit_cast(bf16x8, zf[ks][pb_[k6]]), acc[m], 0, 0, 0);
+          }
+    };
     for (int64_t tile = 0; tile < n_tiles; tile++) {
       const bool more = tile + 1 < n_tiles;
       if (more) {
         load_stage(tile + 1);   // (uses the ids requested one iteration ago)
         load_idx(tile + 2);
       }
-      if (more) load_z(tile + 1);
       const uint16_t* pb = planes + (tile & 1) * kBuf + ((wm * MT) * 32 + lm) * TRP + lh * 8;
-      constexpr int pa_[6] = {2, 0, 1, 1, 0, 0};   // smallest terms first (as the forward)
-      constexpr int pb_[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-          if (m < mt_live) {
-            const uint16_t* ap = pb + m * 32 * TRP + ks * 16;
-            u32x4 fa[3];
-#pragma unroll
-            for (int p = 0; p < 3; p++) fa[p] = *reinterpret_cast<const u32x4*>(ap + p * kPlane);
-#pragma unroll
-            for (int k6 = 0; k6 < 6; k6++)
-              acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa_[k6]]),
-                                                               __builtin_bit_cast(bf16x8, zf[ks][pb_[k6]]), acc[m], 0, 0, 0);
-          }
+      if (mt_live == MT) multiply_full(pb, more, tile);
+      else {
+        if (more) load_z(tile + 1);
+        multiply_some(pb);
+      }
       if (more) {
         store_stage(tile + 1, planes + ((tile + 1) & 1) * kBuf);
         split_z(tile + 1);
