@@ -446,20 +446,19 @@ class CallGroupIterator:
                     ids, torch.tensor([0, ragged], dtype=torch.int32, device=dev), torch.zeros(ragged, dtype=torch.int32, device=dev))})
                 n_seeds = ragged
             state, G_ = rec["state"], walk.G
+            T = len(walk.ntypes)
             pieces = [state[t]["seg"][G_:G_ + 1] for t in walk.ntypes]
-            cseg = []
-            for k in range(H):      # vertices per type after k hops: a batch-major compact numbering per level
-                lvl = {}
-                for t in walk.ntypes:
-                    cs = torch.zeros(G_ + 1, dtype=torch.int64, device=dev)
-                    cs[1:] = torch.cumsum(rec["sizes"][k][t].long(), 0)
-                    lvl[t] = cs
-                    pieces.append(cs[G_:G_ + 1])
-                cseg.append(lvl)
+            # vertices per type after k hops as batch-major compact numberings — every (level, type) in ONE cumsum (the walk
+            # of a heterogeneous call group is a chain of ~170 small launches; glue that can be one launch is one launch)
+            sizes = torch.stack([rec["sizes"][k][t] for k in range(H) for t in walk.ntypes]).to(torch.int64)      # [H T, G]
+            cs_all = torch.zeros((H * T, G_ + 1), dtype=torch.int64, device=dev)
+            cs_all[:, 1:] = torch.cumsum(sizes, 1)
+            cseg = [{t: cs_all[k * T + i] for i, t in enumerate(walk.ntypes)} for k in range(H)]
+            totals = cs_all[:, G_].to(torch.int32)
+            pieces.append(totals)
             for c in rec["calls"]:
                 if c is not None:
-                    n_f = c["f_seg"][G_:G_ + 1]
-                    pieces += [n_f, c["offsets"][n_f.long()]]
+                    pieces += [c["f_seg"][G_:G_ + 1], c["counts"][0:1]]       # (frontier entries, sampled edges): views
             rec["calls_seed_seg"] = cseg[0][self._seed_type].to(torch.int32)
             sizes_d = torch.cat([p.to(torch.int32).reshape(-1) for p in pieces])
             sizes_h = torch.empty(sizes_d.shape, dtype=torch.int32, pin_memory=True)

@@ -718,8 +718,10 @@ class HeteroPygWalk:
                          st["nodes"], st["batch"], st["seg"]]
                 # (f_batch / f_local0 / frontier_cap: what a call-group consumer needs to place the hop's rows in the node list
                 #  of the destination type without going through per-batch views — bench_mag.py)
+                # (counts = {sampled edges, vertices of the source type after the call}: device-resident; a call-group consumer
+                #  reads them in its one size read-back instead of indexing `offsets` once more)
                 rec["calls"].append(dict(et=et, offsets=offsets, row=row_l, col=col_l, gid=gid, f_seg=f_seg, f_batch=f_batch,
-                                         f_local0=f_l0, frontier_cap=fc, hop=h))
+                                         f_local0=f_l0, frontier_cap=fc, hop=h, counts=counts))
                 st["nodes"], st["batch"], st["seg"] = nodes_out, nodes_out_batch, nodes_out_seg
                 st["cap"] = nc + ec
                 st["gained_cap"] += ec
