@@ -25,3 +25,14 @@ def test_link_prediction_example_learns(hiplib, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["x", "--nodes", "8000", "--epochs", "3", "--batch-size", "256"])
     loss, acc = ex.main()
     assert loss < 0.6 and acc > 0.7, (loss, acc)
+
+
+def test_call_group_training_example_learns(hiplib, monkeypatch):
+    """examples/sage_call_group_training.py: the call-group loop — lazy features, one-kernel SAGE layers forward and backward,
+    one optimizer step per call group — recovers the planted communities."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import sage_call_group_training as ex
+    monkeypatch.setattr(sys, "argv", ["x", "--nodes", "30000", "--epochs", "6", "--batch-size", "256", "--group", "4",
+                                      "--fanout", "10", "5"])
+    loss, acc = ex.main()
+    assert loss < 1.5 and acc > 0.6, (loss, acc)
