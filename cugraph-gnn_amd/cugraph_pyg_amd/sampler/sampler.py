@@ -799,7 +799,7 @@ def _fetch_rows_agreed(t, index):
         worst = torch.tensor([pieces], dtype=torch.int64, device=dev)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
         pieces = int(worst.item())
-    if hasattr(t, "gather_into") and index.is_cuda:
+    if hasattr(t, "gather_into"):
         # ONE output for the whole group, filled piece by piece (a torch.cat of pieces would hold the group's rows twice)
         out = _group_rows.take((int(index.numel()),) + tuple(t.shape)[1:], t.dtype, index.device)
         at = 0

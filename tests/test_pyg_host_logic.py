@@ -225,6 +225,18 @@ def test_group_fetch_fills_one_preallocated_output(monkeypatch):
 
     got = S._fetch_rows_agreed(Pieces(), index)
     assert torch.equal(got, table[index]) and len(Pieces.calls) == 5 and sum(Pieces.calls) == 1000
+    # the output comes from the grow-only rows pool: handed out again only when nothing refers to its storage any more
+    first = got.untyped_storage().data_ptr()
+    view = got[3:5]
+    del got
+    other = S._fetch_rows_agreed(Pieces(), index[:900])
+    assert other.untyped_storage().data_ptr() != first, "a buffer with a live view was recycled"
+    keep = view.clone()
+    del view, other
+    again = S._fetch_rows_agreed(Pieces(), index[:950])
+    assert again.untyped_storage().data_ptr() in (first,) or again.numel() > 0     # (either idle buffer may serve it)
+    assert torch.equal(keep, table[index][3:5]) and torch.equal(again, table[index[:950]])
+    S._group_rows.clear()
     fs = FeatureStore()
     fs["paper", "x", None] = table
     fs["paper", "y", None] = torch.zeros(200, dtype=torch.int64)
