@@ -1110,7 +1110,7 @@ class HeteroConv(torch.nn.Module):
         """(w [in, H C] contiguous, fold(w, att_src) [in, H], fold(w, att_dst) [in, H]) of a relation, rebuilt when a parameter
         changed: ``alpha_src = ((x W).view(H, C) * att).sum(-1) = x (W . att)``."""
         c = self.conv(et)
-        key = tuple((p._version, p.data_ptr()) for p in (c.lin.weight, c.att_src, c.att_dst))
+        key = tuple((p._version, p.data_ptr()) for p in (c.lin.weight, c.att_src, c.att_dst) + ((c.bias,) if c.bias is not None else ()))
         hit = self._folded.get(et)
         if hit is None or hit[0] != key:
             with torch.no_grad():

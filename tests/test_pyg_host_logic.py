@@ -242,3 +242,34 @@ def test_group_fetch_fills_one_preallocated_output(monkeypatch):
     fs["paper", "y", None] = torch.zeros(200, dtype=torch.int64)
     fs[("paper", "cites", "paper"), "w", None] = torch.zeros(50, 3, dtype=torch.float16)
     assert S.store_row_bytes(fs) == (24 + 8, 6)
+
+
+def test_hetero_conv_folds_attention_vectors_and_sums_relation_biases():
+    """``nn.HeteroConv``'s call-group route reads GATConv's parameters in folded form: ``alpha_src = ((x W).view(H, C) * att).sum(-1)
+    = x (W . att)`` per relation, the folded vectors of every relation end of a node type side by side, one bias per destination
+    type = the sum of its relations' biases — and refreshes them when a parameter changes (host logic, no kernel)."""
+    from wholegraph_amd import nn
+    torch.manual_seed(3)
+    ets = [("author", "writes", "paper"), ("paper", "cites", "paper"), ("paper", "rev_writes", "author")]
+    hc = nn.HeteroConv({et: nn.GATConv(12, 5, heads=4, add_self_loops=False, bias=et != ets[1]) for et in ets})
+    x = torch.randn(7, 12)
+    for et in ets:
+        c = hc.conv(et)
+        w, v_src, v_dst = hc._rel(et)
+        assert torch.equal(w, c.lin.weight.t())
+        h = (x @ c.lin.weight.t()).view(7, 4, 5)
+        assert torch.allclose(x @ v_src, (h * c.att_src).sum(-1), atol=1e-5) and torch.allclose(x @ v_dst, (h * c.att_dst).sum(-1), atol=1e-5)
+    keys = hc._term_keys("paper")
+    assert keys == [("dst", ets[0]), ("src", ets[1]), ("dst", ets[1]), ("src", ets[2])]
+    tm = hc._terms_matrix("paper")
+    assert tm.shape == (12, 16) and torch.equal(tm[:, 4:8], hc._rel(ets[1])[1]) and torch.equal(tm[:, 12:], hc._rel(ets[2])[1])
+    assert torch.allclose(hc._bias("paper"), hc.conv(ets[0]).bias) and torch.allclose(hc._bias("author"), hc.conv(ets[2]).bias)
+    assert hc._width("paper") == 20
+    with torch.no_grad():
+        hc.conv(ets[0]).att_dst.mul_(2.0)                       # an optimizer step: the folds follow the parameter version
+        hc.conv(ets[0]).bias.add_(1.0)
+    c = hc.conv(ets[0])
+    assert torch.allclose(x @ hc._terms_matrix("paper")[:, :4], ((x @ c.lin.weight.t()).view(7, 4, 5) * c.att_dst).sum(-1), atol=1e-5)
+    with torch.no_grad():
+        hc.conv(ets[2]).bias.add_(1.0)                          # a bias alone changing is noticed too
+    assert torch.allclose(hc._bias("author"), hc.conv(ets[2]).bias)
