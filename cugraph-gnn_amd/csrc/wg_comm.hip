@@ -855,16 +855,29 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
     const bool host   = memory_location == WHOLEMEMORY_ML_HOST;
     const bool mapped = memory_type != WHOLEMEMORY_MT_DISTRIBUTED && comm->size > 1;
     char shm_name[48] = {0};
-    if (local > 0 && !host && hipMalloc(&h->local_ptr, local) != hipSuccess) {
-      delete h;
-      throw std::bad_alloc();
+    // A PEER-MAPPED allocation is collective: a rank whose own partition cannot be allocated must still meet its peers in
+    // the exchange below and fail WITH them (throwing here would leave them waiting in the allgather for ever).
+    const bool mapped_multi = memory_type != WHOLEMEMORY_MT_DISTRIBUTED && comm->size > 1;
+    bool alloc_failed       = false;
+    // (test hook: WGAMD_TEST_FAIL_MALLOC_RANK=<r> makes rank r's partition of a peer-mapped allocation "fail")
+    const char* inject_env = getenv("WGAMD_TEST_FAIL_MALLOC_RANK");
+    const bool inject      = inject_env != nullptr && mapped_multi && atoi(inject_env) == comm->rank;
+    if (local > 0 && !host && (inject || hipMalloc(&h->local_ptr, local) != hipSuccess)) {
+      (void)hipGetLastError();
+      h->local_ptr = nullptr;
+      if (!mapped_multi) {
+        delete h;
+        throw std::bad_alloc();
+      }
+      alloc_failed = true;
     }
     if (local > 0 && host) {
       // memory_handle.cpp:432-520 (host memory of the mapped types = one shared segment every process maps) /
       // :233-262 (distributed host memory = pinned memory of the owning process).  Pinned either way, so the GPU's loads
       // and stores reach it in place.
-      bool ok = true;
-      if (mapped) {
+      bool ok = !inject;
+      if (!ok) {
+      } else if (mapped) {
         static std::atomic<unsigned> seq{0};
         timespec now{};
         clock_gettime(CLOCK_MONOTONIC, &now);   // pid + counter + time: containers that share /dev/shm may share pids
@@ -891,11 +904,15 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
       }
       if (!ok) {
         (void)hipGetLastError();
-        delete h;
-        throw std::bad_alloc();
+        h->local_ptr = nullptr;
+        if (!mapped_multi) {
+          delete h;
+          throw std::bad_alloc();
+        }
+        alloc_failed = true;
       }
     }
-    if (memory_type != WHOLEMEMORY_MT_DISTRIBUTED && comm->size > 1) {
+    if (mapped_multi) {
       // PEER MAPPING (collective): every rank publishes {HIP IPC handle, pid, pointer} of its partition and opens the
       // others'.  Ranks that live in this very process (threads as ranks) use the pointer as it is — an IPC handle cannot
       // be opened by the process that exported it.
@@ -906,7 +923,9 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         uint64_t bytes;
         int64_t device;
         char shm[48];   // host location: name of the rank's shared-memory segment
+        int64_t failed;  // this rank could not allocate its partition: every rank gives up together
       } mine{};
+      mine.failed = alloc_failed ? 1 : 0;
       memcpy(mine.shm, shm_name, sizeof(shm_name));
       int my_device = 0;
       WG_HIP_CHECK(hipGetDevice(&my_device));
@@ -915,15 +934,25 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
       mine.ptr   = reinterpret_cast<uint64_t>(h->local_ptr);
       mine.bytes = local;
       try {
-        if (local > 0 && !host) WG_HIP_CHECK(hipIpcGetMemHandle(&mine.ipc, h->local_ptr));
+        if (local > 0 && !host && !alloc_failed && hipIpcGetMemHandle(&mine.ipc, h->local_ptr) != hipSuccess) {
+          (void)hipGetLastError();
+          mine.failed = 1;
+        }
         std::vector<char> all;
         allgather_host(comm, &mine, sizeof(mine), all);
+        for (int r = 0; r < comm->size; r++) {
+          record rec;
+          memcpy(&rec, all.data() + (size_t)r * sizeof(rec), sizeof(rec));
+          if (rec.failed) throw std::bad_alloc();   // (every rank sees the same records: all of them leave here)
+        }
         h->peer_ptr.assign(comm->size, nullptr);
         h->peer_opened.assign(comm->size, 0);
         h->peer_host_map.assign(comm->size, nullptr);
         h->peer_map_bytes.assign(comm->size, 0);
         mapped_view view{};
         view.W = comm->size;
+        std::exception_ptr map_error;   // a mapping that fails HERE is reported after every rank has said how it went
+        try {
         for (int r = 0; r < comm->size; r++) {
           record rec;
           memcpy(&rec, all.data() + (size_t)r * sizeof(rec), sizeof(rec));
@@ -941,8 +970,8 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
             if (m == MAP_FAILED) throw logic_error("host peer mapping: the shared-memory segment of a peer cannot be mapped");
             h->peer_host_map[r]  = m;
             h->peer_map_bytes[r] = rec.bytes;
+            h->peer_opened[r]    = 2;   // (set with the mapping: a failing registration below still gets its munmap on release)
             WG_HIP_CHECK(hipHostRegister(m, rec.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
-            h->peer_opened[r] = 2;
             void* dp          = nullptr;
             WG_HIP_CHECK(hipHostGetDevicePointer(&dp, m, 0));
             h->peer_ptr[r] = dp;
@@ -972,12 +1001,21 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
         view.entry_off[comm->size] = (int64_t)(h->byte_offsets[comm->size] / data_granularity);
         WG_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_view), sizeof(mapped_view)));
         WG_HIP_CHECK(hipMemcpy(h->d_view, &view, sizeof(view), hipMemcpyHostToDevice));
-        if (host) {
-          // every process holds its mappings now: the names can go (the memory lives until the last unmap)
+        } catch (...) {
+          map_error = std::current_exception();
+          (void)hipGetLastError();
+        }
+        {
+          // every rank says whether it holds all its mappings; one failure fails the allocation everywhere (and only after
+          // this exchange may the shared-memory names go: the memory lives until the last unmap)
           std::vector<char> seen;
-          char done = 1;
+          char done = map_error ? 0 : 1;
           allgather_host(comm, &done, 1, seen);
           if (shm_name[0]) shm_unlink(shm_name);
+          shm_name[0] = 0;
+          if (map_error) std::rethrow_exception(map_error);
+          for (int r = 0; r < comm->size; r++)
+            if (!seen[r]) throw logic_error("peer-mapped allocation: another rank could not map a partition");
         }
       } catch (...) {
         if (shm_name[0]) shm_unlink(shm_name);

@@ -243,3 +243,55 @@ def test_continuous_is_peer_mapped_too(shim):
     p = subprocess.run([sys.executable, "-c", WORKER, ROOT, "3", "5000", "100", "2000", "", "continuous"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "ALL_RANKS_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+FAIL_WORKER = textwrap.dedent(r"""
+    import ctypes, os, sys, threading
+    import torch
+    sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/cugraph-gnn_amd")
+    import wholegraph_amd as wg
+    from wholegraph_amd import _lib as L
+    from wholegraph_amd.comm import WholeMemoryCommunicator
+    W, location = int(sys.argv[2]), sys.argv[3]
+    lib = L.lib()
+    uid = L.UniqueId()
+    L.check(lib.wholememory_create_unique_id(ctypes.byref(uid)), "uid")
+    results = [None] * W
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            c = ctypes.c_void_p()
+            L.check(lib.wholememory_create_communicator(ctypes.byref(c), uid, r, W), "create_communicator")
+            comm = WholeMemoryCommunicator(c.value)
+            try:
+                wg.create_wholememory_tensor(comm, "chunked", location, [3000, 16], torch.float32, [16, 1])
+                results[r] = "allocated"
+            except L.WholeMemoryError as e:
+                results[r] = "error %d" % e.code
+            # the communicator is still usable by everybody: the next collective allocation goes through
+            os.environ.pop("WGAMD_TEST_FAIL_MALLOC_RANK", None)
+            comm.barrier()
+            t = wg.create_wholememory_tensor(comm, "chunked", location, [3000, 16], torch.float32, [16, 1])
+            wg.destroy_wholememory_tensor(t)
+            comm.destroy()
+        except BaseException as e:  # noqa
+            import traceback; traceback.print_exc()
+            results[r] = "crash " + repr(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(W)]
+    for th in threads: th.start()
+    for th in threads: th.join(90)
+    alive = [i for i, th in enumerate(threads) if th.is_alive()]
+    print("RESULTS", alive, results); sys.stdout.flush()
+    os._exit(0 if not alive and all(v and v.startswith("error") for v in results) else 1)
+""")
+
+
+@pytest.mark.parametrize("location", ["cuda", "cpu"])
+def test_peer_mapped_malloc_fails_on_every_rank_when_one_partition_cannot_be_allocated(shim, location):
+    """A peer-mapped allocation is collective: when ONE rank cannot allocate its partition, every rank meets it in the exchange
+    and all of them get the error (OUT_OF_MEMORY) — nobody is left waiting in an allgather — and the communicator stays usable."""
+    env = dict(os.environ, WGAMD_RCCL_LIBRARY=shim, WGAMD_TEST_FAIL_MALLOC_RANK="1")
+    p = subprocess.run([sys.executable, "-c", FAIL_WORKER, ROOT, "3", location], env=env, capture_output=True, text=True, timeout=200)
+    assert p.returncode == 0 and "RESULTS [] ['error" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
