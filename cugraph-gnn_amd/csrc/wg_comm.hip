@@ -63,6 +63,7 @@ struct mapped_view {
 }  // namespace wgamd
 
 struct wholememory_handle_ {
+  uint64_t serial = 0;   // unique per allocation (never reused, unlike the address)
   wholememory_comm_t comm;
   wholememory_memory_type_t type;
   wholememory_memory_location_t location;
@@ -1028,6 +1029,8 @@ wholememory_error_code_t wholememory_malloc(wholememory_handle_t* handle_ptr, si
       comm->live_handles.push_back(h);
     }
     {
+      static std::atomic<uint64_t> next_serial{1};
+      h->serial = next_serial.fetch_add(1);
       std::lock_guard<std::mutex> g(g_handles_mu);
       g_handles.insert(h);
     }
@@ -1097,6 +1100,23 @@ wholememory_error_code_t wholememory_free(wholememory_handle_t h)
       fprintf(stderr, "[wholegraph_amd] wholememory_free: not a live handle (already released with its communicator?)\n");
       return WHOLEMEMORY_INVALID_INPUT;
     }
+  }
+  release_handle(h, /*collective=*/true);
+  return WHOLEMEMORY_SUCCESS;
+}
+
+uint64_t wgamd_handle_serial(wholememory_handle_t h)
+{
+  std::lock_guard<std::mutex> g(g_handles_mu);
+  return (h != nullptr && g_handles.count(h)) ? h->serial : 0;
+}
+
+wholememory_error_code_t wgamd_free_if_serial(wholememory_handle_t h, uint64_t serial)
+{
+  if (h == nullptr) return WHOLEMEMORY_INVALID_INPUT;
+  {
+    std::lock_guard<std::mutex> g(g_handles_mu);
+    if (!g_handles.count(h) || h->serial != serial) return WHOLEMEMORY_INVALID_INPUT;   // gone, or another handle at this address
   }
   release_handle(h, /*collective=*/true);
   return WHOLEMEMORY_SUCCESS;
@@ -1260,7 +1280,8 @@ wholememory_error_code_t wholememory_create_tensor(wholememory_tensor_t* out, wh
     release_handle(h, /*collective=*/false);  // local failure: the peers are not in a matching free
     return rc;
   }
-  (*out)->owns_handle = true;
+  (*out)->owns_handle   = true;
+  (*out)->handle_serial = wgamd_handle_serial(h);
   return WHOLEMEMORY_SUCCESS;
 }
 

@@ -21,7 +21,13 @@ struct wholememory_tensor_ {
   wholememory_tensor_* root;      // nullptr for a root tensor
   wholememory_handle_t handle;    // nullptr unless backed by a DISTRIBUTED handle
   bool owns_handle = false;       // wholememory_create_tensor: destroy_tensor frees the handle too
+  uint64_t handle_serial = 0;     // ... if it is still THAT handle: an address can be handed out again after a communicator
+                                  // force-released the handles it still had (wgamd_free_if_serial)
 };
+
+// wg_comm.hip: the serial number of a live handle (0 = not live), and a free that only acts on the handle that carries it
+extern "C" uint64_t wgamd_handle_serial(wholememory_handle_t h);
+extern "C" wholememory_error_code_t wgamd_free_if_serial(wholememory_handle_t h, uint64_t serial);
 
 namespace wgamd {
 

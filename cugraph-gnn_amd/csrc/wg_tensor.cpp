@@ -183,7 +183,9 @@ wholememory_error_code_t wholememory_make_tensor_from_pointer(wholememory_tensor
 wholememory_error_code_t wholememory_destroy_tensor(wholememory_tensor_t t)
 {
   if (t == nullptr) return WHOLEMEMORY_INVALID_INPUT;
-  if (t->owns_handle && t->handle != nullptr) wholememory_free(t->handle);
+  // (the handle may be gone — released with its communicator — and its address reused by an unrelated live handle: the serial
+  //  number tells the two apart, a stale free is a no-op)
+  if (t->owns_handle && t->handle != nullptr) (void)wgamd_free_if_serial(t->handle, t->handle_serial);
   delete t;
   g_live_tensors--;
   return WHOLEMEMORY_SUCCESS;

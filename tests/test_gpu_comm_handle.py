@@ -185,3 +185,25 @@ def test_env_test_op_exercises_every_allocation_type(dtype, entries, dim):
         assert t is not None and tuple(t.shape) == (entries, dim) and t.dtype == dtype and t.device.type == kind
         assert torch.equal(t.cpu(), want)
     assert ctxs[1].get_tensor().is_pinned() or entries == 0
+
+
+def test_a_stale_tensor_cannot_free_the_handle_that_took_its_address(hiplib):
+    """A communicator that is destroyed force-releases the handles it still had; a tensor that owned one of them is destroyed
+    LATER.  By then the allocator may have handed the same address to a new, unrelated handle: the stale destroy must leave it
+    alone (handles carry a serial number that is never reused; `wholememory_destroy_tensor` frees only the handle it created)."""
+    import wholegraph_amd as wg
+    c1 = wg.create_group_communicator()
+    old = [wg.create_wholememory_tensor(c1, "distributed", "cuda", [100, 8], torch.float32, [8, 1]) for _ in range(6)]
+    c1.destroy()                                      # the six handles go with it; `old` still points at their addresses
+    c2 = wg.create_group_communicator()
+    new = [wg.create_wholememory_tensor(c2, "distributed", "cuda", [100, 8], torch.float32, [8, 1]) for _ in range(12)]
+    for k, t in enumerate(new):
+        t.get_local_tensor()[0].fill_(float(k))
+    for t in old:
+        wg.destroy_wholememory_tensor(t)              # stale: must not touch anything live
+    idx = torch.arange(0, 100, 3, device="cuda")
+    for k, t in enumerate(new):
+        assert bool((t.gather(idx) == float(k)).all()), "a live handle was released by a stale tensor"
+    for t in new:
+        wg.destroy_wholememory_tensor(t)
+    c2.destroy()
