@@ -770,8 +770,9 @@ class _GroupRowsPool:
         if fit:
             buf = min(fit, key=lambda b: b.numel())
         else:
-            for b in idle:          # too small for this workload's groups: back to the allocator
-                bufs.remove(b)
+            # idle ones are too small for this workload's groups: back to the allocator (by identity: ``list.remove`` would
+            # compare tensors element-wise)
+            bufs[:] = [b for b in bufs if not any(b is i for i in idle)]
             buf = torch.empty(int(nbytes * 1.12) + (1 << 20), dtype=torch.uint8, device=device)
             bufs.append(buf)
         return buf[:nbytes].view(dtype).view(tuple(int(d) for d in shape))

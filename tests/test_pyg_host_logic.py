@@ -236,6 +236,21 @@ def test_group_fetch_fills_one_preallocated_output(monkeypatch):
     again = S._fetch_rows_agreed(Pieces(), index[:950])
     assert again.untyped_storage().data_ptr() in (first,) or again.numel() > 0     # (either idle buffer may serve it)
     assert torch.equal(keep, table[index][3:5]) and torch.equal(again, table[index[:950]])
+    # a busy buffer FIRST, an idle one of another size behind it, and a request the idle one cannot hold: the idle buffer goes
+    # back to the allocator (dropped by identity — comparing tensors would be element-wise), the busy one stays
+    del again
+    pool = S._group_rows
+    pool.clear()
+    held = pool.take((1000, 4), torch.float32, "cpu")
+    small = pool.take((10, 4), torch.float32, "cpu")
+    bufs = pool._bufs[torch.device("cpu")]
+    assert len(bufs) == 2 and bufs[0].numel() != bufs[1].numel()
+    del small
+    assert not pool._idle(bufs[0]) and pool._idle(bufs[1])
+    big = pool.take((3 << 20, 1), torch.uint8, "cpu")
+    assert len(bufs) == 2 and bufs[0].untyped_storage().data_ptr() == held.untyped_storage().data_ptr()
+    assert bufs[1].numel() >= big.numel()
+    del big, held
     S._group_rows.clear()
     fs = FeatureStore()
     fs["paper", "x", None] = table
