@@ -188,7 +188,7 @@ def test_weighted_pruning_changes_nothing(hiplib, M, weights):
     comparison is bit for bit."""
     from wholegraph_amd import _lib
     degs = np.array([0, 3, M, M + 1, 40, 64, 65, 100, 128, 129, 255, 256, 257, 511, 512, 513, 900, 1024, 1025, 2000, 5000,
-                     12288, 12289, 20000, 70000], np.int64)
+                     12288, 12289, 16384, 16385, 17001, 20000, 70000, 150001], np.int64)   # (> 16384: the hub class of the workgroup kernel's queue)
     rng = np.random.default_rng(100 * M + len(weights))
     row_ptr = np.zeros(len(degs) + 1, np.int64)
     row_ptr[1:] = np.cumsum(degs)
