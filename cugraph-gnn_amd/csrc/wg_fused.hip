@@ -187,26 +187,47 @@ hetero_hop_rows_kernel(const int* __restrict__ offsets, const int* __restrict__ 
 // list of ALL vertices (x = feat[n_id]); the output of a trimmed layer is one segment per hop it ran (the hop's frontier
 // list, batch-major).  For frontier entry j of batch b the kernel writes the input row of the entry itself (self_rows[j]) and
 // of every one of its sampled neighbours (col[e]).  seg_tab: int32 [2 * n_seg, G + 1], row 2 s = local0[s], row 2 s + 1 =
-// start[s]; one 16-lane group per frontier entry.
+// start[s].  Block (batch, chunk): the frontier entries of a batch are consecutive and so are their edges, so a block reads
+// what depends on the batch ONCE (segment table -> LDS as (first local id, row shift) pairs) and then streams its stretch of
+// `row_local` -> `col` with every lane busy — one 16-lane group per frontier entry chased five dependent loads per edge with
+// 10 of 16 lanes (196 us for the 15 M edges of a products call group's second hop; the bytes are worth 17 us).
+constexpr int kLayerSegMax = 16;
 __global__ void __launch_bounds__(256)
-layer_cols_kernel(const int* __restrict__ offsets, const int* __restrict__ f_batch, const int* __restrict__ f_seg,
-                  const int* __restrict__ f_local0, const int* __restrict__ row_local, int n_f, int G, int n_seg,
-                  const int* __restrict__ seg_tab, const int64_t* __restrict__ seg_base, int64_t* __restrict__ self_rows,
-                  int* __restrict__ col)
+layer_cols_kernel(const int* __restrict__ offsets, const int* __restrict__ f_seg, const int* __restrict__ f_local0,
+                  const int* __restrict__ row_local, int G, int chunks, int n_seg, const int* __restrict__ seg_tab,
+                  const int64_t* __restrict__ seg_base, int64_t* __restrict__ self_rows, int* __restrict__ col)
 {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t j   = tid >> 4;
-  const int sub     = (int)(tid & 15);
-  if (j >= n_f) return;
-  const int b = f_batch[j];
+  __shared__ int s_l0[kLayerSegMax];
+  __shared__ int64_t s_add[kLayerSegMax];
+  const int b = blockIdx.x / chunks, c = blockIdx.x % chunks;
+  const int t = threadIdx.x;
+  if (t < n_seg) {
+    const int l0 = seg_tab[(int64_t)(2 * t) * (G + 1) + b];
+    s_l0[t]      = l0;
+    s_add[t]     = seg_base[t] + seg_tab[(int64_t)(2 * t + 1) * (G + 1) + b] - l0;
+  }
+  const int f0 = f_seg[b], f1 = f_seg[b + 1];
+  const int j0 = f0 + (int)((int64_t)(f1 - f0) * c / chunks), j1 = f0 + (int)((int64_t)(f1 - f0) * (c + 1) / chunks);
+  if (j0 >= j1) return;   // (uniform over the block, before the barrier)
+  const int e0 = offsets[j0], e1 = offsets[j1];
+  const int first_local = f_local0[b] - f0;
+  __syncthreads();
   auto row_of = [&](int local) -> int64_t {
     int s = 0;
-    for (int k = 1; k < n_seg; k++) s = seg_tab[(int64_t)(2 * k) * (G + 1) + b] <= local ? k : s;
-    return seg_base[s] + seg_tab[(int64_t)(2 * s + 1) * (G + 1) + b] + (local - seg_tab[(int64_t)(2 * s) * (G + 1) + b]);
+    for (int k = 1; k < n_seg; k++) s = s_l0[k] <= local ? k : s;
+    return (int64_t)local + s_add[s];
   };
-  if (sub == 0 && self_rows) self_rows[j] = row_of(f_local0[b] + ((int)j - f_seg[b]));
-  const int s0 = offsets[j], e0 = offsets[j + 1];
-  for (int i = s0 + sub; i < e0; i += 16) col[i] = (int)row_of(row_local[i]);
+  if (self_rows)
+    for (int j = j0 + t; j < j1; j += 256) self_rows[j] = row_of(first_local + j);
+  int i = e0 + t;
+  for (; i + 768 < e1; i += 1024) {   // four independent loads in flight per lane
+    const int r0 = row_local[i], r1 = row_local[i + 256], r2 = row_local[i + 512], r3 = row_local[i + 768];
+    col[i]       = (int)row_of(r0);
+    col[i + 256] = (int)row_of(r1);
+    col[i + 512] = (int)row_of(r2);
+    col[i + 768] = (int)row_of(r3);
+  }
+  for (; i < e1; i += 256) col[i] = (int)row_of(row_local[i]);
 }
 
 // Frontier of a node type between two hops of the heterogeneous call-group walk (HeteroPygWalk._frontier): batch b gained the
@@ -280,13 +301,14 @@ wholememory_error_code_t wgamd_call_group_layer_cols(const int* offsets, const i
   using namespace wgamd;
   return guarded("wgamd_call_group_layer_cols", [&] {
     WG_REQUIRE_INPUT(n_frontier >= 0 && n_frontier < ((int64_t)1 << 27), "bad frontier count");
-    WG_REQUIRE_INPUT(n_batches >= 1 && n_segments >= 1 && n_segments <= 16, "bad batch / segment count");
+    WG_REQUIRE_INPUT(n_batches >= 1 && n_batches < (1 << 20) && n_segments >= 1 && n_segments <= kLayerSegMax, "bad batch / segment count");
     if (n_frontier == 0) return;
-    WG_REQUIRE_INPUT(offsets && frontier_batch && frontier_seg && frontier_local0 && row_local && seg_tab && seg_base && col,
-                     "null pointer");
-    layer_cols_kernel<<<ceil_div(n_frontier * 16, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      offsets, frontier_batch, frontier_seg, frontier_local0, row_local, (int)n_frontier, n_batches, n_segments, seg_tab,
-      seg_base, self_rows, col);
+    WG_REQUIRE_INPUT(offsets && frontier_seg && frontier_local0 && row_local && seg_tab && seg_base && col, "null pointer");
+    (void)frontier_batch;   // (the batch of a block's entries follows from frontier_seg)
+    // ~512 frontier entries (and their edges) per block: the block's prelude is three dependent loads
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(ceil_div(n_frontier, (int64_t)n_batches), 512)));
+    layer_cols_kernel<<<n_batches * chunks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      offsets, frontier_seg, frontier_local0, row_local, n_batches, chunks, n_segments, seg_tab, seg_base, self_rows, col);
     WG_HIP_CHECK(hipGetLastError());
   });
 }

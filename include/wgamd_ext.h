@@ -389,7 +389,8 @@ wholememory_error_code_t wgamd_call_group_hop_rows(const int* offsets, const int
  * local0[s], row 2s + 1 = start[s].  One segment whose start = the node-list offsets is the batch-major list of all
  * vertices (x = feat[n_id]); the output of a trimmed layer is one segment per hop it ran (that hop's frontier list).
  * Writes self_rows[j] (int64, nullable) = input row of frontier entry j itself (local id frontier_local0[b] + j -
- * frontier_seg[b]) and col[e] = input row of edge e's sampled neighbour (row_local[e] = the hop's `neighbor_local`). */
+ * frontier_seg[b]) and col[e] = input row of edge e's sampled neighbour (row_local[e] = the hop's `neighbor_local`).
+ * frontier_seg has n_batches + 1 entries (the last = n_frontier); frontier_batch is not read (may be NULL). */
 wholememory_error_code_t wgamd_call_group_layer_cols(const int* offsets, const int* frontier_batch, const int* frontier_seg,
                                                      const int* frontier_local0, const int* row_local, int64_t n_frontier,
                                                      int n_batches, int n_segments, const int* seg_tab, const int64_t* seg_base,
