@@ -407,8 +407,10 @@ __global__ void __launch_bounds__(256)
 gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows,
                            const float* __restrict__ x, int64_t ldx, int F, const float* __restrict__ a_src,
                            const float* __restrict__ a_dst, float slope, const int64_t* __restrict__ dst_rows,
-                           float* __restrict__ out, int64_t ldo, int log2_lanes)
+                           float* __restrict__ out, int64_t ldo, int log2_lanes, const int64_t* __restrict__ src_ids)
 {
+  // src_ids (nullable): neighbour j's row of x is src_ids[j] — x is then the feature table itself and src_ids the node list
+  // of the call group (fetch in the layer); the attention terms stay indexed by j
   const int lanes       = 1 << log2_lanes;
   const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int sub         = (int)(tid & (lanes - 1));
@@ -431,16 +433,23 @@ gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restric
     }
     for (int c0 = s; c0 < e; c0 += lanes) {
       const int mine = c0 + sub < e ? col[c0 + sub] : 0;
+      const int64_t mine_row = src_ids ? src_ids[mine] : (int64_t)mine;   // (one coalesced-by-chunk load per lane, shuffled below)
       const int cnt  = min(lanes, e - c0);
       for (int k = 0; k < cnt; k += EIF) {
         int idx[EIF];
+        int64_t xr[EIF];
         float4 t[EIF];
         float sc[EIF][H];
 #pragma unroll
-        for (int u = 0; u < EIF; u++) idx[u] = __shfl(mine, gbase | min(k + u, cnt - 1), 64);
+        for (int u = 0; u < EIF; u++) {
+          const int from = gbase | min(k + u, cnt - 1);
+          idx[u]         = __shfl(mine, from, 64);
+          xr[u]          = src_ids ? (((int64_t)__shfl((int)(mine_row >> 32), from, 64) << 32) | (uint32_t)__shfl((int)mine_row, from, 64))
+                                   : (int64_t)idx[u];
+        }
 #pragma unroll
         for (int u = 0; u < EIF; u++) {
-          t[u] = *reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx + f0);
+          t[u] = *reinterpret_cast<const float4*>(x + xr[u] * ldx + f0);
           if constexpr (H == 4) {
             const float4 a4 = *reinterpret_cast<const float4*>(a_src + (int64_t)idx[u] * 4);
             sc[u][0] = a4.x; sc[u][1] = a4.y; sc[u][2] = a4.z; sc[u][3] = a4.w;
@@ -685,13 +694,13 @@ wholememory_error_code_t wgamd_bias_act_rows_f32(const float* in, int64_t ldi, i
   });
 }
 
-wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                       int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
-                                                       float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
-                                                       void* stream)
+wholememory_error_code_t wgamd_gat_aggregate_heads_ids_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                           int64_t ldx, const int64_t* src_ids, int F, const float* a_src,
+                                                           const float* a_dst, int H, float negative_slope,
+                                                           const int64_t* dst_rows, float* out, int64_t ldo, void* stream)
 {
   using namespace wgamd;
-  return guarded("wgamd_gat_aggregate_heads_f32", [&] {
+  return guarded("wgamd_gat_aggregate_heads_ids_f32", [&] {
     WG_REQUIRE_INPUT(n_rows >= 0 && H > 0 && F > 0, "bad sizes");
     if (n_rows == 0) return;
     WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && out, "null pointer");
@@ -704,7 +713,7 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
     const int grid = grid_rows(n_rows, l2);
 #define WG_GAT_AGG(HH, EE)                                                                                                 \
   gat_aggregate_heads_kernel<HH, EE><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope,     \
-                                                          dst_rows, out, ldo, l2)
+                                                          dst_rows, out, ldo, l2, src_ids)
     switch (H) {
       case 1: WG_GAT_AGG(1, 4); break;
       case 2: WG_GAT_AGG(2, 4); break;
@@ -714,6 +723,15 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
 #undef WG_GAT_AGG
     WG_HIP_CHECK(hipGetLastError());
   });
+}
+
+wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                       int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
+                                                       float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
+                                                       void* stream)
+{
+  return wgamd_gat_aggregate_heads_ids_f32(row_ptr, col, n_rows, x, ldx, nullptr, F, a_src, a_dst, H, negative_slope, dst_rows, out,
+                                           ldo, stream);
 }
 
 wholememory_error_code_t wgamd_gat_csr_rows_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,

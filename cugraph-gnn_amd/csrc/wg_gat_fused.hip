@@ -31,6 +31,8 @@ struct gf_args {
   int64_t n_rows;
   const float* x;
   int64_t ldx;
+  const int64_t* src_ids;    // nullable: neighbour j's row of x is src_ids[j] (fetch in the layer: x = the feature table,
+                             // src_ids = the call group's node list; a_src stays indexed by j)
   const float* a_src;        // [n_src, 4]
   const float* a_dst;        // [*, 4], row dst_rows ? dst_rows[i] : i
   const int64_t* dst_rows;   // nullable
@@ -61,7 +63,7 @@ __device__ __forceinline__ void static_for(Fn&& f)
 
 struct st_a { int s, e, valid; };
 struct st_b { int deg, s, colk; int64_t dst; };
-struct st_c { int deg, s; f32x4 asrc, adst; int64_t off; };
+struct st_c { int deg, s; f32x4 asrc, adst; int64_t off; };   // off: the neighbour's row of x (scaled to bytes at issue)
 
 __device__ __forceinline__ void split_b_opaque2(const braw_t& r, bfrag_t& f, uint32_t mask)
 {
@@ -85,6 +87,7 @@ __device__ __forceinline__ void split_b_opaque2(const braw_t& r, bfrag_t& f, uin
   }
 }
 
+template <bool IDS>
 __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][32][kSDA] + [4][kScratchDw]
@@ -134,12 +137,14 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
       o.s    = i.s;
       o.asrc = *reinterpret_cast<const f32x4*>(a.a_src + (int64_t)i.colk * 4);
       o.adst = *reinterpret_cast<const f32x4*>(a.a_dst + i.dst * 4);
-      o.off  = (int64_t)i.colk * a.ldx * 4;
+      if constexpr (IDS) o.off = a.src_ids[i.colk];   // (one more load of the stage: consumed at `issue`, two steps on)
+      else o.off = (int64_t)i.colk;
     };
     auto issue = [&](const st_c& m, f32x4* vv) __attribute__((always_inline)) {
+      const int64_t boff = m.off * a.ldx * 4;
       static_for<0, kNbG>([&](auto K) {
         constexpr int k = decltype(K)::value;
-        const int lo = WG_ROW_BCAST((int)(m.off & 0xffffffff), k), hi = WG_ROW_BCAST((int)(m.off >> 32), k);
+        const int lo = WG_ROW_BCAST((int)(boff & 0xffffffff), k), hi = WG_ROW_BCAST((int)(boff >> 32), k);
         int64_t off  = ((int64_t)hi << 32) | (uint32_t)lo;
         off          = k < m.deg ? off : (int64_t)0;   // slots past the degree read row 0 (cache-resident), weight 0 below
         vv[k]        = *reinterpret_cast<const f32x4*>(xb + off + f0 * 4);
@@ -198,7 +203,9 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
           const bool on   = k < deg;
           const int idx   = a.col[on ? m.s + k : 0];
           const f32x4 a4  = *reinterpret_cast<const f32x4*>(a.a_src + (int64_t)idx * 4);
-          const f32x4 xv  = *reinterpret_cast<const f32x4*>(xb + (int64_t)idx * a.ldx * 4 + f0 * 4);
+          int64_t xrow    = idx;
+          if constexpr (IDS) xrow = a.src_ids[idx];
+          const f32x4 xv  = *reinterpret_cast<const f32x4*>(xb + xrow * a.ldx * 4 + f0 * 4);
 #pragma unroll
           for (int h = 0; h < kH; h++) {
             float t        = a4[h] + m.adst[h];
@@ -337,15 +344,15 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
 
 extern "C" int wgamd_gat_layer_fused_supported(int F, int H, int C) { return F == 128 && H == 4 && C == 64; }
 
-extern "C" wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                                 int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
+extern "C" wholememory_error_code_t wgamd_gat_layer_fused_ids_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                                 int64_t ldx, const int64_t* src_ids, int F, const float* a_src, const float* a_dst, int H,
                                                                  int C, float negative_slope, const int64_t* dst_rows,
                                                                  const void* w_tiles, const float* acc_in, int64_t ld_acc,
                                                                  const float* bias, int relu, const int64_t* out_rows, float* out,
                                                                  int64_t ldo, void* stream)
 {
   using namespace wgamd;
-  return guarded("wgamd_gat_layer_fused_bf16x3", [&] {
+  return guarded("wgamd_gat_layer_fused_ids_bf16x3", [&] {
     WG_REQUIRE_INPUT(n_rows >= 0, "bad sizes");
     if (n_rows == 0) return;
     WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && w_tiles && out, "null pointer");
@@ -356,16 +363,27 @@ extern "C" wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_
         (reinterpret_cast<uintptr_t>(bias) & 15) != 0 || (reinterpret_cast<uintptr_t>(a_src) & 15) != 0 ||
         (reinterpret_cast<uintptr_t>(a_dst) & 15) != 0)
       throw logic_error("rows, attention terms and the bias must be 16-B aligned");
-    gf_args a{row_ptr, col, n_rows, x, ldx, a_src, a_dst, dst_rows, negative_slope, static_cast<const float*>(w_tiles),
+    gf_args a{row_ptr, col, n_rows, x, ldx, src_ids, a_src, a_dst, dst_rows, negative_slope, static_cast<const float*>(w_tiles),
               acc_in, ld_acc, bias, relu, out_rows, out, ldo};
     auto st               = static_cast<hipStream_t>(stream);
     const int cus         = stream_cu_count(st);
     const int64_t n_tiles = (n_rows + 31) / 32;
     const size_t lds      = (size_t)(2 * kTileDw + 4 * kScratchDw) * 4;
     const int grid        = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus));
-    WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fused_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    gat_layer_fused_kernel<<<grid, 512, lds, st>>>(a);
+    auto kernel = src_ids ? gat_layer_fused_kernel<true> : gat_layer_fused_kernel<false>;
+    WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kernel<<<grid, 512, lds, st>>>(a);
     WG_HIP_CHECK(hipGetLastError());
   });
+}
+
+extern "C" wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                                 int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
+                                                                 int C, float negative_slope, const int64_t* dst_rows,
+                                                                 const void* w_tiles, const float* acc_in, int64_t ld_acc,
+                                                                 const float* bias, int relu, const int64_t* out_rows, float* out,
+                                                                 int64_t ldo, void* stream)
+{
+  return wgamd_gat_layer_fused_ids_bf16x3(row_ptr, col, n_rows, x, ldx, nullptr, F, a_src, a_dst, H, C, negative_slope, dst_rows, w_tiles,
+                                          acc_in, ld_acc, bias, relu, out_rows, out, ldo, stream);
 }

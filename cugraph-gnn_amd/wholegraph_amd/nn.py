@@ -382,18 +382,28 @@ def gat_forward_rows(row_ptr, col, x, a_src, a_dst, heads, out, dst_rows=None, a
     return out
 
 
-def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=None, negative_slope=0.2, out=None):
+def _src_ids_ptr(src_ids, a_src):
+    """The id list of a fetch-in-the-layer GAT launch: int64, contiguous, one id per row of the attention terms."""
+    if src_ids is None:
+        return None
+    assert src_ids.dtype == torch.int64 and src_ids.is_contiguous() and src_ids.shape[0] == a_src.shape[0]
+    return src_ids.data_ptr()
+
+
+def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=None, negative_slope=0.2, out=None, src_ids=None):
     """Aggregate-first GAT (wgamd_gat_aggregate_heads_f32): ``agg[i, h, :] = sum_e alpha_e^h x[col[e], :]`` with x
-    untransformed ([N_src, F]); returns ``[n_rows, heads * F]``.  ``gat_transform_heads`` applies the per-head weights."""
+    untransformed ([N_src, F]); returns ``[n_rows, heads * F]``.  ``gat_transform_heads`` applies the per-head weights.
+    ``src_ids`` (int64 [N_src]): the rows are read THROUGH the list, ``x[src_ids[col[e]]]`` — x the feature table, src_ids the
+    call group's node list (``LazyRows``); the attention terms stay indexed by ``col``."""
     _check_csr(row_ptr, col)
     n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
     if out is None:
         out = torch.empty((n_rows, heads * F_), dtype=torch.float32, device=x.device)
     assert a_src.is_contiguous() and a_dst.is_contiguous() and a_src.shape[1] == heads
-    L.check(L.lib().wgamd_gat_aggregate_heads_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_,
-                                                  a_src.data_ptr(), a_dst.data_ptr(), heads, float(negative_slope),
-                                                  None if dst_rows is None else dst_rows.data_ptr(), out.data_ptr(),
-                                                  out.stride(0), get_stream()), "wgamd_gat_aggregate_heads_f32")
+    L.check(L.lib().wgamd_gat_aggregate_heads_ids_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0),
+                                                      _src_ids_ptr(src_ids, a_src), F_, a_src.data_ptr(), a_dst.data_ptr(), heads,
+                                                      float(negative_slope), None if dst_rows is None else dst_rows.data_ptr(),
+                                                      out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_aggregate_heads_ids_f32")
     return out
 
 
@@ -469,9 +479,10 @@ def gat_layer_fused_supported(F_: int, heads: int, C: int) -> bool:
 
 
 def gat_layer_fused(row_ptr, col, x, a_src, a_dst, w, heads, dst_rows=None, negative_slope=0.2, acc_in=None, bias=None, relu=False,
-                    out_rows=None, out=None):
+                    out_rows=None, out=None, src_ids=None):
     """``gat_aggregate_heads`` + ``gat_transform_heads_fused`` as ONE kernel (``wgamd_gat_layer_fused_bf16x3``): the
-    [n_rows, heads * F] aggregate never leaves the CU.  For hops with a fan-out of at most 10 (longer rows are correct, slow)."""
+    [n_rows, heads * F] aggregate never leaves the CU.  For hops with a fan-out of at most 10 (longer rows are correct, slow).
+    ``src_ids``: as in ``gat_aggregate_heads`` (the rows of ``x`` are read through the id list)."""
     _check_csr(row_ptr, col)
     n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
     C = w.shape[1] // heads
@@ -480,12 +491,13 @@ def gat_layer_fused(row_ptr, col, x, a_src, a_dst, w, heads, dst_rows=None, nega
         assert out_rows is None
         out = torch.empty((n_rows, heads * C), dtype=torch.float32, device=x.device)
     assert col.numel() > 0 and out.stride(1) == 1 and (acc_in is None or acc_in.stride(1) == 1)
-    L.check(L.lib().wgamd_gat_layer_fused_bf16x3(
-        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), F_, a_src.data_ptr(), a_dst.data_ptr(), heads, C,
+    L.check(L.lib().wgamd_gat_layer_fused_ids_bf16x3(
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), _src_ids_ptr(src_ids, a_src), F_, a_src.data_ptr(),
+        a_dst.data_ptr(), heads, C,
         float(negative_slope), None if dst_rows is None else dst_rows.data_ptr(), _gat_weight_tiles(w, heads).data_ptr(),
         None if acc_in is None else acc_in.data_ptr(), 0 if acc_in is None else acc_in.stride(0),
         None if bias is None else bias.data_ptr(), int(bool(relu)), None if out_rows is None else out_rows.data_ptr(),
-        out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_layer_fused_bf16x3")
+        out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_layer_fused_ids_bf16x3")
     return out
 
 
@@ -510,6 +522,19 @@ def gather_with_terms(table: torch.Tensor, ids: torch.Tensor, v: torch.Tensor, o
                                            v.data_ptr(), T, out.data_ptr(), out.stride(0), terms.data_ptr(), T, heads,
                                            get_stream()), "wgamd_gather_terms_f32")
     return out, terms
+
+
+def lazy_rows_terms(table: torch.Tensor, ids: torch.Tensor, v: torch.Tensor, heads: int = 0):
+    """``terms = table[ids] @ v`` WITHOUT writing the gathered rows (``wgamd_gather_terms_f32`` with no row output): the attention
+    logits of a ``LazyRows`` input whose rows the relation kernels then read through ``ids`` themselves."""
+    assert table.dtype == torch.float32 and table.dim() == 2 and table.stride(1) == 1 and v.dtype == torch.float32 and v.is_contiguous()
+    assert ids.dim() == 1 and ids.is_contiguous() and ids.dtype in (torch.int32, torch.int64)
+    n, F_, T = int(ids.shape[0]), int(table.shape[1]), int(v.shape[1])
+    assert v.shape[0] == F_ and heads in (0, 4) and (heads == 0 or T % 4 == 0)
+    terms = torch.empty((T // 4, n, 4) if heads else (n, T), dtype=torch.float32, device=table.device)
+    L.check(L.lib().wgamd_gather_terms_f32(table.data_ptr(), table.stride(0), ids.data_ptr(), torch_dtype_to_wm(ids.dtype), n, F_,
+                                           v.data_ptr(), T, None, 0, terms.data_ptr(), T, heads, get_stream()), "wgamd_gather_terms_f32")
+    return terms
 
 
 def rows_terms(x: torch.Tensor, v: torch.Tensor, heads: int = 0):
@@ -1101,6 +1126,9 @@ class HeteroConv(torch.nn.Module):
         # hops with a larger fan-out take the two-kernel path (the fan-out-25 hop of the mag workload through the one-kernel
         # relation: 0.77 ms instead of 0.39 + 0.16 per call group)
         self.fused_max_fanout = int(os.environ.get("WGAMD_GAT_FUSED_MAX_FANOUT", "10"))
+        # a LazyRows input (table + node list) stays lazy: its attention terms come from one read-only pass over the listed rows
+        # and every relation kernel reads the table through the list — the [n, F] copy of the rows is never written
+        self.fetch_in_layer = os.environ.get("WGAMD_GAT_FETCH_IN_LAYER", "1") != "0"
 
     def conv(self, edge_type):
         return self.convs["__".join(edge_type)]
@@ -1169,8 +1197,16 @@ class HeteroConv(torch.nn.Module):
             slabs = None
             if isinstance(v, LazyRows):
                 n, F_ = len(v), v.table.shape[1]
+                terms_ok = vt is not None and n > 0 and H == 4 and v.table.dtype == torch.float32 and gather_terms_supported(F_, vt.shape[1])
+                if self.fetch_in_layer and terms_ok and v.ids.dtype == torch.int64 and isinstance(v.table, torch.Tensor) \
+                        and v._rows is None and v.table.stride(1) == 1 and v.table.stride(0) % 4 == 0 and v.table.data_ptr() % 16 == 0:
+                    x[t] = v
+                    slabs = _stage("attn_terms(lazy)" + self.stage_tag, lambda: lazy_rows_terms(v.table, v.ids, vt, heads=4))
+                    for k, (dst, et) in enumerate(keys):
+                        dst[et] = slabs[k]
+                    continue
                 buf = torch.empty((n, F_), dtype=torch.float32, device=v.table.device)
-                if vt is not None and n > 0 and H == 4 and v.table.dtype == torch.float32 and gather_terms_supported(F_, vt.shape[1]):
+                if terms_ok:
                     x[t], slabs = _stage("gather+attn_terms" + self.stage_tag, lambda: gather_with_terms(v.table, v.ids, vt, out=buf, heads=4))
                 else:
                     x[t] = _stage("gather", lambda: local_gather(v.table, v.ids, buf))
@@ -1220,16 +1256,19 @@ class HeteroConv(torch.nn.Module):
                 et = r.edge_type
                 w = self._rel(et)[0]
                 xsrc, last = x[et[0]], j == len(live) - 1
+                ids = None
+                if isinstance(xsrc, LazyRows):      # fetch in the layer: the kernels read the table through the node list
+                    xsrc, ids = xsrc.table, xsrc.ids
                 tail = dict(acc_in=acc if j > 0 else None, bias=bias if (last and one_pass) else None, relu=last and one_pass and relu,
                             out_rows=place if (last and one_pass) else None, out=target if (last and one_pass) else acc)
                 name = "%s hop %d (%d rows, %d edges)" % (et[1], hop + 1, n_f, r.n_edges)
                 if one_pass and _GAT_LAYER_FUSED and r.fanout <= self.fused_max_fanout and gat_layer_fused_supported(xsrc.shape[1], H, C):
                     # deep hop (fan-out <= 10): aggregation + dense tail as ONE kernel, the aggregate stays in LDS
                     _stage("gat%s+transform:" % self.stage_tag + name, lambda: gat_layer_fused(r.row_ptr, r.col, xsrc, a_src[et], a_dst[et], w, H,
-                                                                            dst_rows=r.dst_rows, **tail))
+                                                                            dst_rows=r.dst_rows, src_ids=ids, **tail))
                     continue
                 agg = _stage("gat%s:" % self.stage_tag + name, lambda: gat_aggregate_heads(r.row_ptr, r.col, xsrc, a_src[et], a_dst[et], H,
-                                                                       dst_rows=r.dst_rows))
+                                                                       dst_rows=r.dst_rows, src_ids=ids))
                 if one_pass:
                     _stage("transform" + self.stage_tag, lambda: gat_transform_heads_fused(agg, w, H, **tail))
                 else:

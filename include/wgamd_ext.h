@@ -423,6 +423,13 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
                                                        int64_t ldx, int F, const float* a_src, const float* a_dst, int H,
                                                        float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
                                                        void* stream);
+/* The same aggregation reading the source rows THROUGH an id list (fetch in the layer): neighbour j's row is x[src_ids[j]] — x
+ * the feature table, src_ids (int64) the call group's node list of the source type — while a_src stays indexed by j.  The
+ * [n_src, F] copy of the rows (wholememory_gather's output) is never written.  src_ids NULL = wgamd_gat_aggregate_heads_f32. */
+wholememory_error_code_t wgamd_gat_aggregate_heads_ids_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                           int64_t ldx, const int64_t* src_ids, int F, const float* a_src,
+                                                           const float* a_dst, int H, float negative_slope,
+                                                           const int64_t* dst_rows, float* out, int64_t ldo, void* stream);
 
 /* The dense tail after wgamd_gat_aggregate_heads_f32 on the matrix pipe at fp32 accuracy (csrc/wg_gat_transform.hip):
  *   out[out_rows ? out_rows[i] : i, h C + c] = act( sum_k agg[i, h F + k] W[k, h C + c] (+ acc_in[i, h C + c]) (+ bias[h C + c]) )
@@ -451,6 +458,13 @@ wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_ptr, const 
                                                       float negative_slope, const int64_t* dst_rows, const void* w_tiles,
                                                       const float* acc_in, int64_t ld_acc, const float* bias, int relu,
                                                       const int64_t* out_rows, float* out, int64_t ldo, void* stream);
+/* wgamd_gat_layer_fused_bf16x3 reading the source rows through an id list (see wgamd_gat_aggregate_heads_ids_f32). */
+wholememory_error_code_t wgamd_gat_layer_fused_ids_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                          int64_t ldx, const int64_t* src_ids, int F, const float* a_src,
+                                                          const float* a_dst, int H, int C, float negative_slope,
+                                                          const int64_t* dst_rows, const void* w_tiles, const float* acc_in,
+                                                          int64_t ld_acc, const float* bias, int relu, const int64_t* out_rows,
+                                                          float* out, int64_t ldo, void* stream);
 
 /* Backward of wgamd_gat_csr_f32 (csrc/wg_gat_bwd.hip): given grad_out [n_rows, H*C] and the forward's alpha [E, H], writes
  * grad_x [n_src, H*C], grad_a_src [n_src, H], grad_a_dst [n_rows, H]; de [E, H] is scratch.  Needs the hop CSR transposed:

@@ -89,6 +89,43 @@ def test_gat_aggregate_heads_matches_oracle_and_transform_first(oracle_mod, hipl
     np.testing.assert_allclose(acc.cpu().numpy(), out + 1.0, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("fanout", [10, 25])
+def test_gat_kernels_read_the_table_through_an_id_list(hiplib, fanout):
+    """Fetch in the layer for GAT relations: wgamd_gat_aggregate_heads_ids_f32 / wgamd_gat_layer_fused_ids_bf16x3 over
+    (feature table, node list) == the same kernels over the gathered rows, bit for bit (same loads, same order), and the
+    attention terms of the listed rows without a row output == the terms the gather produces."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator(device="cuda").manual_seed(fanout)
+    F, H, C, n_table, n_src, n_rows = 128, 4, 64, 50000, 7000, 1500
+    table = torch.randn((n_table, F), generator=g, device="cuda")
+    ids = torch.randint(0, n_table, (n_src,), generator=g, device="cuda")
+    ids[:2] = torch.tensor([0, n_table - 1], device="cuda")
+    deg = torch.randint(0, fanout + 1, (n_rows,), generator=g, device="cuda")
+    deg[::11] = 0
+    deg[5] = 3 * fanout                      # past the register window of the one-kernel relation
+    rp = torch.zeros(n_rows + 1, dtype=torch.int32, device="cuda")
+    rp[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(0, n_src, (int(rp[-1]),), generator=g, device="cuda", dtype=torch.int32)
+    v = torch.randn((F, 8), generator=g, device="cuda") * 0.3
+    dst_rows = torch.randperm(n_src, generator=g, device="cuda")[:n_rows].contiguous()
+    x, slabs = nn.gather_with_terms(table, ids, v, heads=4)
+    lazy_slabs = nn.lazy_rows_terms(table, ids, v, heads=4)
+    assert torch.equal(x, table[ids]) and torch.equal(slabs, lazy_slabs)
+    a_src, a_dst = slabs[0], slabs[1]
+    agg = nn.gat_aggregate_heads(rp, col, x, a_src, a_dst, H, dst_rows=dst_rows)
+    agg_ids = nn.gat_aggregate_heads(rp, col, table, a_src, a_dst, H, dst_rows=dst_rows, src_ids=ids)
+    assert torch.equal(agg, agg_ids)
+    w = torch.randn((F, H * C), generator=g, device="cuda") / F ** 0.5
+    bias = torch.randn(H * C, generator=g, device="cuda")
+    acc = torch.randn((n_rows, H * C), generator=g, device="cuda")
+    out = nn.gat_layer_fused(rp, col, x, a_src, a_dst, w, H, dst_rows=dst_rows, acc_in=acc, bias=bias, relu=True)
+    out_ids = nn.gat_layer_fused(rp, col, table, a_src, a_dst, w, H, dst_rows=dst_rows, acc_in=acc, bias=bias, relu=True, src_ids=ids)
+    assert torch.equal(out, out_ids)
+    with pytest.raises(AssertionError):
+        nn.gat_aggregate_heads(rp, col, table, a_src, a_dst, H, dst_rows=dst_rows, src_ids=ids.int())
+
+
 def test_mag_pipeline_matches_cpu_port(oracle_mod, hiplib):
     """The config-5 path through the PACKAGE — GraphStore + FeatureStore -> NeighborLoader.call_groups() (HeteroCallGroup) ->
     2 x nn.HeteroConv{GATConv(., 64, heads=4)} — against the float64 composition on the C oracle, mini-batch by mini-batch."""
@@ -111,6 +148,13 @@ def test_mag_pipeline_matches_cpu_port(oracle_mod, hiplib):
     grp = groups[0]
     with torch.no_grad():
         out = bm.forward_group(model, grp)
+        assert all(layer.fetch_in_layer for layer in model)
+        # x stays lazy by default (the relation kernels read the tables through the node lists); gathering first is the same bits
+        for layer in model:
+            layer.fetch_in_layer = False
+        assert torch.equal(bm.forward_group(model, grp), out)
+        for layer in model:
+            layer.fetch_in_layer = True
         # the relation-by-relation route (GATConv modules, transform-first: what trains) computes the same layer
         h = grp.node_attr("x", lazy=False)
         for j, layer in enumerate(model):
