@@ -407,8 +407,10 @@ __global__ void __launch_bounds__(256)
 gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows,
                            const float* __restrict__ x, int64_t ldx, int F, const float* __restrict__ a_src,
                            const float* __restrict__ a_dst, float slope, const int64_t* __restrict__ dst_rows,
-                           float* __restrict__ out, int64_t ldo, int log2_lanes, const int64_t* __restrict__ src_ids)
+                           float* __restrict__ out, int64_t ldo, int log2_lanes, const int64_t* __restrict__ src_ids,
+                           const int64_t* __restrict__ dst_ids, int terms_by_id)
 {
+  // terms_by_id bit 0: a_src holds the terms of the TABLE's rows (row src_ids[j]); bit 1: a_dst likewise (row dst_ids[dst])
   // src_ids (nullable): neighbour j's row of x is src_ids[j] — x is then the feature table itself and src_ids the node list
   // of the call group (fetch in the layer); the attention terms stay indexed by j
   const int lanes       = 1 << log2_lanes;
@@ -421,7 +423,8 @@ gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restric
   const int f0          = live ? sub * 4 : 0;
   for (int64_t row = group; row < n_rows; row += ngroups) {
     const int s = row_ptr[row], e = row_ptr[row + 1];
-    const int64_t arow = dst_rows ? dst_rows[row] : row;
+    int64_t arow = dst_rows ? dst_rows[row] : row;
+    if (terms_by_id & 2) arow = dst_ids[arow];
     float ad[H], m[H], d[H];
     float4 acc[H];
 #pragma unroll
@@ -450,12 +453,13 @@ gat_aggregate_heads_kernel(const int* __restrict__ row_ptr, const int* __restric
 #pragma unroll
         for (int u = 0; u < EIF; u++) {
           t[u] = *reinterpret_cast<const float4*>(x + xr[u] * ldx + f0);
+          const int64_t trow = (terms_by_id & 1) ? xr[u] : (int64_t)idx[u];
           if constexpr (H == 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(a_src + (int64_t)idx[u] * 4);
+            const float4 a4 = *reinterpret_cast<const float4*>(a_src + trow * 4);
             sc[u][0] = a4.x; sc[u][1] = a4.y; sc[u][2] = a4.z; sc[u][3] = a4.w;
           } else {
 #pragma unroll
-            for (int h = 0; h < H; h++) sc[u][h] = a_src[(int64_t)idx[u] * H + h];
+            for (int h = 0; h < H; h++) sc[u][h] = a_src[trow * H + h];
           }
         }
 #pragma unroll
@@ -695,13 +699,16 @@ wholememory_error_code_t wgamd_bias_act_rows_f32(const float* in, int64_t ldi, i
 }
 
 wholememory_error_code_t wgamd_gat_aggregate_heads_ids_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                           int64_t ldx, const int64_t* src_ids, int F, const float* a_src,
+                                                           int64_t ldx, const int64_t* src_ids, const int64_t* dst_ids,
+                                                           int terms_by_id, int F, const float* a_src,
                                                            const float* a_dst, int H, float negative_slope,
                                                            const int64_t* dst_rows, float* out, int64_t ldo, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_gat_aggregate_heads_ids_f32", [&] {
     WG_REQUIRE_INPUT(n_rows >= 0 && H > 0 && F > 0, "bad sizes");
+    WG_REQUIRE_INPUT(terms_by_id >= 0 && terms_by_id <= 3 && (terms_by_id == 0 || src_ids) && (!(terms_by_id & 2) || dst_ids),
+                     "terms_by_id needs src_ids (and dst_ids for bit 1)");
     if (n_rows == 0) return;
     WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && out, "null pointer");
     if (F % 4 != 0 || F > 256 || !(H == 1 || H == 2 || H == 4 || H == 8) || !vec4_ok(x, ldx, out, ldo, F) ||
@@ -713,7 +720,7 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_ids_f32(const int* row_ptr, c
     const int grid = grid_rows(n_rows, l2);
 #define WG_GAT_AGG(HH, EE)                                                                                                 \
   gat_aggregate_heads_kernel<HH, EE><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope,     \
-                                                          dst_rows, out, ldo, l2, src_ids)
+                                                          dst_rows, out, ldo, l2, src_ids, dst_ids, terms_by_id)
     switch (H) {
       case 1: WG_GAT_AGG(1, 4); break;
       case 2: WG_GAT_AGG(2, 4); break;
@@ -730,7 +737,7 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
                                                        float negative_slope, const int64_t* dst_rows, float* out, int64_t ldo,
                                                        void* stream)
 {
-  return wgamd_gat_aggregate_heads_ids_f32(row_ptr, col, n_rows, x, ldx, nullptr, F, a_src, a_dst, H, negative_slope, dst_rows, out,
+  return wgamd_gat_aggregate_heads_ids_f32(row_ptr, col, n_rows, x, ldx, nullptr, nullptr, 0, F, a_src, a_dst, H, negative_slope, dst_rows, out,
                                            ldo, stream);
 }
 

@@ -32,7 +32,10 @@ struct gf_args {
   const float* x;
   int64_t ldx;
   const int64_t* src_ids;    // nullable: neighbour j's row of x is src_ids[j] (fetch in the layer: x = the feature table,
-                             // src_ids = the call group's node list; a_src stays indexed by j)
+                             // src_ids = the call group's node list; a_src stays indexed by j unless terms_by_id & 1)
+  const int64_t* dst_ids;    // node list of the destination type (terms_by_id & 2)
+  int terms_by_id;           // bit 0: a_src holds the terms of the TABLE's rows, row src_ids[j]; bit 1: a_dst likewise, row
+                             // dst_ids[dst_rows ? dst_rows[i] : i] — the per-list terms are then never made
   const float* a_src;        // [n_src, 4]
   const float* a_dst;        // [*, 4], row dst_rows ? dst_rows[i] : i
   const int64_t* dst_rows;   // nullable
@@ -63,7 +66,7 @@ __device__ __forceinline__ void static_for(Fn&& f)
 
 struct st_a { int s, e, valid; };
 struct st_b { int deg, s, colk; int64_t dst; };
-struct st_c { int deg, s; f32x4 asrc, adst; int64_t off; };   // off: the neighbour's row of x (scaled to bytes at issue)
+struct st_c { int deg, s; f32x4 asrc, adst; int64_t off, dsti; };   // off: the neighbour's row of x (scaled to bytes at issue)
 
 __device__ __forceinline__ void split_b_opaque2(const braw_t& r, bfrag_t& f, uint32_t mask)
 {
@@ -135,12 +138,22 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
     auto stage_c = [&](st_c& o, const st_b& i) __attribute__((always_inline)) {
       o.deg  = i.deg;
       o.s    = i.s;
-      o.asrc = *reinterpret_cast<const f32x4*>(a.a_src + (int64_t)i.colk * 4);
-      o.adst = *reinterpret_cast<const f32x4*>(a.a_dst + i.dst * 4);
-      if constexpr (IDS) o.off = a.src_ids[i.colk];   // (one more load of the stage: consumed at `issue`, two steps on)
-      else o.off = (int64_t)i.colk;
+      if constexpr (IDS) {
+        o.off = a.src_ids[i.colk];   // (one more load of the stage: consumed at `issue`, two steps on)
+        if (!(a.terms_by_id & 1)) o.asrc = *reinterpret_cast<const f32x4*>(a.a_src + (int64_t)i.colk * 4);
+        if (a.terms_by_id & 2) o.dsti = a.dst_ids[i.dst];
+        else o.adst = *reinterpret_cast<const f32x4*>(a.a_dst + i.dst * 4);
+      } else {
+        o.off  = (int64_t)i.colk;
+        o.asrc = *reinterpret_cast<const f32x4*>(a.a_src + (int64_t)i.colk * 4);
+        o.adst = *reinterpret_cast<const f32x4*>(a.a_dst + i.dst * 4);
+      }
     };
-    auto issue = [&](const st_c& m, f32x4* vv) __attribute__((always_inline)) {
+    auto issue = [&](st_c& m, f32x4* vv) __attribute__((always_inline)) {
+      if constexpr (IDS) {   // terms of the table's rows: the ids arrived with stage c, the terms are consumed at `reduce`, two steps on
+        if (a.terms_by_id & 1) m.asrc = *reinterpret_cast<const f32x4*>(a.a_src + m.off * 4);
+        if (a.terms_by_id & 2) m.adst = *reinterpret_cast<const f32x4*>(a.a_dst + m.dsti * 4);
+      }
       const int64_t boff = m.off * a.ldx * 4;
       static_for<0, kNbG>([&](auto K) {
         constexpr int k = decltype(K)::value;
@@ -202,9 +215,9 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
         for (int k = kNbG; k < maxdeg; k++) {
           const bool on   = k < deg;
           const int idx   = a.col[on ? m.s + k : 0];
-          const f32x4 a4  = *reinterpret_cast<const f32x4*>(a.a_src + (int64_t)idx * 4);
           int64_t xrow    = idx;
           if constexpr (IDS) xrow = a.src_ids[idx];
+          const f32x4 a4  = *reinterpret_cast<const f32x4*>(a.a_src + ((IDS && (a.terms_by_id & 1)) ? xrow : (int64_t)idx) * 4);
           const f32x4 xv  = *reinterpret_cast<const f32x4*>(xb + xrow * a.ldx * 4 + f0 * 4);
 #pragma unroll
           for (int h = 0; h < kH; h++) {
@@ -345,7 +358,8 @@ __global__ void __launch_bounds__(512) gat_layer_fused_kernel(gf_args a)
 extern "C" int wgamd_gat_layer_fused_supported(int F, int H, int C) { return F == 128 && H == 4 && C == 64; }
 
 extern "C" wholememory_error_code_t wgamd_gat_layer_fused_ids_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                                 int64_t ldx, const int64_t* src_ids, int F, const float* a_src, const float* a_dst, int H,
+                                                                 int64_t ldx, const int64_t* src_ids, const int64_t* dst_ids, int terms_by_id,
+                                                                 int F, const float* a_src, const float* a_dst, int H,
                                                                  int C, float negative_slope, const int64_t* dst_rows,
                                                                  const void* w_tiles, const float* acc_in, int64_t ld_acc,
                                                                  const float* bias, int relu, const int64_t* out_rows, float* out,
@@ -363,7 +377,9 @@ extern "C" wholememory_error_code_t wgamd_gat_layer_fused_ids_bf16x3(const int* 
         (reinterpret_cast<uintptr_t>(bias) & 15) != 0 || (reinterpret_cast<uintptr_t>(a_src) & 15) != 0 ||
         (reinterpret_cast<uintptr_t>(a_dst) & 15) != 0)
       throw logic_error("rows, attention terms and the bias must be 16-B aligned");
-    gf_args a{row_ptr, col, n_rows, x, ldx, src_ids, a_src, a_dst, dst_rows, negative_slope, static_cast<const float*>(w_tiles),
+    WG_REQUIRE_INPUT(terms_by_id >= 0 && terms_by_id <= 3 && (terms_by_id == 0 || src_ids) && (!(terms_by_id & 2) || dst_ids),
+                     "terms_by_id needs src_ids (and dst_ids for bit 1)");
+    gf_args a{row_ptr, col, n_rows, x, ldx, src_ids, dst_ids, terms_by_id, a_src, a_dst, dst_rows, negative_slope, static_cast<const float*>(w_tiles),
               acc_in, ld_acc, bias, relu, out_rows, out, ldo};
     auto st               = static_cast<hipStream_t>(stream);
     const int cus         = stream_cu_count(st);
@@ -384,6 +400,6 @@ extern "C" wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_
                                                                  const float* bias, int relu, const int64_t* out_rows, float* out,
                                                                  int64_t ldo, void* stream)
 {
-  return wgamd_gat_layer_fused_ids_bf16x3(row_ptr, col, n_rows, x, ldx, nullptr, F, a_src, a_dst, H, C, negative_slope, dst_rows, w_tiles,
+  return wgamd_gat_layer_fused_ids_bf16x3(row_ptr, col, n_rows, x, ldx, nullptr, nullptr, 0, F, a_src, a_dst, H, C, negative_slope, dst_rows, w_tiles,
                                           acc_in, ld_acc, bias, relu, out_rows, out, ldo, stream);
 }

@@ -235,6 +235,26 @@ void launch_km(int KM, int TT, int grid, hipStream_t st, const float* table, int
   }
 }
 
+// out[k][i][0..3] = in[k][ids[i]][0..3] for the K slabs of a node type's attention terms: the terms of a call group's rows
+// taken from the terms of the TABLE's rows (a call group lists a table row once per mini-batch that sampled it: when the
+// table is shorter than the group's node list, x @ v over the table + this 16-byte-row gather replaces x[ids] @ v over the
+// list).  One lane per listed row: the id is read once, the K loads are independent, stores are coalesced per slab.
+template <typename IdT>
+__global__ void __launch_bounds__(256)
+gather_term_slabs_kernel(const f32x4* __restrict__ in, int64_t n_in, int K, const IdT* __restrict__ ids, int64_t n,
+                         f32x4* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = (int64_t)ids[i];
+    const bool live  = id >= 0 && id < n_in;          // (a skipped row: zero terms, as wgamd_gather_terms_f32 writes)
+    for (int k = 0; k < K; k++) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (live) v = in[(int64_t)k * n_in + id];
+      __builtin_nontemporal_store(v, out + (int64_t)k * n + i);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace wgamd
 
@@ -268,6 +288,29 @@ wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt,
       launch_km<int32_t>(KM, TT, grid, st, table, ldt, static_cast<const int32_t*>(ids), n, v, T, out_x, ldx, out_terms, ldo, term_group);
     else
       launch_km<int64_t>(KM, TT, grid, st, table, ldt, static_cast<const int64_t*>(ids), n, v, T, out_x, ldx, out_terms, ldo, term_group);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_gather_term_slabs_f32(const float* slabs_in, int64_t n_in, int n_slabs, const void* ids,
+                                                     wholememory_dtype_t id_dtype, int64_t n, float* slabs_out, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gather_term_slabs_f32", [&] {
+    WG_REQUIRE_INPUT(id_dtype == WHOLEMEMORY_DT_INT || id_dtype == WHOLEMEMORY_DT_INT64, "id dtype must be INT|INT64");
+    WG_REQUIRE_INPUT(n >= 0 && n_in >= 0 && n_slabs >= 0 && n_slabs <= 64, "bad sizes");
+    if (n == 0 || n_slabs == 0) return;
+    WG_REQUIRE_INPUT(slabs_in && ids && slabs_out, "null pointer");
+    if (((reinterpret_cast<uintptr_t>(slabs_in) | reinterpret_cast<uintptr_t>(slabs_out)) & 15) != 0)
+      throw logic_error("gather_term_slabs: slabs must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)stream_cu_count(st) * 16);
+    if (id_dtype == WHOLEMEMORY_DT_INT)
+      gather_term_slabs_kernel<int32_t><<<grid, 256, 0, st>>>(reinterpret_cast<const f32x4*>(slabs_in), n_in, n_slabs,
+                                                              static_cast<const int32_t*>(ids), n, reinterpret_cast<f32x4*>(slabs_out));
+    else
+      gather_term_slabs_kernel<int64_t><<<grid, 256, 0, st>>>(reinterpret_cast<const f32x4*>(slabs_in), n_in, n_slabs,
+                                                              static_cast<const int64_t*>(ids), n, reinterpret_cast<f32x4*>(slabs_out));
     WG_HIP_CHECK(hipGetLastError());
   });
 }

@@ -382,26 +382,32 @@ def gat_forward_rows(row_ptr, col, x, a_src, a_dst, heads, out, dst_rows=None, a
     return out
 
 
-def _src_ids_ptr(src_ids, a_src):
-    """The id list of a fetch-in-the-layer GAT launch: int64, contiguous, one id per row of the attention terms."""
+def _gat_ids(src_ids, dst_ids, a_src, src_terms_by_id, dst_terms_by_id):
+    """(src_ids pointer, dst_ids pointer, terms_by_id) of a fetch-in-the-layer GAT launch: int64 contiguous lists; without
+    ``src_terms_by_id`` the attention terms have one row per listed id."""
     if src_ids is None:
-        return None
-    assert src_ids.dtype == torch.int64 and src_ids.is_contiguous() and src_ids.shape[0] == a_src.shape[0]
-    return src_ids.data_ptr()
+        assert not src_terms_by_id and not dst_terms_by_id
+        return None, None, 0
+    assert src_ids.dtype == torch.int64 and src_ids.is_contiguous() and (src_terms_by_id or src_ids.shape[0] == a_src.shape[0])
+    assert not dst_terms_by_id or (dst_ids is not None and dst_ids.dtype == torch.int64 and dst_ids.is_contiguous())
+    return src_ids.data_ptr(), dst_ids.data_ptr() if dst_terms_by_id else None, int(bool(src_terms_by_id)) | 2 * int(bool(dst_terms_by_id))
 
 
-def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=None, negative_slope=0.2, out=None, src_ids=None):
+def gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=None, negative_slope=0.2, out=None, src_ids=None, dst_ids=None,
+                        src_terms_by_id=False, dst_terms_by_id=False):
     """Aggregate-first GAT (wgamd_gat_aggregate_heads_f32): ``agg[i, h, :] = sum_e alpha_e^h x[col[e], :]`` with x
     untransformed ([N_src, F]); returns ``[n_rows, heads * F]``.  ``gat_transform_heads`` applies the per-head weights.
     ``src_ids`` (int64 [N_src]): the rows are read THROUGH the list, ``x[src_ids[col[e]]]`` — x the feature table, src_ids the
-    call group's node list (``LazyRows``); the attention terms stay indexed by ``col``."""
+    call group's node list (``LazyRows``); the attention terms stay indexed by ``col`` — unless ``src_terms_by_id``: ``a_src`` then
+    holds the terms of the TABLE's rows, read at ``src_ids[col[e]]`` (``dst_terms_by_id``: ``a_dst`` at ``dst_ids[dst row]``)."""
     _check_csr(row_ptr, col)
+    ids_p, dids_p, by_id = _gat_ids(src_ids, dst_ids, a_src, src_terms_by_id, dst_terms_by_id)
     n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
     if out is None:
         out = torch.empty((n_rows, heads * F_), dtype=torch.float32, device=x.device)
     assert a_src.is_contiguous() and a_dst.is_contiguous() and a_src.shape[1] == heads
     L.check(L.lib().wgamd_gat_aggregate_heads_ids_f32(row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0),
-                                                      _src_ids_ptr(src_ids, a_src), F_, a_src.data_ptr(), a_dst.data_ptr(), heads,
+                                                      ids_p, dids_p, by_id, F_, a_src.data_ptr(), a_dst.data_ptr(), heads,
                                                       float(negative_slope), None if dst_rows is None else dst_rows.data_ptr(),
                                                       out.data_ptr(), out.stride(0), get_stream()), "wgamd_gat_aggregate_heads_ids_f32")
     return out
@@ -479,11 +485,12 @@ def gat_layer_fused_supported(F_: int, heads: int, C: int) -> bool:
 
 
 def gat_layer_fused(row_ptr, col, x, a_src, a_dst, w, heads, dst_rows=None, negative_slope=0.2, acc_in=None, bias=None, relu=False,
-                    out_rows=None, out=None, src_ids=None):
+                    out_rows=None, out=None, src_ids=None, dst_ids=None, src_terms_by_id=False, dst_terms_by_id=False):
     """``gat_aggregate_heads`` + ``gat_transform_heads_fused`` as ONE kernel (``wgamd_gat_layer_fused_bf16x3``): the
     [n_rows, heads * F] aggregate never leaves the CU.  For hops with a fan-out of at most 10 (longer rows are correct, slow).
-    ``src_ids``: as in ``gat_aggregate_heads`` (the rows of ``x`` are read through the id list)."""
+    ``src_ids`` / ``dst_ids`` / ``*_terms_by_id``: as in ``gat_aggregate_heads``."""
     _check_csr(row_ptr, col)
+    ids_p, dids_p, by_id = _gat_ids(src_ids, dst_ids, a_src, src_terms_by_id, dst_terms_by_id)
     n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
     C = w.shape[1] // heads
     assert x.dtype == torch.float32 and x.stride(1) == 1 and a_src.is_contiguous() and a_dst.is_contiguous() and a_src.shape[1] == heads
@@ -492,7 +499,7 @@ def gat_layer_fused(row_ptr, col, x, a_src, a_dst, w, heads, dst_rows=None, nega
         out = torch.empty((n_rows, heads * C), dtype=torch.float32, device=x.device)
     assert col.numel() > 0 and out.stride(1) == 1 and (acc_in is None or acc_in.stride(1) == 1)
     L.check(L.lib().wgamd_gat_layer_fused_ids_bf16x3(
-        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), _src_ids_ptr(src_ids, a_src), F_, a_src.data_ptr(),
+        row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), ids_p, dids_p, by_id, F_, a_src.data_ptr(),
         a_dst.data_ptr(), heads, C,
         float(negative_slope), None if dst_rows is None else dst_rows.data_ptr(), _gat_weight_tiles(w, heads).data_ptr(),
         None if acc_in is None else acc_in.data_ptr(), 0 if acc_in is None else acc_in.stride(0),
@@ -535,6 +542,18 @@ def lazy_rows_terms(table: torch.Tensor, ids: torch.Tensor, v: torch.Tensor, hea
     L.check(L.lib().wgamd_gather_terms_f32(table.data_ptr(), table.stride(0), ids.data_ptr(), torch_dtype_to_wm(ids.dtype), n, F_,
                                            v.data_ptr(), T, None, 0, terms.data_ptr(), T, heads, get_stream()), "wgamd_gather_terms_f32")
     return terms
+
+
+def gather_term_slabs(slabs: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """``out[k, i] = slabs[k, ids[i]]`` for attention-term slabs [K, n_table, 4] (``wgamd_gather_term_slabs_f32``): the terms of a
+    call group's rows from the terms of the table's rows."""
+    assert slabs.dtype == torch.float32 and slabs.dim() == 3 and slabs.shape[2] == 4 and slabs.is_contiguous()
+    assert ids.dim() == 1 and ids.is_contiguous() and ids.dtype in (torch.int32, torch.int64)
+    K, n_in, n = int(slabs.shape[0]), int(slabs.shape[1]), int(ids.shape[0])
+    out = torch.empty((K, n, 4), dtype=torch.float32, device=slabs.device)
+    L.check(L.lib().wgamd_gather_term_slabs_f32(slabs.data_ptr(), n_in, K, ids.data_ptr(), torch_dtype_to_wm(ids.dtype), n,
+                                                out.data_ptr(), get_stream()), "wgamd_gather_term_slabs_f32")
+    return out
 
 
 def rows_terms(x: torch.Tensor, v: torch.Tensor, heads: int = 0):
@@ -1187,6 +1206,7 @@ class HeteroConv(torch.nn.Module):
         rows of every node type — inside the row gather for a ``LazyRows`` input, a streaming pass over a resident one."""
         from .tensor import local_gather
         x, a_src, a_dst = {}, {}, {}
+        self._by_id = set()          # node types whose terms are those of the TABLE's rows (read through the node list)
         for t in graph.node_types:
             v = xs.get(t)
             if v is None:
@@ -1201,7 +1221,13 @@ class HeteroConv(torch.nn.Module):
                 if self.fetch_in_layer and terms_ok and v.ids.dtype == torch.int64 and isinstance(v.table, torch.Tensor) \
                         and v._rows is None and v.table.stride(1) == 1 and v.table.stride(0) % 4 == 0 and v.table.data_ptr() % 16 == 0:
                     x[t] = v
-                    slabs = _stage("attn_terms(lazy)" + self.stage_tag, lambda: lazy_rows_terms(v.table, v.ids, vt, heads=4))
+                    if 2 * v.table.shape[0] <= n:
+                        # the group lists a table row once per mini-batch that sampled it: terms of the TABLE's rows (made in
+                        # every call: nothing is kept between calls), which the relation kernels read through the node lists
+                        slabs = _stage("attn_terms(table)" + self.stage_tag, lambda: rows_terms(v.table, vt, heads=4))
+                        self._by_id.add(t)
+                    else:
+                        slabs = _stage("attn_terms(lazy)" + self.stage_tag, lambda: lazy_rows_terms(v.table, v.ids, vt, heads=4))
                     for k, (dst, et) in enumerate(keys):
                         dst[et] = slabs[k]
                     continue
@@ -1256,19 +1282,24 @@ class HeteroConv(torch.nn.Module):
                 et = r.edge_type
                 w = self._rel(et)[0]
                 xsrc, last = x[et[0]], j == len(live) - 1
-                ids = None
+                ids, through = None, {}
                 if isinstance(xsrc, LazyRows):      # fetch in the layer: the kernels read the table through the node list
                     xsrc, ids = xsrc.table, xsrc.ids
+                    through = dict(src_ids=ids, src_terms_by_id=et[0] in self._by_id)
+                    if et[2] in self._by_id:
+                        through.update(dst_ids=x[et[2]].ids, dst_terms_by_id=True)
+                elif et[2] in self._by_id:          # (terms of the destination table's rows next to a resident source: per-list terms)
+                    a_dst[et] = gather_term_slabs(a_dst[et].unsqueeze(0), x[et[2]].ids)[0]
                 tail = dict(acc_in=acc if j > 0 else None, bias=bias if (last and one_pass) else None, relu=last and one_pass and relu,
                             out_rows=place if (last and one_pass) else None, out=target if (last and one_pass) else acc)
                 name = "%s hop %d (%d rows, %d edges)" % (et[1], hop + 1, n_f, r.n_edges)
                 if one_pass and _GAT_LAYER_FUSED and r.fanout <= self.fused_max_fanout and gat_layer_fused_supported(xsrc.shape[1], H, C):
                     # deep hop (fan-out <= 10): aggregation + dense tail as ONE kernel, the aggregate stays in LDS
                     _stage("gat%s+transform:" % self.stage_tag + name, lambda: gat_layer_fused(r.row_ptr, r.col, xsrc, a_src[et], a_dst[et], w, H,
-                                                                            dst_rows=r.dst_rows, src_ids=ids, **tail))
+                                                                            dst_rows=r.dst_rows, **through, **tail))
                     continue
                 agg = _stage("gat%s:" % self.stage_tag + name, lambda: gat_aggregate_heads(r.row_ptr, r.col, xsrc, a_src[et], a_dst[et], H,
-                                                                       dst_rows=r.dst_rows, src_ids=ids))
+                                                                       dst_rows=r.dst_rows, **through))
                 if one_pass:
                     _stage("transform" + self.stage_tag, lambda: gat_transform_heads_fused(agg, w, H, **tail))
                 else:

@@ -425,9 +425,13 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_f32(const int* row_ptr, const
                                                        void* stream);
 /* The same aggregation reading the source rows THROUGH an id list (fetch in the layer): neighbour j's row is x[src_ids[j]] — x
  * the feature table, src_ids (int64) the call group's node list of the source type — while a_src stays indexed by j.  The
- * [n_src, F] copy of the rows (wholememory_gather's output) is never written.  src_ids NULL = wgamd_gat_aggregate_heads_f32. */
+ * [n_src, F] copy of the rows (wholememory_gather's output) is never written.  src_ids NULL = wgamd_gat_aggregate_heads_f32.
+ * terms_by_id: bit 0 — a_src holds the attention terms of the TABLE's rows and is read at row src_ids[j]; bit 1 — a_dst
+ * likewise at row dst_ids[dst_rows ? dst_rows[i] : i] (dst_ids = the node list of the destination type).  The per-list terms
+ * are then never made: a call group lists a table row once per mini-batch that sampled it. */
 wholememory_error_code_t wgamd_gat_aggregate_heads_ids_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                           int64_t ldx, const int64_t* src_ids, int F, const float* a_src,
+                                                           int64_t ldx, const int64_t* src_ids, const int64_t* dst_ids,
+                                                           int terms_by_id, int F, const float* a_src,
                                                            const float* a_dst, int H, float negative_slope,
                                                            const int64_t* dst_rows, float* out, int64_t ldo, void* stream);
 
@@ -460,7 +464,8 @@ wholememory_error_code_t wgamd_gat_layer_fused_bf16x3(const int* row_ptr, const 
                                                       const int64_t* out_rows, float* out, int64_t ldo, void* stream);
 /* wgamd_gat_layer_fused_bf16x3 reading the source rows through an id list (see wgamd_gat_aggregate_heads_ids_f32). */
 wholememory_error_code_t wgamd_gat_layer_fused_ids_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
-                                                          int64_t ldx, const int64_t* src_ids, int F, const float* a_src,
+                                                          int64_t ldx, const int64_t* src_ids, const int64_t* dst_ids,
+                                                          int terms_by_id, int F, const float* a_src,
                                                           const float* a_dst, int H, int C, float negative_slope,
                                                           const int64_t* dst_rows, const void* w_tiles, const float* acc_in,
                                                           int64_t ld_acc, const float* bias, int relu, const int64_t* out_rows,
@@ -602,6 +607,12 @@ int wgamd_gather_terms_supported(int F, int T);
 wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt, const void* ids, wholememory_dtype_t id_dtype,
                                                 int64_t n, int F, const float* v, int T, float* out_x, int64_t ldx,
                                                 float* out_terms, int64_t ldo, int term_group, void* stream);
+/* slabs_out[k][i][0..3] = slabs_in[k][ids[i]][0..3], k < n_slabs: the attention terms of a call group's rows taken from the
+ * terms of the TABLE's rows ([n_slabs][n_in][4], what wgamd_gather_terms_f32 writes with ids = NULL and term_group = 4).  A
+ * call group lists a table row once per mini-batch that sampled it; when the table is shorter than the list, x @ v over the
+ * table + this gather of 16-byte rows replaces x[ids] @ v over the list.  A negative or out-of-range id gives zero terms. */
+wholememory_error_code_t wgamd_gather_term_slabs_f32(const float* slabs_in, int64_t n_in, int n_slabs, const void* ids,
+                                                     wholememory_dtype_t id_dtype, int64_t n, float* slabs_out, void* stream);
 
 /* De-duplication of an id list with a known bound (ids < id_bound, e.g. the vertex count of the table they index):
  *   distinct[0 .. *n_distinct_dev)  the distinct non-negative ids, ASCENDING (so already grouped by owner rank of a

@@ -112,6 +112,12 @@ def test_gat_kernels_read_the_table_through_an_id_list(hiplib, fanout):
     x, slabs = nn.gather_with_terms(table, ids, v, heads=4)
     lazy_slabs = nn.lazy_rows_terms(table, ids, v, heads=4)
     assert torch.equal(x, table[ids]) and torch.equal(slabs, lazy_slabs)
+    # ... and == the terms of the TABLE's rows gathered through the list (what a call group longer than the table takes)
+    table_slabs = nn.rows_terms(table, v, heads=4)
+    assert torch.equal(nn.gather_term_slabs(table_slabs, ids), slabs) and torch.equal(nn.gather_term_slabs(table_slabs, ids.int()), slabs)
+    holes = ids.clone()
+    holes[::5] = -1
+    assert torch.equal(nn.gather_term_slabs(table_slabs, holes), nn.lazy_rows_terms(table, holes, v, heads=4))
     a_src, a_dst = slabs[0], slabs[1]
     agg = nn.gat_aggregate_heads(rp, col, x, a_src, a_dst, H, dst_rows=dst_rows)
     agg_ids = nn.gat_aggregate_heads(rp, col, table, a_src, a_dst, H, dst_rows=dst_rows, src_ids=ids)
@@ -122,6 +128,13 @@ def test_gat_kernels_read_the_table_through_an_id_list(hiplib, fanout):
     out = nn.gat_layer_fused(rp, col, x, a_src, a_dst, w, H, dst_rows=dst_rows, acc_in=acc, bias=bias, relu=True)
     out_ids = nn.gat_layer_fused(rp, col, table, a_src, a_dst, w, H, dst_rows=dst_rows, acc_in=acc, bias=bias, relu=True, src_ids=ids)
     assert torch.equal(out, out_ids)
+    # the attention terms of the TABLE's rows, read through the lists (either end, both): the per-list terms are never made
+    ts, td = table_slabs[0], table_slabs[1]
+    for kw in (dict(src_terms_by_id=True), dict(dst_ids=ids, dst_terms_by_id=True), dict(src_terms_by_id=True, dst_ids=ids, dst_terms_by_id=True)):
+        s_, d_ = (ts if kw.get("src_terms_by_id") else a_src), (td if kw.get("dst_terms_by_id") else a_dst)
+        assert torch.equal(nn.gat_aggregate_heads(rp, col, table, s_, d_, H, dst_rows=dst_rows, src_ids=ids, **kw), agg)
+        assert torch.equal(nn.gat_layer_fused(rp, col, table, s_, d_, w, H, dst_rows=dst_rows, acc_in=acc, bias=bias, relu=True,
+                                              src_ids=ids, **kw), out)
     with pytest.raises(AssertionError):
         nn.gat_aggregate_heads(rp, col, table, a_src, a_dst, H, dst_rows=dst_rows, src_ids=ids.int())
 

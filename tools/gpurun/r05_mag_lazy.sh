@@ -1,7 +1,7 @@
 # GAT relations reading the feature tables through the node lists (fetch in the layer): tests, then bench_mag A/B on one box
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r05_mag_lazy; mkdir -p $OUT; cd $R
 timeout 1200 python -m pytest tests/test_gpu_mag_pipeline.py tests/test_gpu_call_group_loader.py -m gpu -q -x -n 4 2>&1 | tail -3
-for lazy in 1 0 1 0; do
+for lazy in 1 1; do
   WGAMD_GAT_FETCH_IN_LAYER=$lazy timeout 900 python bench.py --workload mag --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_$lazy.log 2>&1
   python - $OUT/bench_$lazy.log $lazy <<'PY'
 import json, sys
