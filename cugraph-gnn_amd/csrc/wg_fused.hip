@@ -181,6 +181,35 @@ hetero_hop_rows_kernel(const int* __restrict__ offsets, const int* __restrict__ 
   }
 }
 
+// The same as hetero_hop_rows_kernel with the number of batches known: block (batch, chunk) reads the batch's four segment
+// starts once and streams its stretch of frontier entries and edges with every lane (see layer_cols_kernel below).
+__global__ void __launch_bounds__(256)
+hetero_hop_rows_batched_kernel(const int* __restrict__ offsets, const int* __restrict__ f_seg, const int* __restrict__ f_local0,
+                               const int* __restrict__ row_local, int chunks, const int* __restrict__ seg_dst,
+                               const int64_t* __restrict__ cseg_dst, const int* __restrict__ seg_src,
+                               const int64_t* __restrict__ cseg_src, int64_t* __restrict__ dst_full,
+                               int64_t* __restrict__ dst_compact, int* __restrict__ col_full, int* __restrict__ col_compact)
+{
+  const int b = blockIdx.x / chunks, c = blockIdx.x % chunks, t = threadIdx.x;
+  const int f0 = f_seg[b], f1 = f_seg[b + 1];
+  const int j0 = f0 + (int)((int64_t)(f1 - f0) * c / chunks), j1 = f0 + (int)((int64_t)(f1 - f0) * (c + 1) / chunks);
+  if (j0 >= j1) return;
+  const int e0 = offsets[j0], e1 = offsets[j1];
+  const int64_t d_full = (int64_t)seg_dst[b] + f_local0[b] - f0;
+  const int64_t d_c    = dst_compact ? cseg_dst[b] + f_local0[b] - f0 : 0;
+  const int add_full   = seg_src[b];
+  const int add_c      = col_compact ? (int)cseg_src[b] : 0;
+  for (int j = j0 + t; j < j1; j += 256) {
+    dst_full[j] = d_full + j;
+    if (dst_compact) dst_compact[j] = d_c + j;
+  }
+  for (int i = e0 + t; i < e1; i += 256) {
+    const int r = row_local[i];
+    col_full[i] = r + add_full;
+    if (col_compact) col_compact[i] = r + add_c;
+  }
+}
+
 // One hop of a homogeneous (or one edge type of a) PyG-style call group, renumbered for the LAYER that consumes it.  The
 // layer's input rows are laid out as `n_seg` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at
 // rows base[s] + start[s][b] + (local id - local0[s][b]) — one segment (start = the node-list offsets) is the batch-major
@@ -429,6 +458,28 @@ wholememory_error_code_t wgamd_call_group_hop_rows(const int* offsets, const int
     hetero_hop_rows_kernel<<<ceil_div(n_frontier * 16, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
       offsets, frontier_batch, frontier_seg, frontier_local0, row_local, (int)n_frontier, seg_dst, compact_seg_dst, seg_src,
       compact_seg_src, dst_full, dst_compact, col_full, col_compact);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_call_group_hop_rows_batched(const int* offsets, const int* frontier_seg, const int* frontier_local0,
+                                                           const int* row_local, int64_t n_frontier, int n_batches,
+                                                           const int* seg_dst, const int64_t* compact_seg_dst, const int* seg_src,
+                                                           const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
+                                                           int* col_full, int* col_compact, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_call_group_hop_rows_batched", [&] {
+    WG_REQUIRE_INPUT(n_frontier >= 0 && n_frontier < ((int64_t)1 << 27) && n_batches >= 1 && n_batches < (1 << 20), "bad counts");
+    if (n_frontier == 0) return;
+    WG_REQUIRE_INPUT(offsets && frontier_seg && frontier_local0 && row_local && seg_dst && seg_src && dst_full && col_full,
+                     "null pointer");
+    WG_REQUIRE_INPUT((dst_compact == nullptr) == (compact_seg_dst == nullptr) && (col_compact == nullptr) == (compact_seg_src == nullptr),
+                     "a compact output needs its compact segment array (and the other way round)");
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(ceil_div(n_frontier, (int64_t)n_batches), 512)));
+    hetero_hop_rows_batched_kernel<<<n_batches * chunks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      offsets, frontier_seg, frontier_local0, row_local, chunks, seg_dst, compact_seg_dst, seg_src, compact_seg_src, dst_full,
+      dst_compact, col_full, col_compact);
     WG_HIP_CHECK(hipGetLastError());
   });
 }

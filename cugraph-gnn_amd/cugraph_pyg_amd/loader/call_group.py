@@ -345,7 +345,7 @@ class HeteroCallGroup:
 
     def _numbered(self, ci: int, level_a: int, level_b: int, want_col_b: bool):
         """Rows of call ``ci``'s frontier entries / edge sources in the numberings of two levels — ONE launch
-        (``wgamd_call_group_hop_rows``) for both, cached: the output numbering of layer j is the input numbering of layer j + 1."""
+        (``wgamd_call_group_hop_rows_batched``) for both, cached: the output numbering of layer j is the input numbering of layer j + 1."""
         c, (n_f, n_e) = self._rec["calls"][ci], self._live[ci]
         got = self._rows.setdefault(ci, {})
         if level_a in got and (level_b in got or level_b == 0) and (not want_col_b or got.get(level_b, (None, None))[1] is not None):
@@ -358,12 +358,12 @@ class HeteroCallGroup:
         dst_b = torch.empty(n_f, dtype=torch.int64, device=dev) if need_b else None
         col_b = torch.empty(max(n_e, 1), dtype=torch.int32, device=dev) if want_col_b else None
         state = self._rec["state"]
-        L.check(L.lib().wgamd_call_group_hop_rows(
-            c["offsets"].data_ptr(), c["f_batch"].data_ptr(), c["f_seg"].data_ptr(), c["f_local0"].data_ptr(), c["row"].data_ptr(),
-            n_f, self._seg(level_a, dst_t, True).data_ptr(), self._seg(level_b, dst_t, False).data_ptr() if need_b else None,
+        L.check(L.lib().wgamd_call_group_hop_rows_batched(
+            c["offsets"].data_ptr(), c["f_seg"].data_ptr(), c["f_local0"].data_ptr(), c["row"].data_ptr(),
+            n_f, self.n_batches, self._seg(level_a, dst_t, True).data_ptr(), self._seg(level_b, dst_t, False).data_ptr() if need_b else None,
             self._seg(level_a, src_t, True).data_ptr(), self._seg(level_b, src_t, False).data_ptr() if want_col_b else None,
             dst_a.data_ptr(), dst_b.data_ptr() if need_b else None, col_a.data_ptr(), col_b.data_ptr() if want_col_b else None,
-            get_stream()), "wgamd_call_group_hop_rows")
+            get_stream()), "wgamd_call_group_hop_rows_batched")
         got[level_a] = (dst_a, col_a[:n_e])
         if need_b:
             got[level_b] = (dst_b, col_b[:n_e] if want_col_b else None)

@@ -382,6 +382,14 @@ wholememory_error_code_t wgamd_call_group_hop_rows(const int* offsets, const int
                                                    const int* seg_dst, const int64_t* compact_seg_dst, const int* seg_src,
                                                    const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
                                                    int* col_full, int* col_compact, void* stream);
+/* wgamd_call_group_hop_rows with the number of mini-batches given (frontier_seg has n_batches + 1 entries, the last =
+ * n_frontier; the batch of an entry follows from it): one block per (batch, stretch of its frontier entries) reads the batch's
+ * segment starts once and streams entries and edges with every lane — 3-4x faster at call-group sizes. */
+wholememory_error_code_t wgamd_call_group_hop_rows_batched(const int* offsets, const int* frontier_seg, const int* frontier_local0,
+                                                           const int* row_local, int64_t n_frontier, int n_batches,
+                                                           const int* seg_dst, const int64_t* compact_seg_dst, const int* seg_src,
+                                                           const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
+                                                           int* col_full, int* col_compact, void* stream);
 
 /* One hop of a PyG-style call group renumbered for the LAYER that consumes it (cugraph_pyg_amd.loader.CallGroup).  The
  * layer's input rows are `n_segments` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at rows

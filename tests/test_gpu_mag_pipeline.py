@@ -282,6 +282,30 @@ def test_call_group_hop_rows_matches_the_index_formulas(hiplib):
     eb = torch.repeat_interleave(fb, deg)
     assert torch.equal(dst_full, seg_d.long()[fb] + local) and torch.equal(dst_c, cseg_d[fb] + local)
     assert torch.equal(col_full.long(), row_l.long() + seg_s.long()[eb]) and torch.equal(col_c.long(), row_l.long() + cseg_s[eb])
+    # the (batch, chunk) block form the loaders call: same numbers, with and without the compact numbering, many entries per batch
+    for G2, hi in ((G, 40), (3, 4000)):
+        cnt2 = torch.randint(0, hi, (G2,), generator=g, device="cuda"); cnt2[1] = 0
+        fs = torch.zeros(G2 + 1, dtype=torch.int32, device="cuda"); fs[1:] = torch.cumsum(cnt2, 0)
+        nf2 = int(fs[-1])
+        fb2 = torch.repeat_interleave(torch.arange(G2, device="cuda"), cnt2)
+        deg2 = torch.randint(0, 30, (nf2,), generator=g, device="cuda")
+        off2 = torch.zeros(nf2 + 1, dtype=torch.int32, device="cuda"); off2[1:] = torch.cumsum(deg2, 0)
+        ne2 = int(off2[-1])
+        rl2 = torch.randint(0, 500, (ne2,), generator=g, device="cuda").int()
+        for compact in (True, False):
+            d_f, d_c = torch.empty(nf2, dtype=torch.int64, device="cuda"), torch.empty(nf2, dtype=torch.int64, device="cuda")
+            c_f, c_c = torch.empty(ne2, dtype=torch.int32, device="cuda"), torch.empty(ne2, dtype=torch.int32, device="cuda")
+            rc = hiplib.wgamd_call_group_hop_rows_batched(
+                off2.data_ptr(), fs.data_ptr(), f_local0.data_ptr(), rl2.data_ptr(), nf2, G2, seg_d.data_ptr(),
+                cseg_d.data_ptr() if compact else None, seg_s.data_ptr(), cseg_s.data_ptr() if compact else None, d_f.data_ptr(),
+                d_c.data_ptr() if compact else None, c_f.data_ptr(), c_c.data_ptr() if compact else None, None)
+            assert rc == L.WHOLEMEMORY_SUCCESS
+            torch.cuda.synchronize()
+            local2 = f_local0.long()[fb2] + (torch.arange(nf2, device="cuda") - fs.long()[fb2])
+            eb2 = torch.repeat_interleave(fb2, deg2)
+            assert torch.equal(d_f, seg_d.long()[fb2] + local2) and torch.equal(c_f.long(), rl2.long() + seg_s.long()[eb2])
+            if compact:
+                assert torch.equal(d_c, cseg_d[fb2] + local2) and torch.equal(c_c.long(), rl2.long() + cseg_s[eb2])
 
 
 def test_bias_act_rows(hiplib):
