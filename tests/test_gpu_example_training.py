@@ -36,3 +36,15 @@ def test_call_group_training_example_learns(hiplib, monkeypatch):
                                       "--fanout", "10", "5"])
     loss, acc = ex.main()
     assert loss < 1.5 and acc > 0.6, (loss, acc)
+
+
+def test_hetero_gat_call_group_example_learns_and_lazy_equals_gathered(hiplib, monkeypatch):
+    """examples/hetero_gat_call_groups.py: HeteroConv{GATConv} over heterogeneous call groups — trains relation by relation
+    (autograd), infers through the one-kernel relations reading the feature tables through the node lists; the class signal
+    lives in the AUTHORS, so beating chance means the author -> paper relation is used."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import hetero_gat_call_groups as ex
+    monkeypatch.setattr(sys, "argv", ["x", "--papers", "12000", "--authors", "6000", "--epochs", "6", "--batch-size", "256",
+                                      "--group", "2"])
+    loss, acc, same_bits = ex.main()
+    assert same_bits and acc > 0.4 and loss < 1.7, (loss, acc, same_bits)       # (chance: 0.125, ln 8 = 2.08)
