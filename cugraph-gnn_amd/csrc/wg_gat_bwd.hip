@@ -302,8 +302,156 @@ wholememory_error_code_t gat_csr_bwd(const char* op, const int* row_ptr, const i
     WG_HIP_CHECK(hipGetLastError());
   });
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the AGGREGATE-FIRST GAT aggregation (wgamd_gat_aggregate_heads[_ids]_f32):
+//     agg[i, h, :] = sum_e alpha_e^h x[r(e), :],   alpha^h = softmax_e(LeakyReLU(a_src[t(e), h] + a_dst[d(i), h]))
+// (x untransformed, F floats shared by the H heads; r / t / d = the row of x, of a_src, of a_dst an edge / a destination reads:
+// plain, or through the id lists of the fetch-in-the-layer forward).  Given g = dL/dagg [n_rows, H F]:
+//     p_e^h  = <g[i, h, :], x[r(e), :]>,   ds_e^h = alpha_e^h (p_e^h - sum_k alpha_k^h p_k^h),   de_e^h = ds_e^h LeakyReLU'(.)
+//     ga_dst[d(i), h] += sum_e de_e^h,   ga_src[t(e), h] += de_e^h,   gx[r(e), :] += sum_h alpha_e^h g[i, h, :]   (gx optional)
+// One lane group (F / 4 lanes) per destination row — the forward's mapping: the row's H gradient slices sit in registers, every
+// neighbour row is read once (16 B per lane), the H dot products are reduced with xor-shuffles inside the group, p is parked in
+// `de` between the two passes.  ga_src / ga_dst / gx are ACCUMULATED with float atomics into caller-zeroed buffers: with the
+// terms of the table's rows one table row collects from every mini-batch that sampled it, and a source row from every
+// destination that drew it (a sampled hop has at most `fan-out` edges per row: no long-row path).  The sums' order is not
+// fixed: results are reproducible to fp32 rounding, not bit for bit.  Semantics: torch_geometric.nn.GATConv's message /
+// aggregate (pylibwholegraph/torch/gnn_model.py:45-59) in the aggregate-first form of DESIGN.md section 3.5.
+template <int H>
+__global__ void __launch_bounds__(256)
+gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows,
+                               const float* __restrict__ x, int64_t ldx, int F, const float* __restrict__ a_src,
+                               const float* __restrict__ a_dst, float slope, const int64_t* __restrict__ dst_rows,
+                               const int64_t* __restrict__ src_ids, const int64_t* __restrict__ dst_ids, int terms_by_id,
+                               const float* __restrict__ g, int64_t ldg, float* __restrict__ de, float* __restrict__ ga_src,
+                               float* __restrict__ ga_dst, float* __restrict__ gx, int64_t ldgx, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const bool live       = sub * 4 < F;
+  const int f0          = live ? sub * 4 : 0;
+  for (int64_t row = group; row < n_rows; row += ngroups) {
+    const int s = row_ptr[row], e = row_ptr[row + 1];
+    if (s == e) continue;   // (no edge: nothing flows back; uniform over the lane group)
+    int64_t arow = dst_rows ? dst_rows[row] : row;
+    if (terms_by_id & 2) arow = dst_ids[arow];
+    float ad[H], m[H], den[H], dot[H], gad[H];
+    float4 g4[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      ad[h]  = a_dst[arow * H + h];
+      m[h]   = -INFINITY;
+      den[h] = 0.f;
+      dot[h] = 0.f;
+      gad[h] = 0.f;
+      g4[h]  = live ? *reinterpret_cast<const float4*>(g + row * ldg + (int64_t)h * F + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto score = [&](int64_t trow, int h) {
+      const float v = a_src[trow * H + h] + ad[h];
+      return v > 0.f ? v : v * slope;
+    };
+    auto term_row = [&](int c) -> int64_t { return (terms_by_id & 1) ? src_ids[c] : (int64_t)c; };
+    // the row's softmax statistics (terms only; every lane of the group computes them)
+    for (int j = s; j < e; j++) {
+      const int64_t tr = term_row(col[j]);
+#pragma unroll
+      for (int h = 0; h < H; h++) m[h] = fmaxf(m[h], score(tr, h));
+    }
+    for (int j = s; j < e; j++) {
+      const int64_t tr = term_row(col[j]);
+#pragma unroll
+      for (int h = 0; h < H; h++) den[h] += expf(score(tr, h) - m[h]);
+    }
+    // pass 1: p per edge and head (parked in de), dot = sum alpha p, gx
+    for (int j = s; j < e; j++) {
+      const int c      = col[j];
+      const int64_t xr = src_ids ? src_ids[c] : (int64_t)c;
+      const int64_t tr = (terms_by_id & 1) ? xr : (int64_t)c;
+      float4 x4        = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) x4 = *reinterpret_cast<const float4*>(x + xr * ldx + f0);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        float p = g4[h].x * x4.x + g4[h].y * x4.y + g4[h].z * x4.z + g4[h].w * x4.w;
+        for (int d = lanes >> 1; d >= 1; d >>= 1) p += __shfl_xor(p, d, 64);
+        const float al = expf(score(tr, h) - m[h]) / den[h];
+        dot[h] += al * p;
+        if (sub == 0) de[(int64_t)j * H + h] = p;
+        acc.x += al * g4[h].x; acc.y += al * g4[h].y; acc.z += al * g4[h].z; acc.w += al * g4[h].w;
+      }
+      if (gx != nullptr && live) {
+        float* q = gx + xr * ldgx + f0;
+        unsafeAtomicAdd(q, acc.x); unsafeAtomicAdd(q + 1, acc.y); unsafeAtomicAdd(q + 2, acc.z); unsafeAtomicAdd(q + 3, acc.w);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // lane 0's parked p are read by the other lanes of the group below
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // pass 2: the lanes of the group split the row's edges
+    for (int j = s + sub; j < e; j += lanes) {
+      const int64_t tr = term_row(col[j]);
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const float raw = a_src[tr * H + h] + ad[h];
+        const float sc  = raw > 0.f ? raw : raw * slope;
+        float ds        = expf(sc - m[h]) / den[h] * (de[(int64_t)j * H + h] - dot[h]);
+        ds              = raw > 0.f ? ds : ds * slope;
+        de[(int64_t)j * H + h] = ds;
+        gad[h] += ds;
+        unsafeAtomicAdd(ga_src + tr * H + h, ds);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      float v = gad[h];
+      for (int d = lanes >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if (sub == 0) unsafeAtomicAdd(ga_dst + arow * H + h, v);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace wgamd
+
+extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                                      int64_t ldx, const int64_t* src_ids, const int64_t* dst_ids,
+                                                                      int terms_by_id, int F, const float* a_src, const float* a_dst,
+                                                                      int H, float negative_slope, const int64_t* dst_rows,
+                                                                      const float* grad_agg, int64_t ldg, float* de, float* grad_a_src,
+                                                                      float* grad_a_dst, float* grad_x, int64_t ldgx, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gat_aggregate_heads_bwd_f32", [&] {
+    WG_REQUIRE_INPUT(n_rows >= 0 && H > 0 && F > 0, "bad sizes");
+    WG_REQUIRE_INPUT(terms_by_id >= 0 && terms_by_id <= 3 && (terms_by_id == 0 || src_ids) && (!(terms_by_id & 2) || dst_ids),
+                     "terms_by_id needs src_ids (and dst_ids for bit 1)");
+    if (n_rows == 0) return;
+    WG_REQUIRE_INPUT(row_ptr && col && x && a_src && a_dst && grad_agg && de && grad_a_src && grad_a_dst, "null pointer");
+    if (F % 4 != 0 || F > 256 || !(H == 1 || H == 2 || H == 4 || H == 8) || (ldx & 3) != 0 || (ldg & 3) != 0 ||
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_agg)) & 15) != 0 ||
+        (grad_x && ((ldgx & 3) != 0 || (reinterpret_cast<uintptr_t>(grad_x) & 15) != 0)))
+      throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), H=%d (1, 2, 4 or 8), 16-B aligned rows", F, H));
+    WG_REQUIRE_INPUT(ldx >= F && ldg >= (int64_t)H * F && (!grad_x || ldgx >= F), "leading dimension");
+    auto st      = static_cast<hipStream_t>(stream);
+    int l2       = 0;
+    while ((1 << l2) < F / 4 && l2 < 6) l2++;
+    const int64_t groups_per_block = 256 >> l2;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + groups_per_block - 1) / groups_per_block, 256 * 16));
+#define WG_GAT_AGG_BWD(HH)                                                                                                        \
+  gat_aggregate_heads_bwd_kernel<HH><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope, dst_rows, \
+                                                           src_ids, dst_ids, terms_by_id, grad_agg, ldg, de, grad_a_src, grad_a_dst, \
+                                                           grad_x, ldgx, l2)
+    switch (H) {
+      case 1: WG_GAT_AGG_BWD(1); break;
+      case 2: WG_GAT_AGG_BWD(2); break;
+      case 4: WG_GAT_AGG_BWD(4); break;
+      default: WG_GAT_AGG_BWD(8); break;
+    }
+#undef WG_GAT_AGG_BWD
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
 
 /* the entry point of rounds 1-2 (no n_entries): the piece capacity is whatever the workspace holds */
 extern "C" wholememory_error_code_t wgamd_gat_csr_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,

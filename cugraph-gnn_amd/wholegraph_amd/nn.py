@@ -1119,6 +1119,39 @@ class HeteroLayerGraph:
         return sum(r.n_edges for r in self.relations)
 
 
+class _GatAggregateHeads(torch.autograd.Function):
+    """``gat_aggregate_heads`` under autograd: the aggregate-first GAT aggregation of a sampled hop with gradients for the
+    attention terms (at the rows the forward read them from: per listed row, or per TABLE row) and, when ``x`` requires it, for
+    the source rows (``wgamd_gat_aggregate_heads_bwd_f32``; float atomics: reproducible to fp32 rounding).  The dense tail —
+    per-head weights, the sum over relations, bias — stays in torch on the few destination rows."""
+
+    @staticmethod
+    def forward(ctx, x, a_src, a_dst, row_ptr, col, heads, dst_rows, src_ids, dst_ids, src_by_id, dst_by_id, slope):
+        a_src, a_dst = a_src.contiguous(), a_dst.contiguous()
+        agg = gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=dst_rows, negative_slope=slope, src_ids=src_ids,
+                                  dst_ids=dst_ids, src_terms_by_id=src_by_id, dst_terms_by_id=dst_by_id)
+        ctx.save_for_backward(x, a_src, a_dst, row_ptr, col)
+        ctx.extra = (heads, dst_rows, src_ids, dst_ids, src_by_id, dst_by_id, slope)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a_src, a_dst, row_ptr, col = ctx.saved_tensors
+        heads, dst_rows, src_ids, dst_ids, src_by_id, dst_by_id, slope = ctx.extra
+        g = g.contiguous()
+        n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
+        ga_src, ga_dst = torch.zeros_like(a_src), torch.zeros_like(a_dst)
+        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        de = torch.empty((max(int(col.shape[0]), 1), heads), dtype=torch.float32, device=g.device)
+        ids_p, dids_p, by_id = _gat_ids(src_ids, dst_ids, a_src, src_by_id, dst_by_id)
+        L.check(L.lib().wgamd_gat_aggregate_heads_bwd_f32(
+            row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), ids_p, dids_p, by_id, F_, a_src.data_ptr(),
+            a_dst.data_ptr(), heads, float(slope), None if dst_rows is None else dst_rows.data_ptr(), g.data_ptr(), g.stride(0),
+            de.data_ptr(), ga_src.data_ptr(), ga_dst.data_ptr(), None if gx is None else gx.data_ptr(),
+            0 if gx is None else gx.stride(0), get_stream()), "wgamd_gat_aggregate_heads_bwd_f32")
+        return gx, ga_src, ga_dst, None, None, None, None, None, None, None, None, None
+
+
 class HeteroConv(torch.nn.Module):
     """``torch_geometric.nn.HeteroConv({edge_type: conv}, aggr="sum")`` for ``GATConv`` relations: the output of a node type
     is the sum over the relations ending in it (examples/mag_lp_mnmg.py:141 builds this stack; GATConv as
@@ -1148,6 +1181,9 @@ class HeteroConv(torch.nn.Module):
         # a LazyRows input (table + node list) stays lazy: its attention terms come from one read-only pass over the listed rows
         # and every relation kernel reads the table through the list — the [n, F] copy of the rows is never written
         self.fetch_in_layer = os.environ.get("WGAMD_GAT_FETCH_IN_LAYER", "1") != "0"
+        # under autograd a call-group layer is aggregate-first too (``_forward_layer_train``); 0: PyG's own relation-by-relation,
+        # transform-first formulation on ``GATConv`` (``_forward_relations``: the lin GEMM over every source row)
+        self.train_aggregate_first = os.environ.get("WGAMD_GAT_TRAIN_AGGREGATE_FIRST", "1") != "0"
 
     def conv(self, edge_type):
         return self.convs["__".join(edge_type)]
@@ -1321,8 +1357,13 @@ class HeteroConv(torch.nn.Module):
     def forward(self, x_dict, graph, act=None):
         if isinstance(graph, HeteroLayerGraph):
             needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-            if not needs_grad and all(self.conv(et).concat and not self.conv(et).add_self_loops for et in self.edge_types):
+            plain = all(self.conv(et).concat and not self.conv(et).add_self_loops for et in self.edge_types)
+            if not needs_grad and plain:
                 return self._forward_layer(x_dict, graph, act)
+            if plain and self.train_aggregate_first and all(
+                    self.conv(et).heads in (1, 2, 4, 8) and self.conv(et).lin.weight.shape[1] % 4 == 0
+                    and self.conv(et).lin.weight.shape[1] <= 256 for et in self.edge_types):
+                return self._forward_layer_train(x_dict, graph, act)
             return self._forward_relations(x_dict, graph, act)
         out = {}
         for et in self.edge_types:
@@ -1331,6 +1372,84 @@ class HeteroConv(torch.nn.Module):
             y = self.conv(et)((x_dict[et[0]], x_dict[et[2]]), graph[et])
             out[et[2]] = y if et[2] not in out else out[et[2]] + y
         return {t: torch.relu(v) for t, v in out.items()} if act == "relu" else out
+
+    def _forward_layer_train(self, xs, graph: HeteroLayerGraph, act=None):
+        """The call-group layer under autograd, AGGREGATE-FIRST like the inference route: per relation the attention-weighted
+        sum of the UNTRANSFORMED source rows (``_GatAggregateHeads``: one kernel forward, one backward; a ``LazyRows`` input is
+        read through its node list, its attention terms are those of the table's rows when the table is the shorter side), then
+        the per-head weights on the few destination rows, HeteroConv's sum, bias, activation and row placement in torch — every
+        parameter (lin weight, att_src, att_dst, bias) gets its gradient through ordinary autograd on top of the two kernels."""
+        assert act in (None, "relu")
+        X, ids, by_id, terms = {}, {}, {}, {}
+        for t in graph.node_types:
+            v = xs.get(t)
+            if v is None:
+                continue
+            ends = self._term_keys(t)
+            if isinstance(v, LazyRows) and isinstance(v.table, torch.Tensor) and v.ids.dtype == torch.int64 \
+                    and v.table.dtype == torch.float32 and v.table.stride(1) == 1 and v.table.stride(0) % 4 == 0 \
+                    and v.table.data_ptr() % 16 == 0 and v._rows is None:
+                X[t], ids[t] = v.table, v.ids
+                by_id[t] = 2 * v.table.shape[0] <= len(v)
+                rows = v.table if by_id[t] else None
+            else:
+                X[t] = v.materialize() if isinstance(v, LazyRows) else v
+                ids[t], by_id[t], rows = None, False, X[t]
+            if not ends or len(v) == 0:
+                continue
+            folds = []
+            for end, et in ends:          # differentiable folds: alpha = x (W . att)
+                c = self.conv(et)
+                w3 = c.lin.weight.t().reshape(c.lin.weight.shape[1], c.heads, c.out_channels)
+                folds.append((w3 * (c.att_src if end == "src" else c.att_dst).view(1, c.heads, c.out_channels)).sum(-1))
+            if rows is None:              # lazy, table longer than the list: terms of the listed rows
+                rows = v.materialize()
+            both = rows @ torch.cat(folds, 1)
+            H = self.conv(ends[0][1]).heads
+            for k, (end, et) in enumerate(ends):
+                terms[(end, et)] = both[:, k * H:(k + 1) * H]
+        dev = next(iter(X.values())).device
+        groups = {}
+        for r in graph.relations:
+            groups.setdefault((r.hop, r.edge_type[2]), []).append(r)
+        out = {t: torch.zeros((n, self._width(t)), dtype=torch.float32, device=dev) for t, n in graph.n_out.items()
+               if n > 0 and any(dt == t for _, dt in groups)}
+        for (hop, dt), mine in sorted(groups.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+            n_f = mine[0].n_rows
+            if n_f == 0:
+                continue
+            acc = None
+            for r in mine:
+                if r.n_edges == 0:
+                    continue
+                et = r.edge_type
+                c = self.conv(et)
+                H, C = c.heads, c.out_channels
+                st, dt_ = et[0], et[2]
+                lazy_src = ids[st] is not None
+                # (the kernel's id-list mode needs a lazy source; a resident source next to by-id destination terms reads them per row)
+                a_dst = terms[("dst", et)]
+                dst_by_id = bool(by_id[dt_]) and lazy_src
+                if by_id[dt_] and not lazy_src:
+                    a_dst = a_dst[ids[dt_]]
+                agg = _GatAggregateHeads.apply(X[st], terms[("src", et)], a_dst, r.row_ptr, r.col, H, r.dst_rows,
+                                               ids[st], ids[dt_] if dst_by_id else None, bool(by_id[st]) and lazy_src, dst_by_id,
+                                               c.negative_slope)
+                F_ = X[st].shape[1]
+                w3 = c.lin.weight.t().reshape(F_, H, C)
+                y = torch.einsum("nhf,fhc->nhc", agg.view(n_f, H, F_), w3).reshape(n_f, H * C)
+                acc = y if acc is None else acc + y
+            if acc is None:
+                acc = torch.zeros((n_f, self._width(dt)), dtype=torch.float32, device=dev)
+            for r in mine:
+                b = self.conv(r.edge_type).bias
+                if b is not None:
+                    acc = acc + b
+            if act == "relu":
+                acc = torch.relu(acc)
+            place = mine[0].out_rows
+            out[dt] = acc if place is None else out[dt].index_copy(0, place, acc)
+        return out
 
     def _forward_relations(self, xs, graph: HeteroLayerGraph, act=None):
         """The same layer relation by relation through ``GATConv`` (autograd: the training route of a call group)."""

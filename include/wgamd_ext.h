@@ -442,6 +442,17 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_ids_f32(const int* row_ptr, c
                                                            int terms_by_id, int F, const float* a_src,
                                                            const float* a_dst, int H, float negative_slope,
                                                            const int64_t* dst_rows, float* out, int64_t ldo, void* stream);
+/* Backward of wgamd_gat_aggregate_heads[_ids]_f32 (csrc/wg_gat_bwd.hip): given grad_agg = dL/dagg [n_rows, H F],
+ * ACCUMULATES (float atomics, caller-zeroed buffers) grad_a_src / grad_a_dst at the rows the forward read its terms from
+ * (per listed row, or per TABLE row with terms_by_id) and, when grad_x is given, grad_x[row of x an edge read] += sum_h
+ * alpha_e^h grad_agg[i, h, :].  de: scratch [edges, H] floats (holds dL/d(score) per edge and head on return).  Same
+ * addressing arguments as the forward. */
+wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
+                                                           int64_t ldx, const int64_t* src_ids, const int64_t* dst_ids,
+                                                           int terms_by_id, int F, const float* a_src, const float* a_dst, int H,
+                                                           float negative_slope, const int64_t* dst_rows, const float* grad_agg,
+                                                           int64_t ldg, float* de, float* grad_a_src, float* grad_a_dst,
+                                                           float* grad_x, int64_t ldgx, void* stream);
 
 /* The dense tail after wgamd_gat_aggregate_heads_f32 on the matrix pipe at fp32 accuracy (csrc/wg_gat_transform.hip):
  *   out[out_rows ? out_rows[i] : i, h C + c] = act( sum_k agg[i, h F + k] W[k, h C + c] (+ acc_in[i, h C + c]) (+ bias[h C + c]) )
