@@ -325,13 +325,26 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
                                const float* __restrict__ g, int64_t ldg, float* __restrict__ de, float* __restrict__ ga_src,
                                float* __restrict__ ga_dst, float* __restrict__ gx, int64_t ldgx, int log2_lanes)
 {
+  // Lane k of the group OWNS edge c0 + k of the current chunk of `lanes` edges: its column, term row, scores and attention
+  // weights are loaded / computed once, by that lane (coalesced), and broadcast where the whole group needs them; the
+  // neighbour rows of a chunk are requested four at a time.
+  constexpr int EIF     = 4;
   const int lanes       = 1 << log2_lanes;
   const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int sub         = (int)(tid & (lanes - 1));
+  const int gbase       = (int)(threadIdx.x & 63) & ~(lanes - 1);
   const int64_t group   = tid >> log2_lanes;
   const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
   const bool live       = sub * 4 < F;
   const int f0          = live ? sub * 4 : 0;
+  auto group_sum = [&](float v) {
+    for (int d = lanes >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+  };
+  auto group_max = [&](float v) {
+    for (int d = lanes >> 1; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+  };
   for (int64_t row = group; row < n_rows; row += ngroups) {
     const int s = row_ptr[row], e = row_ptr[row + 1];
     if (s == e) continue;   // (no edge: nothing flows back; uniform over the lane group)
@@ -348,64 +361,110 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
       gad[h] = 0.f;
       g4[h]  = live ? *reinterpret_cast<const float4*>(g + row * ldg + (int64_t)h * F + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto score = [&](int64_t trow, int h) {
-      const float v = a_src[trow * H + h] + ad[h];
-      return v > 0.f ? v : v * slope;
+    // what the owner of edge j needs: the row of x, the row of the terms, the raw scores
+    auto own = [&](int j, int64_t& xr, int64_t& tr, float (&raw)[H]) {
+      const int c = col[j];
+      xr          = src_ids ? src_ids[c] : (int64_t)c;
+      tr          = (terms_by_id & 1) ? xr : (int64_t)c;
+#pragma unroll
+      for (int h = 0; h < H; h++) raw[h] = a_src[tr * H + h] + ad[h];
     };
-    auto term_row = [&](int c) -> int64_t { return (terms_by_id & 1) ? src_ids[c] : (int64_t)c; };
-    // the row's softmax statistics (terms only; every lane of the group computes them)
-    for (int j = s; j < e; j++) {
-      const int64_t tr = term_row(col[j]);
+    auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+    // the row's softmax statistics
+    for (int c0 = s; c0 < e; c0 += lanes)
+      if (c0 + sub < e) {
+        int64_t xr, tr;
+        float raw[H];
+        own(c0 + sub, xr, tr, raw);
 #pragma unroll
-      for (int h = 0; h < H; h++) m[h] = fmaxf(m[h], score(tr, h));
-    }
-    for (int j = s; j < e; j++) {
-      const int64_t tr = term_row(col[j]);
-#pragma unroll
-      for (int h = 0; h < H; h++) den[h] += expf(score(tr, h) - m[h]);
-    }
-    // pass 1: p per edge and head (parked in de), dot = sum alpha p, gx
-    for (int j = s; j < e; j++) {
-      const int c      = col[j];
-      const int64_t xr = src_ids ? src_ids[c] : (int64_t)c;
-      const int64_t tr = (terms_by_id & 1) ? xr : (int64_t)c;
-      float4 x4        = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) x4 = *reinterpret_cast<const float4*>(x + xr * ldx + f0);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int h = 0; h < H; h++) {
-        float p = g4[h].x * x4.x + g4[h].y * x4.y + g4[h].z * x4.z + g4[h].w * x4.w;
-        for (int d = lanes >> 1; d >= 1; d >>= 1) p += __shfl_xor(p, d, 64);
-        const float al = expf(score(tr, h) - m[h]) / den[h];
-        dot[h] += al * p;
-        if (sub == 0) de[(int64_t)j * H + h] = p;
-        acc.x += al * g4[h].x; acc.y += al * g4[h].y; acc.z += al * g4[h].z; acc.w += al * g4[h].w;
+        for (int h = 0; h < H; h++) m[h] = fmaxf(m[h], leaky(raw[h]));
       }
-      if (gx != nullptr && live) {
-        float* q = gx + xr * ldgx + f0;
-        unsafeAtomicAdd(q, acc.x); unsafeAtomicAdd(q + 1, acc.y); unsafeAtomicAdd(q + 2, acc.z); unsafeAtomicAdd(q + 3, acc.w);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // lane 0's parked p are read by the other lanes of the group below
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // pass 2: the lanes of the group split the row's edges
-    for (int j = s + sub; j < e; j += lanes) {
-      const int64_t tr = term_row(col[j]);
 #pragma unroll
-      for (int h = 0; h < H; h++) {
-        const float raw = a_src[tr * H + h] + ad[h];
-        const float sc  = raw > 0.f ? raw : raw * slope;
-        float ds        = expf(sc - m[h]) / den[h] * (de[(int64_t)j * H + h] - dot[h]);
-        ds              = raw > 0.f ? ds : ds * slope;
-        de[(int64_t)j * H + h] = ds;
-        gad[h] += ds;
-        unsafeAtomicAdd(ga_src + tr * H + h, ds);
+    for (int h = 0; h < H; h++) m[h] = group_max(m[h]);
+    for (int c0 = s; c0 < e; c0 += lanes)
+      if (c0 + sub < e) {
+        int64_t xr, tr;
+        float raw[H];
+        own(c0 + sub, xr, tr, raw);
+#pragma unroll
+        for (int h = 0; h < H; h++) den[h] += expf(leaky(raw[h]) - m[h]);
+      }
+#pragma unroll
+    for (int h = 0; h < H; h++) den[h] = group_sum(den[h]);
+    // pass 1: p per edge and head (kept by the owner, parked in de), dot = sum alpha p, gx
+    for (int c0 = s; c0 < e; c0 += lanes) {
+      const bool on = c0 + sub < e;
+      const int cnt = min(lanes, e - c0);
+      int64_t xr = 0, tr = 0;
+      float al[H], pown[H];
+      {
+        float raw[H];
+#pragma unroll
+        for (int h = 0; h < H; h++) raw[h] = 0.f;
+        if (on) own(c0 + sub, xr, tr, raw);
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          al[h]   = on ? expf(leaky(raw[h]) - m[h]) / den[h] : 0.f;
+          pown[h] = 0.f;
+        }
+      }
+      for (int k = 0; k < cnt; k += EIF) {
+        float4 x4[EIF];
+        int64_t xu[EIF];
+#pragma unroll
+        for (int u = 0; u < EIF; u++) {
+          const int from = gbase | min(k + u, cnt - 1);
+          xu[u] = ((int64_t)__shfl((int)(xr >> 32), from, 64) << 32) | (uint32_t)__shfl((int)xr, from, 64);
+          x4[u] = live ? *reinterpret_cast<const float4*>(x + xu[u] * ldx + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < EIF; u++) {
+          if (k + u >= cnt) break;   // (uniform over the group)
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int h = 0; h < H; h++) {
+            const float p = group_sum(g4[h].x * x4[u].x + g4[h].y * x4[u].y + g4[h].z * x4[u].z + g4[h].w * x4[u].w);
+            if (sub == k + u) pown[h] = p;
+            if (gx != nullptr) {
+              const float a_ = __shfl(al[h], gbase | (k + u), 64);
+              acc.x += a_ * g4[h].x; acc.y += a_ * g4[h].y; acc.z += a_ * g4[h].z; acc.w += a_ * g4[h].w;
+            }
+          }
+          if (gx != nullptr && live) {
+            float* q = gx + xu[u] * ldgx + f0;
+            unsafeAtomicAdd(q, acc.x); unsafeAtomicAdd(q + 1, acc.y); unsafeAtomicAdd(q + 2, acc.z); unsafeAtomicAdd(q + 3, acc.w);
+          }
+        }
+      }
+      if (on) {
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          dot[h] += al[h] * pown[h];
+          de[(int64_t)(c0 + sub) * H + h] = pown[h];
+        }
       }
     }
+#pragma unroll
+    for (int h = 0; h < H; h++) dot[h] = group_sum(dot[h]);
+    // pass 2: every owner finishes its edges (it reads back what it parked itself)
+    for (int c0 = s; c0 < e; c0 += lanes)
+      if (c0 + sub < e) {
+        const int j = c0 + sub;
+        int64_t xr, tr;
+        float raw[H];
+        own(j, xr, tr, raw);
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          float ds = expf(leaky(raw[h]) - m[h]) / den[h] * (de[(int64_t)j * H + h] - dot[h]);
+          ds       = raw[h] > 0.f ? ds : ds * slope;
+          de[(int64_t)j * H + h] = ds;
+          gad[h] += ds;
+          unsafeAtomicAdd(ga_src + tr * H + h, ds);
+        }
+      }
 #pragma unroll
     for (int h = 0; h < H; h++) {
-      float v = gad[h];
-      for (int d = lanes >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      const float v = group_sum(gad[h]);
       if (sub == 0) unsafeAtomicAdd(ga_dst + arow * H + h, v);
     }
   }
