@@ -199,6 +199,43 @@ def cpu_baseline(graphs, tables, params, seeds_h, B, fanout, hops, etypes, ntype
                       f"4x64) layers on the C oracle (OpenMP) + torch CPU GEMMs, {dt:.1f} s"}
 
 
+def train_pass(model, tables, num_nodes, order, B, G, dev, groups=6, warm=2):
+    """The TRAINING step of the same configuration through the same API, outside the headline's timed region: call groups ->
+    2 x nn.HeteroConv{GATConv} under autograd (aggregate-first: nn._GatAggregateHeads, wgamd_gat_aggregate_heads_bwd_f32; x lazy,
+    attention terms of the tables' rows) -> linear head -> cross-entropy on synthetic labels -> backward -> SGD step per group."""
+    params = [p for m in model for p in m.parameters()]
+    for p in params:
+        p.requires_grad_(True)
+    head = torch.nn.Linear(HC, 16).to(dev)
+    opt = torch.optim.SGD(params + list(head.parameters()), lr=1e-3)
+    g = torch.Generator(device=dev).manual_seed(11)
+    labels = torch.randint(0, 16, (num_nodes["paper"],), generator=g, device=dev)
+    seeds = order[:(groups + warm) * G * B]
+    loader = make_loader(build_mag_like.graph_store, tables, seeds, B, G)
+    n, edges, t0, first, loss = 0, 0, None, None, None
+    for grp in loader.call_groups():
+        if n == warm:
+            torch.cuda.synchronize()
+            t0, edges = time.perf_counter(), 0
+        out = head(forward_group(model, grp))
+        loss = torch.nn.functional.cross_entropy(out, labels[seeds[n * G * B:(n + 1) * G * B]])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+        edges += grp.num_edges
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for p in params:
+        p.requires_grad_(False)
+        p.grad = None
+    return {"value": edges / dt, "unit": "sampled-edges/s", "ms_per_call_group": dt / (n - warm) * 1e3, "call_groups": n - warm,
+            "loss_first_last": [round(first, 4), round(float(loss.detach()), 4)],
+            "note": "NeighborLoader.call_groups() -> 2 x nn.HeteroConv{GATConv 4x64} (autograd, aggregate-first, x lazy) -> linear head -> "
+                    "cross-entropy -> backward -> SGD step per call group of %d mini-batches" % G}
+
+
 def main(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload mag is the single-GPU configuration (BASELINE configs[4])"
@@ -342,6 +379,9 @@ def main(args):
         prof = load_profiled_avg(roofline["kernel"], "mag")
         if prof:   # (the summary averages ALL launches of the kernel, 11 shapes per call group: the max is the dominant launch)
             roofline["profiled_source"] = "%s (%d launches of all shapes, avg %.1f us)" % (prof["source"], prof["calls"], prof["avg_ns"] * 1e-3)
+    variants = None
+    if not getattr(args, "no_variants", False):
+        variants = {"train_step": train_pass(model, tables, num_nodes, order, B, G, dev)}
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(graphs, tables, params, order[:min(order.numel(), 256 * B)].cpu().numpy(), B, fanout, hops,
@@ -364,6 +404,8 @@ def main(args):
            "gat_launches": [{"edge_type": "%s-%s-%s" % et, "hop": h + 1, "rows": n_f, "edges": n_e, "src_row_floats": f_}
                             for et, h, n_f, n_e, f_ in (launches or [])],
            "roofline": roofline, "cpu_baseline": cpu}
+    if variants is not None:
+        out["variants"] = variants
     if cpu is not None:
         out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 2)
     print(json.dumps(out), flush=True)
