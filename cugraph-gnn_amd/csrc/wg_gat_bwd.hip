@@ -370,53 +370,45 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
       for (int h = 0; h < H; h++) raw[h] = a_src[tr * H + h] + ad[h];
     };
     auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
-    // the row's softmax statistics
-    for (int c0 = s; c0 < e; c0 += lanes)
-      if (c0 + sub < e) {
-        int64_t xr, tr;
-        float raw[H];
-        own(c0 + sub, xr, tr, raw);
-#pragma unroll
-        for (int h = 0; h < H; h++) m[h] = fmaxf(m[h], leaky(raw[h]));
-      }
-#pragma unroll
-    for (int h = 0; h < H; h++) m[h] = group_max(m[h]);
-    for (int c0 = s; c0 < e; c0 += lanes)
-      if (c0 + sub < e) {
-        int64_t xr, tr;
-        float raw[H];
-        own(c0 + sub, xr, tr, raw);
-#pragma unroll
-        for (int h = 0; h < H; h++) den[h] += expf(leaky(raw[h]) - m[h]);
-      }
-#pragma unroll
-    for (int h = 0; h < H; h++) den[h] = group_sum(den[h]);
-    // pass 1: p per edge and head (kept by the owner, parked in de), dot = sum alpha p, gx
-    for (int c0 = s; c0 < e; c0 += lanes) {
-      const bool on = c0 + sub < e;
-      const int cnt = min(lanes, e - c0);
+    if (e - s <= lanes) {
+      // ---- the usual case (a sampled hop: at most `fan-out` edges per row): ONE chunk, the owner of edge s + sub keeps its
+      // column, rows and scores in registers through all phases — one dependent col -> id -> term chain per row instead of four
+      const bool on = s + sub < e;
+      const int cnt = e - s;
       int64_t xr = 0, tr = 0;
-      float al[H], pown[H];
+      float raw[H], al[H], pown[H];
       {
-        float raw[H];
-#pragma unroll
-        for (int h = 0; h < H; h++) raw[h] = 0.f;
-        if (on) own(c0 + sub, xr, tr, raw);
-#pragma unroll
-        for (int h = 0; h < H; h++) {
-          al[h]   = on ? expf(leaky(raw[h]) - m[h]) / den[h] : 0.f;
-          pown[h] = 0.f;
-        }
+        const int c = on ? col[s + sub] : 0;
+        xr          = src_ids ? src_ids[c] : (int64_t)c;
+        tr          = (terms_by_id & 1) ? xr : (int64_t)c;
       }
-      for (int k = 0; k < cnt; k += EIF) {
-        float4 x4[EIF];
-        int64_t xu[EIF];
+      // the neighbour rows of the first four edges are requested BEFORE the scores are waited for (they do not depend on them)
+      float4 x4[EIF];
+      int64_t xu[EIF];
+      auto request = [&](int k, float4 (&xx)[EIF], int64_t (&uu)[EIF]) {
 #pragma unroll
         for (int u = 0; u < EIF; u++) {
           const int from = gbase | min(k + u, cnt - 1);
-          xu[u] = ((int64_t)__shfl((int)(xr >> 32), from, 64) << 32) | (uint32_t)__shfl((int)xr, from, 64);
-          x4[u] = live ? *reinterpret_cast<const float4*>(x + xu[u] * ldx + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+          uu[u] = ((int64_t)__shfl((int)(xr >> 32), from, 64) << 32) | (uint32_t)__shfl((int)xr, from, 64);
+          xx[u] = live ? *reinterpret_cast<const float4*>(x + uu[u] * ldx + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+      };
+      request(0, x4, xu);
+#pragma unroll
+      for (int h = 0; h < H; h++) raw[h] = on ? a_src[tr * H + h] + ad[h] : 0.f;
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const float sc = on ? leaky(raw[h]) : -INFINITY;
+        m[h]           = group_max(sc);
+        const float ex = on ? expf(sc - m[h]) : 0.f;
+        den[h]         = group_sum(ex);
+        al[h]          = ex / den[h];
+        pown[h]        = 0.f;
+      }
+      for (int k = 0; k < cnt; k += EIF) {
+        float4 xn[EIF];
+        int64_t un[EIF];
+        if (k + EIF < cnt) request(k + EIF, xn, un);   // (uniform over the group) the next four, under this batch's arithmetic
 #pragma unroll
         for (int u = 0; u < EIF; u++) {
           if (k + u >= cnt) break;   // (uniform over the group)
@@ -435,33 +427,127 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
             unsafeAtomicAdd(q, acc.x); unsafeAtomicAdd(q + 1, acc.y); unsafeAtomicAdd(q + 2, acc.z); unsafeAtomicAdd(q + 3, acc.w);
           }
         }
-      }
-      if (on) {
+        if (k + EIF < cnt) {
 #pragma unroll
-        for (int h = 0; h < H; h++) {
-          dot[h] += al[h] * pown[h];
-          de[(int64_t)(c0 + sub) * H + h] = pown[h];
+          for (int u = 0; u < EIF; u++) {
+            x4[u] = xn[u];
+            xu[u] = un[u];
+          }
         }
       }
-    }
 #pragma unroll
-    for (int h = 0; h < H; h++) dot[h] = group_sum(dot[h]);
-    // pass 2: every owner finishes its edges (it reads back what it parked itself)
-    for (int c0 = s; c0 < e; c0 += lanes)
-      if (c0 + sub < e) {
-        const int j = c0 + sub;
-        int64_t xr, tr;
-        float raw[H];
-        own(j, xr, tr, raw);
-#pragma unroll
-        for (int h = 0; h < H; h++) {
-          float ds = expf(leaky(raw[h]) - m[h]) / den[h] * (de[(int64_t)j * H + h] - dot[h]);
-          ds       = raw[h] > 0.f ? ds : ds * slope;
-          de[(int64_t)j * H + h] = ds;
-          gad[h] += ds;
+      for (int h = 0; h < H; h++) {
+        dot[h]   = group_sum(al[h] * pown[h]);
+        float ds = al[h] * (pown[h] - dot[h]);
+        ds       = raw[h] > 0.f ? ds : ds * slope;
+        if (on) {
+          de[(int64_t)(s + sub) * H + h] = ds;
+#ifndef WG_ABL_NO_GASRC
           unsafeAtomicAdd(ga_src + tr * H + h, ds);
+#endif
+        }
+        gad[h] = on ? ds : 0.f;
+      }
+    } else {
+      // the row's softmax statistics
+      for (int c0 = s; c0 < e; c0 += lanes)
+        if (c0 + sub < e) {
+          int64_t xr, tr;
+          float raw[H];
+          own(c0 + sub, xr, tr, raw);
+#pragma unroll
+          for (int h = 0; h < H; h++) m[h] = fmaxf(m[h], leaky(raw[h]));
+        }
+#pragma unroll
+      for (int h = 0; h < H; h++) m[h] = group_max(m[h]);
+      for (int c0 = s; c0 < e; c0 += lanes)
+        if (c0 + sub < e) {
+          int64_t xr, tr;
+          float raw[H];
+          own(c0 + sub, xr, tr, raw);
+#pragma unroll
+          for (int h = 0; h < H; h++) den[h] += expf(leaky(raw[h]) - m[h]);
+        }
+#pragma unroll
+      for (int h = 0; h < H; h++) den[h] = group_sum(den[h]);
+      // pass 1: p per edge and head (kept by the owner, parked in de), dot = sum alpha p, gx
+      for (int c0 = s; c0 < e; c0 += lanes) {
+        const bool on = c0 + sub < e;
+        const int cnt = min(lanes, e - c0);
+        int64_t xr = 0, tr = 0;
+        float al[H], pown[H];
+        {
+          float raw[H];
+#pragma unroll
+          for (int h = 0; h < H; h++) raw[h] = 0.f;
+          if (on) own(c0 + sub, xr, tr, raw);
+#pragma unroll
+          for (int h = 0; h < H; h++) {
+            al[h]   = on ? expf(leaky(raw[h]) - m[h]) / den[h] : 0.f;
+            pown[h] = 0.f;
+          }
+        }
+        for (int k = 0; k < cnt; k += EIF) {
+          float4 x4[EIF];
+          int64_t xu[EIF];
+#pragma unroll
+          for (int u = 0; u < EIF; u++) {
+            const int from = gbase | min(k + u, cnt - 1);
+            xu[u] = ((int64_t)__shfl((int)(xr >> 32), from, 64) << 32) | (uint32_t)__shfl((int)xr, from, 64);
+            x4[u] = live ? *reinterpret_cast<const float4*>(x + xu[u] * ldx + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < EIF; u++) {
+            if (k + u >= cnt) break;   // (uniform over the group)
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+  #ifdef WG_ABL_NO_PSUM
+            const float p = (g4[h].x * x4[u].x + g4[h].y * x4[u].y + g4[h].z * x4[u].z + g4[h].w * x4[u].w);
+#else
+            const float p = group_sum(g4[h].x * x4[u].x + g4[h].y * x4[u].y + g4[h].z * x4[u].z + g4[h].w * x4[u].w);
+#endif
+              if (sub == k + u) pown[h] = p;
+              if (gx != nullptr) {
+                const float a_ = __shfl(al[h], gbase | (k + u), 64);
+                acc.x += a_ * g4[h].x; acc.y += a_ * g4[h].y; acc.z += a_ * g4[h].z; acc.w += a_ * g4[h].w;
+              }
+            }
+            if (gx != nullptr && live) {
+              float* q = gx + xu[u] * ldgx + f0;
+              unsafeAtomicAdd(q, acc.x); unsafeAtomicAdd(q + 1, acc.y); unsafeAtomicAdd(q + 2, acc.z); unsafeAtomicAdd(q + 3, acc.w);
+            }
+          }
+        }
+        if (on) {
+#pragma unroll
+          for (int h = 0; h < H; h++) {
+            dot[h] += al[h] * pown[h];
+            de[(int64_t)(c0 + sub) * H + h] = pown[h];
+          }
         }
       }
+#pragma unroll
+      for (int h = 0; h < H; h++) dot[h] = group_sum(dot[h]);
+      // pass 2: every owner finishes its edges (it reads back what it parked itself)
+      for (int c0 = s; c0 < e; c0 += lanes)
+        if (c0 + sub < e) {
+          const int j = c0 + sub;
+          int64_t xr, tr;
+          float raw[H];
+          own(j, xr, tr, raw);
+#pragma unroll
+          for (int h = 0; h < H; h++) {
+            float ds = expf(leaky(raw[h]) - m[h]) / den[h] * (de[(int64_t)j * H + h] - dot[h]);
+            ds       = raw[h] > 0.f ? ds : ds * slope;
+            de[(int64_t)j * H + h] = ds;
+            gad[h] += ds;
+  #ifndef WG_ABL_NO_GASRC
+          unsafeAtomicAdd(ga_src + tr * H + h, ds);
+#endif
+          }
+        }
+    }
 #pragma unroll
     for (int h = 0; h < H; h++) {
       const float v = group_sum(gad[h]);
