@@ -1448,7 +1448,10 @@ class HeteroConv(torch.nn.Module):
             if act == "relu":
                 acc = torch.relu(acc)
             place = mine[0].out_rows
-            out[dt] = acc if place is None else out[dt].index_copy(0, place, acc)
+            if place is None:
+                out[dt] = acc
+            else:
+                out[dt].index_copy_(0, place, acc)      # (in place: the hops of a type write disjoint rows of one buffer)
         return out
 
     def _forward_relations(self, xs, graph: HeteroLayerGraph, act=None):
