@@ -798,6 +798,23 @@ class HopGraph:
     def n_rows(self):
         return int(self.row_ptr.shape[0]) - 1
 
+    def with_self_loops(self):
+        """``(row_ptr, col)`` of the hop with every destination's own input row in front of its sampled neighbours — what
+        ``csr_add_self_loop`` (graph_op.h:44-48) does for a square CSR, here with ``self_rows`` as the diagonal; made once."""
+        if getattr(self, "_loops", None) is None:
+            n, dev = self.n_rows, self.row_ptr.device
+            steps = torch.arange(n + 1, dtype=torch.int32, device=dev)
+            rp = self.row_ptr + steps
+            col = torch.empty(int(self.col.shape[0]) + n, dtype=torch.int32, device=dev)
+            deg = (self.row_ptr[1:] - self.row_ptr[:-1]).long()
+            e = int(self.col.shape[0])
+            if e > 0:
+                row_of_edge = torch.repeat_interleave(steps[:n].long(), deg, output_size=e)
+                col[torch.arange(e, device=dev) + row_of_edge + 1] = self.col
+            col[rp[:n].long()] = self.self_rows.to(torch.int32)
+            self._loops = (rp, col)
+        return self._loops
+
     def transposed(self, n_src: int):
         """The hop seen from its ``n_src`` input rows, for the backward pass — computed once per hop and kept, whichever layers
         and however many backward calls use it: ``(row_ptr_t, col_t, self_t)`` with the source-major CSR of
@@ -1053,8 +1070,53 @@ class GATConv(torch.nn.Module):
         torch.nn.init.uniform_(self.att_src, -bound, bound)
         torch.nn.init.uniform_(self.att_dst, -bound, bound)
 
-    def forward(self, x, graph):
+    def _forward_layer(self, x, lg: LayerGraph, act=None):
+        """A trimmed layer of a loader call group (``CallGroup.layer_graph(j)``), AGGREGATE-FIRST: per hop one
+        ``_GatAggregateHeads`` launch over the untransformed input rows (a ``LazyRows`` input is read through its node list, its
+        attention terms are those of the table's rows when the table is the shorter side), self loops as an extra leading
+        neighbour, then the per-head weights, bias and activation on the hop's destination rows.  Under autograd the same
+        code trains (``wgamd_gat_aggregate_heads_bwd_f32``)."""
+        assert act in (None, "relu")
+        H, C, F_ = self.heads, self.out_channels, self.in_channels
+        lazy = isinstance(x, LazyRows) and isinstance(x.table, torch.Tensor) and x.ids.dtype == torch.int64 \
+            and x.table.dtype == torch.float32 and x.table.stride(1) == 1 and x.table.stride(0) % 4 == 0 \
+            and x.table.data_ptr() % 16 == 0 and x._rows is None
+        if lazy:
+            X, ids = x.table, x.ids
+            by_id = 2 * X.shape[0] <= len(x)
+            rows = X if by_id else x.materialize()
+        else:
+            X = x.materialize() if isinstance(x, LazyRows) else x
+            ids, by_id, rows = None, False, X
+        w3 = self.lin.weight.t().reshape(F_, H, C)
+        folds = torch.cat([(w3 * self.att_src.view(1, H, C)).sum(-1), (w3 * self.att_dst.view(1, H, C)).sum(-1)], 1)
+        terms = rows @ folds
+        a_src, a_dst = terms[:, :H], terms[:, H:]
+        outs = []
+        for hop in lg.hops:
+            n = hop.n_rows
+            if n == 0:
+                continue
+            rp, col = hop.with_self_loops() if self.add_self_loops else (hop.row_ptr, hop.col)
+            if col.shape[0] == 0:         # (no self loops and nothing sampled: the aggregate of an empty neighbourhood)
+                outs.append(torch.zeros((n, H, C), dtype=torch.float32, device=X.device))
+                continue
+            agg = _GatAggregateHeads.apply(X, a_src, a_dst, rp, col, H, hop.self_rows, ids, ids if by_id else None, by_id, by_id,
+                                           self.negative_slope)
+            outs.append(torch.einsum("nhf,fhc->nhc", agg.view(n, H, F_), w3))
+        out = torch.cat(outs) if outs else torch.zeros((0, H, C), dtype=torch.float32, device=X.device)
+        out = out.reshape(out.shape[0], H * C) if self.concat else out.mean(1)
+        if self.bias is not None:
+            out = out + self.bias
+        return torch.relu(out) if act == "relu" else out
+
+    def forward(self, x, graph, act=None):
         from . import graph_ops
+        if isinstance(graph, LayerGraph):
+            if self.in_channels % 4 == 0 and self.in_channels <= 256 and self.heads in (1, 2, 4, 8):
+                return self._forward_layer(x, graph, act)
+            raise NotImplementedError("GATConv over a call group's LayerGraph: in_channels % 4 == 0, <= 256; heads 1, 2, 4 or 8")
+        assert act is None, "act: only with a call group's LayerGraph"
         x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
         H, C = self.heads, self.out_channels
         n_dst = x_dst.shape[0]

@@ -338,3 +338,118 @@ def test_hetero_call_groups_equal_the_per_batch_loader(hiplib, hops):
             assert bool(((got - want).abs() <= 1e-5 * scale + 1e-7).all()), (b0 + j, float(((got - want).abs() / scale).max()))
         b0 += grp.n_batches
     assert b0 == len(batches) == 6
+
+
+def _gat_reference_seed_outputs(convs, data, self_loops):
+    """PyG's GATConv on ONE mini-batch, float64 on the host, every layer over ALL sampled edges and all nodes of the batch
+    (self loops as ``csr_add_self_loop`` makes them: one extra (i, i) edge per node); ReLU between layers; the seeds' rows."""
+    import torch
+    h = data.x.double().cpu()
+    src, dst = data.edge_index[0].cpu(), data.edge_index[1].cpu()
+    n = h.shape[0]
+    if self_loops:
+        loops = torch.arange(n)
+        src, dst = torch.cat([loops, src]), torch.cat([loops, dst])
+    for j, c in enumerate(convs):
+        H, C = c.heads, c.out_channels
+        hw = (h @ c.lin.weight.detach().double().cpu().t()).view(n, H, C)
+        a_s = (hw * c.att_src.detach().double().cpu()).sum(-1)
+        a_d = (hw * c.att_dst.detach().double().cpu()).sum(-1)
+        e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], c.negative_slope)
+        mx = torch.full((n, H), -float("inf"), dtype=torch.float64).index_reduce_(0, dst, e, "amax", include_self=True)
+        ex = torch.exp(e - mx[dst])
+        den = torch.zeros((n, H), dtype=torch.float64).index_add_(0, dst, ex)
+        alpha = ex / den[dst]
+        out = torch.zeros((n, H, C), dtype=torch.float64).index_add_(0, dst, alpha.unsqueeze(-1) * hw[src])
+        out = out.reshape(n, H * C) if c.concat else out.mean(1)
+        if c.bias is not None:
+            out = out + c.bias.detach().double().cpu()
+        h = torch.relu(out) if j + 1 < len(convs) else out
+    return h[:data.batch_size]
+
+
+@pytest.mark.parametrize("self_loops,table_rows", [(True, 3000), (False, 3000), (True, 60000)])
+def test_homogeneous_gatconv_over_call_groups(hiplib, self_loops, table_rows):
+    """nn.GATConv over a homogeneous call group's trimmed layer graphs (aggregate-first, x lazy; with a short table the
+    attention terms are those of the table's rows, with a long one those of the listed rows) equals, for every seed, PyG's
+    formulation over ALL sampled edges of its mini-batch in float64 — and trains: parameter gradients of the call-group route
+    against float64 autograd of the same reference."""
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd import nn
+    from wholegraph_amd.nn import LazyRows
+    V, F0 = table_rows, 64
+    gs, fs, feat = _stores(V, 12, F0, seed=11)
+    torch.manual_seed(4)
+    convs = [nn.GATConv(F0, 16, heads=4, add_self_loops=self_loops).cuda(), nn.GATConv(64, 8, heads=2, add_self_loops=self_loops).cuda()]
+    for c in convs:
+        for p in c.parameters():
+            p.data = (torch.rand(p.shape, device="cuda") - 0.5) * 0.6
+    seeds = torch.randperm(V, generator=torch.Generator().manual_seed(1))[:4 * 96 + 17].cuda()
+    loader = NeighborLoader((fs, gs), [6, 4], input_nodes=seeds, batch_size=96, shuffle=False, random_state=5, local_seeds_per_call=4 * 96)
+    groups = list(loader.call_groups())
+    assert len(groups) == 2
+    for g in groups:
+        x = g.x
+        assert isinstance(x, LazyRows)
+        h = x
+        for j, c in enumerate(convs):
+            h = c(h, g.layer_graph(j), act="relu" if j == 0 else None)
+        got = h.detach().double().cpu()
+        bp = g.batch_ptr.tolist()
+        want = torch.cat([_gat_reference_seed_outputs(convs, d, self_loops) for d in g.to_data_list()])
+        assert got.shape == want.shape == (bp[-1], 16)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 1e-5 * scale, float((got - want).abs().max()) / scale
+    # gradients (first group): the call-group route under autograd against float64 autograd of the reference
+    g = groups[0]
+    params = [p for c in convs for p in c.parameters()]
+    gout = torch.randn((g.batch_ptr.tolist()[-1], 16), generator=torch.Generator().manual_seed(2)).cuda()
+    h = g.x
+    for j, c in enumerate(convs):
+        h = c(h, g.layer_graph(j), act=None)
+    h.backward(gout)
+    got_grads = [p.grad.detach().double().cpu().clone() for p in params]
+
+    class _Dbl:          # the same modules' parameters as float64 leaves on the host
+        def __init__(self, c):
+            self.heads, self.out_channels, self.concat, self.negative_slope = c.heads, c.out_channels, c.concat, c.negative_slope
+            self.lin = type("L", (), {})()
+            self.lin.weight = c.lin.weight.detach().double().cpu().requires_grad_(True)
+            self.att_src = c.att_src.detach().double().cpu().requires_grad_(True)
+            self.att_dst = c.att_dst.detach().double().cpu().requires_grad_(True)
+            self.bias = None if c.bias is None else c.bias.detach().double().cpu().requires_grad_(True)
+
+    def ref_forward(cs, data):
+        hh = data.x.double().cpu()
+        src, dst = data.edge_index[0].cpu(), data.edge_index[1].cpu()
+        n = hh.shape[0]
+        if self_loops:
+            loops = torch.arange(n)
+            src, dst = torch.cat([loops, src]), torch.cat([loops, dst])
+        for c in cs:
+            H, C = c.heads, c.out_channels
+            hw = (hh @ c.lin.weight.t()).view(n, H, C)
+            e = torch.nn.functional.leaky_relu((hw * c.att_src).sum(-1)[src] + (hw * c.att_dst).sum(-1)[dst], c.negative_slope)
+            mx = torch.full((n, H), -float("inf"), dtype=torch.float64).index_reduce_(0, dst, e.detach(), "amax", include_self=True)
+            ex = torch.exp(e - mx[dst])
+            den = torch.zeros((n, H), dtype=torch.float64).index_add(0, dst, ex)
+            out = torch.zeros((n, H, C), dtype=torch.float64).index_add(0, dst, (ex / den[dst]).unsqueeze(-1) * hw[src])
+            hh = out.reshape(n, H * C) + c.bias
+        return hh[:data.batch_size]
+
+    dbl = [_Dbl(c) for c in convs]
+    ref = torch.cat([ref_forward(dbl, d) for d in g.to_data_list()])
+    ref.backward(gout.double().cpu())
+    want_grads = [q.grad for c in dbl for q in (c.lin.weight, c.att_src, c.att_dst, c.bias)]
+    names = [n for c in convs for n, _ in c.named_parameters()]
+    order = {"lin.weight": 0, "att_src": 1, "att_dst": 2, "bias": 3}
+    got_by = {}
+    for (ci, c) in enumerate(convs):
+        for n, p in c.named_parameters():
+            got_by[(ci, order[n])] = p.grad.detach().double().cpu()
+    for ci in range(2):
+        for k in range(4):
+            a, b = got_by[(ci, k)], want_grads[ci * 4 + k]
+            scale = float(b.abs().max())
+            assert float((a - b.reshape(a.shape)).abs().max()) <= 2e-5 * scale + 1e-9, (ci, k, float((a - b.reshape(a.shape)).abs().max()), scale)
