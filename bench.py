@@ -290,7 +290,7 @@ class SagePipeline:
         return h, tuple(v for pair in sz for v in pair)
 
 
-def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("loader_api", "train_step", "loader_api_materialised", "loader_api_per_batch")):
+def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("loader_api", "train_step", "loader_api_materialised", "loader_api_per_batch", "gat")):
     """The same workload through the DROP-IN API: GraphStore + FeatureStore -> cugraph_pyg_amd NeighborLoader ->
     wholegraph_amd.nn.SAGEConv x L forward (the surface of python/cugraph-pyg/cugraph_pyg/loader/node_loader.py:16-178 and
     sampler/sampler.py:51-165).  `loader_api`: the epoch iterated in call groups (loader.call_groups(): one block-diagonal
@@ -425,6 +425,40 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
         v, ms, epb = group_pass(False)
         out["loader_api_materialised"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
                                           "note": "the same loop with x = feat[n_id] gathered once per call group (wholememory_gather)"}
+    if "gat" in which and table.shape[1] % 4 == 0 and table.shape[1] <= 256 and L == 2:
+        # the GAT half of north_star on the SAME graph, features and loader: 2 x nn.GATConv (edge softmax + attention-weighted
+        # sum, 4 heads x 64 then 1 x classes; self loops) over the call groups' trimmed layer graphs, aggregate-first, x lazy
+        from wholegraph_amd import nn as wnn
+        gat = torch.nn.ModuleList([wnn.GATConv(int(table.shape[1]), 64, heads=4), wnn.GATConv(256, CLASSES, heads=1)]).to(dev)
+        labels = torch.randint(0, CLASSES, (V,), generator=torch.Generator(device=dev).manual_seed(6), device=dev)
+        opt = torch.optim.SGD(gat.parameters(), lr=0.01)
+        for train in (False, True):
+            n_g, n_warm = min(n_groups, 6), 2
+            ids = seeds[:(n_g + n_warm) * G * BATCH]
+            loader = NeighborLoader((fs, gs), FANOUT, input_nodes=ids, batch_size=BATCH, shuffle=False, random_state=62)
+            edges, t0, n, loss = 0, None, 0, None
+            with torch.set_grad_enabled(train):
+                for grp in loader.call_groups():
+                    if n == n_warm:
+                        torch.cuda.synchronize()
+                        t0, edges = time.perf_counter(), 0
+                    h = grp.x
+                    for j, c in enumerate(gat):
+                        h = c(h, grp.layer_graph(j), act="relu" if j == 0 else None)
+                    if train:
+                        loss = torch.nn.functional.cross_entropy(h, labels[ids[n * G * BATCH:n * G * BATCH + h.shape[0]]])
+                        opt.zero_grad(set_to_none=True)
+                        loss.backward()
+                        opt.step()
+                    edges += grp.num_edges
+                    n += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["gat_train_step" if train else "gat_loader_api"] = {
+                "value": edges / dt, "ms_per_call_group": dt / max(n - n_warm, 1) * 1e3,
+                "note": "NeighborLoader.call_groups() -> nn.GATConv(%d, 64, heads=4) -> ReLU -> nn.GATConv(256, %d, heads=1), self loops, "
+                        "aggregate-first over the trimmed layer graphs, x lazy%s" % (
+                            int(table.shape[1]), CLASSES, " -> cross-entropy -> backward -> SGD step per call group" if train else " (forward)")}
     if "loader_api_per_batch" not in which:
         return out
     n_b, n_warm = 96, 16
