@@ -802,16 +802,10 @@ class HopGraph:
         """``(row_ptr, col)`` of the hop with every destination's own input row in front of its sampled neighbours — what
         ``csr_add_self_loop`` (graph_op.h:44-48) does for a square CSR, here with ``self_rows`` as the diagonal; made once."""
         if getattr(self, "_loops", None) is None:
-            n, dev = self.n_rows, self.row_ptr.device
-            steps = torch.arange(n + 1, dtype=torch.int32, device=dev)
-            rp = self.row_ptr + steps
-            col = torch.empty(int(self.col.shape[0]) + n, dtype=torch.int32, device=dev)
-            deg = (self.row_ptr[1:] - self.row_ptr[:-1]).long()
-            e = int(self.col.shape[0])
-            if e > 0:
-                row_of_edge = torch.repeat_interleave(steps[:n].long(), deg, output_size=e)
-                col[torch.arange(e, device=dev) + row_of_edge + 1] = self.col
-            col[rp[:n].long()] = self.self_rows.to(torch.int32)
+            from . import graph_ops
+            n = self.n_rows
+            rp, col = graph_ops.add_csr_self_loop(self.row_ptr, self.col)     # row i = [i] ++ row i (csr_add_self_loop) ...
+            col[rp[:n].long()] = self.self_rows.to(torch.int32)              # ... with the destination's own input row as i
             self._loops = (rp, col)
         return self._loops
 
