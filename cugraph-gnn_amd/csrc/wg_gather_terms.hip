@@ -255,6 +255,56 @@ gather_term_slabs_kernel(const f32x4* __restrict__ in, int64_t n_in, int K, cons
   }
 }
 
+// dV [F, T] += X^T [F, n] . dT [n, T]: the weight gradient of `terms = X @ V` for a narrow V (T <= 32) and a LONG X (a whole
+// feature table: K = n is the reduction).  A library GEMM sees an output of 128 x 12 elements and runs it at 0.5 TB/s of
+// X; here every block streams its stretch of rows once — thread (row lane, feature f) reads X[row, f] (a coalesced row per
+// lane group), the rows' dT values come from an LDS tile as broadcast float4 reads — and adds its [T] partial sums to dV with
+// float atomics (F x T per block).  TT = ceil(T / 4) float4 accumulators per thread.
+constexpr int kXtRows = 64;   // dT rows per LDS tile
+template <int TT>
+__global__ void __launch_bounds__(256)
+rows_terms_bwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int F, int fp_log2, const float* __restrict__ dt, int T,
+                      float* __restrict__ dv, int64_t rows_per_block)
+{
+  __shared__ f32x4 tile[kXtRows][TT];
+  const int t  = threadIdx.x;
+  const int fp = 1 << fp_log2, f = t & (fp - 1), rl = t >> fp_log2, n_rl = 256 >> fp_log2;
+  const bool live = f < F;
+  f32x4 acc[TT];
+#pragma unroll
+  for (int q = 0; q < TT; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  for (int64_t base = r0; base < r1; base += kXtRows) {
+    __syncthreads();   // the previous tile's readers are done
+    for (int i = t; i < kXtRows * TT; i += 256) {
+      const int64_t row = base + i / TT;
+      const int q       = i % TT;
+      f32x4 v           = {0.f, 0.f, 0.f, 0.f};
+      if (row < r1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (4 * q + k < T) v[k] = dt[row * T + 4 * q + k];
+      }
+      tile[i / TT][q] = v;
+    }
+    __syncthreads();
+    const int rows = (int)(r1 - base < kXtRows ? r1 - base : kXtRows);
+    if (live)
+      for (int r = rl; r < rows; r += n_rl) {
+        const float xv = x[(base + r) * ldx + f];
+#pragma unroll
+        for (int q = 0; q < TT; q++) acc[q] += xv * tile[r][q];
+      }
+  }
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < TT; q++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (4 * q + k < T) unsafeAtomicAdd(dv + (int64_t)f * T + 4 * q + k, acc[q][k]);
+  }
+}
+
 }  // namespace
 }  // namespace wgamd
 
@@ -311,6 +361,38 @@ wholememory_error_code_t wgamd_gather_term_slabs_f32(const float* slabs_in, int6
     else
       gather_term_slabs_kernel<int64_t><<<grid, 256, 0, st>>>(reinterpret_cast<const f32x4*>(slabs_in), n_in, n_slabs,
                                                               static_cast<const int64_t*>(ids), n, reinterpret_cast<f32x4*>(slabs_out));
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+wholememory_error_code_t wgamd_rows_terms_bwd_f32(const float* x, int64_t ldx, int64_t n, int F, const float* dterms, int T,
+                                                  float* dv, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_rows_terms_bwd_f32", [&] {
+    WG_REQUIRE_INPUT(n >= 0 && F > 0 && F <= 256 && T > 0 && T <= 32 && ldx >= F, "bad sizes (F <= 256, T <= 32)");
+    if (n == 0) return;
+    WG_REQUIRE_INPUT(x && dterms && dv, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int fp_log2    = 0;
+    while ((1 << fp_log2) < F) fp_log2++;
+    const int64_t blocks_wanted = (int64_t)stream_cu_count(st) * 8;
+    int64_t rows_per_block      = std::max<int64_t>(kXtRows, (n + blocks_wanted - 1) / blocks_wanted);
+    rows_per_block              = (rows_per_block + kXtRows - 1) / kXtRows * kXtRows;
+    const int grid              = (int)((n + rows_per_block - 1) / rows_per_block);
+    const int TT                = (T + 3) / 4;
+#define WG_XT(N_) rows_terms_bwd_kernel<N_><<<grid, 256, 0, st>>>(x, ldx, n, F, fp_log2, dterms, T, dv, rows_per_block)
+    switch (TT) {
+      case 1: WG_XT(1); break;
+      case 2: WG_XT(2); break;
+      case 3: WG_XT(3); break;
+      case 4: WG_XT(4); break;
+      case 5: WG_XT(5); break;
+      case 6: WG_XT(6); break;
+      case 7: WG_XT(7); break;
+      default: WG_XT(8); break;
+    }
+#undef WG_XT
     WG_HIP_CHECK(hipGetLastError());
   });
 }

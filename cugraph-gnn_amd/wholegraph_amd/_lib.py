@@ -279,6 +279,7 @@ SYMBOLS = {
                                              c_int64, c_void_p]),
     "wgamd_gat_aggregate_heads_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                               c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wgamd_rows_terms_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "wgamd_gather_term_slabs_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "wgamd_gat_aggregate_heads_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int,
                                                   c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

@@ -1084,7 +1084,7 @@ class GATConv(torch.nn.Module):
             ids, by_id, rows = None, False, X
         w3 = self.lin.weight.t().reshape(F_, H, C)
         folds = torch.cat([(w3 * self.att_src.view(1, H, C)).sum(-1), (w3 * self.att_dst.view(1, H, C)).sum(-1)], 1)
-        terms = rows @ folds
+        terms = _NarrowTerms.apply(rows, folds)
         a_src, a_dst = terms[:, :H], terms[:, H:]
         outs = []
         for hop in lg.hops:
@@ -1173,6 +1173,39 @@ class HeteroLayerGraph:
     @property
     def num_edges(self):
         return sum(r.n_edges for r in self.relations)
+
+
+class _NarrowTerms(torch.autograd.Function):
+    """``terms = x @ v`` for a LONG ``x`` ([n, F], a feature table or a hidden state) and a narrow ``v`` ([F, T], T <= 32: the
+    folded attention vectors of a node type).  Forward: ``rows_terms`` (one streaming pass, exact-fp32 MFMA) where the shape
+    allows, a library product otherwise; backward: ``dv = x^T @ dterms`` by ``wgamd_rows_terms_bwd_f32`` (x streamed once; a
+    library GEMM sees a 128 x 12 output and a reduction over a million rows), ``dx = dterms @ v^T`` only where x asks for it."""
+
+    @staticmethod
+    def forward(ctx, x, v):
+        v = v.contiguous()
+        F_, T = int(v.shape[0]), int(v.shape[1])
+        fast = x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 \
+            and gather_terms_supported(F_, T)
+        terms = rows_terms(x, v) if fast and x.shape[0] > 0 else x @ v
+        ctx.save_for_backward(x, v)
+        return terms
+
+    @staticmethod
+    def backward(ctx, g):
+        x, v = ctx.saved_tensors
+        g = g.contiguous()
+        F_, T = int(v.shape[0]), int(v.shape[1])
+        dv = None
+        if ctx.needs_input_grad[1]:
+            if x.stride(1) == 1 and F_ <= 256 and T <= 32 and x.shape[0] > 0:
+                dv = torch.zeros((F_, T), dtype=torch.float32, device=g.device)
+                L.check(L.lib().wgamd_rows_terms_bwd_f32(x.data_ptr(), x.stride(0), int(x.shape[0]), F_, g.data_ptr(), T, dv.data_ptr(),
+                                                         get_stream()), "wgamd_rows_terms_bwd_f32")
+            else:
+                dv = x.t() @ g
+        dx = g @ v.t() if ctx.needs_input_grad[0] else None
+        return dx, dv
 
 
 class _GatAggregateHeads(torch.autograd.Function):
@@ -1460,7 +1493,7 @@ class HeteroConv(torch.nn.Module):
                 folds.append((w3 * (c.att_src if end == "src" else c.att_dst).view(1, c.heads, c.out_channels)).sum(-1))
             if rows is None:              # lazy, table longer than the list: terms of the listed rows
                 rows = v.materialize()
-            both = rows @ torch.cat(folds, 1)
+            both = _NarrowTerms.apply(rows, torch.cat(folds, 1))
             H = self.conv(ends[0][1]).heads
             for k, (end, et) in enumerate(ends):
                 terms[(end, et)] = both[:, k * H:(k + 1) * H]

@@ -632,6 +632,11 @@ wholememory_error_code_t wgamd_gather_terms_f32(const float* table, int64_t ldt,
  * table + this gather of 16-byte rows replaces x[ids] @ v over the list.  A negative or out-of-range id gives zero terms. */
 wholememory_error_code_t wgamd_gather_term_slabs_f32(const float* slabs_in, int64_t n_in, int n_slabs, const void* ids,
                                                      wholememory_dtype_t id_dtype, int64_t n, float* slabs_out, void* stream);
+/* dv [F, T] += x^T [F, n] . dterms [n, T] (row-major, contiguous): the weight gradient of terms = x @ v for a narrow v
+ * (T <= 32) over a LONG x (a whole feature table: the reduction runs over its rows); float atomics into the caller's
+ * (zeroed) dv.  F <= 256. */
+wholememory_error_code_t wgamd_rows_terms_bwd_f32(const float* x, int64_t ldx, int64_t n, int F, const float* dterms, int T,
+                                                  float* dv, void* stream);
 
 /* De-duplication of an id list with a known bound (ids < id_bound, e.g. the vertex count of the table they index):
  *   distinct[0 .. *n_distinct_dev)  the distinct non-negative ids, ASCENDING (so already grouped by owner rank of a

@@ -194,6 +194,30 @@ def test_gat_aggregate_heads_backward_matches_float64_autograd(hiplib, F, H, mod
         assert scale > 0 and float((got.double() - want).abs().max()) <= 2e-5 * scale, (float((got.double() - want).abs().max()), scale)
 
 
+@pytest.mark.parametrize("n,F,T,x_grad", [(50000, 128, 12, False), (7777, 100, 8, False), (3001, 256, 32, True), (999, 64, 1, True),
+                                            (70000, 40, 20, False)])
+def test_narrow_terms_function_matches_float64(hiplib, n, F, T, x_grad):
+    """nn._NarrowTerms: terms = x @ v for a long x and a narrow v, dv = x^T @ dterms by wgamd_rows_terms_bwd_f32 (float atomics),
+    dx by a library product — against float64."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator(device="cuda").manual_seed(n + T)
+    x = torch.randn((n, F), generator=g, device="cuda").requires_grad_(x_grad)
+    v = (torch.randn((F, T), generator=g, device="cuda") * 0.3).requires_grad_(True)
+    gout = torch.randn((n, T), generator=g, device="cuda")
+    out = nn._NarrowTerms.apply(x, v)
+    out.backward(gout)
+    x64, v64 = x.detach().double().requires_grad_(x_grad), v.detach().double().requires_grad_(True)
+    ref = x64 @ v64
+    ref.backward(gout.double())
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # (a sum of n products per element: compare at the scale of the sum of their magnitudes)
+    scale = (x.detach().double().abs().t() @ gout.double().abs())
+    assert bool(((v.grad.double() - v64.grad).abs() <= 1e-5 * scale + 1e-9).all()), float((v.grad.double() - v64.grad).abs().max())
+    if x_grad:
+        assert float((x.grad.double() - x64.grad).abs().max()) <= 1e-5 * float(x64.grad.abs().max())
+
+
 def test_hetero_conv_trains_aggregate_first_like_relation_by_relation(hiplib):
     """nn.HeteroConv over a heterogeneous call group under autograd: the aggregate-first route (_forward_layer_train: lazy x read
     through the node lists, terms of the tables' rows) gives the outputs and the parameter gradients of PyG's relation-by-relation
