@@ -1175,6 +1175,11 @@ class HeteroLayerGraph:
         return sum(r.n_edges for r in self.relations)
 
 
+from .pool import GrowOnlyPool  # noqa: E402
+
+_agg_pool = GrowOnlyPool()
+
+
 class _NarrowTerms(torch.autograd.Function):
     """``terms = x @ v`` for a LONG ``x`` ([n, F], a feature table or a hidden state) and a narrow ``v`` ([F, T], T <= 32: the
     folded attention vectors of a node type).  Forward: ``rows_terms`` (one streaming pass, exact-fp32 MFMA) where the shape
@@ -1217,7 +1222,10 @@ class _GatAggregateHeads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, a_src, a_dst, row_ptr, col, heads, dst_rows, src_ids, dst_ids, src_by_id, dst_by_id, slope):
         a_src, a_dst = a_src.contiguous(), a_dst.contiguous()
-        agg = gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=dst_rows, negative_slope=slope, src_ids=src_ids,
+        # (the [rows, heads x F] aggregate is gigabytes per hop of a call group and changes size by a per cent from group to
+        #  group: a grow-only buffer instead of a hipMalloc / hipFree pair per hop — recycled once nothing holds it any more)
+        out = _agg_pool.take((int(row_ptr.shape[0]) - 1, heads * int(x.shape[1])), torch.float32, x.device)
+        agg = gat_aggregate_heads(row_ptr, col, x, a_src, a_dst, heads, dst_rows=dst_rows, negative_slope=slope, out=out, src_ids=src_ids,
                                   dst_ids=dst_ids, src_terms_by_id=src_by_id, dst_terms_by_id=dst_by_id)
         ctx.save_for_backward(x, a_src, a_dst, row_ptr, col)
         ctx.extra = (heads, dst_rows, src_ids, dst_ids, src_by_id, dst_by_id, slope)
