@@ -323,8 +323,10 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
                                const float* __restrict__ a_dst, float slope, const int64_t* __restrict__ dst_rows,
                                const int64_t* __restrict__ src_ids, const int64_t* __restrict__ dst_ids, int terms_by_id,
                                const float* __restrict__ g, int64_t ldg, float* __restrict__ de, float* __restrict__ ga_src,
-                               float* __restrict__ ga_dst, float* __restrict__ gx, int64_t ldgx, int log2_lanes)
+                               float* __restrict__ ga_dst, float* __restrict__ gx, int64_t ldgx, int log2_lanes,
+                               float* __restrict__ stats)
 {
+  // stats (nullable): [2][n_rows][H] — the row's softmax maximum and denominator per head, for the source-major gx kernel
   // Lane k of the group OWNS edge c0 + k of the current chunk of `lanes` edges: its column, term row, scores and attention
   // weights are loaded / computed once, by that lane (coalesced), and broadcast where the whole group needs them; the
   // neighbour rows of a chunk are requested four at a time.
@@ -551,8 +553,71 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
 #pragma unroll
     for (int h = 0; h < H; h++) {
       const float v = group_sum(gad[h]);
-      if (sub == 0) unsafeAtomicAdd(ga_dst + arow * H + h, v);
+      if (sub == 0) {
+        unsafeAtomicAdd(ga_dst + arow * H + h, v);
+        if (stats != nullptr) {
+          stats[row * H + h]            = m[h];
+          stats[(n_rows + row) * H + h] = den[h];
+        }
+      }
     }
+  }
+}
+
+// gx[j, :] = sum over the edges (i, j) of sum_h alpha_{ij}^h g[i, h, :] — the gradient of the SOURCE rows of the aggregate-first
+// aggregation, source-major over the transposed hop (row_ptr_t / col_t = destination row of every entry, wgamd_csr_transpose_i32):
+// one lane group per source row, every row of gx written exactly once, no atomics (the destination-major kernel's alternative is
+// F atomics per edge: 1.25 G of them for the seeds' layer of a products call group).  alpha is recomputed from the terms and the
+// destination rows' softmax statistics the destination-major kernel left in `stats`.  Plain addressing only (a hidden-state
+// input: a_src per source row, a_dst at dst_rows[i]).
+template <int H>
+__global__ void __launch_bounds__(256)
+gat_aggregate_heads_bwd_gx_kernel(const int* __restrict__ row_ptr_t, const int* __restrict__ col_t, int64_t n_src, int64_t n_rows,
+                                  int F, const float* __restrict__ a_src, const float* __restrict__ a_dst, float slope,
+                                  const int64_t* __restrict__ dst_rows, const float* __restrict__ stats,
+                                  const float* __restrict__ g, int64_t ldg, float* __restrict__ gx, int64_t ldgx, int log2_lanes)
+{
+  const int lanes       = 1 << log2_lanes;
+  const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub         = (int)(tid & (lanes - 1));
+  const int gbase       = (int)(threadIdx.x & 63) & ~(lanes - 1);
+  const int64_t group   = tid >> log2_lanes;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
+  const bool live       = sub * 4 < F;
+  const int f0          = live ? sub * 4 : 0;
+  for (int64_t j = group; j < n_src; j += ngroups) {
+    const int s = row_ptr_t[j], e = row_ptr_t[j + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float as_[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) as_[h] = a_src[j * H + h];
+    for (int c0 = s; c0 < e; c0 += lanes) {
+      const bool on = c0 + sub < e;
+      const int cnt = min(lanes, e - c0);
+      const int i   = on ? col_t[c0 + sub] : 0;
+      float w[H];
+      {
+        const int64_t arow = dst_rows ? dst_rows[i] : (int64_t)i;
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          float sc = as_[h] + a_dst[arow * H + h];
+          sc       = sc > 0.f ? sc : sc * slope;
+          w[h]     = on ? expf(sc - stats[(int64_t)i * H + h]) / stats[(n_rows + i) * H + h] : 0.f;
+        }
+      }
+      for (int k = 0; k < cnt; k++) {
+        const int ik = __shfl(i, gbase | k, 64);
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          const float wk = __shfl(w[h], gbase | k, 64);
+          if (live) {
+            const float4 g4 = *reinterpret_cast<const float4*>(g + (int64_t)ik * ldg + (int64_t)h * F + f0);
+            acc.x += wk * g4.x; acc.y += wk * g4.y; acc.z += wk * g4.z; acc.w += wk * g4.w;
+          }
+        }
+      }
+    }
+    if (live) *reinterpret_cast<float4*>(gx + j * ldgx + f0) = acc;
   }
 }
 
@@ -564,7 +629,8 @@ extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int*
                                                                       int terms_by_id, int F, const float* a_src, const float* a_dst,
                                                                       int H, float negative_slope, const int64_t* dst_rows,
                                                                       const float* grad_agg, int64_t ldg, float* de, float* grad_a_src,
-                                                                      float* grad_a_dst, float* grad_x, int64_t ldgx, void* stream)
+                                                                      float* grad_a_dst, float* grad_x, int64_t ldgx, float* stats,
+                                                                      void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_gat_aggregate_heads_bwd_f32", [&] {
@@ -586,7 +652,7 @@ extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int*
 #define WG_GAT_AGG_BWD(HH)                                                                                                        \
   gat_aggregate_heads_bwd_kernel<HH><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope, dst_rows, \
                                                            src_ids, dst_ids, terms_by_id, grad_agg, ldg, de, grad_a_src, grad_a_dst, \
-                                                           grad_x, ldgx, l2)
+                                                           grad_x, ldgx, l2, stats)
     switch (H) {
       case 1: WG_GAT_AGG_BWD(1); break;
       case 2: WG_GAT_AGG_BWD(2); break;
@@ -594,6 +660,40 @@ extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int*
       default: WG_GAT_AGG_BWD(8); break;
     }
 #undef WG_GAT_AGG_BWD
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_gx_f32(const int* row_ptr_t, const int* col_t, int64_t n_src,
+                                                                         int64_t n_rows, int F, const float* a_src, const float* a_dst,
+                                                                         int H, float negative_slope, const int64_t* dst_rows,
+                                                                         const float* stats, const float* grad_agg, int64_t ldg,
+                                                                         float* grad_x, int64_t ldgx, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_gat_aggregate_heads_bwd_gx_f32", [&] {
+    WG_REQUIRE_INPUT(n_src >= 0 && n_rows >= 0 && H > 0 && F > 0, "bad sizes");
+    if (n_src == 0) return;
+    WG_REQUIRE_INPUT(row_ptr_t && a_src && a_dst && stats && grad_agg && grad_x, "null pointer");
+    if (F % 4 != 0 || F > 256 || !(H == 1 || H == 2 || H == 4 || H == 8) || (ldg & 3) != 0 || (ldgx & 3) != 0 ||
+        ((reinterpret_cast<uintptr_t>(grad_agg) | reinterpret_cast<uintptr_t>(grad_x)) & 15) != 0)
+      throw logic_error(fmt("unsupported shape: F=%d (multiple of 4, <= 256), H=%d (1, 2, 4 or 8), 16-B aligned rows", F, H));
+    WG_REQUIRE_INPUT(ldg >= (int64_t)H * F && ldgx >= F, "leading dimension");
+    auto st = static_cast<hipStream_t>(stream);
+    int l2  = 0;
+    while ((1 << l2) < F / 4 && l2 < 6) l2++;
+    const int64_t groups_per_block = 256 >> l2;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_src + groups_per_block - 1) / groups_per_block, 256 * 16));
+#define WG_GAT_GX(HH)                                                                                                            \
+  gat_aggregate_heads_bwd_gx_kernel<HH><<<grid, 256, 0, st>>>(row_ptr_t, col_t, n_src, n_rows, F, a_src, a_dst, negative_slope,     \
+                                                              dst_rows, stats, grad_agg, ldg, grad_x, ldgx, l2)
+    switch (H) {
+      case 1: WG_GAT_GX(1); break;
+      case 2: WG_GAT_GX(2); break;
+      case 4: WG_GAT_GX(4); break;
+      default: WG_GAT_GX(8); break;
+    }
+#undef WG_GAT_GX
     WG_HIP_CHECK(hipGetLastError());
   });
 }

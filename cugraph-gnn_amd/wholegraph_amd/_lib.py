@@ -283,7 +283,9 @@ SYMBOLS = {
     "wgamd_gather_term_slabs_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "wgamd_gat_aggregate_heads_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int,
                                                   c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                                  c_void_p, c_void_p, c_int64, c_void_p]),
+                                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "wgamd_gat_aggregate_heads_bwd_gx_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_float,
+                                                     c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_aggregate_heads_ids_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int,
                                                   c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_layer_fused_ids_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int,

@@ -1238,14 +1238,35 @@ class _GatAggregateHeads(torch.autograd.Function):
         g = g.contiguous()
         n_rows, F_ = row_ptr.shape[0] - 1, x.shape[1]
         ga_src, ga_dst = torch.zeros_like(a_src), torch.zeros_like(a_dst)
-        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
         de = torch.empty((max(int(col.shape[0]), 1), heads), dtype=torch.float32, device=g.device)
         ids_p, dids_p, by_id = _gat_ids(src_ids, dst_ids, a_src, src_by_id, dst_by_id)
+        want_gx = ctx.needs_input_grad[0]
+        # the source rows' gradient: source-major over the transposed hop (every row written once) where the addressing is plain —
+        # a hidden-state input —, float atomics (F per edge) otherwise
+        transposed = want_gx and src_ids is None and int(col.shape[0]) > 0
+        gx = torch.zeros_like(x) if (want_gx and not transposed) else None
+        stats = torch.empty((2, n_rows, heads), dtype=torch.float32, device=g.device) if transposed else None
         L.check(L.lib().wgamd_gat_aggregate_heads_bwd_f32(
             row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), ids_p, dids_p, by_id, F_, a_src.data_ptr(),
             a_dst.data_ptr(), heads, float(slope), None if dst_rows is None else dst_rows.data_ptr(), g.data_ptr(), g.stride(0),
             de.data_ptr(), ga_src.data_ptr(), ga_dst.data_ptr(), None if gx is None else gx.data_ptr(),
-            0 if gx is None else gx.stride(0), get_stream()), "wgamd_gat_aggregate_heads_bwd_f32")
+            0 if gx is None else gx.stride(0), None if stats is None else stats.data_ptr(), get_stream()),
+            "wgamd_gat_aggregate_heads_bwd_f32")
+        if transposed:
+            n_src = int(x.shape[0])
+            hit = getattr(row_ptr, "_wgamd_gat_t", None)          # (one transpose per hop CSR, kept on the tensor the layer graph holds)
+            if hit is None or hit[0] != n_src or hit[1] != col.data_ptr():
+                row_ptr_t, _, _, col_t = _csr_transpose(row_ptr, col, n_src, want_col_t=True)
+                hit = (n_src, col.data_ptr(), row_ptr_t, col_t)
+                try:
+                    row_ptr._wgamd_gat_t = hit
+                except AttributeError:
+                    pass
+            gx = torch.empty_like(x)
+            L.check(L.lib().wgamd_gat_aggregate_heads_bwd_gx_f32(
+                hit[2].data_ptr(), hit[3].data_ptr(), n_src, n_rows, F_, a_src.data_ptr(), a_dst.data_ptr(), heads, float(slope),
+                None if dst_rows is None else dst_rows.data_ptr(), stats.data_ptr(), g.data_ptr(), g.stride(0), gx.data_ptr(),
+                gx.stride(0), get_stream()), "wgamd_gat_aggregate_heads_bwd_gx_f32")
         return gx, ga_src, ga_dst, None, None, None, None, None, None, None, None, None
 
 

@@ -452,7 +452,16 @@ wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int* row_ptr, c
                                                            int terms_by_id, int F, const float* a_src, const float* a_dst, int H,
                                                            float negative_slope, const int64_t* dst_rows, const float* grad_agg,
                                                            int64_t ldg, float* de, float* grad_a_src, float* grad_a_dst,
-                                                           float* grad_x, int64_t ldgx, void* stream);
+                                                           float* grad_x, int64_t ldgx, float* stats, void* stream);
+/* (stats, nullable: [2][n_rows][H] floats — the rows' softmax maxima and denominators, what the kernel below reads.)
+ * grad_x of the same aggregation WITHOUT atomics, source-major over the transposed hop (row_ptr_t [n_src + 1], col_t = the
+ * destination row of every entry: wgamd_csr_transpose_i32): every row of grad_x [n_src, F] is written exactly once.  Plain
+ * addressing (a_src per source row, a_dst at dst_rows[i]): the case of a hidden-state input. */
+wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_gx_f32(const int* row_ptr_t, const int* col_t, int64_t n_src, int64_t n_rows,
+                                                              int F, const float* a_src, const float* a_dst, int H,
+                                                              float negative_slope, const int64_t* dst_rows, const float* stats,
+                                                              const float* grad_agg, int64_t ldg, float* grad_x, int64_t ldgx,
+                                                              void* stream);
 
 /* The dense tail after wgamd_gat_aggregate_heads_f32 on the matrix pipe at fp32 accuracy (csrc/wg_gat_transform.hip):
  *   out[out_rows ? out_rows[i] : i, h C + c] = act( sum_k agg[i, h F + k] W[k, h C + c] (+ acc_in[i, h C + c]) (+ bias[h C + c]) )

@@ -177,11 +177,12 @@ def test_gat_aggregate_heads_backward_matches_float64_autograd(hiplib, F, H, mod
     src_by_id, dst_by_id = mode in ("by_id", "by_id_src"), mode == "by_id"
     a_src = (torch.randn((n_table if src_by_id else n_src, H), generator=g, device="cuda") * 2).requires_grad_(True)
     a_dst = (torch.randn((n_table if dst_by_id else n_dst_list, H), generator=g, device="cuda") * 2).requires_grad_(True)
-    x = table.clone().requires_grad_(not lazy)
+    x_grad = (not lazy) or mode == "ids"     # plain: the transposed-hop kernel; "ids": a TABLE that asks for its gradient (atomics)
+    x = table.clone().requires_grad_(x_grad)
     out = nn._GatAggregateHeads.apply(x, a_src, a_dst, rp, col, H, dst_rows, ids, dids if dst_by_id else None, src_by_id, dst_by_id, 0.2)
     out.backward(gout)
     # float64 reference: the list-level quantities spelled out, gradients flow back to the table-level leaves through indexing
-    x64 = table.double().requires_grad_(not lazy)
+    x64 = table.double().requires_grad_(x_grad)
     s64, d64 = a_src.detach().double().requires_grad_(True), a_dst.detach().double().requires_grad_(True)
     x_list = x64[ids] if lazy else x64
     s_list = s64[ids] if src_by_id else s64
@@ -189,7 +190,7 @@ def test_gat_aggregate_heads_backward_matches_float64_autograd(hiplib, F, H, mod
     ref = _agg_heads_reference(x_list, s_list, d_list, rp, col, H, dst_rows)
     ref.backward(gout.double())
     assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
-    for got, want in ((a_src.grad, s64.grad), (a_dst.grad, d64.grad)) + (((x.grad, x64.grad),) if not lazy else ()):
+    for got, want in ((a_src.grad, s64.grad), (a_dst.grad, d64.grad)) + (((x.grad, x64.grad),) if x_grad else ()):
         scale = float(want.abs().max())
         assert scale > 0 and float((got.double() - want).abs().max()) <= 2e-5 * scale, (float((got.double() - want).abs().max()), scale)
 
