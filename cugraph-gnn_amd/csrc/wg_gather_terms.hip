@@ -260,7 +260,7 @@ gather_term_slabs_kernel(const f32x4* __restrict__ in, int64_t n_in, int K, cons
 // X; here every block streams its stretch of rows once — thread (row lane, feature f) reads X[row, f] (a coalesced row per
 // lane group), the rows' dT values come from an LDS tile as broadcast float4 reads — and adds its [T] partial sums to dV with
 // float atomics (F x T per block).  TT = ceil(T / 4) float4 accumulators per thread.
-constexpr int kXtRows = 64;   // dT rows per LDS tile
+constexpr int kXtRows = 128;   // dT rows per LDS tile
 template <int TT>
 __global__ void __launch_bounds__(256)
 rows_terms_bwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int F, int fp_log2, const float* __restrict__ dt, int T,
@@ -289,12 +289,23 @@ rows_terms_bwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int F
     }
     __syncthreads();
     const int rows = (int)(r1 - base < kXtRows ? r1 - base : kXtRows);
-    if (live)
-      for (int r = rl; r < rows; r += n_rl) {
+    if (live) {
+      int r = rl;
+      for (; r + 3 * n_rl < rows; r += 4 * n_rl) {   // four rows' loads in flight per lane
+        float xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = x[(base + r + u * n_rl) * ldx + f];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < TT; q++) acc[q] += xv[u] * tile[r + u * n_rl][q];
+      }
+      for (; r < rows; r += n_rl) {
         const float xv = x[(base + r) * ldx + f];
 #pragma unroll
         for (int q = 0; q < TT; q++) acc[q] += xv * tile[r][q];
       }
+    }
   }
   if (live) {
 #pragma unroll
