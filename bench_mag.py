@@ -247,9 +247,11 @@ def main(args):
     g = torch.Generator(device=dev).manual_seed(5)
     tables = {t: torch.rand((num_nodes[t], F_IN), generator=g, device=dev) * 2 - 1 for t in ntypes}
     params = make_params(etypes, ntypes, dev)
-    # call groups of 64 mini-batches (measured: 32 -> 1.31, 64 -> 1.40, 96 -> 1.39 G edges/s; the walk's ~120 launches per group
-    # are what a larger group amortises)
-    B, G, gps = 1024, args.call_group if args.call_group > 0 else 64, args.groups_per_step
+    # call groups of 128 mini-batches: measured on one box at the end of round 5 — 64 -> 2.66, 128 -> 3.39, 192 -> 3.50 G edges/s
+    # (0.122 / 0.096 / 0.093 ms per mini-batch: the walk's ~180 launches and the layers' eleven launches per group are what a
+    # larger group amortises; rounds 3-4 ran 64).  The loader's own default for this configuration, sized from the walk's
+    # buffer capacities within 2 % of the device memory, is 49 (HeteroNeighborSampler.seeds_per_call).
+    B, G, gps = 1024, args.call_group if args.call_group > 0 else 128, args.groups_per_step
     from wholegraph_amd import nn
     model = build_model(params, etypes, ntypes, dev)
     for j, m in enumerate(model):
@@ -258,7 +260,7 @@ def main(args):
     warm = max(args.warmup * gps, 2)
     n_probe = min(groups, 6)
     gs_ = torch.Generator(device=dev).manual_seed(7)
-    need = (groups + warm + n_probe) * G * B
+    need = (groups + warm + n_probe + 1) * G * B        # (+ 1: the probe pass's own untimed first group)
     reps = -(-need // num_nodes["paper"])
     order = torch.cat([torch.randperm(num_nodes["paper"], generator=gs_, device=dev) for _ in range(reps)])
     fanout = {et: [25, 10] for et in etypes}
@@ -296,7 +298,7 @@ def main(args):
     try:
         with torch.no_grad():
             it = probe.call_groups(overlap=False)
-            for gi in range(n_probe):
+            for gi in range(n_probe + 1):      # group 0 of the pass is not accumulated (first use of this pass's buffer sizes)
                 torch.cuda.synchronize()
                 del timers[:]
                 # (overlap=False: next() enqueues the walk of the FOLLOWING group on this stream — two of them on the first
@@ -305,7 +307,7 @@ def main(args):
                 w0.record()
                 grp = next(it)
                 w1.record()
-                walk_groups = 1 if 0 < gi < n_probe - 1 else 0
+                walk_groups = 1 if 0 < gi < n_probe else 0
                 s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s_.record()
                 lg = [grp.layer_graph(j) for j in range(hops)]
@@ -313,6 +315,8 @@ def main(args):
                 timers.append(("index_prep", s_, e_))
                 forward_group(model, grp)
                 torch.cuda.synchronize()
+                if gi == 0:
+                    continue
                 if walk_groups:
                     walk_ms.append(w0.elapsed_time(w1))
                 for name, a_, b_ in timers:
@@ -366,7 +370,7 @@ def main(args):
             roofline["kernel_all_launches"] = {"stage": same, "launches": sum(1 for k in gat if k.split(":")[0] == same),
                                                "algorithmic_bytes": int(tot_by), "ms": round(tot_ms, 4),
                                                "frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-    if roofline is not None and G == 64 and args.call_group <= 0:
+    if roofline is not None and G == 128 and args.call_group <= 0:
         # HBM traffic and average duration of that launch shape from the committed profile of this command
         # (profiles/rNN/pmc_traffic_mag.json: the `#large` cluster = the largest launch of every call group; mag_kernel_stats.csv)
         from bench import load_pmc, load_profiled_avg

@@ -476,15 +476,64 @@ class HeteroNeighborSampler:
         return biased_ok and (not self.temporal) and (not self.disjoint) and (not self.with_replacement) and all(
             g.col.dtype == torch.int64 for g in self.graphs.values())
 
+    def _walk_capacity_per_seed(self):
+        """(device bytes, largest node + edge slots of one call, node rows) ONE seed of a call group costs in the heterogeneous
+        walk (``wholegraph_amd.fused.HeteroPygWalk``): its buffers are capacity-sized — a hop's frontier of a node type is
+        everything the previous hop could have added to that type, an edge type's call holds frontier x fan-out edge slots —
+        and all calls of a group stay alive until the group is consumed.  The worst seed type counts (the sampler does not
+        know which type a loader seeds).  None when a fan-out is not positive (sample-all: no capacity bound)."""
+        from wholegraph_amd import _lib as L
+        hops = len(next(iter(self.fanout.values())))
+        if any(f <= 0 for v in self.fanout.values() for f in v):
+            return None
+        types = sorted({t for et in self.graphs for t in (et[0], et[2])})
+        worst = None
+        for seed_type in types:
+            gained = {t: 0 for t in types}
+            cap = dict(gained)
+            gained[seed_type] = cap[seed_type] = 1
+            total, ws, slots = 0.0, 0.0, 1
+            for h in range(hops):
+                nxt = {t: 0 for t in types}
+                for et in sorted(self.graphs):
+                    fc = gained[et[2]]
+                    if fc == 0:
+                        continue
+                    ec, nc = fc * self.fanout[et][h], max(cap[et[0]], 1)
+                    # per edge slot: local row / col + two scratch columns (int32), edge id, new node, its batch, next frontier
+                    # entry, its batch; per node slot of the source type's list: id + batch; the frontier's offsets
+                    total += ec * (4 * 4 + 8 + 8 + 4 + 8 + 4) + nc * (8 + 4) + (fc + 1) * 4
+                    ws = max(ws, L.lib().wgamd_sample_hop_workspace_bytes(4096 * max(nc, fc), 4096 * ec, L.DT_INT64) / 4096.0)
+                    slots = max(slots, nc + ec)
+                    cap[et[0]] += ec
+                    nxt[et[0]] += ec
+                gained = nxt
+            mine = (total + ws, slots, sum(cap.values()))
+            worst = mine if worst is None or mine[0] > worst[0] else worst
+        return worst
+
     def seeds_per_call(self, batch_size: int) -> int:
-        """``local_seeds_per_call`` as given, else sized from device memory with the per-hop fan-outs summed over the edge
-        types (distributed_sampler.py:848-856)."""
+        """``local_seeds_per_call`` as given, else sized from device memory: the reference sums the per-hop fan-outs over the
+        edge types as if they were one homogeneous hop (distributed_sampler.py:848-856 — for ogbn-mag's 6 edge types at [25, 10]
+        that prices a seed at 9,000 hop-2 edges, 7x what this walk's buffers can hold, and gives groups of 5 mini-batches);
+        here a seed is priced at the capacity the heterogeneous walk really allocates for it (``_walk_capacity_per_seed``),
+        within the same memory fraction — about 50 mini-batches of 1024 seeds for that configuration on 288 GB."""
         if self.local_seeds_per_call:
             return int(self.local_seeds_per_call)
-        hops = len(next(iter(self.fanout.values())))
-        per_hop = [sum(max(v[h], 0) for v in self.fanout.values()) if all(v[h] > 0 for v in self.fanout.values()) else -1
-                   for h in range(hops)]
-        return default_local_seeds_per_call(per_hop, batch_size, 8, self.disjoint, feature_row_bytes=self.feature_row_bytes)
+        cost = self._walk_capacity_per_seed() if not self.disjoint else None
+        if cost is None:
+            hops = len(next(iter(self.fanout.values())))
+            per_hop = [sum(max(v[h], 0) for v in self.fanout.values()) if all(v[h] > 0 for v in self.fanout.values()) else -1
+                       for h in range(hops)]
+            return default_local_seeds_per_call(per_hop, batch_size, 8, self.disjoint, feature_row_bytes=self.feature_row_bytes)
+        total_memory = (torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+                        if torch.cuda.is_available() else 16 << 30)
+        per_call = int(CALL_GROUP_MEMORY_FRACTION * total_memory / cost[0])
+        per_call = min(per_call, _CALL_GROUP_CAPACITY // max(cost[1], 1))
+        fetched = cost[2] * int(self.feature_row_bytes[0]) + max(cost[2] - 1, 0) * int(self.feature_row_bytes[1])
+        if fetched > 0:
+            per_call = min(per_call, int(CALL_GROUP_FEATURE_FRACTION * total_memory / fetched))
+        return max(batch_size, per_call // batch_size * batch_size)
 
     def fetch_plan(self, n: int, batch_size: int, on_device: bool = True):
         """(call groups, batches outside a group, batches) ``sample_batches`` will produce for ``n`` seeds."""

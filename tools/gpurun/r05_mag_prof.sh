@@ -8,7 +8,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-include-regex "gat_layer_fused|gat_aggregate_heads|gather_terms" --output-format csv -d /tmp/pc_mag_$C -o mag_$C -- python $R/bench.py --workload mag --steps 4 --warmup 2 --no-cpu-baseline --no-variants > $OUT/mag_$C.log 2>&1
   cp /tmp/pc_mag_$C/*counter_collection.csv $OUT/
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_magtrain -o mag_train -- python $R/tools/profile_mag_train.py 4 64 > $OUT/mag_train_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_magtrain -o mag_train -- python $R/tools/profile_mag_train.py 4 128 > $OUT/mag_train_trace.log 2>&1
 cp /tmp/pt_magtrain/mag_train_kernel_stats.csv $OUT/
 tail -1 $OUT/mag_train_trace.log
 ls -la $OUT
