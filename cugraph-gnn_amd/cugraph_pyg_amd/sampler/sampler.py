@@ -497,7 +497,7 @@ class HeteroNeighborSampler:
                 nxt = {t: 0 for t in types}
                 for et in sorted(self.graphs):
                     fc = gained[et[2]]
-                    if fc == 0:
+                    if fc == 0 or et not in self.fanout:      # (an edge type without a fan-out entry is not sampled)
                         continue
                     ec, nc = fc * self.fanout[et][h], max(cap[et[0]], 1)
                     # per edge slot: local row / col + two scratch columns (int32), edge id, new node, its batch, next frontier

@@ -288,3 +288,25 @@ def test_hetero_conv_folds_attention_vectors_and_sums_relation_biases():
     with torch.no_grad():
         hc.conv(ets[2]).bias.add_(1.0)                          # a bias alone changing is noticed too
     assert torch.allclose(hc._bias("author"), hc.conv(ets[2]).bias)
+
+
+def test_hetero_default_call_group_is_sized_from_the_walks_capacities():
+    """HeteroNeighborSampler.seeds_per_call without local_seeds_per_call: a seed costs what the heterogeneous walk allocates for
+    it (frontier capacities grow per node type, an edge type's call holds frontier x fan-out slots), not the reference's
+    fan-outs summed over the edge types as one homogeneous hop; edge types without a fan-out entry are not sampled."""
+    from cugraph_pyg_amd.sampler.sampler import HeteroNeighborSampler, default_local_seeds_per_call
+
+    class G:
+        time = weight = None
+    ets = [("author", "writes", "paper"), ("paper", "cites", "paper"), ("paper", "has_topic", "field"), ("author", "at", "inst"),
+           ("paper", "rev_writes", "author"), ("field", "rev_has_topic", "paper")]
+    smp = HeteroNeighborSampler({et: G() for et in ets}, {et: [25, 10] for et in ets})
+    nbytes, slots, rows = smp._walk_capacity_per_seed()
+    # worst seed type = paper: hop 1 = 3 edge types x 25; hop 2 = (3 into paper + 1 into author + 1 into field) x 25 x 10
+    assert rows == 1 + 75 + 1250 and 60_000 < nbytes < 200_000 and slots >= 250
+    summed = default_local_seeds_per_call([150, 60], 1024, 8, total_memory=16 << 30)
+    assert smp.seeds_per_call(1024) >= summed and smp.seeds_per_call(1024) % 1024 == 0
+    part = HeteroNeighborSampler({et: G() for et in ets}, {ets[0]: [25, 10], ets[1]: [25, 10]})      # four edge types unsampled
+    assert part._walk_capacity_per_seed()[2] < rows
+    assert HeteroNeighborSampler({et: G() for et in ets}, {et: [-1, 10] for et in ets})._walk_capacity_per_seed() is None
+    assert HeteroNeighborSampler({et: G() for et in ets}, {et: [25, 10] for et in ets}, local_seeds_per_call=4096).seeds_per_call(1024) == 4096
