@@ -310,7 +310,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
     fs["n", "x", None] = table
     out = {}
 
-    def group_pass(lazy, n_warm=2):
+    def group_pass(lazy, n_warm=5):
         loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_groups + n_warm) * G * BATCH], batch_size=BATCH,
                                 shuffle=False, random_state=62)
         edges, t0, n = 0, None, 0
@@ -433,7 +433,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
         labels = torch.randint(0, CLASSES, (V,), generator=torch.Generator(device=dev).manual_seed(6), device=dev)
         opt = torch.optim.SGD(gat.parameters(), lr=0.01)
         for train in (False, True):
-            n_g, n_warm = min(n_groups, 6), 3
+            n_g, n_warm = min(n_groups, 6), 6
             ids = seeds[:(n_g + n_warm) * G * BATCH]
             loader = NeighborLoader((fs, gs), FANOUT, input_nodes=ids, batch_size=BATCH, shuffle=False, random_state=62)
             edges, t0, n, loss = 0, None, 0, None
