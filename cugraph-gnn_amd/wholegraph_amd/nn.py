@@ -1413,6 +1413,7 @@ class HeteroConv(torch.nn.Module):
         dev = next(iter(x.values())).device
         out = {}
         groups = {}
+        listed = set()
         for r in graph.relations:
             groups.setdefault((r.hop, r.edge_type[2]), []).append(r)
         for t, n in graph.n_out.items():
@@ -1442,8 +1443,11 @@ class HeteroConv(torch.nn.Module):
                     through = dict(src_ids=ids, src_terms_by_id=et[0] in self._by_id)
                     if et[2] in self._by_id:
                         through.update(dst_ids=x[et[2]].ids, dst_terms_by_id=True)
-                elif et[2] in self._by_id:          # (terms of the destination table's rows next to a resident source: per-list terms)
+                elif et[2] in self._by_id and et not in listed:
+                    # (terms of the destination TABLE's rows next to a resident source: per-list terms, made once per edge type —
+                    #  the relation runs in several hops)
                     a_dst[et] = gather_term_slabs(a_dst[et].unsqueeze(0), x[et[2]].ids)[0]
+                    listed.add(et)
                 tail = dict(acc_in=acc if j > 0 else None, bias=bias if (last and one_pass) else None, relu=last and one_pass and relu,
                             out_rows=place if (last and one_pass) else None, out=target if (last and one_pass) else acc)
                 name = "%s hop %d (%d rows, %d edges)" % (et[1], hop + 1, n_f, r.n_edges)

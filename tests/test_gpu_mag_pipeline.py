@@ -254,6 +254,14 @@ def test_hetero_conv_trains_aggregate_first_like_relation_by_relation(hiplib):
         results.append((out.detach().clone(), [None if p.grad is None else p.grad.clone() for p in params]))
     (o1, g1), (o2, g2) = results
     assert float((o1 - o2).abs().max()) <= 2e-5 * float(o2.abs().max())
+    # mixed inputs under autograd: one node type as gathered rows, the others lazy — the aggregate-first route gives the same bits
+    for m in model:
+        m.train_aggregate_first = True
+    for resident in ("author", "paper"):
+        h = {t: (v.materialize() if t == resident else v) for t, v in grp.x_dict.items()}
+        for j, layer in enumerate(model):
+            h = layer(h, grp.layer_graph(j), act=None)
+        assert h["paper"].requires_grad and torch.equal(h["paper"].detach(), o1), resident
     assert sum(a is not None for a in g1) >= 20
     for a, b in zip(g1, g2):
         if a is None or b is None:        # a relation the seeds cannot see through the remaining layers: no gradient, or zeros
@@ -294,6 +302,13 @@ def test_mag_pipeline_matches_cpu_port(oracle_mod, hiplib):
         assert torch.equal(bm.forward_group(model, grp), out)
         for layer in model:
             layer.fetch_in_layer = True
+        # MIXED inputs: one node type handed over as gathered rows, the others lazy (a resident source next to destinations whose
+        # terms are those of the table's rows, and the other way round) — still the same bits
+        for resident in ("author", "paper"):
+            h = {t: (v.materialize() if t == resident else v) for t, v in grp.x_dict.items()}
+            for j, layer in enumerate(model):
+                h = layer(h, grp.layer_graph(j), act="relu")
+            assert torch.equal(h["paper"], out), resident
         # the relation-by-relation route (GATConv modules, transform-first: what trains) computes the same layer
         h = grp.node_attr("x", lazy=False)
         for j, layer in enumerate(model):
