@@ -368,6 +368,26 @@ def _gat_reference_seed_outputs(convs, data, self_loops):
     return h[:data.batch_size]
 
 
+def test_homogeneous_gatconv_mean_over_heads_and_no_bias(hiplib):
+    """concat=False (mean over the heads) and bias=False through the call-group route, forward against the float64 formulation."""
+    import torch
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd import nn
+    gs, fs, feat = _stores(4000, 10, 32, seed=13)
+    torch.manual_seed(8)
+    convs = [nn.GATConv(32, 8, heads=8, bias=False).cuda(), nn.GATConv(64, 12, heads=2, concat=False).cuda()]
+    seeds = torch.randperm(4000, generator=torch.Generator().manual_seed(3))[:3 * 64].cuda()
+    loader = NeighborLoader((fs, gs), [5, 5], input_nodes=seeds, batch_size=64, shuffle=False, random_state=9, local_seeds_per_call=3 * 64)
+    g = next(iter(loader.call_groups()))
+    with torch.no_grad():
+        h = g.x
+        for j, c in enumerate(convs):
+            h = c(h, g.layer_graph(j), act="relu" if j == 0 else None)
+    want = torch.cat([_gat_reference_seed_outputs(convs, d, True) for d in g.to_data_list()])
+    assert h.shape == want.shape == (3 * 64, 12)
+    assert float((h.double().cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("self_loops,table_rows", [(True, 3000), (False, 3000), (True, 60000)])
 def test_homogeneous_gatconv_over_call_groups(hiplib, self_loops, table_rows):
     """nn.GATConv over a homogeneous call group's trimmed layer graphs (aggregate-first, x lazy; with a short table the
