@@ -473,3 +473,47 @@ def test_homogeneous_gatconv_over_call_groups(hiplib, self_loops, table_rows):
             a, b = got_by[(ci, k)], want_grads[ci * 4 + k]
             scale = float(b.abs().max())
             assert float((a - b.reshape(a.shape)).abs().max()) <= 2e-5 * scale + 1e-9, (ci, k, float((a - b.reshape(a.shape)).abs().max()), scale)
+
+
+@pytest.mark.parametrize("F,H,C", [(64, 4, 16), (100, 2, 8), (32, 8, 4), (256, 4, 64)])
+def test_hetero_conv_routes_agree_for_other_shapes(hiplib, F, H, C):
+    """nn.HeteroConv over a heterogeneous call group for shapes the one-kernel relation does not take: the inference route with
+    x lazy == with x gathered (bit for bit), == the relation-by-relation route on GATConv and the aggregate-first training route
+    to fp32 accuracy."""
+    import torch
+    from cugraph_pyg_amd.data import FeatureStore, GraphStore
+    from cugraph_pyg_amd.loader import NeighborLoader
+    from wholegraph_amd import nn
+    torch.manual_seed(F + H)
+    n = {"paper": 900, "author": 700}
+    rel = {("paper", "cites", "paper"): 9000, ("author", "writes", "paper"): 6000, ("paper", "rev_writes", "author"): 6000}
+    gs, fs = GraphStore(), FeatureStore()
+    for (s, r, d), m in rel.items():
+        gs[(s, r, d), "coo", False, (n[s], n[d])] = torch.stack([torch.randint(0, n[s], (m,)), torch.randint(0, n[d], (m,))])
+    for t in n:
+        fs[t, "x", None] = torch.randn(n[t], F).cuda()
+    B = 48
+    seeds = torch.randperm(n["paper"])[:B * 6].cuda()
+    loader = NeighborLoader((fs, gs), {et: [6, 4] for et in rel}, input_nodes=("paper", seeds), batch_size=B, shuffle=False,
+                            random_state=3, local_seeds_per_call=B * 6)
+    grp = next(iter(loader.call_groups()))
+    layers = [nn.HeteroConv({et: nn.GATConv(F if j == 0 else H * C, C, heads=H, add_self_loops=False) for et in rel}).cuda()
+              for j in range(2)]
+
+    def run(**flags):
+        for layer in layers:
+            for k, v in flags.items():
+                setattr(layer, k, v)
+        h = grp.x_dict
+        for j, layer in enumerate(layers):
+            h = layer(h, grp.layer_graph(j), act=None)
+        return h["paper"]
+    with torch.no_grad():
+        lazy = run(fetch_in_layer=True)
+        gathered = run(fetch_in_layer=False)
+    assert lazy.shape == (B * 6, H * C) and torch.equal(lazy, gathered)
+    trained = run(fetch_in_layer=True, train_aggregate_first=True)
+    relations = run(train_aggregate_first=False)
+    assert trained.requires_grad and relations.requires_grad
+    scale = float(lazy.abs().max())
+    assert float((trained.detach() - lazy).abs().max()) <= 2e-5 * scale and float((relations.detach() - lazy).abs().max()) <= 2e-5 * scale
