@@ -345,6 +345,26 @@ def test_csr_transpose_matches_stable_sort(hiplib, n_dst, n_src, max_deg):
     assert torch.equal(rpt2, row_ptr_t) and torch.equal(ct2, col_t)
 
 
+@pytest.mark.parametrize("n_src,used,E", [(5_000_000, 1000, 30000), (3_000_000, 3_000_000, 2000), (200_000, 50, 5), (40, 40, 3)])
+def test_csr_transpose_with_long_stretches_of_unused_sources(hiplib, n_src, used, E):
+    """The sources a hop never touches — the rest of a trimmed layer's input behind the last referenced row, wide holes between
+    clusters — are filled by the whole grid, not by the one thread that owns the stretch (12 ms per transpose before): row
+    offsets against torch's bincount + cumsum for millions of untouched sources, tiny edge lists (no room for the gap list)."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator().manual_seed(n_src + E)
+    n_dst = 777
+    cuts = torch.sort(torch.randint(0, E + 1, (n_dst - 1,), generator=g)).values
+    row_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), cuts, torch.tensor([E])]).int()
+    clusters = torch.randint(0, max(n_src - used, 0) + 1, (3,), generator=g)               # three clusters of referenced sources
+    col = (clusters[torch.randint(0, 3, (E,), generator=g)] + torch.randint(0, max(used // 3, 1), (E,), generator=g)).clamp_(max=n_src - 1).int()
+    row_ptr_t, perm, dst, col_t = nn._csr_transpose(row_ptr.cuda(), col.cuda(), n_src, want_perm=True, want_dst=True, want_col_t=True)
+    want_rpt = torch.zeros(n_src + 1, dtype=torch.int64)
+    want_rpt[1:] = torch.cumsum(torch.bincount(col.long(), minlength=n_src), 0)
+    assert torch.equal(row_ptr_t.cpu().long(), want_rpt)
+    assert torch.equal(perm.cpu().long(), torch.sort(col, stable=True).indices)
+
+
 @pytest.mark.parametrize("n_dst,n_src,E", [(1000, 4000, 20000), (1, 5, 9), (300, 7, 0), (70000, 70000, 400000)])
 def test_coo_to_csr_matches_torch_formulation(hiplib, n_dst, n_src, E):
     import torch
