@@ -594,6 +594,32 @@ def load_profiled_avg(kernel, workload="products"):
     return None
 
 
+def relaunch_if_needed(args):
+    """`--gpus N` is the number of ranks of this run.  Launched bare (`python bench.py --gpus N`, no WORLD_SIZE in the
+    environment) with N > 1, this process re-executes the same command line under `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N` (the driver's own launch shape) and exits with the launcher's code; launched by a
+    launcher whose WORLD_SIZE disagrees with `--gpus`, it fails loudly instead of printing a line with the wrong n_gpus."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus <= 1:
+            return
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        sys.exit(subprocess.call(cmd, env=env))
+    if int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}; refusing to print a line "
+                 f"whose n_gpus is not the number of ranks that ran (launch with --nproc-per-node {args.gpus}, or pass "
+                 f"--gpus {env_world})")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -650,6 +676,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
+    relaunch_if_needed(args)
     if args.workload == "mag":
         import bench_mag
         return bench_mag.main(args)
@@ -785,6 +812,8 @@ def main():
         info = {"rows": rows, "ids_per_rank": int(ids.numel()), "bit_exact": ok, "dedup_bit_exact": ok_d, "path": feature_fetch_path(t)}
         if hasattr(t, "comm") and hasattr(t.comm, "rccl_info"):
             info["rccl_ranks"], info["rccl_version"] = t.comm.rccl_info()
+            if args.dist_backend == "nccl" and info["rccl_ranks"] != args.gpus:
+                raise RuntimeError("selftest: the RCCL communicator holds %r ranks but --gpus is %d" % (info["rccl_ranks"], args.gpus))
         if hasattr(t, "destroy"):
             t.destroy()        # collective for a peer-mapped handle (every rank is here)
         if not ok:

@@ -238,9 +238,29 @@ def train_pass(model, tables, num_nodes, order, B, G, dev, groups=6, warm=2):
 
 def main(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload mag is the single-GPU configuration (BASELINE configs[4])"
-    dev = torch.device("cuda", 0)
+    # BASELINE configs[4] is a single-GPU configuration.  `--gpus N` (N ranks, one per GPU) runs it data-parallel the way §5
+    # shards every path: each rank walks its own shard of the seed order over a replica of the graph and of the feature
+    # tables (0.6 GB), no data-path collective; the timed region is bracketed by barriers, the time is the MAX over ranks,
+    # the edges the SUM.  The per-stage probe, the training variant and the CPU baseline stay with N = 1 (rank 0's line).
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, "launch through bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    local_rank = 0 if getattr(args, "share_gpu", False) else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world,
+                                **({"device_id": dev} if args.dist_backend == "nccl" else {}))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
     graphs, num_nodes = build_mag_like(dev)
     etypes = sorted(graphs)
     ntypes = sorted(num_nodes)
@@ -259,7 +279,7 @@ def main(args):
     groups = args.steps * gps
     warm = max(args.warmup * gps, 2)
     n_probe = min(groups, 6)
-    gs_ = torch.Generator(device=dev).manual_seed(7)
+    gs_ = torch.Generator(device=dev).manual_seed(7 + 1000003 * rank)     # every rank its own shard of seeds
     need = (groups + warm + n_probe + 1) * G * B        # (+ 1: the probe pass's own untimed first group)
     reps = -(-need // num_nodes["paper"])
     order = torch.cat([torch.randperm(num_nodes["paper"], generator=gs_, device=dev) for _ in range(reps)])
@@ -272,14 +292,29 @@ def main(args):
     with torch.no_grad():
         for grp in loader.call_groups():
             if n == warm:
-                torch.cuda.synchronize()
+                barrier()
                 t0, edges = time.perf_counter(), 0
             forward_group(model, grp)
             edges += grp.num_edges
             n += 1
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
     assert n == groups + warm
+    per_rank_value = [edges / dt]
+    if dist is not None:
+        red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+        t_dt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        t_ed = torch.tensor([float(edges)], dtype=torch.float64, device=red_dev)
+        t_all = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([edges / dt], dtype=torch.float64, device=red_dev))
+        dist.all_reduce(t_dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_ed, op=dist.ReduceOp.SUM)
+        dt, edges, per_rank_value = float(t_dt), float(t_ed), [float(v) for v in t_all]
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return
+        args.no_variants, args.no_cpu_baseline = True, True
 
     # per-stage HIP-event pass (outside the timed region): the layers' stages through nn.set_stage_hook, one call group at a
     # time; the walk alone (the loader's own walk object) between events on the main stream
@@ -392,7 +427,7 @@ def main(args):
                            etypes, ntypes, args.cpu_budget)
     out = {"metric": "sampled-edges/sec (hetero 2-hop sample+renumber + feature gather + 2-layer HeteroConv(GATConv 4x64) fwd), "
                      "ogbn-mag-like fan-out [25, 10] x 6 edge types",
-           "value": edges / dt, "unit": "sampled-edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "value": edges / dt, "unit": "sampled-edges/s", "n_gpus": world, "per_rank_value": per_rank_value, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int64 ids + f32 features (edge softmax + aggregation: f32 HIP kernels; GATConv per-head lin: bf16x3-split MFMA, "
                     "f32 accumulate — the one-kernel relation / wgamd_gat_transform_heads_bf16x3)",
@@ -401,9 +436,9 @@ def main(args):
                                   "6 edge types ~35.8 M edges, feat fp32 [n_t, 128] per type, batch 1024 paper seeds, 2-hop fan-out "
                                   "[25,10] per edge type, 2 x HeteroConv{GATConv(., 64, heads=4)} sum + ReLU, step = %d call groups "
                                   "of %d mini-batches" % (gps, G),
-                      "parallelism": "1 GPU"},
+                      "parallelism": "1 GPU" if world == 1 else "dp%d (seeds sharded, graph + tables replicated, no data-path collective)" % world},
            "call_group": G, "batches_per_step": G * gps, "timed_region_ms": round(dt * 1e3, 2), "timed_call_groups": groups,
-           "ms_per_batch": dt / (groups * G) * 1e3, "edges_per_batch": edges / (groups * G),
+           "ms_per_batch": dt / (groups * G) * 1e3, "edges_per_batch": edges / (groups * G * world),
            "nodes_per_call_group": nn_sizes, "stage_ms_per_call_group": {k: round(v, 4) for k, v in stage_ms.items()},
            "gat_launches": [{"edge_type": "%s-%s-%s" % et, "hop": h + 1, "rows": n_f, "edges": n_e, "src_row_floats": f_}
                             for et, h, n_f, n_e, f_ in (launches or [])],

@@ -135,3 +135,30 @@ def test_a_failing_selftest_is_loud(hiplib):
     assert p.returncode == 1, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     assert d["value"] is None and "selftest" in d["placement_errors"]["partitioned"]
+
+
+def _run_bare(gpus, extra, env=None):
+    """`python bench.py --gpus N ...` with NO launcher and no WORLD_SIZE: the shape of the driver's N = 1 command."""
+    envd = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    envd.update(env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1"] + extra
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=envd)
+
+
+def test_bare_gpus_2_launches_two_ranks(hiplib):
+    """`--gpus` was parsed and never read, so a bare `python bench.py --gpus 8` printed a one-rank line.
+    Now the bare command re-executes itself under torch.distributed.run with N ranks."""
+    p = _run_bare(2, ["--nodes", "200000", "--edges", "3000000", "--call-group", "16", "--groups-per-step", "2", "--no-variants",
+                      "--dist-backend", "gloo", "--share-gpu"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_value"]) == 2 and "dp2" in d["config"]["parallelism"]
+
+
+def test_world_size_disagreeing_with_gpus_fails_loudly(hiplib):
+    p = _run_bare(4, ["--no-variants", "--dist-backend", "gloo", "--share-gpu"],
+                  env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
