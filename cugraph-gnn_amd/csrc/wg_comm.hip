@@ -642,7 +642,10 @@ __global__ void mapped_offsets_kernel(const mapped_view* __restrict__ view, cons
       if (s_off[mid] <= id) lo = mid;
       else hi = mid;
     }
-    out[i] = ok ? (s_base[lo] - base0) + (id - s_off[lo]) * entry_bytes + col0_bytes : (int64_t)-1;
+    // an id outside the table (the -1 slack of a padded unique list) resolves to row 0 of the lowest partition: the readers of
+    // these offsets (sage_layer_mfma_kernel, compose_self_kernel) dereference base + offset unconditionally with 16-byte
+    // loads, so the answer must be an aligned, mapped address; no edge references such a row
+    out[i] = ok ? (s_base[lo] - base0) + (id - s_off[lo]) * entry_bytes + col0_bytes : col0_bytes;
   }
 }
 }  // namespace
@@ -1139,8 +1142,8 @@ wholememory_error_code_t wgamd_get_peer_pointers(void** pointers, wholememory_ha
 /* Row addresses of a peer-mapped (CHUNKED / CONTINUOUS) 2-D table for a kernel that reads the rows ITSELF — the one-kernel
  * SAGE layer with the feature fetch folded in, now over xGMI (the reference's mapped gather reads the partitions through
  * global references the same way: wholememory_ops/functions/gather_scatter_func.cuh:242-505, gather_op_impl_mapped.cu):
- * offsets[i] = byte distance of row ids[i] from *base (the lowest partition base of this process's mapping); -1 for an id
- * that is negative or past the last row.  A single-rank handle answers with its own partition.  Not collective. */
+ * offsets[i] = byte distance of row ids[i] from *base (the lowest partition base of this process's mapping); an id that is
+ * negative or past the last row gets the offset of the first row of the lowest partition (a readable, aligned address).  A single-rank handle answers with its own partition.  Not collective. */
 wholememory_error_code_t wgamd_mapped_row_offsets(wholememory_tensor_t table, const void* ids, wholememory_dtype_t ids_dtype,
                                                   int64_t n, int64_t* offsets, void** base, void* stream)
 {
@@ -1157,7 +1160,6 @@ wholememory_error_code_t wgamd_mapped_row_offsets(wholememory_tensor_t table, co
     WG_EXPECTS((int64_t)h->granularity == entry_bytes, "tensor row stride != handle granularity");
     const int64_t row0 = d->storage_offset / stride, col0 = d->storage_offset % stride;
     auto st = static_cast<hipStream_t>(stream);
-    mapped_view single{};
     const mapped_view* d_view = h->d_view;
     const char* base0         = nullptr;
     if (d_view == nullptr) {
@@ -1176,7 +1178,6 @@ wholememory_error_code_t wgamd_mapped_row_offsets(wholememory_tensor_t table, co
     else
       mapped_offsets_kernel<int64_t><<<grid, 256, 0, st>>>(d_view, base0, row0, entry_bytes, col0 * tes, static_cast<const int64_t*>(ids), n, offsets);
     WG_HIP_CHECK(hipGetLastError());
-    (void)single;
   });
 }
 

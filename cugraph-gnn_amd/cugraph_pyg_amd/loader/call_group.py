@@ -274,6 +274,12 @@ class HeteroCallGroup:
             for lvl in self._cseg:
                 for v in lvl.values():
                     v.record_stream(main)
+            # every other walk-stream tensor the consumer reads (batch_ptr = calls_seed_seg, the per-call edge counts)
+            if torch.is_tensor(self._rec.get("calls_seed_seg")):
+                self._rec["calls_seed_seg"].record_stream(main)
+            for c in self._rec["calls"]:
+                if c is not None and torch.is_tensor(c.get("counts")):
+                    c["counts"].record_stream(main)
         self._ready = True
 
     # ---- nodes -----------------------------------------------------------------------------------------------------

@@ -292,9 +292,13 @@ class DistEmbedding(DistTensor):
         if self._embedding is None:
             return super().__setitem__(idx, val)
         idx = self._idx(idx)
-        self._embedding.get_embedding_tensor().scatter(val.to(device=idx.device, dtype=self.dtype).contiguous(), idx)
         if self._embedding.wmb_cache_policy is not None:
-            self._embedding.drop_all_cache()                   # resident lines must not shadow the rows just written
+            # BEFORE the scatter: dropping a read-write cache writes its modified lines back (wg_embedding.hip,
+            # wholememory_embedding_drop_all_cache), so a line left dirty by an optimizer step would land on top of the rows
+            # written here if the order were the other way round.  After the drop nothing is resident, nothing is dirty, and
+            # no line can shadow the new rows.
+            self._embedding.drop_all_cache()
+        self._embedding.get_embedding_tensor().scatter(val.to(device=idx.device, dtype=self.dtype).contiguous(), idx)
 
     def _idx(self, idx):
         if self._embedding is None:

@@ -907,6 +907,12 @@ class _SageLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.aggs is None:
+            # the kept aggregates (the largest tensors of the layer) are released by the first backward pass whatever
+            # retain_graph says — they are not autograd-saved tensors, so autograd's own message would not appear
+            raise RuntimeError("wholegraph_amd.nn.SAGEConv: backward through this layer a second time — its kept aggregates were "
+                               "released by the first backward pass (retain_graph=True is not supported by the one-kernel "
+                               "layer; run the forward again, or sum the losses before calling backward)")
         src, w_l, w_r, out = ctx.saved_tensors if len(ctx.saved_tensors) == 4 else (ctx.src_obj,) + tuple(ctx.saved_tensors)
         graph, ids, relu, mean = ctx.graph, ctx.ids, ctx.relu, ctx.mean
         N, F_ = w_l.shape

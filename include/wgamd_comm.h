@@ -121,7 +121,8 @@ wholememory_error_code_t wgamd_get_peer_pointers(void** pointers, wholememory_ha
 /* Row addresses of a peer-mapped (CHUNKED / CONTINUOUS, more than one rank) 2-D table, for kernels that read the rows
  * themselves (the one-kernel SAGE layer with the fetch folded in; src_ids_dtype = WGAMD_IDS_BYTE_OFFSETS, wgamd_ext.h):
  * offsets[i] = byte distance of row ids[i] (INT | INT64) from *base, the lowest partition base of this process's mapping;
- * -1 for a negative id or one past the last row.  Not collective.  WHOLEMEMORY_LOGIC_ERROR for a handle that is not
+ * a negative id or one past the last row gets the offset of the first row of that lowest partition (the readers dereference
+ * base + offset unconditionally: the answer is always a mapped, 16-byte-aligned address).  Not collective.  WHOLEMEMORY_LOGIC_ERROR for a handle that is not
  * peer-mapped (DISTRIBUTED rows are not addressable; a single-partition handle is read through its local tensor). */
 wholememory_error_code_t wgamd_mapped_row_offsets(wholememory_tensor_t table, const void* ids, wholememory_dtype_t ids_dtype,
                                                   int64_t n, int64_t* offsets, void** base, void* stream);

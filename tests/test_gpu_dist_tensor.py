@@ -117,6 +117,37 @@ def test_dist_embedding_forwards_its_cache_policy(device, access):
     wg.destroy_wholememory_cache_policy(pol)
 
 
+def test_dist_embedding_setitem_with_dirty_rw_cache_lines():
+    """with a READWRITE policy, rows left DIRTY in the cache by an optimizer step used to be written
+    back over the rows a later ``emb[rows] = v`` had just scattered (drop_all_cache flushes before it empties).  The write
+    must win for the written rows, and the optimizer's update must survive for every other row."""
+    import wholegraph_amd as wg
+    from cugraph_pyg_amd.tensor import DistEmbedding
+    comm = wg.get_global_communicator()
+    pol = wg.create_wholememory_cache_policy(comm, memory_type="distributed", memory_location="cuda", access_type="readwrite", ratio=0.5)
+    n, dim = 4001, 32
+    table = torch.randn((n, dim))
+    emb = DistEmbedding.from_tensor(table, device="cuda", name="emb_rw", cache_policy=pol)
+    opt = wg.create_wholememory_optimizer(emb._embedding, "sgd", {})
+    touched = torch.arange(0, 600, dtype=torch.int64).cuda()
+    grads = torch.ones((600, dim), device="cuda")
+    emb._embedding.gather(touched)                        # lines become resident
+    emb._embedding.add_gradients(touched, grads)
+    emb._embedding.need_apply = True
+    opt.step(0.5)                                         # rows 0..599 are now modified IN THE CACHE (dirty lines)
+    want = table.clone()
+    want[:600] -= 0.5
+    rows = torch.tensor([5, 17, 599, 3000])
+    emb[rows] = torch.full((4, dim), 9.0)
+    want[rows] = 9.0
+    torch.testing.assert_close(emb[torch.arange(n)].cpu(), want, rtol=1e-6, atol=1e-6)
+    emb._embedding.writeback_all_cache()
+    torch.testing.assert_close(emb.get_local_tensor().cpu(), want, rtol=1e-6, atol=1e-6)
+    wg.destroy_wholememory_optimizer(opt)
+    wg.destroy_embedding(emb._embedding)
+    wg.destroy_wholememory_cache_policy(pol)
+
+
 def test_pinned_host_rows_are_fenced_before_the_host_sees_them():
     """A scatter into pinned-host rows runs on the current stream; ``get_local_tensor`` / ``load_from_*`` wait for it
     (a host read straight after ``__setitem__`` used to be able to see the rows from before it)."""
