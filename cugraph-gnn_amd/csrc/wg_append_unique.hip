@@ -249,7 +249,7 @@ void append_unique_impl(const KeyT* targets, int T, const KeyT* neighbors, int E
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // output size
 
   KeyT* unique_out = static_cast<KeyT*>(output_alloc(env, unique_ctx, (int64_t)T + U, key_traits<KeyT>::dt));
-  append_unique_emit_enqueue(targets, Tc, k64, neighbors, Ec, k64, one, minpos, slot_of, rank, unique_out, map_out, nullptr,
+  append_unique_emit_enqueue(targets, Tc, k64, neighbors, Ec, k64, one, minpos, slot_of, rank, slots, unique_out, map_out, nullptr,
                              stream);
   WG_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released on return
 }
@@ -552,19 +552,18 @@ bucket_sort_kernel(const TgtT* __restrict__ targets, dev_count T_, const NbrT* _
 template <bool ID32>
 __global__ void __launch_bounds__(kLdsThreads)
 renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay, int wg_per_batch, sort_scratch sc,
-                    int* __restrict__ slot_of, int* __restrict__ flag)
+                    int* __restrict__ slot_of, int* __restrict__ tile_sums, int n_tile_sums)
 {
   __shared__ unsigned long long tbl[kLdsSlots];
   __shared__ unsigned long long st_lo[kLdsStack], st_span[kLdsStack];
   __shared__ int st_n, overfull;
   __shared__ int seg_base[kLdsChunks], seg_pre[kLdsChunks + 1];
   const unsigned long long kEmpty = ~0ull;
-  const int T = T_.get(), E = E_.get();
+  const int T = T_.get();
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
-    // the scan reads whole tiles: zero-fill the slack of the tile that holds the live end
-    const int end = min(E_.host, (E / kScanTile + 1) * kScanTile);
-    for (int e = E + tid; e < end; e += kLdsThreads) flag[e] = 0;
+    // first_bits_kernel (the next launch) adds its popcounts into these with atomics: cleared here, one launch earlier
+    for (int i = tid; i < n_tile_sums; i += kLdsThreads) tile_sums[i] = 0;
   }
   int b, j;
   if (!batch_of_block(bv.G, wg_per_batch, b, j)) return;
@@ -613,6 +612,7 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
     // on memory latency); a range that fits one trip — nearly all — keeps its pairs in registers for both passes
     const bool one_trip = n_pairs <= kLdsThreads * kLdsUnroll;
     unsigned long long w[kLdsUnroll];
+    int memo[kLdsUnroll];   // one-trip ranges: the slot each pair's id ended up in (insert pass -> look-up pass)
     if (one_trip) {
 #pragma unroll
       for (int k = 0; k < kLdsUnroll; k++) w[k] = pair_at(k * kLdsThreads + tid);
@@ -643,6 +643,7 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
           const unsigned long long word = w[k];
           const unsigned long long id   = word >> lay.pos_bits;
           const uint32_t h              = hash_id<ID32>((int64_t)id);
+          memo[k]                       = -1;
           if (word != kEmpty && (unsigned long long)h - lo < span && !*overfull_now) {
             uint32_t s = __umulhi(h * 0x9E3779B1u, (uint32_t)kLdsSlots);
             int probes = 0;
@@ -660,6 +661,7 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
                 break;
               }
             }
+            memo[k] = (int)s;   // the slot of this id (meaningless when the range overfilled: it is redone)
           }
         }
       }
@@ -680,6 +682,16 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
         continue;
       }
       // ---- first position of every neighbour of the range ----------------------------------------------------------
+      if (one_trip) {
+        // the insert pass left every pair's slot in a register: one straight LDS read per neighbour, no hash, no probe loop
+#pragma unroll
+        for (int k = 0; k < kLdsUnroll; k++) {
+          const int p = (int)(w[k] & pos_mask);
+          if (memo[k] >= 0 && p >= T) slot_of[p] = (int)(tbl[memo[k]] & pos_mask);
+        }
+        __syncthreads();
+        continue;
+      }
       for (int i0 = 0; i0 < n_pairs; i0 += kLdsThreads * kLdsUnroll) {
         if (!one_trip) {
 #pragma unroll
@@ -699,9 +711,7 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
               s   = s + 1 == (uint32_t)kLdsSlots ? 0u : s + 1;
               cur = tbl[s];
             }
-            const int first = (int)(cur & pos_mask);
-            slot_of[p]      = first;
-            flag[p - T]     = first == p ? 1 : 0;
+            slot_of[p] = (int)(cur & pos_mask);
           }
         }
       }
@@ -709,6 +719,92 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
     }
   }
 }
+
+// ---- first-appearance ranks --------------------------------------------------------------------------------------------
+// rank(q) = number of first occurrences among the neighbours before position q (q <= E).  Device-wide table paths keep it as
+// a plain int array (flags -> exclusive scan).  The LDS path keeps ONE BIT per neighbour and a running count per 64-bit word:
+// first_bits_kernel derives the bits from slot_of (neighbour e is a first occurrence iff slot_of[T + e] == T + e — the table
+// kernel no longer writes a flag array), the scan runs over E / 64 word counts instead of E flags, and the emit kernel's
+// random rank look-up lands in 12 bytes per 64 neighbours (2.4 MB for the 12.6 M neighbours of a products hop 2: it stays in
+// L2) instead of a 4-byte entry per neighbour.  Hop 2 of the products call group: flag write 50 MB, scan 150 MB and the rank
+// gather of the emit kernel are gone.
+struct rank_array {
+  const int* rank;
+  __device__ __forceinline__ int at(int q) const { return rank[q]; }
+  // slack flags are 0, so the grand total sits at the capacity end (where the scan publishes it)
+  __device__ __forceinline__ int total(int /*e_live*/, int e_host) const { return rank[e_host]; }
+};
+struct rank_bits {
+  const int* prefix;                  // [E.host / 64 + 2]: exclusive running count per word (+ the grand total behind the scan)
+  const unsigned long long* words;    // [E.host / 64 + 1]: bit (e & 63) of word e >> 6 = neighbour e is a first occurrence
+  __device__ __forceinline__ int at(int q) const
+  {
+    const int w = q >> 6;
+    return prefix[w] + __popcll(words[w] & ((1ull << (q & 63)) - 1ull));
+  }
+  // only the live words are written: the total is the rank of the live end
+  __device__ __forceinline__ int total(int e_live, int /*e_host*/) const { return at(e_live); }
+};
+// where the three pieces sit inside the hop's `rank` buffer of E.host + 1 ints
+struct rank_bits_layout {
+  int nw;              // words for the capacity: E.host / 64 + 1 (position E itself is looked up: the total)
+  int words_at;        // int offset of the words (16-byte aligned)
+  int live_at;         // int offset of one int: the number of LIVE words (device-side bound of the scan)
+  __host__ __device__ explicit rank_bits_layout(int e_host)
+  {
+    nw       = e_host / 64 + 1;
+    words_at = (nw + 1 + 3) / 4 * 4;
+    live_at  = words_at + 2 * nw;
+  }
+  __host__ __device__ int ints() const { return live_at + 1; }
+};
+constexpr int kBitsWordsPerBlock = 64;   // 4,096 neighbours per block iteration: one atomic per iteration into the tile sums
+
+__global__ void __launch_bounds__(256)
+first_bits_kernel(const int* __restrict__ slot_of, dev_count T_, dev_count E_, int* __restrict__ rank_buf, int* __restrict__ tile_sums)
+{
+  __shared__ int wave_cnt[4];
+  const int T = T_.get(), E = E_.get();
+  const rank_bits_layout lay(E_.host);
+  int* cnt                  = rank_buf;
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(rank_buf + lay.words_at);
+  const int nw_live         = E / 64 + 1;
+  // the scan reads whole tiles of word counts: the slack of the tile that holds the live end is zero-filled
+  const int nw_end = min(lay.nw, (nw_live / kScanTile + 1) * kScanTile);
+  if (blockIdx.x == 0 && threadIdx.x == 0) rank_buf[lay.live_at] = nw_live;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w0 = blockIdx.x * kBitsWordsPerBlock; w0 < nw_end; w0 += gridDim.x * kBitsWordsPerBlock) {
+    // wave v takes words w0 + v, w0 + v + 4, ...: a block iteration reads 16 KB of slot_of, all sixteen loads of a lane in
+    // flight before the first ballot
+    bool f[kBitsWordsPerBlock / 4];
+#pragma unroll
+    for (int k = 0; k < kBitsWordsPerBlock / 4; k++) {
+      const int e = (w0 + wave + 4 * k) * 64 + lane;
+      f[k]        = e < E && slot_of[T + e] == T + e;
+    }
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < kBitsWordsPerBlock / 4; k++) {
+      const int w                    = w0 + wave + 4 * k;
+      const unsigned long long word  = __ballot(f[k]);
+      const int c                    = __popcll(word);
+      total += c;
+      if (lane == 0 && w < nw_end) {
+        words[w] = word;
+        cnt[w]   = c;
+      }
+    }
+    // all words of a block iteration lie in ONE scan tile (kScanTile is a multiple of kBitsWordsPerBlock)
+    if (lane == 0) wave_cnt[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      if (t) atomicAdd(&tile_sums[w0 / kScanTile], t);
+    }
+    __syncthreads();
+  }
+}
+static_assert(kScanTile % kBitsWordsPerBlock == 0, "a block iteration of first_bits_kernel must stay inside one scan tile");
 
 // Emit for call groups, one block per (batch, chunk): everything that depends on the batch only (its row shift, where
 // its new vertices start, its local-id origin) is read once per block instead of chased through four dependent loads per
@@ -718,23 +814,23 @@ renumber_lds_kernel(dev_count T_, dev_count E_, batch_view bv, packed_layout lay
 constexpr int kEmitChunks = 16;
 constexpr int kEmitUnroll = 4;
 
-template <typename TgtT, typename NbrT>
+template <typename TgtT, typename NbrT, typename RankT>
 __global__ void __launch_bounds__(256)
 renumber_emit_batched_kernel(const TgtT* __restrict__ targets, const NbrT* __restrict__ neighbors,
-                             const int* __restrict__ slot_of, const int* __restrict__ rank, dev_count T_, dev_count E_,
+                             const int* __restrict__ slot_of, const RankT rank, dev_count T_, dev_count E_,
                              batch_view bv, TgtT* __restrict__ unique_out, int* __restrict__ map_out,
                              int* __restrict__ counts_out)
 {
   using KeyT = TgtT;
   const int T = T_.get(), E = E_.get();
-  const int U = rank[E_.host];  // slack flags are 0, so the grand total sits at the capacity end
+  const int U = rank.total(E, E_.host);
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
   if (gtid == 0 && counts_out) {
     counts_out[0] = E;
     counts_out[1] = T + U;
   }
   if (bv.unique_seg && gtid <= bv.G) {
-    const int new_before = rank[bv.edge_offsets[bv.sseg()[gtid]]];   // new vertices of batches < gtid
+    const int new_before = rank.at(bv.edge_offsets[bv.sseg()[gtid]]);   // new vertices of batches < gtid
     bv.unique_seg[gtid] = bv.target_seg[gtid] + new_before;
     if (bv.frontier_seg_out) bv.frontier_seg_out[gtid] = new_before;
     if (bv.frontier_local0_out && gtid < bv.G) bv.frontier_local0_out[gtid] = bv.target_seg[gtid + 1] - bv.target_seg[gtid];
@@ -750,7 +846,7 @@ renumber_emit_batched_kernel(const TgtT* __restrict__ targets, const NbrT* __res
   const int t0 = bv.target_seg[b], nT = bv.target_seg[b + 1] - t0;
   const int s0 = bv.sseg()[b];
   const int e0 = bv.edge_offsets[s0], nE = bv.edge_offsets[bv.sseg()[b + 1]] - e0;
-  const int shift    = rank[e0];          // rows contributed by the new vertices of earlier batches
+  const int shift    = rank.at(e0);          // rows contributed by the new vertices of earlier batches
   const int tail_row = t0 + nT;           // first row after my batch's targets (before the shift... see below)
   const int local0   = bv.sample_local0 ? bv.sample_local0[b] : 0;
   {
@@ -769,7 +865,7 @@ renumber_emit_batched_kernel(const TgtT* __restrict__ targets, const NbrT* __res
 #pragma unroll
     for (int k = 0; k < kEmitUnroll; k++) first[k] = slot_of[T + e0 + min(i0 + k * 256, end - 1)];
 #pragma unroll
-    for (int k = 0; k < kEmitUnroll; k++) row[k] = first[k] < T ? first[k] + shift : tail_row + rank[first[k] - T];
+    for (int k = 0; k < kEmitUnroll; k++) row[k] = first[k] < T ? first[k] + shift : tail_row + rank.at(first[k] - T);
 #pragma unroll
     for (int k = 0; k < kEmitUnroll; k++) {
       const int i = i0 + k * 256;
@@ -812,6 +908,18 @@ inline bool lds_scratch_fits(int64_t capacity_positions, int G, int64_t slots)
   return 8 * capacity_positions + 256 <= 8 * slots && lds_range_records(capacity_positions, G) * kLdsChunks <= slots;
 }
 
+// does a call take the per-batch LDS tables?  (prepare and emit must agree: the LDS path leaves the ranks as bits)
+inline bool lds_path_taken(dev_count T, dev_count E, bool nbr64, const batch_view& bv, int64_t slots, packed_layout& lay)
+{
+  static const bool no_lds = getenv("WGAMD_RENUMBER_NO_LDS") != nullptr;
+  // 32-bit neighbours promise ids below 2^31 whatever bound the caller stated
+  const int64_t bound = bv.id_bound > 0 ? bv.id_bound : (nbr64 ? 0 : ((int64_t)1 << 31));
+  const bool batched  = bv.target_batch != nullptr;
+  return batched && !no_lds && bv.target_seg && bv.edge_offsets && bv.G > 1 && E.host >= 64 &&
+         rank_bits_layout(E.host).ints() <= E.host + 1 &&
+         packed_layout_for((int64_t)T.host + E.host, 1, bound, lay) && lds_scratch_fits((int64_t)T.host + E.host, bv.G, slots);
+}
+
 template <typename TgtT, typename NbrT>
 void prepare_lds_t(const TgtT* targets, dev_count T, const NbrT* neighbors, dev_count E, batch_view bv, packed_layout lay,
                    void* keys, int* minpos, int* slot_of, int* rank, int* scan_tmp, hipStream_t stream)
@@ -825,11 +933,16 @@ void prepare_lds_t(const TgtT* targets, dev_count T, const NbrT* neighbors, dev_
     bucket_sort_kernel<TgtT, NbrT><<<batch_grid(bv.G, kLdsChunks), kBucketThreads, 0, stream>>>(targets, T, neighbors, bv, lay, sc);
     const int64_t per_batch = (cap + bv.G - 1) / bv.G;
     const int wg_per_batch  = (int)std::max<int64_t>(1, std::min<int64_t>((per_batch + kLdsKeysTarget - 1) / kLdsKeysTarget, 32));
+    const rank_bits_layout rl(E.host);
+    const int n_tiles = (int)((rl.nw + kScanTile - 1) / kScanTile);
     renumber_lds_kernel<sizeof(NbrT) == 4><<<batch_grid(bv.G, wg_per_batch), kLdsThreads, 0, stream>>>(T, E, bv, lay, wg_per_batch, sc,
-                                                                                                     slot_of, rank);
+                                                                                                     slot_of, scan_tmp, n_tiles);
+    // first occurrences as bits + per-word counts (+ their per-tile sums), then the counts' running sums in place
+    const int bits_grid = (int)std::min<int64_t>(((int64_t)rl.nw + kBitsWordsPerBlock - 1) / kBitsWordsPerBlock, 256 * 8);
+    first_bits_kernel<<<bits_grid, 256, 0, stream>>>(slot_of, T, E, rank, scan_tmp);
     WG_HIP_CHECK(hipGetLastError());
+    exclusive_scan_i32_presummed(rank, rank, rl.nw, scan_tmp, stream, rank + rl.live_at);
   }
-  exclusive_scan_i32(rank, rank, E.host, scan_tmp, stream, E.dev);
 }
 
 template <typename TgtT, typename NbrT, typename TableKeyT>
@@ -872,11 +985,8 @@ void append_unique_prepare_enqueue(const void* targets, dev_count T, bool tgt64,
 {
   const bool batched = bv.target_batch != nullptr;
   packed_layout lay{};
-  static const bool no_lds = getenv("WGAMD_RENUMBER_NO_LDS") != nullptr;
-  // 32-bit neighbours promise ids below 2^31 whatever bound the caller stated
   const int64_t bound = bv.id_bound > 0 ? bv.id_bound : (nbr64 ? 0 : ((int64_t)1 << 31));
-  if (batched && !no_lds && bv.target_seg && bv.edge_offsets && bv.G > 1 &&
-      packed_layout_for((int64_t)T.host + E.host, 1, bound, lay) && lds_scratch_fits((int64_t)T.host + E.host, bv.G, slots)) {
+  if (lds_path_taken(T, E, nbr64, bv, slots, lay)) {
     with_id_types(tgt64, nbr64, targets, neighbors, [&](auto* t, auto* n) {
       prepare_lds_t(t, T, n, E, bv, lay, keys, minpos, slot_of, rank, scan_tmp, stream);
     });
@@ -901,9 +1011,11 @@ void append_unique_prepare_enqueue(const void* targets, dev_count T, bool tgt64,
 }
 
 void append_unique_emit_enqueue(const void* targets, dev_count T, bool tgt64, const void* neighbors, dev_count E, bool nbr64,
-                                batch_view bv, const int* minpos, const int* slot_of, const int* rank,
+                                batch_view bv, const int* minpos, const int* slot_of, const int* rank, int64_t slots,
                                 void* unique_out, int* map_out, int* counts_out, hipStream_t stream)
 {
+  packed_layout lay_unused{};
+  const bool bits = lds_path_taken(T, E, nbr64, bv, slots, lay_unused);
   const int P    = T.host + E.host;
   const int grid = ceil_div(P > bv.G + 1 ? P : bv.G + 1, 256);  // thread 0 publishes the counts, threads <= G the segments
   const bool per_batch = bv.target_batch != nullptr && bv.target_seg && bv.edge_offsets && bv.G > 1;
@@ -911,9 +1023,14 @@ void append_unique_emit_enqueue(const void* targets, dev_count T, bool tgt64, co
   with_id_types(tgt64, nbr64, targets, neighbors, [&](auto* t, auto* n) {
     using TgtT = std::remove_cv_t<std::remove_pointer_t<decltype(t)>>;
     using NbrT = std::remove_cv_t<std::remove_pointer_t<decltype(n)>>;
-    if (per_batch)
-      renumber_emit_batched_kernel<TgtT, NbrT><<<bgrid, 256, 0, stream>>>(t, n, slot_of, rank, T, E, bv, static_cast<TgtT*>(unique_out),
-                                                                         map_out, counts_out);
+    if (per_batch && bits) {
+      const rank_bits_layout rl(E.host);
+      const rank_bits rb{rank, reinterpret_cast<const unsigned long long*>(rank + rl.words_at)};
+      renumber_emit_batched_kernel<TgtT, NbrT, rank_bits><<<bgrid, 256, 0, stream>>>(t, n, slot_of, rb, T, E, bv,
+                                                                                    static_cast<TgtT*>(unique_out), map_out, counts_out);
+    } else if (per_batch)
+      renumber_emit_batched_kernel<TgtT, NbrT, rank_array><<<bgrid, 256, 0, stream>>>(t, n, slot_of, rank_array{rank}, T, E, bv,
+                                                                                     static_cast<TgtT*>(unique_out), map_out, counts_out);
     else
       renumber_emit_kernel<TgtT, NbrT><<<grid, 256, 0, stream>>>(t, n, minpos, slot_of, rank, T, E, bv, static_cast<TgtT*>(unique_out),
                                                                 map_out, counts_out);

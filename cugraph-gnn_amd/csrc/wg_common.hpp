@@ -275,6 +275,9 @@ int64_t scan_tmp_ints(int64_t n);
 constexpr int kScanTile = 2048;
 void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_t stream,
                         const int* n_live_dev = nullptr);
+// the same with the per-tile sums (tile t = elements [t kScanTile, (t + 1) kScanTile)) already in `sums` — one launch
+void exclusive_scan_i32_presummed(const int* in, int* out, int64_t n, const int* sums, hipStream_t stream,
+                                  const int* n_live_dev = nullptr);
 // State of one single-pass (chained) scan launch — see wg_scan_chain.hpp.  The buffers are library-owned, one set per
 // (device, stream); `scan_chain_acquire` hands out the next epoch of that set (host side, no device work after the first
 // call on a stream).  At most kScanChainTiles tiles per launch.
@@ -289,10 +292,21 @@ scan_chain scan_chain_acquire(hipStream_t stream);
 
 // ---- building blocks shared by the ABI ops and the no-sync walk (wg_fused.hip) -----------------
 // uniform sampling of `n` targets (n.host = capacity): cnt/offsets have n.host+1 entries
+// `loc` (nullable; needs row_start / row_deg and 0 < M <= 32): walk the seeds grouped by vertex-id range instead of in list
+// order (wg_sample.hip, loc_rec) — same result, the picks of a vertex that occurs many times in the list share cache lines.
+// Scratch: sample_locality_hist_ints() ints and 32 bytes per seed of capacity.
+struct sample_locality {
+  int* hist;     // [sample_locality_hist_ints()]
+  void* recs;    // [n.host] 32-byte records, 32-byte aligned
+  int shift;     // bucket of a vertex id = id >> shift (clamped): sample_locality_shift(id_bound)
+};
+int64_t sample_locality_hist_ints();
+int sample_locality_shift(int64_t id_bound);
 void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
                             dev_count n, int M, rng_plan random_seed, const int* offsets, void* dst, int* src_lid,
                             int64_t* edge_gid, hipStream_t stream,
-                            const int64_t* row_start = nullptr, const int* row_deg = nullptr);
+                            const int64_t* row_start = nullptr, const int* row_deg = nullptr,
+                            const sample_locality* loc = nullptr);
 // row_start / row_deg (nullable): first CSR slot and degree of every live seed, written next to the counts — the sampling
 // kernel then reads them by seed index (coalesced) instead of chasing seeds -> row_ptr again
 void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds64, dev_count n, int M, int* cnt,
@@ -361,7 +375,7 @@ void append_unique_prepare_enqueue(const void* targets, dev_count T, bool tgt64,
                                    batch_view bv, void* keys, int* minpos, int64_t slots, int* slot_of, int* rank,
                                    int* scan_tmp, hipStream_t stream);
 void append_unique_emit_enqueue(const void* targets, dev_count T, bool tgt64, const void* neighbors, dev_count E, bool nbr64,
-                                batch_view bv, const int* minpos, const int* slot_of, const int* rank,
+                                batch_view bv, const int* minpos, const int* slot_of, const int* rank, int64_t slots,
                                 void* unique_out, int* map_out, int* counts_out /*nullable: {E, T+U}*/,
                                 hipStream_t stream);
 

@@ -9,6 +9,8 @@
 // device memory, and a call group (the idea of cugraph_pyg's `local_seeds_per_call`,
 // python/cugraph-pyg/cugraph_pyg/sampler/distributed_sampler.py:279-343) gives every launch G x the
 // work while each mini-batch keeps exactly the result a single-batch call would produce.
+#include <atomic>
+
 #include "wg_common.hpp"
 #include "wgamd_ext.h"
 
@@ -18,7 +20,7 @@ namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct hop_workspace {
-  size_t cnt, scan_tmp, nbr, keys, minpos, slot_of, rank, big_list, slab, row_start, row_deg, total;
+  size_t cnt, scan_tmp, nbr, keys, minpos, slot_of, rank, big_list, slab, row_start, row_deg, loc_hist, total;
   int64_t slots, slab_len;
 };
 
@@ -43,6 +45,7 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
   w.rank         = take(sizeof(int) * (size_t)(edge_cap + 1));
   w.row_start    = take(sizeof(int64_t) * (size_t)target_cap);   // first CSR slot / degree of every sampled row (count -> sample)
   w.row_deg      = take(sizeof(int) * (size_t)target_cap);
+  w.loc_hist     = take(sizeof(int) * (size_t)sample_locality_hist_ints());   // vertex-grouped sampling order (2 MB, any capacity)
   if (max_row_len > 0) {
     w.slab_len = max_row_len > kWeightedLdsKeys ? max_row_len : 1;
     w.big_list = take(sizeof(int) * (size_t)weighted_list_ints(target_cap));
@@ -50,6 +53,17 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
   }
   w.total        = off;
   return w;
+}
+
+// smallest frontier capacity whose hop walks the frontier grouped by vertex range (WGAMD_SAMPLE_LOCALITY: 0 = never, n = from
+// capacity n; wgamd_set_sample_locality_min at run time)
+inline std::atomic<int64_t>& sample_locality_min()
+{
+  static std::atomic<int64_t> v{[] {
+    const char* e = getenv("WGAMD_SAMPLE_LOCALITY");
+    return e ? (atoll(e) > 0 ? (int64_t)atoll(e) : INT64_MAX) : (int64_t)1 << 20;
+  }()};
+  return v;
 }
 
 struct hop_args {
@@ -127,15 +141,22 @@ void run_hop(hop_args a)
     int* row_deg       = reinterpret_cast<int*>(base + w.row_deg);
     sample_count_enqueue(a.csr_row_ptr, s_targets, i64, S, a.M, cnt, nullptr, st, row_start, row_deg);
     exclusive_scan_i32(cnt, a.offsets, s_cap, scan_tmp, st, s_n_dev);  // offsets[cap] = #edges
+    // Long hops of a call group walk the frontier grouped by vertex range (wg_sample.hip, loc_rec): same bits, a third of
+    // the line fetches where the frontier repeats its hubs batch after batch.  The records
+    // live in the renumber scratch, which nothing uses before the sampled neighbours exist (keys: 16 B per position of
+    // capacity); the histogram matrix has its own 2 MB.  WGAMD_SAMPLE_LOCALITY=0 keeps list order; =<n> sets the smallest capacity it applies to.
+    const int64_t loc_min = sample_locality_min().load(std::memory_order_relaxed);
+    sample_locality loc{reinterpret_cast<int*>(base + w.loc_hist), keys, sample_locality_shift(a.bv.id_bound)};
+    const bool use_loc = a.M <= 32 && s_cap >= loc_min && a.bv.id_bound > 0 && batched && 8 * w.slots >= 32 * s_cap;
     uniform_sample_enqueue(a.csr_row_ptr, a.csr_col, col64, s_targets, i64, S, a.M, a.rng, a.offsets, nbr, a.center_row,
-                           a.edge_gid, st, row_start, row_deg);
+                           a.edge_gid, st, row_start, row_deg, use_loc ? &loc : nullptr);
   }
   dev_count E{(int)a.edge_cap, a.offsets + s_cap};
   batch_view bv   = a.bv;
   bv.edge_row     = a.center_row;
   bv.edge_offsets = a.offsets;
   append_unique_prepare_enqueue(a.targets, T, i64, nbr, E, col64, bv, keys, minpos, w.slots, slot_of, rank, scan_tmp, st);
-  append_unique_emit_enqueue(a.targets, T, i64, nbr, E, col64, bv, minpos, slot_of, rank, a.unique, a.neighbor_row,
+  append_unique_emit_enqueue(a.targets, T, i64, nbr, E, col64, bv, minpos, slot_of, rank, w.slots, a.unique, a.neighbor_row,
                              a.counts_dev, st);
 }
 
@@ -306,6 +327,11 @@ frontier_list_kernel(const int64_t* __restrict__ nodes, int64_t n_nodes, const i
 }  // namespace wgamd
 
 extern "C" {
+
+void wgamd_set_sample_locality_min(int64_t min_capacity)
+{
+  wgamd::sample_locality_min().store(min_capacity > 0 ? min_capacity : INT64_MAX, std::memory_order_relaxed);
+}
 
 wholememory_error_code_t wgamd_frontier_list(const int64_t* nodes, int64_t n_nodes, const int* seg, const int* begin, int n_batches,
                                              int64_t capacity, int64_t* ids, int* batch, int* f_seg, void* stream)

@@ -158,6 +158,100 @@ __device__ __forceinline__ void emit(ColT* dst, int* src_lid, int64_t* edge_gid,
 // ---- M <= 32: LANES (32, or 16 when M <= 16) lanes per seed = 2 or 4 seeds per wave64, everything in registers ----
 // (a hop is a chain of three dependent memory latencies per seed — seeds -> row_ptr -> col — so what matters is how
 //  many seeds a wave keeps in flight; with fan-out 10 a 32-lane group would idle 22 lanes)
+// ---- vertex-grouped order for the long hops of a call group --------------------------------------------------------------
+// The frontier of a deep hop of a call group holds the same vertices again and again (products, hop 2 of 191 mini-batches:
+// 1.5 M entries over 0.52 M vertices, the hubs in every batch), and a fan-out-10 pick from a long row fetches one 128-byte
+// line per pick: in frontier (batch-major) order the picks of one hub are spread over the whole launch and every one of them
+// misses — 9.2 M line fetches where the entries together touch 3.2 M distinct lines.  So the sampling kernel walks the
+// frontier GROUPED BY VERTEX RANGE instead: a counting sort of the entry indices over kLocBuckets vertex-id ranges (histogram
+// per block, then every block derives its own write cursors from the histogram matrix and scatters 32-byte records holding
+// everything the sampling kernel needs of an entry), and XCD x takes the x-th eighth of the grouped order, so that the picks
+// of one vertex meet in ONE L2 within microseconds of each other.  Every entry still draws from its own PCG streams and
+// writes its own output positions: the result does not depend on the order, it is bit-identical.
+struct loc_rec {
+  int64_t start;   // first CSR slot of the row
+  int i;           // entry index (output position base, src_lid)
+  int deg;
+  int base;        // offsets[i]
+  int i_local;     // entry index inside its batch (PCG stream numbering)
+  int batch;
+  int pad;
+};
+static_assert(sizeof(loc_rec) == 32, "one 32-byte sector per record");
+constexpr int kLocBuckets = 4096;
+constexpr int kLocBlocks  = 128;    // blocks of both kernels: block b owns entries [b per, (b + 1) per)
+constexpr int kLocThreads = 1024;
+
+template <typename SeedT>
+__global__ void __launch_bounds__(kLocThreads)
+locality_hist_kernel(const SeedT* __restrict__ seeds, dev_count n_, int shift, int* __restrict__ hist /*[kLocBlocks][kLocBuckets]*/)
+{
+  __shared__ int h[kLocBuckets];
+  const int n = n_.get(), per = (n + kLocBlocks - 1) / kLocBlocks;
+  const int lo = min(n, (int)blockIdx.x * per), hi = min(n, lo + per);
+  for (int k = threadIdx.x; k < kLocBuckets; k += kLocThreads) h[k] = 0;
+  __syncthreads();
+  for (int i = lo + threadIdx.x; i < hi; i += kLocThreads)
+    atomicAdd(&h[min((int)((uint64_t)seeds[i] >> shift), kLocBuckets - 1)], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < kLocBuckets; k += kLocThreads) hist[(int64_t)blockIdx.x * kLocBuckets + k] = h[k];
+}
+
+template <typename SeedT>
+__global__ void __launch_bounds__(kLocThreads)
+locality_scatter_kernel(const SeedT* __restrict__ seeds, dev_count n_, int shift, const int* __restrict__ hist,
+                        const int64_t* __restrict__ row_start, const int* __restrict__ row_deg, const int* __restrict__ offsets,
+                        rng_plan rng, loc_rec* __restrict__ recs)
+{
+  __shared__ int cursor[kLocBuckets];
+  __shared__ int wave_tot[kLocThreads / 64];
+  static_assert(kLocBuckets == 4 * kLocThreads, "thread t owns buckets 4 t .. 4 t + 3");
+  const int n = n_.get(), per = (n + kLocBlocks - 1) / kLocBlocks;
+  const int lo = min(n, (int)blockIdx.x * per), hi = min(n, lo + per);
+  // where my entries of bucket k go: all entries of the buckets before k, plus bucket k's entries of the blocks before me
+  int tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+  const int4* h4 = reinterpret_cast<const int4*>(hist);
+  for (int b = 0; b < kLocBlocks; b++) {
+    const int4 v = h4[(int64_t)b * (kLocBuckets / 4) + threadIdx.x];
+    tot[0] += v.x; tot[1] += v.y; tot[2] += v.z; tot[3] += v.w;
+    if (b < (int)blockIdx.x) { before[0] += v.x; before[1] += v.y; before[2] += v.z; before[3] += v.w; }
+  }
+  const int sum = tot[0] + tot[1] + tot[2] + tot[3];
+  int inc = sum;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int run = inc - sum;
+  for (int w = 0; w < wave; w++) run += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    cursor[4 * threadIdx.x + k] = run + before[k];
+    run += tot[k];
+  }
+  __syncthreads();
+  for (int i = lo + threadIdx.x; i < hi; i += kLocThreads) {
+    const int j = atomicAdd(&cursor[min((int)((uint64_t)seeds[i] >> shift), kLocBuckets - 1)], 1);
+    loc_rec r;
+    r.start = row_start[i];
+    r.i     = i;
+    r.deg   = row_deg[i];
+    r.base  = offsets[i];
+    r.i_local = i;
+    r.batch   = 0;
+    if (rng.target_batch) {
+      r.batch   = rng.target_batch[i];
+      r.i_local = i - rng.target_seg[r.batch];
+    }
+    r.pad   = 0;
+    recs[j] = r;
+  }
+}
+
 template <typename SeedT, typename ColT, int LANES>
 __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int64_t* __restrict__ row_ptr,
                                                                       const ColT* __restrict__ col,
@@ -170,13 +264,27 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
                                                                       int* __restrict__ src_lid,
                                                                       int64_t* __restrict__ edge_gid,
                                                                       const int64_t* __restrict__ row_start,
-                                                                      const int* __restrict__ row_deg)
+                                                                      const int* __restrict__ row_deg,
+                                                                      const loc_rec* __restrict__ recs = nullptr)
 {
   const int n    = n_.get();
   const int lane = threadIdx.x & 63;
   const int hl   = lane & (LANES - 1);   // lane inside my group
   const int hb   = lane & ~(LANES - 1);  // first lane of my group
-  const int i    = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES);  // seed index
+  int i          = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES);  // seed index
+  loc_rec rec{};
+  if (recs) {
+    // vertex-grouped order: XCD x (workgroups are dealt to the XCDs round-robin) walks the x-th eighth of the records
+    constexpr int kGroups = 256 / LANES;   // entries per workgroup
+    const int per_x = ((n + 7) / 8 + kGroups - 1) / kGroups * kGroups;
+    const int k     = (int)(blockIdx.x >> 3) * kGroups + (int)threadIdx.x / LANES;
+    const int j     = (int)(blockIdx.x & 7) * per_x + k;
+    i               = n;   // (nothing to do)
+    if (k < per_x && j < n) {
+      rec = recs[j];
+      i   = rec.i;
+    }
+  }
   // The draw of lane t depends only on (seed index, t), not on the row: it is computed FIRST, so that the ~60 ALU
   // instructions of the table jump run under the latency of the dependent seeds -> row_ptr loads issued right after
   // (rows that turn out to be copied whole waste the draw, which is cheaper than putting it on the critical path).
@@ -184,7 +292,11 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   if (i < n && hl < M) {
     uint64_t random_seed;
     int i_local;
-    rng.resolve(i, random_seed, i_local);
+    if (recs) {
+      i_local     = rec.i_local;
+      random_seed = rng.seeds_dev ? rng.seeds_dev[rec.batch] : rng.seed;
+    } else
+      rng.resolve(i, random_seed, i_local);
     // stream index = i_local*32 + lane; the table jump covers every index below 2^31, the generic
     // loop keeps the reference's sign-extension semantics beyond that
     if (i_local < (1 << 26)) {
@@ -197,7 +309,11 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   }
   int64_t start = 0;
   int N = 0, base = 0;
-  if (i < n) {
+  if (i < n && recs) {
+    start = rec.start;
+    N     = rec.deg;
+    base  = rec.base;
+  } else if (i < n) {
     if (row_start) {   // written by the count kernel: one coalesced read instead of the seeds -> row_ptr chain
       start = row_start[i];
       N     = row_deg[i];
@@ -1313,10 +1429,26 @@ __global__ void __launch_bounds__(256) copy_short_rows_kernel(const int64_t* __r
 template <typename SeedT, typename ColT>
 void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds, dev_count n, int M,
                     rng_plan random_seed, const int* offsets, ColT* dst, int* lid, int64_t* gid, hipStream_t stream,
-                    const int64_t* row_start = nullptr, const int* row_deg = nullptr)
+                    const int64_t* row_start = nullptr, const int* row_deg = nullptr, const sample_locality* loc = nullptr)
 {
   const int cap = n.host;
   if (cap <= 0) return;
+  if (loc != nullptr && M > 0 && M <= 32 && row_start != nullptr) {
+    // vertex-grouped order (see loc_rec): two short launches build the records, the sampling kernel walks them
+    auto* recs = static_cast<loc_rec*>(loc->recs);
+    locality_hist_kernel<SeedT><<<kLocBlocks, kLocThreads, 0, stream>>>(seeds, n, loc->shift, loc->hist);
+    locality_scatter_kernel<SeedT><<<kLocBlocks, kLocThreads, 0, stream>>>(seeds, n, loc->shift, loc->hist, row_start, row_deg,
+                                                                          offsets, random_seed, recs);
+    // (the eight XCD shares are each rounded up to whole workgroups)
+    if (M <= 16)
+      sample_uniform_halfwave_kernel<SeedT, ColT, 16><<<ceil_div((int64_t)cap * 16, 256) + 8, 256, 0, stream>>>(
+        row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg, recs);
+    else
+      sample_uniform_halfwave_kernel<SeedT, ColT, 32><<<ceil_div((int64_t)cap * 32, 256) + 8, 256, 0, stream>>>(
+        row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg, recs);
+    WG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (M <= 0) {
     // sample-all: every row is copied whole (rows can be long -> workgroup copy path)
     sample_uniform_block_kernel<SeedT, ColT><<<cap, 64, 0, stream>>>(row_ptr, col, seeds, n, 0x7fffffff, 32, 1,
@@ -1710,14 +1842,24 @@ void weighted_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64
   WG_HIP_CHECK(hipGetLastError());
 }
 
+int64_t sample_locality_hist_ints() { return (int64_t)kLocBlocks * kLocBuckets; }
+int sample_locality_shift(int64_t id_bound)
+{
+  int bits = 0;
+  while (bits < 62 && ((int64_t)1 << bits) < id_bound) bits++;
+  int buckets_log2 = 0;
+  while ((1 << buckets_log2) < kLocBuckets) buckets_log2++;
+  return bits > buckets_log2 ? bits - buckets_log2 : 0;
+}
+
 void uniform_sample_enqueue(const int64_t* row_ptr, const void* col, bool col64, const void* seeds, bool seeds64,
                             dev_count n, int M, rng_plan random_seed, const int* offsets, void* dst, int* src_lid,
                             int64_t* edge_gid, hipStream_t stream, const int64_t* row_start,
-                            const int* row_deg)
+                            const int* row_deg, const sample_locality* loc)
 {
 #define WG_U(ST, CT)                                                                                               \
   uniform_launch<ST, CT>(row_ptr, static_cast<const CT*>(col), static_cast<const ST*>(seeds), n, M, random_seed, \
-                         offsets, static_cast<CT*>(dst), src_lid, edge_gid, stream, row_start, row_deg)
+                         offsets, static_cast<CT*>(dst), src_lid, edge_gid, stream, row_start, row_deg, loc)
   if (seeds64 && col64) WG_U(int64_t, int64_t);
   else if (seeds64) WG_U(int64_t, int32_t);
   else if (col64) WG_U(int32_t, int64_t);

@@ -259,4 +259,17 @@ void exclusive_scan_i32(const int* in, int* out, int64_t n, int* tmp, hipStream_
   WG_HIP_CHECK(hipGetLastError());
 }
 
+void exclusive_scan_i32_presummed(const int* in, int* out, int64_t n, const int* sums, hipStream_t stream, const int* n_live_dev)
+{
+  dev_count live{(int)n, n_live_dev};
+  if (n <= kTile) {
+    scan_single_kernel<<<1, kThreads, 0, stream>>>(in, out, n);
+  } else {
+    const int64_t m     = (n + kTile - 1) / kTile;
+    const unsigned grid = (unsigned)std::min<int64_t>(m, kScanGrid);
+    scan_tile_final_kernel<<<grid, kThreads, 0, stream>>>(in, out, n, sums, m, live);
+  }
+  WG_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace wgamd

@@ -294,6 +294,7 @@ SYMBOLS = {
     "wgamd_gat_csr_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_float,
                                        c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_set_weighted_sampling_mode": (None, [c_int, c_int]),
+    "wgamd_set_sample_locality_min": (None, [c_int64]),
     "wgamd_sample_hop_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "wgamd_sample_hop_weighted_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int64]),
     "wgamd_sample_hop_nosync": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,

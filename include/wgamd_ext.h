@@ -608,6 +608,11 @@ wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, int64_t ld_ag
  * WGAMD_WEIGHTED_FORCE_REDO=1) sends every row through the hand-back path the pruned kernels take for a row they cannot
  * decide: a test switch.  A negative argument leaves that setting as it is. */
 void wgamd_set_weighted_sampling_mode(int pruning, int force_redo);
+/* Uniform hops of a call group whose frontier capacity is at least `min_capacity` entries (and whose fan-out is at most 32)
+ * walk the frontier grouped by vertex-id range instead of in list order: identical results (every entry keeps its own PCG
+ * streams and output positions), a third of the cache-line fetches where the frontier repeats its hubs batch after batch.
+ * Default 2^20 (environment: WGAMD_SAMPLE_LOCALITY=<n>, 0 = never); min_capacity <= 0 switches it off. */
+void wgamd_set_sample_locality_min(int64_t min_capacity);
 
 /* Uniform neighbour sampling WITH replacement (cugraph_pyg `replace=True`; the reference forwards it to libcugraph,
  * sampler/distributed_sampler.py:775-792,864 — not in its tree, so the draw layout is this library's and is pinned by
