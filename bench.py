@@ -290,7 +290,7 @@ class SagePipeline:
         return h, tuple(v for pair in sz for v in pair)
 
 
-def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("loader_api", "train_step", "loader_api_materialised", "loader_api_per_batch", "gat")):
+def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("loader_api", "train_step", "train_step_per_batch", "forward_per_batch", "loader_api_materialised", "loader_api_per_batch", "gat")):
     """The same workload through the DROP-IN API: GraphStore + FeatureStore -> cugraph_pyg_amd NeighborLoader ->
     wholegraph_amd.nn.SAGEConv x L forward (the surface of python/cugraph-pyg/cugraph_pyg/loader/node_loader.py:16-178 and
     sampler/sampler.py:51-165).  `loader_api`: the epoch iterated in call groups (loader.call_groups(): one block-diagonal
@@ -421,6 +421,71 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
         pass
     except Exception as exc:   # noqa: BLE001
         out["train_step"] = {"value": None, "error": repr(exc)[:300]}
+    def per_batch_pass(train, n_warm=1, n_timed=4):
+        """The reference's optimizer semantics: SAMPLE per call group, STEP per mini-batch of BATCH seeds
+        (pylibwholegraph/torch/gnn_model.py:119-125: loss.backward(); optimizer.step() inside the batch loop).
+        cugraph_pyg_amd.loader.PerBatchStep: the group's walk and lazy x are made once, every mini-batch is staged into
+        fixed-size buffers by one launch and the whole step (trimmed forward over the mini-batch's own slice of the layer
+        graphs, cross-entropy, backward, SGD) is one HIP-graph replay.  `train=False`: the forward alone, per mini-batch."""
+        from wholegraph_amd import nn as wnn
+        from cugraph_pyg_amd.loader import PerBatchStep
+        model = torch.nn.ModuleList([wnn.SAGEConv(c.in_channels[0], c.out_channels) for c in convs]).to(dev)
+        with torch.no_grad():
+            for m, c in zip(model, convs):
+                for pm, pc in zip(m.parameters(), c.parameters()):
+                    pm.copy_(pc)
+        opt = torch.optim.SGD(model.parameters(), lr=0.01)
+        labels = torch.randint(0, CLASSES, (V,), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+
+        def step(batch):
+            if train:
+                opt.zero_grad(set_to_none=True)
+            h = batch.x
+            for j, c in enumerate(model):
+                h = c(h, batch.layer_graph(j), act="relu" if j < L - 1 else None)
+            if not train:
+                return h[:batch.batch_size].sum()
+            loss = torch.nn.functional.cross_entropy(h[:batch.batch_size], labels[batch.seeds])
+            loss.backward()
+            opt.step()
+            return loss
+        loader = NeighborLoader((fs, gs), FANOUT, input_nodes=seeds[:(n_timed + n_warm) * G * BATCH], batch_size=BATCH,
+                                shuffle=False, random_state=62)
+        stepper = PerBatchStep(step, table=table, optimizer=opt if train else None)
+        edges, t0, n, steps, first, last = 0, None, 0, 0, None, None
+        with torch.set_grad_enabled(train):
+            for grp in loader.call_groups():
+                if n == n_warm:
+                    torch.cuda.synchronize()
+                    t0, edges, steps = time.perf_counter(), 0, 0
+                for b in range(grp.n_batches):
+                    last = stepper(grp, b)
+                    if first is None:
+                        first = float(last.detach())
+                edges += grp.num_edges
+                steps += grp.n_batches
+                n += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": edges / dt, "ms_per_call_group": dt / max(n - n_warm, 1) * 1e3, "ms_per_mini_batch": dt / max(steps, 1) * 1e3,
+                "optimizer_steps_timed": steps if train else 0, "graph_captures": stepper.captures,
+                "loss_first_last": [round(first, 4), round(float(last.detach()), 4)] if train else None,
+                "buffers": {"rows": stepper.batch.row_cap, "edges": stepper.batch.edge_cap, "nodes": stepper.batch.node_cap}}
+
+    for name, train in (("train_step_per_batch", True), ("forward_per_batch", False)):
+        if name not in which:
+            continue
+        try:
+            out[name] = per_batch_pass(train)
+            out[name]["note"] = (
+                "REFERENCE OPTIMIZER SEMANTICS: NeighborLoader.call_groups() samples %d mini-batches per call, then ONE SGD step per "
+                "mini-batch of %d seeds (%d steps per call group): wgamd_call_group_stage_batch + one HIP-graph replay of forward "
+                "(trimmed, x lazy) -> cross-entropy -> backward -> SGD per mini-batch (cugraph_pyg_amd.loader.PerBatchStep)"
+                % (G, BATCH, G) if train else
+                "the forward alone per mini-batch of %d seeds through the same staged buffers + HIP graph (what a per-batch "
+                "inference loop gets without consuming call groups whole)" % BATCH)
+        except Exception as exc:   # noqa: BLE001
+            out[name] = {"value": None, "error": repr(exc)[:400]}
     if "loader_api_materialised" in which:
         v, ms, epb = group_pass(False)
         out["loader_api_materialised"] = {"value": v, "ms_per_call_group": ms, "edges_per_batch": epb,
@@ -673,6 +738,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes of the other code paths")
     ap.add_argument("--extra-placement-timeout", type=int, default=180,
                     help="seconds the also-measured feature placement may take before the headline line is printed without it")
+    ap.add_argument("--mag-rels", choices=["all", "r5"], default="all",
+                    help="--workload mag: all 8 directed edge types (4 + reverses, ~42 M edges: BASELINE configs[4]) or the six "
+                         "that rounds 3-5 ran (no rev_cites / rev_affiliated_with, 35.8 M edges) for round-to-round comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()

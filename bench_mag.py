@@ -1,7 +1,7 @@
 """bench.py --workload mag — BASELINE configs[4]: ogbn-mag-like heterogeneous 2-hop sampling + GATConv, one MI355X.
 
 One "step" = `--groups-per-step` CALL GROUPS of `--call-group` mini-batches of 1024 paper seeds through the whole path:
-  heterogeneous 2-hop walk over 6 edge types, fan-out [25, 10] each (wholegraph_amd.fused.HeteroPygWalk behind the loader: one
+  heterogeneous 2-hop walk over the 8 edge types (4 + reverses), fan-out [25, 10] each (wholegraph_amd.fused.HeteroPygWalk behind the loader: one
   launch sequence per hop and edge type for the whole call group, no host sync)                                   [reference: cugraph_pyg NeighborLoader on
   a heterogeneous GraphStore, examples/mag_lp_mnmg.py:141; sampler/distributed_sampler.py:877-908]
   -> feature gather for every node type (fp32 [n_t, 128]; paper = the dataset's features, the other types = embedding
@@ -34,9 +34,13 @@ import torch
 
 HBM_PEAK_GBPS = 8000.0
 MAG_NODES = {"paper": 736_389, "author": 1_134_649, "institution": 8_740, "field_of_study": 59_965}
-MAG_RELS = {("author", "writes", "paper"): 7_145_660, ("paper", "cites", "paper"): 5_416_271,
-            ("paper", "has_topic", "field_of_study"): 7_505_078, ("author", "affiliated_with", "institution"): 1_043_998,
-            ("paper", "rev_writes", "author"): 7_145_660, ("field_of_study", "rev_has_topic", "paper"): 7_505_078}
+# ogbn-mag's four relations and their reverses (BASELINE.md S4 / SURVEY §8(d): "4 (+reverse) edge types", ~42 M directed edges).
+# Rounds 3-5 ran six of the eight (no rev_cites / rev_affiliated_with, 35.8 M edges): MAG_RELS_R5, `--mag-rels r5`.
+MAG_FWD = {("author", "writes", "paper"): 7_145_660, ("paper", "cites", "paper"): 5_416_271,
+           ("paper", "has_topic", "field_of_study"): 7_505_078, ("author", "affiliated_with", "institution"): 1_043_998}
+MAG_RELS = dict(MAG_FWD)
+MAG_RELS.update({(d_, "rev_" + r_, s_): m for (s_, r_, d_), m in MAG_FWD.items()})
+MAG_RELS_R5 = {k: v for k, v in MAG_RELS.items() if k[1] not in ("rev_cites", "rev_affiliated_with")}
 F_IN, HEADS, CH = 128, 4, 64
 HC = HEADS * CH
 
@@ -47,10 +51,17 @@ def build_mag_like(dev, nodes=None, rels=None, seed=11):
     nodes, rels = nodes or MAG_NODES, rels or MAG_RELS
     g = torch.Generator(device=dev).manual_seed(seed)
     gs = GraphStore()
+    made = {}
     for (s_, r_, d_), m in rels.items():
-        src = (torch.rand(m, generator=g, device=dev) ** 2 * nodes[s_]).long().clamp_(max=nodes[s_] - 1)
-        dst = (torch.rand(m, generator=g, device=dev) ** 2 * nodes[d_]).long().clamp_(max=nodes[d_] - 1)
-        gs[(s_, r_, d_), "coo", False, (nodes[s_], nodes[d_])] = torch.stack([src, dst])
+        fwd = (d_, r_[4:], s_) if r_.startswith("rev_") else None
+        if fwd in made:      # a reverse relation is the forward one flipped (PyG's ToUndirected on ogbn-mag)
+            ei = made[fwd].flip(0)
+        else:
+            src = (torch.rand(m, generator=g, device=dev) ** 2 * nodes[s_]).long().clamp_(max=nodes[s_] - 1)
+            dst = (torch.rand(m, generator=g, device=dev) ** 2 * nodes[d_]).long().clamp_(max=nodes[d_] - 1)
+            ei = torch.stack([src, dst])
+        made[(s_, r_, d_)] = ei
+        gs[(s_, r_, d_), "coo", False, (nodes[s_], nodes[d_])] = ei
     build_mag_like.graph_store = gs           # (the loader path needs the store itself)
     return gs._hetero_graphs, dict(nodes)
 
@@ -195,7 +206,7 @@ def cpu_baseline(graphs, tables, params, seeds_h, B, fanout, hops, etypes, ntype
         nb += 1
     dt = time.perf_counter() - t0
     return {"value": edges / dt, "unit": "sampled-edges/s", "cores": threads, "kind": "port",
-            "sample": f"{nb} mini-batches of {B} paper seeds: 2-hop [25,10] x 6 edge types + feature gather + 2 HeteroConv(GATConv "
+            "sample": f"{nb} mini-batches of {B} paper seeds: 2-hop [25,10] x {len(etypes)} edge types + feature gather + 2 HeteroConv(GATConv "
                       f"4x64) layers on the C oracle (OpenMP) + torch CPU GEMMs, {dt:.1f} s"}
 
 
@@ -261,7 +272,9 @@ def main(args):
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
-    graphs, num_nodes = build_mag_like(dev)
+    rels = MAG_RELS_R5 if getattr(args, "mag_rels", "all") == "r5" else MAG_RELS
+    graphs, num_nodes = build_mag_like(dev, rels=rels)
+    n_graph_edges = sum(rels.values())
     etypes = sorted(graphs)
     ntypes = sorted(num_nodes)
     g = torch.Generator(device=dev).manual_seed(5)
@@ -366,7 +379,7 @@ def main(args):
         nn.set_stage_hook(None)
     stage_ms = {k: v / n_probe for k, v in acc.items() if ":" not in k}
     if walk_ms:
-        stage_ms["walk(2 hops x 6 edge types)"] = sum(walk_ms) / len(walk_ms)
+        stage_ms["walk(2 hops x %d edge types)" % len(etypes)] = sum(walk_ms) / len(walk_ms)
     # dominant GAT launch over the probed groups (shapes differ by a per cent between groups: the stage name carries the shape)
     import re
     gat = {k: v for k, v in acc.items() if k.startswith("gat") and ":" in k}
@@ -426,16 +439,16 @@ def main(args):
         cpu = cpu_baseline(graphs, tables, params, order[:min(order.numel(), 256 * B)].cpu().numpy(), B, fanout, hops,
                            etypes, ntypes, args.cpu_budget)
     out = {"metric": "sampled-edges/sec (hetero 2-hop sample+renumber + feature gather + 2-layer HeteroConv(GATConv 4x64) fwd), "
-                     "ogbn-mag-like fan-out [25, 10] x 6 edge types",
+                     "ogbn-mag-like fan-out [25, 10] x %d edge types" % len(etypes),
            "value": edges / dt, "unit": "sampled-edges/s", "n_gpus": world, "per_rank_value": per_rank_value, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int64 ids + f32 features (edge softmax + aggregation: f32 HIP kernels; GATConv per-head lin: bf16x3-split MFMA, "
                     "f32 accumulate — the one-kernel relation / wgamd_gat_transform_heads_bf16x3)",
            "data": "synthetic",
            "config": {"workload": "ogbn-mag-like hetero (BASELINE configs[4]): 4 node types (736,389 / 1,134,649 / 8,740 / 59,965), "
-                                  "6 edge types ~35.8 M edges, feat fp32 [n_t, 128] per type, batch 1024 paper seeds, 2-hop fan-out "
+                                  "%d directed edge types (%s) ~%.1f M edges, feat fp32 [n_t, 128] per type, batch 1024 paper seeds, 2-hop fan-out "
                                   "[25,10] per edge type, 2 x HeteroConv{GATConv(., 64, heads=4)} sum + ReLU, step = %d call groups "
-                                  "of %d mini-batches" % (gps, G),
+                                  "of %d mini-batches" % (len(etypes), ", ".join(et[1] for et in etypes), n_graph_edges / 1e6, gps, G),
                       "parallelism": "1 GPU" if world == 1 else "dp%d (seeds sharded, graph + tables replicated, no data-path collective)" % world},
            "call_group": G, "batches_per_step": G * gps, "timed_region_ms": round(dt * 1e3, 2), "timed_call_groups": groups,
            "ms_per_batch": dt / (groups * G) * 1e3, "edges_per_batch": edges / (groups * G * world),

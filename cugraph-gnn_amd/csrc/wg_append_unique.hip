@@ -777,10 +777,14 @@ first_bits_kernel(const int* __restrict__ slot_of, dev_count T_, dev_count E_, i
     // wave v takes words w0 + v, w0 + v + 4, ...: a block iteration reads 16 KB of slot_of, all sixteen loads of a lane in
     // flight before the first ballot
     bool f[kBitsWordsPerBlock / 4];
+    int first[kBitsWordsPerBlock / 4];
+#pragma unroll
+    for (int k = 0; k < kBitsWordsPerBlock / 4; k++)   // unconditional loads (index clamped): all sixteen in flight at once
+      first[k] = slot_of[max(T + min((w0 + wave + 4 * k) * 64 + lane, E - 1), 0)];
 #pragma unroll
     for (int k = 0; k < kBitsWordsPerBlock / 4; k++) {
       const int e = (w0 + wave + 4 * k) * 64 + lane;
-      f[k]        = e < E && slot_of[T + e] == T + e;
+      f[k]        = e < E && first[k] == T + e;
     }
     int total = 0;
 #pragma unroll

@@ -55,13 +55,15 @@ hop_workspace plan(int64_t target_cap, int64_t edge_cap, size_t id_bytes, bool b
   return w;
 }
 
-// smallest frontier capacity whose hop walks the frontier grouped by vertex range (WGAMD_SAMPLE_LOCALITY: 0 = never, n = from
-// capacity n; wgamd_set_sample_locality_min at run time)
+// smallest frontier capacity whose hop walks the frontier grouped by vertex range (WGAMD_SAMPLE_LOCALITY=<n>: from capacity
+// n; wgamd_set_sample_locality_min at run time).  OFF by default: measured on the products hop 2 the grouped order fetches
+// 2.7x fewer lines but the sampling kernel is bound by VALU issue, so its duration is unchanged and the two launches that
+// build the order (78 us) are a net loss (profiles/r06/README.md)
 inline std::atomic<int64_t>& sample_locality_min()
 {
   static std::atomic<int64_t> v{[] {
     const char* e = getenv("WGAMD_SAMPLE_LOCALITY");
-    return e ? (atoll(e) > 0 ? (int64_t)atoll(e) : INT64_MAX) : (int64_t)1 << 20;
+    return e && atoll(e) > 0 ? (int64_t)atoll(e) : INT64_MAX;
   }()};
   return v;
 }
@@ -323,10 +325,139 @@ frontier_list_kernel(const int64_t* __restrict__ nodes, int64_t n_nodes, const i
   }
 }
 
+// ---- one mini-batch of a PyG-style call group, staged into FIXED-SIZE buffers ------------------------------------------------
+// The reference's training loops step the optimizer once per mini-batch (pylibwholegraph/torch/gnn_model.py:119-125,
+// cugraph_pyg/examples/gcn_dist_mnmg.py).  A call group is walked once; its mini-batches are then consecutive slices of every
+// array — frontier entries [frontier_seg[b], frontier_seg[b + 1]) of each hop and their edges, vertices [node_seg[b],
+// node_seg[b + 1]) — in BATCH-LOCAL ids.  This kernel copies one mini-batch into buffers whose sizes and addresses never
+// change, padded to their capacities (padded frontier rows have no edges, padded vertices repeat a valid id), so the whole
+// per-batch training step — forward, loss, backward, optimizer — can be captured in ONE hipGraph and replayed per mini-batch:
+// one staging launch and one graph launch instead of ~30 kernel launches and the host work behind them.
+// Layout of a trimmed layer's OUTPUT rows (and so of the next layer's input): hop 0's row_cap[0] rows, then hop 1's
+// row_cap[1], ...: `col_seg` holds the sources as rows of that layout, `col` as batch-local ids (= rows of x for layer 0).
+constexpr int kStageMaxHops = 8;
+struct stage_hop {
+  const int* offsets;
+  const int* row_local;
+  const int* f_seg;
+  const int* f_local0;
+  int row_cap, edge_cap;
+  int* row_ptr;       // [row_cap + 1]
+  int64_t* self0;     // [row_cap]: input row of the entry itself for layer 0 (its batch-local id)
+  int* col;           // [edge_cap]
+  int* col_seg;       // [edge_cap] (nullable)
+};
+struct stage_args {
+  stage_hop hop[kStageMaxHops];
+  int n_hops, batch, node_cap;
+  const void* nodes;
+  const int* node_seg;
+  void* n_id;         // [node_cap]
+  int* sizes;         // [2 n_hops + 2]: rows and edges per hop, vertices, overflow flag
+};
+
+template <typename IdT>
+__global__ void __launch_bounds__(256) stage_batch_kernel(const stage_args a)
+{
+  __shared__ int s_l0[kStageMaxHops + 1];     // first local id of every hop's frontier (+ the vertex count)
+  __shared__ int s_base[kStageMaxHops + 1];   // first row of every hop's segment in a layer's output layout
+  const int b = a.batch, t = threadIdx.x;
+  const int n0 = a.node_seg[b], n_nodes = a.node_seg[b + 1] - n0;
+  if (t == 0) {
+    int base = 0;
+    for (int k = 0; k < a.n_hops; k++) {
+      s_l0[k]   = a.hop[k].f_local0[b];
+      s_base[k] = base;
+      base += a.hop[k].row_cap;
+    }
+    s_l0[a.n_hops] = n_nodes;
+  }
+  __syncthreads();
+  const int gtid = blockIdx.x * blockDim.x + t, gsize = gridDim.x * blockDim.x;
+  int over = n_nodes > a.node_cap;
+  // vertices (global ids, the layer-0 kernel reads the feature table through them); the padding repeats the first one
+  const IdT* nodes = static_cast<const IdT*>(a.nodes) + n0;
+  IdT* out_ids     = static_cast<IdT*>(a.n_id);
+  for (int i = gtid; i < a.node_cap; i += gsize) out_ids[i] = nodes[i < n_nodes ? i : 0];
+  for (int k = 0; k < a.n_hops; k++) {
+    const stage_hop h = a.hop[k];
+    const int j0 = h.f_seg[b], n_rows = h.f_seg[b + 1] - j0;
+    const int e0 = h.offsets[j0], n_edges = h.offsets[j0 + n_rows] - e0;
+    // (one padded row at least: the padding edges below must belong to rows that are not the mini-batch's)
+    over |= (n_rows >= h.row_cap) | (n_edges > h.edge_cap);
+    const int rows = min(n_rows, h.row_cap - 1), edges = min(n_edges, h.edge_cap);
+    if (gtid == 0 && a.sizes) {
+      a.sizes[2 * k]     = n_rows;
+      a.sizes[2 * k + 1] = n_edges;
+    }
+    // Every entry of the fixed-size arrays must be a well-formed edge (kernels take the edge count from the array, and so does
+    // the transpose of the backward pass): the slack edges are dealt evenly to the slack rows, with sources spread over the
+    // input rows — no long row, no hub source.  Nothing reads a slack row's output and its gradient is zero.
+    const int64_t pad_rows = h.row_cap - rows, pad_edges = h.edge_cap - edges;
+    for (int r = gtid; r <= h.row_cap; r += gsize) {
+      h.row_ptr[r] = r <= rows ? min(h.offsets[j0 + r] - e0, edges) : edges + (int)((int64_t)(r - rows) * pad_edges / pad_rows);
+      if (r < h.row_cap) h.self0[r] = r < rows ? (int64_t)(s_l0[k] + r) : 0;
+    }
+    for (int e = gtid; e < h.edge_cap; e += gsize) {
+      if (e < edges) {
+        const int local = h.row_local[e0 + e];
+        h.col[e]        = local;
+        if (h.col_seg) {
+          int s = 0;
+          for (int q = 1; q < a.n_hops; q++) s = s_l0[q] <= local ? q : s;
+          h.col_seg[e] = s_base[s] + (local - s_l0[s]);
+        }
+      } else {
+        h.col[e] = (e - edges) % max(min(n_nodes, a.node_cap), 1);
+        if (h.col_seg) h.col_seg[e] = (e - edges) % a.hop[0].row_cap;
+      }
+    }
+  }
+  if (gtid == 0 && a.sizes) {
+    a.sizes[2 * a.n_hops]     = n_nodes;
+    a.sizes[2 * a.n_hops + 1] = over;
+  }
+}
+
 }  // namespace
 }  // namespace wgamd
 
 extern "C" {
+
+wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* const* offsets, const int* const* row_local,
+                                                      const int* const* frontier_seg, const int* const* frontier_local0,
+                                                      const void* nodes, wholememory_dtype_t id_dtype, const int* node_seg,
+                                                      int batch, const int* row_cap, const int* edge_cap, int node_cap,
+                                                      int* const* row_ptr_out, int64_t* const* self_rows_out, int* const* col_out,
+                                                      int* const* col_seg_out, void* n_id_out, int* sizes_out, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_call_group_stage_batch", [&] {
+    WG_REQUIRE_INPUT(n_hops >= 1 && n_hops <= kStageMaxHops, "1 <= n_hops <= 8");
+    WG_REQUIRE_INPUT(id_dtype == WHOLEMEMORY_DT_INT || id_dtype == WHOLEMEMORY_DT_INT64, "ids must be INT or INT64");
+    WG_REQUIRE_INPUT(offsets && row_local && frontier_seg && frontier_local0 && nodes && node_seg && row_cap && edge_cap &&
+                       row_ptr_out && self_rows_out && col_out && n_id_out && batch >= 0 && node_cap >= 1,
+                     "null pointer / bad sizes");
+    stage_args a{};
+    int64_t work = node_cap;
+    for (int k = 0; k < n_hops; k++) {
+      WG_REQUIRE_INPUT(offsets[k] && row_local[k] && frontier_seg[k] && frontier_local0[k] && row_ptr_out[k] && self_rows_out[k] &&
+                         col_out[k] && row_cap[k] >= 1 && edge_cap[k] >= 1,
+                       "hop %d: null pointer / empty capacity", k);
+      a.hop[k] = stage_hop{offsets[k], row_local[k], frontier_seg[k], frontier_local0[k], row_cap[k], edge_cap[k], row_ptr_out[k],
+                           self_rows_out[k], col_out[k], col_seg_out ? col_seg_out[k] : nullptr};
+      work     = std::max<int64_t>(work, std::max(row_cap[k], edge_cap[k]));
+    }
+    a.n_hops = n_hops, a.batch = batch, a.node_cap = node_cap, a.nodes = nodes, a.node_seg = node_seg, a.n_id = n_id_out;
+    a.sizes  = sizes_out;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, (int64_t)1024), 256));
+    if (id_dtype == WHOLEMEMORY_DT_INT64)
+      stage_batch_kernel<int64_t><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    else
+      stage_batch_kernel<int32_t><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
 
 void wgamd_set_sample_locality_min(int64_t min_capacity)
 {

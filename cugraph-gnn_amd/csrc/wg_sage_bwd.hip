@@ -441,7 +441,11 @@ extern "C" wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, in
     const wgrad_plan p = plan_for(F, N);
     const int cus      = stream_cu_count(st);
     const int64_t tiles = (n_rows + p.TR - 1) / p.TR;
-    const int grid_x   = (int)std::max<int64_t>(1, std::min<int64_t>({tiles, (int64_t)std::max(1, cus / p.grid_y), (int64_t)max_grid_x(p)}));
+    // every workgroup leaves a [2F + 1, N] partial sum that wgrad_reduce_kernel adds up: with few row tiles (one mini-batch:
+    // 338 tiles) a workgroup takes at least three of them.  Measured per launch at F = 100, N = 256, 10 k rows: 256 workgroups
+    // 16 us + 31 us of reduction; 42 workgroups 47 + 8; the model a + b tiles / grid + c grid puts the optimum near 110.
+    const int64_t tiles_x = std::max<int64_t>(1, tiles / 3);
+    const int grid_x   = (int)std::max<int64_t>(1, std::min<int64_t>({tiles_x, (int64_t)std::max(1, cus / p.grid_y), (int64_t)max_grid_x(p)}));
     char* ws           = static_cast<char*>(workspace);
     ws                 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     float* part        = reinterpret_cast<float*>(ws);

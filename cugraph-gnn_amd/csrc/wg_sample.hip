@@ -87,8 +87,29 @@ __global__ void __launch_bounds__(256) sample_count_kernel(const int64_t* __rest
                                                            int64_t* __restrict__ row_start = nullptr,
                                                            int* __restrict__ row_deg       = nullptr)
 {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_live = n_.get();
+  if (lists == nullptr) {
+    // uniform hop of the no-sync walk: a bounded grid strides over the live seeds and the slack of their last scan tile
+    // (a capacity-sized grid is 2/3 workgroups with nothing to do: the dispatcher, not the loads, then bounds the launch)
+    const int end = min(n_.host, (n_live / kScanTile + 1) * kScanTile);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+      int deg = 0;
+      if (i < n_live) {
+        const int64_t nid   = (int64_t)seeds[i];
+        const int64_t first = row_ptr[nid];
+        deg                 = (int)(row_ptr[nid + 1] - first);
+        if (row_start) {
+          row_start[i] = first;
+          row_deg[i]   = deg;
+        }
+        deg = (M > 0 && deg > M) ? M : deg;
+      }
+      cnt[i] = deg;
+      if (big_deg) big_deg[i] = 0;
+    }
+    return;
+  }
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   int cls          = -1;
   int deg          = 0;
   if (i < n_.host) {
@@ -145,6 +166,8 @@ __device__ __forceinline__ ColT col_at(const ColT* __restrict__ col, int64_t at)
 {
   return col ? col[at] : (ColT)0;
 }
+
+constexpr int kWalkGrid = 256 * 16;   // workgroups of the walk's bounded, grid-striding launches (16 per CU: 8 resident, 8 queued)
 
 template <typename ColT>
 __device__ __forceinline__ void emit(ColT* dst, int* src_lid, int64_t* edge_gid, int64_t out, ColT v,
@@ -359,6 +382,127 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
   } else if (hl < N) {
     emit<ColT>(dst, src_lid, edge_gid, (int64_t)base + hl, col_at<ColT>(col, start + hl), i, start + hl);
   }
+}
+
+// ---- the same hop for the no-sync walk: lane groups as wide as the fan-out, K seeds per group ----------------------------
+// (row_start / row_deg come from the count kernel.)  What round 6 measured on the products hop 2 (1.6 M seeds x fan-out 10):
+// the launch is bound by VALU issue, not by memory — the vertex-grouped order below cut the lines it fetches 2.7x (PMC) and
+// its duration by 2 %, four seeds in flight per group instead of one (K) bought 14 %; a wave spends ~2,000 cycles on four
+// seeds, a third of them in the quarter-rate 64-bit multiplies of the PCG jump.  So the lanes are what is scarce: a group is
+// GW = the fan-out lanes wide (10 -> six seeds per wave where the 16-lane groups of sample_uniform_halfwave_kernel hold
+// four with six lanes idle; fan-out 5 -> twelve), and takes K consecutive seeds whose loads are issued stage by stage.
+// Same draws (stream 32 i_local + t), same output positions.
+template <typename SeedT, typename ColT, int GW, int K>
+__global__ void __launch_bounds__(256)
+sample_uniform_multi_kernel(const ColT* __restrict__ col, dev_count n_, int M, rng_plan rng, const int* __restrict__ offsets,
+                            ColT* __restrict__ dst, int* __restrict__ src_lid, int64_t* __restrict__ edge_gid,
+                            const int64_t* __restrict__ row_start, const int* __restrict__ row_deg,
+                            const loc_rec* __restrict__ recs)
+{
+  constexpr int kGPW    = 64 / GW;        // lane groups per wave (the lanes past kGPW * GW idle)
+  constexpr int kGroups = 4 * kGPW;       // lane groups per workgroup
+  constexpr int kRounds = GW <= 2 ? 1 : GW <= 4 ? 2 : GW <= 8 ? 3 : GW <= 16 ? 4 : 5;   // pointer jumping: ceil(log2 GW)
+  const int n    = n_.get();
+  const int lane = threadIdx.x & 63;
+  const int grp  = lane / GW;             // (GW is a compile-time constant: a multiply and a shift)
+  const int hl   = lane - grp * GW;       // lane inside my group
+  const int hb   = grp * GW;              // first lane of my group
+  const bool live_group = grp < kGPW;
+  const int wg_group    = (int)(threadIdx.x >> 6) * kGPW + grp;
+  // The grid is BOUNDED (a few workgroups per CU) and strides over the live seeds: the walk's buffers are sized for the worst
+  // case, 3-4x the live count, and a grid sized for the capacity spends its time dispatching workgroups that find nothing
+  // to do — measured on the products hop 2 (PMC): 53 k workgroups of which 17 k had seeds, 1.8 waves resident per SIMD on
+  // average instead of 8, the launch bound by the dispatcher.
+  const int per_x = ((n + 7) / 8 + kGroups * K - 1) / (kGroups * K) * (kGroups * K);   // an XCD's share of the grouped order
+  const int64_t n_chunks = recs ? (int64_t)(per_x / (kGroups * K)) * 8 : ((int64_t)n + kGroups * K - 1) / (kGroups * K);
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  int i[K], N[K], base[K], i_local[K], batch[K];
+  int64_t start[K];
+  // ---- stage 1: the row records of my K seeds ----------------------------------------------------------------------
+  if (recs) {
+    // vertex-grouped order: XCD x (workgroups are dealt to the XCDs round-robin; the grid is a multiple of 8) walks the x-th
+    // eighth of the records
+    const int k0    = ((int)(chunk >> 3) * kGroups + wg_group) * K;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int j = (int)(chunk & 7) * per_x + k0 + k;
+      i[k] = n, N[k] = 0, base[k] = 0, start[k] = 0, i_local[k] = 0, batch[k] = 0;
+      if (live_group && k0 + k < per_x && j < n) {
+        const loc_rec r = recs[j];
+        i[k] = r.i, N[k] = r.deg, base[k] = r.base, start[k] = r.start, i_local[k] = r.i_local, batch[k] = r.batch;
+      }
+    }
+  } else {
+    const int64_t g = chunk * kGroups + wg_group;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      i[k] = live_group ? (int)min(g * K + k, (int64_t)n) : n;
+      N[k] = 0, base[k] = 0, start[k] = 0, i_local[k] = i[k], batch[k] = 0;
+      if (i[k] < n) {
+        start[k] = row_start[i[k]];
+        N[k]     = row_deg[i[k]];
+        base[k]  = offsets[i[k]];
+        if (rng.target_batch) batch[k] = rng.target_batch[i[k]];
+      }
+    }
+    if (rng.target_batch) {
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (i[k] < n) i_local[k] = i[k] - rng.target_seg[batch[k]];
+    }
+  }
+  // ---- stage 2: the draws (ALU work under the latency of stage 1) -----------------------------------------------------
+  int32_t r_draw[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    r_draw[k] = 0;
+    if (i[k] < n && hl < M) {
+      const uint64_t random_seed = rng.seeds_dev ? rng.seeds_dev[rng.target_batch ? batch[k] : 0] : rng.seed;
+      if (i_local[k] < (1 << 26)) {
+        Pcg32 g(random_seed, (uint32_t)(i_local[k] * 32 + hl), Pcg32::table_tag{});   // stream layout: 32 per seed, always
+        r_draw[k] = g.next_i31();
+      } else {
+        Pcg32 g(random_seed, stream_id(i_local[k], 32, hl));
+        r_draw[k] = g.next_i31();
+      }
+    }
+  }
+  // ---- stage 3: Fisher-Yates resolved with shuffles (see sample_uniform_halfwave_kernel), then the K picks in flight ----
+  int a[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const bool pick = N[k] > M;
+    a[k]            = hl;
+    if (__ballot(pick) != 0ull) {   // (wave-uniform)
+      int r = 0;
+      if (pick && hl < M) r = r_draw[k] % (N[k] - hl);
+      const int tail = N[k] - hl - 1;
+      int p1 = -1, p2 = -1;
+      for (int s = 0; s + 1 < M; s++) {
+        const int rs    = __shfl(r, hb + s, 64);
+        const bool prev = s < hl;
+        p1 = (prev && rs == r) ? s : p1;
+        p2 = (prev && rs == tail) ? s : p2;
+      }
+      int root = p2 >= 0 ? p2 : hl;
+#pragma unroll
+      for (int round = 0; round < kRounds; round++) root = __shfl(root, hb + root, 64);
+      const int val = N[k] - root - 1;
+      const int vp1 = __shfl(val, hb + max(p1, 0), 64);
+      if (pick) a[k] = p1 >= 0 ? vp1 : r;
+    }
+  }
+  ColT v[K];
+  bool on[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    on[k] = live_group && hl < (N[k] > M ? M : N[k]);
+    v[k]  = on[k] ? col_at<ColT>(col, start[k] + a[k]) : (ColT)0;
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++)
+    if (on[k]) emit<ColT>(dst, src_lid, edge_gid, (int64_t)base[k] + hl, v[k], i[k], start[k] + a[k]);
+  }   // chunk
 }
 
 // ---- 32 < M <= 1024: one workgroup per seed ------------------------------------------------
@@ -1433,19 +1577,42 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
 {
   const int cap = n.host;
   if (cap <= 0) return;
-  if (loc != nullptr && M > 0 && M <= 32 && row_start != nullptr) {
-    // vertex-grouped order (see loc_rec): two short launches build the records, the sampling kernel walks them
-    auto* recs = static_cast<loc_rec*>(loc->recs);
-    locality_hist_kernel<SeedT><<<kLocBlocks, kLocThreads, 0, stream>>>(seeds, n, loc->shift, loc->hist);
-    locality_scatter_kernel<SeedT><<<kLocBlocks, kLocThreads, 0, stream>>>(seeds, n, loc->shift, loc->hist, row_start, row_deg,
-                                                                          offsets, random_seed, recs);
-    // (the eight XCD shares are each rounded up to whole workgroups)
-    if (M <= 16)
-      sample_uniform_halfwave_kernel<SeedT, ColT, 16><<<ceil_div((int64_t)cap * 16, 256) + 8, 256, 0, stream>>>(
-        row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg, recs);
-    else
-      sample_uniform_halfwave_kernel<SeedT, ColT, 32><<<ceil_div((int64_t)cap * 32, 256) + 8, 256, 0, stream>>>(
-        row_ptr, col, seeds, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg, recs);
+  if (M > 0 && M <= 32 && row_start != nullptr) {
+    // the no-sync walk: K seeds per lane group (WGAMD_SAMPLE_K = 1 | 2 | 4 | 8, default 4), optionally in vertex-grouped
+    // order (see loc_rec): two short launches build the records, the sampling kernel walks them
+    static const int K = [] {
+      const char* e = getenv("WGAMD_SAMPLE_K");
+      const int k   = e ? atoi(e) : 4;
+      return k == 1 || k == 2 ? k : 4;
+    }();
+    const loc_rec* recs = nullptr;
+    if (loc != nullptr) {
+      auto* r = static_cast<loc_rec*>(loc->recs);
+      locality_hist_kernel<SeedT><<<kLocBlocks, kLocThreads, 0, stream>>>(seeds, n, loc->shift, loc->hist);
+      locality_scatter_kernel<SeedT><<<kLocBlocks, kLocThreads, 0, stream>>>(seeds, n, loc->shift, loc->hist, row_start, row_deg,
+                                                                            offsets, random_seed, r);
+      recs = r;
+    }
+    // (grid: a multiple of 8 — the grouped order deals chunk c to XCD c % 8 — bounded by kWalkGrid, striding over the seeds)
+#define WG_MULTI(GW, KK)                                                                                             \
+  sample_uniform_multi_kernel<SeedT, ColT, GW, KK>                                                                   \
+    <<<(int)std::min<int64_t>((ceil_div((int64_t)cap, 4 * (64 / GW) * KK) + 15) / 8 * 8, kWalkGrid), 256, 0, stream>>>(           \
+      col, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg, recs)
+#define WG_MULTI_K(GW)                                                                                               \
+  do {                                                                                                               \
+    if (K == 1) WG_MULTI(GW, 1); else if (K == 2) WG_MULTI(GW, 2); else WG_MULTI(GW, 4);                              \
+  } while (0)
+    // group width = the fan-out where a kernel is built for it (the BASELINE fan-outs), else the next of 8 / 16 / 32
+    static const bool exact = getenv("WGAMD_SAMPLE_EXACT_WIDTH") == nullptr || atoi(getenv("WGAMD_SAMPLE_EXACT_WIDTH")) != 0;
+    if (exact && M == 5) WG_MULTI_K(5);
+    else if (exact && M == 10) WG_MULTI_K(10);
+    else if (exact && M == 15) WG_MULTI_K(15);
+    else if (exact && M == 25) WG_MULTI_K(25);
+    else if (M <= 8) WG_MULTI_K(8);
+    else if (M <= 16) WG_MULTI_K(16);
+    else WG_MULTI_K(32);
+#undef WG_MULTI_K
+#undef WG_MULTI
     WG_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1800,10 +1967,10 @@ void sample_count_enqueue(const int64_t* row_ptr, const void* seeds, bool seeds6
 {
   if (n.host <= 0) return;
   if (seeds64)
-    sample_count_kernel<int64_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
+    sample_count_kernel<int64_t><<<std::min(ceil_div(n.host, 256), kWalkGrid), 256, 0, stream>>>(
       row_ptr, static_cast<const int64_t*>(seeds), n, M, cnt, big_deg, nullptr, 0, 0, row_start, row_deg);
   else
-    sample_count_kernel<int32_t><<<ceil_div(n.host, 256), 256, 0, stream>>>(
+    sample_count_kernel<int32_t><<<std::min(ceil_div(n.host, 256), kWalkGrid), 256, 0, stream>>>(
       row_ptr, static_cast<const int32_t*>(seeds), n, M, cnt, big_deg, nullptr, 0, 0, row_start, row_deg);
   WG_HIP_CHECK(hipGetLastError());
 }

@@ -122,10 +122,36 @@ def sage_layer_fused_preferred(F_: int, N: int) -> bool:
     return N == _padded_width(N) and F_ <= 152
 
 
+# ---- derived-weight caches and HIP-graph capture ---------------------------------------------------------------------------
+# The transposed / padded / bf16-split forms of a layer's weights are cached against the weight tensor's version counter.  A
+# captured training step (cugraph_pyg_amd.loader.PerBatchStep) updates the weights INSIDE the graph: Python does not run on a
+# replay, so (a) while a stream is capturing the derived forms are rebuilt unconditionally — their kernels become part of the
+# graph and run on every replay — and nothing is cached, and (b) every replay bumps `_weights_gen`, which is part of every
+# cache key, so eager code that follows a replay never sees a form derived from the weights of an earlier step.
+_weights_gen = 0
+_capture_epoch = 0       # bumped by begin_capture(): per-capture caches (a hop's transpose) are keyed on it
+
+
+def begin_capture():
+    """Call right before capturing a HIP graph that runs layers over fixed, refilled graph buffers."""
+    global _capture_epoch
+    _capture_epoch += 1
+
+
+def bump_weight_generation():
+    """Invalidate every cached derived weight (call after the weights changed behind autograd's back, e.g. a graph replay)."""
+    global _weights_gen
+    _weights_gen += 1
+
+
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _padded_head(w_t: torch.Tensor, bias, Np: int):
     """``w_t`` [2F, N] and ``bias`` [N] with zero columns up to Np, cached on the weight tensor (version-checked)."""
-    hit = getattr(w_t, "_wgamd_padded", None)
-    key = (w_t._version, w_t.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), Np)
+    hit = getattr(w_t, "_wgamd_padded", None) if not _capturing() else None
+    key = (w_t._version, w_t.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), Np, _weights_gen)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     wp = torch.zeros((w_t.shape[0], Np), dtype=w_t.dtype, device=w_t.device)
@@ -134,10 +160,11 @@ def _padded_head(w_t: torch.Tensor, bias, Np: int):
     if bias is not None:
         bp = torch.zeros(Np, dtype=bias.dtype, device=bias.device)
         bp[:bias.shape[0]] = bias
-    try:
-        w_t._wgamd_padded = (key, wp, bp)
-    except AttributeError:
-        pass
+    if not _capturing():
+        try:
+            w_t._wgamd_padded = (key, wp, bp)
+        except AttributeError:
+            pass
     return wp, bp
 
 
@@ -145,17 +172,18 @@ def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
     """``w_t`` [2F, N] fp32 -> the three bf16 planes ``wgamd_sage_layer_fused_bf16x3`` multiplies with (exact 3-way split:
     hi + mid + lo == w).  Cached ON the weight tensor object together with its version counter, so a layer pays for the
     split once per optimizer step and the cache can never outlive (or be confused with another tensor at) the same address."""
-    hit = getattr(w_t, "_wgamd_planes", None)
-    if hit is not None and hit[0] == w_t._version and hit[1] == w_t.data_ptr():
+    hit = getattr(w_t, "_wgamd_planes", None) if not _capturing() else None
+    if hit is not None and hit[0] == (w_t._version, _weights_gen) and hit[1] == w_t.data_ptr():
         return hit[2]
     K, N = w_t.shape
     planes = torch.empty(L.lib().wgamd_sage_weight_planes_bytes(K, N), dtype=torch.uint8, device=w_t.device)
     L.check(L.lib().wgamd_sage_split_weight_bf16x3(w_t.data_ptr(), w_t.stride(0), K, N, planes.data_ptr(), get_stream()),
             "wgamd_sage_split_weight_bf16x3")
-    try:
-        w_t._wgamd_planes = (w_t._version, w_t.data_ptr(), planes)
-    except AttributeError:      # a tensor subclass without a __dict__: split on every call
-        pass
+    if not _capturing():
+        try:
+            w_t._wgamd_planes = ((w_t._version, _weights_gen), w_t.data_ptr(), planes)
+        except AttributeError:      # a tensor subclass without a __dict__: split on every call
+            pass
     return planes
 
 
@@ -240,6 +268,8 @@ def _wgrad_workspace(n_rows: int, F_: int, N: int, device) -> torch.Tensor:
     """Scratch of the weight-gradient launches (the workgroups' partial sums + the composed self rows), grown on demand and
     kept per device: every use is stream-ordered on the caller's stream."""
     need = L.lib().wgamd_sage_wgrad_workspace_bytes(int(n_rows), F_, N)
+    if _capturing():       # a captured graph must own its scratch: the shared buffer may be re-allocated by a later eager call
+        return torch.empty(int(need) + 4096, dtype=torch.uint8, device=device)
     ws = _WGRAD_WS.get(device)
     if ws is None or ws.numel() < need:
         ws = torch.empty(int(need * 1.15) + 4096, dtype=torch.uint8, device=device)
@@ -448,14 +478,14 @@ def gat_transform_supported(F_: int, heads: int, C: int) -> bool:
 def _gat_weight_tiles(w: torch.Tensor, heads: int) -> torch.Tensor:
     """``w`` [F, H C] in the order ``wgamd_gat_transform_heads_bf16x3`` reads it; cached on the weight like ``sage_weight_planes``."""
     hit = getattr(w, "_wgamd_gat_tiles", None)
-    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+    if hit is not None and hit[0] == (w._version, _weights_gen) and hit[1] == w.data_ptr():
         return hit[2]
     F_, C = w.shape[0], w.shape[1] // heads
     tiles = torch.empty(L.lib().wgamd_gat_transform_weight_bytes(F_, heads, C), dtype=torch.uint8, device=w.device)
     L.check(L.lib().wgamd_gat_transform_weight_tiles(w.data_ptr(), w.stride(0), F_, heads, C, tiles.data_ptr(), get_stream()),
             "wgamd_gat_transform_weight_tiles")
     try:
-        w._wgamd_gat_tiles = (w._version, w.data_ptr(), tiles)
+        w._wgamd_gat_tiles = ((w._version, _weights_gen), w.data_ptr(), tiles)
     except AttributeError:
         pass
     return tiles
@@ -801,7 +831,8 @@ class HopGraph:
     def with_self_loops(self):
         """``(row_ptr, col)`` of the hop with every destination's own input row in front of its sampled neighbours — what
         ``csr_add_self_loop`` (graph_op.h:44-48) does for a square CSR, here with ``self_rows`` as the diagonal; made once."""
-        if getattr(self, "_loops", None) is None:
+        if getattr(self, "_loops", None) is None or self._loops_key != (_capture_epoch if _capturing() else 0):
+            self._loops_key = _capture_epoch if _capturing() else 0
             from . import graph_ops
             n = self.n_rows
             rp, col = graph_ops.add_csr_self_loop(self.row_ptr, self.col)     # row i = [i] ++ row i (csr_add_self_loop) ...
@@ -816,7 +847,10 @@ class HopGraph:
         ``self_t[j]`` = ``n_rows + i`` where input row j is destination i itself (``self_rows`` is injective: every
         destination is a different vertex of its mini-batch), ``2 n_rows`` otherwise — the row indices ``_sage_dx`` reads its
         stacked gradient through."""
-        if self._t is None or self._t[0] != n_src:
+        # (under HIP-graph capture the hop's arrays are fixed buffers REFILLED before every replay: the transpose must be part
+        #  of the graph, once per capture)
+        key = (n_src, _capture_epoch if _capturing() else 0)
+        if self._t is None or self._t[0] != key:
             n, dev = self.n_rows, self.row_ptr.device
             if self.col.shape[0] > 0:
                 row_ptr_t, _, _, col_t = _csr_transpose(self.row_ptr, self.col, n_src, want_col_t=True)
@@ -824,7 +858,7 @@ class HopGraph:
                 row_ptr_t, col_t = torch.zeros(n_src + 1, dtype=torch.int32, device=dev), self.col
             self_t = torch.full((n_src,), 2 * n, dtype=torch.int64, device=dev)
             self_t[self.self_rows] = torch.arange(n, 2 * n, dtype=torch.int64, device=dev)
-            self._t = (n_src, row_ptr_t, col_t, self_t)
+            self._t = (key, row_ptr_t, col_t, self_t)
         return self._t[1:]
 
 
@@ -840,6 +874,9 @@ class LayerGraph:
         return sum(h.n_rows for h in self.hops)
 
 
+_SAGE_DX_SMALL_ROWS = int(os.environ.get("WGAMD_SAGE_DX_SMALL_ROWS", 16384))
+
+
 def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tensor, w_bwd, mean: bool, n_src: int):
     """Gradient of one hop of the SAGE layer w.r.t. its input rows:
     ``dX[j] = sum_{edges (i, j)} dZ[i] W_l / (deg_i if mean) + [j == self(i)] dZ[i] W_r``.
@@ -850,8 +887,12 @@ def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tens
     n, N = gz.shape
     F_ = w_l.shape[1]
     Nq = (N + 3) // 4 * 4
-    row_ptr_t, col_t, self_t = hop.transposed(n_src)
-    if w_bwd is not None and sage_layer_fused_supported(Nq, F_) and n > 0:
+    # A SMALL hop (one mini-batch: PerBatchStep) goes through the dense products + the segmented transposed SpMM instead: in the
+    # transposed hop a popular source is a row of hundreds of entries, which one lane group of the layer kernel walks as a
+    # chain of dependent loads — hidden inside a call group's millisecond launch, 250 us of a mini-batch's step when exposed
+    # (profiles/r06); the segmented SpMM cuts long rows into pieces.
+    if w_bwd is not None and sage_layer_fused_supported(Nq, F_) and n > _SAGE_DX_SMALL_ROWS:
+        row_ptr_t, col_t, self_t = hop.transposed(n_src)
         xs = torch.zeros((2 * n + 1, Nq), dtype=torch.float32, device=gz.device)
         if mean:
             deg = (hop.row_ptr[1:] - hop.row_ptr[:-1]).clamp_(min=1).unsqueeze(1)
@@ -860,6 +901,21 @@ def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tens
             xs[:n, :N] = gz
         xs[n:2 * n, :N] = gz
         return sage_layer_fused_forward(row_ptr_t, col_t, xs, self_t, w_bwd, None, relu=False, mean=False)
+    if n <= _SAGE_DX_SMALL_ROWS and n > 0 and hop.col.shape[0] > 0 and _BWD_SEGMENTS:
+        # the hop's own (kept) transpose + the segmented SpMM; self_rows is injective, so the W_r term is a plain indexed add
+        row_ptr_t, col_t, _ = hop.transposed(n_src)
+        g = gz
+        if mean:
+            g = gz / (hop.row_ptr[1:] - hop.row_ptr[:-1]).clamp_(min=1).unsqueeze(1)
+        gl = g @ w_l
+        E = col_t.shape[0]
+        gx = torch.empty((n_src, F_), dtype=torch.float32, device=gz.device)
+        need = L.lib().wgamd_spmm_csr_segmented_workspace_bytes(E, F_)
+        ws = torch.empty(need, dtype=torch.uint8, device=gz.device)
+        L.check(L.lib().wgamd_spmm_csr_segmented_f32(row_ptr_t.data_ptr(), col_t.data_ptr(), n_src, E, gl.data_ptr(), gl.stride(0), F_,
+                                                     gx.data_ptr(), gx.stride(0), ws.data_ptr(), need, get_stream()),
+                "wgamd_spmm_csr_segmented_f32")
+        return gx.index_add_(0, hop.self_rows, gz @ w_r)
     gx = spmm_csr_backward(hop.row_ptr, hop.col, gz @ w_l, n_src, mean)
     return gx.index_add_(0, hop.self_rows, gz @ w_r)
 
@@ -924,7 +980,7 @@ class _SageLayer(torch.autograd.Function):
             g, act = torch.ops.aten.threshold_backward(g, out, 0), None      # dZ once, read by both gradients
         gwl, gwr = torch.empty_like(w_l, memory_format=torch.contiguous_format), torch.empty_like(w_r, memory_format=torch.contiguous_format)
         gb = torch.empty(N, dtype=torch.float32, device=g.device) if ctx.has_bias else None
-        w_bwd = ctx.conv._weight_bwd() if need_x else None
+        w_bwd = ctx.conv._weight_bwd() if need_x and any(h.n_rows > _SAGE_DX_SMALL_ROWS for h in graph.hops) else None
         gx, at, first = None, 0, True
         for h, agg in zip(graph.hops, ctx.aggs):
             n = h.n_rows
@@ -972,17 +1028,21 @@ class SAGEConv(torch.nn.Module):
         Nq = (N + 3) // 4 * 4
         if not sage_layer_fused_supported(Nq, F_):
             return None
-        key = (wl._version, wl.data_ptr(), wr._version, wr.data_ptr())
-        if self._w_bwd is None or self._w_bwd[0] != key:
+        key = (wl._version, wl.data_ptr(), wr._version, wr.data_ptr(), _weights_gen)
+        if _capturing() or self._w_bwd is None or self._w_bwd[0] != key:
             w = torch.zeros((2 * Nq, F_), dtype=torch.float32, device=wl.device)
             w[:N], w[Nq:Nq + N] = wl.detach(), wr.detach()
+            if _capturing():
+                return w
             self._w_bwd = (key, w)
         return self._w_bwd[1]
 
     def _weight_t(self):
         """``cat([W_l, W_r], 1).t()`` ([2F, N]) for the one-kernel layer, rebuilt when a weight changed."""
         wl, wr = self.lin_l.weight, self.lin_r.weight
-        key = (wl._version, wl.data_ptr(), wr._version, wr.data_ptr())
+        key = (wl._version, wl.data_ptr(), wr._version, wr.data_ptr(), _weights_gen)
+        if _capturing():
+            return torch.cat([wl.detach(), wr.detach()], dim=1).t().contiguous()
         if self._w_t is None or self._w_t[0] != key:
             self._w_t = (key, torch.cat([wl.detach(), wr.detach()], dim=1).t().contiguous())
         return self._w_t[1]
@@ -1317,7 +1377,8 @@ class HeteroConv(torch.nn.Module):
         """(w [in, H C] contiguous, fold(w, att_src) [in, H], fold(w, att_dst) [in, H]) of a relation, rebuilt when a parameter
         changed: ``alpha_src = ((x W).view(H, C) * att).sum(-1) = x (W . att)``."""
         c = self.conv(et)
-        key = tuple((p._version, p.data_ptr()) for p in (c.lin.weight, c.att_src, c.att_dst) + ((c.bias,) if c.bias is not None else ()))
+        key = tuple((p._version, p.data_ptr()) for p in (c.lin.weight, c.att_src, c.att_dst) + ((c.bias,) if c.bias is not None else ())) \
+            + (_weights_gen,)
         hit = self._folded.get(et)
         if hit is None or hit[0] != key:
             with torch.no_grad():

@@ -391,6 +391,26 @@ wholememory_error_code_t wgamd_call_group_hop_rows_batched(const int* offsets, c
                                                            const int64_t* compact_seg_src, int64_t* dst_full, int64_t* dst_compact,
                                                            int* col_full, int* col_compact, void* stream);
 
+/* ONE mini-batch of a PyG-style call group copied into fixed-size buffers (cugraph_pyg_amd.loader.PerBatchStep): the
+ * reference's training loops step the optimizer once per mini-batch (pylibwholegraph/torch/gnn_model.py:119-125); with
+ * every per-batch array at a fixed address and size the whole step can be captured in one hipGraph and replayed per
+ * mini-batch.  For hop k (arrays of n_hops pointers): frontier entries [frontier_seg[k][batch], frontier_seg[k][batch + 1]) of
+ * `offsets[k]` / `row_local[k]` (the hop's CSR over its frontier and the batch-local id of every sampled neighbour) become
+ * row_ptr_out[k] (int32 [row_cap[k] + 1], from 0, row_ptr_out[k][row_cap[k]] = edge_cap[k]: the slack edges are dealt evenly
+ * to the slack rows — at least one: a hop with row_cap[k] live rows overflows — with sources spread over the input rows, so
+ * every entry of the fixed-size arrays is a well-formed edge of a row nobody reads), self_rows_out[k] (int64 [row_cap[k]]:
+ * batch-local id of the entry = its row of x; 0 in the padding), col_out[k] (int32 [edge_cap[k]]: batch-local ids) and, when col_seg_out
+ * is given, col_seg_out[k]: the same sources as rows of a trimmed layer's output, laid out as hop 0's row_cap[0] rows, then
+ * hop 1's row_cap[1], ... .  n_id_out [node_cap] = the mini-batch's vertices (padding repeats the first).  sizes_out
+ * (nullable, int32 [2 n_hops + 2]): live rows and edges per hop, live vertices, 1 if anything exceeded its capacity (the
+ * copy is then truncated).  One launch, no synchronisation. */
+wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* const* offsets, const int* const* row_local,
+                                                      const int* const* frontier_seg, const int* const* frontier_local0,
+                                                      const void* nodes, wholememory_dtype_t id_dtype, const int* node_seg,
+                                                      int batch, const int* row_cap, const int* edge_cap, int node_cap,
+                                                      int* const* row_ptr_out, int64_t* const* self_rows_out, int* const* col_out,
+                                                      int* const* col_seg_out, void* n_id_out, int* sizes_out, void* stream);
+
 /* One hop of a PyG-style call group renumbered for the LAYER that consumes it (cugraph_pyg_amd.loader.CallGroup).  The
  * layer's input rows are `n_segments` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at rows
  * seg_base[s] + start[s][b] + (local id - local0[s][b]); seg_tab is int32 [2 n_segments, n_batches + 1] with row 2s =
@@ -611,7 +631,8 @@ void wgamd_set_weighted_sampling_mode(int pruning, int force_redo);
 /* Uniform hops of a call group whose frontier capacity is at least `min_capacity` entries (and whose fan-out is at most 32)
  * walk the frontier grouped by vertex-id range instead of in list order: identical results (every entry keeps its own PCG
  * streams and output positions), a third of the cache-line fetches where the frontier repeats its hubs batch after batch.
- * Default 2^20 (environment: WGAMD_SAMPLE_LOCALITY=<n>, 0 = never); min_capacity <= 0 switches it off. */
+ * OFF by default (the sampling kernel is bound by VALU issue on an MI355X, not by the lines it fetches: same duration, plus
+ * the two launches that build the order); environment: WGAMD_SAMPLE_LOCALITY=<n>; min_capacity <= 0 switches it off. */
 void wgamd_set_sample_locality_min(int64_t min_capacity);
 
 /* Uniform neighbour sampling WITH replacement (cugraph_pyg `replace=True`; the reference forwards it to libcugraph,

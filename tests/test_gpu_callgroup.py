@@ -18,19 +18,20 @@ def _check(oracle_mod, row_ptr, col, seeds_b, fanouts, rs_b, got):
 
 
 @pytest.mark.parametrize("G,B", [(1, 256), (5, 128), (16, 64), (3, 1)])
-@pytest.mark.parametrize("fanouts", [[25, 10], [15, 10, 5], [5]])
+@pytest.mark.parametrize("fanouts", [[25, 10], [15, 10, 5], [5], [20, 7], [32, 3]])
 @pytest.mark.parametrize("dtype,compact", [(np.int64, True), (np.int64, False), (np.int32, True)])
 @pytest.mark.parametrize("grouped", [False, True])
 def test_call_group_equals_per_batch_oracle(oracle_mod, hiplib, G, B, fanouts, dtype, compact, grouped):
     """``compact``: int64 ids over the 32-bit twin of the column array (WGAMD_HOP_COL_INT32, the default for graphs below
     2^31 vertices) — the same bits as the int64 columns and as the oracle.  ``grouped``: every hop walks its frontier grouped
-    by vertex-id range (wgamd_set_sample_locality_min(1); by default only frontiers of 2^20 entries and more) — same bits."""
+    by vertex-id range (wgamd_set_sample_locality_min(1); off by default) — same bits.  Fan-outs 5 / 10 / 15 / 25 run lane groups
+    exactly as wide as the fan-out, the others the next of 8 / 16 / 32 (sample_uniform_multi_kernel)."""
     import torch
-    hiplib.wgamd_set_sample_locality_min(1 if grouped else 1 << 20)
+    hiplib.wgamd_set_sample_locality_min(1 if grouped else 0)
     try:
         _call_group_equals_per_batch_oracle(oracle_mod, G, B, fanouts, dtype, compact)
     finally:
-        hiplib.wgamd_set_sample_locality_min(1 << 20)
+        hiplib.wgamd_set_sample_locality_min(0)
 
 
 def _call_group_equals_per_batch_oracle(oracle_mod, G, B, fanouts, dtype, compact):
