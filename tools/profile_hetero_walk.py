@@ -9,14 +9,10 @@ from cugraph_pyg_amd.sampler.sampler import HeteroNeighborSampler
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(11)
 n = {"paper": 736_389, "author": 1_134_649, "institution": 8_740, "field_of_study": 59_965}
-rel = {("author", "writes", "paper"): 7_145_660, ("paper", "cites", "paper"): 5_416_271,
-       ("paper", "has_topic", "field_of_study"): 7_505_078, ("author", "affiliated_with", "institution"): 1_043_998,
-       ("paper", "rev_writes", "author"): 7_145_660, ("field_of_study", "rev_has_topic", "paper"): 7_505_078}
-gs = GraphStore()
-for (s_, r_, d_), m in rel.items():
-    src = (torch.rand(m, generator=g, device=dev) ** 2 * n[s_]).long().clamp_(max=n[s_] - 1)
-    dst = (torch.rand(m, generator=g, device=dev) ** 2 * n[d_]).long().clamp_(max=n[d_] - 1)
-    gs[(s_, r_, d_), "coo", False, (n[s_], n[d_])] = torch.stack([src, dst])
+import bench_mag
+rel = bench_mag.MAG_RELS_R5 if os.environ.get("RELS", "all") == "r5" else bench_mag.MAG_RELS     # all 8 directed edge types by default
+bench_mag.build_mag_like(dev, n, rel)
+gs = bench_mag.build_mag_like.graph_store
 B, G = 1024, int(os.environ.get("G", 32))
 smp = HeteroNeighborSampler(gs._hetero_graphs, {et: [25, 10] for et in rel}, local_seeds_per_call=B * G, num_nodes=n)
 walk = smp._call_group_walk(B, G)
