@@ -606,7 +606,7 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
                       f"(C oracle with OpenMP + torch CPU linear), {dt:.1f} s"}
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")
 
 
 def load_pmc(kernel_prefix, want_void=True, workload="products"):

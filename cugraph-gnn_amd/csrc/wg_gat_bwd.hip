@@ -316,7 +316,40 @@ wholememory_error_code_t gat_csr_bwd(const char* op, const int* row_ptr, const i
 // destination that drew it (a sampled hop has at most `fan-out` edges per row: no long-row path).  The sums' order is not
 // fixed: results are reproducible to fp32 rounding, not bit for bit.  Semantics: torch_geometric.nn.GATConv's message /
 // aggregate (pylibwholegraph/torch/gnn_model.py:45-59) in the aggregate-first form of DESIGN.md section 3.5.
-template <int H>
+// Sum / maximum over a lane group of 2^LG lanes, the result in every lane.  Inside a 16-lane row the butterfly runs on DPP
+// moves folded into VALU instructions (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: after the first
+// two steps a quad is uniform, so the mirrors act as xor 4 and xor 8); the steps across rows (groups of 32 / 64 lanes) are
+// permlane swaps — nothing goes through the LDS crossbar.  The generic `__shfl_xor` loop is ds_bpermute + wait + add per step: 5 LDS round trips per reduction
+// in a 32-lane group, and this kernel makes H of them per edge — most of its issue time (round 6).  LG < 0: runtime width.
+template <int LG, bool MAX>
+__device__ __forceinline__ float group_reduce(float v, int lanes_rt)
+{
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+#define WG_DPP(ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
+  if constexpr (LG < 0) {
+    for (int d = lanes_rt >> 1; d >= 1; d >>= 1) v = op(v, __shfl_xor(v, d, 64));
+  } else {
+    if constexpr (LG >= 1) v = op(v, WG_DPP(0xB1));
+    if constexpr (LG >= 2) v = op(v, WG_DPP(0x4E));
+    if constexpr (LG >= 3) v = op(v, WG_DPP(0x141));
+    if constexpr (LG >= 4) v = op(v, WG_DPP(0x140));
+    // across rows: gfx950's v_permlane16_swap / v_permlane32_swap (VALU; swap the odd rows / the upper half of the first
+    // operand with the even rows / the lower half of the second): with both operands = v, a lane finds its partner's value in
+    // the first result when it sits in an odd row (upper half), in the second otherwise
+    if constexpr (LG >= 5) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v            = op(v, __uint_as_float((__lane_id() & 16) ? r[0] : r[1]));
+    }
+    if constexpr (LG >= 6) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v            = op(v, __uint_as_float((__lane_id() & 32) ? r[0] : r[1]));
+    }
+  }
+#undef WG_DPP
+  return v;
+}
+
+template <int H, int LG>
 __global__ void __launch_bounds__(256)
 gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int64_t n_rows,
                                const float* __restrict__ x, int64_t ldx, int F, const float* __restrict__ a_src,
@@ -331,6 +364,7 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
   // weights are loaded / computed once, by that lane (coalesced), and broadcast where the whole group needs them; the
   // neighbour rows of a chunk are requested four at a time.
   constexpr int EIF     = 4;
+  if constexpr (LG >= 0) log2_lanes = LG;
   const int lanes       = 1 << log2_lanes;
   const int64_t tid     = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int sub         = (int)(tid & (lanes - 1));
@@ -339,14 +373,8 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
   const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> log2_lanes;
   const bool live       = sub * 4 < F;
   const int f0          = live ? sub * 4 : 0;
-  auto group_sum = [&](float v) {
-    for (int d = lanes >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-  };
-  auto group_max = [&](float v) {
-    for (int d = lanes >> 1; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-    return v;
-  };
+  auto group_sum = [&](float v) { return group_reduce<LG, false>(v, lanes); };
+  auto group_max = [&](float v) { return group_reduce<LG, true>(v, lanes); };
   for (int64_t row = group; row < n_rows; row += ngroups) {
     const int s = row_ptr[row], e = row_ptr[row + 1];
     if (s == e) continue;   // (no edge: nothing flows back; uniform over the lane group)
@@ -649,10 +677,16 @@ extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int*
     while ((1 << l2) < F / 4 && l2 < 6) l2++;
     const int64_t groups_per_block = 256 >> l2;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + groups_per_block - 1) / groups_per_block, 256 * 16));
-#define WG_GAT_AGG_BWD(HH)                                                                                                        \
-  gat_aggregate_heads_bwd_kernel<HH><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope, dst_rows, \
-                                                           src_ids, dst_ids, terms_by_id, grad_agg, ldg, de, grad_a_src, grad_a_dst, \
-                                                           grad_x, ldgx, l2, stats)
+#define WG_GAT_AGG_BWD_(HH, LL)                                                                                                       \
+  gat_aggregate_heads_bwd_kernel<HH, LL><<<grid, 256, 0, st>>>(row_ptr, col, n_rows, x, ldx, F, a_src, a_dst, negative_slope,          \
+                                                               dst_rows, src_ids, dst_ids, terms_by_id, grad_agg, ldg, de, grad_a_src, \
+                                                               grad_a_dst, grad_x, ldgx, l2, stats)
+    // (the group width is a compile-time constant for rows of 32 floats and more: the reductions then run on DPP moves)
+#define WG_GAT_AGG_BWD(HH)                                                                                                         \
+  do {                                                                                                                             \
+    if (l2 == 3) WG_GAT_AGG_BWD_(HH, 3); else if (l2 == 4) WG_GAT_AGG_BWD_(HH, 4); else if (l2 == 5) WG_GAT_AGG_BWD_(HH, 5);       \
+    else if (l2 == 6) WG_GAT_AGG_BWD_(HH, 6); else WG_GAT_AGG_BWD_(HH, -1);                                                        \
+  } while (0)
     switch (H) {
       case 1: WG_GAT_AGG_BWD(1); break;
       case 2: WG_GAT_AGG_BWD(2); break;
@@ -660,6 +694,7 @@ extern "C" wholememory_error_code_t wgamd_gat_aggregate_heads_bwd_f32(const int*
       default: WG_GAT_AGG_BWD(8); break;
     }
 #undef WG_GAT_AGG_BWD
+#undef WG_GAT_AGG_BWD_
     WG_HIP_CHECK(hipGetLastError());
   });
 }
