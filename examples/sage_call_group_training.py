@@ -7,7 +7,11 @@ group's trimmed layer graph — forward AND backward (`wholegraph_amd.nn._SageLa
 On the products-like workload of bench.py this loop moves 2.3 G sampled edges/s through forward + loss + backward + SGD
 (`variants.train_step`); the per-mini-batch loop of the other example is bound by its launches.
 
-    python examples/sage_call_group_training.py [--nodes 200000] [--epochs 3]
+`--per-batch` keeps the reference's optimizer semantics instead — ONE step per mini-batch (pylibwholegraph/torch/gnn_model.py:
+119-125) — while still sampling per call group: `cugraph_pyg_amd.loader.PerBatchStep` stages every mini-batch of a group into
+fixed-size buffers with one launch and replays the whole step (forward, loss, backward, Adam) as one HIP graph.
+
+    python examples/sage_call_group_training.py [--nodes 200000] [--epochs 3] [--per-batch]
 """
 import argparse
 import os
@@ -21,7 +25,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 from cugraph_pyg_amd.data import FeatureStore, GraphStore  # noqa: E402
-from cugraph_pyg_amd.loader import NeighborLoader  # noqa: E402
+from cugraph_pyg_amd.loader import NeighborLoader, PerBatchStep  # noqa: E402
 from wholegraph_amd.nn import SAGEConv  # noqa: E402
 
 
@@ -35,6 +39,8 @@ def main():
     ap.add_argument("--group", type=int, default=16, help="mini-batches per call group (= per optimizer step)")
     ap.add_argument("--fanout", type=int, nargs="+", default=[25, 10])
     ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--per-batch", action="store_true", help="one optimizer step per mini-batch (the reference's semantics) through "
+                                                             "loader.PerBatchStep instead of one per call group")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "needs an MI355X (there is no CPU fallback)"
     dev = torch.device("cuda")
@@ -57,7 +63,9 @@ def main():
     L = len(args.fanout)
     dims = [args.features] + [128] * (L - 1) + [args.classes]
     convs = torch.nn.ModuleList(SAGEConv(dims[i], dims[i + 1]) for i in range(L)).to(dev)
-    opt = torch.optim.Adam(convs.parameters(), lr=0.01)
+    opt = torch.optim.Adam(convs.parameters(), lr=0.01, capturable=args.per_batch)
+    if args.per_batch:
+        return train_per_batch(args, loader, convs, opt, community, x, L)
     for epoch in range(args.epochs):
         t0, total, correct, seen, edges = time.perf_counter(), 0.0, 0, 0, 0
         for grp in loader.call_groups():
@@ -78,6 +86,41 @@ def main():
         print(f"epoch {epoch}: loss {total / seen:.4f}  train acc {correct / seen:.3f}  {edges / dt / 1e6:.1f} M sampled edges/s "
               f"(sampling + forward + backward + Adam, one step per {args.group} mini-batches), {dt:.2f} s")
     return total / seen, correct / seen
+
+
+def train_per_batch(args, loader, convs, opt, community, table, L):
+    """One optimizer step per mini-batch: the step below is what a reference user writes inside `for batch in loader`; it is
+    captured once as a HIP graph over the staged mini-batch's fixed-size buffers and replayed for every mini-batch."""
+    def step(batch):
+        opt.zero_grad(set_to_none=True)
+        h = batch.x                                                 # LazyRows over the staged n_id
+        for j, conv in enumerate(convs):
+            h = conv(h, batch.layer_graph(j), act="relu" if j + 1 < L else None)
+        B = batch.batch_size
+        y = community[batch.seeds]
+        mask = batch.seed_mask[:B]                                  # a ragged last mini-batch has fewer than B live seeds
+        loss = (F.cross_entropy(h[:B], y, reduction="none") * mask).sum() / batch.n_live_seeds
+        loss.backward()
+        opt.step()
+        return loss.detach(), ((h[:B].argmax(1) == y).float() * mask).sum()
+    stepper = PerBatchStep(step, table=table, optimizer=opt)
+    for epoch in range(args.epochs):
+        t0, seen, edges, steps = time.perf_counter(), 0, 0, 0
+        total = torch.zeros((), device=table.device)
+        correct = torch.zeros((), device=table.device)
+        for grp in loader.call_groups():
+            for b in range(grp.n_batches):
+                loss, ok = stepper(grp, b)
+                total += loss                                       # (device-side running sums: no read-back per step)
+                correct += ok
+            seen += grp.num_seeds
+            edges += grp.num_edges
+            steps += grp.n_batches
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"epoch {epoch}: mean step loss {float(total) / steps:.4f}  train acc {float(correct) / seen:.3f}  "
+              f"{edges / dt / 1e6:.1f} M sampled edges/s ({steps} Adam steps of {args.batch_size} seeds, {dt / steps * 1e3:.3f} ms each), {dt:.2f} s")
+    return float(total) / steps, float(correct) / seen
 
 
 if __name__ == "__main__":

@@ -38,6 +38,17 @@ def test_call_group_training_example_learns(hiplib, monkeypatch):
     assert loss < 1.5 and acc > 0.6, (loss, acc)
 
 
+def test_per_mini_batch_training_example_learns(hiplib, monkeypatch):
+    """The same example with `--per-batch`: one Adam step per mini-batch of 256 seeds (the reference's semantics) through
+    loader.PerBatchStep — sample per call group, one staging launch + one HIP-graph replay per step, a ragged last mini-batch."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import sage_call_group_training as ex
+    monkeypatch.setattr(sys, "argv", ["x", "--nodes", "30000", "--epochs", "3", "--batch-size", "256", "--group", "4",
+                                      "--fanout", "10", "5", "--per-batch"])
+    loss, acc = ex.main()
+    assert loss < 1.5 and acc > 0.6, (loss, acc)
+
+
 def test_hetero_gat_call_group_example_learns_and_lazy_equals_gathered(hiplib, monkeypatch):
     """examples/hetero_gat_call_groups.py: HeteroConv{GATConv} over heterogeneous call groups — trains relation by relation
     (autograd), infers through the one-kernel relations reading the feature tables through the node lists; the class signal
