@@ -528,6 +528,43 @@ __global__ void tile_weight_kernel(const float* __restrict__ w_t, int64_t ldw, i
   }
 }
 
+// The same two orders straight from a layer's parameters: the [K = 2F, N] operand is [W_l | W_r]^T (torch.nn.Linear keeps
+// [N, F] row-major), its columns and the bias zero-padded from N to Np — ONE launch instead of cat / transpose / pad / split
+// (ten launches per layer pair in a captured per-mini-batch training step, where the weights change on every replay).
+__global__ void layer_weight_kernel(const float* __restrict__ w_l, int64_t ldl, const float* __restrict__ w_r, int64_t ldr,
+                                    const float* __restrict__ bias, int F, int N, int Np, int KS, int half,
+                                    void* __restrict__ planes_, float* __restrict__ bias_out)
+{
+  auto w_at = [&](int k, int n) -> float {
+    if (n >= N || k >= 2 * F) return 0.f;
+    return k < F ? w_l[(int64_t)n * ldl + k] : w_r[(int64_t)n * ldr + (k - F)];
+  };
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  if (bias_out)
+    for (int64_t n = tid; n < Np; n += stride) bias_out[n] = (bias && n < N) ? bias[n] : 0.f;
+  if (half) {
+    uint32_t* planes    = static_cast<uint32_t*>(planes_);
+    const int64_t total = (int64_t)KS * Np * 8;
+    for (int64_t i = tid; i < total; i += stride) {
+      const int kk2 = (int)(i & 7), n = (int)((i >> 3) % Np), ks = (int)((i >> 3) / Np);
+      const int k0  = ks * 16 + kk2 * 2;
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split3(w_at(k0, n), h0, m0, l0);
+      split3(w_at(k0 + 1, n), h1, m1, l1);
+      planes[i]             = pack_hi16(h0, h1);
+      planes[total + i]     = pack_hi16(m0, m1);
+      planes[2 * total + i] = pack_hi16(l0, l1);
+    }
+  } else {
+    float* tiles        = static_cast<float*>(planes_);
+    const int64_t total = (int64_t)KS * Np * 16;
+    for (int64_t i = tid; i < total; i += stride) {
+      const int kk = (int)(i & 15), n = (int)((i >> 4) % Np), ks = (int)((i >> 4) / Np);
+      tiles[i]     = w_at(ks * 16 + kk, n);
+    }
+  }
+}
+
 constexpr size_t kLdsBudget = 160 * 1024;
 __host__ inline size_t lds_bytes(int F, int TR) { return (size_t)(2 * TR * row_stride_dw(F) + 16 + 4 * kScratchDw + 16) * 4; }
 __host__ inline size_t lds_bytes_half(int F) { return (size_t)(2 * 64 * row_stride_half_dw(F) + 16 + 4 * kScratchDw + 16) * 4; }
@@ -650,6 +687,22 @@ extern "C" wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* 
       split_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_t, ldw, K, N, KS, static_cast<uint32_t*>(planes));
     else
       tile_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_t, ldw, K, N, KS, static_cast<float*>(planes));
+    WG_HIP_CHECK(hipGetLastError());
+  });
+}
+
+extern "C" wholememory_error_code_t wgamd_sage_layer_weight_planes(const float* w_l, int64_t ldl, const float* w_r, int64_t ldr,
+                                                                  const float* bias, int F, int N, int Np, void* planes,
+                                                                  float* bias_out, void* stream)
+{
+  using namespace wgamd;
+  return guarded("wgamd_sage_layer_weight_planes", [&] {
+    WG_REQUIRE_INPUT(w_l && w_r && planes && F > 0 && N > 0 && Np >= N && ldl >= F && ldr >= F, "bad weights");
+    const int K = 2 * F, KS = (K + 15) / 16;
+    const int half      = use_half_tiles(F) ? 1 : 0;
+    const int64_t total = (int64_t)KS * Np * 16;
+    const int grid      = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    layer_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_l, ldl, w_r, ldr, bias, F, N, Np, KS, half, planes, bias_out);
     WG_HIP_CHECK(hipGetLastError());
   });
 }

@@ -187,8 +187,23 @@ def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
     return planes
 
 
+def sage_layer_planes(w_l: torch.Tensor, w_r: torch.Tensor, bias, Np: int):
+    """``(planes, padded bias, N)`` of a layer straight from its ``torch.nn.Linear`` parameters in ONE launch
+    (``wgamd_sage_layer_weight_planes``) — what ``sage_layer_fused_forward(prepared=...)`` takes instead of deriving the
+    transposed / padded / split forms with half a dozen framework launches.  Not cached: made for captured training steps,
+    whose weights change on every replay."""
+    N, F_ = w_l.shape
+    planes = torch.empty(L.lib().wgamd_sage_weight_planes_bytes(2 * F_, Np), dtype=torch.uint8, device=w_l.device)
+    bias_p = torch.empty(Np, dtype=torch.float32, device=w_l.device) if (bias is not None or Np != N) else None
+    L.check(L.lib().wgamd_sage_layer_weight_planes(w_l.data_ptr(), w_l.stride(0), w_r.data_ptr(), w_r.stride(0),
+                                                   None if bias is None else bias.data_ptr(), F_, N, Np, planes.data_ptr(),
+                                                   None if bias_p is None else bias_p.data_ptr(), get_stream()),
+            "wgamd_sage_layer_weight_planes")
+    return planes, bias_p, N
+
+
 def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None, out=None,
-                             precision=None, agg_out=None):
+                             precision=None, agg_out=None, prepared=None):
     """A whole SAGEConv layer over a sampled hop in ONE kernel: ``act([mean_j X[col_j] | X[self_i]] @ w_t + bias)`` with
     ``X[r] = x[src_ids[r]]`` when ``src_ids`` is given (``x`` is then the global feature table: the feature fetch is fused
     in too).  ``w_t`` = ``cat([W_l, W_r], 1).t()`` ([2F, N], contiguous).  The ``[n_rows, 2F]`` operand never leaves LDS.
@@ -197,12 +212,21 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     (``wgamd_sage_layer_fused_bf16x3_train``; same bits in ``out``) — needs ``sage_layer_train_supported``."""
     _check_csr(row_ptr, col)
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
-    assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
     assert self_rows.dtype == torch.int64 and self_rows.is_contiguous()
-    n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], w_t.shape[1]
+    if prepared is not None:      # (planes, padded bias, N) of sage_layer_planes: the bf16x3 kernel's operand, ready made
+        n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], prepared[2]
+        assert sage_layer_fused_supported(F_, _padded_width(N)) and _pick_precision(F_, _padded_width(N), precision) == "bf16x3"
+        bias = prepared[1]
+    else:
+        assert w_t.dtype == torch.float32 and w_t.dim() == 2 and w_t.stride(1) == 1 and w_t.shape[0] == 2 * x.shape[1]
+        n_rows, F_, N = row_ptr.shape[0] - 1, x.shape[1], w_t.shape[1]
     Np = _padded_width(N) if sage_layer_fused_supported(F_, N) else N
     user_out = None
-    if Np != N:
+    if Np != N and prepared is not None:
+        if out is not None and out.stride(0) != Np:
+            assert out.shape == (n_rows, N) and out.dtype == torch.float32, "out must be float32 [n_rows, N]"
+            user_out, out = out, None
+    elif Np != N:
         # zero weight columns / bias entries up to the width the kernel runs at (cached on the weight like its planes); the
         # kernel then WRITES Np columns per row.  A caller's `out` is written in place only when it is the [:, :N] view of
         # an explicit [n_rows, Np] scratch (row stride == Np: columns N..Np-1 are the caller's padding by construction);
@@ -230,7 +254,7 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
         "a peer-mapped table is read by the bf16x3 layer kernel only"
     if (sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3"
             and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):      # its epilogue stores 16 B per lane
-        planes = sage_weight_planes(w_t)
+        planes = prepared[0] if prepared is not None else sage_weight_planes(w_t)
         if agg_out is not None:
             assert agg_out.shape == (n_rows, F_) and agg_out.dtype == torch.float32 and agg_out.stride(1) == 1
             L.check(L.lib().wgamd_sage_layer_fused_bf16x3_train(
@@ -927,13 +951,19 @@ def _sage_layer_launch(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean):
     Np = _padded_width(N)
     keep = ctx is not None and any(ctx.needs_input_grad[:4])
     buf = torch.empty((graph.n_rows, Np), dtype=torch.float32, device=src.device)
-    w_t, aggs, at = conv._weight_t(), [], 0
+    # under HIP-graph capture (a per-mini-batch training step: the weights change on every replay) the kernel's operand is made
+    # from the parameters by ONE launch; otherwise the cached transposed / padded / split forms
+    prepared = None
+    if _capturing() and sage_layer_fused_supported(F_, Np) and _pick_precision(F_, Np, None) == "bf16x3" \
+            and w_l.stride(1) == 1 and w_r.stride(1) == 1:
+        prepared = sage_layer_planes(w_l, w_r, bias, Np)
+    w_t, aggs, at = (None if prepared is not None else conv._weight_t()), [], 0
     for h in graph.hops:
         n = h.n_rows
         agg = torch.empty((n, F_), dtype=torch.float32, device=src.device) if keep and n > 0 else None
         if n > 0:
             sage_layer_fused_forward(h.row_ptr, h.col, src, h.self_rows, w_t, bias, relu=relu, mean=mean, src_ids=ids,
-                                     out=buf[at:at + n, :N], agg_out=agg)
+                                     out=buf[at:at + n, :N], agg_out=agg, prepared=prepared)
         aggs.append(agg)
         at += n
     out = buf[:, :N]

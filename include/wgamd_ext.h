@@ -572,6 +572,12 @@ wholememory_error_code_t wgamd_sage_layer_fused_f32(const int* row_ptr, const in
  * 160 KB of LDS (F <= 208), N in {64, 128, 256}: wgamd_sage_layer_bf16x3_supported.  Inf/NaN features give NaN rows. */
 size_t wgamd_sage_weight_planes_bytes(int K, int N);
 int wgamd_sage_layer_bf16x3_supported(int F, int N);
+/* The same buffer (and the padded bias) straight from a layer's parameters in torch.nn.Linear's layout — w_l, w_r [N, F]
+ * row-major, bias [N] (nullable): the operand [W_l | W_r]^T with its columns zero-padded from N to Np, one launch.  `planes`
+ * holds wgamd_sage_weight_planes_bytes(2F, Np) bytes, `bias_out` (nullable) Np floats. */
+wholememory_error_code_t wgamd_sage_layer_weight_planes(const float* w_l, int64_t ldl, const float* w_r, int64_t ldr,
+                                                        const float* bias, int F, int N, int Np, void* planes, float* bias_out,
+                                                        void* stream);
 wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* w_t, int64_t ldw, int K, int N, void* planes,
                                                         void* stream);
 wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,
