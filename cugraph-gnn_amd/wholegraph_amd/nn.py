@@ -864,7 +864,7 @@ class HopGraph:
             self._loops = (rp, col)
         return self._loops
 
-    def transposed(self, n_src: int):
+    def transposed(self, n_src: int, need_self: bool = True):
         """The hop seen from its ``n_src`` input rows, for the backward pass — computed once per hop and kept, whichever layers
         and however many backward calls use it: ``(row_ptr_t, col_t, self_t)`` with the source-major CSR of
         ``wgamd_csr_transpose_i32`` (entries = destination rows, hop order inside a source: deterministic sums) and
@@ -880,10 +880,13 @@ class HopGraph:
                 row_ptr_t, _, _, col_t = _csr_transpose(self.row_ptr, self.col, n_src, want_col_t=True)
             else:
                 row_ptr_t, col_t = torch.zeros(n_src + 1, dtype=torch.int32, device=dev), self.col
+            self._t = [key, row_ptr_t, col_t, None]
+        if need_self and self._t[3] is None:     # (only the layer kernel over the transposed hop reads it: three launches)
+            n, dev = self.n_rows, self.row_ptr.device
             self_t = torch.full((n_src,), 2 * n, dtype=torch.int64, device=dev)
             self_t[self.self_rows] = torch.arange(n, 2 * n, dtype=torch.int64, device=dev)
-            self._t = (key, row_ptr_t, col_t, self_t)
-        return self._t[1:]
+            self._t[3] = self_t
+        return tuple(self._t[1:])
 
 
 class LayerGraph:
@@ -927,7 +930,7 @@ def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tens
         return sage_layer_fused_forward(row_ptr_t, col_t, xs, self_t, w_bwd, None, relu=False, mean=False)
     if n <= _SAGE_DX_SMALL_ROWS and n > 0 and hop.col.shape[0] > 0 and _BWD_SEGMENTS:
         # the hop's own (kept) transpose + the segmented SpMM; self_rows is injective, so the W_r term is a plain indexed add
-        row_ptr_t, col_t, _ = hop.transposed(n_src)
+        row_ptr_t, col_t, _ = hop.transposed(n_src, need_self=False)
         g = gz
         if mean:
             g = gz / (hop.row_ptr[1:] - hop.row_ptr[:-1]).clamp_(min=1).unsqueeze(1)

@@ -181,7 +181,7 @@ def test_one_captured_step_has_the_fp64_gradients_of_its_mini_batch(hiplib, fano
         for b, d in enumerate(datas):
             loss = stepper(grp, b)
             ref_loss, ref = _fp64_grads(model, d, labels, _hidden_masks(model, stepper.batch))
-            assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (n, float(loss), ref_loss)
+            assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (n, float(loss.detach()), ref_loss)
             for c, (gl, gr, gb) in zip(model, ref):
                 _close(c.lin_l.weight.grad, gl, ("lin_l", n))
                 _close(c.lin_r.weight.grad, gr, ("lin_r", n))
