@@ -392,9 +392,9 @@ __global__ void __launch_bounds__(256) sample_uniform_halfwave_kernel(const int6
 // GW = the fan-out lanes wide (10 -> six seeds per wave where the 16-lane groups of sample_uniform_halfwave_kernel hold
 // four with six lanes idle; fan-out 5 -> twelve), and takes K consecutive seeds whose loads are issued stage by stage.
 // Same draws (stream 32 i_local + t), same output positions.
-template <typename SeedT, typename ColT, int GW, int K>
+template <typename SeedT, typename ColT, int GW, int K, bool EXACT>
 __global__ void __launch_bounds__(256)
-sample_uniform_multi_kernel(const ColT* __restrict__ col, dev_count n_, int M, rng_plan rng, const int* __restrict__ offsets,
+sample_uniform_multi_kernel(const ColT* __restrict__ col, dev_count n_, int M_rt, rng_plan rng, const int* __restrict__ offsets,
                             ColT* __restrict__ dst, int* __restrict__ src_lid, int64_t* __restrict__ edge_gid,
                             const int64_t* __restrict__ row_start, const int* __restrict__ row_deg,
                             const loc_rec* __restrict__ recs)
@@ -402,6 +402,9 @@ sample_uniform_multi_kernel(const ColT* __restrict__ col, dev_count n_, int M, r
   constexpr int kGPW    = 64 / GW;        // lane groups per wave (the lanes past kGPW * GW idle)
   constexpr int kGroups = 4 * kGPW;       // lane groups per workgroup
   constexpr int kRounds = GW <= 2 ? 1 : GW <= 4 ? 2 : GW <= 8 ? 3 : GW <= 16 ? 4 : 5;   // pointer jumping: ceil(log2 GW)
+  // EXACT: the group is exactly as wide as the fan-out — M is a compile-time constant (the all-pairs loop unrolls, every lane
+  // of a group draws)
+  const int M    = EXACT ? GW : M_rt;
   const int n    = n_.get();
   const int lane = threadIdx.x & 63;
   const int grp  = lane / GW;             // (GW is a compile-time constant: a multiply and a shift)
@@ -478,11 +481,17 @@ sample_uniform_multi_kernel(const ColT* __restrict__ col, dev_count n_, int M, r
       if (pick && hl < M) r = r_draw[k] % (N[k] - hl);
       const int tail = N[k] - hl - 1;
       int p1 = -1, p2 = -1;
-      for (int s = 0; s + 1 < M; s++) {
+      auto step = [&](int s) {
         const int rs    = __shfl(r, hb + s, 64);
         const bool prev = s < hl;
         p1 = (prev && rs == r) ? s : p1;
         p2 = (prev && rs == tail) ? s : p2;
+      };
+      if constexpr (EXACT) {
+#pragma unroll
+        for (int s = 0; s + 1 < GW; s++) step(s);
+      } else {
+        for (int s = 0; s + 1 < M; s++) step(s);
       }
       int root = p2 >= 0 ? p2 : hl;
 #pragma unroll
@@ -1595,7 +1604,7 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
     }
     // (grid: a multiple of 8 — the grouped order deals chunk c to XCD c % 8 — bounded by kWalkGrid, striding over the seeds)
 #define WG_MULTI(GW, KK)                                                                                             \
-  sample_uniform_multi_kernel<SeedT, ColT, GW, KK>                                                                   \
+  sample_uniform_multi_kernel<SeedT, ColT, GW, KK, WG_EXACT>                                                          \
     <<<(int)std::min<int64_t>((ceil_div((int64_t)cap, 4 * (64 / GW) * KK) + 15) / 8 * 8, kWalkGrid), 256, 0, stream>>>(           \
       col, n, M, random_seed, offsets, dst, lid, gid, row_start, row_deg, recs)
 #define WG_MULTI_K(GW)                                                                                               \
@@ -1604,13 +1613,19 @@ void uniform_launch(const int64_t* row_ptr, const ColT* col, const SeedT* seeds,
   } while (0)
     // group width = the fan-out where a kernel is built for it (the BASELINE fan-outs), else the next of 8 / 16 / 32
     static const bool exact = getenv("WGAMD_SAMPLE_EXACT_WIDTH") == nullptr || atoi(getenv("WGAMD_SAMPLE_EXACT_WIDTH")) != 0;
+#define WG_EXACT true
     if (exact && M == 5) WG_MULTI_K(5);
     else if (exact && M == 10) WG_MULTI_K(10);
     else if (exact && M == 15) WG_MULTI_K(15);
     else if (exact && M == 25) WG_MULTI_K(25);
-    else if (M <= 8) WG_MULTI_K(8);
-    else if (M <= 16) WG_MULTI_K(16);
-    else WG_MULTI_K(32);
+    else {
+#undef WG_EXACT
+#define WG_EXACT false
+      if (M <= 8) WG_MULTI_K(8);
+      else if (M <= 16) WG_MULTI_K(16);
+      else WG_MULTI_K(32);
+    }
+#undef WG_EXACT
 #undef WG_MULTI_K
 #undef WG_MULTI
     WG_HIP_CHECK(hipGetLastError());
