@@ -108,7 +108,9 @@ class PerBatchStep:
     loss, ``loss.backward()``, ``optimizer.step()`` — over ``batch.x`` / ``batch.layer_graph(j)`` / ``batch.seeds``; it must not
     synchronise or read values back (it runs under HIP-graph capture) and every tensor it reads from outside must keep its
     address (labels tables, the model's parameters: true of ``torch.optim`` in-place updates).  Optimizers with host-side step
-    counters need their ``capturable=True`` form.
+    counters need their ``capturable=True`` form.  Layers: ``wholegraph_amd.nn.SAGEConv`` (its derived weights are rebuilt inside
+    the graph) and anything made of plain torch ops; ``nn.GATConv`` / ``nn.HeteroConv`` refuse capture (their derived-weight
+    caches live in Python).
 
     ``table``: the float32 feature table held whole on this device (then ``batch.x`` is a ``LazyRows``: the first layer reads
     it through ``batch.n_id``).  ``margin``: capacities = the largest mini-batch of the first call group x margin; a later

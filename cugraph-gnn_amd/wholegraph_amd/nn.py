@@ -1204,6 +1204,11 @@ class GATConv(torch.nn.Module):
         return torch.relu(out) if act == "relu" else out
 
     def forward(self, x, graph, act=None):
+        if _capturing():
+            # (the derived forms of this layer's parameters — folded attention vectors, weight tiles, pooled buffers — are cached
+            #  in Python against the parameters' versions: a replayed graph would keep using the ones of the capture)
+            raise RuntimeError("wholegraph_amd.nn.%s is not supported under HIP-graph capture (loader.PerBatchStep): its "
+                               "derived-weight caches are not capture-safe; SAGEConv layers are" % type(self).__name__)
         from . import graph_ops
         if isinstance(graph, LayerGraph):
             if self.in_channels % 4 == 0 and self.in_channels <= 256 and self.heads in (1, 2, 4, 8):
@@ -1577,6 +1582,11 @@ class HeteroConv(torch.nn.Module):
         return c.heads * c.out_channels if c.concat else c.out_channels
 
     def forward(self, x_dict, graph, act=None):
+        if _capturing():
+            # (the derived forms of this layer's parameters — folded attention vectors, weight tiles, pooled buffers — are cached
+            #  in Python against the parameters' versions: a replayed graph would keep using the ones of the capture)
+            raise RuntimeError("wholegraph_amd.nn.%s is not supported under HIP-graph capture (loader.PerBatchStep): its "
+                               "derived-weight caches are not capture-safe; SAGEConv layers are" % type(self).__name__)
         if isinstance(graph, HeteroLayerGraph):
             needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
             plain = all(self.conv(et).concat and not self.conv(et).add_self_loops for et in self.edge_types)

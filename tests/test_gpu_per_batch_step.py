@@ -228,3 +228,26 @@ def test_an_epoch_of_captured_steps_equals_the_eager_per_batch_loop(hiplib):
         for j, (c, q) in enumerate(zip(model, eager)):
             h, hq = c(h, d.edge_index, act="relu" if j == 0 else None), q(hq, d.edge_index, act="relu" if j == 0 else None)
         assert float((h - hq).abs().max()) <= 1e-4 * float(hq.abs().max())
+
+
+def test_layers_that_are_not_capture_safe_refuse_loudly(hiplib):
+    """GATConv / HeteroConv keep derived forms of their parameters in Python-side caches: under capture they raise instead of
+    replaying a graph that multiplies with the weights of the capture."""
+    import torch
+    from wholegraph_amd import nn
+    from cugraph_pyg_amd.loader import NeighborLoader, PerBatchStep
+    gs, fs, feat = _stores(3000, 10)
+    seeds = torch.arange(128).cuda()
+    loader = NeighborLoader((fs, gs), [4, 3], input_nodes=seeds, batch_size=64, shuffle=False, random_state=3, local_seeds_per_call=128)
+    conv = nn.GATConv(F_IN, 16, heads=4).cuda()
+
+    def step(batch):
+        return conv(batch.x, batch.layer_graph(0), act="relu").sum()
+    stepper = PerBatchStep(step, table=feat)
+    grp = next(iter(loader.call_groups()))
+    with pytest.raises(RuntimeError, match="not supported under HIP-graph capture"):
+        with torch.no_grad():
+            stepper(grp, 0)
+    torch.cuda.synchronize()
+    # the stream is usable afterwards
+    assert float(torch.ones(4, device="cuda").sum()) == 4.0
