@@ -131,6 +131,9 @@ class PerBatchStep:
         key = id(grp)
         if self._group_key is not None and self._group_key[0] == key:
             return self._group_key[1]
+        if not hasattr(grp, "_res") or not hasattr(grp._res, "frontier_local0"):
+            raise NotImplementedError("PerBatchStep stages the mini-batches of a homogeneous CallGroup (NeighborLoader.call_groups() "
+                                      "over a homogeneous GraphStore); got %s" % type(grp).__name__)
         grp._wait()
         res, H = grp._res, grp.hops
         rows, edges = [], []
