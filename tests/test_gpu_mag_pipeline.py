@@ -160,7 +160,8 @@ def _agg_heads_reference(x, a_src, a_dst, rp, col, H, dst_rows, slope=0.2):
 def test_gat_aggregate_heads_backward_matches_float64_autograd(hiplib, F, H, mode):
     """wgamd_gat_aggregate_heads_bwd_f32 through nn._GatAggregateHeads: gradients of the attention terms (per listed row, or per
     TABLE row — a table row collects from every place the list names it) and of the source rows against float64 autograd of
-    the same formula; 1e-5 of the scale of the sums involved."""
+    the same formula, held to the SAGE side's contract: |err| <= 1e-5 x the magnitude sum of the terms of an entry, and 1e-5
+    relative on the entries that are not cancellations (round 6; rounds 4-5 used 2e-5 of the gradient's maximum)."""
     import torch
     from wholegraph_amd import nn
     g = torch.Generator(device="cuda").manual_seed(F + H)
@@ -189,10 +190,42 @@ def test_gat_aggregate_heads_backward_matches_float64_autograd(hiplib, F, H, mod
     d_list = d64[dids] if dst_by_id else d64
     ref = _agg_heads_reference(x_list, s_list, d_list, rp, col, H, dst_rows)
     ref.backward(gout.double())
-    assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
-    for got, want in ((a_src.grad, s64.grad), (a_dst.grad, d64.grad)) + (((x.grad, x64.grad),) if x_grad else ()):
-        scale = float(want.abs().max())
-        assert scale > 0 and float((got.double() - want).abs().max()) <= 2e-5 * scale, (float((got.double() - want).abs().max()), scale)
+    assert float((out.double() - ref.detach()).abs().max()) <= 1e-5 * float(ref.detach().abs().max())
+    # The contract of tests/test_gpu_sage_train.py (north_star's 1e-5): |err| <= 1e-5 x the MAGNITUDE SUM of the terms a gradient
+    # entry is made of, and 1e-5 relative on the entries that are not cancellations.  The magnitude sums, in float64:
+    #   p_e^h = <g_i^h, x_e> has magnitude P = sum_f |g||x|;  ds = alpha (p - sum_k alpha_k p_k) has alpha (P + sum alpha P);
+    #   ga_src / ga_dst add |de| = |ds| slope' over the edges of a term row;  gx adds sum_h alpha |g_i^h| over a row's edges.
+    with torch.no_grad():
+        n = rp.shape[0] - 1
+        deg = (rp[1:] - rp[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+        c = col.long()
+        xl, sl, dl = x_list.detach(), s_list.detach(), d_list.detach()
+        raw = sl[c] + dl[dst_rows][row]
+        sc = torch.nn.functional.leaky_relu(raw, 0.2)
+        mx = torch.full((n, H), -float("inf"), dtype=torch.float64, device="cuda").index_reduce_(0, row, sc, "amax", include_self=True)
+        ex = torch.exp(sc - mx[row])
+        alpha = ex / torch.zeros((n, H), dtype=torch.float64, device="cuda").index_add_(0, row, ex)[row]
+        g3 = gout.double().view(n, H, F)
+        P = (g3[row].abs() * xl[c].abs().unsqueeze(1)).sum(-1)                                              # [E, H]
+        de_mag = alpha * (P + torch.zeros((n, H), dtype=torch.float64, device="cuda").index_add_(0, row, alpha * P)[row])
+        src_rows = (ids[c] if src_by_id else c)
+        dst_term_rows = (dids[dst_rows] if dst_by_id else dst_rows)[row]
+        mag_src = torch.zeros_like(s64).index_add_(0, src_rows, de_mag)
+        mag_dst = torch.zeros_like(d64).index_add_(0, dst_term_rows, de_mag)
+        mag_x = torch.zeros_like(x64).index_add_(0, ids[c] if lazy else c, (alpha.unsqueeze(-1) * g3[row].abs()).sum(1)) if x_grad else None
+
+    def close(got, want, mag, what):
+        err = (got.double() - want).abs()
+        assert bool((err <= 1e-5 * mag + 1e-9).all()), (what, float((err - 1e-5 * mag).max()))
+        big = want.abs() >= 0.1 * mag
+        big &= mag > 0
+        if int(big.sum()) > 0:
+            assert float((err[big] / want.abs()[big]).max()) <= 1e-5, what
+    close(a_src.grad, s64.grad, mag_src, "ga_src")
+    close(a_dst.grad, d64.grad, mag_dst, "ga_dst")
+    if x_grad:
+        close(x.grad, x64.grad, mag_x, "gx")
 
 
 @pytest.mark.parametrize("n,F,T,x_grad", [(50000, 128, 12, False), (7777, 100, 8, False), (3001, 256, 32, True), (999, 64, 1, True),
@@ -263,6 +296,55 @@ def test_hetero_conv_trains_aggregate_first_like_relation_by_relation(hiplib):
             h = layer(h, grp.layer_graph(j), act=None)
         assert h["paper"].requires_grad and torch.equal(h["paper"].detach(), o1), resident
     assert sum(a is not None for a in g1) >= 20
+    # ---- float64 end to end (round 6): both layers spelled out with torch index ops in PyG's transform-first order, autograd
+    # in float64 from `gout` back to every parameter; the aggregate-first fp32 route is held to it (this replaces relying on the
+    # fp32 relation-by-relation route below as the only witness)
+    p64 = {id(p): p.detach().double().requires_grad_(True) for p in params}
+
+    def layer64(layer, xs, graph):
+        out = {t: torch.zeros((n, bm.HC), dtype=torch.float64, device=dev) for t, n in graph.n_out.items() if n > 0}
+        biased = set()
+        for r in graph.relations:
+            if r.n_rows == 0:
+                continue
+            c = layer.conv(r.edge_type)
+            st, dt = r.edge_type[0], r.edge_type[2]
+            W = p64[id(c.lin.weight)].t()
+            hs, hd = xs[st] @ W, xs[dt][r.dst_rows] @ W
+            a_s = (hs.view(-1, bm.HEADS, bm.CH) * p64[id(c.att_src)].view(1, bm.HEADS, bm.CH)).sum(-1)
+            a_d = (hd.view(-1, bm.HEADS, bm.CH) * p64[id(c.att_dst)].view(1, bm.HEADS, bm.CH)).sum(-1)
+            deg = (r.row_ptr[1:] - r.row_ptr[:-1]).long()
+            row = torch.repeat_interleave(torch.arange(r.n_rows, device=dev), deg)
+            cl = r.col.long()
+            sc = torch.nn.functional.leaky_relu(a_s[cl] + a_d[row], c.negative_slope)
+            mx = torch.full((r.n_rows, bm.HEADS), -float("inf"), dtype=torch.float64, device=dev).index_reduce_(0, row, sc, "amax", include_self=True)
+            ex = torch.exp(sc - mx[row])
+            alpha = ex / torch.zeros((r.n_rows, bm.HEADS), dtype=torch.float64, device=dev).index_add_(0, row, ex)[row]
+            y = torch.zeros((r.n_rows, bm.HEADS, bm.CH), dtype=torch.float64, device=dev).index_add_(
+                0, row, alpha.unsqueeze(-1) * hs.view(-1, bm.HEADS, bm.CH)[cl]).reshape(r.n_rows, bm.HC)
+            if c.bias is not None:
+                y = y + p64[id(c.bias)]
+            rows = r.out_rows if r.out_rows is not None else torch.arange(r.n_rows, device=dev)
+            out[dt] = out[dt].index_add(0, rows, y)
+            biased.add((r.hop, dt))
+        return out
+    h64 = {t: (v.materialize() if hasattr(v, "materialize") else v).double() for t, v in grp.x_dict.items()}
+    for j, layer in enumerate(model):
+        h64 = layer64(layer, h64, grp.layer_graph(j))
+    h64["paper"].backward(gout.double())
+    assert float((o1.double() - h64["paper"].detach()).abs().max()) <= 1e-5 * float(h64["paper"].detach().abs().max())
+    worst = 0.0
+    for p, a in zip(params, g1):
+        w = p64[id(p)].grad
+        if a is None or w is None:
+            assert (a is None or float(a.abs().max()) == 0.0) and (w is None or float(w.abs().max()) == 0.0)
+            continue
+        scale = float(w.abs().max())
+        worst = max(worst, float((a.double() - w).abs().max()) / scale)
+        # north_star's 1e-5, here of the gradient's own maximum (measured on this graph: <= 1.3e-6); the per-kernel bars are the
+        # magnitude-sum tests above
+        assert float((a.double() - w).abs().max()) <= 1e-5 * scale + 1e-12, (float((a.double() - w).abs().max()), scale, tuple(a.shape))
+    print("hetero training route vs float64: worst relative-to-max gradient error %.2e" % worst)
     for a, b in zip(g1, g2):
         if a is None or b is None:        # a relation the seeds cannot see through the remaining layers: no gradient, or zeros
             assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0)
