@@ -472,7 +472,9 @@ def test_homogeneous_gatconv_over_call_groups(hiplib, self_loops, table_rows):
         for k in range(4):
             a, b = got_by[(ci, k)], want_grads[ci * 4 + k]
             scale = float(b.abs().max())
-            assert float((a - b.reshape(a.shape)).abs().max()) <= 2e-5 * scale + 1e-9, (ci, k, float((a - b.reshape(a.shape)).abs().max()), scale)
+            # (north_star's 1e-5 of the gradient's own maximum; the aggregation's gradients are held entry by entry to 1e-5 x the
+            #  magnitude sum of their terms in tests/test_gpu_mag_pipeline.py)
+            assert float((a - b.reshape(a.shape)).abs().max()) <= 1e-5 * scale + 1e-9, (ci, k, float((a - b.reshape(a.shape)).abs().max()), scale)
 
 
 @pytest.mark.parametrize("F,H,C", [(64, 4, 16), (100, 2, 8), (32, 8, 4), (256, 4, 64)])
