@@ -4,7 +4,10 @@
 One "step" = `batches_per_step` (default 8 x 191) mini-batches of 1024 seeds through the whole hot path with everything
 resident in HBM, processed as `--groups-per-step` (8) CALL GROUPS of `--call-group` mini-batches (default: the loaders' own
 memory-sized call group, 191 on a 288 GB MI355X) — the launch shape is FIXED and does not depend on --steps:   2-hop uniform fan-out walk [25,10] (sample + renumber, no host sync)  ->
-feature gather x = feat[n_id] (fp32, F=100)  ->  2-layer GraphSAGE forward (mean aggregation + lin_l/lin_r in HIP).
+feature gather (fp32, F=100: every DISTINCT row of the call group's node list once — the list is de-duplicated on the walk
+stream right behind the walk, layer 1 reads the gathered rows through the inverse index; `--fetch rows` = x = feat[n_id] row for
+row, the form rounds 1-5 measured, reported as variants.materialised_full)  ->  2-layer GraphSAGE forward (mean aggregation +
+lin_l/lin_r in HIP).
 `value` = sampled edges of all ranks / max-over-ranks wall time of exactly K steps (the driver's `--steps 20 --warmup 5`
 = 160 timed call groups after 40 untimed ones, a steady-state software-pipelined region of ~0.7 s).
 
@@ -98,12 +101,21 @@ class SagePipeline:
     block-diagonal concatenation.  Groups are software-pipelined: the walk of group g+1 is enqueued
     before the host reads the (tiny, pinned) size vector of group g, so the GPU queue never drains."""
 
-    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True, walk_priority=0, walk_stream=None):
+    def __init__(self, row_ptr, col, feat_table, device, G, overlap_walk=True, walk_priority=0, walk_stream=None, dedup=True):
         from wholegraph_amd import fused, nn
         self.nn = nn
         self.device = device
         self.G = G
         self.distinct_rows = []
+        # dedup (round 6, the headline's feature fetch at every N): the call group's node list names a table row once per
+        # mini-batch that sampled it (10.9 M rows per products group over 1.19 M distinct ones).  The list is de-duplicated on
+        # the walk stream right behind the walk (wgamd_unique_bounded_live: mark / scan over V / compact / look up, no host
+        # sync — the count travels with the walk's sizes), every DISTINCT row is gathered once (locally, or through the RCCL
+        # exchange when the table is partitioned) and layer 1 reads the gathered rows through the inverse index (its src_ids).
+        # dedup=False: x = feat[n_id] row for row, as rounds 1-5 measured it (variants.materialised_full).
+        self.dedup = bool(dedup)
+        self.mode = "fused"            # the mode of the pass being enqueued (run_groups / probe_stages set it)
+        self.n_vertices = int(row_ptr.shape[0]) - 1
         self.walk = fused.NoSyncWalk(row_ptr, col, BATCH, FANOUT, col.dtype, G, pad_unique=False)   # ids take the CSR's column dtype
         self.feat = feat_table  # WholeMemoryTensor
         g = torch.Generator(device=device).manual_seed(1)
@@ -183,8 +195,18 @@ class SagePipeline:
             self.rs_base = (torch.arange(self.G, device=self.device, dtype=torch.int64).view(1, -1) * hops
                             + torch.arange(hops, device=self.device, dtype=torch.int64).view(-1, 1) + 62)
         rs = self.rs_base + group_id * self.G * hops    # one launch per call group
+
+        def distinct_rows(res):
+            if not self.dedup or self.mode.endswith("_fetch"):     # (the fetch-in-the-layer variants read the table through n_id)
+                return
+            from wholegraph_amd.tensor import unique_bounded_nosync
+            distinct, inverse, info = unique_bounded_nosync(res.unique[hops - 1], res.counts[hops - 1][1:2], self.n_vertices)
+            info_h = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            info_h.copy_(info, non_blocking=True)
+            res.fetch = (distinct, inverse, info_h)
         if self.walk_stream is None:
             res = self.walk.run(seeds, rs)
+            distinct_rows(res)
             sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
             sizes_h.copy_(res.counts, non_blocking=True)
             ev = torch.cuda.Event()
@@ -196,6 +218,7 @@ class SagePipeline:
         self.walk_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.walk_stream):
             res = self.walk.run(seeds, rs)
+            distinct_rows(res)
             sizes_h = torch.empty((hops, 2), dtype=torch.int32, pin_memory=True)
             sizes_h.copy_(res.counts, non_blocking=True)
             ev = torch.cuda.Event()
@@ -218,6 +241,8 @@ class SagePipeline:
                         res.center_row):
                 for t in lst:
                     t.record_stream(main)
+            for t in (getattr(res, "fetch", None) or ())[:2]:
+                t.record_stream(main)
         t0 = self.G * BATCH
 
         def stage(name, fn):
@@ -242,7 +267,21 @@ class SagePipeline:
         u_last = n_uniq[L - 1]
         n_id = res.unique[L - 1][:u_last]
         lazy = None
-        if fused_fetch and self.distributed:
+        ids1 = None          # layer 1 reads its input THROUGH this index (dedup: the inverse of the distinct-row list)
+        if self.dedup and not fused_fetch and getattr(res, "fetch", None) is not None:
+            distinct, inverse, info_h = res.fetch
+            n_d, bad = (int(v) for v in info_h.tolist())
+            assert not bad, "a sampled vertex id is not a row of the feature table"
+            if timers is not None:
+                self.distinct_rows.append(n_d)
+            ids1 = inverse[:u_last]
+            if self.distributed:      # every distinct row through the exchange ONCE; nothing is expanded afterwards
+                x = stage("gather(" + self.fetch_tag + ")", lambda: self.feat.gather(distinct[:n_d], dedup=False))
+            else:
+                from wholegraph_amd.tensor import local_gather
+                x = stage("gather", lambda: local_gather(self.feat.local_tensor, distinct[:n_d],
+                                                         self.rows_buffer("x", n_d, FEAT_DIM)))
+        elif fused_fetch and self.distributed:
             # a PEER-MAPPED partitioned table: layer 1 reads every rank's partition itself through byte offsets over this
             # process's mapping (wgamd_mapped_row_offsets): remote rows cross xGMI inside the layer kernel, no gathered copy
             lazy = stage("row_offsets(peer-mapped)", lambda: nn.mapped_lazy_rows(self.feat, n_id))
@@ -252,7 +291,7 @@ class SagePipeline:
         elif self.distributed:
             if timers is not None:   # stage probe only (untimed here): what the de-duplicated fetch puts on the wire
                 self.distinct_rows.append(int(torch.unique(n_id).numel()))
-            x = stage("gather(" + self.fetch_tag + ")", lambda: self.feat.gather(n_id))
+            x = stage("gather(" + self.fetch_tag + ")", lambda: self.feat.gather(n_id))      # (de-duplicates on the wire, expands)
         elif timers is None and getattr(res, "x_prefetched", None) is not None:
             x, evx = res.x_prefetched     # gathered on the walk stream while the previous group's layers ran here
             torch.cuda.current_stream().wait_event(evx)
@@ -275,15 +314,18 @@ class SagePipeline:
             if fused_layer and nn.sage_layer_fused_preferred(self.dims[j], self.dims[j + 1]):
                 fetch = j == 0 and fused_fetch
                 table = (lazy.table if lazy is not None else self.feat.local_tensor) if fetch else h
+                through = (lazy.ids if lazy is not None else n_id) if fetch else (ids1 if j == 0 else None)
                 h = stage(("fetch+" if fetch else "") + "sage_layer%d(fused)" % (j + 1), lambda: nn.sage_layer_fused_forward(
                     ptr, nbr, table, rows, self.w_t[j], self.bias[j], relu=j < L - 1,
-                    mean=True, src_ids=(lazy.ids if lazy is not None else n_id) if fetch else None,
+                    mean=True, src_ids=through,
                     # (row stride = the width the kernel runs at: a 47-class head is computed as 64 zero-padded columns)
                     out=self.rows_buffer("h%d" % j, n_dst, -(-self.dims[j + 1] // 64) * 64)[:, :self.dims[j + 1]]))
                 continue
             if j == 0 and fused_fetch:
                 cat = stage("fetch+" + spmm_label(0), lambda: nn.sage_aggregate_fetch_forward(
                     ptr, nbr, self.feat.local_tensor, n_id, rows, True))
+            elif j == 0 and ids1 is not None:
+                cat = stage(spmm_label(0), lambda: nn.sage_aggregate_fetch_forward(ptr, nbr, h, ids1, rows, True))
             else:
                 cat = stage(spmm_label(j), lambda: nn.sage_aggregate_forward(ptr, nbr, h, rows, True))
             h = stage("dense%d" % (j + 1), lambda: self.dense(cat, self.w_t[j], self.bias[j], relu=j < L - 1))
@@ -609,7 +651,7 @@ def cpu_baseline(row_ptr_h, col_h, feat_h, seeds_h, weights, budget_s=15.0):
 PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")
 
 
-def load_pmc(kernel_prefix, want_void=True, workload="products"):
+def load_pmc(kernel_prefix, want_void=True, workload="products", prefer=None):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/rNN/pmc_traffic.json — pmc_traffic_<workload>.json
     for the other BASELINE configurations —, newest round first: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS
     command's launch shape, FETCH_SIZE x 2 per MI355X_MICROARCH.md §HBM; tools/pmc_summary.py).  Counters cannot be read from
@@ -623,6 +665,8 @@ def load_pmc(kernel_prefix, want_void=True, workload="products"):
             pmc = json.load(f)
         hit = [(k, v) for k, v in pmc["kernels"].items() if k.startswith(kernel_prefix)
                and (not want_void or "<void" in k or "<long" not in k)]
+        if prefer is not None:      # the instantiation whose id type (first template argument) is `prefer`, where the pass has it
+            hit = [kv for kv in hit if kv[0].startswith(kernel_prefix + "<" + prefer + ",")] or hit
         per_shape = [kv for kv in hit if "#large" in kv[0]]
         if per_shape:     # one kernel, two launch shapes per call group: `#large` is the layer-1 launch
             hit = per_shape
@@ -635,7 +679,7 @@ def load_pmc(kernel_prefix, want_void=True, workload="products"):
     return None
 
 
-def load_profiled_avg(kernel, workload="products"):
+def load_profiled_avg(kernel, workload="products", prefer=None):
     """Average launch duration (ns) of the dominant kernel in the COMMITTED rocprofv3 --kernel-trace --stats summary of this
     command (profiles/rNN/rNN_kernel_stats.csv — <workload>_kernel_stats.csv for the other configurations —, newest round first).  A kernel that serves two layers appears as two template
     instantiations; the dominant stage is the longer one.  Lets the line carry `frac_profiled` next to the live HIP-event
@@ -651,7 +695,8 @@ def load_profiled_avg(kernel, workload="products"):
         with open(path, newline="") as f:
             rows = [r for r in csv.DictReader(f) if kernel + "<" in r["Name"] or kernel + "(" in r["Name"]]
         plain = [r for r in rows if kernel + "<void" in r["Name"]]   # not the fetch-folded variant (ids type != void)
-        rows = plain or rows
+        pref = [r for r in rows if prefer is not None and kernel + "<" + prefer + "," in r["Name"]]
+        rows = pref or plain or rows
         if rows:
             r = max(rows, key=lambda r: float(r["AverageNs"]))
             return {"avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"]), "min_ns": float(r["MinNs"]),
@@ -736,6 +781,9 @@ def main():
                                                             "one-GPU rehearsal of the N>1 control flow in the tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test aid: every rank uses cuda:0")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes of the other code paths")
+    ap.add_argument("--fetch", choices=["distinct", "rows"], default="distinct",
+                    help="feature fetch of the headline: 'distinct' (default) gathers every distinct row of a call group once and "
+                         "lets layer 1 read through the inverse index; 'rows' gathers x = feat[n_id] row for row (rounds 1-5)")
     ap.add_argument("--extra-placement-timeout", type=int, default=180,
                     help="seconds the also-measured feature placement may take before the headline line is printed without it")
     ap.add_argument("--mag-rels", choices=["all", "r5"], default="all",
@@ -918,6 +966,7 @@ def main():
 
     def run_groups(pipe, first, last, timers=None, sizes=None, mode="split"):
         """software pipeline: walk(g+1) is enqueued before forward(g) waits for the sizes of g"""
+        pipe.mode = mode
         pending = pipe.sample(batches[first % distinct], first)
         for g in range(first, last):
             t0 = time.perf_counter()
@@ -977,6 +1026,7 @@ def main():
 
     def probe_stages_(pipe, mode, n_groups):
         acc, sizes_p = {}, []
+        pipe.mode = mode
         for g in range(warm_groups, warm_groups + n_groups):
             timers = []
             w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1006,7 +1056,7 @@ def main():
         nonlocal batches
         partitioned = placement != "replicated"
         pipe = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority,
-                            walk_stream=walk_masked)
+                            walk_stream=walk_masked, dedup=args.fetch == "distinct")
         # headline: explicit feature gather (the reference's flow), then every SAGE layer whose shape allows it as ONE
         # kernel; --layer-kernel split keeps the aggregation kernel + library GEMM pair for every layer
         fusable = nn_mod.sage_layer_fused_preferred(pipe.dims[0], pipe.dims[1])
@@ -1028,6 +1078,15 @@ def main():
         for m in ([] if (args.no_variants or world > 1) else others):
             vs, ve = measure(pipe, m)
             variants[m] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3, "note": notes[m]}
+        if pipe.dedup and not (args.no_variants or world > 1):
+            pipe_full = SagePipeline(row_ptr, col, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority,
+                                     walk_stream=walk_masked, dedup=False)
+            pipe_full.convs, pipe_full.w_t, pipe_full.bias = pipe.convs, pipe.w_t, pipe.bias
+            vs, ve = measure(pipe_full, head_mode)
+            variants["materialised_full"] = {"value": ve / vs, "ms_per_step": vs / args.steps * 1e3,
+                                             "note": "x = feat[n_id] gathered row for row (10.9 M rows per products call group), layer 1 "
+                                                     "reads x directly: the headline pipeline of rounds 1-5"}
+            del pipe_full
         lazy_pass = None
         if placement == "partitioned_mapped" and fusable and not args.no_variants:
             # the same groups with the fetch folded into layer 1 OVER THE MAPPING (no gather, remote rows read by the layer
@@ -1038,7 +1097,8 @@ def main():
                                  "WGAMD_IDS_BYTE_OFFSETS): x = feat[n_id] never exists"}
         if col_alt is not None and world == 1:
             # the same pipeline with int32 ids (csr_col, seeds, node lists): the WholeGraph test default
-            pipe32 = SagePipeline(row_ptr, col_alt, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority)
+            pipe32 = SagePipeline(row_ptr, col_alt, feat, device, G, overlap_walk=not args.no_overlap, walk_priority=args.walk_priority,
+                                  dedup=args.fetch == "distinct")
             b64 = batches
             batches = b64.to(torch.int32)
             vs, ve = measure(pipe32, head_mode)
@@ -1087,7 +1147,9 @@ def main():
             # algorithmic bytes per launch; b = id bytes, fp32 features
             F = FEAT_DIM
             idb = 4 if id_dtype == torch.int32 else 8
-            kernels = {"gather": ("row_copy_kernel", n_src * (idb + 2 * 4 * F))}
+            n_fetch = (sum(pipe.distinct_rows) / len(pipe.distinct_rows)) if (pipe.dedup and pipe.distinct_rows) else n_src
+            kernels = {"gather": ("row_copy_kernel", n_fetch * ((8 if pipe.dedup else idb) + 2 * 4 * F))}
+            layer1_ids = "int" if pipe.dedup else None    # layer 1 reads the gathered rows through the int32 inverse index
             spmm_root = {}
             for j in range(L):
                 k = L - 1 - j
@@ -1116,13 +1178,14 @@ def main():
                      "avg_launch_ms": round(stage_ms[st], 5),
                      "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                f"{G} mini-batches, averaged over {stage_n} call groups"}
+                pref = layer1_ids if st == "sage_layer1(fused)" else ("long" if (st == "gather" and pipe.dedup) else None)
                 if std_shape:
-                    prof = load_profiled_avg(r["kernel"], args.workload)
+                    prof = load_profiled_avg(r["kernel"], args.workload, prefer=pref)
                     if prof:    # the same algorithmic bytes over the committed profile's average launch duration
                         r["frac_profiled"] = round(kernels[st][1] / (prof["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)
                         r["profiled_avg_launch_ms"] = round(prof["avg_ns"] * 1e-6, 5)
                         r["profiled_source"] = "%s (%d launches, min %.1f us)" % (prof["source"], prof["calls"], prof["min_ns"] * 1e-3)
-                    hit = load_pmc(r["kernel"], workload=args.workload)
+                    hit = load_pmc(r["kernel"], workload=args.workload, prefer=pref)
                     if hit:
                         r["traffic"] = hit["bytes"]
                         r["traffic_over_algorithmic"] = round(hit["bytes"] / kernels[st][1], 3)
@@ -1218,6 +1281,10 @@ def main():
                 "spmm_with_root_copy_GBps": None if spmm_root_gbps is None else round(spmm_root_gbps, 1),
                 "spmm_hbm_util_pmc": spmm_pmc,
                 "layer_kernel": head_mode,
+                "feature_fetch": ("distinct rows of the call group gathered ONCE (list de-duplicated on the walk stream: "
+                                  "wgamd_unique_bounded_live), layer 1 reads them through the inverse index; %d listed rows -> %d "
+                                  "gathered per call group" % (int(n_src), int(n_fetch))) if pipe.dedup else
+                                 "x = feat[n_id] row for row",
                 "fused_fetch_variant": fused,
                 "variants": variants,
                 "roofline": roofline,
@@ -1241,11 +1308,11 @@ def main():
                         rep["fetch_in_layer"] = pr["lazy_pass"]
                     if name != "replicated":
                         p_src = sum(s_[2 * L - 1] for s_ in pr["psizes"]) / pr["stage_n"]
-                        # the partitioned fetch sends every DISTINCT row of the call group once (gather(dedup="auto"),
-                        # wholegraph_amd/tensor.py) and expands locally; ids travel as int64
+                        # the partitioned fetch sends every DISTINCT row of the call group once (the list is de-duplicated
+                        # behind the walk; layer 1 reads the fetched rows through the inverse index); ids travel as int64
                         from wholegraph_amd.tensor import dedup_pays
                         dd = pr["pipe"].distinct_rows
-                        deduped = bool(dd) and dedup_pays(int(p_src), V, world)
+                        deduped = bool(dd) and (pr["pipe"].dedup or dedup_pays(int(p_src), V, world))
                         wire_rows = sum(dd) / len(dd) if deduped else p_src
                         a2a = wire_rows * (world - 1) / max(world, 1) * (8 + 4 * F)
                         rep.update(requested_rows_per_call_group=int(p_src), deduplicated=deduped,

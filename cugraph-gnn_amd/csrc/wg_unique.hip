@@ -20,8 +20,9 @@ namespace {
 
 template <typename IdT>
 __global__ void __launch_bounds__(256) unique_mark_kernel(const IdT* __restrict__ ids, int64_t n, int64_t bound, int* __restrict__ flags,
-                                                          int* __restrict__ bad)
+                                                          int* __restrict__ bad, const int* __restrict__ n_live)
 {
+  if (n_live) n = min(n, (int64_t)*n_live);   // (capacity-sized list of a no-sync walk: the live count is on the device)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t id = (int64_t)ids[i];
     if (id < 0) continue;
@@ -43,8 +44,9 @@ __global__ void __launch_bounds__(256) unique_compact_kernel(const int* __restri
 
 template <typename IdT>
 __global__ void __launch_bounds__(256) unique_inverse_kernel(const IdT* __restrict__ ids, int64_t n, int64_t bound, const int* __restrict__ pos,
-                                                             int* __restrict__ inverse)
+                                                             int* __restrict__ inverse, const int* __restrict__ n_live)
 {
+  if (n_live) n = min(n, (int64_t)*n_live);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t id = (int64_t)ids[i];
     inverse[i]       = (id < 0 || id >= bound) ? -1 : pos[id];
@@ -88,6 +90,14 @@ wholememory_error_code_t wgamd_unique_bounded(const void* ids, wholememory_dtype
                                               int64_t* distinct, int* inverse, int* n_distinct_dev, int* out_of_bound_dev,
                                               void* workspace, size_t workspace_bytes, void* stream)
 {
+  return wgamd_unique_bounded_live(ids, id_dtype, n, nullptr, id_bound, distinct, inverse, n_distinct_dev, out_of_bound_dev,
+                                   workspace, workspace_bytes, stream);
+}
+
+wholememory_error_code_t wgamd_unique_bounded_live(const void* ids, wholememory_dtype_t id_dtype, int64_t n, const int* n_live_dev,
+                                                   int64_t id_bound, int64_t* distinct, int* inverse, int* n_distinct_dev,
+                                                   int* out_of_bound_dev, void* workspace, size_t workspace_bytes, void* stream)
+{
   using namespace wgamd;
   return guarded("wgamd_unique_bounded", [&] {
     WG_REQUIRE_INPUT(id_dtype == WHOLEMEMORY_DT_INT || id_dtype == WHOLEMEMORY_DT_INT64, "id dtype must be INT|INT64");
@@ -107,8 +117,8 @@ wholememory_error_code_t wgamd_unique_bounded(const void* ids, wholememory_dtype
     WG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
     if (n > 0) {
       const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 256 * 32);
-      if (id_dtype == WHOLEMEMORY_DT_INT) unique_mark_kernel<int32_t><<<grid, 256, 0, st>>>(static_cast<const int32_t*>(ids), n, id_bound, flags, bad);
-      else unique_mark_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, flags, bad);
+      if (id_dtype == WHOLEMEMORY_DT_INT) unique_mark_kernel<int32_t><<<grid, 256, 0, st>>>(static_cast<const int32_t*>(ids), n, id_bound, flags, bad, n_live_dev);
+      else unique_mark_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, flags, bad, n_live_dev);
       WG_HIP_CHECK(hipGetLastError());
     }
     exclusive_scan_i32(flags, pos, id_bound, tmp, st);   // pos[id_bound] = number of distinct ids
@@ -116,8 +126,8 @@ wholememory_error_code_t wgamd_unique_bounded(const void* ids, wholememory_dtype
     WG_HIP_CHECK(hipGetLastError());
     if (n > 0) {
       const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 256 * 32);
-      if (id_dtype == WHOLEMEMORY_DT_INT) unique_inverse_kernel<int32_t><<<grid, 256, 0, st>>>(static_cast<const int32_t*>(ids), n, id_bound, pos, inverse);
-      else unique_inverse_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, pos, inverse);
+      if (id_dtype == WHOLEMEMORY_DT_INT) unique_inverse_kernel<int32_t><<<grid, 256, 0, st>>>(static_cast<const int32_t*>(ids), n, id_bound, pos, inverse, n_live_dev);
+      else unique_inverse_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, pos, inverse, n_live_dev);
       WG_HIP_CHECK(hipGetLastError());
     }
     if (out_of_bound_dev) WG_HIP_CHECK(hipMemcpyAsync(out_of_bound_dev, bad, sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -316,6 +316,8 @@ SYMBOLS = {
     "wgamd_unique_bounded_workspace_bytes": (c_size_t, [c_int64]),
     "wgamd_unique_bounded": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    "wgamd_unique_bounded_live": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "wgamd_sample_hop_batched_nosync_ex": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                                    c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -64,6 +64,28 @@ def unique_bounded(indice: torch.Tensor, id_bound: int, *, report_out_of_bound: 
     return distinct[:n_d], inverse
 
 
+def unique_bounded_nosync(indice: torch.Tensor, n_live_dev: torch.Tensor, id_bound: int):
+    """``unique_bounded`` over a CAPACITY-sized id list whose live length is a device int (``n_live_dev``: a 1-element int32
+    view, e.g. ``counts[k][1:2]`` of a no-sync walk), WITHOUT a host synchronisation: ``-> (distinct [min(cap, id_bound)] int64,
+    inverse [cap] int32, info [2] int32 = {distinct count, any id out of bound})`` — entries past the live counts are
+    unwritten.  Enqueue it behind the walk, copy ``info`` back with the walk's own sizes."""
+    from .env import torch_dtype_to_wm
+    assert indice.is_cuda and indice.dim() == 1 and indice.dtype in (torch.int32, torch.int64) and indice.is_contiguous()
+    assert n_live_dev.is_cuda and n_live_dev.dtype == torch.int32 and n_live_dev.numel() == 1
+    lib, dev, n = L.lib(), indice.device, int(indice.shape[0])
+    nbytes = lib.wgamd_unique_bounded_workspace_bytes(int(id_bound))
+    if nbytes == 0:
+        raise ValueError("unique_bounded: id_bound %d is outside (0, 2^31 - 4096)" % id_bound)
+    buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    distinct = torch.empty(min(n, int(id_bound)), dtype=torch.int64, device=dev)
+    inverse = torch.empty(n, dtype=torch.int32, device=dev)
+    info = torch.empty(2, dtype=torch.int32, device=dev)
+    L.check(lib.wgamd_unique_bounded_live(indice.data_ptr(), torch_dtype_to_wm(indice.dtype), n, n_live_dev.data_ptr(), int(id_bound),
+                                          distinct.data_ptr(), inverse.data_ptr(), info.data_ptr(), info.data_ptr() + 4,
+                                          buf.data_ptr() + (-buf.data_ptr()) % 256, nbytes, get_stream()), "wgamd_unique_bounded_live")
+    return distinct, inverse, info
+
+
 def dedup_pays(n: int, rows: int, world: int) -> bool:
     """The ``dedup="auto"`` rule of the partitioned gathers: more than one rank (a repeat costs wire bytes only then) and
     an id list that is large next to the table (a call group of mini-batches: 10.9 M ids into the 2.45 M rows of products —

@@ -693,6 +693,13 @@ size_t wgamd_unique_bounded_workspace_bytes(int64_t id_bound);
 wholememory_error_code_t wgamd_unique_bounded(const void* ids, wholememory_dtype_t id_dtype, int64_t n, int64_t id_bound,
                                               int64_t* distinct, int* inverse, int* n_distinct_dev, int* out_of_bound_dev,
                                               void* workspace, size_t workspace_bytes, void* stream);
+/* The same over a CAPACITY-sized list whose live length is on the device (`n_live_dev`, nullable = n): the node list of a
+ * no-sync call-group walk.  Lets the de-duplication run on the walk's stream right behind the walk, its count travelling
+ * with the walk's own size read-back — the call group's distinct feature rows are then fetched ONCE and the first layer
+ * reads them through `inverse` (its src_ids), at N = 1 as at N > 1 (bench.py, round 6). */
+wholememory_error_code_t wgamd_unique_bounded_live(const void* ids, wholememory_dtype_t id_dtype, int64_t n, const int* n_live_dev,
+                                                   int64_t id_bound, int64_t* distinct, int* inverse, int* n_distinct_dev,
+                                                   int* out_of_bound_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
