@@ -9,52 +9,112 @@
 // the products call group.  The reference's NCCL gather (wholememory_gather_nccl, gather_op_impl_nccl.cu:23-171) exchanges
 // every requested id; its embedding cache path de-duplicates for a different purpose (embedding_cache_func.cuh).
 //
-// Because the ids are bounded the job needs no sort and no hash table: mark -> scan over the bound -> compact -> look up.
-// The marks are one int per possible id (10 MB for products: L2-resident while 10.9 M lanes write into it), the compacted list
-// comes out ascending, i.e. already grouped by owner rank of a range-partitioned table.
+// Because the ids are bounded the job needs no sort and no hash table: mark -> pack + count -> scan over bound / 32 counts ->
+// compact -> look up.  The compacted list comes out ascending, i.e. already grouped by owner rank of a range-partitioned table.
 #include "wg_common.hpp"
 #include "wgamd_ext.h"
 
 namespace wgamd {
 namespace {
 
+// Round 6: the marks are one BYTE per possible id (2.4 MB for products: resident in every XCD's 4 MB L2, where the int flags'
+// 10 MB were not), packed afterwards into one bit per id + a count per 32 ids; positions are prefix[id >> 5] + popc(bits below),
+// kept side by side as {bits, prefix} so the look-up pass makes ONE scattered 8-byte load into 0.6 MB instead of two into 20 MB.
+// For the 10.7 M listed rows of a products call group: mark 195 -> 134 us, look-up 114 -> 53 us (profiles/r06/README.md).  What is
+// left of the mark is its stores (57 us without them, measured): every scattered byte store is one fabric write, and a mark set
+// by one XCD is not seen by the other seven before the kernel ends, so an id listed by k batches is stored up to min(k, 8) times.
 template <typename IdT>
-__global__ void __launch_bounds__(256) unique_mark_kernel(const IdT* __restrict__ ids, int64_t n, int64_t bound, int* __restrict__ flags,
+__global__ void __launch_bounds__(256) unique_mark_kernel(const IdT* __restrict__ ids, int64_t n, int64_t bound, uint8_t* __restrict__ flags,
                                                           int* __restrict__ bad, const int* __restrict__ n_live)
 {
   if (n_live) n = min(n, (int64_t)*n_live);   // (capacity-sized list of a no-sync walk: the live count is on the device)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t id = (int64_t)ids[i];
-    if (id < 0) continue;
-    if (id >= bound) {
-      *bad = 1;   // (every such lane writes the same value)
-      continue;
+  // four independent id loads, then four independent mark loads per trip
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * T) {
+    int64_t id[4];
+    uint8_t f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) id[k] = i + k * T < n ? (int64_t)ids[i + k * T] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (id[k] >= bound) {
+        *bad  = 1;   // (every such lane writes the same value)
+        id[k] = -1;
+      }
+      f[k] = id[k] >= 0 ? flags[id[k]] : 1;
     }
-    flags[id] = 1;   // plain stores of one value: no atomics needed
+    // plain stores of one value: no atomics needed.  Test first: a call group names a hub thousands of times, and thousands of
+    // stores to one address queue up in its L2 channel; the read of a byte that is already set is a broadcast hit
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (f[k] == 0) flags[id[k]] = 1;
   }
 }
 
-__global__ void __launch_bounds__(256) unique_compact_kernel(const int* __restrict__ flags, const int* __restrict__ pos, int64_t bound,
+// 32 marks -> one word of bits + its population count (flags is padded with zeros to a multiple of 32)
+__global__ void __launch_bounds__(256) unique_pack_kernel(const uint8_t* __restrict__ flags, int64_t n_words, uint2* __restrict__ rank,
+                                                          int* __restrict__ cnt, int64_t cnt_padded)
+{
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_words) {
+    const uint4* p = reinterpret_cast<const uint4*>(flags + w * 32);
+    const uint4 a = p[0], b = p[1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {   // bytes are 0 or 1: bit 0 of every byte, gathered
+      const uint32_t x = v[k];
+      word |= ((x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u)) << (4 * k);
+    }
+    rank[w].x = word;
+    cnt[w]    = __popc(word);
+  } else if (w < cnt_padded) {
+    cnt[w] = 0;   // the scan reads whole tiles
+  }
+}
+
+__global__ void __launch_bounds__(256) unique_compact_kernel(uint2* __restrict__ rank, const int* __restrict__ prefix, int64_t n_words,
                                                              int64_t* __restrict__ distinct, int* __restrict__ n_distinct)
 {
-  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id == 0 && n_distinct) *n_distinct = pos[bound];
-  if (id < bound && flags[id]) distinct[pos[id]] = id;
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w == 0 && n_distinct) *n_distinct = prefix[n_words];
+  if (w >= n_words) return;
+  uint32_t word = rank[w].x;
+  int at        = prefix[w];
+  rank[w].y     = (uint32_t)at;   // {bits, ids set below this word} side by side: ONE scattered 8-byte load per look-up
+  while (word) {
+    const int k    = __ffs(word) - 1;
+    distinct[at++] = w * 32 + k;
+    word &= word - 1;
+  }
 }
 
 template <typename IdT>
-__global__ void __launch_bounds__(256) unique_inverse_kernel(const IdT* __restrict__ ids, int64_t n, int64_t bound, const int* __restrict__ pos,
-                                                             int* __restrict__ inverse, const int* __restrict__ n_live)
+__global__ void __launch_bounds__(256) unique_inverse_kernel(const IdT* __restrict__ ids, int64_t n, int64_t bound, const uint2* __restrict__ rank,
+                                                             int* __restrict__ inverse,
+                                                             const int* __restrict__ n_live)
 {
   if (n_live) n = min(n, (int64_t)*n_live);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t id = (int64_t)ids[i];
-    inverse[i]       = (id < 0 || id >= bound) ? -1 : pos[id];
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * T) {
+    int64_t id[4];
+    uint2 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) id[k] = i + k * T < n ? (int64_t)ids[i + k * T] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool ok = id[k] >= 0 && id[k] < bound;
+      r[k]          = ok ? rank[id[k] >> 5] : make_uint2(0u, 0xffffffffu);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (i + k * T < n) inverse[i + k * T] = (int)r[k].y + __popc(r[k].x & ((1u << (id[k] & 31)) - 1u));
   }
 }
 
 struct unique_plan {
-  size_t flags, pos, tmp, bad, total;
+  size_t flags, bits, cnt, tmp, bad, total;
+  int64_t n_words, cnt_padded;
 };
 unique_plan plan_unique(int64_t bound)
 {
@@ -65,11 +125,12 @@ unique_plan plan_unique(int64_t bound)
     at += (bytes + 255) / 256 * 256;
     return o;
   };
-  // flags are read by the scan in whole tiles: pad to the tile
-  const int64_t padded = (bound + kScanTile) / kScanTile * kScanTile;
-  p.flags = add(sizeof(int) * (size_t)padded);
-  p.pos   = add(sizeof(int) * (size_t)(padded + 1));
-  p.tmp   = add(sizeof(int) * (size_t)scan_tmp_ints(bound));
+  p.n_words    = (bound + 31) / 32;
+  p.cnt_padded = (p.n_words + kScanTile) / kScanTile * kScanTile;   // counts are read by the scan in whole tiles
+  p.flags = add((size_t)p.n_words * 32);
+  p.bits  = add(sizeof(uint2) * (size_t)p.n_words);
+  p.cnt   = add(sizeof(int) * (size_t)(p.cnt_padded + 1));           // scanned in place: prefix[n_words] = number of distinct ids
+  p.tmp   = add(sizeof(int) * (size_t)scan_tmp_ints(p.n_words));
   p.bad   = add(sizeof(int));
   p.total = at;
   return p;
@@ -109,11 +170,12 @@ wholememory_error_code_t wgamd_unique_bounded_live(const void* ids, wholememory_
     WG_REQUIRE_INPUT((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* base     = static_cast<char*>(workspace);
-    int* flags     = reinterpret_cast<int*>(base + p.flags);
-    int* pos       = reinterpret_cast<int*>(base + p.pos);
+    uint8_t* flags = reinterpret_cast<uint8_t*>(base + p.flags);
+    uint2* rank    = reinterpret_cast<uint2*>(base + p.bits);
+    int* cnt       = reinterpret_cast<int*>(base + p.cnt);
     int* tmp       = reinterpret_cast<int*>(base + p.tmp);
     int* bad       = reinterpret_cast<int*>(base + p.bad);
-    WG_HIP_CHECK(hipMemsetAsync(flags, 0, p.pos - p.flags, st));
+    WG_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.n_words * 32, st));
     WG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
     if (n > 0) {
       const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 256 * 32);
@@ -121,13 +183,14 @@ wholememory_error_code_t wgamd_unique_bounded_live(const void* ids, wholememory_
       else unique_mark_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, flags, bad, n_live_dev);
       WG_HIP_CHECK(hipGetLastError());
     }
-    exclusive_scan_i32(flags, pos, id_bound, tmp, st);   // pos[id_bound] = number of distinct ids
-    unique_compact_kernel<<<(int)ceil_div(id_bound, 256), 256, 0, st>>>(flags, pos, id_bound, distinct, n_distinct_dev);
+    unique_pack_kernel<<<(int)ceil_div(p.cnt_padded, 256), 256, 0, st>>>(flags, p.n_words, rank, cnt, p.cnt_padded);
+    exclusive_scan_i32(cnt, cnt, p.n_words, tmp, st);   // cnt[w] -> ids set below word w; cnt[n_words] = number of distinct ids
+    unique_compact_kernel<<<(int)ceil_div(p.n_words, 256), 256, 0, st>>>(rank, cnt, p.n_words, distinct, n_distinct_dev);
     WG_HIP_CHECK(hipGetLastError());
     if (n > 0) {
       const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 256 * 32);
-      if (id_dtype == WHOLEMEMORY_DT_INT) unique_inverse_kernel<int32_t><<<grid, 256, 0, st>>>(static_cast<const int32_t*>(ids), n, id_bound, pos, inverse, n_live_dev);
-      else unique_inverse_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, pos, inverse, n_live_dev);
+      if (id_dtype == WHOLEMEMORY_DT_INT) unique_inverse_kernel<int32_t><<<grid, 256, 0, st>>>(static_cast<const int32_t*>(ids), n, id_bound, rank, inverse, n_live_dev);
+      else unique_inverse_kernel<int64_t><<<grid, 256, 0, st>>>(static_cast<const int64_t*>(ids), n, id_bound, rank, inverse, n_live_dev);
       WG_HIP_CHECK(hipGetLastError());
     }
     if (out_of_bound_dev) WG_HIP_CHECK(hipMemcpyAsync(out_of_bound_dev, bad, sizeof(int), hipMemcpyDeviceToDevice, st));
