@@ -10,7 +10,7 @@ cp /tmp/pt_$TAG/${TAG}_kernel_stats.csv $OUT/
 python $R/tools/trace_large_launches.py /tmp/pt_$TAG/${TAG}_kernel_trace.csv $OUT/${TAG}_kernel_stats_large.csv
 grep "^{\"metric" $OUT/bench_trace.log | tail -1 > $OUT/bench_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex "row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|renumber_lds|bucket_sort|renumber_emit|first_bits|scan_tile|sample_count" --output-format csv -d /tmp/pc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex "row_copy|spmm_csr|sage_layer_fused|sage_layer_mfma|sample_uniform|renumber_lds|bucket_sort|renumber_emit|first_bits|scan_tile|sample_count|unique_" --output-format csv -d /tmp/pc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_$C.log 2>&1
   cp /tmp/pc_${TAG}_$C/*counter_collection.csv $OUT/
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "Cijk|sage_layer_fused|sage_layer_mfma" --output-format csv -d /tmp/pc_${TAG}_MFMA -o ${TAG}_MFMA -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_MFMA.log 2>&1
@@ -19,6 +19,9 @@ cp /tmp/pc_${TAG}_MFMA/*counter_collection.csv $OUT/
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_walk -o walk -- python $R/tools/profile_walk.py > $OUT/walk_trace.log 2>&1
 cp /tmp/pt_walk/walk_kernel_stats.csv $OUT/
 python $R/tools/profile_walk.py 2>&1 | tail -1 > $OUT/walk_alone.txt
+DEDUP=1 python $R/tools/profile_walk.py 2>&1 | tail -1 > $OUT/walk_dedup_alone.txt
+DEDUP=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_walkd -o walkd -- python $R/tools/profile_walk.py > /dev/null 2>&1
+cp /tmp/pt_walkd/walkd_kernel_stats.csv $OUT/walk_dedup_kernel_stats.csv
 # (3) the training loops: per call group (profile_train_groups) and per mini-batch (PerBatchStep)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_train -o train -- python $R/tools/profile_train_groups.py 16 > $OUT/train_trace.log 2>&1
 cp /tmp/pt_train/train_kernel_stats.csv $OUT/
