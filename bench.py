@@ -487,7 +487,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
                 h = c(h, batch.layer_graph(j), act="relu" if j < L - 1 else None)
             if not train:
                 return h[:batch.batch_size].sum()
-            loss = torch.nn.functional.cross_entropy(h[:batch.batch_size], labels[batch.seeds])
+            loss = wnn.cross_entropy(h[:batch.batch_size], labels.index_select(0, batch.seeds))     # (one launch forward, one backward)
             loss.backward()
             opt.step()
             return loss

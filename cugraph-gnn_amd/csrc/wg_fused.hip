@@ -354,6 +354,10 @@ struct stage_args {
   const int* node_seg;
   void* n_id;         // [node_cap]
   int* sizes;         // [2 n_hops + 2]: rows and edges per hop, vertices, overflow flag
+  float* inv_deg_all; // [sum row_cap] (nullable): 1 / max(degree, 1) of every row of that CSR (the mean's backward scales by it)
+  int* row_ptr_all;   // [sum row_cap + 1] (nullable): the hops' CSRs back to back as ONE CSR — hop k's rows start at
+                      // sum(row_cap[:k]), its edges at sum(edge_cap[:k]).  With the hops' col / self arrays allocated back to
+                      // back by the caller, a layer over hops 0..j is one launch over a prefix of it instead of j + 1 launches
 };
 
 template <typename IdT>
@@ -361,14 +365,17 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(const stage_args a)
 {
   __shared__ int s_l0[kStageMaxHops + 1];     // first local id of every hop's frontier (+ the vertex count)
   __shared__ int s_base[kStageMaxHops + 1];   // first row of every hop's segment in a layer's output layout
+  __shared__ int s_ebase[kStageMaxHops + 1];  // first edge of every hop in the back-to-back CSR
   const int b = a.batch, t = threadIdx.x;
   const int n0 = a.node_seg[b], n_nodes = a.node_seg[b + 1] - n0;
   if (t == 0) {
-    int base = 0;
+    int base = 0, ebase = 0;
     for (int k = 0; k < a.n_hops; k++) {
-      s_l0[k]   = a.hop[k].f_local0[b];
-      s_base[k] = base;
+      s_l0[k]    = a.hop[k].f_local0[b];
+      s_base[k]  = base;
+      s_ebase[k] = ebase;
       base += a.hop[k].row_cap;
+      ebase += a.hop[k].edge_cap;
     }
     s_l0[a.n_hops] = n_nodes;
   }
@@ -395,7 +402,11 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(const stage_args a)
     // input rows — no long row, no hub source.  Nothing reads a slack row's output and its gradient is zero.
     const int64_t pad_rows = h.row_cap - rows, pad_edges = h.edge_cap - edges;
     for (int r = gtid; r <= h.row_cap; r += gsize) {
-      h.row_ptr[r] = r <= rows ? min(h.offsets[j0 + r] - e0, edges) : edges + (int)((int64_t)(r - rows) * pad_edges / pad_rows);
+      auto at_of = [&](int q) { return q <= rows ? min(h.offsets[j0 + q] - e0, edges) : edges + (int)((int64_t)(q - rows) * pad_edges / pad_rows); };
+      const int at = at_of(r);
+      h.row_ptr[r] = at;
+      if (a.row_ptr_all) a.row_ptr_all[s_base[k] + r] = s_ebase[k] + at;   // (r = row_cap: the next hop's first entry, same value)
+      if (a.inv_deg_all && r < h.row_cap) a.inv_deg_all[s_base[k] + r] = 1.f / (float)max(at_of(r + 1) - at, 1);
       if (r < h.row_cap) h.self0[r] = r < rows ? (int64_t)(s_l0[k] + r) : 0;
     }
     for (int e = gtid; e < h.edge_cap; e += gsize) {
@@ -429,7 +440,8 @@ wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* con
                                                       const void* nodes, wholememory_dtype_t id_dtype, const int* node_seg,
                                                       int batch, const int* row_cap, const int* edge_cap, int node_cap,
                                                       int* const* row_ptr_out, int64_t* const* self_rows_out, int* const* col_out,
-                                                      int* const* col_seg_out, void* n_id_out, int* sizes_out, void* stream)
+                                                      int* const* col_seg_out, void* n_id_out, int* sizes_out, int* row_ptr_all_out,
+                                                      float* inv_deg_all_out, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_call_group_stage_batch", [&] {
@@ -449,7 +461,7 @@ wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* con
       work     = std::max<int64_t>(work, std::max(row_cap[k], edge_cap[k]));
     }
     a.n_hops = n_hops, a.batch = batch, a.node_cap = node_cap, a.nodes = nodes, a.node_seg = node_seg, a.n_id = n_id_out;
-    a.sizes  = sizes_out;
+    a.sizes  = sizes_out, a.row_ptr_all = row_ptr_all_out, a.inv_deg_all = inv_deg_all_out;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, (int64_t)1024), 256));
     if (id_dtype == WHOLEMEMORY_DT_INT64)
       stage_batch_kernel<int64_t><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(a);

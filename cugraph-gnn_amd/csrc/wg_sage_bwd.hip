@@ -337,8 +337,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int grid_x, 
     const int n = (int)(i % N), f = (int)(i / N);   // f == 2F: the bias row
     const int y = n / NB, nl = n - y * NB;
     const float* p = part + ((int64_t)y * grid_x * (KL + 1) + (f == 2 * F ? KL : f)) * NB + nl;
-    float s = 0.f;
-    for (int b = 0; b < grid_x; b++) s += p[(int64_t)b * (KL + 1) * NB];
+    // eight loads in flight, eight running sums combined in a fixed tree: the order is a function of grid_x alone (run-to-run
+    // deterministic); one serial sum over 115 partials was 19 us of a mini-batch's 330-us training step
+    const int64_t step = (int64_t)(KL + 1) * NB;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= grid_x; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = p[(int64_t)(b + k) * step];
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] += v[k];
+    }
+    for (int k = 0; b < grid_x; b++, k++) acc[k] += p[(int64_t)b * step];
+    const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     float* dst = f == 2 * F ? (gb ? gb + n : nullptr) : (f < F ? gwl + (int64_t)n * F + f : gwr + (int64_t)n * F + (f - F));
     if (dst) *dst = accumulate ? *dst + s : s;
   }

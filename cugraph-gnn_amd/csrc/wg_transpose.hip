@@ -103,6 +103,157 @@ __global__ void __launch_bounds__(256) permute_sources_kernel(const int64_t* __r
   if (i < n) col[i] = (int)src[perm[i]];
 }
 
+// ---- a SMALL hop (one mini-batch of a per-mini-batch training step: 11 k edges, 10 k sources) in ONE launch --------------------
+// The radix-sort pipeline above is nine launches; at this size each of them is its launch latency and the transpose is 45 us of
+// a 390-us step.  Here one workgroup keeps the source counters AND the permutation in LDS: count (LDS atomics) -> scan -> place
+// every edge into its source's segment (LDS atomics: arbitrary order inside a segment) -> order every segment by edge id, which
+// IS the stable order (= ascending destination row: the gradient sums stay run-to-run deterministic) -> write.  Segments of up
+// to 32 entries: insertion sort by the thread that owns the source; up to 512: rank sort by one wave (d^2 / 64 steps); longer:
+// one wave re-reads the edge list and ranks the source's edges by ballots (E / 64 steps, whatever the degree).
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallHubMax  = 1024;
+constexpr int kSmallLdsInts = 36 * 1024;   // n_src + 1 + n_edges + n_rows + 1 <= this (144 KB of the CU's 160 KB)
+constexpr int kSmallBatch   = 8;           // independent loads of the edge list in flight per thread
+
+struct small_out {
+  const int* row_ptr;   // (the LDS copy: eleven dependent steps of a search are 0.5 us there, 4 us through L2)
+  int n_rows;
+  int* edge_perm;
+  int* col_t;
+  __device__ __forceinline__ void emit(int p, int e) const
+  {
+    if (edge_perm) edge_perm[p] = e;
+    if (col_t) col_t[p] = row_of_edge(row_ptr, n_rows, e);
+  }
+};
+
+__global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                                            int n_rows, int n_edges, int n_src,
+                                                                            int* __restrict__ row_ptr_t, int* __restrict__ edge_perm,
+                                                                            int* __restrict__ edge_dst, int* __restrict__ col_t)
+{
+  extern __shared__ int lds[];
+  int* start = lds;                 // [n_src + 1]: counts -> offsets -> (after the placement) the END of every segment
+  int* perm  = lds + n_src + 1;     // [n_edges]: edge ids by source; bit 31 = already written by a hub pass
+  int* rows  = perm + n_edges;      // [n_rows + 1]: row_ptr
+  __shared__ int wave_sums[kSmallThreads / 64];
+  __shared__ int n_hubs;
+  __shared__ int hubs[kSmallHubMax];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const small_out out{rows, n_rows, edge_perm, col_t};
+  for (int i = t; i <= n_src; i += kSmallThreads) start[i] = 0;
+  for (int i = t; i <= n_rows; i += kSmallThreads) rows[i] = row_ptr[i];
+  if (t == 0) n_hubs = 0;
+  __syncthreads();
+  // (an id outside [0, n_src) is the caller's error; it is counted on the last source so that nothing is written out of bounds)
+  for (int e0 = t; e0 < n_edges; e0 += kSmallThreads * kSmallBatch) {
+    int s[kSmallBatch];
+#pragma unroll
+    for (int k = 0; k < kSmallBatch; k++) {
+      const int e = e0 + k * kSmallThreads;
+      s[k]        = e < n_edges ? (int)min((unsigned)col[e], (unsigned)(n_src - 1)) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallBatch; k++)
+      if (s[k] >= 0) atomicAdd(&start[s[k]], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of start[0..n_src]: a contiguous chunk per thread, wave scans, 16 wave sums
+    const int chunk = (n_src + kSmallThreads) / kSmallThreads, lo = min(t * chunk, n_src + 1), hi = min(lo + chunk, n_src + 1);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += start[i];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_sums[w] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int k = 0; k < w; k++) run += wave_sums[k];
+    for (int i = lo; i < hi; i++) {
+      const int c = start[i];
+      start[i]    = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int i = t; i <= n_src; i += kSmallThreads) row_ptr_t[i] = start[i];
+  if (edge_dst)
+    for (int e = t; e < n_edges; e += kSmallThreads) edge_dst[e] = row_of_edge(rows, n_rows, e);
+  __syncthreads();
+  for (int e0 = t; e0 < n_edges; e0 += kSmallThreads * kSmallBatch) {
+    int s[kSmallBatch];
+#pragma unroll
+    for (int k = 0; k < kSmallBatch; k++) {
+      const int e = e0 + k * kSmallThreads;
+      s[k]        = e < n_edges ? (int)min((unsigned)col[e], (unsigned)(n_src - 1)) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallBatch; k++)
+      if (s[k] >= 0) perm[atomicAdd(&start[s[k]], 1)] = e0 + k * kSmallThreads;
+  }
+  __syncthreads();
+  for (int s = t; s < n_src; s += kSmallThreads) {
+    const int b = s ? start[s - 1] : 0, d = start[s] - b;
+    if (d < 2) continue;
+    if (d > 32) {
+      const int h = atomicAdd(&n_hubs, 1);
+      if (h < kSmallHubMax) {
+        hubs[h] = s;
+        continue;
+      }
+    }
+    for (int i = 1; i < d; i++) {   // (also the hubs that did not fit the list: slow, correct)
+      const int v = perm[b + i];
+      int j       = i - 1;
+      while (j >= 0 && perm[b + j] > v) {
+        perm[b + j + 1] = perm[b + j];
+        j--;
+      }
+      perm[b + j + 1] = v;
+    }
+  }
+  __syncthreads();
+  const int nh = min(n_hubs, kSmallHubMax);
+  for (int h = w; h < nh; h += kSmallThreads / 64) {
+    const int s = hubs[h], b = s ? start[s - 1] : 0, d = start[s] - b;
+    if (d <= 512) {
+      for (int i = lane; i < d; i += 64) {
+        const int v = perm[b + i] & 0x7fffffff;
+        int r       = 0;
+        for (int j = 0; j < d; j++) r += (perm[b + j] & 0x7fffffff) < v;
+        out.emit(b + r, v);
+      }
+    } else {
+      int seen = 0;
+      for (int e0 = 0; e0 < n_edges; e0 += 64) {
+        const int e                 = e0 + lane;
+        const bool mine             = e < n_edges && (int)min((unsigned)col[e], (unsigned)(n_src - 1)) == s;
+        const unsigned long long bm = __ballot(mine);
+        if (mine) out.emit(b + seen + __popcll(bm & ((1ull << lane) - 1ull)), e);
+        seen += __popcll(bm);
+      }
+    }
+    for (int i = lane; i < d; i += 64) atomicOr(&perm[b + i], (int)0x80000000);   // (entries another lane may still be comparing: the flag is masked there)
+  }
+  __syncthreads();
+  for (int p = t; p < n_edges; p += kSmallThreads) {
+    const int e = perm[p];
+    if (e >= 0) out.emit(p, e);
+  }
+}
+
+bool small_transpose_enabled()
+{
+  static const bool on = [] {
+    const char* v = getenv("WGAMD_TRANSPOSE_SMALL");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
 unsigned key_bits(int64_t n_src)
 {
   unsigned bits = 1;
@@ -146,6 +297,15 @@ extern "C" wholememory_error_code_t wgamd_csr_transpose_i32(const int* row_ptr, 
     auto st = static_cast<hipStream_t>(stream);
     if (n_edges == 0) {
       WG_HIP_CHECK(hipMemsetAsync(row_ptr_t, 0, sizeof(int) * (size_t)(n_src + 1), st));
+      return;
+    }
+    if (n_src >= 1 && n_src + 1 + n_edges + n_rows + 1 <= kSmallLdsInts && small_transpose_enabled()) {
+      const size_t lds = sizeof(int) * (size_t)(n_src + 1 + n_edges + n_rows + 1);
+      WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_transpose_small_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * kSmallLdsInts)));
+      csr_transpose_small_kernel<<<1, kSmallThreads, lds, st>>>(row_ptr, col, (int)n_rows, (int)n_edges, (int)n_src, row_ptr_t, edge_perm,
+                                                               edge_dst, col_t);
+      WG_HIP_CHECK(hipGetLastError());
       return;
     }
     char* ws        = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);

@@ -49,17 +49,28 @@ class StagedBatch:
                  table: Optional[torch.Tensor]):
         self.hops, self.batch_size, self.row_cap, self.edge_cap, self.node_cap = hops, batch_size, list(row_cap), list(edge_cap), node_cap
         i32 = dict(dtype=torch.int32, device=device)
-        self.row_ptr = [torch.zeros(r + 1, **i32) for r in row_cap]
-        self.self0 = [torch.zeros(r, dtype=torch.int64, device=device) for r in row_cap]
-        self.col = [torch.zeros(e, **i32) for e in edge_cap]
+        R, E = sum(row_cap), sum(edge_cap)
+        # The hops' arrays lie back to back, and `row_ptr_all` is their CSRs as ONE CSR (hop k's rows from sum(row_cap[:k]), its
+        # edges from sum(edge_cap[:k])): a layer over hops 0..j is ONE launch over a prefix instead of j + 1 launches — every
+        # launch of a mini-batch's step sits on its latency floor (30-47 us for 1-10 k rows), so launches are what a step costs.
+        self.row_ptr_all = torch.zeros(R + 1, **i32)
+        self.inv_deg_all = torch.ones(R, dtype=torch.float32, device=device)    # 1 / max(degree, 1): the mean's backward
+        self.self0_all = torch.zeros(R, dtype=torch.int64, device=device)
+        self.col_all = torch.zeros(E, **i32)
         # (the LAST hop's sources include the vertices it discovered itself, which no layer's output holds: no col_seg for it)
-        self.col_seg = [torch.zeros(e, **i32) if k + 1 < hops else None for k, e in enumerate(edge_cap)]
+        self.col_seg_all = torch.zeros(max(E - edge_cap[-1], 1), **i32)
+        self.self_seg_all = torch.arange(R, dtype=torch.int64, device=device)   # input row of an entry itself for layers >= 1
+        self.row_ptr = [torch.zeros(r + 1, **i32) for r in row_cap]
+        self.self0, self.col, self.col_seg, self.self_seg = [], [], [], []
+        rb = eb = 0
+        for k, (r, e) in enumerate(zip(row_cap, edge_cap)):
+            self.self0.append(self.self0_all[rb:rb + r])
+            self.self_seg.append(self.self_seg_all[rb:rb + r])
+            self.col.append(self.col_all[eb:eb + e])
+            self.col_seg.append(self.col_seg_all[eb:eb + e] if k + 1 < hops else None)
+            rb, eb = rb + r, eb + e
         self.n_id = torch.zeros(node_cap, dtype=id_dtype, device=device)
         self.sizes = torch.zeros(2 * hops + 2, **i32)
-        base, self.self_seg = 0, []
-        for r in row_cap:                       # input row of a frontier entry itself for layers >= 1: its row of the layout
-            self.self_seg.append(torch.arange(base, base + r, dtype=torch.int64, device=device))
-            base += r
         self.table = table
         self.x = LazyRows(table, self.n_id) if table is not None else None
         self.seeds = self.n_id[:batch_size]
@@ -76,17 +87,24 @@ class StagedBatch:
     def n_live_seeds(self):
         return self.sizes[0].to(torch.float32)
 
-    def layer_graph(self, layer: int) -> LayerGraph:
+    def layer_graph(self, layer: int, per_hop: bool = False) -> LayerGraph:
+        """The trimmed graph of layer ``layer``: ONE ``HopGraph`` over hops 0..H-1-layer back to back (``per_hop=True``: one
+        ``HopGraph`` per hop, the form ``CallGroup.layer_graph`` has — same output rows either way)."""
         H = self.hops
         if not 0 <= layer < H:
             raise IndexError(f"layer {layer} of a {H}-hop mini-batch")
-        if layer not in self._layers:
-            hops = []
-            for k in range(H - layer):
-                hops.append(HopGraph(self.row_ptr[k], self.col[k] if layer == 0 else self.col_seg[k],
-                                     self.self0[k] if layer == 0 else self.self_seg[k]))
-            self._layers[layer] = LayerGraph(hops)
-        return self._layers[layer]
+        key = (layer, bool(per_hop))
+        if key not in self._layers:
+            if per_hop:
+                hops = [HopGraph(self.row_ptr[k], self.col[k] if layer == 0 else self.col_seg[k],
+                                 self.self0[k] if layer == 0 else self.self_seg[k]) for k in range(H - layer)]
+            else:
+                R, E = sum(self.row_cap[:H - layer]), sum(self.edge_cap[:H - layer])
+                hops = [HopGraph(self.row_ptr_all[:R + 1], (self.col_all if layer == 0 else self.col_seg_all)[:E],
+                                 (self.self0_all if layer == 0 else self.self_seg_all)[:R])]
+                hops[0].inv_deg = self.inv_deg_all[:R]
+            self._layers[key] = LayerGraph(hops)
+        return self._layers[key]
 
     def refilled(self):
         """The buffers hold another mini-batch: drop what eager code cached on the hop objects (transposes, self-loop forms).
@@ -167,7 +185,7 @@ class PerBatchStep:
             H, _ptr_array(res.offsets[:H]), _ptr_array(res.row_local[:H]), _ptr_array(res.frontier_seg[:H]),
             _ptr_array(res.frontier_local0[:H]), res.nodes.data_ptr(), torch_dtype_to_wm(res.nodes.dtype), res.node_seg.data_ptr(),
             int(b), sb._caps[0], sb._caps[1], sb.node_cap, sb._ptrs[0], sb._ptrs[1], sb._ptrs[2], sb._ptrs[3], sb.n_id.data_ptr(),
-            sb.sizes.data_ptr(), get_stream()), "wgamd_call_group_stage_batch")
+            sb.sizes.data_ptr(), sb.row_ptr_all.data_ptr(), sb.inv_deg_all.data_ptr(), get_stream()), "wgamd_call_group_stage_batch")
         sb.refilled()
 
     def _snapshot(self):

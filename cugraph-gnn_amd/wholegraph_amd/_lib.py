@@ -270,7 +270,12 @@ SYMBOLS = {
     "wgamd_call_group_hop_rows_batched": (c_int, [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 8 + [c_void_p]),
     "wgamd_call_group_layer_cols": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 5),
     "wgamd_call_group_stage_batch": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_int, c_void_p, c_void_p, c_int]
-                                     + [c_void_p] * 7),
+                                     + [c_void_p] * 9),
+    "wgamd_softmax_xent_state_bytes": (c_size_t, [c_int64]),
+    "wgamd_softmax_xent_forward_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p]),
+    "wgamd_softmax_xent_backward_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_int64, c_void_p]),
     "wgamd_bias_act_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wgamd_gat_transform_heads_supported": (c_int, [c_int, c_int, c_int]),
     "wgamd_gat_transform_weight_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -11,7 +11,7 @@ plain ``torch.nn.functional.linear`` (hipBLASLt, MFMA).
 """
 import math
 import os
-from typing import Tuple, Union
+from typing import Optional, Tuple, Union
 
 import torch
 
@@ -398,6 +398,52 @@ class _SpmmCsr(torch.autograd.Function):
     def backward(ctx, grad_out):
         row_ptr, col = ctx.saved_tensors
         return spmm_csr_backward(row_ptr, col, grad_out, ctx.n_src, ctx.mean), None, None, None
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, row_weight):
+        n, C = logits.shape
+        lib, dev = L.lib(), logits.device
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        state = torch.zeros((lib.wgamd_softmax_xent_state_bytes(n) + 3) // 4, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        L.check(lib.wgamd_softmax_xent_forward_f32(logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(),
+                                                   row_weight.data_ptr() if row_weight is not None else None, lse.data_ptr(),
+                                                   state.data_ptr(), 1, loss.data_ptr(), get_stream()), "wgamd_softmax_xent_forward_f32")
+        ctx.save_for_backward(logits, target, lse, state)
+        ctx.row_weight = row_weight
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        logits, target, lse, state = ctx.saved_tensors
+        n, C = logits.shape
+        g = grad_loss.to(torch.float32).contiguous()
+        gx = torch.empty((n, C), dtype=torch.float32, device=logits.device)
+        w = ctx.row_weight
+        L.check(L.lib().wgamd_softmax_xent_backward_f32(logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(),
+                                                        w.data_ptr() if w is not None else None, lse.data_ptr(), state.data_ptr(),
+                                                        g.data_ptr(), gx.data_ptr(), gx.stride(0), get_stream()),
+                "wgamd_softmax_xent_backward_f32")
+        return gx, None, None
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, row_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``torch.nn.functional.cross_entropy(logits, target)`` (mean over the rows whose target is not negative — torch's
+    ``ignore_index``), optionally with a float weight per ROW (``loader.StagedBatch.seed_mask``: the padding of a ragged last
+    mini-batch) — as two launches, forward and backward, instead of torch's seven: the loss of the reference's training loops
+    (pylibwholegraph/torch/gnn_model.py:119-125) inside a per-mini-batch step whose every launch sits on its latency floor.
+    fp32 logits [n, C] with unit column stride, int64 targets; anything else goes to torch."""
+    if (logits.dim() != 2 or logits.dtype != torch.float32 or not logits.is_cuda or logits.stride(1) != 1 or logits.shape[0] == 0
+            or target.dtype != torch.int64 or target.shape != logits.shape[:1]):
+        loss = torch.nn.functional.cross_entropy(logits, target, reduction="none", ignore_index=-100)
+        w = (target >= 0).to(loss.dtype) if row_weight is None else row_weight * (target >= 0)
+        return (loss * w).sum() / w.sum()
+    target = target.contiguous()
+    if row_weight is not None:
+        row_weight = row_weight.to(torch.float32).contiguous()
+    return _SoftmaxXent.apply(logits, target, row_weight)
 
 
 def spmm_csr(x, row_ptr, col, reduce: str = "mean"):
@@ -847,6 +893,7 @@ class HopGraph:
     def __init__(self, row_ptr, col, self_rows):
         self.row_ptr, self.col, self.self_rows = row_ptr, col, self_rows
         self._t = None
+        self.inv_deg = None     # float32 [n] = 1 / max(degree, 1) when whoever built the hop has it (loader.StagedBatch)
 
     @property
     def n_rows(self):
@@ -933,7 +980,8 @@ def _sage_dx(hop: HopGraph, gz: torch.Tensor, w_l: torch.Tensor, w_r: torch.Tens
         row_ptr_t, col_t, _ = hop.transposed(n_src, need_self=False)
         g = gz
         if mean:
-            g = gz / (hop.row_ptr[1:] - hop.row_ptr[:-1]).clamp_(min=1).unsqueeze(1)
+            g = gz * hop.inv_deg.unsqueeze(1) if hop.inv_deg is not None \
+                else gz / (hop.row_ptr[1:] - hop.row_ptr[:-1]).clamp_(min=1).unsqueeze(1)
         gl = g @ w_l
         E = col_t.shape[0]
         gx = torch.empty((n_src, F_), dtype=torch.float32, device=gz.device)

@@ -403,13 +403,18 @@ wholememory_error_code_t wgamd_call_group_hop_rows_batched(const int* offsets, c
  * is given, col_seg_out[k]: the same sources as rows of a trimmed layer's output, laid out as hop 0's row_cap[0] rows, then
  * hop 1's row_cap[1], ... .  n_id_out [node_cap] = the mini-batch's vertices (padding repeats the first).  sizes_out
  * (nullable, int32 [2 n_hops + 2]): live rows and edges per hop, live vertices, 1 if anything exceeded its capacity (the
- * copy is then truncated).  One launch, no synchronisation. */
+ * copy is then truncated).  row_ptr_all_out (nullable, int32 [sum row_cap + 1]): the hops' CSRs back to back as ONE CSR — hop
+ * k's rows start at sum(row_cap[:k]) and point at edges from sum(edge_cap[:k]); a caller that allocates the hops' col /
+ * self_rows arrays back to back runs a layer over hops 0..j as one launch over a prefix of it; inv_deg_all_out (nullable, float
+ * [sum row_cap]) = 1 / max(degree, 1) of every row of that CSR (what the backward of a mean aggregation scales by).  One
+ * launch, no synchronisation. */
 wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* const* offsets, const int* const* row_local,
                                                       const int* const* frontier_seg, const int* const* frontier_local0,
                                                       const void* nodes, wholememory_dtype_t id_dtype, const int* node_seg,
                                                       int batch, const int* row_cap, const int* edge_cap, int node_cap,
                                                       int* const* row_ptr_out, int64_t* const* self_rows_out, int* const* col_out,
-                                                      int* const* col_seg_out, void* n_id_out, int* sizes_out, void* stream);
+                                                      int* const* col_seg_out, void* n_id_out, int* sizes_out, int* row_ptr_all_out,
+                                                      float* inv_deg_all_out, void* stream);
 
 /* One hop of a PyG-style call group renumbered for the LAYER that consumes it (cugraph_pyg_amd.loader.CallGroup).  The
  * layer's input rows are `n_segments` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at rows
@@ -700,6 +705,23 @@ wholememory_error_code_t wgamd_unique_bounded(const void* ids, wholememory_dtype
 wholememory_error_code_t wgamd_unique_bounded_live(const void* ids, wholememory_dtype_t id_dtype, int64_t n, const int* n_live_dev,
                                                    int64_t id_bound, int64_t* distinct, int* inverse, int* n_distinct_dev,
                                                    int* out_of_bound_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Softmax cross-entropy of the seeds' logits — the loss of every training loop of the reference
+ * (/root/reference/python/pylibwholegraph/pylibwholegraph/torch/gnn_model.py:119-125: F.cross_entropy inside the batch loop).
+ *   loss = sum_i w_i (lse_i - x[i, t_i]) / sum_i w_i  over rows with 0 <= t_i < n_classes (a negative target = torch's
+ *   ignore_index), w_i = row_weight[i] or 1;   d x[i, c] = g w_i (exp(x[i, c] - lse_i) - [c == t_i]) / sum_i w_i.
+ * forward: ONE launch; writes lse [n_rows], *loss_out, and into `state` (wgamd_softmax_xent_state_bytes(n_rows) bytes, zeroed
+ * by the call unless state_is_zeroed; reusable as it is left) the sum of weights the backward divides by.  Per-workgroup
+ * partial sums are added in workgroup order: run-to-run deterministic.  backward: ONE launch; grad_loss (nullable = 1) is a
+ * DEVICE scalar, so the pair sits inside a captured per-mini-batch step (cugraph_pyg_amd.loader.PerBatchStep). */
+size_t wgamd_softmax_xent_state_bytes(int64_t n_rows);
+wholememory_error_code_t wgamd_softmax_xent_forward_f32(const float* logits, int64_t ld, int64_t n_rows, int n_classes,
+                                                        const int64_t* target, const float* row_weight, float* lse, void* state,
+                                                        int state_is_zeroed, float* loss_out, void* stream);
+wholememory_error_code_t wgamd_softmax_xent_backward_f32(const float* logits, int64_t ld, int64_t n_rows, int n_classes,
+                                                         const int64_t* target, const float* row_weight, const float* lse,
+                                                         const void* state, const float* grad_loss, float* grad_logits, int64_t ldg,
+                                                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -319,7 +319,8 @@ def test_gat_backward_kernels_match_autograd_of_dense_formula(hiplib, H, C, hubs
     assert not nn.gat_backward_supported(2, 5)       # falls back to the torch-op backward (covered by the layer test)
 
 
-@pytest.mark.parametrize("n_dst,n_src,max_deg", [(1000, 5000, 12), (1, 1, 1), (257, 3, 40), (5000, 100000, 3), (64, 10, 0)])
+@pytest.mark.parametrize("n_dst,n_src,max_deg", [(1000, 5000, 12), (1, 1, 1), (257, 3, 40), (5000, 100000, 3), (64, 10, 0),
+                                                  (2000, 60, 10), (1200, 9800, 18), (3000, 700, 22), (20000, 9000, 12)])
 def test_csr_transpose_matches_stable_sort(hiplib, n_dst, n_src, max_deg):
     """wgamd_csr_transpose_i32 (one radix sort over the bits a source row needs) against the torch formulation it replaces:
     stable sort of the sources, bincount + cumsum, repeat_interleave.  Sources without edges, rows without edges, no edges."""
@@ -343,6 +344,32 @@ def test_csr_transpose_matches_stable_sort(hiplib, n_dst, n_src, max_deg):
     assert torch.equal(col_t.cpu().long(), want_dst[want_perm])
     rpt2, ct2 = nn.csr_transpose(rp, cc, n_src)
     assert torch.equal(rpt2, row_ptr_t) and torch.equal(ct2, col_t)
+
+
+def test_csr_transpose_one_launch_path_segment_tiers(hiplib):
+    """The one-launch transpose of a small hop (n_src + E <= 36 k: one workgroup, counters and permutation in LDS) orders every
+    source's segment by edge id with three mechanisms — <= 32 entries, <= 512, longer — and keeps a list of at most 1024 long
+    segments: 1040 sources of exactly 33 edges overflow that list; a mix of degrees 1 / 40 / 600 / 3000 takes every tier."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator().manual_seed(11)
+    cases = [torch.arange(1040).repeat(33)[torch.randperm(1040 * 33, generator=g)],
+             torch.cat([torch.arange(100, 2100), torch.full((40,), 3), torch.full((600,), 7), torch.full((3000,), 9),
+                        torch.full((513,), 11), torch.full((33,), 13)])[torch.randperm(2000 + 40 + 600 + 3000 + 513 + 33, generator=g)]]
+    for col in cases:
+        E, n_src, n_dst = col.numel(), int(col.max()) + 5, 611
+        cuts = torch.sort(torch.randint(0, E + 1, (n_dst - 1,), generator=g)).values
+        row_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), cuts, torch.tensor([E])]).int()
+        assert n_src + 1 + E + n_dst + 1 <= 36 * 1024
+        row_ptr_t, perm, dst, col_t = nn._csr_transpose(row_ptr.cuda(), col.int().cuda(), n_src, want_perm=True, want_dst=True, want_col_t=True)
+        want_perm = torch.sort(col, stable=True).indices
+        want_dst = torch.repeat_interleave(torch.arange(n_dst), (row_ptr[1:] - row_ptr[:-1]).long())
+        want_rpt = torch.zeros(n_src + 1, dtype=torch.int64)
+        want_rpt[1:] = torch.cumsum(torch.bincount(col, minlength=n_src), 0)
+        assert torch.equal(row_ptr_t.cpu().long(), want_rpt)
+        assert torch.equal(perm.cpu().long(), want_perm)
+        assert torch.equal(dst.cpu().long(), want_dst)
+        assert torch.equal(col_t.cpu().long(), want_dst[want_perm])
 
 
 @pytest.mark.parametrize("n_src,used,E", [(5_000_000, 1000, 30000), (3_000_000, 3_000_000, 2000), (200_000, 50, 5), (40, 40, 3)])

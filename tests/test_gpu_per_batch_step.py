@@ -40,7 +40,7 @@ def _model(seed=5):
     return convs.cuda()
 
 
-def _step_fn(model, opt, labels):
+def _step_fn(model, opt, labels, fused_loss=False):
     import torch
 
     def step(batch):
@@ -49,8 +49,12 @@ def _step_fn(model, opt, labels):
         for j, c in enumerate(model):
             h = c(h, batch.layer_graph(j), act="relu" if j + 1 < len(model) else None)
         B = batch.batch_size
-        per_seed = torch.nn.functional.cross_entropy(h[:B], labels[batch.seeds], reduction="none")
-        loss = (per_seed * batch.seed_mask[:B]).sum() / batch.n_live_seeds
+        if fused_loss:      # wholegraph_amd.nn.cross_entropy: one launch forward, one backward (what bench.py's step uses)
+            from wholegraph_amd import nn as wnn
+            loss = wnn.cross_entropy(h[:B], labels[batch.seeds], batch.seed_mask[:B])
+        else:
+            per_seed = torch.nn.functional.cross_entropy(h[:B], labels[batch.seeds], reduction="none")
+            loss = (per_seed * batch.seed_mask[:B]).sum() / batch.n_live_seeds
         loss.backward()
         opt.step()
         return loss
@@ -158,8 +162,8 @@ def test_staged_batch_is_the_loaders_data(hiplib):
     assert n_checked == 6
 
 
-@pytest.mark.parametrize("fanout", [[5, 3], [4, 3, 2]])
-def test_one_captured_step_has_the_fp64_gradients_of_its_mini_batch(hiplib, fanout):
+@pytest.mark.parametrize("fanout,fused_loss", [([5, 3], False), ([4, 3, 2], False), ([5, 3], True), ([4, 3, 2], True)])
+def test_one_captured_step_has_the_fp64_gradients_of_its_mini_batch(hiplib, fanout, fused_loss):
     import torch
     from wholegraph_amd import nn
     from cugraph_pyg_amd.loader import NeighborLoader, PerBatchStep
@@ -174,7 +178,7 @@ def test_one_captured_step_has_the_fp64_gradients_of_its_mini_batch(hiplib, fano
         p.data = (torch.rand(p.shape, generator=g) - 0.5) * 0.3
     model = model.cuda()
     opt = torch.optim.SGD(model.parameters(), lr=0.0)        # lr 0: every step sees the same weights, p.grad stays readable
-    stepper = PerBatchStep(_step_fn(model, opt, labels), table=feat, optimizer=opt)
+    stepper = PerBatchStep(_step_fn(model, opt, labels, fused_loss), table=feat, optimizer=opt)
     n = 0
     for grp in loader.call_groups():
         datas = grp.to_data_list()
@@ -212,7 +216,7 @@ def test_an_epoch_of_captured_steps_equals_the_eager_per_batch_loop(hiplib):
     # captured: the same steps, one graph replay per mini-batch
     model = _model()
     opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
-    stepper = PerBatchStep(_step_fn(model, opt, labels), table=feat, optimizer=opt)
+    stepper = PerBatchStep(_step_fn(model, opt, labels, fused_loss=True), table=feat, optimizer=opt)
     steps = 0
     for grp in loader().call_groups():
         stepper.run_group(grp)

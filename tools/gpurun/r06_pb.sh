@@ -1,14 +1,14 @@
-set -x
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r06_pb; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-cd $R
-timeout 900 python -m pytest tests/test_gpu_per_batch_step.py -x -q 2>&1 | tail -30 > $OUT/tests.log
-cat $OUT/tests.log
-timeout 900 python -m pytest tests/test_gpu_callgroup.py tests/test_gpu_call_group_loader.py tests/test_gpu_sage_train.py -x -q 2>&1 | tail -3 >> $OUT/tests.log
-tail -3 $OUT/tests.log
-python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_plain.log 2>&1; grep "^{\"metric" $OUT/bench_plain.log | tail -1 > $OUT/bench_n1.json
-tail -5 $OUT/bench_plain.log | cut -c1-600
+R=$GRAFT_REPO_ROOT; cd $R
+python -m pytest tests/test_gpu_aggregate.py -m gpu -x -q -k "transpose" 2>&1 | tail -5
+python -m pytest tests/test_gpu_per_batch_step.py tests/test_gpu_sage_train.py tests/test_gpu_cross_entropy.py tests/test_gpu_example_training.py -m gpu -x -q 2>&1 | tail -5
+cd /tmp; export TMPDIR=/tmp
+GROUPS=2 TRAIN=1 python $R/tools/profile_per_batch_step.py 2>&1 | tail -1
+GROUPS=2 TRAIN=0 python $R/tools/profile_per_batch_step.py 2>&1 | tail -1
+GROUPS=1 TRAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_pb -o pb -- python $R/tools/profile_per_batch_step.py > /dev/null 2>&1
 python - <<PY
-import json
-d=json.load(open("$OUT/bench_n1.json")); print(d["value"], d["ms_per_step"], d.get("stage_ms_per_call_group"));
-for k,v in d["variants"].items(): print(k, {a:b for a,b in v.items() if a!="note" and a!="wgrad_roofline"})
+import csv
+rows=list(csv.DictReader(open('/tmp/pt_pb/pb_kernel_stats.csv')))
+for r in rows:
+    c=int(r['Calls'])
+    if c>=900: print("%-100s calls %5d avg %7.1f us"%(r['Name'][:100],c,float(r['AverageNs'])/1e3))
 PY
