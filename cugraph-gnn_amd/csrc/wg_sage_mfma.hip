@@ -641,7 +641,7 @@ void launch_tr(const mfma_args& a, hipStream_t st)
   } else {
     // (128 < F <= 148: two whole 64-row tiles would fit, but a 64-lane group then carries sixteen rows of metadata per tile
     //  and the kernel spills ~100 VGPRs; 32-row tiles do not)
-    if (use_half_tiles(a.F)) {
+    if (use_half_tiles(a.F) && !a.full_tiles) {
       switch (a.N / 64) {
         case 1: launch_half<IdT, LG, 1>(a, st); break;
         case 2: launch_half<IdT, LG, 2>(a, st); break;
@@ -691,15 +691,17 @@ extern "C" wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* 
   });
 }
 
+extern "C" int wgamd_sage_layer_uses_half_tiles(int F) { return wgamd::use_half_tiles(F) ? 1 : 0; }
+
 extern "C" wholememory_error_code_t wgamd_sage_layer_weight_planes(const float* w_l, int64_t ldl, const float* w_r, int64_t ldr,
                                                                   const float* bias, int F, int N, int Np, void* planes,
-                                                                  float* bias_out, void* stream)
+                                                                  float* bias_out, int full_tiles, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_sage_layer_weight_planes", [&] {
     WG_REQUIRE_INPUT(w_l && w_r && planes && F > 0 && N > 0 && Np >= N && ldl >= F && ldr >= F, "bad weights");
     const int K = 2 * F, KS = (K + 15) / 16;
-    const int half      = use_half_tiles(F) ? 1 : 0;
+    const int half      = (use_half_tiles(F) && !full_tiles) ? 1 : 0;
     const int64_t total = (int64_t)KS * Np * 16;
     const int grid      = (int)std::min<int64_t>((total + 255) / 256, 2048);
     layer_weight_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(w_l, ldl, w_r, ldr, bias, F, N, Np, KS, half, planes, bias_out);
@@ -739,8 +741,8 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3_train(const in
     // x below 2 GB (extent known): 32-bit row offsets and buffer loads whose out-of-range slots read as zero
     const uint64_t xb = x_rows > 0 ? (uint64_t)x_rows * (uint64_t)ldx * 4u : 0;
     mfma_args a{row_ptr, col, n_rows, x, ldx, (uint32_t)(xb > 0 && xb < (1ull << 31) ? xb : 0), F, src_ids, self_rows, mean,
-                static_cast<const float*>(w_planes), N, (2 * F + 15) / 16, bias, relu, out, ldo, row_stride_dw(F), 0, nullptr,
-                ldx * 4, agg_out, ld_agg};
+                static_cast<const float*>(w_planes), N, (2 * F + 15) / 16, bias, relu & 1, out, ldo, row_stride_dw(F), 0, nullptr,
+                ldx * 4, agg_out, ld_agg, (relu & WGAMD_SAGE_FULL_TILES) != 0};
     const bool byte_offsets = src_ids != nullptr && src_ids_dtype == WGAMD_IDS_BYTE_OFFSETS;
     if (byte_offsets) {      // rows addressed by byte offsets from x (a peer-mapped table): 64-bit addressing, no extent
       a.row_scale = 1;
@@ -750,7 +752,7 @@ extern "C" wholememory_error_code_t wgamd_sage_layer_fused_bf16x3_train(const in
     static const int dbg = [] { const char* e = getenv("WGAMD_SAGE_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug = dbg;
     auto st = static_cast<hipStream_t>(stream);
-    if (agg_out == nullptr && !byte_offsets && sage_ws_supported(F, N)) {
+    if (agg_out == nullptr && !byte_offsets && !a.full_tiles && sage_ws_supported(F, N)) {
       if (src_ids != nullptr && src_ids_dtype != WHOLEMEMORY_DT_INT && src_ids_dtype != WHOLEMEMORY_DT_INT64)
         throw invalid_input("src_ids must be INT or INT64");
       return sage_ws_launch(a, src_ids == nullptr ? 0 : (src_ids_dtype == WHOLEMEMORY_DT_INT ? 1 : 2), st);

@@ -60,6 +60,8 @@ struct mfma_args {
   int64_t row_scale;         // bytes per unit of a row number: 4 ldx — or 1 when src_ids holds BYTE offsets (a peer-mapped table)
   float* agg_out;            // training (nullable): the finished mean / sum rows [n_rows, F] also go to HBM — the weight-gradient
   int64_t ld_agg;            // kernel (wg_sage_bwd.hip) reads them back instead of fetching every neighbour row a second time
+  int full_tiles;            // host side only: w_tiles holds fp32 tiles and the launch takes whole 32-row tiles even where F
+                             // would take 64-row half tiles (relu flag WGAMD_SAGE_FULL_TILES: a small launch, see wgamd_ext.h)
 };
 
 // a == hi + mid + lo exactly; every piece has <= 8 significant bits, i.e. is a bf16 (the top half of the fp32 word)

@@ -256,7 +256,8 @@ SYMBOLS = {
     "wgamd_sage_split_weight_bf16x3": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "wgamd_sage_weight_planes_bytes": (c_size_t, [c_int, c_int]),
     "wgamd_sage_layer_weight_planes": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
-                                             c_void_p]),
+                                             c_int, c_void_p]),
+    "wgamd_sage_layer_uses_half_tiles": (c_int, [c_int]),
     "wgamd_sage_layer_bf16x3_supported": (c_int, [c_int, c_int]),
     "wgamd_spmm_csr_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_int64, c_void_p]),

@@ -187,7 +187,17 @@ def sage_weight_planes(w_t: torch.Tensor) -> torch.Tensor:
     return planes
 
 
-def sage_layer_planes(w_l: torch.Tensor, w_r: torch.Tensor, bias, Np: int):
+SAGE_FULL_TILES = 2          # WGAMD_SAGE_FULL_TILES (include/wgamd_ext.h): or-ed into the relu argument of a small launch
+_SAGE_SMALL_ROWS = int(os.environ.get("WGAMD_SAGE_SMALL_ROWS", 8192))
+
+
+def sage_layer_small_launch(F_: int, n_rows: int) -> bool:
+    """A launch of one mini-batch's rows at a width whose throughput shape is 64-row half tiles (F > 148): whole 32-row tiles
+    give it twice the workgroups, each with half the serial chain of row fetches (47 -> 30 us for 1.2 k rows at F = 256)."""
+    return 0 < n_rows <= _SAGE_SMALL_ROWS and bool(L.lib().wgamd_sage_layer_uses_half_tiles(int(F_)))
+
+
+def sage_layer_planes(w_l: torch.Tensor, w_r: torch.Tensor, bias, Np: int, full_tiles: bool = False):
     """``(planes, padded bias, N)`` of a layer straight from its ``torch.nn.Linear`` parameters in ONE launch
     (``wgamd_sage_layer_weight_planes``) — what ``sage_layer_fused_forward(prepared=...)`` takes instead of deriving the
     transposed / padded / split forms with half a dozen framework launches.  Not cached: made for captured training steps,
@@ -197,9 +207,9 @@ def sage_layer_planes(w_l: torch.Tensor, w_r: torch.Tensor, bias, Np: int):
     bias_p = torch.empty(Np, dtype=torch.float32, device=w_l.device) if (bias is not None or Np != N) else None
     L.check(L.lib().wgamd_sage_layer_weight_planes(w_l.data_ptr(), w_l.stride(0), w_r.data_ptr(), w_r.stride(0),
                                                    None if bias is None else bias.data_ptr(), F_, N, Np, planes.data_ptr(),
-                                                   None if bias_p is None else bias_p.data_ptr(), get_stream()),
+                                                   None if bias_p is None else bias_p.data_ptr(), int(bool(full_tiles)), get_stream()),
             "wgamd_sage_layer_weight_planes")
-    return planes, bias_p, N
+    return planes, bias_p, N, bool(full_tiles)
 
 
 def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=False, mean=True, src_ids=None, out=None,
@@ -255,18 +265,19 @@ def sage_layer_fused_forward(row_ptr, col, x, self_rows, w_t, bias=None, relu=Fa
     if (sage_layer_fused_supported(F_, N) and _pick_precision(F_, N, precision) == "bf16x3"
             and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):      # its epilogue stores 16 B per lane
         planes = prepared[0] if prepared is not None else sage_weight_planes(w_t)
+        flags = int(bool(relu)) | (SAGE_FULL_TILES if prepared is not None and prepared[3] else 0)
         if agg_out is not None:
             assert agg_out.shape == (n_rows, F_) and agg_out.dtype == torch.float32 and agg_out.stride(1) == 1
             L.check(L.lib().wgamd_sage_layer_fused_bf16x3_train(
                 row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
                 self_rows.data_ptr(), int(bool(mean)), planes.data_ptr(), N, None if bias is None else bias.data_ptr(),
-                int(bool(relu)), out.data_ptr(), out.stride(0), agg_out.data_ptr(), agg_out.stride(0), get_stream()),
+                flags, out.data_ptr(), out.stride(0), agg_out.data_ptr(), agg_out.stride(0), get_stream()),
                 "wgamd_sage_layer_fused_bf16x3_train")
             return done(out)
         L.check(L.lib().wgamd_sage_layer_fused_bf16x3(
             row_ptr.data_ptr(), col.data_ptr(), n_rows, x.data_ptr(), x.stride(0), x.shape[0], F_, ids_ptr, ids_dt,
             self_rows.data_ptr(), int(bool(mean)), planes.data_ptr(), N, None if bias is None else bias.data_ptr(),
-            int(bool(relu)), out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_bf16x3")
+            flags, out.data_ptr(), out.stride(0), get_stream()), "wgamd_sage_layer_fused_bf16x3")
         return done(out)
     assert agg_out is None, "agg_out: only the bf16x3 layer kernel keeps the aggregate (sage_layer_train_supported)"
     L.check(L.lib().wgamd_sage_layer_fused_f32(
@@ -1007,7 +1018,8 @@ def _sage_layer_launch(ctx, src, w_l, w_r, bias, conv, graph, ids, relu, mean):
     prepared = None
     if _capturing() and sage_layer_fused_supported(F_, Np) and _pick_precision(F_, Np, None) == "bf16x3" \
             and w_l.stride(1) == 1 and w_r.stride(1) == 1:
-        prepared = sage_layer_planes(w_l, w_r, bias, Np)
+        # (a mini-batch's few thousand rows at a width of half tiles: whole 32-row tiles — sage_layer_small_launch)
+        prepared = sage_layer_planes(w_l, w_r, bias, Np, full_tiles=all(sage_layer_small_launch(F_, h.n_rows) for h in graph.hops))
     w_t, aggs, at = (None if prepared is not None else conv._weight_t()), [], 0
     for h in graph.hops:
         n = h.n_rows

@@ -579,10 +579,16 @@ size_t wgamd_sage_weight_planes_bytes(int K, int N);
 int wgamd_sage_layer_bf16x3_supported(int F, int N);
 /* The same buffer (and the padded bias) straight from a layer's parameters in torch.nn.Linear's layout — w_l, w_r [N, F]
  * row-major, bias [N] (nullable): the operand [W_l | W_r]^T with its columns zero-padded from N to Np, one launch.  `planes`
- * holds wgamd_sage_weight_planes_bytes(2F, Np) bytes, `bias_out` (nullable) Np floats. */
+ * holds wgamd_sage_weight_planes_bytes(2F, Np) bytes, `bias_out` (nullable) Np floats; `full_tiles`: see WGAMD_SAGE_FULL_TILES. */
 wholememory_error_code_t wgamd_sage_layer_weight_planes(const float* w_l, int64_t ldl, const float* w_r, int64_t ldr,
-                                                        const float* bias, int F, int N, int Np, void* planes, float* bias_out,
-                                                        void* stream);
+                                                        const float* bias, int F, int N, int Np, void* planes,
+                                                        float* bias_out, int full_tiles, void* stream);
+/* Tile shape of the layer kernel.  F > 148 (wgamd_sage_layer_uses_half_tiles) runs 64-row tiles whose mean half alone goes
+ * through LDS, with pre-split weight planes; a launch of a few thousand rows (ONE mini-batch: 20 tiles on 256 CUs, each a serial
+ * chain of row fetches) is faster on whole 32-row tiles.  Such a launch passes `relu | WGAMD_SAGE_FULL_TILES` and planes made with
+ * full_tiles = 1 (fp32 tiles); both default to the throughput shape. */
+#define WGAMD_SAGE_FULL_TILES 2
+int wgamd_sage_layer_uses_half_tiles(int F);
 wholememory_error_code_t wgamd_sage_split_weight_bf16x3(const float* w_t, int64_t ldw, int K, int N, void* planes,
                                                         void* stream);
 wholememory_error_code_t wgamd_sage_layer_fused_bf16x3(const int* row_ptr, const int* col, int64_t n_rows, const float* x,

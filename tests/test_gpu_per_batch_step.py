@@ -255,3 +255,41 @@ def test_layers_that_are_not_capture_safe_refuse_loudly(hiplib):
     torch.cuda.synchronize()
     # the stream is usable afterwards
     assert float(torch.ones(4, device="cuda").sum()) == 4.0
+
+
+@pytest.mark.parametrize("F_,N,n,relu", [(256, 47, 1248, False), (256, 256, 3000, True), (160, 64, 500, True), (208, 128, 77, False)])
+def test_small_launch_tile_shape_matches_the_throughput_shape(hiplib, F_, N, n, relu):
+    """A mini-batch's few thousand rows at a width whose throughput shape is 64-row half tiles (F > 148) run on whole 32-row
+    tiles (`relu | WGAMD_SAGE_FULL_TILES`, planes made with full_tiles = 1): same layer — output and kept aggregate against the
+    float64 formula at 1e-5 x sum|terms|, and against the half-tile launch of the same operands."""
+    import torch
+    from wholegraph_amd import nn
+    g = torch.Generator().manual_seed(F_ + N + n)
+    n_src = 4000
+    deg = torch.randint(0, 13, (n,), generator=g)
+    row_ptr = torch.zeros(n + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(0, n_src, (int(row_ptr[-1]),), generator=g).int()
+    self_rows = torch.randperm(n_src, generator=g)[:n]
+    x = torch.rand((n_src, F_), generator=g) * 2 - 1
+    w_l, w_r, bias = (torch.rand((N, F_), generator=g) - 0.5) * 0.2, (torch.rand((N, F_), generator=g) - 0.5) * 0.2, torch.rand(N, generator=g) - 0.5
+    assert nn.sage_layer_small_launch(F_, n) and not nn.sage_layer_small_launch(100, n) and not nn.sage_layer_small_launch(F_, 10 ** 6)
+    Np = nn._padded_width(N)
+    outs = []
+    for full in (False, True):
+        prepared = nn.sage_layer_planes(w_l.cuda(), w_r.cuda(), bias.cuda(), Np, full_tiles=full)
+        agg = torch.empty((n, F_), dtype=torch.float32, device="cuda")
+        out = nn.sage_layer_fused_forward(row_ptr.cuda(), col.cuda(), x.cuda(), self_rows.cuda(), None, relu=relu, mean=True,
+                                          agg_out=agg, prepared=prepared)
+        outs.append((out.cpu().double(), agg.cpu().double()))
+    xd = x.double()
+    dst = torch.repeat_interleave(torch.arange(n), deg)
+    mean = torch.zeros((n, F_), dtype=torch.float64).index_add_(0, dst, xd[col.long()]) / deg.clamp(min=1).double().unsqueeze(1)
+    ref = mean @ w_l.double().t() + xd[self_rows] @ w_r.double().t() + bias.double()
+    mag = mean.abs() @ w_l.double().abs().t() + xd[self_rows].abs() @ w_r.double().abs().t() + bias.double().abs()
+    if relu:
+        ref = ref.clamp(min=0)
+    for out, agg in outs:
+        assert float(((out - ref).abs() / mag).max()) <= 1e-5
+        assert float((agg - mean).abs().max()) <= 1e-5
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-6 * float(mag.max())
