@@ -103,29 +103,28 @@ __global__ void __launch_bounds__(256) permute_sources_kernel(const int64_t* __r
   if (i < n) col[i] = (int)src[perm[i]];
 }
 
-// ---- a SMALL hop (one mini-batch of a per-mini-batch training step: 11 k edges, 10 k sources) in ONE launch --------------------
+// ---- a SMALL hop (one mini-batch of a per-mini-batch training step: 11 k edges, 11 k sources) in ONE launch --------------------
 // The radix-sort pipeline above is nine launches; at this size each of them is its launch latency and the transpose is 45 us of
-// a 390-us step.  Here one workgroup keeps the source counters AND the permutation in LDS: count (LDS atomics) -> scan -> place
-// every edge into its source's segment (LDS atomics: arbitrary order inside a segment) -> order every segment by edge id, which
-// IS the stable order (= ascending destination row: the gradient sums stay run-to-run deterministic) -> write.  Segments of up
-// to 32 entries: insertion sort by the thread that owns the source; up to 512: rank sort by one wave (d^2 / 64 steps); longer:
-// one wave re-reads the edge list and ranks the source's edges by ballots (E / 64 steps, whatever the degree).
-constexpr int kSmallThreads = 1024;
-constexpr int kSmallHubMax  = 1024;
-constexpr int kSmallLdsInts = 36 * 1024;   // n_src + 1 + n_edges + n_rows + 1 <= this (144 KB of the CU's 160 KB)
-constexpr int kSmallBatch   = 8;           // independent loads of the edge list in flight per thread
+// a 390-us step.  Here one workgroup keeps the source counters AND the permutation in LDS: destination row of every edge (by
+// rows, 16 bits) -> count (LDS atomics) -> scan -> place every edge, packed as dst:15 | edge:16, into its source's segment (LDS
+// atomics: arbitrary order inside a segment) -> order every segment by edge id, which IS the stable order (= ascending
+// destination row: the gradient sums stay run-to-run deterministic) -> write.  Segments of up to 8 entries: a sorting network
+// in the registers of the thread that owns the source (an insertion sort in LDS was 10 us of dependent LDS round trips); up to
+// 512: rank sort by one wave (d^2 / 64 steps); longer: one wave re-reads the edge list and ranks the source's edges by ballots
+// (E / 64 steps, whatever the degree).  Per phase at the products hop (us): 1.8 / 1.9 / 1.7 / 3.3 / sort / 0 / write.
+constexpr int kSmallThreads    = 1024;
+constexpr int kSmallHubMax     = 4096;
+constexpr int kSmallThreadSort = 8;
+constexpr int kSmallLdsInts    = 32 * 1024;   // n_src + 1 + n_edges + ceil(n_edges / 2) <= this (128 KB of the CU's 160 KB; the
+                                              // list of long segments takes 16)
+constexpr int kSmallBatch      = 8;           // independent loads of the edge list in flight per thread
+constexpr int kSmallEdgeMask   = 0xffff;      // packed entry: bit 31 = written by a long-segment pass, 30..16 dst, 15..0 edge
 
-struct small_out {
-  const int* row_ptr;   // (the LDS copy: eleven dependent steps of a search are 0.5 us there, 4 us through L2)
-  int n_rows;
-  int* edge_perm;
-  int* col_t;
-  __device__ __forceinline__ void emit(int p, int e) const
-  {
-    if (edge_perm) edge_perm[p] = e;
-    if (col_t) col_t[p] = row_of_edge(row_ptr, n_rows, e);
-  }
-};
+__device__ __forceinline__ void cswap(int& a, int& b)
+{
+  const int lo = min(a, b), hi = max(a, b);   // (edge ids sit in the LOW bits, but equal edges do not exist and the destination
+  a = lo, b = hi;                             //  row is monotone in the edge id: the packed words order like the edge ids)
+}
 
 __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
                                                                             int n_rows, int n_edges, int n_src,
@@ -134,15 +133,21 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
 {
   extern __shared__ int lds[];
   int* start = lds;                 // [n_src + 1]: counts -> offsets -> (after the placement) the END of every segment
-  int* perm  = lds + n_src + 1;     // [n_edges]: edge ids by source; bit 31 = already written by a hub pass
-  int* rows  = perm + n_edges;      // [n_rows + 1]: row_ptr
+  int* perm  = lds + n_src + 1;     // [n_edges]: packed entries by source
+  unsigned short* dst16 = reinterpret_cast<unsigned short*>(perm + n_edges);   // [n_edges]: destination row of every edge
   __shared__ int wave_sums[kSmallThreads / 64];
   __shared__ int n_hubs;
   __shared__ int hubs[kSmallHubMax];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const small_out out{rows, n_rows, edge_perm, col_t};
+  auto emit = [&](int p, int v) {
+    if (edge_perm) edge_perm[p] = v & kSmallEdgeMask;
+    if (col_t) col_t[p] = (v >> 16) & 0x7fff;
+  };
   for (int i = t; i <= n_src; i += kSmallThreads) start[i] = 0;
-  for (int i = t; i <= n_rows; i += kSmallThreads) rows[i] = row_ptr[i];
+  for (int r = t; r < n_rows; r += kSmallThreads) {
+    const int e1 = min(row_ptr[r + 1], n_edges);
+    for (int e = max(row_ptr[r], 0); e < e1; e++) dst16[e] = (unsigned short)r;
+  }
   if (t == 0) n_hubs = 0;
   __syncthreads();
   // (an id outside [0, n_src) is the caller's error; it is counted on the last source so that nothing is written out of bounds)
@@ -181,7 +186,7 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
   __syncthreads();
   for (int i = t; i <= n_src; i += kSmallThreads) row_ptr_t[i] = start[i];
   if (edge_dst)
-    for (int e = t; e < n_edges; e += kSmallThreads) edge_dst[e] = row_of_edge(rows, n_rows, e);
+    for (int e = t; e < n_edges; e += kSmallThreads) edge_dst[e] = dst16[e];
   __syncthreads();
   for (int e0 = t; e0 < n_edges; e0 += kSmallThreads * kSmallBatch) {
     int s[kSmallBatch];
@@ -191,29 +196,45 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
       s[k]        = e < n_edges ? (int)min((unsigned)col[e], (unsigned)(n_src - 1)) : -1;
     }
 #pragma unroll
-    for (int k = 0; k < kSmallBatch; k++)
-      if (s[k] >= 0) perm[atomicAdd(&start[s[k]], 1)] = e0 + k * kSmallThreads;
+    for (int k = 0; k < kSmallBatch; k++) {
+      const int e = e0 + k * kSmallThreads;
+      if (s[k] >= 0) perm[atomicAdd(&start[s[k]], 1)] = e | ((int)dst16[e] << 16);
+    }
   }
   __syncthreads();
   for (int s = t; s < n_src; s += kSmallThreads) {
     const int b = s ? start[s - 1] : 0, d = start[s] - b;
     if (d < 2) continue;
-    if (d > 32) {
+    if (d > kSmallThreadSort) {
       const int h = atomicAdd(&n_hubs, 1);
       if (h < kSmallHubMax) {
         hubs[h] = s;
         continue;
       }
-    }
-    for (int i = 1; i < d; i++) {   // (also the hubs that did not fit the list: slow, correct)
-      const int v = perm[b + i];
-      int j       = i - 1;
-      while (j >= 0 && perm[b + j] > v) {
-        perm[b + j + 1] = perm[b + j];
-        j--;
+      for (int i = 1; i < d; i++) {   // (a long segment that did not fit the list — 32 k / 9 < 4096: cannot happen; slow, correct)
+        const int v = perm[b + i];
+        int j       = i - 1;
+        while (j >= 0 && perm[b + j] > v) {
+          perm[b + j + 1] = perm[b + j];
+          j--;
+        }
+        perm[b + j + 1] = v;
       }
-      perm[b + j + 1] = v;
+      continue;
     }
+    int v[kSmallThreadSort];
+#pragma unroll
+    for (int i = 0; i < kSmallThreadSort; i++) v[i] = i < d ? perm[b + i] : 0x7fffffff;
+    // Batcher's odd-even merge sort of 8 (19 compare-exchanges, static register indices)
+    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+    cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+    cswap(v[1], v[2]); cswap(v[5], v[6]);
+    cswap(v[0], v[4]); cswap(v[1], v[5]); cswap(v[2], v[6]); cswap(v[3], v[7]);
+    cswap(v[2], v[4]); cswap(v[3], v[5]);
+    cswap(v[1], v[2]); cswap(v[3], v[4]); cswap(v[5], v[6]);
+#pragma unroll
+    for (int i = 0; i < kSmallThreadSort; i++)
+      if (i < d) perm[b + i] = v[i];
   }
   __syncthreads();
   const int nh = min(n_hubs, kSmallHubMax);
@@ -224,7 +245,7 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
         const int v = perm[b + i] & 0x7fffffff;
         int r       = 0;
         for (int j = 0; j < d; j++) r += (perm[b + j] & 0x7fffffff) < v;
-        out.emit(b + r, v);
+        emit(b + r, v);
       }
     } else {
       int seen = 0;
@@ -232,7 +253,7 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
         const int e                 = e0 + lane;
         const bool mine             = e < n_edges && (int)min((unsigned)col[e], (unsigned)(n_src - 1)) == s;
         const unsigned long long bm = __ballot(mine);
-        if (mine) out.emit(b + seen + __popcll(bm & ((1ull << lane) - 1ull)), e);
+        if (mine) emit(b + seen + __popcll(bm & ((1ull << lane) - 1ull)), e | ((int)dst16[e] << 16));
         seen += __popcll(bm);
       }
     }
@@ -240,8 +261,8 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
   }
   __syncthreads();
   for (int p = t; p < n_edges; p += kSmallThreads) {
-    const int e = perm[p];
-    if (e >= 0) out.emit(p, e);
+    const int v = perm[p];
+    if (v >= 0) emit(p, v);
   }
 }
 
@@ -299,8 +320,8 @@ extern "C" wholememory_error_code_t wgamd_csr_transpose_i32(const int* row_ptr, 
       WG_HIP_CHECK(hipMemsetAsync(row_ptr_t, 0, sizeof(int) * (size_t)(n_src + 1), st));
       return;
     }
-    if (n_src >= 1 && n_src + 1 + n_edges + n_rows + 1 <= kSmallLdsInts && small_transpose_enabled()) {
-      const size_t lds = sizeof(int) * (size_t)(n_src + 1 + n_edges + n_rows + 1);
+    if (n_src >= 1 && n_src + 1 + n_edges + (n_edges + 1) / 2 <= kSmallLdsInts && n_rows < 32768 && small_transpose_enabled()) {
+      const size_t lds = sizeof(int) * (size_t)(n_src + 1 + n_edges + (n_edges + 1) / 2);
       WG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_transpose_small_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * kSmallLdsInts)));
       csr_transpose_small_kernel<<<1, kSmallThreads, lds, st>>>(row_ptr, col, (int)n_rows, (int)n_edges, (int)n_src, row_ptr_t, edge_perm,

@@ -347,20 +347,22 @@ def test_csr_transpose_matches_stable_sort(hiplib, n_dst, n_src, max_deg):
 
 
 def test_csr_transpose_one_launch_path_segment_tiers(hiplib):
-    """The one-launch transpose of a small hop (n_src + E <= 36 k: one workgroup, counters and permutation in LDS) orders every
-    source's segment by edge id with three mechanisms — <= 32 entries, <= 512, longer — and keeps a list of at most 1024 long
-    segments: 1040 sources of exactly 33 edges overflow that list; a mix of degrees 1 / 40 / 600 / 3000 takes every tier."""
+    """The one-launch transpose of a small hop (n_src + 1.5 E <= 32 k: one workgroup, counters and permutation in LDS) orders
+    every source's segment by edge id with three mechanisms — <= 8 entries (a sorting network in registers), <= 512, longer —
+    and keeps a list of at most 4096 longer-than-8 segments (it cannot overflow): 1800 sources of exactly 9 edges, 1400 of 9 +
+    700 of 3, and a mix of degrees 1 / 40 / 600 / 3000 that takes every tier."""
     import torch
     from wholegraph_amd import nn
     g = torch.Generator().manual_seed(11)
-    cases = [torch.arange(1040).repeat(33)[torch.randperm(1040 * 33, generator=g)],
+    cases = [torch.arange(1800).repeat(9)[torch.randperm(1800 * 9, generator=g)],
+             torch.cat([torch.arange(1400).repeat(9), torch.arange(1400, 2100).repeat(3)])[torch.randperm(1400 * 9 + 700 * 3, generator=g)],
              torch.cat([torch.arange(100, 2100), torch.full((40,), 3), torch.full((600,), 7), torch.full((3000,), 9),
                         torch.full((513,), 11), torch.full((33,), 13)])[torch.randperm(2000 + 40 + 600 + 3000 + 513 + 33, generator=g)]]
     for col in cases:
         E, n_src, n_dst = col.numel(), int(col.max()) + 5, 611
         cuts = torch.sort(torch.randint(0, E + 1, (n_dst - 1,), generator=g)).values
         row_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), cuts, torch.tensor([E])]).int()
-        assert n_src + 1 + E + n_dst + 1 <= 36 * 1024
+        assert n_src + 1 + E + (E + 1) // 2 <= 32 * 1024
         row_ptr_t, perm, dst, col_t = nn._csr_transpose(row_ptr.cuda(), col.int().cuda(), n_src, want_perm=True, want_dst=True, want_col_t=True)
         want_perm = torch.sort(col, stable=True).indices
         want_dst = torch.repeat_interleave(torch.arange(n_dst), (row_ptr[1:] - row_ptr[:-1]).long())
