@@ -45,10 +45,13 @@ def test_export_open_read_write_across_processes(hiplib):
     from wholegraph_amd import _lib as L
     rows, dim = 4096, 100
     owner = (torch.arange(rows, device="cuda").view(-1, 1) * 1000 + torch.arange(dim, device="cuda")).float()
-    # hipIpcGetMemHandle wants the base of an allocation: take a block of its own from the driver, not a slice of torch's pool
-    big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")   # > the caching allocator's small-block pools
-    block = big[: rows * dim * 4].view(torch.float32).view(rows, dim)
-    assert block.data_ptr() == big.data_ptr()
+    # hipIpcGetMemHandle wants the base of an allocation: a block of its own straight from the driver (a tensor of torch's caching
+    # allocator may be a slice of a larger cached segment, depending on what ran before in the process)
+    from wholegraph_amd.tensor import _DevicePointerView
+    hip = ctypes.CDLL("libamdhip64.so")
+    base = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(base), ctypes.c_size_t(rows * dim * 4)) == 0
+    block = torch.as_tensor(_DevicePointerView(base.value, (rows, dim), "<f4", base), device="cuda")
     block.copy_(owner)
     torch.cuda.synchronize()
     handle = (ctypes.c_char * 64)()
@@ -58,4 +61,8 @@ def test_export_open_read_write_across_processes(hiplib):
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "CHILD_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
     torch.cuda.synchronize()
-    assert torch.all(block[5] == -1.0) and torch.equal(block[6], owner[6])
+    ok = bool(torch.all(block[5] == -1.0)) and torch.equal(block[6], owner[6])
+    del block
+    torch.cuda.synchronize()
+    hip.hipFree(base)
+    assert ok
