@@ -695,7 +695,7 @@ def load_profiled_avg(kernel, workload="products", prefer=None):
         with open(path, newline="") as f:
             rows = [r for r in csv.DictReader(f) if kernel + "<" in r["Name"] or kernel + "(" in r["Name"]]
         plain = [r for r in rows if kernel + "<void" in r["Name"]]   # not the fetch-folded variant (ids type != void)
-        pref = [r for r in rows if prefer is not None and kernel + "<" + prefer + "," in r["Name"]]
+        pref = [r for r in rows if prefer is not None and kernel + "<" + prefer + "," in r["Name"].replace(" ", "")]
         rows = pref or plain or rows
         if rows:
             r = max(rows, key=lambda r: float(r["AverageNs"]))
@@ -1163,8 +1163,9 @@ def main():
                 k = L - 1 - j
                 fj, nj = pipe.dims[j], pipe.dims[j + 1]
                 n_dst = hop_u[k - 1] if k >= 1 else G * BATCH
+                # (the layer runs at its output width padded to 64 / 128 / 256: 47 classes -> 64 columns)
                 kname = "sage_layer_mfma_kernel" if (nn_mod.sage_layer_fused_precision() == "bf16x3" and nn_mod.L.lib(
-                ).wgamd_sage_layer_bf16x3_supported(fj, nj)) else "sage_layer_fused_kernel"
+                ).wgamd_sage_layer_bf16x3_supported(fj, nn_mod._padded_width(nj))) else "sage_layer_fused_kernel"
                 kernels["sage_layer%d(fused)" % (j + 1)] = (kname, hop_e[k] * (4 * fj + 4) + n_dst * (4 * fj + 16) + n_dst * 4 * nj)
             std_shape = G == std_call_group and args.nodes == wv and args.edges == we   # the shape the committed profiles are of
 
@@ -1179,6 +1180,9 @@ def main():
                      "timing": "HIP events around the launch on the launch stream, one launch per call group of "
                                f"{G} mini-batches, averaged over {stage_n} call groups"}
                 pref = layer1_ids if st == "sage_layer1(fused)" else ("long" if (st == "gather" and pipe.dedup) else None)
+                if st.startswith("sage_layer") and st != "sage_layer1(fused)":
+                    # a hidden layer reads its input directly (ids type void); rows wider than 128 floats take 64-lane groups
+                    pref = "void,64" if pipe.dims[int(st[len("sage_layer")]) - 1] > 128 else "void"
                 if std_shape:
                     prof = load_profiled_avg(r["kernel"], args.workload, prefer=pref)
                     if prof:    # the same algorithmic bytes over the committed profile's average launch duration
