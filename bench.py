@@ -417,7 +417,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
             h = grp.x
             for j, c in enumerate(model):
                 h = c(h, grp.layer_graph(j), act="relu" if j < L - 1 else None)
-            loss = torch.nn.functional.cross_entropy(h, labels[grp.batch])
+            loss = wnn.cross_entropy(h, labels[grp.batch])     # (wgamd_softmax_xent: one launch forward, one backward)
             if probe:
                 ev[1].record()
             opt.zero_grad(set_to_none=True)
@@ -553,7 +553,7 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
                     for j, c in enumerate(gat):
                         h = c(h, grp.layer_graph(j), act="relu" if j == 0 else None)
                     if train:
-                        loss = torch.nn.functional.cross_entropy(h, labels[ids[n * G * BATCH:n * G * BATCH + h.shape[0]]])
+                        loss = wnn.cross_entropy(h, labels[ids[n * G * BATCH:n * G * BATCH + h.shape[0]]])
                         opt.zero_grad(set_to_none=True)
                         loss.backward()
                         opt.step()

@@ -214,6 +214,7 @@ def train_pass(model, tables, num_nodes, order, B, G, dev, groups=6, warm=2):
     """The TRAINING step of the same configuration through the same API, outside the headline's timed region: call groups ->
     2 x nn.HeteroConv{GATConv} under autograd (aggregate-first: nn._GatAggregateHeads, wgamd_gat_aggregate_heads_bwd_f32; x lazy,
     attention terms of the tables' rows) -> linear head -> cross-entropy on synthetic labels -> backward -> SGD step per group."""
+    from wholegraph_amd import nn as wnn
     params = [p for m in model for p in m.parameters()]
     for p in params:
         p.requires_grad_(True)
@@ -229,7 +230,7 @@ def train_pass(model, tables, num_nodes, order, B, G, dev, groups=6, warm=2):
             torch.cuda.synchronize()
             t0, edges = time.perf_counter(), 0
         out = head(forward_group(model, grp))
-        loss = torch.nn.functional.cross_entropy(out, labels[seeds[n * G * B:(n + 1) * G * B]])
+        loss = wnn.cross_entropy(out, labels[seeds[n * G * B:(n + 1) * G * B]])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

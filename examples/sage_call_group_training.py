@@ -74,7 +74,7 @@ def main():
             for j, conv in enumerate(convs):
                 h = conv(h, grp.layer_graph(j), act="relu" if j + 1 < L else None)
             y = community[grp.batch]                                # labels of the group's seeds, batch-major like h
-            loss = F.cross_entropy(h, y)
+            loss = wnn.cross_entropy(h, y)
             opt.zero_grad(set_to_none=True)
             loss.backward()
             opt.step()
