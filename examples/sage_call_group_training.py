@@ -22,7 +22,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cugraph-gnn_amd")]
 
 import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 from cugraph_pyg_amd.data import FeatureStore, GraphStore  # noqa: E402
 from cugraph_pyg_amd.loader import NeighborLoader, PerBatchStep  # noqa: E402
