@@ -158,6 +158,24 @@ def test_staged_batch_is_the_loaders_data(hiplib):
                 else:
                     assert sb.col_seg[k] is None
                 at_e, at_n = at_e + n_edges, at_n + n_rows
+            # the hops back to back as ONE CSR (what layer_graph(j) hands to a layer: one launch over a prefix) and 1 / degree
+            want_rp = [torch.zeros(1, dtype=torch.int32, device="cuda")]
+            ebase = 0
+            for k in range(grp.hops):
+                want_rp.append(sb.row_ptr[k][1:] + ebase)
+                ebase += sb.edge_cap[k]
+            want_rp = torch.cat(want_rp)
+            assert torch.equal(sb.row_ptr_all, want_rp)
+            assert torch.equal(sb.col_all, torch.cat(sb.col)) and torch.equal(sb.self0_all, torch.cat(sb.self0))
+            deg = (want_rp[1:] - want_rp[:-1]).clamp(min=1).float()
+            assert torch.equal(sb.inv_deg_all, 1.0 / deg)
+            for layer in range(grp.hops):
+                one, per_hop = sb.layer_graph(layer), sb.layer_graph(layer, per_hop=True)
+                assert len(one.hops) == 1 and len(per_hop.hops) == grp.hops - layer and one.n_rows == per_hop.n_rows
+                R, E = sum(sb.row_cap[:grp.hops - layer]), sum(sb.edge_cap[:grp.hops - layer])
+                assert int(one.hops[0].row_ptr[-1]) == E and one.hops[0].col.shape[0] == E and one.hops[0].self_rows.shape[0] == R
+                assert torch.equal(one.hops[0].col, torch.cat([h.col for h in per_hop.hops]))
+                assert torch.equal(one.hops[0].self_rows, torch.cat([h.self_rows for h in per_hop.hops]))
             n_checked += 1
     assert n_checked == 6
 
