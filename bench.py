@@ -1289,6 +1289,9 @@ def main():
                                   "wgamd_unique_bounded_live), layer 1 reads them through the inverse index; %d listed rows -> %d "
                                   "gathered per call group" % (int(n_src), int(n_fetch))) if pipe.dedup else
                                  "x = feat[n_id] row for row",
+                # the same pipeline with EVERY listed row gathered (what the reference's loader fetches per mini-batch; the headline of
+                # rounds 1-5), measured in this run — next to `value` at the top level so that neither figure is read without the other
+                "value_row_for_row_fetch": (variants.get("materialised_full") or {}).get("value") if pipe.dedup else None,
                 "fused_fetch_variant": fused,
                 "variants": variants,
                 "roofline": roofline,
