@@ -144,6 +144,9 @@ __global__ void __launch_bounds__(kSmallThreads) csr_transpose_small_kernel(cons
     if (col_t) col_t[p] = (v >> 16) & 0x7fff;
   };
   for (int i = t; i <= n_src; i += kSmallThreads) start[i] = 0;
+  // (edges outside [row_ptr[0], row_ptr[n_rows]) — a malformed CSR — read as row 0 instead of whatever the LDS held)
+  for (int i = t; i < (n_edges + 1) / 2; i += kSmallThreads) reinterpret_cast<int*>(dst16)[i] = 0;
+  __syncthreads();
   for (int r = t; r < n_rows; r += kSmallThreads) {
     const int e1 = min(row_ptr[r + 1], n_edges);
     for (int e = max(row_ptr[r], 0); e < e1; e++) dst16[e] = (unsigned short)r;
