@@ -487,7 +487,8 @@ def loader_api_variants(row_ptr, col, table, convs, seeds, n_groups, G, which=("
                 h = c(h, batch.layer_graph(j), act="relu" if j < L - 1 else None)
             if not train:
                 return h[:batch.batch_size].sum()
-            loss = wnn.cross_entropy(h[:batch.batch_size], labels.index_select(0, batch.seeds))     # (one launch forward, one backward)
+            # mean loss over the live seeds of the row_cap[0] output rows: no slice (its backward is a zero-fill + a copy per step)
+            loss = wnn.cross_entropy(h, labels.index_select(0, batch.n_id[:h.shape[0]]), batch.seed_mask)
             loss.backward()
             opt.step()
             return loss

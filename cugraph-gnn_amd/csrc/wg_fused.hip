@@ -355,6 +355,7 @@ struct stage_args {
   void* n_id;         // [node_cap]
   int* sizes;         // [2 n_hops + 2]: rows and edges per hop, vertices, overflow flag
   float* inv_deg_all; // [sum row_cap] (nullable): 1 / max(degree, 1) of every row of that CSR (the mean's backward scales by it)
+  float* seed_mask;   // [hop[0].row_cap] (nullable): 1 for a live seed row, 0 for the padding (the weight of a row in the loss)
   int* row_ptr_all;   // [sum row_cap + 1] (nullable): the hops' CSRs back to back as ONE CSR — hop k's rows start at
                       // sum(row_cap[:k]), its edges at sum(edge_cap[:k]).  With the hops' col / self arrays allocated back to
                       // back by the caller, a layer over hops 0..j is one launch over a prefix of it instead of j + 1 launches
@@ -407,6 +408,7 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(const stage_args a)
       h.row_ptr[r] = at;
       if (a.row_ptr_all) a.row_ptr_all[s_base[k] + r] = s_ebase[k] + at;   // (r = row_cap: the next hop's first entry, same value)
       if (a.inv_deg_all && r < h.row_cap) a.inv_deg_all[s_base[k] + r] = 1.f / (float)max(at_of(r + 1) - at, 1);
+      if (k == 0 && a.seed_mask && r < h.row_cap) a.seed_mask[r] = r < rows ? 1.f : 0.f;
       if (r < h.row_cap) h.self0[r] = r < rows ? (int64_t)(s_l0[k] + r) : 0;
     }
     for (int e = gtid; e < h.edge_cap; e += gsize) {
@@ -441,7 +443,7 @@ wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* con
                                                       int batch, const int* row_cap, const int* edge_cap, int node_cap,
                                                       int* const* row_ptr_out, int64_t* const* self_rows_out, int* const* col_out,
                                                       int* const* col_seg_out, void* n_id_out, int* sizes_out, int* row_ptr_all_out,
-                                                      float* inv_deg_all_out, void* stream)
+                                                      float* inv_deg_all_out, float* seed_mask_out, void* stream)
 {
   using namespace wgamd;
   return guarded("wgamd_call_group_stage_batch", [&] {
@@ -461,7 +463,7 @@ wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* con
       work     = std::max<int64_t>(work, std::max(row_cap[k], edge_cap[k]));
     }
     a.n_hops = n_hops, a.batch = batch, a.node_cap = node_cap, a.nodes = nodes, a.node_seg = node_seg, a.n_id = n_id_out;
-    a.sizes  = sizes_out, a.row_ptr_all = row_ptr_all_out, a.inv_deg_all = inv_deg_all_out;
+    a.sizes  = sizes_out, a.row_ptr_all = row_ptr_all_out, a.inv_deg_all = inv_deg_all_out, a.seed_mask = seed_mask_out;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, (int64_t)1024), 256));
     if (id_dtype == WHOLEMEMORY_DT_INT64)
       stage_batch_kernel<int64_t><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(a);

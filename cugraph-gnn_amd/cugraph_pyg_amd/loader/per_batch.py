@@ -55,6 +55,7 @@ class StagedBatch:
         # launch of a mini-batch's step sits on its latency floor (30-47 us for 1-10 k rows), so launches are what a step costs.
         self.row_ptr_all = torch.zeros(R + 1, **i32)
         self.inv_deg_all = torch.ones(R, dtype=torch.float32, device=device)    # 1 / max(degree, 1): the mean's backward
+        self._seed_mask = torch.zeros(row_cap[0], dtype=torch.float32, device=device)
         self.self0_all = torch.zeros(R, dtype=torch.int64, device=device)
         self.col_all = torch.zeros(E, **i32)
         # (the LAST hop's sources include the vertices it discovered itself, which no layer's output holds: no col_seg for it)
@@ -80,8 +81,11 @@ class StagedBatch:
 
     @property
     def seed_mask(self):
-        """float32 [row_cap[0]]: 1 for the live seed rows of the staged mini-batch (device-side: sizes[0] live seeds)."""
-        return (torch.arange(self.row_cap[0], device=self.n_id.device) < self.sizes[0]).to(torch.float32)
+        """float32 [row_cap[0]]: 1 for the live seed rows of the staged mini-batch, 0 for the padding — written by the staging
+        launch.  The last layer's output has row_cap[0] rows: ``nn.cross_entropy(out, labels[batch.n_id[:out.shape[0]]],
+        batch.seed_mask)`` is the mean loss over the live seeds without slicing ``out`` (a slice costs a zero-fill and a copy in
+        the backward pass of every step)."""
+        return self._seed_mask
 
     @property
     def n_live_seeds(self):
@@ -185,7 +189,7 @@ class PerBatchStep:
             H, _ptr_array(res.offsets[:H]), _ptr_array(res.row_local[:H]), _ptr_array(res.frontier_seg[:H]),
             _ptr_array(res.frontier_local0[:H]), res.nodes.data_ptr(), torch_dtype_to_wm(res.nodes.dtype), res.node_seg.data_ptr(),
             int(b), sb._caps[0], sb._caps[1], sb.node_cap, sb._ptrs[0], sb._ptrs[1], sb._ptrs[2], sb._ptrs[3], sb.n_id.data_ptr(),
-            sb.sizes.data_ptr(), sb.row_ptr_all.data_ptr(), sb.inv_deg_all.data_ptr(), get_stream()), "wgamd_call_group_stage_batch")
+            sb.sizes.data_ptr(), sb.row_ptr_all.data_ptr(), sb.inv_deg_all.data_ptr(), sb._seed_mask.data_ptr(), get_stream()), "wgamd_call_group_stage_batch")
         sb.refilled()
 
     def _snapshot(self):

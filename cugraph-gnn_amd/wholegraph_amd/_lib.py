@@ -271,7 +271,7 @@ SYMBOLS = {
     "wgamd_call_group_hop_rows_batched": (c_int, [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 8 + [c_void_p]),
     "wgamd_call_group_layer_cols": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 5),
     "wgamd_call_group_stage_batch": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_int, c_void_p, c_void_p, c_int]
-                                     + [c_void_p] * 9),
+                                     + [c_void_p] * 10),
     "wgamd_softmax_xent_state_bytes": (c_size_t, [c_int64]),
     "wgamd_softmax_xent_forward_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p]),

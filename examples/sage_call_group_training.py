@@ -99,7 +99,8 @@ def train_per_batch(args, loader, convs, opt, community, table, L):
         B = batch.batch_size
         y = community[batch.seeds]
         mask = batch.seed_mask[:B]                                  # a ragged last mini-batch has fewer than B live seeds
-        loss = wnn.cross_entropy(h[:B], y, mask)                    # mean over the live seeds: two launches instead of torch's ten
+        # mean over the live seeds of the row_cap[0] output rows, no slice: two launches instead of torch's ten
+        loss = wnn.cross_entropy(h, community[batch.n_id[:h.shape[0]]], batch.seed_mask)
         loss.backward()
         opt.step()
         return loss.detach(), ((h[:B].argmax(1) == y).float() * mask).sum()

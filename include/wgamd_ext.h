@@ -406,15 +406,16 @@ wholememory_error_code_t wgamd_call_group_hop_rows_batched(const int* offsets, c
  * copy is then truncated).  row_ptr_all_out (nullable, int32 [sum row_cap + 1]): the hops' CSRs back to back as ONE CSR — hop
  * k's rows start at sum(row_cap[:k]) and point at edges from sum(edge_cap[:k]); a caller that allocates the hops' col /
  * self_rows arrays back to back runs a layer over hops 0..j as one launch over a prefix of it; inv_deg_all_out (nullable, float
- * [sum row_cap]) = 1 / max(degree, 1) of every row of that CSR (what the backward of a mean aggregation scales by).  One
- * launch, no synchronisation. */
+ * [sum row_cap]) = 1 / max(degree, 1) of every row of that CSR (what the backward of a mean aggregation scales by);
+ * seed_mask_out (nullable, float [row_cap[0]]) = 1 for a live seed row, 0 for the padding (the row weights of the loss over the
+ * last layer's row_cap[0] output rows: no slice, no mask arithmetic in the captured step).  One launch, no synchronisation. */
 wholememory_error_code_t wgamd_call_group_stage_batch(int n_hops, const int* const* offsets, const int* const* row_local,
                                                       const int* const* frontier_seg, const int* const* frontier_local0,
                                                       const void* nodes, wholememory_dtype_t id_dtype, const int* node_seg,
                                                       int batch, const int* row_cap, const int* edge_cap, int node_cap,
                                                       int* const* row_ptr_out, int64_t* const* self_rows_out, int* const* col_out,
                                                       int* const* col_seg_out, void* n_id_out, int* sizes_out, int* row_ptr_all_out,
-                                                      float* inv_deg_all_out, void* stream);
+                                                      float* inv_deg_all_out, float* seed_mask_out, void* stream);
 
 /* One hop of a PyG-style call group renumbered for the LAYER that consumes it (cugraph_pyg_amd.loader.CallGroup).  The
  * layer's input rows are `n_segments` segments per batch: local ids [local0[s][b], local0[s+1][b]) of batch b sit at rows

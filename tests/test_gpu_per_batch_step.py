@@ -51,7 +51,7 @@ def _step_fn(model, opt, labels, fused_loss=False):
         B = batch.batch_size
         if fused_loss:      # wholegraph_amd.nn.cross_entropy: one launch forward, one backward (what bench.py's step uses)
             from wholegraph_amd import nn as wnn
-            loss = wnn.cross_entropy(h[:B], labels[batch.seeds], batch.seed_mask[:B])
+            loss = wnn.cross_entropy(h, labels[batch.n_id[:h.shape[0]]], batch.seed_mask)       # (no slice: row weights)
         else:
             per_seed = torch.nn.functional.cross_entropy(h[:B], labels[batch.seeds], reduction="none")
             loss = (per_seed * batch.seed_mask[:B]).sum() / batch.n_live_seeds
