@@ -792,6 +792,53 @@ def _to_csr(edge_index, n_dst):
 _ARANGE = {}
 
 
+_HEADS_WGRAD_MIN_ROWS = int(os.environ.get("WGAMD_HEADS_WGRAD_MIN_ROWS", 16384))
+
+
+class _HeadsTransform(torch.autograd.Function):
+    """``y[n, h, :] = agg[n, h, :] @ w3[:, h, :]`` — the dense tail of the aggregate-first GAT layer (per-head weights on the
+    destination rows).  Forward and the gradient of ``agg`` are library products of ordinary shapes; the WEIGHT gradient
+    ``agg_h^T dY_h`` is a [F, n] x [n, C] product with n in the hundreds of thousands and a 128 x 64 result, which the library
+    runs at 0.16 TB/s (2.07 ms per mag relation, 6 % of the whole mag run) — it goes to the split-K bf16x3 kernel of the SAGE
+    layer's weight gradient instead (``wgamd_sage_wgrad_bf16x3``: ``dZ^T [A | B]`` with A, B = the two halves of agg_h's columns,
+    so nothing is read twice), one launch + its partial-sum reduction per head."""
+
+    @staticmethod
+    def forward(ctx, agg3, w3):
+        ctx.save_for_backward(agg3, w3)
+        return torch.einsum("nhf,fhc->nhc", agg3, w3)
+
+    @staticmethod
+    def backward(ctx, g):
+        agg3, w3 = ctx.saved_tensors
+        g = g.contiguous()
+        d_agg = torch.einsum("nhc,fhc->nhf", g, w3) if ctx.needs_input_grad[0] else None
+        d_w3 = None
+        if ctx.needs_input_grad[1]:
+            n, H, F_ = agg3.shape
+            C = g.shape[2]
+            split = F_ % 8 == 0                  # the halves of a row must start 16-byte aligned
+            Fk = F_ // 2 if split else F_
+            rows = _arange(n, g.device)
+            buf = torch.empty((H, 2, C, Fk), dtype=torch.float32, device=g.device)
+            for h in range(H):
+                a_h = agg3[:, h, :]
+                sage_wgrad(a_h[:, :Fk], a_h[:, Fk:] if split else a_h, rows, g[:, h, :], buf[h, 0], buf[h, 1])
+            # buf[h, s, c, k] = d w3[s Fk + k, h, c]
+            d_w3 = (buf.permute(1, 3, 0, 2).reshape(F_, H, C) if split else buf[:, 0].permute(2, 0, 1)).contiguous()
+        return d_agg, d_w3
+
+
+def _heads_transform(agg3: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    n, H, F_ = agg3.shape
+    C = w3.shape[2]
+    if (agg3.is_cuda and agg3.dtype == torch.float32 and agg3.is_contiguous() and n >= _HEADS_WGRAD_MIN_ROWS and F_ % 4 == 0
+            and (H * F_) % 4 == 0 and (C % 4 == 0 or H == 1) and torch.is_grad_enabled() and w3.requires_grad
+            and L.lib().wgamd_sage_wgrad_workspace_bytes(1, F_ // 2 if F_ % 8 == 0 else F_, C) > 0):
+        return _HeadsTransform.apply(agg3, w3)
+    return torch.einsum("nhf,fhc->nhc", agg3, w3)
+
+
 def _arange(n: int, device) -> torch.Tensor:
     """``arange(n)`` int64 on ``device`` as a view of one grow-only buffer (the "self rows" of a mini-batch graph whose
     destinations are the first rows of x)."""
@@ -1256,7 +1303,7 @@ class GATConv(torch.nn.Module):
                 continue
             agg = _GatAggregateHeads.apply(X, a_src, a_dst, rp, col, H, hop.self_rows, ids, ids if by_id else None, by_id, by_id,
                                            self.negative_slope)
-            outs.append(torch.einsum("nhf,fhc->nhc", agg.view(n, H, F_), w3))
+            outs.append(_heads_transform(agg.view(n, H, F_), w3))
         out = torch.cat(outs) if outs else torch.zeros((0, H, C), dtype=torch.float32, device=X.device)
         out = out.reshape(out.shape[0], H * C) if self.concat else out.mean(1)
         if self.bias is not None:
@@ -1729,7 +1776,7 @@ class HeteroConv(torch.nn.Module):
                                                c.negative_slope)
                 F_ = X[st].shape[1]
                 w3 = c.lin.weight.t().reshape(F_, H, C)
-                y = torch.einsum("nhf,fhc->nhc", agg.view(n_f, H, F_), w3).reshape(n_f, H * C)
+                y = _heads_transform(agg.view(n_f, H, F_), w3).reshape(n_f, H * C)
                 acc = y if acc is None else acc + y
             if acc is None:
                 acc = torch.zeros((n_f, self._width(dt)), dtype=torch.float32, device=dev)

@@ -64,3 +64,30 @@ def test_cross_entropy_inside_a_captured_graph(hiplib):
         ref.backward()
         assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
         assert float((x.grad.double() - ref_x.grad).abs().max()) <= 1e-6 * float(ref_x.grad.abs().max())
+
+
+@pytest.mark.parametrize("n,H,F_,C", [(20000, 4, 128, 64), (3000, 4, 100, 64), (5000, 1, 256, 47), (70000, 4, 128, 64), (1, 2, 8, 4)])
+def test_gat_dense_tail_weight_gradient_on_the_split_k_kernel(hiplib, n, H, F_, C, monkeypatch):
+    """nn._heads_transform (the per-head weights of the aggregate-first GAT layer): its weight gradient agg_h^T dY_h — a product
+    with hundreds of thousands of rows and a 128 x 64 result — runs on wgamd_sage_wgrad_bf16x3 (the two halves of agg_h's columns
+    as its two operands; the whole row twice where the halves would not be 16-byte aligned).  Output and both gradients against
+    the float64 einsum at 1e-5 x sum |terms|."""
+    import torch
+    from wholegraph_amd import nn
+    monkeypatch.setattr(nn, "_HEADS_WGRAD_MIN_ROWS", 0)
+    g = torch.Generator(device="cuda").manual_seed(n + F_)
+    agg = (torch.rand((n, H, F_), generator=g, device="cuda") * 2 - 1).requires_grad_(True)
+    w = ((torch.rand((F_, H, C), generator=g, device="cuda") - 0.5) * 0.3).requires_grad_(True)
+    gy = torch.rand((n, H, C), generator=g, device="cuda") * 2 - 1
+    y = nn._heads_transform(agg, w)
+    assert y.grad_fn is not None and "HeadsTransform" in type(y.grad_fn).__name__
+    y.backward(gy)
+    a64, w64 = agg.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    y64 = torch.einsum("nhf,fhc->nhc", a64, w64)
+    y64.backward(gy.double())
+    mag_y = torch.einsum("nhf,fhc->nhc", a64.detach().abs(), w64.detach().abs())
+    assert float(((y.double() - y64).abs() / (mag_y + 1e-30)).max()) <= 1e-5
+    mag_w = torch.einsum("nhf,nhc->fhc", a64.detach().abs(), gy.double().abs())
+    assert float(((w.grad.double() - w64.grad).abs() / (mag_w + 1e-30)).max()) <= 1e-5
+    mag_a = torch.einsum("nhc,fhc->nhf", gy.double().abs(), w64.detach().abs())
+    assert float(((agg.grad.double() - a64.grad).abs() / (mag_a + 1e-30)).max()) <= 1e-5
