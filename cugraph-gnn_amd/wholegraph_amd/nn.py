@@ -804,15 +804,22 @@ class _HeadsTransform(torch.autograd.Function):
     so nothing is read twice), one launch + its partial-sum reduction per head."""
 
     @staticmethod
-    def forward(ctx, agg3, w3):
+    def forward(ctx, agg3, w3, acc3=None):
         # one product per head, written straight into its columns of the [n, H, C] result: the batched form (einsum -> bmm)
-        # leaves [H, n, C] and pays a 450 MB permute-copy per mag relation to bring it back (10 % of the mag training step)
+        # leaves [H, n, C] and pays a 450 MB permute-copy per mag relation to bring it back (10 % of the mag training step).
+        # ``acc3`` (the sum of the relations before this one, HeteroConv's aggregation): the products are added INTO it (beta =
+        # 1) instead of a separate 3 x 450 MB addition per relation.
         ctx.save_for_backward(agg3, w3)
         n, H, _ = agg3.shape
-        y = torch.empty((n, H, w3.shape[2]), dtype=torch.float32, device=agg3.device)
+        if acc3 is None:
+            y = torch.empty((n, H, w3.shape[2]), dtype=torch.float32, device=agg3.device)
+            for h in range(H):
+                torch.mm(agg3[:, h, :], w3[:, h, :], out=y[:, h, :])
+            return y
+        ctx.mark_dirty(acc3)
         for h in range(H):
-            torch.mm(agg3[:, h, :], w3[:, h, :], out=y[:, h, :])
-        return y
+            acc3[:, h, :].addmm_(agg3[:, h, :], w3[:, h, :])
+        return acc3
 
     @staticmethod
     def backward(ctx, g):
@@ -836,17 +843,22 @@ class _HeadsTransform(torch.autograd.Function):
                 sage_wgrad(a_h[:, :Fk], a_h[:, Fk:] if split else a_h, rows, g[:, h, :], buf[h, 0], buf[h, 1])
             # buf[h, s, c, k] = d w3[s Fk + k, h, c]
             d_w3 = (buf.permute(1, 3, 0, 2).reshape(F_, H, C) if split else buf[:, 0].permute(2, 0, 1)).contiguous()
-        return d_agg, d_w3
+        return d_agg, d_w3, (g if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None)
 
 
-def _heads_transform(agg3: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+def _heads_transform(agg3: torch.Tensor, w3: torch.Tensor, acc3: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[acc3 +] agg3 @ w3`` per head; ``acc3`` ([n, H, C], the sum so far) may be updated in place and returned."""
     n, H, F_ = agg3.shape
     C = w3.shape[2]
     if (agg3.is_cuda and agg3.dtype == torch.float32 and agg3.is_contiguous() and n >= _HEADS_WGRAD_MIN_ROWS and F_ % 4 == 0
             and (H * F_) % 4 == 0 and (C % 4 == 0 or H == 1) and torch.is_grad_enabled() and w3.requires_grad
             and L.lib().wgamd_sage_wgrad_workspace_bytes(1, F_ // 2 if F_ % 8 == 0 else F_, C) > 0):
-        return _HeadsTransform.apply(agg3, w3)
-    return torch.einsum("nhf,fhc->nhc", agg3, w3)
+        if acc3 is not None and acc3.is_contiguous() and acc3.requires_grad and not acc3.is_leaf:
+            return _HeadsTransform.apply(agg3, w3, acc3)
+        y = _HeadsTransform.apply(agg3, w3)
+        return y if acc3 is None else acc3 + y
+    y = torch.einsum("nhf,fhc->nhc", agg3, w3)
+    return y if acc3 is None else acc3 + y
 
 
 def _arange(n: int, device) -> torch.Tensor:
@@ -1786,14 +1798,17 @@ class HeteroConv(torch.nn.Module):
                                                c.negative_slope)
                 F_ = X[st].shape[1]
                 w3 = c.lin.weight.t().reshape(F_, H, C)
-                y = _heads_transform(agg.view(n_f, H, F_), w3).reshape(n_f, H * C)
-                acc = y if acc is None else acc + y
+                if acc is not None and acc.shape[1:] != (H, C):      # (relations of one destination type with different head shapes)
+                    acc = (acc.reshape(n_f, H * C) + _heads_transform(agg.view(n_f, H, F_), w3).reshape(n_f, H * C)).view(n_f, H, C)
+                else:
+                    acc = _heads_transform(agg.view(n_f, H, F_), w3, acc)
+            if acc is not None:
+                acc = acc.reshape(n_f, -1)
             if acc is None:
                 acc = torch.zeros((n_f, self._width(dt)), dtype=torch.float32, device=dev)
-            for r in mine:
-                b = self.conv(r.edge_type).bias
-                if b is not None:
-                    acc = acc + b
+            bs = [self.conv(r.edge_type).bias for r in mine if self.conv(r.edge_type).bias is not None]
+            if bs:            # the relations' biases summed first: ONE pass over the rows (HeteroConv adds outputs, bias included)
+                acc = acc + (bs[0] if len(bs) == 1 else torch.stack(bs).sum(0))
             if act == "relu":
                 acc = torch.relu(acc)
             place = mine[0].out_rows

@@ -252,12 +252,17 @@ def test_narrow_terms_function_matches_float64(hiplib, n, F, T, x_grad):
         assert float((x.grad.double() - x64.grad).abs().max()) <= 1e-5 * float(x64.grad.abs().max())
 
 
-def test_hetero_conv_trains_aggregate_first_like_relation_by_relation(hiplib):
+@pytest.mark.parametrize("tails", ["library", "split_k"])
+def test_hetero_conv_trains_aggregate_first_like_relation_by_relation(hiplib, tails, monkeypatch):
     """nn.HeteroConv over a heterogeneous call group under autograd: the aggregate-first route (_forward_layer_train: lazy x read
     through the node lists, terms of the tables' rows) gives the outputs and the parameter gradients of PyG's relation-by-relation
-    formulation on GATConv (_forward_relations)."""
+    formulation on GATConv (_forward_relations).  ``split_k``: the dense tails on nn._HeadsTransform whatever the row count — the
+    products per head accumulated into the relations' running sum in place, the weight gradients on the split-K kernel (the route
+    call groups of production size take)."""
     import torch
     import bench_mag as bm
+    from wholegraph_amd import nn as wnn
+    monkeypatch.setattr(wnn, "_HEADS_WGRAD_MIN_ROWS", 0 if tails == "split_k" else 1 << 60)
     dev = torch.device("cuda", 0)
     nodes = {"paper": 3000, "author": 4000, "institution": 200, "field_of_study": 500}
     rels = {k: max(v // 400, 1500) for k, v in bm.MAG_RELS.items()}
