@@ -375,22 +375,59 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
   const int f0          = live ? sub * 4 : 0;
   auto group_sum = [&](float v) { return group_reduce<LG, false>(v, lanes); };
   auto group_max = [&](float v) { return group_reduce<LG, true>(v, lanes); };
+  // A lane group works on ONE destination row at a time, and a row starts with a chain of dependent loads — row_ptr -> col ->
+  // id list -> rows of x / of the terms (and dst_rows -> id list -> a_dst): four round trips before the first useful byte, which
+  // with 24 rows in flight per CU was the kernel's time (2.6 ms for the 1.8 M rows of a products hop).  The chain is software-
+  // pipelined over the group's rows: stage A (row_ptr, dst_rows) runs three rows ahead, B (col, the destination's id) two, C (the
+  // source's id, a_dst, the row's gradient slices) one — every load a row's arithmetic waits for was issued a row earlier.
+  auto stage_a = [&](int64_t r, int& s_, int& e_, int64_t& ar_) {
+    const bool in = r < n_rows;
+    s_  = in ? row_ptr[r] : 0;
+    e_  = in ? row_ptr[r + 1] : 0;
+    ar_ = in ? (dst_rows ? dst_rows[r] : r) : 0;
+  };
+  auto stage_b = [&](int s_, int e_, int64_t& ar_, int& c_) {
+    c_ = s_ + sub < e_ ? col[s_ + sub] : 0;
+    if (terms_by_id & 2) ar_ = dst_ids[ar_];
+  };
+  auto stage_c = [&](int64_t r, int c_, int64_t ar_, int64_t& xr_, float (&ad_)[H], float4 (&g_)[H]) {
+    xr_ = src_ids ? src_ids[c_] : (int64_t)c_;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      ad_[h] = a_dst[ar_ * H + h];
+      g_[h]  = (live && r < n_rows) ? *reinterpret_cast<const float4*>(g + r * ldg + (int64_t)h * F + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int s1, e1, c1, s2, e2, c2, s3, e3;
+  int64_t ar1, ar2, ar3, xr1;
+  float ad1[H];
+  float4 g1[H];
+  stage_a(group, s1, e1, ar1);
+  stage_b(s1, e1, ar1, c1);
+  stage_c(group, c1, ar1, xr1, ad1, g1);
+  stage_a(group + ngroups, s2, e2, ar2);
+  stage_b(s2, e2, ar2, c2);
+  stage_a(group + 2 * ngroups, s3, e3, ar3);
   for (int64_t row = group; row < n_rows; row += ngroups) {
-    const int s = row_ptr[row], e = row_ptr[row + 1];
-    if (s == e) continue;   // (no edge: nothing flows back; uniform over the lane group)
-    int64_t arow = dst_rows ? dst_rows[row] : row;
-    if (terms_by_id & 2) arow = dst_ids[arow];
+    const int s = s1, e = e1, c_own = c1;
+    const int64_t arow = ar1, xr_own = xr1;
     float ad[H], m[H], den[H], dot[H], gad[H];
     float4 g4[H];
 #pragma unroll
     for (int h = 0; h < H; h++) {
-      ad[h]  = a_dst[arow * H + h];
+      ad[h]  = ad1[h];
+      g4[h]  = g1[h];
       m[h]   = -INFINITY;
       den[h] = 0.f;
       dot[h] = 0.f;
       gad[h] = 0.f;
-      g4[h]  = live ? *reinterpret_cast<const float4*>(g + row * ldg + (int64_t)h * F + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    s1 = s2, e1 = e2, ar1 = ar2, c1 = c2;
+    stage_c(row + ngroups, c1, ar1, xr1, ad1, g1);
+    s2 = s3, e2 = e3, ar2 = ar3;
+    stage_b(s2, e2, ar2, c2);
+    stage_a(row + 3 * ngroups, s3, e3, ar3);
+    if (s == e) continue;   // (no edge: nothing flows back; uniform over the lane group)
     // what the owner of edge j needs: the row of x, the row of the terms, the raw scores
     auto own = [&](int j, int64_t& xr, int64_t& tr, float (&raw)[H]) {
       const int c = col[j];
@@ -405,13 +442,8 @@ gat_aggregate_heads_bwd_kernel(const int* __restrict__ row_ptr, const int* __res
       // column, rows and scores in registers through all phases — one dependent col -> id -> term chain per row instead of four
       const bool on = s + sub < e;
       const int cnt = e - s;
-      int64_t xr = 0, tr = 0;
       float raw[H], al[H], pown[H];
-      {
-        const int c = on ? col[s + sub] : 0;
-        xr          = src_ids ? src_ids[c] : (int64_t)c;
-        tr          = (terms_by_id & 1) ? xr : (int64_t)c;
-      }
+      const int64_t xr = xr_own, tr = (terms_by_id & 1) ? xr_own : (int64_t)c_own;   // (stages B and C of this row, a row ago)
       // the neighbour rows of the first four edges are requested BEFORE the scores are waited for (they do not depend on them)
       float4 x4[EIF];
       int64_t xu[EIF];

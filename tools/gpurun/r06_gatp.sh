@@ -5,6 +5,6 @@ python - <<PY
 import csv
 rows=list(csv.DictReader(open('/tmp/gp/gp_kernel_stats.csv')))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
-for r in rows[:16]:
+for r in rows[:34]:
     print("%-100s calls %5s avg %9.1f us %5.1f%%"%(r['Name'][:100],r['Calls'],float(r['AverageNs'])/1e3,100*float(r['TotalDurationNs'])/tot))
 PY

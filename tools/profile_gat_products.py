@@ -10,5 +10,8 @@ row_ptr, col = rmat_csr(V_PRODUCTS, E_UNDIRECTED, 0, dev)
 g = torch.Generator(device=dev).manual_seed(1)
 table = torch.randn((V_PRODUCTS, 100), generator=g, device=dev)
 seeds = torch.cat([torch.randperm(V_PRODUCTS, generator=g, device=dev)] * 2)
-out = loader_api_variants(row_ptr, col, table, [], seeds, 4, 191, which=("gat",))
+from cugraph_pyg_amd.sampler.sampler import default_local_seeds_per_call
+import bench
+G = max(1, default_local_seeds_per_call(bench.FANOUT, bench.BATCH, 8) // bench.BATCH)      # the loader's own call-group size
+out = loader_api_variants(row_ptr, col, table, [], seeds, 4, G, which=("gat",))
 print({k: (round(v["value"] / 1e9, 3), round(v["ms_per_call_group"], 2)) for k, v in out.items()})
