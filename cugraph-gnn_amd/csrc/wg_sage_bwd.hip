@@ -365,7 +365,10 @@ __host__ inline wgrad_plan plan_for(int F, int N)
   int WN = 2;   // (N <= 32 runs with one dead column wave: no instances for a single one)
   while (WN < n_ct && WN < 8) WN *= 2;
   while (WN > 2 && (mtiles + (8 / WN) - 1) / (8 / WN) > 8) WN /= 2;   // at most 8 accumulator tiles per wave
-  const int WM = 8 / WN, mt = (mtiles + WM - 1) / WM, TR = F <= 128 ? 32 : 16;
+  // (rows per tile: the LDS holds two tiles of three bf16 planes of 2F x (TR + 8); narrow shapes — the dense tails of the GAT layers,
+  //  F = 64 — take 64-row tiles: a tile is so few MFMAs that the per-tile staging and barriers were the launch's time, 1.5 TB/s)
+  static const bool wide_tiles = [] { const char* e = getenv("WGAMD_WGRAD_TR64"); return !(e && e[0] == '0'); }();
+  const int WM = 8 / WN, mt = (mtiles + WM - 1) / WM, TR = (F <= 64 && wide_tiles) ? 64 : (F <= 128 ? 32 : 16);
   // (accumulator tiles per wave are a template parameter: 4, 8, and 7 for the products layer-1 shape, whose 16 registers
   //  fewer keep that instance clear of spills)
   const int MT = mt <= 4 ? 4 : (mt == 7 && TR == 32 && WN == 8 ? 7 : 8);
@@ -472,7 +475,8 @@ extern "C" wholememory_error_code_t wgamd_sage_wgrad_bf16x3(const float* agg, in
     wgrad_args a{agg, ld_agg, x, byte_offsets ? (int64_t)1 : ldx, F, self_global, n_rows, grad_out, ldg, act_out, ld_act, N, part,
                  (tiles + grid_x - 1) / grid_x * p.TR, p.KL};
     const dim3 grid(grid_x, p.grid_y);
-    if (p.TR == 32) launch_mt<32>(p, a, grid, st);
+    if (p.TR == 64) launch_mt<64>(p, a, grid, st);
+    else if (p.TR == 32) launch_mt<32>(p, a, grid, st);
     else launch_mt<16>(p, a, grid, st);
     const int64_t total = (int64_t)(2 * F + 1) * N;
     wgrad_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(part, grid_x, p.KL, p.NB, F, N, grad_w_l, grad_w_r, grad_bias,
